@@ -1,0 +1,105 @@
+"""ctypes binding of libbgflow_amd.so (the C ABI declared in include/bgflow_amd.h).
+
+The product path has NO fallback: if the library is missing, cannot be loaded, or a kernel is
+asked to run on a non-HIP tensor, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbgflow_amd.so")
+_lib = None
+
+i32, i64, f32, f64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+_SIGNATURES = {
+    "bgk_abi_version": (ctypes.c_int, []),
+    "bgk_last_error": (ctypes.c_char_p, []),
+    "bgk_detmath_probe": (ctypes.c_int, [vp, i64, i32, vp, vp]),
+    "bgk_rqs_transform": (ctypes.c_int, [vp, i64, vp, i64, i32, vp, i64, i32, i32, i32,
+                                         f64, f64, f64, f64, f64, f64, f64, i32,
+                                         vp, i64, vp, i32, vp, vp, vp]),
+    "bgk_rqs_backward": (ctypes.c_int, [vp, i64, vp, i64, i32, vp, i64, i32, i32, i32,
+                                        f64, f64, f64, f64, f64, f64, f64, i32,
+                                        vp, i64, vp, vp, i64, vp, i64, vp]),
+    "bgk_affine_transform": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i64, i32,
+                                            vp, i64, vp, i32, vp]),
+    "bgk_affine_backward": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i64, i32,
+                                           vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp]),
+    "bgk_ic_xyz2ic": (ctypes.c_int, [vp, i64, vp, i32, vp, i32, i32, f32, i32, vp, vp, i32, f32, i64,
+                                     vp, vp, vp, i64, vp, i64, vp, i32, vp, vp]),
+    "bgk_ic_ic2xyz": (ctypes.c_int, [vp, vp, vp, i64, vp, i64, vp, i32, vp, i32, i32, f32, i32,
+                                     vp, vp, i32, f32, i64, vp, i64, vp, i32, vp, vp]),
+    "bgk_coupling_rqs_dense": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32,
+                                              vp, i64, i64, i32, i32, i32,
+                                              f64, f64, f64, f64, f64, f64, f64, i32,
+                                              vp, i64, vp, i32, vp, vp, vp]),
+    "bgk_pack_rqs_columns": (i32, [i32, i32, vp, vp]),
+}
+
+ABI_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load libbgflow_amd.so (built by ``python -m bgflow_amd.build`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X kernels are not built. Run `python -m bgflow_amd.build` "
+                "(hipcc, gfx950). bgflow_amd has no CPU fallback.")
+        try:
+            handle = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise RuntimeError(f"cannot load {LIB_PATH}: {e}. bgflow_amd has no CPU fallback.") from e
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError = ABI mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().bgk_last_error().decode(errors="replace")
+        if status == -1 and "Minimal bin" in msg:
+            raise ValueError(msg)
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")
+
+
+def require_hip(*tensors):
+    """Every operand of a kernel must be an f32 tensor on a HIP device (no CPU path)."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "bgflow_amd kernels run on MI355X (HIP) tensors only; got a tensor on "
+                f"'{t.device}'. There is no CPU fallback in this package.")
+        if t.dtype not in (torch.float32, torch.int32):
+            raise RuntimeError(f"bgflow_amd kernels are float32; got {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rowmajor(t):
+    """Return a 2-d view with unit column stride (copy only if needed) and its row stride."""
+    assert t.dim() == 2, "expected [batch, features]"
+    if t.stride(1) != 1 and t.shape[1] > 1:
+        t = t.contiguous()
+    if t.shape[1] == 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else t.shape[1]
+    if t.shape[0] > 1 and ld < t.shape[1]:   # broadcast / expanded rows
+        t = t.contiguous()
+        ld = t.stride(0)
+    return t, ld

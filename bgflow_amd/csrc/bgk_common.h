@@ -1,0 +1,177 @@
+/* bgk_common.h -- shared host/device helpers of libbgflow_amd (gfx950 only). */
+#ifndef BGK_COMMON_H
+#define BGK_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/bgflow_amd.h"
+#include "bgk_detmath.h"
+
+#define BGK_WAVE 64
+
+/* thread-local last-error string (host) */
+void bgk_set_error(const char* fmt, ...);
+
+#define BGK_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            bgk_set_error(__VA_ARGS__);          \
+            return BGK_EINVAL;                   \
+        }                                        \
+    } while (0)
+
+static inline int bgk_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        bgk_set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+/* scalar spline settings, converted from the python doubles exactly like torch applies python
+ * scalars to f32 tensors (and like oracle/bgo_impl.h does) */
+struct BgkRqsCfg {
+    float left, right, bottom, top;
+    float xspan, yspan;
+    float min_w, min_h, min_d;
+    float w_scale, h_scale;
+    float beta;
+};
+
+static inline BgkRqsCfg bgk_make_rqs_cfg(double left, double right, double bottom, double top,
+                                         double min_w, double min_h, double min_d,
+                                         int identity_init, int K) {
+    BgkRqsCfg c;
+    c.left = (float)left; c.right = (float)right; c.bottom = (float)bottom; c.top = (float)top;
+    c.xspan = (float)(right - left); c.yspan = (float)(top - bottom);
+    c.min_w = (float)min_w; c.min_h = (float)min_h; c.min_d = (float)min_d;
+    c.w_scale = (float)(1.0 - min_w * K);
+    c.h_scale = (float)(1.0 - min_h * K);
+    c.beta = (float)(identity_init ? (0.6931471805599453 / (1.0 - min_d)) : 1.0);
+    return c;
+}
+
+/* One rational-quadratic spline element (device).  `pw`, `ph`, `ps` point at the K unnormalised
+ * widths / heights / slopes of this (sample, dim) with element stride `st`; s_last is the slope at
+ * knot K (periodic copy of s[0] or the non-circular extra slope).  Same operation order as
+ * oracle/bgo_impl.h::bgo_rqs (which follows nflows): every op is a
+ * separately rounded f32 op, the TU is compiled with -ffp-contract=off.
+ * Returns the transformed value; *lad = per-element log|det| contribution in bgflow's sign
+ * convention; *bin = bin index; *oob = 1 if x had to be clamped.  */
+template <int KT>
+__device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const float* ph,
+                                                 const float* ps, int st, float s_last, int Krt,
+                                                 int inverse, const BgkRqsCfg& c, float* lad,
+                                                 int* bin, int* oob) {
+    const int K = KT ? KT : Krt;
+    /* clamp (InputOutsideDomain path, spline.py:145-155) */
+    int o = (x < c.left) | (x > c.right);
+    x = x < c.left ? c.left : (x > c.right ? c.right : x);
+    *oob = o;
+    /* searched set A (heights for bgflow-forward, widths for bgflow-inverse), other set Bq */
+    const float* pa = inverse ? pw : ph;
+    const float* pb = inverse ? ph : pw;
+    const float minA = inverse ? c.min_w : c.min_h, minB = inverse ? c.min_h : c.min_w;
+    const float scA = inverse ? c.w_scale : c.h_scale, scB = inverse ? c.h_scale : c.w_scale;
+    const float spanA = inverse ? c.xspan : c.yspan, spanB = inverse ? c.yspan : c.xspan;
+    const float lowA = inverse ? c.left : c.bottom, lowB = inverse ? c.bottom : c.left;
+    const float highA = inverse ? c.right : c.top, highB = inverse ? c.top : c.right;
+
+    /* ---- searched set: softmax -> min + scale*p -> cumsum -> affine -> ends; count x >= knot ---- */
+    float mA = pa[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) { float v = pa[k * st]; mA = v > mA ? v : mA; }
+    float sA = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) sA += bgk_expf(pa[k * st] - mA);
+    int idx = -1 + (x >= lowA ? 1 : 0);
+    float lo = lowA, hi = lowA;
+    {
+        float cum = 0.0f, prev = lowA;
+        bool hi_set = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float p = bgk_expf(pa[k * st] - mA) / sA;
+            p = minA + scA * p;
+            cum += p;
+            float kn = spanA * cum + lowA;
+            if (k == K - 1) kn = highA;
+            float ks = (k == K - 1) ? kn + 1e-6f : kn;   /* in-place eps of nflows' searchsorted */
+            bool ge = x >= ks;
+            idx += ge ? 1 : 0;
+            if (ge) lo = kn;
+            if (!ge && !hi_set) { hi = kn; hi_set = true; }
+            prev = kn;
+        }
+        (void)prev;
+    }
+    idx = idx < 0 ? 0 : idx;
+    *bin = idx;
+    const float a_i = lo, A_i = hi - lo;   /* knot[idx], bin size in the searched direction */
+
+    /* ---- other set: knot[idx], knot[idx+1] ---- */
+    float mB = pb[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) { float v = pb[k * st]; mB = v > mB ? v : mB; }
+    float sB = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) sB += bgk_expf(pb[k * st] - mB);
+    float b_i = lowB, b_ip1 = lowB;
+    {
+        float cum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float p = bgk_expf(pb[k * st] - mB) / sB;
+            p = minB + scB * p;
+            cum += p;
+            float kn = spanB * cum + lowB;
+            if (k == K - 1) kn = highB;
+            if (k + 1 == idx) b_i = kn;
+            if (k == idx) b_ip1 = kn;
+        }
+    }
+    const float B_i = b_ip1 - b_i;
+
+    /* ---- the two derivatives that are gathered ---- */
+    float s_lo = ps[idx * st];
+    float s_hi = (idx + 1 < K) ? ps[(idx + 1) * st] : s_last;
+    float d_i = c.min_d + bgk_softplusf(s_lo, c.beta);
+    float d_ip1 = c.min_d + bgk_softplusf(s_hi, c.beta);
+
+    float cw_i, W_i, ch_i, H_i;
+    if (inverse) { cw_i = a_i; W_i = A_i; ch_i = b_i; H_i = B_i; }
+    else { ch_i = a_i; H_i = A_i; cw_i = b_i; W_i = B_i; }
+    float delta = H_i / W_i;
+    float S = d_i + d_ip1 - 2.0f * delta;
+    float outv, l;
+    if (!inverse) {
+        float dx = x - ch_i;
+        float a = dx * S + H_i * (delta - d_i);
+        float b = H_i * d_i - dx * S;
+        float cc = -delta * dx;
+        float disc = b * b - 4.0f * a * cc;
+        float root = (2.0f * cc) / (-b - __builtin_sqrtf(disc));
+        outv = root * W_i + cw_i;
+        float t1mt = root * (1.0f - root);
+        float den = delta + S * t1mt;
+        float omr = 1.0f - root;
+        float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
+        l = -(bgk_logf(num) - 2.0f * bgk_logf(den));
+    } else {
+        float theta = (x - cw_i) / W_i;
+        float t1mt = theta * (1.0f - theta);
+        float numer = H_i * (delta * (theta * theta) + d_i * t1mt);
+        float den = delta + S * t1mt;
+        outv = ch_i + numer / den;
+        float omt = 1.0f - theta;
+        float num = (delta * delta) * (d_ip1 * (theta * theta) + 2.0f * delta * t1mt + d_i * (omt * omt));
+        l = bgk_logf(num) - 2.0f * bgk_logf(den);
+    }
+    *lad = l;
+    return outv;
+}
+
+#endif /* BGK_COMMON_H */

@@ -1,0 +1,125 @@
+/* bgk_detmath.h -- deterministic single-precision transcendental primitives.
+ *
+ * Every function here is a fixed sequence of IEEE-754 binary32 add / mul / div / fma / compare /
+ * integer-bit operations.  It compiles to the same arithmetic under gcc (host C, used by the CPU
+ * oracle in oracle/) and under hipcc for gfx950 (device code of the HIP kernels), PROVIDED both
+ * translation units are built with floating-point contraction disabled (-ffp-contract=off), no
+ * fast-math, IEEE division/sqrt on the device (-fhip-fp32-correctly-rounded-divide-sqrt, the hipcc
+ * default) and f32 denormals kept (the gfx950 default).  That is what makes the spline knots --
+ * and therefore the rational-quadratic-spline BIN INDICES -- bit-identical between the MI355X
+ * kernels and the CPU restatement ("Bit-exact bin indices").
+ *
+ * Accuracy: expf/logf <= ~1.5 ulp (Cephes single-precision minimax polynomials, FMA-evaluated).
+ *
+ * No libm / OCML calls; usable from C99, C++ and HIP.
+ */
+#ifndef BGK_DETMATH_H
+#define BGK_DETMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define BGK_FN __host__ __device__ __forceinline__
+#else
+#define BGK_FN static inline __attribute__((always_inline))
+#endif
+
+BGK_FN uint32_t bgk_f2u(float x) { uint32_t u; __builtin_memcpy(&u, &x, 4); return u; }
+BGK_FN float bgk_u2f(uint32_t u) { float x; __builtin_memcpy(&x, &u, 4); return x; }
+
+/* exp(x), x clamped to [-87, 88] (results stay normal; callers only use it on softmax-shifted,
+ * softplus-thresholded or SiLU arguments where the clamp is below fp32 resolution of the result's
+ * consumer). */
+BGK_FN float bgk_expf(float x) {
+    x = x < -87.0f ? -87.0f : x;
+    x = x > 88.0f ? 88.0f : x;
+    /* n = round-half-even(x * log2(e)) through the 1.5*2^23 magic constant */
+    const float magic = 12582912.0f;
+    float t = __builtin_fmaf(x, 1.44269504088896341f, magic);
+    float n = t - magic;
+    int32_t ni = (int32_t)(bgk_f2u(t) - 0x4B400000u);
+    /* r = x - n*ln2 in two pieces (ln2_hi has 9 trailing zero bits -> n*ln2_hi exact) */
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    p = __builtin_fmaf(p, r2, r);
+    p = p + 1.0f;
+    float scale = bgk_u2f((uint32_t)(ni + 127) << 23);
+    return p * scale;
+}
+
+/* natural log of a non-negative finite float (denormals handled; log(0) = -inf; negative
+ * arguments are never passed by the callers). */
+BGK_FN float bgk_logf(float x) {
+    if (x == 0.0f) return -__builtin_inff();
+    int32_t eadj = 0;
+    if (x < 1.17549435e-38f) { x = x * 8388608.0f; eadj = -23; }
+    uint32_t bits = bgk_f2u(x);
+    int32_t e = (int32_t)((bits >> 23) & 0xffu) - 126 + eadj;
+    float m = bgk_u2f((bits & 0x007fffffu) | 0x3f000000u); /* [0.5, 1) */
+    if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; }
+    else { m = m - 1.0f; }
+    float z = m * m;
+    float y = 7.0376836292e-2f;
+    y = __builtin_fmaf(y, m, -1.1514610310e-1f);
+    y = __builtin_fmaf(y, m, 1.1676998740e-1f);
+    y = __builtin_fmaf(y, m, -1.2420140846e-1f);
+    y = __builtin_fmaf(y, m, 1.4249322787e-1f);
+    y = __builtin_fmaf(y, m, -1.6668057665e-1f);
+    y = __builtin_fmaf(y, m, 2.0000714765e-1f);
+    y = __builtin_fmaf(y, m, -2.4999993993e-1f);
+    y = __builtin_fmaf(y, m, 3.3333331174e-1f);
+    y = y * m;
+    y = y * z;
+    float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(z, -0.5f, y);
+    float r = m + y;
+    r = __builtin_fmaf(fe, 0.693359375f, r);
+    return r;
+}
+
+/* log(1 + e) for e >= 0 (Kahan's correction keeps full relative accuracy for tiny e) */
+BGK_FN float bgk_log1pf_pos(float e) {
+    float u = 1.0f + e;
+    if (u == 1.0f) return e;
+    return bgk_logf(u) * (e / (u - 1.0f));
+}
+
+/* torch.nn.functional.softplus(x, beta, threshold=20):  x*beta > 20 ? x : log1p(exp(x*beta))/beta */
+BGK_FN float bgk_softplusf(float x, float beta) {
+    float z = x * beta;
+    if (z > 20.0f) return x;
+    return bgk_log1pf_pos(bgk_expf(z)) / beta;
+}
+
+/* SiLU  x * sigmoid(x) = x / (1 + exp(-x)) */
+BGK_FN float bgk_siluf(float x) {
+    return x / (1.0f + bgk_expf(-x));
+}
+
+/* tanh (Cephes tanhf split at 0.625) */
+BGK_FN float bgk_tanhf(float x) {
+    float ax = x < 0.0f ? -x : x;
+    if (ax >= 0.625f) {
+        float e = bgk_expf(ax + ax);
+        float r = 1.0f - 2.0f / (e + 1.0f);
+        return x < 0.0f ? -r : r;
+    }
+    float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = __builtin_fmaf(p, z, 2.06390887954e-2f);
+    p = __builtin_fmaf(p, z, -5.37397155531e-2f);
+    p = __builtin_fmaf(p, z, 1.33314422036e-1f);
+    p = __builtin_fmaf(p, z, -3.33332819422e-1f);
+    p = p * z;
+    return __builtin_fmaf(p, x, x);
+}
+
+#endif /* BGK_DETMATH_H */

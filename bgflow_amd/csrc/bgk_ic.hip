@@ -1,0 +1,298 @@
+/* bgk_ic.hip -- Z-matrix <-> Cartesian internal-coordinate transform (relative to fixed atoms,
+ * optional PCA whitening of the fixed block) with log|det J|.
+ *
+ * One lane owns one sample and walks the Z-matrix rows (xyz->IC) or the placement table
+ * (IC->xyz, NeRF-style sequential placement); the index tables are wave-uniform (scalar loads).
+ * Per-sample rows are staged through LDS so every HBM access is a coalesced stream over the
+ * tile: algorithmic bytes 4*(3*n_atoms + 3n + keep + 2) per sample.  Row strides in LDS are odd
+ * -> the lane-per-row accesses are bank-conflict-free.
+ *
+ * Arithmetic follows SURVEY.md Appendix B / oracle/bgo_impl.h (explicit 3x3 Jacobian determinant
+ * like the reference, eps clamps included); transcendental functions are the precise OCML ones.
+ */
+#include "bgk_common.h"
+
+namespace {
+
+constexpr int IC_THREADS = 128;
+#define PI_F 3.14159265358979323846f
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float norm(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ V3 divs(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ float det3(V3 r0, V3 r1, V3 r2) { return dot(cross(r0, r1), r2); }
+
+struct IcArgs {
+    float* x; int64_t ldx;                  /* in (xyz2ic) or out (ic2xyz) */
+    float* bonds; float* angles; float* torsions; int64_t ldic;
+    float* xfix; int64_t ldf;
+    const int32_t* table;                   /* zmat [n,4] or place [n,5] */
+    const int32_t* fixed;
+    int n, n_fixed, n_atoms, keep;
+    int normalize, enforce;
+    float eps;
+    const float* wh_mean; const float* T;   /* Twhiten [3nf, keep] or Tblacken [keep, 3nf] */
+    float jac_xz;
+    int64_t B;
+    float* dlogp; int accumulate;
+    int32_t* warn_count;
+    int sx;                                 /* LDS row stride of the xyz tile (odd) */
+    int sic;                                /* LDS row stride of one IC tile (odd)  */
+    int sfx;                                /* LDS row stride of the xfix tile (odd) */
+};
+
+__device__ __forceinline__ float clamp_min_flag(float v, float eps, int enforce, int& warn) {
+    if (v < eps) { warn += 1; if (enforce) v = eps; }
+    return v;
+}
+
+/* cooperative coalesced copy of a [rows, cols] global tile (row stride ld) <-> LDS (row stride s) */
+__device__ __forceinline__ void tile_load(float* dst, int s, const float* src, int64_t ld, int rows, int cols) {
+    for (int i = threadIdx.x; i < rows * cols; i += IC_THREADS) {
+        int r = i / cols, c = i - r * cols;
+        dst[r * s + c] = src[(int64_t)r * ld + c];
+    }
+}
+__device__ __forceinline__ void tile_store(float* dst, int64_t ld, const float* src, int s, int rows, int cols) {
+    for (int i = threadIdx.x; i < rows * cols; i += IC_THREADS) {
+        int r = i / cols, c = i - r * cols;
+        dst[(int64_t)r * ld + c] = src[r * s + c];
+    }
+}
+
+__global__ __launch_bounds__(IC_THREADS) void ic_xyz2ic_kernel(IcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TS = IC_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
+    float* s_x = smem;                       /* [TS][sx]  */
+    float* s_b = s_x + TS * a.sx;            /* [TS][sic] */
+    float* s_a = s_b + TS * a.sic;
+    float* s_t = s_a + TS * a.sic;
+    float* s_f = s_t + TS * a.sic;           /* [TS][sfx] */
+    const int tid = threadIdx.x;
+    const int64_t n_tiles = (a.B + TS - 1) / TS;
+    int warn = 0;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * TS;
+        const int rows = (int)((a.B - b0) < TS ? (a.B - b0) : TS);
+        tile_load(s_x, a.sx, a.x + b0 * a.ldx, a.ldx, rows, 3 * a.n_atoms);
+        __syncthreads();
+        if (tid < rows) {
+            const float* xr = s_x + tid * a.sx;
+            float acc = 0.0f;
+            for (int i = 0; i < n; ++i) {
+                const int i1 = a.table[4 * i], i2 = a.table[4 * i + 1], i3 = a.table[4 * i + 2], i4 = a.table[4 * i + 3];
+                V3 x1 = ld3(xr + 3 * i1), x2 = ld3(xr + 3 * i2), x3 = ld3(xr + 3 * i3), x4 = ld3(xr + 3 * i4);
+                /* dist_deriv (ic_helper.py:148-165) */
+                V3 r = sub(x2, x1);
+                float rn = clamp_min_flag(norm(r), a.eps, a.enforce, warn);
+                V3 Jb = {-r.x / rn, -r.y / rn, -r.z / rn};
+                /* angle_deriv (ic_helper.py:168-210) */
+                V3 r12 = sub(x1, x2);
+                float n12 = clamp_min_flag(norm(r12), a.eps, a.enforce, warn);
+                V3 u12 = divs(r12, n12);
+                V3 r32 = sub(x3, x2);
+                float n32 = clamp_min_flag(norm(r32), a.eps, a.enforce, warn);
+                V3 u32 = divs(r32, n32);
+                float cosa = dot(u12, u32);
+                /* J = u32^T (I - u12 u12^T) / n12 : column c = sum_k u32[k] * (delta_kc - u12[k] u12[c]) / n12 */
+                float u12v[3] = {u12.x, u12.y, u12.z}, u32v[3] = {u32.x, u32.y, u32.z}, Jav[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float Pkc = ((k == c ? 1.0f : 0.0f) - u12v[k] * u12v[c]) / n12;
+                        s += u32v[k] * Pkc;
+                    }
+                    Jav[c] = s;
+                }
+                if (a.enforce) { cosa = cosa < -1.0f + a.eps ? -1.0f + a.eps : cosa; cosa = cosa > 1.0f - a.eps ? 1.0f - a.eps : cosa; }
+                float ang = acosf(cosa);
+                float sq = __builtin_sqrtf(1.0f - cosa * cosa);
+                V3 Ja = {-Jav[0] / sq, -Jav[1] / sq, -Jav[2] / sq};
+                /* torsion_deriv (ic_helper.py:213-293) */
+                V3 b0v = {-(x2.x - x1.x), -(x2.y - x1.y), -(x2.z - x1.z)};
+                V3 b1 = sub(x3, x2), b2 = sub(x4, x3);
+                float b1n = clamp_min_flag(norm(b1), a.eps, a.enforce, warn);
+                V3 u = divs(b1, b1n);
+                float b0u = dot(b0v, u), b2u = dot(b2, u);
+                V3 v = {b0v.x - b0u * u.x, b0v.y - b0u * u.y, b0v.z - b0u * u.z};
+                V3 w = {b2.x - b2u * u.x, b2.y - b2u * u.y, b2.z - b2u * u.z};
+                float xx = dot(v, w);
+                float yy = dot(cross(u, v), w);
+                float tor = atan2f(yy, xx);
+                float q = clamp_min_flag(xx * xx + yy * yy, a.eps, a.enforce, warn);
+                float dadx = -yy / q, dady = xx / q;
+                V3 wxu = cross(w, u);
+                V3 g = {dadx * w.x + dady * wxu.x, dadx * w.y + dady * wxu.y, dadx * w.z + dady * wxu.z};
+                float gu = dot(g, u);
+                V3 Jt = {g.x - gu * u.x, g.y - gu * u.y, g.z - gu * u.z};
+                float det = det3(Jb, Ja, Jt);
+                acc += logf(fabsf(det));
+                if (a.normalize) { ang = ang / PI_F; tor = (tor + PI_F) / (2.0f * PI_F); }
+                s_b[tid * a.sic + i] = rn;
+                s_a[tid * a.sic + i] = ang;
+                s_t[tid * a.sic + i] = tor;
+            }
+            if (a.normalize) acc += -(float)n * logf(PI_F) - (float)n * logf(2.0f * PI_F);
+            if (a.T) {
+                for (int k = 0; k < a.keep; ++k) {
+                    float s = 0.0f;
+                    for (int c = 0; c < nf3; ++c) {
+                        float xc = xr[3 * a.fixed[c / 3] + c % 3] - a.wh_mean[c];
+                        s += xc * a.T[c * a.keep + k];
+                    }
+                    s_f[tid * a.sfx + k] = s;
+                }
+                acc += a.jac_xz;
+            } else {
+                for (int c = 0; c < nf3; ++c) s_f[tid * a.sfx + c] = xr[3 * a.fixed[c / 3] + c % 3];
+            }
+            if (a.accumulate) a.dlogp[b0 + tid] += acc; else a.dlogp[b0 + tid] = acc;
+        }
+        __syncthreads();
+        tile_store(a.bonds + b0 * a.ldic, a.ldic, s_b, a.sic, rows, n);
+        tile_store(a.angles + b0 * a.ldic, a.ldic, s_a, a.sic, rows, n);
+        tile_store(a.torsions + b0 * a.ldic, a.ldic, s_t, a.sic, rows, n);
+        tile_store(a.xfix + b0 * a.ldf, a.ldf, s_f, a.sfx, rows, a.keep);
+        __syncthreads();
+    }
+    if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
+}
+
+__global__ __launch_bounds__(IC_THREADS) void ic_ic2xyz_kernel(IcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TS = IC_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
+    float* s_x = smem;
+    float* s_b = s_x + TS * a.sx;
+    float* s_a = s_b + TS * a.sic;
+    float* s_t = s_a + TS * a.sic;
+    float* s_f = s_t + TS * a.sic;
+    const int tid = threadIdx.x;
+    const int64_t n_tiles = (a.B + TS - 1) / TS;
+    int warn = 0;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * TS;
+        const int rows = (int)((a.B - b0) < TS ? (a.B - b0) : TS);
+        tile_load(s_b, a.sic, a.bonds + b0 * a.ldic, a.ldic, rows, n);
+        tile_load(s_a, a.sic, a.angles + b0 * a.ldic, a.ldic, rows, n);
+        tile_load(s_t, a.sic, a.torsions + b0 * a.ldic, a.ldic, rows, n);
+        tile_load(s_f, a.sfx, a.xfix + b0 * a.ldf, a.ldf, rows, a.keep);
+        __syncthreads();
+        if (tid < rows) {
+            float* xr = s_x + tid * a.sx;
+            float acc = 0.0f;
+            if (a.T) {
+                for (int c = 0; c < nf3; ++c) {
+                    float s = 0.0f;
+                    for (int k = 0; k < a.keep; ++k) s += s_f[tid * a.sfx + k] * a.T[k * nf3 + c];
+                    xr[3 * a.fixed[c / 3] + c % 3] = s + a.wh_mean[c];
+                }
+                acc += -a.jac_xz;
+            } else {
+                for (int c = 0; c < nf3; ++c) xr[3 * a.fixed[c / 3] + c % 3] = s_f[tid * a.sfx + c];
+            }
+            if (a.normalize) acc += (float)n * logf(PI_F) + (float)n * logf(2.0f * PI_F);
+            for (int i = 0; i < n; ++i) {
+                const int at = a.table[5 * i], i1 = a.table[5 * i + 1], i2 = a.table[5 * i + 2],
+                          i3 = a.table[5 * i + 3], zr = a.table[5 * i + 4];
+                V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
+                float dd = s_b[tid * a.sic + zr], an = s_a[tid * a.sic + zr], t = s_t[tid * a.sic + zr];
+                if (a.normalize) { an = an * PI_F; t = t * (2.0f * PI_F) - PI_F; }
+                /* ic2xyz_deriv (ic_helper.py:372-452) */
+                V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
+                V3 nv = cross(v1, v2), nn = cross(v1, nv);
+                float nvn = clamp_min_flag(norm(nv), a.eps, a.enforce, warn);
+                float nnn = clamp_min_flag(norm(nn), a.eps, a.enforce, warn);
+                V3 nh = divs(nv, nvn), nnh = divs(nn, nnn);
+                float st = sinf(t), ct = cosf(t), sa = sinf(an), ca = cosf(an);
+                V3 v3 = {nh.x * (-st) + nnh.x * ct, nh.y * (-st) + nnh.y * ct, nh.z * (-st) + nnh.z * ct};
+                float v3n = clamp_min_flag(norm(v3), a.eps, a.enforce, warn);
+                V3 v3h = divs(v3, v3n);
+                float v1n = clamp_min_flag(norm(v1), a.eps, a.enforce, warn);
+                V3 v1h = divs(v1, v1n);
+                V3 pos = {p1.x + v3h.x * dd * sa - v1h.x * dd * ca, p1.y + v3h.y * dd * sa - v1h.y * dd * ca,
+                          p1.z + v3h.z * dd * sa - v1h.z * dd * ca};
+                V3 Jd = {v3h.x * sa - v1h.x * ca, v3h.y * sa - v1h.y * ca, v3h.z * sa - v1h.z * ca};
+                V3 Ja = {v3h.x * dd * ca + v1h.x * dd * sa, v3h.y * dd * ca + v1h.y * dd * sa,
+                         v3h.z * dd * ca + v1h.z * dd * sa};
+                V3 Jt3 = {nh.x * (-ct) + nnh.x * (-st), nh.y * (-ct) + nnh.y * (-st), nh.z * (-ct) + nnh.z * (-st)};
+                float jt1 = dd * sa, h3 = dot(v3h, Jt3), inv = 1.0f / v3n;
+                V3 Jt = {jt1 * inv * (Jt3.x - v3h.x * h3), jt1 * inv * (Jt3.y - v3h.y * h3), jt1 * inv * (Jt3.z - v3h.z * h3)};
+                /* rows of J = stack([Jd, Ja, Jt], dim=-1) */
+                V3 R0 = {Jd.x, Ja.x, Jt.x}, R1 = {Jd.y, Ja.y, Jt.y}, R2 = {Jd.z, Ja.z, Jt.z};
+                float det = det3(R0, R1, R2);
+                acc += logf(fabsf(det));
+                xr[3 * at] = pos.x; xr[3 * at + 1] = pos.y; xr[3 * at + 2] = pos.z;
+            }
+            if (a.accumulate) a.dlogp[b0 + tid] += acc; else a.dlogp[b0 + tid] = acc;
+        }
+        __syncthreads();
+        tile_store(a.x + b0 * a.ldx, a.ldx, s_x, a.sx, rows, 3 * a.n_atoms);
+        __syncthreads();
+    }
+    if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
+}
+
+int ic_launch(bool to_ic, IcArgs& a, void* stream, const char* what) {
+    a.n_atoms = a.n + a.n_fixed;
+    a.sx = (3 * a.n_atoms) | 1;
+    a.sic = a.n | 1;
+    a.sfx = a.keep | 1;
+    size_t shmem = sizeof(float) * (size_t)IC_THREADS * (size_t)(a.sx + 3 * a.sic + a.sfx);
+    if (shmem > 160 * 1024) { bgk_set_error("%s: %d atoms do not fit the LDS tile", what, a.n_atoms); return BGK_EUNSUPPORTED; }
+    int64_t n_tiles = (a.B + IC_THREADS - 1) / IC_THREADS;
+    int grid = (int)(n_tiles < 256 * 8 ? n_tiles : 256 * 8);
+    if (to_ic) hipLaunchKernelGGL(ic_xyz2ic_kernel, dim3(grid), dim3(IC_THREADS), shmem, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(ic_ic2xyz_kernel, dim3(grid), dim3(IC_THREADS), shmem, (hipStream_t)stream, a);
+    return bgk_launch_status(what);
+}
+
+}  // namespace
+
+extern "C" int bgk_ic_xyz2ic(const float* x, int64_t ldx, const int32_t* zmat, int32_t n,
+                             const int32_t* fixed, int32_t n_fixed, int32_t normalize_angles,
+                             float eps, int32_t enforce_boundaries, const float* wh_mean,
+                             const float* Twhiten, int32_t keep, float jac_xz, int64_t B,
+                             float* bonds, float* angles, float* torsions, int64_t ldic,
+                             float* xfix, int64_t ldf, float* dlogp, int32_t accumulate,
+                             int32_t* warn_count, void* stream) {
+    BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_ic_xyz2ic: bad sizes");
+    BGK_CHECK_ARG(x && zmat && fixed && bonds && angles && torsions && xfix && dlogp, "bgk_ic_xyz2ic: null pointer");
+    BGK_CHECK_ARG(Twhiten ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_ic_xyz2ic: bad whitening arguments");
+    if (B == 0) return 0;
+    IcArgs a{};
+    a.x = const_cast<float*>(x); a.ldx = ldx; a.bonds = bonds; a.angles = angles; a.torsions = torsions;
+    a.ldic = ldic; a.xfix = xfix; a.ldf = ldf; a.table = zmat; a.fixed = fixed; a.n = n; a.n_fixed = n_fixed;
+    a.keep = keep; a.normalize = normalize_angles; a.enforce = enforce_boundaries; a.eps = eps;
+    a.wh_mean = wh_mean; a.T = Twhiten; a.jac_xz = jac_xz; a.B = B; a.dlogp = dlogp; a.accumulate = accumulate;
+    a.warn_count = warn_count;
+    return ic_launch(true, a, stream, "bgk_ic_xyz2ic");
+}
+
+extern "C" int bgk_ic_ic2xyz(const float* bonds, const float* angles, const float* torsions,
+                             int64_t ldic, const float* xfix, int64_t ldf, const int32_t* place,
+                             int32_t n, const int32_t* fixed, int32_t n_fixed,
+                             int32_t normalize_angles, float eps, int32_t enforce_boundaries,
+                             const float* wh_mean, const float* Tblacken, int32_t keep,
+                             float jac_xz, int64_t B, float* x, int64_t ldx, float* dlogp,
+                             int32_t accumulate, int32_t* warn_count, void* stream) {
+    BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_ic_ic2xyz: bad sizes");
+    BGK_CHECK_ARG(x && place && fixed && bonds && angles && torsions && xfix && dlogp, "bgk_ic_ic2xyz: null pointer");
+    BGK_CHECK_ARG(Tblacken ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_ic_ic2xyz: bad whitening arguments");
+    if (B == 0) return 0;
+    IcArgs a{};
+    a.x = x; a.ldx = ldx; a.bonds = const_cast<float*>(bonds); a.angles = const_cast<float*>(angles);
+    a.torsions = const_cast<float*>(torsions); a.ldic = ldic; a.xfix = const_cast<float*>(xfix); a.ldf = ldf;
+    a.table = place; a.fixed = fixed; a.n = n; a.n_fixed = n_fixed; a.keep = keep;
+    a.normalize = normalize_angles; a.enforce = enforce_boundaries; a.eps = eps;
+    a.wh_mean = wh_mean; a.T = Tblacken; a.jac_xz = jac_xz; a.B = B; a.dlogp = dlogp; a.accumulate = accumulate;
+    a.warn_count = warn_count;
+    return ic_launch(false, a, stream, "bgk_ic_ic2xyz");
+}

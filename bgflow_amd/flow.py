@@ -1,0 +1,287 @@
+"""Flow protocol and tuple-plumbing blocks, API-compatible with bgflow.nn.flow.
+
+``Flow.forward(*xs, inverse=False, **kwargs) -> (*ys, dlogp)`` with ``dlogp`` of shape [batch, 1]
+(reference: bgflow/nn/flow/base.py:17-33).  The blocks in this file move tensors around and never
+touch the data with arithmetic; the arithmetic blocks (transformers, internal coordinates) live in
+transformer.py / ic.py and run hand-written HIP kernels.
+
+Reference files mirrored here (names, constructor signatures, error behaviour):
+  bgflow/nn/flow/base.py, sequential.py, inverted.py, coupling.py.
+"""
+import warnings
+from collections.abc import Sequence
+
+import numpy as np
+import torch
+
+__all__ = [
+    "Flow", "SequentialFlow", "InverseFlow", "SplitFlow", "MergeFlow", "SwapFlow", "CouplingFlow",
+    "WrapFlow", "SetConstantFlow",
+]
+
+
+class Flow(torch.nn.Module):
+    """Base class: subclasses implement ``_forward`` / ``_inverse`` (base.py:7-33)."""
+
+    def _forward(self, *xs, **kwargs):
+        raise NotImplementedError()
+
+    def _inverse(self, *xs, **kwargs):
+        raise NotImplementedError()
+
+    def forward(self, *xs, inverse=False, **kwargs):
+        return self._inverse(*xs, **kwargs) if inverse else self._forward(*xs, **kwargs)
+
+
+def _zero_dlogp(x):
+    return torch.zeros(*x.shape[:-1], 1, dtype=x.dtype, device=x.device)
+
+
+class SequentialFlow(Flow):
+    """Chain of blocks; log-dets are summed, blocks run reversed for ``inverse=True``
+    (sequential.py:26-59)."""
+
+    def __init__(self, blocks):
+        super().__init__()
+        self._blocks = torch.nn.ModuleList(blocks)
+
+    def forward(self, *xs, inverse=False, **kwargs):
+        order = reversed(self._blocks) if inverse else self._blocks
+        # same accumulation as the reference (sequential.py:49,58): start from the python float 0.0,
+        # `dlogp += ddlogp` (new tensor for the first block, in place afterwards)
+        total = 0.0
+        for block in order:
+            *xs, ddlogp = block(*xs, inverse=inverse, **kwargs)
+            total += ddlogp
+        return (*xs, total)
+
+    def _forward(self, *args, **kwargs):
+        return self.forward(*args, **kwargs, inverse=False)
+
+    def _inverse(self, *args, **kwargs):
+        return self.forward(*args, **kwargs, inverse=True)
+
+    def trigger(self, function_name):
+        """Call ``function_name()`` on every block that has it; stack the results (sequential.py:67-80)."""
+        results = [getattr(b, function_name)() for b in self._blocks
+                   if callable(getattr(b, function_name, None))]
+        if results and all(r is not None for r in results):
+            return torch.stack(results)
+        return torch.zeros(0)
+
+    def __iter__(self):
+        return iter(self._blocks)
+
+    def __len__(self):
+        return len(self._blocks)
+
+    def __getitem__(self, index):
+        if isinstance(index, int):
+            return self._blocks[index]
+        picked = np.arange(len(self))[index]
+        return SequentialFlow([self._blocks[i] for i in picked])
+
+
+class InverseFlow(Flow):
+    """Swap the two directions of ``delegate`` (inverted.py:7-23)."""
+
+    def __init__(self, delegate):
+        super().__init__()
+        self._delegate = delegate
+
+    def _forward(self, *xs, **kwargs):
+        return self._delegate._inverse(*xs, **kwargs)
+
+    def _inverse(self, *xs, **kwargs):
+        return self._delegate._forward(*xs, **kwargs)
+
+
+class SplitFlow(Flow):
+    """Split one tensor into several along ``dim`` by sizes (views) or by index lists (gathers);
+    the inverse concatenates / scatters (coupling.py:13-104).  The size of the last chunk may be
+    omitted.  Raises ValueError on a too-short tensor, overlapping or missing indices."""
+
+    def __init__(self, *sizes_or_indices, dim=-1):
+        super().__init__()
+        first = sizes_or_indices[0]
+        by_index = isinstance(first, (Sequence, np.ndarray))
+        self._sizes = None if by_index else sizes_or_indices
+        self._indices = sizes_or_indices if by_index else None
+        self._split_dim = dim
+
+    def _forward(self, x, **kwargs):
+        parts = self._split_with_sizes(x) if self._indices is None else self._split_with_indices(x)
+        return (*parts, self._dlogp(x))
+
+    def _inverse(self, *xs, **kwargs):
+        if self._indices is None:
+            y = torch.cat(xs, dim=self._split_dim)
+        else:
+            y = self._cat_with_indices(*xs)
+        return y, self._dlogp(xs[0])
+
+    def _dlogp(self, x):
+        return torch.zeros_like(x.narrow(self._split_dim, 0, 1))
+
+    def _split_with_sizes(self, x):
+        rest = x.shape[self._split_dim] - sum(self._sizes)
+        if rest < 0:
+            raise ValueError(f"can't split x [{x.shape}] into sizes {self._sizes} along {self._split_dim}")
+        sizes = list(self._sizes) + ([rest] if rest > 0 else [])
+        return torch.split(x, sizes, dim=self._split_dim)
+
+    def _check_cover(self, length, verb):
+        seen = np.zeros(length, dtype=bool)
+        for idx in self._indices:
+            idx = np.asarray(idx, dtype=np.int64)
+            if seen[idx].any():
+                raise ValueError(f"Cannot {verb} tensor. Indices are overlapping.")
+            seen[idx] = True
+        if not seen.all():
+            word = "Split" if verb == "split" else "Merge"
+            raise ValueError(f"{word} with indices missed indices {np.arange(length)[~seen]}")
+
+    def _take(self, x, idx):
+        index = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=x.device)
+        return x.index_select(self._split_dim, index)
+
+    def _split_with_indices(self, x):
+        self._check_cover(x.shape[self._split_dim], "split")
+        return [self._take(x, idx) for idx in self._indices]
+
+    def _cat_with_indices(self, *xs):
+        length = sum(len(idx) for idx in self._indices)
+        self._check_cover(length, "merge")
+        shape = list(xs[0].shape)
+        shape[self._split_dim] = length
+        y = torch.empty(*shape, device=xs[0].device, dtype=xs[0].dtype)
+        for x, idx in zip(xs, self._indices):
+            index = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=x.device)
+            y.index_copy_(self._split_dim if self._split_dim >= 0 else y.dim() + self._split_dim, index, x)
+        return y
+
+
+class MergeFlow(InverseFlow):
+    """``InverseFlow(SplitFlow(*sizes))`` (coupling.py:107-110)."""
+
+    def __init__(self, *sizes, dim=-1):
+        super().__init__(SplitFlow(*sizes, dim=dim))
+
+
+class SwapFlow(Flow):
+    """Exchange the first two tensors (coupling.py:113-130)."""
+
+    def _swap(self, *xs):
+        if len(xs) == 1:
+            warnings.warn("applying swapping on a single tensor has no effect")
+        return (xs[1], xs[0], *xs[2:], _zero_dlogp(xs[0]))
+
+    def _forward(self, *xs, **kwargs):
+        return self._swap(*xs)
+
+    def _inverse(self, *xs, **kwargs):
+        return self._swap(*xs)
+
+
+class CouplingFlow(Flow):
+    """Coupling layer: tensors ``transformed_indices`` are transformed conditioned on tensors
+    ``cond_indices`` (coupling.py:133-182).  ValueError if the two index sets intersect."""
+
+    def __init__(self, transformer, transformed_indices=(1,), cond_indices=(0,), cat_dim=-1):
+        super().__init__()
+        self.transformer = transformer
+        self.transformed_indices = transformed_indices
+        self.cond_indices = cond_indices
+        clash = np.intersect1d(self.transformed_indices, self.cond_indices)
+        if len(clash) > 0:
+            raise ValueError(f"Indices {clash} cannot be both transformed and conditioned on.")
+        self.cat_dim = cat_dim
+
+    def _gather(self, x, indices):
+        # a single tensor needs no concatenation copy (the kernels take strided rows)
+        if len(indices) == 1:
+            return x[indices[0]]
+        return torch.cat([x[i] for i in indices], dim=self.cat_dim)
+
+    def _couple(self, x, inverse, kwargs):
+        lengths = [x[i].shape[self.cat_dim] for i in self.transformed_indices]
+        inputs = self._gather(x, self.transformed_indices)
+        cond = self._gather(x, self.cond_indices)
+        x = list(x)
+        if inverse:
+            y, dlogp = self.transformer.forward(cond, inputs, **kwargs, inverse=True)
+        else:
+            y, dlogp = self.transformer.forward(cond, inputs, **kwargs)
+        parts = (y,) if len(lengths) == 1 else torch.split(y, lengths, self.cat_dim)
+        for i, yi in zip(self.transformed_indices, parts):
+            x[i] = yi
+        return (*x, dlogp)
+
+    def _forward(self, *x, **kwargs):
+        return self._couple(x, False, kwargs)
+
+    def _inverse(self, *x, **kwargs):
+        return self._couple(x, True, kwargs)
+
+
+class WrapFlow(Flow):
+    """Apply ``flow`` to the tensors at ``indices``; its outputs are inserted at ``out_indices``
+    (default: the same positions) among the untouched tensors (coupling.py:185-222)."""
+
+    def __init__(self, flow, indices, out_indices=None):
+        super().__init__()
+        self._flow = flow
+        self._indices = indices
+        self._argsort_indices = np.argsort(indices)
+        self._out_indices = indices if out_indices is None else out_indices
+        self._argsort_out_indices = np.argsort(self._out_indices)
+
+    @staticmethod
+    def _route(flow, xs, take, put, put_order, kwargs):
+        rest = [x for i, x in enumerate(xs) if i not in take]
+        *ys, dlogp = flow(*(xs[i] for i in take), **kwargs)
+        for k in put_order:
+            rest.insert(put[k], ys[k])
+        return (*rest, dlogp)
+
+    def _forward(self, *xs, **kwargs):
+        return self._route(self._flow, xs, self._indices, self._out_indices, self._argsort_out_indices, kwargs)
+
+    def _inverse(self, *xs, **kwargs):
+        return self._route(self._flow, xs, self._out_indices, self._indices, self._argsort_indices,
+                           dict(kwargs, inverse=True))
+
+
+class SetConstantFlow(Flow):
+    """Forward inserts constant tensors (repeated over the batch) at ``indices``; inverse drops
+    them (coupling.py:227-272)."""
+
+    def __init__(self, indices, values, n_event_dims0=1):
+        super().__init__()
+        order = np.argsort(indices)
+        self.indices = [indices[i] for i in order]
+        for k, i in enumerate(order):
+            self.register_buffer(f"_values_{k}", values[i])
+        self.n_event_dims0 = n_event_dims0
+
+    @property
+    def values(self):
+        out, k = [], 0
+        while hasattr(self, f"_values_{k}"):
+            out.append(getattr(self, f"_values_{k}"))
+            k += 1
+        return out
+
+    def _forward(self, *xs, **kwargs):
+        batch = list(xs[0].shape[:self.n_event_dims0])
+        ys = list(xs)
+        for i, v in zip(self.indices, self.values):
+            ys.insert(i, v.repeat([*batch, *([1] * v.dim())]))
+        dlogp = torch.zeros(batch + [1], device=xs[0].device, dtype=xs[0].dtype)
+        return (*ys, dlogp)
+
+    def _inverse(self, *xs, **kwargs):
+        ys = tuple(x for i, x in enumerate(xs) if i not in self.indices)
+        batch = list(ys[0].shape[:self.n_event_dims0])
+        dlogp = torch.zeros(batch + [1], device=ys[0].device, dtype=ys[0].dtype)
+        return (*ys, dlogp)

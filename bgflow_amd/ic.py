@@ -1,0 +1,314 @@
+"""Internal-coordinate (Z-matrix <-> Cartesian) transforms on the HIP kernels bgk_ic_xyz2ic /
+bgk_ic_ic2xyz, API-compatible with bgflow/nn/flow/crd_transform/{ic,pca}.py.
+
+``forward`` maps xyz -> (bonds, angles, torsions, fixed) and ``inverse`` back, each with
+log|det J| (ic.py:386-513).  ``MixedCoordinateTransformation`` adds PCA whitening of the fixed
+atoms (ic.py:719-884, pca.py:37-107); in the kernels the whitening matvec is fused into the same
+launch.  Z-matrix decomposition and the PCA are construction-time host code (numpy).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .flow import Flow
+
+__all__ = [
+    "decompose_z_matrix", "RelativeInternalCoordinateTransformation", "MixedCoordinateTransformation",
+    "WhitenFlow",
+]
+
+
+def decompose_z_matrix(z_matrix, fixed):
+    """Group the rows of a relative Z-matrix into placement stages: a row (a, b, c, d) can be
+    placed once b, c, d are known (fixed or placed earlier).  Returns ``(blocks, index2atom,
+    atom2index, index2order)`` with the meaning of bgflow's function of the same name
+    (crd_transform/ic.py:25-91); raises ValueError if some atom is unreachable."""
+    z = np.asarray(z_matrix)
+    fixed = np.asarray(fixed)
+    known = np.zeros(int(max(z.max(), fixed.max())) + 1, dtype=bool)
+    known[fixed] = True
+    pending = [i for i in range(len(z)) if not known[z[i, 0]]]
+    row_of = {i: k for k, i in enumerate(pending)}   # position among the non-fixed rows
+    blocks, atoms, order = [], [fixed], []
+    while pending:
+        ready = [i for i in pending if known[z[i, 1:]].all()]
+        if not ready:
+            raise ValueError(
+                "Z-matrix decomposition failed. The following atoms were not reachable from the fixed atoms: \n"
+                f"{z[pending, 0]}")
+        blocks.append(z[ready])
+        atoms.append(z[ready, 0])
+        order.append(np.array([row_of[i] for i in ready]))
+        known[z[ready, 0]] = True
+        ready_set = set(ready)
+        pending = [i for i in pending if i not in ready_set]
+    index2atom = np.concatenate(atoms)
+    atom2index = np.argsort(index2atom)
+    index2order = np.concatenate(order) if order else np.zeros(0, dtype=np.int64)
+    return blocks, index2atom, atom2index, index2order
+
+
+def _placement_table(z_matrix, fixed):
+    """[n,5] int32 rows (atom, p1, p2, p3, zrow) in placement order for bgk_ic_ic2xyz."""
+    blocks, _, _, index2order = decompose_z_matrix(z_matrix, fixed)
+    rows = np.concatenate(blocks) if blocks else np.zeros((0, 4), dtype=np.int64)
+    return np.concatenate([rows, index2order[:, None]], axis=1).astype(np.int32)
+
+
+class _DeviceTables:
+    """Small int32 / f32 constant tables, uploaded once per device."""
+
+    def __init__(self):
+        self._host = {}
+        self._dev = {}
+
+    def set(self, name, array):
+        self._host[name] = array
+        self._dev = {k: v for k, v in self._dev.items() if k[0] != name}
+
+    def get(self, name, device):
+        key = (name, str(device))
+        if key not in self._dev:
+            self._dev[key] = torch.as_tensor(self._host[name]).to(device)
+        return self._dev[key]
+
+
+def _contig_rows(*ts):
+    """make IC tensors [B, n] row-major with a COMMON row stride (copy only when needed)."""
+    outs = []
+    ld0 = None
+    for t in ts:
+        t2, ld = _lib.rowmajor(t)
+        if ld0 is None:
+            ld0 = ld
+        outs.append((t2, ld))
+    if any(ld != ld0 for _, ld in outs):
+        outs = [(t.contiguous(), t.shape[1]) for t, _ in outs]
+        ld0 = outs[0][1]
+    return [t for t, _ in outs], ld0
+
+
+class _ICFn(torch.autograd.Function):
+    """Placeholder for the analytic IC backward (not written yet): raises loudly."""
+
+    @staticmethod
+    def forward(ctx, *args):  # pragma: no cover
+        raise NotImplementedError("gradients through the HIP internal-coordinate kernels are not implemented yet")
+
+
+class RelativeInternalCoordinateTransformation(Flow):
+    """Internal coordinates relative to a set of fixed atoms (crd_transform/ic.py:268-513).
+
+    forward:  x [B, 3*n_atoms] -> bonds, angles, torsions [B, n] each, x_fixed [B, 3*n_fixed], dlogp
+    inverse:  the reverse (NeRF-style sequential placement in Z-matrix dependency order).
+    Angles / torsions are mapped to [0, 1] when ``normalize_angles``.  Near-singular geometry is
+    clamped at ``eps`` exactly like the reference when ``enforce_boundaries``; instead of
+    ``warnings.warn`` inside the hot path the kernels count clamp events in a device counter
+    (``check_singularities()``)."""
+
+    def __init__(self, z_matrix, fixed_atoms, normalize_angles=True, eps=1e-7, enforce_boundaries=True,
+                 raise_warnings=True):
+        super().__init__()
+        self._z_matrix = z_matrix
+        self._fixed_atoms = fixed_atoms
+        z = np.asarray(z_matrix if not torch.is_tensor(z_matrix) else z_matrix.cpu().numpy())
+        f = np.asarray(fixed_atoms if not torch.is_tensor(fixed_atoms) else fixed_atoms.cpu().numpy())
+        (self._z_blocks, self._index2atom, self._atom2index, self._index2order) = decompose_z_matrix(z, f)
+        self._bond_indices = z[:, :2]
+        self._angle_indices = z[:, :3]
+        self._torsion_indices = z[:, :4]
+        self._normalize_angles = normalize_angles
+        self._eps = eps
+        self._enforce_boundaries = enforce_boundaries
+        self._raise_warnings = raise_warnings
+        self._tables = _DeviceTables()
+        self._tables.set("zmat", np.ascontiguousarray(z[:, :4], dtype=np.int32))
+        self._tables.set("place", _placement_table(z, f))
+        self._tables.set("fixed", np.ascontiguousarray(f, dtype=np.int32))
+        self._n, self._n_fixed = len(z), len(f)
+        self._warn = {}
+
+    # reference properties (ic.py:315-353)
+    z_matrix = property(lambda self: self._z_matrix)
+    fixed_atoms = property(lambda self: self._fixed_atoms)
+    dim_bonds = property(lambda self: len(self._z_matrix))
+    dim_angles = property(lambda self: len(self._z_matrix))
+    dim_torsions = property(lambda self: len(self._z_matrix))
+    dim_fixed = property(lambda self: 3 * len(self._fixed_atoms))
+    bond_indices = property(lambda self: self._bond_indices)
+    angle_indices = property(lambda self: self._angle_indices)
+    torsion_indices = property(lambda self: self._torsion_indices)
+    normalize_angles = property(lambda self: self._normalize_angles)
+
+    def _warn_counter(self, device):
+        if not self._raise_warnings:
+            return None
+        key = str(device)
+        if key not in self._warn:
+            self._warn[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._warn[key]
+
+    def check_singularities(self):
+        """Poll (host sync) and reset the clamp-event counters; warn like the reference would have."""
+        import warnings
+        total = 0
+        for c in self._warn.values():
+            total += int(c.item())
+            c.zero_()
+        if total:
+            warnings.warn(f"singular geometry: {total} norm / division clamps at eps={self._eps}")
+        return total
+
+    def _no_grad_only(self, *ts):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
+            raise NotImplementedError(
+                "gradients through the HIP internal-coordinate kernels are not implemented yet")
+
+    def _xyz2ic(self, x, whiten=None):
+        _lib.require_hip(x)
+        self._no_grad_only(x)
+        dev = x.device
+        x2, ldx = _lib.rowmajor(x.reshape(x.shape[0], -1))
+        B, n, nf = x2.shape[0], self._n, self._n_fixed
+        assert x2.shape[1] == 3 * (n + nf), "x must be [batch, 3 * n_atoms]"
+        ics = torch.empty((3, B, n), dtype=torch.float32, device=dev)
+        if whiten is None:
+            mean = T = None
+            keep, jac = 3 * nf, 0.0
+        else:
+            mean, T, jac = whiten
+            keep = T.shape[1]
+        xfix = torch.empty((B, keep), dtype=torch.float32, device=dev)
+        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_ic_xyz2ic(
+                _lib.ptr(x2), ldx, _lib.ptr(self._tables.get("zmat", dev)), n,
+                _lib.ptr(self._tables.get("fixed", dev)), nf, int(self._normalize_angles), float(self._eps),
+                int(self._enforce_boundaries), _lib.ptr(mean), _lib.ptr(T), keep, float(jac), B,
+                _lib.ptr(ics[0]), _lib.ptr(ics[1]), _lib.ptr(ics[2]), n, _lib.ptr(xfix), keep,
+                _lib.ptr(dlogp), 0, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_ic_xyz2ic")
+        return ics[0], ics[1], ics[2], xfix, dlogp[:, None]
+
+    def _ic2xyz(self, bonds, angles, torsions, xfix, blacken=None):
+        _lib.require_hip(bonds, angles, torsions, xfix)
+        self._no_grad_only(bonds, angles, torsions, xfix)
+        dev = bonds.device
+        B, n, nf = bonds.shape[0], self._n, self._n_fixed
+        assert bonds.shape[-1] == n
+        assert angles.shape[-1] == n
+        assert torsions.shape[-1] == n
+        (b2, a2, t2), ldic = _contig_rows(bonds, angles, torsions)
+        f2, ldf = _lib.rowmajor(xfix.reshape(B, -1))
+        if blacken is None:
+            mean = T = None
+            keep, jac = 3 * nf, 0.0
+        else:
+            mean, T, jac = blacken
+            keep = T.shape[0]
+        assert f2.shape[1] == keep
+        x = torch.empty((B, 3 * (n + nf)), dtype=torch.float32, device=dev)
+        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_ic_ic2xyz(
+                _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), ldic, _lib.ptr(f2), ldf,
+                _lib.ptr(self._tables.get("place", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
+                int(self._normalize_angles), float(self._eps), int(self._enforce_boundaries),
+                _lib.ptr(mean), _lib.ptr(T), keep, float(jac), B, _lib.ptr(x), x.shape[1],
+                _lib.ptr(dlogp), 0, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_ic_ic2xyz")
+        return x, dlogp[:, None]
+
+    def _forward(self, x, with_pose=True, *args, **kwargs):
+        return self._xyz2ic(x)
+
+    def _inverse(self, bonds, angles, torsions, x_fixed, **kwargs):
+        return self._ic2xyz(bonds, angles, torsions, x_fixed)
+
+
+def _pca(X0, keepdims=None):
+    """PCA of the rows of X0 (numpy, float64 like the input): mean, whitening and blackening
+    matrices and the kept standard deviations, eigenvalues descending (pca.py:9-34)."""
+    keepdims = X0.shape[1] if keepdims is None else keepdims
+    mean = X0.mean(axis=0)
+    Xc = X0 - mean
+    cov = Xc.T @ Xc / (Xc.shape[0] - 1.0)
+    eigval, eigvec = np.linalg.eigh(cov)
+    pick = np.argsort(eigval)[::-1][:keepdims]
+    std = np.sqrt(eigval[pick])
+    V = eigvec[:, pick]
+    return mean, V @ np.diag(1.0 / std), np.diag(std) @ V.T, std
+
+
+class WhitenFlow(Flow):
+    """Static PCA whitening ``z = (x - mean) @ Twhiten`` with constant log-det (pca.py:37-107).
+    Stand-alone it is a tiny GEMM and runs stock torch ops; inside MixedCoordinateTransformation
+    the matvec is fused into the IC kernels.  Buffers: X0mean, Twhiten, Tblacken, std."""
+
+    def __init__(self, X0, keepdims=None, whiten_inverse=True):
+        super().__init__()
+        keepdims = X0.shape[1] if keepdims is None else keepdims
+        self.dim = X0.shape[1]
+        self.keepdims = keepdims
+        self.whiten_inverse = whiten_inverse
+        mean, Tw, Tb, std = _pca(X0.detach().cpu().numpy(), keepdims=keepdims)
+        self.register_buffer("X0mean", torch.tensor(mean).to(X0))
+        self.register_buffer("Twhiten", torch.tensor(Tw).to(X0))
+        self.register_buffer("Tblacken", torch.tensor(Tb).to(X0))
+        self.register_buffer("std", torch.tensor(std).to(X0))
+        if torch.any(self.std <= 0):
+            raise ValueError("Cannot construct whiten layer because trying to keep nonpositive eigenvalues.")
+        self.jacobian_xz = -torch.sum(torch.log(self.std))
+
+    def _whiten(self, x):
+        z = torch.matmul(x - self.X0mean, self.Twhiten)
+        return z, self.jacobian_xz.to(x) * torch.ones((x.shape[0], 1), dtype=x.dtype, device=x.device)
+
+    def _blacken(self, z):
+        x = torch.matmul(z, self.Tblacken) + self.X0mean
+        return x, -self.jacobian_xz.to(z) * torch.ones((z.shape[0], 1), dtype=z.dtype, device=z.device)
+
+    def _forward(self, x, *args, **kwargs):
+        return self._blacken(x) if self.whiten_inverse else self._whiten(x)
+
+    def _inverse(self, x, *args, **kwargs):
+        return self._whiten(x) if self.whiten_inverse else self._blacken(x)
+
+
+class MixedCoordinateTransformation(Flow):
+    """Relative internal coordinates + PCA-whitened fixed atoms (crd_transform/ic.py:719-884).
+    Sub-modules keep the reference's names (``_whiten``, ``_rel_ic``) so state_dicts load."""
+
+    def __init__(self, data, z_matrix, fixed_atoms, keepdims=None, normalize_angles=True, eps=1e-7,
+                 enforce_boundaries=True, raise_warnings=True):
+        super().__init__()
+        n_data = data.shape[0]
+        fa = np.asarray(fixed_atoms if not torch.is_tensor(fixed_atoms) else fixed_atoms.cpu().numpy())
+        fixed = data.view(n_data, -1, 3)[:, fa].reshape(n_data, -1)
+        self._whiten = WhitenFlow(fixed, keepdims=keepdims, whiten_inverse=False)
+        self._rel_ic = RelativeInternalCoordinateTransformation(
+            z_matrix=z_matrix, fixed_atoms=fixed_atoms, normalize_angles=normalize_angles, eps=eps,
+            enforce_boundaries=enforce_boundaries, raise_warnings=raise_warnings)
+
+    z_matrix = property(lambda self: self._rel_ic.z_matrix)
+    fixed_atoms = property(lambda self: self._rel_ic.fixed_atoms)
+    dim_bonds = property(lambda self: len(self.z_matrix))
+    dim_angles = property(lambda self: len(self.z_matrix))
+    dim_torsions = property(lambda self: len(self.z_matrix))
+    dim_fixed = property(lambda self: self._whiten.keepdims)
+    bond_indices = property(lambda self: self._rel_ic.bond_indices)
+    angle_indices = property(lambda self: self._rel_ic.angle_indices)
+    torsion_indices = property(lambda self: self._rel_ic.torsion_indices)
+    normalize_angles = property(lambda self: self._rel_ic.normalize_angles)
+
+    def _wh(self, which, device):
+        w = self._whiten
+        T = (w.Twhiten if which == "whiten" else w.Tblacken).to(device=device, dtype=torch.float32).contiguous()
+        mean = w.X0mean.to(device=device, dtype=torch.float32).contiguous()
+        return mean, T, float(w.jacobian_xz)
+
+    def _forward(self, x, *args, **kwargs):
+        return self._rel_ic._xyz2ic(x, whiten=self._wh("whiten", x.device))
+
+    def _inverse(self, bonds, angles, torsions, z_fixed, *args, **kwargs):
+        return self._rel_ic._ic2xyz(bonds, angles, torsions, z_fixed, blacken=self._wh("blacken", bonds.device))

@@ -1,0 +1,64 @@
+"""Small host-side helpers (no kernels)."""
+import zlib
+from collections.abc import Iterable
+
+import numpy as np
+import torch
+
+__all__ = ["hash_init_", "synth", "is_list_or_tuple", "pack_tensor_in_tuple", "unpack_tensor_tuple"]
+
+
+def hash_init_(module, scale=1.0):
+    """Fill every parameter of ``module`` with closed-form pseudo-random values that depend only on the
+    parameter NAME, its shape and the flat index: exact integer arithmetic -> identical on every
+    platform / rank, no weight files, no RNG.  Magnitude = ``scale`` / sqrt(fan_in) (torch's default
+    Linear range); 1-d parameters use 1/sqrt(len); AffineTransformer's ``_log_alpha`` keeps its
+    constructor value.  Used for synthetic benchmark weights and golden-vector generation."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if name.endswith("_log_alpha"):   # learnable scalar of AffineTransformer keeps its ctor value
+                continue
+            h = zlib.crc32(name.encode()) % 2001
+            idx = np.arange(p.numel(), dtype=np.int64)
+            v = ((h + 7919 * idx + 104729 * (idx // 97)) % 2001 - 1000).astype(np.float64) / 1000.0
+            fan_in = p.shape[-1] if p.dim() > 1 else p.shape[0]
+            v = v * (scale / np.sqrt(float(fan_in)))
+            # always float32-representable, so float64 copies of a model carry the SAME weights
+            v = v.astype(np.float32)
+            p.copy_(torch.from_numpy(v.reshape(tuple(p.shape))).to(dtype=p.dtype))
+    return module
+
+
+def synth(seed, *shape, scale=1.0, uniform=False, dtype=np.float32):
+    """Closed-form synthetic array (exact integer arithmetic -> bit-identical everywhere, no RNG):
+    ``uniform`` -> values in (0,1) on a 20011-level grid; otherwise zero-mean values with standard
+    deviation ``scale`` (a rescaled uniform).  Used for fixture inputs so that golden files only
+    have to store OUTPUTS."""
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.int64)
+    h = (int(seed) * 1000003 + idx * 7919 + (idx // 97) * 104729 + (idx // 8191) * 31337) % 20011
+    u = (h.astype(np.float64) + 0.5) / 20011.0
+    v = u if uniform else (u - 0.5) * (scale * 3.4641016151377544)
+    return v.reshape(shape).astype(dtype)
+
+
+def is_list_or_tuple(x):
+    return isinstance(x, (list, tuple))
+
+
+def pack_tensor_in_tuple(seq):
+    """bgflow/utils/types.py:46-53"""
+    if isinstance(seq, torch.Tensor):
+        return (seq,)
+    elif isinstance(seq, Iterable):
+        return (*seq,)
+    return seq
+
+
+def unpack_tensor_tuple(seq):
+    """bgflow/utils/types.py:35-43"""
+    if isinstance(seq, torch.Tensor):
+        return seq
+    if len(seq) == 1:
+        return seq[0]
+    return (*seq,)

@@ -1,0 +1,162 @@
+/* bgflow_amd.h -- C ABI of libbgflow_amd.so: MI355X (gfx950) kernels for the bgflow coupling-flow
+ * hot path.  Plain pointers and sizes only (no torch types); every pointer is a DEVICE pointer
+ * unless stated otherwise; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * No entry point allocates, synchronises or mutates its inputs.  Return value: 0 on success,
+ * otherwise a hipError_t code (launch failure) or a negative BGK_E* code (bad arguments); the
+ * message is available from bgk_last_error().
+ *
+ * bgflow itself has no FFI: its "operator interface" for this path is the Python Flow /
+ * Transformer protocol.  Each entry point below replaces the aten-op chain of ONE reference
+ * method (file:line relative to /root/reference/bgflow/); bgflow_amd/ (python) binds them with ctypes
+ * behind classes that keep the reference's names and signatures.
+ *
+ * Layout conventions: 2-d operands are row-major with an explicit row stride in ELEMENTS
+ * (ld*), unit column stride; `dlogp` vectors are [B] contiguous (the [B,1] tensors of bgflow).
+ * `accumulate` != 0 adds the layer's log|det J| to dlogp (SequentialFlow's `dlogp += ddlogp`,
+ * nn/flow/sequential.py:58) instead of overwriting it.
+ */
+#ifndef BGFLOW_AMD_H
+#define BGFLOW_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGK_EINVAL (-1)      /* bad argument (shape / unsupported size)          */
+#define BGK_EUNSUPPORTED (-2) /* valid request the kernels do not cover (yet)    */
+
+/* library identification / diagnostics */
+int bgk_abi_version(void);
+const char* bgk_last_error(void);            /* thread-local, host string */
+
+/* Deterministic-math probe: out[i] = f(x[i]) on the device with the same primitives the spline
+ * kernels use (which: 0 exp, 1 log, 2 softplus(beta=ln2/(1-1e-3)), 3 silu, 4 tanh).  Test hook. */
+int bgk_detmath_probe(const float* x, int64_t n, int32_t which, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rational-quadratic spline transformer, conditioner output given.
+ * Replaces ConditionalSplineTransformer._compute_params (reshape/cat/index_put,
+ * nn/flow/transformer/spline.py:109-126) + nflows rational_quadratic_spline (spline.py:133-144,
+ * 164-175) + the clamp-and-retry on InputOutsideDomain (spline.py:145-155) + sum(-1)
+ * (spline.py:157,188).
+ *   y       [B, d]   inputs in [left, right]           (ldy)
+ *   params  [B, P]   P = 3*K*d + n_nc, packed [w: d*K | h: d*K | s: d*K | s_nc: n_nc]   (ldp >= P)
+ *   nc_slot [d]      int32: index of dim j's extra slope inside the s_nc block, -1 if circular
+ *   inverse          0 = bgflow _forward (nflows inverse=True, root solve), 1 = bgflow _inverse
+ *   out     [B, d]   (ldo);  dlogp [B];  bin_idx [B, d] int32 or NULL (parity output)
+ *   oob_count        int32[1] or NULL: += number of inputs that were outside [left,right]
+ *                    (they are clamped exactly as the reference does; the caller raises the
+ *                    UserWarning lazily)
+ * --------------------------------------------------------------------------------------------- */
+int bgk_rqs_transform(const float* y, int64_t ldy, const float* params, int64_t ldp, int32_t P,
+                      const int32_t* nc_slot, int64_t B, int32_t d, int32_t K, int32_t inverse,
+                      double left, double right, double bottom, double top,
+                      double min_bin_width, double min_bin_height, double min_derivative,
+                      int32_t identity_init,
+                      float* out, int64_t ldo, float* dlogp, int32_t accumulate,
+                      int32_t* bin_idx, int32_t* oob_count, void* stream);
+
+/* Backward of bgk_rqs_transform for first-order losses (KL / NLL):
+ *   given g_out [B,d] (ldgo) and g_dlogp [B], produces g_y [B,d] (ldgy) and g_params [B,P] (ldgp).
+ * Replaces torch autograd through the op chain above. */
+int bgk_rqs_backward(const float* y, int64_t ldy, const float* params, int64_t ldp, int32_t P,
+                     const int32_t* nc_slot, int64_t B, int32_t d, int32_t K, int32_t inverse,
+                     double left, double right, double bottom, double top,
+                     double min_bin_width, double min_bin_height, double min_derivative,
+                     int32_t identity_init,
+                     const float* g_out, int64_t ldgo, const float* g_dlogp,
+                     float* g_y, int64_t ldgy, float* g_params, int64_t ldgp, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Affine (RealNVP / NICE) transformer, conditioner outputs given.
+ * Replaces AffineTransformer._get_mu_and_log_sigma's elementwise tail + _forward/_inverse
+ * (nn/flow/transformer/affine.py:41-45, 50-70): log_sigma = tanh(s_raw)*exp(log_alpha)
+ * [- mean], y' = exp(+-log_sigma)*(...), dlogp = +-sum log_sigma, optional `% 1.0`.
+ *   mu / s_raw may be NULL (no shift / no scale network); log_alpha is a DEVICE scalar
+ *   (the learnable parameter, affine.py:31).
+ * --------------------------------------------------------------------------------------------- */
+int bgk_affine_transform(const float* y, int64_t ldy, const float* mu, int64_t ldmu,
+                         const float* s_raw, int64_t lds, const float* log_alpha,
+                         int32_t preserve_volume, int32_t is_circular, int32_t inverse,
+                         int64_t B, int32_t d, float* out, int64_t ldo,
+                         float* dlogp, int32_t accumulate, void* stream);
+
+/* backward: g_y, g_mu, g_s_raw [B,d] (any may be NULL), g_log_alpha float[1] (+=, may be NULL) */
+int bgk_affine_backward(const float* y, int64_t ldy, const float* mu, int64_t ldmu,
+                        const float* s_raw, int64_t lds, const float* log_alpha,
+                        int32_t preserve_volume, int32_t is_circular, int32_t inverse,
+                        int64_t B, int32_t d,
+                        const float* g_out, int64_t ldgo, const float* g_dlogp,
+                        float* g_y, int64_t ldgy, float* g_mu, int64_t ldgmu,
+                        float* g_s, int64_t ldgs, float* g_log_alpha, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Internal coordinates (Z-matrix <-> Cartesian), relative to fixed atoms, optional PCA
+ * whitening of the fixed block.
+ * bgk_ic_xyz2ic replaces RelativeInternalCoordinateTransformation._forward
+ *   (nn/flow/crd_transform/ic.py:386-433; dist/angle/torsion_deriv ic_helper.py:148-293) and, with
+ *   Twhiten != NULL, MixedCoordinateTransformation._forward (ic.py:838-860, pca.py:74-83).
+ * bgk_ic_ic2xyz replaces RelativeInternalCoordinateTransformation._inverse
+ *   (ic.py:435-513; ic2xyz_deriv ic_helper.py:372-452) and, with Tblacken != NULL,
+ *   MixedCoordinateTransformation._inverse (ic.py:862-884, pca.py:85-93).
+ *   x        [B, 3*n_atoms] (ldx)
+ *   zmat     [n, 4] int32 rows (a, b, c, d)                        (xyz2ic)
+ *   place    [n, 5] int32 rows (atom, p1, p2, p3, zrow) in placement order (ic2xyz)
+ *   fixed    [n_fixed] int32 atom ids
+ *   bonds/angles/torsions [B, n] (ld 'ldic'), xfix [B, keep] (ldf) with keep = 3*n_fixed when
+ *   no whitening;  wh_mean [3*n_fixed], Twhiten [3*n_fixed, keep], Tblacken [keep, 3*n_fixed]
+ *   warn_count int32[1] or NULL: += number of eps-clamps that fired (reference: warnings.warn)
+ * --------------------------------------------------------------------------------------------- */
+int bgk_ic_xyz2ic(const float* x, int64_t ldx, const int32_t* zmat, int32_t n,
+                  const int32_t* fixed, int32_t n_fixed, int32_t normalize_angles, float eps,
+                  int32_t enforce_boundaries,
+                  const float* wh_mean, const float* Twhiten, int32_t keep, float jac_xz,
+                  int64_t B, float* bonds, float* angles, float* torsions, int64_t ldic,
+                  float* xfix, int64_t ldf, float* dlogp, int32_t accumulate,
+                  int32_t* warn_count, void* stream);
+
+int bgk_ic_ic2xyz(const float* bonds, const float* angles, const float* torsions, int64_t ldic,
+                  const float* xfix, int64_t ldf, const int32_t* place, int32_t n,
+                  const int32_t* fixed, int32_t n_fixed, int32_t normalize_angles, float eps,
+                  int32_t enforce_boundaries,
+                  const float* wh_mean, const float* Tblacken, int32_t keep, float jac_xz,
+                  int64_t B, float* x, int64_t ldx, float* dlogp, int32_t accumulate,
+                  int32_t* warn_count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused spline coupling layer with a DenseNet conditioner (fast path of
+ * CouplingFlow(ConditionalSplineTransformer(DenseNet | WrapPeriodic(DenseNet)))).
+ * One launch replaces CouplingFlow._forward/_inverse (nn/flow/coupling.py:162-182) including the
+ * conditioner MLP (nn/dense.py:47-48: Linear+act, Linear+act, Linear), the optional cos/sin
+ * featuriser (nn/periodic.py:30-37) and everything bgk_rqs_transform does.  The three GEMMs run
+ * on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ascending fma chain, bias added
+ * last) and the spline parameters never leave the CU.
+ *   cond  [B, d_c] (ldc): conditioner input; if `periodic` != 0 it is expanded to
+ *         [cos(2 pi c), sin(2 pi c)] (all conditioner inputs circular) before layer 0
+ *   W0t [n_in, H0], b0 [H0], W1t [H0, H1], b1 [H1]: TRANSPOSED torch Linear weights
+ *   W2p [H1, NCp], b2p [NCp]: last layer, transposed AND column-packed by bgk_pack_rqs_columns
+ *         (per transformed dim j the 3K+1 columns w_j[0..K) h_j[0..K) s_j[0..K) s_nc_j)
+ *   act: 1 SiLU (builder default), 2 ReLU, 3 Tanh
+ * --------------------------------------------------------------------------------------------- */
+int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                           const float* W0t, const float* b0, const float* W1t, const float* b1,
+                           const float* W2p, const float* b2p, int32_t H0, int32_t H1, int32_t act,
+                           const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
+                           int32_t inverse,
+                           double left, double right, double bottom, double top,
+                           double min_bin_width, double min_bin_height, double min_derivative,
+                           int32_t identity_init,
+                           float* out, int64_t ldo, float* dlogp, int32_t accumulate,
+                           int32_t* bin_idx, int32_t* oob_count, void* stream);
+
+/* number of packed columns NCp for (d, K) and the source column (in the reference's params
+ * layout, P = 3*K*d + n_nc) of every packed column, -1 for padding.  HOST function:
+ * src_col is a host int32[NCp] buffer (pass NULL to query NCp only). */
+int32_t bgk_pack_rqs_columns(int32_t d, int32_t K, const int32_t* nc_slot_host, int32_t* src_col);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGFLOW_AMD_H */

@@ -1,0 +1,468 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/*.npz by IMPORTING the reference.
+
+Run in the build container only (needs /root/reference; never on the GPU box):
+
+    python tests/golden/make_goldens.py
+
+What runs: the UNMODIFIED reference classes (bgflow.ConditionalSplineTransformer, AffineTransformer,
+CouplingFlow, SequentialFlow, the internal-coordinate transforms, BoltzmannGeneratorBuilder, ...)
+on the PyTorch-CPU path.  Two shims, neither touching the reference tree:
+  * ``numpy.infty = numpy.inf`` (removed in numpy 2; used at import by distribution/normal.py:126);
+  * the third-party ``nflows`` package (absent here) is replaced by tests/golden/nflows_stub.py, a
+    restatement of its public rational-quadratic-spline algorithm.  Its evaluate/search core is
+    cross-checked below against the reference's own in-tree copy bgflow/nn/flow/spline.py.
+
+All network weights come from bgflow_amd.utils.hash_init_ (closed-form, name-keyed), so the tests can
+rebuild identical networks without weight files.  The fixtures hold DATA only: inputs, expected
+outputs, and the Z-matrix / geometry tables that the reference's own test-suite embeds
+(tests/nn/flow/crd_transform/test_ic.py:37-118).
+"""
+import os
+import sys
+import warnings
+
+import numpy
+
+numpy.infty = numpy.inf  # numpy-2 shim, see module docstring
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, "/root/reference/tests")
+
+import nflows_stub  # noqa: E402
+
+nflows_stub.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bgflow as bg  # noqa: E402
+from bgflow.factory.generator_builder import BoltzmannGeneratorBuilder  # noqa: E402
+from bgflow.factory.tensor_info import ShapeDictionary, BONDS, ANGLES, TORSIONS, FIXED, AUGMENTED  # noqa: E402
+import importlib  # noqa: E402
+intree_spline = importlib.import_module("bgflow.nn.flow.spline")  # dead code in the reference; oracle evidence
+from bgflow_amd.utils import hash_init_, synth  # noqa: E402
+
+warnings.filterwarnings("ignore")
+torch.set_num_threads(4)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+class FixedNet(torch.nn.Module):
+    """Conditioner that returns a fixed tensor (so the spline parameters ARE the fixture input)."""
+
+    def __init__(self, out):
+        super().__init__()
+        self.out = out
+
+    def forward(self, x):
+        return self.out
+
+
+def rng_f32(seed, *shape, scale=1.0, uniform=False):
+    """fixture INPUTS are closed-form (bgflow_amd.utils.synth): tests regenerate them, files store outputs"""
+    return synth(seed, *shape, scale=scale, uniform=uniform)
+
+
+# ---------------------------------------------------------------------------------------------
+# G-rqs-unit
+# ---------------------------------------------------------------------------------------------
+def run_spline(params, y, circ, inverse, dtype):
+    p = torch.tensor(params, dtype=dtype)
+    yy = torch.tensor(y, dtype=dtype)
+    tr = bg.ConditionalSplineTransformer(FixedNet(p), is_circular=circ)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        z, dl = tr(torch.zeros(len(y), 1, dtype=dtype), yy, inverse=inverse)
+        warned = any("InputOutsideDomain" in str(x.message) for x in w)
+    last = {k: v.numpy().copy() for k, v in nflows_stub.LAST.items()}
+    return z.numpy(), dl.numpy(), last, warned
+
+
+def intree_check(params, y, circ_mask, inverse, last):
+    """Feed the knots/derivatives the stub produced to the reference's in-tree rq_spline
+    (bgflow/nn/flow/spline.py:60-180, offsets set to 0) and require bitwise agreement in fp64
+    of the evaluate / root-solve / log-det core."""
+    yy = torch.tensor(y, dtype=torch.float64)
+    outs, lads = [], []
+    cw = torch.tensor(last["cumwidths"]).clone()
+    ch = torch.tensor(last["cumheights"]).clone()
+    # undo the in-place eps (the in-tree searchsorted adds its own)
+    (ch if not inverse else cw)[..., -1] -= 1e-6
+    der = torch.tensor(last["derivatives"])
+    # rq_spline wants per-distribution (not per-sample) knots: loop samples (small fixture)
+    for b in range(min(len(y), 32)):
+        o, l = intree_spline.rq_spline(
+            yy[b], cw[b].clone(), ch[b].clone(), der[b].clone(), inverse=not inverse,
+            min_bin_width=0.0, min_bin_height=0.0, min_derivative=0.0)
+        outs.append(o.numpy()); lads.append(l.numpy())
+    return np.stack(outs), np.stack(lads)
+
+
+def g_rqs_unit():
+    K = 8
+    cases = {}
+    intree_err = [0.0, 0.0]
+    for name, d, circ in [
+        ("nc17", 17, np.zeros(17, bool)),
+        ("c17", 17, np.ones(17, bool)),
+        ("nc9", 9, np.zeros(9, bool)),
+        ("mix6", 6, np.array([1, 0, 1, 1, 0, 0], bool)),  # #circ == #noncirc: the only mixed case the reference supports
+    ]:
+        n_nc = int((~circ).sum())
+        P = 3 * K * d + n_nc
+        B = 128
+        params = rng_f32(100 + d + int(circ.sum()), B, P, scale=0.5)
+        y = rng_f32(200 + d, B, d, uniform=True)
+        circ_arg = bool(circ[0]) if circ.all() or (~circ).all() else torch.tensor(circ)
+        cases[f"{name}_circ"] = circ   # inputs: synth(100+d+n_circ, B, P, scale=.5), synth(200+d, B, d, uniform=True)
+        for inverse in (False, True):
+            tag = f"{name}_{'inv' if inverse else 'fwd'}"
+            z32, dl32, last32, _ = run_spline(params, y, circ_arg, inverse, torch.float32)
+            z64, dl64, last64, _ = run_spline(params, y, circ_arg, inverse, torch.float64)
+            o_it, lad_it = intree_check(params, y, circ, inverse, last64)
+            sign = -1.0 if not inverse else 1.0
+            # in-tree copy returns per-element logdet with the same sign convention as nflows
+            # (the in-tree copy re-derives the knots from cumsum(diff(knots)), so agreement is to a few
+            #  fp64 ulps rather than bitwise)
+            intree_err[0] = max(intree_err[0], np.abs(o_it - z64[: len(o_it)]).max())
+            lad_sum = lad_it.sum(-1, keepdims=True)
+            intree_err[1] = max(intree_err[1], np.abs(lad_sum - dl64[: len(o_it)]).max())
+            assert intree_err[0] < 1e-13 and intree_err[1] < 1e-11, f"in-tree rq_spline mismatch ({tag}): {intree_err}"
+            cases[f"{tag}_z32"] = z32
+            cases[f"{tag}_dlogp32"] = dl32
+            cases[f"{tag}_z64"] = z64
+            cases[f"{tag}_dlogp64"] = dl64
+            cases[f"{tag}_idx32"] = last32["bin_idx"].astype(np.int32)
+            cases[f"{tag}_idx64"] = last64["bin_idx"].astype(np.int32)
+    print(f"  in-tree bgflow/nn/flow/spline.py cross-check (fp64): max|dy| {intree_err[0]:.2e}, max|dlogdet| {intree_err[1]:.2e}")
+
+    # ---- edge vectors (non-circular, d=4): domain ends, exact knots, +-1ulp, clamp path, saturation ----
+    d = 4
+    P = 3 * K * d + d
+    base = rng_f32(7, 1, P, scale=0.7)
+    _, _, last, _ = run_spline(np.repeat(base, 1, 0), np.full((1, d), 0.5, np.float32), False, False, torch.float32)
+    kh = last["cumheights"][0].copy()   # [d, K+1] (fwd searches cumheights); last one carries +1e-6
+    _, _, last, _ = run_spline(np.repeat(base, 1, 0), np.full((1, d), 0.5, np.float32), False, True, torch.float32)
+    kw = last["cumwidths"][0].copy()
+    rows_f, rows_i = [], []
+    for k in range(K + 1):
+        for off in (-1, 0, 1):
+            vf = kh[:, k].copy(); vi = kw[:, k].copy()
+            if off:
+                vf = np.nextafter(vf, np.float32(2.0 * off)).astype(np.float32)
+                vi = np.nextafter(vi, np.float32(2.0 * off)).astype(np.float32)
+            rows_f.append(np.clip(vf, 0, 1)); rows_i.append(np.clip(vi, 0, 1))
+    for v in (0.0, 1.0, 1e-9, 1 - 1e-7, 0.5):
+        rows_f.append(np.full(d, v, np.float32)); rows_i.append(np.full(d, v, np.float32))
+    yf = np.stack(rows_f).astype(np.float32); yi = np.stack(rows_i).astype(np.float32)
+    pf = np.repeat(base, len(yf), 0)
+    for tag, yy, inverse in (("edge_fwd", yf, False), ("edge_inv", yi, True)):
+        z32, dl32, last32, _ = run_spline(pf, yy, False, inverse, torch.float32)
+        z64, dl64, last64, _ = run_spline(pf, yy, False, inverse, torch.float64)
+        cases[f"{tag}_y"] = yy
+        cases[f"{tag}_z32"] = z32; cases[f"{tag}_dlogp32"] = dl32
+        cases[f"{tag}_z64"] = z64; cases[f"{tag}_dlogp64"] = dl64
+        cases[f"{tag}_idx32"] = last32["bin_idx"].astype(np.int32)
+        cases[f"{tag}_knots32"] = (last32["cumwidths"] if inverse else last32["cumheights"])
+    # out-of-domain (clamp + warning path, spline.py:145-155)
+    yo = rng_f32(11, 16, d, uniform=True)
+    yo[0, 0] = -0.25; yo[3, 2] = 1.5; yo[7, 1] = 1.0000001
+    po = rng_f32(12, 16, P, scale=0.5)
+    for tag, inverse in (("oob_fwd", False), ("oob_inv", True)):
+        z32, dl32, last32, warned = run_spline(po, yo, False, inverse, torch.float32)
+        assert warned
+        cases[f"{tag}_z32"] = z32; cases[f"{tag}_dlogp32"] = dl32
+        cases[f"{tag}_idx32"] = last32["bin_idx"].astype(np.int32)
+    cases["oob_y"] = yo   # params: synth(12, 16, P, scale=.5)
+    # zero parameters = identity (enable_identity_init), and saturated parameters
+    yz = rng_f32(13, 32, d, uniform=True)
+    pz = np.zeros((32, P), np.float32)
+    z32, dl32, _, _ = run_spline(pz, yz, False, False, torch.float32)
+    cases["zero_z32"] = z32; cases["zero_dlogp32"] = dl32   # y: synth(13, 32, d, uniform=True)
+    ps = rng_f32(14, 32, P, scale=12.0)   # softmax saturation / softplus threshold (beta*s > 20)
+    for tag, inverse in (("sat_fwd", False), ("sat_inv", True)):
+        z32, dl32, last32, _ = run_spline(ps, yz, False, inverse, torch.float32)
+        z64, dl64, last64, _ = run_spline(ps, yz, False, inverse, torch.float64)
+        cases[f"{tag}_z32"] = z32; cases[f"{tag}_dlogp32"] = dl32
+        cases[f"{tag}_z64"] = z64; cases[f"{tag}_dlogp64"] = dl64
+        cases[f"{tag}_idx32"] = last32["bin_idx"].astype(np.int32)
+        cases[f"{tag}_idx64"] = last64["bin_idx"].astype(np.int32)
+    save("g_rqs_unit", **cases)
+
+
+# ---------------------------------------------------------------------------------------------
+# G-affine (unit + README flow + cfg-2 flow)
+# ---------------------------------------------------------------------------------------------
+def g_affine():
+    out = {}
+    B, d = 128, 32
+    y = rng_f32(21, B, d)
+    mu = rng_f32(22, B, d)
+    s = rng_f32(23, B, d, scale=2.0)
+    x = torch.zeros(B, 1)
+    for tag, kw in [("plain", {}), ("vp", dict(preserve_volume=True))]:
+        tr = bg.AffineTransformer(FixedNet(torch.tensor(mu)), FixedNet(torch.tensor(s)), **kw)
+        for inverse in (False, True):
+            for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+                tr2 = bg.AffineTransformer(FixedNet(torch.tensor(mu, dtype=dt)), FixedNet(torch.tensor(s, dtype=dt)), **kw)
+                z, dl = tr2(x.to(dt), torch.tensor(y, dtype=dt), inverse=inverse)
+                out[f"{tag}_{'inv' if inverse else 'fwd'}_z{sfx}"] = z.detach().numpy()
+                out[f"{tag}_{'inv' if inverse else 'fwd'}_dlogp{sfx}"] = dl.detach().numpy()
+    # shift-only circular (NICE on a circle)
+    yc = rng_f32(24, B, d, uniform=True)
+    tr = bg.AffineTransformer(FixedNet(torch.tensor(mu)), None, is_circular=True)
+    for inverse in (False, True):
+        z, dl = tr(x, torch.tensor(yc), inverse=inverse)
+        out[f"circ_{'inv' if inverse else 'fwd'}_z32"] = z.numpy()
+        out[f"circ_{'inv' if inverse else 'fwd'}_dlogp32"] = dl.numpy()
+    out.update(log_alpha=np.float32(-1.0))  # inputs: synth(21..24)
+    save("g_affine_unit", **out)
+
+    # README flow (cfg 1), README.md:54-96
+    dim = 2
+    prior = bg.NormalDistribution(dim)
+    target = bg.DoubleWellEnergy(dim)
+    layers = [bg.SplitFlow(dim // 2),
+              bg.CouplingFlow(bg.AffineTransformer(
+                  shift_transformation=bg.DenseNet([dim // 2, 4, dim // 2], activation=torch.nn.ReLU()),
+                  scale_transformation=bg.DenseNet([dim // 2, 4, dim // 2], activation=torch.nn.Tanh()))),
+              bg.InverseFlow(bg.SplitFlow(dim // 2))]
+    flow = bg.SequentialFlow(layers)
+    hash_init_(flow)
+    gen = bg.BoltzmannGenerator(prior, flow, target)
+    z = rng_f32(31, 64, dim)
+    with torch.no_grad():
+        x, dlogp = flow(torch.tensor(z))
+        zi, dlogp_inv = flow(x, inverse=True)
+        nll = gen.energy(x)
+        kl_terms = target.energy(x) - dlogp
+    save("g_readme", z=z, x=x.numpy(), dlogp=dlogp.numpy(), z_back=zi.numpy(), dlogp_inv=dlogp_inv.numpy(),
+         nll=nll.numpy(), kl_terms=kl_terms.numpy())
+
+    # cfg 2: dim 64, 8 x (affine coupling, swap)
+    dim = 64
+    layers = [bg.SplitFlow(dim // 2)]
+    for _ in range(8):
+        layers.append(bg.CouplingFlow(bg.AffineTransformer(
+            shift_transformation=bg.DenseNet([32, 64, 64, 32], activation=torch.nn.ReLU()),
+            scale_transformation=bg.DenseNet([32, 64, 64, 32], activation=torch.nn.Tanh()))))
+        layers.append(bg.SwapFlow())
+    layers.append(bg.MergeFlow(dim // 2))
+    flow = bg.SequentialFlow(layers)
+    hash_init_(flow)
+    z = rng_f32(32, 128, dim)
+    target = bg.DoubleWellEnergy(dim)
+    res = {}
+    for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+        f = flow.to(dt)
+        with torch.no_grad():
+            x, dlogp = f(torch.tensor(z, dtype=dt))
+            zb, dli = f(x, inverse=True)
+            res[f"x{sfx}"] = x.numpy(); res[f"dlogp{sfx}"] = dlogp.numpy()
+            res[f"z_back{sfx}"] = zb.numpy(); res[f"dlogp_inv{sfx}"] = dli.numpy()
+            res[f"kl_terms{sfx}"] = (target.energy(x) - dlogp).numpy()
+    save("g_affine8", z=z, **res)
+
+
+# ---------------------------------------------------------------------------------------------
+# G-ic
+# ---------------------------------------------------------------------------------------------
+def ala2_tables():
+    from nn.flow.crd_transform.test_ic import alanine_ics
+    zrel, zglob, rigid, xyz = alanine_ics.__wrapped__()
+    return zrel, zglob, rigid, xyz
+
+
+def whitening_data(xyz):
+    """1000 frames of the reference geometry + closed-form 0.01 nm noise (bgflow_amd.utils.synth)"""
+    return (xyz + 0.01 * synth(0, 1000, 66, scale=1.0, dtype=np.float64)).astype(np.float32)
+
+
+def g_ic():
+    zrel, zglob, rigid, xyz = ala2_tables()
+    data = whitening_data(xyz)
+    g = np.random.default_rng(5)
+    x = (xyz + 0.005 * g.standard_normal((128, 66))).astype(np.float32)
+    # 8 near-singular frames: collapse a bond / straighten an angle (clamp path of ic_helper)
+    xs = x[:8].copy().reshape(8, 22, 3)
+    xs[0, 0] = xs[0, 1] + 1e-9                       # bond ~ 0
+    xs[1, 2] = xs[1, 1] + (xs[1, 1] - xs[1, 4])       # angle 2-1-4 = pi
+    xs[2, 5] = xs[2, 4] + 0.3 * (xs[2, 6] - xs[2, 4])  # collinear 5-4-6
+    xs = xs.reshape(8, 66).astype(np.float32)
+    out = dict(z_matrix=zrel.astype(np.int32), global_z_matrix=zglob.astype(np.int32),
+               rigid_block=rigid.astype(np.int32), xyz0=xyz.astype(np.float64), x=x, x_singular=xs)
+    for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+        rel = bg.RelativeInternalCoordinateTransformation(zrel, rigid, raise_warnings=False)
+        mix = bg.MixedCoordinateTransformation(torch.tensor(data, dtype=dt), zrel, rigid, keepdims=9,
+                                               raise_warnings=False)
+        xt = torch.tensor(x, dtype=dt)
+        b, a, t, xf, dl = rel(xt)
+        xr, dlr = rel(b, a, t, xf, inverse=True)
+        out.update({f"rel_bonds{sfx}": b.numpy(), f"rel_angles{sfx}": a.numpy(), f"rel_torsions{sfx}": t.numpy(),
+                    f"rel_xfixed{sfx}": xf.numpy(), f"rel_dlogp{sfx}": dl.numpy(),
+                    f"rel_xback{sfx}": xr.numpy(), f"rel_dlogp_inv{sfx}": dlr.numpy()})
+        b, a, t, zf, dl = mix(xt)
+        xr, dlr = mix(b, a, t, zf, inverse=True)
+        out.update({f"mix_bonds{sfx}": b.numpy(), f"mix_angles{sfx}": a.numpy(), f"mix_torsions{sfx}": t.numpy(),
+                    f"mix_zfixed{sfx}": zf.numpy(), f"mix_dlogp{sfx}": dl.numpy(),
+                    f"mix_xback{sfx}": xr.numpy(), f"mix_dlogp_inv{sfx}": dlr.numpy()})
+        if sfx == "32":
+            out.update(wh_mean=mix._whiten.X0mean.numpy(), wh_Twhiten=mix._whiten.Twhiten.numpy(),
+                       wh_Tblacken=mix._whiten.Tblacken.numpy(), wh_std=mix._whiten.std.numpy())
+        else:
+            out.update(wh_mean64=mix._whiten.X0mean.numpy(), wh_Twhiten64=mix._whiten.Twhiten.numpy(),
+                       wh_Tblacken64=mix._whiten.Tblacken.numpy(), wh_std64=mix._whiten.std.numpy())
+        xst = torch.tensor(xs, dtype=dt)
+        b, a, t, xf, dl = rel(xst)
+        out.update({f"sing_bonds{sfx}": b.numpy(), f"sing_angles{sfx}": a.numpy(), f"sing_torsions{sfx}": t.numpy(),
+                    f"sing_dlogp{sfx}": dl.numpy()})
+    rel = bg.RelativeInternalCoordinateTransformation(zrel, rigid)
+    blocks, i2a, a2i, i2o = rel._z_blocks, rel._index2atom, rel._atom2index, rel._index2order
+    out.update(dec_block_sizes=np.array([len(bk) for bk in blocks], np.int32), dec_blocks=np.concatenate(blocks).astype(np.int32),
+               dec_index2atom=i2a.astype(np.int32), dec_atom2index=a2i.astype(np.int32), dec_index2order=i2o.astype(np.int32))
+    # IC -> xyz on ICs that do not come from a forward pass (flow-generated ICs): perturbed ICs
+    b32 = out["mix_bonds32"]; a32 = out["mix_angles32"]; t32 = out["mix_torsions32"]; z32 = out["mix_zfixed32"]
+    g = np.random.default_rng(6)
+    bp = (b32 * (1 + 0.05 * g.standard_normal(b32.shape))).astype(np.float32)
+    ap = np.clip(a32 + 0.02 * g.standard_normal(a32.shape), 0.05, 0.95).astype(np.float32)
+    tp = ((t32 + 0.1 * g.standard_normal(t32.shape)) % 1.0).astype(np.float32)
+    zp = (z32 + 0.3 * g.standard_normal(z32.shape)).astype(np.float32)
+    for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+        mix = bg.MixedCoordinateTransformation(torch.tensor(data, dtype=dt), zrel, rigid, keepdims=9, raise_warnings=False)
+        xg, dlg = mix(*(torch.tensor(v, dtype=dt) for v in (bp, ap, tp, zp)), inverse=True)
+        out.update({f"gen_x{sfx}": xg.numpy(), f"gen_dlogp{sfx}": dlg.numpy()})
+    out.update(gen_bonds=bp, gen_angles=ap, gen_torsions=tp, gen_zfixed=zp)
+    save("g_ic", **out)
+    # molecule definition used by bgflow_amd.configs (data only: topology tables + one geometry)
+    np.savez_compressed(os.path.join(REPO, "bgflow_amd", "data", "ala2_system.npz"),
+                        z_matrix=zrel.astype(np.int32), global_z_matrix=zglob.astype(np.int32),
+                        rigid_block=rigid.astype(np.int32), xyz=xyz.astype(np.float64))
+
+
+# ---------------------------------------------------------------------------------------------
+# G-flow16 (cfg 3) and G-aug (cfg 5)
+# ---------------------------------------------------------------------------------------------
+def build_cfg3(dtype=torch.float32):
+    zrel, zglob, rigid, xyz = ala2_tables()
+    data = torch.tensor(whitening_data(xyz), dtype=dtype)
+    ic = bg.MixedCoordinateTransformation(data, zrel, rigid, keepdims=9, raise_warnings=False)
+    shape_info = ShapeDictionary.from_coordinate_transform(ic)
+    target = bg.NormalDistribution(66, torch.tensor(xyz[0], dtype=dtype))
+    builder = BoltzmannGeneratorBuilder(shape_info, target=target, dtype=dtype)
+    for _ in range(4):
+        builder.add_condition(TORSIONS, on=FIXED)
+        builder.add_condition(FIXED, on=TORSIONS)
+    for _ in range(4):
+        builder.add_condition(BONDS, on=ANGLES)
+        builder.add_condition(ANGLES, on=BONDS)
+    builder.add_map_to_ic_domains()
+    builder.add_map_to_cartesian(ic)
+    gen = builder.build_generator()
+    hash_init_(gen.flow)
+    return gen
+
+
+def build_cfg5(dtype=torch.float32):
+    zrel, zglob, rigid, xyz = ala2_tables()
+    data = torch.tensor(whitening_data(xyz), dtype=dtype)
+    ic = bg.MixedCoordinateTransformation(data, zrel, rigid, keepdims=9, raise_warnings=False)
+    shape_info = ShapeDictionary.from_coordinate_transform(ic, dim_augmented=66)
+    target = bg.NormalDistribution(66, torch.tensor(xyz[0], dtype=dtype))
+    builder = BoltzmannGeneratorBuilder(shape_info, target=target, dtype=dtype)
+    builder.transformer_type[AUGMENTED] = bg.AffineTransformer
+    for _ in range(4):
+        builder.add_condition(TORSIONS, on=AUGMENTED)
+        builder.add_condition(AUGMENTED, on=TORSIONS)
+    for _ in range(2):
+        builder.add_condition(BONDS, on=ANGLES)
+        builder.add_condition(ANGLES, on=BONDS)
+    for _ in range(2):
+        builder.add_condition(FIXED, on=AUGMENTED)
+        builder.add_condition(AUGMENTED, on=(FIXED, BONDS, ANGLES))
+    builder.add_map_to_ic_domains()
+    builder.add_map_to_cartesian(ic)
+    gen = builder.build_generator()
+    hash_init_(gen.flow)
+    return gen
+
+
+def run_flow_recording(flow, zs, inverse=False):
+    """SequentialFlow.forward (sequential.py:49-59) with per-block outputs recorded."""
+    xs = tuple(zs)
+    dlogp = 0.0
+    per_block = []
+    blocks = list(flow._blocks)
+    if inverse:
+        blocks = blocks[::-1]
+    for block in blocks:
+        *xs, dd = block(*xs, inverse=inverse)
+        dlogp = dlogp + dd
+        per_block.append(torch.cat([*xs, dd], dim=-1).numpy())
+    return xs, dlogp, per_block
+
+
+def g_flow16():
+    B = 64
+    res = {}
+    u = [rng_f32(41 + i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9))]
+    for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+        gen = build_cfg3(dt)
+        with torch.no_grad():
+            zs = [torch.tensor(v, dtype=dt) for v in u]
+            xs, dlogp, per_block = run_flow_recording(gen.flow, zs)
+            x = xs[0]
+            res[f"x{sfx}"] = x.numpy(); res[f"dlogp{sfx}"] = dlogp.numpy()
+            for i, pb in enumerate(per_block):
+                if pb.shape[1] <= 61 and sfx == "32":  # IC-space blocks: cat of the 4 fields + ddlogp
+                    res[f"block{i:02d}_{sfx}"] = pb
+            zb, dli, _ = run_flow_recording(gen.flow, [x], inverse=True)
+            res[f"z_back{sfx}"] = torch.cat(list(zb), dim=-1).numpy(); res[f"dlogp_inv{sfx}"] = dli.numpy()
+            res[f"kl_terms{sfx}"] = (gen._target.energy(x) - dlogp).numpy()
+            res[f"nll{sfx}"] = gen.energy(x).numpy()
+        if sfx == "32":
+            res["n_params"] = np.int64(sum(p.numel() for p in gen.flow.parameters()))
+            res["n_blocks"] = np.int64(len(gen.flow))
+    save("g_flow16", u_bonds=u[0], u_angles=u[1], u_torsions=u[2], u_fixed=u[3], **res)
+
+
+def g_aug():
+    B = 64
+    res = {}
+    u = [rng_f32(51 + i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9, 66))]
+    for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+        gen = build_cfg5(dt)
+        with torch.no_grad():
+            zs = [torch.tensor(v, dtype=dt) for v in u]
+            xs, dlogp, _ = run_flow_recording(gen.flow, zs)
+            res[f"x{sfx}"] = xs[0].numpy(); res[f"aug{sfx}"] = xs[1].numpy(); res[f"dlogp{sfx}"] = dlogp.numpy()
+            zb, dli, _ = run_flow_recording(gen.flow, list(xs), inverse=True)
+            res[f"z_back{sfx}"] = torch.cat(list(zb), dim=-1).numpy(); res[f"dlogp_inv{sfx}"] = dli.numpy()
+        if sfx == "32":
+            res["n_params"] = np.int64(sum(p.numel() for p in gen.flow.parameters()))
+            res["n_blocks"] = np.int64(len(gen.flow))
+            res["block_types"] = np.array([type(b).__name__ + ":" + type(getattr(b, "transformer", b)).__name__ for b in gen.flow])
+    save("g_aug", u_bonds=u[0], u_angles=u[1], u_torsions=u[2], u_fixed=u[3], u_aug=u[4], **res)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rqs", "affine", "ic", "flow16", "aug"]
+    if "rqs" in which:
+        g_rqs_unit()
+    if "affine" in which:
+        g_affine()
+    if "ic" in which:
+        g_ic()
+    if "flow16" in which:
+        g_flow16()
+    if "aug" in which:
+        g_aug()

@@ -1,0 +1,232 @@
+"""CPU: pin the oracle (oracle/bgo_oracle.c) against golden vectors generated from the reference
+(tests/golden/make_goldens.py).  f64 flavour: agreement to double rounding.  f32 flavour: as close
+to the reference's f64 result as the reference's own f32 path is (both are f32 evaluations of the
+same formulas; their mutual distance is bounded by the f32 self-noise the fixtures record)."""
+import numpy as np
+import pytest
+
+from bgflow_amd.utils import synth
+
+K = 8
+UNIT_CASES = [("nc17", 17, np.zeros(17, bool)), ("c17", 17, np.ones(17, bool)), ("nc9", 9, np.zeros(9, bool)),
+              ("mix6", 6, np.array([1, 0, 1, 1, 0, 0], bool))]
+
+
+def unit_inputs(name, d, circ, B=128):
+    n_nc = int((~circ).sum())
+    P = 3 * K * d + n_nc
+    return synth(100 + d + int(circ.sum()), B, P, scale=0.5), synth(200 + d, B, d, uniform=True)
+
+
+@pytest.mark.parametrize("name,d,circ", UNIT_CASES)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_unit_f64(oracle, golden, name, d, circ, inverse):
+    G = golden("g_rqs_unit")
+    params, y = unit_inputs(name, d, circ)
+    tag = f"{name}_{'inv' if inverse else 'fwd'}"
+    z, dl, det = oracle.rqs(y, params, is_circular=circ, inverse=inverse, dtype=np.float64, want_details=True)
+    assert np.array_equal(det["bin_idx"], G[tag + "_idx64"])
+    np.testing.assert_allclose(z, G[tag + "_z64"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(dl, G[tag + "_dlogp64"], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,d,circ", UNIT_CASES)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_unit_f32(oracle, golden, name, d, circ, inverse):
+    G = golden("g_rqs_unit")
+    params, y = unit_inputs(name, d, circ)
+    tag = f"{name}_{'inv' if inverse else 'fwd'}"
+    z, dl, det = oracle.rqs(y, params, is_circular=circ, inverse=inverse, dtype=np.float32, want_details=True)
+    # bin indices identical to the reference's f32 path on the fixture set
+    assert np.array_equal(det["bin_idx"], G[tag + "_idx32"])
+    ref_noise_z = np.abs(G[tag + "_z32"] - G[tag + "_z64"]).max()
+    ref_noise_dl = np.abs(G[tag + "_dlogp32"] - G[tag + "_dlogp64"]).max()
+    assert np.abs(z - G[tag + "_z64"]).max() <= 3 * ref_noise_z + 2e-7
+    assert np.abs(dl - G[tag + "_dlogp64"]).max() <= 3 * ref_noise_dl + 1e-6
+    # north-star tolerance: log-det-J within 1e-5 relative (of the batch scale of |dlogp|) of the f32 reference
+    scale = np.sqrt((G[tag + "_dlogp32"] ** 2).mean())
+    assert np.abs(dl - G[tag + "_dlogp32"]).max() <= 1e-5 * scale + 1e-5
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_edges(oracle, golden, inverse):
+    """domain ends, exact knots and knots +-1 ulp: indices must agree with the reference except for
+    exact ties (|x - knot| <= 1 ulp of the oracle's own knot), which are reported."""
+    G = golden("g_rqs_unit")
+    tag = "edge_inv" if inverse else "edge_fwd"
+    d = 4
+    P = 3 * K * d + d
+    y = G[tag + "_y"]
+    params = np.repeat(synth(7, 1, P, scale=0.7), len(y), 0)
+    z, dl, det = oracle.rqs(y, params, inverse=inverse, dtype=np.float32, want_details=True)
+    mism = det["bin_idx"] != G[tag + "_idx32"]
+    if mism.any():
+        # every mismatch must be an ulp-tie between x and one of the oracle's knots
+        kn = det["knots"]
+        dist = np.abs(kn - y[..., None]).min(-1)
+        assert (dist[mism] <= 2.4e-7).all(), f"non-tie bin mismatches: {mism.sum()}"
+    ok = ~mism.any(-1)
+    np.testing.assert_allclose(z[ok], G[tag + "_z32"][ok], rtol=0, atol=5e-6)
+    assert mism.mean() < 0.25
+
+
+def test_rqs_out_of_domain_clamps(oracle, golden):
+    G = golden("g_rqs_unit")
+    d = 4
+    P = 3 * K * d + d
+    params = synth(12, 16, P, scale=0.5)
+    y = G["oob_y"]
+    for tag, inverse in (("oob_fwd", False), ("oob_inv", True)):
+        z, dl, det = oracle.rqs(y, params, inverse=inverse, dtype=np.float32, want_details=True)
+        assert det["n_oob"] == 3
+        assert np.array_equal(det["bin_idx"], G[tag + "_idx32"])
+        np.testing.assert_allclose(z, G[tag + "_z32"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(dl, G[tag + "_dlogp32"], rtol=1e-5, atol=2e-5)
+
+
+def test_rqs_zero_params_is_identity(oracle, golden):
+    G = golden("g_rqs_unit")
+    d = 4
+    y = synth(13, 32, d, uniform=True)
+    z, dl = oracle.rqs(y, np.zeros((32, 3 * K * d + d), np.float32), dtype=np.float32)
+    np.testing.assert_allclose(z, y, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(dl, 0, atol=2e-6)
+    np.testing.assert_allclose(z, G["zero_z32"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_saturated(oracle, golden, inverse):
+    G = golden("g_rqs_unit")
+    d = 4
+    P = 3 * K * d + d
+    y = synth(13, 32, d, uniform=True)
+    params = synth(14, 32, P, scale=12.0)
+    tag = "sat_inv" if inverse else "sat_fwd"
+    z, dl, det = oracle.rqs(y, params, inverse=inverse, dtype=np.float64, want_details=True)
+    assert np.array_equal(det["bin_idx"], G[tag + "_idx64"])
+    np.testing.assert_allclose(z, G[tag + "_z64"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(dl, G[tag + "_dlogp64"], rtol=1e-11, atol=1e-10)
+    z, dl, det = oracle.rqs(y, params, inverse=inverse, dtype=np.float32, want_details=True)
+    assert (det["bin_idx"] != G[tag + "_idx32"]).mean() < 0.02   # saturated softmax: knots collapse onto each other
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", {}), ("vp", dict(preserve_volume=True))])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_unit(oracle, golden, tag, kw, inverse):
+    G = golden("g_affine_unit")
+    y, mu, s = synth(21, 128, 32), synth(22, 128, 32), synth(23, 128, 32, scale=2.0)
+    key = f"{tag}_{'inv' if inverse else 'fwd'}_"
+    o, dl = oracle.affine(y, mu, s, log_alpha=-1.0, inverse=inverse, dtype=np.float64, **kw)
+    np.testing.assert_allclose(o, G[key + "z64"], rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(dl, G[key + "dlogp64"], rtol=1e-12, atol=1e-13)
+    o, dl = oracle.affine(y, mu, s, log_alpha=-1.0, inverse=inverse, dtype=np.float32, **kw)
+    np.testing.assert_allclose(o, G[key + "z32"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(dl, G[key + "dlogp32"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_circular(oracle, golden, inverse):
+    G = golden("g_affine_unit")
+    y, mu = synth(24, 128, 32, uniform=True), synth(22, 128, 32)
+    key = f"circ_{'inv' if inverse else 'fwd'}_"
+    o, dl = oracle.affine(y, mu, None, is_circular=True, inverse=inverse, dtype=np.float32)
+    assert np.array_equal(o, G[key + "z32"])
+    assert (o >= 0).all() and (o <= 1).all()
+    assert np.array_equal(dl, G[key + "dlogp32"])
+
+
+def test_decompose_z_matrix(oracle, golden):
+    G = golden("g_ic")
+    blocks, i2a, a2i, i2o, table = oracle.decompose_z_matrix(G["z_matrix"], G["rigid_block"])
+    assert [len(b) for b in blocks] == list(G["dec_block_sizes"])
+    assert np.array_equal(np.concatenate(blocks), G["dec_blocks"])
+    assert np.array_equal(i2a, G["dec_index2atom"])
+    assert np.array_equal(a2i, G["dec_atom2index"])
+    assert np.array_equal(i2o, G["dec_index2order"])
+
+
+@pytest.mark.parametrize("dtype,sfx,tol_ic,tol_dl", [(np.float64, "64", 1e-13, 1e-12), (np.float32, "32", 5e-7, 4e-5)])
+def test_ic_relative_and_mixed(oracle, golden, dtype, sfx, tol_ic, tol_dl):
+    G = golden("g_ic")
+    z, rigid, x = G["z_matrix"], G["rigid_block"], G["x"]
+    b, a, t, xf, dl = oracle.ic_xyz2ic(x, z, rigid, dtype=dtype)
+    for got, key in ((b, "rel_bonds"), (a, "rel_angles"), (t, "rel_torsions"), (xf, "rel_xfixed")):
+        np.testing.assert_allclose(got, G[key + sfx], rtol=0, atol=tol_ic)
+    np.testing.assert_allclose(dl, G["rel_dlogp" + sfx], rtol=0, atol=tol_dl)
+    xb, dli = oracle.ic_ic2xyz(G["rel_bonds" + sfx], G["rel_angles" + sfx], G["rel_torsions" + sfx],
+                               G["rel_xfixed" + sfx], z, rigid, dtype=dtype)
+    np.testing.assert_allclose(xb, G["rel_xback" + sfx], rtol=0, atol=4 * tol_ic)
+    np.testing.assert_allclose(dli, G["rel_dlogp_inv" + sfx], rtol=0, atol=tol_dl)
+    sf = "" if sfx == "32" else "64"
+    jac = -np.log(G["wh_std" + sf].astype(np.float64)).sum()
+    b, a, t, zf, dl = oracle.ic_xyz2ic(x, z, rigid, whiten=(G["wh_mean" + sf], G["wh_Twhiten" + sf], jac), dtype=dtype)
+    np.testing.assert_allclose(zf, G["mix_zfixed" + sfx], rtol=0, atol=8 * tol_ic)
+    np.testing.assert_allclose(dl, G["mix_dlogp" + sfx], rtol=0, atol=tol_dl)
+    xg, dlg = oracle.ic_ic2xyz(G["gen_bonds"], G["gen_angles"], G["gen_torsions"], G["gen_zfixed"], z, rigid,
+                               blacken=(G["wh_mean" + sf], G["wh_Tblacken" + sf], jac), dtype=dtype)
+    np.testing.assert_allclose(xg, G["gen_x" + sfx], rtol=0, atol=4 * tol_ic)
+    np.testing.assert_allclose(dlg, G["gen_dlogp" + sfx], rtol=0, atol=tol_dl)
+    # log-det within 1e-5 relative (|dlogp| ~ 20..60 here)
+    assert (np.abs(dlg - G["gen_dlogp" + sfx]) / np.abs(G["gen_dlogp" + sfx])).max() < 1e-5
+
+
+def test_ic_singular_geometry_is_clamped_like_the_reference(oracle, golden):
+    G = golden("g_ic")
+    b, a, t, xf, dl = oracle.ic_xyz2ic(G["x_singular"], G["z_matrix"], G["rigid_block"], dtype=np.float32)
+    np.testing.assert_allclose(b, G["sing_bonds32"], rtol=0, atol=1e-6)     # collapsed bond -> eps clamp
+    np.testing.assert_allclose(a, G["sing_angles32"], rtol=0, atol=1e-6)    # straight angle -> cos clamp
+    fin = np.isfinite(G["sing_dlogp32"]).ravel()
+    np.testing.assert_allclose(dl.ravel()[fin], G["sing_dlogp32"].ravel()[fin], rtol=2e-5, atol=2e-4)
+    assert not np.isfinite(dl.ravel()[~fin]).any() or (dl.ravel()[~fin] < -80).all()
+
+
+def test_readme_and_affine8_flows(golden):
+    """whole affine flows (cfg 1, cfg 2) through the oracle walker vs reference"""
+    import torch
+    from bgflow_amd import configs
+    from oracle import flow_oracle as fo
+    G = golden("g_readme")
+    gen = configs.make_readme_generator()
+    (x,), dl = fo.run_flow(gen.flow, [G["z"]], dtype=np.float32)
+    np.testing.assert_allclose(x, G["x"], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(dl, G["dlogp"], rtol=1e-5, atol=1e-6)
+    (zb,), dli = fo.run_flow(gen.flow, [G["x"]], inverse=True, dtype=np.float32)
+    np.testing.assert_allclose(zb, G["z_back"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(dli, G["dlogp_inv"], rtol=1e-5, atol=1e-6)
+    G = golden("g_affine8")
+    z = synth(32, 128, 64)
+    for tdt, dt, sfx, rt, at in ((torch.float64, np.float64, "64", 1e-11, 1e-12), (torch.float32, np.float32, "32", 1e-5, 3e-5)):
+        gen = configs.make_affine8_generator().to(tdt)
+        (x,), dl = fo.run_flow(gen.flow, [z], dtype=dt)
+        np.testing.assert_allclose(x, G["x" + sfx], rtol=rt * 10, atol=at)
+        np.testing.assert_allclose(dl, G["dlogp" + sfx], rtol=rt, atol=at)
+        (zb,), dli = fo.run_flow(gen.flow, [G["x" + sfx]], inverse=True, dtype=dt)
+        np.testing.assert_allclose(dli, G["dlogp_inv" + sfx], rtol=rt, atol=at)
+
+
+def test_flow16_whole_flow(golden):
+    """cfg 3: 16 spline couplings + domain maps + mixed IC, oracle walker vs the reference builder flow"""
+    import torch
+    from bgflow_amd import configs
+    from oracle import flow_oracle as fo
+    G = golden("g_flow16")
+    u = [G["u_bonds"], G["u_angles"], G["u_torsions"], G["u_fixed"]]
+    gen64 = configs.make_ala2_spline_generator(dtype=torch.float64).double()
+    assert sum(p.numel() for p in gen64.flow.parameters()) == int(G["n_params"]) and len(gen64.flow) == int(G["n_blocks"])
+    (x,), dl = fo.run_flow(gen64.flow, u, dtype=np.float64)
+    np.testing.assert_allclose(x, G["x64"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(dl, G["dlogp64"], rtol=1e-12, atol=1e-11)
+    zb, dli = fo.run_flow(gen64.flow, [G["x64"]], inverse=True, dtype=np.float64)
+    np.testing.assert_allclose(np.concatenate(zb, -1), G["z_back64"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(dli, G["dlogp_inv64"], rtol=1e-9, atol=1e-8)
+    # f32: per-block agreement with the reference's f32 path in IC space, and log-det-J within 1e-5
+    # relative of the f64 truth up to the reference's own f32 noise
+    gen32 = configs.make_ala2_spline_generator()
+    pb = []
+    (x,), dl = fo.run_flow(gen32.flow, u, dtype=np.float32, per_block=pb)
+    for i in range(16):
+        got = np.concatenate([*pb[i][0], pb[i][1]], axis=-1)
+        np.testing.assert_allclose(got, G[f"block{i:02d}_32"], rtol=0, atol=2e-5)
+    noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
+    assert np.abs(dl - G["dlogp64"]).max() <= 1e-5 * np.abs(G["dlogp64"]).max() + noise
+    assert (np.abs(dl - G["dlogp32"]) / np.abs(G["dlogp32"])).max() < 2e-5
