@@ -204,20 +204,32 @@ void FN(bgo_affine)(const REAL* y, int64_t ldy, const REAL* mu, int64_t ldmu,
 void FN(bgo_linear)(const REAL* x, int64_t ldx, const REAL* W, const REAL* bias,
                     int64_t B, int n_in, int n_out, int act, REAL* out, int64_t ldo)
 {
+    /* W^T [n_in][n_out] so that the inner loop runs over outputs: every output is still its own
+     * k-ascending fma chain (same bits as the textbook loop), but the loop vectorises. */
+    REAL* Wt = (REAL*)malloc(sizeof(REAL) * (size_t)n_in * (size_t)n_out);
+    for (int o = 0; o < n_out; ++o)
+        for (int k = 0; k < n_in; ++k) Wt[(size_t)k * n_out + o] = W[(size_t)o * n_in + k];
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) {
         const REAL* xr = x + b * ldx;
+        REAL* acc = out + b * ldo;
+        for (int o = 0; o < n_out; ++o) acc[o] = (REAL)0;
+        for (int k = 0; k < n_in; ++k) {
+            const REAL xk = xr[k];
+            const REAL* wr = Wt + (size_t)k * n_out;
+#pragma omp simd
+            for (int o = 0; o < n_out; ++o) acc[o] = R_FMA(xk, wr[o], acc[o]);
+        }
         for (int o = 0; o < n_out; ++o) {
-            const REAL* wr = W + (int64_t)o * n_in;
-            REAL acc = (REAL)0;
-            for (int k = 0; k < n_in; ++k) acc = R_FMA(xr[k], wr[k], acc);
-            if (bias) acc = acc + bias[o];
-            if (act == 1) acc = R_SILU(acc);
-            else if (act == 2) acc = acc > (REAL)0 ? acc : (REAL)0;
-            else if (act == 3) acc = R_TANH(acc);
-            out[b * ldo + o] = acc;
+            REAL v = acc[o];
+            if (bias) v = v + bias[o];
+            if (act == 1) v = R_SILU(v);
+            else if (act == 2) v = v > (REAL)0 ? v : (REAL)0;
+            else if (act == 3) v = R_TANH(v);
+            acc[o] = v;
         }
     }
+    free(Wt);
 }
 
 /* WrapPeriodic featuriser, nn/periodic.py:30-37 with all indices periodic on [0,1]:
