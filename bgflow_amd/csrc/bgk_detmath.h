@@ -122,4 +122,33 @@ BGK_FN float bgk_tanhf(float x) {
     return __builtin_fmaf(p, x, x);
 }
 
+/* cos(2 pi x), sin(2 pi x) for the WrapPeriodic featuriser (|x| < 2^20): exact quadrant reduction
+ * in units of 1/4 turn, then the Cephes sinf / cosf minimax polynomials on [-pi/4, pi/4]. */
+BGK_FN void bgk_sincos2pif(float x, float* s_out, float* c_out) {
+    const float magic = 12582912.0f;
+    float t = __builtin_fmaf(x, 4.0f, magic);
+    float kq = t - magic;                                   /* round-half-even(4x) */
+    int32_t q = (int32_t)(bgk_f2u(t) - 0x4B400000u) & 3;
+    float f = __builtin_fmaf(kq, -0.25f, x);                /* exact: x - kq/4 in [-1/8, 1/8] */
+    float th = f * 6.28318530717958647692f;
+    float z = th * th;
+    float sp = -1.9515295891e-4f;
+    sp = __builtin_fmaf(sp, z, 8.3321608736e-3f);
+    sp = __builtin_fmaf(sp, z, -1.6666654611e-1f);
+    sp = sp * z;
+    float sn = __builtin_fmaf(sp, th, th);
+    float cp = 2.443315711809948e-5f;
+    cp = __builtin_fmaf(cp, z, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
+    cp = cp * z;
+    cp = cp * z;
+    float cs = __builtin_fmaf(z, -0.5f, cp) + 1.0f;
+    float so, co;
+    if (q == 0) { so = sn; co = cs; }
+    else if (q == 1) { so = cs; co = -sn; }
+    else if (q == 2) { so = -sn; co = -cs; }
+    else { so = -cs; co = sn; }
+    *s_out = so; *c_out = co;
+}
+
 #endif /* BGK_DETMATH_H */

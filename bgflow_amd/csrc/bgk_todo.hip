@@ -18,13 +18,3 @@ extern "C" int bgk_affine_backward(const float*, int64_t, const float*, int64_t,
     return BGK_EUNSUPPORTED;
 }
 
-extern "C" int bgk_coupling_rqs_dense(const float*, int64_t, int32_t, int32_t, const float*, const float*,
-                                      const float*, const float*, const float*, const float*, int32_t, int32_t,
-                                      int32_t, const float*, int64_t, int64_t, int32_t, int32_t, int32_t, double,
-                                      double, double, double, double, double, double, int32_t, float*, int64_t,
-                                      float*, int32_t, int32_t*, int32_t*, void*) {
-    bgk_set_error("bgk_coupling_rqs_dense: not implemented yet");
-    return BGK_EUNSUPPORTED;
-}
-
-extern "C" int32_t bgk_pack_rqs_columns(int32_t, int32_t, const int32_t*, int32_t*) { return BGK_EUNSUPPORTED; }

@@ -88,7 +88,130 @@ def _fusable_dense(net):
     return (l0, l1, l2), _ACT_CODES[type(a0)]
 
 
-def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter):
-    """Try the one-launch coupling layer (bgk_coupling_rqs_dense).  Returns (y', dlogp) or None when
-    the conditioner is not a fusable DenseNet (the caller then runs conditioner + bgk_rqs_transform)."""
-    return None
+# ---- MFMA operand packing for bgk_coupling_rqs_dense ------------------------------------------------
+# One k-step of the f32 MFMA (v_mfma_f32_32x32x2_f32, A = weights) over 4 output tiles consumes, per
+# lane l (i = l & 31, h = l >> 5), the four values W[32*m + i][k(step, h)], m = 0..3: stored as one
+# float4 -> a packed layer is [steps + 1][64 lanes][4] floats; the extra last step carries the bias in
+# the lower half-wave (A = bias, B = 1.0) and zeros in the upper one.
+#   layer 0 (input from LDS, natural order):            k(t, h) = 2 t + h
+#   hidden layers (input = accumulator registers):      k(16 kb + r, h) = 32 kb + (r & 3) + 8 (r >> 2) + 4 h
+_LANE_I = torch.arange(64) & 31
+_LANE_H = torch.arange(64) >> 5
+
+
+def _pack_steps(W, bias, k_of_step):
+    """W [128, n_in] (rows = output features), k_of_step [S, 2] (k index for half-wave 0 / 1, -1 = none)"""
+    S = k_of_step.shape[0]
+    dev = W.device
+    rows = (32 * torch.arange(4, device=dev)[None, None, :] + _LANE_I.to(dev)[None, :, None]).expand(S, 64, 4)
+    kk = k_of_step.to(dev)[:, _LANE_H.to(dev)][:, :, None].expand(S, 64, 4)
+    vals = W[rows.reshape(-1), kk.clamp_min(0).reshape(-1)].reshape(S, 64, 4)
+    vals = torch.where(kk >= 0, vals, torch.zeros_like(vals))
+    bstep = torch.zeros(1, 64, 4, dtype=W.dtype, device=dev)
+    bstep[0, :32, :] = bias.reshape(4, 32).t()
+    return torch.cat([vals, bstep], dim=0).contiguous()
+
+
+def _k_natural(n_in):
+    T = (n_in + 1) // 2
+    k = torch.arange(2 * T).reshape(T, 2)
+    return torch.where(k < n_in, k, torch.full_like(k, -1))
+
+
+def _k_hidden():
+    s = torch.arange(64)
+    kb, r = s // 16, s % 16
+    k0 = 32 * kb + (r & 3) + 8 * (r >> 2)
+    return torch.stack([k0, k0 + 4], dim=1)
+
+
+def pack_dense_for_fused(linears, nc_slot_host, d, n_bins):
+    """Pack the three Linear layers of a DenseNet([n_in, 128, 128, P]) for bgk_coupling_rqs_dense.
+    Returns (W0p, W1p, W2p) float32 device tensors."""
+    l0, l1, l2 = linears
+    W0p = _pack_steps(l0.weight.detach().float(), l0.bias.detach().float(), _k_natural(l0.in_features))
+    W1p = _pack_steps(l1.weight.detach().float(), l1.bias.detach().float(), _k_hidden())
+    # last layer: rows (= reference params columns) regrouped per transformed dim by bgk_pack_rqs_columns
+    ncp = _lib.lib().bgk_pack_rqs_columns(d, n_bins, None, None)
+    src = np.empty(ncp, dtype=np.int32)
+    slots = np.ascontiguousarray(nc_slot_host, dtype=np.int32)
+    _lib.lib().bgk_pack_rqs_columns(d, n_bins, slots.ctypes.data, src.ctypes.data)
+    src_t = torch.as_tensor(src.astype(np.int64), device=l2.weight.device)
+    W2 = l2.weight.detach().float()
+    b2 = l2.bias.detach().float()
+    W2r = torch.where(src_t[:, None] >= 0, W2[src_t.clamp_min(0)], torch.zeros((), dtype=W2.dtype, device=W2.device))
+    b2r = torch.where(src_t >= 0, b2[src_t.clamp_min(0)], torch.zeros((), dtype=b2.dtype, device=b2.device))
+    chunks = [_pack_steps(W2r[c * 128:(c + 1) * 128], b2r[c * 128:(c + 1) * 128], _k_hidden()) for c in range(ncp // 128)]
+    return W0p, W1p, torch.cat(chunks, dim=0).contiguous()
+
+
+def _fused_plan(transformer, y_dim, nc_slot_host):
+    """Decide (and cache) whether the transformer's conditioner can run fused; pack its weights."""
+    net = transformer._params_net
+    periodic = False
+    if type(net) is WrapPeriodic:
+        if not (net.left == 0.0 and net.right == 1.0):
+            return None
+        inner = net.net
+        periodic = True
+    else:
+        inner = net
+    spec = _fusable_dense(inner)
+    if spec is None:
+        return None
+    (l0, l1, l2), act = spec
+    if l0.out_features != 128 or l1.out_features != 128 or y_dim > 64:
+        return None
+    n_nc = int((nc_slot_host >= 0).sum())
+    P = l2.out_features
+    n_bins = (P - n_nc) // (3 * y_dim)
+    if n_bins != 8 or 3 * n_bins * y_dim + n_nc != P:
+        return None
+    d_c = l0.in_features // 2 if periodic else l0.in_features
+    if periodic:
+        idx = np.arange(d_c)[net.indices] if not isinstance(net.indices, slice) or net.indices != slice(None) else np.arange(d_c)
+        if len(idx) != d_c or 2 * d_c != l0.in_features:
+            return None   # only "all conditioner inputs periodic" is fused
+    params = [p for lin in (l0, l1, l2) for p in (lin.weight, lin.bias)]
+    version = tuple((p.data_ptr(), p._version) for p in params)
+    cache = transformer._fused_cache
+    if cache.get("version") != version or cache.get("y_dim") != y_dim:
+        cache.clear()
+        cache.update(version=version, y_dim=y_dim, packed=pack_dense_for_fused((l0, l1, l2), nc_slot_host, y_dim, n_bins),
+                     act=act, periodic=periodic, d_c=d_c, n_bins=n_bins,
+                     circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
+    return cache
+
+
+def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter, want_bin_idx=False):
+    """Try the one-launch coupling layer (bgk_coupling_rqs_dense).  Returns (y', dlogp[, bin_idx]) or
+    None when the conditioner is not a fusable DenseNet (the caller then runs conditioner +
+    bgk_rqs_transform)."""
+    if x.dim() != 2 or y.dim() != 2 or not x.is_cuda:
+        return None
+    plan = _fused_plan(transformer, y.shape[-1], nc_slot_host)
+    if plan is None or x.shape[-1] != plan["d_c"]:
+        return None
+    _lib.require_hip(x, y)
+    W0p, W1p, W2p = plan["packed"]
+    if W0p.device != y.device:
+        return None
+    x2, ldc = _lib.rowmajor(x)
+    y2, ldy = _lib.rowmajor(y)
+    B, d = y2.shape
+    out = torch.empty((B, d), dtype=torch.float32, device=y.device)
+    dlogp = torch.empty((B,), dtype=torch.float32, device=y.device)
+    bins = torch.empty((B, d), dtype=torch.int32, device=y.device) if want_bin_idx else None
+    s = transformer._default_settings
+    with torch.cuda.device(y.device):
+        st = _lib.lib().bgk_coupling_rqs_dense(
+            _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p),
+            128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
+            transformer._left, transformer._right, transformer._bottom, transformer._top,
+            s["min_bin_width"], s["min_bin_height"], s["min_derivative"], int(s.get("enable_identity_init", False)),
+            _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.ptr(bins), _lib.ptr(oob_counter), _lib.stream_ptr(y.device))
+    if st == -2:
+        return None
+    _lib.check(st, "bgk_coupling_rqs_dense")
+    res = (out, dlogp[:, None])
+    return res + (bins,) if want_bin_idx else res

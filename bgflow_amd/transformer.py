@@ -236,6 +236,7 @@ class ConditionalSplineTransformer(Transformer):
         self._nc_cache = {}
         self._oob = {}
         self._fused_cache = {}
+        self.allow_fused = True           # set False to force conditioner + bgk_rqs_transform
         self.return_bin_indices = False   # parity hook: stash the bin indices of the last call
         self.last_bin_indices = None
 
@@ -281,10 +282,12 @@ class ConditionalSplineTransformer(Transformer):
         oob = self._oob_counter(y.device)
         grad = torch.is_grad_enabled() and (
             y.requires_grad or x.requires_grad or any(p.requires_grad for p in self._params_net.parameters()))
-        if not grad:
-            fused = fused_spline_coupling(self, x, y, nc_host, inverse, oob)
+        if not grad and self.allow_fused:
+            fused = fused_spline_coupling(self, x, y, nc_host, inverse, oob, want_bin_idx=self.return_bin_indices)
             if fused is not None:
-                return fused
+                if self.return_bin_indices:
+                    self.last_bin_indices = fused[2]
+                return fused[0], fused[1]
         params = self._params_net(x)
         n_nc = int((nc_host >= 0).sum())
         P = params.shape[-1]

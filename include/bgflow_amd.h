@@ -134,17 +134,21 @@ int bgk_ic_ic2xyz(const float* bonds, const float* angles, const float* torsions
  * on the f32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ascending fma chain, bias added
  * last) and the spline parameters never leave the CU.
  *   cond  [B, d_c] (ldc): conditioner input; if `periodic` != 0 it is expanded to
- *         [cos(2 pi c), sin(2 pi c)] (all conditioner inputs circular) before layer 0
- *   W0t [n_in, H0], b0 [H0], W1t [H0, H1], b1 [H1]: TRANSPOSED torch Linear weights
- *   W2p [H1, NCp], b2p [NCp]: last layer, transposed AND column-packed by bgk_pack_rqs_columns
- *         (per transformed dim j the 3K+1 columns w_j[0..K) h_j[0..K) s_j[0..K) s_nc_j)
+ *         [cos(2 pi c), sin(2 pi c)] (all conditioner inputs circular, [0,1]) before layer 0
+ *   W0p, W1p, W2p: the three Linear layers in the kernel's MFMA operand packing (built once per
+ *         weight update by bgflow_amd/dense.py::pack_dense_for_fused; layout documented there and in
+ *         DESIGN.md): per k-step one [64 lanes][4 tiles] float4 block, bias as the final k-step;
+ *         W2p column-packed per transformed dim in the order given by bgk_pack_rqs_columns.
+ *   circ_mask: bit j set = transformed dim j is circular (its slope at knot K is the slope at knot 0)
  *   act: 1 SiLU (builder default), 2 ReLU, 3 Tanh
+ * Returns BGK_EUNSUPPORTED for shapes outside the fused envelope (hidden != (128,128), n_bins != 8,
+ * d > 64): the caller then runs conditioner + bgk_rqs_transform.
  * --------------------------------------------------------------------------------------------- */
 int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
-                           const float* W0t, const float* b0, const float* W1t, const float* b1,
-                           const float* W2p, const float* b2p, int32_t H0, int32_t H1, int32_t act,
+                           const float* W0p, const float* W1p, const float* W2p,
+                           int32_t H0, int32_t H1, int32_t act,
                            const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
-                           int32_t inverse,
+                           uint64_t circ_mask, int32_t inverse,
                            double left, double right, double bottom, double top,
                            double min_bin_width, double min_bin_height, double min_derivative,
                            int32_t identity_init,

@@ -202,8 +202,13 @@ void FN(bgo_affine)(const REAL* y, int64_t ldy, const REAL* mu, int64_t ldmu,
  * is applied by the caller (bgo_wrap_periodic).
  * ------------------------------------------------------------------------------------------ */
 void FN(bgo_linear)(const REAL* x, int64_t ldx, const REAL* W, const REAL* bias,
-                    int64_t B, int n_in, int n_out, int act, REAL* out, int64_t ldo)
+                    int64_t B, int n_in, int n_out, int act, const int32_t* k_order,
+                    REAL* out, int64_t ldo)
 {
+    /* k_order (NULL = 0,1,2,...): the order in which the inputs enter each output's fma chain.  The
+     * fused HIP kernel keeps hidden activations in MFMA accumulator registers and feeds them back
+     * as the B operand without a shuffle, which visits the 32 features of a block in the order
+     * 0,4,1,5,2,6,3,7, 8,12,9,13,...; passing that permutation makes this function bit-identical. */
     /* W^T [n_in][n_out] so that the inner loop runs over outputs: every output is still its own
      * k-ascending fma chain (same bits as the textbook loop), but the loop vectorises. */
     REAL* Wt = (REAL*)malloc(sizeof(REAL) * (size_t)n_in * (size_t)n_out);
@@ -214,7 +219,8 @@ void FN(bgo_linear)(const REAL* x, int64_t ldx, const REAL* W, const REAL* bias,
         const REAL* xr = x + b * ldx;
         REAL* acc = out + b * ldo;
         for (int o = 0; o < n_out; ++o) acc[o] = (REAL)0;
-        for (int k = 0; k < n_in; ++k) {
+        for (int kk = 0; kk < n_in; ++kk) {
+            const int k = k_order ? k_order[kk] : kk;
             const REAL xk = xr[k];
             const REAL* wr = Wt + (size_t)k * n_out;
 #pragma omp simd
@@ -233,15 +239,17 @@ void FN(bgo_linear)(const REAL* x, int64_t ldx, const REAL* W, const REAL* bias,
 }
 
 /* WrapPeriodic featuriser, nn/periodic.py:30-37 with all indices periodic on [0,1]:
- * out = [cos(2 pi x), sin(2 pi x)]  ([B,2d]).  Uses libm sin/cos in both flavours. */
+ * out = [cos(2 pi x), sin(2 pi x)]  ([B,2d]).  f32 flavour: deterministic bgk_sincos2pif (what the
+ * fused HIP kernel evaluates); f64 flavour: libm. */
 void FN(bgo_wrap_periodic)(const REAL* x, int64_t ldx, int64_t B, int d, REAL* out, int64_t ldo)
 {
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b)
         for (int j = 0; j < d; ++j) {
-            REAL a = (REAL)(2.0 * 3.14159265358979323846) * x[b * ldx + j];
-            out[b * ldo + j] = R_COS(a);
-            out[b * ldo + d + j] = R_SIN(a);
+            REAL sv, cv;
+            R_SINCOS2PI(x[b * ldx + j], &sv, &cv);
+            out[b * ldo + j] = cv;
+            out[b * ldo + d + j] = sv;
         }
 }
 

@@ -17,6 +17,12 @@ import scipy.special as sps
 from . import oracle as orc
 
 
+# accumulation order of hidden DenseNet layers: False = k ascending (textbook), True = the order of the
+# fused HIP kernel (oracle.mfma_k_order).  Both are valid f32 evaluations of the same sums; the switch
+# only matters for BIT-exact comparisons with bgk_coupling_rqs_dense.
+MFMA_ORDER = False
+
+
 def _np(t, dtype):
     if hasattr(t, "detach"):
         t = t.detach().cpu().numpy()
@@ -43,7 +49,7 @@ def dense_spec(net, dtype):
 def conditioner(net, x, dtype):
     n = _name(net)
     if n == "DenseNet":
-        return orc.dense_net(x, *dense_spec(net, dtype), dtype=dtype)
+        return orc.dense_net(x, *dense_spec(net, dtype), dtype=dtype, mfma_order=MFMA_ORDER)
     if n == "WrapPeriodic":
         idx = np.arange(x.shape[-1])[net.indices]
         assert len(idx) == x.shape[-1] and net.left == 0.0 and net.right == 1.0, "oracle: all-periodic [0,1] only"

@@ -125,8 +125,21 @@ def affine(y, mu=None, s_raw=None, log_alpha=-1.0, preserve_volume=False, is_cir
 _ACT = {None: 0, "none": 0, "silu": 1, "relu": 2, "tanh": 3}
 
 
-def linear(x, W, b=None, act=None, dtype=np.float32):
-    """torch.nn.Linear (+activation): k-ascending fma chain, bias added last (nn/dense.py:30-48)."""
+def mfma_k_order(n):
+    """Accumulation order of the fused HIP kernel for a layer whose INPUT lives in MFMA accumulator
+    registers (32-feature blocks visited as 0,4,1,5,2,6,3,7,8,12,...); n must be a multiple of 32."""
+    assert n % 32 == 0
+    order = []
+    for kb in range(n // 32):
+        for r in range(16):
+            k0 = 32 * kb + (r & 3) + 8 * (r >> 2)
+            order += [k0, k0 + 4]
+    return np.asarray(order, dtype=np.int32)
+
+
+def linear(x, W, b=None, act=None, dtype=np.float32, k_order=None):
+    """torch.nn.Linear (+activation): one fma chain per output (k ascending unless ``k_order``), bias
+    added last (nn/dense.py:30-48)."""
     sfx, _ = _suffix(dtype)
     x = _np(x, dtype)
     W = _np(W, dtype)
@@ -135,17 +148,20 @@ def linear(x, W, b=None, act=None, dtype=np.float32):
     n_out = W.shape[0]
     assert W.shape[1] == n_in
     out = np.empty((B, n_out), dtype)
+    ko = None if k_order is None else _np(k_order, np.int32)
     fn = getattr(lib(), "bgo_linear" + sfx)
     fn(_ptr(x), _c_i64(n_in), _ptr(W), _ptr(b), _c_i64(B), _c_int(n_in), _c_int(n_out),
-       _c_int(_ACT[act]), _ptr(out), _c_i64(n_out))
+       _c_int(_ACT[act]), _ptr(ko), _ptr(out), _c_i64(n_out))
     return out
 
 
-def dense_net(x, weights, biases, acts, dtype=np.float32):
-    """DenseNet.forward (nn/dense.py:47-48): acts[i] follows layer i (None after the last)."""
+def dense_net(x, weights, biases, acts, dtype=np.float32, mfma_order=False):
+    """DenseNet.forward (nn/dense.py:47-48): acts[i] follows layer i (None after the last).
+    ``mfma_order``: hidden layers (every layer but the first) accumulate in the fused kernel's order."""
     h = x
-    for W, b, a in zip(weights, biases, acts):
-        h = linear(h, W, b, a, dtype)
+    for i, (W, b, a) in enumerate(zip(weights, biases, acts)):
+        ko = mfma_k_order(W.shape[1]) if (mfma_order and i > 0 and W.shape[1] % 32 == 0) else None
+        h = linear(h, W, b, a, dtype, k_order=ko)
     return h
 
 

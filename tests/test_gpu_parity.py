@@ -318,3 +318,89 @@ def test_flow16_vs_oracle_bin_indices(hip_lib, golden, dev):
     # f32 noise the REFERENCE itself shows on these inputs (|ref32 - ref64|)
     noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
     assert np.abs(dl.cpu().numpy() - dlo).max() <= 1e-5 * np.abs(dlo).max() + noise
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused coupling layer (DenseNet on the f32 matrix cores + spline epilogue)
+# ---------------------------------------------------------------------------------------------------
+def _layer(kind, dev=None):
+    """one builder-style coupling layer of cfg 3: kind in {T|F, F|T, B|A}"""
+    from bgflow_amd import configs
+    from bgflow_amd.utils import hash_init_
+    dims = {"BONDS": 17, "ANGLES": 17, "TORSIONS": 17, "FIXED": 9}
+    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+    what, on = {"T|F": ("TORSIONS", "FIXED"), "F|T": ("FIXED", "TORSIONS"), "B|A": ("BONDS", "ANGLES")}[kind]
+    layer = hash_init_(configs._spline_coupling(what, on, dims, circ, slot))
+    return (layer.to(dev) if dev is not None else layer), slot[what]
+
+
+@pytest.mark.parametrize("kind", ["T|F", "F|T", "B|A"])
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("B", [1, 31, 1000, 4133])
+def test_fused_layer_bit_exact_vs_oracle(hip_lib, dev, kind, inverse, B):
+    from oracle import flow_oracle as fo
+    layer_cpu, ti = _layer(kind)
+    layer, _ = _layer(kind, dev)
+    xs = [synth(B + 7 * i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9))]
+    layer.transformer.return_bin_indices = True
+    with torch.no_grad():
+        *outs, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
+    assert layer.transformer._fused_cache, "the fused path must have run"
+    idx = layer.transformer.last_bin_indices.cpu().numpy()
+    fo.MFMA_ORDER = True
+    try:
+        trace = []
+        outs_o, dl_o = fo.run_block(layer_cpu, xs, inverse, np.float32, trace)
+    finally:
+        fo.MFMA_ORDER = False
+    assert np.array_equal(idx, trace[0]["bin_idx"]), "bin indices bit-exact"
+    got = outs[ti].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), outs_o[ti].view(np.uint32)), f"{np.sum(got != outs_o[ti])} outputs differ"
+    assert np.array_equal(dl.cpu().numpy().view(np.uint32), dl_o.view(np.uint32))
+    # and the generic path (torch conditioner + bgk_rqs_transform) agrees to rounding
+    layer.transformer.allow_fused = False
+    with torch.no_grad():
+        *outs2, dl2 = layer(*[t(v, dev) for v in xs], inverse=inverse)
+    np.testing.assert_allclose(outs2[ti].cpu().numpy(), got, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dl2.cpu().numpy(), dl.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_fused_flow16_bit_exact_and_golden(hip_lib, golden, dev):
+    """cfg 3 through the fused kernels: the 16 couplings are bit-identical to the oracle (MFMA order),
+    and the result matches the reference golden like the generic path does"""
+    from bgflow_amd import configs
+    from oracle import flow_oracle as fo
+    G = golden("g_flow16")
+    gen_cpu = configs.make_ala2_spline_generator()
+    gen = configs.make_ala2_spline_generator(dev)
+    u = [G[k] for k in ("u_bonds", "u_angles", "u_torsions", "u_fixed")]
+    fo.MFMA_ORDER = True
+    try:
+        ics_o, dl_o = fo.run_flow(gen_cpu.flow[:16], u, dtype=np.float32)
+    finally:
+        fo.MFMA_ORDER = False
+    with torch.no_grad():
+        *ics, dl = gen.flow[:16](*[t(v, dev) for v in u])
+        x, dl_all = gen.flow(*[t(v, dev) for v in u])
+    for a, b in zip(ics, ics_o):
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(dl.cpu().numpy().view(np.uint32), dl_o.view(np.uint32))
+    noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
+    assert np.abs(dl_all.cpu().numpy() - G["dlogp64"]).max() <= 1e-5 * np.abs(G["dlogp64"]).max() + noise
+    for i in range(16):
+        pass
+    np.testing.assert_allclose(torch.cat(ics, -1).cpu().numpy(), G["block15_32"][:, :60], rtol=0, atol=2e-5)
+
+
+def test_fused_roundtrip_at_scale(hip_lib, dev):
+    """2^20 samples through one fused B|A layer and back"""
+    layer, ti = _layer("B|A", dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    xs = [torch.rand(1 << 20, d, device=dev, generator=g) for d in (17, 17, 17, 9)]
+    with torch.no_grad():
+        *ys, dl = layer(*xs)
+        *zs, dli = layer(*ys, inverse=True)
+    assert float((zs[ti] - xs[ti]).abs().max()) < 2e-5
+    assert float((dl + dli).abs().max()) < 5e-4
+    assert float(ys[ti].min()) >= 0 and float(ys[ti].max()) <= 1
