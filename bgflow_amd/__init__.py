@@ -14,6 +14,6 @@ from .ic import *            # noqa: F401,F403
 from .distributions import * # noqa: F401,F403
 from .cdf import *           # noqa: F401,F403
 from .bg import *            # noqa: F401,F403
-from . import dp, utils      # noqa: F401
+from . import configs, dp, utils      # noqa: F401
 
 __version__ = "0.1.0"

@@ -39,7 +39,7 @@ def build_extension(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + sources()
+    cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("BGK_EXTRA_FLAGS", "").split() + ["-o", LIB] + sources()
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

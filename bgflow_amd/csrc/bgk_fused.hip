@@ -7,8 +7,12 @@
  * 19.7 flop/B machine balance.
  *
  * Decomposition (gfx950).  A wave owns 32 samples for the whole layer; a workgroup is 4 independent
- * waves (no workgroup barrier anywhere), 2 workgroups per CU = 2 waves per SIMD so that one wave's
- * VALU phases (SiLU, spline) overlap the other's MFMA phases.
+ * waves (no workgroup barrier anywhere), 2 workgroups per CU = 2 waves per SIMD.
+ * Measured on MI355X (profiles/r01_*): the f32-input MFMA and the f32 VALU do NOT overlap -- time is
+ * additive (chunk GEMMs alone run at ~100 % of the f32 MFMA rate; SiLU + spline VALU phases add on
+ * top, whether the VALU work sits in the partner wave or is software-pipelined into the same wave's
+ * MFMA stream; the BGK_PIPE_* build switches keep that experiment reproducible).  The lever left
+ * is VALU instruction count, not scheduling.
  *   GEMM orientation: D[feature, sample] = W[feature, k] * X[k, sample]   (A = weights, B = data)
  *   - A fragments: weights pre-packed on the host so that one k-step of 4 output tiles is ONE
  *     coalesced 16-byte-per-lane load (1 KiB per wave, L1/L2 resident), software-prefetched
@@ -30,6 +34,13 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef BGK_PIPE_SPLINE
+#define BGK_PIPE_SPLINE 0
+#endif
+#ifndef BGK_PIPE_ACT
+#define BGK_PIPE_ACT 0
+#endif
+
 constexpr int FW = 4;                 /* waves per workgroup */
 constexpr int FTHREADS = FW * 64;
 constexpr int HID = 128;              /* hidden width (both hidden layers) */
@@ -42,7 +53,7 @@ constexpr int SROW = 33;              /* padded row stride of the small per-wave
 
 struct FusedArgs {
     const float* cond; int64_t ldc; int d_c; int periodic;
-    const float4* W0; int T0;        /* layer 0: T0 = ceil(n_in/2) k-steps (+1 bias step) */
+    const float4* W0; int T0;        /* layer 0: T0 = ceil(n_in/2) k-steps rounded up to x4 (+1 bias step) */
     const float4* W1;                /* 64 + 1 steps */
     const float4* W2; int n_chunks;  /* per chunk 64 + 1 steps */
     int act;
@@ -63,29 +74,37 @@ __device__ __forceinline__ float act_fn(float v) {
     return bgk_tanhf(v);
 }
 
-/* Packed-weight fetch: one wave-uniform base pointer + ONE per-lane byte offset (lane * 16) for the
- * whole kernel; the k-step part (step * 1 KiB) folds into the instruction's immediate offset, so
- * there is no per-load 64-bit address arithmetic (the compiler otherwise materialises one address
- * pair per step and spills them). */
-struct WBuf {
-    const char* base;
-    unsigned voff;
-};
-__device__ __forceinline__ WBuf wbuf_make(const float4* base, int /*n_steps*/, int lane) {
-    WBuf w;
-    w.base = reinterpret_cast<const char*>(base);
-    w.voff = (unsigned)lane * 16u;
-    return w;
-}
-__device__ __forceinline__ float4 wbuf_ld(const WBuf& w, int step) {
-    return *reinterpret_cast<const float4*>(w.base + (size_t)step * 1024 + w.voff);
-}
+/* ---- packed-weight stream --------------------------------------------------------------------
+ * One k-step = one 1 KiB block = one global_load_dwordx4 per lane with a wave-uniform SGPR base, a
+ * single per-lane VGPR byte offset (lane * 16) for the whole kernel and an immediate step offset.
+ * hipcc (ROCm 7.2) sinks ordinary prefetch loads down to their first use (one full L2 round trip
+ * per 4 MFMAs) and materialises/spills one 64-bit address per step, so the stream is issued from
+ * inline asm and counted by hand (guide 5.7 form (ii)): every destination is named "+v" in the
+ * s_waitcnt statement that precedes its first consumer, so no MFMA can be scheduled above its wait. */
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 /* row of output tile m held in accumulator register r by this lane (hh = lane >> 5) */
 __device__ __forceinline__ int drow(int m, int r, int hh) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-/* 4 output tiles x one k-step */
-__device__ __forceinline__ void mfma4(f32x16 (&acc)[4], const float4& a, float b) {
+template <int IMM>
+__device__ __forceinline__ void wload(f32x4& dst, unsigned voff, const char* sbase) {
+    /* s_nop 4: the SGPR base may have been (re)materialised by a VALU v_readlane right before this
+     * statement; VALU-written SGPR -> VMEM read needs 5 wait states and hipcc pads nothing inside asm */
+    /* no "memory" clobber: the packed weights are read-only for the whole launch, and the spline's LDS reads
+     * must be free to be scheduled between these statements */
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(IMM));
+}
+template <int N>
+__device__ __forceinline__ void wwait(f32x4& v) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "i"(N));
+}
+/* load of k-step S relative to a uniform base (steps are grouped in fours: 13-bit signed immediate) */
+template <int S>
+__device__ __forceinline__ void wload_step(f32x4& dst, unsigned voff, const char* base) {
+    wload<(S % 4) * 1024>(dst, voff + (unsigned)((S / 4) * 4096), base);   /* one SGPR base per GEMM */
+}
+
+__device__ __forceinline__ void mfma4v(f32x16 (&acc)[4], const f32x4& a, float b) {
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[1], 0, 0, 0);
     acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b, acc[2], 0, 0, 0);
@@ -96,22 +115,204 @@ __device__ __forceinline__ void mfma4(f32x16 (&acc)[4], const float4& a, float b
  * The packed operand has 64 + 1 k-steps: the last one multiplies the bias (A, lower half-wave) by
  * 1.0 (B) -- fma(bias, 1, acc) == acc + bias, the oracle's "bias added last". */
 constexpr int HSTEPS = 65;
-__device__ __forceinline__ void gemm_hidden(f32x16 (&acc)[4], const f32x16 (&h)[4], const float4* Wbase, int lane) {
-    const WBuf w = wbuf_make(Wbase, HSTEPS, lane);
-    float4 ring[PF];
+
+/* state of one in-flight 65-step GEMM (A stream) */
+struct Stream {
+    f32x4 ring[PF];
+    unsigned voff;
+    const char* base;
+    float bias_b;
+};
+
+__device__ __forceinline__ void gstart(Stream& st, const float4* Wbase, int lane) {
+    st.base = reinterpret_cast<const char*>(Wbase);
+    st.voff = (unsigned)lane * 16u;
+    st.bias_b = lane < 32 ? 1.0f : 0.0f;
+    static_assert(PF == 4, "prologue written for PF = 4");
+    wload_step<0>(st.ring[0], st.voff, st.base);
+    wload_step<1>(st.ring[1], st.voff, st.base);
+    wload_step<2>(st.ring[2], st.voff, st.base);
+    wload_step<3>(st.ring[3], st.voff, st.base);
+}
+
+/* k-step S: wait for its A block, refill the ring slot, 4 MFMAs (B = in[S/16][S%16] or the bias 1/0) */
+template <int S>
+__device__ __forceinline__ void gstep(Stream& st, f32x16 (&out)[4], const f32x16 (&in)[4]) {
+    constexpr int newer = (HSTEPS - 1 - S) < (PF - 1) ? (HSTEPS - 1 - S) : (PF - 1);
+    wwait<newer>(st.ring[S % PF]);
+    const f32x4 a = st.ring[S % PF];
+    if constexpr (S + PF < HSTEPS) wload_step<S + PF>(st.ring[S % PF], st.voff, st.base);
+    if constexpr (S < 64) mfma4v(out, a, in[S / 16][S % 16]);
+    else mfma4v(out, a, st.bias_b);
+}
+
+/* GEMM whose INPUT tiles 1..3 still need their activation: tile 0 must already be activated; tile
+ * 1 + S/16 is activated element by element behind k-steps 0..47 (it is first consumed at step 16). */
+template <int ACT, int S>
+struct ActGemm {
+    static __device__ __forceinline__ void run(Stream& st, f32x16 (&out)[4], f32x16 (&in)[4]) {
+        gstep<S>(st, out, in);
+#if BGK_PIPE_ACT
+        if constexpr (S < 48) in[1 + S / 16][S % 16] = act_fn<ACT>(in[1 + S / 16][S % 16]);
+#else
+        if constexpr (S == 0) {
 #pragma unroll
-    for (int p = 0; p < PF; ++p) ring[p] = wbuf_ld(w, p);
+            for (int t = 1; t < 4; ++t)
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int s = kb * 16 + r;
-            float4 a = ring[s % PF];
-            if (s + PF < HSTEPS) ring[s % PF] = wbuf_ld(w, s + PF);
-            mfma4(acc, a, h[kb][r]);
+                for (int r = 0; r < 16; ++r) in[t][r] = act_fn<ACT>(in[t][r]);
+        }
+#endif
+        if constexpr (S + 1 < HSTEPS) ActGemm<ACT, S + 1>::run(st, out, in);
+    }
+};
+
+/* plain steps [S, E) */
+template <int S, int E>
+struct PlainSteps {
+    static __device__ __forceinline__ void run(Stream& st, f32x16 (&out)[4], const f32x16 (&in)[4]) {
+        if constexpr (S < E) {
+            gstep<S>(st, out, in);
+            PlainSteps<S + 1, E>::run(st, out, in);
         }
     }
-    mfma4(acc, ring[64 % PF], lane < 32 ? 1.0f : 0.0f);
+};
+
+/* hook policies for the pipelined spline: a live GEMM, or nothing (last chunk) */
+struct LiveGemm {
+    Stream& st; f32x16 (&out)[4]; const f32x16 (&in)[4];
+    template <int S> __device__ __forceinline__ void step() { if constexpr (S < HSTEPS) gstep<S>(st, out, in); }
+};
+struct NoGemm {
+    template <int S> __device__ __forceinline__ void step() {}
+};
+
+/* One spline element with 21 hook points; hook i runs k-step S0 + i of the overlapped GEMM.  Same
+ * arithmetic, same order as bgk_rqs_element (bgk_common.h) -- only the instruction placement differs. */
+constexpr int HOOKS = 21;
+template <int INV, int S0, class G>
+__device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* pw, const float* ph, const float* ps,
+                                                   float s_last, const BgkRqsCfg& c, float* lad, int* bin, int* oob) {
+    constexpr int K = KB, st = 32;
+    int o = (x < c.left) | (x > c.right);
+    x = x < c.left ? c.left : (x > c.right ? c.right : x);
+    *oob = o;
+    const float* pa = INV ? pw : ph;
+    const float* pb = INV ? ph : pw;
+    const float minA = INV ? c.min_w : c.min_h, minB = INV ? c.min_h : c.min_w;
+    const float scA = INV ? c.w_scale : c.h_scale, scB = INV ? c.h_scale : c.w_scale;
+    const float spanA = INV ? c.xspan : c.yspan, spanB = INV ? c.yspan : c.xspan;
+    const float lowA = INV ? c.left : c.bottom, lowB = INV ? c.bottom : c.left;
+    const float highA = INV ? c.right : c.top, highB = INV ? c.top : c.right;
+    float ra[K], e[K];
+    /* ---- searched set ---- */
+#pragma unroll
+    for (int k = 0; k < K; ++k) ra[k] = pa[k * st];
+    float mA = ra[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) mA = ra[k] > mA ? ra[k] : mA;
+    g.template step<S0 + 0>();
+    e[0] = bgk_expf(ra[0] - mA); e[1] = bgk_expf(ra[1] - mA); g.template step<S0 + 1>();
+    e[2] = bgk_expf(ra[2] - mA); e[3] = bgk_expf(ra[3] - mA); g.template step<S0 + 2>();
+    e[4] = bgk_expf(ra[4] - mA); e[5] = bgk_expf(ra[5] - mA); g.template step<S0 + 3>();
+    e[6] = bgk_expf(ra[6] - mA); e[7] = bgk_expf(ra[7] - mA);
+    float sA = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) sA += e[k];
+    g.template step<S0 + 4>();
+    int idx = -1 + (x >= lowA ? 1 : 0);
+    float lo = lowA, hi = lowA, cum = 0.0f;
+    bool hi_set = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float p = e[k] / sA;
+        p = minA + scA * p;
+        cum += p;
+        float kn = spanA * cum + lowA;
+        if (k == K - 1) kn = highA;
+        float ks = (k == K - 1) ? kn + 1e-6f : kn;
+        bool ge = x >= ks;
+        idx += ge ? 1 : 0;
+        if (ge) lo = kn;
+        if (!ge && !hi_set) { hi = kn; hi_set = true; }
+        if (k == 1) g.template step<S0 + 5>();
+        if (k == 3) g.template step<S0 + 6>();
+        if (k == 5) g.template step<S0 + 7>();
+        if (k == 7) g.template step<S0 + 8>();
+    }
+    idx = idx < 0 ? 0 : idx;
+    *bin = idx;
+    const float a_i = lo, A_i = hi - lo;
+    /* ---- other set ---- */
+#pragma unroll
+    for (int k = 0; k < K; ++k) ra[k] = pb[k * st];
+    float mB = ra[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) mB = ra[k] > mB ? ra[k] : mB;
+    g.template step<S0 + 9>();
+    e[0] = bgk_expf(ra[0] - mB); e[1] = bgk_expf(ra[1] - mB); g.template step<S0 + 10>();
+    e[2] = bgk_expf(ra[2] - mB); e[3] = bgk_expf(ra[3] - mB); g.template step<S0 + 11>();
+    e[4] = bgk_expf(ra[4] - mB); e[5] = bgk_expf(ra[5] - mB); g.template step<S0 + 12>();
+    e[6] = bgk_expf(ra[6] - mB); e[7] = bgk_expf(ra[7] - mB);
+    float sB = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) sB += e[k];
+    g.template step<S0 + 13>();
+    float b_i = lowB, b_ip1 = lowB;
+    cum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float p = e[k] / sB;
+        p = minB + scB * p;
+        cum += p;
+        float kn = spanB * cum + lowB;
+        if (k == K - 1) kn = highB;
+        if (k + 1 == idx) b_i = kn;
+        if (k == idx) b_ip1 = kn;
+        if (k == 1) g.template step<S0 + 14>();
+        if (k == 3) g.template step<S0 + 15>();
+        if (k == 5) g.template step<S0 + 16>();
+        if (k == 7) g.template step<S0 + 17>();
+    }
+    const float B_i = b_ip1 - b_i;
+    /* ---- gathered derivatives ---- */
+    float s_lo = ps[idx * st];
+    float s_hi = (idx + 1 < K) ? ps[(idx + 1 < K ? idx + 1 : 0) * st] : s_last;
+    float d_i = c.min_d + bgk_softplusf(s_lo, c.beta);
+    g.template step<S0 + 18>();
+    float d_ip1 = c.min_d + bgk_softplusf(s_hi, c.beta);
+    g.template step<S0 + 19>();
+    float cw_i, W_i, ch_i, H_i;
+    if (INV) { cw_i = a_i; W_i = A_i; ch_i = b_i; H_i = B_i; }
+    else { ch_i = a_i; H_i = A_i; cw_i = b_i; W_i = B_i; }
+    float delta = H_i / W_i;
+    float S = d_i + d_ip1 - 2.0f * delta;
+    float outv, l;
+    if (!INV) {
+        float dx = x - ch_i;
+        float a = dx * S + H_i * (delta - d_i);
+        float b = H_i * d_i - dx * S;
+        float cc = -delta * dx;
+        float disc = b * b - 4.0f * a * cc;
+        float root = (2.0f * cc) / (-b - __builtin_sqrtf(disc));
+        outv = root * W_i + cw_i;
+        float t1mt = root * (1.0f - root);
+        float den = delta + S * t1mt;
+        float omr = 1.0f - root;
+        float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
+        l = -(bgk_logf(num) - 2.0f * bgk_logf(den));
+    } else {
+        float theta = (x - cw_i) / W_i;
+        float t1mt = theta * (1.0f - theta);
+        float numer = H_i * (delta * (theta * theta) + d_i * t1mt);
+        float den = delta + S * t1mt;
+        outv = ch_i + numer / den;
+        float omt = 1.0f - theta;
+        float num = (delta * delta) * (d_ip1 * (theta * theta) + 2.0f * delta * t1mt + d_i * (omt * omt));
+        l = bgk_logf(num) - 2.0f * bgk_logf(den);
+    }
+    g.template step<S0 + 20>();
+    *lad = l;
+    return outv;
 }
 
 __device__ __forceinline__ void zero4(f32x16 (&acc)[4]) {
@@ -121,7 +322,54 @@ __device__ __forceinline__ void zero4(f32x16 (&acc)[4]) {
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
 }
 
-template <int ACT>
+/* Spline of one parameter chunk held in LDS: 3 element evaluations per lane (q = hh, hh+2, hh+4),
+ * written branch-free so that the whole routine is ONE basic block and can be software-pipelined
+ * under the next chunk's MFMAs.  Invalid (q >= nd) slots evaluate dim 0 of the chunk and are
+ * discarded (their output goes to the dummy row d of s_y). */
+template <int INV, int IT, class G>
+__device__ __forceinline__ void spline_slot(G& g, const FusedArgs& a, const float* s_p, float* s_y, int c, int nd,
+                                            int hh, int j, int rows, float& run, int& oob_local, int (&bins)[3]) {
+    const int q = 2 * IT + hh;
+    const bool valid = q < nd;
+    const int qq = valid ? q : 0;
+    const int dim = c * DPC + qq;
+    const float* pw = s_p + (qq * PPD) * 32 + j;
+    const float* ph = pw + KB * 32;
+    const float* ps = ph + KB * 32;
+    const bool circ = (a.circ_mask >> dim) & 1ull;
+    const float s_nc = ps[KB * 32];
+    const float s_last = circ ? ps[0] : s_nc;
+    int bin, oob;
+    float lad;
+    const float x = s_y[dim * SROW + j];
+    const float o = rqs_element_piped<INV, IT * HOOKS>(g, x, pw, ph, ps, s_last, a.cfg, &lad, &bin, &oob);
+    s_y[(valid ? dim : a.d) * SROW + j] = o;
+    oob_local += (valid && j < rows) ? oob : 0;
+    bins[IT] = bin;
+    lad = valid ? lad : 0.0f;
+    /* dim 2*IT lives in the lower half-wave, dim 2*IT+1 in the upper one: exchange the two log-dets and let
+     * BOTH halves add them in ascending dim order (same bits as the oracle) */
+    const float lad_other = __shfl_xor(lad, 32);
+    const float l0 = hh ? lad_other : lad;
+    const float l1 = hh ? lad : lad_other;
+    const float r0 = run + l0;
+    run = (2 * IT < nd) ? r0 : run;
+    const float r1 = run + l1;
+    run = (2 * IT + 1 < nd) ? r1 : run;
+}
+
+/* Spline of one parameter chunk held in LDS: 3 element evaluations per lane (q = hh, hh+2, hh+4), branch-free
+ * (invalid slots evaluate dim 0 of the chunk and are discarded into the dummy row d of s_y), with the hook
+ * policy G running the overlapped GEMM's k-steps 0..62 in between. */
+template <int INV, class G>
+__device__ __forceinline__ void spline_chunk(G& g, const FusedArgs& a, const float* s_p, float* s_y, int c, int nd,
+                                             int hh, int j, int rows, float& run, int& oob_local, int (&bins)[3]) {
+    spline_slot<INV, 0>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 1>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 2>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+}
+
+template <int ACT, int INV>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -132,7 +380,9 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedAr
     const int d = a.d;
     const int64_t n_tiles = (a.B + 31) / 32;
 
-    for (int64_t tile = (int64_t)blockIdx.x * FW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * FW) {
+    /* one 32-sample tile per wave (no grid-stride loop: hipcc peels/duplicates the 13k-instruction body) */
+    const int64_t tile = (int64_t)blockIdx.x * FW + wave;
+    if (tile < n_tiles) {
         const int64_t b0 = tile * 32;
         const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
 
@@ -150,7 +400,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedAr
                 s_p[c * SROW + r] = v;
             }
         }
-        if (n_in & 1) { if (lane < 32) s_p[n_in * SROW + lane] = 0.0f; }   /* zero pad row for the odd k */
+        for (int i = lane; i < (2 * a.T0 - n_in) * 32; i += 64) s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = 0.0f;   /* pad rows (zero weights) */
         for (int i = lane; i < 32 * d; i += 64) {
             const int r = i / d, c = i - r * d;
             s_y[c * SROW + r] = r < rows ? a.y[(b0 + r) * a.ldy + c] : 0.5f;
@@ -158,85 +408,100 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedAr
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        /* ---- layer 0: h = act(W0 * x + b0), B operand from LDS, natural k order, bias = last step ---- */
+        /* ---- layer 0: h = act(W0 * x + b0), B operand from LDS, natural k order, bias = last step.
+         * T0 (k-steps) is padded to a multiple of 4 with zero weights on the host; groups of 4 steps are
+         * double-buffered (group g+1 in flight while group g feeds the MFMAs). ---- */
         f32x16 h[4], acc[4];
         zero4(h);
         {
-            const int T0 = a.T0;
-            const WBuf w = wbuf_make(a.W0, T0 + 1, lane);
-            float4 ring[PF];
-#pragma unroll
-            for (int p = 0; p < PF; ++p) ring[p] = wbuf_ld(w, p <= T0 ? p : T0);
-            for (int t0 = 0; t0 < T0; t0 += PF) {
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int t = t0 + u;
-                    if (t < T0) {
-                        float4 av = ring[u];
-                        const int tn = t + PF;
-                        ring[u] = wbuf_ld(w, tn <= T0 ? tn : T0);
-                        float bv = s_p[(2 * t + hh) * SROW + j];
-                        mfma4(h, av, bv);
-                    }
+            const char* base = reinterpret_cast<const char*>(a.W0);
+            const unsigned voff = (unsigned)lane * 16u;
+            const int G = a.T0 >> 2;
+            f32x4 A0, A1, A2, A3, B0, B1, B2, B3;
+            wload<0>(A0, voff, base); wload<1024>(A1, voff, base); wload<2048>(A2, voff, base); wload<3072>(A3, voff, base);
+            for (int g = 0; g < G; g += 2) {
+                {
+                    const int gn = (g + 1 < G) ? g + 1 : G - 1;          /* last group again = dummy prefetch */
+                    const char* bn = base + (size_t)gn * 4096;
+                    wload<0>(B0, voff, bn); wload<1024>(B1, voff, bn); wload<2048>(B2, voff, bn); wload<3072>(B3, voff, bn);
+                }
+                const float* xr = s_p + (8 * g + hh) * SROW + j;
+                wwait<7>(A0); mfma4v(h, A0, xr[0 * 2 * SROW]);
+                wwait<6>(A1); mfma4v(h, A1, xr[1 * 2 * SROW]);
+                wwait<5>(A2); mfma4v(h, A2, xr[2 * 2 * SROW]);
+                wwait<4>(A3); mfma4v(h, A3, xr[3 * 2 * SROW]);
+                if (g + 1 < G) {
+                    const int gn = (g + 2 < G) ? g + 2 : G - 1;
+                    const char* bn = base + (size_t)gn * 4096;
+                    wload<0>(A0, voff, bn); wload<1024>(A1, voff, bn); wload<2048>(A2, voff, bn); wload<3072>(A3, voff, bn);
+                    const float* xq = xr + 8 * SROW;
+                    wwait<7>(B0); mfma4v(h, B0, xq[0 * 2 * SROW]);
+                    wwait<6>(B1); mfma4v(h, B1, xq[1 * 2 * SROW]);
+                    wwait<5>(B2); mfma4v(h, B2, xq[2 * 2 * SROW]);
+                    wwait<4>(B3); mfma4v(h, B3, xq[3 * 2 * SROW]);
                 }
             }
-            /* bias step (index T0): by construction ring[T0 % PF] holds it */
-            float4 ab = wbuf_ld(w, T0);
-            mfma4(h, ab, lane < 32 ? 1.0f : 0.0f);
+            /* retire the dummy prefetches before their registers are reused */
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3));
+            /* bias step (index T0) */
+            const f32x4 ab = reinterpret_cast<const f32x4*>(base + (size_t)a.T0 * 1024)[lane];
+            mfma4v(h, ab, lane < 32 ? 1.0f : 0.0f);
+            /* activation of tile 0 only; tiles 1..3 are activated behind the next GEMM's k-steps */
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) h[m][r] = act_fn<ACT>(h[m][r]);
+            for (int r = 0; r < 16; ++r) h[0][r] = act_fn<ACT>(h[0][r]);
         }
-        /* ---- layer 1: h = act(W1 * h + b1), B operand = registers ---- */
+        /* ---- layer 1: acc = W1 * act(h) + b1 (B operand = registers) ---- */
+        Stream st;
         zero4(acc);
-        gemm_hidden(acc, h, a.W1, lane);
+        gstart(st, a.W1, lane);
+        ActGemm<ACT, 0>::run(st, acc, h);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[m][r] = act_fn<ACT>(acc[m][r]);
+        for (int r = 0; r < 16; ++r) acc[0][r] = act_fn<ACT>(acc[0][r]);
 
-        /* ---- layer 2 in chunks of 128 packed columns + spline ---- */
-        float run = 0.0f;          /* running sum of log-dets of sample j (handed between the two half-waves) */
+        /* ---- layer 2 in chunks of 128 packed columns + spline, software-pipelined inside the wave:
+         *   GEMM(chunk 0) [activating its own input tiles 1..3 on the fly];
+         *   for c: { h -> LDS;  [ GEMM(chunk c+1) || spline(chunk c) ] }
+         * From here on the roles are swapped: `acc` (layer-1 output, activated in place) is the B operand,
+         * `h` (dead layer-0 activations) is the accumulator.  The spline is threaded through the GEMM's
+         * k-steps (21 hook points per element): the f32 MFMA holds the matrix pipe for 64 cycles per
+         * instruction, during which the same wave issues the spline's VALU work. ---- */
+        float run = 0.0f;          /* running sum of log-dets of sample j (kept identical in both half-waves) */
         int oob_local = 0;
-        __builtin_amdgcn_wave_barrier();
+        zero4(h);
+        gstart(st, a.W2, lane);
+        ActGemm<ACT, 0>::run(st, h, acc);
         for (int c = 0; c < a.n_chunks; ++c) {
-            zero4(acc);
-            gemm_hidden(acc, h, a.W2 + (size_t)c * HSTEPS * 64, lane);
-            /* previous chunk's spline reads of s_p are complete (same wave, program order) */
+            /* spline(c-1) reads of s_p are complete (same wave, program order) */
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * 32 + j] = acc[m][r];
+                for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * 32 + j] = h[m][r];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
-            /* elements (q, j): q = hh, hh+2, hh+4; log-det sum in ascending dim order via half-wave hand-off */
-#pragma unroll 1
-            for (int it = 0; it < (DPC + 1) / 2; ++it) {
-                const int q = 2 * it + hh;
-                const int dim = c * DPC + q;
-                float lad = 0.0f;
-                if (q < nd) {
-                    const float* pw = s_p + (q * PPD) * 32 + j;
-                    const float* ph = pw + KB * 32;
-                    const float* ps = ph + KB * 32;
-                    const bool circ = (a.circ_mask >> dim) & 1ull;
-                    const float s_last = circ ? ps[0] : ps[KB * 32];
-                    int bin, oob;
-                    float x = s_y[dim * SROW + j];
-                    float o = bgk_rqs_element<KB>(x, pw, ph, ps, 32, s_last, KB, a.inverse, a.cfg, &lad, &bin, &oob);
-                    s_y[dim * SROW + j] = o;
-                    oob_local += (j < rows) ? oob : 0;
-                    if (a.bin_idx && j < rows) a.bin_idx[(b0 + j) * d + dim] = bin;
+            int bins[3];
+            if (c + 1 < a.n_chunks) {
+                zero4(h);
+                gstart(st, a.W2 + (size_t)(c + 1) * HSTEPS * 64, lane);
+#if BGK_PIPE_SPLINE
+                LiveGemm g{st, h, acc};
+                spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+                PlainSteps<3 * HOOKS, HSTEPS>::run(st, h, acc);
+#else
+                PlainSteps<0, HSTEPS>::run(st, h, acc);
+                NoGemm g;
+                spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+#endif
+            } else {
+                NoGemm g;
+                spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+            }
+            if (a.bin_idx) {
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int q = 2 * it + hh;
+                    if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
                 }
-                /* dim 2*it lives in the lower half-wave, dim 2*it+1 in the upper one: exchange the two
-                 * log-dets and let BOTH halves add them in ascending dim order (same bits as the oracle) */
-                const float lad_other = __shfl_xor(lad, 32);
-                const float l0 = hh ? lad_other : lad;
-                const float l1 = hh ? lad : lad_other;
-                if (2 * it < nd) run = run + l0;
-                if (2 * it + 1 < nd) run = run + l1;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -299,27 +564,30 @@ extern "C" int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_
         return BGK_EUNSUPPORTED;
     }
     const int n_in = periodic ? 2 * d_c : d_c;
-    BGK_CHECK_ARG((n_in + 1) * SROW <= LDS_P, "bgk_coupling_rqs_dense: conditioner input of %d features too wide", n_in);
+    BGK_CHECK_ARG((n_in + 9) * SROW <= LDS_P, "bgk_coupling_rqs_dense: conditioner input of %d features too wide", n_in);
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
     if (B == 0) return 0;
     FusedArgs a;
     a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
-    a.W0 = reinterpret_cast<const float4*>(W0p); a.T0 = (n_in + 1) / 2;
+    a.W0 = reinterpret_cast<const float4*>(W0p); a.T0 = ((n_in + 1) / 2 + 3) & ~3;   /* padded to x4 by the packer */
     a.W1 = reinterpret_cast<const float4*>(W1p);
     a.W2 = reinterpret_cast<const float4*>(W2p); a.n_chunks = (d + DPC - 1) / DPC;
     a.act = act; a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.inverse = inverse;
     a.circ_mask = circ_mask;
     a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
     a.bin_idx = bin_idx; a.oob_count = oob_count;
-    a.lds_per_wave = LDS_P + d * SROW;
+    a.lds_per_wave = LDS_P + (d + 1) * SROW;   /* + dummy row for discarded spline slots */
     a.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, K);
     size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
     int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
-    int grid = (int)(n_wg < 256 * 2 * 8 ? n_wg : 256 * 2 * 8);
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_coupling_rqs_dense: batch too large for one launch");
+    int grid = (int)n_wg;
     hipStream_t st = (hipStream_t)stream;
-    if (act == 1) hipLaunchKernelGGL(coupling_rqs_dense_kernel<1>, dim3(grid), dim3(FTHREADS), shmem, st, a);
-    else if (act == 2) hipLaunchKernelGGL(coupling_rqs_dense_kernel<2>, dim3(grid), dim3(FTHREADS), shmem, st, a);
-    else hipLaunchKernelGGL(coupling_rqs_dense_kernel<3>, dim3(grid), dim3(FTHREADS), shmem, st, a);
+#define BGK_LAUNCH(A, I) hipLaunchKernelGGL((coupling_rqs_dense_kernel<A, I>), dim3(grid), dim3(FTHREADS), shmem, st, a)
+    if (act == 1) { if (inverse) BGK_LAUNCH(1, 1); else BGK_LAUNCH(1, 0); }
+    else if (act == 2) { if (inverse) BGK_LAUNCH(2, 1); else BGK_LAUNCH(2, 0); }
+    else { if (inverse) BGK_LAUNCH(3, 1); else BGK_LAUNCH(3, 0); }
+#undef BGK_LAUNCH
     return bgk_launch_status("bgk_coupling_rqs_dense");
 }

@@ -113,7 +113,7 @@ def _pack_steps(W, bias, k_of_step):
 
 
 def _k_natural(n_in):
-    T = (n_in + 1) // 2
+    T = ((n_in + 1) // 2 + 3) & ~3          # k-steps padded to a multiple of 4 (zero weights)
     k = torch.arange(2 * T).reshape(T, 2)
     return torch.where(k < n_in, k, torch.full_like(k, -1))
 

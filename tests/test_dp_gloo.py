@@ -1,0 +1,68 @@
+"""CPU, world_size 2 (gloo): the data-parallel helpers of bgflow_amd.dp -- the single all-reduce of
+[sum loss, count] for the KL / NLL mean, the flat gradient bucket, sharding and per-rank seeds."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from bgflow_amd import dp
+    r, w, l = dp.init_from_env("gloo")
+    assert (r, w) == (rank, world) and dp.is_distributed()
+    # uneven shards of a global batch of 11 samples
+    n_local = dp.shard_size(11)
+    assert n_local == (6 if rank == 0 else 5)
+    g = torch.Generator().manual_seed(dp.rank_seed(1234))
+    theta = torch.nn.Parameter(torch.tensor([0.5, -1.0]))
+    x = torch.randn(n_local, 2, generator=g)
+    per_sample = ((x * theta).sum(-1, keepdim=True)) ** 2          # stand-in for u(x_i) - dlogp_i
+    loss = dp.global_mean(per_sample)
+    loss.backward()
+    dp.allreduce_gradients_([theta])
+    out.put((rank, float(loss.detach()), theta.grad.clone(), x.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_mean_and_gradient_bucket_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, g0, x0), (_, l1, g1, x1) = res
+    assert l0 == pytest.approx(l1, rel=1e-6)                      # every rank holds the GLOBAL mean
+    assert not torch.equal(x0[:5], x1)                            # per-rank RNG streams differ
+    theta = torch.nn.Parameter(torch.tensor([0.5, -1.0]))
+    x = torch.cat([x0, x1])
+    ref = (((x * theta).sum(-1, keepdim=True)) ** 2).mean()
+    ref.backward()
+    assert l0 == pytest.approx(float(ref.detach()), rel=1e-5)
+    assert torch.allclose(g0, theta.grad, rtol=1e-5, atol=1e-6) and torch.allclose(g1, theta.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_single_process_is_a_noop():
+    from bgflow_amd import dp
+    assert not dp.is_distributed()
+    assert dp.shard_size(10) == 10
+    v = torch.arange(4.0).reshape(4, 1)
+    assert float(dp.global_mean(v)) == pytest.approx(1.5)

@@ -1,0 +1,217 @@
+"""CPU: host-side logic of the bgflow-compatible layer (tuple plumbing, error behaviour, shape
+bookkeeping), the C-ABI library's exported symbols, and that the product refuses to run without
+a HIP device.  Mirrors the reference's tests/nn/flow/test_coupling.py, test_sequential.py,
+test_inverted.py, tests/nn/flow/transformer/test_affine.py (:36-42), test_ic.py (:499-516)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import bgflow_amd as bg
+from bgflow_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_library_exports_every_declared_symbol(hip_lib):
+    header = open(os.path.join(ROOT, "include", "bgflow_amd.h")).read()
+    declared = set(re.findall(r"\b(bgk_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), f"{name} is declared in include/bgflow_amd.h but not exported"
+    assert declared == set(_lib.ABI_SYMBOLS), "ctypes signature table and header disagree"
+    assert hip_lib.bgk_abi_version() == 1
+
+
+def test_pack_rqs_columns_host_function(hip_lib):
+    d, K = 7, 8
+    slots = np.array([0, -1, 1, 2, -1, 3, 4], dtype=np.int32)
+    ncp = hip_lib.bgk_pack_rqs_columns(d, K, None, None)
+    assert ncp == 256
+    src = np.empty(ncp, dtype=np.int32)
+    hip_lib.bgk_pack_rqs_columns(d, K, slots.ctypes.data, src.ctypes.data)
+    P = 3 * K * d + 5
+    used = src[src >= 0]
+    assert len(set(used)) == len(used) == P and used.max() == P - 1      # a permutation of the reference columns
+    assert src[0] == 0 and src[8] == d * K and src[16] == 2 * d * K and src[24] == 3 * d * K
+    assert src[25 + 24] == -1                                               # circular dim: no extra slope
+    assert src[128] == 5 * K                                                # chunk 1 starts with dim 5
+
+
+def test_kernels_refuse_cpu_tensors(hip_lib):
+    tr = bg.ConditionalSplineTransformer(torch.nn.Linear(3, 3 * 8 * 2 + 2))
+    with pytest.raises(RuntimeError, match="HIP"):
+        tr(torch.zeros(4, 3), torch.rand(4, 2))
+    aff = bg.AffineTransformer(torch.nn.Linear(3, 2), torch.nn.Linear(3, 2))
+    with pytest.raises(RuntimeError, match="HIP"):
+        aff(torch.zeros(4, 3), torch.rand(4, 2))
+    ic = bg.RelativeInternalCoordinateTransformation(np.array([[0, 1, 2, 3]]), np.array([1, 2, 3]))
+    with pytest.raises(RuntimeError, match="HIP"):
+        ic(torch.rand(4, 12))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+# ---- split / merge / swap / coupling / wrap plumbing (reference tests/nn/flow/test_coupling.py) ----
+def test_split_flow_sizes_and_indices():
+    t = torch.arange(24.0).reshape(2, 12)
+    split = bg.SplitFlow(3, 4)
+    a, b, c, dlogp = split(t)
+    assert a.shape == (2, 3) and b.shape == (2, 4) and c.shape == (2, 5) and dlogp.shape == (2, 1)
+    y, dl = split(a, b, c, inverse=True)
+    assert torch.equal(y, t)
+    with pytest.raises(ValueError):
+        bg.SplitFlow(8, 8)(t)
+    split = bg.SplitFlow([0, 2], [1, 3, 5], [4, 6, 7, 8, 9, 10, 11])
+    a, b, c, _ = split(t)
+    assert torch.equal(a, t[:, [0, 2]]) and torch.equal(b, t[:, [1, 3, 5]])
+    y, _ = split(a, b, c, inverse=True)
+    assert torch.equal(y, t)
+    with pytest.raises(ValueError, match="overlapping"):
+        bg.SplitFlow([0, 1], [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])(t)
+    with pytest.raises(ValueError, match="missed"):
+        bg.SplitFlow([0, 1], [3, 4, 5, 6, 7, 8, 9, 10, 11])(t)
+
+
+def test_merge_and_swap_and_inverse():
+    t = torch.arange(8.0).reshape(2, 4)
+    flow = bg.SequentialFlow([bg.SplitFlow(2), bg.SwapFlow(), bg.MergeFlow(2)])
+    y, dlogp = flow(t)
+    assert torch.equal(y, t[:, [2, 3, 0, 1]]) and torch.equal(dlogp, torch.zeros(2, 1))
+    z, dl = flow(y, inverse=True)
+    assert torch.equal(z, t)
+    inv = bg.InverseFlow(flow)
+    z2, _ = inv(y)
+    assert torch.equal(z2, t)
+    assert len(flow) == 3 and isinstance(flow[0], bg.SplitFlow) and len(flow[1:]) == 2
+    assert [type(b).__name__ for b in flow] == ["SplitFlow", "SwapFlow", "MergeFlow"]
+
+
+class DummyTransformer(bg.Transformer):
+    """y +- 2x, like the reference's DummyTransformer (tests/nn/flow/test_coupling.py:58-70)"""
+
+    def _forward(self, x, y, **kwargs):
+        return y + 2 * x.sum(-1, keepdim=True), torch.zeros(*y.shape[:-1], 1)
+
+    def _inverse(self, x, y, **kwargs):
+        return y - 2 * x.sum(-1, keepdim=True), torch.zeros(*y.shape[:-1], 1)
+
+
+@pytest.mark.parametrize("ti,ci", [((1,), (0,)), ((0, 2), (1,)), ((2,), (0, 1))])
+def test_coupling_flow_routing(ti, ci):
+    xs = [torch.rand(5, 2), torch.rand(5, 3), torch.rand(5, 1)]
+    flow = bg.CouplingFlow(DummyTransformer(), transformed_indices=ti, cond_indices=ci)
+    *ys, dlogp = flow(*xs, temperature=2.0)          # unknown kwargs are passed through / ignored
+    cond_sum = sum(xs[i].sum(-1, keepdim=True) for i in ci)
+    for i in range(3):
+        expect = xs[i] + 2 * cond_sum if i in ti else xs[i]
+        assert torch.allclose(ys[i], expect)
+    *zs, _ = flow(*ys, inverse=True)
+    for a, b in zip(zs, xs):
+        assert torch.allclose(a, b, atol=1e-6)
+    with pytest.raises(ValueError):
+        bg.CouplingFlow(DummyTransformer(), transformed_indices=(0, 1), cond_indices=(1,))
+
+
+def test_wrap_flow_and_set_constant():
+    xs = [torch.rand(4, 2), torch.rand(4, 3), torch.rand(4, 1)]
+    wrap = bg.WrapFlow(bg.SwapFlow(), indices=(0, 2))
+    a, b, c, dl = wrap(*xs)
+    assert torch.equal(a, xs[2]) and torch.equal(b, xs[1]) and torch.equal(c, xs[0])
+    a2, b2, c2, _ = wrap(a, b, c, inverse=True)
+    assert torch.equal(a2, xs[0]) and torch.equal(c2, xs[2])
+    merge = bg.WrapFlow(bg.MergeFlow(2), indices=(0, 1), out_indices=(0,))
+    m, rest, _ = merge(*xs)
+    assert m.shape == (4, 5) and torch.equal(rest, xs[2])
+    const = bg.SetConstantFlow(indices=[1], values=[torch.tensor([1.0, 2.0])])
+    a, k, b, c, dl = const(*xs)
+    assert k.shape == (4, 2) and torch.equal(k[3], torch.tensor([1.0, 2.0])) and dl.shape == (4, 1)
+    back = const(a, k, b, c, inverse=True)
+    assert len(back) == 4 and torch.equal(back[1], xs[1])
+
+
+def test_sequential_trigger_and_empty():
+    class Pen(bg.Flow):
+        def _forward(self, x, **kw):
+            return x, torch.zeros(x.shape[0], 1)
+
+        def penalty(self):
+            return torch.tensor(2.0)
+    flow = bg.SequentialFlow([Pen(), bg.SwapFlow(), Pen()])
+    assert torch.equal(flow.trigger("penalty"), torch.tensor([2.0, 2.0]))
+    assert flow.trigger("nope").numel() == 0
+
+
+def test_affine_scale_and_circular_is_rejected():
+    with pytest.raises(ValueError):
+        bg.AffineTransformer(torch.nn.Linear(2, 2), torch.nn.Linear(2, 2), is_circular=True)
+
+
+def test_state_dict_keys_match_reference_layout():
+    gen = bg.configs.make_ala2_spline_generator() if hasattr(bg, "configs") else None
+    from bgflow_amd import configs
+    gen = configs.make_ala2_spline_generator()
+    keys = set(gen.flow.state_dict().keys())
+    assert "_blocks.0.transformer._params_net._layers.0.weight" in keys
+    assert "_blocks.1.transformer._params_net.net._layers.4.bias" in keys
+    assert "_blocks.20._flow._delegate._whiten.Twhiten" in keys
+    assert "_blocks.16._flow._delegate.distribution._cdf_lower_bound" in keys
+    assert sum(p.numel() for p in gen.flow.parameters()) == 1070892
+    aff = bg.AffineTransformer(bg.DenseNet([2, 4, 2]), bg.DenseNet([2, 4, 2]))
+    assert set(aff.state_dict()) >= {"_log_alpha", "_shift_transformation._layers.0.weight", "_scale_transformation._layers.1.bias"}
+
+
+def test_decompose_z_matrix_matches_reference(golden):
+    G = golden("g_ic")
+    blocks, i2a, a2i, i2o = bg.decompose_z_matrix(G["z_matrix"].astype(np.int64), G["rigid_block"].astype(np.int64))
+    assert [len(b) for b in blocks] == list(G["dec_block_sizes"])
+    assert np.array_equal(np.concatenate(blocks), G["dec_blocks"])
+    assert np.array_equal(i2a, G["dec_index2atom"]) and np.array_equal(a2i, G["dec_atom2index"])
+    assert np.array_equal(i2o, G["dec_index2order"])
+    # invariants of the reference's test_ic.py:499-516
+    assert sorted(i2a.tolist()) == list(range(22)) and np.array_equal(i2a[a2i], np.arange(22))
+    with pytest.raises(ValueError, match="not reachable"):
+        bg.decompose_z_matrix(np.array([[0, 1, 2, 3], [4, 5, 0, 1]]), np.array([1, 2, 3]))
+
+
+def test_whiten_flow_roundtrip_and_buffers():
+    torch.manual_seed(0)
+    X = torch.randn(500, 6) @ torch.randn(6, 6)
+    wf = bg.WhitenFlow(X, keepdims=4, whiten_inverse=False)
+    z, dl = wf(X)
+    assert z.shape == (500, 4) and torch.allclose(z.std(0), torch.ones(4), atol=0.05)
+    xb, dli = wf(z, inverse=True)
+    assert torch.allclose(dl + dli, torch.zeros(500, 1))
+    assert set(wf.state_dict()) == {"X0mean", "Twhiten", "Tblacken", "std"}
+    with pytest.raises(ValueError):
+        bg.WhitenFlow(torch.ones(10, 3), keepdims=3)
+
+
+def test_boltzmann_generator_api_with_stub_flow():
+    class Shift(bg.Flow):
+        def _forward(self, x, **kw):
+            return x + 1.0, torch.full((x.shape[0], 1), 0.5)
+
+        def _inverse(self, x, **kw):
+            return x - 1.0, torch.full((x.shape[0], 1), -0.5)
+    prior = bg.NormalDistribution(3)
+    target = bg.NormalDistribution(3, mean=torch.ones(3))
+    gen = bg.BoltzmannGenerator(prior, bg.SequentialFlow([Shift()]), target)
+    torch.manual_seed(1)
+    x, z, dlogp, e, lw, w = gen.sample(64, with_latent=True, with_dlogp=True, with_energy=True, with_log_weights=True, with_weights=True)
+    assert torch.allclose(x, z + 1) and torch.allclose(w.sum(), torch.tensor(1.0), atol=1e-5)
+    kl = gen.kldiv(32)
+    assert kl.shape == (32, 1)
+    nll = gen.energy(x)
+    assert torch.allclose(nll, prior.energy(z) + 0.5)
+    ess = bg.effective_sample_size(lw.view(-1))
+    assert 0 < float(ess) <= 64.0 + 1e-3
