@@ -46,23 +46,32 @@ def make_workload(name, dev):
     return gen, sampler, desc
 
 
-def kernel_roofline(gen, zs, workload, steps):
-    """HIP-event timing of the dominant hand-written kernel on the current stream."""
-    import bgflow_amd as bg
-    dev = zs[0].device
-    B = zs[0].shape[0]
+def layer_macs(block):
+    """multiply-accumulates per sample of a coupling block's conditioner"""
+    macs = 0
+    for m in block.modules():
+        if isinstance(m, torch.nn.Linear):
+            macs += m.in_features * m.out_features
+    return macs
+
+
+def timed_steps(gen, zs, steps):
+    """K passes of the flow with HIP events around every hand-written-kernel block (events are recorded
+    on the current stream = the stream the kernels are launched on).  Returns {block index: [ms,...]}."""
+    from bgflow_amd.flow import CouplingFlow, WrapFlow
+    evs = []
     with torch.no_grad():
-        # locate the most expensive coupling layer type: time every block once with events
-        xs = tuple(zs)
-        timings = []
-        for block in gen.flow:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-            *xs, _ = block(*xs)
-            ev1.record()
-            torch.cuda.synchronize(dev)
-            timings.append(ev0.elapsed_time(ev1))
-    return timings
+        for _ in range(steps):
+            xs = tuple(zs)
+            total = 0.0
+            for i, block in enumerate(gen.flow):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                *xs, dd = block(*xs)
+                e1.record()
+                total = total + dd
+                evs.append((i, e0, e1))
+    return evs
 
 
 def cpu_baseline(workload, n_samples):
@@ -105,20 +114,14 @@ def main():
     g = torch.Generator(device=dev).manual_seed(dp.rank_seed(1234, rank))
     zs = sampler(args.batch, g)
 
-    def step():
-        with torch.no_grad():
-            *x, dlogp = gen.flow(*zs)
-        return x, dlogp
-
     for _ in range(args.warmup):
-        step()
+        timed_steps(gen, zs, 1)
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    evs = timed_steps(gen, zs, args.steps)
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()
@@ -133,20 +136,32 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
 
     if rank == 0:
-        block_ms = kernel_roofline(gen, zs, args.workload, args.steps)
-        k = int(np.argmax(block_ms))
-        # algorithmic bytes of the dominant block (per launch) -- see DESIGN.md
         from bgflow_amd.flow import CouplingFlow
-        blk = gen.flow[k]
-        alg = None
-        if isinstance(blk, CouplingFlow):
-            d_t = zs[blk.transformed_indices[0]].shape[1] if args.workload == "cfg3" else 32
-        roof = dict(bound="hbm", achieved=ALG_BYTES[args.workload] * args.batch / (ms_per_step * 1e-3) / 1e9,
-                    peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
-                    note="whole-step algorithmic bytes / step time (per-kernel breakdown: see DESIGN.md)",
-                    block_ms=[round(v, 3) for v in block_ms])
+        n_blocks = len(gen.flow)
+        block_ms = [0.0] * n_blocks
+        for i, e0, e1 in evs:
+            block_ms[i] += e0.elapsed_time(e1) / args.steps
+        coupling = [i for i, b in enumerate(gen.flow) if isinstance(b, CouplingFlow)]
+        # dominant kernel = the coupling-layer kernel (one launch per coupling block)
+        t_coupling_ms = sum(block_ms[i] for i in coupling)
+        n_launch = len(coupling)
+        avg_launch_s = 1e-3 * t_coupling_ms / n_launch
+        flops_per_launch = 2.0 * sum(layer_macs(gen.flow[i]) for i in coupling) / n_launch * args.batch
+        alg_bytes_step = ALG_BYTES[args.workload] * args.batch
+        if args.workload == "cfg3":
+            roof = dict(bound="mfma", achieved=flops_per_launch / avg_launch_s / 1e12, peak=MFMA_F32_PEAK_TFLOPS,
+                        unit="TFLOP/s", traffic=None,
+                        kernel="coupling_rqs_dense_kernel (fused DenseNet-on-MFMA + RQ-spline coupling layer)",
+                        launches_per_step=n_launch, avg_launch_ms=1e3 * avg_launch_s,
+                        flops_per_launch=flops_per_launch,
+                        hbm_view=dict(algorithmic_bytes_per_step=alg_bytes_step,
+                                      achieved_GBs=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak_GBs=HBM_PEAK_GBS))
+        else:
+            roof = dict(bound="hbm", achieved=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak=HBM_PEAK_GBS,
+                        unit="GB/s", traffic=None, kernel="affine_kernel + hipBLASLt conditioner GEMMs")
         roof["frac"] = roof["achieved"] / roof["peak"]
-        out = dict(metric="flow samples/s (fwd+log|detJ|)", value=value, unit="samples/s", n_gpus=world,
+        roof["block_ms"] = [round(v, 3) for v in block_ms]
+        out = dict(metric="flow samples/s (fwd+log|detJ|) at batch 2^20", value=value, unit="samples/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload=desc, batch_per_gpu=args.batch, global_batch=args.batch * world,
