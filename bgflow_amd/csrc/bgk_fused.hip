@@ -56,6 +56,7 @@ struct FusedArgs {
     const float4* W0; int T0;        /* layer 0: T0 = ceil(n_in/2) k-steps rounded up to x4 (+1 bias step) */
     const float4* W1;                /* 64 + 1 steps */
     const float4* W2; int n_chunks;  /* per chunk 64 + 1 steps */
+    int last_tiles;                  /* live 32-row tiles of the last chunk */
     int act;
     const float* y; int64_t ldy;
     int64_t B; int d; int inverse;
@@ -104,11 +105,13 @@ __device__ __forceinline__ void wload_step(f32x4& dst, unsigned voff, const char
     wload<(S % 4) * 1024>(dst, voff + (unsigned)((S / 4) * 4096), base);   /* one SGPR base per GEMM */
 }
 
+/* NT = number of live output tiles (the last parameter chunk of a layer may need fewer than 4) */
+template <int NT = 4>
 __device__ __forceinline__ void mfma4v(f32x16 (&acc)[4], const f32x4& a, float b) {
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b, acc[3], 0, 0, 0);
+    if constexpr (NT > 1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[1], 0, 0, 0);
+    if constexpr (NT > 2) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b, acc[2], 0, 0, 0);
+    if constexpr (NT > 3) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b, acc[3], 0, 0, 0);
 }
 
 /* acc[4] = W[128 x 128] * h + bias   with h in accumulator layout (k order = mfma order).
@@ -136,14 +139,14 @@ __device__ __forceinline__ void gstart(Stream& st, const float4* Wbase, int lane
 }
 
 /* k-step S: wait for its A block, refill the ring slot, 4 MFMAs (B = in[S/16][S%16] or the bias 1/0) */
-template <int S>
+template <int S, int NT = 4>
 __device__ __forceinline__ void gstep(Stream& st, f32x16 (&out)[4], const f32x16 (&in)[4]) {
     constexpr int newer = (HSTEPS - 1 - S) < (PF - 1) ? (HSTEPS - 1 - S) : (PF - 1);
     wwait<newer>(st.ring[S % PF]);
     const f32x4 a = st.ring[S % PF];
     if constexpr (S + PF < HSTEPS) wload_step<S + PF>(st.ring[S % PF], st.voff, st.base);
-    if constexpr (S < 64) mfma4v(out, a, in[S / 16][S % 16]);
-    else mfma4v(out, a, st.bias_b);
+    if constexpr (S < 64) mfma4v<NT>(out, a, in[S / 16][S % 16]);
+    else mfma4v<NT>(out, a, st.bias_b);
 }
 
 /* GEMM whose INPUT tiles 1..3 still need their activation: tile 0 must already be activated; tile
@@ -167,12 +170,12 @@ struct ActGemm {
 };
 
 /* plain steps [S, E) */
-template <int S, int E>
+template <int S, int E, int NT = 4>
 struct PlainSteps {
     static __device__ __forceinline__ void run(Stream& st, f32x16 (&out)[4], const f32x16 (&in)[4]) {
         if constexpr (S < E) {
-            gstep<S>(st, out, in);
-            PlainSteps<S + 1, E>::run(st, out, in);
+            gstep<S, NT>(st, out, in);
+            PlainSteps<S + 1, E, NT>::run(st, out, in);
         }
     }
 };
@@ -409,40 +412,27 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedAr
         __builtin_amdgcn_wave_barrier();
 
         /* ---- layer 0: h = act(W0 * x + b0), B operand from LDS, natural k order, bias = last step.
-         * T0 (k-steps) is padded to a multiple of 4 with zero weights on the host; groups of 4 steps are
-         * double-buffered (group g+1 in flight while group g feeds the MFMAs). ---- */
+         * T0 (k-steps) is padded to a multiple of 4 with zero weights on the host. ---- */
         f32x16 h[4], acc[4];
         zero4(h);
         {
             const char* base = reinterpret_cast<const char*>(a.W0);
             const unsigned voff = (unsigned)lane * 16u;
             const int G = a.T0 >> 2;
-            f32x4 A0, A1, A2, A3, B0, B1, B2, B3;
-            wload<0>(A0, voff, base); wload<1024>(A1, voff, base); wload<2048>(A2, voff, base); wload<3072>(A3, voff, base);
-            for (int g = 0; g < G; g += 2) {
-                {
-                    const int gn = (g + 1 < G) ? g + 1 : G - 1;          /* last group again = dummy prefetch */
-                    const char* bn = base + (size_t)gn * 4096;
-                    wload<0>(B0, voff, bn); wload<1024>(B1, voff, bn); wload<2048>(B2, voff, bn); wload<3072>(B3, voff, bn);
-                }
+            /* one group = 4 k-steps: 4 loads, then counted waits -- loads and the waits that retire them stay
+             * in ONE basic block (asm destinations must not be live across a branch: hipcc may copy them while
+             * the data is still in flight).  The exposed L2 round trip per group is ~2 % of the tile time. */
+            for (int g = 0; g < G; ++g) {
+                f32x4 A0, A1, A2, A3;
+                const char* bn = base + (size_t)g * 4096;
+                wload<0>(A0, voff, bn); wload<1024>(A1, voff, bn); wload<2048>(A2, voff, bn); wload<3072>(A3, voff, bn);
                 const float* xr = s_p + (8 * g + hh) * SROW + j;
-                wwait<7>(A0); mfma4v(h, A0, xr[0 * 2 * SROW]);
-                wwait<6>(A1); mfma4v(h, A1, xr[1 * 2 * SROW]);
-                wwait<5>(A2); mfma4v(h, A2, xr[2 * 2 * SROW]);
-                wwait<4>(A3); mfma4v(h, A3, xr[3 * 2 * SROW]);
-                if (g + 1 < G) {
-                    const int gn = (g + 2 < G) ? g + 2 : G - 1;
-                    const char* bn = base + (size_t)gn * 4096;
-                    wload<0>(A0, voff, bn); wload<1024>(A1, voff, bn); wload<2048>(A2, voff, bn); wload<3072>(A3, voff, bn);
-                    const float* xq = xr + 8 * SROW;
-                    wwait<7>(B0); mfma4v(h, B0, xq[0 * 2 * SROW]);
-                    wwait<6>(B1); mfma4v(h, B1, xq[1 * 2 * SROW]);
-                    wwait<5>(B2); mfma4v(h, B2, xq[2 * 2 * SROW]);
-                    wwait<4>(B3); mfma4v(h, B3, xq[3 * 2 * SROW]);
-                }
+                const float x0 = xr[0 * 2 * SROW], x1 = xr[1 * 2 * SROW], x2 = xr[2 * 2 * SROW], x3 = xr[3 * 2 * SROW];
+                wwait<3>(A0); mfma4v(h, A0, x0);
+                wwait<2>(A1); mfma4v(h, A1, x1);
+                wwait<1>(A2); mfma4v(h, A2, x2);
+                wwait<0>(A3); mfma4v(h, A3, x3);
             }
-            /* retire the dummy prefetches before their registers are reused */
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(A0), "+v"(A1), "+v"(A2), "+v"(A3), "+v"(B0), "+v"(B1), "+v"(B2), "+v"(B3));
             /* bias step (index T0) */
             const f32x4 ab = reinterpret_cast<const f32x4*>(base + (size_t)a.T0 * 1024)[lane];
             mfma4v(h, ab, lane < 32 ? 1.0f : 0.0f);
@@ -482,13 +472,18 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedAr
             int bins[3];
             if (c + 1 < a.n_chunks) {
                 zero4(h);
-                gstart(st, a.W2 + (size_t)(c + 1) * HSTEPS * 64, lane);
+                const float4* Wn = a.W2 + (size_t)(c + 1) * HSTEPS * 64;
 #if BGK_PIPE_SPLINE
+                gstart(st, Wn, lane);
                 LiveGemm g{st, h, acc};
                 spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
                 PlainSteps<3 * HOOKS, HSTEPS>::run(st, h, acc);
 #else
-                PlainSteps<0, HSTEPS>::run(st, h, acc);
+                /* the last chunk holds d - 5 (n_chunks - 1) dims = ceil(25 nd / 32) live row tiles: skip the rest */
+                /* NB: the asm loads of gstart() and the waits that retire them must sit in ONE basic block --
+                 * across a branch hipcc may copy the (still in flight) destination registers */
+                if (c + 2 == a.n_chunks && a.last_tiles <= 2) { gstart(st, Wn, lane); PlainSteps<0, HSTEPS, 2>::run(st, h, acc); }
+                else { gstart(st, Wn, lane); PlainSteps<0, HSTEPS>::run(st, h, acc); }
                 NoGemm g;
                 spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #endif
@@ -573,6 +568,7 @@ extern "C" int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_
     a.W0 = reinterpret_cast<const float4*>(W0p); a.T0 = ((n_in + 1) / 2 + 3) & ~3;   /* padded to x4 by the packer */
     a.W1 = reinterpret_cast<const float4*>(W1p);
     a.W2 = reinterpret_cast<const float4*>(W2p); a.n_chunks = (d + DPC - 1) / DPC;
+    a.last_tiles = ((d - (a.n_chunks - 1) * DPC) * PPD + 31) / 32;
     a.act = act; a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.inverse = inverse;
     a.circ_mask = circ_mask;
     a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
