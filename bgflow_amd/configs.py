@@ -157,6 +157,54 @@ def make_ala2_spline_generator(device=None, dtype=torch.float32, hidden=(128, 12
     return gen.to(device) if device is not None else gen
 
 
+def _affine_coupling(what, on, dims, circular, slot, hidden=(128, 128)):
+    """One builder-style affine (RealNVP) coupling: ``what`` transformed, fields ``on`` condition
+    (conditioner_factory.py:236-241: separate shift and scale DenseNets, SiLU hidden layers)."""
+    on = (on,) if isinstance(on, str) else tuple(on)
+    d_what = dims[what]
+    d_nc = sum(dims[f] for f in on if not circular[f])
+    d_c = sum(dims[f] for f in on if circular[f])
+    dim_in = d_nc + 2 * d_c
+
+    def net():
+        n = DenseNet([dim_in, *hidden, d_what], activation=torch.nn.SiLU())
+        if d_c > 0:
+            idx = np.concatenate([np.arange(dims[f]) + sum(dims[g] for g in on[:k])
+                                  for k, f in enumerate(on) if circular[f]])
+            n = WrapPeriodic(n, indices=idx)
+        return n
+    transformer = AffineTransformer(shift_transformation=net(), scale_transformation=net(), is_circular=False)
+    return CouplingFlow(transformer, transformed_indices=[slot[what]], cond_indices=[slot[f] for f in on])
+
+
 def make_ala2_augmented_generator(device=None, dtype=torch.float32):
-    """cfg 5 (augmented normalizing flow): placeholder until the mixed affine/spline recipe is wired."""
-    raise NotImplementedError("cfg 5 (augmented flow) is not assembled yet")
+    """cfg 5 (augmented normalizing flow): the cfg-3 coordinate transform + 66 auxiliary dims; 16 couplings
+    = 10 RQ-spline + 6 affine, 5 icdf maps, Mixed IC.  ``flow(bonds, angles, torsions, fixed, aug) ->
+    (x[B,66], aug[B,66], dlogp)``."""
+    zmat, rigid, xyz = ala2_system()
+    ic = MixedCoordinateTransformation(ala2_whitening_data(dtype), zmat, rigid, keepdims=9, raise_warnings=False)
+    fields = IC_FIELDS + ("AUGMENTED",)
+    dims = {"BONDS": ic.dim_bonds, "ANGLES": ic.dim_angles, "TORSIONS": ic.dim_torsions, "FIXED": ic.dim_fixed,
+            "AUGMENTED": 66}
+    circular = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False, "AUGMENTED": False}
+    slot = {f: i for i, f in enumerate(fields)}
+    ctx = dict(dtype=dtype)
+    layers = []
+    for _ in range(4):
+        layers.append(_spline_coupling("TORSIONS", "AUGMENTED", dims, circular, slot))
+        layers.append(_affine_coupling("AUGMENTED", "TORSIONS", dims, circular, slot))
+    for _ in range(2):
+        layers.append(_spline_coupling("BONDS", "ANGLES", dims, circular, slot))
+        layers.append(_spline_coupling("ANGLES", "BONDS", dims, circular, slot))
+    for _ in range(2):
+        layers.append(_spline_coupling("FIXED", "AUGMENTED", dims, circular, slot))
+        layers.append(_affine_coupling("AUGMENTED", ("FIXED", "BONDS", "ANGLES"), dims, circular, slot))
+    layers += _ic_domain_maps(dims, slot, ctx)
+    layers.append(WrapFlow(InverseFlow(ic), indices=[0, 1, 2, 3], out_indices=(0,)))
+    flow = hash_init_(SequentialFlow(layers))
+    prior = ProductDistribution([UniformDistribution(torch.zeros(dims[f], **ctx), torch.ones(dims[f], **ctx))
+                                 for f in fields])
+    target = ProductDistribution([NormalDistribution(66, torch.tensor(xyz[0], dtype=dtype)),
+                                  NormalDistribution(66, torch.zeros(66, **ctx))])
+    gen = BoltzmannGenerator(prior, flow, target)
+    return gen.to(device) if device is not None else gen

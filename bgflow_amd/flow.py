@@ -16,7 +16,7 @@ import torch
 
 __all__ = [
     "Flow", "SequentialFlow", "InverseFlow", "SplitFlow", "MergeFlow", "SwapFlow", "CouplingFlow",
-    "WrapFlow", "SetConstantFlow",
+    "WrapFlow", "SetConstantFlow", "StochasticAugmentation",
 ]
 
 
@@ -285,3 +285,36 @@ class SetConstantFlow(Flow):
         batch = list(ys[0].shape[:self.n_event_dims0])
         dlogp = torch.zeros(batch + [1], device=ys[0].device, dtype=ys[0].dtype)
         return (*ys, dlogp)
+
+
+class StochasticAugmentation(Flow):
+    """Append auxiliary coordinates sampled from ``distribution`` (forward) / strip them (inverse);
+    their energy enters dlogp (bgflow/nn/flow/stochastic/augment.py:27-55).  Pure tuple plumbing +
+    the distribution's own sample/energy (stock torch ops)."""
+
+    def __init__(self, distribution):
+        super().__init__()
+        self.distribution = distribution
+        self._cached_momenta_forward = None
+        self._cached_momenta_backward = None
+
+    def _forward(self, q, **kwargs):
+        temperature = kwargs.get("temperature", 1.0)
+        p = kwargs.get("momenta", None)
+        if p is None:
+            p = self.distribution.sample(q.shape[0], temperature=temperature)
+            dlogp = self.distribution.energy(p, temperature=temperature)
+        else:
+            dlogp = torch.zeros(p.shape[0], 1).to(p)
+        if kwargs.get("cache_momenta", False):
+            self._cached_momenta_forward = p
+        return torch.cat([q, p], dim=1), dlogp
+
+    def _inverse(self, x, **kwargs):
+        dim = self.distribution.dim
+        p = x[:, dim:]
+        if kwargs.get("cache_momenta", False):
+            self._cached_momenta_backward = p
+        if kwargs.get("return_momenta", False):
+            return x, torch.zeros(p.shape[0], 1).to(p)
+        return x[:, :dim], -self.distribution.energy(p, temperature=kwargs.get("temperature", 1.0))

@@ -230,3 +230,28 @@ def test_flow16_whole_flow(golden):
     noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
     assert np.abs(dl - G["dlogp64"]).max() <= 1e-5 * np.abs(G["dlogp64"]).max() + noise
     assert (np.abs(dl - G["dlogp32"]) / np.abs(G["dlogp32"])).max() < 2e-5
+
+
+def test_augmented_flow_cfg5(golden):
+    """cfg 5 (10 spline + 6 affine couplings over 5 fields incl. 66 auxiliary dims) vs the reference builder flow"""
+    import torch
+    from bgflow_amd import configs
+    from oracle import flow_oracle as fo
+    G = golden("g_aug")
+    u = [G[k] for k in ("u_bonds", "u_angles", "u_torsions", "u_fixed", "u_aug")]
+    gen64 = configs.make_ala2_augmented_generator(dtype=torch.float64).double()
+    assert sum(p.numel() for p in gen64.flow.parameters()) == int(G["n_params"]) and len(gen64.flow) == int(G["n_blocks"])
+    assert [type(b).__name__ + ":" + type(getattr(b, "transformer", b)).__name__ for b in gen64.flow] == list(G["block_types"])
+    (x, aug), dl = fo.run_flow(gen64.flow, u, dtype=np.float64)
+    np.testing.assert_allclose(x, G["x64"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(aug, G["aug64"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(dl, G["dlogp64"], rtol=1e-11, atol=1e-8)
+    zb, dli = fo.run_flow(gen64.flow, [G["x64"], G["aug64"]], inverse=True, dtype=np.float64)
+    np.testing.assert_allclose(dli, G["dlogp_inv64"], rtol=1e-8, atol=1e-6)
+    # f32: this flow is ill-conditioned in f32 (the reference's own f32 path is 0.86 off its f64 result in dlogp):
+    # require our f32 evaluation to be as close to the f64 truth as the reference's
+    gen32 = configs.make_ala2_augmented_generator()
+    (x, aug), dl = fo.run_flow(gen32.flow, u, dtype=np.float32)
+    assert np.abs(dl - G["dlogp64"]).max() <= 2 * np.abs(G["dlogp32"] - G["dlogp64"]).max()
+    assert np.abs(aug - G["aug64"]).max() <= 2 * np.abs(G["aug32"] - G["aug64"]).max()
+    # (clamped icdf inputs, eps = 1e-7 = half an f32 ulp of 1.0, dominate: each costs ~0.17 in log-prob in f32)
