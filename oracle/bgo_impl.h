@@ -157,6 +157,144 @@ int64_t FN(bgo_rqs)(const REAL* y, int64_t ldy, const REAL* params, int64_t ldp,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Backward (vector-Jacobian product) of bgo_rqs for first-order losses.  The reference has no
+ * backward code: it differentiates the op chain above with torch autograd; this is the analytic
+ * VJP of the same chain (softmax -> min + scale*p -> cumsum knots -> gather -> rational-quadratic
+ * evaluate / implicit root), pinned against autograd gradients of the reference in
+ * tests/test_oracle_golden.py.  The bin index is piecewise constant (no gradient); a clamped
+ * (out-of-domain) input gets zero input-gradient like torch.clamp.
+ *   g_out [B,d] (ldgo), g_dlogp [B]  ->  g_y [B,d] (ldgy), g_params [B,P] (ldgp, fully written)
+ * ------------------------------------------------------------------------------------------ */
+void FN(bgo_rqs_backward)(const REAL* y, int64_t ldy, const REAL* params, int64_t ldp,
+                          const int32_t* nc_slot, int64_t B, int d, int K, int bgflow_inverse,
+                          double left_d, double right_d, double bottom_d, double top_d,
+                          double min_w_d, double min_h_d, double min_d_d, int identity_init,
+                          const REAL* g_out, int64_t ldgo, const REAL* g_dlogp,
+                          REAL* g_y, int64_t ldgy, REAL* g_params, int64_t ldgp)
+{
+    const REAL beta = (REAL)(identity_init ? (0.6931471805599453 / (1.0 - min_d_d)) : 1.0);
+    const REAL w_scale = (REAL)(1.0 - min_w_d * K);
+    const REAL h_scale = (REAL)(1.0 - min_h_d * K);
+    const REAL min_w = (REAL)min_w_d, min_h = (REAL)min_h_d, min_d = (REAL)min_d_d;
+    const REAL left = (REAL)left_d, right = (REAL)right_d, bottom = (REAL)bottom_d, top = (REAL)top_d;
+    const REAL xspan = (REAL)(right_d - left_d), yspan = (REAL)(top_d - bottom_d);
+    int n_nc = 0;
+    for (int j = 0; j < d; ++j) if (nc_slot[j] >= 0) n_nc++;
+    const int P = 3 * d * K + n_nc;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        const REAL* prow = params + b * ldp;
+        REAL* grow = g_params + b * ldgp;
+        for (int q = 0; q < P; ++q) grow[q] = (REAL)0;
+        for (int j = 0; j < d; ++j) {
+            const REAL* uw = prow + (int64_t)j * K;
+            const REAL* uh = prow + (int64_t)d * K + (int64_t)j * K;
+            const REAL* us = prow + (int64_t)2 * d * K + (int64_t)j * K;
+            REAL pw[BGO_MAX_BINS], ph[BGO_MAX_BINS], cw[BGO_MAX_BINS + 1], ch[BGO_MAX_BINS + 1];
+            {
+                REAL m = uw[0]; for (int k = 1; k < K; ++k) m = uw[k] > m ? uw[k] : m;
+                REAL s = (REAL)0; for (int k = 0; k < K; ++k) { pw[k] = R_EXP(uw[k] - m); s += pw[k]; }
+                REAL c = (REAL)0; cw[0] = (REAL)0;
+                for (int k = 0; k < K; ++k) { pw[k] = pw[k] / s; c += min_w + w_scale * pw[k]; cw[k + 1] = c; }
+                for (int k = 0; k <= K; ++k) cw[k] = xspan * cw[k] + left;
+                cw[0] = left; cw[K] = right;
+            }
+            {
+                REAL m = uh[0]; for (int k = 1; k < K; ++k) m = uh[k] > m ? uh[k] : m;
+                REAL s = (REAL)0; for (int k = 0; k < K; ++k) { ph[k] = R_EXP(uh[k] - m); s += ph[k]; }
+                REAL c = (REAL)0; ch[0] = (REAL)0;
+                for (int k = 0; k < K; ++k) { ph[k] = ph[k] / s; c += min_h + h_scale * ph[k]; ch[k + 1] = c; }
+                for (int k = 0; k <= K; ++k) ch[k] = yspan * ch[k] + bottom;
+                ch[0] = bottom; ch[K] = top;
+            }
+            REAL x = y[b * ldy + j];
+            int clamped = 0;
+            if (x < left || x > right) { clamped = 1; x = x < left ? left : (x > right ? right : x); }
+            const REAL* knots = bgflow_inverse ? cw : ch;
+            int idx = -1;
+            for (int k = 0; k <= K; ++k) idx += (x >= (k == K ? knots[k] + (REAL)1e-6 : knots[k])) ? 1 : 0;
+            if (idx < 0) idx = 0;
+            if (idx > K - 1) idx = K - 1;
+            const int hi_is_last = (idx + 1 == K);
+            const REAL s_lo = us[idx];
+            const REAL s_hi = !hi_is_last ? us[idx + 1] : ((nc_slot[j] >= 0) ? prow[(int64_t)3 * d * K + nc_slot[j]] : us[0]);
+            const REAL d0 = min_d + R_SOFTPLUS(s_lo, beta), d1 = min_d + R_SOFTPLUS(s_hi, beta);
+            const REAL cw_i = cw[idx], W_i = cw[idx + 1] - cw[idx], ch_i = ch[idx], H_i = ch[idx + 1] - ch[idx];
+            const REAL delta = H_i / W_i, S = d0 + d1 - (REAL)2 * delta;
+            REAL theta;
+            if (!bgflow_inverse) {
+                REAL dx = x - ch_i;
+                REAL a = dx * S + H_i * (delta - d0), bb = H_i * d0 - dx * S, c = -delta * dx;
+                theta = ((REAL)2 * c) / (-bb - R_SQRT(bb * bb - (REAL)4 * a * c));
+            } else {
+                theta = (x - cw_i) / W_i;
+            }
+            const REAL t = theta * ((REAL)1 - theta), tp = (REAL)1 - (REAL)2 * theta, omt = (REAL)1 - theta;
+            const REAL N = delta * theta * theta + d0 * t, den = delta + S * t;
+            const REAL Q = N / den;
+            const REAL N_th = (REAL)2 * delta * theta + d0 * tp, den_th = S * tp;
+            const REAL Q_th = (N_th * den - N * den_th) / (den * den);
+            const REAL Q_de = (theta * theta * den - N * ((REAL)1 - (REAL)2 * t)) / (den * den);
+            const REAL Q_d0 = (t * den - N * t) / (den * den);
+            const REAL Q_d1 = (-N * t) / (den * den);
+            const REAL M = d1 * theta * theta + (REAL)2 * delta * t + d0 * omt * omt;
+            const REAL lf_th = ((REAL)2 * d1 * theta + (REAL)2 * delta * tp - (REAL)2 * d0 * omt) / M - (REAL)2 * den_th / den;
+            const REAL lf_de = (REAL)2 / delta + (REAL)2 * t / M - (REAL)2 * ((REAL)1 - (REAL)2 * t) / den;
+            const REAL lf_d0 = omt * omt / M - (REAL)2 * t / den;
+            const REAL lf_d1 = theta * theta / M - (REAL)2 * t / den;
+            const REAL gy = g_out[b * ldgo + j], gl = g_dlogp[b];
+            REAL G_de, G_d0, G_d1, G_H, G_W, G_cw, G_ch, gx;
+            if (bgflow_inverse) {
+                const REAL G_th = gy * H_i * Q_th + gl * lf_th;
+                G_de = gy * H_i * Q_de + gl * lf_de;
+                G_d0 = gy * H_i * Q_d0 + gl * lf_d0;
+                G_d1 = gy * H_i * Q_d1 + gl * lf_d1;
+                G_H = gy * Q + G_de / W_i;
+                G_W = -G_de * delta / W_i - G_th * theta / W_i;
+                G_ch = gy;
+                G_cw = -G_th / W_i;
+                gx = G_th / W_i;
+            } else {
+                const REAL A_th = gy * W_i - gl * lf_th;     /* out = cw_i + W_i theta, lad = -lf */
+                const REAL inv = (REAL)1 / (H_i * Q_th);
+                G_de = -gl * lf_de - A_th * Q_de / Q_th;
+                G_d0 = -gl * lf_d0 - A_th * Q_d0 / Q_th;
+                G_d1 = -gl * lf_d1 - A_th * Q_d1 / Q_th;
+                G_H = G_de / W_i - A_th * Q * inv;
+                G_W = -G_de * delta / W_i + gy * theta;
+                G_cw = gy;
+                G_ch = -A_th * inv;
+                gx = A_th * inv;
+            }
+            g_y[b * ldgy + j] = clamped ? (REAL)0 : gx;
+            /* knots: W_i = cw[i+1] - cw[i] (cw[0], cw[K] are constants) -> W'_m via the cumulative sum -> softmax */
+            {
+                const REAL gA = (idx >= 1) ? (G_cw - G_W) : (REAL)0, gB = (idx + 1 <= K - 1) ? G_W : (REAL)0;
+                REAL gp[BGO_MAX_BINS], dot = (REAL)0;
+                for (int m = 0; m < K; ++m) { gp[m] = w_scale * xspan * ((m < idx ? gA : (REAL)0) + (m <= idx ? gB : (REAL)0)); dot += pw[m] * gp[m]; }
+                for (int m = 0; m < K; ++m) grow[(int64_t)j * K + m] = pw[m] * (gp[m] - dot);
+            }
+            {
+                const REAL gA = (idx >= 1) ? (G_ch - G_H) : (REAL)0, gB = (idx + 1 <= K - 1) ? G_H : (REAL)0;
+                REAL gp[BGO_MAX_BINS], dot = (REAL)0;
+                for (int m = 0; m < K; ++m) { gp[m] = h_scale * yspan * ((m < idx ? gA : (REAL)0) + (m <= idx ? gB : (REAL)0)); dot += ph[m] * gp[m]; }
+                for (int m = 0; m < K; ++m) grow[(int64_t)d * K + (int64_t)j * K + m] = ph[m] * (gp[m] - dot);
+            }
+            /* slopes: dD/ds = sigmoid(beta s) (1 beyond the softplus threshold) */
+            {
+                const REAL z0 = s_lo * beta, z1 = s_hi * beta;
+                const REAL sg0 = z0 > (REAL)20 ? (REAL)1 : (REAL)1 / ((REAL)1 + R_EXP(-z0));
+                const REAL sg1 = z1 > (REAL)20 ? (REAL)1 : (REAL)1 / ((REAL)1 + R_EXP(-z1));
+                grow[(int64_t)2 * d * K + (int64_t)j * K + idx] += G_d0 * sg0;
+                if (!hi_is_last) grow[(int64_t)2 * d * K + (int64_t)j * K + idx + 1] += G_d1 * sg1;
+                else if (nc_slot[j] >= 0) grow[(int64_t)3 * d * K + nc_slot[j]] += G_d1 * sg1;
+                else grow[(int64_t)2 * d * K + (int64_t)j * K] += G_d1 * sg1;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Affine (RealNVP / NICE) transformer: nn/flow/transformer/affine.py:35-70.
  *   mu [B,d] (NULL -> 0), s_raw [B,d] = scale-net output before tanh (NULL -> log_sigma = 0),
  *   log_sigma = tanh(s_raw) * exp(log_alpha)  [- mean over d if preserve_volume]
@@ -191,6 +329,50 @@ void FN(bgo_affine)(const REAL* y, int64_t ldy, const REAL* mu, int64_t ldmu,
         }
         dlogp[b] = acc;
     }
+}
+
+/* Backward (VJP) of bgo_affine; the reference uses torch autograd through affine.py:35-70.
+ * g_log_alpha is RETURNED as the sum over the batch (double accumulator). */
+double FN(bgo_affine_backward)(const REAL* y, int64_t ldy, const REAL* mu, int64_t ldmu,
+                               const REAL* s_raw, int64_t lds, REAL log_alpha, int preserve_volume,
+                               int is_circular, int inverse, int64_t B, int d,
+                               const REAL* g_out, int64_t ldgo, const REAL* g_dlogp,
+                               REAL* g_y, REAL* g_mu, REAL* g_s)
+{
+    const REAL alpha = R_EXP(log_alpha);
+    double g_alpha = 0.0;
+    (void)is_circular;   /* d(o mod 1)/do = 1 */
+#pragma omp parallel for schedule(static) reduction(+ : g_alpha)
+    for (int64_t b = 0; b < B; ++b) {
+        REAL mean = (REAL)0;
+        if (s_raw && preserve_volume) {
+            for (int j = 0; j < d; ++j) mean += R_TANH(s_raw[b * lds + j]) * alpha;
+            mean = mean / (REAL)d;
+        }
+        REAL gmean = (REAL)0;
+        for (int pass = 0; pass < 2; ++pass) {
+            /* pass 0: accumulate mean of g_ls (only needed for preserve_volume); pass 1: write */
+            if (pass == 0 && !(s_raw && preserve_volume)) continue;
+            REAL acc = (REAL)0;
+            for (int j = 0; j < d; ++j) {
+                REAL th = s_raw ? R_TANH(s_raw[b * lds + j]) : (REAL)0;
+                REAL ls = s_raw ? th * alpha - mean : (REAL)0;
+                REAL m = mu ? mu[b * ldmu + j] : (REAL)0;
+                REAL v = y[b * ldy + j], go = g_out[b * ldgo + j], gl = g_dlogp[b];
+                REAL gy, gm, gls;
+                if (!inverse) { REAL e = R_EXP(ls); gy = go * e; gm = go; gls = go * e * v + gl; }
+                else { REAL e = R_EXP(-ls); gy = go * e; gm = -go * e; gls = -go * e * (v - m) - gl; }
+                if (pass == 0) { acc += gls; continue; }
+                REAL gl_raw = gls - gmean;
+                g_y[b * d + j] = gy;
+                if (g_mu) g_mu[b * d + j] = gm;
+                if (g_s) g_s[b * d + j] = gl_raw * alpha * ((REAL)1 - th * th);
+                g_alpha += (double)(gl_raw * th);
+            }
+            if (pass == 0) gmean = acc / (REAL)d;
+        }
+    }
+    return s_raw ? g_alpha * (double)alpha : 0.0;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -104,6 +104,28 @@ def rqs(y, params, is_circular=False, inverse=False, left=0.0, right=1.0, bottom
     return out, dlogp[:, None]
 
 
+def rqs_backward(y, params, g_out, g_dlogp, is_circular=False, inverse=False, left=0.0, right=1.0, bottom=0.0,
+                 top=1.0, min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, identity_init=True,
+                 n_bins=None, dtype=np.float32):
+    """Analytic VJP of ``rqs``: returns (g_y [B,d], g_params [B,P]) for upstream g_out [B,d], g_dlogp [B,1]."""
+    sfx, _ = _suffix(dtype)
+    y, params, g_out = _np(y, dtype), _np(params, dtype), _np(g_out, dtype)
+    g_dlogp = _np(np.asarray(g_dlogp).reshape(-1), dtype)
+    B, d = y.shape
+    slots = nc_slots(is_circular, d)
+    n_nc = int((slots >= 0).sum())
+    P = params.shape[1]
+    K = (P - n_nc) // (3 * d) if n_bins is None else n_bins
+    g_y = np.empty((B, d), dtype)
+    g_p = np.empty((B, P), dtype)
+    getattr(lib(), "bgo_rqs_backward" + sfx)(
+        _ptr(y), _c_i64(d), _ptr(params), _c_i64(P), _ptr(slots), _c_i64(B), _c_int(d), _c_int(K), _c_int(int(inverse)),
+        _c_dbl(left), _c_dbl(right), _c_dbl(bottom), _c_dbl(top), _c_dbl(min_bin_width), _c_dbl(min_bin_height),
+        _c_dbl(min_derivative), _c_int(int(identity_init)), _ptr(g_out), _c_i64(d), _ptr(g_dlogp),
+        _ptr(g_y), _c_i64(d), _ptr(g_p), _c_i64(P))
+    return g_y, g_p
+
+
 def affine(y, mu=None, s_raw=None, log_alpha=-1.0, preserve_volume=False, is_circular=False,
            inverse=False, dtype=np.float32):
     """AffineTransformer._forward/_inverse (transformer/affine.py:35-70) given the shift-net output
@@ -120,6 +142,26 @@ def affine(y, mu=None, s_raw=None, log_alpha=-1.0, preserve_volume=False, is_cir
        _c_int(int(preserve_volume)), _c_int(int(is_circular)), _c_int(int(inverse)), _c_i64(B), _c_int(d),
        _ptr(out), _c_i64(d), _ptr(dlogp))
     return out, dlogp[:, None]
+
+
+def affine_backward(y, mu, s_raw, g_out, g_dlogp, log_alpha=-1.0, preserve_volume=False, is_circular=False,
+                    inverse=False, dtype=np.float32):
+    """Analytic VJP of ``affine``: returns (g_y, g_mu, g_s_raw, g_log_alpha)."""
+    sfx, cr = _suffix(dtype)
+    y, g_out = _np(y, dtype), _np(g_out, dtype)
+    g_dlogp = _np(np.asarray(g_dlogp).reshape(-1), dtype)
+    B, d = y.shape
+    mu = None if mu is None else _np(mu, dtype)
+    s_raw = None if s_raw is None else _np(s_raw, dtype)
+    g_y = np.empty((B, d), dtype)
+    g_mu = np.empty((B, d), dtype) if mu is not None else None
+    g_s = np.empty((B, d), dtype) if s_raw is not None else None
+    fn = getattr(lib(), "bgo_affine_backward" + sfx)
+    fn.restype = ctypes.c_double
+    g_la = fn(_ptr(y), _c_i64(d), _ptr(mu), _c_i64(d), _ptr(s_raw), _c_i64(d), cr(log_alpha),
+              _c_int(int(preserve_volume)), _c_int(int(is_circular)), _c_int(int(inverse)), _c_i64(B), _c_int(d),
+              _ptr(g_out), _c_i64(d), _ptr(g_dlogp), _ptr(g_y), _ptr(g_mu), _ptr(g_s))
+    return g_y, g_mu, g_s, float(g_la)
 
 
 _ACT = {None: 0, "none": 0, "silu": 1, "relu": 2, "tanh": 3}

@@ -454,8 +454,76 @@ def g_aug():
     save("g_aug", u_bonds=u[0], u_angles=u[1], u_torsions=u[2], u_fixed=u[3], u_aug=u[4], **res)
 
 
+# ---------------------------------------------------------------------------------------------
+# G-grads: gradients by torch autograd through the reference (pins the analytic backward kernels)
+# ---------------------------------------------------------------------------------------------
+def g_grads():
+    out = {}
+    K = 8
+    for name, d, circ in [("nc17", 17, np.zeros(17, bool)), ("c9", 9, np.ones(9, bool)),
+                          ("mix6", 6, np.array([1, 0, 1, 1, 0, 0], bool))]:
+        n_nc = int((~circ).sum()); P = 3 * K * d + n_nc; B = 48
+        params = synth(300 + d, B, P, scale=0.7); y = synth(400 + d, B, d, uniform=True)
+        a = synth(500 + d, B, d); bw = synth(600 + d, B, 1)
+        circ_arg = bool(circ[0]) if circ.all() or (~circ).all() else torch.tensor(circ)
+        for inverse in (False, True):
+            for dt, sfx in ((torch.float64, "64"),):
+                p = torch.tensor(params, dtype=dt, requires_grad=True)
+                yy = torch.tensor(y, dtype=dt, requires_grad=True)
+                tr = bg.ConditionalSplineTransformer(FixedNet(p), is_circular=circ_arg)
+                z, dl = tr(torch.zeros(B, 1, dtype=dt), yy, inverse=inverse)
+                ((z * torch.tensor(a, dtype=dt)).sum() + (dl * torch.tensor(bw, dtype=dt)).sum()).backward()
+                tag = f"rqs_{name}_{'inv' if inverse else 'fwd'}"
+                out[f"{tag}_gy{sfx}"] = yy.grad.numpy(); out[f"{tag}_gp{sfx}"] = p.grad.numpy()
+    B, d = 64, 12
+    y = synth(1, B, d); mu = synth(2, B, d); s = synth(3, B, d, scale=1.5); a = synth(4, B, d); bw = synth(5, B, 1)
+    for pv in (False, True):
+        for inverse in (False, True):
+            dt = torch.float64
+            ty, tm, ts = (torch.tensor(v, dtype=dt, requires_grad=True) for v in (y, mu, s))
+            tr = bg.AffineTransformer(FixedNet(tm), FixedNet(ts), preserve_volume=pv).double()
+            z, dl = tr(torch.zeros(B, 1, dtype=dt), ty, inverse=inverse)
+            ((z * torch.tensor(a, dtype=dt)).sum() + (dl * torch.tensor(bw, dtype=dt)).sum()).backward()
+            tag = f"aff_{'vp' if pv else 'plain'}_{'inv' if inverse else 'fwd'}"
+            out.update({f"{tag}_gy": ty.grad.numpy(), f"{tag}_gmu": tm.grad.numpy(), f"{tag}_gs": ts.grad.numpy(),
+                        f"{tag}_gla": tr._log_alpha.grad.numpy()})
+    # KL gradient of the cfg-2 flow (8 affine blocks): per-block d loss / d log_alpha, first-layer bias gradients
+    dim = 64
+    layers = [bg.SplitFlow(dim // 2)]
+    for _ in range(8):
+        layers.append(bg.CouplingFlow(bg.AffineTransformer(
+            shift_transformation=bg.DenseNet([32, 64, 64, 32], activation=torch.nn.ReLU()),
+            scale_transformation=bg.DenseNet([32, 64, 64, 32], activation=torch.nn.Tanh()))))
+        layers.append(bg.SwapFlow())
+    layers.append(bg.MergeFlow(dim // 2))
+    flow = hash_init_(bg.SequentialFlow(layers)).double()
+    target = bg.DoubleWellEnergy(dim)
+    z = torch.tensor(synth(32, 128, dim), dtype=torch.float64)
+    x, dlogp = flow(z)
+    loss = (target.energy(x) - dlogp).mean()
+    loss.backward()
+    out["kl2_loss"] = loss.detach().numpy()
+    out["kl2_g_log_alpha"] = np.array([float(flow[1 + 2 * i].transformer._log_alpha.grad) for i in range(8)])
+    out["kl2_g_bias0"] = np.stack([flow[1 + 2 * i].transformer._shift_transformation._layers[0].bias.grad.numpy() for i in range(8)])
+    out["kl2_gnorm"] = np.sqrt(sum(float((p.grad ** 2).sum()) for p in flow.parameters()))
+    # KL-style gradient through the 16 spline couplings of cfg 3 (IC-space loss: sum of squares of the outputs - dlogp)
+    gen = build_cfg3(torch.float64)
+    sub = gen.flow[:16]
+    u = [torch.tensor(rng_f32(41 + i, 64, dd, uniform=True), dtype=torch.float64) for i, dd in enumerate((17, 17, 17, 9))]
+    *ys, dl = sub(*u)
+    loss = (sum((v ** 2).sum(-1, keepdim=True) for v in ys) - dl).mean()
+    loss.backward()
+    out["kl3_loss"] = loss.detach().numpy()
+    out["kl3_g_bias_last"] = np.stack([np.resize(b.transformer._params_net.net._layers[4].bias.grad.numpy()
+                                                 if hasattr(b.transformer._params_net, "net")
+                                                 else b.transformer._params_net._layers[4].bias.grad.numpy(), 200)
+                                       for b in sub])
+    out["kl3_gnorm"] = np.sqrt(sum(float((p.grad ** 2).sum()) for p in sub.parameters()))
+    save("g_grads", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rqs", "affine", "ic", "flow16", "aug"]
+    which = sys.argv[1:] or ["rqs", "affine", "ic", "flow16", "aug", "grads"]
     if "rqs" in which:
         g_rqs_unit()
     if "affine" in which:
@@ -466,3 +534,5 @@ if __name__ == "__main__":
         g_flow16()
     if "aug" in which:
         g_aug()
+    if "grads" in which:
+        g_grads()

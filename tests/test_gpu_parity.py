@@ -421,3 +421,100 @@ def test_augmented_flow_cfg5_on_gpu(hip_lib, golden, dev):
     assert np.abs(x.cpu().numpy() - G["x64"]).max() <= 3 * np.abs(G["x32"] - G["x64"]).max() + 1e-5
     assert np.abs(aug.cpu().numpy() - G["aug64"]).max() <= 2 * np.abs(G["aug32"] - G["aug64"]).max()
     assert torch.isfinite(dli).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# backward kernels (KL / NLL training path)
+# ---------------------------------------------------------------------------------------------------
+GRAD_CASES = [("nc17", 17, np.zeros(17, bool)), ("c9", 9, np.ones(9, bool)), ("mix6", 6, np.array([1, 0, 1, 1, 0, 0], bool))]
+
+
+@pytest.mark.parametrize("name,d,circ", GRAD_CASES)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_backward_kernel(hip_lib, oracle, golden, dev, name, d, circ, inverse):
+    """bgk_rqs_backward through the autograd Function vs the oracle VJP and the reference's autograd gradients"""
+    import bgflow_amd as bg
+    G = golden("g_grads")
+    n_nc = int((~circ).sum())
+    P = 3 * K * d + n_nc
+    B = 48
+    params, y, a, bw = synth(300 + d, B, P, scale=0.7), synth(400 + d, B, d, uniform=True), synth(500 + d, B, d), synth(600 + d, B, 1)
+    p = t(params, dev).requires_grad_(True)
+    yy = t(y, dev).requires_grad_(True)
+
+    class Fixed(torch.nn.Module):
+        def forward(self, x):
+            return p
+    circ_arg = bool(circ[0]) if circ.all() or (~circ).all() else torch.tensor(circ)
+    tr = bg.ConditionalSplineTransformer(Fixed(), is_circular=circ_arg)
+    z, dl = tr(torch.zeros(B, 1, device=dev), yy, inverse=inverse)
+    ((z * t(a, dev)).sum() + (dl * t(bw, dev)).sum()).backward()
+    tag = f"rqs_{name}_{'inv' if inverse else 'fwd'}"
+    gy, gp = yy.grad.cpu().numpy(), p.grad.cpu().numpy()
+    gyo, gpo = oracle.rqs_backward(y, params, a, bw, is_circular=circ, inverse=inverse, dtype=np.float32)
+    np.testing.assert_allclose(gy, gyo, rtol=0, atol=2e-5 * np.abs(gyo).max())
+    np.testing.assert_allclose(gp, gpo, rtol=0, atol=2e-5 * np.abs(gpo).max())
+    assert np.abs(gy - G[tag + "_gy64"]).max() <= 1e-4 * np.abs(G[tag + "_gy64"]).max()
+    assert np.abs(gp - G[tag + "_gp64"]).max() <= 1e-4 * np.abs(G[tag + "_gp64"]).max()
+
+
+@pytest.mark.parametrize("pv", [False, True])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_backward_kernel(hip_lib, golden, dev, pv, inverse):
+    import bgflow_amd as bg
+    G = golden("g_grads")
+    B, d = 64, 12
+    y, mu, s, a, bw = synth(1, B, d), synth(2, B, d), synth(3, B, d, scale=1.5), synth(4, B, d), synth(5, B, 1)
+    ty, tm, ts = (t(v, dev).requires_grad_(True) for v in (y, mu, s))
+
+    class Fixed(torch.nn.Module):
+        def __init__(self, v):
+            super().__init__()
+            self.v = v
+
+        def forward(self, x):
+            return self.v
+    tr = bg.AffineTransformer(Fixed(tm), Fixed(ts), preserve_volume=pv).to(dev)
+    z, dl = tr(torch.zeros(B, 1, device=dev), ty, inverse=inverse)
+    ((z * t(a, dev)).sum() + (dl * t(bw, dev)).sum()).backward()
+    tag = f"aff_{'vp' if pv else 'plain'}_{'inv' if inverse else 'fwd'}"
+    np.testing.assert_allclose(ty.grad.cpu().numpy(), G[tag + "_gy"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(tm.grad.cpu().numpy(), G[tag + "_gmu"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ts.grad.cpu().numpy(), G[tag + "_gs"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(tr._log_alpha.grad), float(G[tag + "_gla"][0]), rtol=1e-4)
+
+
+def test_kl_gradient_affine_flow(hip_lib, golden, dev):
+    """cfg 2: d/d theta of mean(u(x) - dlogp) through 8 affine couplings (HIP fwd+bwd kernels, torch MLPs)"""
+    from bgflow_amd import configs
+    G = golden("g_grads")
+    gen = configs.make_affine8_generator(device=dev)
+    z = t(synth(32, 128, 64), dev)
+    x, dlogp = gen.flow(z)
+    loss = (gen._target.energy(x) - dlogp).mean()
+    loss.backward()
+    assert abs(float(loss) - float(G["kl2_loss"])) <= 1e-5 * abs(float(G["kl2_loss"])) + 1e-4
+    gla = np.array([float(gen.flow[1 + 2 * i].transformer._log_alpha.grad) for i in range(8)])
+    np.testing.assert_allclose(gla, G["kl2_g_log_alpha"], rtol=2e-3, atol=1e-4)
+    gb = np.stack([gen.flow[1 + 2 * i].transformer._shift_transformation._layers[0].bias.grad.cpu().numpy() for i in range(8)])
+    np.testing.assert_allclose(gb, G["kl2_g_bias0"], rtol=0, atol=2e-3 * np.abs(G["kl2_g_bias0"]).max())
+    gnorm = np.sqrt(sum(float((p.grad ** 2).sum()) for p in gen.flow.parameters()))
+    assert abs(gnorm - float(G["kl2_gnorm"])) <= 2e-3 * float(G["kl2_gnorm"])
+
+
+def test_kl_gradient_spline_couplings(hip_lib, golden, dev):
+    """cfg 3 couplings: gradient through 16 spline layers (generic path: torch conditioner + HIP spline fwd/bwd)"""
+    from bgflow_amd import configs
+    G = golden("g_grads")
+    gen = configs.make_ala2_spline_generator(dev)
+    sub = gen.flow[:16]
+    u = [t(synth(41 + i, 64, dd, uniform=True), dev) for i, dd in enumerate((17, 17, 17, 9))]
+    *ys, dl = sub(*u)
+    loss = (sum((v ** 2).sum(-1, keepdim=True) for v in ys) - dl).mean()
+    loss.backward()
+    assert abs(float(loss) - float(G["kl3_loss"])) <= 2e-5 * abs(float(G["kl3_loss"]))
+    gb = np.stack([np.resize((b.transformer._params_net.net if hasattr(b.transformer._params_net, "net")
+                              else b.transformer._params_net)._layers[4].bias.grad.cpu().numpy(), 200) for b in sub])
+    np.testing.assert_allclose(gb, G["kl3_g_bias_last"], rtol=0, atol=2e-3 * np.abs(G["kl3_g_bias_last"]).max())
+    gnorm = np.sqrt(sum(float((p.grad ** 2).sum()) for p in sub.parameters()))
+    assert abs(gnorm - float(G["kl3_gnorm"])) <= 2e-3 * float(G["kl3_gnorm"])

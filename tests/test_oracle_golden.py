@@ -255,3 +255,41 @@ def test_augmented_flow_cfg5(golden):
     assert np.abs(dl - G["dlogp64"]).max() <= 2 * np.abs(G["dlogp32"] - G["dlogp64"]).max()
     assert np.abs(aug - G["aug64"]).max() <= 2 * np.abs(G["aug32"] - G["aug64"]).max()
     # (clamped icdf inputs, eps = 1e-7 = half an f32 ulp of 1.0, dominate: each costs ~0.17 in log-prob in f32)
+
+
+# ---- analytic backward (VJP) restatements vs torch autograd through the reference ---------------------
+GRAD_CASES = [("nc17", 17, np.zeros(17, bool)), ("c9", 9, np.ones(9, bool)), ("mix6", 6, np.array([1, 0, 1, 1, 0, 0], bool))]
+
+
+def grad_inputs(d, circ, B=48):
+    n_nc = int((~circ).sum())
+    P = 3 * K * d + n_nc
+    return (synth(300 + d, B, P, scale=0.7), synth(400 + d, B, d, uniform=True), synth(500 + d, B, d), synth(600 + d, B, 1))
+
+
+@pytest.mark.parametrize("name,d,circ", GRAD_CASES)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_backward_vs_reference_autograd(oracle, golden, name, d, circ, inverse):
+    G = golden("g_grads")
+    params, y, a, bw = grad_inputs(d, circ)
+    tag = f"rqs_{name}_{'inv' if inverse else 'fwd'}"
+    gy, gp = oracle.rqs_backward(y, params, a, bw, is_circular=circ, inverse=inverse, dtype=np.float64)
+    np.testing.assert_allclose(gy, G[tag + "_gy64"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(gp, G[tag + "_gp64"], rtol=1e-9, atol=1e-12)
+    gy, gp = oracle.rqs_backward(y, params, a, bw, is_circular=circ, inverse=inverse, dtype=np.float32)
+    assert np.abs(gy - G[tag + "_gy64"]).max() <= 1e-4 * np.abs(G[tag + "_gy64"]).max()
+    assert np.abs(gp - G[tag + "_gp64"]).max() <= 1e-4 * np.abs(G[tag + "_gp64"]).max()
+
+
+@pytest.mark.parametrize("pv", [False, True])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_backward_vs_reference_autograd(oracle, golden, pv, inverse):
+    G = golden("g_grads")
+    B, d = 64, 12
+    y, mu, s, a, bw = synth(1, B, d), synth(2, B, d), synth(3, B, d, scale=1.5), synth(4, B, d), synth(5, B, 1)
+    tag = f"aff_{'vp' if pv else 'plain'}_{'inv' if inverse else 'fwd'}"
+    gy, gm, gs, gla = oracle.affine_backward(y, mu, s, a, bw, log_alpha=-1.0, preserve_volume=pv, inverse=inverse, dtype=np.float64)
+    np.testing.assert_allclose(gy, G[tag + "_gy"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(gm, G[tag + "_gmu"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(gs, G[tag + "_gs"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(gla, float(G[tag + "_gla"][0]), rtol=1e-11, atol=1e-12)
