@@ -240,6 +240,120 @@ __global__ __launch_bounds__(IC_THREADS) void ic_ic2xyz_kernel(IcArgs a) {
     if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
 }
 
+/* ---- backward (VJP) of ic_ic2xyz_kernel: reverse sweep over the placement table ------------------
+ * Same math as oracle/bgo_impl.h::bgo_ic_ic2xyz_backward (hand-derived adjoint of ic2xyz_deriv,
+ * log|det J| = 2 ln d + ln|sin a|).  Lane = sample; x (forward output) and the running position
+ * adjoints live in per-lane LDS rows; IC tiles are overwritten in place by their gradients. */
+constexpr int ICB_THREADS = 64;
+
+struct IcBwdArgs {
+    const float* bonds; const float* angles; const float* torsions; int64_t ldic;
+    const float* x; int64_t ldx;
+    const float* g_x; int64_t ldgx;
+    const float* g_dlogp;
+    const int32_t* place; const int32_t* fixed;
+    int n, n_fixed, n_atoms, keep, normalize;
+    const float* T;                     /* Tblacken [keep, 3nf] or NULL */
+    int64_t B;
+    float* g_bonds; float* g_angles; float* g_torsions; int64_t ldgic;
+    float* g_xfix; int64_t ldgf;
+    int sx, sic, sfx;
+};
+
+__device__ __forceinline__ void tile_load64(float* dst, int s, const float* src, int64_t ld, int rows, int cols) {
+    for (int i = threadIdx.x; i < rows * cols; i += ICB_THREADS) {
+        int r = i / cols, c = i - r * cols;
+        dst[r * s + c] = src[(int64_t)r * ld + c];
+    }
+}
+__device__ __forceinline__ void tile_store64(float* dst, int64_t ld, const float* src, int s, int rows, int cols) {
+    for (int i = threadIdx.x; i < rows * cols; i += ICB_THREADS) {
+        int r = i / cols, c = i - r * cols;
+        dst[(int64_t)r * ld + c] = src[r * s + c];
+    }
+}
+__device__ __forceinline__ V3 scale(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 proj_out(V3 g, V3 u, float inv_norm) {   /* (g - u (u.g)) / |v|  : adjoint of v -> v/|v| */
+    float p = dot(u, g);
+    return {(g.x - u.x * p) * inv_norm, (g.y - u.y * p) * inv_norm, (g.z - u.z * p) * inv_norm};
+}
+
+__global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TS = ICB_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
+    float* s_x = smem;                        /* [TS][sx] forward positions */
+    float* s_g = s_x + TS * a.sx;             /* [TS][sx] position adjoints */
+    float* s_b = s_g + TS * a.sx;             /* [TS][sic] bonds -> g_bonds */
+    float* s_a = s_b + TS * a.sic;
+    float* s_t = s_a + TS * a.sic;
+    float* s_f = s_t + TS * a.sic;            /* [TS][sfx] g_xfix */
+    const int tid = threadIdx.x;
+    const int64_t n_tiles = (a.B + TS - 1) / TS;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * TS;
+        const int rows = (int)((a.B - b0) < TS ? (a.B - b0) : TS);
+        tile_load64(s_x, a.sx, a.x + b0 * a.ldx, a.ldx, rows, 3 * a.n_atoms);
+        tile_load64(s_g, a.sx, a.g_x + b0 * a.ldgx, a.ldgx, rows, 3 * a.n_atoms);
+        tile_load64(s_b, a.sic, a.bonds + b0 * a.ldic, a.ldic, rows, n);
+        tile_load64(s_a, a.sic, a.angles + b0 * a.ldic, a.ldic, rows, n);
+        tile_load64(s_t, a.sic, a.torsions + b0 * a.ldic, a.ldic, rows, n);
+        __syncthreads();
+        if (tid < rows) {
+            const float* xr = s_x + tid * a.sx;
+            float* gp = s_g + tid * a.sx;
+            const float gl = a.g_dlogp[b0 + tid];
+            for (int i = n - 1; i >= 0; --i) {
+                const int at = a.place[5 * i], i1 = a.place[5 * i + 1], i2 = a.place[5 * i + 2],
+                          i3 = a.place[5 * i + 3], zr = a.place[5 * i + 4];
+                V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
+                float dd = s_b[tid * a.sic + zr], an = s_a[tid * a.sic + zr], t = s_t[tid * a.sic + zr];
+                if (a.normalize) { an = an * PI_F; t = t * (2.0f * PI_F) - PI_F; }
+                V3 g = ld3(gp + 3 * at);
+                V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
+                V3 nv = cross(v1, v2), nn = cross(v1, nv);
+                float inv_nv = 1.0f / norm(nv), inv_nn = 1.0f / norm(nn), inv_v1 = 1.0f / norm(v1);
+                V3 nh = scale(nv, inv_nv), nnh = scale(nn, inv_nn), v1h = scale(v1, inv_v1);
+                float st = sinf(t), ct = cosf(t), sa = sinf(an), ca = cosf(an);
+                V3 v3 = add(scale(nh, -st), scale(nnh, ct));
+                float inv_v3 = 1.0f / norm(v3);
+                V3 v3h = scale(v3, inv_v3);
+                float gd = dot(g, add(scale(v3h, sa), scale(v1h, -ca))) + gl * 2.0f / dd;
+                float ga = dot(g, add(scale(v3h, dd * ca), scale(v1h, dd * sa))) + gl * ca / sa;
+                V3 g_v3 = proj_out(scale(g, dd * sa), v3h, inv_v3);
+                float gt = dot(g_v3, add(scale(nh, -ct), scale(nnh, -st)));
+                V3 g_n = proj_out(scale(g_v3, -st), nh, inv_nv);
+                V3 g_nn = proj_out(scale(g_v3, ct), nnh, inv_nn);
+                V3 g_v1 = cross(nv, g_nn);
+                g_n = add(g_n, cross(g_nn, v1));
+                g_v1 = add(g_v1, cross(v2, g_n));
+                V3 g_v2 = cross(g_n, v1);
+                g_v1 = add(g_v1, proj_out(scale(g, -dd * ca), v1h, inv_v1));
+                gp[3 * i1] += g.x + g_v1.x + g_v2.x; gp[3 * i1 + 1] += g.y + g_v1.y + g_v2.y; gp[3 * i1 + 2] += g.z + g_v1.z + g_v2.z;
+                gp[3 * i2] -= g_v1.x; gp[3 * i2 + 1] -= g_v1.y; gp[3 * i2 + 2] -= g_v1.z;
+                gp[3 * i3] -= g_v2.x; gp[3 * i3 + 1] -= g_v2.y; gp[3 * i3 + 2] -= g_v2.z;
+                if (a.normalize) { ga = ga * PI_F; gt = gt * (2.0f * PI_F); }
+                s_b[tid * a.sic + zr] = gd; s_a[tid * a.sic + zr] = ga; s_t[tid * a.sic + zr] = gt;
+            }
+            if (a.T) {
+                for (int k = 0; k < a.keep; ++k) {
+                    float s = 0.0f;
+                    for (int c = 0; c < nf3; ++c) s += gp[3 * a.fixed[c / 3] + c % 3] * a.T[k * nf3 + c];
+                    s_f[tid * a.sfx + k] = s;
+                }
+            } else {
+                for (int c = 0; c < nf3; ++c) s_f[tid * a.sfx + c] = gp[3 * a.fixed[c / 3] + c % 3];
+            }
+        }
+        __syncthreads();
+        tile_store64(a.g_bonds + b0 * a.ldgic, a.ldgic, s_b, a.sic, rows, n);
+        tile_store64(a.g_angles + b0 * a.ldgic, a.ldgic, s_a, a.sic, rows, n);
+        tile_store64(a.g_torsions + b0 * a.ldgic, a.ldgic, s_t, a.sic, rows, n);
+        tile_store64(a.g_xfix + b0 * a.ldgf, a.ldgf, s_f, a.sfx, rows, a.keep);
+        __syncthreads();
+    }
+}
+
 int ic_launch(bool to_ic, IcArgs& a, void* stream, const char* what) {
     a.n_atoms = a.n + a.n_fixed;
     a.sx = (3 * a.n_atoms) | 1;
@@ -295,4 +409,30 @@ extern "C" int bgk_ic_ic2xyz(const float* bonds, const float* angles, const floa
     a.wh_mean = wh_mean; a.T = Tblacken; a.jac_xz = jac_xz; a.B = B; a.dlogp = dlogp; a.accumulate = accumulate;
     a.warn_count = warn_count;
     return ic_launch(false, a, stream, "bgk_ic_ic2xyz");
+}
+
+extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float* torsions,
+                                      int64_t ldic, const float* x, int64_t ldx, const int32_t* place,
+                                      int32_t n, const int32_t* fixed, int32_t n_fixed,
+                                      int32_t normalize_angles, const float* Tblacken, int32_t keep,
+                                      int64_t B, const float* g_x, int64_t ldgx, const float* g_dlogp,
+                                      float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,
+                                      float* g_xfix, int64_t ldgf, void* stream) {
+    BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_ic_ic2xyz_backward: bad sizes");
+    BGK_CHECK_ARG(bonds && angles && torsions && x && place && fixed && g_x && g_dlogp && g_bonds && g_angles &&
+                  g_torsions && g_xfix, "bgk_ic_ic2xyz_backward: null pointer");
+    BGK_CHECK_ARG(Tblacken ? keep > 0 : keep == 3 * n_fixed, "bgk_ic_ic2xyz_backward: bad whitening arguments");
+    if (B == 0) return 0;
+    IcBwdArgs a{};
+    a.bonds = bonds; a.angles = angles; a.torsions = torsions; a.ldic = ldic; a.x = x; a.ldx = ldx;
+    a.g_x = g_x; a.ldgx = ldgx; a.g_dlogp = g_dlogp; a.place = place; a.fixed = fixed; a.n = n; a.n_fixed = n_fixed;
+    a.n_atoms = n + n_fixed; a.keep = keep; a.normalize = normalize_angles; a.T = Tblacken; a.B = B;
+    a.g_bonds = g_bonds; a.g_angles = g_angles; a.g_torsions = g_torsions; a.ldgic = ldgic; a.g_xfix = g_xfix; a.ldgf = ldgf;
+    a.sx = (3 * a.n_atoms) | 1; a.sic = n | 1; a.sfx = keep | 1;
+    size_t shmem = sizeof(float) * (size_t)ICB_THREADS * (size_t)(2 * a.sx + 3 * a.sic + a.sfx);
+    if (shmem > 160 * 1024) { bgk_set_error("bgk_ic_ic2xyz_backward: %d atoms do not fit the LDS tile", a.n_atoms); return BGK_EUNSUPPORTED; }
+    int64_t n_tiles = (B + ICB_THREADS - 1) / ICB_THREADS;
+    int grid = (int)(n_tiles < 256 * 12 ? n_tiles : 256 * 12);
+    hipLaunchKernelGGL(ic_ic2xyz_bwd_kernel, dim3(grid), dim3(ICB_THREADS), shmem, (hipStream_t)stream, a);
+    return bgk_launch_status("bgk_ic_ic2xyz_backward");
 }

@@ -88,12 +88,37 @@ def _contig_rows(*ts):
     return [t for t, _ in outs], ld0
 
 
-class _ICFn(torch.autograd.Function):
-    """Placeholder for the analytic IC backward (not written yet): raises loudly."""
+class _IC2XYZFn(torch.autograd.Function):
+    """IC -> xyz with the analytic backward kernel bgk_ic_ic2xyz_backward."""
 
     @staticmethod
-    def forward(ctx, *args):  # pragma: no cover
-        raise NotImplementedError("gradients through the HIP internal-coordinate kernels are not implemented yet")
+    def forward(ctx, rel, bonds, angles, torsions, xfix, blacken):
+        x, dlogp = rel._ic2xyz_launch(bonds, angles, torsions, xfix, blacken)
+        ctx.rel, ctx.blacken = rel, blacken
+        ctx.save_for_backward(bonds, angles, torsions, x)
+        return x, dlogp
+
+    @staticmethod
+    def backward(ctx, g_x, g_dlogp):
+        bonds, angles, torsions, x = ctx.saved_tensors
+        rel, blacken = ctx.rel, ctx.blacken
+        dev = x.device
+        B, n, nf = bonds.shape[0], rel._n, rel._n_fixed
+        (b2, a2, t2), ldic = _contig_rows(bonds, angles, torsions)
+        g_x2, ldgx = _lib.rowmajor(g_x.contiguous())
+        g_dl = g_dlogp.reshape(-1).contiguous()
+        T = None if blacken is None else blacken[1]
+        keep = 3 * nf if T is None else T.shape[0]
+        g_ic = torch.empty((3, B, n), dtype=torch.float32, device=dev)
+        g_f = torch.empty((B, keep), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_ic_ic2xyz_backward(
+                _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), ldic, _lib.ptr(x), x.shape[1],
+                _lib.ptr(rel._tables.get("place", dev)), n, _lib.ptr(rel._tables.get("fixed", dev)), nf,
+                int(rel._normalize_angles), _lib.ptr(T), keep, B, _lib.ptr(g_x2), ldgx, _lib.ptr(g_dl),
+                _lib.ptr(g_ic[0]), _lib.ptr(g_ic[1]), _lib.ptr(g_ic[2]), n, _lib.ptr(g_f), keep, _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_ic_ic2xyz_backward")
+        return None, g_ic[0], g_ic[1], g_ic[2], g_f, None
 
 
 class RelativeInternalCoordinateTransformation(Flow):
@@ -192,7 +217,11 @@ class RelativeInternalCoordinateTransformation(Flow):
 
     def _ic2xyz(self, bonds, angles, torsions, xfix, blacken=None):
         _lib.require_hip(bonds, angles, torsions, xfix)
-        self._no_grad_only(bonds, angles, torsions, xfix)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (bonds, angles, torsions, xfix)):
+            return _IC2XYZFn.apply(self, bonds, angles, torsions, xfix.reshape(xfix.shape[0], -1), blacken)
+        return self._ic2xyz_launch(bonds, angles, torsions, xfix, blacken)
+
+    def _ic2xyz_launch(self, bonds, angles, torsions, xfix, blacken=None):
         dev = bonds.device
         B, n, nf = bonds.shape[0], self._n, self._n_fixed
         assert bonds.shape[-1] == n

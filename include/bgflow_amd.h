@@ -125,6 +125,18 @@ int bgk_ic_ic2xyz(const float* bonds, const float* angles, const float* torsions
                   int64_t B, float* x, int64_t ldx, float* dlogp, int32_t accumulate,
                   int32_t* warn_count, void* stream);
 
+/* Backward (VJP) of bgk_ic_ic2xyz for first-order losses (replaces torch autograd through
+ * ic2xyz_deriv / det3x3, ic.py:435-513): x is the forward OUTPUT; g_x [B, 3*n_atoms], g_dlogp [B]
+ * -> g_bonds / g_angles / g_torsions [B, n] (ldgic), g_xfix [B, keep] (ldgf).  The log-det term uses
+ * log|det J| = 2 ln d + ln|sin a| (exact away from the eps clamps). */
+int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float* torsions, int64_t ldic,
+                           const float* x, int64_t ldx, const int32_t* place, int32_t n,
+                           const int32_t* fixed, int32_t n_fixed, int32_t normalize_angles,
+                           const float* Tblacken, int32_t keep, int64_t B,
+                           const float* g_x, int64_t ldgx, const float* g_dlogp,
+                           float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,
+                           float* g_xfix, int64_t ldgf, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused spline coupling layer with a DenseNet conditioner (fast path of
  * CouplingFlow(ConditionalSplineTransformer(DenseNet | WrapPeriodic(DenseNet)))).

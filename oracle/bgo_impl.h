@@ -614,6 +614,92 @@ void FN(bgo_ic_ic2xyz)(const REAL* bonds, const REAL* angles, const REAL* torsio
     }
 }
 
+/* Backward (VJP) of bgo_ic_ic2xyz for first-order losses.  The reference differentiates
+ * ic2xyz_deriv (ic_helper.py:372-452) and det3x3(J).abs().log() (ic.py:503) with torch autograd;
+ * this is the hand-derived reverse sweep over the placement table, using the analytic identity
+ * log|det J| = 2 ln d + ln|sin a| for the log-det term (exact away from the eps clamps).
+ *   x [B,3*n_atoms] = the forward OUTPUT (saved), g_x [B,3*n_atoms], g_dlogp [B]
+ *   -> g_bonds, g_angles, g_torsions [B,n], g_xfix [B,keep] */
+void FN(bgo_ic_ic2xyz_backward)(const REAL* bonds, const REAL* angles, const REAL* torsions,
+                                const REAL* x, int64_t ldx, const int32_t* place, int n,
+                                const int32_t* fixed, int n_fixed, int normalize,
+                                const REAL* Tblacken, int keep, int64_t B,
+                                const REAL* g_x, int64_t ldgx, const REAL* g_dlogp,
+                                REAL* g_bonds, REAL* g_angles, REAL* g_torsions, REAL* g_xfix)
+{
+    const REAL PI = (REAL)3.14159265358979323846;
+    const int n_atoms = n + n_fixed;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        const REAL* xr = x + b * ldx;
+        REAL gp[3 * 128];
+        for (int c = 0; c < 3 * n_atoms; ++c) gp[c] = g_x[b * ldgx + c];
+        const REAL gl = g_dlogp[b];
+        for (int i = n - 1; i >= 0; --i) {
+            const int32_t* pl = place + 5 * i;
+            const REAL* p1 = xr + 3 * pl[1]; const REAL* p2 = xr + 3 * pl[2]; const REAL* p3 = xr + 3 * pl[3];
+            const int zr = pl[4];
+            REAL dd = bonds[b * n + zr], a = angles[b * n + zr], t = torsions[b * n + zr];
+            if (normalize) { a = a * PI; t = t * ((REAL)2 * PI) - PI; }
+            const REAL* g = gp + 3 * pl[0];
+            REAL v1[3], v2[3], nv[3], nn[3];
+            FN(v3sub)(p1, p2, v1); FN(v3sub)(p1, p3, v2);
+            FN(v3cross)(v1, v2, nv); FN(v3cross)(v1, nv, nn);
+            const REAL nvn = FN(v3norm)(nv), nnn = FN(v3norm)(nn), v1n = FN(v3norm)(v1);
+            REAL nh[3], nnh[3], v1h[3], v3[3], v3h[3];
+            const REAL st = R_SIN(t), ct = R_COS(t), sa = R_SIN(a), ca = R_COS(a);
+            for (int c = 0; c < 3; ++c) { nh[c] = nv[c] / nvn; nnh[c] = nn[c] / nnn; v1h[c] = v1[c] / v1n; }
+            for (int c = 0; c < 3; ++c) v3[c] = -st * nh[c] + ct * nnh[c];
+            const REAL v3n = FN(v3norm)(v3);
+            for (int c = 0; c < 3; ++c) v3h[c] = v3[c] / v3n;
+            /* scalars */
+            REAL gd = (REAL)0, ga = (REAL)0;
+            for (int c = 0; c < 3; ++c) {
+                gd += g[c] * (sa * v3h[c] - ca * v1h[c]);
+                ga += g[c] * (dd * ca * v3h[c] + dd * sa * v1h[c]);
+            }
+            gd += gl * (REAL)2 / dd;
+            ga += gl * ca / sa;
+            /* vectors */
+            REAL g_v3h[3], g_v1h[3], g_v3[3], g_nh[3], g_nnh[3], g_n[3], g_nn[3], g_v1[3], g_v2[3], tmp[3];
+            for (int c = 0; c < 3; ++c) { g_v3h[c] = dd * sa * g[c]; g_v1h[c] = -dd * ca * g[c]; }
+            REAL pr = FN(v3dot)(v3h, g_v3h);
+            for (int c = 0; c < 3; ++c) g_v3[c] = (g_v3h[c] - v3h[c] * pr) / v3n;
+            REAL gt = (REAL)0;
+            for (int c = 0; c < 3; ++c) { gt += g_v3[c] * (-ct * nh[c] - st * nnh[c]); g_nh[c] = -st * g_v3[c]; g_nnh[c] = ct * g_v3[c]; }
+            pr = FN(v3dot)(nh, g_nh);
+            for (int c = 0; c < 3; ++c) g_n[c] = (g_nh[c] - nh[c] * pr) / nvn;
+            pr = FN(v3dot)(nnh, g_nnh);
+            for (int c = 0; c < 3; ++c) g_nn[c] = (g_nnh[c] - nnh[c] * pr) / nnn;
+            /* nn = v1 x n :  g_v1 = n x g_nn ; g_n += g_nn x v1 */
+            FN(v3cross)(nv, g_nn, g_v1);
+            FN(v3cross)(g_nn, v1, tmp); for (int c = 0; c < 3; ++c) g_n[c] += tmp[c];
+            /* n = v1 x v2 :  g_v1 += v2 x g_n ; g_v2 = g_n x v1 */
+            FN(v3cross)(v2, g_n, tmp); for (int c = 0; c < 3; ++c) g_v1[c] += tmp[c];
+            FN(v3cross)(g_n, v1, g_v2);
+            pr = FN(v3dot)(v1h, g_v1h);
+            for (int c = 0; c < 3; ++c) g_v1[c] += (g_v1h[c] - v1h[c] * pr) / v1n;
+            for (int c = 0; c < 3; ++c) {
+                gp[3 * pl[1] + c] += g[c] + g_v1[c] + g_v2[c];
+                gp[3 * pl[2] + c] -= g_v1[c];
+                gp[3 * pl[3] + c] -= g_v2[c];
+            }
+            if (normalize) { ga = ga * PI; gt = gt * ((REAL)2 * PI); }
+            g_bonds[b * n + zr] = gd; g_angles[b * n + zr] = ga; g_torsions[b * n + zr] = gt;
+        }
+        const int nf3 = 3 * n_fixed;
+        if (Tblacken) {
+            for (int k = 0; k < keep; ++k) {
+                REAL s = (REAL)0;
+                for (int c = 0; c < nf3; ++c) s += gp[3 * fixed[c / 3] + c % 3] * Tblacken[k * nf3 + c];
+                g_xfix[b * keep + k] = s;
+            }
+        } else {
+            for (int c = 0; c < nf3; ++c) g_xfix[b * nf3 + c] = gp[3 * fixed[c / 3] + c % 3];
+        }
+    }
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

@@ -301,6 +301,27 @@ def ic_ic2xyz(bonds, angles, torsions, xfix, z_matrix, fixed, normalize_angles=T
     return x, dlogp[:, None]
 
 
+def ic_ic2xyz_backward(bonds, angles, torsions, x, g_x, g_dlogp, z_matrix, fixed, normalize_angles=True,
+                       blacken=None, dtype=np.float32):
+    """Analytic VJP of ``ic_ic2xyz`` (x = its forward output): returns (g_bonds, g_angles, g_torsions, g_xfix)."""
+    sfx, _ = _suffix(dtype)
+    bonds, angles, torsions, x, g_x = (_np(t, dtype) for t in (bonds, angles, torsions, x, g_x))
+    g_dlogp = _np(np.asarray(g_dlogp).reshape(-1), dtype)
+    B, n = bonds.shape
+    fixed = _np(fixed, np.int32)
+    nf = fixed.shape[0]
+    place = decompose_z_matrix(z_matrix, fixed)[4]
+    Tb = None if blacken is None else _np(blacken[1], dtype)
+    keep = 3 * nf if Tb is None else Tb.shape[0]
+    gb, ga, gt = (np.empty((B, n), dtype) for _ in range(3))
+    gf = np.empty((B, keep), dtype)
+    getattr(lib(), "bgo_ic_ic2xyz_backward" + sfx)(
+        _ptr(bonds), _ptr(angles), _ptr(torsions), _ptr(x), _c_i64(x.shape[1]), _ptr(place), _c_int(n), _ptr(fixed),
+        _c_int(nf), _c_int(int(normalize_angles)), _ptr(Tb), _c_int(keep), _c_i64(B), _ptr(g_x), _c_i64(g_x.shape[1]),
+        _ptr(g_dlogp), _ptr(gb), _ptr(ga), _ptr(gt), _ptr(gf))
+    return gb, ga, gt, gf
+
+
 def detmath_probe(x, which):
     names = {"exp": 0, "log": 1, "softplus": 2, "silu": 3, "tanh": 4}
     x = _np(x, np.float32)

@@ -519,6 +519,29 @@ def g_grads():
                                                  else b.transformer._params_net._layers[4].bias.grad.numpy(), 200)
                                        for b in sub])
     out["kl3_gnorm"] = np.sqrt(sum(float((p.grad ** 2).sum()) for p in sub.parameters()))
+    # IC -> xyz (Mixed) gradients: loss = sum(a * x) + sum(b * dlogp) on the flow-like ICs of g_ic
+    Gic = np.load(os.path.join(HERE, "g_ic.npz"))
+    zrel, zglob, rigid, xyz = ala2_tables()
+    mix = bg.MixedCoordinateTransformation(torch.tensor(whitening_data(xyz), dtype=torch.float64), zrel, rigid,
+                                           keepdims=9, raise_warnings=False)
+    ins = [torch.tensor(Gic[k], dtype=torch.float64, requires_grad=True)
+           for k in ("gen_bonds", "gen_angles", "gen_torsions", "gen_zfixed")]
+    x, dl = mix(*ins, inverse=True)
+    a = synth(77, 128, 66); bw = synth(78, 128, 1)
+    ((x * torch.tensor(a, dtype=torch.float64)).sum() + (dl * torch.tensor(bw, dtype=torch.float64)).sum()).backward()
+    out.update(ic_g_bonds=ins[0].grad.numpy(), ic_g_angles=ins[1].grad.numpy(), ic_g_torsions=ins[2].grad.numpy(),
+               ic_g_zfixed=ins[3].grad.numpy(), ic_x=x.detach().numpy())
+    # full cfg-3 KL gradient (prior sample -> 16 couplings -> icdf maps -> IC -> Normal(66) target)
+    gen = build_cfg3(torch.float64)
+    u = [torch.tensor(rng_f32(41 + i, 64, dd, uniform=True), dtype=torch.float64) for i, dd in enumerate((17, 17, 17, 9))]
+    x, dlogp = gen.flow(*u)
+    loss = (gen._target.energy(x) - dlogp).mean()
+    loss.backward()
+    out["klfull_loss"] = loss.detach().numpy()
+    out["klfull_gnorm"] = np.sqrt(sum(float((p.grad ** 2).sum()) for p in gen.flow.parameters()))
+    out["klfull_g_bias_last"] = np.stack([np.resize((b.transformer._params_net.net if hasattr(b.transformer._params_net, "net")
+                                                      else b.transformer._params_net)._layers[4].bias.grad.numpy(), 200)
+                                          for b in list(gen.flow)[:16]])
     save("g_grads", **out)
 
 

@@ -293,3 +293,15 @@ def test_affine_backward_vs_reference_autograd(oracle, golden, pv, inverse):
     np.testing.assert_allclose(gm, G[tag + "_gmu"], rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(gs, G[tag + "_gs"], rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(gla, float(G[tag + "_gla"][0]), rtol=1e-11, atol=1e-12)
+
+
+def test_ic_backward_vs_reference_autograd(oracle, golden):
+    G, Gic = golden("g_grads"), golden("g_ic")
+    z, rigid = Gic["z_matrix"], Gic["rigid_block"]
+    a, bw = synth(77, 128, 66), synth(78, 128, 1)
+    jac = -np.log(Gic["wh_std64"]).sum()
+    ins = [Gic[k] for k in ("gen_bonds", "gen_angles", "gen_torsions")]
+    gb, ga, gt, gf = oracle.ic_ic2xyz_backward(*ins, G["ic_x"], a, bw, z, rigid,
+                                               blacken=(Gic["wh_mean64"], Gic["wh_Tblacken64"], jac), dtype=np.float64)
+    for got, key in ((gb, "ic_g_bonds"), (ga, "ic_g_angles"), (gt, "ic_g_torsions"), (gf, "ic_g_zfixed")):
+        np.testing.assert_allclose(got, G[key], rtol=1e-10, atol=1e-11)
