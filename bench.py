@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU per step")
     ap.add_argument("--cpu-samples", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kl-steps", type=int, default=3, help="extra: time this many KL-loss training steps (0 = skip)")
+    ap.add_argument("--kl-batch", type=int, default=1 << 18, help="samples per GPU per KL step")
     args = ap.parse_args()
 
     rank, world, local = dp.init_from_env("nccl")
@@ -130,6 +132,38 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # ---- extra (second half of BASELINE.json's metric): KL-loss training steps/s -------------------------
+    # one step = kldiv(B).mean() -> backward through the hand-written backward kernels -> one all-reduce of
+    # [sum, n] (+ one flat gradient bucket) -> Adam.  Reported next to the headline, not instead of it.
+    kl = None
+    if args.kl_steps > 0:
+        params = [p for p in gen.flow.parameters()]
+        opt = torch.optim.Adam(params, lr=1e-5)
+        zk = sampler(args.kl_batch, g)
+
+        def kl_step():
+            opt.zero_grad(set_to_none=True)
+            *x, dlogp = gen.flow(*zk)
+            loss = dp.global_mean(gen._target.energy(*x) - dlogp, drop_nonfinite=True)
+            loss.backward()
+            dp.allreduce_gradients_(params)
+            opt.step()
+            return loss
+        kl_step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        tk = time.perf_counter()
+        for _ in range(args.kl_steps):
+            last = kl_step()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        dtk = time.perf_counter() - tk
+        kl = dict(steps_per_s=args.kl_steps / dtk, samples_per_s=args.kl_steps * args.kl_batch * world / dtk,
+                  batch_per_gpu=args.kl_batch, steps=args.kl_steps, loss=float(last.detach()),
+                  note="fwd (generic path: torch conditioner GEMMs + HIP spline/IC kernels) + analytic HIP backward + Adam")
 
     total_samples = args.batch * world * args.steps
     value = total_samples / elapsed
@@ -169,6 +203,8 @@ def main():
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_samples)
+        if kl is not None:
+            out["kl"] = kl
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

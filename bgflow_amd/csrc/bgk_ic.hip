@@ -303,7 +303,12 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
             const float* xr = s_x + tid * a.sx;
             float* gp = s_g + tid * a.sx;
             const float gl = a.g_dlogp[b0 + tid];
+            /* a sample whose upstream adjoints are all zero (e.g. masked out of the loss because its geometry
+             * is degenerate and its log-det is -inf) must get exactly zero gradients, not 0 * inf = NaN */
+            bool live = gl != 0.0f;
+            for (int c = 0; c < 3 * a.n_atoms; ++c) live = live || (gp[c] != 0.0f);
             for (int i = n - 1; i >= 0; --i) {
+                if (!live) { s_b[tid * a.sic + i] = 0.0f; s_a[tid * a.sic + i] = 0.0f; s_t[tid * a.sic + i] = 0.0f; continue; }
                 const int at = a.place[5 * i], i1 = a.place[5 * i + 1], i2 = a.place[5 * i + 2],
                           i3 = a.place[5 * i + 3], zr = a.place[5 * i + 4];
                 V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);

@@ -51,16 +51,22 @@ def rank_seed(base_seed, rank=None):
     return int(base_seed) + int(rank)
 
 
-def global_mean(per_sample_loss):
+def global_mean(per_sample_loss, drop_nonfinite=False):
     """Mean of a per-sample loss [n_local, 1] over ALL ranks with a single all-reduce of the
     2-vector [sum, count].  Differentiable w.r.t. the local losses (each rank's gradient is its own
-    share d/d loss_i = 1 / n_global)."""
+    share d/d loss_i = 1 / n_global).  ``drop_nonfinite``: samples with a non-finite loss (degenerate
+    geometries give log|det J| = -inf) get weight zero instead of poisoning the mean -- the reference's
+    KLTrainer skips the whole optimizer step in that case (nn/training/trainers.py:198-201)."""
+    if drop_nonfinite:
+        ok = torch.isfinite(per_sample_loss)
+        per_sample_loss = torch.where(ok, per_sample_loss, torch.zeros_like(per_sample_loss))
+        n_local = ok.sum()
+    else:
+        n_local = torch.tensor(float(per_sample_loss.numel()), device=per_sample_loss.device)
     local_sum = per_sample_loss.sum()
-    n_local = per_sample_loss.numel()
     if not is_distributed():
-        return local_sum / n_local
-    stats = torch.stack([local_sum.detach().to(torch.float64),
-                         torch.tensor(float(n_local), dtype=torch.float64, device=local_sum.device)])
+        return local_sum / n_local.to(local_sum.dtype)
+    stats = torch.stack([local_sum.detach().to(torch.float64), n_local.to(torch.float64)])
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     n_global = stats[1].item() if False else stats[1]
     mean_value = (stats[0] / n_global).to(local_sum.dtype)
