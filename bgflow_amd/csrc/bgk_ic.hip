@@ -359,6 +359,85 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
     }
 }
 
+/* ---- global reference frame of the first three atoms (ReferenceSystemTransformation) -------------
+ * 9 floats in, 9 floats out per sample; log|det J_9x9| in closed form -(2 ln d01 + 2 ln d12 + ln sin a012)
+ * (the reference uses a batched autograd Jacobian + 24-term permutation expansion; see oracle bgo_refsys). */
+struct RefSysArgs { const float* in; float* out; float* dlogp; int64_t B; int inverse, normalize, enforce, accumulate; float eps; };
+
+__global__ __launch_bounds__(256) void ic_refsys_kernel(RefSysArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const float* v = a.in + 9 * b;
+    float* o = a.out + 9 * b;
+    int warn = 0;
+    float dl;
+    if (!a.inverse) {
+        V3 x0 = ld3(v), x1 = ld3(v + 3), x2 = ld3(v + 6);
+        V3 r01 = sub(x1, x0), r12 = sub(x2, x1);
+        float d01 = clamp_min_flag(norm(r01), a.eps, a.enforce, warn);
+        float d12 = clamp_min_flag(norm(r12), a.eps, a.enforce, warn);
+        V3 aa = sub(x0, x1), cc = sub(x2, x1);
+        float an = clamp_min_flag(norm(aa), a.eps, a.enforce, warn), cn = clamp_min_flag(norm(cc), a.eps, a.enforce, warn);
+        float cosang = (aa.x / an) * (cc.x / cn) + (aa.y / an) * (cc.y / cn) + (aa.z / an) * (cc.z / cn);
+        if (a.enforce) { cosang = cosang < -1.0f + a.eps ? -1.0f + a.eps : cosang; cosang = cosang > 1.0f - a.eps ? 1.0f - a.eps : cosang; }
+        float a012 = acosf(cosang);
+        float e1n = clamp_min_flag(norm(r01), a.eps, a.enforce, warn);
+        V3 e1 = divs(r01, e1n);
+        V3 e2 = cross(sub(x2, x0), e1);
+        float e2n = clamp_min_flag(norm(e2), a.eps, a.enforce, warn);
+        e2 = divs(e2, e2n);
+        V3 e3 = cross(e2, e1);
+        float alpha = atan2f(e1.x, -e1.y), beta = e1.z, gamma = atan2f(-e3.z, -e2.z);
+        dl = -(2.0f * logf(d01) + 2.0f * logf(d12) + logf(sinf(a012)));
+        if (a.normalize) {
+            a012 = a012 / PI_F; alpha = (alpha + PI_F) / (2.0f * PI_F); gamma = (gamma + PI_F) / (2.0f * PI_F);
+            dl += -logf(PI_F) - 2.0f * logf(2.0f * PI_F);
+        }
+        o[0] = x0.x; o[1] = x0.y; o[2] = x0.z; o[3] = d01; o[4] = d12; o[5] = a012; o[6] = alpha; o[7] = beta; o[8] = gamma;
+    } else {
+        V3 x0 = ld3(v);
+        float d01 = v[3], d12 = v[4], a012 = v[5], alpha = v[6], beta = v[7], gamma = v[8];
+        dl = 0.0f;
+        if (a.normalize) {
+            alpha = alpha * (2.0f * PI_F) - PI_F; gamma = gamma * (2.0f * PI_F) - PI_F; a012 = a012 * PI_F;
+            dl += logf(PI_F) + 2.0f * logf(2.0f * PI_F);
+        }
+        dl += 2.0f * logf(d01) + 2.0f * logf(d12) + logf(sinf(a012));
+        V3 p1 = {0.0f, 0.0f, d01}, p0 = {0.0f, 0.0f, 0.0f}, p3 = {0.0f, -1.0f, 0.0f};
+        V3 v1 = sub(p1, p0), v2 = sub(p1, p3);
+        V3 nv = cross(v1, v2), nn = cross(v1, nv);
+        float nvn = clamp_min_flag(norm(nv), a.eps, a.enforce, warn), nnn = clamp_min_flag(norm(nn), a.eps, a.enforce, warn);
+        float tq = 0.5f * PI_F, st = sinf(tq), ct = cosf(tq), sa = sinf(a012), ca = cosf(a012);
+        V3 nh = divs(nv, nvn), nnh = divs(nn, nnn);
+        V3 v3 = {nh.x * (-st) + nnh.x * ct, nh.y * (-st) + nnh.y * ct, nh.z * (-st) + nnh.z * ct};
+        float v3n = clamp_min_flag(norm(v3), a.eps, a.enforce, warn), v1n = clamp_min_flag(norm(v1), a.eps, a.enforce, warn);
+        V3 v3h = divs(v3, v3n), v1h = divs(v1, v1n);
+        V3 p2 = {p1.x + v3h.x * d12 * sa - v1h.x * d12 * ca, p1.y + v3h.y * d12 * sa - v1h.y * d12 * ca,
+                 p1.z + v3h.z * d12 * sa - v1h.z * d12 * ca};
+        float bA = acosf(beta);
+        float caA = cosf(alpha), saA = sinf(alpha), cb = cosf(bA), sb = sinf(bA), cg = cosf(gamma), sg = sinf(gamma);
+        float Rz1[9] = {caA, -saA, 0, saA, caA, 0, 0, 0, 1}, Rx[9] = {1, 0, 0, 0, cb, -sb, 0, sb, cb}, Rz2[9] = {cg, -sg, 0, sg, cg, 0, 0, 0, 1};
+        float T[9], R[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { float s = 0.0f; for (int k = 0; k < 3; ++k) s += Rz1[3 * i + k] * Rx[3 * k + j]; T[3 * i + j] = s; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { float s = 0.0f; for (int k = 0; k < 3; ++k) s += T[3 * i + k] * Rz2[3 * k + j]; R[3 * i + j] = s; }
+        const float p1v[3] = {p1.x, p1.y, p1.z}, p2v[3] = {p2.x, p2.y, p2.z}, x0v[3] = {x0.x, x0.y, x0.z};
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int dd = 0; dd < 3; ++dd) { s1 += p1v[dd] * R[3 * e + dd]; s2 += p2v[dd] * R[3 * e + dd]; }
+            o[e] = x0v[e]; o[3 + e] = s1 + x0v[e]; o[6 + e] = s2 + x0v[e];
+        }
+    }
+    if (a.accumulate) a.dlogp[b] += dl; else a.dlogp[b] = dl;
+    (void)warn;
+}
+
 int ic_launch(bool to_ic, IcArgs& a, void* stream, const char* what) {
     a.n_atoms = a.n + a.n_fixed;
     a.sx = (3 * a.n_atoms) | 1;
@@ -440,4 +519,13 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
     int grid = (int)(n_tiles < 256 * 12 ? n_tiles : 256 * 12);
     hipLaunchKernelGGL(ic_ic2xyz_bwd_kernel, dim3(grid), dim3(ICB_THREADS), shmem, (hipStream_t)stream, a);
     return bgk_launch_status("bgk_ic_ic2xyz_backward");
+}
+
+extern "C" int bgk_ic_refsys(const float* in, int64_t B, int32_t inverse, int32_t normalize_angles, float eps,
+                             int32_t enforce_boundaries, float* out, float* dlogp, int32_t accumulate, void* stream) {
+    BGK_CHECK_ARG(B >= 0 && in && out && dlogp, "bgk_ic_refsys: bad arguments");
+    if (B == 0) return 0;
+    RefSysArgs a{in, out, dlogp, B, inverse, normalize_angles, enforce_boundaries, accumulate, eps};
+    hipLaunchKernelGGL(ic_refsys_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return bgk_launch_status("bgk_ic_refsys");
 }

@@ -14,7 +14,7 @@ from .flow import Flow
 
 __all__ = [
     "decompose_z_matrix", "RelativeInternalCoordinateTransformation", "MixedCoordinateTransformation",
-    "WhitenFlow",
+    "WhitenFlow", "ReferenceSystemTransformation", "GlobalInternalCoordinateTransformation",
 ]
 
 
@@ -341,3 +341,98 @@ class MixedCoordinateTransformation(Flow):
 
     def _inverse(self, bonds, angles, torsions, z_fixed, *args, **kwargs):
         return self._rel_ic._ic2xyz(bonds, angles, torsions, z_fixed, blacken=self._wh("blacken", bonds.device))
+
+
+def slice_initial_atoms(z_matrix):
+    """The three rows of a global Z-matrix with -1 entries define the initial atoms (most -1s first);
+    the rest is a relative Z-matrix (crd_transform/ic.py:94-97)."""
+    z = np.asarray(z_matrix)
+    missing = np.sum(z == -1, axis=-1)
+    order = np.argsort(missing)[::-1][:3]
+    return z[:, 0][order], z[missing == 0]
+
+
+class ReferenceSystemTransformation(Flow):
+    """Origin + Euler orientation + (d01, d12, a012) of the first three atoms (crd_transform/ic.py:128-265)
+    on the kernel bgk_ic_refsys; log|det J| in closed form instead of an autograd 9x9 Jacobian."""
+
+    def __init__(self, normalize_angles=True, eps=1e-7, enforce_boundaries=True, raise_warnings=True):
+        super().__init__()
+        self._normalize_angles = normalize_angles
+        self._eps = eps
+        self._enforce_boundaries = enforce_boundaries
+        self._raise_warnings = raise_warnings
+
+    def _launch(self, packed, inverse):
+        _lib.require_hip(packed)
+        if torch.is_grad_enabled() and packed.requires_grad:
+            raise NotImplementedError("gradients through the global reference frame kernel are not implemented yet")
+        packed = packed.contiguous()
+        B = packed.shape[0]
+        out = torch.empty_like(packed)
+        dlogp = torch.empty((B,), dtype=torch.float32, device=packed.device)
+        with torch.cuda.device(packed.device):
+            st = _lib.lib().bgk_ic_refsys(_lib.ptr(packed), B, int(inverse), int(self._normalize_angles), float(self._eps),
+                                          int(self._enforce_boundaries), _lib.ptr(out), _lib.ptr(dlogp), 0,
+                                          _lib.stream_ptr(packed.device))
+        _lib.check(st, "bgk_ic_refsys")
+        return out, dlogp[:, None]
+
+    def _forward(self, x0, x1, x2, *args, **kwargs):
+        B = x0.shape[0]
+        out, dlogp = self._launch(torch.cat([x0.reshape(B, 3), x1.reshape(B, 3), x2.reshape(B, 3)], dim=-1), False)
+        return out[:, None, 0:3], out[:, 6:9], out[:, 3:4], out[:, 4:5], out[:, 5:6], dlogp
+
+    def _inverse(self, x0, orientation, d01, d12, a012, *args, **kwargs):
+        B = x0.shape[0]
+        out, dlogp = self._launch(torch.cat([x0.reshape(B, 3), d01, d12, a012, orientation], dim=-1), True)
+        return out[:, None, 0:3], out[:, None, 3:6], out[:, None, 6:9], dlogp
+
+
+class GlobalInternalCoordinateTransformation(Flow):
+    """Full Z-matrix transform: every atom but the origin / orientation of the first three becomes an
+    internal coordinate (crd_transform/ic.py:516-716).  forward: x -> bonds [B,n+2], angles [B,n+1],
+    torsions [B,n], x0 [B,1,3], R [B,3], dlogp."""
+
+    def __init__(self, z_matrix, normalize_angles=True, eps=1e-7, enforce_boundaries=True, raise_warnings=True):
+        super().__init__()
+        initial_atoms, z_rel = slice_initial_atoms(z_matrix)
+        self._rel_ic = RelativeInternalCoordinateTransformation(
+            z_matrix=z_rel, fixed_atoms=initial_atoms, normalize_angles=normalize_angles, eps=eps,
+            enforce_boundaries=enforce_boundaries, raise_warnings=raise_warnings)
+        self._ref_ic = ReferenceSystemTransformation(normalize_angles=normalize_angles, eps=eps,
+                                                     enforce_boundaries=enforce_boundaries, raise_warnings=raise_warnings)
+
+    z_matrix = property(lambda self: self._rel_ic.z_matrix)
+    fixed_atoms = property(lambda self: np.array([], dtype=np.int64))
+    dim_bonds = property(lambda self: len(self.z_matrix) + 2)
+    dim_angles = property(lambda self: len(self.z_matrix) + 1)
+    dim_torsions = property(lambda self: len(self.z_matrix))
+    dim_fixed = property(lambda self: 0)
+    torsion_indices = property(lambda self: self._rel_ic.torsion_indices)
+    normalize_angles = property(lambda self: self._rel_ic.normalize_angles)
+
+    @property
+    def bond_indices(self):
+        fix = self._rel_ic.fixed_atoms
+        return np.vstack([np.array([[fix[1], fix[0]], [fix[2], fix[1]]]), self._rel_ic.bond_indices])
+
+    @property
+    def angle_indices(self):
+        fix = self._rel_ic.fixed_atoms
+        return np.vstack([np.array([[fix[2], fix[1], fix[0]]]), self._rel_ic.angle_indices])
+
+    def _forward(self, x, *args, **kwargs):
+        B = x.shape[0]
+        bonds, angles, torsions, x_fixed, dlogp_rel = self._rel_ic._xyz2ic(x.reshape(B, -1))
+        ref, dlogp_ref = self._ref_ic._launch(x_fixed.reshape(B, 9), False)
+        bonds = torch.cat([ref[:, 3:5], bonds], dim=-1)
+        angles = torch.cat([ref[:, 5:6], angles], dim=-1)
+        return bonds, angles, torsions, ref[:, None, 0:3], ref[:, 6:9], dlogp_rel + dlogp_ref
+
+    def _inverse(self, bonds, angles, torsions, x0, R, *args, **kwargs):
+        B = bonds.shape[0]
+        packed = torch.cat([x0.reshape(B, 3), bonds[:, 0:2], angles[:, 0:1], R], dim=-1)
+        x_init, dlogp_ref = self._ref_ic._launch(packed, True)
+        x, dlogp_rel = self._rel_ic._ic2xyz(bonds[:, 2:], angles[:, 1:], torsions, x_init)
+        return x, dlogp_rel + dlogp_ref

@@ -125,6 +125,14 @@ int bgk_ic_ic2xyz(const float* bonds, const float* angles, const float* torsions
                   int64_t B, float* x, int64_t ldx, float* dlogp, int32_t accumulate,
                   int32_t* warn_count, void* stream);
 
+/* Global reference frame of the first three atoms: replaces ReferenceSystemTransformation._forward /
+ * _inverse (crd_transform/ic.py:162-265; init_xyz2ics / init_ics2xyz with their batched autograd
+ * 9x9 Jacobians, ic_helper.py:480-680).  Packed 9-vectors per sample:
+ *   inverse = 0:  (x0, x1, x2) -> (x0[3], d01, d12, a012, alpha, beta, gamma);  inverse = 1: the reverse.
+ * log|det J| in closed form: -/+ (2 ln d01 + 2 ln d12 + ln sin a012) (+ angle-normalisation constants). */
+int bgk_ic_refsys(const float* in, int64_t B, int32_t inverse, int32_t normalize_angles, float eps,
+                  int32_t enforce_boundaries, float* out, float* dlogp, int32_t accumulate, void* stream);
+
 /* Backward (VJP) of bgk_ic_ic2xyz for first-order losses (replaces torch autograd through
  * ic2xyz_deriv / det3x3, ic.py:435-513): x is the forward OUTPUT; g_x [B, 3*n_atoms], g_dlogp [B]
  * -> g_bonds / g_angles / g_torsions [B, n] (ldgic), g_xfix [B, keep] (ldgf).  The log-det term uses

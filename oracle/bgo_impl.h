@@ -614,6 +614,97 @@ void FN(bgo_ic_ic2xyz)(const REAL* bonds, const REAL* angles, const REAL* torsio
     }
 }
 
+/* Global reference frame of the first three atoms (ReferenceSystemTransformation, ic.py:128-265;
+ * init_xyz2ics / init_ics2xyz, tripod, _to_euler_angles, _from_euler_angles: ic_helper.py:114-138,
+ * 330-368, 480-680).  The reference obtains log|det J_9x9| from a batched autograd Jacobian and a
+ * 24-term permutation expansion; analytically it is  -(2 ln d01 + 2 ln d12 + ln sin a012)  for
+ * xyz -> ICs (beta is stored as a cosine, which absorbs the sin(beta) of the Euler measure) -- checked
+ * against the reference to 1e-15 by the golden tests.
+ *   fwd:  x3 [B,9] = (x0,x1,x2)  ->  out [B,9] = (x0[3], d01, d12, a012, alpha, beta, gamma), dlogp
+ *   inv:  the reverse.  normalize: a012/pi, (alpha,gamma + pi)/2pi; beta stays in [-1,1]. */
+void FN(bgo_refsys)(const REAL* in, int64_t B, int inverse, int normalize, REAL eps, int enforce,
+                    REAL* out, REAL* dlogp)
+{
+    const REAL PI = (REAL)3.14159265358979323846;
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; ++b) {
+        const REAL* v = in + 9 * b;
+        REAL* o = out + 9 * b;
+        if (!inverse) {
+            const REAL* x0 = v; const REAL* x1 = v + 3; const REAL* x2 = v + 6;
+            REAL r01[3], r12[3]; FN(v3sub)(x1, x0, r01); FN(v3sub)(x2, x1, r12);
+            REAL d01 = FN(v3norm)(r01); if (enforce && d01 < eps) d01 = eps;
+            REAL d12 = FN(v3norm)(r12); if (enforce && d12 < eps) d12 = eps;
+            /* angle_deriv(x0, x1, x2): angle at x1 */
+            REAL a[3], c[3]; FN(v3sub)(x0, x1, a); FN(v3sub)(x2, x1, c);
+            REAL an = FN(v3norm)(a); if (enforce && an < eps) an = eps;
+            REAL cn = FN(v3norm)(c); if (enforce && cn < eps) cn = eps;
+            REAL cosang = (a[0]/an)*(c[0]/cn) + (a[1]/an)*(c[1]/cn) + (a[2]/an)*(c[2]/cn);
+            if (enforce) { if (cosang < (REAL)-1 + eps) cosang = (REAL)-1 + eps; if (cosang > (REAL)1 - eps) cosang = (REAL)1 - eps; }
+            REAL a012 = R_ACOS(cosang);
+            /* tripod(x0, x1, x2) */
+            REAL e1n = FN(v3norm)(r01); if (enforce && e1n < eps) e1n = eps;
+            REAL e1[3] = { r01[0]/e1n, r01[1]/e1n, r01[2]/e1n };
+            REAL u[3]; FN(v3sub)(x2, x0, u);
+            REAL e2[3]; FN(v3cross)(u, e1, e2);
+            REAL e2n = FN(v3norm)(e2); if (enforce && e2n < eps) e2n = eps;
+            e2[0] /= e2n; e2[1] /= e2n; e2[2] /= e2n;
+            REAL e3[3]; FN(v3cross)(e2, e1, e3);
+            /* basis (x, y, z) = (-e3, -e2, e1) */
+            REAL alpha = R_ATAN2(e1[0], -e1[1]);
+            REAL beta = e1[2];
+            REAL gamma = R_ATAN2(-e3[2], -e2[2]);
+            REAL dl = -((REAL)2 * R_LOG(d01) + (REAL)2 * R_LOG(d12) + R_LOG(R_SIN(a012)));
+            if (normalize) {
+                a012 = a012 / PI; alpha = (alpha + PI) / ((REAL)2 * PI); gamma = (gamma + PI) / ((REAL)2 * PI);
+                dl += -R_LOG(PI) - (REAL)2 * R_LOG((REAL)2 * PI);
+            }
+            o[0] = x0[0]; o[1] = x0[1]; o[2] = x0[2]; o[3] = d01; o[4] = d12; o[5] = a012; o[6] = alpha; o[7] = beta; o[8] = gamma;
+            dlogp[b] = dl;
+        } else {
+            const REAL* x0 = v;
+            REAL d01 = v[3], d12 = v[4], a012 = v[5], alpha = v[6], beta = v[7], gamma = v[8];
+            REAL dl = (REAL)0;
+            if (normalize) {
+                alpha = alpha * ((REAL)2 * PI) - PI; gamma = gamma * ((REAL)2 * PI) - PI; a012 = a012 * PI;
+                dl += R_LOG(PI) + (REAL)2 * R_LOG((REAL)2 * PI);
+            }
+            dl += (REAL)2 * R_LOG(d01) + (REAL)2 * R_LOG(d12) + R_LOG(R_SIN(a012));
+            /* local frame: p0 = 0, p1 = (0,0,d01), p2 from ic2xyz(p1, p0, (0,-1,0), d12, a012, pi/2):
+             * v1 = p1 - p0 = (0,0,d01) -> v1h = z;  n = v1 x (p1 - p3) ... evaluates to p2 = p1 + d12 (sin a * y' - cos a * z)
+             * with the reference's conventions y' = (0, 1, 0) direction below */
+            REAL p1[3] = { 0, 0, d01 };
+            REAL p3[3] = { 0, -1, 0 }, p0[3] = { 0, 0, 0 };
+            REAL v1[3], v2[3], nv[3], nn[3];
+            FN(v3sub)(p1, p0, v1); FN(v3sub)(p1, p3, v2);
+            FN(v3cross)(v1, v2, nv); FN(v3cross)(v1, nv, nn);
+            REAL nvn = FN(v3norm)(nv); if (enforce && nvn < eps) nvn = eps;
+            REAL nnn = FN(v3norm)(nn); if (enforce && nnn < eps) nnn = eps;
+            REAL tq = (REAL)0.5 * PI, st = R_SIN(tq), ct = R_COS(tq), sa = R_SIN(a012), ca = R_COS(a012);
+            REAL v3[3] = { nv[0]/nvn*(-st) + nn[0]/nnn*ct, nv[1]/nvn*(-st) + nn[1]/nnn*ct, nv[2]/nvn*(-st) + nn[2]/nnn*ct };
+            REAL v3n = FN(v3norm)(v3); if (enforce && v3n < eps) v3n = eps;
+            REAL v1n = FN(v3norm)(v1); if (enforce && v1n < eps) v1n = eps;
+            REAL p2[3];
+            for (int c = 0; c < 3; ++c) p2[c] = p1[c] + v3[c]/v3n * d12 * sa - v1[c]/v1n * d12 * ca;
+            /* R = Rz(alpha) Rx(acos beta) Rz(gamma) (_rotmat3x3 axis 2, 0, 2) */
+            REAL bA = R_ACOS(beta);
+            REAL caA = R_COS(alpha), saA = R_SIN(alpha), cb = R_COS(bA), sb = R_SIN(bA), cg = R_COS(gamma), sg = R_SIN(gamma);
+            REAL Rz1[9] = { caA, -saA, 0, saA, caA, 0, 0, 0, 1 };
+            REAL Rx[9] = { 1, 0, 0, 0, cb, -sb, 0, sb, cb };
+            REAL Rz2[9] = { cg, -sg, 0, sg, cg, 0, 0, 0, 1 };
+            REAL T[9], R[9];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { REAL s = 0; for (int k = 0; k < 3; ++k) s += Rz1[3*i+k] * Rx[3*k+j]; T[3*i+j] = s; }
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { REAL s = 0; for (int k = 0; k < 3; ++k) s += T[3*i+k] * Rz2[3*k+j]; R[3*i+j] = s; }
+            for (int e = 0; e < 3; ++e) {
+                REAL s1 = 0, s2 = 0;
+                for (int dd = 0; dd < 3; ++dd) { s1 += p1[dd] * R[3*e+dd]; s2 += p2[dd] * R[3*e+dd]; }
+                o[e] = x0[e]; o[3 + e] = s1 + x0[e]; o[6 + e] = s2 + x0[e];
+            }
+            dlogp[b] = dl;
+        }
+    }
+}
+
 /* Backward (VJP) of bgo_ic_ic2xyz for first-order losses.  The reference differentiates
  * ic2xyz_deriv (ic_helper.py:372-452) and det3x3(J).abs().log() (ic.py:503) with torch autograd;
  * this is the hand-derived reverse sweep over the placement table, using the analytic identity

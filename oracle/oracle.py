@@ -322,6 +322,49 @@ def ic_ic2xyz_backward(bonds, angles, torsions, x, g_x, g_dlogp, z_matrix, fixed
     return gb, ga, gt, gf
 
 
+def refsys(v, inverse=False, normalize_angles=True, eps=1e-7, enforce_boundaries=True, dtype=np.float32):
+    """ReferenceSystemTransformation (crd_transform/ic.py:128-265) on packed 9-vectors:
+    forward (x0,x1,x2) -> (x0, d01, d12, a012, alpha, beta, gamma); inverse the reverse.  Returns (out [B,9], dlogp [B,1])."""
+    sfx, cr = _suffix(dtype)
+    v = _np(v, dtype)
+    B = v.shape[0]
+    out = np.empty((B, 9), dtype)
+    dl = np.empty((B,), dtype)
+    getattr(lib(), "bgo_refsys" + sfx)(_ptr(v), _c_i64(B), _c_int(int(inverse)), _c_int(int(normalize_angles)), cr(eps),
+                                       _c_int(int(enforce_boundaries)), _ptr(out), _ptr(dl))
+    return out, dl[:, None]
+
+
+def slice_initial_atoms(z_matrix):
+    """first three atoms and the remaining rows of a global Z-matrix (crd_transform/ic.py:94-97)"""
+    z = np.asarray(z_matrix)
+    s = np.sum(z == -1, axis=-1)
+    order = np.argsort(s)[::-1][:3]
+    return z[:, 0][order], z[s == 0]
+
+
+def global_ic_forward(x, z_matrix, normalize_angles=True, eps=1e-7, enforce_boundaries=True, dtype=np.float32):
+    """GlobalInternalCoordinateTransformation._forward (ic.py:632-672)"""
+    init, zrel = slice_initial_atoms(z_matrix)
+    b, a, t, xf, dl_rel = ic_xyz2ic(x, zrel, init, normalize_angles, eps, enforce_boundaries, dtype=dtype)
+    ref, dl_ref = refsys(xf, False, normalize_angles, eps, enforce_boundaries, dtype)
+    bonds = np.concatenate([ref[:, 3:5], b], axis=1)
+    angles = np.concatenate([ref[:, 5:6], a], axis=1)
+    return bonds, angles, t, ref[:, None, 0:3], ref[:, 6:9], dl_rel + dl_ref
+
+
+def global_ic_inverse(bonds, angles, torsions, x0, R, z_matrix, normalize_angles=True, eps=1e-7,
+                      enforce_boundaries=True, dtype=np.float32):
+    """GlobalInternalCoordinateTransformation._inverse (ic.py:674-716)"""
+    init, zrel = slice_initial_atoms(z_matrix)
+    bonds, angles = _np(bonds, dtype), _np(angles, dtype)
+    v = np.concatenate([_np(x0, dtype).reshape(-1, 3), bonds[:, 0:2], angles[:, 0:1], _np(R, dtype)], axis=1)
+    xinit, dl_ref = refsys(v, True, normalize_angles, eps, enforce_boundaries, dtype)
+    x, dl_rel = ic_ic2xyz(bonds[:, 2:], angles[:, 1:], torsions, xinit, zrel, init, normalize_angles, eps,
+                          enforce_boundaries, dtype=dtype)
+    return x, dl_rel + dl_ref
+
+
 def detmath_probe(x, which):
     names = {"exp": 0, "log": 1, "softplus": 2, "silu": 3, "tanh": 4}
     x = _np(x, np.float32)

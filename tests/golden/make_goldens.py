@@ -342,6 +342,16 @@ def g_ic():
         xg, dlg = mix(*(torch.tensor(v, dtype=dt) for v in (bp, ap, tp, zp)), inverse=True)
         out.update({f"gen_x{sfx}": xg.numpy(), f"gen_dlogp{sfx}": dlg.numpy()})
     out.update(gen_bonds=bp, gen_angles=ap, gen_torsions=tp, gen_zfixed=zp)
+    # Global internal coordinates (a15): forward on x, inverse on the result
+    for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+        gic = bg.GlobalInternalCoordinateTransformation(zglob, raise_warnings=False)
+        xt = torch.tensor(x[:64], dtype=dt)
+        b, a, t, x0, R, dl = gic(xt)
+        xb, dli = gic(b.detach(), a.detach(), t.detach(), x0.detach(), R.detach(), inverse=True)
+        out.update({f"glob_bonds{sfx}": b.detach().numpy(), f"glob_angles{sfx}": a.detach().numpy(),
+                    f"glob_torsions{sfx}": t.detach().numpy(), f"glob_x0{sfx}": x0.detach().numpy(),
+                    f"glob_R{sfx}": R.detach().numpy(), f"glob_dlogp{sfx}": dl.detach().numpy(),
+                    f"glob_xback{sfx}": xb.detach().numpy(), f"glob_dlogp_inv{sfx}": dli.detach().numpy()})
     save("g_ic", **out)
     # molecule definition used by bgflow_amd.configs (data only: topology tables + one geometry)
     np.savez_compressed(os.path.join(REPO, "bgflow_amd", "data", "ala2_system.npz"),

@@ -554,3 +554,25 @@ def test_kl_step_full_cfg3(hip_lib, golden, dev):
     # and one optimizer step runs
     opt = torch.optim.Adam(gen.flow.parameters(), lr=1e-4)
     opt.step()
+
+
+def test_global_ic_on_gpu(hip_lib, oracle, golden, dev):
+    """GlobalInternalCoordinateTransformation on the GPU (relative-IC kernel + bgk_ic_refsys) vs golden + round trip"""
+    import bgflow_amd as bg
+    G = golden("g_ic")
+    gic = bg.GlobalInternalCoordinateTransformation(G["global_z_matrix"].astype(np.int64), raise_warnings=False)
+    assert (gic.dim_bonds, gic.dim_angles, gic.dim_torsions, gic.dim_fixed) == (21, 20, 19, 0)
+    x = G["x"][:64]
+    with torch.no_grad():
+        b, a, tt, x0, R, dl = gic(t(x, dev))
+        for got, key in ((b, "glob_bonds"), (a, "glob_angles"), (tt, "glob_torsions"), (x0, "glob_x0"), (R, "glob_R")):
+            np.testing.assert_allclose(got.cpu().numpy(), G[key + "64"], rtol=0, atol=3e-6)
+        assert (np.abs(dl.cpu().numpy() - G["glob_dlogp64"]) / np.abs(G["glob_dlogp64"])).max() < 1e-5
+        xb, dli = gic(b, a, tt, x0, R, inverse=True)
+        np.testing.assert_allclose(xb.cpu().numpy(), x, rtol=0, atol=1e-5)
+        assert float((dl + dli).abs().max()) < 2e-4
+        # at scale
+        big = t(G["xyz0"].astype(np.float32), dev) + 0.005 * torch.randn(1 << 18, 66, device=dev)
+        out = gic(big)
+        xb, dli = gic(*out[:-1], inverse=True)
+        assert float((xb - big).abs().max()) < 5e-5 and float((out[-1] + dli).abs().max()) < 1e-3

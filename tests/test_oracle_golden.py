@@ -305,3 +305,21 @@ def test_ic_backward_vs_reference_autograd(oracle, golden):
                                                blacken=(Gic["wh_mean64"], Gic["wh_Tblacken64"], jac), dtype=np.float64)
     for got, key in ((gb, "ic_g_bonds"), (ga, "ic_g_angles"), (gt, "ic_g_torsions"), (gf, "ic_g_zfixed")):
         np.testing.assert_allclose(got, G[key], rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("dtype,sfx,tol,tol_dl", [(np.float64, "64", 1e-13, 1e-11), (np.float32, "32", 2e-6, 1e-4)])
+def test_global_ic(oracle, golden, dtype, sfx, tol, tol_dl):
+    """GlobalInternalCoordinateTransformation (a15): closed-form 9x9 log-det vs the reference's autograd Jacobian"""
+    G = golden("g_ic")
+    zg, x = G["global_z_matrix"], G["x"][:64]
+    b, a, t, x0, R, dl = oracle.global_ic_forward(x, zg, dtype=dtype)
+    assert b.shape == (64, 21) and a.shape == (64, 20) and t.shape == (64, 19)
+    for got, key in ((b, "glob_bonds"), (a, "glob_angles"), (t, "glob_torsions"), (x0, "glob_x0"), (R, "glob_R")):
+        np.testing.assert_allclose(got, G[key + sfx], rtol=0, atol=tol)
+    np.testing.assert_allclose(dl, G["glob_dlogp" + sfx], rtol=0, atol=tol_dl)
+    xb, dli = oracle.global_ic_inverse(G["glob_bonds" + sfx], G["glob_angles" + sfx], G["glob_torsions" + sfx],
+                                       G["glob_x0" + sfx], G["glob_R" + sfx], zg, dtype=dtype)
+    np.testing.assert_allclose(dli, G["glob_dlogp_inv" + sfx], rtol=0, atol=tol_dl)
+    # the reference's own inverse is only 3e-8 accurate in f64 (eps clamps); compare with the original x as well
+    np.testing.assert_allclose(xb, G["glob_xback" + sfx], rtol=0, atol=max(tol, 1e-7) * 10)
+    np.testing.assert_allclose(xb, x, rtol=0, atol=max(tol * 50, 1e-12))
