@@ -166,52 +166,62 @@ __global__ __launch_bounds__(IC_THREADS) void ic_xyz2ic_kernel(IcArgs a) {
     if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
 }
 
-__global__ __launch_bounds__(IC_THREADS) void ic_ic2xyz_kernel(IcArgs a) {
+/* IC -> xyz.  Only the growing position table (dynamic atom indexing) lives in LDS (one odd-stride row per
+ * lane, 8 waves / CU); bonds / angles / torsions are read straight from global memory -- a wave walks a
+ * contiguous [64, n] block column by column, so every line is fetched once and served from L1 afterwards.
+ * With normalised angles the trigonometry uses the exact-quadrant sincos(2 pi x) of bgk_detmath.h on the
+ * NORMALISED value (sin(pi a) = sin(2 pi a/2), sin(2 pi t - pi) = -sin(2 pi t)) instead of OCML sinf/cosf
+ * with their general argument reduction. */
+constexpr int IC2_THREADS = 64;
+__global__ __launch_bounds__(IC2_THREADS) void ic_ic2xyz_kernel(IcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TS = IC_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
-    float* s_x = smem;
-    float* s_b = s_x + TS * a.sx;
-    float* s_a = s_b + TS * a.sic;
-    float* s_t = s_a + TS * a.sic;
-    float* s_f = s_t + TS * a.sic;
+    const int TS = IC2_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
+    float* s_x = smem;                  /* [TS][sx] */
     const int tid = threadIdx.x;
     const int64_t n_tiles = (a.B + TS - 1) / TS;
     int warn = 0;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t b0 = tile * TS;
         const int rows = (int)((a.B - b0) < TS ? (a.B - b0) : TS);
-        tile_load(s_b, a.sic, a.bonds + b0 * a.ldic, a.ldic, rows, n);
-        tile_load(s_a, a.sic, a.angles + b0 * a.ldic, a.ldic, rows, n);
-        tile_load(s_t, a.sic, a.torsions + b0 * a.ldic, a.ldic, rows, n);
-        tile_load(s_f, a.sfx, a.xfix + b0 * a.ldf, a.ldf, rows, a.keep);
-        __syncthreads();
         if (tid < rows) {
+            const int64_t b = b0 + tid;
             float* xr = s_x + tid * a.sx;
+            const float* fx = a.xfix + b * a.ldf;
             float acc = 0.0f;
             if (a.T) {
                 for (int c = 0; c < nf3; ++c) {
                     float s = 0.0f;
-                    for (int k = 0; k < a.keep; ++k) s += s_f[tid * a.sfx + k] * a.T[k * nf3 + c];
+                    for (int k = 0; k < a.keep; ++k) s += fx[k] * a.T[k * nf3 + c];
                     xr[3 * a.fixed[c / 3] + c % 3] = s + a.wh_mean[c];
                 }
                 acc += -a.jac_xz;
             } else {
-                for (int c = 0; c < nf3; ++c) xr[3 * a.fixed[c / 3] + c % 3] = s_f[tid * a.sfx + c];
+                for (int c = 0; c < nf3; ++c) xr[3 * a.fixed[c / 3] + c % 3] = fx[c];
             }
             if (a.normalize) acc += (float)n * logf(PI_F) + (float)n * logf(2.0f * PI_F);
+            const float* pb = a.bonds + b * a.ldic;
+            const float* pa = a.angles + b * a.ldic;
+            const float* pt = a.torsions + b * a.ldic;
             for (int i = 0; i < n; ++i) {
                 const int at = a.table[5 * i], i1 = a.table[5 * i + 1], i2 = a.table[5 * i + 2],
                           i3 = a.table[5 * i + 3], zr = a.table[5 * i + 4];
                 V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
-                float dd = s_b[tid * a.sic + zr], an = s_a[tid * a.sic + zr], t = s_t[tid * a.sic + zr];
-                if (a.normalize) { an = an * PI_F; t = t * (2.0f * PI_F) - PI_F; }
+                const float dd = pb[zr];
+                float st, ct, sa, ca;
+                if (a.normalize) {
+                    bgk_sincos2pif(0.5f * pa[zr], &sa, &ca);
+                    bgk_sincos2pif(pt[zr], &st, &ct);
+                    st = -st; ct = -ct;
+                } else {
+                    const float an = pa[zr], t = pt[zr];
+                    st = sinf(t); ct = cosf(t); sa = sinf(an); ca = cosf(an);
+                }
                 /* ic2xyz_deriv (ic_helper.py:372-452) */
                 V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
                 V3 nv = cross(v1, v2), nn = cross(v1, nv);
                 float nvn = clamp_min_flag(norm(nv), a.eps, a.enforce, warn);
                 float nnn = clamp_min_flag(norm(nn), a.eps, a.enforce, warn);
                 V3 nh = divs(nv, nvn), nnh = divs(nn, nnn);
-                float st = sinf(t), ct = cosf(t), sa = sinf(an), ca = cosf(an);
                 V3 v3 = {nh.x * (-st) + nnh.x * ct, nh.y * (-st) + nnh.y * ct, nh.z * (-st) + nnh.z * ct};
                 float v3n = clamp_min_flag(norm(v3), a.eps, a.enforce, warn);
                 V3 v3h = divs(v3, v3n);
@@ -228,13 +238,16 @@ __global__ __launch_bounds__(IC_THREADS) void ic_ic2xyz_kernel(IcArgs a) {
                 /* rows of J = stack([Jd, Ja, Jt], dim=-1) */
                 V3 R0 = {Jd.x, Ja.x, Jt.x}, R1 = {Jd.y, Ja.y, Jt.y}, R2 = {Jd.z, Ja.z, Jt.z};
                 float det = det3(R0, R1, R2);
-                acc += logf(fabsf(det));
+                acc += bgk_logf(fabsf(det));
                 xr[3 * at] = pos.x; xr[3 * at + 1] = pos.y; xr[3 * at + 2] = pos.z;
             }
-            if (a.accumulate) a.dlogp[b0 + tid] += acc; else a.dlogp[b0 + tid] = acc;
+            if (a.accumulate) a.dlogp[b] += acc; else a.dlogp[b] = acc;
         }
         __syncthreads();
-        tile_store(a.x + b0 * a.ldx, a.ldx, s_x, a.sx, rows, 3 * a.n_atoms);
+        for (int i = tid; i < rows * 3 * a.n_atoms; i += IC2_THREADS) {
+            int r = i / (3 * a.n_atoms), c = i - r * 3 * a.n_atoms;
+            a.x[(b0 + r) * a.ldx + c] = s_x[r * a.sx + c];
+        }
         __syncthreads();
     }
     if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
@@ -448,7 +461,12 @@ int ic_launch(bool to_ic, IcArgs& a, void* stream, const char* what) {
     int64_t n_tiles = (a.B + IC_THREADS - 1) / IC_THREADS;
     int grid = (int)(n_tiles < 256 * 8 ? n_tiles : 256 * 8);
     if (to_ic) hipLaunchKernelGGL(ic_xyz2ic_kernel, dim3(grid), dim3(IC_THREADS), shmem, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(ic_ic2xyz_kernel, dim3(grid), dim3(IC_THREADS), shmem, (hipStream_t)stream, a);
+    else {
+        size_t shmem2 = sizeof(float) * (size_t)IC2_THREADS * (size_t)a.sx;
+        int64_t nt2 = (a.B + IC2_THREADS - 1) / IC2_THREADS;
+        int grid2 = (int)(nt2 < 256 * 32 ? nt2 : 256 * 32);
+        hipLaunchKernelGGL(ic_ic2xyz_kernel, dim3(grid2), dim3(IC2_THREADS), shmem2, (hipStream_t)stream, a);
+    }
     return bgk_launch_status(what);
 }
 

