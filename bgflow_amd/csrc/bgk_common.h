@@ -163,8 +163,9 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
     /* ---- the two derivatives that are gathered ---- */
     float s_lo = ps[idx * st];
     float s_hi = (idx + 1 < K) ? ps[(idx + 1) * st] : s_last;
-    float d_i = c.min_d + bgk_softplusf(s_lo, c.beta);
-    float d_ip1 = c.min_d + bgk_softplusf(s_hi, c.beta);
+    const bgk_f2 sp = bgk_softplusf2((bgk_f2){s_lo, s_hi}, c.beta);
+    float d_i = c.min_d + sp.x;
+    float d_ip1 = c.min_d + sp.y;
 
     float cw_i, W_i, ch_i, H_i;
     if (inverse) { cw_i = a_i; W_i = A_i; ch_i = b_i; H_i = B_i; }
@@ -184,7 +185,7 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
         float den = delta + S * t1mt;
         float omr = 1.0f - root;
         float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
-        l = -(bgk_logf(num) - 2.0f * bgk_logf(den));
+        { const bgk_f2 lg = bgk_logf2((bgk_f2){num, den}); l = -(lg.x - 2.0f * lg.y); }
     } else {
         float theta = bgk_div_safe(x - cw_i, W_i);
         float t1mt = theta * (1.0f - theta);
@@ -193,7 +194,7 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
         outv = ch_i + bgk_div_safe(numer, den);
         float omt = 1.0f - theta;
         float num = (delta * delta) * (d_ip1 * (theta * theta) + 2.0f * delta * t1mt + d_i * (omt * omt));
-        l = bgk_logf(num) - 2.0f * bgk_logf(den);
+        { const bgk_f2 lg = bgk_logf2((bgk_f2){num, den}); l = lg.x - 2.0f * lg.y; }
     }
     *lad = l;
     return outv;

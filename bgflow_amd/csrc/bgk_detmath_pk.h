@@ -62,6 +62,52 @@ __device__ __forceinline__ bgk_f2 bgk_div_fast2(bgk_f2 n, bgk_f2 d) {
     return bgk_div_r2(n, d, r);
 }
 
+/* log of two non-negative finite values; identical to bgk_logf on each (v_frexp_mant/_exp give the same
+ * [0.5, 1) mantissa / exponent split as the portable bit manipulation, denormals included) */
+__device__ __forceinline__ bgk_f2 bgk_logf2(bgk_f2 x) {
+    bgk_f2 m;
+    m.x = __builtin_amdgcn_frexp_mantf(x.x); m.y = __builtin_amdgcn_frexp_mantf(x.y);
+    int32_t ex = __builtin_amdgcn_frexp_expf(x.x), ey = __builtin_amdgcn_frexp_expf(x.y);
+    const bool cx = m.x < 0.707106781186547524f, cy = m.y < 0.707106781186547524f;
+    ex -= cx ? 1 : 0; ey -= cy ? 1 : 0;
+    m.x = cx ? m.x + m.x : m.x; m.y = cy ? m.y + m.y : m.y;
+    m = m - bgk_splat2(1.0f);
+    bgk_f2 z = m * m;
+    bgk_f2 y = bgk_splat2(7.0376836292e-2f);
+    y = bgk_fma2(y, m, bgk_splat2(-1.1514610310e-1f));
+    y = bgk_fma2(y, m, bgk_splat2(1.1676998740e-1f));
+    y = bgk_fma2(y, m, bgk_splat2(-1.2420140846e-1f));
+    y = bgk_fma2(y, m, bgk_splat2(1.4249322787e-1f));
+    y = bgk_fma2(y, m, bgk_splat2(-1.6668057665e-1f));
+    y = bgk_fma2(y, m, bgk_splat2(2.0000714765e-1f));
+    y = bgk_fma2(y, m, bgk_splat2(-2.4999993993e-1f));
+    y = bgk_fma2(y, m, bgk_splat2(3.3333331174e-1f));
+    y = y * m;
+    y = y * z;
+    bgk_f2 fe = (bgk_f2){(float)ex, (float)ey};
+    y = bgk_fma2(fe, bgk_splat2(-2.12194440e-4f), y);
+    y = bgk_fma2(z, bgk_splat2(-0.5f), y);
+    bgk_f2 r = m + y;
+    r = bgk_fma2(fe, bgk_splat2(0.693359375f), r);
+    r.x = x.x == 0.0f ? -__builtin_inff() : r.x;
+    r.y = x.y == 0.0f ? -__builtin_inff() : r.y;
+    return r;
+}
+
+/* softplus of two values with a common beta; identical to bgk_softplusf on each */
+__device__ __forceinline__ bgk_f2 bgk_softplusf2(bgk_f2 x, float beta) {
+    bgk_f2 z = x * bgk_splat2(beta);
+    bgk_f2 e = bgk_expf2(z);
+    bgk_f2 u = bgk_splat2(1.0f) + e;
+    bgk_f2 l1p = bgk_logf2(u) * bgk_div_fast2(e, u - bgk_splat2(1.0f));   /* garbage where u == 1, replaced below */
+    l1p.x = u.x == 1.0f ? e.x : l1p.x;
+    l1p.y = u.y == 1.0f ? e.y : l1p.y;
+    bgk_f2 r = bgk_div_r2(l1p, bgk_splat2(beta), bgk_splat2(bgk_rcp_refined(beta)));
+    r.x = z.x > 20.0f ? x.x : r.x;
+    r.y = z.y > 20.0f ? x.y : r.y;
+    return r;
+}
+
 /* SiLU of two values: x / (1 + exp(-x)) */
 __device__ __forceinline__ bgk_f2 bgk_siluf2(bgk_f2 x) {
     return bgk_div_fast2(x, bgk_splat2(1.0f) + bgk_expf2(-x));

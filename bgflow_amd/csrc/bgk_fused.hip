@@ -305,9 +305,10 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
     /* ---- gathered derivatives ---- */
     float s_lo = ps[idx * st];
     float s_hi = (idx + 1 < K) ? ps[(idx + 1 < K ? idx + 1 : 0) * st] : s_last;
-    float d_i = c.min_d + bgk_softplusf(s_lo, c.beta);
+    const bgk_f2 sp = bgk_softplusf2((bgk_f2){s_lo, s_hi}, c.beta);
     g.template step<S0 + 18>();
-    float d_ip1 = c.min_d + bgk_softplusf(s_hi, c.beta);
+    float d_i = c.min_d + sp.x;
+    float d_ip1 = c.min_d + sp.y;
     g.template step<S0 + 19>();
     float cw_i, W_i, ch_i, H_i;
     if (INV) { cw_i = a_i; W_i = A_i; ch_i = b_i; H_i = B_i; }
@@ -327,7 +328,7 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
         float den = delta + S * t1mt;
         float omr = 1.0f - root;
         float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
-        l = -(bgk_logf(num) - 2.0f * bgk_logf(den));
+        { const bgk_f2 lg = bgk_logf2((bgk_f2){num, den}); l = -(lg.x - 2.0f * lg.y); }
     } else {
         float theta = bgk_div_safe(x - cw_i, W_i);
         float t1mt = theta * (1.0f - theta);
@@ -336,7 +337,7 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
         outv = ch_i + bgk_div_safe(numer, den);
         float omt = 1.0f - theta;
         float num = (delta * delta) * (d_ip1 * (theta * theta) + 2.0f * delta * t1mt + d_i * (omt * omt));
-        l = bgk_logf(num) - 2.0f * bgk_logf(den);
+        { const bgk_f2 lg = bgk_logf2((bgk_f2){num, den}); l = lg.x - 2.0f * lg.y; }
     }
     g.template step<S0 + 20>();
     *lad = l;
@@ -393,8 +394,15 @@ template <int INV, class G>
 __device__ __forceinline__ void spline_chunk(G& g, const FusedArgs& a, const float* s_p, float* s_y, int c, int nd,
                                              int hh, int j, int rows, float& run, int& oob_local, int (&bins)[3]) {
     spline_slot<INV, 0>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+#if BGK_PIPE_SPLINE
     spline_slot<INV, 1>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
     spline_slot<INV, 2>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+#else
+    /* slots whose two dims both lie beyond the chunk's last dim are skipped (wave-uniform branch) */
+    bins[1] = bins[2] = 0;
+    if (nd > 2) spline_slot<INV, 1>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    if (nd > 4) spline_slot<INV, 2>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+#endif
 }
 
 template <int ACT, int INV>
