@@ -548,6 +548,217 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedAr
     }
 }
 
+
+/* =====================================================================================================
+ * Split-f16 variant: the same layer with the three GEMMs on the f16 matrix cores.
+ * Every f32 operand v (weight, bias, activation) is represented EXACTLY-to-f32-rounding as hi + lo with
+ * hi = rne_f16(v), lo = rne_f16(v - hi) (22-24 significant bits); a product needs three MFMAs
+ * (lo*hi, hi*lo, hi*hi -- lo*lo is below f32 resolution), accumulated in f32 by v_mfma_f32_32x32x16_f16.
+ * Measured on MI355X (tools/ubench/split_gemm.hip, 128-term dot products of N(0, 0.1) weights with
+ * SiLU-distributed activations incl. 1e-6-scaled ones): rms error 0.47 ulp32 of sum|a||b| (max 3.5) versus
+ * 0.65 (max 5.7) for the exact-f32 fma chain -- the same accuracy class, 16/3 times the MFMA rate
+ * (v_mfma_f32_32x32x16_f16: 32 cycles for 16 k, f32-input 32x32x2: 64 cycles for 2 k).
+ * Weights are scaled by a per-layer power of two (exact) into the upper f16 range on the host; the
+ * accumulator is scaled back (exact) before the activation / the spline.  Activations beyond +-65000 are
+ * clamped (f16 range) -- far outside anything a trained conditioner produces.
+ * Not bit-identical to the oracle's fma chain (the accumulation order inside the instruction is the
+ * hardware's); parity is asserted to the reference at the north-star tolerance instead.
+ *   packed A operand (host: dense.py::pack_dense_for_fused_h2): per layer / per 128-row chunk
+ *     block(s, m, p) = [(s * 4 + m) * 2 + p] of 1 KiB: lane l = 32 kb + i holds W'[32 m + i][k(s, kb, e)], e = 0..7,
+ *     part p (0 = hi, 1 = lo); after the 8 (S0 for layer 0) k-steps: bias block m (lanes < 32: {b_hi, b_lo, 0...}).
+ *   k(s, kb, e): layer 0 natural 16 s + 8 kb + e (LDS rows); hidden layers = the accumulator layout, so that the
+ *     previous layer's registers are the B operand without data movement.
+ */
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+struct FusedArgsH2 {
+    FusedArgs f;                 /* shared part (W0/W1/W2/T0 unused) */
+    const uint4* A0; int S0;     /* layer 0: S0 k16-steps */
+    const uint4* A1;             /* layer 1: 8 steps */
+    const uint4* A2;             /* layer 2: n_chunks x (8 steps + bias) */
+    float c0, c1, c2;            /* 2^-s of the three layers */
+};
+
+constexpr int H2_STEPS = 8;                            /* 128 hidden units / 16 */
+constexpr int H2_BLOCKS = (H2_STEPS * 4 * 2 + 4);      /* 1 KiB blocks per 128-row GEMM incl. bias */
+
+template <int NT>
+struct AFrag { uint4 v[NT][2]; };
+
+template <int NT>
+__device__ __forceinline__ void h2_load(AFrag<NT>& f, const uint4* W, int s, int lane) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        f.v[m][0] = W[((s * 4 + m) * 2 + 0) * 64 + lane];
+        f.v[m][1] = W[((s * 4 + m) * 2 + 1) * 64 + lane];
+    }
+}
+
+__device__ __forceinline__ void h2_split(const float (&v)[8], h16x8& hi, h16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float c = __builtin_amdgcn_fmed3f(v[e], -65000.0f, 65000.0f);
+        const _Float16 h = (_Float16)c;
+        hi[e] = h;
+        lo[e] = (_Float16)(c - (float)h);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void h2_mfma(f32x16 (&out)[4], const AFrag<NT>& a, const h16x8& bhi, const h16x8& blo) {
+    /* small terms first; tiles interleaved so that consecutive MFMAs are independent */
+#pragma unroll
+    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][1]), bhi, out[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), blo, out[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), bhi, out[m], 0, 0, 0);
+}
+
+/* out[0..NT) = W' * in + b'  for a 128-wide hidden input held in accumulator layout (already activated) */
+template <int NT>
+__device__ __forceinline__ void h2_gemm_hidden(f32x16 (&out)[4], const f32x16 (&in)[4], const uint4* W, int lane) {
+    AFrag<NT> cur, nxt;
+    h2_load<NT>(cur, W, 0, lane);
+#pragma unroll
+    for (int s = 0; s < H2_STEPS; ++s) {
+        if (s + 1 < H2_STEPS) h2_load<NT>(nxt, W, s + 1, lane);
+        else {
+#pragma unroll
+            for (int m = 0; m < NT; ++m) nxt.v[m][0] = W[(H2_STEPS * 8 + m) * 64 + lane];   /* bias blocks */
+        }
+        __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch above this step's work */
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = in[s >> 1][8 * (s & 1) + e];
+        h16x8 bhi, blo;
+        h2_split(v, bhi, blo);
+        h2_mfma<NT>(out, cur, bhi, blo);
+        if (s + 1 < H2_STEPS) cur = nxt;
+    }
+    const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, nxt.v[m][0]), one2, out[m], 0, 0, 0);
+}
+
+/* activation of x = t * c (c = exact power-of-two unscale) */
+template <int ACT>
+__device__ __forceinline__ void act_tile_scaled(f32x16& t, float c) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] *= c;
+    act_tile<ACT>(t);
+}
+
+template <int ACT, int INV>
+__global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(FusedArgsH2 ah) {
+    const FusedArgs& a = ah.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;
+    float* s_y = s_p + LDS_P;
+    const int d = a.d;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * FW + wave;
+    if (tile < n_tiles) {
+        const int64_t b0 = tile * 32;
+        const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+
+        /* ---- stage the (featurised) conditioner input [feature][sample], a constant-1 row for the bias, zero pad rows ---- */
+        const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
+        for (int i = lane; i < 32 * a.d_c; i += 64) {
+            const int r = i / a.d_c, c = i - r * a.d_c;
+            float v = r < rows ? a.cond[(b0 + r) * a.ldc + c] : 0.0f;
+            if (a.periodic) {
+                float sv, cv;
+                bgk_sincos2pif(v, &sv, &cv);
+                s_p[c * SROW + r] = cv;
+                s_p[(a.d_c + c) * SROW + r] = sv;
+            } else {
+                s_p[c * SROW + r] = v;
+            }
+        }
+        for (int i = lane; i < (16 * ah.S0 - n_in) * 32; i += 64)
+            s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
+        for (int i = lane; i < 32 * d; i += 64) {
+            const int r = i / d, c = i - r * d;
+            s_y[c * SROW + r] = r < rows ? a.y[(b0 + r) * a.ldy + c] : 0.5f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        /* ---- layer 0 (bias = weight column of the constant-1 feature) ---- */
+        f32x16 h[4], acc[4];
+        zero4(h);
+        for (int s = 0; s < ah.S0; ++s) {
+            AFrag<4> fr;
+            h2_load<4>(fr, ah.A0, s, lane);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = s_p[(16 * s + 8 * hh + e) * SROW + j];
+            h16x8 bhi, blo;
+            h2_split(v, bhi, blo);
+            h2_mfma<4>(h, fr, bhi, blo);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(h[m], ah.c0);
+
+        /* ---- layer 1 ---- */
+        zero4(acc);
+        h2_gemm_hidden<4>(acc, h, ah.A1, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(acc[m], ah.c1);
+
+        /* ---- layer 2 in chunks of 128 packed columns + spline (roles swapped: acc = B operand, h = accumulator) ---- */
+        float run = 0.0f;
+        int oob_local = 0;
+        zero4(h);
+        if (a.n_chunks == 1 && a.last_tiles <= 2) h2_gemm_hidden<2>(h, acc, ah.A2, lane);
+        else h2_gemm_hidden<4>(h, acc, ah.A2, lane);
+        for (int c = 0; c < a.n_chunks; ++c) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * 32 + j] = h[m][r] * ah.c2;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
+            int bins[3];
+            if (c + 1 < a.n_chunks) {
+                zero4(h);
+                const uint4* Wn = ah.A2 + (size_t)(c + 1) * H2_BLOCKS * 64;
+                if (c + 2 == a.n_chunks && a.last_tiles <= 2) h2_gemm_hidden<2>(h, acc, Wn, lane);
+                else h2_gemm_hidden<4>(h, acc, Wn, lane);
+            }
+            NoGemm g;
+            spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+            if (a.bin_idx) {
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int q = 2 * it + hh;
+                    if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (hh == 0 && j < rows) {
+            if (a.accumulate) a.dlogp[b0 + j] += run; else a.dlogp[b0 + j] = run;
+        }
+        for (int i = lane; i < rows * d; i += 64) {
+            const int r = i / d, cc = i - r * d;
+            a.out[(b0 + r) * a.ldo + cc] = s_y[cc * SROW + r];
+        }
+        if (a.oob_count) {
+            for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
+            if (lane == 0 && oob_local) atomicAdd(a.oob_count, oob_local);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t bgk_pack_rqs_columns(int32_t d, int32_t K, const int32_t* nc_slot_host, int32_t* src_col) {
@@ -617,4 +828,57 @@ extern "C" int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_
     else { if (inverse) BGK_LAUNCH(3, 1); else BGK_LAUNCH(3, 0); }
 #undef BGK_LAUNCH
     return bgk_launch_status("bgk_coupling_rqs_dense");
+}
+
+extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                         const void* A0p, const void* A1p, const void* A2p,
+                                         float c0, float c1, float c2,
+                                         int32_t H0, int32_t H1, int32_t act, const float* y,
+                                         int64_t ldy, int64_t B, int32_t d, int32_t K, uint64_t circ_mask,
+                                         int32_t inverse,
+                                         double left, double right, double bottom, double top,
+                                         double min_bin_width, double min_bin_height,
+                                         double min_derivative, int32_t identity_init, float* out,
+                                         int64_t ldo, float* dlogp, int32_t accumulate,
+                                         int32_t* bin_idx, int32_t* oob_count, void* stream) {
+    BGK_CHECK_ARG(cond && A0p && A1p && A2p && y && out && dlogp, "bgk_coupling_rqs_dense_h2: null pointer");
+    BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "bgk_coupling_rqs_dense_h2: bad sizes");
+    if (H0 != HID || H1 != HID || K != KB || d > 64 || act < 1 || act > 3) {
+        bgk_set_error("bgk_coupling_rqs_dense_h2: only hidden=(128,128), n_bins=8, d<=64, act in {SiLU,ReLU,Tanh} are fused "
+                      "(got H0=%d H1=%d K=%d d=%d act=%d)", H0, H1, K, d, act);
+        return BGK_EUNSUPPORTED;
+    }
+    const int n_in = periodic ? 2 * d_c : d_c;
+    const int S0 = (n_in + 1 + 15) / 16;
+    BGK_CHECK_ARG(16 * S0 * SROW <= LDS_P, "bgk_coupling_rqs_dense_h2: conditioner input of %d features too wide", n_in);
+    BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
+                  "Minimal bin width/height too large for the number of bins");
+    if (B == 0) return 0;
+    FusedArgsH2 ah;
+    FusedArgs& a = ah.f;
+    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
+    a.W0 = nullptr; a.W1 = nullptr; a.W2 = nullptr; a.T0 = 0;
+    a.n_chunks = (d + DPC - 1) / DPC;
+    a.last_tiles = ((d - (a.n_chunks - 1) * DPC) * PPD + 31) / 32;
+    a.act = act; a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.inverse = inverse;
+    a.circ_mask = circ_mask;
+    a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
+    a.bin_idx = bin_idx; a.oob_count = oob_count;
+    a.lds_per_wave = LDS_P + (d + 1) * SROW;
+    a.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, K);
+    ah.A0 = reinterpret_cast<const uint4*>(A0p); ah.S0 = S0;
+    ah.A1 = reinterpret_cast<const uint4*>(A1p);
+    ah.A2 = reinterpret_cast<const uint4*>(A2p);
+    ah.c0 = c0; ah.c1 = c1; ah.c2 = c2;
+    size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
+    int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_coupling_rqs_dense_h2: batch too large for one launch");
+    int grid = (int)n_wg;
+    hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCH(A, I) hipLaunchKernelGGL((coupling_rqs_dense_h2_kernel<A, I>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
+    if (act == 1) { if (inverse) BGK_LAUNCH(1, 1); else BGK_LAUNCH(1, 0); }
+    else if (act == 2) { if (inverse) BGK_LAUNCH(2, 1); else BGK_LAUNCH(2, 0); }
+    else { if (inverse) BGK_LAUNCH(3, 1); else BGK_LAUNCH(3, 0); }
+#undef BGK_LAUNCH
+    return bgk_launch_status("bgk_coupling_rqs_dense_h2");
 }

@@ -145,8 +145,94 @@ def pack_dense_for_fused(linears, nc_slot_host, d, n_bins):
     return W0p, W1p, torch.cat(chunks, dim=0).contiguous()
 
 
+# ---- split-f16 operand packing for bgk_coupling_rqs_dense_h2 ---------------------------------------
+# v = hi + lo with hi = rne_f16(v), lo = rne_f16(v - hi); weights are first scaled by 2^s (exact) so that
+# max(|W|, |b|) lands in [2^14, 2^15).  One 1 KiB block = 64 lanes x 8 f16; block(s, m, p) = (s*4 + m)*2 + p
+# holds, for lane l = 32 kb + i, W'[32 m + i][k(s, kb, e)], e = 0..7, part p; after the S k16-steps follow 4
+# bias blocks (lanes < 32: {b_hi, b_lo, 0, ...}).  See bgk_fused.hip (coupling_rqs_dense_h2_kernel).
+GEMM_MODE = "f32"     # module default: "f32" (exact f32-input MFMA, bit-identical to the oracle) or "f16x2"
+
+
+def _h2_scale_exp(*tensors):
+    m = max(float(t.abs().max()) for t in tensors if t.numel())
+    if not np.isfinite(m) or m <= 0.0:
+        return 0
+    return int(np.clip(np.floor(np.log2(32768.0 / m)), -16, 24))
+
+
+def _h2_split(v):
+    hi = v.to(torch.float16)
+    lo = (v - hi.to(torch.float32)).to(torch.float16)
+    return hi, lo
+
+
+def _h2_k_natural(S):
+    s, kb, e = torch.meshgrid(torch.arange(S), torch.arange(2), torch.arange(8), indexing="ij")
+    return 16 * s + 8 * kb + e
+
+
+def _h2_k_hidden():
+    s, kb, e = torch.meshgrid(torch.arange(8), torch.arange(2), torch.arange(8), indexing="ij")
+    return 32 * (s >> 1) + (e & 3) + 8 * (2 * (s & 1) + (e >> 2)) + 4 * kb
+
+
+def _pack_h2(Ws, bs, kidx):
+    """Ws [128, Kdim] scaled f32 weights, bs [128] scaled bias or None, kidx [S, 2, 8] -> f16 tensor of
+    (S*8 [+ 4]) blocks x 64 lanes x 8."""
+    dev = Ws.device
+    S = kidx.shape[0]
+    lane_i, lane_kb = _LANE_I.to(dev), _LANE_H.to(dev)
+    rows = 32 * torch.arange(4, device=dev)[:, None] + lane_i[None, :]                  # [4, 64]
+    k = kidx.to(dev)[:, lane_kb, :]                                                      # [S, 64, 8]
+    vals = Ws[rows[None, :, :, None].expand(S, 4, 64, 8), k[:, None, :, :].expand(S, 4, 64, 8)]
+    hi, lo = _h2_split(vals)
+    blocks = torch.stack([hi, lo], dim=2).reshape(S * 8, 64, 8)                          # [S, 4, 2, 64, 8]
+    if bs is None:
+        return blocks.contiguous()
+    bb = torch.zeros(4, 64, 8, dtype=torch.float16, device=dev)
+    bhi, blo = _h2_split(bs.reshape(4, 32))
+    bb[:, :32, 0] = bhi
+    bb[:, :32, 1] = blo
+    return torch.cat([blocks, bb], dim=0).contiguous()
+
+
+def pack_dense_for_fused_h2(linears, nc_slot_host, d, n_bins):
+    """Pack DenseNet([n_in, 128, 128, P]) for bgk_coupling_rqs_dense_h2.
+    Returns (A0, A1, A2 f16 device tensors, (c0, c1, c2) unscale factors)."""
+    l0, l1, l2 = linears
+    W0, b0 = l0.weight.detach().float(), l0.bias.detach().float()
+    W1, b1 = l1.weight.detach().float(), l1.bias.detach().float()
+    W2, b2 = l2.weight.detach().float(), l2.bias.detach().float()
+    n_in = l0.in_features
+    S0 = (n_in + 1 + 15) // 16
+    e0, e1, e2 = _h2_scale_exp(W0, b0), _h2_scale_exp(W1, b1), _h2_scale_exp(W2, b2)
+    W0e = torch.zeros(128, 16 * S0, dtype=torch.float32, device=W0.device)
+    W0e[:, :n_in] = W0
+    W0e[:, n_in] = b0                                   # column of the constant-1 feature
+    A0 = _pack_h2(W0e * 2.0 ** e0, None, _h2_k_natural(S0))
+    A1 = _pack_h2(W1 * 2.0 ** e1, b1 * 2.0 ** e1, _h2_k_hidden())
+    ncp = _lib.lib().bgk_pack_rqs_columns(d, n_bins, None, None)
+    src = np.empty(ncp, dtype=np.int32)
+    slots = np.ascontiguousarray(nc_slot_host, dtype=np.int32)
+    _lib.lib().bgk_pack_rqs_columns(d, n_bins, slots.ctypes.data, src.ctypes.data)
+    src_t = torch.as_tensor(src.astype(np.int64), device=W2.device)
+    W2r = torch.where(src_t[:, None] >= 0, W2[src_t.clamp_min(0)], torch.zeros((), dtype=W2.dtype, device=W2.device)) * 2.0 ** e2
+    b2r = torch.where(src_t >= 0, b2[src_t.clamp_min(0)], torch.zeros((), dtype=b2.dtype, device=b2.device)) * 2.0 ** e2
+    A2 = torch.cat([_pack_h2(W2r[c * 128:(c + 1) * 128], b2r[c * 128:(c + 1) * 128], _h2_k_hidden())
+                    for c in range(ncp // 128)], dim=0).contiguous()
+    return A0, A1, A2, (2.0 ** -e0, 2.0 ** -e1, 2.0 ** -e2)
+
+
+def _gemm_mode(transformer):
+    mode = getattr(transformer, "gemm_mode", None) or GEMM_MODE
+    if mode not in ("f32", "f16x2"):
+        raise ValueError(f"unknown gemm_mode {mode!r} (expected 'f32' or 'f16x2')")
+    return mode
+
+
 def _fused_plan(transformer, y_dim, nc_slot_host):
     """Decide (and cache) whether the transformer's conditioner can run fused; pack its weights."""
+    mode = _gemm_mode(transformer)
     net = transformer._params_net
     periodic = False
     if type(net) is WrapPeriodic:
@@ -175,9 +261,10 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     params = [p for lin in (l0, l1, l2) for p in (lin.weight, lin.bias)]
     version = tuple((p.data_ptr(), p._version) for p in params)
     cache = transformer._fused_cache
-    if cache.get("version") != version or cache.get("y_dim") != y_dim:
+    if cache.get("version") != version or cache.get("y_dim") != y_dim or cache.get("mode") != mode:
         cache.clear()
-        cache.update(version=version, y_dim=y_dim, packed=pack_dense_for_fused((l0, l1, l2), nc_slot_host, y_dim, n_bins),
+        pack = pack_dense_for_fused if mode == "f32" else pack_dense_for_fused_h2
+        cache.update(version=version, y_dim=y_dim, mode=mode, packed=pack((l0, l1, l2), nc_slot_host, y_dim, n_bins),
                      act=act, periodic=periodic, d_c=d_c, n_bins=n_bins,
                      circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
     return cache
@@ -193,7 +280,7 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
     if plan is None or x.shape[-1] != plan["d_c"]:
         return None
     _lib.require_hip(x, y)
-    W0p, W1p, W2p = plan["packed"]
+    W0p, W1p, W2p = plan["packed"][:3]
     if W0p.device != y.device:
         return None
     x2, ldc = _lib.rowmajor(x)
@@ -203,13 +290,19 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
     dlogp = torch.empty((B,), dtype=torch.float32, device=y.device)
     bins = torch.empty((B, d), dtype=torch.int32, device=y.device) if want_bin_idx else None
     s = transformer._default_settings
-    with torch.cuda.device(y.device):
-        st = _lib.lib().bgk_coupling_rqs_dense(
-            _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p),
-            128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
+    tail = (128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
             transformer._left, transformer._right, transformer._bottom, transformer._top,
             s["min_bin_width"], s["min_bin_height"], s["min_derivative"], int(s.get("enable_identity_init", False)),
             _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.ptr(bins), _lib.ptr(oob_counter), _lib.stream_ptr(y.device))
+    with torch.cuda.device(y.device):
+        if plan["mode"] == "f32":
+            st = _lib.lib().bgk_coupling_rqs_dense(
+                _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p), *tail)
+        else:
+            c0, c1, c2 = plan["packed"][3]
+            st = _lib.lib().bgk_coupling_rqs_dense_h2(
+                _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p),
+                c0, c1, c2, *tail)
     if st == -2:
         return None
     _lib.check(st, "bgk_coupling_rqs_dense")

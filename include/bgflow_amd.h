@@ -184,6 +184,23 @@ int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_c, int32_t 
                            float* out, int64_t ldo, float* dlogp, int32_t accumulate,
                            int32_t* bin_idx, int32_t* oob_count, void* stream);
 
+/* Same layer, same arguments, with the conditioner GEMMs on the f16 matrix cores in split-f16 form
+ * (every f32 operand = hi + lo f16 pair, three v_mfma_f32_32x32x16_f16 per product, f32 accumulate): f32-class
+ * accuracy (measured 0.47 ulp32 rms of sum|a||b| vs 0.65 for the f32 fma chain) at 16/3 times the MFMA rate;
+ * not bit-identical to the f32 chain.  A0p/A1p/A2p: f16 operand blocks and c0..c2: per-layer power-of-two
+ * unscale factors from bgflow_amd/dense.py::pack_dense_for_fused_h2 (layout in bgk_fused.hip / DESIGN.md). */
+int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                              const void* A0p, const void* A1p, const void* A2p,
+                              float c0, float c1, float c2,
+                              int32_t H0, int32_t H1, int32_t act,
+                              const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
+                              uint64_t circ_mask, int32_t inverse,
+                              double left, double right, double bottom, double top,
+                              double min_bin_width, double min_bin_height, double min_derivative,
+                              int32_t identity_init,
+                              float* out, int64_t ldo, float* dlogp, int32_t accumulate,
+                              int32_t* bin_idx, int32_t* oob_count, void* stream);
+
 /* number of packed columns NCp for (d, K) and the source column (in the reference's params
  * layout, P = 3*K*d + n_nc) of every packed column, -1 for padding.  HOST function:
  * src_col is a host int32[NCp] buffer (pass NULL to query NCp only). */

@@ -406,6 +406,74 @@ def test_fused_roundtrip_at_scale(hip_lib, dev):
     assert float(ys[ti].min()) >= 0 and float(ys[ti].max()) <= 1
 
 
+def _set_gemm_mode(flow, mode):
+    import bgflow_amd as bg
+    for block in flow:
+        if isinstance(block, bg.CouplingFlow) and hasattr(block.transformer, "_fused_cache"):
+            block.transformer.gemm_mode = mode
+
+
+@pytest.mark.parametrize("kind", ["T|F", "F|T", "B|A"])
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("B", [1, 31, 4133])
+def test_fused_split_f16_layer_vs_oracle(hip_lib, dev, kind, inverse, B):
+    """gemm_mode='f16x2' (conditioner GEMMs as hi+lo f16 pairs on the f16 matrix cores): same accuracy class as
+    the exact-f32 kernel -- measured against the f64 oracle -- and agreement with the f32 oracle to rounding"""
+    from oracle import flow_oracle as fo
+    layer_cpu, ti = _layer(kind)
+    layer, _ = _layer(kind, dev)
+    xs = [synth(B + 7 * i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9))]
+    layer.transformer.return_bin_indices = True
+    res = {}
+    for mode in ("f32", "f16x2"):
+        layer.transformer.gemm_mode = mode
+        with torch.no_grad():
+            *outs, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
+        assert layer.transformer._fused_cache.get("mode") == mode, "the fused path must have run in this mode"
+        res[mode] = (outs[ti].cpu().numpy(), dl.cpu().numpy(), layer.transformer.last_bin_indices.cpu().numpy())
+    trace = []
+    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, trace)
+    e32 = np.abs(res["f32"][0] - outs64[ti]).max(), np.abs(res["f32"][1] - dl64).max()
+    e16 = np.abs(res["f16x2"][0] - outs64[ti]).max(), np.abs(res["f16x2"][1] - dl64).max()
+    assert e16[0] <= 3 * e32[0] + 2e-7, f"outputs: split-f16 {e16[0]:.2e} vs f32 {e32[0]:.2e} (error to the f64 oracle)"
+    assert e16[1] <= 3 * e32[1] + 2e-6, f"dlogp: split-f16 {e16[1]:.2e} vs f32 {e32[1]:.2e}"
+    np.testing.assert_allclose(res["f16x2"][0], res["f32"][0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(res["f16x2"][1], res["f32"][1], rtol=2e-5, atol=2e-5)
+    # bin indices: identical except for inputs within rounding distance of a knot (then the neighbouring bin)
+    diff = res["f16x2"][2] != trace[0]["bin_idx"]
+    assert diff.mean() <= 1e-3 and np.abs(res["f16x2"][2] - trace[0]["bin_idx"]).max() <= 1
+
+
+def test_fused_split_f16_flow16_golden(hip_lib, golden, dev):
+    """cfg 3 with gemm_mode='f16x2' against the reference goldens at the same tolerances as the f32 path"""
+    from bgflow_amd import configs
+    G = golden("g_flow16")
+    gen = configs.make_ala2_spline_generator(dev)
+    _set_gemm_mode(gen.flow, "f16x2")
+    u = [G[k] for k in ("u_bonds", "u_angles", "u_torsions", "u_fixed")]
+    with torch.no_grad():
+        *ics, dl = gen.flow[:16](*[t(v, dev) for v in u])
+        x, dl_all = gen.flow(*[t(v, dev) for v in u])
+    assert all(b.transformer._fused_cache.get("mode") == "f16x2" for b in list(gen.flow)[:16])
+    noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
+    assert np.abs(dl_all.cpu().numpy() - G["dlogp64"]).max() <= 1e-5 * np.abs(G["dlogp64"]).max() + noise
+    np.testing.assert_allclose(torch.cat(ics, -1).cpu().numpy(), G["block15_32"][:, :60], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(x.cpu().numpy(), G["x64"], rtol=0, atol=5 * np.abs(G["x32"] - G["x64"]).max() + 1e-5)
+
+
+def test_fused_split_f16_roundtrip_at_scale(hip_lib, dev):
+    layer, ti = _layer("B|A", dev)
+    layer.transformer.gemm_mode = "f16x2"
+    g = torch.Generator(device=dev).manual_seed(3)
+    xs = [torch.rand(1 << 20, d, device=dev, generator=g) for d in (17, 17, 17, 9)]
+    with torch.no_grad():
+        *ys, dl = layer(*xs)
+        *zs, dli = layer(*ys, inverse=True)
+    assert float((zs[ti] - xs[ti]).abs().max()) < 2e-5
+    assert float((dl + dli).abs().max()) < 5e-4
+    assert float(ys[ti].min()) >= 0 and float(ys[ti].max()) <= 1
+
+
 def test_augmented_flow_cfg5_on_gpu(hip_lib, golden, dev):
     """cfg 5 through the GPU path (fused spline layers + affine kernel with torch conditioners) vs golden"""
     from bgflow_amd import configs
