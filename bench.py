@@ -74,6 +74,19 @@ def timed_steps(gen, zs, steps):
     return evs
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/<round>_traffic.json,
+    written by tools/profile_round.sh: FETCH_SIZE x 2 [gfx950 rule] + WRITE_SIZE, KiB units), or None"""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1])).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(workload, n_samples):
     """the CPU oracle (C restatement + OpenMP) on a bounded sample of the same workload"""
     from oracle import flow_oracle as fo
@@ -142,6 +155,23 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- extra: the same workload with the conditioner GEMMs in exact-f32 MFMA mode (bit-identical to the CPU oracle)
+    exact = None
+    gemm_mode = _dense.GEMM_MODE
+    if args.workload == "cfg3" and gemm_mode != "f32" and rank == 0 and world == 1:
+        _dense.GEMM_MODE = "f32"
+        timed_steps(gen, zs, 1)
+        torch.cuda.synchronize(dev)
+        te = time.perf_counter()
+        timed_steps(gen, zs, 3)
+        torch.cuda.synchronize(dev)
+        te = (time.perf_counter() - te) / 3
+        exact = dict(gemm="f32", value=args.batch / te, unit="samples/s", ms_per_step=1e3 * te, steps=3,
+                     note="same flow, conditioner GEMMs on the f32-input MFMA (exact fma chain, bit-identical to the oracle)")
+        _dense.GEMM_MODE = gemm_mode
+        timed_steps(gen, zs, 1)   # re-pack for the headline mode (KL bench below uses the generic path)
+        torch.cuda.synchronize(dev)
+
     # ---- extra (second half of BASELINE.json's metric): KL-loss training steps/s -------------------------
     # one step = kldiv(B).mean() -> backward through the hand-written backward kernels -> one all-reduce of
     # [sum, n] (+ one flat gradient bucket) -> Adam.  Reported next to the headline, not instead of it.
@@ -192,9 +222,16 @@ def main():
         flops_per_launch = 2.0 * sum(layer_macs(gen.flow[i]) for i in coupling) / n_launch * args.batch
         alg_bytes_step = ALG_BYTES[args.workload] * args.batch
         if args.workload == "cfg3":
+            split = gemm_mode == "f16x2"
             roof = dict(bound="mfma", achieved=flops_per_launch / avg_launch_s / 1e12, peak=MFMA_F32_PEAK_TFLOPS,
-                        unit="TFLOP/s", traffic=None,
-                        kernel="coupling_rqs_dense_kernel (fused DenseNet-on-MFMA + RQ-spline coupling layer)",
+                        unit="TFLOP/s", traffic=measured_traffic("coupling_rqs_dense_h2_kernel" if split else "coupling_rqs_dense_kernel"),
+                        kernel=("coupling_rqs_dense_h2_kernel (fused DenseNet on the f16 matrix cores in split-f16 form + RQ-spline "
+                                "coupling layer)" if split else
+                                "coupling_rqs_dense_kernel (fused DenseNet on the f32-input MFMA + RQ-spline coupling layer)"),
+                        note=("achieved = algorithmic f32 flops of the conditioner (2*MACs) / launch time, peak = dense f32-input MFMA "
+                              "peak: the split-f16 form executes 3 f16 MFMAs per product at 16x the f32 rate, so the fraction can "
+                              "exceed 1; the kernel is then VALU-issue bound (spline + SiLU), see profiles/README.md" if split else
+                              "f32-input MFMA and f32 VALU share the issue port on gfx950: time = MFMA + VALU, see profiles/README.md"),
                         launches_per_step=n_launch, avg_launch_ms=1e3 * avg_launch_s,
                         flops_per_launch=flops_per_launch,
                         hbm_view=dict(algorithmic_bytes_per_step=alg_bytes_step,
@@ -208,10 +245,14 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload=desc, batch_per_gpu=args.batch, global_batch=args.batch * world,
-                               parallelism=f"dp{world}"),
+                               parallelism=f"dp{world}",
+                               conditioner_gemm=("split-f16: f32 operands as hi+lo f16 pairs, 3 MFMAs per product, f32 accumulate "
+                                                 "(f32-class accuracy)" if gemm_mode == "f16x2" else "f32-input MFMA (exact)")),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_samples)
+        if exact is not None:
+            out["exact_f32_mode"] = exact
         if kl is not None:
             out["kl"] = kl
         print(json.dumps(out))

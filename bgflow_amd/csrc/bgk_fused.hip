@@ -582,16 +582,19 @@ struct FusedArgsH2 {
 constexpr int H2_STEPS = 8;                            /* 128 hidden units / 16 */
 constexpr int H2_BLOCKS = (H2_STEPS * 4 * 2 + 4);      /* 1 KiB blocks per 128-row GEMM incl. bias */
 
-template <int NT>
-struct AFrag { uint4 v[NT][2]; };
+struct AFrag { uint4 v[4][2]; };     /* one k16-step: 4 output tiles x {hi, lo} */
+struct BFrag { h16x8 hi[H2_STEPS], lo[H2_STEPS]; };   /* a 128-wide activation vector as B operands: 64 VGPRs */
 
-template <int NT>
-__device__ __forceinline__ void h2_load(AFrag<NT>& f, const uint4* W, int s, int lane) {
+__device__ __forceinline__ void h2_load(AFrag& f, const uint4* W, int s, int lane) {
 #pragma unroll
-    for (int m = 0; m < NT; ++m) {
+    for (int m = 0; m < 4; ++m) {
         f.v[m][0] = W[((s * 4 + m) * 2 + 0) * 64 + lane];
         f.v[m][1] = W[((s * 4 + m) * 2 + 1) * 64 + lane];
     }
+}
+__device__ __forceinline__ void h2_load_bias(AFrag& f, const uint4* W, int lane) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) f.v[m][0] = W[(H2_STEPS * 8 + m) * 64 + lane];
 }
 
 __device__ __forceinline__ void h2_split(const float (&v)[8], h16x8& hi, h16x8& lo) {
@@ -604,41 +607,53 @@ __device__ __forceinline__ void h2_split(const float (&v)[8], h16x8& hi, h16x8& 
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void h2_mfma(f32x16 (&out)[4], const AFrag<NT>& a, const h16x8& bhi, const h16x8& blo) {
-    /* small terms first; tiles interleaved so that consecutive MFMAs are independent */
-#pragma unroll
-    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][1]), bhi, out[m], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), blo, out[m], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), bhi, out[m], 0, 0, 0);
-}
-
-/* out[0..NT) = W' * in + b'  for a 128-wide hidden input held in accumulator layout (already activated) */
-template <int NT>
-__device__ __forceinline__ void h2_gemm_hidden(f32x16 (&out)[4], const f32x16 (&in)[4], const uint4* W, int lane) {
-    AFrag<NT> cur, nxt;
-    h2_load<NT>(cur, W, 0, lane);
+/* activated f32 tiles (accumulator layout) -> B operands of the 8 k16-steps; done ONCE per layer input */
+__device__ __forceinline__ void h2_make_b(BFrag& b, const f32x16 (&in)[4]) {
 #pragma unroll
     for (int s = 0; s < H2_STEPS; ++s) {
-        if (s + 1 < H2_STEPS) h2_load<NT>(nxt, W, s + 1, lane);
-        else {
-#pragma unroll
-            for (int m = 0; m < NT; ++m) nxt.v[m][0] = W[(H2_STEPS * 8 + m) * 64 + lane];   /* bias blocks */
-        }
-        __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch above this step's work */
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = in[s >> 1][8 * (s & 1) + e];
-        h16x8 bhi, blo;
-        h2_split(v, bhi, blo);
-        h2_mfma<NT>(out, cur, bhi, blo);
-        if (s + 1 < H2_STEPS) cur = nxt;
+        h2_split(v, b.hi[s], b.lo[s]);
+    }
+}
+
+__device__ __forceinline__ void h2_mfma(f32x16 (&out)[4], const AFrag& a, const h16x8& bhi, const h16x8& blo) {
+    /* small terms first; tiles interleaved so that consecutive MFMAs are independent */
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][1]), bhi, out[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), blo, out[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), bhi, out[m], 0, 0, 0);
+}
+
+/* A-operand ring of one 128-row GEMM: the first H2_RING - 1 steps are requested by h2_gemm_start (possibly long before the
+ * GEMM runs -- e.g. ahead of the previous chunk's spline, which hides the L2 round trip), step s + H2_RING - 1
+ * while step s computes. */
+constexpr int H2_RING = 2;
+struct H2Ring { AFrag f[H2_RING]; };
+
+__device__ __forceinline__ void h2_gemm_start(H2Ring& r, const uint4* W, int lane) {
+#pragma unroll
+    for (int s = 0; s < H2_RING - 1; ++s) h2_load(r.f[s], W, s, lane);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+/* out[0..4) += W' * b + b'   (ring already started) */
+__device__ __forceinline__ void h2_gemm_run(f32x16 (&out)[4], H2Ring& r, const BFrag& b, const uint4* W, int lane) {
+#pragma unroll
+    for (int s = 0; s < H2_STEPS; ++s) {
+        constexpr int D = H2_RING - 1;
+        if (s + D < H2_STEPS) h2_load(r.f[(s + D) % H2_RING], W, s + D, lane);
+        else if (s + D == H2_STEPS) h2_load_bias(r.f[(s + D) % H2_RING], W, lane);
+        __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch above this step's MFMAs */
+        h2_mfma(out, r.f[s % H2_RING], b.hi[s], b.lo[s]);
     }
     const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, nxt.v[m][0]), one2, out[m], 0, 0, 0);
+    for (int m = 0; m < 4; ++m)
+        out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, r.f[H2_STEPS % H2_RING].v[m][0]), one2, out[m], 0, 0, 0);
 }
 
 /* activation of x = t * c (c = exact power-of-two unscale) */
@@ -692,30 +707,36 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
         f32x16 h[4], acc[4];
         zero4(h);
         for (int s = 0; s < ah.S0; ++s) {
-            AFrag<4> fr;
-            h2_load<4>(fr, ah.A0, s, lane);
+            AFrag fr;
+            h2_load(fr, ah.A0, s, lane);
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = s_p[(16 * s + 8 * hh + e) * SROW + j];
             h16x8 bhi, blo;
             h2_split(v, bhi, blo);
-            h2_mfma<4>(h, fr, bhi, blo);
+            h2_mfma(h, fr, bhi, blo);
         }
+        H2Ring ring;
+        h2_gemm_start(ring, ah.A1, lane);          /* layer-1 operands in flight during the activation */
 #pragma unroll
         for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(h[m], ah.c0);
 
         /* ---- layer 1 ---- */
+        BFrag bf;
+        h2_make_b(bf, h);
         zero4(acc);
-        h2_gemm_hidden<4>(acc, h, ah.A1, lane);
+        h2_gemm_run(acc, ring, bf, ah.A1, lane);
+        h2_gemm_start(ring, ah.A2, lane);
 #pragma unroll
         for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(acc[m], ah.c1);
+        h2_make_b(bf, acc);                         /* the layer-2 B operands, shared by all chunks */
 
-        /* ---- layer 2 in chunks of 128 packed columns + spline (roles swapped: acc = B operand, h = accumulator) ---- */
+        /* ---- layer 2 in chunks of 128 packed columns + spline:
+         *   GEMM(0);  for c: { h -> LDS;  request A(c+1);  spline(c);  GEMM(c+1) } ---- */
         float run = 0.0f;
         int oob_local = 0;
         zero4(h);
-        if (a.n_chunks == 1 && a.last_tiles <= 2) h2_gemm_hidden<2>(h, acc, ah.A2, lane);
-        else h2_gemm_hidden<4>(h, acc, ah.A2, lane);
+        h2_gemm_run(h, ring, bf, ah.A2, lane);
         for (int c = 0; c < a.n_chunks; ++c) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -724,13 +745,10 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
+            const uint4* Wn = ah.A2 + (size_t)(c + 1) * H2_BLOCKS * 64;
+            const bool more = c + 1 < a.n_chunks;
+            if (more) h2_gemm_start(ring, Wn, lane);
             int bins[3];
-            if (c + 1 < a.n_chunks) {
-                zero4(h);
-                const uint4* Wn = ah.A2 + (size_t)(c + 1) * H2_BLOCKS * 64;
-                if (c + 2 == a.n_chunks && a.last_tiles <= 2) h2_gemm_hidden<2>(h, acc, Wn, lane);
-                else h2_gemm_hidden<4>(h, acc, Wn, lane);
-            }
             NoGemm g;
             spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
             if (a.bin_idx) {
@@ -739,6 +757,10 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
                     const int q = 2 * it + hh;
                     if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
                 }
+            }
+            if (more) {
+                zero4(h);
+                h2_gemm_run(h, ring, bf, Wn, lane);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -150,7 +150,10 @@ def pack_dense_for_fused(linears, nc_slot_host, d, n_bins):
 # max(|W|, |b|) lands in [2^14, 2^15).  One 1 KiB block = 64 lanes x 8 f16; block(s, m, p) = (s*4 + m)*2 + p
 # holds, for lane l = 32 kb + i, W'[32 m + i][k(s, kb, e)], e = 0..7, part p; after the S k16-steps follow 4
 # bias blocks (lanes < 32: {b_hi, b_lo, 0, ...}).  See bgk_fused.hip (coupling_rqs_dense_h2_kernel).
-GEMM_MODE = "f32"     # module default: "f32" (exact f32-input MFMA, bit-identical to the oracle) or "f16x2"
+# module default of the fused kernel's conditioner GEMMs; a transformer's `gemm_mode` attribute overrides it:
+#   "f16x2": split-f16 on the f16 matrix cores (f32-class accuracy, see bgk_fused.hip; ~1.75x the layer throughput)
+#   "f32":   f32-input MFMA = exact k-ordered fma chain, bit-identical to the CPU oracle
+GEMM_MODE = "f16x2"
 
 
 def _h2_scale_exp(*tensors):

@@ -332,6 +332,7 @@ def _layer(kind, dev=None):
     slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
     what, on = {"T|F": ("TORSIONS", "FIXED"), "F|T": ("FIXED", "TORSIONS"), "B|A": ("BONDS", "ANGLES")}[kind]
     layer = hash_init_(configs._spline_coupling(what, on, dims, circ, slot))
+    layer.transformer.gemm_mode = "f32"      # the bit-exact tests pin the exact-f32 GEMM mode; split-f16 has its own tests
     return (layer.to(dev) if dev is not None else layer), slot[what]
 
 
@@ -374,6 +375,7 @@ def test_fused_flow16_bit_exact_and_golden(hip_lib, golden, dev):
     G = golden("g_flow16")
     gen_cpu = configs.make_ala2_spline_generator()
     gen = configs.make_ala2_spline_generator(dev)
+    _set_gemm_mode(gen.flow, "f32")
     u = [G[k] for k in ("u_bonds", "u_angles", "u_torsions", "u_fixed")]
     fo.MFMA_ORDER = True
     try:

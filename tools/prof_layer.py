@@ -1,9 +1,12 @@
 """Micro-benchmark of single kernels (used under rocprofv3): python tools/prof_layer.py [kind] [B] [reps]
-kind: fused-BA | fused-TF | fused-FT | rqs-BA (generic spline kernel only) | ic | affine"""
+kind: fused-BA | fused-TF | fused-FT | rqs-BA (generic spline kernel only) | ic | affine
+env BGK_GEMM=f32|f16x2 selects the conditioner GEMM mode of the fused kernel"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from bgflow_amd import configs
+from bgflow_amd import configs, dense
+if os.environ.get("BGK_GEMM"):
+    dense.GEMM_MODE = os.environ["BGK_GEMM"]
 from bgflow_amd.utils import hash_init_
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "fused-BA"

@@ -1,24 +1,38 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): rocprofv3 kernel stats of the default bench command + HBM traffic counters
+# Run ON THE GPU BOX (via gpurun): rocprofv3 kernel stats of the default bench command + HBM traffic / SQ counters
 # of the dominant kernel.  Outputs land in gpurun_out/prof_$1; copy the summaries to profiles/ afterwards.
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+SHORT="--no-cpu-baseline --kl-steps 0"
+# 1. kernel trace + stats of the bench command (default flags except the CPU leg / KL extra, which launch no hot-path kernels)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py $SHORT > $OUT/bench_under_rocprof.log 2>&1
 grep '"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_line_under_rocprof.json
-# PMC passes (separate runs, counters only): FETCH_SIZE / WRITE_SIZE (KiB units; gfx950: FETCH_SIZE reads 1/2 of wide coalesced streams)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_rqs -o p -- python tools/prof_layer.py rqs-BA 1048576 3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_rqs -o p -- python tools/prof_layer.py rqs-BA 1048576 3 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_sq -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
-for d in pmc_fetch pmc_write pmc_fetch_rqs pmc_write_rqs pmc_sq pmc_grbm; do echo "== $d"; python tools/pmc_summary.py $OUT/$d | grep -A12 "coupling_rqs\|rqs_kernel" ; done > $OUT/pmc_summary.txt
-python bench.py > $OUT/bench_plain.json 2>/dev/null
-head -c 600 $OUT/bench_plain.json; echo; cat $OUT/pmc_summary.txt | head -60
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32 -o bench -- python bench.py $SHORT --gemm f32 > $OUT/bench_f32_under_rocprof.log 2>&1
+# 2. PMC passes (separate runs, counters only) over the same command, 2 steps: HBM traffic of every kernel
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python bench.py $SHORT --steps 2 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python bench.py $SHORT --steps 2 --warmup 1 > /dev/null 2>&1
+python tools/traffic_json.py $OUT/pmc_fetch $OUT/pmc_write $OUT/traffic.json > $OUT/traffic.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_f32 -o p -- python bench.py $SHORT --gemm f32 --steps 2 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_f32 -o p -- python bench.py $SHORT --gemm f32 --steps 2 --warmup 1 > /dev/null 2>&1
+python tools/traffic_json.py $OUT/pmc_fetch_f32 $OUT/pmc_write_f32 $OUT/traffic_f32.json > $OUT/traffic_f32.txt
+# 3. SQ / GRBM counters of one fused layer (B|A, d = 17), both GEMM modes
+for MODE in f16x2 f32; do
+  export BGK_GEMM=$MODE
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_sq_$MODE -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm_$MODE -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
+done
+unset BGK_GEMM
+for d in pmc_sq_f16x2 pmc_grbm_f16x2 pmc_sq_f32 pmc_grbm_f32; do echo "== $d"; python tools/pmc_summary.py $OUT/$d coupling; done > $OUT/pmc_summary.txt
+# 4. un-profiled bench line (full default command incl. cpu_baseline + KL extra)
+python bench.py > $OUT/bench_plain.json 2>$OUT/bench_plain.err
+head -c 900 $OUT/bench_plain.json; echo
+cat $OUT/traffic.txt; cat $OUT/pmc_summary.txt | head -60
 python - <<PY
 import csv,glob
-f=glob.glob("$OUT/stats/**/*kernel_stats.csv",recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:12]: print(r["Name"][:80], r["Calls"], r["AverageNs"], r["Percentage"])
+for tag in ("stats","stats_f32"):
+    f=glob.glob("$OUT/%s/**/*kernel_stats.csv" % tag,recursive=True)[0]
+    print(tag)
+    for r in list(csv.DictReader(open(f)))[:8]: print("  ", r["Name"][:80], r["Calls"], r["AverageNs"], r["Percentage"])
 PY

@@ -6,7 +6,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE, int KIND>   // MODE bit0: mfma, bit1: valu ; KIND 0: bf16 32x32x16, 1: f32 32x32x2
-__global__ __launch_bounds__(512) void k(float* out, int iters) {
+__global__ __launch_bounds__(1024) void k(float* out, int iters) {
     f32x16 acc[4];
     for (int m = 0; m < 4; ++m) for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     bf16x8 a, b;
@@ -51,11 +51,10 @@ float run(float* out, int blocks, int threads, int iters) {
 }
 
 int main() {
-    float* out; hipMalloc(&out, 256 * 8 * 512 * 4);
+    float* out; hipMalloc(&out, 256 * 8 * 1024 * 4);
     const int iters = 20000;
-    for (int wps = 1; wps <= 2; ++wps) {   // waves per SIMD
+    for (int wps = 1; wps <= 4; ++wps) {   // waves per SIMD
         int threads = 256 * wps / 1;       // 4 SIMDs x wps waves
-        if (threads > 512) threads = 512;
         int blocks = 256;
         printf("waves/SIMD=%d\n", wps);
         printf("  bf16 mfma only            %.3f ms\n", run<1, 0>(out, blocks, threads, iters));
