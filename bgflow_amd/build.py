@@ -36,7 +36,7 @@ def _stale():
 
 
 def build_extension(force=False, verbose=False):
-    if not force and not _stale():
+    if not force and not os.environ.get("BGK_EXTRA_FLAGS") and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("BGK_EXTRA_FLAGS", "").split() + ["-o", LIB] + sources()

@@ -40,6 +40,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef BGK_PIPE_ACT
 #define BGK_PIPE_ACT 0
 #endif
+#ifndef BGK_ABL
+#define BGK_ABL 0   /* timing ablations of the split-f16 kernel (tools/ablate_h2.sh): 1 no spline, 2 no chunk GEMMs, 4 no activation, 8 no layer-2 LDS transpose */
+#endif
 
 constexpr int FW = 4;                 /* waves per workgroup */
 constexpr int FTHREADS = FW * 64;
@@ -661,7 +664,9 @@ template <int ACT>
 __device__ __forceinline__ void act_tile_scaled(f32x16& t, float c) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] *= c;
+#if !(BGK_ABL & 4)
     act_tile<ACT>(t);
+#endif
 }
 
 template <int ACT, int INV>
@@ -738,19 +743,27 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
         zero4(h);
         h2_gemm_run(h, ring, bf, ah.A2, lane);
         for (int c = 0; c < a.n_chunks; ++c) {
+#if !(BGK_ABL & 8)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * 32 + j] = h[m][r] * ah.c2;
+#else
+            s_p[lane] = h[0][0] + h[1][1] + h[2][2] + h[3][3];
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
             const uint4* Wn = ah.A2 + (size_t)(c + 1) * H2_BLOCKS * 64;
             const bool more = c + 1 < a.n_chunks;
             if (more) h2_gemm_start(ring, Wn, lane);
-            int bins[3];
+            int bins[3] = {0, 0, 0};
             NoGemm g;
+#if !(BGK_ABL & 1)
             spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+#else
+            run += s_p[(lane & 127) * 32 + j];
+#endif
             if (a.bin_idx) {
 #pragma unroll
                 for (int it = 0; it < 3; ++it) {
@@ -759,8 +772,12 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
                 }
             }
             if (more) {
+#if !(BGK_ABL & 2)
                 zero4(h);
                 h2_gemm_run(h, ring, bf, Wn, lane);
+#else
+                h[0][0] += ring.f[0].v[0][0].x;
+#endif
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -17,6 +17,51 @@ from .utils import is_list_or_tuple
 __all__ = ["DenseNet", "MeanFreeDenseNet", "WrapPeriodic"]
 
 
+def column_sum(g, nblk=1024):
+    """out[c] = sum_r g[r, c] on the HIP kernel bgk_column_sum (f32, 2-D, HIP device)"""
+    _lib.require_hip(g)
+    g2, ldg = _lib.rowmajor(g)
+    B, P = g2.shape
+    nblk = int(max(1, min(nblk, (B + 63) // 64)))
+    partial = torch.empty((nblk, P), dtype=torch.float32, device=g.device)
+    out = torch.empty((P,), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        st = _lib.lib().bgk_column_sum(_lib.ptr(g2), ldg, B, P, _lib.ptr(partial), nblk, _lib.ptr(out), _lib.stream_ptr(g.device))
+    _lib.check(st, "bgk_column_sum")
+    return out
+
+
+class _LinearFn(torch.autograd.Function):
+    """``addmm`` whose backward takes the bias gradient from bgk_column_sum instead of torch's column reduction
+    (``grad.sum(0)`` of a [2^18, 425] tensor runs at ~170 GB/s on MI355X: 2.7 ms per layer, a third of a KL
+    training step; rocBLAS gemv with a ones vector is slower still)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = g.t() @ x if ctx.needs_input_grad[1] else None
+        gb = column_sum(g) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def _run_layers(layers, x):
+    """Sequential forward; 2-D HIP inputs under autograd go through _LinearFn"""
+    fast = x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+    for m in layers:
+        if fast and type(m) is torch.nn.Linear and m.bias is not None and (m.weight.requires_grad or x.requires_grad):
+            x = _LinearFn.apply(x, m.weight, m.bias)
+        else:
+            x = m(x)
+    return x
+
+
 class DenseNet(torch.nn.Module):
     """Multi-layer perceptron ``n_units[0] -> ... -> n_units[-1]`` with ``activation`` after every
     hidden layer (nn/dense.py:9-48)."""
@@ -38,12 +83,12 @@ class DenseNet(torch.nn.Module):
         self._layers = torch.nn.Sequential(*layers)
 
     def forward(self, x):
-        return self._layers(x)
+        return _run_layers(self._layers, x)
 
 
 class MeanFreeDenseNet(DenseNet):
     def forward(self, x):
-        y = self._layers(x)
+        y = _run_layers(self._layers, x)
         return y - y.mean(dim=1, keepdim=True)
 
 
@@ -62,8 +107,12 @@ class WrapPeriodic(torch.nn.Module):
         n = x.shape[-1]
         per = np.arange(n)[self.indices]
         other = np.setdiff1d(np.arange(n), per)
-        ang = 2 * np.pi * (x[..., per] - self.left) / (self.right - self.left)
-        feats = torch.cat([torch.cos(ang), torch.sin(ang), x[..., other]], dim=-1)
+        if len(other) == 0 and np.array_equal(per, np.arange(n)):
+            xp, xo = x, x[..., :0]        # all inputs periodic: no gather (and no scatter-add in backward)
+        else:
+            xp, xo = x[..., per], x[..., other]
+        ang = 2 * np.pi * (xp - self.left) / (self.right - self.left)
+        feats = torch.cat([torch.cos(ang), torch.sin(ang), xo], dim=-1)
         return self.net.forward(feats)
 
 

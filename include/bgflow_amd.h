@@ -201,6 +201,12 @@ int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32
                               float* out, int64_t ldo, float* dlogp, int32_t accumulate,
                               int32_t* bin_idx, int32_t* oob_count, void* stream);
 
+/* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
+ * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).
+ * Deterministic two-stage reduction; `partial` is a caller-provided [nblk, P] workspace. */
+int bgk_column_sum(const float* x, int64_t ldx, int64_t B, int32_t P, float* partial, int32_t nblk,
+                   float* out, void* stream);
+
 /* number of packed columns NCp for (d, K) and the source column (in the reference's params
  * layout, P = 3*K*d + n_nc) of every packed column, -1 for padding.  HOST function:
  * src_col is a host int32[NCp] buffer (pass NULL to query NCp only). */

@@ -683,3 +683,33 @@ def test_cdf_kernel_vs_torch_and_oracle(hip_lib, dev):
         y, dl = bg.CDFTransform(dists[3]).to(dev)(u, inverse=True)
     ref = 20.0 * sps.ndtri(np.clip(u.cpu().numpy().astype(np.float64), 1e-7, 1 - 1e-7))
     np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=3e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,P", [(1, 5), (63, 425), (4133, 128), (1 << 16, 408)])
+def test_column_sum_kernel(hip_lib, dev, B, P):
+    """bias-gradient reduction (bgk_column_sum) vs an f64 sum; through a strided view too"""
+    from bgflow_amd.dense import column_sum
+    x = synth(77 + B, B, P + 3, scale=2.0)
+    xd = t(x, dev)
+    got = column_sum(xd[:, :P]).cpu().numpy()
+    ref = x[:, :P].astype(np.float64).sum(0)
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6 * np.abs(x).sum(0).max())
+
+
+def test_densenet_backward_matches_torch_linear(hip_lib, dev):
+    """DenseNet's custom Linear backward (bias gradient on bgk_column_sum) vs stock torch autograd"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    net = hash_init_(bg.DenseNet([9, 128, 128, 57], torch.nn.SiLU())).to(dev)
+    x = t(synth(5, 1000, 9), dev).requires_grad_(True)
+    w = t(synth(6, 1000, 57), dev)
+    (net(x) * w).sum().backward()
+    g1 = [p.grad.clone() for p in net.parameters()] + [x.grad.clone()]
+    for p in net.parameters():
+        p.grad = None
+    x.grad = None
+    (net._layers(x) * w).sum().backward()
+    g2 = [p.grad for p in net.parameters()] + [x.grad]
+    for a, b in zip(g1, g2):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+
