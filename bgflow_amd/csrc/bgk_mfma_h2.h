@@ -1,0 +1,128 @@
+/* bgk_mfma_h2.h -- split-f16 GEMM building blocks for gfx950 (device only).
+ * f32 operand v = hi + lo, hi = rne_f16(v), lo = rne_f16(v - hi); a product = 3 x v_mfma_f32_32x32x16_f16
+ * (lo*hi, hi*lo, hi*hi; f32 accumulate).  Accuracy: tools/ubench/split_gemm.hip (0.47 ulp32 rms of sum|a||b|).
+ * Orientation D[feature, sample] = W[feature, k] * X[k, sample]: A = packed weights (host: dense.py::_pack_h2),
+ * B = activations of the wave's 32 samples.  Hidden k order = accumulator layout, so a layer's output registers
+ * become the next layer's B operand without data movement.
+ *   packed A of a layer with NT output tiles and S k16-steps: 1 KiB blocks, block(s, m, p) = (s * NT + m) * 2 + p
+ *   (p = 0 hi, 1 lo; lane l = 32 kb + i holds W'[32 m + i][k(s, kb, e)], e = 0..7), then NT bias blocks
+ *   (lanes < 32: {b_hi, b_lo, 0...}).
+ */
+#ifndef BGK_MFMA_H2_H
+#define BGK_MFMA_H2_H
+
+#include "bgk_common.h"
+
+typedef float h2_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h2_h16x8 __attribute__((ext_vector_type(8)));
+
+template <int NT>
+struct H2A { uint4 v[NT][2]; };
+
+template <int NT>
+__device__ __forceinline__ void h2a_load(H2A<NT>& f, const uint4* W, int s, int lane) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        f.v[m][0] = W[((s * NT + m) * 2 + 0) * 64 + lane];
+        f.v[m][1] = W[((s * NT + m) * 2 + 1) * 64 + lane];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void h2a_load_bias(H2A<NT>& f, const uint4* W, int S, int lane) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) f.v[m][0] = W[(S * NT * 2 + m) * 64 + lane];
+}
+
+__device__ __forceinline__ void h2_split8(const float (&v)[8], h2_h16x8& hi, h2_h16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float c = __builtin_amdgcn_fmed3f(v[e], -65000.0f, 65000.0f);
+        const _Float16 h = (_Float16)c;
+        hi[e] = h;
+        lo[e] = (_Float16)(c - (float)h);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void h2_mfma3(h2_f32x16 (&out)[NT], const H2A<NT>& a, const h2_h16x8& bhi, const h2_h16x8& blo) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, a.v[m][1]), bhi, out[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, a.v[m][0]), blo, out[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, a.v[m][0]), bhi, out[m], 0, 0, 0);
+}
+
+/* a 32*HT-wide activation vector (accumulator layout, already activated) as B operands of 2*HT k16-steps */
+template <int HT>
+struct H2B { h2_h16x8 hi[2 * HT], lo[2 * HT]; };
+
+template <int HT>
+__device__ __forceinline__ void h2_make_b(H2B<HT>& b, const h2_f32x16 (&in)[HT]) {
+#pragma unroll
+    for (int s = 0; s < 2 * HT; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = in[s >> 1][8 * (s & 1) + e];
+        h2_split8(v, b.hi[s], b.lo[s]);
+    }
+}
+
+/* out[0..NT) += W' * b + bias'  (K = 32 HT, two-deep A ring) */
+template <int NT, int HT>
+__device__ __forceinline__ void h2_gemm_hidden(h2_f32x16 (&out)[NT], const H2B<HT>& b, const uint4* W, int lane) {
+    constexpr int S = 2 * HT;
+    H2A<NT> ring[2];
+    h2a_load<NT>(ring[0], W, 0, lane);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) h2a_load<NT>(ring[(s + 1) & 1], W, s + 1, lane);
+        else h2a_load_bias<NT>(ring[(s + 1) & 1], W, S, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        h2_mfma3<NT>(out, ring[s & 1], b.hi[s], b.lo[s]);
+    }
+    const h2_h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+        out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, ring[S & 1].v[m][0]), one2, out[m], 0, 0, 0);
+}
+
+/* out[0..NT) += W0' * x   with x rows in LDS [16 S0][srow] (constant-1 row carries the bias column) */
+template <int NT>
+__device__ __forceinline__ void h2_gemm_lds(h2_f32x16 (&out)[NT], const float* s_x, int srow, int S0, const uint4* W, int lane) {
+    const int j = lane & 31, hh = lane >> 5;
+    for (int s = 0; s < S0; ++s) {
+        H2A<NT> fr;
+        h2a_load<NT>(fr, W, s, lane);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = s_x[(16 * s + 8 * hh + e) * srow + j];
+        h2_h16x8 bhi, blo;
+        h2_split8(v, bhi, blo);
+        h2_mfma3<NT>(out, fr, bhi, blo);
+    }
+}
+
+/* t = act(t * c), act: 0 identity, 1 SiLU, 2 ReLU, 3 Tanh (wave-uniform runtime switch) */
+__device__ __forceinline__ void h2_act_tile(h2_f32x16& t, float c, int act) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] *= c;
+    if (act == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            bgk_f2 v = bgk_siluf2((bgk_f2){t[r], t[r + 1]});
+            t[r] = v.x; t[r + 1] = v.y;
+        }
+    } else if (act == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = t[r] > 0.0f ? t[r] : 0.0f;
+    } else if (act == 3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = bgk_tanhf(t[r]);
+    }
+}
+
+/* feature row of output tile m held in accumulator register r by this lane (hh = lane >> 5) */
+__device__ __forceinline__ int h2_row(int m, int r, int hh) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+#endif /* BGK_MFMA_H2_H */

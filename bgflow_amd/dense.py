@@ -223,29 +223,128 @@ def _h2_k_natural(S):
     return 16 * s + 8 * kb + e
 
 
-def _h2_k_hidden():
-    s, kb, e = torch.meshgrid(torch.arange(8), torch.arange(2), torch.arange(8), indexing="ij")
+def _h2_k_hidden(HT=4):
+    s, kb, e = torch.meshgrid(torch.arange(2 * HT), torch.arange(2), torch.arange(8), indexing="ij")
     return 32 * (s >> 1) + (e & 3) + 8 * (2 * (s & 1) + (e >> 2)) + 4 * kb
 
 
-def _pack_h2(Ws, bs, kidx):
-    """Ws [128, Kdim] scaled f32 weights, bs [128] scaled bias or None, kidx [S, 2, 8] -> f16 tensor of
-    (S*8 [+ 4]) blocks x 64 lanes x 8."""
+def _pack_h2(Ws, bs, kidx, NT=4):
+    """Ws [32 NT, Kdim] scaled f32 weights, bs [32 NT] scaled bias or None, kidx [S, 2, 8] -> f16 tensor of
+    (S * NT * 2 [+ NT]) blocks x 64 lanes x 8."""
     dev = Ws.device
     S = kidx.shape[0]
     lane_i, lane_kb = _LANE_I.to(dev), _LANE_H.to(dev)
-    rows = 32 * torch.arange(4, device=dev)[:, None] + lane_i[None, :]                  # [4, 64]
+    rows = 32 * torch.arange(NT, device=dev)[:, None] + lane_i[None, :]                 # [NT, 64]
     k = kidx.to(dev)[:, lane_kb, :]                                                      # [S, 64, 8]
-    vals = Ws[rows[None, :, :, None].expand(S, 4, 64, 8), k[:, None, :, :].expand(S, 4, 64, 8)]
+    vals = Ws[rows[None, :, :, None].expand(S, NT, 64, 8), k[:, None, :, :].expand(S, NT, 64, 8)]
     hi, lo = _h2_split(vals)
-    blocks = torch.stack([hi, lo], dim=2).reshape(S * 8, 64, 8)                          # [S, 4, 2, 64, 8]
+    blocks = torch.stack([hi, lo], dim=2).reshape(S * NT * 2, 64, 8)                     # [S, NT, 2, 64, 8]
     if bs is None:
         return blocks.contiguous()
-    bb = torch.zeros(4, 64, 8, dtype=torch.float16, device=dev)
-    bhi, blo = _h2_split(bs.reshape(4, 32))
+    bb = torch.zeros(NT, 64, 8, dtype=torch.float16, device=dev)
+    bhi, blo = _h2_split(bs.reshape(NT, 32))
     bb[:, :32, 0] = bhi
     bb[:, :32, 1] = blo
     return torch.cat([blocks, bb], dim=0).contiguous()
+
+
+def _pad_rows(W, b, R):
+    Wp = torch.zeros(R, W.shape[1], dtype=torch.float32, device=W.device)
+    bp = torch.zeros(R, dtype=torch.float32, device=W.device)
+    Wp[:W.shape[0]] = W
+    bp[:b.shape[0]] = b
+    return Wp, bp
+
+
+def pack_dense_for_affine_h2(linears):
+    """Pack DenseNet([n_in, H, H, d]) (H = 64 | 128, d <= 96) for bgk_coupling_affine_dense_h2.
+    Returns (A0, A1, A2 f16 device tensors, (c0, c1, c2))."""
+    l0, l1, l2 = linears
+    W0, b0 = l0.weight.detach().float(), l0.bias.detach().float()
+    W1, b1 = l1.weight.detach().float(), l1.bias.detach().float()
+    W2, b2 = l2.weight.detach().float(), l2.bias.detach().float()
+    n_in, H, d = l0.in_features, l0.out_features, l2.out_features
+    HT, OT = H // 32, (d + 31) // 32
+    S0 = (n_in + 1 + 15) // 16
+    e0, e1, e2 = _h2_scale_exp(W0, b0), _h2_scale_exp(W1, b1), _h2_scale_exp(W2, b2)
+    W0e = torch.zeros(H, 16 * S0, dtype=torch.float32, device=W0.device)
+    W0e[:, :n_in] = W0
+    W0e[:, n_in] = b0
+    A0 = _pack_h2(W0e * 2.0 ** e0, None, _h2_k_natural(S0), NT=HT)
+    A1 = _pack_h2(W1 * 2.0 ** e1, b1 * 2.0 ** e1, _h2_k_hidden(HT), NT=HT)
+    W2p, b2p = _pad_rows(W2 * 2.0 ** e2, b2 * 2.0 ** e2, 32 * OT)
+    A2 = _pack_h2(W2p, b2p, _h2_k_hidden(HT), NT=OT)
+    return A0, A1, A2, (2.0 ** -e0, 2.0 ** -e1, 2.0 ** -e2)
+
+
+def _affine_plan(transformer, y_dim):
+    """Decide (and cache) whether an AffineTransformer's conditioners can run fused; pack their weights."""
+    nets = (transformer._shift_transformation, transformer._scale_transformation)
+    if all(n is None for n in nets):
+        return None
+    specs = []
+    for n in nets:
+        if n is None:
+            specs.append(None)
+            continue
+        spec = _fusable_dense(n)
+        if spec is None:
+            return None
+        specs.append(spec)
+    live = [sp for sp in specs if sp is not None]
+    (l0, l1, l2), _ = live[0]
+    H, n_in = l0.out_features, l0.in_features
+    for (m0, m1, m2), _ in live:
+        if not (m0.out_features == H and m1.in_features == H and m1.out_features == H and m2.in_features == H
+                and m0.in_features == n_in and m2.out_features == y_dim):
+            return None
+    if H not in (64, 128) or y_dim > 96 or n_in > 127:
+        return None
+    params = [p for (ls, _) in live for lin in ls for p in (lin.weight, lin.bias)]
+    version = tuple((p.data_ptr(), p._version) for p in params)
+    cache = transformer._fused_cache
+    if cache.get("version") != version or cache.get("y_dim") != y_dim:
+        cache.clear()
+        cache.update(version=version, y_dim=y_dim, hidden=H, d_c=n_in,
+                     packed=[None if sp is None else (pack_dense_for_affine_h2(sp[0]), sp[1]) for sp in specs])
+    return cache
+
+
+def fused_affine_coupling(transformer, x, y, inverse):
+    """Try the one-launch affine coupling layer (bgk_coupling_affine_dense_h2).  Returns (y', dlogp) or None when
+    the conditioners are not fusable DenseNets (the caller then runs the nets + bgk_affine_transform)."""
+    if _gemm_mode(transformer) != "f16x2":
+        return None            # there is no exact-f32 fused affine kernel: "f32" selects the generic path
+    if x.dim() != 2 or y.dim() != 2 or not x.is_cuda or x.dtype != torch.float32:
+        return None
+    plan = _affine_plan(transformer, y.shape[-1])
+    if plan is None or x.shape[-1] != plan["d_c"]:
+        return None
+    _lib.require_hip(x, y)
+    x2, ldc = _lib.rowmajor(x)
+    y2, ldy = _lib.rowmajor(y)
+    B, d = y2.shape
+    out = torch.empty((B, d), dtype=torch.float32, device=y.device)
+    dlogp = torch.empty((B,), dtype=torch.float32, device=y.device)
+    args = []
+    for entry in plan["packed"]:
+        if entry is None:
+            args += [None, None, None, 1.0, 1.0, 1.0, 0]
+        else:
+            (A0, A1, A2, (c0, c1, c2)), act = entry
+            if A0.device != y.device:
+                return None
+            args += [_lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2, act]
+    log_alpha = transformer._log_alpha.detach().to(device=y.device, dtype=torch.float32)
+    with torch.cuda.device(y.device):
+        st = _lib.lib().bgk_coupling_affine_dense_h2(
+            _lib.ptr(x2), ldc, plan["d_c"], *args, plan["hidden"], _lib.ptr(log_alpha),
+            int(transformer._preserve_volume), int(transformer._is_circular), int(inverse),
+            _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.stream_ptr(y.device))
+    if st == -2:
+        return None
+    _lib.check(st, "bgk_coupling_affine_dense_h2")
+    return out, dlogp[:, None]
 
 
 def pack_dense_for_fused_h2(linears, nc_slot_host, d, n_bins):

@@ -123,8 +123,17 @@ class AffineTransformer(Transformer):
         self._log_alpha = torch.nn.Parameter(torch.zeros(1) - init_downscale)
         self._preserve_volume = preserve_volume
         self._is_circular = is_circular
+        self._fused_cache = {}
+        self.allow_fused = True           # set False to force conditioner networks + bgk_affine_transform
 
     def _run(self, x, y, cond, inverse):
+        grad = torch.is_grad_enabled() and (
+            y.requires_grad or x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not grad and self.allow_fused and not cond:
+            from .dense import fused_affine_coupling   # late import (dense imports nothing from here)
+            fused = fused_affine_coupling(self, x, y, inverse)
+            if fused is not None:
+                return fused
         mu = self._shift_transformation(x, *cond) if self._shift_transformation is not None else None
         s_raw = self._scale_transformation(x, *cond) if self._scale_transformation is not None else None
         if mu is not None:

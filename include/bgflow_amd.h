@@ -201,6 +201,25 @@ int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32
                               float* out, int64_t ldo, float* dlogp, int32_t accumulate,
                               int32_t* bin_idx, int32_t* oob_count, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused affine coupling layer: replaces CouplingFlow._forward/_inverse (nn/flow/coupling.py:162-182) around
+ * AffineTransformer (nn/flow/transformer/affine.py:41-70) when shift / scale conditioners are DenseNets
+ * [d_c, H, H, d] (nn/dense.py:47-48) with H = 64 | 128, d <= 96, d_c <= 127: both MLPs on the f16 matrix cores
+ * (split-f16, see bgk_coupling_rqs_dense_h2) + everything bgk_affine_transform does, one launch.
+ *   s* / t*: shift / scale network operands from bgflow_amd/dense.py::pack_dense_for_affine_h2 (A0 == NULL: network
+ *            absent), c0..c2 power-of-two unscale factors, act: 1 SiLU, 2 ReLU, 3 Tanh (hidden activations)
+ * Returns BGK_EUNSUPPORTED outside the envelope: the caller runs the networks + bgk_affine_transform.
+ * --------------------------------------------------------------------------------------------- */
+int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c,
+                                 const void* sA0, const void* sA1, const void* sA2,
+                                 float sc0, float sc1, float sc2, int32_t s_act,
+                                 const void* tA0, const void* tA1, const void* tA2,
+                                 float tc0, float tc1, float tc2, int32_t t_act,
+                                 int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                 int32_t is_circular, int32_t inverse,
+                                 const float* y, int64_t ldy, int64_t B, int32_t d,
+                                 float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
+
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).
  * Deterministic two-stage reduction; `partial` is a caller-provided [nblk, P] workspace. */

@@ -713,3 +713,62 @@ def test_densenet_backward_matches_torch_linear(hip_lib, dev):
     for a, b in zip(g1, g2):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(b.abs().max()))
 
+
+# ---------------------------------------------------------------------------------------------------
+# fused affine coupling layer (both conditioner MLPs on the f16 matrix cores + affine tail)
+# ---------------------------------------------------------------------------------------------------
+def _affine_layer(kind, dev=None):
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    if kind == "cfg2":          # DoubleWell dim 64: x | y = 32 | 32, nets [32, 64, 64, 32], ReLU / Tanh
+        tr = bg.AffineTransformer(bg.DenseNet([32, 64, 64, 32], torch.nn.ReLU()), bg.DenseNet([32, 64, 64, 32], torch.nn.Tanh()))
+        dims = (32, 32)
+    elif kind == "aug66":       # cfg 5: AUGMENTED (66) | TORSIONS (17), hidden (128, 128) SiLU
+        tr = bg.AffineTransformer(bg.DenseNet([17, 128, 128, 66], torch.nn.SiLU()), bg.DenseNet([17, 128, 128, 66], torch.nn.SiLU()))
+        dims = (17, 66)
+    elif kind == "nice_circ":   # shift only, circular
+        tr = bg.AffineTransformer(bg.DenseNet([5, 64, 64, 7], torch.nn.SiLU()), None, is_circular=True)
+        dims = (5, 7)
+    elif kind == "pv":          # volume preserving
+        tr = bg.AffineTransformer(bg.DenseNet([9, 128, 128, 33], torch.nn.Tanh()), bg.DenseNet([9, 128, 128, 33], torch.nn.ReLU()),
+                                  preserve_volume=True)
+        dims = (9, 33)
+    layer = hash_init_(bg.CouplingFlow(tr, transformed_indices=(1,), cond_indices=(0,)))
+    return (layer.to(dev) if dev is not None else layer), dims
+
+
+@pytest.mark.parametrize("kind", ["cfg2", "aug66", "nice_circ", "pv"])
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("B", [1, 31, 4133])
+def test_fused_affine_layer_vs_oracle(hip_lib, dev, kind, inverse, B):
+    from oracle import flow_oracle as fo
+    layer_cpu, dims = _affine_layer(kind)
+    layer, _ = _affine_layer(kind, dev)
+    xs = [synth(B + 3 * i, B, d, uniform=(kind == "nice_circ")) for i, d in enumerate(dims)]
+    with torch.no_grad():
+        x_out, y_out, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
+    assert layer.transformer._fused_cache, "the fused affine path must have run"
+    layer.transformer.allow_fused = False
+    with torch.no_grad():
+        _, y_gen, dl_gen = layer(*[t(v, dev) for v in xs], inverse=inverse)
+    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, [])
+    scale = max(1.0, float(np.abs(outs64[1]).max()))
+    e_f = np.abs(y_out.cpu().numpy() - outs64[1]).max(), np.abs(dl.cpu().numpy() - dl64).max()
+    e_g = np.abs(y_gen.cpu().numpy() - outs64[1]).max(), np.abs(dl_gen.cpu().numpy() - dl64).max()
+    assert e_f[0] <= 3 * e_g[0] + 1e-6 * scale, f"outputs: fused {e_f[0]:.2e} vs generic {e_g[0]:.2e} (error to the f64 oracle)"
+    assert e_f[1] <= 3 * e_g[1] + 2e-6 * max(1.0, float(np.abs(dl64).max())), f"dlogp: fused {e_f[1]:.2e} vs generic {e_g[1]:.2e}"
+    np.testing.assert_allclose(y_out.cpu().numpy(), outs64[1], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=2e-5, atol=2e-5)
+    assert torch.equal(x_out, t(xs[0], dev))
+
+
+def test_fused_affine_roundtrip_at_scale(hip_lib, dev):
+    layer, dims = _affine_layer("cfg2", dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    xs = [torch.randn(1 << 20, d, device=dev, generator=g) for d in dims]
+    with torch.no_grad():
+        x, y, dl = layer(*xs)
+        _, z, dli = layer(x, y, inverse=True)
+    assert float((z - xs[1]).abs().max()) < 1e-4
+    assert float((dl + dli).abs().max()) < 1e-5
+
