@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU per step")
     ap.add_argument("--cpu-samples", type=int, default=1 << 17)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-f32 and cfg-2 side measurements")
     ap.add_argument("--kl-steps", type=int, default=3, help="extra: time this many KL-loss training steps (0 = skip)")
     ap.add_argument("--kl-batch", type=int, default=1 << 18, help="samples per GPU per KL step")
     args = ap.parse_args()
@@ -158,7 +159,7 @@ def main():
     # ---- extra: the same workload with the conditioner GEMMs in exact-f32 MFMA mode (bit-identical to the CPU oracle)
     exact = None
     gemm_mode = _dense.GEMM_MODE
-    if args.workload == "cfg3" and gemm_mode != "f32" and rank == 0 and world == 1:
+    if args.workload == "cfg3" and gemm_mode != "f32" and rank == 0 and world == 1 and not args.no_extras:
         _dense.GEMM_MODE = "f32"
         timed_steps(gen, zs, 1)
         torch.cuda.synchronize(dev)
@@ -171,6 +172,23 @@ def main():
         _dense.GEMM_MODE = gemm_mode
         timed_steps(gen, zs, 1)   # re-pack for the headline mode (KL bench below uses the generic path)
         torch.cuda.synchronize(dev)
+
+    # ---- extra: BASELINE.json configs[1] (8 affine coupling blocks, dim 64, batch 2^20) on the same GPU
+    cfg2 = None
+    if args.workload == "cfg3" and not args.no_extras and rank == 0 and world == 1:
+        gen2, sampler2, desc2 = make_workload("cfg2", dev)
+        z2 = sampler2(1 << 20, torch.Generator(device=dev).manual_seed(1234))
+        timed_steps(gen2, z2, 2)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        timed_steps(gen2, z2, 5)
+        torch.cuda.synchronize(dev)
+        t2 = (time.perf_counter() - t2) / 5
+        cfg2 = dict(workload=desc2, value=(1 << 20) / t2, unit="samples/s", ms_per_step=1e3 * t2, steps=5, batch=1 << 20,
+                    hbm_view=dict(algorithmic_bytes_per_sample=ALG_BYTES["cfg2"],
+                                  achieved_GBs=ALG_BYTES["cfg2"] * (1 << 20) / t2 / 1e9, peak_GBs=HBM_PEAK_GBS),
+                    note="fused affine coupling kernel (both conditioner MLPs on the f16 matrix cores + affine tail), 8 launches")
+        del gen2, z2
 
     # ---- extra (second half of BASELINE.json's metric): KL-loss training steps/s -------------------------
     # one step = kldiv(B).mean() -> backward through the hand-written backward kernels -> one all-reduce of
@@ -238,7 +256,8 @@ def main():
                                       achieved_GBs=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak_GBs=HBM_PEAK_GBS))
         else:
             roof = dict(bound="hbm", achieved=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak=HBM_PEAK_GBS,
-                        unit="GB/s", traffic=None, kernel="affine_kernel + hipBLASLt conditioner GEMMs")
+                        unit="GB/s", traffic=measured_traffic("coupling_affine_dense_kernel"),
+                        kernel="coupling_affine_dense_kernel (fused: 2 DenseNets on the f16 matrix cores + affine tail)")
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["block_ms"] = [round(v, 3) for v in block_ms]
         out = dict(metric="flow samples/s (fwd+log|detJ|) at batch 2^20", value=value, unit="samples/s", n_gpus=world,
@@ -253,6 +272,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_samples)
         if exact is not None:
             out["exact_f32_mode"] = exact
+        if cfg2 is not None:
+            out["cfg2"] = cfg2
         if kl is not None:
             out["kl"] = kl
         print(json.dumps(out))

@@ -138,7 +138,7 @@ BGK_FN float bgk_tanhf(float x) {
     float ax = x < 0.0f ? -x : x;
     if (ax >= 0.625f) {
         float e = bgk_expf(ax + ax);
-        float r = 1.0f - 2.0f / (e + 1.0f);
+        float r = 1.0f - bgk_div_safe(2.0f, e + 1.0f);   /* e <= exp(80): safe range */
         return x < 0.0f ? -r : r;
     }
     float z = x * x;

@@ -113,4 +113,24 @@ __device__ __forceinline__ bgk_f2 bgk_siluf2(bgk_f2 x) {
     return bgk_div_fast2(x, bgk_splat2(1.0f) + bgk_expf2(-x));
 }
 
+/* tanh of two values; identical to bgk_tanhf on each (both branches evaluated, the scalar form's one selected) */
+__device__ __forceinline__ bgk_f2 bgk_tanhf2(bgk_f2 x) {
+    bgk_f2 ax;
+    ax.x = __builtin_fabsf(x.x); ax.y = __builtin_fabsf(x.y);
+    const bgk_f2 e = bgk_expf2(ax + ax);
+    bgk_f2 r = bgk_splat2(1.0f) - bgk_div_fast2(bgk_splat2(2.0f), e + bgk_splat2(1.0f));
+    const bgk_f2 z = x * x;
+    bgk_f2 p = bgk_splat2(-5.70498872745e-3f);
+    p = bgk_fma2(p, z, bgk_splat2(2.06390887954e-2f));
+    p = bgk_fma2(p, z, bgk_splat2(-5.37397155531e-2f));
+    p = bgk_fma2(p, z, bgk_splat2(1.33314422036e-1f));
+    p = bgk_fma2(p, z, bgk_splat2(-3.33332819422e-1f));
+    p = p * z;
+    const bgk_f2 small = bgk_fma2(p, x, x);
+    bgk_f2 o;
+    o.x = ax.x >= 0.625f ? (x.x < 0.0f ? -r.x : r.x) : small.x;
+    o.y = ax.y >= 0.625f ? (x.y < 0.0f ? -r.y : r.y) : small.y;
+    return o;
+}
+
 #endif /* BGK_DETMATH_PK_H */

@@ -96,6 +96,12 @@ __device__ __forceinline__ void act_tile(f32x16& t) {
             bgk_f2 v = bgk_siluf2((bgk_f2){t[r], t[r + 1]});
             t[r] = v.x; t[r + 1] = v.y;
         }
+    } else if constexpr (ACT == 3) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            bgk_f2 v = bgk_tanhf2((bgk_f2){t[r], t[r + 1]});
+            t[r] = v.x; t[r + 1] = v.y;
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) t[r] = act_fn<ACT>(t[r]);

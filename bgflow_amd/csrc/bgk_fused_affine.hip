@@ -28,6 +28,7 @@ struct FusedAffArgs {
     const float* y; int64_t ldy; int64_t B; int d;
     float* out; int64_t ldo; float* dlogp; int accumulate;
     int lds_per_wave;
+    int vec4;                    /* y / out rows 16-byte aligned */
 };
 
 template <int HT, int OT>
@@ -81,6 +82,10 @@ __global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(Fused
     __builtin_amdgcn_wave_barrier();
 
     h2_f32x16 mu[OT], sr[OT];
+#pragma unroll
+    for (int m = 0; m < OT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { mu[m][r] = 0.0f; sr[m][r] = 0.0f; }
     if (a.has_shift) net_eval<HT, OT>(mu, a.shift, s_x, a.S0, lane);
     if (a.has_scale) net_eval<HT, OT>(sr, a.scale, s_x, a.S0, lane);
 
@@ -90,11 +95,13 @@ __global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(Fused
 #pragma unroll
     for (int m = 0; m < OT; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool valid = h2_row(m, r, hh) < d;
-            const float ls = (a.has_scale && valid) ? bgk_tanhf(sr[m][r] * a.scale.c2) * alpha : 0.0f;
-            sr[m][r] = ls;
-            lsum += ls;
+        for (int r = 0; r < 16; r += 2) {
+            const bgk_f2 th = bgk_tanhf2((bgk_f2){sr[m][r] * a.scale.c2, sr[m][r + 1] * a.scale.c2});
+            const float l0 = (a.has_scale && h2_row(m, r, hh) < d) ? th.x * alpha : 0.0f;
+            const float l1 = (a.has_scale && h2_row(m, r + 1, hh) < d) ? th.y * alpha : 0.0f;
+            sr[m][r] = l0; sr[m][r + 1] = l1;
+            lsum += l0;
+            lsum += l1;
         }
     float total = lsum + __shfl_xor(lsum, 32);
     if (a.preserve_volume && a.has_scale) {
@@ -114,18 +121,37 @@ __global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(Fused
     if (j < rows) {
         const float* yr = a.y + (b0 + j) * a.ldy;
         float* orow = a.out + (b0 + j) * a.ldo;
+        /* registers 4q..4q+3 of a tile hold 4 consecutive dims: one 16-byte access per group when aligned */
 #pragma unroll
         for (int m = 0; m < OT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dim = h2_row(m, r, hh);
-                if (dim < d) {
-                    const float v = yr[dim];
+            for (int q = 0; q < 4; ++q) {
+                const int dim0 = h2_row(m, 4 * q, hh);
+                if (dim0 >= d) continue;
+                const bool full = a.vec4 && dim0 + 4 <= d;
+                float v[4];
+                if (full) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(yr + dim0);
+                    v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = dim0 + u < d ? yr[dim0 + u] : 0.0f;
+                }
+                float o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * q + u;
                     const float mm = a.has_shift ? mu[m][r] * a.shift.c2 : 0.0f;
                     const float ls = sr[m][r];
-                    float o = a.inverse ? bgk_expf(-ls) * (v - mm) : bgk_expf(ls) * v + mm;
-                    if (a.is_circular) { o = o - __builtin_truncf(o); if (o < 0.0f) o = o + 1.0f; }
-                    orow[dim] = o;
+                    float t = a.inverse ? bgk_expf(-ls) * (v[u] - mm) : bgk_expf(ls) * v[u] + mm;
+                    if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
+                    o[u] = t;
+                }
+                if (full) {
+                    *reinterpret_cast<float4*>(orow + dim0) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (dim0 + u < d) orow[dim0 + u] = o[u];
                 }
             }
         if (hh == 0) {
@@ -167,6 +193,7 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
     a.log_alpha = log_alpha; a.preserve_volume = preserve_volume; a.is_circular = is_circular; a.inverse = inverse;
     a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
     a.lds_per_wave = 16 * a.S0 * ASROW;
+    a.vec4 = (ldy % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)y | (uintptr_t)out) % 16 == 0);
     const size_t shmem = sizeof(float) * (size_t)AW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + AW - 1) / AW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_coupling_affine_dense_h2: batch too large for one launch");

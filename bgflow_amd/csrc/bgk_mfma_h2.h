@@ -118,7 +118,10 @@ __device__ __forceinline__ void h2_act_tile(h2_f32x16& t, float c, int act) {
         for (int r = 0; r < 16; ++r) t[r] = t[r] > 0.0f ? t[r] : 0.0f;
     } else if (act == 3) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t[r] = bgk_tanhf(t[r]);
+        for (int r = 0; r < 16; r += 2) {
+            bgk_f2 v = bgk_tanhf2((bgk_f2){t[r], t[r + 1]});
+            t[r] = v.x; t[r + 1] = v.y;
+        }
     }
 }
 

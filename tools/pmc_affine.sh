@@ -1,0 +1,16 @@
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmc_aff
+mkdir -p $OUT
+CMD="python bench.py --workload cfg2 --no-cpu-baseline --kl-steps 0 --steps 2 --warmup 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA --output-format csv -d $OUT/sq1 -o p -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/sq2 -o p -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -o p -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -o p -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -o p -- $CMD > /dev/null 2>&1
+for d in sq1 sq2 grbm f w; do python tools/pmc_summary.py $OUT/$d coupling_affine; done
+python - <<PY
+import csv,glob
+f=glob.glob("$OUT/stats/**/*kernel_stats.csv",recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:5]: print(r["Name"][:90], r["Calls"], r["AverageNs"], r["Percentage"])
+PY
