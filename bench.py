@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak
 
 # algorithmic bytes per sample of the hand-written kernels (fp32)
-ALG_BYTES = {"cfg3": 26800.0, "cfg2": 4672.0}
+ALG_BYTES = {"cfg3": 26800.0, "cfg2": 4672.0, "cfg5": 24384.0}
 
 
 def make_workload(name, dev):
@@ -37,6 +37,11 @@ def make_workload(name, dev):
         dims = (17, 17, 17, 9)
         sampler = lambda n, g: [torch.rand(n, d, device=dev, generator=g) for d in dims]  # noqa: E731
         desc = "ala2-shaped 16x RQ-spline coupling (K=8, hidden 128x128 SiLU) + 4 icdf maps + mixed IC -> 66 xyz (cfg 3 recipe)"
+    elif name == "cfg5":
+        gen = configs.make_ala2_augmented_generator(dev)
+        dims = (17, 17, 17, 9, 66)
+        sampler = lambda n, g: [torch.rand(n, d, device=dev, generator=g) for d in dims]  # noqa: E731
+        desc = "augmented ala2 flow: 10 RQ-spline + 6 affine couplings (hidden 128x128 SiLU) + 5 icdf maps + mixed IC (cfg 5, f32)"
     elif name == "cfg2":
         gen = configs.make_affine8_generator(device=dev)
         sampler = lambda n, g: [torch.randn(n, 64, device=dev, generator=g)]  # noqa: E731
@@ -239,7 +244,7 @@ def main():
         avg_launch_s = 1e-3 * t_coupling_ms / n_launch
         flops_per_launch = 2.0 * sum(layer_macs(gen.flow[i]) for i in coupling) / n_launch * args.batch
         alg_bytes_step = ALG_BYTES[args.workload] * args.batch
-        if args.workload == "cfg3":
+        if args.workload in ("cfg3", "cfg5"):
             split = gemm_mode == "f16x2"
             roof = dict(bound="mfma", achieved=flops_per_launch / avg_launch_s / 1e12, peak=MFMA_F32_PEAK_TFLOPS,
                         unit="TFLOP/s", traffic=measured_traffic("coupling_rqs_dense_h2_kernel" if split else "coupling_rqs_dense_kernel"),

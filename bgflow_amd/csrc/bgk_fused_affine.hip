@@ -22,7 +22,7 @@ struct AffNet {
 };
 
 struct FusedAffArgs {
-    const float* cond; int64_t ldc; int d_c; int S0;
+    const float* cond; int64_t ldc; int d_c; int S0; int periodic;
     AffNet shift, scale; int has_shift, has_scale;
     const float* log_alpha; int preserve_volume, is_circular, inverse;
     const float* y; int64_t ldy; int64_t B; int d;
@@ -72,12 +72,21 @@ __global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(Fused
     const int d = a.d;
 
     /* conditioner input [feature][sample] + constant-1 row (bias column) + zero pad rows */
+    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
     for (int i = lane; i < 32 * a.d_c; i += 64) {
         const int r = i / a.d_c, c = i - r * a.d_c;
-        s_x[c * ASROW + r] = r < rows ? a.cond[(b0 + r) * a.ldc + c] : 0.0f;
+        const float v = r < rows ? a.cond[(b0 + r) * a.ldc + c] : 0.0f;
+        if (a.periodic) {          /* WrapPeriodic featuriser (nn/periodic.py:30-37), all inputs circular on [0, 1] */
+            float sv, cv;
+            bgk_sincos2pif(v, &sv, &cv);
+            s_x[c * ASROW + r] = cv;
+            s_x[(a.d_c + c) * ASROW + r] = sv;
+        } else {
+            s_x[c * ASROW + r] = v;
+        }
     }
-    for (int i = lane; i < (16 * a.S0 - a.d_c) * 32; i += 64)
-        s_x[(a.d_c + (i >> 5)) * ASROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
+    for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
+        s_x[(n_in + (i >> 5)) * ASROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(Fused
 
 }  // namespace
 
-extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c,
+extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                             const void* sA0, const void* sA1, const void* sA2,
                                             float sc0, float sc1, float sc2, int32_t s_act,
                                             const void* tA0, const void* tA1, const void* tA2,
@@ -179,14 +188,15 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
     BGK_CHECK_ARG(!has_shift || (sA1 && sA2), "bgk_coupling_affine_dense_h2: incomplete shift network");
     BGK_CHECK_ARG(!has_scale || (tA1 && tA2 && log_alpha), "bgk_coupling_affine_dense_h2: incomplete scale network");
     BGK_CHECK_ARG(!(has_scale && is_circular), "Scaling is not compatible with periodicity.");
-    if ((hidden != 64 && hidden != 128) || d > 96 || d_c > 127 || s_act < 0 || s_act > 3 || t_act < 0 || t_act > 3) {
-        bgk_set_error("bgk_coupling_affine_dense_h2: only hidden = (64,64) | (128,128), d <= 96, d_c <= 127 are fused "
-                      "(got hidden=%d d=%d d_c=%d)", hidden, d, d_c);
+    const int n_in = periodic ? 2 * d_c : d_c;
+    if ((hidden != 64 && hidden != 128) || d > 96 || n_in > 127 || s_act < 0 || s_act > 3 || t_act < 0 || t_act > 3) {
+        bgk_set_error("bgk_coupling_affine_dense_h2: only hidden = (64,64) | (128,128), d <= 96, <= 127 input features are fused "
+                      "(got hidden=%d d=%d n_in=%d)", hidden, d, n_in);
         return BGK_EUNSUPPORTED;
     }
     if (B == 0) return 0;
     FusedAffArgs a;
-    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.S0 = (d_c + 1 + 15) / 16;
+    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic; a.S0 = (n_in + 1 + 15) / 16;
     a.shift = AffNet{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA2, sc0, sc1, sc2, s_act};
     a.scale = AffNet{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA2, tc0, tc1, tc2, t_act};
     a.has_shift = has_shift; a.has_scale = has_scale;

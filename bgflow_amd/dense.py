@@ -283,10 +283,22 @@ def _affine_plan(transformer, y_dim):
     if all(n is None for n in nets):
         return None
     specs = []
+    periodic = None
     for n in nets:
         if n is None:
             specs.append(None)
             continue
+        per = type(n) is WrapPeriodic
+        if per:
+            inner = n.net
+            n_raw = getattr(getattr(inner, "_layers", [None])[0], "in_features", 0) // 2
+            idx = np.arange(n_raw)[n.indices] if n_raw else np.zeros(0, int)
+            if not (n.left == 0.0 and n.right == 1.0) or n_raw == 0 or not np.array_equal(np.asarray(idx), np.arange(n_raw)):
+                return None          # only "all conditioner inputs periodic on [0, 1]" is fused
+            n = inner
+        if periodic is not None and per != periodic:
+            return None
+        periodic = per
         spec = _fusable_dense(n)
         if spec is None:
             return None
@@ -298,14 +310,14 @@ def _affine_plan(transformer, y_dim):
         if not (m0.out_features == H and m1.in_features == H and m1.out_features == H and m2.in_features == H
                 and m0.in_features == n_in and m2.out_features == y_dim):
             return None
-    if H not in (64, 128) or y_dim > 96 or n_in > 127:
+    if H not in (64, 128) or y_dim > 96 or n_in > 127 or (periodic and n_in % 2):
         return None
     params = [p for (ls, _) in live for lin in ls for p in (lin.weight, lin.bias)]
     version = tuple((p.data_ptr(), p._version) for p in params)
     cache = transformer._fused_cache
     if cache.get("version") != version or cache.get("y_dim") != y_dim:
         cache.clear()
-        cache.update(version=version, y_dim=y_dim, hidden=H, d_c=n_in,
+        cache.update(version=version, y_dim=y_dim, hidden=H, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic),
                      packed=[None if sp is None else (pack_dense_for_affine_h2(sp[0]), sp[1]) for sp in specs])
     return cache
 
@@ -338,7 +350,7 @@ def fused_affine_coupling(transformer, x, y, inverse):
     log_alpha = transformer._log_alpha.detach().to(device=y.device, dtype=torch.float32)
     with torch.cuda.device(y.device):
         st = _lib.lib().bgk_coupling_affine_dense_h2(
-            _lib.ptr(x2), ldc, plan["d_c"], *args, plan["hidden"], _lib.ptr(log_alpha),
+            _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), *args, plan["hidden"], _lib.ptr(log_alpha),
             int(transformer._preserve_volume), int(transformer._is_circular), int(inverse),
             _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.stream_ptr(y.device))
     if st == -2:

@@ -204,13 +204,14 @@ int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32
 /* ---------------------------------------------------------------------------------------------
  * Fused affine coupling layer: replaces CouplingFlow._forward/_inverse (nn/flow/coupling.py:162-182) around
  * AffineTransformer (nn/flow/transformer/affine.py:41-70) when shift / scale conditioners are DenseNets
- * [d_c, H, H, d] (nn/dense.py:47-48) with H = 64 | 128, d <= 96, d_c <= 127: both MLPs on the f16 matrix cores
+ * [n_in, H, H, d] (nn/dense.py:47-48; n_in = d_c, or 2 d_c behind the WrapPeriodic cos/sin featuriser when
+ * `periodic` != 0) with H = 64 | 128, d <= 96, n_in <= 127: both MLPs on the f16 matrix cores
  * (split-f16, see bgk_coupling_rqs_dense_h2) + everything bgk_affine_transform does, one launch.
  *   s* / t*: shift / scale network operands from bgflow_amd/dense.py::pack_dense_for_affine_h2 (A0 == NULL: network
  *            absent), c0..c2 power-of-two unscale factors, act: 1 SiLU, 2 ReLU, 3 Tanh (hidden activations)
  * Returns BGK_EUNSUPPORTED outside the envelope: the caller runs the networks + bgk_affine_transform.
  * --------------------------------------------------------------------------------------------- */
-int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c,
+int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                  const void* sA0, const void* sA1, const void* sA2,
                                  float sc0, float sc1, float sc2, int32_t s_act,
                                  const void* tA0, const void* tA1, const void* tA2,

@@ -729,6 +729,10 @@ def _affine_layer(kind, dev=None):
     elif kind == "nice_circ":   # shift only, circular
         tr = bg.AffineTransformer(bg.DenseNet([5, 64, 64, 7], torch.nn.SiLU()), None, is_circular=True)
         dims = (5, 7)
+    elif kind == "periodic":    # cfg 5: AUGMENTED (66) | TORSIONS (17, circular -> cos/sin featuriser)
+        tr = bg.AffineTransformer(bg.WrapPeriodic(bg.DenseNet([34, 128, 128, 66], torch.nn.SiLU())),
+                                  bg.WrapPeriodic(bg.DenseNet([34, 128, 128, 66], torch.nn.SiLU())))
+        dims = (17, 66)
     elif kind == "pv":          # volume preserving
         tr = bg.AffineTransformer(bg.DenseNet([9, 128, 128, 33], torch.nn.Tanh()), bg.DenseNet([9, 128, 128, 33], torch.nn.ReLU()),
                                   preserve_volume=True)
@@ -737,14 +741,14 @@ def _affine_layer(kind, dev=None):
     return (layer.to(dev) if dev is not None else layer), dims
 
 
-@pytest.mark.parametrize("kind", ["cfg2", "aug66", "nice_circ", "pv"])
+@pytest.mark.parametrize("kind", ["cfg2", "aug66", "periodic", "nice_circ", "pv"])
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("B", [1, 31, 4133])
 def test_fused_affine_layer_vs_oracle(hip_lib, dev, kind, inverse, B):
     from oracle import flow_oracle as fo
     layer_cpu, dims = _affine_layer(kind)
     layer, _ = _affine_layer(kind, dev)
-    xs = [synth(B + 3 * i, B, d, uniform=(kind == "nice_circ")) for i, d in enumerate(dims)]
+    xs = [synth(B + 3 * i, B, d, uniform=(kind == "nice_circ" or (kind == "periodic" and i == 0))) for i, d in enumerate(dims)]
     with torch.no_grad():
         x_out, y_out, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
     assert layer.transformer._fused_cache, "the fused affine path must have run"
