@@ -215,3 +215,71 @@ def test_boltzmann_generator_api_with_stub_flow():
     assert torch.allclose(nll, prior.energy(z) + 0.5)
     ess = bg.effective_sample_size(lw.view(-1))
     assert 0 < float(ess) <= 64.0 + 1e-3
+
+
+def _emulate_h2_gemm(blocks, NT, S, bvals):
+    """numpy restatement of the split-f16 MFMA dataflow: blocks [(S*NT*2 [+NT]), 64, 8] f16 as packed by dense._pack_h2,
+    bvals[s][kb][e] = the B operand value lane-half kb supplies for k-slot e of step s.  Returns out[32*NT]."""
+    out = np.zeros(32 * NT, np.float64)
+    blk = blocks.astype(np.float64)
+    for s in range(S):
+        for m in range(NT):
+            a = blk[(s * NT + m) * 2 + 0] + blk[(s * NT + m) * 2 + 1]          # [64 lanes, 8]: hi + lo
+            for lane in range(64):
+                i, kb = lane & 31, lane >> 5
+                out[32 * m + i] += float(np.dot(a[lane], bvals[s][kb]))
+    if blocks.shape[0] > S * NT * 2:
+        for m in range(NT):
+            b = blk[S * NT * 2 + m]
+            out[32 * m:32 * m + 32] += b[:32, 0] + b[:32, 1]
+    return out
+
+
+def test_split_f16_packing_layout():
+    """the host-side operand packing of the split-f16 kernels reproduces W x + b when the B operand is fed in the MFMA
+    accumulator layout (hidden layers) / natural order (layer 0) -- no GPU needed"""
+    from bgflow_amd import dense
+    rng = np.random.default_rng(0)
+    # hidden layer, HT = 4 input tiles (K = 128), NT = 2 output tiles
+    W = torch.tensor(rng.normal(size=(64, 128)) * 0.3, dtype=torch.float32)
+    b = torch.tensor(rng.normal(size=64), dtype=torch.float32)
+    x = rng.normal(size=128)
+    e = dense._h2_scale_exp(W, b)
+    blocks = dense._pack_h2(W * 2.0 ** e, b * 2.0 ** e, dense._h2_k_hidden(4), NT=2).numpy()
+    assert blocks.shape == (8 * 2 * 2 + 2, 64, 8) and blocks.dtype == np.float16
+    assert np.abs(blocks.astype(np.float64)).max() < 65504
+    # accumulator layout: lane-half kb, register r of tile t holds hidden unit 32 t + (r & 3) + 8 (r >> 2) + 4 kb;
+    # k16-step s consumes registers 8 (s & 1) .. + 7 of tile s >> 1
+    bv = [[np.array([x[32 * (s >> 1) + ((8 * (s & 1) + ee) & 3) + 8 * ((8 * (s & 1) + ee) >> 2) + 4 * kb] for ee in range(8)])
+           for kb in range(2)] for s in range(8)]
+    got = _emulate_h2_gemm(blocks, 2, 8, bv) * 2.0 ** -e
+    ref = W.double().numpy() @ x + b.double().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * np.abs(W.numpy()).sum(1).max() * np.abs(x).max())
+    # layer 0: natural order, bias as the column of the constant-1 feature, zero padding up to 16 S0
+    n_in = 21
+    W0 = torch.tensor(rng.normal(size=(128, n_in)), dtype=torch.float32)
+    b0 = torch.tensor(rng.normal(size=128), dtype=torch.float32)
+    S0 = (n_in + 1 + 15) // 16
+    W0e = torch.zeros(128, 16 * S0)
+    W0e[:, :n_in] = W0
+    W0e[:, n_in] = b0
+    blocks0 = dense._pack_h2(W0e, None, dense._h2_k_natural(S0), NT=4).numpy()
+    x0 = np.zeros(16 * S0)
+    x0[:n_in] = rng.normal(size=n_in)
+    x0[n_in] = 1.0
+    bv0 = [[x0[16 * s + 8 * kb:16 * s + 8 * kb + 8] for kb in range(2)] for s in range(S0)]
+    got0 = _emulate_h2_gemm(blocks0, 4, S0, bv0)
+    np.testing.assert_allclose(got0, W0.double().numpy() @ x0[:n_in] + b0.double().numpy(), rtol=0, atol=1e-5)
+
+
+def test_gemm_mode_switch_and_errors():
+    import bgflow_amd as bg
+    from bgflow_amd import dense
+    tr = bg.ConditionalSplineTransformer(bg.DenseNet([9, 128, 128, 408], torch.nn.SiLU()), is_circular=True)
+    assert dense._gemm_mode(tr) == dense.GEMM_MODE
+    tr.gemm_mode = "f32"
+    assert dense._gemm_mode(tr) == "f32"
+    tr.gemm_mode = "fp8"
+    with pytest.raises(ValueError):
+        dense._gemm_mode(tr)
+
