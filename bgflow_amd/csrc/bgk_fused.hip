@@ -213,10 +213,10 @@ struct NoGemm {
 /* One spline element with 21 hook points; hook i runs k-step S0 + i of the overlapped GEMM.  Same
  * arithmetic, same order as bgk_rqs_element (bgk_common.h) -- only the instruction placement differs. */
 constexpr int HOOKS = 21;
-template <int INV, int S0, class G>
+template <int INV, int S0, class G, int ST = 32>
 __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* pw, const float* ph, const float* ps,
                                                    float s_last, const BgkRqsCfg& c, float* lad, int* bin, int* oob) {
-    constexpr int K = KB, st = 32;
+    constexpr int K = KB, st = ST;
     int o = (x < c.left) | (x > c.right);
     x = x < c.left ? c.left : (x > c.right ? c.right : x);
     *oob = o;
@@ -364,23 +364,23 @@ __device__ __forceinline__ void zero4(f32x16 (&acc)[4]) {
  * written branch-free so that the whole routine is ONE basic block and can be software-pipelined
  * under the next chunk's MFMAs.  Invalid (q >= nd) slots evaluate dim 0 of the chunk and are
  * discarded (their output goes to the dummy row d of s_y). */
-template <int INV, int IT, class G>
+template <int INV, int IT, class G, int ST = 32>
 __device__ __forceinline__ void spline_slot(G& g, const FusedArgs& a, const float* s_p, float* s_y, int c, int nd,
                                             int hh, int j, int rows, float& run, int& oob_local, int (&bins)[3]) {
     const int q = 2 * IT + hh;
     const bool valid = q < nd;
     const int qq = valid ? q : 0;
     const int dim = c * DPC + qq;
-    const float* pw = s_p + (qq * PPD) * 32 + j;
-    const float* ph = pw + KB * 32;
-    const float* ps = ph + KB * 32;
+    const float* pw = s_p + (qq * PPD) * ST + j;
+    const float* ph = pw + KB * ST;
+    const float* ps = ph + KB * ST;
     const bool circ = (a.circ_mask >> dim) & 1ull;
-    const float s_nc = ps[KB * 32];
+    const float s_nc = ps[KB * ST];
     const float s_last = circ ? ps[0] : s_nc;
     int bin, oob;
     float lad;
     const float x = s_y[dim * SROW + j];
-    const float o = rqs_element_piped<INV, IT * HOOKS>(g, x, pw, ph, ps, s_last, a.cfg, &lad, &bin, &oob);
+    const float o = rqs_element_piped<INV, IT * HOOKS, G, ST>(g, x, pw, ph, ps, s_last, a.cfg, &lad, &bin, &oob);
     s_y[(valid ? dim : a.d) * SROW + j] = o;
     oob_local += (valid && j < rows) ? oob : 0;
     bins[IT] = bin;
@@ -399,18 +399,18 @@ __device__ __forceinline__ void spline_slot(G& g, const FusedArgs& a, const floa
 /* Spline of one parameter chunk held in LDS: 3 element evaluations per lane (q = hh, hh+2, hh+4), branch-free
  * (invalid slots evaluate dim 0 of the chunk and are discarded into the dummy row d of s_y), with the hook
  * policy G running the overlapped GEMM's k-steps 0..62 in between. */
-template <int INV, class G>
+template <int INV, class G, int ST = 32>
 __device__ __forceinline__ void spline_chunk(G& g, const FusedArgs& a, const float* s_p, float* s_y, int c, int nd,
                                              int hh, int j, int rows, float& run, int& oob_local, int (&bins)[3]) {
-    spline_slot<INV, 0>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 0, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #if BGK_PIPE_SPLINE
-    spline_slot<INV, 1>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
-    spline_slot<INV, 2>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 1, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 2, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #else
     /* slots whose two dims both lie beyond the chunk's last dim are skipped (wave-uniform branch) */
     bins[1] = bins[2] = 0;
-    if (nd > 2) spline_slot<INV, 1>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
-    if (nd > 4) spline_slot<INV, 2>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    if (nd > 2) spline_slot<INV, 1, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    if (nd > 4) spline_slot<INV, 2, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #endif
 }
 
@@ -586,6 +586,11 @@ struct FusedArgsH2 {
     const uint4* A1;             /* layer 1: 8 steps */
     const uint4* A2;             /* layer 2: n_chunks x (8 steps + bias) */
     float c0, c1, c2;            /* 2^-s of the three layers */
+    const float* cs_dev;         /* if non-null: {2^s0, 2^-s0, 2^s1, 2^-s1, 2^s2, 2^-s2} on the device (bgk_pack_dense_h2) */
+    /* training forward (SAVE): pre-activations and spline parameters for the backward pass */
+    float* z0; float* z1;        /* [B, 128] each */
+    float* params; int64_t ldp;  /* [B, P] in the reference layout [w | h | s | s_nc] */
+    const int32_t* src_col;      /* device copy of bgk_pack_rqs_columns' table: packed row -> params column, -1 = padding */
 };
 
 constexpr int H2_STEPS = 8;                            /* 128 hidden units / 16 */
@@ -675,15 +680,31 @@ __device__ __forceinline__ void act_tile_scaled(f32x16& t, float c) {
 #endif
 }
 
-template <int ACT, int INV>
+/* pre-activation tile set (accumulator layout) -> z[b0 + j][0..128): 16-byte groups of 4 consecutive features */
+__device__ __forceinline__ void h2_store_z(const f32x16 (&t)[4], float* z, int64_t b0, int j, int hh, int rows) {
+    if (j < rows) {
+        float* zr = z + (b0 + j) * HID;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(zr + 32 * m + 8 * q + 4 * hh) = make_float4(t[m][4 * q], t[m][4 * q + 1], t[m][4 * q + 2], t[m][4 * q + 3]);
+    }
+}
+
+template <int ACT, int INV, bool SAVE>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(FusedArgsH2 ah) {
     const FusedArgs& a = ah.f;
+    if (ah.cs_dev) { ah.c0 = ah.cs_dev[1]; ah.c1 = ah.cs_dev[3]; ah.c2 = ah.cs_dev[5]; }   /* wave-uniform scalar loads */
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
+    /* parameter chunk [128][ST]: stride 33 in the training variant so that the chunk can also be read row-wise
+     * (lane = row) without bank conflicts for the coalesced parameter write-out */
+    constexpr int ST = SAVE ? 33 : 32;
     float* s_p = smem + (size_t)wave * a.lds_per_wave;
-    float* s_y = s_p + LDS_P;
+    float* s_y = s_p + 128 * ST;
     const int d = a.d;
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * FW + wave;
@@ -729,8 +750,18 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
         }
         H2Ring ring;
         h2_gemm_start(ring, ah.A1, lane);          /* layer-1 operands in flight during the activation */
+        if constexpr (SAVE) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(h[m], ah.c0);
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[m][r] *= ah.c0;
+            h2_store_z(h, ah.z0, b0, j, hh, rows);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) act_tile<ACT>(h[m]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(h[m], ah.c0);
+        }
 
         /* ---- layer 1 ---- */
         BFrag bf;
@@ -738,8 +769,18 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
         zero4(acc);
         h2_gemm_run(acc, ring, bf, ah.A1, lane);
         h2_gemm_start(ring, ah.A2, lane);
+        if constexpr (SAVE) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(acc[m], ah.c1);
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] *= ah.c1;
+            h2_store_z(acc, ah.z1, b0, j, hh, rows);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) act_tile<ACT>(acc[m]);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(acc[m], ah.c1);
+        }
         h2_make_b(bf, acc);                         /* the layer-2 B operands, shared by all chunks */
 
         /* ---- layer 2 in chunks of 128 packed columns + spline:
@@ -753,12 +794,22 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * 32 + j] = h[m][r] * ah.c2;
+                for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * ST + j] = h[m][r] * ah.c2;
 #else
             s_p[lane] = h[0][0] + h[1][1] + h[2][2] + h[3][3];
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if constexpr (SAVE) {
+                /* parameters of this chunk -> params[b][col]: lane = packed row (two passes of 64), one sample row per
+                 * store instruction: contiguous 32-byte runs (the 8 bins of a (dim, component)) instead of a 32-line scatter */
+                const int col_lo = ah.src_col[c * 128 + lane], col_hi = ah.src_col[c * 128 + 64 + lane];
+                for (int jj = 0; jj < rows; ++jj) {
+                    float* prow = ah.params + (b0 + jj) * ah.ldp;
+                    if (col_lo >= 0) prow[col_lo] = s_p[lane * ST + jj];
+                    if (col_hi >= 0) prow[col_hi] = s_p[(64 + lane) * ST + jj];
+                }
+            }
             const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
             const uint4* Wn = ah.A2 + (size_t)(c + 1) * H2_BLOCKS * 64;
             const bool more = c + 1 < a.n_chunks;
@@ -766,9 +817,9 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
             int bins[3] = {0, 0, 0};
             NoGemm g;
 #if !(BGK_ABL & 1)
-            spline_chunk<INV>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+            spline_chunk<INV, NoGemm, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #else
-            run += s_p[(lane & 127) * 32 + j];
+            run += s_p[(lane & 127) * ST + j];
 #endif
             if (a.bin_idx) {
 #pragma unroll
@@ -875,27 +926,24 @@ extern "C" int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_
     return bgk_launch_status("bgk_coupling_rqs_dense");
 }
 
-extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
-                                         const void* A0p, const void* A1p, const void* A2p,
-                                         float c0, float c1, float c2,
-                                         int32_t H0, int32_t H1, int32_t act, const float* y,
-                                         int64_t ldy, int64_t B, int32_t d, int32_t K, uint64_t circ_mask,
-                                         int32_t inverse,
-                                         double left, double right, double bottom, double top,
-                                         double min_bin_width, double min_bin_height,
-                                         double min_derivative, int32_t identity_init, float* out,
-                                         int64_t ldo, float* dlogp, int32_t accumulate,
-                                         int32_t* bin_idx, int32_t* oob_count, void* stream) {
-    BGK_CHECK_ARG(cond && A0p && A1p && A2p && y && out && dlogp, "bgk_coupling_rqs_dense_h2: null pointer");
-    BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "bgk_coupling_rqs_dense_h2: bad sizes");
+namespace {
+int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+              const void* A0p, const void* A1p, const void* A2p, float c0, float c1, float c2, const float* cs_dev,
+              int32_t H0, int32_t H1, int32_t act, const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
+              uint64_t circ_mask, int32_t inverse, double left, double right, double bottom, double top,
+              double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
+              float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
+              float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col, void* stream) {
+    BGK_CHECK_ARG(cond && A0p && A1p && A2p && y && out && dlogp, "%s: null pointer", what);
+    BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "%s: bad sizes", what);
     if (H0 != HID || H1 != HID || K != KB || d > 64 || act < 1 || act > 3) {
-        bgk_set_error("bgk_coupling_rqs_dense_h2: only hidden=(128,128), n_bins=8, d<=64, act in {SiLU,ReLU,Tanh} are fused "
-                      "(got H0=%d H1=%d K=%d d=%d act=%d)", H0, H1, K, d, act);
+        bgk_set_error("%s: only hidden=(128,128), n_bins=8, d<=64, act in {SiLU,ReLU,Tanh} are fused "
+                      "(got H0=%d H1=%d K=%d d=%d act=%d)", what, H0, H1, K, d, act);
         return BGK_EUNSUPPORTED;
     }
     const int n_in = periodic ? 2 * d_c : d_c;
     const int S0 = (n_in + 1 + 15) / 16;
-    BGK_CHECK_ARG(16 * S0 * SROW <= LDS_P, "bgk_coupling_rqs_dense_h2: conditioner input of %d features too wide", n_in);
+    BGK_CHECK_ARG(16 * S0 * SROW <= LDS_P, "%s: conditioner input of %d features too wide", what, n_in);
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
     if (B == 0) return 0;
@@ -909,21 +957,63 @@ extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t
     a.circ_mask = circ_mask;
     a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
     a.bin_idx = bin_idx; a.oob_count = oob_count;
-    a.lds_per_wave = LDS_P + (d + 1) * SROW;
+    const bool save = z0 != nullptr;
+    a.lds_per_wave = 128 * (save ? 33 : 32) + (d + 1) * SROW;
     a.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, K);
     ah.A0 = reinterpret_cast<const uint4*>(A0p); ah.S0 = S0;
     ah.A1 = reinterpret_cast<const uint4*>(A1p);
     ah.A2 = reinterpret_cast<const uint4*>(A2p);
-    ah.c0 = c0; ah.c1 = c1; ah.c2 = c2;
+    ah.c0 = c0; ah.c1 = c1; ah.c2 = c2; ah.cs_dev = cs_dev;
+    ah.z0 = z0; ah.z1 = z1; ah.params = params; ah.ldp = ldp; ah.src_col = src_col;
     size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
     int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
-    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_coupling_rqs_dense_h2: batch too large for one launch");
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
     int grid = (int)n_wg;
     hipStream_t st = (hipStream_t)stream;
-#define BGK_LAUNCH(A, I) hipLaunchKernelGGL((coupling_rqs_dense_h2_kernel<A, I>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
-    if (act == 1) { if (inverse) BGK_LAUNCH(1, 1); else BGK_LAUNCH(1, 0); }
-    else if (act == 2) { if (inverse) BGK_LAUNCH(2, 1); else BGK_LAUNCH(2, 0); }
-    else { if (inverse) BGK_LAUNCH(3, 1); else BGK_LAUNCH(3, 0); }
+#define BGK_LAUNCH(A, I, S) hipLaunchKernelGGL((coupling_rqs_dense_h2_kernel<A, I, S>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
+#define BGK_LAUNCH2(A, I) do { if (save) BGK_LAUNCH(A, I, true); else BGK_LAUNCH(A, I, false); } while (0)
+    if (act == 1) { if (inverse) BGK_LAUNCH2(1, 1); else BGK_LAUNCH2(1, 0); }
+    else if (act == 2) { if (inverse) BGK_LAUNCH2(2, 1); else BGK_LAUNCH2(2, 0); }
+    else { if (inverse) BGK_LAUNCH2(3, 1); else BGK_LAUNCH2(3, 0); }
+#undef BGK_LAUNCH2
 #undef BGK_LAUNCH
-    return bgk_launch_status("bgk_coupling_rqs_dense_h2");
+    return bgk_launch_status(what);
+}
+}  // namespace
+
+extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                         const void* A0p, const void* A1p, const void* A2p,
+                                         float c0, float c1, float c2, const float* cs_dev,
+                                         int32_t H0, int32_t H1, int32_t act, const float* y,
+                                         int64_t ldy, int64_t B, int32_t d, int32_t K, uint64_t circ_mask,
+                                         int32_t inverse,
+                                         double left, double right, double bottom, double top,
+                                         double min_bin_width, double min_bin_height,
+                                         double min_derivative, int32_t identity_init, float* out,
+                                         int64_t ldo, float* dlogp, int32_t accumulate,
+                                         int32_t* bin_idx, int32_t* oob_count, void* stream) {
+    return launch_h2("bgk_coupling_rqs_dense_h2", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, H0, H1, act, y, ldy, B, d, K,
+                     circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
+                     identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count,
+                     nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                               const void* A0p, const void* A1p, const void* A2p,
+                                               float c0, float c1, float c2, const float* cs_dev,
+                                               int32_t H0, int32_t H1, int32_t act, const float* y,
+                                               int64_t ldy, int64_t B, int32_t d, int32_t K, uint64_t circ_mask,
+                                               int32_t inverse,
+                                               double left, double right, double bottom, double top,
+                                               double min_bin_width, double min_bin_height,
+                                               double min_derivative, int32_t identity_init, float* out,
+                                               int64_t ldo, float* dlogp, int32_t accumulate,
+                                               int32_t* oob_count, float* z0, float* z1, float* params, int64_t ldp,
+                                               const int32_t* src_col_dev, void* stream) {
+    BGK_CHECK_ARG(z0 && z1 && params && src_col_dev, "bgk_coupling_rqs_dense_h2_train: null save buffer");
+    const int n_nc = d - __builtin_popcountll(circ_mask & (d >= 64 ? ~0ull : ((1ull << d) - 1)));
+    BGK_CHECK_ARG(ldp >= 3 * K * d + n_nc, "bgk_coupling_rqs_dense_h2_train: params row stride %lld too small", (long long)ldp);
+    return launch_h2("bgk_coupling_rqs_dense_h2_train", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, H0, H1, act, y, ldy, B, d,
+                     K, circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
+                     identity_init, out, ldo, dlogp, accumulate, nullptr, oob_count, z0, z1, params, ldp, src_col_dev, stream);
 }

@@ -1,0 +1,119 @@
+/* bgk_pack.hip -- device-side operand packing for the split-f16 fused kernels (bgk_fused.hip, bgk_mfma_h2.h).
+ * Replaces the host/torch packer (bgflow_amd/dense.py::_pack_h2, kept as the layout's reference and tested
+ * against this one) where the weights change every step: a KL / NLL training step re-packs 16 conditioners, which
+ * as ~30 small torch ops + 3 host syncs per layer cost more than the fused forward itself.
+ *   pass 1 (one workgroup per layer): m = max(|W|, |b|) -> scale 2^e with e = clamp(floor(log2(32768 / m)), -16, 24);
+ *           cs[2 l] = 2^e, cs[2 l + 1] = 2^-e (the kernels read the unscale factor from device memory)
+ *   pass 2: one thread per (1 KiB block, lane): 8 weights -> hi = rne_f16(v), lo = rne_f16(v - hi)
+ */
+#include "bgk_common.h"
+
+namespace {
+
+struct PackLayer {
+    const float* W; const float* b;   /* source Linear: weight [rows, K] row-major, bias [rows] */
+    int rows, K;
+    const int32_t* row_map;           /* packed row -> source row (-1 = padding), NULL = identity */
+    int n_groups;                     /* independent 32*NT-row groups (layer-2 chunks), each followed by its bias blocks */
+    int NT, S, natural;               /* natural = 1: k = 16 s + 8 kb + e with the bias as column K; 0: accumulator order */
+    _Float16* out;
+};
+
+__global__ __launch_bounds__(256) void pack_scale_kernel(PackLayer L0, PackLayer L1, PackLayer L2, float* cs) {
+    const PackLayer& L = blockIdx.x == 0 ? L0 : (blockIdx.x == 1 ? L1 : L2);
+    __shared__ float red[256];
+    float m = 0.0f;
+    const int nW = L.rows * L.K;
+    for (int i = threadIdx.x; i < nW; i += 256) m = fmaxf(m, fabsf(L.W[i]));
+    for (int i = threadIdx.x; i < L.rows; i += 256) m = fmaxf(m, fabsf(L.b[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        m = red[0];
+        int e = 0;
+        if (m > 0.0f && m < 3.0e38f) {
+            e = (int)floorf(log2f(32768.0f / m));
+            e = e < -16 ? -16 : (e > 24 ? 24 : e);
+        }
+        cs[2 * blockIdx.x] = ldexpf(1.0f, e);
+        cs[2 * blockIdx.x + 1] = ldexpf(1.0f, -e);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_blocks_kernel(PackLayer L, const float* cs, int layer) {
+    const int blocks_per_group = L.S * L.NT * 2 + (L.natural ? 0 : L.NT);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)L.n_groups * blocks_per_group * 64;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    const int blk = (int)((t >> 6) % blocks_per_group);
+    const int grp = (int)((t >> 6) / blocks_per_group);
+    const int i = lane & 31, kb = lane >> 5;
+    const float scale = cs[2 * layer];
+    _Float16 o[8];
+    if (blk < L.S * L.NT * 2) {
+        const int p = blk & 1, m = (blk >> 1) % L.NT, s = (blk >> 1) / L.NT;
+        const int prow = grp * 32 * L.NT + 32 * m + i;
+        const int srow = L.row_map ? L.row_map[prow] : (prow < L.rows ? prow : -1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = L.natural ? 16 * s + 8 * kb + e : 32 * (s >> 1) + (e & 3) + 8 * (2 * (s & 1) + (e >> 2)) + 4 * kb;
+            float v = 0.0f;
+            if (srow >= 0) {
+                if (k < L.K) v = L.W[(int64_t)srow * L.K + k];
+                else if (L.natural && k == L.K) v = L.b[srow];
+            }
+            v *= scale;
+            const _Float16 h = (_Float16)v;
+            o[e] = p ? (_Float16)(v - (float)h) : h;
+        }
+    } else {
+        const int m = blk - L.S * L.NT * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.0f;
+        if (kb == 0) {
+            const int prow = grp * 32 * L.NT + 32 * m + i;
+            const int srow = L.row_map ? L.row_map[prow] : (prow < L.rows ? prow : -1);
+            if (srow >= 0) {
+                const float v = L.b[srow] * scale;
+                const _Float16 h = (_Float16)v;
+                o[0] = h;
+                o[1] = (_Float16)(v - (float)h);
+            }
+        }
+    }
+    _Float16* dst = L.out + ((int64_t)(grp * blocks_per_group + blk) * 64 + lane) * 8;
+    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
+}
+
+void launch_pack(const PackLayer& L, const float* cs, int layer, hipStream_t st) {
+    const int blocks_per_group = L.S * L.NT * 2 + (L.natural ? 0 : L.NT);
+    const int64_t total = (int64_t)L.n_groups * blocks_per_group * 64;
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, L, cs, layer);
+}
+
+}  // namespace
+
+extern "C" int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
+                                 const float* W1, const float* b1,
+                                 const float* W2, const float* b2, int32_t rows2,
+                                 const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2,
+                                 void* A0, void* A1, void* A2, float* cs, void* stream) {
+    BGK_CHECK_ARG(W0 && b0 && W1 && b1 && W2 && b2 && A0 && A1 && A2 && cs, "bgk_pack_dense_h2: null pointer");
+    BGK_CHECK_ARG(n_in > 0 && (H == 32 || H == 64 || H == 96 || H == 128) && rows2 > 0 && n_groups2 > 0 && NT2 > 0 && NT2 <= 4,
+                  "bgk_pack_dense_h2: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int HT = H / 32;
+    PackLayer L0{W0, b0, H, n_in, nullptr, 1, HT, (n_in + 1 + 15) / 16, 1, (_Float16*)A0};
+    PackLayer L1{W1, b1, H, H, nullptr, 1, HT, 2 * HT, 0, (_Float16*)A1};
+    PackLayer L2{W2, b2, rows2, H, row_map2_dev, n_groups2, NT2, 2 * HT, 0, (_Float16*)A2};
+    hipLaunchKernelGGL(pack_scale_kernel, dim3(3), dim3(256), 0, st, L0, L1, L2, cs);
+    launch_pack(L0, cs, 0, st);
+    launch_pack(L1, cs, 1, st);
+    launch_pack(L2, cs, 2, st);
+    return bgk_launch_status("bgk_pack_dense_h2");
+}

@@ -17,6 +17,22 @@ from .utils import is_list_or_tuple
 __all__ = ["DenseNet", "MeanFreeDenseNet", "WrapPeriodic"]
 
 
+def _matmul_nn(g, w):
+    """g [B, n] @ w [n, k] for tall g: hipBLASLt's NN heuristics pick a 32x32x256 tile here (55 TFLOP/s); the same product
+    through the TN entry (``linear`` with the small operand transposed once) runs the kernels the forward pass uses."""
+    return torch.nn.functional.linear(g, w.t().contiguous())
+
+
+def _gram_tn(g, h, splits=64):
+    """g^T h for tall g [B, n], h [B, k] (weight gradient of a Linear layer): one GEMM with K = B leaves most of the chip
+    idle (n k / tile^2 workgroups, hipBLASLt picks no split-K here: 0.5 ms at B = 2^18); as a batched GEMM over row slabs
+    + a small sum it runs ~5x faster."""
+    B = g.shape[0]
+    if B % splits or B // splits < 256:
+        return g.t() @ h
+    return torch.bmm(g.view(splits, B // splits, -1).transpose(1, 2), h.view(splits, B // splits, -1)).sum(0)
+
+
 def column_sum(g, nblk=1024):
     """out[c] = sum_r g[r, c] on the HIP kernel bgk_column_sum (f32, 2-D, HIP device)"""
     _lib.require_hip(g)
@@ -45,8 +61,8 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
-        gx = g @ weight if ctx.needs_input_grad[0] else None
-        gw = g.t() @ x if ctx.needs_input_grad[1] else None
+        gx = _matmul_nn(g, weight) if ctx.needs_input_grad[0] else None
+        gw = _gram_tn(g, x.contiguous()) if ctx.needs_input_grad[1] else None
         gb = column_sum(g) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
@@ -386,6 +402,42 @@ def pack_dense_for_fused_h2(linears, nc_slot_host, d, n_bins):
     return A0, A1, A2, (2.0 ** -e0, 2.0 ** -e1, 2.0 ** -e2)
 
 
+DEVICE_PACK = True     # pack split-f16 operands with bgk_pack_dense_h2 (no host sync); False: the torch reference packer
+
+
+def pack_dense_for_fused_h2_device(linears, src_col_dev, n_chunks, bufs=None):
+    """Device-side twin of pack_dense_for_fused_h2 (bgk_pack_dense_h2): returns (A0, A1, A2, cs) with cs the
+    device scale table {2^s, 2^-s} x 3.  ``bufs`` = previous result to overwrite in place."""
+    l0, l1, l2 = linears
+    dev = l0.weight.device
+    n_in = l0.in_features
+    S0 = (n_in + 1 + 15) // 16
+    if bufs is None:
+        A0 = torch.empty((S0 * 8, 64, 8), dtype=torch.float16, device=dev)
+        A1 = torch.empty((8 * 8 + 4, 64, 8), dtype=torch.float16, device=dev)
+        A2 = torch.empty((n_chunks * (8 * 8 + 4), 64, 8), dtype=torch.float16, device=dev)
+        cs = torch.empty(6, dtype=torch.float32, device=dev)
+    else:
+        A0, A1, A2, cs = bufs
+    ws = [t.detach().contiguous() for lin in linears for t in (lin.weight, lin.bias)]
+    assert all(w.dtype == torch.float32 for w in ws)
+    with torch.cuda.device(dev):
+        st = _lib.lib().bgk_pack_dense_h2(
+            _lib.ptr(ws[0]), _lib.ptr(ws[1]), n_in, 128, _lib.ptr(ws[2]), _lib.ptr(ws[3]), _lib.ptr(ws[4]), _lib.ptr(ws[5]),
+            l2.out_features, _lib.ptr(src_col_dev), n_chunks, 4, _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), _lib.ptr(cs),
+            _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_pack_dense_h2")
+    return A0, A1, A2, cs
+
+
+def _src_col_table(d, n_bins, nc_slot_host, device):
+    ncp = _lib.lib().bgk_pack_rqs_columns(d, n_bins, None, None)
+    src = np.empty(ncp, dtype=np.int32)
+    slots = np.ascontiguousarray(nc_slot_host, dtype=np.int32)
+    _lib.lib().bgk_pack_rqs_columns(d, n_bins, slots.ctypes.data, src.ctypes.data)
+    return torch.as_tensor(src, device=device)
+
+
 def _gemm_mode(transformer):
     mode = getattr(transformer, "gemm_mode", None) or GEMM_MODE
     if mode not in ("f32", "f16x2"):
@@ -424,12 +476,24 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     params = [p for lin in (l0, l1, l2) for p in (lin.weight, lin.bias)]
     version = tuple((p.data_ptr(), p._version) for p in params)
     cache = transformer._fused_cache
-    if cache.get("version") != version or cache.get("y_dim") != y_dim or cache.get("mode") != mode:
+    dev = l0.weight.device
+    stale = cache.get("version") != version
+    if cache.get("y_dim") != y_dim or cache.get("mode") != mode or cache.get("device") != dev:
         cache.clear()
-        pack = pack_dense_for_fused if mode == "f32" else pack_dense_for_fused_h2
-        cache.update(version=version, y_dim=y_dim, mode=mode, packed=pack((l0, l1, l2), nc_slot_host, y_dim, n_bins),
-                     act=act, periodic=periodic, d_c=d_c, n_bins=n_bins,
-                     circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
+        stale = True
+    if stale:
+        common = dict(version=version, y_dim=y_dim, mode=mode, device=dev, act=act, periodic=periodic, d_c=d_c, n_bins=n_bins,
+                      circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
+        if mode == "f16x2" and DEVICE_PACK and dev.type == "cuda":
+            if "src_col_dev" not in cache:
+                cache["src_col_dev"] = _src_col_table(y_dim, n_bins, nc_slot_host, dev)
+            n_chunks = cache["src_col_dev"].numel() // 128
+            A0, A1, A2, cs = pack_dense_for_fused_h2_device((l0, l1, l2), cache["src_col_dev"], n_chunks, cache.get("bufs"))
+            cache.update(common, bufs=(A0, A1, A2, cs), packed=(A0, A1, A2, (1.0, 1.0, 1.0)), cs=cs)
+        else:
+            pack = pack_dense_for_fused if mode == "f32" else pack_dense_for_fused_h2
+            cache.update(common, packed=pack((l0, l1, l2), nc_slot_host, y_dim, n_bins), cs=None)
+            cache.pop("bufs", None)
     return cache
 
 
@@ -465,9 +529,110 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
             c0, c1, c2 = plan["packed"][3]
             st = _lib.lib().bgk_coupling_rqs_dense_h2(
                 _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p),
-                c0, c1, c2, *tail)
+                c0, c1, c2, _lib.ptr(plan.get("cs")), *tail)
     if st == -2:
         return None
     _lib.check(st, "bgk_coupling_rqs_dense")
     res = (out, dlogp[:, None])
     return res + (bins,) if want_bin_idx else res
+
+
+# ---- training forward of the fused spline coupling layer -------------------------------------------------------
+def _act_fwd_bwd(code):
+    if code == 1:
+        return torch.nn.functional.silu, lambda g, z, h: torch.ops.aten.silu_backward(g, z)
+    if code == 2:
+        return torch.relu, lambda g, z, h: g * (z > 0).to(g.dtype)
+    return torch.tanh, lambda g, z, h: g * (1.0 - h * h)
+
+
+def _featurise(x, periodic):
+    if not periodic:
+        return x
+    ang = 2 * np.pi * x
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+
+
+class _FusedSplineTrainFn(torch.autograd.Function):
+    """Forward = ONE launch of bgk_coupling_rqs_dense_h2_train (conditioner MLP on the f16 matrix cores + spline; the
+    pre-activations z0, z1 and the spline parameters are written out for the backward pass).  Backward = bgk_rqs_backward
+    + the MLP's backward as plain GEMMs on the saved tensors (bias gradients on bgk_column_sum)."""
+
+    @staticmethod
+    def forward(ctx, x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob):
+        A0, A1, A2, (c0, c1, c2) = plan["packed"]
+        x2, ldc = _lib.rowmajor(x)
+        y2, ldy = _lib.rowmajor(y)
+        B, d = y2.shape
+        dev = y.device
+        P = W2.shape[0]
+        out = torch.empty((B, d), dtype=torch.float32, device=dev)
+        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        z0 = torch.empty((B, 128), dtype=torch.float32, device=dev)
+        z1 = torch.empty((B, 128), dtype=torch.float32, device=dev)
+        params = torch.empty((B, P), dtype=torch.float32, device=dev)
+        left, right, bottom, top, s = tcfg
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_coupling_rqs_dense_h2_train(
+                _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2,
+                _lib.ptr(plan.get("cs")), 128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
+                left, right, bottom, top, s["min_bin_width"], s["min_bin_height"], s["min_derivative"],
+                int(s.get("enable_identity_init", False)), _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.ptr(oob),
+                _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), P, _lib.ptr(plan["src_col_dev"]), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_coupling_rqs_dense_h2_train")
+        ctx.save_for_backward(x, y, W0, W1, W2, z0, z1, params, nc_dev)
+        ctx.meta = (plan["act"], bool(plan["periodic"]), (plan["n_bins"], inverse, left, right, bottom, top, dict(s)))
+        return out, dlogp[:, None]
+
+    @staticmethod
+    def backward(ctx, g_out, g_dlogp):
+        from .transformer import rqs_backward
+        x, y, W0, W1, W2, z0, z1, params, nc_dev = ctx.saved_tensors
+        act_code, periodic, rcfg = ctx.meta
+        act, act_bwd = _act_fwd_bwd(act_code)
+        g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp)
+        need = ctx.needs_input_grad
+        h1 = act(z1)
+        gW2 = _gram_tn(g_p, h1) if need[6] else None
+        gb2 = column_sum(g_p) if need[7] else None
+        g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
+        del h1
+        h0 = act(z0)
+        gW1 = _gram_tn(g_z1, h0) if need[4] else None
+        gb1 = column_sum(g_z1) if need[5] else None
+        g_z0 = act_bwd(_matmul_nn(g_z1, W1), z0, h0)
+        del h0, g_z1
+        g_x = None
+        if need[0] and periodic:
+            with torch.enable_grad():
+                xx = x.detach().requires_grad_(True)
+                feats = _featurise(xx, True)
+            g_x = torch.autograd.grad(feats, xx, _matmul_nn(g_z0, W0))[0]
+            feats = feats.detach()
+        else:
+            feats = _featurise(x, periodic)
+            if need[0]:
+                g_x = _matmul_nn(g_z0, W0)
+        gW0 = _gram_tn(g_z0, feats.contiguous()) if need[2] else None
+        gb0 = column_sum(g_z0) if need[3] else None
+        return (g_x, g_y if need[1] else None, gW0, gb0, gW1, gb1, gW2, gb2) + (None,) * 5
+
+
+def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob_counter):
+    """Differentiable one-launch forward of the spline coupling layer (split-f16 mode only).  Returns (y', dlogp) or None
+    when the conditioner is not a fusable DenseNet."""
+    if x.dim() != 2 or y.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or _gemm_mode(transformer) != "f16x2":
+        return None
+    plan = _fused_plan(transformer, y.shape[-1], nc_host)
+    if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device:
+        return None
+    _lib.require_hip(x, y)
+    if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:
+        plan["src_col_dev"] = _src_col_table(y.shape[-1], plan["n_bins"], nc_host, y.device)
+    net = transformer._params_net
+    inner = net.net if type(net) is WrapPeriodic else net
+    (l0, l1, l2), _ = _fusable_dense(inner)
+    tcfg = (transformer._left, transformer._right, transformer._bottom, transformer._top, transformer._default_settings)
+    return _FusedSplineTrainFn.apply(x, y, l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias, plan, tcfg,
+                                     nc_dev, inverse, oob_counter)
+

@@ -192,24 +192,31 @@ class _RQSFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_dlogp):
         y, params, nc_slot = ctx.saved_tensors
-        n_bins, inverse, left, right, bottom, top, settings = ctx.cfg
-        d, P = y.shape[-1], params.shape[-1]
-        y2, ldy = _lib.rowmajor(y.reshape(-1, d))
-        p2, ldp = _lib.rowmajor(params.reshape(-1, P))
-        B = y2.shape[0]
-        g_out2 = g_out.reshape(-1, d).contiguous()
-        g_dl = g_dlogp.reshape(-1).contiguous()
-        g_y = torch.empty((B, d), dtype=torch.float32, device=y.device)
-        g_p = torch.empty((B, P), dtype=torch.float32, device=y.device)
-        with torch.cuda.device(y.device):
-            st = _lib.lib().bgk_rqs_backward(
-                _lib.ptr(y2), ldy, _lib.ptr(p2), ldp, P, _lib.ptr(nc_slot), B, d, n_bins, int(inverse),
-                left, right, bottom, top, settings["min_bin_width"], settings["min_bin_height"],
-                settings["min_derivative"], int(settings.get("enable_identity_init", False)),
-                _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), P,
-                _lib.stream_ptr(y.device))
-        _lib.check(st, "bgk_rqs_backward")
-        return (g_y.reshape(y.shape), g_p.reshape(params.shape)) + (None,) * 9
+        g_y, g_p = rqs_backward(y, params, nc_slot, ctx.cfg, g_out, g_dlogp)
+        return (g_y, g_p) + (None,) * 9
+
+
+def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp):
+    """Launch bgk_rqs_backward: VJP of rqs_transform w.r.t. (y, params); cfg = (n_bins, inverse, left, right, bottom,
+    top, settings)."""
+    n_bins, inverse, left, right, bottom, top, settings = cfg
+    d, P = y.shape[-1], params.shape[-1]
+    y2, ldy = _lib.rowmajor(y.reshape(-1, d))
+    p2, ldp = _lib.rowmajor(params.reshape(-1, P))
+    B = y2.shape[0]
+    g_out2 = g_out.reshape(-1, d).contiguous()
+    g_dl = g_dlogp.reshape(-1).contiguous()
+    g_y = torch.empty((B, d), dtype=torch.float32, device=y.device)
+    g_p = torch.empty((B, P), dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        st = _lib.lib().bgk_rqs_backward(
+            _lib.ptr(y2), ldy, _lib.ptr(p2), ldp, P, _lib.ptr(nc_slot), B, d, n_bins, int(inverse),
+            left, right, bottom, top, settings["min_bin_width"], settings["min_bin_height"],
+            settings["min_derivative"], int(settings.get("enable_identity_init", False)),
+            _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), P,
+            _lib.stream_ptr(y.device))
+    _lib.check(st, "bgk_rqs_backward")
+    return g_y.reshape(y.shape), g_p.reshape(params.shape)
 
 
 class ConditionalSplineTransformer(Transformer):
@@ -285,7 +292,7 @@ class ConditionalSplineTransformer(Transformer):
 
     # -- forward / inverse ------------------------------------------------------------------
     def _run(self, x, y, inverse):
-        from .dense import fused_spline_coupling   # late import (dense imports nothing from here)
+        from .dense import fused_spline_coupling, fused_spline_coupling_train   # late import
         y_dim = y.shape[-1]
         nc_dev, nc_host = self._nc_slot(y_dim, y.device)
         oob = self._oob_counter(y.device)
@@ -297,6 +304,10 @@ class ConditionalSplineTransformer(Transformer):
                 if self.return_bin_indices:
                     self.last_bin_indices = fused[2]
                 return fused[0], fused[1]
+        if grad and self.allow_fused and not self.return_bin_indices:
+            fused = fused_spline_coupling_train(self, x, y, nc_dev, nc_host, inverse, oob)
+            if fused is not None:
+                return fused
         params = self._params_net(x)
         n_nc = int((nc_host >= 0).sum())
         P = params.shape[-1]

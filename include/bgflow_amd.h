@@ -188,10 +188,11 @@ int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_c, int32_t 
  * (every f32 operand = hi + lo f16 pair, three v_mfma_f32_32x32x16_f16 per product, f32 accumulate): f32-class
  * accuracy (measured 0.47 ulp32 rms of sum|a||b| vs 0.65 for the f32 fma chain) at 16/3 times the MFMA rate;
  * not bit-identical to the f32 chain.  A0p/A1p/A2p: f16 operand blocks and c0..c2: per-layer power-of-two
- * unscale factors from bgflow_amd/dense.py::pack_dense_for_fused_h2 (layout in bgk_fused.hip / DESIGN.md). */
+ * unscale factors from bgflow_amd/dense.py::pack_dense_for_fused_h2 (layout in bgk_fused.hip / DESIGN.md); or, when the
+ * operands were packed on the device by bgk_pack_dense_h2, cs_dev = its scale table (c0..c2 are then ignored). */
 int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                               const void* A0p, const void* A1p, const void* A2p,
-                              float c0, float c1, float c2,
+                              float c0, float c1, float c2, const float* cs_dev,
                               int32_t H0, int32_t H1, int32_t act,
                               const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
                               uint64_t circ_mask, int32_t inverse,
@@ -200,6 +201,23 @@ int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32
                               int32_t identity_init,
                               float* out, int64_t ldo, float* dlogp, int32_t accumulate,
                               int32_t* bin_idx, int32_t* oob_count, void* stream);
+
+/* Training forward of the same layer: additionally writes what the backward pass needs -- the hidden layers'
+ * pre-activations z0, z1 [B, 128] and the spline parameters [B, P] in the reference layout [w | h | s | s_nc]
+ * (transformer/spline.py:113-126) -- so that autograd (KLTrainer.train, nn/training/trainers.py:158-170) can run
+ * bgk_rqs_backward and the MLP backward on them.  src_col_dev: device copy of bgk_pack_rqs_columns' table. */
+int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                    const void* A0p, const void* A1p, const void* A2p,
+                                    float c0, float c1, float c2, const float* cs_dev,
+                                    int32_t H0, int32_t H1, int32_t act,
+                                    const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
+                                    uint64_t circ_mask, int32_t inverse,
+                                    double left, double right, double bottom, double top,
+                                    double min_bin_width, double min_bin_height, double min_derivative,
+                                    int32_t identity_init,
+                                    float* out, int64_t ldo, float* dlogp, int32_t accumulate,
+                                    int32_t* oob_count, float* z0, float* z1, float* params, int64_t ldp,
+                                    const int32_t* src_col_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused affine coupling layer: replaces CouplingFlow._forward/_inverse (nn/flow/coupling.py:162-182) around
@@ -220,6 +238,17 @@ int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c, in
                                  int32_t is_circular, int32_t inverse,
                                  const float* y, int64_t ldy, int64_t B, int32_t d,
                                  float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
+
+/* Device-side packing of a DenseNet [n_in, H, H, rows2] into split-f16 MFMA operands (no host synchronisation; used
+ * whenever the weights change, i.e. every training step).  Layer 2's packed rows are row_map2_dev[packed row] (source
+ * row or -1; NULL = identity), laid out as n_groups2 groups of NT2 32-row tiles, each group followed by its bias
+ * blocks -- the spline kernel uses (row_map = bgk_pack_rqs_columns, n_groups = chunks, NT2 = 4), the affine kernel
+ * (NULL, 1, ceil(d / 32)).  cs[6] receives {2^s, 2^-s} per layer.  Replaces bgflow_amd/dense.py::_pack_h2. */
+int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
+                      const float* W1, const float* b1,
+                      const float* W2, const float* b2, int32_t rows2,
+                      const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2,
+                      void* A0, void* A1, void* A2, float* cs, void* stream);
 
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).

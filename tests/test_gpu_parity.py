@@ -806,3 +806,50 @@ def test_nll_training_step_cfg3(hip_lib, golden, dev):
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - analytic) <= 0.05 * abs(analytic) + 1e-3, (fd, analytic)
 
+
+@pytest.mark.parametrize("kind", ["T|F", "F|T", "B|A"])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fused_training_forward_gradients(hip_lib, dev, kind, inverse):
+    """differentiable one-launch forward (bgk_coupling_rqs_dense_h2_train + MLP backward on the saved tensors) vs the
+    generic autograd path (torch conditioner + bgk_rqs_transform / bgk_rqs_backward): outputs and every gradient"""
+    B = 777
+    res = {}
+    for fused in (True, False):
+        layer, ti = _layer(kind, dev)
+        layer.transformer.gemm_mode = "f16x2"
+        layer.transformer.allow_fused = fused
+        xs = [t(synth(B + 7 * i, B, d, uniform=True), dev).requires_grad_(True) for i, d in enumerate((17, 17, 17, 9))]
+        *outs, dl = layer(*xs, inverse=inverse)
+        if fused:
+            assert layer.transformer._fused_cache.get("src_col_dev") is not None, "the fused training path must have run"
+        w = t(synth(55, B, outs[ti].shape[1]), dev)
+        ((outs[ti] * w).sum() + (dl * t(synth(56, B, 1), dev)).sum()).backward()
+        res[fused] = ([outs[ti].detach(), dl.detach()], [p.grad for p in layer.parameters()] + [x.grad for x in xs if x.grad is not None])
+    for a, b in zip(res[True][0], res[False][0]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    assert len(res[True][1]) == len(res[False][1])
+    for a, b in zip(res[True][1], res[False][1]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=2e-4 * float(b.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("kind", ["T|F", "F|T", "B|A"])
+def test_device_packer_equals_torch_packer(hip_lib, dev, kind):
+    """bgk_pack_dense_h2 (device, no host sync) produces the same split-f16 operand blocks and scales as the torch
+    reference packer whose layout tests/test_host_logic.py checks on the CPU"""
+    from bgflow_amd import dense
+    layer, ti = _layer(kind, dev)
+    tr = layer.transformer
+    net = tr._params_net
+    inner = net.net if type(net) is dense.WrapPeriodic else net
+    (l0, l1, l2), _ = dense._fusable_dense(inner)
+    d = {"T|F": 17, "F|T": 9, "B|A": 17}[kind]
+    _, nc_host = tr._nc_slot(d, dev)
+    A0, A1, A2, (c0, c1, c2) = dense.pack_dense_for_fused_h2((l0, l1, l2), nc_host, d, 8)
+    src = dense._src_col_table(d, 8, nc_host, dev)
+    B0, B1, B2, cs = dense.pack_dense_for_fused_h2_device((l0, l1, l2), src, src.numel() // 128)
+    cs = cs.cpu().numpy()
+    assert np.allclose(cs[1::2], [c0, c1, c2]) and np.allclose(cs[0::2] * cs[1::2], 1.0)
+    for a, b in zip((A0, A1, A2), (B0, B1, B2)):
+        assert a.shape == b.shape
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
