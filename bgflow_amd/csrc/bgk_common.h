@@ -62,7 +62,9 @@ static inline BgkRqsCfg bgk_make_rqs_cfg(double left, double right, double botto
  * separately rounded f32 op, the TU is compiled with -ffp-contract=off.
  * Returns the transformed value; *lad = per-element log|det| contribution in bgflow's sign
  * convention; *bin = bin index; *oob = 1 if x had to be clamped.  */
-template <int KT>
+/* REGS = true: pw / ph / ps are per-lane register arrays (st == 1): the two bin-indexed slope reads become select
+ * chains instead of dynamically indexed loads (which would force the arrays into scratch memory). */
+template <int KT, bool REGS = false>
 __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const float* ph,
                                                  const float* ps, int st, float s_last, int Krt,
                                                  int inverse, const BgkRqsCfg& c, float* lad,
@@ -161,8 +163,18 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
     const float B_i = b_ip1 - b_i;
 
     /* ---- the two derivatives that are gathered ---- */
-    float s_lo = ps[idx * st];
-    float s_hi = (idx + 1 < K) ? ps[(idx + 1) * st] : s_last;
+    float s_lo, s_hi;
+    if constexpr (REGS && KT > 0) {
+        s_lo = ps[0]; s_hi = s_last;
+#pragma unroll
+        for (int k = 1; k < KT; ++k) {
+            s_lo = (k == idx) ? ps[k] : s_lo;
+            s_hi = (k == idx + 1) ? ps[k] : s_hi;
+        }
+    } else {
+        s_lo = ps[idx * st];
+        s_hi = (idx + 1 < K) ? ps[(idx + 1) * st] : s_last;
+    }
     const bgk_f2 sp = bgk_softplusf2((bgk_f2){s_lo, s_hi}, c.beta);
     float d_i = c.min_d + sp.x;
     float d_ip1 = c.min_d + sp.y;

@@ -117,6 +117,62 @@ __global__ __launch_bounds__(RQS_THREADS) void rqs_kernel(RqsArgs a) {
     }
 }
 
+/* ---- K = 8 streaming variant: no parameter staging --------------------------------------------------------
+ * Elements are enumerated dim-fastest (e = s * d + j), so the 8 raw widths (heights, slopes) of 64 consecutive
+ * lanes are 64 consecutive 32-byte runs of a parameter row: every lane fetches its 24 parameters with six 16-byte
+ * loads straight into registers (4-byte aligned is enough for global_load_dwordx4), y / out / bin indices are
+ * plain coalesced accesses, and only the per-element log-dets pass through LDS for the ascending-dim row sum.
+ * No barrier between load and compute, ~100 VGPRs -> 4-5 waves / SIMD hide the HBM latency. */
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int RQS2_TS = 128;   /* samples per workgroup tile */
+
+__global__ __launch_bounds__(RQS_THREADS) void rqs_stream_kernel(RqsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_lad[];   /* [RQS2_TS * d] */
+    constexpr int K = 8;
+    const int d = a.d, tid = threadIdx.x;
+    const uint64_t magicd = (0x100000000ull + (uint64_t)d - 1) / (uint64_t)d;   /* 2^32 for d = 1: needs 33 bits */
+    const int64_t n_tiles = (a.B + RQS2_TS - 1) / RQS2_TS;
+    int oob_local = 0;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * RQS2_TS;
+        const int rows = (int)((a.B - b0) < RQS2_TS ? (a.B - b0) : RQS2_TS);
+        const int n = rows * d;
+        for (int e = tid; e < n; e += RQS_THREADS) {
+            const int s = (int)(((uint64_t)(uint32_t)e * magicd) >> 32), j = e - s * d;
+            const float* row = a.params + (b0 + s) * a.ldp;
+            const float* gw = row + j * K;
+            const float* gh = gw + d * K;
+            const float* gs = gh + d * K;
+            float pw[K], ph[K], ps[K];
+            const f4u w0 = *reinterpret_cast<const f4u*>(gw), w1 = *reinterpret_cast<const f4u*>(gw + 4);
+            const f4u h0 = *reinterpret_cast<const f4u*>(gh), h1 = *reinterpret_cast<const f4u*>(gh + 4);
+            const f4u t0 = *reinterpret_cast<const f4u*>(gs), t1 = *reinterpret_cast<const f4u*>(gs + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { pw[k] = w0[k]; pw[4 + k] = w1[k]; ph[k] = h0[k]; ph[4 + k] = h1[k]; ps[k] = t0[k]; ps[4 + k] = t1[k]; }
+            const int slot = a.nc_slot[j];
+            const float s_last = slot >= 0 ? row[3 * d * K + slot] : ps[0];
+            const float x = a.y[(b0 + s) * a.ldy + j];
+            float lad; int bin, oob;
+            const float o = bgk_rqs_element<K, true>(x, pw, ph, ps, 1, s_last, K, a.inverse, a.cfg, &lad, &bin, &oob);
+            a.out[(b0 + s) * a.ldo + j] = o;
+            if (a.bin_idx) a.bin_idx[(b0 + s) * d + j] = bin;
+            s_lad[e] = lad;
+            oob_local += oob;
+        }
+        __syncthreads();
+        for (int s = tid; s < rows; s += RQS_THREADS) {
+            float acc = 0.0f;
+            for (int j = 0; j < d; ++j) acc += s_lad[s * d + j];
+            if (a.accumulate) a.dlogp[b0 + s] += acc; else a.dlogp[b0 + s] = acc;
+        }
+        __syncthreads();
+    }
+    if (a.oob_count) {
+        for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
+        if ((tid & 63) == 0 && oob_local) atomicAdd(a.oob_count, oob_local);
+    }
+}
+
 }  // namespace
 
 extern "C" int bgk_rqs_transform(const float* y, int64_t ldy, const float* params, int64_t ldp,
@@ -155,7 +211,11 @@ extern "C" int bgk_rqs_transform(const float* y, int64_t ldy, const float* param
     int64_t n_tiles = (B + TS - 1) / TS;
     int grid = (int)(n_tiles < 256 * 12 ? n_tiles : 256 * 12);
     hipStream_t st = (hipStream_t)stream;
-    if (K == 8) hipLaunchKernelGGL(rqs_kernel<8>, dim3(grid), dim3(RQS_THREADS), shmem, st, a);
+    if (K == 8 && d <= 1024) {
+        const int64_t nt2 = (B + RQS2_TS - 1) / RQS2_TS;
+        const int grid2 = (int)(nt2 < 256 * 16 ? nt2 : 256 * 16);
+        hipLaunchKernelGGL(rqs_stream_kernel, dim3(grid2), dim3(RQS_THREADS), sizeof(float) * (size_t)RQS2_TS * d, st, a);
+    } else if (K == 8) hipLaunchKernelGGL(rqs_kernel<8>, dim3(grid), dim3(RQS_THREADS), shmem, st, a);
     else hipLaunchKernelGGL(rqs_kernel<0>, dim3(grid), dim3(RQS_THREADS), shmem, st, a);
     return bgk_launch_status("bgk_rqs_transform");
 }
