@@ -3,10 +3,8 @@
  * (nn/flow/transformer/spline.py:109-188 + nflows).  Same math as oracle/bgo_impl.h::bgo_rqs_backward.
  *
  * HBM-bound: per sample it reads P + 2d + 1 floats (params, y, g_out, g_dlogp) and writes P + d
- * floats (g_params, g_y): 4*(2P + 3d + 1) algorithmic bytes.  Same tiling as bgk_rqs.hip: the
- * parameter rows of a tile are staged in LDS (odd row stride, lane -> sample); every (sample, dim)
- * element owns its 3K(+1) parameter slots exclusively, so the gradients OVERWRITE the staged
- * parameters in place and the tile is streamed back out coalesced as g_params.
+ * floats (g_params, g_y): 4*(2P + 3d + 1) algorithmic bytes.  Every (sample, dim) element owns its 3K(+1)
+ * parameter slots exclusively, so an element's gradients are written straight from registers.
  */
 #include "bgk_common.h"
 
@@ -57,48 +55,44 @@ __device__ __forceinline__ float pick(const float (&a)[KT], int i) {
     return v;
 }
 
+/* Streaming form (same scheme as rqs_stream_kernel, bgk_rqs.hip): elements enumerated dim-fastest, the 24 parameters
+ * of an element loaded with six 16-byte loads into registers, the 24 (+1) parameter gradients written back the same
+ * way; no LDS, no barrier -- nothing in the backward pass crosses lanes. */
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int BWD_TS = 128;
+
 template <int KT>
 __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = KT;
-    const int TS = a.TS, d = a.d, P = a.P, Pp = a.Pp;
-    float* s_par = smem;                 /* [TS][Pp] params in, g_params out */
-    float* s_y = s_par + TS * Pp;        /* [TS][d]  y in, g_y out */
-    float* s_go = s_y + TS * d;          /* [TS][d]  g_out */
-    const int tid = threadIdx.x;
+    static_assert(KT == 8, "two 16-byte loads per parameter group");
+    const int d = a.d, tid = threadIdx.x;
     const BgkRqsCfg& c = a.cfg;
-    const int64_t n_tiles = (a.B + TS - 1) / TS;
+    const uint64_t magicd = (0x100000000ull + (uint64_t)d - 1) / (uint64_t)d;
+    const int64_t n_tiles = (a.B + BWD_TS - 1) / BWD_TS;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t b0 = tile * TS;
-        const int rows = (int)((a.B - b0) < TS ? (a.B - b0) : TS);
-        for (int i = tid; i < rows * P; i += BWD_THREADS) {
-            uint32_t r = __umulhi((uint32_t)i, a.magicP);
-            uint32_t cc = i - r * P;
-            s_par[r * Pp + cc] = a.params[(b0 + r) * a.ldp + cc];
-        }
-        for (int i = tid; i < rows * d; i += BWD_THREADS) {
-            int r = i / d, j = i - r * d;
-            s_y[i] = a.y[(b0 + r) * a.ldy + j];
-            s_go[i] = a.g_out[(b0 + r) * a.ldgo + j];
-        }
-        __syncthreads();
-        for (int e = tid; e < TS * d; e += BWD_THREADS) {
-            const int j = e / TS, s = e - j * TS;
-            if (s >= rows) continue;
-            float* row = s_par + s * Pp;
-            float* uw = row + j * K;
-            float* uh = row + d * K + j * K;
-            float* us = row + 2 * d * K + j * K;
-            const int slot = a.nc_slot[j];
-            float* last = slot >= 0 ? row + 3 * d * K + slot : us;   /* slope at knot K */
-            float rw[K], rh[K], rs[K];
+        const int64_t b0 = tile * BWD_TS;
+        const int rows = (int)((a.B - b0) < BWD_TS ? (a.B - b0) : BWD_TS);
+        for (int e = tid; e < rows * d; e += BWD_THREADS) {
+            const int s = (int)(((uint64_t)(uint32_t)e * magicd) >> 32), j = e - s * d;
+            const float* row = a.params + (b0 + s) * a.ldp;
+            float* grow = a.g_params + (b0 + s) * a.ldgp;
+            const float* gw = row + j * K;
+            const float* gh = gw + d * K;
+            const float* gs = gh + d * K;
+            float rw[K], rh[K], rs[K], ow[K], oh[K], os[K];
+            {
+                const f4u w0 = *reinterpret_cast<const f4u*>(gw), w1 = *reinterpret_cast<const f4u*>(gw + 4);
+                const f4u h0 = *reinterpret_cast<const f4u*>(gh), h1 = *reinterpret_cast<const f4u*>(gh + 4);
+                const f4u t0 = *reinterpret_cast<const f4u*>(gs), t1 = *reinterpret_cast<const f4u*>(gs + 4);
 #pragma unroll
-            for (int k = 0; k < K; ++k) { rw[k] = uw[k]; rh[k] = uh[k]; rs[k] = us[k]; }
-            const float s_K = *last;
+                for (int k = 0; k < 4; ++k) { rw[k] = w0[k]; rw[4 + k] = w1[k]; rh[k] = h0[k]; rh[4 + k] = h1[k]; rs[k] = t0[k]; rs[4 + k] = t1[k]; }
+            }
+            const int slot = a.nc_slot[j];
+            const float s_K = slot >= 0 ? row[3 * d * K + slot] : rs[0];   /* slope at knot K */
             float pw[K], ph[K], cw[K + 1], ch[K + 1];
             softmax_knots<K>(rw, c.min_w, c.w_scale, c.xspan, c.left, c.right, pw, cw);
             softmax_knots<K>(rh, c.min_h, c.h_scale, c.yspan, c.bottom, c.top, ph, ch);
-            float x = s_y[s * d + j];
+            float x = a.y[(b0 + s) * a.ldy + j];
             const bool clamped = (x < c.left) | (x > c.right);
             x = x < c.left ? c.left : (x > c.right ? c.right : x);
             int idx = -1;
@@ -145,7 +139,7 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
             const float lf_de = 2.0f / delta + 2.0f * t / M - 2.0f * (1.0f - 2.0f * t) / den;
             const float lf_d0 = omt * omt / M - 2.0f * t / den;
             const float lf_d1 = theta * theta / M - 2.0f * t / den;
-            const float gy = s_go[s * d + j], gl = a.g_dlogp[b0 + s];
+            const float gy = a.g_out[(b0 + s) * a.ldgo + j], gl = a.g_dlogp[b0 + s];
             float G_de, G_d0, G_d1, G_H, G_W, G_cw, G_ch, gx;
             if (a.inverse) {
                 const float G_th = gy * H_i * Q_th + gl * lf_th;
@@ -171,14 +165,14 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
             }
             const bool dead = (gy == 0.0f) & (gl == 0.0f);   /* masked-out sample: exact zeros, never 0 * inf */
             if (dead) { G_de = G_d0 = G_d1 = G_H = G_W = G_cw = G_ch = gx = 0.0f; }
-            s_y[s * d + j] = clamped ? 0.0f : gx;
+            a.g_y[(b0 + s) * a.ldgy + j] = clamped ? 0.0f : gx;
             {
                 const float gA = (idx >= 1) ? (G_cw - G_W) : 0.0f, gB = (idx + 1 <= K - 1) ? G_W : 0.0f;
                 float gp[K], dot = 0.0f;
 #pragma unroll
                 for (int m = 0; m < K; ++m) { gp[m] = c.w_scale * c.xspan * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f)); dot += pw[m] * gp[m]; }
 #pragma unroll
-                for (int m = 0; m < K; ++m) uw[m] = pw[m] * (gp[m] - dot);
+                for (int m = 0; m < K; ++m) ow[m] = pw[m] * (gp[m] - dot);
             }
             {
                 const float gA = (idx >= 1) ? (G_ch - G_H) : 0.0f, gB = (idx + 1 <= K - 1) ? G_H : 0.0f;
@@ -186,35 +180,32 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
 #pragma unroll
                 for (int m = 0; m < K; ++m) { gp[m] = c.h_scale * c.yspan * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f)); dot += ph[m] * gp[m]; }
 #pragma unroll
-                for (int m = 0; m < K; ++m) uh[m] = ph[m] * (gp[m] - dot);
+                for (int m = 0; m < K; ++m) oh[m] = ph[m] * (gp[m] - dot);
             }
             {
                 const float z0 = s_lo * c.beta, z1 = s_hi * c.beta;
                 const float sg0 = z0 > 20.0f ? 1.0f : 1.0f / (1.0f + bgk_expf(-z0));
                 const float sg1 = z1 > 20.0f ? 1.0f : 1.0f / (1.0f + bgk_expf(-z1));
                 const float g0 = G_d0 * sg0, g1 = G_d1 * sg1;
-                if (slot >= 0) *last = hi_last ? g1 : 0.0f;
+                if (slot >= 0) grow[3 * d * K + slot] = hi_last ? g1 : 0.0f;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     float g = 0.0f;
                     g += (k == idx) ? g0 : 0.0f;
                     g += (!hi_last && k == idx + 1) ? g1 : 0.0f;
                     g += (hi_last && slot < 0 && k == 0) ? g1 : 0.0f;
-                    us[k] = g;
+                    os[k] = g;
                 }
             }
+            {
+                float* qw = grow + j * K;
+                float* qh = qw + d * K;
+                float* qs = qh + d * K;
+                *reinterpret_cast<f4u*>(qw) = (f4u){ow[0], ow[1], ow[2], ow[3]}; *reinterpret_cast<f4u*>(qw + 4) = (f4u){ow[4], ow[5], ow[6], ow[7]};
+                *reinterpret_cast<f4u*>(qh) = (f4u){oh[0], oh[1], oh[2], oh[3]}; *reinterpret_cast<f4u*>(qh + 4) = (f4u){oh[4], oh[5], oh[6], oh[7]};
+                *reinterpret_cast<f4u*>(qs) = (f4u){os[0], os[1], os[2], os[3]}; *reinterpret_cast<f4u*>(qs + 4) = (f4u){os[4], os[5], os[6], os[7]};
+            }
         }
-        __syncthreads();
-        for (int i = tid; i < rows * P; i += BWD_THREADS) {
-            uint32_t r = __umulhi((uint32_t)i, a.magicP);
-            uint32_t cc = i - r * P;
-            a.g_params[(b0 + r) * a.ldgp + cc] = s_par[r * Pp + cc];
-        }
-        for (int i = tid; i < rows * d; i += BWD_THREADS) {
-            int r = i / d, j = i - r * d;
-            a.g_y[(b0 + r) * a.ldgy + j] = s_y[i];
-        }
-        __syncthreads();
     }
 }
 
@@ -240,15 +231,10 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
     a.inverse = inverse; a.g_out = g_out; a.ldgo = ldgo; a.g_dlogp = g_dlogp; a.g_y = g_y; a.ldgy = ldgy;
     a.g_params = g_params; a.ldgp = ldgp;
     a.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, K);
-    a.Pp = P | 1;
-    a.magicP = (uint32_t)((0x100000000ull + (uint64_t)P - 1) / (uint64_t)P);
-    int TS = (int)((52 * 1024) / (sizeof(float) * (size_t)(a.Pp + 2 * d)));
-    TS = TS > 64 ? 64 : TS;
-    BGK_CHECK_ARG(TS >= 1, "bgk_rqs_backward: parameter row too wide for the LDS tile");
-    a.TS = TS;
-    size_t shmem = sizeof(float) * (size_t)TS * (size_t)(a.Pp + 2 * d);
-    int64_t n_tiles = (B + TS - 1) / TS;
-    int grid = (int)(n_tiles < 256 * 12 ? n_tiles : 256 * 12);
+    a.Pp = P | 1; a.TS = BWD_TS; a.magicP = 0;
+    int64_t n_tiles = (B + BWD_TS - 1) / BWD_TS;
+    int grid = (int)(n_tiles < 256 * 16 ? n_tiles : 256 * 16);
+    const size_t shmem = 0;
     hipLaunchKernelGGL(rqs_bwd_kernel<8>, dim3(grid), dim3(BWD_THREADS), shmem, (hipStream_t)stream, a);
     return bgk_launch_status("bgk_rqs_backward");
 }
