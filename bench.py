@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3")
-    ap.add_argument("--gemm", default=None, choices=["f32", "f16x2"],
+    ap.add_argument("--gemm", default=None, choices=["f32", "f16x2", "bf16"],
                     help="conditioner GEMM mode of the fused coupling kernel (default: bgflow_amd.dense.GEMM_MODE)")
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU per step")
     ap.add_argument("--cpu-samples", type=int, default=1 << 17)
@@ -176,6 +176,23 @@ def main():
                      note="same flow, conditioner GEMMs on the f32-input MFMA (exact fma chain, bit-identical to the oracle)")
         _dense.GEMM_MODE = gemm_mode
         timed_steps(gen, zs, 1)   # re-pack for the headline mode (KL bench below uses the generic path)
+        torch.cuda.synchronize(dev)
+
+    # ---- extra (cfg 5 is specified "fp32 vs bf16"): the same flow with bf16 weights / GEMM inputs in the spline layers
+    bf16_leg = None
+    if args.workload == "cfg5" and gemm_mode != "bf16" and rank == 0 and world == 1 and not args.no_extras:
+        _dense.GEMM_MODE = "bf16"
+        timed_steps(gen, zs, 2)
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter()
+        timed_steps(gen, zs, 5)
+        torch.cuda.synchronize(dev)
+        tb = (time.perf_counter() - tb) / 5
+        bf16_leg = dict(gemm="bf16", value=args.batch / tb, unit="samples/s", ms_per_step=1e3 * tb, steps=5,
+                        note="REDUCED PRECISION leg: bf16 weights + GEMM inputs in the 10 spline layers (f32 accumulate; knots, bin "
+                             "search, log-det f32); the 6 affine layers stay split-f16")
+        _dense.GEMM_MODE = gemm_mode
+        timed_steps(gen, zs, 1)
         torch.cuda.synchronize(dev)
 
     # ---- extra: BASELINE.json configs[1] (8 affine coupling blocks, dim 64, batch 2^20) on the same GPU
@@ -247,7 +264,7 @@ def main():
         flops_per_launch = 2.0 * sum(layer_macs(gen.flow[i]) for i in coupling) / n_launch * args.batch
         alg_bytes_step = ALG_BYTES[args.workload] * args.batch
         if args.workload in ("cfg3", "cfg5"):
-            split = gemm_mode == "f16x2"
+            split = gemm_mode in ("f16x2", "bf16")
             roof = dict(bound="mfma", achieved=flops_per_launch / avg_launch_s / 1e12, peak=MFMA_F32_PEAK_TFLOPS,
                         unit="TFLOP/s", traffic=measured_traffic("coupling_rqs_dense_h2_kernel" if split else "coupling_rqs_dense_kernel"),
                         kernel=("coupling_rqs_dense_h2_kernel (fused DenseNet on the f16 matrix cores in split-f16 form + RQ-spline "
@@ -269,11 +286,14 @@ def main():
         roof["block_ms"] = [round(v, 3) for v in block_ms]
         out = dict(metric="flow samples/s (fwd+log|detJ|) at batch 2^20", value=value, unit="samples/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
-                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   scaling="weak", vs_baseline=None, dtype="bf16" if gemm_mode == "bf16" else "f32", data="synthetic",
                    config=dict(workload=desc, batch_per_gpu=args.batch, global_batch=args.batch * world,
                                parallelism=f"dp{world}",
-                               conditioner_gemm=("split-f16: f32 operands as hi+lo f16 pairs, 3 MFMAs per product, f32 accumulate "
-                                                 "(f32-class accuracy)" if gemm_mode == "f16x2" else "f32-input MFMA (exact)")),
+                               conditioner_gemm={"f16x2": "split-f16: f32 operands as hi+lo f16 pairs, 3 MFMAs per product, f32 accumulate "
+                                                          "(f32-class accuracy)",
+                                                 "f32": "f32-input MFMA (exact)",
+                                                 "bf16": "REDUCED PRECISION: bf16 weights and GEMM inputs (spline layers), f32 accumulate; "
+                                                         "spline / log-det arithmetic f32"}[gemm_mode]),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_samples)
@@ -281,6 +301,8 @@ def main():
             out["exact_f32_mode"] = exact
         if cfg2 is not None:
             out["cfg2"] = cfg2
+        if bf16_leg is not None:
+            out["bf16_mode"] = bf16_leg
         if kl is not None:
             out["kl"] = kl
         print(json.dumps(out))

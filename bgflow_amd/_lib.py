@@ -40,11 +40,11 @@ _SIGNATURES = {
                                               vp, i64, i64, i32, i32, ctypes.c_uint64, i32,
                                               f64, f64, f64, f64, f64, f64, f64, i32,
                                               vp, i64, vp, i32, vp, vp, vp]),
-    "bgk_coupling_rqs_dense_h2": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, vp, i32, i32, i32,
+    "bgk_coupling_rqs_dense_h2": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, vp, i32, i32, i32, i32,
                                                  vp, i64, i64, i32, i32, ctypes.c_uint64, i32,
                                                  f64, f64, f64, f64, f64, f64, f64, i32,
                                                  vp, i64, vp, i32, vp, vp, vp]),
-    "bgk_pack_dense_h2": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "bgk_pack_dense_h2": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "bgk_coupling_rqs_dense_h2_train": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, vp, i32, i32, i32,
                                                        vp, i64, i64, i32, i32, ctypes.c_uint64, i32,
                                                        f64, f64, f64, f64, f64, f64, f64, i32,

@@ -598,12 +598,22 @@ constexpr int H2_BLOCKS = (H2_STEPS * 4 * 2 + 4);      /* 1 KiB blocks per 128-r
 
 struct AFrag { uint4 v[4][2]; };     /* one k16-step: 4 output tiles x {hi, lo} */
 struct BFrag { h16x8 hi[H2_STEPS], lo[H2_STEPS]; };   /* a 128-wide activation vector as B operands: 64 VGPRs */
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+/* BF = true: single-bf16 operands (gemm_mode "bf16": bf16 parameter storage + bf16 GEMM inputs, f32 accumulate --
+ * the reduced-precision variant of BASELINE config 5); same operand layout, only the hi blocks are read and hold
+ * bf16 instead of f16, one v_mfma_f32_32x32x16_bf16 per product. */
+__device__ __forceinline__ uint16_t bf16_rne(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <bool BF>
 __device__ __forceinline__ void h2_load(AFrag& f, const uint4* W, int s, int lane) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         f.v[m][0] = W[((s * 4 + m) * 2 + 0) * 64 + lane];
-        f.v[m][1] = W[((s * 4 + m) * 2 + 1) * 64 + lane];
+        if constexpr (!BF) f.v[m][1] = W[((s * 4 + m) * 2 + 1) * 64 + lane];
     }
 }
 __device__ __forceinline__ void h2_load_bias(AFrag& f, const uint4* W, int lane) {
@@ -611,35 +621,51 @@ __device__ __forceinline__ void h2_load_bias(AFrag& f, const uint4* W, int lane)
     for (int m = 0; m < 4; ++m) f.v[m][0] = W[(H2_STEPS * 8 + m) * 64 + lane];
 }
 
+template <bool BF>
 __device__ __forceinline__ void h2_split(const float (&v)[8], h16x8& hi, h16x8& lo) {
+    if constexpr (BF) {
+        s16x8 t;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float c = __builtin_amdgcn_fmed3f(v[e], -65000.0f, 65000.0f);
-        const _Float16 h = (_Float16)c;
-        hi[e] = h;
-        lo[e] = (_Float16)(c - (float)h);
+        for (int e = 0; e < 8; ++e) t[e] = (short)bf16_rne(v[e]);
+        hi = __builtin_bit_cast(h16x8, t);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = __builtin_amdgcn_fmed3f(v[e], -65000.0f, 65000.0f);
+            const _Float16 h = (_Float16)c;
+            hi[e] = h;
+            lo[e] = (_Float16)(c - (float)h);
+        }
     }
 }
 
 /* activated f32 tiles (accumulator layout) -> B operands of the 8 k16-steps; done ONCE per layer input */
+template <bool BF>
 __device__ __forceinline__ void h2_make_b(BFrag& b, const f32x16 (&in)[4]) {
 #pragma unroll
     for (int s = 0; s < H2_STEPS; ++s) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = in[s >> 1][8 * (s & 1) + e];
-        h2_split(v, b.hi[s], b.lo[s]);
+        h2_split<BF>(v, b.hi[s], b.lo[s]);
     }
 }
 
+template <bool BF>
 __device__ __forceinline__ void h2_mfma(f32x16 (&out)[4], const AFrag& a, const h16x8& bhi, const h16x8& blo) {
-    /* small terms first; tiles interleaved so that consecutive MFMAs are independent */
+    if constexpr (BF) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][1]), bhi, out[m], 0, 0, 0);
+        for (int m = 0; m < 4; ++m)
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a.v[m][0]), __builtin_bit_cast(s16x8, bhi), out[m], 0, 0, 0);
+    } else {
+        /* small terms first; tiles interleaved so that consecutive MFMAs are independent */
 #pragma unroll
-    for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), blo, out[m], 0, 0, 0);
+        for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][1]), bhi, out[m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), bhi, out[m], 0, 0, 0);
+        for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), blo, out[m], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), bhi, out[m], 0, 0, 0);
+    }
 }
 
 /* A-operand ring of one 128-row GEMM: the first H2_RING - 1 steps are requested by h2_gemm_start (possibly long before the
@@ -648,26 +674,35 @@ __device__ __forceinline__ void h2_mfma(f32x16 (&out)[4], const AFrag& a, const 
 constexpr int H2_RING = 2;
 struct H2Ring { AFrag f[H2_RING]; };
 
+template <bool BF>
 __device__ __forceinline__ void h2_gemm_start(H2Ring& r, const uint4* W, int lane) {
 #pragma unroll
-    for (int s = 0; s < H2_RING - 1; ++s) h2_load(r.f[s], W, s, lane);
+    for (int s = 0; s < H2_RING - 1; ++s) h2_load<BF>(r.f[s], W, s, lane);
     __builtin_amdgcn_sched_barrier(0);
 }
 
 /* out[0..4) += W' * b + b'   (ring already started) */
+template <bool BF>
 __device__ __forceinline__ void h2_gemm_run(f32x16 (&out)[4], H2Ring& r, const BFrag& b, const uint4* W, int lane) {
 #pragma unroll
     for (int s = 0; s < H2_STEPS; ++s) {
         constexpr int D = H2_RING - 1;
-        if (s + D < H2_STEPS) h2_load(r.f[(s + D) % H2_RING], W, s + D, lane);
+        if (s + D < H2_STEPS) h2_load<BF>(r.f[(s + D) % H2_RING], W, s + D, lane);
         else if (s + D == H2_STEPS) h2_load_bias(r.f[(s + D) % H2_RING], W, lane);
         __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch above this step's MFMAs */
-        h2_mfma(out, r.f[s % H2_RING], b.hi[s], b.lo[s]);
+        h2_mfma<BF>(out, r.f[s % H2_RING], b.hi[s], b.lo[s]);
     }
-    const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+    if constexpr (BF) {
+        const s16x8 one2 = {(short)0x3f80, (short)0x3f80, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-        out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, r.f[H2_STEPS % H2_RING].v[m][0]), one2, out[m], 0, 0, 0);
+        for (int m = 0; m < 4; ++m)
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, r.f[H2_STEPS % H2_RING].v[m][0]), one2, out[m], 0, 0, 0);
+    } else {
+        const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, r.f[H2_STEPS % H2_RING].v[m][0]), one2, out[m], 0, 0, 0);
+    }
 }
 
 /* activation of x = t * c (c = exact power-of-two unscale) */
@@ -692,7 +727,7 @@ __device__ __forceinline__ void h2_store_z(const f32x16 (&t)[4], float* z, int64
     }
 }
 
-template <int ACT, int INV, bool SAVE>
+template <int ACT, int INV, bool SAVE, bool BF>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(FusedArgsH2 ah) {
     const FusedArgs& a = ah.f;
     if (ah.cs_dev) { ah.c0 = ah.cs_dev[1]; ah.c1 = ah.cs_dev[3]; ah.c2 = ah.cs_dev[5]; }   /* wave-uniform scalar loads */
@@ -740,16 +775,16 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
         zero4(h);
         for (int s = 0; s < ah.S0; ++s) {
             AFrag fr;
-            h2_load(fr, ah.A0, s, lane);
+            h2_load<BF>(fr, ah.A0, s, lane);
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = s_p[(16 * s + 8 * hh + e) * SROW + j];
             h16x8 bhi, blo;
-            h2_split(v, bhi, blo);
-            h2_mfma(h, fr, bhi, blo);
+            h2_split<BF>(v, bhi, blo);
+            h2_mfma<BF>(h, fr, bhi, blo);
         }
         H2Ring ring;
-        h2_gemm_start(ring, ah.A1, lane);          /* layer-1 operands in flight during the activation */
+        h2_gemm_start<BF>(ring, ah.A1, lane);          /* layer-1 operands in flight during the activation */
         if constexpr (SAVE) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -765,10 +800,10 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
 
         /* ---- layer 1 ---- */
         BFrag bf;
-        h2_make_b(bf, h);
+        h2_make_b<BF>(bf, h);
         zero4(acc);
-        h2_gemm_run(acc, ring, bf, ah.A1, lane);
-        h2_gemm_start(ring, ah.A2, lane);
+        h2_gemm_run<BF>(acc, ring, bf, ah.A1, lane);
+        h2_gemm_start<BF>(ring, ah.A2, lane);
         if constexpr (SAVE) {
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -781,14 +816,14 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
 #pragma unroll
             for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(acc[m], ah.c1);
         }
-        h2_make_b(bf, acc);                         /* the layer-2 B operands, shared by all chunks */
+        h2_make_b<BF>(bf, acc);                         /* the layer-2 B operands, shared by all chunks */
 
         /* ---- layer 2 in chunks of 128 packed columns + spline:
          *   GEMM(0);  for c: { h -> LDS;  request A(c+1);  spline(c);  GEMM(c+1) } ---- */
         float run = 0.0f;
         int oob_local = 0;
         zero4(h);
-        h2_gemm_run(h, ring, bf, ah.A2, lane);
+        h2_gemm_run<BF>(h, ring, bf, ah.A2, lane);
         for (int c = 0; c < a.n_chunks; ++c) {
 #if !(BGK_ABL & 8)
 #pragma unroll
@@ -813,7 +848,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
             const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
             const uint4* Wn = ah.A2 + (size_t)(c + 1) * H2_BLOCKS * 64;
             const bool more = c + 1 < a.n_chunks;
-            if (more) h2_gemm_start(ring, Wn, lane);
+            if (more) h2_gemm_start<BF>(ring, Wn, lane);
             int bins[3] = {0, 0, 0};
             NoGemm g;
 #if !(BGK_ABL & 1)
@@ -831,7 +866,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
             if (more) {
 #if !(BGK_ABL & 2)
                 zero4(h);
-                h2_gemm_run(h, ring, bf, Wn, lane);
+                h2_gemm_run<BF>(h, ring, bf, Wn, lane);
 #else
                 h[0][0] += ring.f[0].v[0][0].x;
 #endif
@@ -929,7 +964,7 @@ extern "C" int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_
 namespace {
 int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
               const void* A0p, const void* A1p, const void* A2p, float c0, float c1, float c2, const float* cs_dev,
-              int32_t H0, int32_t H1, int32_t act, const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
+              int32_t operand_dtype, int32_t H0, int32_t H1, int32_t act, const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
               uint64_t circ_mask, int32_t inverse, double left, double right, double bottom, double top,
               double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
               float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
@@ -970,8 +1005,11 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
     int grid = (int)n_wg;
     hipStream_t st = (hipStream_t)stream;
-#define BGK_LAUNCH(A, I, S) hipLaunchKernelGGL((coupling_rqs_dense_h2_kernel<A, I, S>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
-#define BGK_LAUNCH2(A, I) do { if (save) BGK_LAUNCH(A, I, true); else BGK_LAUNCH(A, I, false); } while (0)
+    BGK_CHECK_ARG(operand_dtype == 0 || (operand_dtype == 1 && !save), "%s: operand_dtype %d (0 = split-f16, 1 = bf16; the training "
+                  "forward is split-f16 only)", what, operand_dtype);
+#define BGK_LAUNCH(A, I, S, F) hipLaunchKernelGGL((coupling_rqs_dense_h2_kernel<A, I, S, F>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
+#define BGK_LAUNCH2(A, I) do { if (save) BGK_LAUNCH(A, I, true, false); else if (operand_dtype == 1) BGK_LAUNCH(A, I, false, true); \
+                               else BGK_LAUNCH(A, I, false, false); } while (0)
     if (act == 1) { if (inverse) BGK_LAUNCH2(1, 1); else BGK_LAUNCH2(1, 0); }
     else if (act == 2) { if (inverse) BGK_LAUNCH2(2, 1); else BGK_LAUNCH2(2, 0); }
     else { if (inverse) BGK_LAUNCH2(3, 1); else BGK_LAUNCH2(3, 0); }
@@ -983,7 +1021,7 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
 
 extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                          const void* A0p, const void* A1p, const void* A2p,
-                                         float c0, float c1, float c2, const float* cs_dev,
+                                         float c0, float c1, float c2, const float* cs_dev, int32_t operand_dtype,
                                          int32_t H0, int32_t H1, int32_t act, const float* y,
                                          int64_t ldy, int64_t B, int32_t d, int32_t K, uint64_t circ_mask,
                                          int32_t inverse,
@@ -992,7 +1030,7 @@ extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t
                                          double min_derivative, int32_t identity_init, float* out,
                                          int64_t ldo, float* dlogp, int32_t accumulate,
                                          int32_t* bin_idx, int32_t* oob_count, void* stream) {
-    return launch_h2("bgk_coupling_rqs_dense_h2", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, H0, H1, act, y, ldy, B, d, K,
+    return launch_h2("bgk_coupling_rqs_dense_h2", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, operand_dtype, H0, H1, act, y, ldy, B, d, K,
                      circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
                      identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count,
                      nullptr, nullptr, nullptr, 0, nullptr, stream);
@@ -1013,7 +1051,7 @@ extern "C" int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, i
     BGK_CHECK_ARG(z0 && z1 && params && src_col_dev, "bgk_coupling_rqs_dense_h2_train: null save buffer");
     const int n_nc = d - __builtin_popcountll(circ_mask & (d >= 64 ? ~0ull : ((1ull << d) - 1)));
     BGK_CHECK_ARG(ldp >= 3 * K * d + n_nc, "bgk_coupling_rqs_dense_h2_train: params row stride %lld too small", (long long)ldp);
-    return launch_h2("bgk_coupling_rqs_dense_h2_train", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, H0, H1, act, y, ldy, B, d,
+    return launch_h2("bgk_coupling_rqs_dense_h2_train", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, 0, H0, H1, act, y, ldy, B, d,
                      K, circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
                      identity_init, out, ldo, dlogp, accumulate, nullptr, oob_count, z0, z1, params, ldp, src_col_dev, stream);
 }

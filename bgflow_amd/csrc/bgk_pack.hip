@@ -10,6 +10,22 @@
 
 namespace {
 
+__device__ __forceinline__ uint16_t pk_bf16_rne(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float pk_bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+/* 16-bit pattern of part p (0 hi, 1 lo) of v in the layer's operand type */
+__device__ __forceinline__ uint16_t pk_part(float v, int p, int bf16) {
+    if (bf16) {
+        const uint16_t h = pk_bf16_rne(v);
+        return p ? pk_bf16_rne(v - pk_bf16_to_f32(h)) : h;
+    }
+    const _Float16 h = (_Float16)v;
+    const _Float16 r = p ? (_Float16)(v - (float)h) : h;
+    return __builtin_bit_cast(uint16_t, r);
+}
+
 struct PackLayer {
     const float* W; const float* b;   /* source Linear: weight [rows, K] row-major, bias [rows] */
     int rows, K;
@@ -17,6 +33,7 @@ struct PackLayer {
     int n_groups;                     /* independent 32*NT-row groups (layer-2 chunks), each followed by its bias blocks */
     int NT, S, natural;               /* natural = 1: k = 16 s + 8 kb + e with the bias as column K; 0: accumulator order */
     _Float16* out;
+    int bf16;                         /* 1: hi = rne_bf16(v) (no scaling), lo = rne_bf16(v - hi) [lo is read for the bias blocks only] */
 };
 
 __global__ __launch_bounds__(256) void pack_scale_kernel(PackLayer L0, PackLayer L1, PackLayer L2, float* cs) {
@@ -35,7 +52,7 @@ __global__ __launch_bounds__(256) void pack_scale_kernel(PackLayer L0, PackLayer
     if (threadIdx.x == 0) {
         m = red[0];
         int e = 0;
-        if (m > 0.0f && m < 3.0e38f) {
+        if (!L.bf16 && m > 0.0f && m < 3.0e38f) {
             e = (int)floorf(log2f(32768.0f / m));
             e = e < -16 ? -16 : (e > 24 ? 24 : e);
         }
@@ -54,7 +71,7 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(PackLayer L, const flo
     const int grp = (int)((t >> 6) / blocks_per_group);
     const int i = lane & 31, kb = lane >> 5;
     const float scale = cs[2 * layer];
-    _Float16 o[8];
+    uint16_t o[8];
     if (blk < L.S * L.NT * 2) {
         const int p = blk & 1, m = (blk >> 1) % L.NT, s = (blk >> 1) / L.NT;
         const int prow = grp * 32 * L.NT + 32 * m + i;
@@ -67,22 +84,19 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(PackLayer L, const flo
                 if (k < L.K) v = L.W[(int64_t)srow * L.K + k];
                 else if (L.natural && k == L.K) v = L.b[srow];
             }
-            v *= scale;
-            const _Float16 h = (_Float16)v;
-            o[e] = p ? (_Float16)(v - (float)h) : h;
+            o[e] = pk_part(v * scale, p, L.bf16);
         }
     } else {
         const int m = blk - L.S * L.NT * 2;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.0f;
+        for (int e = 0; e < 8; ++e) o[e] = 0;
         if (kb == 0) {
             const int prow = grp * 32 * L.NT + 32 * m + i;
             const int srow = L.row_map ? L.row_map[prow] : (prow < L.rows ? prow : -1);
             if (srow >= 0) {
                 const float v = L.b[srow] * scale;
-                const _Float16 h = (_Float16)v;
-                o[0] = h;
-                o[1] = (_Float16)(v - (float)h);
+                o[0] = pk_part(v, 0, L.bf16);
+                o[1] = pk_part(v, 1, L.bf16);
             }
         }
     }
@@ -101,16 +115,17 @@ void launch_pack(const PackLayer& L, const float* cs, int layer, hipStream_t st)
 extern "C" int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
                                  const float* W1, const float* b1,
                                  const float* W2, const float* b2, int32_t rows2,
-                                 const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2,
+                                 const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2, int32_t operand_dtype,
                                  void* A0, void* A1, void* A2, float* cs, void* stream) {
     BGK_CHECK_ARG(W0 && b0 && W1 && b1 && W2 && b2 && A0 && A1 && A2 && cs, "bgk_pack_dense_h2: null pointer");
     BGK_CHECK_ARG(n_in > 0 && (H == 32 || H == 64 || H == 96 || H == 128) && rows2 > 0 && n_groups2 > 0 && NT2 > 0 && NT2 <= 4,
                   "bgk_pack_dense_h2: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int HT = H / 32;
-    PackLayer L0{W0, b0, H, n_in, nullptr, 1, HT, (n_in + 1 + 15) / 16, 1, (_Float16*)A0};
-    PackLayer L1{W1, b1, H, H, nullptr, 1, HT, 2 * HT, 0, (_Float16*)A1};
-    PackLayer L2{W2, b2, rows2, H, row_map2_dev, n_groups2, NT2, 2 * HT, 0, (_Float16*)A2};
+    BGK_CHECK_ARG(operand_dtype == 0 || operand_dtype == 1, "bgk_pack_dense_h2: operand_dtype %d (0 = split-f16, 1 = bf16)", operand_dtype);
+    PackLayer L0{W0, b0, H, n_in, nullptr, 1, HT, (n_in + 1 + 15) / 16, 1, (_Float16*)A0, operand_dtype};
+    PackLayer L1{W1, b1, H, H, nullptr, 1, HT, 2 * HT, 0, (_Float16*)A1, operand_dtype};
+    PackLayer L2{W2, b2, rows2, H, row_map2_dev, n_groups2, NT2, 2 * HT, 0, (_Float16*)A2, operand_dtype};
     hipLaunchKernelGGL(pack_scale_kernel, dim3(3), dim3(256), 0, st, L0, L1, L2, cs);
     launch_pack(L0, cs, 0, st);
     launch_pack(L1, cs, 1, st);

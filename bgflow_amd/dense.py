@@ -218,6 +218,8 @@ def pack_dense_for_fused(linears, nc_slot_host, d, n_bins):
 # module default of the fused kernel's conditioner GEMMs; a transformer's `gemm_mode` attribute overrides it:
 #   "f16x2": split-f16 on the f16 matrix cores (f32-class accuracy, see bgk_fused.hip; ~1.75x the layer throughput)
 #   "f32":   f32-input MFMA = exact k-ordered fma chain, bit-identical to the CPU oracle
+#   "bf16":  single-bf16 weights and GEMM inputs, f32 accumulate (reduced precision: the "bf16" leg of BASELINE config 5;
+#            spline layers only -- affine layers and training run split-f16)
 GEMM_MODE = "f16x2"
 
 
@@ -341,8 +343,8 @@ def _affine_plan(transformer, y_dim):
 def fused_affine_coupling(transformer, x, y, inverse):
     """Try the one-launch affine coupling layer (bgk_coupling_affine_dense_h2).  Returns (y', dlogp) or None when
     the conditioners are not fusable DenseNets (the caller then runs the nets + bgk_affine_transform)."""
-    if _gemm_mode(transformer) != "f16x2":
-        return None            # there is no exact-f32 fused affine kernel: "f32" selects the generic path
+    if _gemm_mode(transformer) == "f32":
+        return None            # there is no exact-f32 fused affine kernel: "f32" selects the generic path ("bf16": split-f16)
     if x.dim() != 2 or y.dim() != 2 or not x.is_cuda or x.dtype != torch.float32:
         return None
     plan = _affine_plan(transformer, y.shape[-1])
@@ -405,7 +407,7 @@ def pack_dense_for_fused_h2(linears, nc_slot_host, d, n_bins):
 DEVICE_PACK = True     # pack split-f16 operands with bgk_pack_dense_h2 (no host sync); False: the torch reference packer
 
 
-def pack_dense_for_fused_h2_device(linears, src_col_dev, n_chunks, bufs=None):
+def pack_dense_for_fused_h2_device(linears, src_col_dev, n_chunks, bufs=None, bf16=False):
     """Device-side twin of pack_dense_for_fused_h2 (bgk_pack_dense_h2): returns (A0, A1, A2, cs) with cs the
     device scale table {2^s, 2^-s} x 3.  ``bufs`` = previous result to overwrite in place."""
     l0, l1, l2 = linears
@@ -424,7 +426,7 @@ def pack_dense_for_fused_h2_device(linears, src_col_dev, n_chunks, bufs=None):
     with torch.cuda.device(dev):
         st = _lib.lib().bgk_pack_dense_h2(
             _lib.ptr(ws[0]), _lib.ptr(ws[1]), n_in, 128, _lib.ptr(ws[2]), _lib.ptr(ws[3]), _lib.ptr(ws[4]), _lib.ptr(ws[5]),
-            l2.out_features, _lib.ptr(src_col_dev), n_chunks, 4, _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), _lib.ptr(cs),
+            l2.out_features, _lib.ptr(src_col_dev), n_chunks, 4, int(bf16), _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), _lib.ptr(cs),
             _lib.stream_ptr(dev))
     _lib.check(st, "bgk_pack_dense_h2")
     return A0, A1, A2, cs
@@ -440,8 +442,8 @@ def _src_col_table(d, n_bins, nc_slot_host, device):
 
 def _gemm_mode(transformer):
     mode = getattr(transformer, "gemm_mode", None) or GEMM_MODE
-    if mode not in ("f32", "f16x2"):
-        raise ValueError(f"unknown gemm_mode {mode!r} (expected 'f32' or 'f16x2')")
+    if mode not in ("f32", "f16x2", "bf16"):
+        raise ValueError(f"unknown gemm_mode {mode!r} (expected 'f32', 'f16x2' or 'bf16')")
     return mode
 
 
@@ -484,11 +486,14 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     if stale:
         common = dict(version=version, y_dim=y_dim, mode=mode, device=dev, act=act, periodic=periodic, d_c=d_c, n_bins=n_bins,
                       circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
-        if mode == "f16x2" and DEVICE_PACK and dev.type == "cuda":
+        if mode == "bf16" and dev.type != "cuda":
+            return None
+        if mode == "bf16" or (mode == "f16x2" and DEVICE_PACK and dev.type == "cuda"):
             if "src_col_dev" not in cache:
                 cache["src_col_dev"] = _src_col_table(y_dim, n_bins, nc_slot_host, dev)
             n_chunks = cache["src_col_dev"].numel() // 128
-            A0, A1, A2, cs = pack_dense_for_fused_h2_device((l0, l1, l2), cache["src_col_dev"], n_chunks, cache.get("bufs"))
+            A0, A1, A2, cs = pack_dense_for_fused_h2_device((l0, l1, l2), cache["src_col_dev"], n_chunks, cache.get("bufs"),
+                                                            bf16=(mode == "bf16"))
             cache.update(common, bufs=(A0, A1, A2, cs), packed=(A0, A1, A2, (1.0, 1.0, 1.0)), cs=cs)
         else:
             pack = pack_dense_for_fused if mode == "f32" else pack_dense_for_fused_h2
@@ -529,7 +534,7 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
             c0, c1, c2 = plan["packed"][3]
             st = _lib.lib().bgk_coupling_rqs_dense_h2(
                 _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p),
-                c0, c1, c2, _lib.ptr(plan.get("cs")), *tail)
+                c0, c1, c2, _lib.ptr(plan.get("cs")), int(plan["mode"] == "bf16"), *tail)
     if st == -2:
         return None
     _lib.check(st, "bgk_coupling_rqs_dense")

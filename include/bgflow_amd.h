@@ -189,10 +189,12 @@ int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_c, int32_t 
  * accuracy (measured 0.47 ulp32 rms of sum|a||b| vs 0.65 for the f32 fma chain) at 16/3 times the MFMA rate;
  * not bit-identical to the f32 chain.  A0p/A1p/A2p: f16 operand blocks and c0..c2: per-layer power-of-two
  * unscale factors from bgflow_amd/dense.py::pack_dense_for_fused_h2 (layout in bgk_fused.hip / DESIGN.md); or, when the
- * operands were packed on the device by bgk_pack_dense_h2, cs_dev = its scale table (c0..c2 are then ignored). */
+ * operands were packed on the device by bgk_pack_dense_h2, cs_dev = its scale table (c0..c2 are then ignored).
+ * operand_dtype 0: split-f16 (above); 1: single bf16 operands (bf16 parameter storage + bf16 GEMM inputs, f32
+ * accumulate; knots, bin search and log-det stay f32) -- the reduced-precision variant of BASELINE config 5. */
 int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                               const void* A0p, const void* A1p, const void* A2p,
-                              float c0, float c1, float c2, const float* cs_dev,
+                              float c0, float c1, float c2, const float* cs_dev, int32_t operand_dtype,
                               int32_t H0, int32_t H1, int32_t act,
                               const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
                               uint64_t circ_mask, int32_t inverse,
@@ -247,7 +249,7 @@ int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c, in
 int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
                       const float* W1, const float* b1,
                       const float* W2, const float* b2, int32_t rows2,
-                      const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2,
+                      const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2, int32_t operand_dtype,
                       void* A0, void* A1, void* A2, float* cs, void* stream);
 
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer

@@ -853,3 +853,25 @@ def test_device_packer_equals_torch_packer(hip_lib, dev, kind):
         assert a.shape == b.shape
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))
 
+
+@pytest.mark.parametrize("kind", ["T|F", "B|A"])
+def test_fused_bf16_mode_is_consistent_and_invertible(hip_lib, dev, kind):
+    """gemm_mode='bf16' (bf16 weights + GEMM inputs, the reduced-precision leg of BASELINE config 5): close to the f32-class
+    result at bf16 resolution, and -- the conditioner being deterministic -- exactly as invertible as the f32 path"""
+    B = 4133
+    layer, ti = _layer(kind, dev)
+    xs = [t(synth(B + 7 * i, B, d, uniform=True), dev) for i, d in enumerate((17, 17, 17, 9))]
+    res = {}
+    for mode in ("f16x2", "bf16"):
+        layer.transformer.gemm_mode = mode
+        with torch.no_grad():
+            *ys, dl = layer(*xs)
+            *zs, dli = layer(*ys, inverse=True)
+        assert layer.transformer._fused_cache.get("mode") == mode
+        res[mode] = (ys[ti], dl)
+        assert float((zs[ti] - xs[ti]).abs().max()) < 2e-5
+        assert float((dl + dli).abs().max()) < 5e-4
+    dy = float((res["bf16"][0] - res["f16x2"][0]).abs().max())
+    ddl = float((res["bf16"][1] - res["f16x2"][1]).abs().max())
+    assert 0 < dy < 3e-2 and ddl < 0.5, (dy, ddl)
+
