@@ -1001,6 +1001,9 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     ah.c0 = c0; ah.c1 = c1; ah.c2 = c2; ah.cs_dev = cs_dev;
     ah.z0 = z0; ah.z1 = z1; ah.params = params; ah.ldp = ldp; ah.src_col = src_col;
     size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
+#ifdef BGK_DBG_EXTRA_LDS
+    shmem += BGK_DBG_EXTRA_LDS;   /* occupancy experiments (tools/ablate_h2.sh): e.g. 20000 -> one workgroup per CU */
+#endif
     int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
     int grid = (int)n_wg;
