@@ -11,7 +11,8 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["init_from_env", "is_distributed", "shard_size", "global_mean", "allreduce_gradients_", "rank_seed"]
+__all__ = ["init_from_env", "is_distributed", "shard_size", "global_mean", "allreduce_gradients_", "rank_seed",
+           "global_logsumexp", "global_normalized_log_weights", "global_effective_sample_size"]
 
 
 def init_from_env(backend=None):
@@ -88,3 +89,29 @@ def allreduce_gradients_(parameters):
         n = g.numel()
         g.copy_(flat[offset:offset + n].view_as(g))
         offset += n
+
+
+def global_logsumexp(x):
+    """log sum_i exp(x_i) over the samples of ALL ranks (x: local [n] or [n, 1]).  Two tiny all-reduces (MAX, then SUM of
+    the shifted exponentials) -- the importance-weight normalisation of bg.py:62-63 for a batch sharded over the GPUs."""
+    x = x.reshape(-1)
+    m = x.detach().max() if x.numel() else torch.tensor(float("-inf"), dtype=x.dtype, device=x.device)
+    if is_distributed():
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    m = torch.where(torch.isfinite(m), m, torch.zeros_like(m))
+    s = torch.exp(x - m).sum().to(torch.float64)
+    if is_distributed():
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    return m + torch.log(s).to(x.dtype)
+
+
+def global_normalized_log_weights(log_w):
+    """log w_i - logsumexp over all ranks (log_weights_given_latent(normalize=True), bg.py:54-64, for sharded batches)"""
+    return log_w.reshape(-1) - global_logsumexp(log_w)
+
+
+def global_effective_sample_size(log_w):
+    """Kish ESS (bg.py:67-69) of a weight set sharded over the ranks: exp(2 LSE(log w) - LSE(2 log w))"""
+    log_w = log_w.reshape(-1)
+    return torch.exp(2 * global_logsumexp(log_w) - global_logsumexp(2 * log_w))
+

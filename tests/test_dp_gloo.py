@@ -33,7 +33,9 @@ def _worker(rank, world, port, out):
     loss = dp.global_mean(per_sample)
     loss.backward()
     dp.allreduce_gradients_([theta])
-    out.put((rank, float(loss.detach()), theta.grad.clone(), x.clone()))
+    logw = x[:, 0] * 3.0
+    out.put((rank, float(loss.detach()), theta.grad.clone(), x.clone(),
+             float(dp.global_logsumexp(logw)), dp.global_normalized_log_weights(logw).clone(), float(dp.global_effective_sample_size(logw))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +51,7 @@ def test_global_mean_and_gradient_bucket_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, l0, g0, x0), (_, l1, g1, x1) = res
+    (_, l0, g0, x0, lse0, nw0, ess0), (_, l1, g1, x1, lse1, nw1, ess1) = res
     assert l0 == pytest.approx(l1, rel=1e-6)                      # every rank holds the GLOBAL mean
     assert not torch.equal(x0[:5], x1)                            # per-rank RNG streams differ
     theta = torch.nn.Parameter(torch.tensor([0.5, -1.0]))
@@ -58,6 +60,12 @@ def test_global_mean_and_gradient_bucket_world2():
     ref.backward()
     assert l0 == pytest.approx(float(ref.detach()), rel=1e-5)
     assert torch.allclose(g0, theta.grad, rtol=1e-5, atol=1e-6) and torch.allclose(g1, theta.grad, rtol=1e-5, atol=1e-6)
+    # importance-weight normalisation / ESS over the sharded batch == the single-process formulas of bg.py on the union
+    from bgflow_amd.bg import effective_sample_size
+    logw = torch.cat([x0[:, 0], x1[:, 0]]) * 3.0
+    assert lse0 == pytest.approx(float(torch.logsumexp(logw, 0)), rel=1e-6) and lse1 == pytest.approx(lse0, rel=1e-7)
+    assert torch.allclose(torch.cat([nw0, nw1]), logw - torch.logsumexp(logw, 0), atol=1e-6)
+    assert ess0 == pytest.approx(float(effective_sample_size(logw)), rel=1e-5) and ess1 == pytest.approx(ess0, rel=1e-7)
 
 
 def test_single_process_is_a_noop():
