@@ -14,6 +14,7 @@ from .ic import *            # noqa: F401,F403
 from .distributions import * # noqa: F401,F403
 from .cdf import *           # noqa: F401,F403
 from .bg import *            # noqa: F401,F403
-from . import configs, dp, utils      # noqa: F401
+from .factory import *       # noqa: F401,F403
+from . import configs, dp, factory, utils      # noqa: F401
 
 __version__ = "0.1.0"

@@ -283,3 +283,112 @@ def test_gemm_mode_switch_and_errors():
     with pytest.raises(ValueError):
         dense._gemm_mode(tr)
 
+
+def _builder_cfg3():
+    """the cfg-3 recipe written against the builder API exactly as a bgflow user would (generator_builder.py docstring)"""
+    from bgflow_amd import configs
+    zmat, rigid, xyz = configs.ala2_system()
+    ic = bg.MixedCoordinateTransformation(configs.ala2_whitening_data(), zmat, rigid, keepdims=9, raise_warnings=False)
+    shapes = bg.ShapeDictionary.from_coordinate_transform(ic)
+    builder = bg.BoltzmannGeneratorBuilder(shapes, target=bg.NormalDistribution(66, torch.tensor(xyz[0], dtype=torch.float32)),
+                                           dtype=torch.float32)
+    for _ in range(4):
+        builder.add_condition(bg.TORSIONS, on=bg.FIXED)
+        builder.add_condition(bg.FIXED, on=bg.TORSIONS)
+    for _ in range(4):
+        builder.add_condition(bg.BONDS, on=bg.ANGLES)
+        builder.add_condition(bg.ANGLES, on=bg.BONDS)
+    builder.add_map_to_ic_domains()
+    builder.add_map_to_cartesian(ic)
+    return builder, shapes
+
+
+def test_builder_reproduces_the_cfg3_flow():
+    from bgflow_amd import configs
+    builder, shapes = _builder_cfg3()
+    assert list(shapes.items()) == [(bg.BONDS, (17,)), (bg.ANGLES, (17,)), (bg.TORSIONS, (17,)), (bg.FIXED, (9,))]
+    assert list(builder.current_dims) == [bg.TARGET] and builder.current_dims[bg.TARGET] == (60,)
+    gen = builder.build_generator()
+    assert builder.layers == [] and list(builder.current_dims) == list(shapes)      # cleared after building
+    ref = configs.make_ala2_spline_generator()
+    a, b = gen.flow.state_dict(), ref.flow.state_dict()
+    assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
+    assert [type(x).__name__ for x in gen.flow] == [type(x).__name__ for x in ref.flow]
+    for x, y in zip(gen.flow, ref.flow):
+        if isinstance(x, bg.CouplingFlow):
+            assert (x.transformed_indices, x.cond_indices) == (y.transformed_indices, y.cond_indices)
+    assert [tuple(s) for s in gen.prior.event_shapes] == [(17,), (17,), (17,), (9,)]
+    z = gen.prior.sample(5)
+    assert [tuple(t.shape) for t in z] == [(5, 17), (5, 17), (5, 17), (5, 9)] and all((t >= 0).all() and (t <= 1).all() for t in z)
+
+
+def test_shape_dictionary_and_builder_bookkeeping():
+    s = bg.ShapeDictionary()
+    s[bg.BONDS], s[bg.ANGLES], s[bg.TORSIONS] = (21,), (20,), (19,)
+    a1, a2 = bg.TensorInfo("A1"), bg.TensorInfo("A2")
+    s.split(bg.ANGLES, (a1, a2), (8, 12))
+    assert list(s) == [bg.BONDS, a1, a2, bg.TORSIONS] and s[a2] == (12,)
+    with pytest.raises(ValueError):
+        s.split(a1, (bg.TensorInfo("x"), bg.TensorInfo("y")), (3, 3))
+    assert s.dim_all() == 60 and s.dim_circular() == 19 and s.dim_noncircular((bg.BONDS, a1)) == 29
+    assert s.circular_indices((a2, bg.TORSIONS)).tolist() == list(range(12, 31))
+    assert s.is_circular((bg.TORSIONS,)).all() and s.index(a2) == 2 and s.names((a1,)) == ["A1"]
+    s.merge((a1, a2), to=bg.ANGLES)
+    assert list(s) == [bg.BONDS, bg.ANGLES, bg.TORSIONS] and s[bg.ANGLES] == (20,)
+    r = s.replace(bg.BONDS, "B2")
+    assert r.name == "B2" and list(s)[0] == r and s.copy() == s and s.copy() is not s
+    # builder: split / merge layers, errors of add_condition, param groups
+    shapes = bg.ShapeDictionary()
+    shapes[bg.BONDS], shapes[bg.ANGLES] = (4,), (6,)
+    b = bg.BoltzmannGeneratorBuilder(shapes)
+    s1, s2 = b.add_split(bg.ANGLES, ("S1", "S2"), (2, 4))
+    assert list(b.current_dims) == [bg.BONDS, s1, s2] and not s1.is_circular
+    b.add_condition(s1, on=s2, param_groups=("g",), hidden=(16,))
+    b.add_condition(bg.BONDS, on=(s1, s2), transformer_type=bg.AffineTransformer)
+    assert len(b.param_groups["g"]) == 4
+    with pytest.raises(ValueError):
+        b.add_condition(s1, on=())
+    with pytest.raises(ValueError):
+        b.add_merge((s1, bg.TensorInfo("c", True)), to="M")
+    b.add_merge((s1, s2), to=bg.ANGLES)
+    assert list(b.current_dims) == [bg.BONDS, bg.ANGLES]
+    flow = b.build_flow()
+    names = [type(x).__name__ for x in flow]
+    assert names == ["WrapFlow", "CouplingFlow", "CouplingFlow", "WrapFlow"]
+    net = flow[1].transformer._params_net
+    assert [m.out_features for m in net._layers if hasattr(m, "out_features")] == [16, 3 * 8 * 2 + 2]
+    assert isinstance(flow[2].transformer, bg.AffineTransformer) and flow[2].cond_indices == [1, 2]
+    with pytest.raises(NotImplementedError):
+        b.add_merge_constraints()
+    prior = bg.BoltzmannGeneratorBuilder(shapes).build_prior()
+    assert [tuple(e) for e in prior.event_shapes] == [(4,), (6,)]
+
+
+def test_builder_reproduces_the_augmented_cfg5_flow():
+    """cfg 5 through the builder: AUGMENTED field, per-field transformer type, multi-field conditioning"""
+    from bgflow_amd import configs
+    zmat, rigid, xyz = configs.ala2_system()
+    ic = bg.MixedCoordinateTransformation(configs.ala2_whitening_data(), zmat, rigid, keepdims=9, raise_warnings=False)
+    shapes = bg.ShapeDictionary.from_coordinate_transform(ic, dim_augmented=66)
+    builder = bg.BoltzmannGeneratorBuilder(shapes, target=bg.NormalDistribution(66, torch.tensor(xyz[0], dtype=torch.float32)),
+                                           dtype=torch.float32)
+    assert bg.AUGMENTED in builder.targets
+    builder.transformer_type[bg.AUGMENTED] = bg.AffineTransformer
+    for _ in range(4):
+        builder.add_condition(bg.TORSIONS, on=bg.AUGMENTED)
+        builder.add_condition(bg.AUGMENTED, on=bg.TORSIONS)
+    for _ in range(2):
+        builder.add_condition(bg.BONDS, on=bg.ANGLES)
+        builder.add_condition(bg.ANGLES, on=bg.BONDS)
+    for _ in range(2):
+        builder.add_condition(bg.FIXED, on=bg.AUGMENTED)
+        builder.add_condition(bg.AUGMENTED, on=(bg.FIXED, bg.BONDS, bg.ANGLES))
+    builder.add_map_to_ic_domains()
+    builder.add_map_to_cartesian(ic)
+    assert list(builder.current_dims) == [bg.TARGET, bg.AUGMENTED]
+    gen = builder.build_generator()
+    ref = configs.make_ala2_augmented_generator()
+    a, b = gen.flow.state_dict(), ref.flow.state_dict()
+    assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
+    assert sum(p.numel() for p in gen.flow.parameters()) == 1072356      # SURVEY.md 8(d): probe of the reference builder
+
