@@ -133,4 +133,29 @@ __device__ __forceinline__ bgk_f2 bgk_tanhf2(bgk_f2 x) {
     return o;
 }
 
+/* ---- hardware-transcendental forms for HIDDEN activations of the split-f16 / bf16 kernels only ----------------------
+ * v_exp_f32 / v_rcp_f32 (1 ulp each) instead of the reproducible polynomial + exactly rounded division: relative error
+ * <= ~|x| 2^-24 + 2^-22, i.e. below the 22-24 bit operand representation the activation is converted to right afterwards.
+ * Not used for anything that reaches an output directly (spline arithmetic, log sigma) nor in the exact-f32 kernel.
+ * Cost on gfx950 (packed-f32 ops issue at half the scalar rate, transcendentals at a quarter): ~80 cycles per pair vs
+ * ~170 (SiLU) / ~220 (tanh) for the reproducible forms. */
+__device__ __forceinline__ bgk_f2 bgk_siluf2_fast(bgk_f2 x) {
+    const bgk_f2 y = x * bgk_splat2(-1.44269504088896341f);
+    bgk_f2 d;
+    d.x = __builtin_amdgcn_exp2f(y.x); d.y = __builtin_amdgcn_exp2f(y.y);
+    d = d + bgk_splat2(1.0f);
+    bgk_f2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    return x * r;
+}
+__device__ __forceinline__ bgk_f2 bgk_tanhf2_fast(bgk_f2 x) {
+    const bgk_f2 y = x * bgk_splat2(2.88539008177792681f);
+    bgk_f2 d;
+    d.x = __builtin_amdgcn_exp2f(y.x); d.y = __builtin_amdgcn_exp2f(y.y);
+    d = d + bgk_splat2(1.0f);
+    bgk_f2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    return bgk_fma2(r, bgk_splat2(-2.0f), bgk_splat2(1.0f));
+}
+
 #endif /* BGK_DETMATH_PK_H */

@@ -108,6 +108,20 @@ __device__ __forceinline__ void act_tile(f32x16& t) {
     }
 }
 
+/* hidden activation of the split-f16 / bf16 kernels: hardware exp / rcp (bgk_detmath_pk.h) */
+template <int ACT>
+__device__ __forceinline__ void act_tile_fast(f32x16& t) {
+    if constexpr (ACT == 1 || ACT == 3) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const bgk_f2 v = ACT == 1 ? bgk_siluf2_fast((bgk_f2){t[r], t[r + 1]}) : bgk_tanhf2_fast((bgk_f2){t[r], t[r + 1]});
+            t[r] = v.x; t[r + 1] = v.y;
+        }
+    } else {
+        act_tile<ACT>(t);
+    }
+}
+
 /* row of output tile m held in accumulator register r by this lane (hh = lane >> 5) */
 __device__ __forceinline__ int drow(int m, int r, int hh) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
@@ -711,7 +725,7 @@ __device__ __forceinline__ void act_tile_scaled(f32x16& t, float c) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] *= c;
 #if !(BGK_ABL & 4)
-    act_tile<ACT>(t);
+    act_tile_fast<ACT>(t);
 #endif
 }
 
@@ -792,7 +806,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
                 for (int r = 0; r < 16; ++r) h[m][r] *= ah.c0;
             h2_store_z(h, ah.z0, b0, j, hh, rows);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) act_tile<ACT>(h[m]);
+            for (int m = 0; m < 4; ++m) act_tile_fast<ACT>(h[m]);
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(h[m], ah.c0);
@@ -811,7 +825,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
                 for (int r = 0; r < 16; ++r) acc[m][r] *= ah.c1;
             h2_store_z(acc, ah.z1, b0, j, hh, rows);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) act_tile<ACT>(acc[m]);
+            for (int m = 0; m < 4; ++m) act_tile_fast<ACT>(acc[m]);
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) act_tile_scaled<ACT>(acc[m], ah.c1);

@@ -107,10 +107,10 @@ __device__ __forceinline__ void h2_gemm_lds(h2_f32x16 (&out)[NT], const float* s
 __device__ __forceinline__ void h2_act_tile(h2_f32x16& t, float c, int act) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] *= c;
-    if (act == 1) {
+    if (act == 1) {        /* hidden activations: hardware exp / rcp forms (bgk_detmath_pk.h) */
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            bgk_f2 v = bgk_siluf2((bgk_f2){t[r], t[r + 1]});
+            bgk_f2 v = bgk_siluf2_fast((bgk_f2){t[r], t[r + 1]});
             t[r] = v.x; t[r + 1] = v.y;
         }
     } else if (act == 2) {
@@ -119,7 +119,7 @@ __device__ __forceinline__ void h2_act_tile(h2_f32x16& t, float c, int act) {
     } else if (act == 3) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            bgk_f2 v = bgk_tanhf2((bgk_f2){t[r], t[r + 1]});
+            bgk_f2 v = bgk_tanhf2_fast((bgk_f2){t[r], t[r + 1]});
             t[r] = v.x; t[r + 1] = v.y;
         }
     }
