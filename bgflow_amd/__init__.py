@@ -18,3 +18,9 @@ from .factory import *       # noqa: F401,F403
 from . import configs, dp, factory, utils      # noqa: F401
 
 __version__ = "0.1.0"
+
+# reference-style dotted import paths (bgflow_amd.nn.flow.crd_transform.ic, bgflow_amd.factory.tensor_info, ...)
+from . import _compat as _compat_mod   # noqa: E402
+import sys as _sys                     # noqa: E402
+_compat_mod.register(__name__, _sys.modules[__name__])
+

@@ -392,3 +392,22 @@ def test_builder_reproduces_the_augmented_cfg5_flow():
     assert list(a) == list(b) and all(a[k].shape == b[k].shape for k in a)
     assert sum(p.numel() for p in gen.flow.parameters()) == 1072356      # probe of the reference builder
 
+
+def test_reference_style_import_paths_resolve():
+    """sub-package import paths used by bgflow code resolve to the accelerated classes (bgflow_amd/_compat.py)"""
+    import importlib
+    from bgflow_amd.nn.flow.crd_transform.ic import GlobalInternalCoordinateTransformation, MixedCoordinateTransformation
+    from bgflow_amd.nn.flow.transformer.spline import ConditionalSplineTransformer
+    from bgflow_amd.nn.flow.coupling import CouplingFlow, SplitFlow
+    from bgflow_amd.nn.periodic import WrapPeriodic
+    from bgflow_amd.distribution.normal import NormalDistribution
+    from bgflow_amd.factory.tensor_info import BONDS, TORSIONS, ShapeDictionary
+    from bgflow_amd.factory.generator_builder import BoltzmannGeneratorBuilder
+    assert MixedCoordinateTransformation is bg.MixedCoordinateTransformation and CouplingFlow is bg.CouplingFlow
+    assert ConditionalSplineTransformer is bg.ConditionalSplineTransformer and WrapPeriodic is bg.WrapPeriodic
+    assert BoltzmannGeneratorBuilder is bg.BoltzmannGeneratorBuilder and TORSIONS.is_circular and not BONDS.is_circular
+    assert importlib.import_module("bgflow_amd.nn.flow.cdf").CDFTransform is bg.CDFTransform
+    assert GlobalInternalCoordinateTransformation is bg.GlobalInternalCoordinateTransformation and ShapeDictionary and SplitFlow and NormalDistribution
+    with pytest.raises(ImportError):
+        importlib.import_module("bgflow_amd.nn.flow.dynamics")      # outside the hot path: not provided
+
