@@ -34,8 +34,11 @@ def _worker(rank, world, port, out):
     loss.backward()
     dp.allreduce_gradients_([theta])
     logw = x[:, 0] * 3.0
-    out.put((rank, float(loss.detach()), theta.grad.clone(), x.clone(),
-             float(dp.global_logsumexp(logw)), dp.global_normalized_log_weights(logw).clone(), float(dp.global_effective_sample_size(logw))))
+    # plain lists, not tensors: tensor storages travel through the queue as file descriptors served by THIS process,
+    # which may already have exited when the parent reads them
+    out.put((rank, float(loss.detach()), theta.grad.tolist(), x.tolist(),
+             float(dp.global_logsumexp(logw)), dp.global_normalized_log_weights(logw).tolist(),
+             float(dp.global_effective_sample_size(logw))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,6 +55,7 @@ def test_global_mean_and_gradient_bucket_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, l0, g0, x0, lse0, nw0, ess0), (_, l1, g1, x1, lse1, nw1, ess1) = res
+    g0, g1, x0, x1, nw0, nw1 = (torch.tensor(v) for v in (g0, g1, x0, x1, nw0, nw1))
     assert l0 == pytest.approx(l1, rel=1e-6)                      # every rank holds the GLOBAL mean
     assert not torch.equal(x0[:5], x1)                            # per-rank RNG streams differ
     theta = torch.nn.Parameter(torch.tensor([0.5, -1.0]))
