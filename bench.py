@@ -276,8 +276,11 @@ def main():
                               "f32-input MFMA and f32 VALU share the issue port on gfx950: time = MFMA + VALU, see profiles/README.md"),
                         launches_per_step=n_launch, avg_launch_ms=1e3 * avg_launch_s,
                         flops_per_launch=flops_per_launch,
-                        hbm_view=dict(algorithmic_bytes_per_step=alg_bytes_step,
-                                      achieved_GBs=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak_GBs=HBM_PEAK_GBS))
+                        hbm_view=dict(note="SURVEY 8(d) algorithmic bytes (unfused kernel boundaries: 26 800 B per sample for cfg 3) "
+                                           "per GPU and step / step time, against the 8 TB/s HBM3E peak",
+                                      algorithmic_bytes_per_step=alg_bytes_step,
+                                      achieved_GBs=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak_GBs=HBM_PEAK_GBS,
+                                      frac=alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS))
         else:
             roof = dict(bound="hbm", achieved=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak=HBM_PEAK_GBS,
                         unit="GB/s", traffic=measured_traffic("coupling_affine_dense_kernel"),
