@@ -905,3 +905,25 @@ def test_builder_built_generator_equals_configs_generator(hip_lib, dev):
     assert torch.equal(x, xr) and torch.equal(dl, dlr)
     assert kl.shape == (64, 1) and torch.isfinite(kl).all()
 
+
+@pytest.mark.parametrize("act", [torch.nn.ReLU, torch.nn.Tanh])
+def test_fused_training_forward_other_activations(hip_lib, dev, act):
+    """the differentiable one-launch forward with ReLU / Tanh conditioners (non-circular, d = 9 conditioned on 17 dims)"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    B = 515
+    res = {}
+    for fused in (True, False):
+        tr = bg.ConditionalSplineTransformer(bg.DenseNet([17, 128, 128, 3 * 8 * 9 + 9], act()), is_circular=False)
+        layer = hash_init_(bg.CouplingFlow(tr, transformed_indices=(1,), cond_indices=(0,))).to(dev)
+        tr.allow_fused = fused
+        x = t(synth(11, B, 17, uniform=True), dev).requires_grad_(True)
+        y = t(synth(12, B, 9, uniform=True), dev).requires_grad_(True)
+        xo, yo, dl = layer(x, y)
+        ((yo * t(synth(13, B, 9), dev)).sum() + (dl * t(synth(14, B, 1), dev)).sum()).backward()
+        res[fused] = [yo.detach(), dl.detach(), x.grad, y.grad] + [p.grad for p in layer.parameters()]
+        if fused:
+            assert tr._fused_cache.get("src_col_dev") is not None
+    for a, b in zip(res[True], res[False]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=3e-4 * float(b.abs().max()) + 2e-5)
+
