@@ -79,7 +79,7 @@ def timed_steps(gen, zs, steps):
     return evs
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, batch=1 << 20):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/<round>_traffic.json,
     written by tools/profile_round.sh: FETCH_SIZE x 2 [gfx950 rule] + WRITE_SIZE, KiB units), or None"""
     import glob
@@ -87,7 +87,8 @@ def measured_traffic(kernel):
     if not files:
         return None
     try:
-        return json.load(open(files[-1])).get(kernel, {}).get("hbm_bytes_per_launch")
+        v = json.load(open(files[-1])).get(kernel, {}).get("hbm_bytes_per_launch")
+        return None if v is None else v * (batch / float(1 << 20))     # the PMC passes ran at 2^20 samples per launch
     except Exception:
         return None
 
@@ -133,7 +134,12 @@ def main():
     ap.add_argument("--kl-batch", type=int, default=1 << 18, help="samples per GPU per KL step")
     args = ap.parse_args()
 
-    rank, world, local = dp.init_from_env("nccl")
+    # BGK_BENCH_TEST_SHARED_GPU=1: self-test of the multi-rank code path on a ONE-GPU box (all ranks on cuda:0, gloo for
+    # the collectives -- RCCL refuses two ranks on one device).  Never set by the driver; numbers of such a run mean nothing.
+    shared_gpu_test = os.environ.get("BGK_BENCH_TEST_SHARED_GPU") == "1"
+    rank, world, local = dp.init_from_env("gloo" if shared_gpu_test else "nccl")
+    if shared_gpu_test:
+        local = 0
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -266,7 +272,7 @@ def main():
         if args.workload in ("cfg3", "cfg5"):
             split = gemm_mode in ("f16x2", "bf16")
             roof = dict(bound="mfma", achieved=flops_per_launch / avg_launch_s / 1e12, peak=MFMA_F32_PEAK_TFLOPS,
-                        unit="TFLOP/s", traffic=measured_traffic("coupling_rqs_dense_h2_kernel" if split else "coupling_rqs_dense_kernel"),
+                        unit="TFLOP/s", traffic=measured_traffic("coupling_rqs_dense_h2_kernel" if split else "coupling_rqs_dense_kernel", args.batch),
                         kernel=("coupling_rqs_dense_h2_kernel (fused DenseNet on the f16 matrix cores in split-f16 form + RQ-spline "
                                 "coupling layer)" if split else
                                 "coupling_rqs_dense_kernel (fused DenseNet on the f32-input MFMA + RQ-spline coupling layer)"),
@@ -283,7 +289,7 @@ def main():
                                       frac=alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS))
         else:
             roof = dict(bound="hbm", achieved=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak=HBM_PEAK_GBS,
-                        unit="GB/s", traffic=measured_traffic("coupling_affine_dense_kernel"),
+                        unit="GB/s", traffic=measured_traffic("coupling_affine_dense_kernel", args.batch),
                         kernel="coupling_affine_dense_kernel (fused: 2 DenseNets on the f16 matrix cores + affine tail)")
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["block_ms"] = [round(v, 3) for v in block_ms]
