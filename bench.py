@@ -249,8 +249,9 @@ def main():
         kl = dict(steps_per_s=args.kl_steps / dtk, samples_per_s=args.kl_steps * args.kl_batch * world / dtk,
                   batch_per_gpu=args.kl_batch, steps=args.kl_steps, loss=float(last.detach()),
                   note="fwd: one-launch coupling layers (training variant, saves pre-activations + spline parameters) + IC / CDF kernels; "
-                       "bwd: bgk_rqs_backward / bgk_ic_ic2xyz_backward + MLP backward GEMMs (split-K weight gradients, bias "
-                       "gradients on bgk_column_sum); one all-reduce of [sum, n] + one gradient bucket; Adam")
+                       "bwd: bgk_rqs_backward / bgk_ic_ic2xyz_backward, conditioner input-gradient chain on bgk_dense_backward_dx, "
+                       "split-K weight-gradient GEMMs, bias gradients on bgk_column_sum; one all-reduce of [sum, n] + one "
+                       "gradient bucket; Adam")
 
     total_samples = args.batch * world * args.steps
     value = total_samples / elapsed

@@ -1,0 +1,253 @@
+/* bgk_dense_bwd.hip -- input-gradient chain of the conditioner MLP in one launch (training step, autograd of
+ * nn/dense.py:47-48 behind ConditionalSplineTransformer, nn/flow/transformer/spline.py:109):
+ *   g_h1 = g_params W2            g_z1 = g_h1 * act'(z1)      h1 = act(z1)
+ *   g_h0 = g_z1 W1                g_z0 = g_h0 * act'(z0)      h0 = act(z0)
+ *   g_feat = g_z0 W0              g_cond = featuriser^T g_feat  (cos / sin featuriser of nn/periodic.py:30-37 or identity)
+ * replacing three tall-skinny hipBLASLt GEMMs, two activation recomputations and two activation-backward passes per
+ * layer; the weight / bias gradients stay GEMMs over the batch on the tensors written here (g_z1, g_z0, h1, h0).
+ * Same split-f16 machinery as the forward (bgk_mfma_h2.h): a wave owns 32 samples; the B operand of the first GEMM is
+ * read straight from the row-major g_params (8 consecutive floats per lane and k16-step), later ones are the previous
+ * GEMM's accumulator registers.  A operands = transposed weights packed by bgk_pack_dense_h2_t.
+ * Roofline: HBM 4 (P + 4*128 + 2*128 + d_c) B per sample (cfg 3 B|A: 4.8 kB); hidden activations' derivative on the
+ * hardware exp / rcp forms like the forward.
+ */
+#include "bgk_mfma_h2.h"
+
+namespace {
+
+constexpr int DW = 4;
+constexpr int DSROW = 33;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct DenseBwdArgs {
+    const float* g; int64_t ldg; int P;           /* gradient w.r.t. the MLP output [B, P] */
+    const float* z1; const float* z0;             /* saved pre-activations [B, 128] */
+    const float* cond; int64_t ldc; int d_c; int periodic;
+    const uint4 *T2, *T1, *T0; int S2;            /* transposed-weight operands; S2 = ceil(P / 16) */
+    const float* cs;                              /* {2^s, 2^-s} x 3 (layer 0, 1, 2) */
+    int act; int64_t B;
+    float* g_z1; float* g_z0; float* h1; float* h0;
+    float* g_cond; int64_t ldgc;
+    int lds_per_wave;
+};
+
+/* d = g * act'(z), h = act(z) for a pair (hardware exp / rcp) */
+__device__ __forceinline__ void act_grad2(int act, bgk_f2 z, bgk_f2 g, bgk_f2& gz, bgk_f2& h) {
+    if (act == 1) {
+        const bgk_f2 y = z * bgk_splat2(-1.44269504088896341f);
+        bgk_f2 e; e.x = __builtin_amdgcn_exp2f(y.x); e.y = __builtin_amdgcn_exp2f(y.y);
+        e = e + bgk_splat2(1.0f);
+        bgk_f2 s; s.x = __builtin_amdgcn_rcpf(e.x); s.y = __builtin_amdgcn_rcpf(e.y);
+        h = z * s;
+        gz = g * (s * (bgk_splat2(1.0f) + z * (bgk_splat2(1.0f) - s)));
+    } else if (act == 2) {
+        h.x = z.x > 0.0f ? z.x : 0.0f; h.y = z.y > 0.0f ? z.y : 0.0f;
+        gz.x = z.x > 0.0f ? g.x : 0.0f; gz.y = z.y > 0.0f ? g.y : 0.0f;
+    } else {
+        h = bgk_tanhf2_fast(z);
+        gz = g * (bgk_splat2(1.0f) - h * h);
+    }
+}
+
+/* acc (accumulator layout, 4 tiles) -> g_z = acc * c * act'(z), h = act(z): z read and g_z / h written as 16-byte groups */
+__device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, int act, const float* z, float* gz_out, float* h_out,
+                                                   int64_t b0, int j, int hh, int rows) {
+    const int64_t row = (b0 + (j < rows ? j : 0)) * 128;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * m + 8 * q + 4 * hh;
+            const float4 zz = *reinterpret_cast<const float4*>(z + row + f0);
+            bgk_f2 g0, g1, a0, a1;
+            act_grad2(act, (bgk_f2){zz.x, zz.y}, (bgk_f2){t[m][4 * q] * c, t[m][4 * q + 1] * c}, g0, a0);
+            act_grad2(act, (bgk_f2){zz.z, zz.w}, (bgk_f2){t[m][4 * q + 2] * c, t[m][4 * q + 3] * c}, g1, a1);
+            t[m][4 * q] = g0.x; t[m][4 * q + 1] = g0.y; t[m][4 * q + 2] = g1.x; t[m][4 * q + 3] = g1.y;
+            if (j < rows) {
+                *reinterpret_cast<float4*>(gz_out + row + f0) = make_float4(g0.x, g0.y, g1.x, g1.y);
+                *reinterpret_cast<float4*>(h_out + row + f0) = make_float4(a0.x, a0.y, a1.x, a1.y);
+            }
+        }
+}
+
+template <int FT>
+__global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* s_f = smem + (size_t)wave * a.lds_per_wave;       /* g_feat tile [32 FT][DSROW] (periodic featuriser only) */
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * DW + wave;
+    if (tile >= n_tiles) return;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    const float c2 = a.cs[5], c1 = a.cs[3], c0 = a.cs[1];
+
+    /* ---- g_h1 = W2^T g : B operand straight from the row-major gradient ---- */
+    h2_f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+    {
+        /* the gradient rows are far apart in memory (one 32-byte piece of 32 different rows per load instruction): keep
+         * four k16-steps of B values in flight in a register ring so that the HBM / L2 latency hides behind the MFMAs */
+        const float* grow = a.g + (b0 + (j < rows ? j : 0)) * a.ldg;
+        const bool live = j < rows;
+        auto load_g = [&](int s, float (&v)[8]) {
+            const int k0 = 16 * s + 8 * hh;
+            if (live && k0 + 8 <= a.P) {
+                const f4u u0 = *reinterpret_cast<const f4u*>(grow + k0), u1 = *reinterpret_cast<const f4u*>(grow + k0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (live && k0 + e < a.P) ? grow[k0 + e] : 0.0f;
+            }
+        };
+        float ring[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_g(u, ring[u]);
+        for (int s0 = 0; s0 < a.S2; s0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = s0 + u;
+                if (s < a.S2) {
+                    H2A<4> fr;
+                    h2a_load<4>(fr, a.T2, s, lane);
+                    h2_h16x8 bhi, blo;
+                    h2_split8(ring[u], bhi, blo);
+                    load_g(s + 4, ring[u]);
+                    h2_mfma3<4>(acc, fr, bhi, blo);
+                }
+            }
+        }
+    }
+    act_backward_tiles(acc, c2, a.act, a.z1, a.g_z1, a.h1, b0, j, hh, rows);
+
+    /* ---- g_h0 = W1^T g_z1 ---- */
+    H2B<4> bf;
+    h2_make_b<4>(bf, acc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+    h2_gemm_hidden<4, 4>(acc, bf, a.T1, lane);
+    act_backward_tiles(acc, c1, a.act, a.z0, a.g_z0, a.h0, b0, j, hh, rows);
+
+    /* ---- g_feat = W0^T g_z0, then the featuriser's transpose ---- */
+    if (a.g_cond == nullptr) return;
+    h2_make_b<4>(bf, acc);
+    h2_f32x16 gf[FT];
+#pragma unroll
+    for (int m = 0; m < FT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gf[m][r] = 0.0f;
+    h2_gemm_hidden<FT, 4>(gf, bf, a.T0, lane);
+    if (!a.periodic) {
+        if (j < rows) {
+            float* orow = a.g_cond + (b0 + j) * a.ldgc;
+#pragma unroll
+            for (int m = 0; m < FT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = h2_row(m, r, hh);
+                    if (f < a.d_c) orow[f] = gf[m][r] * c0;
+                }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < FT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_f[h2_row(m, r, hh) * DSROW + j] = gf[m][r] * c0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        /* feats = [cos 2 pi x, sin 2 pi x]  ->  g_x = 2 pi (cos * g_sin - sin * g_cos) */
+        for (int i = lane; i < rows * a.d_c; i += 64) {
+            const int r = i / a.d_c, c = i - r * a.d_c;
+            float sv, cv;
+            bgk_sincos2pif(a.cond[(b0 + r) * a.ldc + c], &sv, &cv);
+            const float gc = s_f[c * DSROW + r], gs = s_f[(a.d_c + c) * DSROW + r];
+            a.g_cond[(b0 + r) * a.ldgc + c] = 6.28318530717958648f * (cv * gs - sv * gc);
+        }
+    }
+}
+
+/* transposed-weight operand blocks: M[i][k] = W[ksrc(k)][i] * scale, i = output row of the backward GEMM (= input feature of
+ * the layer), k in natural order (natural = 1: ksrc = k) or in accumulator order (ksrc = hidden unit of slot k) */
+struct PackT {
+    const float* W; int rows_src, cols_src;   /* the layer's weight [rows_src = out features, cols_src = in features] */
+    int NT, S, natural;
+    _Float16* out;
+};
+
+__global__ __launch_bounds__(256) void pack_t_kernel(PackT L, const float* cs, int layer) {
+    const int blocks = L.S * L.NT * 2 + L.NT;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)blocks * 64) return;
+    const int lane = (int)(t & 63), blk = (int)(t >> 6);
+    const int i = lane & 31, kb = lane >> 5;
+    const float scale = cs[2 * layer];
+    _Float16 o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)0.0f;
+    if (blk < L.S * L.NT * 2) {
+        const int p = blk & 1, m = (blk >> 1) % L.NT, s = (blk >> 1) / L.NT;
+        const int col = 32 * m + i;                                  /* input feature of the layer */
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = L.natural ? 16 * s + 8 * kb + e : 32 * (s >> 1) + (e & 3) + 8 * (2 * (s & 1) + (e >> 2)) + 4 * kb;
+            float v = 0.0f;
+            if (k < L.rows_src && col < L.cols_src) v = L.W[(int64_t)k * L.cols_src + col] * scale;
+            const _Float16 h = (_Float16)v;
+            o[e] = p ? (_Float16)(v - (float)h) : h;
+        }
+    }   /* else: zero "bias" blocks (the backward GEMMs have no bias) */
+    *reinterpret_cast<uint4*>(L.out + ((int64_t)blk * 64 + lane) * 8) = *reinterpret_cast<const uint4*>(o);
+}
+
+}  // namespace
+
+extern "C" int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
+                                   const float* cs, void* T0, void* T1, void* T2, void* stream) {
+    BGK_CHECK_ARG(W0 && W1 && W2 && cs && T0 && T1 && T2, "bgk_pack_dense_h2_t: null pointer");
+    BGK_CHECK_ARG(n_in > 0 && n_in <= 96 && P > 0, "bgk_pack_dense_h2_t: bad sizes (n_in <= 96)");
+    hipStream_t st = (hipStream_t)stream;
+    const int FT = (n_in + 31) / 32, S2 = (P + 15) / 16;
+    const PackT L2{W2, P, 128, 4, S2, 1, (_Float16*)T2};       /* M[hidden i][k] = W2[k][i], k = output column of the MLP */
+    const PackT L1{W1, 128, 128, 4, 8, 0, (_Float16*)T1};      /* M[i][k] = W1[unit(k)][i] */
+    const PackT L0{W0, 128, n_in, FT, 8, 0, (_Float16*)T0};    /* M[feature i][k] = W0[unit(k)][i] */
+    const PackT* Ls[3] = {&L0, &L1, &L2};
+    for (int l = 0; l < 3; ++l) {
+        const int64_t total = (int64_t)(Ls[l]->S * Ls[l]->NT * 2 + Ls[l]->NT) * 64;
+        hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *Ls[l], cs, l);
+    }
+    return bgk_launch_status("bgk_pack_dense_h2_t");
+}
+
+extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,
+                                     const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                     const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
+                                     int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
+                                     float* g_cond, int64_t ldgc, void* stream) {
+    BGK_CHECK_ARG(g && z1 && z0 && T0 && T1 && T2 && cs && g_z1 && g_z0 && h1 && h0, "bgk_dense_backward_dx: null pointer");
+    BGK_CHECK_ARG(B >= 0 && P > 0 && ldg >= P && d_c > 0 && act >= 1 && act <= 3, "bgk_dense_backward_dx: bad sizes");
+    BGK_CHECK_ARG(!(g_cond && periodic && !cond), "bgk_dense_backward_dx: the periodic featuriser needs the conditioner input");
+    const int n_in = periodic ? 2 * d_c : d_c;
+    if (n_in > 96) { bgk_set_error("bgk_dense_backward_dx: %d input features > 96", n_in); return BGK_EUNSUPPORTED; }
+    if (B == 0) return 0;
+    DenseBwdArgs a;
+    a.g = g; a.ldg = ldg; a.P = P; a.z1 = z1; a.z0 = z0; a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
+    a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.S2 = (P + 15) / 16; a.cs = cs; a.act = act; a.B = B;
+    a.g_z1 = g_z1; a.g_z0 = g_z0; a.h1 = h1; a.h0 = h0; a.g_cond = g_cond; a.ldgc = ldgc;
+    const int FT = (n_in + 31) / 32;
+    a.lds_per_wave = periodic ? 32 * FT * DSROW : 0;
+    const size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;
+    const int64_t n_wg = ((B + 31) / 32 + DW - 1) / DW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_dense_backward_dx: batch too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    if (FT == 1) hipLaunchKernelGGL(dense_bwd_dx_kernel<1>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a);
+    else if (FT == 2) hipLaunchKernelGGL(dense_bwd_dx_kernel<2>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a);
+    else hipLaunchKernelGGL(dense_bwd_dx_kernel<3>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a);
+    return bgk_launch_status("bgk_dense_backward_dx");
+}

@@ -558,6 +558,40 @@ def _featurise(x, periodic):
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
 
 
+FUSED_MLP_BACKWARD = True    # input-gradient chain of the conditioner on bgk_dense_backward_dx (False: three GEMMs + torch act ops)
+
+
+def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs):
+    """bgk_pack_dense_h2_t + bgk_dense_backward_dx: returns (g_z1, g_z0, h1, h0, g_x or None)"""
+    dev = g_p.device
+    B, P = g_p.shape
+    n_in = W0.shape[1]
+    FT, S2 = (n_in + 31) // 32, (P + 15) // 16
+    key = (P, n_in, str(dev))
+    if bufs.get("key") != key:
+        bufs.clear()
+        bufs.update(key=key, T0=torch.empty((8 * FT * 2 + FT, 64, 8), dtype=torch.float16, device=dev),
+                    T1=torch.empty((8 * 8 + 4, 64, 8), dtype=torch.float16, device=dev),
+                    T2=torch.empty((S2 * 8 + 4, 64, 8), dtype=torch.float16, device=dev))
+    T0, T1, T2 = bufs["T0"], bufs["T1"], bufs["T2"]
+    g2, ldg = _lib.rowmajor(g_p)
+    x2, ldc = _lib.rowmajor(x.detach())
+    d_c = x2.shape[1]
+    out = torch.empty((4, B, 128), dtype=torch.float32, device=dev)
+    g_x = torch.empty((B, d_c), dtype=torch.float32, device=dev) if want_gx else None
+    ws = [w.detach().contiguous() for w in (W0, W1, W2)]
+    with torch.cuda.device(dev):
+        st = _lib.lib().bgk_pack_dense_h2_t(_lib.ptr(ws[0]), n_in, _lib.ptr(ws[1]), _lib.ptr(ws[2]), P, _lib.ptr(cs),
+                                            _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_pack_dense_h2_t")
+        st = _lib.lib().bgk_dense_backward_dx(_lib.ptr(g2), ldg, P, _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic),
+                                              _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.ptr(cs), act_code, B,
+                                              _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
+                                              _lib.ptr(g_x), d_c, _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_dense_backward_dx")
+    return out[0], out[1], out[2], out[3], g_x
+
+
 class _FusedSplineTrainFn(torch.autograd.Function):
     """Forward = ONE launch of bgk_coupling_rqs_dense_h2_train (conditioner MLP on the f16 matrix cores + spline; the
     pre-activations z0, z1 and the spline parameters are written out for the backward pass).  Backward = bgk_rqs_backward
@@ -586,6 +620,8 @@ class _FusedSplineTrainFn(torch.autograd.Function):
                 _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), P, _lib.ptr(plan["src_col_dev"]), _lib.stream_ptr(dev))
         _lib.check(st, "bgk_coupling_rqs_dense_h2_train")
         ctx.save_for_backward(x, y, W0, W1, W2, z0, z1, params, nc_dev)
+        ctx.cs = plan.get("cs")                 # scale table of the operands packed for this forward (same weights in backward)
+        ctx.tbufs = plan.setdefault("tbufs", {})
         ctx.meta = (plan["act"], bool(plan["periodic"]), (plan["n_bins"], inverse, left, right, bottom, top, dict(s)))
         return out, dlogp[:, None]
 
@@ -597,27 +633,27 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         act, act_bwd = _act_fwd_bwd(act_code)
         g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp)
         need = ctx.needs_input_grad
-        h1 = act(z1)
+        cs = ctx.cs
+        if cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= 96:
+            g_z1, g_z0, h1, h0, g_x = _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, need[0], ctx.tbufs)
+        else:
+            h1 = act(z1)
+            g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
+            h0 = act(z0)
+            g_z0 = act_bwd(_matmul_nn(g_z1, W1), z0, h0)
+            g_x = None
+            if need[0] and periodic:
+                with torch.enable_grad():
+                    xx = x.detach().requires_grad_(True)
+                    feats = _featurise(xx, True)
+                g_x = torch.autograd.grad(feats, xx, _matmul_nn(g_z0, W0))[0]
+            elif need[0]:
+                g_x = _matmul_nn(g_z0, W0)
+        feats = _featurise(x.detach(), periodic)
         gW2 = _gram_tn(g_p, h1) if need[6] else None
         gb2 = column_sum(g_p) if need[7] else None
-        g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
-        del h1
-        h0 = act(z0)
         gW1 = _gram_tn(g_z1, h0) if need[4] else None
         gb1 = column_sum(g_z1) if need[5] else None
-        g_z0 = act_bwd(_matmul_nn(g_z1, W1), z0, h0)
-        del h0, g_z1
-        g_x = None
-        if need[0] and periodic:
-            with torch.enable_grad():
-                xx = x.detach().requires_grad_(True)
-                feats = _featurise(xx, True)
-            g_x = torch.autograd.grad(feats, xx, _matmul_nn(g_z0, W0))[0]
-            feats = feats.detach()
-        else:
-            feats = _featurise(x, periodic)
-            if need[0]:
-                g_x = _matmul_nn(g_z0, W0)
         gW0 = _gram_tn(g_z0, feats.contiguous()) if need[2] else None
         gb0 = column_sum(g_z0) if need[3] else None
         return (g_x, g_y if need[1] else None, gW0, gb0, gW1, gb1, gW2, gb2) + (None,) * 5

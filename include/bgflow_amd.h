@@ -252,6 +252,20 @@ int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
                       const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2, int32_t operand_dtype,
                       void* A0, void* A1, void* A2, float* cs, void* stream);
 
+/* Input-gradient chain of the conditioner MLP [n_in, 128, 128, P] in one launch (autograd of nn/dense.py:47-48 in the
+ * training step): from g [B, P] (gradient w.r.t. the MLP output, e.g. bgk_rqs_backward's g_params) and the saved
+ * pre-activations z1, z0 it writes g_z1, g_z0 (gradients w.r.t. the pre-activations), h1, h0 (the activations) -- the
+ * operands of the weight / bias gradient GEMMs -- and g_cond [B, d_c] (NULL to skip; periodic != 0: through the cos / sin
+ * featuriser of nn/periodic.py:30-37, needs cond).  T0..T2: transposed-weight operands from bgk_pack_dense_h2_t with the
+ * scale table cs of bgk_pack_dense_h2 for the same weights. */
+int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
+                        const float* cs, void* T0, void* T1, void* T2, void* stream);
+int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,
+                          const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                          const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
+                          int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
+                          float* g_cond, int64_t ldgc, void* stream);
+
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).
  * Deterministic two-stage reduction; `partial` is a caller-provided [nblk, P] workspace. */
