@@ -49,10 +49,13 @@ __device__ __forceinline__ void act_grad2(int act, bgk_f2 z, bgk_f2 g, bgk_f2& g
     }
 }
 
-/* acc (accumulator layout, 4 tiles) -> g_z = acc * c * act'(z), h = act(z): z read and g_z / h written as 16-byte groups */
+/* acc (accumulator layout, 4 tiles) -> g_z = acc * c * act'(z), h = act(z); z is read as 16-byte groups, g_z / h leave as
+ * full rows through the LDS slab */
 __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, int act, const float* z, float* gz_out, float* h_out,
-                                                   int64_t b0, int j, int hh, int rows) {
+                                                   float* s_buf, int64_t b0, int lane, int rows) {
+    const int j = lane & 31, hh = lane >> 5;
     const int64_t row = (b0 + (j < rows ? j : 0)) * 128;
+    h2_f32x16 hv[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -63,11 +66,10 @@ __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, i
             act_grad2(act, (bgk_f2){zz.x, zz.y}, (bgk_f2){t[m][4 * q] * c, t[m][4 * q + 1] * c}, g0, a0);
             act_grad2(act, (bgk_f2){zz.z, zz.w}, (bgk_f2){t[m][4 * q + 2] * c, t[m][4 * q + 3] * c}, g1, a1);
             t[m][4 * q] = g0.x; t[m][4 * q + 1] = g0.y; t[m][4 * q + 2] = g1.x; t[m][4 * q + 3] = g1.y;
-            if (j < rows) {
-                *reinterpret_cast<float4*>(gz_out + row + f0) = make_float4(g0.x, g0.y, g1.x, g1.y);
-                *reinterpret_cast<float4*>(h_out + row + f0) = make_float4(a0.x, a0.y, a1.x, a1.y);
-            }
+            hv[m][4 * q] = a0.x; hv[m][4 * q + 1] = a0.y; hv[m][4 * q + 2] = a1.x; hv[m][4 * q + 3] = a1.y;
         }
+    h2_store_rows128(hv, h_out, s_buf, b0, rows, lane);
+    h2_store_rows128(t, gz_out, s_buf, b0, rows, lane);
 }
 
 template <int FT>
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
-    float* s_f = smem + (size_t)wave * a.lds_per_wave;       /* g_feat tile [32 FT][DSROW] (periodic featuriser only) */
+    float* s_f = smem + (size_t)wave * a.lds_per_wave;       /* [32][H2_SLAB] output slab; later the g_feat tile [32 FT][DSROW] */
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * DW + wave;
     if (tile >= n_tiles) return;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
             }
         }
     }
-    act_backward_tiles(acc, c2, a.act, a.z1, a.g_z1, a.h1, b0, j, hh, rows);
+    act_backward_tiles(acc, c2, a.act, a.z1, a.g_z1, a.h1, s_f, b0, lane, rows);
 
     /* ---- g_h0 = W1^T g_z1 ---- */
     H2B<4> bf;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     h2_gemm_hidden<4, 4>(acc, bf, a.T1, lane);
-    act_backward_tiles(acc, c1, a.act, a.z0, a.g_z0, a.h0, b0, j, hh, rows);
+    act_backward_tiles(acc, c1, a.act, a.z0, a.g_z0, a.h0, s_f, b0, lane, rows);
 
     /* ---- g_feat = W0^T g_z0, then the featuriser's transpose ---- */
     if (a.g_cond == nullptr) return;
@@ -241,7 +243,7 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.S2 = (P + 15) / 16; a.cs = cs; a.act = act; a.B = B;
     a.g_z1 = g_z1; a.g_z0 = g_z0; a.h1 = h1; a.h0 = h0; a.g_cond = g_cond; a.ldgc = ldgc;
     const int FT = (n_in + 31) / 32;
-    a.lds_per_wave = periodic ? 32 * FT * DSROW : 0;
+    a.lds_per_wave = 32 * H2_SLAB > 32 * FT * DSROW ? 32 * H2_SLAB : 32 * FT * DSROW;   /* output slab, reused for the g_feat tile */
     const size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + DW - 1) / DW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_dense_backward_dx: batch too large for one launch");

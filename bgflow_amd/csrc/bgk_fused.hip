@@ -28,7 +28,7 @@
  * Every f32 operation is the same IEEE op in the same order as oracle/bgo_impl.h -> bit-exact
  * parity (MFMA f32 = k-ordered fma chain, one rounding per product).
  */
-#include "bgk_common.h"
+#include "bgk_mfma_h2.h"
 
 namespace {
 
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[m][r] *= ah.c0;
-            h2_store_z(h, ah.z0, b0, j, hh, rows);
+            h2_store_rows128(h, ah.z0, s_p, b0, rows, lane);
 #pragma unroll
             for (int m = 0; m < 4; ++m) act_tile_fast<ACT>(h[m]);
         } else {
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][r] *= ah.c1;
-            h2_store_z(acc, ah.z1, b0, j, hh, rows);
+            h2_store_rows128(acc, ah.z1, s_p, b0, rows, lane);
 #pragma unroll
             for (int m = 0; m < 4; ++m) act_tile_fast<ACT>(acc[m]);
         } else {
