@@ -729,18 +729,6 @@ __device__ __forceinline__ void act_tile_scaled(f32x16& t, float c) {
 #endif
 }
 
-/* pre-activation tile set (accumulator layout) -> z[b0 + j][0..128): 16-byte groups of 4 consecutive features */
-__device__ __forceinline__ void h2_store_z(const f32x16 (&t)[4], float* z, int64_t b0, int j, int hh, int rows) {
-    if (j < rows) {
-        float* zr = z + (b0 + j) * HID;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(zr + 32 * m + 8 * q + 4 * hh) = make_float4(t[m][4 * q], t[m][4 * q + 1], t[m][4 * q + 2], t[m][4 * q + 3]);
-    }
-}
-
 template <int ACT, int INV, bool SAVE, bool BF>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(FusedArgsH2 ah) {
     const FusedArgs& a = ah.f;
