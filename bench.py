@@ -114,8 +114,15 @@ def cpu_baseline(workload, n_samples):
         fo.run_flow(gen.flow, u, dtype=np.float32)
         dt += time.perf_counter() - t0
         passes += 1
-    return dict(value=passes * n_samples / dt, unit="samples/s", cores=orc.num_threads(), kind="port",
-                sample=f"{passes} pass(es) over {n_samples} samples of the same flow, forward + log|det J|, f32 ({dt:.1f} s)")
+    cpu = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), cpu)
+    except OSError:
+        pass
+    return dict(value=passes * n_samples / dt, unit="samples/s", cores=orc.num_threads(), kind="port", cpu=cpu,
+                sample=f"{passes} pass(es) over {n_samples} samples of the same flow, forward + log|det J|, f32 ({dt:.1f} s); "
+                       f"C restatement of the reference's op chain (oracle/), OpenMP over samples")
 
 
 def main():
