@@ -224,10 +224,73 @@ struct NoGemm {
     template <int S> __device__ __forceinline__ void step() {}
 };
 
+/* Arithmetic policy of the spline element.  HW = false: the reproducible f32 sequences of bgk_detmath*.h (exact-f32 kernel,
+ * bit-identical to the oracle).  HW = true (split-f16 / bf16 kernels, whose conditioner output is tolerance-class anyway):
+ * v_exp_f32 / v_log_f32 (1 ulp each) for the softmax terms, the softplus and the log-det; divisions stay exactly rounded.
+ * Measured on cfg 3 against the reference's f64 evaluation: max relative log-det error 1.8e-6 (exact arithmetic: 1.6e-6; the
+ * reference's own f32 path: 4.9e-6), 12 % faster end to end (packed-f32 polynomials cost 2 issue slots per instruction on
+ * gfx950, the hardware ops a quarter-rate slot each). */
+template <bool HW> struct SpMath;
+template <> struct SpMath<false> {
+    static __device__ __forceinline__ bgk_f2 exp2(bgk_f2 x) { return bgk_expf2(x); }
+    static __device__ __forceinline__ bgk_f2 log2(bgk_f2 x) { return bgk_logf2(x); }
+    static __device__ __forceinline__ float div(float n, float d) { return bgk_div_safe(n, d); }
+    static __device__ __forceinline__ bgk_f2 divr2(bgk_f2 n, bgk_f2 d, bgk_f2 r) { return bgk_div_r2(n, d, r); }
+    static __device__ __forceinline__ float rcp(float d) { return bgk_rcp_refined(d); }
+    static __device__ __forceinline__ bgk_f2 softplus2(bgk_f2 x, float beta) { return bgk_softplusf2(x, beta); }
+};
+#ifndef BGK_HW_EXP
+#define BGK_HW_EXP 1
+#endif
+#ifndef BGK_HW_LOG
+#define BGK_HW_LOG 1
+#endif
+#ifndef BGK_HW_DIV
+#define BGK_HW_DIV 0      /* measured (tools/exp_hw_combos.sh, cfg 3 vs the f64 goldens): exp + log cost nothing in accuracy
+                           * (1.8e-6 vs 1.6e-6 max relative log-det error) and give the whole speed-up (13.8 -> 12.25 ms);
+                           * unrefined reciprocals on top are no faster and 3x less accurate (5.9e-6) */
+#endif
+template <> struct SpMath<true> {
+    static __device__ __forceinline__ bgk_f2 exp2(bgk_f2 x) {
+#if BGK_HW_EXP
+        const bgk_f2 y = x * bgk_splat2(1.44269504088896341f);
+        bgk_f2 r; r.x = __builtin_amdgcn_exp2f(y.x); r.y = __builtin_amdgcn_exp2f(y.y); return r;
+#else
+        return bgk_expf2(x);
+#endif
+    }
+    static __device__ __forceinline__ bgk_f2 log2(bgk_f2 x) {
+#if BGK_HW_LOG
+        bgk_f2 r; r.x = __builtin_amdgcn_logf(x.x); r.y = __builtin_amdgcn_logf(x.y); return r * bgk_splat2(0.693147180559945309f);
+#else
+        return bgk_logf2(x);
+#endif
+    }
+#if BGK_HW_DIV
+    static __device__ __forceinline__ float div(float n, float d) { return n * __builtin_amdgcn_rcpf(d); }
+    static __device__ __forceinline__ bgk_f2 divr2(bgk_f2 n, bgk_f2, bgk_f2 r) { return n * r; }
+    static __device__ __forceinline__ float rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+#else
+    static __device__ __forceinline__ float div(float n, float d) { return bgk_div_safe(n, d); }
+    static __device__ __forceinline__ bgk_f2 divr2(bgk_f2 n, bgk_f2 d, bgk_f2 r) { return bgk_div_r2(n, d, r); }
+    static __device__ __forceinline__ float rcp(float d) { return bgk_rcp_refined(d); }
+#endif
+    static __device__ __forceinline__ bgk_f2 softplus2(bgk_f2 x, float beta) {
+#if BGK_HW_EXP && BGK_HW_LOG
+        const bgk_f2 z = x * bgk_splat2(beta);
+        bgk_f2 l = log2(bgk_splat2(1.0f) + exp2(z)) * bgk_splat2(__builtin_amdgcn_rcpf(beta));
+        l.x = z.x > 20.0f ? x.x : l.x; l.y = z.y > 20.0f ? x.y : l.y;
+        return l;
+#else
+        return bgk_softplusf2(x, beta);
+#endif
+    }
+};
+
 /* One spline element with 21 hook points; hook i runs k-step S0 + i of the overlapped GEMM.  Same
  * arithmetic, same order as bgk_rqs_element (bgk_common.h) -- only the instruction placement differs. */
 constexpr int HOOKS = 21;
-template <int INV, int S0, class G, int ST = 32>
+template <int INV, int S0, class G, int ST = 32, bool HW = false>
 __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* pw, const float* ph, const float* ps,
                                                    float s_last, const BgkRqsCfg& c, float* lad, int* bin, int* oob) {
     constexpr int K = KB, st = ST;
@@ -249,10 +312,10 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
 #pragma unroll
     for (int k = 1; k < K; ++k) mA = ra[k] > mA ? ra[k] : mA;
     g.template step<S0 + 0>();
-    { bgk_f2 t = bgk_expf2((bgk_f2){ra[0] - mA, ra[1] - mA}); e[0] = t.x; e[1] = t.y; } g.template step<S0 + 1>();
-    { bgk_f2 t = bgk_expf2((bgk_f2){ra[2] - mA, ra[3] - mA}); e[2] = t.x; e[3] = t.y; } g.template step<S0 + 2>();
-    { bgk_f2 t = bgk_expf2((bgk_f2){ra[4] - mA, ra[5] - mA}); e[4] = t.x; e[5] = t.y; } g.template step<S0 + 3>();
-    { bgk_f2 t = bgk_expf2((bgk_f2){ra[6] - mA, ra[7] - mA}); e[6] = t.x; e[7] = t.y; }
+    { bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[0] - mA, ra[1] - mA}); e[0] = t.x; e[1] = t.y; } g.template step<S0 + 1>();
+    { bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[2] - mA, ra[3] - mA}); e[2] = t.x; e[3] = t.y; } g.template step<S0 + 2>();
+    { bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[4] - mA, ra[5] - mA}); e[4] = t.x; e[5] = t.y; } g.template step<S0 + 3>();
+    { bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[6] - mA, ra[7] - mA}); e[6] = t.x; e[7] = t.y; }
     float sA = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) sA += e[k];
@@ -260,11 +323,11 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
     int idx = -1 + (x >= lowA ? 1 : 0);
     float lo = lowA, hi = lowA, cum = 0.0f;
     bool hi_set = false;
-    const bgk_f2 rA2 = bgk_splat2(bgk_rcp_refined(sA)), sA2 = bgk_splat2(sA);
+    const bgk_f2 rA2 = bgk_splat2(SpMath<HW>::rcp(sA)), sA2 = bgk_splat2(sA);
 #pragma unroll
     for (int k = 0; k < K; k += 2) {
         /* two knots per packed op; the running sum stays sequential (same bits as the scalar oracle) */
-        bgk_f2 p = bgk_div_r2((bgk_f2){e[k], e[k + 1]}, sA2, rA2);
+        bgk_f2 p = SpMath<HW>::divr2((bgk_f2){e[k], e[k + 1]}, sA2, rA2);
         p = bgk_splat2(minA) + bgk_splat2(scA) * p;
         const float c0 = cum + p.x, c1 = c0 + p.y;
         cum = c1;
@@ -294,20 +357,20 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
 #pragma unroll
     for (int k = 1; k < K; ++k) mB = ra[k] > mB ? ra[k] : mB;
     g.template step<S0 + 9>();
-    { bgk_f2 t = bgk_expf2((bgk_f2){ra[0] - mB, ra[1] - mB}); e[0] = t.x; e[1] = t.y; } g.template step<S0 + 10>();
-    { bgk_f2 t = bgk_expf2((bgk_f2){ra[2] - mB, ra[3] - mB}); e[2] = t.x; e[3] = t.y; } g.template step<S0 + 11>();
-    { bgk_f2 t = bgk_expf2((bgk_f2){ra[4] - mB, ra[5] - mB}); e[4] = t.x; e[5] = t.y; } g.template step<S0 + 12>();
-    { bgk_f2 t = bgk_expf2((bgk_f2){ra[6] - mB, ra[7] - mB}); e[6] = t.x; e[7] = t.y; }
+    { bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[0] - mB, ra[1] - mB}); e[0] = t.x; e[1] = t.y; } g.template step<S0 + 10>();
+    { bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[2] - mB, ra[3] - mB}); e[2] = t.x; e[3] = t.y; } g.template step<S0 + 11>();
+    { bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[4] - mB, ra[5] - mB}); e[4] = t.x; e[5] = t.y; } g.template step<S0 + 12>();
+    { bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[6] - mB, ra[7] - mB}); e[6] = t.x; e[7] = t.y; }
     float sB = 0.0f;
 #pragma unroll
     for (int k = 0; k < K; ++k) sB += e[k];
     g.template step<S0 + 13>();
     float b_i = lowB, b_ip1 = lowB;
     cum = 0.0f;
-    const bgk_f2 rB2 = bgk_splat2(bgk_rcp_refined(sB)), sB2 = bgk_splat2(sB);
+    const bgk_f2 rB2 = bgk_splat2(SpMath<HW>::rcp(sB)), sB2 = bgk_splat2(sB);
 #pragma unroll
     for (int k = 0; k < K; k += 2) {
-        bgk_f2 p = bgk_div_r2((bgk_f2){e[k], e[k + 1]}, sB2, rB2);
+        bgk_f2 p = SpMath<HW>::divr2((bgk_f2){e[k], e[k + 1]}, sB2, rB2);
         p = bgk_splat2(minB) + bgk_splat2(scB) * p;
         const float c0 = cum + p.x, c1 = c0 + p.y;
         cum = c1;
@@ -328,7 +391,7 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
     /* ---- gathered derivatives ---- */
     float s_lo = ps[idx * st];
     float s_hi = (idx + 1 < K) ? ps[(idx + 1 < K ? idx + 1 : 0) * st] : s_last;
-    const bgk_f2 sp = bgk_softplusf2((bgk_f2){s_lo, s_hi}, c.beta);
+    const bgk_f2 sp = SpMath<HW>::softplus2((bgk_f2){s_lo, s_hi}, c.beta);
     g.template step<S0 + 18>();
     float d_i = c.min_d + sp.x;
     float d_ip1 = c.min_d + sp.y;
@@ -336,7 +399,7 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
     float cw_i, W_i, ch_i, H_i;
     if (INV) { cw_i = a_i; W_i = A_i; ch_i = b_i; H_i = B_i; }
     else { ch_i = a_i; H_i = A_i; cw_i = b_i; W_i = B_i; }
-    float delta = bgk_div_safe(H_i, W_i);
+    float delta = SpMath<HW>::div(H_i, W_i);
     float S = d_i + d_ip1 - 2.0f * delta;
     float outv, l;
     if (!INV) {
@@ -345,22 +408,22 @@ __device__ __forceinline__ float rqs_element_piped(G& g, float x, const float* p
         float b = H_i * d_i - dx * S;
         float cc = -delta * dx;
         float disc = b * b - 4.0f * a * cc;
-        float root = bgk_div_safe(2.0f * cc, -b - __builtin_sqrtf(disc));
+        float root = SpMath<HW>::div(2.0f * cc, -b - __builtin_sqrtf(disc));
         outv = root * W_i + cw_i;
         float t1mt = root * (1.0f - root);
         float den = delta + S * t1mt;
         float omr = 1.0f - root;
         float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
-        { const bgk_f2 lg = bgk_logf2((bgk_f2){num, den}); l = -(lg.x - 2.0f * lg.y); }
+        { const bgk_f2 lg = SpMath<HW>::log2((bgk_f2){num, den}); l = -(lg.x - 2.0f * lg.y); }
     } else {
-        float theta = bgk_div_safe(x - cw_i, W_i);
+        float theta = SpMath<HW>::div(x - cw_i, W_i);
         float t1mt = theta * (1.0f - theta);
         float numer = H_i * (delta * (theta * theta) + d_i * t1mt);
         float den = delta + S * t1mt;
-        outv = ch_i + bgk_div_safe(numer, den);
+        outv = ch_i + SpMath<HW>::div(numer, den);
         float omt = 1.0f - theta;
         float num = (delta * delta) * (d_ip1 * (theta * theta) + 2.0f * delta * t1mt + d_i * (omt * omt));
-        { const bgk_f2 lg = bgk_logf2((bgk_f2){num, den}); l = lg.x - 2.0f * lg.y; }
+        { const bgk_f2 lg = SpMath<HW>::log2((bgk_f2){num, den}); l = lg.x - 2.0f * lg.y; }
     }
     g.template step<S0 + 20>();
     *lad = l;
@@ -378,7 +441,7 @@ __device__ __forceinline__ void zero4(f32x16 (&acc)[4]) {
  * written branch-free so that the whole routine is ONE basic block and can be software-pipelined
  * under the next chunk's MFMAs.  Invalid (q >= nd) slots evaluate dim 0 of the chunk and are
  * discarded (their output goes to the dummy row d of s_y). */
-template <int INV, int IT, class G, int ST = 32>
+template <int INV, int IT, class G, int ST = 32, bool HW = false>
 __device__ __forceinline__ void spline_slot(G& g, const FusedArgs& a, const float* s_p, float* s_y, int c, int nd,
                                             int hh, int j, int rows, float& run, int& oob_local, int (&bins)[3]) {
     const int q = 2 * IT + hh;
@@ -394,7 +457,7 @@ __device__ __forceinline__ void spline_slot(G& g, const FusedArgs& a, const floa
     int bin, oob;
     float lad;
     const float x = s_y[dim * SROW + j];
-    const float o = rqs_element_piped<INV, IT * HOOKS, G, ST>(g, x, pw, ph, ps, s_last, a.cfg, &lad, &bin, &oob);
+    const float o = rqs_element_piped<INV, IT * HOOKS, G, ST, HW>(g, x, pw, ph, ps, s_last, a.cfg, &lad, &bin, &oob);
     s_y[(valid ? dim : a.d) * SROW + j] = o;
     oob_local += (valid && j < rows) ? oob : 0;
     bins[IT] = bin;
@@ -413,18 +476,18 @@ __device__ __forceinline__ void spline_slot(G& g, const FusedArgs& a, const floa
 /* Spline of one parameter chunk held in LDS: 3 element evaluations per lane (q = hh, hh+2, hh+4), branch-free
  * (invalid slots evaluate dim 0 of the chunk and are discarded into the dummy row d of s_y), with the hook
  * policy G running the overlapped GEMM's k-steps 0..62 in between. */
-template <int INV, class G, int ST = 32>
+template <int INV, class G, int ST = 32, bool HW = false>
 __device__ __forceinline__ void spline_chunk(G& g, const FusedArgs& a, const float* s_p, float* s_y, int c, int nd,
                                              int hh, int j, int rows, float& run, int& oob_local, int (&bins)[3]) {
-    spline_slot<INV, 0, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 0, G, ST, HW>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #if BGK_PIPE_SPLINE
-    spline_slot<INV, 1, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
-    spline_slot<INV, 2, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 1, G, ST, HW>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 2, G, ST, HW>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #else
     /* slots whose two dims both lie beyond the chunk's last dim are skipped (wave-uniform branch) */
     bins[1] = bins[2] = 0;
-    if (nd > 2) spline_slot<INV, 1, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
-    if (nd > 4) spline_slot<INV, 2, G, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    if (nd > 2) spline_slot<INV, 1, G, ST, HW>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+    if (nd > 4) spline_slot<INV, 2, G, ST, HW>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #endif
 }
 
@@ -854,7 +917,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
             int bins[3] = {0, 0, 0};
             NoGemm g;
 #if !(BGK_ABL & 1)
-            spline_chunk<INV, NoGemm, ST>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+            spline_chunk<INV, NoGemm, ST, true>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #else
             run += s_p[(lane & 127) * ST + j];
 #endif
