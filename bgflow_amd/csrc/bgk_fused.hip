@@ -1,6 +1,15 @@
-/* bgk_fused.hip -- one-launch spline coupling layer: DenseNet conditioner on the f32 matrix cores
+/* bgk_fused.hip -- one-launch spline coupling layer: DenseNet conditioner on the matrix cores
  * + rational-quadratic spline epilogue.  The conditioner activations and the spline parameters
  * never touch HBM: per sample the kernel reads d_c + d floats and writes d (+1) floats.
+ *
+ * Two kernels share the tiling and the spline code:
+ *   coupling_rqs_dense_kernel     (first half of this file)  f32-input MFMA, reproducible f32 arithmetic throughout:
+ *                                 bit-identical to the CPU oracle (gemm_mode "f32");
+ *   coupling_rqs_dense_h2_kernel  (second half)  conditioner GEMMs in split-f16 form (or single bf16) on the f16 matrix
+ *                                 cores, hidden activations and the spline's exp / log on the hardware transcendentals
+ *                                 (SpMath<true>): the shipped default, f32-class accuracy, 2.1x faster;
+ *                                 also the training forward (SAVE) that writes pre-activations and spline parameters.
+ * The notes below describe the first kernel.
  *
  * Roofline: MFMA (f32-input v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s dense peak): 2*(n_in*H0 + H0*H1 +
  * H1*NCp) flops per sample against 4*(d_c + 2d + 2) bytes -> arithmetic intensity >> the
@@ -25,7 +34,7 @@
  *     chunks of 128 columns = 5 dims for K = 8; a chunk goes once through wave-private LDS
  *     ([row][32 samples], conflict-free both ways) to regroup from "lane = column" to
  *     "lane = (sample, dim)" for the spline.
- * Every f32 operation is the same IEEE op in the same order as oracle/bgo_impl.h -> bit-exact
+ * In this kernel every f32 operation is the same IEEE op in the same order as oracle/bgo_impl.h -> bit-exact
  * parity (MFMA f32 = k-ordered fma chain, one rounding per product).
  */
 #include "bgk_mfma_h2.h"
