@@ -50,7 +50,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define BGK_PIPE_ACT 0
 #endif
 #ifndef BGK_ABL
-#define BGK_ABL 0   /* timing ablations of the split-f16 kernel (tools/ablate_h2.sh): 1 no spline, 2 no chunk GEMMs, 4 no activation, 8 no layer-2 LDS transpose */
+#define BGK_ABL 0   /* timing ablations of the split-f16 kernel (tools/ablate_h2.sh): 1 no spline, 2 no chunk GEMMs, 4 no activation,
+                     * 8 no layer-2 LDS transpose, 16 A operands always from block 0 (L1-resident / hoisted: -3.5 % only, i.e. the
+                     * weight stream from L2 is not what limits the GEMM phases; a 3-deep ring gave nothing either) */
 #endif
 
 constexpr int FW = 4;                 /* waves per workgroup */
@@ -698,8 +700,13 @@ template <bool BF>
 __device__ __forceinline__ void h2_load(AFrag& f, const uint4* W, int s, int lane) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
+#if (BGK_ABL & 16)   /* timing experiment: every k-step re-reads block 0 (L1-resident): is the A stream the limiter? */
+        f.v[m][0] = W[((0 * 4 + m) * 2 + 0) * 64 + lane + (s & 0)];
+        if constexpr (!BF) f.v[m][1] = W[((0 * 4 + m) * 2 + 1) * 64 + lane + (s & 0)];
+#else
         f.v[m][0] = W[((s * 4 + m) * 2 + 0) * 64 + lane];
         if constexpr (!BF) f.v[m][1] = W[((s * 4 + m) * 2 + 1) * 64 + lane];
+#endif
     }
 }
 __device__ __forceinline__ void h2_load_bias(AFrag& f, const uint4* W, int lane) {
