@@ -411,3 +411,35 @@ def test_reference_style_import_paths_resolve():
     with pytest.raises(ImportError):
         importlib.import_module("bgflow_amd.nn.flow.dynamics")      # outside the hot path: not provided
 
+
+def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
+    """status codes and bgk_last_error of the entry points: validation happens before any launch, so this runs on a CPU box
+    (fake non-null pointers are never dereferenced on these paths)"""
+    L = hip_lib
+    P1 = ctypes.c_void_p(0x1000)         # a non-null placeholder
+    err = lambda: L.bgk_last_error().decode(errors="replace")      # noqa: E731
+    # empty batches are a no-op
+    assert L.bgk_rqs_transform(P1, 17, P1, 425, 425, P1, 0, 17, 8, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None) == 0
+    assert L.bgk_affine_transform(P1, 4, P1, 4, P1, 4, P1, 0, 0, 0, 0, 4, P1, 4, P1, 0, None) == 0
+    # bad sizes / null pointers -> BGK_EINVAL with a message
+    assert L.bgk_rqs_transform(P1, 17, P1, 425, 425, P1, -1, 17, 8, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None) == -1
+    assert "bad sizes" in err()
+    assert L.bgk_rqs_transform(None, 17, P1, 425, 425, P1, 4, 17, 8, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None) == -1
+    assert "null pointer" in err()
+    assert L.bgk_rqs_transform(P1, 17, P1, 425, 425, P1, 4, 17, 8, 0, 0.0, 1.0, 0.0, 1.0, 0.2, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None) == -1
+    assert "Minimal bin width/height too large" in err()                      # the reference's ValueError text (nflows)
+    assert L.bgk_affine_transform(P1, 4, P1, 4, P1, 4, P1, 0, 1, 0, 8, 4, P1, 4, P1, 0, None) == -1
+    assert "Scaling is not compatible with periodicity." in err()             # transformer/affine.py:26-27
+    # valid requests outside a fused kernel's envelope -> BGK_EUNSUPPORTED (callers fall back to the generic kernels)
+    assert L.bgk_rqs_backward(P1, 17, P1, 212, 212, P1, 8, 17, 4, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 212, None) == -2
+    assert "n_bins = 8" in err()
+    tail = (P1, 17, 8, 17, 8, 0, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None)
+    assert L.bgk_coupling_rqs_dense_h2(P1, 17, 17, 0, P1, P1, P1, 1.0, 1.0, 1.0, None, 0, 64, 64, 1, *tail) == -2
+    assert "hidden=(128,128)" in err()
+    assert L.bgk_coupling_rqs_dense_h2(P1, 17, 17, 0, P1, P1, P1, 1.0, 1.0, 1.0, None, 7, 128, 128, 1, *tail) == -1
+    assert "operand_dtype" in err()
+    assert L.bgk_coupling_affine_dense_h2(P1, 32, 32, 0, P1, P1, P1, 1.0, 1.0, 1.0, 2, P1, P1, P1, 1.0, 1.0, 1.0, 3,
+                                          256, P1, 0, 0, 0, P1, 32, 8, 32, P1, 32, P1, 0, None) == -2
+    assert L.bgk_dense_backward_dx(P1, 425, 425, P1, P1, P1, 120, 120, 0, P1, P1, P1, P1, 1, 8, P1, P1, P1, P1, None, 0, None) == -2
+    assert L.bgk_column_sum(P1, 4, 8, 0, P1, 4, P1, None) == -1
+
