@@ -17,6 +17,7 @@ i32, i64, f32, f64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.
 _SIGNATURES = {
     "bgk_abi_version": (ctypes.c_int, []),
     "bgk_last_error": (ctypes.c_char_p, []),
+    "bgk_set_option": (ctypes.c_int, [i32, i32]),
     "bgk_detmath_probe": (ctypes.c_int, [vp, i64, i32, vp, vp]),
     "bgk_rqs_transform": (ctypes.c_int, [vp, i64, vp, i64, i32, vp, i64, i32, i32, i32,
                                          f64, f64, f64, f64, f64, f64, f64, i32,

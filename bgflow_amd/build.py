@@ -1,7 +1,8 @@
 """Build libbgflow_amd.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc.
 
 hipcc cross-compiles without a GPU; the resulting .so stays IN-TREE (bgflow_amd/libbgflow_amd.so,
-git-ignored) so that it travels to the GPU box with the repository snapshot.
+git-ignored) so that it travels to the GPU box with the repository snapshot.  Every translation unit is
+compiled to its own object (in parallel, rebuilt only when it or a header changed), then linked.
 
     python -m bgflow_amd.build [--force]
 """
@@ -9,37 +10,66 @@ import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbgflow_amd.so")
 
 # -ffp-contract=off + correctly rounded div/sqrt: the f32 arithmetic of the kernels is then the same
 # sequence of IEEE ops as the CPU oracle's (bit-identical spline bin indices); see csrc/bgk_detmath.h.
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
     "-Wno-comment",
 ]
+# per-TU additions.  bgk_fused2.hip threads VALU work between MFMAs: packed-f32 ops (which the SLP vectoriser
+# would form from adjacent scalar ops) do not overlap with the matrix pipe on gfx950 (tools/ubench/issue_bench).
+TU_FLAGS = {"bgk_fused2.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+
+
+def _obj(src, tag):
+    return os.path.join(OBJ, os.path.basename(src) + tag + ".o")
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    return any(os.path.getmtime(p) > t for p in deps)
+    return any(os.path.getmtime(p) > t for p in sources() + _headers())
 
 
 def build_extension(force=False, verbose=False):
-    if not force and not os.environ.get("BGK_EXTRA_FLAGS") and not _stale():
+    extra = os.environ.get("BGK_EXTRA_FLAGS", "").split()
+    if not force and not extra and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("BGK_EXTRA_FLAGS", "").split() + ["-o", LIB] + sources()
+    os.makedirs(OBJ, exist_ok=True)
+    tag = ("." + "".join(c if c.isalnum() else "_" for c in " ".join(extra))) if extra else ""
+    hdr_t = max(os.path.getmtime(p) for p in _headers())
+
+    def compile_one(src):
+        obj = _obj(src, tag)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            return obj
+        cmd = [hipcc] + HIPCC_FLAGS + TU_FLAGS.get(os.path.basename(src), []) + extra + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "bgk_common.h"
+#include "bgk_fused2.h"
 
 static thread_local char g_err[512] = "";
 
@@ -14,6 +15,16 @@ void bgk_set_error(const char* fmt, ...) {
 
 extern "C" int bgk_abi_version(void) { return 1; }
 extern "C" const char* bgk_last_error(void) { return g_err; }
+
+extern "C" int bgk_set_option(int32_t option, int32_t value) {
+    if (option == 1 && (value == 1 || value == 2)) {
+        const int prev = bgk_h2_variant;
+        bgk_h2_variant = value;
+        return prev;
+    }
+    bgk_set_error("bgk_set_option: unknown option %d / value %d", option, value);
+    return BGK_EINVAL;
+}
 
 namespace {
 __global__ void detmath_probe_kernel(const float* x, int64_t n, int which, float* out) {

@@ -38,6 +38,7 @@
  * parity (MFMA f32 = k-ordered fma chain, one rounding per product).
  */
 #include "bgk_mfma_h2.h"
+#include "bgk_fused2.h"
 
 namespace {
 
@@ -780,8 +781,12 @@ __device__ __forceinline__ void h2_gemm_run(f32x16 (&out)[4], H2Ring& r, const B
 #pragma unroll
     for (int s = 0; s < H2_STEPS; ++s) {
         constexpr int D = H2_RING - 1;
+#if (BGK_ABL & 32)   /* timing experiment: the A stream of steps 2.. is not loaded (is the vector-memory path the limiter?) */
+        if (s == 0) h2_load<BF>(r.f[(s + D) % H2_RING], W, s + D, lane);
+#else
         if (s + D < H2_STEPS) h2_load<BF>(r.f[(s + D) % H2_RING], W, s + D, lane);
         else if (s + D == H2_STEPS) h2_load_bias(r.f[(s + D) % H2_RING], W, lane);
+#endif
         __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch above this step's MFMAs */
         h2_mfma<BF>(out, r.f[s % H2_RING], b.hi[s], b.lo[s]);
     }
@@ -1063,6 +1068,10 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
     if (B == 0) return 0;
+    if (bgk_h2_variant == 2 && z0 == nullptr && operand_dtype == 0)   /* split-f16 inference: the second-generation kernel */
+        return bgk_launch_rqs_dense_h2v2(what, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, act, y, ldy, B, d, circ_mask,
+                                         inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
+                                         identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream);
     FusedArgsH2 ah;
     FusedArgs& a = ah.f;
     a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;

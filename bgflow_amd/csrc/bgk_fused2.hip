@@ -1,0 +1,641 @@
+/* bgk_fused2.hip -- second-generation one-launch spline coupling layer (inference, split-f16 conditioner GEMMs).
+ *
+ * Same contract, same packed operands (dense.py::pack_dense_for_fused_h2 / bgk_pack_dense_h2) and the same tiling as
+ * coupling_rqs_dense_h2_kernel (bgk_fused.hip): a wave owns 32 samples for the whole layer, 4 independent waves per
+ * workgroup, 2 workgroups per CU.  What changed, and why (measurements: tools/ubench/issue_bench, profiles/README.md r02):
+ *
+ *  1. MFMA and VALU time were ADDITIVE in the first kernel (30 % matrix pipe busy + 52 % VALU active + waits).  On
+ *     gfx950 a wave issues one instruction per ~4-5 cycles, the f16 MFMA holds the matrix pipe for 32 cycles, and plain
+ *     (non-packed) f32 VALU work placed in the same wave between consecutive MFMAs hides ~60-75 % of the smaller of
+ *     the two -- packed-f32 VALU ops (v_pk_*) hide nothing.  So every GEMM after layer 0 is issued as a stream of
+ *     single MFMA "events" threaded through the VALU work that is independent of it:
+ *        layer-1 GEMM          <-> activation + f16 hi/lo split of the layer-0 tiles 1..3   (k-step s needs tile s/2 only)
+ *        layer-2 chunk-0 GEMM  <-> activation + split of the layer-1 tiles 1..3
+ *        layer-2 chunk c+1     <-> spline of chunk c (3 elements per lane, 34 hook points each)
+ *     The placement is pinned with sched_barrier(0) fences; the weight (A) fragments are loaded per (k-step, tile)
+ *     through a 4-deep register ring (32 VGPRs instead of 64), SGPR-base addressing, no per-load address arithmetic.
+ *  2. Fewer VALU instructions (first kernel: 6.3 k per 32-sample tile; packed ops avoided altogether):
+ *     - the spline's normalisation is algebraically regrouped: knot_k = low + span*min*(k+1) + (span*scale / sum e) * prefix_k(e):
+ *       7 adds + 7 fma per set instead of 8 exactly rounded divisions + scale + cumsum + affine map; the other set only
+ *       evaluates the two knots of the bin found (select chains on the comparison masks);
+ *     - the exact power-of-two unscale of the last GEMM is folded into the exp2 / softplus constants;
+ *     - accumulators start from the inline-constant 0 C operand (no zero fills), dead tiles of the last chunk are
+ *       not computed, staging index math uses a magic-number division.
+ *  Accuracy class: like the first split-f16 kernel (hardware exp2 / log2 / rcp / sqrt with one Newton step on the
+ *  reciprocals): not bit-identical to the oracle; parity is asserted per sample at 1e-5 relative on log|det J| and
+ *  bin indices may differ only where x is within rounding distance of a knot (tests/test_gpu_parity.py).
+ *  The exact-f32 kernel (bgk_fused.hip, gemm_mode "f32") stays the bit-exact reference path.
+ */
+#include "bgk_common.h"
+#include "bgk_fused2.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) char* gptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gptr4_t;
+
+constexpr int FW = 4;                 /* waves per workgroup */
+constexpr int FTHREADS = FW * 64;
+constexpr int KB = 8;                 /* spline bins */
+constexpr int PPD = 3 * KB + 1;       /* packed rows per transformed dim = 25 */
+constexpr int DPC = 128 / PPD;        /* dims per 128-row chunk = 5 */
+constexpr int SROW = 33;              /* padded row stride of the y / input tiles */
+constexpr int ST = 32;                /* row stride of the parameter chunk in LDS */
+constexpr int KS = 8;                 /* k16-steps of a 128-wide hidden layer */
+constexpr int GBLK = KS * 8 + 4;      /* 1 KiB blocks per packed 128-row GEMM incl. the 4 bias blocks */
+constexpr int RD = 4;                 /* A-fragment ring depth in tile-steps */
+constexpr int EH = 34;                /* hook points per spline element */
+
+struct SetK { float gnum, low, high, dstep; float kc[7]; };   /* gnum = span * scale, dstep = span * min_bin, kc[k] = low + dstep (k + 1) */
+
+struct V2Args {
+    const float* cond; int64_t ldc; int d_c; int periodic; uint32_t magic_dc;
+    const float* y; int64_t ldy; float* out; int64_t ldo; int d; uint32_t magic_d;
+    int64_t B; float* dlogp; int accumulate; int32_t* bin_idx; int32_t* oob_count;
+    const uint4* A0; const uint4* A1; const uint4* A2; int S0; int n_chunks; int last_tiles;
+    float c0, c1, c2; const float* cs_dev;
+    uint64_t circ_mask;
+    float left, right;
+    SetK sa, sb;                      /* searched set / other set */
+    float beta, kout, min_d;          /* softplus: log(1 + exp(beta s)) / beta = log2(1 + exp2(beta log2e s)) * kout */
+    int lds_per_wave;
+};
+
+struct BFrag { h16x8 hi[KS], lo[KS]; };     /* a 128-wide activation vector as B operands: 64 VGPRs */
+struct TFrag { u32x4 hi, lo; };             /* A operand of one (k-step, tile): 8 VGPRs */
+
+__device__ __forceinline__ int drow(int m, int r, int hh) { return 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+/* block BLK (1 KiB) of a packed operand: uniform SGPR base (advanced by SALU in 4 KiB steps) + per-lane VGPR offset + immediate */
+template <int BLK>
+__device__ __forceinline__ u32x4 ld_block(const uint4* base, unsigned voff) {
+    unsigned long long gb = (unsigned long long)base + (unsigned long long)((BLK * 1024) & ~4095);
+    asm volatile("" : "+s"(gb));
+    return *(gptr4_t)((gptr_t)gb + voff + ((BLK * 1024) & 4095));
+}
+/* blocks BLK (even) and BLK + 1: the hi / lo parts of one (k-step, tile) share their 4 KiB group and its SGPR base */
+template <int BLK>
+__device__ __forceinline__ void ld_pair(u32x4& hi, u32x4& lo, const uint4* base, unsigned voff) {
+    static_assert((BLK & 1) == 0, "hi / lo pairs start at even blocks");
+    unsigned long long gb = (unsigned long long)base + (unsigned long long)((BLK * 1024) & ~4095);
+    asm volatile("" : "+s"(gb));
+    hi = *(gptr4_t)((gptr_t)gb + voff + ((BLK * 1024) & 4095));
+    lo = *(gptr4_t)((gptr_t)gb + voff + ((BLK * 1024) & 4095) + 1024);
+}
+
+/* ---- one 128-row (NT live tiles) x 128 GEMM as a stream of single-MFMA events ----------------------------------------
+ * tile-step T = s * NT + m (k-step s, tile m), then NT bias tile-steps; event E = 3 T + p: p = 0 lo*hi, 1 hi*lo, 2 hi*hi
+ * (small terms first), bias events one MFMA each.  The ring slot of tile-step T is refilled with T + RD right after its
+ * last MFMA has been issued. */
+template <int NT>
+struct Live {
+    static constexpr int NTS = KS * NT;           /* product tile-steps */
+    static constexpr int NEV = 3 * NTS + NT;      /* events */
+    f32x16 (&out)[4];
+    const BFrag& b;
+    const uint4* W;
+    unsigned voff;
+    TFrag (&ring)[RD];
+
+    template <int T>
+    __device__ __forceinline__ void load() {
+        if constexpr (T < NTS) {
+            constexpr int s = T / NT, m = T % NT;
+            ld_pair<(s * 4 + m) * 2>(ring[T % RD].hi, ring[T % RD].lo, W, voff);
+        } else if constexpr (T < NTS + NT) {
+            ring[T % RD].hi = ld_block<KS * 8 + (T - NTS)>(W, voff);
+        }
+    }
+    __device__ __forceinline__ void start() {
+        __builtin_amdgcn_sched_barrier(0);
+        load<0>(); load<1>(); load<2>(); load<3>();
+        __builtin_amdgcn_sched_barrier(0);
+        static_assert(RD == 4, "prologue written for RD = 4");
+    }
+    template <int E>
+    __device__ __forceinline__ void event() {
+        __builtin_amdgcn_sched_barrier(0);      /* pin the MFMA and the ring refill: the scheduler would sink the loads to their uses */
+        if constexpr (E < 3 * NTS) {
+            constexpr int T = E / 3, p = E % 3, s = T / NT, m = T % NT;
+            const TFrag& f = ring[T % RD];
+            const h16x8 a = __builtin_bit_cast(h16x8, p == 0 ? f.lo : f.hi);
+            const h16x8 bb = p == 1 ? b.lo[s] : b.hi[s];
+            if constexpr (s == 0 && p == 0) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bb, z, 0, 0, 0);
+            } else {
+                out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bb, out[m], 0, 0, 0);
+            }
+            if constexpr (p == 2) load<T + RD>();
+        } else if constexpr (E < NEV) {
+            constexpr int m = E - 3 * NTS, T = NTS + m;
+            const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[T % RD].hi), one2, out[m], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int E0, int E1>
+    __device__ __forceinline__ void events() {
+        if constexpr (E0 < E1) {
+            event<E0>();
+            events<E0 + 1, E1>();
+        }
+    }
+    /* hook HK of NH: its share of the NEV events, fenced so that neither the MFMAs nor the surrounding VALU work move */
+    template <int HK, int NH>
+    __device__ __forceinline__ void hook() {
+        constexpr int e0 = (HK * NEV) / NH, e1 = ((HK + 1) * NEV) / NH;
+        if constexpr (e0 < e1) events<e0, e1>();
+    }
+};
+struct NoLive {
+    template <int HK, int NH> __device__ __forceinline__ void hook() {}
+};
+
+/* hook adapters: map the hook index of a code region (activation of one tile: 8 hooks; spline slot: EH hooks) to the
+ * hook space of the overlapped GEMM */
+template <class G, int BASE, int NH>
+struct Hooks {
+    G& g;
+    template <int I> __device__ __forceinline__ void at() { g.template hook<BASE + I, NH>(); }
+};
+
+/* ---- hidden activation (hardware exp2 / rcp) of x = t * c and split into f16 hi + lo ---- */
+template <int ACT>
+__device__ __forceinline__ float act_hw(float x) {
+    if constexpr (ACT == 1) {           /* SiLU */
+        const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896341f);
+        return x * __builtin_amdgcn_rcpf(1.0f + e);
+    } else if constexpr (ACT == 2) {    /* ReLU */
+        return x > 0.0f ? x : 0.0f;
+    } else {                            /* tanh = 1 - 2 / (1 + exp(2x)) */
+        const float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681f);
+        return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+    }
+}
+
+/* tile T of a layer output (accumulator layout, 16 values per lane) -> B operands of k-steps 2T and 2T + 1; three hooks per pair */
+template <int ACT, int T, int P, class H>
+__device__ __forceinline__ void act_split_pair(H& hk, const f32x16& t, float c, BFrag& bf) {
+    constexpr int r = 2 * P;
+    float a0 = act_hw<ACT>(t[r] * c);
+    hk.template at<3 * P>();
+    float a1 = act_hw<ACT>(t[r + 1] * c);
+    hk.template at<3 * P + 1>();
+    if constexpr (ACT != 3) {       /* SiLU / ReLU outputs are bounded below; keep the f16 conversion finite above */
+        a0 = __builtin_fminf(a0, 65000.0f); a1 = __builtin_fminf(a1, 65000.0f);
+    }
+    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+    constexpr int s = 2 * T + (r >> 3), e = r & 7;
+    bf.hi[s][e] = h0; bf.hi[s][e + 1] = h1;
+    bf.lo[s][e] = (_Float16)(a0 - (float)h0); bf.lo[s][e + 1] = (_Float16)(a1 - (float)h1);
+    hk.template at<3 * P + 2>();
+}
+template <int ACT, int T, class H>
+__device__ __forceinline__ void act_split_tile(H hk, const f32x16& t, float c, BFrag& bf) {
+    act_split_pair<ACT, T, 0>(hk, t, c, bf); act_split_pair<ACT, T, 1>(hk, t, c, bf);
+    act_split_pair<ACT, T, 2>(hk, t, c, bf); act_split_pair<ACT, T, 3>(hk, t, c, bf);
+    act_split_pair<ACT, T, 4>(hk, t, c, bf); act_split_pair<ACT, T, 5>(hk, t, c, bf);
+    act_split_pair<ACT, T, 6>(hk, t, c, bf); act_split_pair<ACT, T, 7>(hk, t, c, bf);
+}
+
+/* ---- spline element, hardware-transcendental / regrouped form ------------------------------------------------------
+ * pa / pb / ps: the element's 8 unnormalised searched-set / other-set / slope rows in the LDS chunk (row stride ST), UNSCALED
+ * accumulator values (true parameter = value * c2; kL = c2 log2 e, kz = c2 beta log2 e fold the factor).  ps[8 ST] is the
+ * non-circular extra slope row.  Follows nflows' rational_quadratic_spline like bgk_rqs_element. */
+struct SpK { float kL, kz, c2; };
+
+__device__ __forceinline__ float fdiv_hw(float n, float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = n * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+__device__ __forceinline__ float rcp_nr(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+
+template <int INV, class H>
+__device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const float* pb, const float* ps, bool circ,
+                                          const V2Args& a, const SpK& k, float* lad, int* bin, int* oob) {
+    float va[KB], vb[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) va[i] = pa[i * ST];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) vb[i] = pb[i * ST];
+    *oob = (x < a.left) | (x > a.right);
+    x = __builtin_amdgcn_fmed3f(x, a.left, a.right);
+    /* ---- searched set: softmax numerators, running sums, the 7 interior knots, comparison masks ---- */
+    float mA = __builtin_fmaxf(__builtin_fmaxf(va[0], va[1]), va[2]);
+    mA = __builtin_fmaxf(__builtin_fmaxf(mA, va[3]), va[4]);
+    mA = __builtin_fmaxf(__builtin_fmaxf(mA, va[5]), va[6]);
+    mA = __builtin_fmaxf(mA, va[7]);
+    const float nmA = -(mA * k.kL);
+    hk.template at<0>();
+    float E[KB];
+    E[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(va[0], k.kL, nmA));
+    E[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(va[1], k.kL, nmA));
+    E[2] = __builtin_amdgcn_exp2f(__builtin_fmaf(va[2], k.kL, nmA));
+    hk.template at<1>();
+    E[3] = __builtin_amdgcn_exp2f(__builtin_fmaf(va[3], k.kL, nmA));
+    E[4] = __builtin_amdgcn_exp2f(__builtin_fmaf(va[4], k.kL, nmA));
+    E[5] = __builtin_amdgcn_exp2f(__builtin_fmaf(va[5], k.kL, nmA));
+    hk.template at<2>();
+    E[6] = __builtin_amdgcn_exp2f(__builtin_fmaf(va[6], k.kL, nmA));
+    E[7] = __builtin_amdgcn_exp2f(__builtin_fmaf(va[7], k.kL, nmA));
+    E[1] += E[0]; E[2] += E[1];
+    hk.template at<3>();
+    E[3] += E[2]; E[4] += E[3]; E[5] += E[4]; E[6] += E[5]; E[7] += E[6];
+    hk.template at<4>();
+    const float gA = a.sa.gnum * rcp_nr(E[7]);
+    float kn[7];
+    kn[0] = __builtin_fmaf(E[0], gA, a.sa.kc[0]);
+    kn[1] = __builtin_fmaf(E[1], gA, a.sa.kc[1]);
+    hk.template at<5>();
+    kn[2] = __builtin_fmaf(E[2], gA, a.sa.kc[2]);
+    kn[3] = __builtin_fmaf(E[3], gA, a.sa.kc[3]);
+    kn[4] = __builtin_fmaf(E[4], gA, a.sa.kc[4]);
+    kn[5] = __builtin_fmaf(E[5], gA, a.sa.kc[5]);
+    kn[6] = __builtin_fmaf(E[6], gA, a.sa.kc[6]);
+    hk.template at<6>();
+    const bool g0 = x >= kn[0], g1 = x >= kn[1], g2 = x >= kn[2], g3 = x >= kn[3], g4 = x >= kn[4], g5 = x >= kn[5], g6 = x >= kn[6];
+    hk.template at<7>();
+    int idx = (g0 ? 1 : 0) + (g1 ? 1 : 0) + (g2 ? 1 : 0) + (g3 ? 1 : 0) + (g4 ? 1 : 0) + (g5 ? 1 : 0) + (g6 ? 1 : 0);
+    *bin = idx;
+    hk.template at<8>();
+    /* the two slopes of the bin (dynamic LDS rows; circular dims wrap the last knot's slope to row 0) */
+    const int j1 = circ ? ((idx + 1) & 7) : (idx + 1);
+    const float s_lo = ps[idx * ST], s_hi = ps[j1 * ST];
+    float lo = a.sa.low;
+    lo = g0 ? kn[0] : lo; lo = g1 ? kn[1] : lo; lo = g2 ? kn[2] : lo;
+    hk.template at<9>();
+    lo = g3 ? kn[3] : lo; lo = g4 ? kn[4] : lo; lo = g5 ? kn[5] : lo; lo = g6 ? kn[6] : lo;
+    hk.template at<10>();
+    float hi = a.sa.high;
+    hi = g6 ? hi : kn[6]; hi = g5 ? hi : kn[5]; hi = g4 ? hi : kn[4]; hi = g3 ? hi : kn[3];
+    hk.template at<11>();
+    hi = g2 ? hi : kn[2]; hi = g1 ? hi : kn[1]; hi = g0 ? hi : kn[0];
+    const float A_i = hi - lo;
+    /* ---- other set: only knot[idx], knot[idx + 1] ---- */
+    float mB = __builtin_fmaxf(__builtin_fmaxf(vb[0], vb[1]), vb[2]);
+    hk.template at<12>();
+    mB = __builtin_fmaxf(__builtin_fmaxf(mB, vb[3]), vb[4]);
+    mB = __builtin_fmaxf(__builtin_fmaxf(mB, vb[5]), vb[6]);
+    mB = __builtin_fmaxf(mB, vb[7]);
+    const float nmB = -(mB * k.kL);
+    float F[KB];
+    F[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[0], k.kL, nmB));
+    hk.template at<13>();
+    F[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[1], k.kL, nmB));
+    F[2] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[2], k.kL, nmB));
+    F[3] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[3], k.kL, nmB));
+    hk.template at<14>();
+    F[4] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[4], k.kL, nmB));
+    F[5] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[5], k.kL, nmB));
+    F[6] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[6], k.kL, nmB));
+    hk.template at<15>();
+    F[7] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[7], k.kL, nmB));
+    F[1] += F[0]; F[2] += F[1]; F[3] += F[2];
+    hk.template at<16>();
+    F[4] += F[3]; F[5] += F[4]; F[6] += F[5]; F[7] += F[6];
+    const float rB = __builtin_amdgcn_rcpf(F[7]);
+    hk.template at<17>();
+    const float gB = a.sb.gnum * __builtin_fmaf(__builtin_fmaf(-F[7], rB, 1.0f), rB, rB);
+    float Flo = 0.0f;
+    Flo = g0 ? F[0] : Flo; Flo = g1 ? F[1] : Flo; Flo = g2 ? F[2] : Flo;
+    hk.template at<18>();
+    Flo = g3 ? F[3] : Flo; Flo = g4 ? F[4] : Flo; Flo = g5 ? F[5] : Flo; Flo = g6 ? F[6] : Flo;
+    hk.template at<19>();
+    float Fhi = F[7];
+    Fhi = g6 ? Fhi : F[6]; Fhi = g5 ? Fhi : F[5]; Fhi = g4 ? Fhi : F[4]; Fhi = g3 ? Fhi : F[3];
+    hk.template at<20>();
+    Fhi = g2 ? Fhi : F[2]; Fhi = g1 ? Fhi : F[1]; Fhi = g0 ? Fhi : F[0];
+    const float cb = __builtin_fmaf((float)idx, a.sb.dstep, a.sb.low);
+    hk.template at<21>();
+    const float b_i = __builtin_fmaf(Flo, gB, cb);
+    float b_ip1 = __builtin_fmaf(Fhi, gB, cb + a.sb.dstep);
+    b_ip1 = g6 ? a.sb.high : b_ip1;
+    const float B_i = b_ip1 - b_i;
+    /* ---- derivatives: min_d + softplus(beta s) / beta ---- */
+    const float z0 = s_lo * k.kz;                           /* log2(e) beta s_true */
+    hk.template at<22>();
+    const float ez0 = __builtin_amdgcn_exp2f(z0);
+    float lg0 = __builtin_amdgcn_logf(1.0f + ez0);          /* v_log_f32 = log2 */
+    asm volatile("" : "+v"(lg0));                           /* keep the select below a select (no divergent branch around the log) */
+    const float sm0 = ez0 * __builtin_fmaf(ez0, -0.5f, 1.0f) * 1.44269504088896341f;   /* log1p for tiny arguments */
+    hk.template at<23>();
+    float l0 = (ez0 < 2.44140625e-4f ? sm0 : lg0) * a.kout;
+    l0 = z0 > 28.8539008177792681f ? s_lo * k.c2 : l0;      /* beta s > 20: identity (torch softplus threshold) */
+    const float d_i = a.min_d + l0;
+    const float z1 = s_hi * k.kz;
+    hk.template at<24>();
+    const float ez1 = __builtin_amdgcn_exp2f(z1);
+    float lg1 = __builtin_amdgcn_logf(1.0f + ez1);
+    asm volatile("" : "+v"(lg1));
+    const float sm1 = ez1 * __builtin_fmaf(ez1, -0.5f, 1.0f) * 1.44269504088896341f;
+    hk.template at<25>();
+    float l1 = (ez1 < 2.44140625e-4f ? sm1 : lg1) * a.kout;
+    l1 = z1 > 28.8539008177792681f ? s_hi * k.c2 : l1;
+    const float d_ip1 = a.min_d + l1;
+    float cw_i, W_i, ch_i, H_i;
+    if (INV) { cw_i = lo; W_i = A_i; ch_i = b_i; H_i = B_i; }
+    else { ch_i = lo; H_i = A_i; cw_i = b_i; W_i = B_i; }
+    hk.template at<26>();
+    const float delta = fdiv_hw(H_i, W_i);
+    const float S = d_i + d_ip1 - 2.0f * delta;
+    hk.template at<27>();
+    float outv, l;
+    if (!INV) {
+        const float dx = x - ch_i;
+        const float dxS = dx * S;
+        const float qa = dxS + H_i * (delta - d_i);
+        const float qb = H_i * d_i - dxS;
+        hk.template at<28>();
+        const float qc = -delta * dx;
+        const float disc = qb * qb - 4.0f * qa * qc;
+        const float sq = __builtin_amdgcn_sqrtf(disc);
+        hk.template at<29>();
+        const float root = fdiv_hw(2.0f * qc, -qb - sq);
+        outv = __builtin_fmaf(root, W_i, cw_i);
+        hk.template at<30>();
+        const float omr = 1.0f - root;
+        const float t1mt = root * omr;
+        const float den = delta + S * t1mt;
+        const float lden = __builtin_amdgcn_logf(den);
+        hk.template at<31>();
+        const float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
+        hk.template at<32>();
+        l = (2.0f * lden - __builtin_amdgcn_logf(num)) * 0.693147180559945309f;
+    } else {
+        const float theta = fdiv_hw(x - cw_i, W_i);
+        const float omt = 1.0f - theta;
+        hk.template at<28>();
+        const float t1mt = theta * omt;
+        const float numer = H_i * (delta * (theta * theta) + d_i * t1mt);
+        const float den = delta + S * t1mt;
+        hk.template at<29>();
+        outv = ch_i + fdiv_hw(numer, den);
+        const float lden = __builtin_amdgcn_logf(den);
+        hk.template at<30>();
+        const float inner = d_ip1 * (theta * theta) + 2.0f * delta * t1mt;
+        hk.template at<31>();
+        const float num = (delta * delta) * (inner + d_i * (omt * omt));
+        hk.template at<32>();
+        l = (__builtin_amdgcn_logf(num) - 2.0f * lden) * 0.693147180559945309f;
+    }
+    hk.template at<33>();
+    *lad = l;
+    return outv;
+}
+
+/* slot IT of a chunk: element q = 2 IT + hh of sample j; invalid slots evaluate dim 0 of the chunk and are discarded */
+template <int INV, int IT, int NHK, class G>
+__device__ __forceinline__ void spline_slot(G& g, const V2Args& a, const SpK& k, const float* s_p, float* s_y, int c, int nd,
+                                            int hh, int j, int rows, float& run, int& oob_local, int (&bins)[3]) {
+    const int q = 2 * IT + hh;
+    const bool valid = q < nd;
+    const int qq = valid ? q : 0;
+    const int dim = c * DPC + qq;
+    const float* pw = s_p + (qq * PPD) * ST + j;
+    const float* ph = pw + KB * ST;
+    const float* ps = ph + KB * ST;
+    const bool circ = (a.circ_mask >> dim) & 1ull;
+    int bin, oob;
+    float lad;
+    const float x = s_y[dim * SROW + j];
+    Hooks<G, IT * EH, NHK> hk{g};
+    const float o = rqs_fast<INV>(hk, x, INV ? pw : ph, INV ? ph : pw, ps, circ, a, k, &lad, &bin, &oob);
+    s_y[(valid ? dim : a.d) * SROW + j] = o;
+    oob_local += (valid && j < rows) ? oob : 0;
+    bins[IT] = bin;
+    lad = valid ? lad : 0.0f;
+    /* dim 2 IT lives in the lower half-wave, dim 2 IT + 1 in the upper one: both halves add them in ascending dim order */
+    /* v_permlane32_swap (lanes 32..63 of the first register <-> lanes 0..31 of the second): afterwards l0 holds the lower
+     * half-wave's value in both halves and l1 the upper one's.  Inline asm: hipcc 7.2's __builtin_amdgcn_permlane32_swap
+     * returns the first result for both elements (checked in the ISA); s_nop 1 = the VALU-write -> permlane-read wait states. */
+    float l0 = lad, l1 = lad;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(l0), "+v"(l1));
+    run += l0;
+    run += l1;
+}
+
+/* chunk c: registers -> LDS (transposition), then the spline of this chunk threaded through the next chunk's GEMM */
+template <int INV, int NT>
+__device__ __forceinline__ void chunk_piped(const V2Args& a, const SpK& k, float* s_p, float* s_y, int c, int hh, int j, int rows,
+                                            float& run, int& oob_local, int (&bins)[3], f32x16 (&h)[4], const BFrag& bf,
+                                            TFrag (&ring)[RD], unsigned voff) {
+    Live<NT> g{h, bf, a.A2 + (size_t)(c + 1) * GBLK * 64, voff, ring};
+    g.start();
+    __builtin_amdgcn_sched_barrier(0);
+    spline_slot<INV, 0, 3 * EH>(g, a, k, s_p, s_y, c, DPC, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 1, 3 * EH>(g, a, k, s_p, s_y, c, DPC, hh, j, rows, run, oob_local, bins);
+    spline_slot<INV, 2, 3 * EH>(g, a, k, s_p, s_y, c, DPC, hh, j, rows, run, oob_local, bins);
+}
+
+template <int ACT, int INV>
+__global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2Args a) {
+    if (a.cs_dev) { a.c0 = a.cs_dev[1]; a.c1 = a.cs_dev[3]; a.c2 = a.cs_dev[5]; }   /* wave-uniform scalar loads */
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* parameter chunk [128][32]; first the layer-0 input [16 S0][SROW] */
+    float* s_y = s_p + 128 * ST;                          /* y / out tile [d + 1][SROW] */
+    const int d = a.d;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * FW + wave;
+    if (tile >= n_tiles) return;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    const unsigned voff = (unsigned)lane * 16u;
+    const SpK k{a.c2 * 1.44269504088896341f, a.c2 * a.beta * 1.44269504088896341f, a.c2};
+
+    /* ---- stage the (featurised) conditioner input [feature][sample], a constant-1 row for the bias, zero pad rows ---- */
+    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
+    const float* cond_t = a.cond + b0 * a.ldc;     /* wave-uniform tile bases, 32-bit per-lane offsets */
+    const float* y_t = a.y + b0 * a.ldy;
+    float* out_t = a.out + b0 * a.ldo;
+    const int ldc32 = (int)a.ldc, ldy32 = (int)a.ldy, ldo32 = (int)a.ldo;
+    for (int i = lane; i < 32 * a.d_c; i += 64) {
+        const int r = (int)__umulhi((unsigned)i, a.magic_dc), c = i - r * a.d_c;
+        float v = r < rows ? cond_t[r * ldc32 + c] : 0.0f;
+        if (a.periodic) {
+            float sv, cv;
+            bgk_sincos2pif(v, &sv, &cv);
+            s_p[c * SROW + r] = cv;
+            s_p[(a.d_c + c) * SROW + r] = sv;
+        } else {
+            s_p[c * SROW + r] = __builtin_amdgcn_fmed3f(v, -65000.0f, 65000.0f);
+        }
+    }
+    for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
+        s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
+    for (int i = lane; i < 32 * d; i += 64) {
+        const int r = (int)__umulhi((unsigned)i, a.magic_d), c = i - r * d;
+        s_y[c * SROW + r] = r < rows ? y_t[r * ldy32 + c] : 0.5f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    /* ---- layer 0 (bias = weight column of the constant-1 feature); B operand from LDS, split on the fly ---- */
+    f32x16 h[4], acc[4];
+    TFrag ring[RD];
+    BFrag bf;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
+    for (int s = 0; s < a.S0; ++s) {
+        uint4 fa[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            fa[m][0] = a.A0[((s * 4 + m) * 2 + 0) * 64 + lane];
+            fa[m][1] = a.A0[((s * 4 + m) * 2 + 1) * 64 + lane];
+        }
+        h16x8 bhi, blo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = s_p[(16 * s + 8 * hh + e) * SROW + j];
+            const _Float16 hv = (_Float16)v;
+            bhi[e] = hv;
+            blo[e] = (_Float16)(v - (float)hv);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[m][1]), bhi, h[m], 0, 0, 0);
+            h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[m][0]), blo, h[m], 0, 0, 0);
+            h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[m][0]), bhi, h[m], 0, 0, 0);
+        }
+    }
+
+    /* ---- layer 1: events of k-steps 2t, 2t + 1 behind the activation of tile t + 1 ---- */
+    {
+        Live<4> g{acc, bf, a.A1, voff, ring};
+        g.start();
+        NoLive none;
+        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, h[0], a.c0, bf);
+        __builtin_amdgcn_sched_barrier(0);
+        act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, h[1], a.c0, bf);      /* hook i = event i (100 events) */
+        act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, h[2], a.c0, bf);
+        act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, h[3], a.c0, bf);
+        __builtin_amdgcn_sched_barrier(0);
+        g.template events<72, Live<4>::NEV>();
+    }
+    /* ---- layer 2, chunk 0: the same behind the activation of the layer-1 tiles ---- */
+    float run = 0.0f;
+    int oob_local = 0;
+    {
+        Live<4> g{h, bf, a.A2, voff, ring};
+        g.start();
+        NoLive none;
+        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, acc[0], a.c1, bf);
+        __builtin_amdgcn_sched_barrier(0);
+        act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, acc[1], a.c1, bf);
+        act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, acc[2], a.c1, bf);
+        act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, acc[3], a.c1, bf);
+        __builtin_amdgcn_sched_barrier(0);
+        g.template events<72, Live<4>::NEV>();
+    }
+    /* ---- chunks: h -> LDS; spline(c) threaded through GEMM(c + 1) ---- */
+    for (int c = 0; c < a.n_chunks; ++c) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * ST + j] = h[m][r];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int bins[3] = {0, 0, 0};
+        const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
+        if (c + 2 < a.n_chunks || (c + 2 == a.n_chunks && a.last_tiles > 2)) {
+            chunk_piped<INV, 4>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff);
+        } else if (c + 2 == a.n_chunks) {
+            chunk_piped<INV, 2>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff);
+        } else {
+            NoLive none;
+            spline_slot<INV, 0, 1>(none, a, k, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+            if (nd > 2) spline_slot<INV, 1, 1>(none, a, k, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+            if (nd > 4) spline_slot<INV, 2, 1>(none, a, k, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+        }
+        if (a.bin_idx) {
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int q = 2 * it + hh;
+                if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (hh == 0 && j < rows) {
+        if (a.accumulate) a.dlogp[b0 + j] += run; else a.dlogp[b0 + j] = run;
+    }
+    for (int i = lane; i < rows * d; i += 64) {
+        const int r = (int)__umulhi((unsigned)i, a.magic_d), cc = i - r * d;
+        out_t[r * ldo32 + cc] = s_y[cc * SROW + r];
+    }
+    if (a.oob_count) {
+        for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
+        if (lane == 0 && oob_local) atomicAdd(a.oob_count, oob_local);
+    }
+}
+
+SetK make_set(double low, double high, double min_bin, int K) {
+    SetK s;
+    const double span = high - low, scale = 1.0 - min_bin * K;
+    /* the products of f32-rounded factors, like the first kernel's cfg (bgk_make_rqs_cfg) composes them */
+    s.gnum = (float)((double)(float)span * (double)(float)scale);
+    s.low = (float)low; s.high = (float)high;
+    s.dstep = (float)((double)(float)span * (double)(float)min_bin);
+    for (int k = 0; k < 7; ++k) s.kc[k] = (float)((double)(float)low + (double)(float)span * (double)(float)min_bin * (k + 1));
+    return s;
+}
+
+uint32_t magic_div(int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
+
+}  // namespace
+
+int bgk_h2_variant = 2;
+
+int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                              const void* A0p, const void* A1p, const void* A2p, float c0, float c1, float c2, const float* cs_dev,
+                              int32_t act, const float* y, int64_t ldy, int64_t B, int32_t d, uint64_t circ_mask, int32_t inverse,
+                              double left, double right, double bottom, double top,
+                              double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
+                              float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
+                              void* stream) {
+    V2Args a;
+    const int n_in = periodic ? 2 * d_c : d_c;
+    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic; a.magic_dc = magic_div(d_c);
+    a.y = y; a.ldy = ldy; a.out = out; a.ldo = ldo; a.d = d; a.magic_d = magic_div(d);
+    a.B = B; a.dlogp = dlogp; a.accumulate = accumulate; a.bin_idx = bin_idx; a.oob_count = oob_count;
+    a.A0 = reinterpret_cast<const uint4*>(A0p); a.A1 = reinterpret_cast<const uint4*>(A1p); a.A2 = reinterpret_cast<const uint4*>(A2p);
+    a.S0 = (n_in + 1 + 15) / 16;
+    a.n_chunks = (d + DPC - 1) / DPC;
+    a.last_tiles = ((d - (a.n_chunks - 1) * DPC) * PPD + 31) / 32;
+    a.c0 = c0; a.c1 = c1; a.c2 = c2; a.cs_dev = cs_dev;
+    a.circ_mask = circ_mask;
+    a.left = (float)left; a.right = (float)right;
+    /* bgflow forward = nflows inverse: the heights are searched, the widths evaluated; bgflow inverse: the other way round */
+    const SetK sw = make_set(left, right, min_bin_width, KB), sh = make_set(bottom, top, min_bin_height, KB);
+    a.sa = inverse ? sw : sh;
+    a.sb = inverse ? sh : sw;
+    const double beta = identity_init ? (0.6931471805599453 / (1.0 - min_derivative)) : 1.0;
+    a.beta = (float)beta; a.kout = (float)(0.6931471805599453 / (double)(float)beta); a.min_d = (float)min_derivative;
+    a.lds_per_wave = 128 * ST + (d + 1) * SROW;
+    const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
+    const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
+    BGK_CHECK_ARG((int64_t)32 * (d > d_c ? d : d_c) < (1 << 16), "%s: tile index range", what);
+    BGK_CHECK_ARG(ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24), "%s: row stride too large", what);
+    const int grid = (int)n_wg;
+    hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCH(A, I) hipLaunchKernelGGL((coupling_rqs_dense_h2v2_kernel<A, I>), dim3(grid), dim3(FTHREADS), shmem, st, a)
+    if (act == 1) { if (inverse) BGK_LAUNCH(1, 1); else BGK_LAUNCH(1, 0); }
+    else if (act == 2) { if (inverse) BGK_LAUNCH(2, 1); else BGK_LAUNCH(2, 0); }
+    else { if (inverse) BGK_LAUNCH(3, 1); else BGK_LAUNCH(3, 0); }
+#undef BGK_LAUNCH
+    return bgk_launch_status(what);
+}

@@ -31,6 +31,13 @@ extern "C" {
 int bgk_abi_version(void);
 const char* bgk_last_error(void);            /* thread-local, host string */
 
+/* Library-wide switches (diagnostics / A-B measurements; defaults are the shipped configuration).
+ *   option 1: generation of the split-f16 inference coupling kernel behind bgk_coupling_rqs_dense_h2:
+ *             2 (default) = coupling_rqs_dense_h2v2_kernel (MFMA stream threaded through the VALU work, bgk_fused2.hip),
+ *             1 = the first-generation kernel (bgk_fused.hip).
+ * Returns the previous value, BGK_EINVAL for an unknown option / value. */
+int bgk_set_option(int32_t option, int32_t value);
+
 /* Deterministic-math probe: out[i] = f(x[i]) on the device with the same primitives the spline
  * kernels use (which: 0 exp, 1 log, 2 softplus(beta=ln2/(1-1e-3)), 3 silu, 4 tanh).  Test hook. */
 int bgk_detmath_probe(const float* x, int64_t n, int32_t which, float* out, void* stream);

@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Generates tools/ubench/issue_bench.hip: per-instruction issue costs and MFMA / VALU interleave behaviour on gfx950.
+Every loop body is ONE asm volatile block, so the instruction order is exactly the written one (the r01 bench mixed
+MFMA builtins with asm volatile VALU blocks, which the scheduler was free to re-cluster).
+    python tools/ubench/gen_issue_bench.py && hipcc --offload-arch=gfx950 -O3 -o tools/ubench/issue_bench tools/ubench/issue_bench.hip
+"""
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# operand numbering inside the asm block
+#  %0..%3  acc f32x16 (+v)   %4..%11 chains c0..c7 (+v, float)   %12..%15 pairs p0..p3 (+v, float2)
+#  %16 k1 (v)  %17 k2 (v)  %18 a (v, 4 regs)  %19 b (v, 4 regs)  %20 lds addr (v)  %21 pk const (v, float2)
+def chain(j): return f"%{4 + (j % 8)}"
+def pair(j): return f"%{12 + (j % 4)}"
+
+FILL = {
+    "fma":    lambda j: f"v_fma_f32 {chain(j)}, {chain(j)}, %16, %17",
+    "mul":    lambda j: f"v_mul_f32 {chain(j)}, {chain(j)}, %16",
+    "add":    lambda j: f"v_add_f32 {chain(j)}, {chain(j)}, %17",
+    "pkfma":  lambda j: f"v_pk_fma_f32 {pair(j)}, {pair(j)}, %21, %21",
+    "pkmul":  lambda j: f"v_pk_mul_f32 {pair(j)}, {pair(j)}, %21",
+    "pkadd":  lambda j: f"v_pk_add_f32 {pair(j)}, {pair(j)}, %21",
+    "exp":    lambda j: f"v_exp_f32 {chain(j)}, {chain(j)}",
+    "log":    lambda j: f"v_log_f32 {chain(j)}, {chain(j)}",
+    "rcp":    lambda j: f"v_rcp_f32 {chain(j)}, {chain(j)}",
+    "sqrt":   lambda j: f"v_sqrt_f32 {chain(j)}, {chain(j)}",
+    "cnd":    lambda j: f"v_cndmask_b32 {chain(j)}, {chain(j)}, %16, vcc",
+    "cmpcnd": lambda j: f"v_cmp_ge_f32 vcc, {chain(j)}, %16\n v_cndmask_b32 {chain(j)}, {chain(j)}, %17, vcc",
+    "cmp64":  lambda j: f"v_cmp_ge_f32 s[20:21], {chain(j)}, %16\n v_cndmask_b32 {chain(j)}, {chain(j)}, %17, s[20:21]",
+    "med3":   lambda j: f"v_med3_f32 {chain(j)}, {chain(j)}, %16, %17",
+    "cvtpk":  lambda j: f"v_cvt_pk_f16_f32 {chain(j)}, {chain(j)}, %16",
+    "mixlo":  lambda j: f"v_fma_mixlo_f16 {chain(j)}, {chain(j)}, %16, %17 op_sel_hi:[1,0,0]",
+    "mix32":  lambda j: f"v_fma_mix_f32 {chain(j)}, {chain(j)}, %16, %17 op_sel_hi:[1,0,0]",
+    "dsr":    lambda j: f"ds_read_b32 {chain(j)}, %20 offset:{128 * (j % 8)}",
+    "dsr2":   lambda j: f"ds_read2_b32 {pair(j)}, %20 offset0:{(2 * j) % 64} offset1:{(2 * j) % 64 + 32}",
+    "dsw":    lambda j: f"ds_write_b32 %20, {chain(j)} offset:{128 * (j % 8)}",
+    "dsw2":   lambda j: f"ds_write2_b32 %20, {chain(j)}, {chain(j + 1)} offset0:{(2 * j) % 64} offset1:{(2 * j) % 64 + 32}",
+    "mov":    lambda j: f"v_mov_b32 {chain(j)}, %16",
+    "addu":   lambda j: f"v_add_u32 {chain(j)}, {chain(j)}, %16",
+    "nop":    lambda j: "s_nop 0",
+}
+MFMA = lambda u: f"v_mfma_f32_32x32x16_f16 %{u}, %18, %19, %{u}"
+
+tests = []   # (name, body lines, n_mfma, n_fill)
+
+def add(name, lines, n_mfma, n_fill, lds_wait=False):
+    if lds_wait:
+        lines = lines + ["s_waitcnt lgkmcnt(0)"]
+    tests.append((name, lines, n_mfma, n_fill))
+
+# 1. plain issue throughput: 32 instructions per body
+for k in ("fma", "mul", "add", "pkfma", "pkmul", "pkadd", "exp", "log", "rcp", "sqrt", "cnd", "cmpcnd", "cmp64", "med3", "cvtpk",
+          "mixlo", "mix32", "mov", "addu"):
+    n = 16 if k in ("cmpcnd", "cmp64") else 32
+    add(f"only_{k}", [FILL[k](j) for j in range(n)], 0, 32)
+for k in ("dsr", "dsr2", "dsw", "dsw2"):
+    add(f"only_{k}", [FILL[k](j) for j in range(16)], 0, 16, lds_wait=True)
+# mixes typical of the spline: 1 transcendental per 4 / per 8 plain
+add("mix_exp1in4", [FILL["exp"](j) if j % 4 == 0 else FILL["fma"](j) for j in range(32)], 0, 32)
+add("mix_exp1in8", [FILL["exp"](j) if j % 8 == 0 else FILL["fma"](j) for j in range(32)], 0, 32)
+add("mix_pk1in2", [FILL["pkfma"](j) if j % 2 == 0 else FILL["fma"](j) for j in range(32)], 0, 32)
+
+# 2. MFMA with N fillers behind each (4 MFMAs per body, rotating accumulators)
+for kind in ("fma", "pkfma", "exp", "cnd", "dsr", "dsw"):
+    for n in (0, 2, 4, 5, 6, 8, 10, 12, 16):
+        if kind != "fma" and n not in (4, 8):
+            continue
+        if kind == "fma" or n:
+            lines = []
+            jj = 0
+            for u in range(4):
+                lines.append(MFMA(u))
+                for _ in range(n):
+                    lines.append(FILL[kind](jj)); jj += 1
+            add(f"mfma+{n}{kind}", lines, 4, 4 * n, lds_wait=kind.startswith("ds"))
+# realistic filler mix behind each MFMA: 6 plain + 1 exp + 1 pk
+for n in (8, 12):
+    lines = []
+    jj = 0
+    for u in range(4):
+        lines.append(MFMA(u))
+        for q in range(n):
+            kind = "exp" if q == 3 else ("pkfma" if q == 6 else "fma")
+            lines.append(FILL[kind](jj)); jj += 1
+    add(f"mfma+{n}mixed", lines, 4, 4 * n)
+# 3. phase separated: 16 MFMAs, then 16*n fillers
+for n in (4, 8):
+    lines = [MFMA(u % 4) for u in range(16)] + [FILL["fma"](j) for j in range(16 * n)]
+    add(f"phase16mfma_then_{16 * n}fma", lines, 16, 16 * n)
+# 3b. 12 MFMAs of one k-step (3 per accumulator, back to back like h2_mfma: m inner) then fillers
+lines = [MFMA(u % 4) for u in range(12)] + [FILL["fma"](j) for j in range(60)]
+add("kstep12_then_60fma", lines, 12, 60)
+lines = []
+for u in range(12):
+    lines.append(MFMA(u % 4)); lines += [FILL["fma"](5 * u + q) for q in range(5)]
+add("kstep12_interleaved_5fma", lines, 12, 60)
+# dependent accumulator chains: 2 accumulators alternating / 1 accumulator
+add("mfma_2acc", [MFMA(u % 2) for u in range(8)], 8, 0)
+add("mfma_1acc", [MFMA(0) for u in range(8)], 8, 0)
+
+src = ['// GENERATED by gen_issue_bench.py -- do not edit', '#include <hip/hip_runtime.h>', '#include <stdio.h>', '#include <stdint.h>',
+       'typedef float f32x16 __attribute__((ext_vector_type(16)));', 'typedef float f32x2 __attribute__((ext_vector_type(2)));',
+       'typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));', '']
+for i, (name, lines, nm, nf) in enumerate(tests):
+    body = "\\n\\t".join(l.replace("\n", "\\n\\t") for l in lines)
+    src.append(f'''__global__ __launch_bounds__(256) void k{i}(unsigned long long* cyc, float* out, int iters) {{
+    __shared__ float lds[256 * 40];
+    f32x16 a0, a1, a2, a3;
+    for (int r = 0; r < 16; ++r) {{ a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; a3[r] = 0.f; }}
+    float c0 = threadIdx.x * 1e-3f + 1.0f, c1 = 1.1f, c2 = 1.2f, c3 = 1.3f, c4 = 1.4f, c5 = 1.5f, c6 = 1.6f, c7 = 1.7f;
+    f32x2 p0 = {{c0, c1}}, p1 = {{c2, c3}}, p2 = {{c4, c5}}, p3 = {{c6, c7}}, pk = {{0.9999f, 0.9998f}};
+    float k1 = 0.99999f, k2 = 1e-6f;
+    h16x8 a, b;
+    for (int e = 0; e < 8; ++e) {{ a[e] = (_Float16)(0.001f * (threadIdx.x + e)); b[e] = (_Float16)(0.5f + 0.01f * e); }}
+    for (int i = threadIdx.x; i < 256 * 40; i += 256) lds[i] = 1.0f;
+    __syncthreads();
+    unsigned ldsa = (unsigned)(uintptr_t)lds + threadIdx.x * 4;   /* one dword per lane, conflict free */
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {{
+        asm volatile("{body}"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7),
+                       "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
+                     : "v"(k1), "v"(k2), "v"(a), "v"(b), "v"(ldsa), "v"(pk) : "vcc", "s20", "s21", "memory");
+    }}
+    asm volatile("s_nop 15\\n\\ts_nop 15\\n\\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s + lds[threadIdx.x];
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}}
+''')
+src.append('typedef void (*kern_t)(unsigned long long*, float*, int);')
+src.append('struct T { const char* name; kern_t k; int n_mfma; int n_fill; };')
+src.append('static T tests[] = {')
+for i, (name, lines, nm, nf) in enumerate(tests):
+    src.append(f'    {{"{name}", k{i}, {nm}, {len(lines) - nm}}},')
+src.append('};')
+src.append(r'''
+int main(int argc, char** argv) {
+    const int iters = 4000;
+    unsigned long long* cyc; float* out;
+    hipMalloc(&cyc, 256 * 8 * 4 * sizeof(unsigned long long));
+    hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+    static unsigned long long h[256 * 8 * 4];
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("%-34s %3s %9s %9s %8s %9s %9s %7s\n", "test", "wps", "cyc/body", "cyc/inst", "cyc/mfma", "wall_ms", "GHz_eff", "n_inst");
+    for (size_t t = 0; t < sizeof(tests) / sizeof(tests[0]); ++t) {
+        for (int wps = 1; wps <= 4; ++wps) {
+            if (wps == 3 && tests[t].n_mfma == 0) continue;
+            const int blocks = 256 * wps;
+            hipLaunchKernelGGL(tests[t].k, dim3(blocks), dim3(256), 0, 0, cyc, out, iters);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(tests[t].k, dim3(blocks), dim3(256), 0, 0, cyc, out, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(h, cyc, blocks * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double sum = 0; for (int i = 0; i < blocks * 4; ++i) sum += (double)h[i];
+            const double per_wave = sum / (blocks * 4);             /* s_memtime ticks (100 MHz?) or shader cycles: reported raw */
+            const double body = per_wave / iters;
+            const int n_inst = tests[t].n_mfma + tests[t].n_fill;
+            /* SIMD-level cost: wps waves share the SIMD, so SIMD cycles per body = body / wps */
+            printf("%-34s %3d %9.1f %9.2f %8.1f %9.4f %9.3f %7d\n", tests[t].name, wps, body / wps, body / wps / n_inst,
+                   tests[t].n_mfma ? body / wps / tests[t].n_mfma : 0.0, ms, per_wave / (ms * 1e6), n_inst);
+        }
+    }
+    return 0;
+}
+''')
+open(os.path.join(HERE, "issue_bench.hip"), "w").write("\n".join(src))
+print(len(tests), "tests")
