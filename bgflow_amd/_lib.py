@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbgflow_amd.so")
+LIB_PATH = os.environ.get("BGK_LIB") or os.path.join(_HERE, "libbgflow_amd.so")   # BGK_LIB: A/B builds (tools/)
 _lib = None
 
 i32, i64, f32, f64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p

@@ -48,8 +48,11 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in sources() + _headers())
 
 
-def build_extension(force=False, verbose=False):
+def build_extension(force=False, verbose=False, out=None):
+    """BGK_EXTRA_FLAGS: extra hipcc flags (experiments); BGK_EXTRA_TU: comma list of sources they apply to (default: all);
+    ``out``: path of the linked library (default: the in-tree libbgflow_amd.so)."""
     extra = os.environ.get("BGK_EXTRA_FLAGS", "").split()
+    only = [t for t in os.environ.get("BGK_EXTRA_TU", "").split(",") if t]
     if not force and not extra and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -58,10 +61,11 @@ def build_extension(force=False, verbose=False):
     hdr_t = max(os.path.getmtime(p) for p in _headers())
 
     def compile_one(src):
-        obj = _obj(src, tag)
+        mine = extra if (not only or os.path.basename(src) in only) else []
+        obj = _obj(src, tag if mine else "")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
             return obj
-        cmd = [hipcc] + HIPCC_FLAGS + TU_FLAGS.get(os.path.basename(src), []) + extra + ["-c", "-o", obj, src]
+        cmd = [hipcc] + HIPCC_FLAGS + TU_FLAGS.get(os.path.basename(src), []) + mine + ["-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -69,12 +73,14 @@ def build_extension(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources()))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    target = out or LIB
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":
-    print(build_extension(force="--force" in sys.argv, verbose=True))
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    print(build_extension(force="--force" in sys.argv, verbose="--quiet" not in sys.argv, out=out))

@@ -46,10 +46,28 @@ constexpr int SROW = 33;              /* padded row stride of the y / input tile
 constexpr int ST = 32;                /* row stride of the parameter chunk in LDS */
 constexpr int KS = 8;                 /* k16-steps of a 128-wide hidden layer */
 constexpr int GBLK = KS * 8 + 4;      /* 1 KiB blocks per packed 128-row GEMM incl. the 4 bias blocks */
-constexpr int RD = 4;                 /* A-fragment ring depth in tile-steps */
+#ifndef BGK_V2_ABL
+#define BGK_V2_ABL 0                /* timing ablations (wrong results): 1 no spline, 2 no activation math, 4 no LDS transposition, 8 no staging / output */
+#endif
+#ifndef BGK_V2_KARG
+#define BGK_V2_KARG 1
+#endif
+#ifndef BGK_V2_RD
+#define BGK_V2_RD 4
+#endif
+#ifndef BGK_V2_BUF
+#define BGK_V2_BUF 1                  /* A stream through buffer loads: one s_mov per 4 KiB group instead of a 64-bit SALU add per tile-step */
+#endif
+constexpr int RD = BGK_V2_RD;         /* A-fragment ring depth in tile-steps */
 constexpr int EH = 34;                /* hook points per spline element */
 
 struct SetK { float gnum, low, high, dstep; float kc[7]; };   /* gnum = span * scale, dstep = span * min_bin, kc[k] = low + dstep (k + 1) */
+
+struct SpC {                          /* spline constants */
+    float left, right;
+    SetK sa, sb;                      /* searched set / other set */
+    float beta, kout, min_d;          /* softplus: log(1 + exp(beta s)) / beta = log2(1 + exp2(beta log2e s)) * kout */
+};
 
 struct V2Args {
     const float* cond; int64_t ldc; int d_c; int periodic; uint32_t magic_dc;
@@ -58,11 +76,12 @@ struct V2Args {
     const uint4* A0; const uint4* A1; const uint4* A2; int S0; int n_chunks; int last_tiles;
     float c0, c1, c2; const float* cs_dev;
     uint64_t circ_mask;
-    float left, right;
-    SetK sa, sb;                      /* searched set / other set */
-    float beta, kout, min_d;          /* softplus: log(1 + exp(beta s)) / beta = log2(1 + exp2(beta log2e s)) * kout */
+    SpC sc;
     int lds_per_wave;
 };
+/* the kernel argument block in the constant address space: the spline constants are (re)read with scalar loads where they are
+ * used instead of occupying ~30 SGPRs for the whole persistent loop */
+typedef const __attribute__((address_space(4))) V2Args* kargs_t;
 
 struct BFrag { h16x8 hi[KS], lo[KS]; };     /* a 128-wide activation vector as B operands: 64 VGPRs */
 struct TFrag { u32x4 hi, lo; };             /* A operand of one (k-step, tile): 8 VGPRs */
@@ -99,21 +118,46 @@ struct Live {
     const uint4* W;
     unsigned voff;
     TFrag (&ring)[RD];
+#if BGK_V2_BUF
+    __amdgpu_buffer_rsrc_t rs;
+#endif
 
+    template <int BLK>
+    __device__ __forceinline__ u32x4 blk() {
+#if BGK_V2_BUF
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ((BLK * 1024) & 4095), (BLK * 1024) & ~4095, 0);
+#else
+        return ld_block<BLK>(W, voff);
+#endif
+    }
     template <int T>
     __device__ __forceinline__ void load() {
+#ifdef BGK_V2_ABL_NOLOAD     /* timing experiment: only the prologue of each GEMM loads A (wrong results) */
+        if constexpr (T >= RD) return;
+#endif
         if constexpr (T < NTS) {
             constexpr int s = T / NT, m = T % NT;
+#if BGK_V2_BUF
+            ring[T % RD].hi = blk<(s * 4 + m) * 2>();
+            ring[T % RD].lo = blk<(s * 4 + m) * 2 + 1>();
+#else
             ld_pair<(s * 4 + m) * 2>(ring[T % RD].hi, ring[T % RD].lo, W, voff);
+#endif
         } else if constexpr (T < NTS + NT) {
-            ring[T % RD].hi = ld_block<KS * 8 + (T - NTS)>(W, voff);
+            ring[T % RD].hi = blk<KS * 8 + (T - NTS)>();
         }
+    }
+    template <int T0, int T1>
+    __device__ __forceinline__ void loads() {
+        if constexpr (T0 < T1) { load<T0>(); loads<T0 + 1, T1>(); }
     }
     __device__ __forceinline__ void start() {
         __builtin_amdgcn_sched_barrier(0);
-        load<0>(); load<1>(); load<2>(); load<3>();
+#if BGK_V2_BUF
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);   /* raw buffer, dword3 = gfx9 default format */
+#endif
+        loads<0, RD>();
         __builtin_amdgcn_sched_barrier(0);
-        static_assert(RD == 4, "prologue written for RD = 4");
     }
     template <int E>
     __device__ __forceinline__ void event() {
@@ -166,6 +210,9 @@ struct Hooks {
 /* ---- hidden activation (hardware exp2 / rcp) of x = t * c and split into f16 hi + lo ---- */
 template <int ACT>
 __device__ __forceinline__ float act_hw(float x) {
+#if (BGK_V2_ABL & 2)
+    return x;
+#endif
     if constexpr (ACT == 1) {           /* SiLU */
         const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896341f);
         return x * __builtin_amdgcn_rcpf(1.0f + e);
@@ -221,13 +268,20 @@ __device__ __forceinline__ float rcp_nr(float d) {
 template <int INV, class H>
 __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const float* pb, const float* ps, bool circ,
                                           const V2Args& a, const SpK& k, float* lad, int* bin, int* oob) {
+#if BGK_V2_KARG     /* the spline constants (re)read from the kernel argument block by scalar loads inside the element */
+    kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+#define SC ka->sc
+#else
+#define SC a.sc
+#endif
     float va[KB], vb[KB];
 #pragma unroll
     for (int i = 0; i < KB; ++i) va[i] = pa[i * ST];
 #pragma unroll
     for (int i = 0; i < KB; ++i) vb[i] = pb[i * ST];
-    *oob = (x < a.left) | (x > a.right);
-    x = __builtin_amdgcn_fmed3f(x, a.left, a.right);
+    *oob = (x < SC.left) | (x > SC.right);
+    x = __builtin_amdgcn_fmed3f(x, SC.left, SC.right);
     /* ---- searched set: softmax numerators, running sums, the 7 interior knots, comparison masks ---- */
     float mA = __builtin_fmaxf(__builtin_fmaxf(va[0], va[1]), va[2]);
     mA = __builtin_fmaxf(__builtin_fmaxf(mA, va[3]), va[4]);
@@ -250,16 +304,16 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     hk.template at<3>();
     E[3] += E[2]; E[4] += E[3]; E[5] += E[4]; E[6] += E[5]; E[7] += E[6];
     hk.template at<4>();
-    const float gA = a.sa.gnum * rcp_nr(E[7]);
+    const float gA = SC.sa.gnum * rcp_nr(E[7]);
     float kn[7];
-    kn[0] = __builtin_fmaf(E[0], gA, a.sa.kc[0]);
-    kn[1] = __builtin_fmaf(E[1], gA, a.sa.kc[1]);
+    kn[0] = __builtin_fmaf(E[0], gA, SC.sa.kc[0]);
+    kn[1] = __builtin_fmaf(E[1], gA, SC.sa.kc[1]);
     hk.template at<5>();
-    kn[2] = __builtin_fmaf(E[2], gA, a.sa.kc[2]);
-    kn[3] = __builtin_fmaf(E[3], gA, a.sa.kc[3]);
-    kn[4] = __builtin_fmaf(E[4], gA, a.sa.kc[4]);
-    kn[5] = __builtin_fmaf(E[5], gA, a.sa.kc[5]);
-    kn[6] = __builtin_fmaf(E[6], gA, a.sa.kc[6]);
+    kn[2] = __builtin_fmaf(E[2], gA, SC.sa.kc[2]);
+    kn[3] = __builtin_fmaf(E[3], gA, SC.sa.kc[3]);
+    kn[4] = __builtin_fmaf(E[4], gA, SC.sa.kc[4]);
+    kn[5] = __builtin_fmaf(E[5], gA, SC.sa.kc[5]);
+    kn[6] = __builtin_fmaf(E[6], gA, SC.sa.kc[6]);
     hk.template at<6>();
     const bool g0 = x >= kn[0], g1 = x >= kn[1], g2 = x >= kn[2], g3 = x >= kn[3], g4 = x >= kn[4], g5 = x >= kn[5], g6 = x >= kn[6];
     hk.template at<7>();
@@ -269,12 +323,12 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     /* the two slopes of the bin (dynamic LDS rows; circular dims wrap the last knot's slope to row 0) */
     const int j1 = circ ? ((idx + 1) & 7) : (idx + 1);
     const float s_lo = ps[idx * ST], s_hi = ps[j1 * ST];
-    float lo = a.sa.low;
+    float lo = SC.sa.low;
     lo = g0 ? kn[0] : lo; lo = g1 ? kn[1] : lo; lo = g2 ? kn[2] : lo;
     hk.template at<9>();
     lo = g3 ? kn[3] : lo; lo = g4 ? kn[4] : lo; lo = g5 ? kn[5] : lo; lo = g6 ? kn[6] : lo;
     hk.template at<10>();
-    float hi = a.sa.high;
+    float hi = SC.sa.high;
     hi = g6 ? hi : kn[6]; hi = g5 ? hi : kn[5]; hi = g4 ? hi : kn[4]; hi = g3 ? hi : kn[3];
     hk.template at<11>();
     hi = g2 ? hi : kn[2]; hi = g1 ? hi : kn[1]; hi = g0 ? hi : kn[0];
@@ -303,7 +357,7 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     F[4] += F[3]; F[5] += F[4]; F[6] += F[5]; F[7] += F[6];
     const float rB = __builtin_amdgcn_rcpf(F[7]);
     hk.template at<17>();
-    const float gB = a.sb.gnum * __builtin_fmaf(__builtin_fmaf(-F[7], rB, 1.0f), rB, rB);
+    const float gB = SC.sb.gnum * __builtin_fmaf(__builtin_fmaf(-F[7], rB, 1.0f), rB, rB);
     float Flo = 0.0f;
     Flo = g0 ? F[0] : Flo; Flo = g1 ? F[1] : Flo; Flo = g2 ? F[2] : Flo;
     hk.template at<18>();
@@ -313,11 +367,11 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     Fhi = g6 ? Fhi : F[6]; Fhi = g5 ? Fhi : F[5]; Fhi = g4 ? Fhi : F[4]; Fhi = g3 ? Fhi : F[3];
     hk.template at<20>();
     Fhi = g2 ? Fhi : F[2]; Fhi = g1 ? Fhi : F[1]; Fhi = g0 ? Fhi : F[0];
-    const float cb = __builtin_fmaf((float)idx, a.sb.dstep, a.sb.low);
+    const float cb = __builtin_fmaf((float)idx, SC.sb.dstep, SC.sb.low);
     hk.template at<21>();
     const float b_i = __builtin_fmaf(Flo, gB, cb);
-    float b_ip1 = __builtin_fmaf(Fhi, gB, cb + a.sb.dstep);
-    b_ip1 = g6 ? a.sb.high : b_ip1;
+    float b_ip1 = __builtin_fmaf(Fhi, gB, cb + SC.sb.dstep);
+    b_ip1 = g6 ? SC.sb.high : b_ip1;
     const float B_i = b_ip1 - b_i;
     /* ---- derivatives: min_d + softplus(beta s) / beta ---- */
     const float z0 = s_lo * k.kz;                           /* log2(e) beta s_true */
@@ -327,9 +381,9 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     asm volatile("" : "+v"(lg0));                           /* keep the select below a select (no divergent branch around the log) */
     const float sm0 = ez0 * __builtin_fmaf(ez0, -0.5f, 1.0f) * 1.44269504088896341f;   /* log1p for tiny arguments */
     hk.template at<23>();
-    float l0 = (ez0 < 2.44140625e-4f ? sm0 : lg0) * a.kout;
+    float l0 = (ez0 < 2.44140625e-4f ? sm0 : lg0) * SC.kout;
     l0 = z0 > 28.8539008177792681f ? s_lo * k.c2 : l0;      /* beta s > 20: identity (torch softplus threshold) */
-    const float d_i = a.min_d + l0;
+    const float d_i = SC.min_d + l0;
     const float z1 = s_hi * k.kz;
     hk.template at<24>();
     const float ez1 = __builtin_amdgcn_exp2f(z1);
@@ -337,9 +391,9 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     asm volatile("" : "+v"(lg1));
     const float sm1 = ez1 * __builtin_fmaf(ez1, -0.5f, 1.0f) * 1.44269504088896341f;
     hk.template at<25>();
-    float l1 = (ez1 < 2.44140625e-4f ? sm1 : lg1) * a.kout;
+    float l1 = (ez1 < 2.44140625e-4f ? sm1 : lg1) * SC.kout;
     l1 = z1 > 28.8539008177792681f ? s_hi * k.c2 : l1;
-    const float d_ip1 = a.min_d + l1;
+    const float d_ip1 = SC.min_d + l1;
     float cw_i, W_i, ch_i, H_i;
     if (INV) { cw_i = lo; W_i = A_i; ch_i = b_i; H_i = B_i; }
     else { ch_i = lo; H_i = A_i; cw_i = b_i; W_i = B_i; }
@@ -391,6 +445,8 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     return outv;
 }
 
+#undef SC
+
 /* slot IT of a chunk: element q = 2 IT + hh of sample j; invalid slots evaluate dim 0 of the chunk and are discarded */
 template <int INV, int IT, int NHK, class G>
 __device__ __forceinline__ void spline_slot(G& g, const V2Args& a, const SpK& k, const float* s_p, float* s_y, int c, int nd,
@@ -422,61 +478,113 @@ __device__ __forceinline__ void spline_slot(G& g, const V2Args& a, const SpK& k,
     run += l1;
 }
 
+/* accumulator layout [row = feature][lane = (half, sample)] -> LDS [row][sample] (conflict-free both ways) */
+__device__ __forceinline__ void chunk_to_lds(const f32x16 (&h)[4], float* s_p, int hh, int j) {
+#if (BGK_V2_ABL & 4)
+    s_p[threadIdx.x & 63] = h[0][0] + h[1][1] + h[2][2] + h[3][3];
+    return;
+#endif
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * ST + j] = h[m][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 /* chunk c: registers -> LDS (transposition), then the spline of this chunk threaded through the next chunk's GEMM */
 template <int INV, int NT>
 __device__ __forceinline__ void chunk_piped(const V2Args& a, const SpK& k, float* s_p, float* s_y, int c, int hh, int j, int rows,
                                             float& run, int& oob_local, int (&bins)[3], f32x16 (&h)[4], const BFrag& bf,
                                             TFrag (&ring)[RD], unsigned voff) {
     Live<NT> g{h, bf, a.A2 + (size_t)(c + 1) * GBLK * 64, voff, ring};
-    g.start();
+    g.start();                       /* the next GEMM's first A fragments travel while this chunk goes through LDS */
+    chunk_to_lds(h, s_p, hh, j);
     __builtin_amdgcn_sched_barrier(0);
+#if (BGK_V2_ABL & 1)
+    g.template events<0, Live<NT>::NEV>();
+    run += s_p[(threadIdx.x & 127) * ST + j];
+#else
     spline_slot<INV, 0, 3 * EH>(g, a, k, s_p, s_y, c, DPC, hh, j, rows, run, oob_local, bins);
     spline_slot<INV, 1, 3 * EH>(g, a, k, s_p, s_y, c, DPC, hh, j, rows, run, oob_local, bins);
     spline_slot<INV, 2, 3 * EH>(g, a, k, s_p, s_y, c, DPC, hh, j, rows, run, oob_local, bins);
+#endif
 }
 
 template <int ACT, int INV>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2Args a) {
     if (a.cs_dev) { a.c0 = a.cs_dev[1]; a.c1 = a.cs_dev[3]; a.c2 = a.cs_dev[5]; }   /* wave-uniform scalar loads */
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int j = lane & 31, hh = lane >> 5;
     float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* parameter chunk [128][32]; first the layer-0 input [16 S0][SROW] */
     float* s_y = s_p + 128 * ST;                          /* y / out tile [d + 1][SROW] */
     const int d = a.d;
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * FW + wave;
     if (tile >= n_tiles) return;
+    const SpK k{a.c2 * 1.44269504088896341f, a.c2 * a.sc.beta * 1.44269504088896341f, a.c2};
+    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
+    const int ldc32 = (int)a.ldc, ldy32 = (int)a.ldy, ldo32 = (int)a.ldo;
+    const int n_c = 32 * a.d_c, n_y = 32 * d;
+
+  {
+    const int lane = (int)threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+    const unsigned voff = (unsigned)lane * 16u;
     const int64_t b0 = tile * 32;
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
-    const unsigned voff = (unsigned)lane * 16u;
-    const SpK k{a.c2 * 1.44269504088896341f, a.c2 * a.beta * 1.44269504088896341f, a.c2};
-
-    /* ---- stage the (featurised) conditioner input [feature][sample], a constant-1 row for the bias, zero pad rows ---- */
-    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
     const float* cond_t = a.cond + b0 * a.ldc;     /* wave-uniform tile bases, 32-bit per-lane offsets */
     const float* y_t = a.y + b0 * a.ldy;
     float* out_t = a.out + b0 * a.ldo;
-    const int ldc32 = (int)a.ldc, ldy32 = (int)a.ldy, ldo32 = (int)a.ldo;
-    for (int i = lane; i < 32 * a.d_c; i += 64) {
-        const int r = (int)__umulhi((unsigned)i, a.magic_dc), c = i - r * a.d_c;
-        float v = r < rows ? cond_t[r * ldc32 + c] : 0.0f;
-        if (a.periodic) {
-            float sv, cv;
-            bgk_sincos2pif(v, &sv, &cv);
-            s_p[c * SROW + r] = cv;
-            s_p[(a.d_c + c) * SROW + r] = sv;
-        } else {
-            s_p[c * SROW + r] = __builtin_amdgcn_fmed3f(v, -65000.0f, 65000.0f);
+
+    /* ---- stage the (featurised) conditioner input [feature][sample], a constant-1 row for the bias, zero pad rows.
+     * All global loads of a batch (SB per array and lane) are issued before anything waits on them: one HBM round trip per batch
+     * instead of one per 64 elements.  (A persistent-wave variant with register prefetch of the next tile's inputs measured 6 %
+     * SLOWER than letting the dispatcher overlap the prologue of fresh workgroups with the tails of retiring ones.) ---- */
+    constexpr int SB = 10;
+    for (int base = 0; base < (n_c > n_y ? n_c : n_y); base += 64 * SB) {
+        float vc[SB], vy[SB];
+        int oc[SB], oy[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = base + u * 64 + lane;
+            const int r = (int)__umulhi((unsigned)i, a.magic_dc), c = i - r * a.d_c;
+            oc[u] = i < n_c ? c * SROW + r : -1;
+#if (BGK_V2_ABL & 8)
+            vc[u] = 0.25f;
+#else
+            vc[u] = (i < n_c && r < rows) ? cond_t[r * ldc32 + c] : 0.0f;
+#endif
         }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = base + u * 64 + lane;
+            const int r = (int)__umulhi((unsigned)i, a.magic_d), c = i - r * d;
+            oy[u] = i < n_y ? c * SROW + r : -1;
+#if (BGK_V2_ABL & 8)
+            vy[u] = 0.5f;
+#else
+            vy[u] = (i < n_y && r < rows) ? y_t[r * ldy32 + c] : 0.5f;
+#endif
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            if (oc[u] >= 0) {
+                if (a.periodic) {
+                    float sv, cv;
+                    bgk_sincos2pif(vc[u], &sv, &cv);
+                    s_p[oc[u]] = cv;
+                    s_p[a.d_c * SROW + oc[u]] = sv;
+                } else {
+                    s_p[oc[u]] = __builtin_amdgcn_fmed3f(vc[u], -65000.0f, 65000.0f);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+            if (oy[u] >= 0) s_y[oy[u]] = vy[u];
     }
     for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
         s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
-    for (int i = lane; i < 32 * d; i += 64) {
-        const int r = (int)__umulhi((unsigned)i, a.magic_d), c = i - r * d;
-        s_y[c * SROW + r] = r < rows ? y_t[r * ldy32 + c] : 0.5f;
-    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -541,12 +649,6 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
     }
     /* ---- chunks: h -> LDS; spline(c) threaded through GEMM(c + 1) ---- */
     for (int c = 0; c < a.n_chunks; ++c) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * ST + j] = h[m][r];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         int bins[3] = {0, 0, 0};
         const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
         if (c + 2 < a.n_chunks || (c + 2 == a.n_chunks && a.last_tiles > 2)) {
@@ -555,9 +657,14 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
             chunk_piped<INV, 2>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff);
         } else {
             NoLive none;
+            chunk_to_lds(h, s_p, hh, j);
+#if (BGK_V2_ABL & 1)
+            run += s_p[(threadIdx.x & 127) * ST + j];
+#else
             spline_slot<INV, 0, 1>(none, a, k, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
             if (nd > 2) spline_slot<INV, 1, 1>(none, a, k, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
             if (nd > 4) spline_slot<INV, 2, 1>(none, a, k, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+#endif
         }
         if (a.bin_idx) {
 #pragma unroll
@@ -572,14 +679,19 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
     if (hh == 0 && j < rows) {
         if (a.accumulate) a.dlogp[b0 + j] += run; else a.dlogp[b0 + j] = run;
     }
+#if (BGK_V2_ABL & 8)
+    if (lane < d) out_t[lane] = s_y[lane * SROW];
+#else
     for (int i = lane; i < rows * d; i += 64) {
         const int r = (int)__umulhi((unsigned)i, a.magic_d), cc = i - r * d;
         out_t[r * ldo32 + cc] = s_y[cc * SROW + r];
     }
-    if (a.oob_count) {
+#endif
+    if (a.oob_count && __builtin_amdgcn_ballot_w64(oob_local != 0)) {     /* rare: inputs outside the spline domain */
         for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
-        if (lane == 0 && oob_local) atomicAdd(a.oob_count, oob_local);
+        if (lane == 0) atomicAdd(a.oob_count, oob_local);
     }
+  }
 }
 
 SetK make_set(double low, double high, double min_bin, int K) {
@@ -617,13 +729,13 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
     a.last_tiles = ((d - (a.n_chunks - 1) * DPC) * PPD + 31) / 32;
     a.c0 = c0; a.c1 = c1; a.c2 = c2; a.cs_dev = cs_dev;
     a.circ_mask = circ_mask;
-    a.left = (float)left; a.right = (float)right;
+    a.sc.left = (float)left; a.sc.right = (float)right;
     /* bgflow forward = nflows inverse: the heights are searched, the widths evaluated; bgflow inverse: the other way round */
     const SetK sw = make_set(left, right, min_bin_width, KB), sh = make_set(bottom, top, min_bin_height, KB);
-    a.sa = inverse ? sw : sh;
-    a.sb = inverse ? sh : sw;
+    a.sc.sa = inverse ? sw : sh;
+    a.sc.sb = inverse ? sh : sw;
     const double beta = identity_init ? (0.6931471805599453 / (1.0 - min_derivative)) : 1.0;
-    a.beta = (float)beta; a.kout = (float)(0.6931471805599453 / (double)(float)beta); a.min_d = (float)min_derivative;
+    a.sc.beta = (float)beta; a.sc.kout = (float)(0.6931471805599453 / (double)(float)beta); a.sc.min_d = (float)min_derivative;
     a.lds_per_wave = 128 * ST + (d + 1) * SROW;
     const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;

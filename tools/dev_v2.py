@@ -56,14 +56,14 @@ if "--check" in sys.argv or len(sys.argv) == 1:
                       f"dlogp rel v1 {e1[1]:.2e} v2 {e2[1]:.2e} orc32 {e3[1]:.2e} | bin mismatches vs orc32 v1 {nb1} v2 {nb2} of {b1.size} | pass-through same {others_same} "
                       f"| max|dl| {np.abs(dl64).max():.1f}")
 
-if "--time" in sys.argv or len(sys.argv) == 1:
+if "--time" in sys.argv or "--time-v2" in sys.argv or len(sys.argv) == 1:
     B = 1 << 20
     g = torch.Generator(device=dev).manual_seed(0)
     xs = [torch.rand(B, d, device=dev, generator=g) for d in (17, 17, 17, 9)]
     for kind in ("B|A", "T|F", "F|T"):
         lg, _ = layer(kind, dev)
         lg.transformer.gemm_mode = "f16x2"
-        for variant in (1, 2):
+        for variant in ((2,) if "--time-v2" in sys.argv else (1, 2)):
             L.bgk_set_option(1, variant)
             for inverse in (False, True):
                 with torch.no_grad():
