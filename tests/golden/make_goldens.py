@@ -421,6 +421,21 @@ def run_flow_recording(flow, zs, inverse=False):
     return xs, dlogp, per_block
 
 
+def coupling_prefix(flow, zs):
+    """state and accumulated log|det J| after the leading CouplingFlow blocks (i.e. before the icdf domain maps and the
+    coordinate transform): the part of the flow the hand-written coupling kernels cover, pinned on its own."""
+    xs = tuple(zs)
+    dlogp = 0.0
+    n = 0
+    for block in flow._blocks:
+        if not isinstance(block, bg.CouplingFlow):
+            break
+        *xs, dd = block(*xs)
+        dlogp = dlogp + dd
+        n += 1
+    return torch.cat(list(xs), dim=-1).numpy(), dlogp.numpy(), n
+
+
 def g_flow16():
     B = 64
     res = {}
@@ -439,6 +454,8 @@ def g_flow16():
             res[f"z_back{sfx}"] = torch.cat(list(zb), dim=-1).numpy(); res[f"dlogp_inv{sfx}"] = dli.numpy()
             res[f"kl_terms{sfx}"] = (gen._target.energy(x) - dlogp).numpy()
             res[f"nll{sfx}"] = gen.energy(x).numpy()
+            res[f"state_c{sfx}"], res[f"dlogp_c{sfx}"], n_c = coupling_prefix(gen.flow, zs)
+            res["n_couplings"] = np.int64(n_c)
         if sfx == "32":
             res["n_params"] = np.int64(sum(p.numel() for p in gen.flow.parameters()))
             res["n_blocks"] = np.int64(len(gen.flow))
@@ -449,11 +466,16 @@ def g_aug():
     B = 64
     res = {}
     u = [rng_f32(51 + i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9, 66))]
+    # auxiliary variables away from the ends of (0, 1): their images go through the Normal icdf (f32 erfinv: the reference's
+    # own f32-vs-f64 gap explodes in the tails and would hide every other error)
+    u[4] = (np.float32(0.1) + np.float32(0.8) * u[4]).astype(np.float32)
     for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
         gen = build_cfg5(dt)
         with torch.no_grad():
             zs = [torch.tensor(v, dtype=dt) for v in u]
             xs, dlogp, _ = run_flow_recording(gen.flow, zs)
+            res[f"state_c{sfx}"], res[f"dlogp_c{sfx}"], n_c = coupling_prefix(gen.flow, zs)
+            res["n_couplings"] = np.int64(n_c)
             res[f"x{sfx}"] = xs[0].numpy(); res[f"aug{sfx}"] = xs[1].numpy(); res[f"dlogp{sfx}"] = dlogp.numpy()
             zb, dli, _ = run_flow_recording(gen.flow, list(xs), inverse=True)
             res[f"z_back{sfx}"] = torch.cat(list(zb), dim=-1).numpy(); res[f"dlogp_inv{sfx}"] = dli.numpy()

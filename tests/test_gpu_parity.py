@@ -252,6 +252,43 @@ def test_ic_roundtrip_at_scale(hip_lib, golden, dev):
     assert torch.isfinite(dl).all() and torch.isfinite(dli).all()
 
 
+def rel_per_sample(a, ref, floor=0.0):
+    a, ref = np.asarray(a).reshape(-1), np.asarray(ref).reshape(-1)
+    return np.abs(a - ref) / np.maximum(np.abs(ref), floor)
+
+
+def assert_cfg3_contract(gen, u, dl, G):
+    """The north-star parity contract on the cfg-3 goldens (reference evaluated in f64), PER SAMPLE:
+      * whole flow: |dlogp - dlogp64| <= 1e-5 |dlogp64|  (the reference's own f32 path: 8.1e-6 on these inputs);
+      * the 16 couplings alone (hand-written coupling kernels; |dlogp| <= 2.1 there, f32 round-off of 272 log terms): state
+        within 1e-6 of the f64 state, log-det within 1e-5 of the sample's whole-flow |dlogp64| and not worse than 1.5x
+        the deviation of the reference's own f32 evaluation from its f64 one."""
+    dl = dl.cpu().numpy()
+    r = rel_per_sample(dl, G["dlogp64"])
+    assert r.max() <= 1e-5, f"whole-flow log-det: per-sample relative error {r.max():.2e}"
+    nc = int(G["n_couplings"])
+    with torch.no_grad():
+        *st, dlc = gen.flow[:nc](*u)
+    state = torch.cat(st, -1).cpu().numpy()
+    assert np.abs(state - G["state_c64"]).max() <= 1e-6
+    err_c = np.abs(dlc.cpu().numpy() - G["dlogp_c64"]).reshape(-1)
+    assert (err_c <= 1e-5 * np.abs(G["dlogp64"]).reshape(-1)).all()
+    ref_noise = np.abs(G["dlogp_c32"] - G["dlogp_c64"]).max()
+    assert err_c.max() <= 1.5 * ref_noise, f"couplings: {err_c.max():.2e} vs the reference's own f32 deviation {ref_noise:.2e}"
+    return r.max()
+
+
+def assert_bin_ties(idx, det, y, what=""):
+    """bin indices of a tolerance-class kernel vs the f32 oracle: any mismatch must be the neighbouring bin of an input within
+    rounding distance of one of the oracle's knots (|x - knot| <= 2.4e-7 = 2 ulp at 1, like tests/test_oracle_golden.py)"""
+    mis = idx != det["bin_idx"]
+    if mis.any():
+        dist = np.abs(det["knots"] - np.asarray(y)[..., None]).min(-1)
+        assert (dist[mis] <= 2.4e-7).all(), f"{what}: {int(mis.sum())} bin mismatches, farthest from a knot {dist[mis].max():.2e}"
+        assert np.abs(idx - det["bin_idx"]).max() <= 1
+    return int(mis.sum())
+
+
 def test_flows_vs_reference_goldens(hip_lib, golden, dev):
     """whole flows through the bgflow-compatible API on the GPU vs the reference's outputs"""
     import bgflow_amd as bg
@@ -278,11 +315,8 @@ def test_flows_vs_reference_goldens(hip_lib, golden, dev):
     u = [t(G[k], dev) for k in ("u_bonds", "u_angles", "u_torsions", "u_fixed")]
     with torch.no_grad():
         x, dl = gen.flow(*u)
-        noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
-        err = np.abs(dl.cpu().numpy() - G["dlogp64"])
-        assert err.max() <= 1e-5 * np.abs(G["dlogp64"]).max() + noise, err.max()
-        assert (np.abs(dl.cpu().numpy() - G["dlogp32"]) / np.abs(G["dlogp32"])).max() < 2e-5
-        np.testing.assert_allclose(x.cpu().numpy(), G["x64"], rtol=0, atol=5 * np.abs(G["x32"] - G["x64"]).max() + 1e-5)  # f32 erfinv tails of the icdf maps (torch ops) dominate
+        assert_cfg3_contract(gen, u, dl, G)
+        np.testing.assert_allclose(x.cpu().numpy(), G["x64"], rtol=0, atol=5 * np.abs(G["x32"] - G["x64"]).max() + 1e-5)  # f32 erfinv tails of the icdf maps dominate
         kl = gen._target.energy(x) - dl
         np.testing.assert_allclose(kl.cpu().numpy(), G["kl_terms64"], rtol=2e-4, atol=0.5)
 
@@ -300,7 +334,7 @@ def test_flow16_vs_oracle_bin_indices(hip_lib, golden, dev):
     pb, trace = [], []
     (xo,), dlo = fo.run_flow(gen_cpu.flow, u, dtype=np.float32, per_block=pb, trace=trace)
     xs = [t(v, dev) for v in u]
-    total = 0
+    n_ties = 0
     with torch.no_grad():
         for i, block in enumerate(gen.flow):
             if isinstance(block, bg.CouplingFlow):
@@ -308,16 +342,19 @@ def test_flow16_vs_oracle_bin_indices(hip_lib, golden, dev):
                 # feed the ORACLE's inputs of this layer, so that index equality is a per-layer statement
                 ins = [t(v, dev) for v in (u if i == 0 else pb[i - 1][0])]
                 *outs, ddl = block(*ins)
-                idx = block.transformer.last_bin_indices
-                if idx is not None:   # (None when the fused path ran; covered by test_fused_*)
-                    assert np.array_equal(idx.cpu().numpy(), trace[i]["bin_idx"]), f"layer {i}"
+                idx = block.transformer.last_bin_indices.cpu().numpy()
                 ti = block.transformed_indices[0]
+                # the shipped default (fused split-f16 kernel) is tolerance-class: equal, or an ulp-tie at a knot
+                n_ties += assert_bin_ties(idx, trace[i], (u if i == 0 else pb[i - 1][0])[ti], f"layer {i}")
                 np.testing.assert_allclose(outs[ti].cpu().numpy(), pb[i][0][ti], rtol=0, atol=2e-6)
         x, dl = gen.flow(*xs)
-    # whole flow (the 4 icdf domain maps run stock torch ops, erfinv in f32): within 1e-5 relative plus the
-    # f32 noise the REFERENCE itself shows on these inputs (|ref32 - ref64|)
-    noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
-    assert np.abs(dl.cpu().numpy() - dlo).max() <= 1e-5 * np.abs(dlo).max() + noise
+    assert n_ties <= 2, f"{n_ties} tie mismatches on 64 x 240 elements"
+    assert_cfg3_contract(gen, xs, dl, G)
+    # and against the f32 CPU oracle, per sample: two f32 evaluations, each within 1e-5 of the f64 reference (asserted above for
+    # the GPU; 4.6e-6 for the oracle), cannot be asked to agree better than the sum
+    r64 = rel_per_sample(dlo, G["dlogp64"]).max()
+    assert r64 <= 1e-5
+    assert rel_per_sample(dl.cpu().numpy(), dlo).max() <= 1e-5 + r64
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -388,11 +425,8 @@ def test_fused_flow16_bit_exact_and_golden(hip_lib, golden, dev):
     for a, b in zip(ics, ics_o):
         assert np.array_equal(a.cpu().numpy().view(np.uint32), b.view(np.uint32))
     assert np.array_equal(dl.cpu().numpy().view(np.uint32), dl_o.view(np.uint32))
-    noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
-    assert np.abs(dl_all.cpu().numpy() - G["dlogp64"]).max() <= 1e-5 * np.abs(G["dlogp64"]).max() + noise
-    for i in range(16):
-        pass
-    np.testing.assert_allclose(torch.cat(ics, -1).cpu().numpy(), G["block15_32"][:, :60], rtol=0, atol=2e-5)
+    assert_cfg3_contract(gen, [t(v, dev) for v in u], dl_all, G)
+    np.testing.assert_allclose(torch.cat(ics, -1).cpu().numpy(), G["block15_32"][:, :60], rtol=0, atol=2e-6)
 
 
 def test_fused_roundtrip_at_scale(hip_lib, dev):
@@ -418,32 +452,37 @@ def _set_gemm_mode(flow, mode):
 @pytest.mark.parametrize("kind", ["T|F", "F|T", "B|A"])
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("B", [1, 31, 4133])
-def test_fused_split_f16_layer_vs_oracle(hip_lib, dev, kind, inverse, B):
-    """gemm_mode='f16x2' (conditioner GEMMs as hi+lo f16 pairs on the f16 matrix cores): same accuracy class as
-    the exact-f32 kernel -- measured against the f64 oracle -- and agreement with the f32 oracle to rounding"""
+@pytest.mark.parametrize("generation", [2, 1])
+def test_fused_split_f16_layer_vs_oracle(hip_lib, dev, kind, inverse, B, generation):
+    """gemm_mode='f16x2' (conditioner GEMMs as hi+lo f16 pairs on the f16 matrix cores; generation 2 = the shipped
+    bgk_fused2.hip kernel, 1 = its predecessor): per sample within 1e-5 of the f64 oracle, outputs within 1e-6, same accuracy
+    class as the exact-f32 kernel, and every bin index equal to the f32 oracle's or an ulp-tie at a knot"""
     from oracle import flow_oracle as fo
     layer_cpu, ti = _layer(kind)
     layer, _ = _layer(kind, dev)
     xs = [synth(B + 7 * i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9))]
     layer.transformer.return_bin_indices = True
     res = {}
-    for mode in ("f32", "f16x2"):
-        layer.transformer.gemm_mode = mode
-        with torch.no_grad():
-            *outs, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
-        assert layer.transformer._fused_cache.get("mode") == mode, "the fused path must have run in this mode"
-        res[mode] = (outs[ti].cpu().numpy(), dl.cpu().numpy(), layer.transformer.last_bin_indices.cpu().numpy())
+    prev = hip_lib.bgk_set_option(1, generation)
+    try:
+        for mode in ("f32", "f16x2"):
+            layer.transformer.gemm_mode = mode
+            with torch.no_grad():
+                *outs, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
+            assert layer.transformer._fused_cache.get("mode") == mode, "the fused path must have run in this mode"
+            res[mode] = (outs[ti].cpu().numpy(), dl.cpu().numpy(), layer.transformer.last_bin_indices.cpu().numpy())
+    finally:
+        hip_lib.bgk_set_option(1, prev)
+    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64)
     trace = []
-    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, trace)
+    fo.run_block(layer_cpu, xs, inverse, np.float32, trace)
     e32 = np.abs(res["f32"][0] - outs64[ti]).max(), np.abs(res["f32"][1] - dl64).max()
     e16 = np.abs(res["f16x2"][0] - outs64[ti]).max(), np.abs(res["f16x2"][1] - dl64).max()
-    assert e16[0] <= 3 * e32[0] + 2e-7, f"outputs: split-f16 {e16[0]:.2e} vs f32 {e32[0]:.2e} (error to the f64 oracle)"
+    assert e16[0] <= 1e-6 and e16[0] <= 3 * e32[0] + 2e-7, f"outputs: split-f16 {e16[0]:.2e} vs f32 {e32[0]:.2e} (error to the f64 oracle)"
+    assert rel_per_sample(res["f16x2"][1], dl64, floor=1.0).max() <= 1e-5      # one layer: |dlogp| < 1, i.e. absolute 1e-5
     assert e16[1] <= 3 * e32[1] + 2e-6, f"dlogp: split-f16 {e16[1]:.2e} vs f32 {e32[1]:.2e}"
-    np.testing.assert_allclose(res["f16x2"][0], res["f32"][0], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(res["f16x2"][1], res["f32"][1], rtol=2e-5, atol=2e-5)
-    # bin indices: identical except for inputs within rounding distance of a knot (then the neighbouring bin)
-    diff = res["f16x2"][2] != trace[0]["bin_idx"]
-    assert diff.mean() <= 1e-3 and np.abs(res["f16x2"][2] - trace[0]["bin_idx"]).max() <= 1
+    n_ties = assert_bin_ties(res["f16x2"][2], trace[0], xs[ti], f"{kind} generation {generation}")
+    assert n_ties <= max(2, res["f16x2"][2].size // 10000)
 
 
 def test_fused_split_f16_flow16_golden(hip_lib, golden, dev):
@@ -457,9 +496,8 @@ def test_fused_split_f16_flow16_golden(hip_lib, golden, dev):
         *ics, dl = gen.flow[:16](*[t(v, dev) for v in u])
         x, dl_all = gen.flow(*[t(v, dev) for v in u])
     assert all(b.transformer._fused_cache.get("mode") == "f16x2" for b in list(gen.flow)[:16])
-    noise = np.abs(G["dlogp32"] - G["dlogp64"]).max()
-    assert np.abs(dl_all.cpu().numpy() - G["dlogp64"]).max() <= 1e-5 * np.abs(G["dlogp64"]).max() + noise
-    np.testing.assert_allclose(torch.cat(ics, -1).cpu().numpy(), G["block15_32"][:, :60], rtol=0, atol=2e-5)
+    assert_cfg3_contract(gen, [t(v, dev) for v in u], dl_all, G)
+    np.testing.assert_allclose(torch.cat(ics, -1).cpu().numpy(), G["block15_32"][:, :60], rtol=0, atol=2e-6)
     np.testing.assert_allclose(x.cpu().numpy(), G["x64"], rtol=0, atol=5 * np.abs(G["x32"] - G["x64"]).max() + 1e-5)
 
 
@@ -485,9 +523,15 @@ def test_augmented_flow_cfg5_on_gpu(hip_lib, golden, dev):
     with torch.no_grad():
         x, aug, dl = gen.flow(*u)
         *zb, dli = gen.flow(x, aug, inverse=True)
-    noise = np.abs(G["dlogp32"] - G["dlogp64"])
-    assert np.abs(dl.cpu().numpy() - G["dlogp64"]).max() <= 2 * noise.max()
-    assert np.median(np.abs(dl.cpu().numpy() - G["dlogp32"]) / np.abs(G["dlogp32"])) < 1e-3
+        nc = int(G["n_couplings"])
+        *st, dlc = gen.flow[:nc](*u)
+    # the 16 couplings (10 spline + 6 affine: the hand-written kernels), per sample, against the reference's f64 evaluation
+    assert rel_per_sample(dlc.cpu().numpy(), G["dlogp_c64"]).max() <= 1e-5
+    assert np.abs(torch.cat(st, -1).cpu().numpy() - G["state_c64"]).max() <= 1e-6
+    # whole flow: the Normal icdf of the 66 auxiliary variables is an f32 erfinv in the reference too -- its own f32 path
+    # is 3.7e-3 (relative, per sample) away from its f64 one on these inputs; we must not be farther
+    ref_dev = rel_per_sample(G["dlogp32"], G["dlogp64"])
+    assert (rel_per_sample(dl.cpu().numpy(), G["dlogp64"]) <= 1.1 * ref_dev.max()).all()
     assert np.abs(x.cpu().numpy() - G["x64"]).max() <= 5 * np.abs(G["x32"] - G["x64"]).max() + 1e-5
     assert np.abs(aug.cpu().numpy() - G["aug64"]).max() <= 2 * np.abs(G["aug32"] - G["aug64"]).max()
     assert torch.isfinite(dli).all()
