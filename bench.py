@@ -1,18 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- flow samples/s (forward + log|det J|) of the BASELINE workload on N MI355X GPUs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg5] [--batch B]
 
-One "step" = one pass of the hot path (prior sample already resident in HBM -> flow forward ->
-x, dlogp) over one batch of B synthetic samples PER RANK (weak scaling: the batch is sharded
-data-parallel, parameters replicated, no data-path collective in sampling).  Rank 0 prints ONE JSON
-line.  `roofline` describes the dominant kernel (HIP-event timed inside this process, on the stream
-the kernels are launched on); `cpu_baseline` times the CPU oracle (oracle/, kind "port") on a bounded
-sample of the same workload on the host cores (rank 0, N=1 only).
+One "step" = one pass of the hot path (prior sample already resident in HBM -> flow forward -> x, dlogp) over one batch of
+B synthetic samples PER RANK (weak scaling: the batch is sharded data-parallel, parameters replicated, no data-path collective
+in sampling).  With --gpus N > 1 and no torchrun environment the script launches its N ranks itself
+(``python -m torch.distributed.run --nproc-per-node N``, rendezvous on 127.0.0.1); under torchrun it is one of the ranks.
+Rank 0 prints ONE JSON line:
+
+  value / ms_per_step   whole-job samples/s over the timed K steps (barrier + synchronize on both sides, max over ranks)
+  roofline              the dominant kernel (the fused coupling layer, one launch per coupling block): SURVEY.md 8(d)'s algorithmic
+                        bytes per launch / its average launch duration (HIP events on the launch stream, this process) against the
+                        8 TB/s HBM peak; `mfma_util` = matrix-core flops the kernel executes / duration against the 2.5 PFLOP/s
+                        dense f16 peak; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes (a profile
+                        constant, labelled as such); `step_view` = the whole step in the same accounting
+  cpu_baseline          the reference's op chain on the host cores (rank 0, N = 1): `value` = stock torch-CPU ops, all physical
+                        cores (oracle/torch_flow.py, kind "port"); the scalar C oracle is timed beside it; `parity_sample` compares
+                        the GPU path with the C oracle on the first samples (log-det error, bin-index ties)
+  exact_f32_mode, cfg2, cfg5, kl   side measurements (HIP events, >= 10 steps each)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,16 +34,28 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from bgflow_amd import configs, dp  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (gemm_mode "f32" only)
 
-# algorithmic bytes per sample of the hand-written kernels (fp32)
+# algorithmic bytes per sample of the hand-written kernels (fp32), whole step
 ALG_BYTES = {"cfg3": 26800.0, "cfg2": 4672.0, "cfg5": 24384.0}
 
 
+def self_launch(args_list, n):
+    """Re-exec under torch.distributed.run with one rank per GPU and relay rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + args_list
+    return subprocess.call(cmd, env=env)
+
+
 def make_workload(name, dev):
+    from bgflow_amd import configs
     if name == "cfg3":
         gen = configs.make_ala2_spline_generator(dev)
         dims = (17, 17, 17, 9)
@@ -41,7 +65,7 @@ def make_workload(name, dev):
         gen = configs.make_ala2_augmented_generator(dev)
         dims = (17, 17, 17, 9, 66)
         sampler = lambda n, g: [torch.rand(n, d, device=dev, generator=g) for d in dims]  # noqa: E731
-        desc = "augmented ala2 flow: 10 RQ-spline + 6 affine couplings (hidden 128x128 SiLU) + 5 icdf maps + mixed IC (cfg 5, f32)"
+        desc = "augmented ala2 flow: 10 RQ-spline + 6 affine couplings (hidden 128x128 SiLU) + 5 icdf maps + mixed IC (cfg 5)"
     elif name == "cfg2":
         gen = configs.make_affine8_generator(device=dev)
         sampler = lambda n, g: [torch.randn(n, 64, device=dev, generator=g)]  # noqa: E731
@@ -51,19 +75,35 @@ def make_workload(name, dev):
     return gen, sampler, desc
 
 
-def layer_macs(block):
-    """multiply-accumulates per sample of a coupling block's conditioner"""
-    macs = 0
-    for m in block.modules():
-        if isinstance(m, torch.nn.Linear):
-            macs += m.in_features * m.out_features
-    return macs
+def coupling_stats(block, gemm_mode):
+    """(SURVEY 8(d) algorithmic bytes per sample, conditioner MACs per sample, matrix-core flops per 32-sample tile the fused
+    kernel executes) of one coupling block"""
+    tr = block.transformer
+    lin = [m for m in block.modules() if isinstance(m, torch.nn.Linear)]
+    macs = sum(m.in_features * m.out_features for m in lin)
+    if type(tr).__name__ == "ConditionalSplineTransformer":
+        P, n_in = lin[-1].out_features, lin[0].in_features
+        nm = int(torch.as_tensor(tr._is_circular).numel())
+        d = nm if nm > 1 else (P // 24 if bool(torch.as_tensor(tr._is_circular).any()) else P // 25)   # P = 3 K d + #non-circular, K = 8
+        alg = 4.0 * (P + 2 * d + 2)
+        S0 = (n_in + 1 + 15) // 16
+        chunks = (d + 4) // 5
+        last_tiles = ((d - 5 * (chunks - 1)) * 25 + 31) // 32
+        if gemm_mode == "f32":      # 32x32x2 f32 MFMAs: k2-steps incl. bias, 4 tiles each (bgk_fused.hip)
+            T0 = (((n_in + 1) // 2 + 3) & ~3) + 1
+            n_mfma = 4 * T0 + 4 * 65 + (chunks - 1) * 4 * 65 + (2 if last_tiles <= 2 else 4) * 65
+            return alg, macs, n_mfma * 2 * 32 * 32 * 2
+        per = 1 if gemm_mode == "bf16" else 3
+        n_mfma = 4 * per * S0 + (4 * 8 * per + 4) + (chunks - 1) * (4 * 8 * per + 4)
+        n_mfma += (2 * 8 * per + 2) if (last_tiles <= 2 and gemm_mode == "f16x2") else (4 * 8 * per + 4)
+        return alg, macs, n_mfma * 2 * 32 * 32 * 16
+    d = lin[-1].out_features            # affine: mu, s, y in, y out, dlogp
+    return 4.0 * (4 * d + 2), macs, None
 
 
 def timed_steps(gen, zs, steps):
-    """K passes of the flow with HIP events around every hand-written-kernel block (events are recorded
-    on the current stream = the stream the kernels are launched on).  Returns {block index: [ms,...]}."""
-    from bgflow_amd.flow import CouplingFlow, WrapFlow
+    """K passes of the flow with HIP events around every block (recorded on the current stream = the stream the kernels are
+    launched on).  Returns [(block index, start event, end event), ...]."""
     evs = []
     with torch.no_grad():
         for _ in range(steps):
@@ -79,50 +119,202 @@ def timed_steps(gen, zs, steps):
     return evs
 
 
-def measured_traffic(kernel, batch=1 << 20):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/<round>_traffic.json,
-    written by tools/profile_round.sh: FETCH_SIZE x 2 [gfx950 rule] + WRITE_SIZE, KiB units), or None"""
+def event_ms_per_call(fn, steps, warmup):
+    """average duration of fn() over `steps` calls, HIP events on the current stream"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def flow_pass(gen, zs):
+    def run():
+        with torch.no_grad():
+            xs = tuple(zs)
+            total = 0.0
+            for block in gen.flow:
+                *xs, dd = block(*xs)
+                total = total + dd
+        return total
+    return run
+
+
+def measured_traffic(kernel, batch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/<round>_traffic.json, written by
+    tools/profile_round.sh: FETCH_SIZE x 2 [gfx950 rule] + WRITE_SIZE), scaled to the batch, or (None, None)"""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
-    if not files:
-        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    for f in reversed(files):
+        try:
+            v = json.load(open(f)).get(kernel, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            v = None
+        if v is not None:
+            return v * (batch / float(1 << 20)), os.path.relpath(f, ROOT)
+    return None, None
+
+
+def host_cpu():
+    model, cores = "unknown CPU", set()
     try:
-        v = json.load(open(files[-1])).get(kernel, {}).get("hbm_bytes_per_launch")
-        return None if v is None else v * (batch / float(1 << 20))     # the PMC passes ran at 2^20 samples per launch
-    except Exception:
-        return None
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_phys = min(len(cores), avail) if cores else max(1, avail // 2)
+    return model, n_phys, avail
 
 
-def cpu_baseline(workload, n_samples):
-    """the CPU oracle (C restatement + OpenMP) on a bounded sample of the same workload"""
+def _cpu_flow(workload):
+    from bgflow_amd import configs
+    return {"cfg3": configs.make_ala2_spline_generator, "cfg5": configs.make_ala2_augmented_generator,
+            "cfg2": configs.make_affine8_generator}[workload]()
+
+
+def _cpu_worker(job):
+    """one process of the multi-process torch-CPU leg: seconds per pass (best of 3) over its own chunk"""
+    workload, chunk, threads, seed = job
+    torch.set_num_threads(threads)
+    from oracle import torch_flow as tfl
+    gen = _cpu_flow(workload)
+    g = torch.Generator().manual_seed(seed)
+    dims = {"cfg3": (17, 17, 17, 9), "cfg5": (17, 17, 17, 9, 66), "cfg2": (64,)}[workload]
+    ut = [torch.rand(chunk, d, generator=g) if workload != "cfg2" else torch.randn(chunk, d, generator=g) for d in dims]
+    tfl.run_flow(gen.flow, ut)
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        tfl.run_flow(gen.flow, ut)
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def cpu_baseline(workload, gen_gpu, dev, n_c_samples):
+    """The reference's op chain on the host cores (the reference itself cannot travel to the GPU box):
+       leg 1 (value): stock torch-CPU ops -- vectorised aten, all physical cores, chunks of 2^15 samples, best of 5;
+       leg 2: the scalar C oracle (OpenMP over samples; the parity checker, latency-bound by design);
+       parity_sample: the GPU path against the C oracle on the first 2^14 samples."""
+    from bgflow_amd import configs
     from oracle import flow_oracle as fo
     from oracle import oracle as orc
+    from oracle import torch_flow as tfl
     orc.build()
+    model, n_phys, n_avail = host_cpu()
     if workload == "cfg3":
         gen = configs.make_ala2_spline_generator()
+        dims = (17, 17, 17, 9)
         rng = np.random.default_rng(1234)
-        u = [rng.random((n_samples, d), dtype=np.float32) for d in (17, 17, 17, 9)]
+        u = [rng.random((n_c_samples, d), dtype=np.float32) for d in dims]
+    elif workload == "cfg5":
+        gen = configs.make_ala2_augmented_generator()
+        dims = (17, 17, 17, 9, 66)
+        rng = np.random.default_rng(1234)
+        u = [rng.random((n_c_samples, d), dtype=np.float32) for d in dims]
     else:
         gen = configs.make_affine8_generator()
         rng = np.random.default_rng(1234)
-        u = [rng.standard_normal((n_samples, 64), dtype=np.float32)]
-    fo.run_flow(gen.flow, [v[:256] for v in u], dtype=np.float32)   # warm-up
-    # passes over the same n_samples batch until >= 12 s of CPU work (bounded at 8 passes)
+        u = [rng.standard_normal((n_c_samples, 64), dtype=np.float32)]
+    # ---- leg 1: torch CPU.  Two ways of using all physical cores: one process with n_phys intra-op threads, and
+    # n_phys / 8 processes x 8 threads on independent chunks (the reference's ops are small: they scale poorly past ~8 threads)
+    chunk = 1 << 15
+    legs = {}
+    prev = torch.get_num_threads()
+    torch.set_num_threads(n_phys)
+    ut = [torch.as_tensor(v[:chunk]) for v in u]
+    tfl.run_flow(gen.flow, ut)                                       # warm-up
+    best = float("inf")
+    t_leg = time.perf_counter()
+    for _ in range(5):
+        t0 = time.perf_counter()
+        tfl.run_flow(gen.flow, ut)
+        best = min(best, time.perf_counter() - t0)
+        if time.perf_counter() - t_leg > 10.0:
+            break
+    torch.set_num_threads(prev)
+    legs["one_process"] = dict(value=chunk / best, cores=n_phys, sample=f"best of <=5 passes over one chunk of {chunk} samples "
+                               f"({best:.2f} s each), {n_phys} intra-op threads")
+    workers = max(1, n_phys // 8)
+    if workers > 1:
+        try:
+            import concurrent.futures as cf
+            import multiprocessing as mp
+            with cf.ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as ex:
+                res = list(ex.map(_cpu_worker, [(workload, chunk, 8, 1234 + i) for i in range(workers)], timeout=120))
+            tmax = max(r for r in res)
+            legs["multi_process"] = dict(value=workers * chunk / tmax, cores=workers * 8,
+                                         sample=f"{workers} processes x 8 intra-op threads, each best of 3 passes over its own chunk of {chunk} "
+                                                f"samples, all concurrently (slowest worker {tmax:.2f} s per pass)")
+        except Exception as e:   # the baseline must never take the bench line down
+            legs["multi_process"] = dict(value=None, error=repr(e)[:200])
+    pick = max((k for k in legs if legs[k].get("value")), key=lambda k: legs[k]["value"])
+    torch_leg = dict(value=legs[pick]["value"], unit="samples/s", cores=legs[pick]["cores"], kind="port",
+                     sample=f"forward + log|det J|, f32, torch.no_grad; oracle/torch_flow.py = the reference's op chain on stock aten ops (coordinate "
+                            f"transform: C oracle); best of the two all-core configurations ({pick}): " + legs[pick]["sample"],
+                     torch_cpu_configurations=legs)
+    # ---- leg 2: C oracle
+    fo.run_flow(gen.flow, [v[:256] for v in u], dtype=np.float32)
     passes, dt = 0, 0.0
-    while dt < 12.0 and passes < 8:
+    while dt < 6.0 and passes < 4:
         t0 = time.perf_counter()
         fo.run_flow(gen.flow, u, dtype=np.float32)
         dt += time.perf_counter() - t0
         passes += 1
-    cpu = "unknown CPU"
-    try:
-        with open("/proc/cpuinfo") as f:
-            cpu = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), cpu)
-    except OSError:
-        pass
-    return dict(value=passes * n_samples / dt, unit="samples/s", cores=orc.num_threads(), kind="port", cpu=cpu,
-                sample=f"{passes} pass(es) over {n_samples} samples of the same flow, forward + log|det J|, f32 ({dt:.1f} s); "
-                       f"C restatement of the reference's op chain (oracle/), OpenMP over samples")
+    c_leg = dict(value=passes * n_c_samples / dt, unit="samples/s", cores=orc.num_threads(), kind="port",
+                 sample=f"{passes} pass(es) over {n_c_samples} samples ({dt:.1f} s); scalar C restatement (oracle/bgo_oracle.c, k-ordered fmaf "
+                        f"chains, OpenMP over samples): the bit-exact parity checker, not a throughput reference")
+    # ---- parity sample: GPU path vs the C oracle, layer by layer on the oracle's inputs
+    parity = None
+    if workload == "cfg3" and gen_gpu is not None:
+        import bgflow_amd as bg
+        gen_gpu = configs.make_ala2_spline_generator(dev)     # fresh weights (the KL extra has stepped the bench's generator)
+        n = min(1 << 14, n_c_samples)
+        v = [w[:n] for w in u]
+        pb, trace = [], []
+        _, dl32 = fo.run_flow(gen.flow, v, dtype=np.float32, per_block=pb, trace=trace)
+        n_mis = n_el = 0
+        far = 0.0
+        k = 0
+        with torch.no_grad():
+            for i, block in enumerate(gen_gpu.flow):
+                if not isinstance(block, bg.CouplingFlow):
+                    continue
+                block.transformer.return_bin_indices = True
+                ins = v if i == 0 else pb[i - 1][0]
+                block(*[torch.as_tensor(w).to(dev) for w in ins])
+                idx = block.transformer.last_bin_indices.cpu().numpy()
+                block.transformer.return_bin_indices = False
+                det = trace[k]; k += 1
+                mis = idx != det["bin_idx"]
+                n_mis += int(mis.sum()); n_el += mis.size
+                if mis.any():
+                    y = np.asarray(ins[block.transformed_indices[0]])
+                    far = max(far, float(np.abs(det["knots"] - y[..., None]).min(-1)[mis].max()))
+            *_, dl = gen_gpu.flow(*[torch.as_tensor(w).to(dev) for w in v])
+        r = np.abs(dl.cpu().numpy() - dl32) / np.abs(dl32)
+        parity = dict(samples=n, elements=n_el, bin_index_differences=n_mis, tie_rate=n_mis / max(n_el, 1),
+                      max_distance_to_knot_of_differences=far,
+                      dlogp_rel_vs_f32_oracle=dict(median=float(np.median(r)), p99=float(np.quantile(r, 0.99)), max=float(r.max())),
+                      note="GPU (shipped mode) vs the f32 C oracle, every coupling fed the oracle's inputs; a bin index may differ only "
+                           "where x is within rounding distance (<= 2.4e-7) of a knot; random inputs include icdf tails (the contract "
+                           "tolerance 1e-5 is asserted on the reference's golden vectors in tests/ and smoke())")
+    return dict(torch_leg, cpu=model, logical_cpus=n_avail, c_oracle=c_leg, parity_sample=parity)
 
 
 def main():
@@ -134,29 +326,37 @@ def main():
     ap.add_argument("--gemm", default=None, choices=["f32", "f16x2", "bf16"],
                     help="conditioner GEMM mode of the fused coupling kernel (default: bgflow_amd.dense.GEMM_MODE)")
     ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU per step")
-    ap.add_argument("--cpu-samples", type=int, default=1 << 17)
+    ap.add_argument("--cpu-samples", type=int, default=1 << 16, help="samples of the C-oracle leg of cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the exact-f32 and cfg-2 side measurements")
-    ap.add_argument("--kl-steps", type=int, default=3, help="extra: time this many KL-loss training steps (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-f32, cfg-2 and cfg-5 side measurements")
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of every side measurement")
+    ap.add_argument("--kl-steps", type=int, default=10, help="extra: time this many KL-loss training steps (0 = skip)")
     ap.add_argument("--kl-batch", type=int, default=1 << 18, help="samples per GPU per KL step")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+
+    from bgflow_amd import dp
+    from bgflow_amd import dense as _dense
+    from bgflow_amd.flow import CouplingFlow
     # BGK_BENCH_TEST_SHARED_GPU=1: self-test of the multi-rank code path on a ONE-GPU box (all ranks on cuda:0, gloo for
     # the collectives -- RCCL refuses two ranks on one device).  Never set by the driver; numbers of such a run mean nothing.
     shared_gpu_test = os.environ.get("BGK_BENCH_TEST_SHARED_GPU") == "1"
     rank, world, local = dp.init_from_env("gloo" if shared_gpu_test else "nccl")
     if shared_gpu_test:
         local = 0
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    from bgflow_amd import dense as _dense
     if args.gemm:
         _dense.GEMM_MODE = args.gemm
+    gemm_mode = _dense.GEMM_MODE
     gen, sampler, desc = make_workload(args.workload, dev)
     g = torch.Generator(device=dev).manual_seed(dp.rank_seed(1234, rank))
     zs = sampler(args.batch, g)
 
+    # ---- headline: W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize, max over ranks
     for _ in range(args.warmup):
         timed_steps(gen, zs, 1)
     torch.cuda.synchronize(dev)
@@ -168,71 +368,70 @@ def main():
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank = [args.batch * args.steps / elapsed_local]
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tl = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(tl) for _ in range(world)]
+        torch.distributed.all_gather(allt, tl)
+        elapsed = max(float(v.item()) for v in allt)
+        per_rank = [args.batch * args.steps / float(v.item()) for v in allt]
+    solo = rank == 0 and world == 1
+    E, W = args.extra_steps, 2
 
     # ---- extra: the same workload with the conditioner GEMMs in exact-f32 MFMA mode (bit-identical to the CPU oracle)
     exact = None
-    gemm_mode = _dense.GEMM_MODE
-    if args.workload == "cfg3" and gemm_mode != "f32" and rank == 0 and world == 1 and not args.no_extras:
+    if args.workload == "cfg3" and gemm_mode != "f32" and solo and not args.no_extras:
         _dense.GEMM_MODE = "f32"
-        timed_steps(gen, zs, 1)
-        torch.cuda.synchronize(dev)
-        te = time.perf_counter()
-        timed_steps(gen, zs, 3)
-        torch.cuda.synchronize(dev)
-        te = (time.perf_counter() - te) / 3
-        exact = dict(gemm="f32", value=args.batch / te, unit="samples/s", ms_per_step=1e3 * te, steps=3,
-                     note="same flow, conditioner GEMMs on the f32-input MFMA (exact fma chain, bit-identical to the oracle)")
+        ms = event_ms_per_call(flow_pass(gen, zs), E, W)
+        exact = dict(gemm="f32", value=args.batch / (1e-3 * ms), unit="samples/s", ms_per_step=ms, steps=E, timer="HIP events",
+                     note="same flow, conditioner GEMMs on the f32-input MFMA (exact fma chain): bit-identical to the CPU oracle")
         _dense.GEMM_MODE = gemm_mode
-        timed_steps(gen, zs, 1)   # re-pack for the headline mode (KL bench below uses the generic path)
+        flow_pass(gen, zs)()      # re-pack for the headline mode
         torch.cuda.synchronize(dev)
 
-    # ---- extra (cfg 5 is specified "fp32 vs bf16"): the same flow with bf16 weights / GEMM inputs in the spline layers
-    bf16_leg = None
-    if args.workload == "cfg5" and gemm_mode != "bf16" and rank == 0 and world == 1 and not args.no_extras:
-        _dense.GEMM_MODE = "bf16"
-        timed_steps(gen, zs, 2)
-        torch.cuda.synchronize(dev)
-        tb = time.perf_counter()
-        timed_steps(gen, zs, 5)
-        torch.cuda.synchronize(dev)
-        tb = (time.perf_counter() - tb) / 5
-        bf16_leg = dict(gemm="bf16", value=args.batch / tb, unit="samples/s", ms_per_step=1e3 * tb, steps=5,
-                        note="REDUCED PRECISION leg: bf16 weights + GEMM inputs in the 10 spline layers (f32 accumulate; knots, bin "
-                             "search, log-det f32); the 6 affine layers stay split-f16")
-        _dense.GEMM_MODE = gemm_mode
-        timed_steps(gen, zs, 1)
-        torch.cuda.synchronize(dev)
-
-    # ---- extra: BASELINE.json configs[1] (8 affine coupling blocks, dim 64, batch 2^20) on the same GPU
+    # ---- extra: BASELINE.json configs[1] (8 affine coupling blocks, dim 64, batch 2^20)
     cfg2 = None
-    if args.workload == "cfg3" and not args.no_extras and rank == 0 and world == 1:
+    if args.workload == "cfg3" and solo and not args.no_extras:
         gen2, sampler2, desc2 = make_workload("cfg2", dev)
         z2 = sampler2(1 << 20, torch.Generator(device=dev).manual_seed(1234))
-        timed_steps(gen2, z2, 2)
-        torch.cuda.synchronize(dev)
-        t2 = time.perf_counter()
-        timed_steps(gen2, z2, 5)
-        torch.cuda.synchronize(dev)
-        t2 = (time.perf_counter() - t2) / 5
-        cfg2 = dict(workload=desc2, value=(1 << 20) / t2, unit="samples/s", ms_per_step=1e3 * t2, steps=5, batch=1 << 20,
-                    hbm_view=dict(algorithmic_bytes_per_sample=ALG_BYTES["cfg2"],
-                                  achieved_GBs=ALG_BYTES["cfg2"] * (1 << 20) / t2 / 1e9, peak_GBs=HBM_PEAK_GBS),
+        ms = event_ms_per_call(flow_pass(gen2, z2), E, W)
+        cfg2 = dict(workload=desc2, value=(1 << 20) / (1e-3 * ms), unit="samples/s", ms_per_step=ms, steps=E, batch=1 << 20,
+                    timer="HIP events",
+                    hbm_view=dict(algorithmic_bytes_per_sample=ALG_BYTES["cfg2"], achieved_GBs=ALG_BYTES["cfg2"] * (1 << 20) / (1e-3 * ms) / 1e9,
+                                  peak_GBs=HBM_PEAK_GBS, frac=ALG_BYTES["cfg2"] * (1 << 20) / (1e-3 * ms) / 1e9 / HBM_PEAK_GBS),
                     note="fused affine coupling kernel (both conditioner MLPs on the f16 matrix cores + affine tail), 8 launches")
         del gen2, z2
 
-    # ---- extra (second half of BASELINE.json's metric): KL-loss training steps/s -------------------------
-    # one step = kldiv(B).mean() -> backward through the hand-written backward kernels -> one all-reduce of
-    # [sum, n] (+ one flat gradient bucket) -> Adam.  Reported next to the headline, not instead of it.
+    # ---- extra: BASELINE.json configs[4] (augmented flow, fp32 vs bf16, batch 2^20)
+    cfg5 = None
+    if args.workload == "cfg3" and solo and not args.no_extras:
+        gen5, sampler5, desc5 = make_workload("cfg5", dev)
+        z5 = sampler5(1 << 20, torch.Generator(device=dev).manual_seed(1234))
+        legs = {}
+        for mode in (gemm_mode if gemm_mode != "bf16" else "f16x2", "bf16"):
+            _dense.GEMM_MODE = mode
+            ms = event_ms_per_call(flow_pass(gen5, z5), E, W)
+            legs["bf16" if mode == "bf16" else "f32"] = dict(
+                gemm=mode, value=(1 << 20) / (1e-3 * ms), unit="samples/s", ms_per_step=ms, steps=E,
+                hbm_view_frac=ALG_BYTES["cfg5"] * (1 << 20) / (1e-3 * ms) / 1e9 / HBM_PEAK_GBS)
+        _dense.GEMM_MODE = gemm_mode
+        legs["bf16"]["note"] = ("REDUCED PRECISION leg: bf16 weights + GEMM inputs in the 10 spline layers (f32 accumulate; knots, bin search, "
+                                "log-det f32); the 6 affine layers stay split-f16")
+        cfg5 = dict(workload=desc5, batch=1 << 20, timer="HIP events", **legs)
+        del gen5, z5
+        flow_pass(gen, zs)()
+        torch.cuda.synchronize(dev)
+
+    # ---- extra (second half of BASELINE.json's metric): KL-loss training steps/s.  One step = kldiv(B).mean() -> backward through
+    # the hand-written backward kernels -> ONE all-reduce of [sum, n] (+ one flat gradient bucket) -> optimizer step.
     kl = None
-    if args.kl_steps > 0:
+    if args.kl_steps > 0 and args.workload != "cfg2":
         params = [p for p in gen.flow.parameters()]
         opt = torch.optim.Adam(params, lr=1e-5)
         zk = sampler(args.kl_batch, g)
+        last = [None]
 
         def kl_step():
             opt.zero_grad(set_to_none=True)
@@ -241,65 +440,74 @@ def main():
             loss.backward()
             dp.allreduce_gradients_(params)
             opt.step()
-            return loss
+            last[0] = loss
         kl_step()
         torch.cuda.synchronize(dev)
         if world > 1:
             torch.distributed.barrier()
-        tk = time.perf_counter()
-        for _ in range(args.kl_steps):
-            last = kl_step()
-        torch.cuda.synchronize(dev)
+        ms = event_ms_per_call(kl_step, args.kl_steps, 1)
         if world > 1:
-            torch.distributed.barrier()
-        dtk = time.perf_counter() - tk
-        kl = dict(steps_per_s=args.kl_steps / dtk, samples_per_s=args.kl_steps * args.kl_batch * world / dtk,
-                  batch_per_gpu=args.kl_batch, steps=args.kl_steps, loss=float(last.detach()),
+            tm = torch.tensor([ms], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+            ms = float(tm.item())
+        kl = dict(steps_per_s=1e3 / ms, samples_per_s=args.kl_batch * world * 1e3 / ms, ms_per_step=ms, batch_per_gpu=args.kl_batch,
+                  steps=args.kl_steps, timer="HIP events", loss=float(last[0].detach()),
                   note="fwd: one-launch coupling layers (training variant, saves pre-activations + spline parameters) + IC / CDF kernels; "
                        "bwd: bgk_rqs_backward / bgk_ic_ic2xyz_backward, conditioner input-gradient chain on bgk_dense_backward_dx, "
-                       "split-K weight-gradient GEMMs, bias gradients on bgk_column_sum; one all-reduce of [sum, n] + one "
-                       "gradient bucket; Adam")
+                       "split-K weight-gradient GEMMs, bias gradients on bgk_column_sum; one all-reduce of [sum, n] + one gradient bucket; Adam")
 
     total_samples = args.batch * world * args.steps
     value = total_samples / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
     if rank == 0:
-        from bgflow_amd.flow import CouplingFlow
         n_blocks = len(gen.flow)
         block_ms = [0.0] * n_blocks
         for i, e0, e1 in evs:
             block_ms[i] += e0.elapsed_time(e1) / args.steps
         coupling = [i for i, b in enumerate(gen.flow) if isinstance(b, CouplingFlow)]
-        # dominant kernel = the coupling-layer kernel (one launch per coupling block)
-        t_coupling_ms = sum(block_ms[i] for i in coupling)
-        n_launch = len(coupling)
-        avg_launch_s = 1e-3 * t_coupling_ms / n_launch
-        flops_per_launch = 2.0 * sum(layer_macs(gen.flow[i]) for i in coupling) / n_launch * args.batch
+        stats = [coupling_stats(gen.flow[i], gemm_mode) for i in coupling]
+        fused = [i for i, st in zip(coupling, stats) if st[2] is not None]          # spline couplings = the dominant kernel's launches
+        n_launch = len(fused) if fused else len(coupling)
+        idxs = fused if fused else coupling
+        avg_launch_s = 1e-3 * sum(block_ms[i] for i in idxs) / n_launch
+        sel = [st for i, st in zip(coupling, stats) if i in idxs]
+        alg_bytes_launch = sum(st[0] for st in sel) / n_launch * args.batch
         alg_bytes_step = ALG_BYTES[args.workload] * args.batch
-        if args.workload in ("cfg3", "cfg5"):
-            split = gemm_mode in ("f16x2", "bf16")
-            roof = dict(bound="mfma", achieved=flops_per_launch / avg_launch_s / 1e12, peak=MFMA_F32_PEAK_TFLOPS,
-                        unit="TFLOP/s", traffic=measured_traffic("coupling_rqs_dense_h2_kernel" if split else "coupling_rqs_dense_kernel", args.batch),
-                        kernel=("coupling_rqs_dense_h2_kernel (fused DenseNet on the f16 matrix cores in split-f16 form + RQ-spline "
-                                "coupling layer)" if split else
-                                "coupling_rqs_dense_kernel (fused DenseNet on the f32-input MFMA + RQ-spline coupling layer)"),
-                        note=("achieved = algorithmic f32 flops of the conditioner (2*MACs) / launch time, peak = dense f32-input MFMA "
-                              "peak: the split-f16 form executes 3 f16 MFMAs per product at 16x the f32 rate, so the fraction can "
-                              "exceed 1; the kernel is then VALU-issue bound (spline + SiLU), see profiles/README.md" if split else
-                              "f32-input MFMA and f32 VALU share the issue port on gfx950: time = MFMA + VALU, see profiles/README.md"),
-                        launches_per_step=n_launch, avg_launch_ms=1e3 * avg_launch_s,
-                        flops_per_launch=flops_per_launch,
-                        hbm_view=dict(note="SURVEY 8(d) algorithmic bytes (unfused kernel boundaries: 26 800 B per sample for cfg 3) "
-                                           "per GPU and step / step time, against the 8 TB/s HBM3E peak",
-                                      algorithmic_bytes_per_step=alg_bytes_step,
-                                      achieved_GBs=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak_GBs=HBM_PEAK_GBS,
-                                      frac=alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS))
+        split = gemm_mode in ("f16x2", "bf16")
+        if args.workload == "cfg2":
+            kname, klabel = "coupling_affine_dense_kernel", "coupling_affine_dense_kernel (fused: 2 DenseNets on the f16 matrix cores + affine tail)"
+        elif gemm_mode == "f16x2":
+            kname, klabel = "coupling_rqs_dense_h2v2_kernel", ("coupling_rqs_dense_h2v2_kernel (bgk_fused2.hip: DenseNet conditioner in split-f16 form on the "
+                                                                "f16 matrix cores threaded through the RQ-spline / activation VALU work, one launch per coupling)")
+        elif gemm_mode == "bf16":
+            kname, klabel = "coupling_rqs_dense_h2_kernel", "coupling_rqs_dense_h2_kernel<bf16> (REDUCED PRECISION conditioner GEMMs)"
         else:
-            roof = dict(bound="hbm", achieved=alg_bytes_step / (1e-3 * ms_per_step) / 1e9, peak=HBM_PEAK_GBS,
-                        unit="GB/s", traffic=measured_traffic("coupling_affine_dense_kernel", args.batch),
-                        kernel="coupling_affine_dense_kernel (fused: 2 DenseNets on the f16 matrix cores + affine tail)")
+            kname, klabel = "coupling_rqs_dense_kernel", "coupling_rqs_dense_kernel (fused DenseNet on the f32-input MFMA + RQ-spline coupling layer)"
+        traffic, traffic_src = measured_traffic(kname, args.batch)
+        roof = dict(bound="hbm", achieved=alg_bytes_launch / avg_launch_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                    traffic=traffic,
+                    traffic_source=(f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, per launch, scaled to "
+                                    f"the batch -- a committed profile constant, not measured in this run") if traffic else None,
+                    kernel=klabel, launches_per_step=n_launch, avg_launch_ms=1e3 * avg_launch_s,
+                    algorithmic_bytes_per_launch=alg_bytes_launch,
+                    note="achieved = SURVEY 8(d) algorithmic bytes of a coupling layer (4 (P + 2 d + 2) B per sample: conditioner output "
+                         "materialised once -- the fused kernel keeps it on chip, so `traffic` is ~8x smaller) x samples per launch / average "
+                         "launch duration (HIP events around each coupling block on the launch stream)")
         roof["frac"] = roof["achieved"] / roof["peak"]
+        flops = [st[2] for st in sel if st[2] is not None]
+        if flops:
+            tiles = (args.batch + 31) // 32
+            ex = sum(flops) / len(flops) * tiles
+            peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS
+            roof["mfma_util"] = dict(executed_flops_per_launch=ex, achieved=ex / avg_launch_s / 1e12, peak=peak, unit="TFLOP/s",
+                                     frac=ex / avg_launch_s / 1e12 / peak,
+                                     algorithmic_flops_per_launch=2.0 * sum(st[1] for st in sel) / n_launch * args.batch,
+                                     note="executed = matrix-core instructions the kernel issues per 32-sample tile x their flops (split-f16: 3 "
+                                          "MFMAs per product, padded tiles included); peak = dense " + ("f16" if split else "f32-input") + " MFMA")
+        roof["step_view"] = dict(algorithmic_bytes_per_step=alg_bytes_step, achieved_GBs=alg_bytes_step / (1e-3 * ms_per_step) / 1e9,
+                                 peak_GBs=HBM_PEAK_GBS, frac=alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS,
+                                 note="SURVEY 8(d) bytes of the WHOLE step (couplings + icdf maps + coordinate transform) / step time")
         roof["block_ms"] = [round(v, 3) for v in block_ms]
         out = dict(metric="flow samples/s (fwd+log|detJ|) at batch 2^20", value=value, unit="samples/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
@@ -307,19 +515,20 @@ def main():
                    config=dict(workload=desc, batch_per_gpu=args.batch, global_batch=args.batch * world,
                                parallelism=f"dp{world}",
                                conditioner_gemm={"f16x2": "split-f16: f32 operands as hi+lo f16 pairs, 3 MFMAs per product, f32 accumulate "
-                                                          "(f32-class accuracy)",
-                                                 "f32": "f32-input MFMA (exact)",
+                                                          "(f32-class accuracy: per-sample log-det within 1e-5 of the reference's f64 goldens)",
+                                                 "f32": "f32-input MFMA (exact, bit-identical to the CPU oracle)",
                                                  "bf16": "REDUCED PRECISION: bf16 weights and GEMM inputs (spline layers), f32 accumulate; "
                                                          "spline / log-det arithmetic f32"}[gemm_mode]),
+                   per_rank_samples_per_s=per_rank,
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_samples)
+            out["cpu_baseline"] = cpu_baseline(args.workload, gen, dev, args.cpu_samples)
         if exact is not None:
             out["exact_f32_mode"] = exact
         if cfg2 is not None:
             out["cfg2"] = cfg2
-        if bf16_leg is not None:
-            out["bf16_mode"] = bf16_leg
+        if cfg5 is not None:
+            out["cfg5"] = cfg5
         if kl is not None:
             out["kl"] = kl
         print(json.dumps(out))

@@ -323,3 +323,25 @@ def test_global_ic(oracle, golden, dtype, sfx, tol, tol_dl):
     # the reference's own inverse is only 3e-8 accurate in f64 (eps clamps); compare with the original x as well
     np.testing.assert_allclose(xb, G["glob_xback" + sfx], rtol=0, atol=max(tol, 1e-7) * 10)
     np.testing.assert_allclose(xb, x, rtol=0, atol=max(tol * 50, 1e-12))
+
+
+def test_torch_cpu_restatement_matches_reference_goldens(golden):
+    """oracle/torch_flow.py (bench.py's second cpu_baseline leg: the reference's op chain on stock torch-CPU ops) reproduces
+    the reference's own f32 outputs on the cfg-3 / cfg-5 fixtures -- forward and inverse -- to f32 round-off"""
+    import torch
+    from bgflow_amd import configs
+    from oracle import torch_flow as tfl
+    for name, make, keys in (("g_flow16", configs.make_ala2_spline_generator, ("u_bonds", "u_angles", "u_torsions", "u_fixed")),
+                             ("g_aug", configs.make_ala2_augmented_generator, ("u_bonds", "u_angles", "u_torsions", "u_fixed", "u_aug"))):
+        G = golden(name)
+        gen = make()
+        xs, dl = tfl.run_flow(gen.flow, [torch.tensor(G[k]) for k in keys])
+        scale = np.abs(G["dlogp32"]).max()
+        assert np.abs(dl.numpy() - G["dlogp32"]).max() <= 2e-7 * scale + 2e-5
+        assert np.abs(xs[0].numpy() - G["x32"]).max() <= 1e-4
+        # inverse direction from the reference's own x (the icdf maps are ill-conditioned in x near the domain ends)
+        xin = [torch.tensor(G["x32"])] + ([torch.tensor(G["aug32"])] if "aug32" in G else [])
+        zs, dli = tfl.run_flow(gen.flow, xin, inverse=True)
+        e = np.abs(dli.numpy() - G["dlogp_inv32"]).reshape(-1)
+        assert np.median(e) <= 1e-4 and np.quantile(e, 0.9) <= 1e-3 and e.max() <= 1e-3 * scale   # cdf maps: steep near the domain ends
+        assert np.abs(torch.cat(list(zs), -1).numpy() - G["z_back32"]).max() <= 1e-4

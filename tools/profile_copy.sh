@@ -1,0 +1,13 @@
+#!/bin/bash
+# copy the judged summaries of a profile round from gpurun_out/prof_<tag> into profiles/ (tracked)
+TAG=${1:-r02}
+cd "$(dirname "$0")/.."
+S=gpurun_out/prof_$TAG
+cp $S/stats/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
+cp $S/traffic.json profiles/${TAG}_traffic.json
+cp $S/traffic.txt profiles/${TAG}_traffic.txt
+cp $S/pmc_summary.txt profiles/${TAG}_pmc_summary.txt
+cp $S/bench_plain.json profiles/${TAG}_bench_line.json
+cp $S/bench_line_under_rocprof.json profiles/${TAG}_bench_line_under_rocprof.json
+[ -s $S/bench_2rank_selftest.json ] && cp $S/bench_2rank_selftest.json profiles/${TAG}_bench_2rank_selftest_shared_gpu.json
+ls -la profiles/ | grep $TAG

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel stats of the default bench command + HBM traffic / SQ counters
-# of the dominant kernel.  Outputs land in gpurun_out/prof_$1; copy the summaries to profiles/ afterwards.
-TAG=${1:-r01}
+# of the dominant kernel.  Outputs land in gpurun_out/prof_$1; copy the summaries to profiles/ afterwards (tools/profile_copy.sh).
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -9,30 +9,26 @@ SHORT="--no-cpu-baseline --kl-steps 0"
 # 1. kernel trace + stats of the bench command (default flags except the CPU leg / KL extra, which launch no hot-path kernels)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py $SHORT > $OUT/bench_under_rocprof.log 2>&1
 grep '"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_line_under_rocprof.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32 -o bench -- python bench.py $SHORT --gemm f32 > $OUT/bench_f32_under_rocprof.log 2>&1
-# 2. PMC passes (separate runs, counters only) over the same command, 2 steps: HBM traffic of every kernel
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python bench.py $SHORT --steps 2 --warmup 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python bench.py $SHORT --steps 2 --warmup 1 > /dev/null 2>&1
+# 2. PMC passes (separate runs, counters only) over the headline workload, 2 steps: HBM traffic of every kernel
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python bench.py $SHORT --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python bench.py $SHORT --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
 python tools/traffic_json.py $OUT/pmc_fetch $OUT/pmc_write $OUT/traffic.json > $OUT/traffic.txt
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_f32 -o p -- python bench.py $SHORT --gemm f32 --steps 2 --warmup 1 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_f32 -o p -- python bench.py $SHORT --gemm f32 --steps 2 --warmup 1 > /dev/null 2>&1
-python tools/traffic_json.py $OUT/pmc_fetch_f32 $OUT/pmc_write_f32 $OUT/traffic_f32.json > $OUT/traffic_f32.txt
-# 3. SQ / GRBM counters of one fused layer (B|A, d = 17), both GEMM modes
+# 3. SQ / GRBM counters of one fused layer (B|A, d = 17), shipped mode and exact-f32 mode
 for MODE in f16x2 f32; do
   export BGK_GEMM=$MODE
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA --output-format csv -d $OUT/pmc_sq_$MODE -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
+  rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/pmc_sq2_$MODE -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
   rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm_$MODE -o p -- python tools/prof_layer.py fused-BA 1048576 3 > /dev/null 2>&1
 done
 unset BGK_GEMM
-for d in pmc_sq_f16x2 pmc_grbm_f16x2 pmc_sq_f32 pmc_grbm_f32; do echo "== $d"; python tools/pmc_summary.py $OUT/$d coupling; done > $OUT/pmc_summary.txt
-# 4. un-profiled bench line (full default command incl. cpu_baseline + KL extra)
+for d in pmc_sq_f16x2 pmc_sq2_f16x2 pmc_grbm_f16x2 pmc_sq_f32 pmc_sq2_f32 pmc_grbm_f32; do echo "== $d"; python tools/pmc_summary.py $OUT/$d coupling; done > $OUT/pmc_summary.txt
+# 4. un-profiled bench line (full default command incl. cpu_baseline + KL extra) and the multi-rank self-test of bench.py
 python bench.py > $OUT/bench_plain.json 2>$OUT/bench_plain.err
-head -c 900 $OUT/bench_plain.json; echo
-cat $OUT/traffic.txt; cat $OUT/pmc_summary.txt | head -60
+BGK_BENCH_TEST_SHARED_GPU=1 python bench.py --gpus 2 --steps 3 --warmup 1 --batch 262144 --kl-steps 2 --kl-batch 65536 > $OUT/bench_2rank_selftest.json 2>$OUT/bench_2rank_selftest.err
+head -c 600 $OUT/bench_plain.json; echo
+cat $OUT/traffic.txt
 python - <<PY
 import csv,glob
-for tag in ("stats","stats_f32"):
-    f=glob.glob("$OUT/%s/**/*kernel_stats.csv" % tag,recursive=True)[0]
-    print(tag)
-    for r in list(csv.DictReader(open(f)))[:8]: print("  ", r["Name"][:80], r["Calls"], r["AverageNs"], r["Percentage"])
+f=glob.glob("$OUT/stats/**/*kernel_stats.csv",recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:10]: print("  ", r["Name"][:80], r["Calls"], r["AverageNs"], r["Percentage"])
 PY
