@@ -6,7 +6,7 @@ from .utils import pack_tensor_in_tuple
 
 __all__ = [
     "BoltzmannGenerator", "unnormalized_kl_div", "unormalized_nll", "sampling_efficiency",
-    "effective_sample_size", "log_weights", "log_weights_given_latent",
+    "effective_sample_size", "log_weights", "log_weights_given_latent", "log_weights_from_samples",
 ]
 
 
@@ -35,6 +35,22 @@ def log_weights_given_latent(x, z, dlogp, prior, target, temperature=1.0, normal
 def log_weights(*x, prior, flow, target, temperature=1.0, normalize=True):
     *z, neg_dlogp = flow(*x, inverse=True, temperature=temperature)
     return log_weights_given_latent(x, z, -neg_dlogp, prior, target, temperature=temperature, normalize=normalize)
+
+
+def log_weights_from_samples(prior, flow, target, num_samples, batch_size, temperature=1.0, normalize=True):
+    """Importance weights of ``num_samples // batch_size`` freshly sampled batches (bg.py:31-52): the batches run through the
+    flow one after the other (bounded memory), weights are normalised over all of them.  Unlike the reference, priors / flows
+    with several tensors per sample are handled too (its ``x_batch, dlogp_batch = flow(*z_batch)`` assumes one)."""
+    zs, xs, dls = [], [], []
+    with torch.no_grad():
+        for _ in range(num_samples // batch_size):
+            z = pack_tensor_in_tuple(prior.sample(batch_size, temperature=temperature))
+            *x, dlogp = flow(*z, temperature=temperature)
+            zs.append(z); xs.append(tuple(x)); dls.append(dlogp)
+        z_cat = tuple(torch.cat([z[i] for z in zs], dim=0) for i in range(len(zs[0])))
+        x_cat = tuple(torch.cat([x[i] for x in xs], dim=0) for i in range(len(xs[0])))
+        dlogp = torch.cat(dls, dim=0)
+    return log_weights_given_latent(x_cat, z_cat, dlogp, prior, target, temperature=temperature, normalize=normalize)
 
 
 def effective_sample_size(log_weights):

@@ -487,6 +487,27 @@ def g_aug():
 
 
 # ---------------------------------------------------------------------------------------------
+# G-augment: StochasticAugmentation (nn/flow/stochastic/augment.py:27-55) with pre-sampled momenta (no RNG in the fixture)
+# ---------------------------------------------------------------------------------------------
+def g_augment():
+    from bgflow.nn.flow.stochastic.augment import StochasticAugmentation
+    B, dim = 48, 6
+    q, p = rng_f32(61, B, dim), rng_f32(62, B, dim, scale=1.3)
+    out = dict(q=q, p=p)
+    for T, sfx in ((1.0, "T1"), (2.5, "T2p5")):
+        layer = StochasticAugmentation(bg.NormalDistribution(dim))
+        with torch.no_grad():
+            x, dl = layer(torch.tensor(q), momenta=torch.tensor(p), temperature=T, cache_momenta=True)
+            qb, dli = layer(x, inverse=True, temperature=T, cache_momenta=True)
+            xm, dlm = layer(x, inverse=True, temperature=T, return_momenta=True)
+            e = layer.distribution.energy(torch.tensor(p), temperature=T)
+        assert torch.equal(layer._cached_momenta_forward, torch.tensor(p)) and torch.equal(layer._cached_momenta_backward, torch.tensor(p))
+        out.update({f"x_{sfx}": x.numpy(), f"dlogp_{sfx}": dl.numpy(), f"q_back_{sfx}": qb.numpy(), f"dlogp_inv_{sfx}": dli.numpy(),
+                    f"x_mom_{sfx}": xm.numpy(), f"dlogp_mom_{sfx}": dlm.numpy(), f"energy_{sfx}": e.numpy()})
+    save("g_augment", **out)
+
+
+# ---------------------------------------------------------------------------------------------
 # G-grads: gradients by torch autograd through the reference (pins the analytic backward kernels)
 # ---------------------------------------------------------------------------------------------
 def g_grads():
@@ -578,7 +599,7 @@ def g_grads():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rqs", "affine", "ic", "flow16", "aug", "grads"]
+    which = sys.argv[1:] or ["rqs", "affine", "ic", "flow16", "aug", "augment", "grads"]
     if "rqs" in which:
         g_rqs_unit()
     if "affine" in which:
@@ -589,5 +610,7 @@ if __name__ == "__main__":
         g_flow16()
     if "aug" in which:
         g_aug()
+    if "augment" in which:
+        g_augment()
     if "grads" in which:
         g_grads()

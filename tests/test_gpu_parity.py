@@ -971,3 +971,9 @@ def test_fused_training_forward_other_activations(hip_lib, dev, act):
     for a, b in zip(res[True], res[False]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=3e-4 * float(b.abs().max()) + 2e-5)
 
+
+
+def test_stochastic_augmentation_on_gpu(hip_lib, golden, dev):
+    """a17: the augmentation layer of cfg 5 on device tensors against the reference golden (augment.py:27-55)"""
+    from test_host_logic import _check_augmentation
+    _check_augmentation(golden("g_augment"), dev)

@@ -443,3 +443,51 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
     assert L.bgk_dense_backward_dx(P1, 425, 425, P1, P1, P1, 120, 120, 0, P1, P1, P1, P1, 1, 8, P1, P1, P1, P1, None, 0, None) == -2
     assert L.bgk_column_sum(P1, 4, 8, 0, P1, 4, P1, None) == -1
 
+
+
+def _check_augmentation(G, device):
+    """StochasticAugmentation vs the reference (nn/flow/stochastic/augment.py:27-55; golden g_augment): pre-sampled momenta pass
+    through with zero log-det, the inverse strips them and charges their energy, return_momenta keeps them, caches work"""
+    t = lambda a: torch.as_tensor(a).to(device)  # noqa: E731
+    q, p = t(G["q"]), t(G["p"])
+    for T, sfx in ((1.0, "T1"), (2.5, "T2p5")):
+        layer = bg.StochasticAugmentation(bg.NormalDistribution(6).to(device))
+        x, dl = layer(q, momenta=p, temperature=T, cache_momenta=True)
+        assert torch.equal(x.cpu(), torch.as_tensor(G[f"x_{sfx}"])) and torch.equal(dl.cpu(), torch.as_tensor(G[f"dlogp_{sfx}"]))
+        assert layer._cached_momenta_forward is p
+        qb, dli = layer(x, inverse=True, temperature=T, cache_momenta=True)
+        assert torch.equal(qb.cpu(), torch.as_tensor(G[f"q_back_{sfx}"]))
+        np.testing.assert_allclose(dli.cpu().numpy(), G[f"dlogp_inv_{sfx}"], rtol=1e-6, atol=1e-6)
+        assert torch.equal(layer._cached_momenta_backward.cpu(), p.cpu())
+        xm, dlm = layer(x, inverse=True, temperature=T, return_momenta=True)
+        assert torch.equal(xm.cpu(), torch.as_tensor(G[f"x_mom_{sfx}"])) and float(dlm.abs().max()) == 0.0
+        # without momenta: fresh samples of the right shape, log-det = their energy at this temperature
+        torch.manual_seed(3)
+        x2, dl2 = layer(q, temperature=T)
+        assert x2.shape == (q.shape[0], 12) and torch.equal(x2[:, :6], q)
+        np.testing.assert_allclose(dl2.cpu().numpy(), layer.distribution.energy(x2[:, 6:], temperature=T).cpu().numpy(), rtol=1e-6)
+        assert abs(float(x2[:, 6:].var()) - T) < 0.6 * T
+
+
+def test_stochastic_augmentation_vs_reference_golden(golden):
+    _check_augmentation(golden("g_augment"), torch.device("cpu"))
+
+
+def test_log_weights_from_samples_host():
+    """bg.py:31-52: weights of freshly sampled batches, normalised over all of them"""
+    from bgflow_amd.bg import log_weights_from_samples, log_weights_given_latent
+
+    class Shift(bg.Flow):
+        def _forward(self, x, **kw):
+            return x + 1.0, torch.full((x.shape[0], 1), 0.25)
+
+        def _inverse(self, x, **kw):
+            return x - 1.0, torch.full((x.shape[0], 1), -0.25)
+    prior, target = bg.NormalDistribution(3), bg.NormalDistribution(3, mean=torch.ones(3))
+    torch.manual_seed(0)
+    lw = log_weights_from_samples(prior, Shift(), target, num_samples=64, batch_size=16)
+    assert lw.shape == (64,) and abs(float(torch.logsumexp(lw, 0))) < 1e-5
+    # N(0,1) pushed by +1 onto N(1,1): all weights equal
+    np.testing.assert_allclose(lw.numpy(), np.full(64, -np.log(64.0)), atol=1e-5)
+    lw_raw = log_weights_from_samples(prior, Shift(), target, num_samples=32, batch_size=16, normalize=False)
+    np.testing.assert_allclose(lw_raw.numpy(), 0.25, atol=1e-5)
