@@ -1,9 +1,10 @@
 """Domain-mapping layer ``CDFTransform`` (bgflow/nn/flow/cdf.py:13-46).
 
 For the marginals the builder installs (truncated normal, normal, uniform; factory/icmarginals.py:41-77)
-and f32 HIP tensors without autograd, one hand-written kernel (bgk_cdf_transform) replaces the ~10
-elementwise aten launches + row reduction; any other distribution, or a call that needs gradients,
-runs the distribution's own cdf / icdf / log_prob (stock PyTorch-ROCm ops, differentiable)."""
+and f32 HIP tensors one hand-written kernel (bgk_cdf_transform) replaces the ~10 elementwise aten launches +
+row reduction, with bgk_cdf_backward behind a torch.autograd.Function for inputs that need gradients; any other
+distribution, or a marginal whose own parameters are being trained, runs the distribution's cdf / icdf / log_prob
+(stock PyTorch-ROCm ops, differentiable)."""
 import numpy as np
 import torch
 
@@ -41,6 +42,54 @@ def _descriptor(dist, d):
         return None
 
 
+def _source_tensors(dist):
+    """the tensors a descriptor is built from (parameters / buffers of the marginal), for cache validation"""
+    out = []
+    for name in ("_mu", "_logsigma", "_cdf_lower_bound", "_cdf_upper_bound", "loc", "scale", "low", "high"):
+        v = getattr(dist, name, None)
+        if torch.is_tensor(v):
+            out.append(v)
+    return out
+
+
+class _CdfFn(torch.autograd.Function):
+    """bgk_cdf_transform with the backward kernel bgk_cdf_backward (no aten ops in the KL / NLL step)"""
+
+    @staticmethod
+    def forward(ctx, x, desc, inverse, eps):
+        out, dlogp = _launch(x, desc, inverse, eps)
+        ctx.desc, ctx.inverse, ctx.eps = desc, inverse, eps
+        ctx.save_for_backward(x, out)
+        return out, dlogp
+
+    @staticmethod
+    def backward(ctx, g_y, g_dlogp):
+        x, y = ctx.saved_tensors
+        x2, ldx = _lib.rowmajor(x)
+        gy2, ldgy = _lib.rowmajor(g_y.contiguous())
+        B, d = x2.shape
+        g_x = torch.empty((B, d), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            st = _lib.lib().bgk_cdf_backward(_lib.ptr(x2), ldx, _lib.ptr(y), d, _lib.ptr(ctx.desc), B, d, int(ctx.inverse),
+                                             int(ctx.eps is not None), float(ctx.eps or 0.0), _lib.ptr(gy2), ldgy,
+                                             _lib.ptr(g_dlogp.reshape(-1).contiguous()), _lib.ptr(g_x), d, _lib.stream_ptr(x.device))
+        _lib.check(st, "bgk_cdf_backward")
+        return g_x, None, None, None
+
+
+def _launch(x, desc, inverse, eps):
+    x2, ldx = _lib.rowmajor(x)
+    B, d = x2.shape
+    out = torch.empty((B, d), dtype=torch.float32, device=x.device)
+    dlogp = torch.empty((B,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = _lib.lib().bgk_cdf_transform(_lib.ptr(x2), ldx, _lib.ptr(desc), B, d, int(inverse),
+                                          int(eps is not None), float(eps or 0.0), _lib.ptr(out), d,
+                                          _lib.ptr(dlogp), 0, _lib.stream_ptr(x.device))
+    _lib.check(st, "bgk_cdf_transform")
+    return out, dlogp[:, None]
+
+
 class CDFTransform(Flow):
     """x -> cdf(x) in [0,1] with log-det = log_prob(x); values are clamped to [eps, 1-eps] and
     log-dets to >= -1/eps exactly like the reference."""
@@ -54,26 +103,27 @@ class CDFTransform(Flow):
     def _kernel(self, x, inverse):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
             return None
-        if torch.is_grad_enabled() and x.requires_grad:
-            return None
+        src = _source_tensors(self.distribution)
+        grad = torch.is_grad_enabled()
+        if grad and any(t.requires_grad for t in src):
+            return None          # learnable marginal: its parameters need gradients -> the distribution's own torch ops
         d = x.shape[-1]
-        key = (d, str(x.device))
-        if key not in self._desc_cache:
+        # the descriptor is a host snapshot of the marginal's parameters: rebuilt whenever one of them was replaced or written
+        # (load_state_dict, optimiser steps, .to()), keyed on storage + version counter
+        key = (d, str(x.device), tuple((t.data_ptr(), t._version, str(t.device)) for t in src))
+        if self._desc_cache.get("key") != key:
             desc = _descriptor(self.distribution, d)
-            self._desc_cache[key] = None if desc is None else desc.to(x.device)
-        desc = self._desc_cache[key]
+            self._desc_cache = {"key": key, "desc": None if desc is None else desc.to(x.device)}
+        desc = self._desc_cache["desc"]
         if desc is None:
             return None
-        x2, ldx = _lib.rowmajor(x)
-        B = x2.shape[0]
-        out = torch.empty((B, d), dtype=torch.float32, device=x.device)
-        dlogp = torch.empty((B,), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            st = _lib.lib().bgk_cdf_transform(_lib.ptr(x2), ldx, _lib.ptr(desc), B, d, int(inverse),
-                                              int(self._eps is not None), float(self._eps or 0.0), _lib.ptr(out), d,
-                                              _lib.ptr(dlogp), 0, _lib.stream_ptr(x.device))
-        _lib.check(st, "bgk_cdf_transform")
-        return out, dlogp[:, None]
+        if grad and x.requires_grad:
+            return _CdfFn.apply(x, desc, inverse, self._eps)
+        return _launch(x, desc, inverse, self._eps)
+
+    def invalidate_kernel_cache(self):
+        """forget the cached descriptor (after in-place edits through ``.data``, which bump no version counter)"""
+        self._desc_cache = {}
 
     def _forward(self, x, *args, **kwargs):
         fast = self._kernel(x, False)

@@ -104,3 +104,68 @@ extern "C" int bgk_cdf_transform(const float* x, int64_t ldx, const float* desc,
     hipLaunchKernelGGL(cdf_kernel, dim3(grid), dim3(CDF_THREADS), shmem, (hipStream_t)stream, a);
     return bgk_launch_status("bgk_cdf_transform");
 }
+
+/* ---- backward (VJP) of cdf_kernel: g_x = g_y dy/dx + g_dlogp d logdet/dx, elementwise --------------------------------
+ * With y saved from the forward pass no erf / erfinv is needed: dy/dx = exp(logdet element) in both directions (the
+ * density resp. its reciprocal), d logdet/dx = -z/sigma (cdf direction) or (z/sigma) dy/dx (icdf direction); clamped
+ * values (eps) pass no gradient, like torch.clamp in the reference (nn/flow/cdf.py:31-45). */
+namespace {
+struct CdfBwdArgs {
+    const float* x; int64_t ldx; const float* y; int64_t ldy; const float* desc;
+    int64_t B; int d; int inverse; int use_eps; float eps;
+    const float* g_y; int64_t ldgy; const float* g_dlogp; float* g_x; int64_t ldgx;
+};
+
+__global__ __launch_bounds__(CDF_THREADS) void cdf_bwd_kernel(CdfBwdArgs a) {
+    const int64_t total = a.B * a.d;
+    for (int64_t i = (int64_t)blockIdx.x * CDF_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * CDF_THREADS) {
+        const int64_t r = i / a.d;
+        const int j = (int)(i - r * a.d);
+        const float* ds = a.desc + 6 * j;
+        const int kind = (int)ds[0];
+        const float x = a.x[r * a.ldx + j], y = a.y[r * a.ldy + j];
+        const float gy = a.g_y[r * a.ldgy + j], gl = a.g_dlogp[r];
+        float dy, dld, ld;
+        bool pass;
+        if (a.inverse) {                     /* x = u in [0,1], y = icdf(u), logdet = -log_prob(y) */
+            pass = !a.use_eps || (x >= a.eps && x <= 1.0f - a.eps);
+            if (kind == 0) { dy = ds[2] - ds[1]; dld = 0.0f; ld = 0.0f; }
+            else {
+                const float sig = kind == 1 ? ds[2] : ds[2], mu = ds[1];
+                const float z = (y - mu) / sig;
+                ld = 0.5f * z * z + LOG_SQRT_2PI_F + (kind == 1 ? logf(sig) : logf(ds[4] * sig));
+                dy = expf(ld);
+                dld = (z / sig) * dy;
+            }
+        } else {                             /* y = cdf(x), logdet = log_prob(x) */
+            pass = !a.use_eps || (y > a.eps && y < 1.0f - a.eps);
+            if (kind == 0) {
+                const float u = (x - ds[1]) / (ds[2] - ds[1]);
+                dy = (u >= 0.0f && u <= 1.0f) ? 1.0f / (ds[2] - ds[1]) : 0.0f;
+                dld = 0.0f; ld = 0.0f;
+            } else {
+                const float sig = ds[2], mu = ds[1];
+                const float z = (x - mu) / sig;
+                ld = -0.5f * z * z - LOG_SQRT_2PI_F - (kind == 1 ? logf(sig) : logf(ds[4] * sig));
+                dy = expf(ld);
+                dld = -z / sig;
+            }
+        }
+        if (a.use_eps && ld < -1.0f / a.eps) dld = 0.0f;
+        const float g = (pass ? gy * dy : 0.0f) + gl * dld * ((a.inverse && !pass) ? 0.0f : 1.0f);
+        a.g_x[r * a.ldgx + j] = g;
+    }
+}
+}  // namespace
+
+extern "C" int bgk_cdf_backward(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* desc, int64_t B, int32_t d,
+                                int32_t inverse, int32_t use_eps, float eps, const float* g_y, int64_t ldgy,
+                                const float* g_dlogp, float* g_x, int64_t ldgx, void* stream) {
+    BGK_CHECK_ARG(B >= 0 && d > 0 && x && y && desc && g_y && g_dlogp && g_x, "bgk_cdf_backward: bad arguments");
+    if (B == 0) return 0;
+    CdfBwdArgs a{x, ldx, y, ldy, desc, B, d, inverse, use_eps, eps, g_y, ldgy, g_dlogp, g_x, ldgx};
+    const int64_t nb = (B * d + CDF_THREADS - 1) / CDF_THREADS;
+    const int grid = (int)(nb < 256 * 32 ? nb : 256 * 32);
+    hipLaunchKernelGGL(cdf_bwd_kernel, dim3(grid), dim3(CDF_THREADS), 0, (hipStream_t)stream, a);
+    return bgk_launch_status("bgk_cdf_backward");
+}

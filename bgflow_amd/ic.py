@@ -121,6 +121,64 @@ class _IC2XYZFn(torch.autograd.Function):
         return None, g_ic[0], g_ic[1], g_ic[2], g_f, None
 
 
+class _XYZ2ICFn(torch.autograd.Function):
+    """xyz -> IC with the backward kernel bgk_ic_xyz2ic_backward (dual-number evaluation of the forward formulas)."""
+
+    @staticmethod
+    def forward(ctx, rel, x, whiten):
+        outs = rel._xyz2ic_launch(x, whiten)
+        ctx.rel, ctx.whiten = rel, whiten
+        ctx.save_for_backward(x)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_b, g_a, g_t, g_f, g_dlogp):
+        (x,) = ctx.saved_tensors
+        rel, whiten = ctx.rel, ctx.whiten
+        dev = x.device
+        x2, ldx = _lib.rowmajor(x.reshape(x.shape[0], -1))
+        B, n, nf = x2.shape[0], rel._n, rel._n_fixed
+        (gb2, ga2, gt2), ldgic = _contig_rows(g_b, g_a, g_t)
+        T = None if whiten is None else whiten[1]
+        keep = 3 * nf if T is None else T.shape[1]
+        gf2, ldgf = _lib.rowmajor(g_f.reshape(B, -1).contiguous())
+        g_dl = g_dlogp.reshape(-1).contiguous()
+        g_x = torch.empty((B, 3 * (n + nf)), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_ic_xyz2ic_backward(
+                _lib.ptr(x2), ldx, _lib.ptr(rel._tables.get("zmat", dev)), n, _lib.ptr(rel._tables.get("fixed", dev)), nf,
+                int(rel._normalize_angles), float(rel._eps), int(rel._enforce_boundaries), _lib.ptr(T), keep, B,
+                _lib.ptr(gb2), _lib.ptr(ga2), _lib.ptr(gt2), ldgic, _lib.ptr(gf2), ldgf, _lib.ptr(g_dl),
+                _lib.ptr(g_x), g_x.shape[1], _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_ic_xyz2ic_backward")
+        return None, g_x.reshape(x.shape), None
+
+
+class _RefSysFn(torch.autograd.Function):
+    """global reference system (either direction) with the backward kernel bgk_ic_refsys_backward"""
+
+    @staticmethod
+    def forward(ctx, ref, packed, inverse):
+        out, dlogp = ref._launch_nograd(packed, inverse)
+        ctx.ref, ctx.inverse = ref, inverse
+        ctx.save_for_backward(packed)
+        return out, dlogp
+
+    @staticmethod
+    def backward(ctx, g_out, g_dlogp):
+        (packed,) = ctx.saved_tensors
+        ref = ctx.ref
+        B = packed.shape[0]
+        g_in = torch.empty_like(packed)
+        with torch.cuda.device(packed.device):
+            st = _lib.lib().bgk_ic_refsys_backward(
+                _lib.ptr(packed), _lib.ptr(g_out.contiguous()), _lib.ptr(g_dlogp.reshape(-1).contiguous()), B, int(ctx.inverse),
+                int(ref._normalize_angles), float(ref._eps), int(ref._enforce_boundaries), _lib.ptr(g_in),
+                _lib.stream_ptr(packed.device))
+        _lib.check(st, "bgk_ic_refsys_backward")
+        return None, g_in, None
+
+
 class RelativeInternalCoordinateTransformation(Flow):
     """Internal coordinates relative to a set of fixed atoms (crd_transform/ic.py:268-513).
 
@@ -184,14 +242,13 @@ class RelativeInternalCoordinateTransformation(Flow):
             warnings.warn(f"singular geometry: {total} norm / division clamps at eps={self._eps}")
         return total
 
-    def _no_grad_only(self, *ts):
-        if torch.is_grad_enabled() and any(t.requires_grad for t in ts):
-            raise NotImplementedError(
-                "gradients through the HIP internal-coordinate kernels are not implemented yet")
-
     def _xyz2ic(self, x, whiten=None):
         _lib.require_hip(x)
-        self._no_grad_only(x)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _XYZ2ICFn.apply(self, x, whiten)
+        return self._xyz2ic_launch(x, whiten)
+
+    def _xyz2ic_launch(self, x, whiten=None):
         dev = x.device
         x2, ldx = _lib.rowmajor(x.reshape(x.shape[0], -1))
         B, n, nf = x2.shape[0], self._n, self._n_fixed
@@ -365,9 +422,12 @@ class ReferenceSystemTransformation(Flow):
 
     def _launch(self, packed, inverse):
         _lib.require_hip(packed)
-        if torch.is_grad_enabled() and packed.requires_grad:
-            raise NotImplementedError("gradients through the global reference frame kernel are not implemented yet")
         packed = packed.contiguous()
+        if torch.is_grad_enabled() and packed.requires_grad:
+            return _RefSysFn.apply(self, packed, inverse)
+        return self._launch_nograd(packed, inverse)
+
+    def _launch_nograd(self, packed, inverse):
         B = packed.shape[0]
         out = torch.empty_like(packed)
         dlogp = torch.empty((B,), dtype=torch.float32, device=packed.device)

@@ -152,6 +152,23 @@ int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float*
                            float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,
                            float* g_xfix, int64_t ldgf, void* stream);
 
+/* Backward (VJP) of bgk_ic_xyz2ic (replaces torch autograd through RelativeInternalCoordinateTransformation._forward,
+ * crd_transform/ic.py:386-433, the row Jacobians dist_deriv / angle_deriv / torsion_deriv of ic_helper.py:148-293 and the
+ * whitening pca.py:74-82): upstream g_bonds / g_angles / g_torsions [B, n] (ldgic), g_xfix [B, keep] (ldgf), g_dlogp [B]
+ * -> g_x [B, 3 n_atoms] (ldgx).  The same explicit-Jacobian formulas as the forward kernel, evaluated on dual numbers. */
+int bgk_ic_xyz2ic_backward(const float* x, int64_t ldx, const int32_t* zmat, int32_t n,
+                           const int32_t* fixed, int32_t n_fixed, int32_t normalize_angles, float eps,
+                           int32_t enforce_boundaries, const float* Twhiten, int32_t keep, int64_t B,
+                           const float* g_bonds, const float* g_angles, const float* g_torsions, int64_t ldgic,
+                           const float* g_xfix, int64_t ldgf, const float* g_dlogp,
+                           float* g_x, int64_t ldgx, void* stream);
+
+/* Backward (VJP) of bgk_ic_refsys, both directions (replaces torch autograd through ReferenceSystemTransformation,
+ * crd_transform/ic.py:162-265, ic_helper.py:480-680 incl. its autograd-Jacobian log-det): in [B, 9] = the forward INPUT,
+ * g_out [B, 9], g_dlogp [B] -> g_in [B, 9]. */
+int bgk_ic_refsys_backward(const float* in, const float* g_out, const float* g_dlogp, int64_t B, int32_t inverse,
+                           int32_t normalize_angles, float eps, int32_t enforce_boundaries, float* g_in, void* stream);
+
 /* Domain-mapping layer: replaces CDFTransform._forward/_inverse (nn/flow/cdf.py:28-46) for the
  * marginals of factory/icmarginals.py:41-77.  desc [d,6] floats per column: (kind, p0..p4) with
  * kind 0 uniform (low, high, tol), 1 normal (loc, scale), 2 truncated normal (mu, sigma, cdf_lower, Z).
@@ -160,6 +177,13 @@ int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float*
 int bgk_cdf_transform(const float* x, int64_t ldx, const float* desc, int64_t B, int32_t d,
                       int32_t inverse, int32_t use_eps, float eps, float* out, int64_t ldo,
                       float* dlogp, int32_t accumulate, void* stream);
+
+/* Backward (VJP) of bgk_cdf_transform (replaces torch autograd through CDFTransform, nn/flow/cdf.py:28-46, and the
+ * marginals' cdf / icdf / log_prob, distribution/normal.py:215-227): x = forward input, y = forward output (saved),
+ * g_y [B, d], g_dlogp [B] -> g_x [B, d].  Values the forward pass clamped at eps receive no gradient (torch.clamp). */
+int bgk_cdf_backward(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* desc, int64_t B, int32_t d,
+                     int32_t inverse, int32_t use_eps, float eps, const float* g_y, int64_t ldgy,
+                     const float* g_dlogp, float* g_x, int64_t ldgx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused spline coupling layer with a DenseNet conditioner (fast path of

@@ -598,8 +598,72 @@ def g_grads():
     save("g_grads", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G-grads2: reference autograd gradients (f64) of the layers whose backward kernels came in round 2:
+# CDFTransform (nn/flow/cdf.py:28-46), xyz -> IC (crd_transform/ic.py:386-433), global reference system (ic.py:162-265)
+# ---------------------------------------------------------------------------------------------
+def g_grads2():
+    out = {}
+    dt = torch.float64
+    # --- the four domain maps of the cfg-3 builder flow, both directions
+    gen = build_cfg3(dt)
+    k = 0
+    for block in gen.flow:
+        inner = block
+        while not isinstance(inner, bg.CDFTransform) and hasattr(inner, "_flow"):
+            inner = inner._flow
+        while not isinstance(inner, bg.CDFTransform) and hasattr(inner, "_delegate"):
+            inner = inner._delegate
+        if not isinstance(inner, bg.CDFTransform):
+            continue
+        d = {0: 17, 1: 17, 2: 17, 3: 9}[k]
+        B = 40
+        u = (0.02 + 0.96 * rng_f32(700 + k, B, d, uniform=True)).astype(np.float64)
+        a, bw = synth(710 + k, B, d).astype(np.float64), synth(720 + k, B, 1).astype(np.float64)
+        ut = torch.tensor(u, requires_grad=True)
+        y, dl = inner(ut, inverse=True)                      # [0,1] -> physical (the direction the generator runs)
+        ((y * torch.tensor(a)).sum() + (dl * torch.tensor(bw)).sum()).backward()
+        out.update({f"cdf{k}_u": u, f"cdf{k}_a": a, f"cdf{k}_bw": bw, f"cdf{k}_y": y.detach().numpy(), f"cdf{k}_inv_gx": ut.grad.numpy()})
+        xt = torch.tensor(y.detach().numpy(), requires_grad=True)
+        uu, dl2 = inner(xt)
+        ((uu * torch.tensor(a)).sum() + (dl2 * torch.tensor(bw)).sum()).backward()
+        out.update({f"cdf{k}_fwd_gx": xt.grad.numpy(), f"cdf{k}_kind": np.array(type(inner.distribution).__name__)})
+        k += 1
+    assert k == 4
+    # --- xyz -> IC (relative and mixed)
+    Gic = np.load(os.path.join(HERE, "g_ic.npz"))
+    zrel, zglob, rigid, xyz = ala2_tables()
+    x = Gic["x"][:64].astype(np.float64)
+    wb, wa, wt = synth(801, 64, 17).astype(np.float64), synth(802, 64, 17).astype(np.float64), synth(803, 64, 17).astype(np.float64)
+    wf15, wf9, wl = synth(804, 64, 15).astype(np.float64), synth(805, 64, 9).astype(np.float64), synth(806, 64, 1).astype(np.float64)
+    out.update(x2ic_wb=wb, x2ic_wa=wa, x2ic_wt=wt, x2ic_wf15=wf15, x2ic_wf9=wf9, x2ic_wl=wl)
+    rel = bg.RelativeInternalCoordinateTransformation(zrel, rigid, raise_warnings=False)
+    mix = bg.MixedCoordinateTransformation(torch.tensor(whitening_data(xyz), dtype=dt), zrel, rigid, keepdims=9, raise_warnings=False)
+    for name, tr, wf in (("rel", rel, wf15), ("mix", mix, wf9)):
+        xt = torch.tensor(x, requires_grad=True)
+        b, a, t, f, dl = tr(xt)
+        ((b * torch.tensor(wb)).sum() + (a * torch.tensor(wa)).sum() + (t * torch.tensor(wt)).sum() + (f * torch.tensor(wf)).sum()
+         + (dl * torch.tensor(wl)).sum()).backward()
+        out[f"x2ic_{name}_gx"] = xt.grad.numpy()
+    # --- global internal coordinates: forward (x -> ICs) and inverse (ICs -> x)
+    gic = bg.GlobalInternalCoordinateTransformation(zglob, raise_warnings=False)
+    xg = Gic["x"][:32].astype(np.float64)
+    xt = torch.tensor(xg, requires_grad=True)
+    b, a, t, x0, R, dl = gic(xt)
+    ws = [synth(900 + i, *v.shape).astype(np.float64) for i, v in enumerate((b, a, t, x0, R, dl))]
+    sum((v * torch.tensor(w)).sum() for v, w in zip((b, a, t, x0, R, dl), ws)).backward()
+    out.update(glob_x=xg, glob_fwd_gx=xt.grad.numpy(), **{f"glob_w{i}": w for i, w in enumerate(ws)})
+    ins = [torch.tensor(v.detach().numpy(), requires_grad=True) for v in (b, a, t, x0, R)]
+    xb, dli = gic(*ins, inverse=True)
+    wx, wl2 = synth(910, 32, 66).astype(np.float64), synth(911, 32, 1).astype(np.float64)
+    ((xb * torch.tensor(wx)).sum() + (dli * torch.tensor(wl2)).sum()).backward()
+    out.update(glob_wx=wx, glob_wl2=wl2, **{f"glob_inv_g{i}": v.grad.numpy() for i, v in enumerate(ins)},
+               **{f"glob_in{i}": v.detach().numpy() for i, v in enumerate(ins)})
+    save("g_grads2", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rqs", "affine", "ic", "flow16", "aug", "augment", "grads"]
+    which = sys.argv[1:] or ["rqs", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2"]
     if "rqs" in which:
         g_rqs_unit()
     if "affine" in which:
@@ -614,3 +678,5 @@ if __name__ == "__main__":
         g_augment()
     if "grads" in which:
         g_grads()
+    if "grads2" in which:
+        g_grads2()

@@ -977,3 +977,90 @@ def test_stochastic_augmentation_on_gpu(hip_lib, golden, dev):
     """a17: the augmentation layer of cfg 5 on device tensors against the reference golden (augment.py:27-55)"""
     from test_host_logic import _check_augmentation
     _check_augmentation(golden("g_augment"), dev)
+
+
+# ---------------------------------------------------------------------------------------------------
+# round-2 backward kernels: CDF maps, xyz -> IC, global reference system (goldens: reference autograd in f64, g_grads2)
+# ---------------------------------------------------------------------------------------------------
+def _inner_cdf(block):
+    import bgflow_amd as bg
+    inner = block
+    while not isinstance(inner, bg.CDFTransform) and hasattr(inner, "_flow"):
+        inner = inner._flow
+    while not isinstance(inner, bg.CDFTransform) and hasattr(inner, "_delegate"):
+        inner = inner._delegate
+    return inner if isinstance(inner, bg.CDFTransform) else None
+
+
+def _close(got, ref, rtol, what):
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    assert err <= rtol * scale, f"{what}: max abs err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_cdf_backward_kernel(hip_lib, golden, dev):
+    """bgk_cdf_backward behind CDFTransform (both directions, the four marginals of the cfg-3 builder flow) against the
+    reference's autograd (nn/flow/cdf.py:28-46); and the stale-descriptor fix: new marginal parameters are picked up"""
+    from bgflow_amd import configs
+    G = golden("g_grads2")
+    gen = configs.make_ala2_spline_generator(dev)
+    cdfs = [c for c in (_inner_cdf(b) for b in gen.flow) if c is not None]
+    assert len(cdfs) == 4
+    for k, cdf in enumerate(cdfs):
+        a, bw = t(G[f"cdf{k}_a"].astype(np.float32), dev), t(G[f"cdf{k}_bw"].astype(np.float32), dev)
+        u = t(G[f"cdf{k}_u"].astype(np.float32), dev).requires_grad_(True)
+        y, dl = cdf(u, inverse=True)
+        assert y.grad_fn is not None and "CdfFn" in type(y.grad_fn).__name__, "the kernel path must run under autograd"
+        ((y * a).sum() + (dl * bw).sum()).backward()
+        _close(u.grad.cpu().numpy(), G[f"cdf{k}_inv_gx"], 2e-4, f"cdf {k} icdf direction")
+        x = t(G[f"cdf{k}_y"].astype(np.float32), dev).requires_grad_(True)
+        uu, dl2 = cdf(x)
+        ((uu * a).sum() + (dl2 * bw).sum()).backward()
+        _close(x.grad.cpu().numpy(), G[f"cdf{k}_fwd_gx"], 2e-4, f"cdf {k} cdf direction")
+    # parameters written after a first call (load_state_dict) must reach the kernel
+    cdf = cdfs[0]
+    u = t(G["cdf0_u"].astype(np.float32), dev)
+    with torch.no_grad():
+        y0, _ = cdf(u, inverse=True)
+        sd = {k: v.clone() for k, v in cdf.state_dict().items()}
+        for k in sd:
+            if k.endswith("_mu"):
+                sd[k] = sd[k] + 0.05
+        assert any(k.endswith("_mu") for k in sd)
+        cdf.load_state_dict(sd)
+        y1, _ = cdf(u, inverse=True)
+    assert float((y1 - y0).abs().min()) > 0.04, "the cached descriptor went stale"
+
+
+def test_xyz2ic_backward_kernel(hip_lib, golden, dev):
+    """bgk_ic_xyz2ic_backward (relative and mixed / whitened) against the reference's autograd through
+    crd_transform/ic.py:386-433 + ic_helper.py:148-293"""
+    import bgflow_amd as bg
+    G, Gic = golden("g_grads2"), golden("g_ic")
+    ic_mixed, _ = _mixed_ic(dev, golden)
+    rel = bg.RelativeInternalCoordinateTransformation(Gic["z_matrix"].astype(np.int64), Gic["rigid_block"].astype(np.int64))
+    w = {k: t(G[k].astype(np.float32), dev) for k in ("x2ic_wb", "x2ic_wa", "x2ic_wt", "x2ic_wf15", "x2ic_wf9", "x2ic_wl")}
+    for name, tr, wf in (("rel", rel, w["x2ic_wf15"]), ("mix", ic_mixed, w["x2ic_wf9"])):
+        x = t(Gic["x"][:64].astype(np.float32), dev).requires_grad_(True)
+        b, a, tt, f, dl = tr(x)
+        ((b * w["x2ic_wb"]).sum() + (a * w["x2ic_wa"]).sum() + (tt * w["x2ic_wt"]).sum() + (f * wf).sum() + (dl * w["x2ic_wl"]).sum()).backward()
+        _close(x.grad.cpu().numpy(), G[f"x2ic_{name}_gx"], 5e-4, f"xyz->IC ({name})")
+
+
+def test_global_ic_backward_kernels(hip_lib, golden, dev):
+    """Global internal coordinates under autograd (bgk_ic_xyz2ic_backward + bgk_ic_refsys_backward forward direction;
+    bgk_ic_ic2xyz_backward + bgk_ic_refsys_backward inverse direction) against the reference's autograd
+    (crd_transform/ic.py:162-265, 516-716)"""
+    import bgflow_amd as bg
+    G, Gic = golden("g_grads2"), golden("g_ic")
+    gic = bg.GlobalInternalCoordinateTransformation(Gic["global_z_matrix"].astype(np.int64))
+    x = t(G["glob_x"].astype(np.float32), dev).requires_grad_(True)
+    outs = gic(x)
+    ws = [t(G[f"glob_w{i}"].astype(np.float32), dev) for i in range(6)]
+    sum((v * w).sum() for v, w in zip(outs, ws)).backward()
+    _close(x.grad.cpu().numpy(), G["glob_fwd_gx"], 1e-3, "global IC forward")
+    ins = [t(G[f"glob_in{i}"].astype(np.float32), dev).requires_grad_(True) for i in range(5)]
+    xb, dli = gic(*ins, inverse=True)
+    ((xb * t(G["glob_wx"].astype(np.float32), dev)).sum() + (dli * t(G["glob_wl2"].astype(np.float32), dev)).sum()).backward()
+    for i, v in enumerate(ins):
+        _close(v.grad.cpu().numpy(), G[f"glob_inv_g{i}"], 1e-3, f"global IC inverse, input {i}")
