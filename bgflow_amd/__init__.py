@@ -15,7 +15,8 @@ from .distributions import * # noqa: F401,F403
 from .cdf import *           # noqa: F401,F403
 from .bg import *            # noqa: F401,F403
 from .factory import *       # noqa: F401,F403
-from . import configs, dp, factory, utils      # noqa: F401
+from .training import *      # noqa: F401,F403
+from . import configs, dp, factory, training, utils      # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -38,6 +38,9 @@ _MAP = {
     "distribution.energy.double_well": "distributions",
     "distribution.sampling": "distributions",
     "distribution.sampling.base": "distributions",
+    "distribution.sampling.dataset": "training",
+    "nn.training": "training",
+    "nn.training.trainers": "training",
     "factory.tensor_info": "factory",
     "factory.generator_builder": "factory",
     "factory.conditioner_factory": "factory",

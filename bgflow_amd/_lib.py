@@ -61,6 +61,11 @@ _SIGNATURES = {
     "bgk_dense_backward_dx": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, i64,
                                              vp, vp, vp, vp, vp, i64, vp]),
     "bgk_column_sum": (ctypes.c_int, [vp, i64, i64, i32, vp, i32, vp, vp]),
+    "bgk_grad_nan_flag": (ctypes.c_int, [vp, i64, vp, vp]),
+    "bgk_adam_step": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp, vp]),
+    "bgk_dense_weight_grad_workspace": (i64, [i64, i32, i32]),
+    "bgk_dense_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, vp, vp, i64, i32, i32, i64, vp, i64,
+                                             vp, vp, vp, vp, vp, vp, vp]),
     "bgk_pack_rqs_columns": (i32, [i32, i32, vp, vp]),
 }
 

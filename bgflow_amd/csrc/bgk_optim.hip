@@ -1,0 +1,65 @@
+/* bgk_optim.hip -- optimizer step of the training loop on the flat parameter / gradient bucket:
+ *   bgk_grad_nan_flag   flag[0] = 1 if any gradient is NaN (the reference KLTrainer skips the optimizer step in that case,
+ *                       nn/training/trainers.py:198-201 -- there with a host round trip per parameter tensor)
+ *   bgk_adam_step       torch.optim.Adam's update (bias-corrected first / second moments, eps outside the square root, optional
+ *                       L2 weight decay) over ONE contiguous bucket, skipped on the device when flag[0] != 0; counts skipped steps
+ * One launch each instead of torch's per-tensor-list multi-tensor kernels + the NaN scans; HBM-bound: 4 x 4 B read + 3 x 4 B
+ * written per parameter (1.07 M parameters for cfg 3: microseconds). */
+#include "bgk_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void nan_flag_kernel(const float* g, int64_t n, int32_t* flag) {
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= (g[i] != g[i]);
+    if (__builtin_amdgcn_ballot_w64(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; int64_t n;
+    float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;     /* bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t) */
+    const int32_t* flag; int32_t* skipped;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    if (a.flag && a.flag[0] != 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.skipped) atomicAdd(a.skipped, 1);
+        return;
+    }
+    const float step_size = a.lr / a.bc1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        float g = a.g[i];
+        const float p = a.p[i];
+        if (a.weight_decay != 0.0f) g = g + a.weight_decay * p;
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * (g * g);
+        a.m[i] = m; a.v[i] = v;
+        const float denom = __builtin_sqrtf(v) / a.bc2_sqrt + a.eps;
+        a.p[i] = p - step_size * (m / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int bgk_grad_nan_flag(const float* g, int64_t n, int32_t* flag, void* stream) {
+    BGK_CHECK_ARG(g && flag && n >= 0, "bgk_grad_nan_flag: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) { bgk_set_error("bgk_grad_nan_flag: %s", hipGetErrorString(e)); return (int)e; }
+    if (n == 0) return 0;
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(nan_flag_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, st, g, n, flag);
+    return bgk_launch_status("bgk_grad_nan_flag");
+}
+
+extern "C" int bgk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int64_t step, const int32_t* skip_flag, int32_t* skipped_count, void* stream) {
+    BGK_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "bgk_adam_step: bad arguments");
+    if (n == 0) return 0;
+    AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+               (float)(1.0 - __builtin_pow((double)beta1, (double)step)), (float)__builtin_sqrt(1.0 - __builtin_pow((double)beta2, (double)step)),
+               skip_flag, skipped_count};
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, a);
+    return bgk_launch_status("bgk_adam_step");
+}

@@ -592,6 +592,39 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
     return out[0], out[1], out[2], out[3], g_x
 
 
+FUSED_WEIGHT_GRAD = True     # weight / bias gradients on bgk_dense_weight_grad (False: split-K bmm + bgk_column_sum)
+
+
+def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs):
+    """bgk_dense_weight_grad: (gW0, gb0, gW1, gb1, gW2, gb2) of one coupling layer's conditioner"""
+    dev = g_p.device
+    B, P = g_p.shape
+    g2, ldg = _lib.rowmajor(g_p)
+    x2, ldc = _lib.rowmajor(x)
+    lib = _lib.lib()
+    need_ws = int(lib.bgk_dense_weight_grad_workspace(B, P, n_in))
+    ws = bufs.get("wgrad_ws")
+    if ws is None or ws.numel() < need_ws or ws.device != dev:
+        ws = bufs["wgrad_ws"] = torch.empty(need_ws, dtype=torch.float32, device=dev)
+    gW2 = torch.empty((P, 128), dtype=torch.float32, device=dev) if need[6] else None
+    gb2 = torch.empty((P,), dtype=torch.float32, device=dev) if need[7] else None
+    gW1 = torch.empty((128, 128), dtype=torch.float32, device=dev) if need[4] else None
+    gb1 = torch.empty((128,), dtype=torch.float32, device=dev) if need[5] else None
+    gW0 = torch.empty((128, n_in), dtype=torch.float32, device=dev) if need[2] else None
+    gb0 = torch.empty((128,), dtype=torch.float32, device=dev) if need[3] else None
+    # a bias gradient without its weight gradient: give the kernel a scratch weight buffer
+    def wbuf(w, b, shape):
+        return w if (w is not None or b is None) else torch.empty(shape, dtype=torch.float32, device=dev)
+    w2, w1, w0 = wbuf(gW2, gb2, (P, 128)), wbuf(gW1, gb1, (128, 128)), wbuf(gW0, gb0, (128, n_in))
+    with torch.cuda.device(dev):
+        st = lib.bgk_dense_weight_grad(_lib.ptr(g2), ldg, P, _lib.ptr(g_z1), _lib.ptr(g_z0), _lib.ptr(h1), _lib.ptr(h0),
+                                       _lib.ptr(x2), ldc, x2.shape[1], int(periodic), B, _lib.ptr(ws), ws.numel(),
+                                       _lib.ptr(w2), _lib.ptr(gb2), _lib.ptr(w1), _lib.ptr(gb1), _lib.ptr(w0), _lib.ptr(gb0),
+                                       _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_dense_weight_grad")
+    return gW0, gb0, gW1, gb1, gW2, gb2
+
+
 class _FusedSplineTrainFn(torch.autograd.Function):
     """Forward = ONE launch of bgk_coupling_rqs_dense_h2_train (conditioner MLP on the f16 matrix cores + spline; the
     pre-activations z0, z1 and the spline parameters are written out for the backward pass).  Backward = bgk_rqs_backward
@@ -649,13 +682,16 @@ class _FusedSplineTrainFn(torch.autograd.Function):
                 g_x = torch.autograd.grad(feats, xx, _matmul_nn(g_z0, W0))[0]
             elif need[0]:
                 g_x = _matmul_nn(g_z0, W0)
-        feats = _featurise(x.detach(), periodic)
-        gW2 = _gram_tn(g_p, h1) if need[6] else None
-        gb2 = column_sum(g_p) if need[7] else None
-        gW1 = _gram_tn(g_z1, h0) if need[4] else None
-        gb1 = column_sum(g_z1) if need[5] else None
-        gW0 = _gram_tn(g_z0, feats.contiguous()) if need[2] else None
-        gb0 = column_sum(g_z0) if need[3] else None
+        if FUSED_WEIGHT_GRAD and g_p.is_cuda and W0.shape[1] <= 128:
+            gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs)
+        else:
+            feats = _featurise(x.detach(), periodic)
+            gW2 = _gram_tn(g_p, h1) if need[6] else None
+            gb2 = column_sum(g_p) if need[7] else None
+            gW1 = _gram_tn(g_z1, h0) if need[4] else None
+            gb1 = column_sum(g_z1) if need[5] else None
+            gW0 = _gram_tn(g_z0, feats.contiguous()) if need[2] else None
+            gb0 = column_sum(g_z0) if need[3] else None
         return (g_x, g_y if need[1] else None, gW0, gb0, gW1, gb1, gW2, gb2) + (None,) * 5
 
 

@@ -1,0 +1,261 @@
+"""Training loop of the accelerated path: ``KLTrainer`` / ``LossReporter`` with the reference's
+signatures (bgflow/nn/training/trainers.py:13-205), ``DataSetSampler`` (distribution/sampling/dataset.py) and ``FlatAdam``, an
+Adam optimizer over ONE flat parameter / gradient bucket.
+
+What differs from the reference loop, and why:
+  * parameters and their gradients live in two contiguous buffers (``FlatAdam`` re-points ``p.data`` / ``p.grad`` at views of
+    them): ``zero_grad`` is one memset, the data-parallel gradient all-reduce is ONE collective on the bucket without a
+    gather / scatter copy (dp.py), and the optimizer step is one launch (bgk_adam_step);
+  * the "found nan in grad; skipping optimization step" rule (trainers.py:198-201) is evaluated on the device
+    (bgk_grad_nan_flag -> bgk_adam_step skips itself): no host synchronisation per step; ``skipped_steps()`` polls the count;
+  * losses are kept as device scalars and converted lazily by the reporter (the reference's ``assert_numpy`` per iteration
+    is a host sync);
+  * with an initialised process group the KL / NLL means are global means (one all-reduce of [sum, n], dp.global_mean).
+Any other ``torch.optim`` optimizer passed as ``optim`` is used as is (then the NaN check costs a host round trip, like
+the reference)."""
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib, dp
+
+__all__ = ["LossReporter", "KLTrainer", "FlatAdam", "DataSetSampler"]
+
+
+class DataSetSampler(torch.nn.Module):
+    """Sample batches from a data set without replacement, reshuffling when exhausted (distribution/sampling/dataset.py)."""
+
+    def __init__(self, *data, shuffle=True):
+        super().__init__()
+        assert all(d.shape[0] == data[0].shape[0] for d in data)
+        self._data = list(data)
+        self._shuffle = shuffle
+        self._perm = None
+        self._pos = 0
+
+    def __len__(self):
+        return self._data[0].shape[0]
+
+    def _next_indices(self, n):
+        N = len(self)
+        out = []
+        while n > 0:
+            if self._perm is None or self._pos >= N:
+                self._perm = torch.randperm(N, device=self._data[0].device) if self._shuffle else torch.arange(N, device=self._data[0].device)
+                self._pos = 0
+            take = min(n, N - self._pos)
+            out.append(self._perm[self._pos:self._pos + take])
+            self._pos += take
+            n -= take
+        return torch.cat(out) if len(out) > 1 else out[0]
+
+    def sample(self, n_samples, **kwargs):
+        idx = self._next_indices(n_samples)
+        res = tuple(d[idx] for d in self._data)
+        return res[0] if len(res) == 1 else res
+
+
+class LossReporter:
+    """Collects the reported losses (trainers.py:13-45); tensors stay on the device until somebody looks at them."""
+
+    def __init__(self, *labels):
+        self._labels = labels
+        self._n_reported = len(labels)
+        self._raw = [[] for _ in range(self._n_reported)]
+
+    def report(self, *losses):
+        assert len(losses) == self._n_reported
+        for i in range(self._n_reported):
+            v = losses[i]
+            self._raw[i].append(v.detach() if torch.is_tensor(v) else v)
+
+    def _np(self, seq):
+        return np.array([float(v) for v in seq])
+
+    def print(self, *losses):
+        it = len(self._raw[0])
+        print(f"{it}\t" + "".join(f"{self._labels[i]}: {float(self._raw[i][-1]):.4f}\t" for i in range(self._n_reported)))
+
+    def losses(self, n_smooth=1):
+        x = np.arange(n_smooth, len(self._raw[0]) + 1)
+        kernel = np.ones(shape=(n_smooth,)) / n_smooth
+        ys = [np.convolve(self._np(raw).reshape(-1), kernel, mode="valid") for raw in self._raw]
+        return self._labels, x, ys
+
+    def recent(self, n_recent=1):
+        return np.array([self._np(raw[-n_recent:]) for raw in self._raw])
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """Adam (torch.optim.Adam semantics: lr, betas, eps, L2 weight_decay) over one flat f32 bucket on a HIP device."""
+
+    def __init__(self, params, lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        assert ps and all(p.is_cuda and p.dtype == torch.float32 for p in ps), "FlatAdam: f32 parameters on a HIP device"
+        assert len(self.param_groups) == 1, "FlatAdam: one parameter group"
+        dev = ps[0].device
+        self._params = ps
+        n = sum(p.numel() for p in ps)
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._step = 0
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view_as(p)          # same values, now a view of the bucket
+                p.grad = self.grad[off:off + k].view_as(p)
+                off += k
+
+    def zero_grad(self, set_to_none=False):
+        """one memset; the per-parameter .grad views stay attached (autograd accumulates into them in place)"""
+        self.grad.zero_()
+        off = 0
+        for p in self._params:
+            k = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+
+    def allreduce_gradients(self):
+        """data-parallel training: ONE all-reduce of the gradient bucket (sum over ranks)"""
+        if dp.is_distributed():
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+
+    @torch.no_grad()
+    def step(self, closure=None, skip_on_nan=True):
+        assert closure is None
+        g = self.param_groups[0]
+        off = 0
+        for p in self._params:       # a gradient tensor autograd swapped in instead of accumulating: bring it home
+            k = p.numel()
+            if p.grad is not None and p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                self.grad[off:off + k].copy_(p.grad.reshape(-1))
+                p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+        self._step += 1
+        lib = _lib.lib()
+        dev = self.flat.device
+        with torch.cuda.device(dev):
+            if skip_on_nan:
+                _lib.check(lib.bgk_grad_nan_flag(_lib.ptr(self.grad), self.grad.numel(), _lib.ptr(self._flag), _lib.stream_ptr(dev)),
+                           "bgk_grad_nan_flag")
+            _lib.check(lib.bgk_adam_step(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                         self.flat.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                         float(g["weight_decay"]), self._step, _lib.ptr(self._flag) if skip_on_nan else None,
+                                         _lib.ptr(self._skipped), _lib.stream_ptr(dev)), "bgk_adam_step")
+        # the kernel wrote through the bucket: bump the parameters' version counters (the packed-operand caches of the fused
+        # kernels are keyed on (data_ptr, _version), exactly as if torch's Adam had updated the parameters in place)
+        torch._C._autograd._unsafe_set_version_counter(self._params, [p._version + 1 for p in self._params])
+
+    def skipped_steps(self):
+        """number of optimizer steps skipped because a gradient was NaN (host sync)"""
+        return int(self._skipped.item())
+
+
+class KLTrainer(object):
+    """Same constructor and ``train`` signature as the reference (trainers.py:48-205)."""
+
+    def __init__(self, bg, optim=None, train_likelihood=True, train_energy=True, custom_loss=None, test_likelihood=False):
+        self.bg = bg
+        if optim is None:
+            ps = [p for p in bg.parameters() if p.requires_grad]
+            optim = FlatAdam(ps, lr=5e-3) if ps and all(p.is_cuda for p in ps) else torch.optim.Adam(bg.parameters(), lr=5e-3)
+        self.optim = optim
+        loss_names = []
+        self.train_likelihood = train_likelihood
+        self.w_likelihood = 0.0
+        self.train_energy = train_energy
+        self.w_energy = 0.0
+        self.test_likelihood = test_likelihood
+        if train_energy:
+            loss_names.append("KLL")
+            self.w_energy = 1.0
+        if train_likelihood:
+            loss_names.append("NLL")
+            self.w_likelihood = 1.0
+        if test_likelihood:
+            loss_names.append("NLL(Test)")
+        if custom_loss is not None:
+            # deviation: the reference reports the custom loss without registering a label for it, so its own reporter
+            # assertion (trainers.py:24) fires as soon as w_custom is used
+            loss_names.append("custom")
+        self.reporter = LossReporter(*loss_names)
+        self.custom_loss = custom_loss
+
+    @staticmethod
+    def _mean(per_sample):
+        return dp.global_mean(per_sample) if dp.is_distributed() else per_sample.mean()
+
+    def train(self, n_iter, data=None, testdata=None, batchsize=128, w_likelihood=None, w_energy=None, w_custom=None,
+              custom_loss_kwargs={}, n_print=0, temperature=1.0, schedulers=(), clip_forces=None, progress_bar=lambda x: x):
+        if w_likelihood is None:
+            w_likelihood = self.w_likelihood
+        if w_energy is None:
+            w_energy = self.w_energy
+        if clip_forces is not None:
+            warnings.warn("clip_forces is deprecated and will be ignored. Use GradientClippedEnergy instances instead",
+                          DeprecationWarning)
+        if isinstance(data, torch.Tensor):
+            data = DataSetSampler(data)
+        if isinstance(testdata, torch.Tensor):
+            testdata = DataSetSampler(testdata)
+        flat = isinstance(self.optim, FlatAdam)
+        params = [p for p in self.bg.parameters()]
+        for it in progress_bar(range(n_iter)):
+            for interval, scheduler in schedulers:
+                if it % interval == 0:
+                    scheduler.step()
+            self.optim.zero_grad()
+            reports = []
+            if self.train_energy:
+                kll = self._mean(self.bg.kldiv(batchsize, temperature=temperature))
+                reports.append(kll)
+                if w_energy > 0:
+                    (w_energy / (w_likelihood + w_energy) * kll).backward(retain_graph=True)
+            if self.train_likelihood:
+                batch = data.sample(batchsize)
+                if isinstance(batch, torch.Tensor):
+                    batch = (batch,)
+                nll = self._mean(self.bg.energy(*batch, temperature=temperature))
+                reports.append(nll)
+                if w_likelihood > 0:
+                    (w_likelihood / (w_likelihood + w_energy) * nll).backward(retain_graph=True)
+            if self.test_likelihood:
+                testnll = torch.zeros_like(nll)
+                if testdata is not None:
+                    testbatch = testdata.sample(batchsize)
+                    if isinstance(testbatch, torch.Tensor):
+                        testbatch = (testbatch,)
+                    with torch.no_grad():
+                        testnll = self._mean(self.bg.energy(*testbatch, temperature=temperature))
+                reports.append(testnll)
+            if w_custom is not None:
+                cl = self.custom_loss(**custom_loss_kwargs)
+                (w_custom * cl).backward(retain_graph=True)
+                reports.append(cl)
+            elif self.custom_loss is not None:
+                reports.append(float("nan"))
+            self.reporter.report(*reports)
+            if n_print > 0 and it % n_print == 0:
+                self.reporter.print(*reports)
+            if flat:
+                self.optim.allreduce_gradients()
+                self.optim.step()            # skips itself on the device when a gradient is NaN
+            else:
+                dp.allreduce_gradients_(params)
+                if any(torch.any(torch.isnan(p.grad)) for p in params if p.grad is not None):
+                    print("found nan in grad; skipping optimization step")
+                else:
+                    self.optim.step()
+
+    def losses(self, n_smooth=1):
+        return self.reporter.losses(n_smooth=n_smooth)

@@ -297,6 +297,28 @@ int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z
                           int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
                           float* g_cond, int64_t ldgc, void* stream);
 
+/* Optimizer step on the flat parameter bucket (f-2: the optimizer of KLTrainer.train, nn/training/trainers.py:148-201).
+ * bgk_grad_nan_flag sets flag[0] = any(isnan(g)) on the device (the reference's "found nan in grad; skipping optimization
+ * step" check, trainers.py:198-201, without a host round trip); bgk_adam_step is torch.optim.Adam's update (step = 1, 2, ...:
+ * bias corrections 1 - beta^step computed on the host in double) over [n] contiguous floats, a no-op that increments
+ * skipped_count[0] when skip_flag[0] != 0 (either pointer may be NULL). */
+int bgk_grad_nan_flag(const float* g, int64_t n, int32_t* flag, void* stream);
+int bgk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, const int32_t* skip_flag, int32_t* skipped_count, void* stream);
+
+/* Weight and bias gradients of the conditioner MLP [n_in, 128, 128, P] of one coupling layer (autograd of nn/dense.py:47-48 in
+ * the training step: dW = g^T h, db = sum over the batch of g) from the tensors bgk_rqs_backward / bgk_dense_backward_dx wrote:
+ *   (g_params [B, P], h1) -> gW2 [P, 128], gb2 [P];  (g_z1, h0) -> gW1 [128, 128], gb1 [128];
+ *   (g_z0, featurised cond) -> gW0 [128, n_in], gb0 [128]   (periodic != 0: cond [B, d_c] is featurised on the fly as
+ *   [cos 2 pi x | sin 2 pi x], nn/periodic.py:30-37; n_in = 2 d_c).  Any gW pointer may be NULL (skipped with its gb).
+ * Split over the batch into slabs whose partials are summed in fixed order (deterministic); workspace size in floats from
+ * bgk_dense_weight_grad_workspace.  Replaces 3 split-K hipBLASLt GEMMs + 3 reductions + 6 column-sum launches per layer. */
+int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in);
+int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
+                          const float* h1, const float* h0, const float* cond, int64_t ldc, int32_t d_c,
+                          int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
+                          float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, void* stream);
+
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).
  * Deterministic two-stage reduction; `partial` is a caller-provided [nblk, P] workspace. */

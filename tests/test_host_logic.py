@@ -491,3 +491,44 @@ def test_log_weights_from_samples_host():
     np.testing.assert_allclose(lw.numpy(), np.full(64, -np.log(64.0)), atol=1e-5)
     lw_raw = log_weights_from_samples(prior, Shift(), target, num_samples=32, batch_size=16, normalize=False)
     np.testing.assert_allclose(lw_raw.numpy(), 0.25, atol=1e-5)
+
+
+def test_kltrainer_host_semantics(capsys):
+    """KLTrainer / LossReporter / DataSetSampler with the reference's signatures (nn/training/trainers.py:13-205) on a tiny
+    pure-torch flow (CPU, torch.optim.Adam path): loss bookkeeping, weighting of the two losses, the NaN-gradient skip"""
+    from bgflow_amd.training import KLTrainer, LossReporter, DataSetSampler
+
+    class Scale(bg.Flow):
+        def __init__(self):
+            super().__init__()
+            self.log_s = torch.nn.Parameter(torch.zeros(1, 2))
+
+        def _forward(self, x, **kw):
+            return x * torch.exp(self.log_s), self.log_s.sum().expand(x.shape[0], 1)
+
+        def _inverse(self, x, **kw):
+            return x * torch.exp(-self.log_s), (-self.log_s.sum()).expand(x.shape[0], 1)
+    torch.manual_seed(0)
+    gen = bg.BoltzmannGenerator(bg.NormalDistribution(2), Scale(), bg.NormalDistribution(2, mean=torch.zeros(2)))
+    data = torch.randn(256, 2) * 2.0
+    tr = KLTrainer(gen, optim=torch.optim.Adam(gen.parameters(), lr=5e-2), train_likelihood=True, train_energy=True, test_likelihood=True)
+    assert tr.reporter._labels == ("KLL", "NLL", "NLL(Test)") and tr.w_energy == 1.0 and tr.w_likelihood == 1.0
+    tr.train(30, data=data, testdata=data[:64], batchsize=64, n_print=0)
+    labels, x, ys = tr.losses(n_smooth=5)
+    assert labels == ("KLL", "NLL", "NLL(Test)") and len(x) == 26 and all(len(y) == 26 for y in ys)
+    assert ys[1][-1] < ys[1][0], "the NLL must go down"
+    assert tr.reporter.recent(3).shape == (3, 3)
+    # NaN gradient -> the step is skipped, the parameters stay
+    before = gen.flow.log_s.detach().clone()
+    tr2 = KLTrainer(gen, optim=torch.optim.Adam(gen.parameters(), lr=5e-2), train_likelihood=False, train_energy=True,
+                    custom_loss=lambda: gen.flow.log_s.sum() * float("nan"))
+    tr2.train(1, batchsize=16, w_custom=1.0)
+    assert "found nan in grad; skipping optimization step" in capsys.readouterr().out
+    assert torch.equal(gen.flow.log_s.detach(), before)
+    # sampler: every element once per epoch
+    s = DataSetSampler(torch.arange(10.0)[:, None])
+    seen = torch.cat([s.sample(5), s.sample(5)]).reshape(-1).sort().values
+    assert torch.equal(seen, torch.arange(10.0))
+    rep = LossReporter("a")
+    rep.report(torch.tensor(1.0)); rep.report(2.0)
+    assert rep.losses()[2][0].tolist() == [1.0, 2.0]
