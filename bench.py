@@ -428,18 +428,19 @@ def main():
     # the hand-written backward kernels -> ONE all-reduce of [sum, n] (+ one flat gradient bucket) -> optimizer step.
     kl = None
     if args.kl_steps > 0 and args.workload != "cfg2":
+        from bgflow_amd.training import FlatAdam
         params = [p for p in gen.flow.parameters()]
-        opt = torch.optim.Adam(params, lr=1e-5)
+        opt = FlatAdam(params, lr=1e-5)            # flat parameter / gradient bucket, bgk_adam_step (what KLTrainer uses)
         zk = sampler(args.kl_batch, g)
         last = [None]
 
         def kl_step():
-            opt.zero_grad(set_to_none=True)
+            opt.zero_grad()
             *x, dlogp = gen.flow(*zk)
             loss = dp.global_mean(gen._target.energy(*x) - dlogp, drop_nonfinite=True)
             loss.backward()
-            dp.allreduce_gradients_(params)
-            opt.step()
+            opt.allreduce_gradients()              # ONE collective on the bucket
+            opt.step()                             # skips itself on the device if a gradient is NaN
             last[0] = loss
         kl_step()
         torch.cuda.synchronize(dev)
@@ -454,7 +455,8 @@ def main():
                   steps=args.kl_steps, timer="HIP events", loss=float(last[0].detach()),
                   note="fwd: one-launch coupling layers (training variant, saves pre-activations + spline parameters) + IC / CDF kernels; "
                        "bwd: bgk_rqs_backward / bgk_ic_ic2xyz_backward, conditioner input-gradient chain on bgk_dense_backward_dx, "
-                       "split-K weight-gradient GEMMs, bias gradients on bgk_column_sum; one all-reduce of [sum, n] + one gradient bucket; Adam")
+                       "weight / bias gradients on bgk_dense_weight_grad; one all-reduce of [sum, n] + one all-reduce of the flat gradient bucket; "
+                       "bgk_adam_step (device-side NaN skip, trainers.py:198-201)")
 
     total_samples = args.batch * world * args.steps
     value = total_samples / elapsed

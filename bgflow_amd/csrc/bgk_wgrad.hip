@@ -57,7 +57,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
     lo = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
 }
 
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgArgs a) {
+__global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   /* 2 buffers x {g_hi, g_lo, h_hi, h_lo} */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     /* block -> (slab, n-block): blocks that share a slab (and re-read the same rows of h) are 8 apart = on the same XCD */
@@ -81,9 +81,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgArgs a) {
     float bsum = 0.0f;
     const int my_off = c * CSTRIDE + rg * 16;                /* where my 16-byte values go */
     const int rd_a = (wave * 32 + (lane & 31)) * CSTRIDE + (lane >> 5) * 16;
-    int buf = 0;
-    for (int64_t r = r0; r < r1; r += 16, buf ^= 1) {
-        float gv[8], hv[8];
+    /* software pipeline: the 16 values of step s + 1 are requested before step s is converted / multiplied, so the HBM latency
+     * overlaps the LDS + matrix-core work (without it every 16-row step paid a full round trip: 144 us per GEMM) */
+    auto fetch = [&](int64_t r, float (&gv)[8], float (&hv)[8]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int64_t row = r + 8 * rg + e;
@@ -91,6 +91,15 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgArgs a) {
             gv[e] = (g_ok && in) ? a.g[row * a.ldg + gcol] : 0.0f;
             hv[e] = (h_ok && in) ? a.h[row * a.ldh + hc] : 0.0f;
         }
+    };
+    float gn[8], hn[8];
+    fetch(r0, gn, hn);
+    int buf = 0;
+    for (int64_t r = r0; r < r1; r += 16, buf ^= 1) {
+        float gv[8], hv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gv[e] = gn[e]; hv[e] = hn[e]; }
+        if (r + 16 < r1) fetch(r + 16, gn, hn);
         if (a.featurise && h_ok) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -141,25 +150,35 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgArgs a) {
     if (g_ok) a.part_b[((int64_t)slab * 2 + rg) * a.n + gcol] = bsum;
 }
 
-/* fixed-order sum of the slab partials */
+/* fixed-order sum of the slab partials: 8 lanes per output element each sum every 8th slab (4 accumulators), combined
+ * by a fixed shuffle tree -- 8x the parallelism of one thread per element (the partial sets are only a few MB: latency-bound) */
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_w, const float* part_b, int n_slabs, int n, int k,
                                                            float* gW, float* gb) {
     const int64_t nk = (int64_t)n * k;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = nk + (gb ? n : 0);
+    const int sub = threadIdx.x & 7;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    float acc = 0.0f;
     if (i < nk) {
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-        int s = 0;
-        for (; s + 4 <= n_slabs; s += 4) {
-            a0 += part_w[(int64_t)(s + 0) * nk + i]; a1 += part_w[(int64_t)(s + 1) * nk + i];
-            a2 += part_w[(int64_t)(s + 2) * nk + i]; a3 += part_w[(int64_t)(s + 3) * nk + i];
-        }
-        for (; s < n_slabs; ++s) a0 += part_w[(int64_t)s * nk + i];
-        gW[i] = (a0 + a1) + (a2 + a3);
-    } else if (gb && i < nk + n) {
+        float a0 = 0.0f, a1 = 0.0f;
+        int s = sub;
+        for (; s + 8 < n_slabs; s += 16) { a0 += part_w[(int64_t)s * nk + i]; a1 += part_w[(int64_t)(s + 8) * nk + i]; }
+        if (s < n_slabs) a0 += part_w[(int64_t)s * nk + i];
+        acc = a0 + a1;
+    } else if (i < total) {
         const int col = (int)(i - nk);
         float a0 = 0.0f, a1 = 0.0f;
-        for (int s = 0; s < 2 * n_slabs; s += 2) { a0 += part_b[(int64_t)s * n + col]; a1 += part_b[(int64_t)(s + 1) * n + col]; }
-        gb[col] = a0 + a1;
+        int s = sub;
+        for (; s + 8 < 2 * n_slabs; s += 16) { a0 += part_b[(int64_t)s * n + col]; a1 += part_b[(int64_t)(s + 8) * n + col]; }
+        if (s < 2 * n_slabs) a0 += part_b[(int64_t)s * n + col];
+        acc = a0 + a1;
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (sub == 0) {
+        if (i < nk) gW[i] = acc;
+        else if (i < total) gb[i - nk] = acc;
     }
 }
 
@@ -178,7 +197,7 @@ int one_gemm(const char* what, const float* g, int64_t ldg, int n, const float* 
     BGK_CHECK_ARG(ws_floats >= need, "%s: workspace of %lld floats needed, %lld given", what, (long long)need, (long long)ws_floats);
     WgArgs a{g, ldg, n, h, ldh, k, featurise, B, rows, n_slabs, n_blocks, ws, ws + (int64_t)n_slabs * n * k};
     hipLaunchKernelGGL(wgrad_kernel, dim3(n_slabs * n_blocks), dim3(WG_THREADS), 2 * 4 * ARR, st, a);
-    const int64_t total = (int64_t)n * k + n;
+    const int64_t total = ((int64_t)n * k + n) * 8;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part_w, a.part_b, n_slabs, n, k, gW, gb);
     return 0;
 }
