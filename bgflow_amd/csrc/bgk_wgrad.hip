@@ -153,7 +153,7 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgArgs a) {
 /* fixed-order sum of the slab partials: 8 lanes per output element each sum every 8th slab (4 accumulators), combined
  * by a fixed shuffle tree -- 8x the parallelism of one thread per element (the partial sets are only a few MB: latency-bound) */
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_w, const float* part_b, int n_slabs, int n, int k,
-                                                           float* gW, float* gb) {
+                                                           float* gW, float* gb, int accumulate) {
     const int64_t nk = (int64_t)n * k;
     const int64_t total = nk + (gb ? n : 0);
     const int sub = threadIdx.x & 7;
@@ -177,13 +177,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_w, 
     acc += __shfl_xor(acc, 2);
     acc += __shfl_xor(acc, 4);
     if (sub == 0) {
-        if (i < nk) gW[i] = acc;
-        else if (i < total) gb[i - nk] = acc;
+        if (i < nk) gW[i] = accumulate ? gW[i] + acc : acc;
+        else if (i < total) gb[i - nk] = accumulate ? gb[i - nk] + acc : acc;
     }
 }
 
 int one_gemm(const char* what, const float* g, int64_t ldg, int n, const float* h, int64_t ldh, int k, int featurise, int64_t B,
-             float* ws, int64_t ws_floats, float* gW, float* gb, hipStream_t st) {
+             float* ws, int64_t ws_floats, float* gW, float* gb, int accumulate, hipStream_t st) {
     BGK_CHECK_ARG(n > 0 && k > 0 && k <= COLS && (!featurise || (k % 2 == 0)), "%s: n = %d, k = %d not supported (k <= 128)", what, n, k);
     const int n_blocks = (n + COLS - 1) / COLS;
     /* ~2 workgroups per CU, slabs of at least 1024 rows, a multiple of 8 slabs (XCD-aware block map) */
@@ -198,7 +198,7 @@ int one_gemm(const char* what, const float* g, int64_t ldg, int n, const float* 
     WgArgs a{g, ldg, n, h, ldh, k, featurise, B, rows, n_slabs, n_blocks, ws, ws + (int64_t)n_slabs * n * k};
     hipLaunchKernelGGL(wgrad_kernel, dim3(n_slabs * n_blocks), dim3(WG_THREADS), 2 * 4 * ARR, st, a);
     const int64_t total = ((int64_t)n * k + n) * 8;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part_w, a.part_b, n_slabs, n, k, gW, gb);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part_w, a.part_b, n_slabs, n, k, gW, gb, accumulate);
     return 0;
 }
 
@@ -223,15 +223,15 @@ extern "C" int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t
 extern "C" int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
                                      const float* h1, const float* h0, const float* cond, int64_t ldc, int32_t d_c,
                                      int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
-                                     float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, void* stream) {
+                                     float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate, void* stream) {
     BGK_CHECK_ARG(g_params && g_z1 && g_z0 && h1 && h0 && cond && workspace, "bgk_dense_weight_grad: null pointer");
     BGK_CHECK_ARG(B > 0 && P > 0 && d_c > 0, "bgk_dense_weight_grad: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int n_in = periodic ? 2 * d_c : d_c;
     int rc = 0;
-    if (gW2) rc = one_gemm("bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, B, workspace, workspace_floats, gW2, gb2, st);
-    if (rc == 0 && gW1) rc = one_gemm("bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, B, workspace, workspace_floats, gW1, gb1, st);
-    if (rc == 0 && gW0) rc = one_gemm("bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, B, workspace, workspace_floats, gW0, gb0, st);
+    if (gW2) rc = one_gemm("bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, B, workspace, workspace_floats, gW2, gb2, accumulate, st);
+    if (rc == 0 && gW1) rc = one_gemm("bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, B, workspace, workspace_floats, gW1, gb1, accumulate, st);
+    if (rc == 0 && gW0) rc = one_gemm("bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, B, workspace, workspace_floats, gW0, gb0, accumulate, st);
     if (rc != 0) return rc;
     return bgk_launch_status("bgk_dense_weight_grad");
 }

@@ -595,8 +595,11 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
 FUSED_WEIGHT_GRAD = True     # weight / bias gradients on bgk_dense_weight_grad (False: split-K bmm + bgk_column_sum)
 
 
-def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs):
-    """bgk_dense_weight_grad: (gW0, gb0, gW1, gb1, gW2, gb2) of one coupling layer's conditioner"""
+def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, params=None):
+    """bgk_dense_weight_grad: (gW0, gb0, gW1, gb1, gW2, gb2) of one coupling layer's conditioner.
+    ``params`` = (W0, b0, W1, b1, W2, b2): when ALL of them carry a flat-bucket gradient destination (``_bgk_grad_dst``, set by
+    training.FlatAdam) the kernel accumulates straight into the bucket and None is returned for every gradient -- no
+    per-parameter AccumulateGrad add kernels (96 tiny launches per cfg-3 step)."""
     dev = g_p.device
     B, P = g_p.shape
     g2, ldg = _lib.rowmajor(g_p)
@@ -606,22 +609,30 @@ def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs):
     ws = bufs.get("wgrad_ws")
     if ws is None or ws.numel() < need_ws or ws.device != dev:
         ws = bufs["wgrad_ws"] = torch.empty(need_ws, dtype=torch.float32, device=dev)
-    gW2 = torch.empty((P, 128), dtype=torch.float32, device=dev) if need[6] else None
-    gb2 = torch.empty((P,), dtype=torch.float32, device=dev) if need[7] else None
-    gW1 = torch.empty((128, 128), dtype=torch.float32, device=dev) if need[4] else None
-    gb1 = torch.empty((128,), dtype=torch.float32, device=dev) if need[5] else None
-    gW0 = torch.empty((128, n_in), dtype=torch.float32, device=dev) if need[2] else None
-    gb0 = torch.empty((128,), dtype=torch.float32, device=dev) if need[3] else None
-    # a bias gradient without its weight gradient: give the kernel a scratch weight buffer
-    def wbuf(w, b, shape):
+    direct = params is not None and all(need[2:8]) and all(
+        getattr(p, "_bgk_grad_dst", None) is not None and p.grad is not None and p.grad.data_ptr() == p._bgk_grad_dst.data_ptr()
+        for p in params)      # only while p.grad IS the bucket view (a zero_grad(set_to_none=True) elsewhere switches this off)
+    if direct:
+        gW0, gb0, gW1, gb1, gW2, gb2 = (p._bgk_grad_dst for p in params)
+    else:
+        gW2 = torch.empty((P, 128), dtype=torch.float32, device=dev) if need[6] else None
+        gb2 = torch.empty((P,), dtype=torch.float32, device=dev) if need[7] else None
+        gW1 = torch.empty((128, 128), dtype=torch.float32, device=dev) if need[4] else None
+        gb1 = torch.empty((128,), dtype=torch.float32, device=dev) if need[5] else None
+        gW0 = torch.empty((128, n_in), dtype=torch.float32, device=dev) if need[2] else None
+        gb0 = torch.empty((128,), dtype=torch.float32, device=dev) if need[3] else None
+
+    def wbuf(w, b, shape):   # a bias gradient without its weight gradient: give the kernel a scratch weight buffer
         return w if (w is not None or b is None) else torch.empty(shape, dtype=torch.float32, device=dev)
     w2, w1, w0 = wbuf(gW2, gb2, (P, 128)), wbuf(gW1, gb1, (128, 128)), wbuf(gW0, gb0, (128, n_in))
     with torch.cuda.device(dev):
         st = lib.bgk_dense_weight_grad(_lib.ptr(g2), ldg, P, _lib.ptr(g_z1), _lib.ptr(g_z0), _lib.ptr(h1), _lib.ptr(h0),
                                        _lib.ptr(x2), ldc, x2.shape[1], int(periodic), B, _lib.ptr(ws), ws.numel(),
                                        _lib.ptr(w2), _lib.ptr(gb2), _lib.ptr(w1), _lib.ptr(gb1), _lib.ptr(w0), _lib.ptr(gb0),
-                                       _lib.stream_ptr(dev))
+                                       int(direct), _lib.stream_ptr(dev))
     _lib.check(st, "bgk_dense_weight_grad")
+    if direct:
+        return (None,) * 6
     return gW0, gb0, gW1, gb1, gW2, gb2
 
 
@@ -653,6 +664,7 @@ class _FusedSplineTrainFn(torch.autograd.Function):
                 _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), P, _lib.ptr(plan["src_col_dev"]), _lib.stream_ptr(dev))
         _lib.check(st, "bgk_coupling_rqs_dense_h2_train")
         ctx.save_for_backward(x, y, W0, W1, W2, z0, z1, params, nc_dev)
+        ctx.params = (W0, b0, W1, b1, W2, b2)   # the nn.Parameters themselves (flat-bucket gradient destinations hang on them)
         ctx.cs = plan.get("cs")                 # scale table of the operands packed for this forward (same weights in backward)
         ctx.tbufs = plan.setdefault("tbufs", {})
         ctx.meta = (plan["act"], bool(plan["periodic"]), (plan["n_bins"], inverse, left, right, bottom, top, dict(s)))
@@ -683,7 +695,8 @@ class _FusedSplineTrainFn(torch.autograd.Function):
             elif need[0]:
                 g_x = _matmul_nn(g_z0, W0)
         if FUSED_WEIGHT_GRAD and g_p.is_cuda and W0.shape[1] <= 128:
-            gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs)
+            gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs,
+                                                              params=ctx.params)
         else:
             feats = _featurise(x.detach(), periodic)
             gW2 = _gram_tn(g_p, h1) if need[6] else None

@@ -113,6 +113,8 @@ class FlatAdam(torch.optim.Optimizer):
                 self.flat[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + k].view_as(p)          # same values, now a view of the bucket
                 p.grad = self.grad[off:off + k].view_as(p)
+                # kernels that compute parameter gradients themselves (bgk_dense_weight_grad) accumulate straight into the bucket
+                p._bgk_grad_dst = self.grad[off:off + k].view_as(p)
                 off += k
 
     def zero_grad(self, set_to_none=False):

@@ -310,14 +310,15 @@ int bgk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * the training step: dW = g^T h, db = sum over the batch of g) from the tensors bgk_rqs_backward / bgk_dense_backward_dx wrote:
  *   (g_params [B, P], h1) -> gW2 [P, 128], gb2 [P];  (g_z1, h0) -> gW1 [128, 128], gb1 [128];
  *   (g_z0, featurised cond) -> gW0 [128, n_in], gb0 [128]   (periodic != 0: cond [B, d_c] is featurised on the fly as
- *   [cos 2 pi x | sin 2 pi x], nn/periodic.py:30-37; n_in = 2 d_c).  Any gW pointer may be NULL (skipped with its gb).
+ *   [cos 2 pi x | sin 2 pi x], nn/periodic.py:30-37; n_in = 2 d_c).  Any gW pointer may be NULL (skipped with its gb);
+ *   accumulate != 0: results are ADDED to the destinations (gradient buckets of the optimizer).
  * Split over the batch into slabs whose partials are summed in fixed order (deterministic); workspace size in floats from
  * bgk_dense_weight_grad_workspace.  Replaces 3 split-K hipBLASLt GEMMs + 3 reductions + 6 column-sum launches per layer. */
 int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in);
 int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
                           const float* h1, const float* h0, const float* cond, int64_t ldc, int32_t d_c,
                           int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
-                          float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, void* stream);
+                          float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate, void* stream);
 
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).
