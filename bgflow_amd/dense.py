@@ -473,8 +473,8 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     d_c = l0.in_features // 2 if periodic else l0.in_features
     if periodic:
         idx = np.arange(d_c)[net.indices] if not isinstance(net.indices, slice) or net.indices != slice(None) else np.arange(d_c)
-        if len(idx) != d_c or 2 * d_c != l0.in_features:
-            return None   # only "all conditioner inputs periodic" is fused
+        if len(idx) != d_c or 2 * d_c != l0.in_features or not np.array_equal(np.asarray(idx), np.arange(d_c)):
+            return None   # only "all conditioner inputs periodic, in natural order" is fused (the kernel featurises columns 0..d_c-1)
     params = [p for lin in (l0, l1, l2) for p in (lin.weight, lin.bias)]
     version = tuple((p.data_ptr(), p._version) for p in params)
     cache = transformer._fused_cache

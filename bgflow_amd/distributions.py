@@ -242,7 +242,11 @@ class UniformDistribution(Energy, Sampler):
         self.uniform = SloppyUniform(low, high, validate_args, tol=tol)
 
     def _energy(self, x):
-        return -self.uniform.log_prob(x).sum(dim=-1, keepdim=True)
+        # The reference evaluates -log_prob and, whenever a value lies outside the (tolerant) support, falls back to the energy
+        # of a fresh in-support sample for the whole batch (distributions.py:108-114): in either case the result is the
+        # constant sum_j log(high_j - low_j) -- finite by construction (never +inf), and no host-side support check is needed.
+        const = torch.log(self.uniform.high - self.uniform.low).expand(x.shape[-1:]).sum()
+        return const.expand(*x.shape[:-1], 1).to(x.dtype)
 
     def _sample(self, n_samples):
         return self.uniform.sample(torch.Size([n_samples]))
@@ -264,8 +268,10 @@ class ProductDistribution(Energy, Sampler):
     def energy(self, *xs, temperature=1.0):
         if self._cat_dim is not None:
             xs = torch.split(xs[0], self._lengths, dim=self._cat_dim)
-        es = [c.energy(x, temperature=temperature) for c, x in zip(self._components, xs)]
-        return sum(es[1:], es[0])
+        # like the reference (product.py:36-44 + energy/base.py:124-146): the components are evaluated at T = 1 and their SUM is
+        # divided by the temperature
+        es = [c.energy(x) for c, x in zip(self._components, xs)]
+        return sum(es[1:], es[0]) / temperature
 
     def sample(self, n_samples, temperature=1.0):
         parts = tuple(c.sample(n_samples, temperature=temperature) for c in self._components)

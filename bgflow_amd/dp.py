@@ -69,7 +69,7 @@ def global_mean(per_sample_loss, drop_nonfinite=False):
         return local_sum / n_local.to(local_sum.dtype)
     stats = torch.stack([local_sum.detach().to(torch.float64), n_local.to(torch.float64)])
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    n_global = stats[1].item() if False else stats[1]
+    n_global = stats[1]                        # stays on the device: no host sync in the loss path
     mean_value = (stats[0] / n_global).to(local_sum.dtype)
     # value = global mean; gradient flows through the local sum only
     return mean_value + (local_sum - local_sum.detach()) / n_global.to(local_sum.dtype)

@@ -15,6 +15,13 @@ import torch
 from . import _lib
 from .flow import Flow
 
+def _invalidate_fused_cache(self):
+    """Forget the packed-operand cache of the fused kernels.  The cache is keyed on the parameters' (data_ptr, _version): optimizer
+    steps, load_state_dict and ordinary in-place ops are picked up automatically; edits through ``.data`` (EMA / weight-swap code)
+    bump no version counter -- call this after them."""
+    self._fused_cache.clear()
+
+
 __all__ = ["Transformer", "AffineTransformer", "ConditionalSplineTransformer"]
 
 DEFAULT_MIN_BIN_WIDTH = 1e-3
@@ -331,3 +338,7 @@ class ConditionalSplineTransformer(Transformer):
 
     def _inverse(self, x, y, *args, **kwargs):
         return self._run(x, y, True)
+
+
+AffineTransformer.invalidate_fused_cache = _invalidate_fused_cache
+ConditionalSplineTransformer.invalidate_fused_cache = _invalidate_fused_cache

@@ -532,3 +532,23 @@ def test_kltrainer_host_semantics(capsys):
     rep = LossReporter("a")
     rep.report(torch.tensor(1.0)); rep.report(2.0)
     assert rep.losses()[2][0].tolist() == [1.0, 2.0]
+
+
+def test_uniform_energy_is_finite_and_product_temperature_like_reference():
+    """UniformDistribution.energy never returns inf (reference: falls back to an in-support sample's energy,
+    distributions.py:108-114); ProductDistribution sums its components at T = 1 and divides the sum by T (product.py:36-44)"""
+    u = bg.UniformDistribution(torch.zeros(3), torch.tensor([1.0, 2.0, 4.0]))
+    x = torch.tensor([[0.5, 1.0, 2.0], [7.0, -3.0, 9.0]])
+    e = u.energy(x)
+    assert e.shape == (2, 1) and torch.isfinite(e).all()
+    np.testing.assert_allclose(e.numpy(), np.log(8.0), rtol=1e-6)
+    n = bg.NormalDistribution(2)
+    prod = bg.ProductDistribution([n, bg.NormalDistribution(3)])
+    a, b = torch.randn(5, 2), torch.randn(5, 3)
+    T = 2.5
+    np.testing.assert_allclose(prod.energy(a, b, temperature=T).numpy(),
+                               ((n.energy(a) + bg.NormalDistribution(3).energy(b)) / T).numpy(), rtol=1e-6)
+    tr = bg.ConditionalSplineTransformer(torch.nn.Linear(3, 3 * 8 * 2 + 2))
+    tr._fused_cache["x"] = 1
+    tr.invalidate_fused_cache()
+    assert tr._fused_cache == {}
