@@ -109,7 +109,7 @@ def timed_steps(gen, zs, steps):
         for _ in range(steps):
             xs = tuple(zs)
             total = 0.0
-            for i, block in enumerate(gen.flow):
+            for i, (_, block) in enumerate(gen.flow.segments()):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 *xs, dd = block(*xs)
@@ -138,7 +138,7 @@ def flow_pass(gen, zs):
         with torch.no_grad():
             xs = tuple(zs)
             total = 0.0
-            for block in gen.flow:
+            for _, block in gen.flow.segments():
                 *xs, dd = block(*xs)
                 total = total + dd
         return total
@@ -463,12 +463,13 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
 
     if rank == 0:
-        n_blocks = len(gen.flow)
+        segs = gen.flow.segments()          # the blocks; a tail of icdf maps + IC -> xyz counts as one (fused) segment
+        n_blocks = len(segs)
         block_ms = [0.0] * n_blocks
         for i, e0, e1 in evs:
             block_ms[i] += e0.elapsed_time(e1) / args.steps
-        coupling = [i for i, b in enumerate(gen.flow) if isinstance(b, CouplingFlow)]
-        stats = [coupling_stats(gen.flow[i], gemm_mode) for i in coupling]
+        coupling = [i for i, (_, b) in enumerate(segs) if isinstance(b, CouplingFlow)]
+        stats = [coupling_stats(segs[i][1], gemm_mode) for i in coupling]
         fused = [i for i, st in zip(coupling, stats) if st[2] is not None]          # spline couplings = the dominant kernel's launches
         n_launch = len(fused) if fused else len(coupling)
         idxs = fused if fused else coupling
@@ -511,6 +512,7 @@ def main():
                                  peak_GBs=HBM_PEAK_GBS, frac=alg_bytes_step / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS,
                                  note="SURVEY 8(d) bytes of the WHOLE step (couplings + icdf maps + coordinate transform) / step time")
         roof["block_ms"] = [round(v, 3) for v in block_ms]
+        roof["block_labels"] = [lbl for lbl, _ in segs]
         out = dict(metric="flow samples/s (fwd+log|detJ|) at batch 2^20", value=value, unit="samples/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="bf16" if gemm_mode == "bf16" else "f32", data="synthetic",

@@ -103,23 +103,28 @@ class CDFTransform(Flow):
     def _kernel(self, x, inverse):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
             return None
-        src = _source_tensors(self.distribution)
         grad = torch.is_grad_enabled()
-        if grad and any(t.requires_grad for t in src):
-            return None          # learnable marginal: its parameters need gradients -> the distribution's own torch ops
-        d = x.shape[-1]
         # the descriptor is a host snapshot of the marginal's parameters: rebuilt whenever one of them was replaced or written
-        # (load_state_dict, optimiser steps, .to()), keyed on storage + version counter
-        key = (d, str(x.device), tuple((t.data_ptr(), t._version, str(t.device)) for t in src))
-        if self._desc_cache.get("key") != key:
-            desc = _descriptor(self.distribution, d)
-            self._desc_cache = {"key": key, "desc": None if desc is None else desc.to(x.device)}
-        desc = self._desc_cache["desc"]
+        # (load_state_dict, optimiser steps, .to()), keyed on storage + version counter; None for a learnable marginal whose
+        # parameters need gradients (-> the distribution's own torch ops)
+        desc = self.kernel_descriptor(x.shape[-1], x.device)
         if desc is None:
             return None
         if grad and x.requires_grad:
             return _CdfFn.apply(x, desc, inverse, self._eps)
         return _launch(x, desc, inverse, self._eps)
+
+    def kernel_descriptor(self, d, device):
+        """the [d, 6] device descriptor of this layer's marginal for the kernels (bgk_cdf_transform, bgk_icdf_ic2xyz), or None
+        when the marginal is not one of the supported kinds or its parameters are being trained"""
+        src = _source_tensors(self.distribution)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in src):
+            return None
+        key = (d, str(device), tuple((t.data_ptr(), t._version, str(t.device)) for t in src))
+        if self._desc_cache.get("key") != key:
+            desc = _descriptor(self.distribution, d)
+            self._desc_cache = {"key": key, "desc": None if desc is None else desc.to(device)}
+        return self._desc_cache["desc"]
 
     def invalidate_kernel_cache(self):
         """forget the cached descriptor (after in-place edits through ``.data``, which bump no version counter)"""

@@ -253,6 +253,152 @@ __global__ __launch_bounds__(IC2_THREADS) void ic_ic2xyz_kernel(IcArgs a) {
     if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
 }
 
+/* ---- generation path: icdf domain maps fused into the IC -> xyz prologue -----------------------------------------------
+ * bgk_icdf_ic2xyz: the four CDFTransform blocks the builder puts in front of the coordinate transform
+ * (generator_builder.py:443-459, nn/flow/cdf.py:36-45, marginals icmarginals.py:41-77) applied on the fly to the values the
+ * placement loop reads anyway -- no [B, 60] round trip, no 4 extra launches.  Channel descriptors are
+ * wave-uniform (scalar loads, no divergence).  Arithmetic of this variant: reciprocal square roots for the normalisations
+ * and the closed-form log|det J| = 2 ln d + ln|sin a| of a placement (what the explicit 3x3 determinant of ic_helper.py:372-452
+ * evaluates to; exact away from the eps clamps, and closer to the f64 value than the f32 determinant). */
+#define SQRT2_F 1.41421356237309504880f
+#define LOG_SQRT_2PI_F 0.91893853320467274178f
+
+struct IcGenArgs {
+    IcArgs ic;
+    const float* dsc_b; const float* dsc_a; const float* dsc_t; const float* dsc_f;   /* [n][6] x 3, [keep][6]; NULL = identity */
+    int use_eps; float cdf_eps;
+};
+
+/* y = icdf(u) of one channel, ld += -log_prob(y) (cdf_kernel's inverse branch, bgk_cdf.hip) */
+__device__ __forceinline__ float icdf_channel(float v, const float* ds, int use_eps, float eps, float& ld_acc) {
+    if (!ds) return v;
+    const int kind = (int)ds[0];
+    if (use_eps) v = v < eps ? eps : (v > 1.0f - eps ? 1.0f - eps : v);
+    float y, ld;
+    if (kind == 0) {
+        y = ds[1] + v * (ds[2] - ds[1]);
+        ld = logf(ds[2] - ds[1]);
+    } else if (kind == 1) {
+        y = ds[1] + ds[2] * erfinvf(2.0f * v - 1.0f) * SQRT2_F;
+        const float dv = y - ds[1];
+        ld = -(-(dv * dv) / (2.0f * (ds[2] * ds[2])) - logf(ds[2]) - LOG_SQRT_2PI_F);
+    } else {
+        const float r0 = ds[4] * v + ds[3];
+        y = (erfinvf(2.0f * r0 - 1.0f) * SQRT2_F) * ds[2] + ds[1];
+        const float z = (y - ds[1]) / ds[2];
+        ld = -((-(z * z) / 2.0f - LOG_SQRT_2PI_F) - logf(ds[4] * ds[2]));
+    }
+    if (use_eps) ld = ld < -1.0f / eps ? -1.0f / eps : ld;
+    ld_acc += ld;
+    return y;
+}
+
+/* 1 / max(|v|, eps) with the clamp counted like clamp_min_flag */
+__device__ __forceinline__ float inv_norm_flag(V3 v, float eps, int enforce, int& warn) {
+    float n2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    if (n2 < eps * eps) { warn += 1; if (enforce) n2 = eps * eps; }
+    float r = __builtin_amdgcn_rsqf(n2);
+    return r * (1.5f - 0.5f * n2 * r * r);       /* one Newton step: ~1 ulp */
+}
+
+/* log|det J| of one placement exactly as the reference evaluates it (explicit 3x3 determinant of ic2xyz_deriv,
+ * ic_helper.py:372-452, with its eps clamps) -- only taken when a norm of the placement had to be clamped: there the
+ * clamped vectors are no longer unit vectors and the determinant differs from d^2 sin a. */
+__device__ __noinline__ float explicit_placement_logdet(V3 p1, V3 p2, V3 p3, float dd, float st, float ct, float sa, float ca,
+                                                        float eps, int enforce) {
+    int w = 0;
+    V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
+    V3 nv = cross(v1, v2), nn = cross(v1, nv);
+    float nvn = clamp_min_flag(norm(nv), eps, enforce, w);
+    float nnn = clamp_min_flag(norm(nn), eps, enforce, w);
+    V3 nh = divs(nv, nvn), nnh = divs(nn, nnn);
+    V3 v3 = {nh.x * (-st) + nnh.x * ct, nh.y * (-st) + nnh.y * ct, nh.z * (-st) + nnh.z * ct};
+    float v3n = clamp_min_flag(norm(v3), eps, enforce, w);
+    V3 v3h = divs(v3, v3n);
+    float v1n = clamp_min_flag(norm(v1), eps, enforce, w);
+    V3 v1h = divs(v1, v1n);
+    V3 Jd = {v3h.x * sa - v1h.x * ca, v3h.y * sa - v1h.y * ca, v3h.z * sa - v1h.z * ca};
+    V3 Ja = {v3h.x * dd * ca + v1h.x * dd * sa, v3h.y * dd * ca + v1h.y * dd * sa, v3h.z * dd * ca + v1h.z * dd * sa};
+    V3 Jt3 = {nh.x * (-ct) + nnh.x * (-st), nh.y * (-ct) + nnh.y * (-st), nh.z * (-ct) + nnh.z * (-st)};
+    float jt1 = dd * sa, h3 = dot(v3h, Jt3), inv = 1.0f / v3n;
+    V3 Jt = {jt1 * inv * (Jt3.x - v3h.x * h3), jt1 * inv * (Jt3.y - v3h.y * h3), jt1 * inv * (Jt3.z - v3h.z * h3)};
+    V3 R0 = {Jd.x, Ja.x, Jt.x}, R1 = {Jd.y, Ja.y, Jt.y}, R2 = {Jd.z, Ja.z, Jt.z};
+    return bgk_logf(fabsf(det3(R0, R1, R2)));
+}
+
+__global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
+    const IcArgs& a = g.ic;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TS = IC2_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
+    float* s_x = smem;                  /* [TS][sx] */
+    const int tid = threadIdx.x;
+    const int64_t n_tiles = (a.B + TS - 1) / TS;
+    int warn = 0;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * TS;
+        const int rows = (int)((a.B - b0) < TS ? (a.B - b0) : TS);
+        if (tid < rows) {
+            const int64_t b = b0 + tid;
+            float* xr = s_x + tid * a.sx;
+            const float* fx = a.xfix + b * a.ldf;
+            float acc = 0.0f;
+            if (a.T) {
+                for (int c = 0; c < nf3; ++c) xr[3 * a.fixed[c / 3] + c % 3] = a.wh_mean[c];
+                for (int k = 0; k < a.keep; ++k) {
+                    const float zk = icdf_channel(fx[k], g.dsc_f ? g.dsc_f + 6 * k : nullptr, g.use_eps, g.cdf_eps, acc);
+                    for (int c = 0; c < nf3; ++c) xr[3 * a.fixed[c / 3] + c % 3] += zk * a.T[k * nf3 + c];
+                }
+                acc += -a.jac_xz;
+            } else {
+                for (int c = 0; c < nf3; ++c)
+                    xr[3 * a.fixed[c / 3] + c % 3] = icdf_channel(fx[c], g.dsc_f ? g.dsc_f + 6 * c : nullptr, g.use_eps, g.cdf_eps, acc);
+            }
+            if (a.normalize) acc += (float)n * logf(PI_F) + (float)n * logf(2.0f * PI_F);
+            const float* pb = a.bonds + b * a.ldic;
+            const float* pa = a.angles + b * a.ldic;
+            const float* pt = a.torsions + b * a.ldic;
+            for (int i = 0; i < n; ++i) {
+                const int at = a.table[5 * i], i1 = a.table[5 * i + 1], i2 = a.table[5 * i + 2],
+                          i3 = a.table[5 * i + 3], zr = a.table[5 * i + 4];
+                const float dd = icdf_channel(pb[zr], g.dsc_b ? g.dsc_b + 6 * zr : nullptr, g.use_eps, g.cdf_eps, acc);
+                const float an = icdf_channel(pa[zr], g.dsc_a ? g.dsc_a + 6 * zr : nullptr, g.use_eps, g.cdf_eps, acc);
+                const float tn = icdf_channel(pt[zr], g.dsc_t ? g.dsc_t + 6 * zr : nullptr, g.use_eps, g.cdf_eps, acc);
+                V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
+                float st, ct, sa, ca;
+                if (a.normalize) {
+                    bgk_sincos2pif(0.5f * an, &sa, &ca);
+                    bgk_sincos2pif(tn, &st, &ct);
+                    st = -st; ct = -ct;
+                } else {
+                    st = sinf(tn); ct = cosf(tn); sa = sinf(an); ca = cosf(an);
+                }
+                V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
+                V3 nv = cross(v1, v2), nn = cross(v1, nv);
+                const int warn0 = warn;
+                const float inv_nv = inv_norm_flag(nv, a.eps, a.enforce, warn), inv_nn = inv_norm_flag(nn, a.eps, a.enforce, warn);
+                V3 nh = {nv.x * inv_nv, nv.y * inv_nv, nv.z * inv_nv}, nnh = {nn.x * inv_nn, nn.y * inv_nn, nn.z * inv_nn};
+                V3 v3 = {nh.x * (-st) + nnh.x * ct, nh.y * (-st) + nnh.y * ct, nh.z * (-st) + nnh.z * ct};
+                const float inv_v3 = inv_norm_flag(v3, a.eps, a.enforce, warn), inv_v1 = inv_norm_flag(v1, a.eps, a.enforce, warn);
+                const float ks = dd * sa * inv_v3, kc = dd * ca * inv_v1;
+                xr[3 * at] = p1.x + v3.x * ks - v1.x * kc;
+                xr[3 * at + 1] = p1.y + v3.y * ks - v1.y * kc;
+                xr[3 * at + 2] = p1.z + v3.z * ks - v1.z * kc;
+                if (warn == warn0) acc += 2.0f * bgk_logf(dd) + bgk_logf(fabsf(sa));
+                else acc += explicit_placement_logdet(p1, p2, p3, dd, st, ct, sa, ca, a.eps, a.enforce);   /* rare: degenerate geometry */
+            }
+            if (a.accumulate) a.dlogp[b] += acc; else a.dlogp[b] = acc;
+        }
+        __syncthreads();
+        const int na3 = 3 * a.n_atoms;
+        for (int i = tid; i < rows * na3; i += IC2_THREADS) {
+            int r = i / na3, c = i - r * na3;
+            a.x[(b0 + r) * a.ldx + c] = s_x[r * a.sx + c];
+        }
+        __syncthreads();
+    }
+    if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
+}
+
 /* ---- backward (VJP) of ic_ic2xyz_kernel: reverse sweep over the placement table ------------------
  * Same math as oracle/bgo_impl.h::bgo_ic_ic2xyz_backward (hand-derived adjoint of ic2xyz_deriv,
  * log|det J| = 2 ln d + ln|sin a|).  Lane = sample; x (forward output) and the running position
@@ -511,6 +657,37 @@ extern "C" int bgk_ic_ic2xyz(const float* bonds, const float* angles, const floa
     a.wh_mean = wh_mean; a.T = Tblacken; a.jac_xz = jac_xz; a.B = B; a.dlogp = dlogp; a.accumulate = accumulate;
     a.warn_count = warn_count;
     return ic_launch(false, a, stream, "bgk_ic_ic2xyz");
+}
+
+extern "C" int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const float* torsions, int64_t ldic,
+                               const float* xfix, int64_t ldf,
+                               const float* desc_bonds, const float* desc_angles, const float* desc_torsions, const float* desc_fixed,
+                               int32_t use_eps, float cdf_eps,
+                               const int32_t* place, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                               int32_t normalize_angles, float eps, int32_t enforce_boundaries,
+                               const float* wh_mean, const float* Tblacken, int32_t keep, float jac_xz, int64_t B,
+                               float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream) {
+    BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_icdf_ic2xyz: bad sizes");
+    BGK_CHECK_ARG(x && place && fixed && bonds && angles && torsions && xfix && dlogp, "bgk_icdf_ic2xyz: null pointer");
+    BGK_CHECK_ARG(Tblacken ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_icdf_ic2xyz: bad whitening arguments");
+    if (B == 0) return 0;
+    IcGenArgs g{};
+    IcArgs& a = g.ic;
+    a.x = x; a.ldx = ldx; a.bonds = const_cast<float*>(bonds); a.angles = const_cast<float*>(angles);
+    a.torsions = const_cast<float*>(torsions); a.ldic = ldic; a.xfix = const_cast<float*>(xfix); a.ldf = ldf;
+    a.table = place; a.fixed = fixed; a.n = n; a.n_fixed = n_fixed; a.keep = keep;
+    a.normalize = normalize_angles; a.enforce = enforce_boundaries; a.eps = eps;
+    a.wh_mean = wh_mean; a.T = Tblacken; a.jac_xz = jac_xz; a.B = B; a.dlogp = dlogp; a.accumulate = accumulate;
+    a.warn_count = warn_count;
+    a.n_atoms = n + n_fixed;
+    a.sx = (3 * a.n_atoms) | 1;
+    g.dsc_b = desc_bonds; g.dsc_a = desc_angles; g.dsc_t = desc_torsions; g.dsc_f = desc_fixed; g.use_eps = use_eps; g.cdf_eps = cdf_eps;
+    size_t shmem = sizeof(float) * (size_t)IC2_THREADS * (size_t)a.sx;
+    if (shmem > 160 * 1024) { bgk_set_error("bgk_icdf_ic2xyz: %d atoms do not fit the LDS tile", a.n_atoms); return BGK_EUNSUPPORTED; }
+    int64_t nt = (B + IC2_THREADS - 1) / IC2_THREADS;
+    int grid = (int)(nt < 256 * 32 ? nt : 256 * 32);
+    hipLaunchKernelGGL(icdf_ic2xyz_kernel, dim3(grid), dim3(IC2_THREADS), shmem, (hipStream_t)stream, g);
+    return bgk_launch_status("bgk_icdf_ic2xyz");
 }
 
 extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float* torsions,

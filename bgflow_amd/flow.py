@@ -45,15 +45,60 @@ class SequentialFlow(Flow):
         super().__init__()
         self._blocks = torch.nn.ModuleList(blocks)
 
+    FUSE_GENERATION_TAIL = True   # icdf domain maps + IC -> xyz as one kernel in the sampling direction (bgk_icdf_ic2xyz)
+
     def forward(self, *xs, inverse=False, **kwargs):
-        order = reversed(self._blocks) if inverse else self._blocks
         # same accumulation as the reference (sequential.py:49,58): start from the python float 0.0,
         # `dlogp += ddlogp` (new tensor for the first block, in place afterwards)
         total = 0.0
-        for block in order:
-            *xs, ddlogp = block(*xs, inverse=inverse, **kwargs)
+        for _, seg in self.segments(inverse=inverse):
+            *xs, ddlogp = seg(*xs, inverse=inverse, **kwargs)
             total += ddlogp
         return (*xs, total)
+
+    def segments(self, inverse=False):
+        """[(label, callable)] in execution order: the blocks themselves, except that in the sampling direction a tail of
+        builder domain maps ``WrapFlow(InverseFlow(CDFTransform))`` followed by ``WrapFlow(InverseFlow(<IC transform>))``
+        (generator_builder.py:443-459 + add_map_to_cartesian) runs as ONE fused kernel when the inputs need no gradients."""
+        blocks = list(self._blocks)
+        if inverse:
+            return [(type(b).__name__, b) for b in reversed(blocks)]
+        tail = self._generation_tail() if self.FUSE_GENERATION_TAIL else None
+        if tail is None:
+            return [(type(b).__name__, b) for b in blocks]
+        start = tail[0]
+        return [(type(b).__name__, b) for b in blocks[:start]] + [("icdf+ic2xyz", _FusedGenerationTail(self, tail))]
+
+    def _generation_tail(self):
+        """(first block index, {slot: CDFTransform}, ic) if the flow ends with [domain maps..., IC -> xyz], else None"""
+        from .cdf import CDFTransform
+        blocks = list(self._blocks)
+        if len(blocks) < 2:
+            return None
+        last = blocks[-1]
+        ic = getattr(getattr(last, "_flow", None), "_delegate", None)
+        if not (type(last) is WrapFlow and type(last._flow) is InverseFlow and hasattr(ic, "_generate_fused")
+                and list(last._indices) == [0, 1, 2, 3] and list(last._out_indices) == [0]):
+            return None
+        maps, others = {}, []
+        i = len(blocks) - 1
+        while i - 1 >= 0:
+            b = blocks[i - 1]
+            cdf = getattr(getattr(b, "_flow", None), "_delegate", None)
+            if not (type(b) is WrapFlow and type(b._flow) is InverseFlow and type(cdf) is CDFTransform and len(b._indices) == 1
+                    and list(b._out_indices) == list(b._indices) and b._indices[0] not in maps):
+                break
+            if b._indices[0] in (0, 1, 2, 3):
+                maps[b._indices[0]] = cdf
+            else:
+                others.insert(0, b)       # a map on another slot (e.g. auxiliary variables): commutes with the tail, runs as a block
+            i -= 1
+        if not maps:
+            return None
+        eps = {c._eps for c in maps.values()}
+        if len(eps) != 1:
+            return None
+        return i, maps, ic, eps.pop(), others
 
     def _forward(self, *args, **kwargs):
         return self.forward(*args, **kwargs, inverse=False)
@@ -80,6 +125,41 @@ class SequentialFlow(Flow):
             return self._blocks[index]
         picked = np.arange(len(self))[index]
         return SequentialFlow([self._blocks[i] for i in picked])
+
+
+class _FusedGenerationTail:
+    """callable standing in for the tail blocks [icdf maps..., IC -> xyz] of a SequentialFlow (sampling direction).  Falls back
+    to the blocks themselves when an input needs gradients, is not an f32 HIP tensor, or a marginal has no kernel descriptor."""
+
+    def __init__(self, flow, tail):
+        self._flow, (self._start, self._maps, self._ic, self._eps, self._others) = flow, tail
+
+    def _blocks_path(self, *xs, **kwargs):
+        total = 0.0
+        for block in list(self._flow._blocks)[self._start:]:
+            *xs, dd = block(*xs, **kwargs)
+            total = total + dd
+        return (*xs, total)
+
+    def __call__(self, *xs, inverse=False, **kwargs):
+        assert not inverse
+        ok = len(xs) >= 4 and all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 for x in xs[:4])
+        if ok and torch.is_grad_enabled() and any(x.requires_grad for x in xs):
+            ok = False
+        descs = [None] * 4
+        if ok:
+            for slot, cdf in self._maps.items():
+                descs[slot] = cdf.kernel_descriptor(xs[slot].shape[-1], xs[slot].device)
+                if descs[slot] is None:
+                    ok = False
+        if not ok:
+            return self._blocks_path(*xs, **kwargs)
+        total = 0.0
+        for block in self._others:                      # maps on slots the coordinate transform does not touch
+            *xs, dd = block(*xs, **kwargs)
+            total = total + dd
+        x, dlogp = self._ic._generate_fused(xs[0], xs[1], xs[2], xs[3], descs, self._eps)
+        return (x, *xs[4:], dlogp + total if self._others else dlogp)
 
 
 class InverseFlow(Flow):

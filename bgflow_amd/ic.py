@@ -305,6 +305,38 @@ class RelativeInternalCoordinateTransformation(Flow):
         _lib.check(st, "bgk_ic_ic2xyz")
         return x, dlogp[:, None]
 
+    def _icdf_ic2xyz(self, bonds, angles, torsions, xfix, descs, eps, blacken=None):
+        """IC -> xyz with the icdf domain maps of the four inputs fused in (bgk_icdf_ic2xyz); ``descs`` = per-field [d, 6]
+        descriptor tensors (cdf.CDFTransform.kernel_descriptor) or None for a field that is used as is.  No autograd."""
+        _lib.require_hip(bonds, angles, torsions, xfix)
+        dev = bonds.device
+        B, n, nf = bonds.shape[0], self._n, self._n_fixed
+        (b2, a2, t2), ldic = _contig_rows(bonds, angles, torsions)
+        f2, ldf = _lib.rowmajor(xfix.reshape(B, -1))
+        if blacken is None:
+            mean = T = None
+            keep, jac = 3 * nf, 0.0
+        else:
+            mean, T, jac = blacken
+            keep = T.shape[0]
+        assert f2.shape[1] == keep
+        x = torch.empty((B, 3 * (n + nf)), dtype=torch.float32, device=dev)
+        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        db, da, dt, df = descs
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_icdf_ic2xyz(
+                _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), ldic, _lib.ptr(f2), ldf,
+                _lib.ptr(db), _lib.ptr(da), _lib.ptr(dt), _lib.ptr(df), int(eps is not None), float(eps or 0.0),
+                _lib.ptr(self._tables.get("place", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
+                int(self._normalize_angles), float(self._eps), int(self._enforce_boundaries),
+                _lib.ptr(mean), _lib.ptr(T), keep, float(jac), B, _lib.ptr(x), x.shape[1],
+                _lib.ptr(dlogp), 0, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_icdf_ic2xyz")
+        return x, dlogp[:, None]
+
+    def _generate_fused(self, bonds, angles, torsions, x_fixed, descs, eps):
+        return self._icdf_ic2xyz(bonds, angles, torsions, x_fixed, descs, eps)
+
     def _forward(self, x, with_pose=True, *args, **kwargs):
         return self._xyz2ic(x)
 
@@ -398,6 +430,9 @@ class MixedCoordinateTransformation(Flow):
 
     def _inverse(self, bonds, angles, torsions, z_fixed, *args, **kwargs):
         return self._rel_ic._ic2xyz(bonds, angles, torsions, z_fixed, blacken=self._wh("blacken", bonds.device))
+
+    def _generate_fused(self, bonds, angles, torsions, z_fixed, descs, eps):
+        return self._rel_ic._icdf_ic2xyz(bonds, angles, torsions, z_fixed, descs, eps, blacken=self._wh("blacken", bonds.device))
 
 
 def slice_initial_atoms(z_matrix):

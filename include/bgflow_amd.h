@@ -140,6 +140,21 @@ int bgk_ic_ic2xyz(const float* bonds, const float* angles, const float* torsions
 int bgk_ic_refsys(const float* in, int64_t B, int32_t inverse, int32_t normalize_angles, float eps,
                   int32_t enforce_boundaries, float* out, float* dlogp, int32_t accumulate, void* stream);
 
+/* Generation path: bgk_ic_ic2xyz with the icdf domain maps of the builder fused into its prologue (replaces the chain
+ * CDFTransform._inverse x 4 -> RelativeInternalCoordinateTransformation._inverse: nn/flow/cdf.py:36-45,
+ * generator_builder.py:443-459, crd_transform/ic.py:435-513): bonds / angles / torsions / xfix arrive as values in [0, 1],
+ * desc_* = per-channel descriptors like bgk_cdf_transform's ([n, 6] x 3, [keep, 6]; NULL = that field is used as is).
+ * dlogp receives the log-dets of the maps AND of the coordinate transform.  Placement log-det in closed form
+ * (2 ln d + ln|sin a|), normalisations on reciprocal square roots. */
+int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const float* torsions, int64_t ldic,
+                    const float* xfix, int64_t ldf,
+                    const float* desc_bonds, const float* desc_angles, const float* desc_torsions, const float* desc_fixed,
+                    int32_t use_eps, float cdf_eps,
+                    const int32_t* place, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                    int32_t normalize_angles, float eps, int32_t enforce_boundaries,
+                    const float* wh_mean, const float* Tblacken, int32_t keep, float jac_xz, int64_t B,
+                    float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream);
+
 /* Backward (VJP) of bgk_ic_ic2xyz for first-order losses (replaces torch autograd through
  * ic2xyz_deriv / det3x3, ic.py:435-513): x is the forward OUTPUT; g_x [B, 3*n_atoms], g_dlogp [B]
  * -> g_bonds / g_angles / g_torsions [B, n] (ldgic), g_xfix [B, keep] (ldgf).  The log-det term uses

@@ -1136,8 +1136,12 @@ def test_kltrainer_cfg3_on_gpu(hip_lib, dev):
     from bgflow_amd import configs
     gen = configs.make_ala2_spline_generator(dev)
     torch.manual_seed(1)
-    with torch.no_grad():
-        ref = float(gen.kldiv(2048).mean())
+    bg.SequentialFlow.FUSE_GENERATION_TAIL = False      # the training path runs the blocks (autograd); compare like with like:
+    try:                                                  # near-degenerate prior samples (angle -> 0) are conditioned differently
+        with torch.no_grad():                             # by the fused tail's closed-form log-det
+            ref = float(gen.kldiv(2048).mean())
+    finally:
+        bg.SequentialFlow.FUSE_GENERATION_TAIL = True
     torch.manual_seed(1)
     tr = bg.KLTrainer(gen, train_likelihood=False)
     assert type(tr.optim).__name__ == "FlatAdam"
@@ -1194,3 +1198,42 @@ def test_world1_rccl_group_kl_loss(hip_lib, dev):
         dist.destroy_process_group()
     assert abs(l1 - l0) <= 1e-6 * abs(l0)
     np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-5, atol=1e-7 * float(g0.abs().max()))
+
+
+def test_fused_generation_tail_equals_blocks(hip_lib, golden, dev):
+    """icdf domain maps + IC -> xyz as ONE kernel (bgk_icdf_ic2xyz, sampling direction) against the same blocks run one by one
+    (bgk_cdf_transform x 4 + bgk_ic_ic2xyz), cfg 3 and cfg 5 (auxiliary slot passes through its own map)"""
+    import bgflow_amd as bg
+    from bgflow_amd import configs
+    for make, keys, name in ((configs.make_ala2_spline_generator, ("u_bonds", "u_angles", "u_torsions", "u_fixed"), "g_flow16"),
+                             (configs.make_ala2_augmented_generator, ("u_bonds", "u_angles", "u_torsions", "u_fixed", "u_aug"), "g_aug")):
+        G = golden(name)
+        gen = make(dev)
+        assert gen.flow.segments()[-1][0] == "icdf+ic2xyz"
+        g = torch.Generator(device=dev).manual_seed(11)
+        u = [torch.cat([t(G[k], dev), 0.02 + 0.96 * torch.rand(4000, G[k].shape[1], device=dev, generator=g)]) for k in keys]
+        with torch.no_grad():
+            *xs, dl = gen.flow(*u)
+            bg.SequentialFlow.FUSE_GENERATION_TAIL = False
+            try:
+                *xs_b, dl_b = gen.flow(*u)
+            finally:
+                bg.SequentialFlow.FUSE_GENERATION_TAIL = True
+        assert len(xs) == len(xs_b)
+        n_g = G[keys[0]].shape[0]
+        # the golden inputs (well-conditioned geometries): the contract tolerance
+        x_noise = 5 * np.abs(G["x32"] - G["x64"]).max() + 1e-5        # f32 erfinv of the Normal(0, 20) marginal dominates x
+        assert float((xs[0][:n_g] - xs_b[0][:n_g]).abs().max()) <= x_noise
+        for a, b in zip(xs[1:], xs_b[1:]):
+            assert float((a[:n_g] - b[:n_g]).abs().max()) <= 5e-6
+        assert rel_per_sample(dl[:n_g].cpu().numpy(), dl_b[:n_g].cpu().numpy()).max() <= (1e-5 if name == "g_flow16" else 1e-3)
+        # random prior samples include near-collinear reference atoms (normalised angle within 1e-6 of 0 or 1), where any two f32
+        # evaluations of the placement chain diverge: compare the bulk
+        dx = (xs[0] - xs_b[0]).abs().max(1).values.cpu().numpy()
+        r = rel_per_sample(dl.cpu().numpy(), dl_b.cpu().numpy())
+        assert np.median(dx) <= 1e-5 and np.quantile(dx, 0.99) <= 2e-3
+        assert np.median(r) <= 5e-6 and np.quantile(r, 0.99) <= 2e-4 and r.max() <= 5e-2
+        # inputs that need gradients take the block path (autograd through the backward kernels)
+        ur = [v[:64].clone().requires_grad_(True) for v in u]
+        *xg, dlg = gen.flow(*ur)
+        assert xg[0].grad_fn is not None
