@@ -37,6 +37,13 @@ def _descriptor(dist, d):
             desc[:, 3] = float(getattr(dist, "tol", 0.0))
         else:
             return None
+        # slot 5: the element-independent part of -log_prob(y) on the icdf side (used by bgk_icdf_ic2xyz; f64 on the host):
+        # uniform log(high - low); normal log(sigma) + log sqrt(2 pi); truncated normal log(Z sigma) + log sqrt(2 pi)
+        d64 = desc.double()
+        half_log_2pi = 0.9189385332046727
+        desc[:, 5] = torch.where(d64[:, 0] == 0, torch.log(d64[:, 2] - d64[:, 1]),
+                                 torch.where(d64[:, 0] == 1, torch.log(d64[:, 2]) + half_log_2pi,
+                                             torch.log((d64[:, 4] * d64[:, 2]).clamp_min(1e-300)) + half_log_2pi)).float()
         return desc.contiguous()
     except (AttributeError, RuntimeError):
         return None

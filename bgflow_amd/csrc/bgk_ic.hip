@@ -269,24 +269,21 @@ struct IcGenArgs {
     int use_eps; float cdf_eps;
 };
 
-/* y = icdf(u) of one channel, ld += -log_prob(y) (cdf_kernel's inverse branch, bgk_cdf.hip) */
+/* y = icdf(u) of one channel, ld += -log_prob(y) (cdf_kernel's inverse branch, bgk_cdf.hip; ds[5] = the channel's
+ * element-independent log-normalisation, precomputed in f64 on the host: no logf per element) */
 __device__ __forceinline__ float icdf_channel(float v, const float* ds, int use_eps, float eps, float& ld_acc) {
-    if (!ds) return v;
     const int kind = (int)ds[0];
+    if (kind < 0) return v;               /* no map on this field */
     if (use_eps) v = v < eps ? eps : (v > 1.0f - eps ? 1.0f - eps : v);
     float y, ld;
     if (kind == 0) {
         y = ds[1] + v * (ds[2] - ds[1]);
-        ld = logf(ds[2] - ds[1]);
-    } else if (kind == 1) {
-        y = ds[1] + ds[2] * erfinvf(2.0f * v - 1.0f) * SQRT2_F;
-        const float dv = y - ds[1];
-        ld = -(-(dv * dv) / (2.0f * (ds[2] * ds[2])) - logf(ds[2]) - LOG_SQRT_2PI_F);
+        ld = ds[5];
     } else {
-        const float r0 = ds[4] * v + ds[3];
-        y = (erfinvf(2.0f * r0 - 1.0f) * SQRT2_F) * ds[2] + ds[1];
-        const float z = (y - ds[1]) / ds[2];
-        ld = -((-(z * z) / 2.0f - LOG_SQRT_2PI_F) - logf(ds[4] * ds[2]));
+        const float r0 = kind == 1 ? v : ds[4] * v + ds[3];
+        const float z = erfinvf(2.0f * r0 - 1.0f) * SQRT2_F;
+        y = z * ds[2] + ds[1];
+        ld = 0.5f * z * z + ds[5];
     }
     if (use_eps) ld = ld < -1.0f / eps ? -1.0f / eps : ld;
     ld_acc += ld;
@@ -329,9 +326,28 @@ __device__ __noinline__ float explicit_placement_logdet(V3 p1, V3 p2, V3 p3, flo
 __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
     const IcArgs& a = g.ic;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TS = IC2_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
-    float* s_x = smem;                  /* [TS][sx] */
+    const int TS = IC2_THREADS, n = a.n, nf3 = 3 * a.n_fixed, keep = a.keep;
+    /* LDS: position table [TS][sx] | Tblacken [keep][nf3] | mean [nf3] | LDS offsets of the fixed coordinates [nf3] | channel
+     * descriptors [3 n + keep][6].  The small wave-uniform tables are staged once per workgroup: read from global memory
+     * inside the per-sample loops they were vector loads with a full round trip each (58 % of the wave time in s_waitcnt). */
+    float* s_x = smem;
+    float* s_T = s_x + TS * a.sx;
+    float* s_mean = s_T + keep * nf3;
+    int* s_off = reinterpret_cast<int*>(s_mean + nf3);
+    float* s_dsc = reinterpret_cast<float*>(s_off + nf3);
     const int tid = threadIdx.x;
+    for (int i = tid; i < nf3; i += TS) {
+        s_off[i] = 3 * a.fixed[i / 3] + i % 3;
+        s_mean[i] = a.T ? a.wh_mean[i] : 0.0f;
+    }
+    if (a.T) for (int i = tid; i < keep * nf3; i += TS) s_T[i] = a.T[i];
+    for (int i = tid; i < (3 * n + keep) * 6; i += TS) {
+        const int ch = i / 6, e = i - 6 * ch;
+        const float* src = ch < n ? g.dsc_b : (ch < 2 * n ? g.dsc_a : (ch < 3 * n ? g.dsc_t : g.dsc_f));
+        const int local = ch < n ? ch : (ch < 2 * n ? ch - n : (ch < 3 * n ? ch - 2 * n : ch - 3 * n));
+        s_dsc[i] = src ? src[6 * local + e] : (e == 0 ? -1.0f : 0.0f);      /* kind -1 = identity */
+    }
+    __syncthreads();
     const int64_t n_tiles = (a.B + TS - 1) / TS;
     int warn = 0;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -341,28 +357,46 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
             const int64_t b = b0 + tid;
             float* xr = s_x + tid * a.sx;
             const float* fx = a.xfix + b * a.ldf;
+            const float* pb = a.bonds + b * a.ldic;
+            const float* pa = a.angles + b * a.ldic;
+            const float* pt = a.torsions + b * a.ldic;
+            /* the first placement's three values and the fixed block travel while the table is initialised */
+            int zr = a.table[4];
+            float ub = pb[zr], ua = pa[zr], ut = pt[zr];
+            float fxv[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) fxv[k] = k < keep ? fx[k] : 0.0f;
             float acc = 0.0f;
             if (a.T) {
-                for (int c = 0; c < nf3; ++c) xr[3 * a.fixed[c / 3] + c % 3] = a.wh_mean[c];
-                for (int k = 0; k < a.keep; ++k) {
-                    const float zk = icdf_channel(fx[k], g.dsc_f ? g.dsc_f + 6 * k : nullptr, g.use_eps, g.cdf_eps, acc);
-                    for (int c = 0; c < nf3; ++c) xr[3 * a.fixed[c / 3] + c % 3] += zk * a.T[k * nf3 + c];
+                for (int c = 0; c < nf3; ++c) xr[s_off[c]] = s_mean[c];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < keep) {
+                        const float zk = icdf_channel(fxv[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
+                        for (int c = 0; c < nf3; ++c) xr[s_off[c]] += zk * s_T[k * nf3 + c];
+                    }
+                }
+                for (int k = 16; k < keep; ++k) {
+                    const float zk = icdf_channel(fx[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
+                    for (int c = 0; c < nf3; ++c) xr[s_off[c]] += zk * s_T[k * nf3 + c];
                 }
                 acc += -a.jac_xz;
             } else {
                 for (int c = 0; c < nf3; ++c)
-                    xr[3 * a.fixed[c / 3] + c % 3] = icdf_channel(fx[c], g.dsc_f ? g.dsc_f + 6 * c : nullptr, g.use_eps, g.cdf_eps, acc);
+                    xr[s_off[c]] = icdf_channel(c < 16 ? fxv[c & 15] : fx[c], s_dsc + 6 * (3 * n + c), g.use_eps, g.cdf_eps, acc);
             }
             if (a.normalize) acc += (float)n * logf(PI_F) + (float)n * logf(2.0f * PI_F);
-            const float* pb = a.bonds + b * a.ldic;
-            const float* pa = a.angles + b * a.ldic;
-            const float* pt = a.torsions + b * a.ldic;
             for (int i = 0; i < n; ++i) {
-                const int at = a.table[5 * i], i1 = a.table[5 * i + 1], i2 = a.table[5 * i + 2],
-                          i3 = a.table[5 * i + 3], zr = a.table[5 * i + 4];
-                const float dd = icdf_channel(pb[zr], g.dsc_b ? g.dsc_b + 6 * zr : nullptr, g.use_eps, g.cdf_eps, acc);
-                const float an = icdf_channel(pa[zr], g.dsc_a ? g.dsc_a + 6 * zr : nullptr, g.use_eps, g.cdf_eps, acc);
-                const float tn = icdf_channel(pt[zr], g.dsc_t ? g.dsc_t + 6 * zr : nullptr, g.use_eps, g.cdf_eps, acc);
+                const int at = a.table[5 * i], i1 = a.table[5 * i + 1], i2 = a.table[5 * i + 2], i3 = a.table[5 * i + 3];
+                const int zc = zr;
+                const float vb = ub, va = ua, vt = ut;
+                if (i + 1 < n) {                      /* next placement's values: requested before this placement's arithmetic */
+                    zr = a.table[5 * (i + 1) + 4];
+                    ub = pb[zr]; ua = pa[zr]; ut = pt[zr];
+                }
+                const float dd = icdf_channel(vb, s_dsc + 6 * zc, g.use_eps, g.cdf_eps, acc);
+                const float an = icdf_channel(va, s_dsc + 6 * (n + zc), g.use_eps, g.cdf_eps, acc);
+                const float tn = icdf_channel(vt, s_dsc + 6 * (2 * n + zc), g.use_eps, g.cdf_eps, acc);
                 V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
                 float st, ct, sa, ca;
                 if (a.normalize) {
@@ -383,7 +417,7 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
                 xr[3 * at] = p1.x + v3.x * ks - v1.x * kc;
                 xr[3 * at + 1] = p1.y + v3.y * ks - v1.y * kc;
                 xr[3 * at + 2] = p1.z + v3.z * ks - v1.z * kc;
-                if (warn == warn0) acc += 2.0f * bgk_logf(dd) + bgk_logf(fabsf(sa));
+                if (warn == warn0) acc += (2.0f * __builtin_amdgcn_logf(dd) + __builtin_amdgcn_logf(fabsf(sa))) * 0.693147180559945309f;
                 else acc += explicit_placement_logdet(p1, p2, p3, dd, st, ct, sa, ca, a.eps, a.enforce);   /* rare: degenerate geometry */
             }
             if (a.accumulate) a.dlogp[b] += acc; else a.dlogp[b] = acc;
@@ -682,7 +716,8 @@ extern "C" int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const fl
     a.n_atoms = n + n_fixed;
     a.sx = (3 * a.n_atoms) | 1;
     g.dsc_b = desc_bonds; g.dsc_a = desc_angles; g.dsc_t = desc_torsions; g.dsc_f = desc_fixed; g.use_eps = use_eps; g.cdf_eps = cdf_eps;
-    size_t shmem = sizeof(float) * (size_t)IC2_THREADS * (size_t)a.sx;
+    const int nf3 = 3 * n_fixed;
+    size_t shmem = sizeof(float) * ((size_t)IC2_THREADS * (size_t)a.sx + (size_t)keep * nf3 + 2 * (size_t)nf3 + (size_t)(3 * n + keep) * 6);
     if (shmem > 160 * 1024) { bgk_set_error("bgk_icdf_ic2xyz: %d atoms do not fit the LDS tile", a.n_atoms); return BGK_EUNSUPPORTED; }
     int64_t nt = (B + IC2_THREADS - 1) / IC2_THREADS;
     int grid = (int)(nt < 256 * 32 ? nt : 256 * 32);
