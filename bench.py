@@ -468,18 +468,23 @@ def main():
         block_ms = [0.0] * n_blocks
         for i, e0, e1 in evs:
             block_ms[i] += e0.elapsed_time(e1) / args.steps
-        coupling = [i for i, (_, b) in enumerate(segs) if isinstance(b, CouplingFlow)]
-        stats = [coupling_stats(segs[i][1], gemm_mode) for i in coupling]
-        fused = [i for i, st in zip(coupling, stats) if st[2] is not None]          # spline couplings = the dominant kernel's launches
-        n_launch = len(fused) if fused else len(coupling)
+        # coupling layers per segment: a CouplingFlow is one launch; a fused coupling stack (Split -> couplings / swaps -> Merge on
+        # one buffer) holds several launches and nothing else, so its segment time / its layer count is the per-launch time
+        layers = {i: ([b] if isinstance(b, CouplingFlow) else [c for c in getattr(b, "_blocks", []) if isinstance(c, CouplingFlow)])
+                  for i, (_, b) in enumerate(segs)}
+        coupling = [i for i in range(n_blocks) if layers[i]]
+        seg_stats = {i: [coupling_stats(c, gemm_mode) for c in layers[i]] for i in coupling}
+        fused = [i for i in coupling if all(st[2] is not None for st in seg_stats[i])]   # spline couplings = the dominant kernel's launches
         idxs = fused if fused else coupling
+        sel = [st for i in idxs for st in seg_stats[i]]
+        n_launch = len(sel)
         avg_launch_s = 1e-3 * sum(block_ms[i] for i in idxs) / n_launch
-        sel = [st for i, st in zip(coupling, stats) if i in idxs]
         alg_bytes_launch = sum(st[0] for st in sel) / n_launch * args.batch
         alg_bytes_step = ALG_BYTES[args.workload] * args.batch
         split = gemm_mode in ("f16x2", "bf16")
         if args.workload == "cfg2":
-            kname, klabel = "coupling_affine_dense_kernel", "coupling_affine_dense_kernel (fused: 2 DenseNets on the f16 matrix cores + affine tail)"
+            kname, klabel = "coupling_affine_resident_kernel", ("coupling_affine_resident_kernel (fused: 2 DenseNets on the f16 matrix cores with both "
+                                                                "networks' operands resident in LDS + affine tail; layers chained on one buffer)")
         elif gemm_mode == "f16x2":
             kname, klabel = "coupling_rqs_dense_h2v2_kernel", ("coupling_rqs_dense_h2v2_kernel (bgk_fused2.hip: DenseNet conditioner in split-f16 form on the "
                                                                 "f16 matrix cores threaded through the RQ-spline / activation VALU work, one launch per coupling)")

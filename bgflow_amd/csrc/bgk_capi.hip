@@ -4,6 +4,8 @@
 #include "bgk_common.h"
 #include "bgk_fused2.h"
 
+extern int bgk_affine_variant;      /* bgk_fused_affine.hip */
+
 static thread_local char g_err[512] = "";
 
 void bgk_set_error(const char* fmt, ...) {
@@ -20,6 +22,11 @@ extern "C" int bgk_set_option(int32_t option, int32_t value) {
     if (option == 1 && (value == 1 || value == 2)) {
         const int prev = bgk_h2_variant;
         bgk_h2_variant = value;
+        return prev;
+    }
+    if (option == 2 && (value == 1 || value == 2)) {
+        const int prev = bgk_affine_variant;
+        bgk_affine_variant = value;
         return prev;
     }
     bgk_set_error("bgk_set_option: unknown option %d / value %d", option, value);

@@ -10,6 +10,8 @@
  */
 #include "bgk_mfma_h2.h"
 
+int bgk_affine_variant = 2;      /* 1: streaming kernel only, 2: weight-resident kernel where the operands fit LDS (bgk_set_option 2) */
+
 namespace {
 
 constexpr int AW = 4;
@@ -29,6 +31,7 @@ struct FusedAffArgs {
     float* out; int64_t ldo; float* dlogp; int accumulate;
     int lds_per_wave;
     int vec4;                    /* y / out rows 16-byte aligned */
+    int cvec4;                   /* cond rows 16-byte aligned */
 };
 
 template <int HT, int OT>
@@ -170,6 +173,320 @@ __global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(Fused
     }
 }
 
+
+/* ---- weight-resident variant (hidden = 64): both conditioners' packed operands (78 KB for cfg 2) are staged ONCE per
+ * workgroup in LDS and the workgroup's waves loop over 32-sample tiles.  The streaming kernel above re-reads every operand
+ * block from L2 for every 32 samples (2.7 KB of L2 traffic per sample against 392 B of HBM traffic: L2-bandwidth bound,
+ * 0.29 ms per cfg 2 layer); here the A fragments come from LDS (ds_read_b128, 624 LDS cycles per tile) and the conditioner
+ * input is loaded from global memory directly in B-operand layout (lane = sample, 8 consecutive features), so the only
+ * per-tile memory traffic is the algorithmic d_c + 2 d + 1 floats per sample. ---- */
+typedef unsigned int r_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef BGK_AFF_NOPRIO
+#define BGK_AFF_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define BGK_AFF_PRIO(p)
+#endif
+
+template <int NT>
+struct RA { r_u32x4 v[NT][2]; };
+
+template <int NT>
+__device__ __forceinline__ void ra_load(RA<NT>& f, const r_u32x4* W, int s, int lane) {
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        f.v[m][0] = W[((s * NT + m) * 2 + 0) * 64 + lane];
+        f.v[m][1] = W[((s * NT + m) * 2 + 1) * 64 + lane];
+    }
+}
+/* 3 MFMAs of one k-step (lo*hi, hi*lo, hi*hi).  ZERO: the accumulators start from the inline constant 0 (saves the 16
+ * v_mov per tile); NOLO: the B operand has no lo part (constant-1 feature of the bias column): 2 MFMAs. */
+template <int NT, bool ZERO, bool NOLO>
+__device__ __forceinline__ void ra_mfma3(h2_f32x16 (&out)[NT], const RA<NT>& a, const h2_h16x8& bhi, const h2_h16x8& blo) {
+    const h2_f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+        out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, a.v[m][1]), bhi, ZERO ? z : out[m], 0, 0, 0);
+    if (!NOLO) {
+#pragma unroll
+        for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, a.v[m][0]), blo, out[m], 0, 0, 0);
+    }
+#pragma unroll
+    for (int m = 0; m < NT; ++m) out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, a.v[m][0]), bhi, out[m], 0, 0, 0);
+}
+
+template <int HT>
+struct RB { r_u32x4 hi[2 * HT], lo[2 * HT]; };
+
+/* out = W' * b + bias'  with W' resident in LDS (K = 32 HT); out need not be initialised */
+template <int NT, int HT>
+__device__ __forceinline__ void ra_gemm_hidden(h2_f32x16 (&out)[NT], const RB<HT>& b, const r_u32x4* W, int lane) {
+    constexpr int S = 2 * HT;
+    RA<NT> ring[2];
+    ra_load<NT>(ring[0], W, 0, lane);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) ra_load<NT>(ring[(s + 1) & 1], W, s + 1, lane);
+        else {
+#pragma unroll
+            for (int m = 0; m < NT; ++m) ring[(s + 1) & 1].v[m][0] = W[(S * NT * 2 + m) * 64 + lane];
+        }
+        if (s == 0) ra_mfma3<NT, true, false>(out, ring[0], __builtin_bit_cast(h2_h16x8, b.hi[0]), __builtin_bit_cast(h2_h16x8, b.lo[0]));
+        else ra_mfma3<NT, false, false>(out, ring[s & 1], __builtin_bit_cast(h2_h16x8, b.hi[s]), __builtin_bit_cast(h2_h16x8, b.lo[s]));
+    }
+    const h2_h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+        out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, ring[S & 1].v[m][0]), one2, out[m], 0, 0, 0);
+}
+
+/* hidden activation of t * c with the hardware exp2 / rcp forms (bgk_detmath_pk.h explains why these are admissible for
+ * HIDDEN activations), immediately split into f16 hi + lo: scalar (non-packed) VALU so that it overlaps other waves' MFMAs.
+ * ACT 0 identity, 1 SiLU, 2 ReLU, 3 Tanh.  k = c (ACT 0, 2), c * log2(e) (1), 2 c log2(e) (3). */
+template <int ACT>
+__device__ __forceinline__ float r_act(float t, float c, float k) {
+    if constexpr (ACT == 2) return __builtin_amdgcn_fmed3f(t * c, 0.0f, 65000.0f);
+    else if constexpr (ACT == 3) return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * k));
+    else if constexpr (ACT == 1) {
+        const float x = t * c;
+        return __builtin_fminf(x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-(t * k))), 65000.0f);
+    } else return __builtin_amdgcn_fmed3f(t * c, -65000.0f, 65000.0f);
+}
+
+/* f32 pair -> f16 hi pair + f16 lo pair in 3 instructions: v_cvt_pk_f16_f32 (RNE), then lo = f16(a - hi) with the mixed-precision
+ * FMA reading hi as an f16 operand and writing one half of the destination (a - hi is exact in f32, so the single rounding equals
+ * (_Float16)(a - (float)hi)). */
+__device__ __forceinline__ void r_split_pair(float a0, float a1, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a0), "v"(a1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
+}
+
+template <int ACT, int HT>
+__device__ __forceinline__ void r_act_split_t(RB<HT>& b, const h2_f32x16 (&in)[HT], float c) {
+    const float k = ACT == 3 ? c * 2.88539008177792681f : (ACT == 1 ? c * 1.44269504088896341f : c);
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float a0 = r_act<ACT>(in[m][r], c, k), a1 = r_act<ACT>(in[m][r + 1], c, k);
+            unsigned hi, lo;
+            r_split_pair(a0, a1, hi, lo);
+            const int s = 2 * m + (r >> 3), e = (r & 7) >> 1;
+            b.hi[s][e] = hi; b.lo[s][e] = lo;
+        }
+}
+template <int HT>
+__device__ __forceinline__ void r_act_split(RB<HT>& b, const h2_f32x16 (&in)[HT], float c, int act) {
+    if (act == 2) r_act_split_t<2, HT>(b, in, c);
+    else if (act == 3) r_act_split_t<3, HT>(b, in, c);
+    else if (act == 1) r_act_split_t<1, HT>(b, in, c);
+    else r_act_split_t<0, HT>(b, in, c);
+}
+
+/* tanh for the OUTPUT layer (log sigma): hardware exp2 + Newton-refined rcp above 0.625 (abs error ~1e-7), odd polynomial below
+ * (same coefficients as bgk_tanhf2) */
+__device__ __forceinline__ float r_tanh_out(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float d = 1.0f + __builtin_amdgcn_exp2f(ax * 2.88539008177792681f);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
+    const float big = __builtin_copysignf(__builtin_fmaf(-2.0f, r, 1.0f), x);
+    const float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = __builtin_fmaf(p, z, 2.06390887954e-2f);
+    p = __builtin_fmaf(p, z, -5.37397155531e-2f);
+    p = __builtin_fmaf(p, z, 1.33314422036e-1f);
+    p = __builtin_fmaf(p, z, -3.33332819422e-1f);
+    const float small = __builtin_fmaf(p * z, x, x);
+    return ax >= 0.625f ? big : small;
+}
+
+struct ResOff { int a0, a1, a2; };          /* offsets (16-byte units) of a network's operands in the LDS image */
+
+template <int HT, int OT>
+__device__ __forceinline__ void res_net_tail(h2_f32x16 (&res)[OT], h2_f32x16 (&h)[HT], const AffNet& n, const r_u32x4* s_w, ResOff o, int lane) {
+    RB<HT> bf;
+    r_act_split<HT>(bf, h, n.c0, n.act);
+    BGK_AFF_PRIO(1);               /* matrix phases first: the other waves of the SIMD fill the gaps with their activation arithmetic */
+    ra_gemm_hidden<HT, HT>(h, bf, s_w + o.a1, lane);
+    BGK_AFF_PRIO(0);
+    r_act_split<HT>(bf, h, n.c1, n.act);
+    BGK_AFF_PRIO(1);
+    ra_gemm_hidden<OT, HT>(res, bf, s_w + o.a2, lane);
+    BGK_AFF_PRIO(0);
+}
+
+constexpr int RES_HT = 2;
+
+template <int OT, int RW>
+__global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_kernel(FusedAffArgs a, ResOff os, ResOff ot, int n16_s0, int n16_s1, int n16_s2,
+                                                                              int n16_t0, int n16_t1, int n16_t2) {
+    constexpr int HT = RES_HT;
+    extern __shared__ __attribute__((aligned(16))) r_u32x4 s_w[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    {
+        const r_u32x4* src[6] = {(const r_u32x4*)a.shift.A0, (const r_u32x4*)a.shift.A1, (const r_u32x4*)a.shift.A2,
+                                 (const r_u32x4*)a.scale.A0, (const r_u32x4*)a.scale.A1, (const r_u32x4*)a.scale.A2};
+        const int cnt[6] = {n16_s0, n16_s1, n16_s2, n16_t0, n16_t1, n16_t2};
+        const int off[6] = {os.a0, os.a1, os.a2, ot.a0, ot.a1, ot.a2};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            for (int i = tid; i < cnt[q]; i += RW * 64) s_w[off[q] + i] = src[q][i];
+    }
+    __syncthreads();
+    const int d = a.d, d_c = a.d_c;
+    const int n_in = a.periodic ? 2 * d_c : d_c;
+    const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * RW + wave; tile < n_tiles; tile += (int64_t)gridDim.x * RW) {
+        const int64_t b0 = tile * 32;
+        const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+        const int jr = j < rows ? j : rows - 1;                 /* rows past the batch end compute on a valid row, nothing is stored */
+        const float* crow = a.cond + (b0 + jr) * a.ldc;
+
+        h2_f32x16 hs[HT], ht[HT];
+        for (int s = 0; s < a.S0; ++s) {
+            const int f0 = 16 * s + 8 * hh;
+            h2_h16x8 bhi, blo;
+            const bool bias_only = 16 * s >= n_in;              /* wave-uniform: the k-step holds only the constant-1 feature */
+            if (bias_only) {
+                const _Float16 one = f0 == n_in ? (_Float16)1.0f : (_Float16)0.0f;
+                bhi = h2_h16x8{one, 0, 0, 0, 0, 0, 0, 0};
+                blo = h2_h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            } else {
+                float v[8];
+                if (!a.periodic && a.cvec4 && 16 * s + 16 <= d_c) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(crow + f0), t1 = *reinterpret_cast<const float4*>(crow + f0 + 4);
+                    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int f = f0 + e;
+                        float x = f == n_in ? 1.0f : 0.0f;          /* constant-1 feature: the bias column of the packed layer */
+                        if (a.periodic) {                           /* WrapPeriodic featuriser (nn/periodic.py:30-37) */
+                            if (f < n_in) {
+                                float sv, cv;
+                                bgk_sincos2pif(crow[f < d_c ? f : f - d_c], &sv, &cv);
+                                x = f < d_c ? cv : sv;
+                            }
+                        } else if (f < d_c) x = crow[f];
+                        v[e] = x;
+                    }
+                }
+                r_u32x4 uh, ul;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float c0 = __builtin_amdgcn_fmed3f(v[e], -65000.0f, 65000.0f), c1 = __builtin_amdgcn_fmed3f(v[e + 1], -65000.0f, 65000.0f);
+                    unsigned hi, lo;
+                    r_split_pair(c0, c1, hi, lo);
+                    uh[e >> 1] = hi; ul[e >> 1] = lo;
+                }
+                bhi = __builtin_bit_cast(h2_h16x8, uh); blo = __builtin_bit_cast(h2_h16x8, ul);
+            }
+            RA<HT> fr;
+            if (a.has_shift) {
+                ra_load<HT>(fr, s_w + os.a0, s, lane);
+                if (s == 0) ra_mfma3<HT, true, false>(hs, fr, bhi, blo);
+                else if (bias_only) ra_mfma3<HT, false, true>(hs, fr, bhi, blo);
+                else ra_mfma3<HT, false, false>(hs, fr, bhi, blo);
+            }
+            if (a.has_scale) {
+                ra_load<HT>(fr, s_w + ot.a0, s, lane);
+                if (s == 0) ra_mfma3<HT, true, false>(ht, fr, bhi, blo);
+                else if (bias_only) ra_mfma3<HT, false, true>(ht, fr, bhi, blo);
+                else ra_mfma3<HT, false, false>(ht, fr, bhi, blo);
+            }
+        }
+        h2_f32x16 mu[OT], sr[OT];
+        if (a.has_shift) res_net_tail<HT, OT>(mu, hs, a.shift, s_w, os, lane);
+        else {
+#pragma unroll
+            for (int m = 0; m < OT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mu[m][r] = 0.0f;
+        }
+        if (a.has_scale) res_net_tail<HT, OT>(sr, ht, a.scale, s_w, ot, lane);
+        else {
+#pragma unroll
+            for (int m = 0; m < OT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sr[m][r] = 0.0f;
+        }
+
+        float lsum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < OT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float l0 = (a.has_scale && h2_row(m, r, hh) < d) ? r_tanh_out(sr[m][r] * a.scale.c2) * alpha : 0.0f;
+                const float l1 = (a.has_scale && h2_row(m, r + 1, hh) < d) ? r_tanh_out(sr[m][r + 1] * a.scale.c2) * alpha : 0.0f;
+                sr[m][r] = l0; sr[m][r + 1] = l1;
+                lsum += l0;
+                lsum += l1;
+            }
+        float total = lsum + __shfl_xor(lsum, 32);
+        if (a.preserve_volume && a.has_scale) {
+            const float mean = total / (float)d;
+            lsum = 0.0f;
+#pragma unroll
+            for (int m = 0; m < OT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool valid = h2_row(m, r, hh) < d;
+                    const float ls = valid ? sr[m][r] - mean : 0.0f;
+                    sr[m][r] = ls;
+                    lsum += ls;
+                }
+            total = lsum + __shfl_xor(lsum, 32);
+        }
+        if (j < rows) {
+            const float* yr = a.y + (b0 + j) * a.ldy;
+            float* orow = a.out + (b0 + j) * a.ldo;
+#pragma unroll
+            for (int m = 0; m < OT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int dim0 = h2_row(m, 4 * q, hh);
+                    if (dim0 >= d) continue;
+                    const bool full = a.vec4 && dim0 + 4 <= d;
+                    float v[4];
+                    if (full) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(yr + dim0);
+                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = dim0 + u < d ? yr[dim0 + u] : 0.0f;
+                    }
+                    float o[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = 4 * q + u;
+                        const float mm = a.has_shift ? mu[m][r] * a.shift.c2 : 0.0f;
+                        const float ls = sr[m][r];
+                        const float sg = __builtin_amdgcn_exp2f((a.inverse ? -ls : ls) * 1.44269504088896341f);     /* |ls| <= exp(log_alpha): 1 ulp */
+                        float t = a.inverse ? sg * (v[u] - mm) : sg * v[u] + mm;
+                        if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
+                        o[u] = t;
+                    }
+                    if (full) {
+                        *reinterpret_cast<float4*>(orow + dim0) = make_float4(o[0], o[1], o[2], o[3]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (dim0 + u < d) orow[dim0 + u] = o[u];
+                    }
+                }
+            if (hh == 0) {
+                const float dl = a.inverse ? -total : total;
+                if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
+            }
+        }
+    }
+}
+
+/* 16-byte blocks of one packed layer: S k-steps x NT tiles x {hi, lo} + NT bias blocks (bias: hidden / output layers only) */
+inline int res_blocks16(int S, int NT, bool bias) { return (S * NT * 2 + (bias ? NT : 0)) * 64; }
+
 }  // namespace
 
 extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
@@ -207,8 +524,39 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
     const size_t shmem = sizeof(float) * (size_t)AW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + AW - 1) / AW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_coupling_affine_dense_h2: batch too large for one launch");
+    a.cvec4 = (ldc % 4 == 0) && ((uintptr_t)cond % 16 == 0);
     const int OT = (d + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    if (hidden == 64 && bgk_affine_variant == 2) {
+        /* weight-resident kernel: operands of both networks in LDS */
+        const int n0 = res_blocks16(a.S0, RES_HT, false), n1 = res_blocks16(2 * RES_HT, RES_HT, true), n2 = res_blocks16(2 * RES_HT, OT, true);
+        ResOff os{0, 0, 0}, ot{0, 0, 0};
+        int top = 0;
+        if (has_shift) { os = ResOff{top, top + n0, top + n0 + n1}; top += n0 + n1 + n2; }
+        if (has_scale) { ot = ResOff{top, top + n0, top + n0 + n1}; top += n0 + n1 + n2; }
+        const size_t res_shmem = (size_t)top * 16;
+        if (res_shmem <= 150 * 1024) {
+            static const int RW = getenv("BGK_AFF_RW") ? atoi(getenv("BGK_AFF_RW")) : 12;
+            const int64_t n_tiles = (B + 31) / 32;
+            const int per_cu = (int)((160 * 1024) / res_shmem) > 2 ? 2 : (int)((160 * 1024) / res_shmem);
+            int64_t grid = (n_tiles + RW - 1) / RW;
+            if (grid > 256 * (per_cu < 1 ? 1 : per_cu)) grid = 256 * (per_cu < 1 ? 1 : per_cu);
+            const int c_s = has_shift, c_t = has_scale;
+#define BGK_LAUNCH_R(O, W) hipLaunchKernelGGL((coupling_affine_resident_kernel<O, W>), dim3((int)grid), dim3(W * 64), res_shmem, st, a, os, ot, \
+                                              c_s * n0, c_s * n1, c_s * n2, c_t * n0, c_t * n1, c_t * n2)
+#define BGK_ATTR_R(O, W) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coupling_affine_resident_kernel<O, W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+            static bool attr_done = false;
+            if (!attr_done) {
+                BGK_ATTR_R(1, 8); BGK_ATTR_R(2, 8); BGK_ATTR_R(3, 8); BGK_ATTR_R(1, 12); BGK_ATTR_R(2, 12); BGK_ATTR_R(3, 12);
+                attr_done = true;
+            }
+            if (RW == 8) { if (OT == 1) BGK_LAUNCH_R(1, 8); else if (OT == 2) BGK_LAUNCH_R(2, 8); else BGK_LAUNCH_R(3, 8); }
+            else { if (OT == 1) BGK_LAUNCH_R(1, 12); else if (OT == 2) BGK_LAUNCH_R(2, 12); else BGK_LAUNCH_R(3, 12); }
+#undef BGK_ATTR_R
+#undef BGK_LAUNCH_R
+            return bgk_launch_status("bgk_coupling_affine_dense_h2");
+        }
+    }
 #define BGK_LAUNCH(H, O) hipLaunchKernelGGL((coupling_affine_dense_kernel<H, O>), dim3((int)n_wg), dim3(AW * 64), shmem, st, a)
     if (hidden == 64) { if (OT == 1) BGK_LAUNCH(2, 1); else if (OT == 2) BGK_LAUNCH(2, 2); else BGK_LAUNCH(2, 3); }
     else { if (OT == 1) BGK_LAUNCH(4, 1); else if (OT == 2) BGK_LAUNCH(4, 2); else BGK_LAUNCH(4, 3); }

@@ -340,9 +340,11 @@ def _affine_plan(transformer, y_dim):
     return cache
 
 
-def fused_affine_coupling(transformer, x, y, inverse):
+def fused_affine_coupling(transformer, x, y, inverse, out=None, dlogp=None, accumulate=False):
     """Try the one-launch affine coupling layer (bgk_coupling_affine_dense_h2).  Returns (y', dlogp) or None when
-    the conditioners are not fusable DenseNets (the caller then runs the nets + bgk_affine_transform)."""
+    the conditioners are not fusable DenseNets (the caller then runs the nets + bgk_affine_transform).
+    ``out`` ([B, d] rows, any row stride; may alias ``y``: every element is read and written by the same lane) and
+    ``dlogp`` ([B] contiguous, ``accumulate``: added to instead of overwritten) let a caller chain layers without copies."""
     if _gemm_mode(transformer) == "f32":
         return None            # there is no exact-f32 fused affine kernel: "f32" selects the generic path ("bf16": split-f16)
     if x.dim() != 2 or y.dim() != 2 or not x.is_cuda or x.dtype != torch.float32:
@@ -354,8 +356,12 @@ def fused_affine_coupling(transformer, x, y, inverse):
     x2, ldc = _lib.rowmajor(x)
     y2, ldy = _lib.rowmajor(y)
     B, d = y2.shape
-    out = torch.empty((B, d), dtype=torch.float32, device=y.device)
-    dlogp = torch.empty((B,), dtype=torch.float32, device=y.device)
+    if out is None:
+        out = torch.empty((B, d), dtype=torch.float32, device=y.device)
+    if dlogp is None:
+        dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=y.device), False
+    ldo = out.stride(0)
+    assert out.shape == (B, d) and out.stride(1) == 1 and dlogp.shape == (B,) and dlogp.is_contiguous()
     args = []
     for entry in plan["packed"]:
         if entry is None:
@@ -370,7 +376,7 @@ def fused_affine_coupling(transformer, x, y, inverse):
         st = _lib.lib().bgk_coupling_affine_dense_h2(
             _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), *args, plan["hidden"], _lib.ptr(log_alpha),
             int(transformer._preserve_volume), int(transformer._is_circular), int(inverse),
-            _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.stream_ptr(y.device))
+            _lib.ptr(y2), ldy, B, d, _lib.ptr(out), ldo, _lib.ptr(dlogp), int(bool(accumulate)), _lib.stream_ptr(y.device))
     if st == -2:
         return None
     _lib.check(st, "bgk_coupling_affine_dense_h2")

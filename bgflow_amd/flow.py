@@ -46,6 +46,7 @@ class SequentialFlow(Flow):
         self._blocks = torch.nn.ModuleList(blocks)
 
     FUSE_GENERATION_TAIL = True   # icdf domain maps + IC -> xyz as one kernel in the sampling direction (bgk_icdf_ic2xyz)
+    FUSE_COUPLING_STACKS = True   # Split -> (affine Coupling | Swap)* -> Merge on ONE [B, D] buffer: no cat / per-layer outputs
 
     def forward(self, *xs, inverse=False, **kwargs):
         # same accumulation as the reference (sequential.py:49,58): start from the python float 0.0,
@@ -62,12 +63,26 @@ class SequentialFlow(Flow):
         (generator_builder.py:443-459 + add_map_to_cartesian) runs as ONE fused kernel when the inputs need no gradients."""
         blocks = list(self._blocks)
         if inverse:
-            return [(type(b).__name__, b) for b in reversed(blocks)]
+            return self._with_coupling_stacks(list(reversed(blocks)), True)
         tail = self._generation_tail() if self.FUSE_GENERATION_TAIL else None
         if tail is None:
-            return [(type(b).__name__, b) for b in blocks]
+            return self._with_coupling_stacks(blocks, False)
         start = tail[0]
-        return [(type(b).__name__, b) for b in blocks[:start]] + [("icdf+ic2xyz", _FusedGenerationTail(self, tail))]
+        return self._with_coupling_stacks(blocks[:start], False) + [("icdf+ic2xyz", _FusedGenerationTail(self, tail))]
+
+    def _with_coupling_stacks(self, blocks, inverse):
+        """[(label, callable)] for ``blocks`` (already in execution order) with every run
+        ``split -> (CouplingFlow(AffineTransformer) | SwapFlow)* -> merge`` replaced by one _FusedCouplingStack"""
+        out, i = [], 0
+        while i < len(blocks):
+            j = _coupling_stack_end(blocks, i, inverse) if self.FUSE_COUPLING_STACKS else None
+            if j is None:
+                out.append((type(blocks[i]).__name__, blocks[i]))
+                i += 1
+            else:
+                out.append(("coupling stack", _FusedCouplingStack(blocks[i:j + 1])))
+                i = j + 1
+        return out
 
     def _generation_tail(self):
         """(first block index, {slot: CDFTransform}, ic) if the flow ends with [domain maps..., IC -> xyz], else None"""
@@ -125,6 +140,111 @@ class SequentialFlow(Flow):
             return self._blocks[index]
         picked = np.arange(len(self))[index]
         return SequentialFlow([self._blocks[i] for i in picked])
+
+
+def _split_sizes(block, inverse, merging):
+    """sizes of a SplitFlow(s0[, s1]) / MergeFlow(s0[, s1]) along the last axis that acts as a split (merging=False) or a
+    merge (True) in the given direction, else None"""
+    split = block if type(block) is SplitFlow else (block._delegate if type(block) is MergeFlow else None)
+    if split is None or split._indices is not None or split._split_dim != -1 or len(split._sizes) not in (1, 2):
+        return None
+    acts_as_merge = (type(block) is MergeFlow) != bool(inverse)
+    return tuple(split._sizes) if acts_as_merge == merging else None
+
+
+def _coupling_stack_end(blocks, i, inverse):
+    """index of the merge closing a run split -> (affine coupling | swap)* -> merge that starts at blocks[i], else None"""
+    from .transformer import AffineTransformer
+    sizes = _split_sizes(blocks[i], inverse, merging=False)
+    if sizes is None:
+        return None
+    n_couplings, swapped = 0, False
+    for j in range(i + 1, len(blocks)):
+        b = blocks[j]
+        if type(b) is SwapFlow:
+            swapped = not swapped
+            continue
+        if type(b) is CouplingFlow and type(b.transformer) is AffineTransformer and tuple(b.transformed_indices) == (1,) \
+                and tuple(b.cond_indices) == (0,) and b.cat_dim == -1:
+            n_couplings += 1
+            continue
+        closing = _split_sizes(b, inverse, merging=True)
+        if closing is None or n_couplings < 2:
+            return None
+        if swapped:                  # the merge sees (part 1, part 0): its first size is the width of part 1 (checked again at run time)
+            return j if (len(sizes) < 2 or closing[0] == sizes[1]) else None
+        return j if closing[0] == sizes[0] else None
+    return None
+
+
+class _FusedCouplingStack:
+    """callable standing in for ``split -> (CouplingFlow(AffineTransformer) | SwapFlow)* -> merge``: the two parts live as column
+    ranges of ONE [B, D] workspace, every coupling layer (bgk_coupling_affine_dense_h2) writes its half there -- in place once the
+    half has been produced -- and adds its log-det to one accumulator, so that neither the per-layer output tensors, nor the
+    dlogp additions, nor the closing concatenation exist.  Falls back to the blocks themselves when gradients are needed, the input
+    is not a contiguous f32 HIP matrix, or a layer's conditioners are outside the fused envelope."""
+
+    def __init__(self, blocks):
+        self._blocks = blocks
+
+    def _blocks_path(self, *xs, inverse=False, **kwargs):
+        total = 0.0
+        for block in self._blocks:
+            *xs, dd = block(*xs, inverse=inverse, **kwargs)
+            total = total + dd
+        return (*xs, total)
+
+    def __call__(self, *xs, inverse=False, **kwargs):
+        from .dense import fused_affine_coupling, _affine_plan, _gemm_mode
+        x = xs[0] if len(xs) == 1 else None
+        ok = (x is not None and not kwargs and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+              and x.is_contiguous() and x.shape[0] > 0)
+        couplings = [b for b in self._blocks if type(b) is CouplingFlow]
+        if ok and torch.is_grad_enabled():
+            ok = not (x.requires_grad or any(p.requires_grad for b in couplings for p in b.parameters()))
+        if ok:
+            split = self._blocks[0] if type(self._blocks[0]) is SplitFlow else self._blocks[0]._delegate
+            s0, D = split._sizes[0], x.shape[1]
+            ok = 0 < s0 < D and (len(split._sizes) == 1 or split._sizes[1] == D - s0)
+        if ok:
+            widths = (s0, D - s0)
+            part = [0, 1]                                   # tuple slot -> column range
+            for b in self._blocks[1:-1]:                    # dry run: every layer must be inside the fused envelope
+                if type(b) is SwapFlow:
+                    part.reverse()
+                    continue
+                tr = b.transformer
+                if not getattr(tr, "allow_fused", False) or _gemm_mode(tr) == "f32" or _affine_plan(tr, widths[part[1]]) is None \
+                        or tr._fused_cache.get("d_c") != widths[part[0]]:
+                    ok = False
+                    break
+            if ok:                                          # the closing merge must describe the parts as they arrive
+                closing = self._blocks[-1] if type(self._blocks[-1]) is SplitFlow else self._blocks[-1]._delegate
+                ok = closing._sizes[0] == widths[part[0]] and (len(closing._sizes) == 1 or closing._sizes[1] == widths[part[1]])
+        if not ok:
+            return self._blocks_path(*xs, inverse=inverse, **kwargs)
+        B = x.shape[0]
+        work = torch.empty_like(x)
+        dlogp = torch.empty(B, dtype=torch.float32, device=x.device)
+        cols = (slice(0, s0), slice(s0, D))
+        where = [x, x]                                      # buffer currently holding each column range
+        part, first = [0, 1], True
+        for b in self._blocks[1:-1]:
+            if type(b) is SwapFlow:
+                part.reverse()
+                continue
+            pc, py = part
+            res = fused_affine_coupling(b.transformer, where[pc][:, cols[pc]], where[py][:, cols[py]], inverse,
+                                        out=work[:, cols[py]], dlogp=dlogp, accumulate=not first)
+            if res is None:                                 # cannot happen after the dry run; keep the semantics anyway
+                return self._blocks_path(*xs, inverse=inverse, **kwargs)
+            where[py], first = work, False
+        for p in (0, 1):
+            if where[p] is x:                               # a half no layer transformed
+                work[:, cols[p]].copy_(x[:, cols[p]])
+        if part != [0, 1]:                                  # odd number of swaps: the merge concatenates (part 1, part 0)
+            work = torch.cat([work[:, cols[1]], work[:, cols[0]]], dim=-1)
+        return work, dlogp[:, None]
 
 
 class _FusedGenerationTail:

@@ -1237,3 +1237,74 @@ def test_fused_generation_tail_equals_blocks(hip_lib, golden, dev):
         ur = [v[:64].clone().requires_grad_(True) for v in u]
         *xg, dlg = gen.flow(*ur)
         assert xg[0].grad_fn is not None
+
+
+def _affine_stack(dev, s0, D, n_layers, hidden=(64, 64), swap_every=True, extra_tail=False):
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    widths = [s0, D - s0]
+    layers, part = [bg.SplitFlow(s0)], [0, 1]
+    for _ in range(n_layers):
+        d_c, d = widths[part[0]], widths[part[1]]
+        layers.append(bg.CouplingFlow(bg.AffineTransformer(
+            shift_transformation=bg.DenseNet([d_c, *hidden, d], activation=torch.nn.ReLU()),
+            scale_transformation=bg.DenseNet([d_c, *hidden, d], activation=torch.nn.Tanh()))))
+        if swap_every:
+            layers.append(bg.SwapFlow())
+            part.reverse()
+    if part == [0, 1]:
+        layers.append(bg.MergeFlow(s0))
+    else:
+        layers.append(bg.MergeFlow(widths[1]))         # odd number of swaps: the merge sees (part 1, part 0)
+    if extra_tail:
+        layers.append(bg.SplitFlow(D // 2)); layers.append(bg.MergeFlow(D // 2))
+    return hash_init_(bg.SequentialFlow(layers)).to(dev)
+
+
+@pytest.mark.parametrize("s0,D,n_layers,B", [(32, 64, 8, 4099), (24, 64, 5, 1000), (32, 64, 2, 31), (40, 72, 3, 257)])
+def test_fused_coupling_stack_equals_blocks(hip_lib, dev, s0, D, n_layers, B):
+    """Split -> (affine coupling, swap)* -> Merge on one [B, D] buffer (in-place layers, in-kernel dlogp accumulation, no cat)
+    against the same blocks run one by one: bit-identical in both directions (same kernels, same summation order)"""
+    import bgflow_amd as bg
+    flow = _affine_stack(dev, s0, D, n_layers)
+    assert [lbl for lbl, _ in flow.segments()] == ["coupling stack"] and [lbl for lbl, _ in flow.segments(inverse=True)] == ["coupling stack"]
+    g = torch.Generator(device=dev).manual_seed(3)
+    z = torch.randn(B, D, device=dev, generator=g)
+    z_keep = z.clone()
+    with torch.no_grad():
+        x1, d1 = flow(z)
+        zi1, di1 = flow(x1, inverse=True)
+        bg.SequentialFlow.FUSE_COUPLING_STACKS = False
+        try:
+            assert "coupling stack" not in [lbl for lbl, _ in flow.segments()]
+            x0, d0 = flow(z)
+            zi0, di0 = flow(x1, inverse=True)
+        finally:
+            bg.SequentialFlow.FUSE_COUPLING_STACKS = True
+    assert torch.equal(z, z_keep)                       # the input is never written
+    assert torch.equal(x1, x0) and torch.equal(d1, d0) and d1.shape == (B, 1)
+    assert torch.equal(zi1, zi0) and torch.equal(di1, di0)
+    assert float((zi1 - z).abs().max()) < 1e-3 * max(1.0, float(z.abs().max()))
+    # gradients requested: the stack must step aside (autograd needs the per-layer tensors)
+    zg = z[:64].clone().requires_grad_(True)
+    xg, dg = flow(zg)
+    (xg.sum() + dg.sum()).backward()
+    assert zg.grad is not None and torch.isfinite(zg.grad).all()
+
+
+def test_fused_coupling_stack_no_swap_and_neighbours(hip_lib, dev):
+    """a half no layer transforms is copied through; blocks after the stack still run"""
+    import bgflow_amd as bg
+    flow = _affine_stack(dev, 32, 64, 3, swap_every=False, extra_tail=True)
+    labels = [lbl for lbl, _ in flow.segments()]
+    assert labels[0] == "coupling stack" and len(labels) == 3
+    z = torch.randn(777, 64, device=dev)
+    with torch.no_grad():
+        x1, d1 = flow(z)
+        bg.SequentialFlow.FUSE_COUPLING_STACKS = False
+        try:
+            x0, d0 = flow(z)
+        finally:
+            bg.SequentialFlow.FUSE_COUPLING_STACKS = True
+    assert torch.equal(x1, x0) and torch.equal(d1, d0)
+    assert torch.equal(x1[:, :32], z[:, :32])

@@ -552,3 +552,31 @@ def test_uniform_energy_is_finite_and_product_temperature_like_reference():
     tr._fused_cache["x"] = 1
     tr.invalidate_fused_cache()
     assert tr._fused_cache == {}
+
+
+def test_coupling_stack_detection_is_conservative():
+    """SequentialFlow.segments(): only Split(sizes) -> (affine Coupling(1 | 0) | Swap)* -> Merge(same sizes) runs become a stack"""
+    from bgflow_amd.flow import _coupling_stack_end
+
+    def aff(d_c, d):
+        return bg.CouplingFlow(bg.AffineTransformer(shift_transformation=bg.DenseNet([d_c, 64, 64, d])))
+
+    ok = [bg.SplitFlow(4), aff(4, 4), bg.SwapFlow(), aff(4, 4), bg.SwapFlow(), bg.MergeFlow(4)]
+    assert _coupling_stack_end(ok, 0, False) == 5
+    assert _coupling_stack_end(list(reversed(ok)), 0, True) == 5          # inverse direction: the merge acts as the split
+    assert _coupling_stack_end(list(reversed(ok)), 0, False) is None
+    assert [lbl for lbl, _ in bg.SequentialFlow(ok).segments()] == ["coupling stack"]
+    one = [bg.SplitFlow(4), aff(4, 4), bg.MergeFlow(4)]
+    assert _coupling_stack_end(one, 0, False) is None                     # a single layer gains nothing
+    by_index = [bg.SplitFlow([0, 1, 2, 3], [4, 5, 6, 7]), aff(4, 4), aff(4, 4), bg.MergeFlow(4)]
+    assert _coupling_stack_end(by_index, 0, False) is None
+    other_cond = [bg.SplitFlow(4), aff(4, 4), bg.CouplingFlow(bg.AffineTransformer(shift_transformation=bg.DenseNet([4, 64, 64, 4])),
+                                                            transformed_indices=(0,), cond_indices=(1,)), bg.MergeFlow(4)]
+    assert _coupling_stack_end(other_cond, 0, False) is None
+    mismatch = [bg.SplitFlow(4), aff(4, 4), aff(4, 4), bg.MergeFlow(3)]
+    assert _coupling_stack_end(mismatch, 0, False) is None
+    three = [bg.SplitFlow(2, 2, 4), aff(2, 2), aff(2, 2), bg.MergeFlow(2, 2, 4)]
+    assert _coupling_stack_end(three, 0, False) is None
+    flow = bg.SequentialFlow([bg.SwapFlow()] + ok + [bg.SwapFlow()])
+    assert [lbl for lbl, _ in flow.segments()] == ["SwapFlow", "coupling stack", "SwapFlow"]
+    assert [lbl for lbl, _ in flow.segments(inverse=True)] == ["SwapFlow", "coupling stack", "SwapFlow"]
