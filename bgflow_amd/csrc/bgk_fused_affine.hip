@@ -275,34 +275,19 @@ __device__ __forceinline__ void r_split_pair(float a0, float a1, unsigned& hi, u
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
 }
 
-struct NoStream {
-    template <int P, int NP> __device__ __forceinline__ void pair_done() {}
-};
-
-/* value pair P (of 8 HT) of a layer output -> activation -> B-operand halves; after every pair the hook lets a concurrent MFMA
- * stream (MStream below) issue its share of matrix instructions, so that the matrix pipe works under this VALU code */
-template <int ACT, int HT, int P, class HK>
-__device__ __forceinline__ void r_act_split_pairs(RB<HT>& b, const h2_f32x16 (&in)[HT], float c, float k, HK& hk) {
-    if constexpr (P < 8 * HT) {
-        constexpr int m = P >> 3, r = 2 * (P & 7);
-        const float a0 = r_act<ACT>(in[m][r], c, k), a1 = r_act<ACT>(in[m][r + 1], c, k);
-        unsigned hi, lo;
-        r_split_pair(a0, a1, hi, lo);
-        constexpr int s = 2 * m + (r >> 3), e = (r & 7) >> 1;
-        b.hi[s][e] = hi; b.lo[s][e] = lo;
-        hk.template pair_done<P, 8 * HT>();
-        r_act_split_pairs<ACT, HT, P + 1, HK>(b, in, c, k, hk);
-    }
-}
-template <int ACT, int HT, class HK>
-__device__ __forceinline__ void r_act_split_t(RB<HT>& b, const h2_f32x16 (&in)[HT], float c, HK& hk) {
-    const float k = ACT == 3 ? c * 2.88539008177792681f : (ACT == 1 ? c * 1.44269504088896341f : c);
-    r_act_split_pairs<ACT, HT, 0, HK>(b, in, c, k, hk);
-}
 template <int ACT, int HT>
 __device__ __forceinline__ void r_act_split_t(RB<HT>& b, const h2_f32x16 (&in)[HT], float c) {
-    NoStream none;
-    r_act_split_t<ACT, HT, NoStream>(b, in, c, none);
+    const float k = ACT == 3 ? c * 2.88539008177792681f : (ACT == 1 ? c * 1.44269504088896341f : c);
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float a0 = r_act<ACT>(in[m][r], c, k), a1 = r_act<ACT>(in[m][r + 1], c, k);
+            unsigned hi, lo;
+            r_split_pair(a0, a1, hi, lo);
+            const int s = 2 * m + (r >> 3), e = (r & 7) >> 1;
+            b.hi[s][e] = hi; b.lo[s][e] = lo;
+        }
 }
 template <int HT>
 __device__ __forceinline__ void r_act_split(RB<HT>& b, const h2_f32x16 (&in)[HT], float c, int act) {
@@ -348,87 +333,9 @@ __device__ __forceinline__ void res_net_tail(h2_f32x16 (&res)[OT], h2_f32x16 (&h
     BGK_AFF_PRIO(0);
 }
 
-/* A hidden / output layer GEMM (operands resident in LDS) as a stream of NM = 2 HT * 3 NT + NT matrix instructions that a VALU
- * code region issues piecewise through pair_done(): instruction I is (k-step s, product p, tile m) in the order of ra_gemm_hidden;
- * the A fragments of step s + 1 are requested when step s starts.  sched_barrier(0) after every instruction pins the interleaving. */
-template <int NT, int HT>
-struct MStream {
-    h2_f32x16 (&out)[NT];
-    const RB<HT>& b;
-    const r_u32x4* W;
-    int lane;
-    RA<NT> ring[2];
-    static constexpr int S = 2 * HT, PER = 3 * NT, NM = S * PER + NT;
-
-    __device__ __forceinline__ MStream(h2_f32x16 (&o)[NT], const RB<HT>& bb, const r_u32x4* w, int l) : out(o), b(bb), W(w), lane(l) {
-        ra_load<NT>(ring[0], W, 0, lane);
-    }
-    template <int I>
-    __device__ __forceinline__ void step() {
-        if constexpr (I < NM) {
-            if constexpr (I < S * PER) {
-                constexpr int s = I / PER, p = (I % PER) / NT, m = I % NT;
-                if constexpr (I % PER == 0) {
-                    if constexpr (s + 1 < S) ra_load<NT>(ring[(s + 1) & 1], W, s + 1, lane);
-                    else {
-#pragma unroll
-                        for (int q = 0; q < NT; ++q) ring[(s + 1) & 1].v[q][0] = W[(S * NT * 2 + q) * 64 + lane];
-                    }
-                }
-                const h2_f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const h2_h16x8 av = __builtin_bit_cast(h2_h16x8, ring[s & 1].v[m][p == 0 ? 1 : 0]);
-                const h2_h16x8 bv = __builtin_bit_cast(h2_h16x8, p == 1 ? b.lo[s] : b.hi[s]);
-                out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, (s == 0 && p == 0) ? z : out[m], 0, 0, 0);
-            } else {
-                constexpr int m = I - S * PER;
-                const h2_h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
-                out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, ring[S & 1].v[m][0]), one2, out[m], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    template <int I0, int I1>
-    __device__ __forceinline__ void steps() {
-        if constexpr (I0 < I1) { step<I0>(); steps<I0 + 1, I1>(); }
-    }
-    /* hook: after VALU pair P of NP, instructions [P NM / NP, (P + 1) NM / NP) */
-    template <int P, int NP>
-    __device__ __forceinline__ void pair_done() {
-        __builtin_amdgcn_sched_barrier(0);
-        steps<(P * NM) / NP, ((P + 1) * NM) / NP>();
-    }
-    __device__ __forceinline__ void all() { steps<0, NM>(); }
-};
-
-/* both conditioner networks in lockstep (compile-time activations AS / AT): while one network's layer runs on the matrix cores,
- * the other network's previous layer is activated and split on the VALU */
-template <int HT, int OT, int AS, int AT>
-__device__ __forceinline__ void res_nets_lockstep(h2_f32x16 (&mu)[OT], h2_f32x16 (&sr)[OT], h2_f32x16 (&hs)[HT], h2_f32x16 (&ht)[HT],
-                                                  const AffNet& ns, const AffNet& nt, const r_u32x4* s_w, ResOff os, ResOff ot, int lane) {
-    RB<HT> bs, bt;
-    r_act_split_t<AS, HT>(bs, hs, ns.c0);
-    {
-        MStream<HT, HT> st(hs, bs, s_w + os.a1, lane);          /* shift layer 1  ||  scale layer-0 activation */
-        r_act_split_t<AT, HT>(bt, ht, nt.c0, st);
-    }
-    {
-        MStream<HT, HT> st(ht, bt, s_w + ot.a1, lane);          /* scale layer 1  ||  shift layer-1 activation */
-        r_act_split_t<AS, HT>(bs, hs, ns.c1, st);
-    }
-    {
-        MStream<OT, HT> st(mu, bs, s_w + os.a2, lane);          /* shift layer 2  ||  scale layer-1 activation */
-        r_act_split_t<AT, HT>(bt, ht, nt.c1, st);
-    }
-    MStream<OT, HT> st(sr, bt, s_w + ot.a2, lane);
-    st.all();
-}
-
 constexpr int RES_HT = 2;
 
-/* PF: the conditioner input is at most two full 16-feature k-steps of aligned rows (d_c = 16 | 32, not periodic): the NEXT tile's
- * input and this tile's y rows are requested while the current tile computes (register double buffer), so that the wave never
- * waits for HBM between tiles. */
-template <int OT, int RW, bool PF, int AS, int AT>
+template <int OT, int RW>
 __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_kernel(FusedAffArgs a, ResOff os, ResOff ot, int n16_s0, int n16_s1, int n16_s2,
                                                                               int n16_t0, int n16_t1, int n16_t2) {
     constexpr int HT = RES_HT;
@@ -450,21 +357,11 @@ __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_kernel(Fu
     const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile_first = (int64_t)blockIdx.x * RW + wave, tile_step = (int64_t)gridDim.x * RW;
-    float4 cq[4];                                                /* PF: conditioner input of the tile about to run */
-    const int pf_steps = d_c >> 4;
-    if (PF && tile_first < n_tiles) {
-        const int64_t r0 = tile_first * 32 + j;
-        const float* cr = a.cond + (r0 < a.B ? r0 : a.B - 1) * a.ldc + 8 * hh;
-        cq[0] = *reinterpret_cast<const float4*>(cr); cq[1] = *reinterpret_cast<const float4*>(cr + 4);
-        if (pf_steps > 1) { cq[2] = *reinterpret_cast<const float4*>(cr + 16); cq[3] = *reinterpret_cast<const float4*>(cr + 20); }
-    }
     for (int64_t tile = tile_first; tile < n_tiles; tile += tile_step) {
         const int64_t b0 = tile * 32;
         const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
         const int jr = j < rows ? j : rows - 1;                 /* rows past the batch end compute on a valid row, nothing is stored */
         const float* crow = a.cond + (b0 + jr) * a.ldc;
-        float4 cc[4];
-        if (PF) { cc[0] = cq[0]; cc[1] = cq[1]; cc[2] = cq[2]; cc[3] = cq[3]; }
 
         h2_f32x16 hs[HT], ht[HT];
         for (int s = 0; s < a.S0; ++s) {
@@ -477,10 +374,7 @@ __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_kernel(Fu
                 blo = h2_h16x8{0, 0, 0, 0, 0, 0, 0, 0};
             } else {
                 float v[8];
-                if (PF) {
-                    const float4 t0 = s == 0 ? cc[0] : cc[2], t1 = s == 0 ? cc[1] : cc[3];
-                    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
-                } else if (!a.periodic && a.cvec4 && 16 * s + 16 <= d_c) {
+                if (!a.periodic && a.cvec4 && 16 * s + 16 <= d_c) {
 #if (BGK_AFF_ABL & 1)
                     const float fl = (float)lane * 0.01f;
                     const float4 t0 = make_float4(fl, fl + 1.f, fl - 1.f, fl), t1 = make_float4(-fl, fl + .5f, fl - .5f, fl);
@@ -527,42 +421,20 @@ __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_kernel(Fu
                 else ra_mfma3<HT, false, false>(ht, fr, bhi, blo);
             }
         }
-        float4 yq[OT][4];
-        if (PF) {
-            const int64_t rn = (tile + tile_step) * 32 + j;
-            if (tile + tile_step < n_tiles) {
-                const float* cr = a.cond + (rn < a.B ? rn : a.B - 1) * a.ldc + 8 * hh;
-                cq[0] = *reinterpret_cast<const float4*>(cr); cq[1] = *reinterpret_cast<const float4*>(cr + 4);
-                if (pf_steps > 1) { cq[2] = *reinterpret_cast<const float4*>(cr + 16); cq[3] = *reinterpret_cast<const float4*>(cr + 20); }
-            }
-            const float* yr = a.y + (b0 + jr) * a.ldy;
+        h2_f32x16 mu[OT], sr[OT];
+        if (a.has_shift) res_net_tail<HT, OT>(mu, hs, a.shift, s_w, os, lane);
+        else {
 #pragma unroll
             for (int m = 0; m < OT; ++m)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int dim0 = h2_row(m, 4 * q, hh);
-                    yq[m][q] = dim0 + 4 <= d ? *reinterpret_cast<const float4*>(yr + dim0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            __builtin_amdgcn_sched_barrier(0);          /* keep the requests ahead of the two conditioner networks */
+                for (int r = 0; r < 16; ++r) mu[m][r] = 0.0f;
         }
-        h2_f32x16 mu[OT], sr[OT];
-        if constexpr (AS >= 0) {            /* both networks present, activations known at compile time */
-            res_nets_lockstep<HT, OT, AS, AT>(mu, sr, hs, ht, a.shift, a.scale, s_w, os, ot, lane);
-        } else {
-            if (a.has_shift) res_net_tail<HT, OT>(mu, hs, a.shift, s_w, os, lane);
-            else {
+        if (a.has_scale) res_net_tail<HT, OT>(sr, ht, a.scale, s_w, ot, lane);
+        else {
 #pragma unroll
-                for (int m = 0; m < OT; ++m)
+            for (int m = 0; m < OT; ++m)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mu[m][r] = 0.0f;
-            }
-            if (a.has_scale) res_net_tail<HT, OT>(sr, ht, a.scale, s_w, ot, lane);
-            else {
-#pragma unroll
-                for (int m = 0; m < OT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sr[m][r] = 0.0f;
-            }
+                for (int r = 0; r < 16; ++r) sr[m][r] = 0.0f;
         }
 
         float lsum = 0.0f;
@@ -602,9 +474,7 @@ __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_kernel(Fu
                     if (dim0 >= d) continue;
                     const bool full = a.vec4 && dim0 + 4 <= d;
                     float v[4];
-                    if (PF && full) {
-                        v[0] = yq[m][q].x; v[1] = yq[m][q].y; v[2] = yq[m][q].z; v[3] = yq[m][q].w;
-                    } else if (full) {
+                    if (full) {
 #if (BGK_AFF_ABL & 1)
                         const float4 t4 = make_float4((float)lane, 1.f, 2.f, 3.f);
 #else
@@ -697,33 +567,18 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
         if (has_scale) { ot = ResOff{top, top + n0, top + n0 + n1}; top += n0 + n1 + n2; }
         const size_t res_shmem = (size_t)top * 16;
         if (res_shmem <= 150 * 1024) {
-            static const int RW = getenv("BGK_AFF_RW") ? atoi(getenv("BGK_AFF_RW")) : 12;
+            const int RW = OT == 1 ? 12 : 8;        /* waves per workgroup: 3 per SIMD where the kernel fits 168 VGPRs, else 2 */
             const int64_t n_tiles = (B + 31) / 32;
             const int per_cu = (int)((160 * 1024) / res_shmem) > 2 ? 2 : (int)((160 * 1024) / res_shmem);
             int64_t grid = (n_tiles + RW - 1) / RW;
             if (grid > 256 * (per_cu < 1 ? 1 : per_cu)) grid = 256 * (per_cu < 1 ? 1 : per_cu);
             const int c_s = has_shift, c_t = has_scale;
-            /* PF path: <= 2 full k-steps of aligned, non-periodic conditioner rows and 16-byte aligned y / out rows of whole float4 groups */
-            const bool pf = !periodic && a.cvec4 && a.vec4 && (d_c == 16 || d_c == 32) && d % 4 == 0 && !getenv("BGK_AFF_NOPF");
-            /* lockstep variants: both networks, activation pairs (shift, scale) in {(ReLU, Tanh), (SiLU, SiLU), (ReLU, ReLU), (Tanh, Tanh)} */
-            int combo = -1;
-            if (has_shift && has_scale && !getenv("BGK_AFF_NOLOCK")) {
-                if (s_act == 2 && t_act == 3) combo = 0; else if (s_act == 1 && t_act == 1) combo = 1;
-                else if (s_act == 2 && t_act == 2) combo = 2; else if (s_act == 3 && t_act == 3) combo = 3;
-            }
-#define BGK_K(O, W, P, AS, AT) coupling_affine_resident_kernel<O, W, P, AS, AT>
 #define BGK_LAUNCH_K(K) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                              hipLaunchKernelGGL(K, dim3((int)grid), dim3(RW * 64), res_shmem, st, a, os, ot, c_s * n0, c_s * n1, c_s * n2, c_t * n0, c_t * n1, c_t * n2); } while (0)
-#define BGK_LAUNCH_C(O, W, P) do { switch (combo) { case 0: BGK_LAUNCH_K((BGK_K(O, W, P, 2, 3))); break; case 1: BGK_LAUNCH_K((BGK_K(O, W, P, 1, 1))); break; \
-                                   case 2: BGK_LAUNCH_K((BGK_K(O, W, P, 2, 2))); break; case 3: BGK_LAUNCH_K((BGK_K(O, W, P, 3, 3))); break; \
-                                   default: BGK_LAUNCH_K((BGK_K(O, W, P, -1, -1))); } } while (0)
-#define BGK_LAUNCH_RW(O, W) do { if (pf) BGK_LAUNCH_C(O, W, true); else BGK_LAUNCH_C(O, W, false); } while (0)
-            if (RW == 8) { if (OT == 1) BGK_LAUNCH_RW(1, 8); else if (OT == 2) BGK_LAUNCH_RW(2, 8); else BGK_LAUNCH_RW(3, 8); }
-            else { if (OT == 1) BGK_LAUNCH_RW(1, 12); else if (OT == 2) BGK_LAUNCH_RW(2, 12); else BGK_LAUNCH_RW(3, 12); }
-#undef BGK_LAUNCH_RW
-#undef BGK_LAUNCH_C
+            if (OT == 1) BGK_LAUNCH_K((coupling_affine_resident_kernel<1, 12>));
+            else if (OT == 2) BGK_LAUNCH_K((coupling_affine_resident_kernel<2, 8>));
+            else BGK_LAUNCH_K((coupling_affine_resident_kernel<3, 8>));
 #undef BGK_LAUNCH_K
-#undef BGK_K
 #undef BGK_LAUNCH_R
             return bgk_launch_status("bgk_coupling_affine_dense_h2");
         }
