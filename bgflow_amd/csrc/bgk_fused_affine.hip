@@ -21,6 +21,8 @@ struct AffNet {
     const uint4 *A0, *A1, *A2;
     float c0, c1, c2;
     int act;
+    const uint4* A1b;            /* second H x H layer of a three-hidden-layer network, else NULL */
+    float c1b;
 };
 
 struct FusedAffArgs {
@@ -54,6 +56,16 @@ __device__ __forceinline__ void net_eval(h2_f32x16 (&res)[OT], const AffNet& n, 
 #pragma unroll
     for (int m = 0; m < HT; ++m) h2_act_tile(h[m], n.c1, n.act);
     h2_make_b<HT>(bf, h);
+    if (n.A1b) {                 /* three hidden layers (e.g. the ala2 RealNVP conditioners [30, 128, 128, 128, 30]) */
+#pragma unroll
+        for (int m = 0; m < HT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
+        h2_gemm_hidden<HT, HT>(h, bf, n.A1b, lane);
+#pragma unroll
+        for (int m = 0; m < HT; ++m) h2_act_tile(h[m], n.c1b, n.act);
+        h2_make_b<HT>(bf, h);
+    }
 #pragma unroll
     for (int m = 0; m < OT; ++m)
 #pragma unroll
@@ -520,15 +532,15 @@ inline int res_blocks16(int S, int NT, bool bias) { return (S * NT * 2 + (bias ?
 
 }  // namespace
 
-extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
-                                            const void* sA0, const void* sA1, const void* sA2,
-                                            float sc0, float sc1, float sc2, int32_t s_act,
-                                            const void* tA0, const void* tA1, const void* tA2,
-                                            float tc0, float tc1, float tc2, int32_t t_act,
-                                            int32_t hidden, const float* log_alpha, int32_t preserve_volume,
-                                            int32_t is_circular, int32_t inverse,
-                                            const float* y, int64_t ldy, int64_t B, int32_t d,
-                                            float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                               const void* sA0, const void* sA1, const void* sA1b, const void* sA2,
+                               float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
+                               const void* tA0, const void* tA1, const void* tA1b, const void* tA2,
+                               float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
+                               int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                               int32_t is_circular, int32_t inverse,
+                               const float* y, int64_t ldy, int64_t B, int32_t d,
+                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
     BGK_CHECK_ARG(cond && y && out && dlogp, "bgk_coupling_affine_dense_h2: null pointer");
     BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "bgk_coupling_affine_dense_h2: bad sizes");
     const int has_shift = sA0 != nullptr, has_scale = tA0 != nullptr;
@@ -545,8 +557,8 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
     if (B == 0) return 0;
     FusedAffArgs a;
     a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic; a.S0 = (n_in + 1 + 15) / 16;
-    a.shift = AffNet{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA2, sc0, sc1, sc2, s_act};
-    a.scale = AffNet{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA2, tc0, tc1, tc2, t_act};
+    a.shift = AffNet{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA2, sc0, sc1, sc2, s_act, (const uint4*)sA1b, sc1b};
+    a.scale = AffNet{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA2, tc0, tc1, tc2, t_act, (const uint4*)tA1b, tc1b};
     a.has_shift = has_shift; a.has_scale = has_scale;
     a.log_alpha = log_alpha; a.preserve_volume = preserve_volume; a.is_circular = is_circular; a.inverse = inverse;
     a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
@@ -558,7 +570,7 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
     a.cvec4 = (ldc % 4 == 0) && ((uintptr_t)cond % 16 == 0);
     const int OT = (d + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-    if (hidden == 64 && bgk_affine_variant == 2) {
+    if (hidden == 64 && bgk_affine_variant == 2 && !sA1b && !tA1b) {
         /* weight-resident kernel: operands of both networks in LDS */
         const int n0 = res_blocks16(a.S0, RES_HT, false), n1 = res_blocks16(2 * RES_HT, RES_HT, true), n2 = res_blocks16(2 * RES_HT, OT, true);
         ResOff os{0, 0, 0}, ot{0, 0, 0};
@@ -588,4 +600,33 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
     else { if (OT == 1) BGK_LAUNCH(4, 1); else if (OT == 2) BGK_LAUNCH(4, 2); else BGK_LAUNCH(4, 3); }
 #undef BGK_LAUNCH
     return bgk_launch_status("bgk_coupling_affine_dense_h2");
+}
+
+extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                            const void* sA0, const void* sA1, const void* sA2,
+                                            float sc0, float sc1, float sc2, int32_t s_act,
+                                            const void* tA0, const void* tA1, const void* tA2,
+                                            float tc0, float tc1, float tc2, int32_t t_act,
+                                            int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                            int32_t is_circular, int32_t inverse,
+                                            const float* y, int64_t ldy, int64_t B, int32_t d,
+                                            float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    return affine_dense_launch(cond, ldc, d_c, periodic, sA0, sA1, nullptr, sA2, sc0, sc1, 1.0f, sc2, s_act,
+                               tA0, tA1, nullptr, tA2, tc0, tc1, 1.0f, tc2, t_act, hidden, log_alpha, preserve_volume, is_circular, inverse,
+                               y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
+}
+
+extern "C" int bgk_coupling_affine_dense_h3(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                            const void* sA0, const void* sA1, const void* sA1b, const void* sA2,
+                                            float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
+                                            const void* tA0, const void* tA1, const void* tA1b, const void* tA2,
+                                            float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
+                                            int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                            int32_t is_circular, int32_t inverse,
+                                            const float* y, int64_t ldy, int64_t B, int32_t d,
+                                            float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    BGK_CHECK_ARG((sA0 == nullptr || sA1b) && (tA0 == nullptr || tA1b), "bgk_coupling_affine_dense_h3: missing third hidden layer");
+    return affine_dense_launch(cond, ldc, d_c, periodic, sA0, sA1, sA1b, sA2, sc0, sc1, sc1b, sc2, s_act,
+                               tA0, tA1, tA1b, tA2, tc0, tc1, tc1b, tc2, t_act, hidden, log_alpha, preserve_volume, is_circular, inverse,
+                               y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
 }

@@ -153,6 +153,22 @@ def _fusable_dense(net):
     return (l0, l1, l2), _ACT_CODES[type(a0)]
 
 
+def _fusable_dense_deep(net):
+    """(linears, act_code) for Linear-(act-Linear) x 2 | x 3 with one supported activation type (the affine coupling kernels take
+    two or three hidden layers), else None"""
+    if type(net) is not DenseNet:
+        return None
+    mods = list(net._layers)
+    if len(mods) not in (5, 7):
+        return None
+    lins, acts = mods[0::2], mods[1::2]
+    if not all(isinstance(m, torch.nn.Linear) and m.bias is not None for m in lins):
+        return None
+    if any(type(a) is not type(acts[0]) for a in acts) or type(acts[0]) not in _ACT_CODES:
+        return None
+    return tuple(lins), _ACT_CODES[type(acts[0])]
+
+
 # ---- MFMA operand packing for bgk_coupling_rqs_dense ------------------------------------------------
 # One k-step of the f32 MFMA (v_mfma_f32_32x32x2_f32, A = weights) over 4 output tiles consumes, per
 # lane l (i = l & 31, h = l >> 5), the four values W[32*m + i][k(step, h)], m = 0..3: stored as one
@@ -275,8 +291,14 @@ def _pad_rows(W, b, R):
 
 
 def pack_dense_for_affine_h2(linears):
-    """Pack DenseNet([n_in, H, H, d]) (H = 64 | 128, d <= 96) for bgk_coupling_affine_dense_h2.
-    Returns (A0, A1, A2 f16 device tensors, (c0, c1, c2))."""
+    """Pack DenseNet([n_in, H, H, d]) (H = 64 | 128, d <= 96) for bgk_coupling_affine_dense_h2, or DenseNet([n_in, H, H, H, d])
+    for bgk_coupling_affine_dense_h3.  Returns (A0, A1, A2 f16 device tensors, (c0, c1, c2)[, A1b, c1b])."""
+    if len(linears) == 4:
+        l0, l1, l1b, l2 = linears
+        A0, A1, A2, cs = pack_dense_for_affine_h2((l0, l1, l2))
+        W, b = l1b.weight.detach().float(), l1b.bias.detach().float()
+        e = _h2_scale_exp(W, b)
+        return A0, A1, A2, cs, _pack_h2(W * 2.0 ** e, b * 2.0 ** e, _h2_k_hidden(l1b.out_features // 32), NT=l1b.out_features // 32), 2.0 ** -e
     l0, l1, l2 = linears
     W0, b0 = l0.weight.detach().float(), l0.bias.detach().float()
     W1, b1 = l1.weight.detach().float(), l1.bias.detach().float()
@@ -317,16 +339,15 @@ def _affine_plan(transformer, y_dim):
         if periodic is not None and per != periodic:
             return None
         periodic = per
-        spec = _fusable_dense(n)
+        spec = _fusable_dense_deep(n)
         if spec is None:
             return None
         specs.append(spec)
     live = [sp for sp in specs if sp is not None]
-    (l0, l1, l2), _ = live[0]
-    H, n_in = l0.out_features, l0.in_features
-    for (m0, m1, m2), _ in live:
-        if not (m0.out_features == H and m1.in_features == H and m1.out_features == H and m2.in_features == H
-                and m0.in_features == n_in and m2.out_features == y_dim):
+    H, n_in, depth = live[0][0][0].out_features, live[0][0][0].in_features, len(live[0][0])
+    for lins, _ in live:
+        if len(lins) != depth or lins[0].in_features != n_in or lins[-1].out_features != y_dim \
+                or any(m.out_features != H for m in lins[:-1]) or any(m.in_features != H for m in lins[1:]):
             return None
     if H not in (64, 128) or y_dim > 96 or n_in > 127 or (periodic and n_in % 2):
         return None
@@ -335,7 +356,7 @@ def _affine_plan(transformer, y_dim):
     cache = transformer._fused_cache
     if cache.get("version") != version or cache.get("y_dim") != y_dim:
         cache.clear()
-        cache.update(version=version, y_dim=y_dim, hidden=H, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic),
+        cache.update(version=version, y_dim=y_dim, hidden=H, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), depth=depth,
                      packed=[None if sp is None else (pack_dense_for_affine_h2(sp[0]), sp[1]) for sp in specs])
     return cache
 
@@ -363,23 +384,29 @@ def fused_affine_coupling(transformer, x, y, inverse, out=None, dlogp=None, accu
     ldo = out.stride(0)
     assert out.shape == (B, d) and out.stride(1) == 1 and dlogp.shape == (B,) and dlogp.is_contiguous()
     args = []
+    deep = plan["depth"] == 4
     for entry in plan["packed"]:
         if entry is None:
-            args += [None, None, None, 1.0, 1.0, 1.0, 0]
+            args += ([None] * 4 + [1.0] * 4 + [0]) if deep else [None, None, None, 1.0, 1.0, 1.0, 0]
         else:
-            (A0, A1, A2, (c0, c1, c2)), act = entry
-            if A0.device != y.device:
+            packed, act = entry
+            if packed[0].device != y.device:
                 return None
-            args += [_lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2, act]
+            A0, A1, A2, (c0, c1, c2) = packed[:4]
+            if deep:
+                args += [_lib.ptr(A0), _lib.ptr(A1), _lib.ptr(packed[4]), _lib.ptr(A2), c0, c1, packed[5], c2, act]
+            else:
+                args += [_lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2, act]
     log_alpha = transformer._log_alpha.detach().to(device=y.device, dtype=torch.float32)
+    entry_point = _lib.lib().bgk_coupling_affine_dense_h3 if deep else _lib.lib().bgk_coupling_affine_dense_h2
     with torch.cuda.device(y.device):
-        st = _lib.lib().bgk_coupling_affine_dense_h2(
+        st = entry_point(
             _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), *args, plan["hidden"], _lib.ptr(log_alpha),
             int(transformer._preserve_volume), int(transformer._is_circular), int(inverse),
             _lib.ptr(y2), ldy, B, d, _lib.ptr(out), ldo, _lib.ptr(dlogp), int(bool(accumulate)), _lib.stream_ptr(y.device))
     if st == -2:
         return None
-    _lib.check(st, "bgk_coupling_affine_dense_h2")
+    _lib.check(st, "bgk_coupling_affine_dense_h3" if deep else "bgk_coupling_affine_dense_h2")
     return out, dlogp[:, None]
 
 

@@ -289,6 +289,20 @@ int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int32_t d_c, in
                                  const float* y, int64_t ldy, int64_t B, int32_t d,
                                  float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
 
+/* Same layer with THREE hidden layers per conditioner (DenseNet [n_in, H, H, H, d], e.g. the ala2 RealNVP conditioners
+ * [30, 128, 128, 128, 30] of the reference's examples; conditioner_factory.py:76-80 lets users choose the depth):
+ * s/tA1b, s/tc1b = operands / unscale factor of the second H x H layer (packed like A1). */
+int bgk_coupling_affine_dense_h3(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                 const void* sA0, const void* sA1, const void* sA1b, const void* sA2,
+                                 float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
+                                 const void* tA0, const void* tA1, const void* tA1b, const void* tA2,
+                                 float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
+                                 int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                 int32_t is_circular, int32_t inverse,
+                                 const float* y, int64_t ldy, int64_t B, int32_t d,
+                                 float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
+
+
 /* Device-side packing of a DenseNet [n_in, H, H, rows2] into split-f16 MFMA operands (no host synchronisation; used
  * whenever the weights change, i.e. every training step).  Layer 2's packed rows are row_map2_dev[packed row] (source
  * row or -1; NULL = identity), laid out as n_groups2 groups of NT2 32-row tiles, each group followed by its bias

@@ -788,6 +788,12 @@ def _affine_layer(kind, dev=None):
         tr = bg.AffineTransformer(bg.WrapPeriodic(bg.DenseNet([34, 128, 128, 66], torch.nn.SiLU())),
                                   bg.WrapPeriodic(bg.DenseNet([34, 128, 128, 66], torch.nn.SiLU())))
         dims = (17, 66)
+    elif kind == "deep128":     # ala2 RealNVP conditioners with three hidden layers [30, 128, 128, 128, 30]
+        tr = bg.AffineTransformer(bg.DenseNet([30, 128, 128, 128, 30], torch.nn.ReLU()), bg.DenseNet([30, 128, 128, 128, 30], torch.nn.Tanh()))
+        dims = (30, 30)
+    elif kind == "deep64":      # three hidden layers, H = 64, shift network only
+        tr = bg.AffineTransformer(bg.DenseNet([12, 64, 64, 64, 40], torch.nn.SiLU()), None)
+        dims = (12, 40)
     elif kind == "pv":          # volume preserving
         tr = bg.AffineTransformer(bg.DenseNet([9, 128, 128, 33], torch.nn.Tanh()), bg.DenseNet([9, 128, 128, 33], torch.nn.ReLU()),
                                   preserve_volume=True)
@@ -796,7 +802,7 @@ def _affine_layer(kind, dev=None):
     return (layer.to(dev) if dev is not None else layer), dims
 
 
-@pytest.mark.parametrize("kind", ["cfg2", "aug66", "periodic", "nice_circ", "pv"])
+@pytest.mark.parametrize("kind", ["cfg2", "aug66", "periodic", "nice_circ", "pv", "deep128", "deep64"])
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("B", [1, 31, 4133])
 def test_fused_affine_layer_vs_oracle(hip_lib, dev, kind, inverse, B):
