@@ -11,11 +11,11 @@
  * form used here.
  * Decomposition: workgroup = 128 rows of the output (4 waves x one 32-row tile) x all k <= 128 columns x one slab of batch
  * rows (split-K); per step of 16 batch rows every thread fetches 8 consecutive batch rows of ONE column of g and of h
- * (each wave-level load = 64 consecutive floats of a row: coalesced), splits them into bf16 hi + lo (bf16 keeps the f32
+ * (each wave-level load = 32 | 64 consecutive floats of a row: coalesced), splits them into bf16 hi + lo (bf16 keeps the f32
  * exponent: gradients of 1e-8 stay normal; hi*hi + hi*lo + lo*hi leaves a 2^-16 relative error per product, below the f32
- * accumulation noise of a 2^18-term sum), and stores them as ONE 16-byte LDS value per part -- already the MFMA operand
- * layout (lane = (column, 8-row block)); column stride 48 B keeps the ds_read_b128 conflict-free.  LDS is double-buffered
- * (one barrier per step).  The bias gradient is the running sum of the g values a thread loads anyway.  Partials per slab go
+ * accumulation noise of a 2^18-term sum).  The g values a thread fetches ARE its A fragment (lane = (column, 8-row block)) and stay
+ * in registers; the h parts (shared by the four waves) go to LDS as ONE 16-byte value per part -- already the B operand layout;
+ * column stride 48 B keeps the ds_read_b128 conflict-free.  LDS is double-buffered (one barrier per step).  The bias gradient is the running sum of the g values a thread loads anyway.  Partials per slab go
  * to a workspace and are summed in fixed order by wgrad_reduce_kernel: deterministic, no atomics.
  */
 #include "bgk_common.h"
@@ -39,36 +39,48 @@ struct WgArgs {
     float* part_b;                             /* [2 n_slabs][n] */
 };
 
-__device__ __forceinline__ unsigned short bf16_rne_bits(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+typedef __bf16 wg_bf2 __attribute__((ext_vector_type(2)));
+typedef float wg_f2 __attribute__((ext_vector_type(2)));
 
-/* 8 values -> bf16 hi and lo parts (16 B each) */
+/* 8 values -> bf16 hi and lo parts (16 B each): v_cvt_pk_bf16_f32 (round to nearest even, 2 values per instruction), hi back to
+ * f32 by a shift / mask, lo = bf16(v - hi) -- 2.5 VALU instructions per value (the integer rounding sequence this replaces took
+ * 14 and made the kernel VALU-bound: 900 VALU cycles against 384 matrix-core cycles per 16-row step) */
 __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
-    unsigned short h[8], l[8];
+    unsigned h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h[e] = bf16_rne_bits(v[e]);
-        l[e] = bf16_rne_bits(v[e] - bf16_to_f32(h[e]));
+    for (int e = 0; e < 4; ++e) {
+        const wg_f2 x = {v[2 * e], v[2 * e + 1]};
+        const wg_bf2 hb = __builtin_convertvector(x, wg_bf2);
+        const wg_f2 r = x - __builtin_convertvector(hb, wg_f2);
+        h[e] = __builtin_bit_cast(unsigned, hb);
+        l[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wg_bf2));
     }
-    hi = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
-    lo = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-__global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   /* 2 buffers x {g_hi, g_lo, h_hi, h_lo} */
+/* the (up to) three GEMMs of one coupling layer in ONE launch: blocks [first[q], first[q + 1]) work on GEMM q.  Alone, the two
+ * 128 x 128 GEMMs fill one workgroup per CU and wait on HBM latency; together with the [P x 128] one the chip is full. */
+struct WgGroup { WgArgs g[3]; int first[4]; };
+
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgGroup grp_args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   /* 2 buffers x {h_hi, h_lo} */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = (int)blockIdx.x >= grp_args.first[2] ? 2 : ((int)blockIdx.x >= grp_args.first[1] ? 1 : 0);
+    const WgArgs& a = grp_args.g[q];
+    const int block = (int)blockIdx.x - grp_args.first[q];
     /* block -> (slab, n-block): blocks that share a slab (and re-read the same rows of h) are 8 apart = on the same XCD */
     const int per8 = 8 * a.n_blocks;
-    const int grp = blockIdx.x / per8, rem = blockIdx.x - grp * per8;
+    const int grp = block / per8, rem = block - grp * per8;
     const int slab = grp * 8 + (rem & 7), nb = rem >> 3;
     if (slab >= a.n_slabs) return;
     const int64_t r0 = (int64_t)slab * a.rows_per_slab;
     const int64_t r1 = (r0 + a.rows_per_slab) < a.B ? (r0 + a.rows_per_slab) : a.B;
-    const int c = tid & 127, rg = tid >> 7;                 /* my column and 8-row block */
-    const int gcol = nb * COLS + c;
+    /* g: a thread fetches exactly the A fragment its MFMAs consume (lane = (column i of the wave's 32-column tile, 8-row block
+     * kb)): no LDS round trip for g.  h (shared by the four waves): thread -> (column c, 8-row block rg), through LDS. */
+    const int gi = lane & 31, gkb = lane >> 5;
+    const int gcol = nb * COLS + wave * 32 + gi;
+    const int c = tid & 127, rg = tid >> 7;
     const bool g_ok = gcol < a.n, h_ok = c < a.k;
     const int kh = a.k >> 1;
     const int hc = a.featurise ? (c < kh ? c : c - kh) : c;  /* source column of h */
@@ -79,27 +91,22 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     float bsum = 0.0f;
-    const int my_off = c * CSTRIDE + rg * 16;                /* where my 16-byte values go */
-    const int rd_a = (wave * 32 + (lane & 31)) * CSTRIDE + (lane >> 5) * 16;
-    /* software pipeline: the 16 values of step s + 1 are requested before step s is converted / multiplied, so the HBM latency
-     * overlaps the LDS + matrix-core work (without it every 16-row step paid a full round trip: 144 us per GEMM) */
+    const int my_off = c * CSTRIDE + rg * 16;                /* where my 16-byte h values go */
+    /* software pipeline, two 16-row steps deep: the 16 values of steps s + 1 and s + 2 are in flight while step s is converted /
+     * multiplied (one step of distance left every step waiting on HBM: a step takes ~500 cycles, a loaded round trip > 2000) */
     auto fetch = [&](int64_t r, float (&gv)[8], float (&hv)[8]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int64_t row = r + 8 * rg + e;
-            const bool in = row < r1;
-            gv[e] = (g_ok && in) ? a.g[row * a.ldg + gcol] : 0.0f;
-            hv[e] = (h_ok && in) ? a.h[row * a.ldh + hc] : 0.0f;
+            const int64_t rowg = r + 8 * gkb + e, rowh = r + 8 * rg + e;
+            gv[e] = (g_ok && rowg < r1) ? a.g[rowg * a.ldg + gcol] : 0.0f;
+            hv[e] = (h_ok && rowh < r1) ? a.h[rowh * a.ldh + hc] : 0.0f;
         }
     };
-    float gn[8], hn[8];
-    fetch(r0, gn, hn);
-    int buf = 0;
-    for (int64_t r = r0; r < r1; r += 16, buf ^= 1) {
+    auto step = [&](int64_t r, float (&gq)[8], float (&hq)[8], int buf) {
         float gv[8], hv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gv[e] = gn[e]; hv[e] = hn[e]; }
-        if (r + 16 < r1) fetch(r + 16, gn, hn);
+        for (int e = 0; e < 8; ++e) { gv[e] = gq[e]; hv[e] = hq[e]; }
+        if (r + 32 < r1) fetch(r + 32, gq, hq);
         if (a.featurise && h_ok) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -113,26 +120,30 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgArgs a) {
         uint4 ghi, glo, hhi, hlo;
         split8(gv, ghi, glo);
         split8(hv, hhi, hlo);
-        unsigned char* base = smem + buf * 4 * ARR;
-        *reinterpret_cast<uint4*>(base + 0 * ARR + my_off) = ghi;
-        *reinterpret_cast<uint4*>(base + 1 * ARR + my_off) = glo;
-        *reinterpret_cast<uint4*>(base + 2 * ARR + my_off) = hhi;
-        *reinterpret_cast<uint4*>(base + 3 * ARR + my_off) = hlo;
+        unsigned char* base = smem + buf * 2 * ARR;
+        *reinterpret_cast<uint4*>(base + 0 * ARR + my_off) = hhi;
+        *reinterpret_cast<uint4*>(base + 1 * ARR + my_off) = hlo;
         __syncthreads();
-        const s16x8 ahi = *reinterpret_cast<const s16x8*>(base + 0 * ARR + rd_a);
-        const s16x8 alo = *reinterpret_cast<const s16x8*>(base + 1 * ARR + rd_a);
+        const s16x8 ahi = __builtin_bit_cast(s16x8, ghi), alo = __builtin_bit_cast(s16x8, glo);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (m < KT) {
                 const int rd_b = (m * 32 + (lane & 31)) * CSTRIDE + (lane >> 5) * 16;
-                const s16x8 bhi = *reinterpret_cast<const s16x8*>(base + 2 * ARR + rd_b);
-                const s16x8 blo = *reinterpret_cast<const s16x8*>(base + 3 * ARR + rd_b);
+                const s16x8 bhi = *reinterpret_cast<const s16x8*>(base + 0 * ARR + rd_b);
+                const s16x8 blo = *reinterpret_cast<const s16x8*>(base + 1 * ARR + rd_b);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[m], 0, 0, 0);
                 acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[m], 0, 0, 0);
             }
         }
         /* the other buffer is written next; its readers finished before the barrier above */
+    };
+    float g0[8], h0[8], g1[8], h1[8];
+    fetch(r0, g0, h0);
+    fetch(r0 + 16, g1, h1);
+    for (int64_t r = r0; r < r1; r += 32) {
+        step(r, g0, h0, 0);
+        if (r + 16 < r1) step(r + 16, g1, h1, 1);
     }
     /* partial dW of this slab: accumulator layout -> [n][k] */
     const int j = lane & 31, hh = lane >> 5;
@@ -147,77 +158,99 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgArgs a) {
             }
         }
     }
-    if (g_ok) a.part_b[((int64_t)slab * 2 + rg) * a.n + gcol] = bsum;
+    if (g_ok) a.part_b[((int64_t)slab * 2 + gkb) * a.n + gcol] = bsum;
 }
 
 /* fixed-order sum of the slab partials: 8 lanes per output element each sum every 8th slab (4 accumulators), combined
  * by a fixed shuffle tree -- 8x the parallelism of one thread per element (the partial sets are only a few MB: latency-bound) */
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part_w, const float* part_b, int n_slabs, int n, int k,
-                                                           float* gW, float* gb, int accumulate) {
-    const int64_t nk = (int64_t)n * k;
-    const int64_t total = nk + (gb ? n : 0);
+struct RedOne { const float* part_w; const float* part_b; int n_slabs, n, k; float* gW; float* gb; };
+struct RedGroup { RedOne r[3]; int64_t first[4]; };      /* first[q]: first output element (8 lanes each) of GEMM q */
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(RedGroup rg, int accumulate) {
     const int sub = threadIdx.x & 7;
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int64_t gi = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int q = gi >= rg.first[2] ? 2 : (gi >= rg.first[1] ? 1 : 0);
+    const RedOne& o = rg.r[q];
+    const int64_t i = gi - rg.first[q];
+    const int n = o.n, n_slabs = o.n_slabs;
+    const int64_t nk = (int64_t)n * o.k;
+    const int64_t total = gi < rg.first[3] ? nk + (o.gb ? n : 0) : 0;
     float acc = 0.0f;
-    if (i < nk) {
+    if (i < nk && i < total) {
         float a0 = 0.0f, a1 = 0.0f;
         int s = sub;
-        for (; s + 8 < n_slabs; s += 16) { a0 += part_w[(int64_t)s * nk + i]; a1 += part_w[(int64_t)(s + 8) * nk + i]; }
-        if (s < n_slabs) a0 += part_w[(int64_t)s * nk + i];
+        for (; s + 8 < n_slabs; s += 16) { a0 += o.part_w[(int64_t)s * nk + i]; a1 += o.part_w[(int64_t)(s + 8) * nk + i]; }
+        if (s < n_slabs) a0 += o.part_w[(int64_t)s * nk + i];
         acc = a0 + a1;
     } else if (i < total) {
         const int col = (int)(i - nk);
         float a0 = 0.0f, a1 = 0.0f;
         int s = sub;
-        for (; s + 8 < 2 * n_slabs; s += 16) { a0 += part_b[(int64_t)s * n + col]; a1 += part_b[(int64_t)(s + 8) * n + col]; }
-        if (s < 2 * n_slabs) a0 += part_b[(int64_t)s * n + col];
+        for (; s + 8 < 2 * n_slabs; s += 16) { a0 += o.part_b[(int64_t)s * n + col]; a1 += o.part_b[(int64_t)(s + 8) * n + col]; }
+        if (s < 2 * n_slabs) a0 += o.part_b[(int64_t)s * n + col];
         acc = a0 + a1;
     }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     acc += __shfl_xor(acc, 4);
     if (sub == 0) {
-        if (i < nk) gW[i] = accumulate ? gW[i] + acc : acc;
-        else if (i < total) gb[i - nk] = accumulate ? gb[i - nk] + acc : acc;
+        if (i < nk && i < total) o.gW[i] = accumulate ? o.gW[i] + acc : acc;
+        else if (i < total) o.gb[i - nk] = accumulate ? o.gb[i - nk] + acc : acc;
     }
 }
 
-int one_gemm(const char* what, const float* g, int64_t ldg, int n, const float* h, int64_t ldh, int k, int featurise, int64_t B,
-             float* ws, int64_t ws_floats, float* gW, float* gb, int accumulate, hipStream_t st) {
-    BGK_CHECK_ARG(n > 0 && k > 0 && k <= COLS && (!featurise || (k % 2 == 0)), "%s: n = %d, k = %d not supported (k <= 128)", what, n, k);
-    const int n_blocks = (n + COLS - 1) / COLS;
+int slabs_for(int64_t B, int n) {
     /* ~2 workgroups per CU, slabs of at least 1024 rows, a multiple of 8 slabs (XCD-aware block map) */
+    const int n_blocks = (n + COLS - 1) / COLS;
     int n_slabs = (int)((B + 1023) / 1024);
     const int want = (512 + n_blocks - 1) / n_blocks;
     n_slabs = n_slabs > want ? want : n_slabs;
-    n_slabs = ((n_slabs + 7) / 8) * 8;
-    int64_t rows = (B + n_slabs - 1) / n_slabs;
-    rows = ((rows + 15) / 16) * 16;
-    const int64_t need = (int64_t)n_slabs * n * k + (int64_t)2 * n_slabs * n;
-    BGK_CHECK_ARG(ws_floats >= need, "%s: workspace of %lld floats needed, %lld given", what, (long long)need, (long long)ws_floats);
-    WgArgs a{g, ldg, n, h, ldh, k, featurise, B, rows, n_slabs, n_blocks, ws, ws + (int64_t)n_slabs * n * k};
-    hipLaunchKernelGGL(wgrad_kernel, dim3(n_slabs * n_blocks), dim3(WG_THREADS), 2 * 4 * ARR, st, a);
-    const int64_t total = ((int64_t)n * k + n) * 8;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.part_w, a.part_b, n_slabs, n, k, gW, gb, accumulate);
+    return ((n_slabs + 7) / 8) * 8;
+}
+int64_t ws_need(int64_t B, int n, int k) {
+    const int n_slabs = slabs_for(B, n);
+    return (int64_t)n_slabs * n * k + (int64_t)2 * n_slabs * n;
+}
+
+struct GemmSpec { const char* what; const float* g; int64_t ldg; int n; const float* h; int64_t ldh; int k; int featurise; float* gW; float* gb; };
+
+int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t ws_floats, int accumulate, hipStream_t st) {
+    WgGroup grp;
+    RedGroup red;
+    int blocks = 0;
+    int64_t used = 0, outs = 0;
+    for (int q = 0; q < 3; ++q) {
+        grp.first[q] = blocks;
+        red.first[q] = outs;
+        if (q >= count) { grp.g[q] = WgArgs{}; red.r[q] = RedOne{}; continue; }
+        const GemmSpec& sp = specs[q];
+        BGK_CHECK_ARG(sp.n > 0 && sp.k > 0 && sp.k <= COLS && (!sp.featurise || (sp.k % 2 == 0)), "%s: n = %d, k = %d not supported (k <= 128)",
+                      sp.what, sp.n, sp.k);
+        const int n_blocks = (sp.n + COLS - 1) / COLS, n_slabs = slabs_for(B, sp.n);
+        int64_t rows = (B + n_slabs - 1) / n_slabs;
+        rows = ((rows + 15) / 16) * 16;
+        const int64_t need = ws_need(B, sp.n, sp.k);
+        BGK_CHECK_ARG(ws_floats >= used + need, "%s: workspace of %lld floats needed, %lld given", sp.what, (long long)(used + need), (long long)ws_floats);
+        float* pw = ws + used;
+        float* pb = pw + (int64_t)n_slabs * sp.n * sp.k;
+        grp.g[q] = WgArgs{sp.g, sp.ldg, sp.n, sp.h, sp.ldh, sp.k, sp.featurise, B, rows, n_slabs, n_blocks, pw, pb};
+        red.r[q] = RedOne{pw, pb, n_slabs, sp.n, sp.k, sp.gW, sp.gb};
+        blocks += n_slabs * n_blocks;
+        used += need;
+        outs += (int64_t)sp.n * sp.k + sp.n;
+    }
+    grp.first[3] = blocks;
+    red.first[3] = outs;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(WG_THREADS), 2 * 2 * ARR, st, grp);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs * 8 + 255) / 256)), dim3(256), 0, st, red, accumulate);
     return 0;
 }
 
 }  // namespace
 
 extern "C" int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in) {
-    /* floats: the largest of the three GEMMs' partial sets (they run one after the other on the stream) */
-    int64_t best = 0;
-    const int ns[3] = {P, 128, 128}, ks[3] = {128, 128, n_in};
-    for (int i = 0; i < 3; ++i) {
-        const int n_blocks = (ns[i] + COLS - 1) / COLS;
-        int n_slabs = (int)((B + 1023) / 1024);
-        const int want = (512 + n_blocks - 1) / n_blocks;
-        n_slabs = n_slabs > want ? want : n_slabs;
-        n_slabs = ((n_slabs + 7) / 8) * 8;
-        const int64_t need = (int64_t)n_slabs * ns[i] * ks[i] + (int64_t)2 * n_slabs * ns[i];
-        best = need > best ? need : best;
-    }
-    return best;
+    /* floats: the partial sets of the three GEMMs (they run in one launch) */
+    return ws_need(B, P, 128) + ws_need(B, 128, 128) + ws_need(B, 128, n_in);
 }
 
 extern "C" int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
@@ -228,10 +261,13 @@ extern "C" int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t
     BGK_CHECK_ARG(B > 0 && P > 0 && d_c > 0, "bgk_dense_weight_grad: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int n_in = periodic ? 2 * d_c : d_c;
-    int rc = 0;
-    if (gW2) rc = one_gemm("bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, B, workspace, workspace_floats, gW2, gb2, accumulate, st);
-    if (rc == 0 && gW1) rc = one_gemm("bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, B, workspace, workspace_floats, gW1, gb1, accumulate, st);
-    if (rc == 0 && gW0) rc = one_gemm("bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, B, workspace, workspace_floats, gW0, gb0, accumulate, st);
+    GemmSpec specs[3];
+    int count = 0;
+    if (gW2) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, gW2, gb2};
+    if (gW1) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, gW1, gb1};
+    if (gW0) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, gW0, gb0};
+    if (count == 0) return 0;
+    const int rc = gemm_group(specs, count, B, workspace, workspace_floats, accumulate, st);
     if (rc != 0) return rc;
     return bgk_launch_status("bgk_dense_weight_grad");
 }
