@@ -49,6 +49,9 @@ constexpr int GBLK = KS * 8 + 4;      /* 1 KiB blocks per packed 128-row GEMM in
 #ifndef BGK_V2_ABL
 #define BGK_V2_ABL 0                /* timing ablations (wrong results): 1 no spline, 2 no activation math, 4 no LDS transposition, 8 no staging / output */
 #endif
+#ifndef BGK_V2_ASMSPLIT
+#define BGK_V2_ASMSPLIT 1            /* f16 hi / lo split of the activations: v_cvt_pk_f16_f32 + 2 x v_fma_mix (3 instructions per pair) */
+#endif
 #ifndef BGK_V2_KARG
 #define BGK_V2_KARG 1
 #endif
@@ -235,10 +238,23 @@ __device__ __forceinline__ void act_split_pair(H& hk, const f32x16& t, float c, 
     if constexpr (ACT != 3) {       /* SiLU / ReLU outputs are bounded below; keep the f16 conversion finite above */
         a0 = __builtin_fminf(a0, 65000.0f); a1 = __builtin_fminf(a1, 65000.0f);
     }
-    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
     constexpr int s = 2 * T + (r >> 3), e = r & 7;
+#if BGK_V2_ASMSPLIT
+    /* hi pair = v_cvt_pk_f16_f32 (RNE); lo = f16(a - hi) by the mixed-precision FMA reading hi as an f16 operand and writing one half
+     * of the destination: a - hi is exact in f32, so the single rounding equals (_Float16)(a - (float)hi).  3 instructions per pair. */
+    unsigned uh, ul;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(uh) : "v"(a0), "v"(a1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ul) : "v"(uh), "v"(a0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(ul) : "v"(uh), "v"(a1));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const h2v ph = __builtin_bit_cast(h2v, uh), pl = __builtin_bit_cast(h2v, ul);
+    bf.hi[s][e] = ph[0]; bf.hi[s][e + 1] = ph[1];
+    bf.lo[s][e] = pl[0]; bf.lo[s][e + 1] = pl[1];
+#else
+    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
     bf.hi[s][e] = h0; bf.hi[s][e + 1] = h1;
     bf.lo[s][e] = (_Float16)(a0 - (float)h0); bf.lo[s][e + 1] = (_Float16)(a1 - (float)h1);
+#endif
     hk.template at<3 * P + 2>();
 }
 template <int ACT, int T, class H>
