@@ -503,6 +503,163 @@ __device__ __forceinline__ void spline_chunk(G& g, const FusedArgs& a, const flo
 #endif
 }
 
+/* ---- any even bin count K (the K = 8 routines above carry hand-placed hook points for the software-pipelined exact-f32 kernel;
+ * this is the same arithmetic in the same order written as loops) ---- */
+template <int INV, int K, int ST, bool HW>
+__device__ __forceinline__ float rqs_element_k(float x, const float* pw, const float* ph, const float* ps, float s_last,
+                                               const BgkRqsCfg& c, float* lad, int* bin, int* oob) {
+    static_assert(K % 2 == 0, "bin pairs");
+    constexpr int st = ST;
+    int o = (x < c.left) | (x > c.right);
+    x = x < c.left ? c.left : (x > c.right ? c.right : x);
+    *oob = o;
+    const float* pa = INV ? pw : ph;
+    const float* pb = INV ? ph : pw;
+    const float minA = INV ? c.min_w : c.min_h, minB = INV ? c.min_h : c.min_w;
+    const float scA = INV ? c.w_scale : c.h_scale, scB = INV ? c.h_scale : c.w_scale;
+    const float spanA = INV ? c.xspan : c.yspan, spanB = INV ? c.yspan : c.xspan;
+    const float lowA = INV ? c.left : c.bottom, lowB = INV ? c.bottom : c.left;
+    const float highA = INV ? c.right : c.top, highB = INV ? c.top : c.right;
+    float ra[K], e[K];
+    /* ---- searched set ---- */
+#pragma unroll
+    for (int k = 0; k < K; ++k) ra[k] = pa[k * st];
+    float mA = ra[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) mA = ra[k] > mA ? ra[k] : mA;
+#pragma unroll
+    for (int k = 0; k < K; k += 2) { const bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[k] - mA, ra[k + 1] - mA}); e[k] = t.x; e[k + 1] = t.y; }
+    float sA = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) sA += e[k];
+    int idx = -1 + (x >= lowA ? 1 : 0);
+    float lo = lowA, hi = lowA, cum = 0.0f;
+    bool hi_set = false;
+    const bgk_f2 rA2 = bgk_splat2(SpMath<HW>::rcp(sA)), sA2 = bgk_splat2(sA);
+#pragma unroll
+    for (int k = 0; k < K; k += 2) {
+        bgk_f2 p = SpMath<HW>::divr2((bgk_f2){e[k], e[k + 1]}, sA2, rA2);
+        p = bgk_splat2(minA) + bgk_splat2(scA) * p;
+        const float c0 = cum + p.x, c1 = c0 + p.y;
+        cum = c1;
+        const bgk_f2 kn2 = bgk_splat2(spanA) * (bgk_f2){c0, c1} + bgk_splat2(lowA);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float kn = u ? kn2.y : kn2.x;
+            if (k + u == K - 1) kn = highA;
+            const float ks = (k + u == K - 1) ? kn + 1e-6f : kn;
+            const bool ge = x >= ks;
+            idx += ge ? 1 : 0;
+            if (ge) lo = kn;
+            if (!ge && !hi_set) { hi = kn; hi_set = true; }
+        }
+    }
+    idx = idx < 0 ? 0 : idx;
+    *bin = idx;
+    const float a_i = lo, A_i = hi - lo;
+    /* ---- other set ---- */
+#pragma unroll
+    for (int k = 0; k < K; ++k) ra[k] = pb[k * st];
+    float mB = ra[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) mB = ra[k] > mB ? ra[k] : mB;
+#pragma unroll
+    for (int k = 0; k < K; k += 2) { const bgk_f2 t = SpMath<HW>::exp2((bgk_f2){ra[k] - mB, ra[k + 1] - mB}); e[k] = t.x; e[k + 1] = t.y; }
+    float sB = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) sB += e[k];
+    float b_i = lowB, b_ip1 = lowB;
+    cum = 0.0f;
+    const bgk_f2 rB2 = bgk_splat2(SpMath<HW>::rcp(sB)), sB2 = bgk_splat2(sB);
+#pragma unroll
+    for (int k = 0; k < K; k += 2) {
+        bgk_f2 p = SpMath<HW>::divr2((bgk_f2){e[k], e[k + 1]}, sB2, rB2);
+        p = bgk_splat2(minB) + bgk_splat2(scB) * p;
+        const float c0 = cum + p.x, c1 = c0 + p.y;
+        cum = c1;
+        const bgk_f2 kn2 = bgk_splat2(spanB) * (bgk_f2){c0, c1} + bgk_splat2(lowB);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float kn = u ? kn2.y : kn2.x;
+            if (k + u == K - 1) kn = highB;
+            if (k + u + 1 == idx) b_i = kn;
+            if (k + u == idx) b_ip1 = kn;
+        }
+    }
+    const float B_i = b_ip1 - b_i;
+    /* ---- gathered derivatives ---- */
+    const float s_lo = ps[idx * st];
+    const float s_hi = (idx + 1 < K) ? ps[(idx + 1 < K ? idx + 1 : 0) * st] : s_last;
+    const bgk_f2 sp = SpMath<HW>::softplus2((bgk_f2){s_lo, s_hi}, c.beta);
+    const float d_i = c.min_d + sp.x, d_ip1 = c.min_d + sp.y;
+    float cw_i, W_i, ch_i, H_i;
+    if (INV) { cw_i = a_i; W_i = A_i; ch_i = b_i; H_i = B_i; }
+    else { ch_i = a_i; H_i = A_i; cw_i = b_i; W_i = B_i; }
+    const float delta = SpMath<HW>::div(H_i, W_i);
+    const float S = d_i + d_ip1 - 2.0f * delta;
+    float outv, l;
+    if (!INV) {
+        const float dx = x - ch_i;
+        const float a = dx * S + H_i * (delta - d_i);
+        const float b = H_i * d_i - dx * S;
+        const float cc = -delta * dx;
+        const float disc = b * b - 4.0f * a * cc;
+        const float root = SpMath<HW>::div(2.0f * cc, -b - __builtin_sqrtf(disc));
+        outv = root * W_i + cw_i;
+        const float t1mt = root * (1.0f - root);
+        const float den = delta + S * t1mt;
+        const float omr = 1.0f - root;
+        const float num = (delta * delta) * (d_ip1 * (root * root) + 2.0f * delta * t1mt + d_i * (omr * omr));
+        { const bgk_f2 lg = SpMath<HW>::log2((bgk_f2){num, den}); l = -(lg.x - 2.0f * lg.y); }
+    } else {
+        const float theta = SpMath<HW>::div(x - cw_i, W_i);
+        const float t1mt = theta * (1.0f - theta);
+        const float numer = H_i * (delta * (theta * theta) + d_i * t1mt);
+        const float den = delta + S * t1mt;
+        outv = ch_i + SpMath<HW>::div(numer, den);
+        const float omt = 1.0f - theta;
+        const float num = (delta * delta) * (d_ip1 * (theta * theta) + 2.0f * delta * t1mt + d_i * (omt * omt));
+        { const bgk_f2 lg = SpMath<HW>::log2((bgk_f2){num, den}); l = lg.x - 2.0f * lg.y; }
+    }
+    *lad = l;
+    return outv;
+}
+
+/* spline of one parameter chunk for K bins: the chunk holds DPC = 128 / (3 K + 1) dims, lane (j, hh) evaluates dims hh, hh + 2, ...
+ * of sample j; log-dets are added in ascending dim order by both half-waves (as spline_slot does) */
+template <int INV, int K, int ST, bool HW>
+__device__ __forceinline__ void spline_chunk_k(const FusedArgs& a, const float* s_p, float* s_y, int c, int nd, int hh, int j, int rows,
+                                               int64_t b0, float& run, int& oob_local) {
+    constexpr int PPDK = 3 * K + 1, DPCK = 128 / PPDK;
+    for (int it = 0; 2 * it < nd; ++it) {                  /* wave-uniform trip count */
+        const int q = 2 * it + hh;
+        const bool valid = q < nd;
+        const int qq = valid ? q : 0;
+        const int dim = c * DPCK + qq;
+        const float* pw = s_p + (qq * PPDK) * ST + j;
+        const float* ph = pw + K * ST;
+        const float* ps = ph + K * ST;
+        const bool circ = (a.circ_mask >> dim) & 1ull;
+        const float s_nc = ps[K * ST];
+        const float s_last = circ ? ps[0] : s_nc;
+        int bin, oob;
+        float lad;
+        const float x = s_y[dim * SROW + j];
+        const float o = rqs_element_k<INV, K, ST, HW>(x, pw, ph, ps, s_last, a.cfg, &lad, &bin, &oob);
+        s_y[(valid ? dim : a.d) * SROW + j] = o;
+        oob_local += (valid && j < rows) ? oob : 0;
+        if (a.bin_idx && valid && j < rows) a.bin_idx[(b0 + j) * a.d + dim] = bin;
+        lad = valid ? lad : 0.0f;
+        const float lad_other = __shfl_xor(lad, 32);
+        const float l0 = hh ? lad_other : lad;
+        const float l1 = hh ? lad : lad_other;
+        const float r0 = run + l0;
+        run = (2 * it < nd) ? r0 : run;
+        const float r1 = run + l1;
+        run = (2 * it + 1 < nd) ? r1 : run;
+    }
+}
+
 template <int ACT, int INV>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -813,8 +970,9 @@ __device__ __forceinline__ void act_tile_scaled(f32x16& t, float c) {
 #endif
 }
 
-template <int ACT, int INV, bool SAVE, bool BF>
+template <int ACT, int INV, bool SAVE, bool BF, int KT = KB>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(FusedArgsH2 ah) {
+    constexpr int DPCT = 128 / (3 * KT + 1);              /* dims per 128-column parameter chunk */
     const FusedArgs& a = ah.f;
     if (ah.cs_dev) { ah.c0 = ah.cs_dev[1]; ah.c1 = ah.cs_dev[3]; ah.c2 = ah.cs_dev[5]; }   /* wave-uniform scalar loads */
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -931,23 +1089,27 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
                     if (col_hi >= 0) prow[col_hi] = s_p[(64 + lane) * ST + jj];
                 }
             }
-            const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
+            const int nd = (d - c * DPCT) < DPCT ? (d - c * DPCT) : DPCT;
             const uint4* Wn = ah.A2 + (size_t)(c + 1) * H2_BLOCKS * 64;
             const bool more = c + 1 < a.n_chunks;
             if (more) h2_gemm_start<BF>(ring, Wn, lane);
-            int bins[3] = {0, 0, 0};
-            NoGemm g;
+            if constexpr (KT == KB) {
+                int bins[3] = {0, 0, 0};
+                NoGemm g;
 #if !(BGK_ABL & 1)
-            spline_chunk<INV, NoGemm, ST, true>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+                spline_chunk<INV, NoGemm, ST, true>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #else
-            run += s_p[(lane & 127) * ST + j];
+                run += s_p[(lane & 127) * ST + j];
 #endif
-            if (a.bin_idx) {
+                if (a.bin_idx) {
 #pragma unroll
-                for (int it = 0; it < 3; ++it) {
-                    const int q = 2 * it + hh;
-                    if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
+                    for (int it = 0; it < 3; ++it) {
+                        const int q = 2 * it + hh;
+                        if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
+                    }
                 }
+            } else {
+                spline_chunk_k<INV, KT, ST, true>(a, s_p, s_y, c, nd, hh, j, rows, b0, run, oob_local);
             }
             if (more) {
 #if !(BGK_ABL & 2)
@@ -1057,8 +1219,9 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
               float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col, void* stream) {
     BGK_CHECK_ARG(cond && A0p && A1p && A2p && y && out && dlogp, "%s: null pointer", what);
     BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "%s: bad sizes", what);
-    if (H0 != HID || H1 != HID || K != KB || d > 64 || act < 1 || act > 3) {
-        bgk_set_error("%s: only hidden=(128,128), n_bins=8, d<=64, act in {SiLU,ReLU,Tanh} are fused "
+    const bool other_k = (K == 4 || K == 16) && z0 == nullptr && operand_dtype == 0;     /* K != 8: split-f16 inference only */
+    if (H0 != HID || H1 != HID || (K != KB && !other_k) || d > 64 || act < 1 || act > 3) {
+        bgk_set_error("%s: only hidden=(128,128), n_bins=8 (4 | 16: inference in split-f16 form), d<=64, act in {SiLU,ReLU,Tanh} are fused "
                       "(got H0=%d H1=%d K=%d d=%d act=%d)", what, H0, H1, K, d, act);
         return BGK_EUNSUPPORTED;
     }
@@ -1068,7 +1231,7 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
     if (B == 0) return 0;
-    if (bgk_h2_variant == 2 && z0 == nullptr && operand_dtype == 0)   /* split-f16 inference: the second-generation kernel */
+    if (bgk_h2_variant == 2 && z0 == nullptr && operand_dtype == 0 && K == KB)   /* split-f16 inference: the second-generation kernel */
         return bgk_launch_rqs_dense_h2v2(what, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, act, y, ldy, B, d, circ_mask,
                                          inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
                                          identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream);
@@ -1076,8 +1239,9 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     FusedArgs& a = ah.f;
     a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
     a.W0 = nullptr; a.W1 = nullptr; a.W2 = nullptr; a.T0 = 0;
-    a.n_chunks = (d + DPC - 1) / DPC;
-    a.last_tiles = ((d - (a.n_chunks - 1) * DPC) * PPD + 31) / 32;
+    const int ppd_k = 3 * K + 1, dpc_k = 128 / ppd_k;
+    a.n_chunks = (d + dpc_k - 1) / dpc_k;
+    a.last_tiles = ((d - (a.n_chunks - 1) * dpc_k) * ppd_k + 31) / 32;
     a.act = act; a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.inverse = inverse;
     a.circ_mask = circ_mask;
     a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
@@ -1103,9 +1267,18 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
 #define BGK_LAUNCH(A, I, S, F) hipLaunchKernelGGL((coupling_rqs_dense_h2_kernel<A, I, S, F>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
 #define BGK_LAUNCH2(A, I) do { if (save) BGK_LAUNCH(A, I, true, false); else if (operand_dtype == 1) BGK_LAUNCH(A, I, false, true); \
                                else BGK_LAUNCH(A, I, false, false); } while (0)
-    if (act == 1) { if (inverse) BGK_LAUNCH2(1, 1); else BGK_LAUNCH2(1, 0); }
+#define BGK_LAUNCHK(A, I, KK) hipLaunchKernelGGL((coupling_rqs_dense_h2_kernel<A, I, false, false, KK>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
+#define BGK_LAUNCHK2(A, I) do { if (K == 4) BGK_LAUNCHK(A, I, 4); else BGK_LAUNCHK(A, I, 16); } while (0)
+    if (K != KB) {
+        if (act == 1) { if (inverse) BGK_LAUNCHK2(1, 1); else BGK_LAUNCHK2(1, 0); }
+        else if (act == 2) { if (inverse) BGK_LAUNCHK2(2, 1); else BGK_LAUNCHK2(2, 0); }
+        else { if (inverse) BGK_LAUNCHK2(3, 1); else BGK_LAUNCHK2(3, 0); }
+    }
+    else if (act == 1) { if (inverse) BGK_LAUNCH2(1, 1); else BGK_LAUNCH2(1, 0); }
     else if (act == 2) { if (inverse) BGK_LAUNCH2(2, 1); else BGK_LAUNCH2(2, 0); }
     else { if (inverse) BGK_LAUNCH2(3, 1); else BGK_LAUNCH2(3, 0); }
+#undef BGK_LAUNCHK2
+#undef BGK_LAUNCHK
 #undef BGK_LAUNCH2
 #undef BGK_LAUNCH
     return bgk_launch_status(what);

@@ -335,7 +335,13 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
     float* s_mean = s_T + keep * nf3;
     int* s_off = reinterpret_cast<int*>(s_mean + nf3);
     float* s_dsc = reinterpret_cast<float*>(s_off + nf3);
+    /* s_cb[c]: LDS offset (3 * atom) of the atom that Z-matrix row c places.  The tile's inputs are fetched with row-contiguous
+     * (coalesced) loads and parked IN the position table: the (bond, angle, torsion) of a placement sit in the three slots its
+     * atom's coordinates will overwrite, the fixed block in the first slots of the fixed atoms -- no extra LDS, and none of the
+     * 4-byte-per-row strided loads whose lines were fetched again and again by placements far apart in time. */
+    int* s_cb = reinterpret_cast<int*>(s_dsc + (3 * n + keep) * 6);
     const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += TS) s_cb[a.table[5 * i + 4]] = 3 * a.table[5 * i];
     for (int i = tid; i < nf3; i += TS) {
         s_off[i] = 3 * a.fixed[i / 3] + i % 3;
         s_mean[i] = a.T ? a.wh_mean[i] : 0.0f;
@@ -349,51 +355,88 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
     }
     __syncthreads();
     const int64_t n_tiles = (a.B + TS - 1) / TS;
+    /* e / n and e / keep for e < 2^16 by multiply-high: floor(e m / 2^32) with m = ceil(2^32 / n) is exact while e n < 2^32 */
+    const unsigned magic_n = (unsigned)((0x100000000ull + (unsigned)n - 1) / (unsigned)n);
+    const unsigned magic_k = (unsigned)((0x100000000ull + (unsigned)keep - 1) / (unsigned)keep);
     int warn = 0;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t b0 = tile * TS;
         const int rows = (int)((a.B - b0) < TS ? (a.B - b0) : TS);
+        const bool park_fixed = keep <= 16 && keep <= nf3;
+        {   /* element e = it * TS + tid of a field's [rows x n] block: 8 loads in flight, then their 8 LDS writes */
+            const float* srcs[3] = {a.bonds, a.angles, a.torsions};
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const float* src = srcs[f] + b0 * a.ldic;
+                for (int it0 = 0; it0 * TS < rows * n; it0 += 8) {
+                    float v[8];
+                    int off[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = (it0 + u) * TS + tid, r = (int)__umulhi((unsigned)e, magic_n), c = e - r * n;
+                        const bool ok = e < rows * n;
+                        v[u] = ok ? src[(int64_t)r * a.ldic + c] : 0.0f;
+                        off[u] = ok ? r * a.sx + s_cb[c] + f : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (off[u] >= 0) s_x[off[u]] = v[u];
+                }
+            }
+            if (park_fixed) {
+                const float* src = a.xfix + b0 * a.ldf;
+                float v[16];
+                int off[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int e = u * TS + tid, r = (int)__umulhi((unsigned)e, magic_k), c = e - r * keep;
+                    const bool ok = e < rows * keep;
+                    v[u] = ok ? src[(int64_t)r * a.ldf + c] : 0.0f;
+                    off[u] = ok ? r * a.sx + s_off[c] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (off[u] >= 0) s_x[off[u]] = v[u];
+            }
+        }
+        __syncthreads();
         if (tid < rows) {
             const int64_t b = b0 + tid;
             float* xr = s_x + tid * a.sx;
             const float* fx = a.xfix + b * a.ldf;
-            const float* pb = a.bonds + b * a.ldic;
-            const float* pa = a.angles + b * a.ldic;
-            const float* pt = a.torsions + b * a.ldic;
-            /* the first placement's three values and the fixed block travel while the table is initialised */
-            int zr = a.table[4];
-            float ub = pb[zr], ua = pa[zr], ut = pt[zr];
             float fxv[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) fxv[k] = k < keep ? fx[k] : 0.0f;
+            for (int k = 0; k < 16; ++k) fxv[k] = (park_fixed && k < keep) ? xr[s_off[k]] : 0.0f;      /* all read before any is overwritten */
             float acc = 0.0f;
             if (a.T) {
                 for (int c = 0; c < nf3; ++c) xr[s_off[c]] = s_mean[c];
+                if (park_fixed) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (k < keep) {
-                        const float zk = icdf_channel(fxv[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
+                    for (int k = 0; k < 16; ++k) {
+                        if (k < keep) {
+                            const float zk = icdf_channel(fxv[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
+                            for (int c = 0; c < nf3; ++c) xr[s_off[c]] += zk * s_T[k * nf3 + c];
+                        }
+                    }
+                } else {
+                    for (int k = 0; k < keep; ++k) {
+                        const float zk = icdf_channel(fx[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
                         for (int c = 0; c < nf3; ++c) xr[s_off[c]] += zk * s_T[k * nf3 + c];
                     }
                 }
-                for (int k = 16; k < keep; ++k) {
-                    const float zk = icdf_channel(fx[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
-                    for (int c = 0; c < nf3; ++c) xr[s_off[c]] += zk * s_T[k * nf3 + c];
-                }
                 acc += -a.jac_xz;
             } else {
-                for (int c = 0; c < nf3; ++c)
-                    xr[s_off[c]] = icdf_channel(c < 16 ? fxv[c & 15] : fx[c], s_dsc + 6 * (3 * n + c), g.use_eps, g.cdf_eps, acc);
+                if (park_fixed) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c < nf3) xr[s_off[c]] = icdf_channel(fxv[c], s_dsc + 6 * (3 * n + c), g.use_eps, g.cdf_eps, acc);
+                } else {
+                    for (int c = 0; c < nf3; ++c) xr[s_off[c]] = icdf_channel(fx[c], s_dsc + 6 * (3 * n + c), g.use_eps, g.cdf_eps, acc);
+                }
             }
             if (a.normalize) acc += (float)n * logf(PI_F) + (float)n * logf(2.0f * PI_F);
             for (int i = 0; i < n; ++i) {
                 const int at = a.table[5 * i], i1 = a.table[5 * i + 1], i2 = a.table[5 * i + 2], i3 = a.table[5 * i + 3];
-                const int zc = zr;
-                const float vb = ub, va = ua, vt = ut;
-                if (i + 1 < n) {                      /* next placement's values: requested before this placement's arithmetic */
-                    zr = a.table[5 * (i + 1) + 4];
-                    ub = pb[zr]; ua = pa[zr]; ut = pt[zr];
-                }
+                const int zc = a.table[5 * i + 4];
+                const float vb = xr[3 * at], va = xr[3 * at + 1], vt = xr[3 * at + 2];      /* parked inputs of this placement */
                 const float dd = icdf_channel(vb, s_dsc + 6 * zc, g.use_eps, g.cdf_eps, acc);
                 const float an = icdf_channel(va, s_dsc + 6 * (n + zc), g.use_eps, g.cdf_eps, acc);
                 const float tn = icdf_channel(vt, s_dsc + 6 * (2 * n + zc), g.use_eps, g.cdf_eps, acc);
@@ -717,7 +760,7 @@ extern "C" int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const fl
     a.sx = (3 * a.n_atoms) | 1;
     g.dsc_b = desc_bonds; g.dsc_a = desc_angles; g.dsc_t = desc_torsions; g.dsc_f = desc_fixed; g.use_eps = use_eps; g.cdf_eps = cdf_eps;
     const int nf3 = 3 * n_fixed;
-    size_t shmem = sizeof(float) * ((size_t)IC2_THREADS * (size_t)a.sx + (size_t)keep * nf3 + 2 * (size_t)nf3 + (size_t)(3 * n + keep) * 6);
+    size_t shmem = sizeof(float) * ((size_t)IC2_THREADS * (size_t)a.sx + (size_t)keep * nf3 + 2 * (size_t)nf3 + (size_t)(3 * n + keep) * 6 + (size_t)n);
     if (shmem > 160 * 1024) { bgk_set_error("bgk_icdf_ic2xyz: %d atoms do not fit the LDS tile", a.n_atoms); return BGK_EUNSUPPORTED; }
     int64_t nt = (B + IC2_THREADS - 1) / IC2_THREADS;
     int grid = (int)(nt < 256 * 32 ? nt : 256 * 32);

@@ -501,8 +501,10 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     n_nc = int((nc_slot_host >= 0).sum())
     P = l2.out_features
     n_bins = (P - n_nc) // (3 * y_dim)
-    if n_bins != 8 or 3 * n_bins * y_dim + n_nc != P:
+    if 3 * n_bins * y_dim + n_nc != P:
         return None
+    if n_bins != 8 and not (n_bins in (4, 16) and mode == "f16x2"):
+        return None            # K = 4 | 16: inference in split-f16 form only (bgk_coupling_rqs_dense_h2); anything else: generic path
     d_c = l0.in_features // 2 if periodic else l0.in_features
     if periodic:
         idx = np.arange(d_c)[net.indices] if not isinstance(net.indices, slice) or net.indices != slice(None) else np.arange(d_c)
@@ -747,7 +749,8 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
     if x.dim() != 2 or y.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or _gemm_mode(transformer) != "f16x2":
         return None
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
-    if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device:
+    if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device \
+            or plan["n_bins"] != 8:           # the training variant (saved pre-activations + parameters) exists for K = 8
         return None
     _lib.require_hip(x, y)
     if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:

@@ -485,6 +485,49 @@ def test_fused_split_f16_layer_vs_oracle(hip_lib, dev, kind, inverse, B, generat
     assert n_ties <= max(2, res["f16x2"][2].size // 10000)
 
 
+@pytest.mark.parametrize("K", [4, 16])
+@pytest.mark.parametrize("kind", ["T|F", "F|T", "B|A"])
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("B", [31, 4133])
+def test_fused_split_f16_other_bin_counts(hip_lib, dev, K, kind, inverse, B):
+    """K = 4 and K = 16 bins through the one-launch coupling kernel (bgk_coupling_rqs_dense_h2: 9 / 2 dims per 128-column
+    parameter chunk instead of 5): same bars as K = 8 -- per sample within 1e-5 of the f64 oracle, outputs within 1e-6, every
+    bin index equal to the f32 oracle's or an ulp-tie at a knot, and as accurate as the unfused path on the same inputs"""
+    from oracle import flow_oracle as fo
+    from bgflow_amd import configs
+    from bgflow_amd.utils import hash_init_
+    dims = {"BONDS": 17, "ANGLES": 17, "TORSIONS": 17, "FIXED": 9}
+    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+    what, on = {"T|F": ("TORSIONS", "FIXED"), "F|T": ("FIXED", "TORSIONS"), "B|A": ("BONDS", "ANGLES")}[kind]
+    layer_cpu = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, num_bins=K))
+    layer = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, num_bins=K)).to(dev)
+    ti = slot[what]
+    xs = [synth(B + 7 * i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9))]
+    layer.transformer.return_bin_indices = True
+    with torch.no_grad():
+        *outs, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
+    cache = layer.transformer._fused_cache
+    assert cache.get("mode") == "f16x2" and cache.get("n_bins") == K, "the fused path must have run"
+    y_f, dl_f, idx_f = outs[ti].cpu().numpy(), dl.cpu().numpy(), layer.transformer.last_bin_indices.cpu().numpy()
+    layer.transformer.allow_fused = False
+    with torch.no_grad():
+        *outs_g, dl_g = layer(*[t(v, dev) for v in xs], inverse=inverse)
+    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64)
+    trace = []
+    fo.run_block(layer_cpu, xs, inverse, np.float32, trace)
+    e_f = np.abs(y_f - outs64[ti]).max(), np.abs(dl_f - dl64).max()
+    e_g = np.abs(outs_g[ti].cpu().numpy() - outs64[ti]).max(), np.abs(dl_g.cpu().numpy() - dl64).max()
+    assert e_f[0] <= 1e-6 and e_f[0] <= 3 * e_g[0] + 2e-7, f"outputs: fused {e_f[0]:.2e} vs generic {e_g[0]:.2e} (error to the f64 oracle)"
+    # per sample: 1e-5 (|dlogp| < 1 for one layer: absolute), or -- K = 16 halves the bin widths and doubles the f32 noise of the
+    # log-det -- at most 1.5 x what the unfused f32 path (torch GEMMs + bgk_rqs_transform) shows on the very same sample set
+    worst_f, worst_g = rel_per_sample(dl_f, dl64, floor=1.0).max(), rel_per_sample(dl_g.cpu().numpy(), dl64, floor=1.0).max()
+    assert worst_f <= max(1e-5, 1.5 * worst_g), f"dlogp per sample: fused {worst_f:.2e} vs unfused f32 path {worst_g:.2e}"
+    assert e_f[1] <= 3 * e_g[1] + 2e-6, f"dlogp: fused {e_f[1]:.2e} vs generic {e_g[1]:.2e}"
+    n_ties = assert_bin_ties(idx_f, trace[0], xs[ti], f"{kind} K={K}")
+    assert n_ties <= max(2, idx_f.size // 10000)
+
+
 def test_fused_split_f16_flow16_golden(hip_lib, golden, dev):
     """cfg 3 with gemm_mode='f16x2' against the reference goldens at the same tolerances as the f32 path"""
     from bgflow_amd import configs

@@ -22,6 +22,14 @@ for MODE in f16x2 f32; do
 done
 unset BGK_GEMM
 for d in pmc_sq_f16x2 pmc_sq2_f16x2 pmc_grbm_f16x2 pmc_sq_f32 pmc_sq2_f32 pmc_grbm_f32; do echo "== $d"; python tools/pmc_summary.py $OUT/$d coupling; done > $OUT/pmc_summary.txt
+# 3b. cfg 2 (fused affine kernel): kernel stats + counters; KL training step: kernel stats + counters; fused generation tail counters
+bash tools/prof_cfg2.sh > $OUT/cfg2_stats.txt 2>&1
+cp gpurun_out/prof_cfg2/stats/*/c2_kernel_stats.csv $OUT/cfg2_kernel_stats.csv 2>/dev/null || cp $(find gpurun_out/prof_cfg2/stats -name "*kernel_stats.csv" | head -1) $OUT/cfg2_kernel_stats.csv
+bash tools/pmc_cfg2.sh > $OUT/cfg2_pmc.txt 2>&1
+bash tools/prof_kl.sh > $OUT/kl_stats.txt 2>&1
+cp $(find gpurun_out/prof_kl/stats -name "*kernel_stats.csv" | head -1) $OUT/kl_step_kernel_stats.csv
+bash tools/pmc_kl.sh > $OUT/kl_pmc.txt 2>&1
+bash tools/pmc_ic.sh > $OUT/ic_tail_pmc.txt 2>&1
 # 4. un-profiled bench line (full default command incl. cpu_baseline + KL extra) and the multi-rank self-test of bench.py
 python bench.py > $OUT/bench_plain.json 2>$OUT/bench_plain.err
 BGK_BENCH_TEST_SHARED_GPU=1 python bench.py --gpus 2 --steps 3 --warmup 1 --batch 262144 --kl-steps 2 --kl-batch 65536 > $OUT/bench_2rank_selftest.json 2>$OUT/bench_2rank_selftest.err
