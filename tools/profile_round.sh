@@ -26,6 +26,10 @@ for d in pmc_sq_f16x2 pmc_sq2_f16x2 pmc_grbm_f16x2 pmc_sq_f32 pmc_sq2_f32 pmc_gr
 bash tools/prof_cfg2.sh > $OUT/cfg2_stats.txt 2>&1
 cp gpurun_out/prof_cfg2/stats/*/c2_kernel_stats.csv $OUT/cfg2_kernel_stats.csv 2>/dev/null || cp $(find gpurun_out/prof_cfg2/stats -name "*kernel_stats.csv" | head -1) $OUT/cfg2_kernel_stats.csv
 bash tools/pmc_cfg2.sh > $OUT/cfg2_pmc.txt 2>&1
+C2="python bench.py --workload cfg2 --no-cpu-baseline --no-extras --kl-steps 0 --steps 2 --warmup 1"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_cfg2 -o p -- $C2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_cfg2 -o p -- $C2 > /dev/null 2>&1
+python tools/traffic_json.py $OUT/pmc_fetch_cfg2 $OUT/pmc_write_cfg2 $OUT/cfg2_traffic.json > $OUT/cfg2_traffic.txt
 bash tools/prof_kl.sh > $OUT/kl_stats.txt 2>&1
 cp $(find gpurun_out/prof_kl/stats -name "*kernel_stats.csv" | head -1) $OUT/kl_step_kernel_stats.csv
 bash tools/pmc_kl.sh > $OUT/kl_pmc.txt 2>&1
