@@ -1310,12 +1310,13 @@ def _affine_stack(dev, s0, D, n_layers, hidden=(64, 64), swap_every=True, extra_
     return hash_init_(bg.SequentialFlow(layers)).to(dev)
 
 
+@pytest.mark.parametrize("hidden", [(64, 64), (128, 128), (64, 64, 64)])
 @pytest.mark.parametrize("s0,D,n_layers,B", [(32, 64, 8, 4099), (24, 64, 5, 1000), (32, 64, 2, 31), (40, 72, 3, 257)])
-def test_fused_coupling_stack_equals_blocks(hip_lib, dev, s0, D, n_layers, B):
+def test_fused_coupling_stack_equals_blocks(hip_lib, dev, s0, D, n_layers, B, hidden):
     """Split -> (affine coupling, swap)* -> Merge on one [B, D] buffer (in-place layers, in-kernel dlogp accumulation, no cat)
     against the same blocks run one by one: bit-identical in both directions (same kernels, same summation order)"""
     import bgflow_amd as bg
-    flow = _affine_stack(dev, s0, D, n_layers)
+    flow = _affine_stack(dev, s0, D, n_layers, hidden=hidden)      # (64, 64): weight-resident kernel; the others: streaming kernel
     assert [lbl for lbl, _ in flow.segments()] == ["coupling stack"] and [lbl for lbl, _ in flow.segments(inverse=True)] == ["coupling stack"]
     g = torch.Generator(device=dev).manual_seed(3)
     z = torch.randn(B, D, device=dev, generator=g)
