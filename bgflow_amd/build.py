@@ -26,7 +26,10 @@ HIPCC_FLAGS = [
 ]
 # per-TU additions.  bgk_fused2.hip threads VALU work between MFMAs: packed-f32 ops (which the SLP vectoriser
 # would form from adjacent scalar ops) do not overlap with the matrix pipe on gfx950 (tools/ubench/issue_bench).
-TU_FLAGS = {"bgk_fused2.hip": ["-fno-slp-vectorize"]}
+TU_FLAGS = {"bgk_fused2.hip": ["-fno-slp-vectorize"], "bgk_fused2_train.hip": ["-fno-slp-vectorize"]}
+
+
+INCLUDES_SOURCE = {"bgk_fused2_train.hip": ["bgk_fused2.hip"]}     # translation units that #include another .hip
 
 
 def sources():
@@ -63,7 +66,8 @@ def build_extension(force=False, verbose=False, out=None):
     def compile_one(src):
         mine = extra if (not only or os.path.basename(src) in only) else []
         obj = _obj(src, tag if mine else "")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+        dep_t = max([os.path.getmtime(src), hdr_t] + [os.path.getmtime(os.path.join(CSRC, d)) for d in INCLUDES_SOURCE.get(os.path.basename(src), [])])
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > dep_t:
             return obj
         cmd = [hipcc] + HIPCC_FLAGS + TU_FLAGS.get(os.path.basename(src), []) + mine + ["-c", "-o", obj, src]
         if verbose:

@@ -29,6 +29,15 @@
 #include "bgk_common.h"
 #include "bgk_fused2.h"
 
+#ifndef BGK_V2_SAVE
+#define BGK_V2_SAVE 0                /* 1 (bgk_fused2_train.hip): the training forward -- the same kernel also writes what the backward
+                                      * needs: the scaled pre-activations z0, z1 [B, 128] and the spline parameters [B, P] */
+#endif
+#if BGK_V2_SAVE
+#include "bgk_mfma_h2.h"             /* h2_store_rows128 */
+#define coupling_rqs_dense_h2v2_kernel coupling_rqs_dense_h2v2_train_kernel
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,7 +52,7 @@ constexpr int KB = 8;                 /* spline bins */
 constexpr int PPD = 3 * KB + 1;       /* packed rows per transformed dim = 25 */
 constexpr int DPC = 128 / PPD;        /* dims per 128-row chunk = 5 */
 constexpr int SROW = 33;              /* padded row stride of the y / input tiles */
-constexpr int ST = 32;                /* row stride of the parameter chunk in LDS */
+constexpr int ST = BGK_V2_SAVE ? 33 : 32;   /* row stride of the parameter chunk in LDS (33: the training variant also reads the chunk row-wise) */
 constexpr int KS = 8;                 /* k16-steps of a 128-wide hidden layer */
 constexpr int GBLK = KS * 8 + 4;      /* 1 KiB blocks per packed 128-row GEMM incl. the 4 bias blocks */
 #ifndef BGK_V2_ABL
@@ -81,6 +90,11 @@ struct V2Args {
     uint64_t circ_mask;
     SpC sc;
     int lds_per_wave;
+#if BGK_V2_SAVE
+    float* z0; float* z1;             /* scaled pre-activations [B, 128] */
+    float* params; int64_t ldp;       /* spline parameters [B, P] in the reference's column order */
+    const int32_t* src_col;           /* packed column -> parameter column (-1: padding) */
+#endif
 };
 /* the kernel argument block in the constant address space: the spline constants are (re)read with scalar loads where they are
  * used instead of occupying ~30 SGPRs for the whole persistent loop */
@@ -635,19 +649,40 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         }
     }
 
+#if BGK_V2_SAVE
+    /* z0 = layer-0 pre-activations, as full rows through the (now free) parameter-chunk buffer: [32][132] = 128 * ST floats */
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[m][r] *= a.c0;
+    h2_store_rows128(h, a.z0, s_p, b0, rows, lane);
+    const float c0_act = 1.0f;
+#else
+    const float c0_act = a.c0;
+#endif
     /* ---- layer 1: events of k-steps 2t, 2t + 1 behind the activation of tile t + 1 ---- */
     {
         Live<4> g{acc, bf, a.A1, voff, ring};
         g.start();
         NoLive none;
-        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, h[0], a.c0, bf);
+        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, h[0], c0_act, bf);
         __builtin_amdgcn_sched_barrier(0);
-        act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, h[1], a.c0, bf);      /* hook i = event i (100 events) */
-        act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, h[2], a.c0, bf);
-        act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, h[3], a.c0, bf);
+        act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, h[1], c0_act, bf);      /* hook i = event i (100 events) */
+        act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, h[2], c0_act, bf);
+        act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, h[3], c0_act, bf);
         __builtin_amdgcn_sched_barrier(0);
         g.template events<72, Live<4>::NEV>();
     }
+#if BGK_V2_SAVE
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] *= a.c1;
+    h2_store_rows128(acc, a.z1, s_p, b0, rows, lane);
+    const float c1_act = 1.0f;
+#else
+    const float c1_act = a.c1;
+#endif
     /* ---- layer 2, chunk 0: the same behind the activation of the layer-1 tiles ---- */
     float run = 0.0f;
     int oob_local = 0;
@@ -655,11 +690,11 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         Live<4> g{h, bf, a.A2, voff, ring};
         g.start();
         NoLive none;
-        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, acc[0], a.c1, bf);
+        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, acc[0], c1_act, bf);
         __builtin_amdgcn_sched_barrier(0);
-        act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, acc[1], a.c1, bf);
-        act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, acc[2], a.c1, bf);
-        act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, acc[3], a.c1, bf);
+        act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, acc[1], c1_act, bf);
+        act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, acc[2], c1_act, bf);
+        act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, acc[3], c1_act, bf);
         __builtin_amdgcn_sched_barrier(0);
         g.template events<72, Live<4>::NEV>();
     }
@@ -689,6 +724,18 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
                 if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
             }
         }
+#if BGK_V2_SAVE
+        {   /* parameters of this chunk (still in s_p; the chunk holds UNSCALED accumulator values: true parameter = value * c2)
+             * -> params[b][col]: lane = packed row (two passes of 64), one sample row per store instruction: contiguous 32-byte
+             * runs (the 8 bins of a (dim, component)) */
+            const int col_lo = a.src_col[c * 128 + lane], col_hi = a.src_col[c * 128 + 64 + lane];
+            for (int jj = 0; jj < rows; ++jj) {
+                float* prow = a.params + (b0 + jj) * a.ldp;
+                if (col_lo >= 0) prow[col_lo] = s_p[lane * ST + jj] * a.c2;
+                if (col_hi >= 0) prow[col_hi] = s_p[(64 + lane) * ST + jj] * a.c2;
+            }
+        }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -725,9 +772,16 @@ uint32_t magic_div(int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) /
 
 }  // namespace
 
+#if !BGK_V2_SAVE
 int bgk_h2_variant = 2;
+#endif
 
+#if BGK_V2_SAVE
+int bgk_launch_rqs_dense_h2v2_train(const char* what, float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col,
+                                    const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+#else
 int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+#endif
                               const void* A0p, const void* A1p, const void* A2p, float c0, float c1, float c2, const float* cs_dev,
                               int32_t act, const float* y, int64_t ldy, int64_t B, int32_t d, uint64_t circ_mask, int32_t inverse,
                               double left, double right, double bottom, double top,
@@ -753,6 +807,9 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
     const double beta = identity_init ? (0.6931471805599453 / (1.0 - min_derivative)) : 1.0;
     a.sc.beta = (float)beta; a.sc.kout = (float)(0.6931471805599453 / (double)(float)beta); a.sc.min_d = (float)min_derivative;
     a.lds_per_wave = 128 * ST + (d + 1) * SROW;
+#if BGK_V2_SAVE
+    a.z0 = z0; a.z1 = z1; a.params = params; a.ldp = ldp; a.src_col = src_col;
+#endif
     const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
