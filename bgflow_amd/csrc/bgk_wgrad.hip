@@ -63,7 +63,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo
  * 128 x 128 GEMMs fill one workgroup per CU and wait on HBM latency; together with the [P x 128] one the chip is full. */
 struct WgGroup { WgArgs g[3]; int first[4]; };
 
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgGroup grp_args) {
+__global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgGroup grp_args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   /* 2 buffers x {h_hi, h_lo} */
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = (int)blockIdx.x >= grp_args.first[2] ? 2 : ((int)blockIdx.x >= grp_args.first[1] ? 1 : 0);
@@ -93,13 +93,25 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgGroup grp_args) 
     float bsum = 0.0f;
     const int my_off = c * CSTRIDE + rg * 16;                /* where my 16-byte h values go */
     /* software pipeline, two 16-row steps deep: the 16 values of steps s + 1 and s + 2 are in flight while step s is converted /
-     * multiplied (one step of distance left every step waiting on HBM: a step takes ~500 cycles, a loaded round trip > 2000) */
+     * multiplied (one step of distance left every step waiting on HBM: a step takes ~500 cycles, a loaded round trip > 2000).
+     * Loads are raw buffer loads: base = the slab's first row, per-lane byte offsets computed ONCE (8 + 8 VGPRs), the step's row
+     * offset in an SGPR, rows past the slab / the batch and padded columns return 0 from the hardware range check -- no per-element
+     * 64-bit address arithmetic or compares (they were 2/3 of the kernel's VALU instructions: 230 per wave and step, VALU 58 % busy). */
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + r0 * a.ldg), 0, (int)((r1 - r0) * a.ldg * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)(a.h + r0 * a.ldh), 0, (int)((r1 - r0) * a.ldh * 4), 0x00020000);
+    unsigned vg[8], vh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        vg[e] = g_ok ? (unsigned)(((8 * gkb + e) * a.ldg + gcol) * 4) : 0x40000000u;      /* beyond num_records: reads as 0 */
+        vh[e] = h_ok ? (unsigned)(((8 * rg + e) * a.ldh + hc) * 4) : 0x40000000u;
+    }
+    const int step_g = (int)(16 * a.ldg * 4), step_h = (int)(16 * a.ldh * 4);
     auto fetch = [&](int64_t r, float (&gv)[8], float (&hv)[8]) {
+        const int sg = (int)((r - r0) >> 4) * step_g, sh = (int)((r - r0) >> 4) * step_h;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int64_t rowg = r + 8 * gkb + e, rowh = r + 8 * rg + e;
-            gv[e] = (g_ok && rowg < r1) ? a.g[rowg * a.ldg + gcol] : 0.0f;
-            hv[e] = (h_ok && rowh < r1) ? a.h[rowh * a.ldh + hc] : 0.0f;
+            gv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, vg[e], sg, 0));
+            hv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_h, vh[e], sh, 0));
         }
     };
     auto step = [&](int64_t r, float (&gq)[8], float (&hq)[8], int buf) {
