@@ -69,7 +69,7 @@ _SIGNATURES = {
     "bgk_grad_nan_flag": (ctypes.c_int, [vp, i64, vp, vp]),
     "bgk_adam_step": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp, vp]),
     "bgk_dense_weight_grad_workspace": (i64, [i64, i32, i32]),
-    "bgk_dense_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, vp, vp, i64, i32, i32, i64, vp, i64,
+    "bgk_dense_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, i32, i32, i64, vp, i64,
                                              vp, vp, vp, vp, vp, vp, i32, vp]),
     "bgk_pack_rqs_columns": (i32, [i32, i32, vp, vp]),
 }

@@ -68,7 +68,7 @@ __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, i
             t[m][4 * q] = g0.x; t[m][4 * q + 1] = g0.y; t[m][4 * q + 2] = g1.x; t[m][4 * q + 3] = g1.y;
             hv[m][4 * q] = a0.x; hv[m][4 * q + 1] = a0.y; hv[m][4 * q + 2] = a1.x; hv[m][4 * q + 3] = a1.y;
         }
-    h2_store_rows128(hv, h_out, s_buf, b0, rows, lane);
+    if (h_out) h2_store_rows128(hv, h_out, s_buf, b0, rows, lane);     /* NULL: the weight-gradient kernel recomputes act(z) itself */
     h2_store_rows128(t, gz_out, s_buf, b0, rows, lane);
 }
 
@@ -232,7 +232,8 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
                                      const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
                                      int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
                                      float* g_cond, int64_t ldgc, void* stream) {
-    BGK_CHECK_ARG(g && z1 && z0 && T0 && T1 && T2 && cs && g_z1 && g_z0 && h1 && h0, "bgk_dense_backward_dx: null pointer");
+    BGK_CHECK_ARG(g && z1 && z0 && T0 && T1 && T2 && cs && g_z1 && g_z0, "bgk_dense_backward_dx: null pointer");
+    BGK_CHECK_ARG((h1 == nullptr) == (h0 == nullptr), "bgk_dense_backward_dx: h1 and h0 are written both or not at all");
     BGK_CHECK_ARG(B >= 0 && P > 0 && ldg >= P && d_c > 0 && act >= 1 && act <= 3, "bgk_dense_backward_dx: bad sizes");
     BGK_CHECK_ARG(!(g_cond && periodic && !cond), "bgk_dense_backward_dx: the periodic featuriser needs the conditioner input");
     const int n_in = periodic ? 2 * d_c : d_c;

@@ -34,6 +34,8 @@ struct WgArgs {
     const float* g; int64_t ldg; int n;        /* [B, n] */
     const float* h; int64_t ldh; int k;        /* [B, k] (k <= 128) or, featurise != 0, the raw conditioner input [B, k / 2] */
     int featurise;                             /* 1: h columns are cos(2 pi x_c) for c < k/2, sin(2 pi x_c) after (nn/periodic.py:30-37) */
+    int act;                                   /* 0: h as given; 1 SiLU, 2 ReLU, 3 Tanh: the array holds pre-activations z, h = act(z) (hardware
+                                                * exp2 / rcp forms, the same as bgk_dense_backward_dx's activation recomputation) */
     int64_t B; int64_t rows_per_slab; int n_slabs; int n_blocks;
     float* part_w;                             /* [n_slabs][n][k] */
     float* part_b;                             /* [2 n_slabs][n] */
@@ -126,6 +128,16 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgGroup grp_args) 
                 bgk_sincos2pif(hv[e], &sv, &cv);
                 hv[e] = (r + 8 * rg + e < r1) ? (c < kh ? cv : sv) : 0.0f;
             }
+        }
+        if (a.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = hv[e] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hv[e] * -1.44269504088896341f));
+        } else if (a.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = hv[e] > 0.0f ? hv[e] : 0.0f;
+        } else if (a.act == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hv[e] * 2.88539008177792681f));
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) bsum += gv[e];
@@ -224,7 +236,7 @@ int64_t ws_need(int64_t B, int n, int k) {
     return (int64_t)n_slabs * n * k + (int64_t)2 * n_slabs * n;
 }
 
-struct GemmSpec { const char* what; const float* g; int64_t ldg; int n; const float* h; int64_t ldh; int k; int featurise; float* gW; float* gb; };
+struct GemmSpec { const char* what; const float* g; int64_t ldg; int n; const float* h; int64_t ldh; int k; int featurise; int act; float* gW; float* gb; };
 
 int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t ws_floats, int accumulate, hipStream_t st) {
     WgGroup grp;
@@ -245,7 +257,7 @@ int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t w
         BGK_CHECK_ARG(ws_floats >= used + need, "%s: workspace of %lld floats needed, %lld given", sp.what, (long long)(used + need), (long long)ws_floats);
         float* pw = ws + used;
         float* pb = pw + (int64_t)n_slabs * sp.n * sp.k;
-        grp.g[q] = WgArgs{sp.g, sp.ldg, sp.n, sp.h, sp.ldh, sp.k, sp.featurise, B, rows, n_slabs, n_blocks, pw, pb};
+        grp.g[q] = WgArgs{sp.g, sp.ldg, sp.n, sp.h, sp.ldh, sp.k, sp.featurise, sp.act, B, rows, n_slabs, n_blocks, pw, pb};
         red.r[q] = RedOne{pw, pb, n_slabs, sp.n, sp.k, sp.gW, sp.gb};
         blocks += n_slabs * n_blocks;
         used += need;
@@ -266,18 +278,18 @@ extern "C" int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t
 }
 
 extern "C" int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
-                                     const float* h1, const float* h0, const float* cond, int64_t ldc, int32_t d_c,
+                                     const float* h1, const float* h0, int32_t h_act, const float* cond, int64_t ldc, int32_t d_c,
                                      int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
                                      float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate, void* stream) {
     BGK_CHECK_ARG(g_params && g_z1 && g_z0 && h1 && h0 && cond && workspace, "bgk_dense_weight_grad: null pointer");
-    BGK_CHECK_ARG(B > 0 && P > 0 && d_c > 0, "bgk_dense_weight_grad: bad sizes");
+    BGK_CHECK_ARG(B > 0 && P > 0 && d_c > 0 && h_act >= 0 && h_act <= 3, "bgk_dense_weight_grad: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int n_in = periodic ? 2 * d_c : d_c;
     GemmSpec specs[3];
     int count = 0;
-    if (gW2) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, gW2, gb2};
-    if (gW1) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, gW1, gb1};
-    if (gW0) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, gW0, gb0};
+    if (gW2) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, h_act, gW2, gb2};
+    if (gW1) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, h_act, gW1, gb1};
+    if (gW0) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, 0, gW0, gb0};
     if (count == 0) return 0;
     const int rc = gemm_group(specs, count, B, workspace, workspace_floats, accumulate, st);
     if (rc != 0) return rc;

@@ -596,8 +596,9 @@ def _featurise(x, periodic):
 FUSED_MLP_BACKWARD = True    # input-gradient chain of the conditioner on bgk_dense_backward_dx (False: three GEMMs + torch act ops)
 
 
-def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs):
-    """bgk_pack_dense_h2_t + bgk_dense_backward_dx: returns (g_z1, g_z0, h1, h0, g_x or None)"""
+def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs, want_h=True):
+    """bgk_pack_dense_h2_t + bgk_dense_backward_dx: returns (g_z1, g_z0, h1, h0, g_x or None); ``want_h=False``: the activations
+    are not written (h1 = h0 = None: the weight-gradient kernel recomputes them from z1 / z0)"""
     dev = g_p.device
     B, P = g_p.shape
     n_in = W0.shape[1]
@@ -612,7 +613,7 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
     g2, ldg = _lib.rowmajor(g_p)
     x2, ldc = _lib.rowmajor(x.detach())
     d_c = x2.shape[1]
-    out = torch.empty((4, B, 128), dtype=torch.float32, device=dev)
+    out = torch.empty((4 if want_h else 2, B, 128), dtype=torch.float32, device=dev)
     g_x = torch.empty((B, d_c), dtype=torch.float32, device=dev) if want_gx else None
     ws = [w.detach().contiguous() for w in (W0, W1, W2)]
     with torch.cuda.device(dev):
@@ -621,20 +622,21 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
         _lib.check(st, "bgk_pack_dense_h2_t")
         st = _lib.lib().bgk_dense_backward_dx(_lib.ptr(g2), ldg, P, _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic),
                                               _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.ptr(cs), act_code, B,
-                                              _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.ptr(out[3]),
-                                              _lib.ptr(g_x), d_c, _lib.stream_ptr(dev))
+                                              _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]) if want_h else None,
+                                              _lib.ptr(out[3]) if want_h else None, _lib.ptr(g_x), d_c, _lib.stream_ptr(dev))
         _lib.check(st, "bgk_dense_backward_dx")
-    return out[0], out[1], out[2], out[3], g_x
+    return out[0], out[1], (out[2] if want_h else None), (out[3] if want_h else None), g_x
 
 
 FUSED_WEIGHT_GRAD = True     # weight / bias gradients on bgk_dense_weight_grad (False: split-K bmm + bgk_column_sum)
 
 
-def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, params=None):
+def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, params=None, h_act=0):
     """bgk_dense_weight_grad: (gW0, gb0, gW1, gb1, gW2, gb2) of one coupling layer's conditioner.
     ``params`` = (W0, b0, W1, b1, W2, b2): when ALL of them carry a flat-bucket gradient destination (``_bgk_grad_dst``, set by
     training.FlatAdam) the kernel accumulates straight into the bucket and None is returned for every gradient -- no
-    per-parameter AccumulateGrad add kernels (96 tiny launches per cfg-3 step)."""
+    per-parameter AccumulateGrad add kernels (96 tiny launches per cfg-3 step).  ``h_act`` != 0: ``h1`` / ``h0`` are the saved
+    pre-activations and the kernel applies activation ``h_act`` while loading them."""
     dev = g_p.device
     B, P = g_p.shape
     g2, ldg = _lib.rowmajor(g_p)
@@ -661,7 +663,7 @@ def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, p
         return w if (w is not None or b is None) else torch.empty(shape, dtype=torch.float32, device=dev)
     w2, w1, w0 = wbuf(gW2, gb2, (P, 128)), wbuf(gW1, gb1, (128, 128)), wbuf(gW0, gb0, (128, n_in))
     with torch.cuda.device(dev):
-        st = lib.bgk_dense_weight_grad(_lib.ptr(g2), ldg, P, _lib.ptr(g_z1), _lib.ptr(g_z0), _lib.ptr(h1), _lib.ptr(h0),
+        st = lib.bgk_dense_weight_grad(_lib.ptr(g2), ldg, P, _lib.ptr(g_z1), _lib.ptr(g_z0), _lib.ptr(h1), _lib.ptr(h0), int(h_act),
                                        _lib.ptr(x2), ldc, x2.shape[1], int(periodic), B, _lib.ptr(ws), ws.numel(),
                                        _lib.ptr(w2), _lib.ptr(gb2), _lib.ptr(w1), _lib.ptr(gb1), _lib.ptr(w0), _lib.ptr(gb0),
                                        int(direct), _lib.stream_ptr(dev))
@@ -714,8 +716,14 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp)
         need = ctx.needs_input_grad
         cs = ctx.cs
+        fused_wg = FUSED_WEIGHT_GRAD and g_p.is_cuda and W0.shape[1] <= 128
+        recompute_h = False
         if cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= 96:
-            g_z1, g_z0, h1, h0, g_x = _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, need[0], ctx.tbufs)
+            # with the fused weight-gradient kernel downstream the activations h1 / h0 are not materialised: it re-applies the
+            # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)
+            recompute_h = fused_wg
+            g_z1, g_z0, h1, h0, g_x = _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, need[0], ctx.tbufs,
+                                                         want_h=not recompute_h)
         else:
             h1 = act(z1)
             g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
@@ -729,9 +737,13 @@ class _FusedSplineTrainFn(torch.autograd.Function):
                 g_x = torch.autograd.grad(feats, xx, _matmul_nn(g_z0, W0))[0]
             elif need[0]:
                 g_x = _matmul_nn(g_z0, W0)
-        if FUSED_WEIGHT_GRAD and g_p.is_cuda and W0.shape[1] <= 128:
-            gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs,
-                                                              params=ctx.params)
+        if fused_wg:
+            if recompute_h:
+                gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, z1, z0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs,
+                                                                  params=ctx.params, h_act=act_code)
+            else:
+                gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs,
+                                                                  params=ctx.params)
         else:
             feats = _featurise(x.detach(), periodic)
             gW2 = _gram_tn(g_p, h1) if need[6] else None

@@ -316,8 +316,8 @@ int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
 
 /* Input-gradient chain of the conditioner MLP [n_in, 128, 128, P] in one launch (autograd of nn/dense.py:47-48 in the
  * training step): from g [B, P] (gradient w.r.t. the MLP output, e.g. bgk_rqs_backward's g_params) and the saved
- * pre-activations z1, z0 it writes g_z1, g_z0 (gradients w.r.t. the pre-activations), h1, h0 (the activations) -- the
- * operands of the weight / bias gradient GEMMs -- and g_cond [B, d_c] (NULL to skip; periodic != 0: through the cos / sin
+ * pre-activations z1, z0 it writes g_z1, g_z0 (gradients w.r.t. the pre-activations), h1, h0 (the activations; both NULL: not
+ * written -- bgk_dense_weight_grad can recompute them from z1 / z0) -- the operands of the weight / bias gradient GEMMs -- and g_cond [B, d_c] (NULL to skip; periodic != 0: through the cos / sin
  * featuriser of nn/periodic.py:30-37, needs cond).  T0..T2: transposed-weight operands from bgk_pack_dense_h2_t with the
  * scale table cs of bgk_pack_dense_h2 for the same weights. */
 int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
@@ -343,11 +343,14 @@ int bgk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  *   (g_z0, featurised cond) -> gW0 [128, n_in], gb0 [128]   (periodic != 0: cond [B, d_c] is featurised on the fly as
  *   [cos 2 pi x | sin 2 pi x], nn/periodic.py:30-37; n_in = 2 d_c).  Any gW pointer may be NULL (skipped with its gb);
  *   accumulate != 0: results are ADDED to the destinations (gradient buckets of the optimizer).
+ *   h_act = 0: h1 / h0 hold the hidden activations; 1 SiLU | 2 ReLU | 3 Tanh: they hold the PRE-activations z1 / z0 saved by the
+ *   training forward and the kernel applies the activation while loading (bgk_dense_backward_dx then need not write h1 / h0:
+ *   a fifth less HBM traffic in that kernel).
  * Split over the batch into slabs whose partials are summed in fixed order (deterministic); workspace size in floats from
  * bgk_dense_weight_grad_workspace.  Replaces 3 split-K hipBLASLt GEMMs + 3 reductions + 6 column-sum launches per layer. */
 int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in);
 int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
-                          const float* h1, const float* h0, const float* cond, int64_t ldc, int32_t d_c,
+                          const float* h1, const float* h0, int32_t h_act, const float* cond, int64_t ldc, int32_t d_c,
                           int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
                           float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate, void* stream);
 

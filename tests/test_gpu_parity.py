@@ -1150,6 +1150,16 @@ def test_dense_weight_grad_kernel(hip_lib, dev, B, P, d_c, periodic, gscale):
         scale = float(want.abs().max())
         err = float((got.double() - want).abs().max())
         assert err <= 3e-5 * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+    # activation applied on the fly: the h arrays hold pre-activations (what bgk_dense_backward_dx's caller passes when it does
+    # not materialise h1 / h0)
+    for code, fn in ((1, torch.nn.functional.silu), (2, torch.relu), (3, torch.tanh)):
+        z1, z0 = 2.0 * h1, 2.0 * h0
+        res_a = _dense_weight_grad(g_p, g_z1, g_z0, z1, z0, x, bool(periodic), n_in, [True] * 8, {}, h_act=code)
+        ref_a = (ref[0], ref[1], g_z1.double().t() @ fn(z0.double()), ref[3], g_p.double().t() @ fn(z1.double()), ref[5])
+        for got, want, name in zip(res_a, ref_a, ("gW0", "gb0", "gW1", "gb1", "gW2", "gb2")):
+            scale = float(want.abs().max())
+            err = float((got.double() - want).abs().max())
+            assert err <= 3e-5 * scale, f"act {code} {name}: {err:.3e} vs scale {scale:.3e}"
 
 
 def test_flat_adam_matches_torch_adam_and_skips_nan(hip_lib, dev):
