@@ -36,162 +36,8 @@ struct FusedAffArgs {
     int cvec4;                   /* cond rows 16-byte aligned */
 };
 
-template <int HT, int OT>
-__device__ __forceinline__ void net_eval(h2_f32x16 (&res)[OT], const AffNet& n, const float* s_x, int S0, int lane) {
-    h2_f32x16 h[HT];
-#pragma unroll
-    for (int m = 0; m < HT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
-    h2_gemm_lds<HT>(h, s_x, ASROW, S0, n.A0, lane);
-#pragma unroll
-    for (int m = 0; m < HT; ++m) h2_act_tile(h[m], n.c0, n.act);
-    H2B<HT> bf;
-    h2_make_b<HT>(bf, h);
-#pragma unroll
-    for (int m = 0; m < HT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
-    h2_gemm_hidden<HT, HT>(h, bf, n.A1, lane);
-#pragma unroll
-    for (int m = 0; m < HT; ++m) h2_act_tile(h[m], n.c1, n.act);
-    h2_make_b<HT>(bf, h);
-    if (n.A1b) {                 /* three hidden layers (e.g. the ala2 RealNVP conditioners [30, 128, 128, 128, 30]) */
-#pragma unroll
-        for (int m = 0; m < HT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
-        h2_gemm_hidden<HT, HT>(h, bf, n.A1b, lane);
-#pragma unroll
-        for (int m = 0; m < HT; ++m) h2_act_tile(h[m], n.c1b, n.act);
-        h2_make_b<HT>(bf, h);
-    }
-#pragma unroll
-    for (int m = 0; m < OT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) res[m][r] = 0.0f;
-    h2_gemm_hidden<OT, HT>(res, bf, n.A2, lane);
-}
-
-template <int HT, int OT>
-__global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(FusedAffArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    float* s_x = smem + (size_t)wave * a.lds_per_wave;
-    const int64_t n_tiles = (a.B + 31) / 32;
-    const int64_t tile = (int64_t)blockIdx.x * AW + wave;
-    if (tile >= n_tiles) return;
-    const int64_t b0 = tile * 32;
-    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
-    const int d = a.d;
-
-    /* conditioner input [feature][sample] + constant-1 row (bias column) + zero pad rows */
-    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
-    for (int i = lane; i < 32 * a.d_c; i += 64) {
-        const int r = i / a.d_c, c = i - r * a.d_c;
-        const float v = r < rows ? a.cond[(b0 + r) * a.ldc + c] : 0.0f;
-        if (a.periodic) {          /* WrapPeriodic featuriser (nn/periodic.py:30-37), all inputs circular on [0, 1] */
-            float sv, cv;
-            bgk_sincos2pif(v, &sv, &cv);
-            s_x[c * ASROW + r] = cv;
-            s_x[(a.d_c + c) * ASROW + r] = sv;
-        } else {
-            s_x[c * ASROW + r] = v;
-        }
-    }
-    for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
-        s_x[(n_in + (i >> 5)) * ASROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    h2_f32x16 mu[OT], sr[OT];
-#pragma unroll
-    for (int m = 0; m < OT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { mu[m][r] = 0.0f; sr[m][r] = 0.0f; }
-    if (a.has_shift) net_eval<HT, OT>(mu, a.shift, s_x, a.S0, lane);
-    if (a.has_scale) net_eval<HT, OT>(sr, a.scale, s_x, a.S0, lane);
-
-    /* ---- affine tail on the accumulator layout: this lane holds dims h2_row(m, r, hh) of sample j ---- */
-    const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
-    float lsum = 0.0f;
-#pragma unroll
-    for (int m = 0; m < OT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const bgk_f2 th = bgk_tanhf2((bgk_f2){sr[m][r] * a.scale.c2, sr[m][r + 1] * a.scale.c2});
-            const float l0 = (a.has_scale && h2_row(m, r, hh) < d) ? th.x * alpha : 0.0f;
-            const float l1 = (a.has_scale && h2_row(m, r + 1, hh) < d) ? th.y * alpha : 0.0f;
-            sr[m][r] = l0; sr[m][r + 1] = l1;
-            lsum += l0;
-            lsum += l1;
-        }
-    float total = lsum + __shfl_xor(lsum, 32);
-    if (a.preserve_volume && a.has_scale) {
-        const float mean = total / (float)d;
-        lsum = 0.0f;
-#pragma unroll
-        for (int m = 0; m < OT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool valid = h2_row(m, r, hh) < d;
-                const float ls = valid ? sr[m][r] - mean : 0.0f;
-                sr[m][r] = ls;
-                lsum += ls;
-            }
-        total = lsum + __shfl_xor(lsum, 32);
-    }
-    if (j < rows) {
-        const float* yr = a.y + (b0 + j) * a.ldy;
-        float* orow = a.out + (b0 + j) * a.ldo;
-        /* registers 4q..4q+3 of a tile hold 4 consecutive dims: one 16-byte access per group when aligned */
-#pragma unroll
-        for (int m = 0; m < OT; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int dim0 = h2_row(m, 4 * q, hh);
-                if (dim0 >= d) continue;
-                const bool full = a.vec4 && dim0 + 4 <= d;
-                float v[4];
-                if (full) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(yr + dim0);
-                    v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = dim0 + u < d ? yr[dim0 + u] : 0.0f;
-                }
-                float o[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = 4 * q + u;
-                    const float mm = a.has_shift ? mu[m][r] * a.shift.c2 : 0.0f;
-                    const float ls = sr[m][r];
-                    float t = a.inverse ? bgk_expf(-ls) * (v[u] - mm) : bgk_expf(ls) * v[u] + mm;
-                    if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
-                    o[u] = t;
-                }
-                if (full) {
-                    *reinterpret_cast<float4*>(orow + dim0) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) if (dim0 + u < d) orow[dim0 + u] = o[u];
-                }
-            }
-        if (hh == 0) {
-            const float dl = a.inverse ? -total : total;
-            if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
-        }
-    }
-}
-
-
-/* ---- weight-resident variant (hidden = 64): both conditioners' packed operands (78 KB for cfg 2) are staged ONCE per
- * workgroup in LDS and the workgroup's waves loop over 32-sample tiles.  The streaming kernel above re-reads every operand
- * block from L2 for every 32 samples (2.7 KB of L2 traffic per sample against 392 B of HBM traffic: L2-bandwidth bound,
- * 0.29 ms per cfg 2 layer); here the A fragments come from LDS (ds_read_b128, 624 LDS cycles per tile) and the conditioner
- * input is loaded from global memory directly in B-operand layout (lane = sample, 8 consecutive features), so the only
- * per-tile memory traffic is the algorithmic d_c + 2 d + 1 floats per sample. ---- */
+/* ---- shared building blocks of both kernels (A fragments through a pointer: global memory in the streaming kernel, LDS in the
+ * weight-resident one) ---- */
 typedef unsigned int r_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef BGK_AFF_ABL
 #define BGK_AFF_ABL 0          /* diagnostic builds: 1 no global loads, 2 no hidden activation math, 4 no output-layer math, 8 no MFMAs */
@@ -241,7 +87,7 @@ template <int HT>
 struct RB { r_u32x4 hi[2 * HT], lo[2 * HT]; };
 
 /* out = W' * b + bias'  with W' resident in LDS (K = 32 HT); out need not be initialised */
-template <int NT, int HT>
+template <int NT, int HT, bool PIN = false>
 __device__ __forceinline__ void ra_gemm_hidden(h2_f32x16 (&out)[NT], const RB<HT>& b, const r_u32x4* W, int lane) {
     constexpr int S = 2 * HT;
     RA<NT> ring[2];
@@ -253,6 +99,8 @@ __device__ __forceinline__ void ra_gemm_hidden(h2_f32x16 (&out)[NT], const RB<HT
 #pragma unroll
             for (int m = 0; m < NT; ++m) ring[(s + 1) & 1].v[m][0] = W[(S * NT * 2 + m) * 64 + lane];
         }
+        if (PIN) __builtin_amdgcn_sched_barrier(0);       /* operands from L2: the next step's fragments stay requested ahead of this step's MFMAs
+                                                           * (with operands in LDS the fence costs 10 %: the scheduler interleaves better) */
         if (s == 0) ra_mfma3<NT, true, false>(out, ring[0], __builtin_bit_cast(h2_h16x8, b.hi[0]), __builtin_bit_cast(h2_h16x8, b.lo[0]));
         else ra_mfma3<NT, false, false>(out, ring[s & 1], __builtin_bit_cast(h2_h16x8, b.hi[s]), __builtin_bit_cast(h2_h16x8, b.lo[s]));
     }
@@ -330,6 +178,145 @@ __device__ __forceinline__ float r_tanh_out(float x) {
     return ax >= 0.625f ? big : small;
 }
 
+template <int HT, int OT>
+__device__ __forceinline__ void net_eval(h2_f32x16 (&res)[OT], const AffNet& n, const float* s_x, int S0, int lane) {
+    h2_f32x16 h[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
+    h2_gemm_lds<HT>(h, s_x, ASROW, S0, n.A0, lane);
+    /* activation + f16 hi / lo split in the lean forms of the resident kernel (hardware exp2 / rcp, 3-instruction split) */
+    RB<HT> bf;
+    r_act_split<HT>(bf, h, n.c0, n.act);
+    ra_gemm_hidden<HT, HT, true>(h, bf, reinterpret_cast<const r_u32x4*>(n.A1), lane);
+    r_act_split<HT>(bf, h, n.c1, n.act);
+    if (n.A1b) {                 /* three hidden layers (e.g. the ala2 RealNVP conditioners [30, 128, 128, 128, 30]) */
+        ra_gemm_hidden<HT, HT, true>(h, bf, reinterpret_cast<const r_u32x4*>(n.A1b), lane);
+        r_act_split<HT>(bf, h, n.c1b, n.act);
+    }
+    ra_gemm_hidden<OT, HT, true>(res, bf, reinterpret_cast<const r_u32x4*>(n.A2), lane);
+}
+
+template <int HT, int OT>
+__global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(FusedAffArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* s_x = smem + (size_t)wave * a.lds_per_wave;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * AW + wave;
+    if (tile >= n_tiles) return;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    const int d = a.d;
+
+    /* conditioner input [feature][sample] + constant-1 row (bias column) + zero pad rows */
+    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
+    for (int i = lane; i < 32 * a.d_c; i += 64) {
+        const int r = i / a.d_c, c = i - r * a.d_c;
+        const float v = r < rows ? a.cond[(b0 + r) * a.ldc + c] : 0.0f;
+        if (a.periodic) {          /* WrapPeriodic featuriser (nn/periodic.py:30-37), all inputs circular on [0, 1] */
+            float sv, cv;
+            bgk_sincos2pif(v, &sv, &cv);
+            s_x[c * ASROW + r] = cv;
+            s_x[(a.d_c + c) * ASROW + r] = sv;
+        } else {
+            s_x[c * ASROW + r] = v;
+        }
+    }
+    for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
+        s_x[(n_in + (i >> 5)) * ASROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    h2_f32x16 mu[OT], sr[OT];
+#pragma unroll
+    for (int m = 0; m < OT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { mu[m][r] = 0.0f; sr[m][r] = 0.0f; }
+    if (a.has_shift) net_eval<HT, OT>(mu, a.shift, s_x, a.S0, lane);
+    if (a.has_scale) net_eval<HT, OT>(sr, a.scale, s_x, a.S0, lane);
+
+    /* ---- affine tail on the accumulator layout: this lane holds dims h2_row(m, r, hh) of sample j ---- */
+    const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
+    float lsum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < OT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float l0 = (a.has_scale && h2_row(m, r, hh) < d) ? r_tanh_out(sr[m][r] * a.scale.c2) * alpha : 0.0f;
+            const float l1 = (a.has_scale && h2_row(m, r + 1, hh) < d) ? r_tanh_out(sr[m][r + 1] * a.scale.c2) * alpha : 0.0f;
+            sr[m][r] = l0; sr[m][r + 1] = l1;
+            lsum += l0;
+            lsum += l1;
+        }
+    float total = lsum + __shfl_xor(lsum, 32);
+    if (a.preserve_volume && a.has_scale) {
+        const float mean = total / (float)d;
+        lsum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < OT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool valid = h2_row(m, r, hh) < d;
+                const float ls = valid ? sr[m][r] - mean : 0.0f;
+                sr[m][r] = ls;
+                lsum += ls;
+            }
+        total = lsum + __shfl_xor(lsum, 32);
+    }
+    if (j < rows) {
+        const float* yr = a.y + (b0 + j) * a.ldy;
+        float* orow = a.out + (b0 + j) * a.ldo;
+        /* registers 4q..4q+3 of a tile hold 4 consecutive dims: one 16-byte access per group when aligned */
+#pragma unroll
+        for (int m = 0; m < OT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int dim0 = h2_row(m, 4 * q, hh);
+                if (dim0 >= d) continue;
+                const bool full = a.vec4 && dim0 + 4 <= d;
+                float v[4];
+                if (full) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(yr + dim0);
+                    v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = dim0 + u < d ? yr[dim0 + u] : 0.0f;
+                }
+                float o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * q + u;
+                    const float mm = a.has_shift ? mu[m][r] * a.shift.c2 : 0.0f;
+                    const float ls = sr[m][r];
+                    const float sg = __builtin_amdgcn_exp2f((a.inverse ? -ls : ls) * 1.44269504088896341f);     /* |ls| <= exp(log_alpha): 1 ulp */
+                    float t = a.inverse ? sg * (v[u] - mm) : sg * v[u] + mm;
+                    if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
+                    o[u] = t;
+                }
+                if (full) {
+                    *reinterpret_cast<float4*>(orow + dim0) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (dim0 + u < d) orow[dim0 + u] = o[u];
+                }
+            }
+        if (hh == 0) {
+            const float dl = a.inverse ? -total : total;
+            if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
+        }
+    }
+}
+
+
+/* ---- weight-resident variant (hidden = 64): both conditioners' packed operands (78 KB for cfg 2) are staged ONCE per
+ * workgroup in LDS and the workgroup's waves loop over 32-sample tiles.  The streaming kernel above re-reads every operand
+ * block from L2 for every 32 samples (2.7 KB of L2 traffic per sample against 392 B of HBM traffic: L2-bandwidth bound,
+ * 0.29 ms per cfg 2 layer); here the A fragments come from LDS (ds_read_b128, 624 LDS cycles per tile) and the conditioner
+ * input is loaded from global memory directly in B-operand layout (lane = sample, 8 consecutive features), so the only
+ * per-tile memory traffic is the algorithmic d_c + 2 d + 1 floats per sample. ---- */
 struct ResOff { int a0, a1, a2; };          /* offsets (16-byte units) of a network's operands in the LDS image */
 
 template <int HT, int OT>
