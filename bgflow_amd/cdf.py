@@ -9,9 +9,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from .flow import Flow
+from .flow import Flow, InverseFlow, SequentialFlow
 
-__all__ = ["CDFTransform"]
+__all__ = ["CDFTransform", "DistributionTransferFlow", "ConstrainGaussianFlow"]
 
 
 def _descriptor(dist, d):
@@ -160,3 +160,36 @@ class CDFTransform(Flow):
         if self._eps is not None:
             logdet = logdet.clamp_min(-1 / self._eps)
         return y, logdet.sum(dim=-1, keepdim=True)
+
+
+class DistributionTransferFlow(SequentialFlow):
+    """Samples of ``source_distribution`` -> samples of ``target_distribution``: cdf of the source followed by the icdf of the target
+    (bgflow/nn/flow/cdf.py:49-63); two launches of bgk_cdf_transform for the supported marginals."""
+
+    def __init__(self, source_distribution, target_distribution, eps=1e-7):
+        super().__init__([CDFTransform(source_distribution, eps=eps), InverseFlow(CDFTransform(target_distribution, eps=eps))])
+
+
+class ConstrainGaussianFlow(Flow):
+    """Squeeze a Gaussian variable N(mu, sigma) into [lower_bound, upper_bound]: Gaussian cdf, then the icdf of the truncated
+    Gaussian N(mu_out or mu, sigma_out or sigma) on that interval; the forward output is clamped to the interval against
+    round-off (bgflow/nn/flow/cdf.py:66-121; same argument names and defaults)."""
+
+    def __init__(self, mu, sigma=torch.tensor(1.0), lower_bound=0.0, upper_bound=np.inf, assert_range=True, mu_out=None,
+                 sigma_out=None, eps=1e-7):
+        super().__init__()
+        from .distributions import TruncatedNormalDistribution
+        lo, hi = float(lower_bound), float(upper_bound)
+        source = torch.distributions.Normal(mu, sigma.to(mu))
+        target = TruncatedNormalDistribution(
+            mu=mu if mu_out is None else mu_out.to(mu), sigma=sigma if sigma_out is None else sigma_out.to(mu),
+            lower_bound=lo * torch.ones_like(mu), upper_bound=hi * torch.ones_like(mu), assert_range=assert_range)
+        self._trafo = DistributionTransferFlow(source, target, eps)
+        self._lower_bound, self._upper_bound = lo, hi
+
+    def _forward(self, x, *args, **kwargs):
+        y, dlogp = self._trafo.forward(x, *args, **kwargs)
+        return y.clamp(self._lower_bound, self._upper_bound), dlogp
+
+    def _inverse(self, x, *args, **kwargs):
+        return self._trafo.forward(x, *args, **kwargs, inverse=True)

@@ -1368,3 +1368,36 @@ def test_fused_coupling_stack_no_swap_and_neighbours(hip_lib, dev):
             bg.SequentialFlow.FUSE_COUPLING_STACKS = True
     assert torch.equal(x1, x0) and torch.equal(d1, d0)
     assert torch.equal(x1[:, :32], z[:, :32])
+
+
+def test_distribution_transfer_and_constrain_gaussian_on_gpu(hip_lib, dev):
+    """DistributionTransferFlow / ConstrainGaussianFlow (cdf.py:49-121) run two bgk_cdf_transform launches: same results as the
+    distributions' torch ops (kernel path switched off through a learnable marginal / f64), learnable truncated normal differentiable"""
+    import bgflow_amd as bg
+    from torch.distributions import Normal
+    g = torch.Generator(device=dev).manual_seed(2)
+    mu, sig = torch.linspace(0.5, 1.5, 12, device=dev), torch.linspace(0.8, 1.2, 12, device=dev)
+    flow = bg.ConstrainGaussianFlow(mu=mu, sigma=sig, lower_bound=0.1, upper_bound=3.0)
+    x = mu + sig * torch.randn(5000, 12, device=dev, generator=g)
+    with torch.no_grad():
+        y, dl = flow.forward(x)
+        assert all(c.kernel_descriptor(12, dev) is not None for c in (flow._trafo._blocks[0], flow._trafo._blocks[1]._delegate))
+        xb, dlb = flow.forward(y, inverse=True)
+        # reference evaluation in f64 on the distributions' torch ops
+        f64 = bg.ConstrainGaussianFlow(mu=mu.double(), sigma=sig.double(), lower_bound=0.1, upper_bound=3.0)
+        y64, dl64 = f64.forward(x.double())
+    assert bool(((y >= 0.1) & (y <= 3.0)).all())
+    core = (x - mu).abs() < 3.0 * sig                    # the icdf of f32 tails is ill-conditioned: compare the bulk tightly, all loosely
+    assert float((y.double() - y64)[core].abs().max()) < 2e-5 and float((y.double() - y64).abs().max()) < 5e-3
+    rows = core.all(dim=1)
+    assert float((dl.double() - dl64)[rows].abs().max()) < 2e-4
+    assert float((xb - x)[core].abs().max()) < 1e-3 and float((dl + dlb)[rows].abs().max()) < 1e-3
+    # the reference's own gradient check (tests/nn/flow/test_cdf.py::test_cdf_transform): learnable marginal, input needs grad
+    inp = torch.arange(0.1, 1.0, 0.1, device=dev)[:, None].requires_grad_(True)
+    tn = bg.TruncatedNormalDistribution(mu=torch.tensor([0.5], device=dev), upper_bound=torch.tensor([1.0], device=dev), is_learnable=True)
+    flow2 = bg.InverseFlow(bg.CDFTransform(tn))
+    out, dlogp = flow2.forward(inp)
+    assert abs(float(out.mean()) - 0.5) < 1e-5
+    out.mean().backward(retain_graph=True)
+    dlogp.mean().backward()
+    assert inp.grad is not None and tn._mu.grad is not None and torch.isfinite(tn._mu.grad).all()

@@ -580,3 +580,24 @@ def test_coupling_stack_detection_is_conservative():
     flow = bg.SequentialFlow([bg.SwapFlow()] + ok + [bg.SwapFlow()])
     assert [lbl for lbl, _ in flow.segments()] == ["SwapFlow", "coupling stack", "SwapFlow"]
     assert [lbl for lbl, _ in flow.segments(inverse=True)] == ["SwapFlow", "coupling stack", "SwapFlow"]
+
+
+def test_distribution_transfer_and_constrain_gaussian_flows():
+    """DistributionTransferFlow / ConstrainGaussianFlow (bgflow/nn/flow/cdf.py:49-121) on the distributions' own torch ops
+    (CPU tensors never reach a kernel): the behaviour the reference's tests/nn/flow/test_cdf.py checks"""
+    from torch.distributions import Normal
+    swap = bg.DistributionTransferFlow(Normal(torch.zeros(2), torch.ones(2)), Normal(torch.ones(2), torch.ones(2)))
+    out, dlogp = swap.forward(torch.zeros(2, 2))
+    assert torch.allclose(out, torch.ones(2, 2)) and torch.allclose(dlogp, torch.zeros(2, 1))
+    back, dlogp = swap.forward(out, inverse=True)
+    assert torch.allclose(back, torch.zeros(2, 2), atol=1e-6) and torch.allclose(dlogp, torch.zeros(2, 1), atol=1e-6)
+    torch.manual_seed(1)
+    positive = bg.ConstrainGaussianFlow(mu=torch.ones(10), lower_bound=1e-10)
+    y, dlogp = positive.forward((1.0 + torch.randn(10, 10)) * 1000.0)
+    assert y.shape == (10, 10) and dlogp.shape == (10, 1) and bool((y >= 0.0).all()) and float(dlogp.sum()) < 0.0
+    generous = bg.ConstrainGaussianFlow(mu=torch.ones(10), sigma=torch.ones(10), lower_bound=-1000.0, upper_bound=1000.0)
+    x = 1.0 + torch.randn(10, 10)
+    y, dlogp = generous.forward(x)
+    assert torch.allclose(x, y, atol=1e-4, rtol=0.0) and torch.allclose(dlogp, torch.zeros_like(dlogp), atol=1e-4, rtol=0.0)
+    x2, dlogp = generous.forward(y, inverse=True)
+    assert torch.allclose(x2, y, atol=1e-4, rtol=0.0) and torch.allclose(dlogp, torch.zeros_like(dlogp), atol=1e-4, rtol=0.0)
