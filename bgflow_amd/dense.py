@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from .utils import is_list_or_tuple
 
-__all__ = ["DenseNet", "MeanFreeDenseNet", "WrapPeriodic"]
+__all__ = ["DenseNet", "MeanFreeDenseNet", "WrapPeriodic", "WrapDistances"]
 
 
 def _matmul_nn(g, w):
@@ -130,6 +130,29 @@ class WrapPeriodic(torch.nn.Module):
         ang = 2 * np.pi * (xp - self.left) / (self.right - self.left)
         feats = torch.cat([torch.cos(ang), torch.sin(ang), xo], dim=-1)
         return self.net.forward(feats)
+
+
+class WrapDistances(torch.nn.Module):
+    """Feed ``net`` with the other inputs followed by all pairwise distances (i < j, row-major) of the points whose flattened
+    xyz coordinates sit at ``indices`` (nn/periodic.py:40-58).  Stock torch ops: a conditioner front end outside the fused
+    envelope."""
+
+    def __init__(self, net, left=0.0, right=1.0, indices=slice(None)):
+        super().__init__()
+        self.net = net
+        self.left = left
+        self.right = right
+        self.indices = indices
+
+    def forward(self, x):
+        n = x.shape[-1]
+        picked = np.arange(n)[self.indices]
+        rest = np.setdiff1d(np.arange(n), picked)
+        points = x[..., picked].view(x.shape[0], -1, 3)
+        dmat = torch.cdist(points, points)
+        upper = torch.triu(torch.ones_like(dmat), diagonal=1).bool()
+        dists = dmat[upper].view(x.shape[0], -1)
+        return self.net.forward(torch.cat([x[..., rest], dists], dim=-1))
 
 
 _ACT_CODES = {torch.nn.SiLU: 1, torch.nn.ReLU: 2, torch.nn.Tanh: 3}

@@ -15,7 +15,36 @@ from .flow import Flow
 __all__ = [
     "decompose_z_matrix", "RelativeInternalCoordinateTransformation", "MixedCoordinateTransformation",
     "WhitenFlow", "ReferenceSystemTransformation", "GlobalInternalCoordinateTransformation",
+    "slice_initial_atoms", "normalize_torsions", "normalize_angles", "unnormalize_torsions", "unnormalize_angles",
 ]
+
+
+# ---- small public helpers of the reference's ic module (crd_transform/ic.py:94-125); the kernels apply the same maps internally
+def slice_initial_atoms(z_matrix):
+    """(the three atoms of a global Z-matrix with the most ``-1`` placeholders -- origin, axis atom, plane atom --, the complete rows)"""
+    n_open = np.sum(z_matrix == -1, axis=-1)
+    first_three = np.argsort(n_open)[::-1][:3]
+    return z_matrix[:, 0][first_three], z_matrix[n_open == 0]
+
+
+def normalize_torsions(torsions):
+    """[-pi, pi) -> [0, 1): (t + pi) / (2 pi); log-det = -d log(2 pi)"""
+    return (torsions + np.pi) / (2 * np.pi), -np.log(2 * np.pi) * torsions.shape[-1]
+
+
+def normalize_angles(angles):
+    """[0, pi] -> [0, 1]: a / pi; log-det = -d log(pi)"""
+    return angles / np.pi, -np.log(np.pi) * angles.shape[-1]
+
+
+def unnormalize_torsions(torsions):
+    """[0, 1) -> [-pi, pi): 2 pi t - pi; log-det = d log(2 pi)"""
+    return torsions * (2 * np.pi) - np.pi, np.log(2 * np.pi) * torsions.shape[-1]
+
+
+def unnormalize_angles(angles):
+    """[0, 1] -> [0, pi]: pi a; log-det = d log(pi)"""
+    return angles * np.pi, np.log(np.pi) * angles.shape[-1]
 
 
 def decompose_z_matrix(z_matrix, fixed):

@@ -601,3 +601,30 @@ def test_distribution_transfer_and_constrain_gaussian_flows():
     assert torch.allclose(x, y, atol=1e-4, rtol=0.0) and torch.allclose(dlogp, torch.zeros_like(dlogp), atol=1e-4, rtol=0.0)
     x2, dlogp = generous.forward(y, inverse=True)
     assert torch.allclose(x2, y, atol=1e-4, rtol=0.0) and torch.allclose(dlogp, torch.zeros_like(dlogp), atol=1e-4, rtol=0.0)
+
+
+def test_ic_helper_functions_and_wrap_distances():
+    """public helpers of the reference's ic module (ic.py:94-125) and the WrapDistances conditioner front end (periodic.py:40-58)"""
+    z = np.array([[0, -1, -1, -1], [1, 0, -1, -1], [2, 1, 0, -1], [3, 2, 1, 0], [4, 3, 2, 1]])
+    first, rest = bg.slice_initial_atoms(z)
+    assert list(first) == [0, 1, 2] and rest.tolist() == [[3, 2, 1, 0], [4, 3, 2, 1]]
+    t0 = torch.tensor([[-3.0, 0.0, 3.0]])
+    tn, dl = bg.normalize_torsions(t0)
+    tb, dlb = bg.unnormalize_torsions(tn)
+    assert torch.allclose(tb, t0, atol=1e-6) and abs(dl + dlb) < 1e-12 and abs(dl + 3 * np.log(2 * np.pi)) < 1e-12
+    assert float(tn.min()) >= 0.0 and float(tn.max()) < 1.0
+    a0 = torch.tensor([[0.1, 1.5, 3.1]])
+    an, dl = bg.normalize_angles(a0)
+    ab, dlb = bg.unnormalize_angles(an)
+    assert torch.allclose(ab, a0, atol=1e-6) and abs(dl + dlb) < 1e-12 and abs(dl + 3 * np.log(np.pi)) < 1e-12
+    # WrapDistances: 2 extra inputs + the 3 pairwise distances of 3 points
+    seen = {}
+
+    class Probe(torch.nn.Module):
+        def forward(self, f):
+            seen["f"] = f
+            return f
+    x = torch.tensor([[7.0, 0.0, 0.0, 0.0, 3.0, 0.0, 0.0, 0.0, 4.0, 0.0, 9.0]])
+    wd = bg.WrapDistances(Probe(), indices=np.arange(1, 10))
+    wd(x)
+    assert torch.allclose(seen["f"], torch.tensor([[7.0, 9.0, 3.0, 4.0, 5.0]]))
