@@ -47,6 +47,7 @@ _MAP = {
     "factory.transformer_factory": "factory",
     "factory.distribution_factory": "factory",
     "factory.icmarginals": "factory",
+    "utils.types": "utils",
 }
 
 

@@ -5,7 +5,8 @@ from collections.abc import Iterable
 import numpy as np
 import torch
 
-__all__ = ["hash_init_", "synth", "is_list_or_tuple", "pack_tensor_in_tuple", "unpack_tensor_tuple"]
+__all__ = ["hash_init_", "synth", "is_list_or_tuple", "pack_tensor_in_tuple", "unpack_tensor_tuple", "pack_tensor_in_list",
+           "as_numpy", "assert_numpy"]
 
 
 def hash_init_(module, scale=1.0):
@@ -62,3 +63,28 @@ def unpack_tensor_tuple(seq):
     if len(seq) == 1:
         return seq[0]
     return (*seq,)
+
+
+def pack_tensor_in_list(seq):
+    """a tensor -> [tensor]; any other iterable -> list of its items (utils/types.py:60-67)"""
+    if isinstance(seq, torch.Tensor):
+        return [seq]
+    try:
+        return list(seq)
+    except TypeError:
+        return seq
+
+
+def as_numpy(tensor):
+    """host numpy copy of anything ``torch.as_tensor`` accepts (utils/types.py:29-31)"""
+    return torch.as_tensor(tensor).detach().cpu().numpy()
+
+
+def assert_numpy(x, arr_type=None):
+    """tensor / list / tuple / array -> ndarray (optionally cast); anything else fails the assertion (utils/types.py:16-26)"""
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    if is_list_or_tuple(x):
+        x = np.array(x)
+    assert isinstance(x, np.ndarray)
+    return x if arr_type is None else x.astype(arr_type)
