@@ -64,7 +64,7 @@ constexpr int BWD_TS = 128;
 template <int KT>
 __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
     constexpr int K = KT;
-    static_assert(KT == 8, "two 16-byte loads per parameter group");
+    static_assert(KT % 4 == 0, "KT / 4 16-byte loads per parameter group");
     const int d = a.d, tid = threadIdx.x;
     const BgkRqsCfg& c = a.cfg;
     const uint64_t magicd = (0x100000000ull + (uint64_t)d - 1) / (uint64_t)d;
@@ -80,12 +80,12 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
             const float* gh = gw + d * K;
             const float* gs = gh + d * K;
             float rw[K], rh[K], rs[K], ow[K], oh[K], os[K];
-            {
-                const f4u w0 = *reinterpret_cast<const f4u*>(gw), w1 = *reinterpret_cast<const f4u*>(gw + 4);
-                const f4u h0 = *reinterpret_cast<const f4u*>(gh), h1 = *reinterpret_cast<const f4u*>(gh + 4);
-                const f4u t0 = *reinterpret_cast<const f4u*>(gs), t1 = *reinterpret_cast<const f4u*>(gs + 4);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { rw[k] = w0[k]; rw[4 + k] = w1[k]; rh[k] = h0[k]; rh[4 + k] = h1[k]; rs[k] = t0[k]; rs[4 + k] = t1[k]; }
+            for (int q = 0; q < K / 4; ++q) {
+                const f4u w4 = *reinterpret_cast<const f4u*>(gw + 4 * q), h4 = *reinterpret_cast<const f4u*>(gh + 4 * q);
+                const f4u t4 = *reinterpret_cast<const f4u*>(gs + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { rw[4 * q + k] = w4[k]; rh[4 * q + k] = h4[k]; rs[4 * q + k] = t4[k]; }
             }
             const int slot = a.nc_slot[j];
             const float s_K = slot >= 0 ? row[3 * d * K + slot] : rs[0];   /* slope at knot K */
@@ -201,9 +201,12 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
                 float* qw = grow + j * K;
                 float* qh = qw + d * K;
                 float* qs = qh + d * K;
-                *reinterpret_cast<f4u*>(qw) = (f4u){ow[0], ow[1], ow[2], ow[3]}; *reinterpret_cast<f4u*>(qw + 4) = (f4u){ow[4], ow[5], ow[6], ow[7]};
-                *reinterpret_cast<f4u*>(qh) = (f4u){oh[0], oh[1], oh[2], oh[3]}; *reinterpret_cast<f4u*>(qh + 4) = (f4u){oh[4], oh[5], oh[6], oh[7]};
-                *reinterpret_cast<f4u*>(qs) = (f4u){os[0], os[1], os[2], os[3]}; *reinterpret_cast<f4u*>(qs + 4) = (f4u){os[4], os[5], os[6], os[7]};
+#pragma unroll
+                for (int q = 0; q < K / 4; ++q) {
+                    *reinterpret_cast<f4u*>(qw + 4 * q) = (f4u){ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3]};
+                    *reinterpret_cast<f4u*>(qh + 4 * q) = (f4u){oh[4 * q], oh[4 * q + 1], oh[4 * q + 2], oh[4 * q + 3]};
+                    *reinterpret_cast<f4u*>(qs + 4 * q) = (f4u){os[4 * q], os[4 * q + 1], os[4 * q + 2], os[4 * q + 3]};
+                }
             }
         }
     }
@@ -221,8 +224,8 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
     BGK_CHECK_ARG(B >= 0 && d > 0 && K > 0, "bgk_rqs_backward: bad sizes");
     BGK_CHECK_ARG(y && params && nc_slot && g_out && g_dlogp && g_y && g_params, "bgk_rqs_backward: null pointer");
     BGK_CHECK_ARG(P >= 3 * K * d && P <= 3 * K * d + d && ldp >= P && ldgp >= P, "bgk_rqs_backward: bad params width %d", P);
-    if (K != 8) {
-        bgk_set_error("bgk_rqs_backward: only n_bins = 8 is implemented (got %d)", K);
+    if (K != 4 && K != 8 && K != 12 && K != 16 && K != 32) {
+        bgk_set_error("bgk_rqs_backward: n_bins in {4, 8, 12, 16, 32} are implemented (got %d)", K);
         return BGK_EUNSUPPORTED;
     }
     if (B == 0) return 0;
@@ -235,6 +238,13 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
     int64_t n_tiles = (B + BWD_TS - 1) / BWD_TS;
     int grid = (int)(n_tiles < 256 * 16 ? n_tiles : 256 * 16);
     const size_t shmem = 0;
-    hipLaunchKernelGGL(rqs_bwd_kernel<8>, dim3(grid), dim3(BWD_THREADS), shmem, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    switch (K) {
+        case 4: hipLaunchKernelGGL(rqs_bwd_kernel<4>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
+        case 8: hipLaunchKernelGGL(rqs_bwd_kernel<8>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
+        case 12: hipLaunchKernelGGL(rqs_bwd_kernel<12>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
+        case 16: hipLaunchKernelGGL(rqs_bwd_kernel<16>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
+        default: hipLaunchKernelGGL(rqs_bwd_kernel<32>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
+    }
     return bgk_launch_status("bgk_rqs_backward");
 }

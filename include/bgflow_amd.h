@@ -69,7 +69,7 @@ int bgk_rqs_transform(const float* y, int64_t ldy, const float* params, int64_t 
 
 /* Backward of bgk_rqs_transform for first-order losses (KL / NLL):
  *   given g_out [B,d] (ldgo) and g_dlogp [B], produces g_y [B,d] (ldgy) and g_params [B,P] (ldgp).
- * Replaces torch autograd through the op chain above. */
+ * Replaces torch autograd through the op chain above.  K in {4, 8, 12, 16, 32} (BGK_EUNSUPPORTED otherwise). */
 int bgk_rqs_backward(const float* y, int64_t ldy, const float* params, int64_t ldp, int32_t P,
                      const int32_t* nc_slot, int64_t B, int32_t d, int32_t K, int32_t inverse,
                      double left, double right, double bottom, double top,
