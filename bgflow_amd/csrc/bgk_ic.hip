@@ -54,13 +54,13 @@ __device__ __forceinline__ float clamp_min_flag(float v, float eps, int enforce,
 
 /* cooperative coalesced copy of a [rows, cols] global tile (row stride ld) <-> LDS (row stride s) */
 __device__ __forceinline__ void tile_load(float* dst, int s, const float* src, int64_t ld, int rows, int cols) {
-    for (int i = threadIdx.x; i < rows * cols; i += IC_THREADS) {
+    for (int i = threadIdx.x; i < rows * cols; i += (int)blockDim.x) {
         int r = i / cols, c = i - r * cols;
         dst[r * s + c] = src[(int64_t)r * ld + c];
     }
 }
 __device__ __forceinline__ void tile_store(float* dst, int64_t ld, const float* src, int s, int rows, int cols) {
-    for (int i = threadIdx.x; i < rows * cols; i += IC_THREADS) {
+    for (int i = threadIdx.x; i < rows * cols; i += (int)blockDim.x) {
         int r = i / cols, c = i - r * cols;
         dst[(int64_t)r * ld + c] = src[r * s + c];
     }
@@ -68,7 +68,7 @@ __device__ __forceinline__ void tile_store(float* dst, int64_t ld, const float* 
 
 __global__ __launch_bounds__(IC_THREADS) void ic_xyz2ic_kernel(IcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TS = IC_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
+    const int TS = (int)blockDim.x, n = a.n, nf3 = 3 * a.n_fixed;
     float* s_x = smem;                       /* [TS][sx]  */
     float* s_b = s_x + TS * a.sx;            /* [TS][sic] */
     float* s_a = s_b + TS * a.sic;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(IC_THREADS) void ic_xyz2ic_kernel(IcArgs a) {
 constexpr int IC2_THREADS = 64;
 __global__ __launch_bounds__(IC2_THREADS) void ic_ic2xyz_kernel(IcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TS = IC2_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
+    const int TS = (int)blockDim.x, n = a.n, nf3 = 3 * a.n_fixed;
     float* s_x = smem;                  /* [TS][sx] */
     const int tid = threadIdx.x;
     const int64_t n_tiles = (a.B + TS - 1) / TS;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(IC2_THREADS) void ic_ic2xyz_kernel(IcArgs a) {
             if (a.accumulate) a.dlogp[b] += acc; else a.dlogp[b] = acc;
         }
         __syncthreads();
-        for (int i = tid; i < rows * 3 * a.n_atoms; i += IC2_THREADS) {
+        for (int i = tid; i < rows * 3 * a.n_atoms; i += (int)blockDim.x) {
             int r = i / (3 * a.n_atoms), c = i - r * 3 * a.n_atoms;
             a.x[(b0 + r) * a.ldx + c] = s_x[r * a.sx + c];
         }
@@ -326,7 +326,7 @@ __device__ __noinline__ float explicit_placement_logdet(V3 p1, V3 p2, V3 p3, flo
 __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
     const IcArgs& a = g.ic;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TS = IC2_THREADS, n = a.n, nf3 = 3 * a.n_fixed, keep = a.keep;
+    const int TS = (int)blockDim.x, n = a.n, nf3 = 3 * a.n_fixed, keep = a.keep;
     /* LDS: position table [TS][sx] | Tblacken [keep][nf3] | mean [nf3] | LDS offsets of the fixed coordinates [nf3] | channel
      * descriptors [3 n + keep][6].  The small wave-uniform tables are staged once per workgroup: read from global memory
      * inside the per-sample loops they were vector loads with a full round trip each (58 % of the wave time in s_waitcnt). */
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
         }
         __syncthreads();
         const int na3 = 3 * a.n_atoms;
-        for (int i = tid; i < rows * na3; i += IC2_THREADS) {
+        for (int i = tid; i < rows * na3; i += (int)blockDim.x) {
             int r = i / na3, c = i - r * na3;
             a.x[(b0 + r) * a.ldx + c] = s_x[r * a.sx + c];
         }
@@ -497,13 +497,13 @@ struct IcBwdArgs {
 };
 
 __device__ __forceinline__ void tile_load64(float* dst, int s, const float* src, int64_t ld, int rows, int cols) {
-    for (int i = threadIdx.x; i < rows * cols; i += ICB_THREADS) {
+    for (int i = threadIdx.x; i < rows * cols; i += (int)blockDim.x) {
         int r = i / cols, c = i - r * cols;
         dst[r * s + c] = src[(int64_t)r * ld + c];
     }
 }
 __device__ __forceinline__ void tile_store64(float* dst, int64_t ld, const float* src, int s, int rows, int cols) {
-    for (int i = threadIdx.x; i < rows * cols; i += ICB_THREADS) {
+    for (int i = threadIdx.x; i < rows * cols; i += (int)blockDim.x) {
         int r = i / cols, c = i - r * cols;
         dst[(int64_t)r * ld + c] = src[r * s + c];
     }
@@ -517,7 +517,7 @@ __device__ __forceinline__ V3 proj_out(V3 g, V3 u, float inv_norm) {   /* (g - u
 
 __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TS = ICB_THREADS, n = a.n, nf3 = 3 * a.n_fixed;
+    const int TS = (int)blockDim.x, n = a.n, nf3 = 3 * a.n_fixed;
     float* s_x = smem;                        /* [TS][sx] forward positions */
     float* s_g = s_x + TS * a.sx;             /* [TS][sx] position adjoints */
     float* s_b = s_g + TS * a.sx;             /* [TS][sic] bonds -> g_bonds */
@@ -674,21 +674,36 @@ __global__ __launch_bounds__(256) void ic_refsys_kernel(RefSysArgs a) {
     (void)warn;
 }
 
+/* samples per workgroup: the kernels keep one sample's atoms per thread in LDS; the default tile is halved until it fits 160 KB, so
+ * molecules of several thousand atoms run (partially filled waves) instead of being refused */
+int fit_tile(int default_ts, size_t floats_per_sample, size_t extra_floats) {
+    int ts = default_ts;
+    while (ts > 1 && sizeof(float) * ((size_t)ts * floats_per_sample + extra_floats) > 160 * 1024) ts >>= 1;
+    return ts;
+}
+
 int ic_launch(bool to_ic, IcArgs& a, void* stream, const char* what) {
     a.n_atoms = a.n + a.n_fixed;
     a.sx = (3 * a.n_atoms) | 1;
     a.sic = a.n | 1;
     a.sfx = a.keep | 1;
-    size_t shmem = sizeof(float) * (size_t)IC_THREADS * (size_t)(a.sx + 3 * a.sic + a.sfx);
-    if (shmem > 160 * 1024) { bgk_set_error("%s: %d atoms do not fit the LDS tile", what, a.n_atoms); return BGK_EUNSUPPORTED; }
-    int64_t n_tiles = (a.B + IC_THREADS - 1) / IC_THREADS;
-    int grid = (int)(n_tiles < 256 * 8 ? n_tiles : 256 * 8);
-    if (to_ic) hipLaunchKernelGGL(ic_xyz2ic_kernel, dim3(grid), dim3(IC_THREADS), shmem, (hipStream_t)stream, a);
-    else {
-        size_t shmem2 = sizeof(float) * (size_t)IC2_THREADS * (size_t)a.sx;
-        int64_t nt2 = (a.B + IC2_THREADS - 1) / IC2_THREADS;
-        int grid2 = (int)(nt2 < 256 * 32 ? nt2 : 256 * 32);
-        hipLaunchKernelGGL(ic_ic2xyz_kernel, dim3(grid2), dim3(IC2_THREADS), shmem2, (hipStream_t)stream, a);
+    if (to_ic) {
+        const size_t per = (size_t)(a.sx + 3 * a.sic + a.sfx);
+        const int ts = fit_tile(IC_THREADS, per, 0);
+        const size_t shmem = sizeof(float) * (size_t)ts * per;
+        if (shmem > 160 * 1024) { bgk_set_error("%s: %d atoms do not fit the LDS tile", what, a.n_atoms); return BGK_EUNSUPPORTED; }
+        const int64_t n_tiles = (a.B + ts - 1) / ts;
+        const int grid = (int)(n_tiles < 256 * 8 ? n_tiles : 256 * 8);
+        if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_xyz2ic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(ic_xyz2ic_kernel, dim3(grid), dim3(ts), shmem, (hipStream_t)stream, a);
+    } else {
+        const int ts = fit_tile(IC2_THREADS, (size_t)a.sx, 0);
+        const size_t shmem2 = sizeof(float) * (size_t)ts * (size_t)a.sx;
+        if (shmem2 > 160 * 1024) { bgk_set_error("%s: %d atoms do not fit the LDS tile", what, a.n_atoms); return BGK_EUNSUPPORTED; }
+        const int64_t nt2 = (a.B + ts - 1) / ts;
+        const int grid2 = (int)(nt2 < 256 * 32 ? nt2 : 256 * 32);
+        if (shmem2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(ic_ic2xyz_kernel, dim3(grid2), dim3(ts), shmem2, (hipStream_t)stream, a);
     }
     return bgk_launch_status(what);
 }
@@ -760,11 +775,14 @@ extern "C" int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const fl
     a.sx = (3 * a.n_atoms) | 1;
     g.dsc_b = desc_bonds; g.dsc_a = desc_angles; g.dsc_t = desc_torsions; g.dsc_f = desc_fixed; g.use_eps = use_eps; g.cdf_eps = cdf_eps;
     const int nf3 = 3 * n_fixed;
-    size_t shmem = sizeof(float) * ((size_t)IC2_THREADS * (size_t)a.sx + (size_t)keep * nf3 + 2 * (size_t)nf3 + (size_t)(3 * n + keep) * 6 + (size_t)n);
+    const size_t extra = (size_t)keep * nf3 + 2 * (size_t)nf3 + (size_t)(3 * n + keep) * 6 + (size_t)n;
+    const int ts = fit_tile(IC2_THREADS, (size_t)a.sx, extra);
+    size_t shmem = sizeof(float) * ((size_t)ts * (size_t)a.sx + extra);
     if (shmem > 160 * 1024) { bgk_set_error("bgk_icdf_ic2xyz: %d atoms do not fit the LDS tile", a.n_atoms); return BGK_EUNSUPPORTED; }
-    int64_t nt = (B + IC2_THREADS - 1) / IC2_THREADS;
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(icdf_ic2xyz_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int64_t nt = (B + ts - 1) / ts;
     int grid = (int)(nt < 256 * 32 ? nt : 256 * 32);
-    hipLaunchKernelGGL(icdf_ic2xyz_kernel, dim3(grid), dim3(IC2_THREADS), shmem, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(icdf_ic2xyz_kernel, dim3(grid), dim3(ts), shmem, (hipStream_t)stream, g);
     return bgk_launch_status("bgk_icdf_ic2xyz");
 }
 
@@ -786,11 +804,14 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
     a.n_atoms = n + n_fixed; a.keep = keep; a.normalize = normalize_angles; a.T = Tblacken; a.B = B;
     a.g_bonds = g_bonds; a.g_angles = g_angles; a.g_torsions = g_torsions; a.ldgic = ldgic; a.g_xfix = g_xfix; a.ldgf = ldgf;
     a.sx = (3 * a.n_atoms) | 1; a.sic = n | 1; a.sfx = keep | 1;
-    size_t shmem = sizeof(float) * (size_t)ICB_THREADS * (size_t)(2 * a.sx + 3 * a.sic + a.sfx);
+    const size_t per = (size_t)(2 * a.sx + 3 * a.sic + a.sfx);
+    const int ts = fit_tile(ICB_THREADS, per, 0);
+    size_t shmem = sizeof(float) * (size_t)ts * per;
     if (shmem > 160 * 1024) { bgk_set_error("bgk_ic_ic2xyz_backward: %d atoms do not fit the LDS tile", a.n_atoms); return BGK_EUNSUPPORTED; }
-    int64_t n_tiles = (B + ICB_THREADS - 1) / ICB_THREADS;
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int64_t n_tiles = (B + ts - 1) / ts;
     int grid = (int)(n_tiles < 256 * 12 ? n_tiles : 256 * 12);
-    hipLaunchKernelGGL(ic_ic2xyz_bwd_kernel, dim3(grid), dim3(ICB_THREADS), shmem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ic_ic2xyz_bwd_kernel, dim3(grid), dim3(ts), shmem, (hipStream_t)stream, a);
     return bgk_launch_status("bgk_ic_ic2xyz_backward");
 }
 

@@ -92,7 +92,7 @@ struct Xyz2IcBwdArgs {
 };
 
 __device__ __forceinline__ void tload(float* dst, int s, const float* src, int64_t ld, int rows, int cols) {
-    for (int i = threadIdx.x; i < rows * cols; i += XB_THREADS) {
+    for (int i = threadIdx.x; i < rows * cols; i += (int)blockDim.x) {
         int r = i / cols, c = i - r * cols;
         dst[r * s + c] = src[(int64_t)r * ld + c];
     }
@@ -106,7 +106,7 @@ __device__ __forceinline__ V seed_atom(const float* p, bool active) {
 
 __global__ __launch_bounds__(XB_THREADS) void ic_xyz2ic_bwd_kernel(Xyz2IcBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TS = XB_THREADS, n = a.n, nf3 = 3 * a.n_fixed, na3 = 3 * a.n_atoms;
+    const int TS = (int)blockDim.x, n = a.n, nf3 = 3 * a.n_fixed, na3 = 3 * a.n_atoms;
     float* s_x = smem;                    /* [TS][sx] positions */
     float* s_g = s_x + TS * a.sx;         /* [TS][sx] position adjoints */
     float* s_b = s_g + TS * a.sx;         /* [TS][sic] upstream g_bonds / g_angles / g_torsions */
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(XB_THREADS) void ic_xyz2ic_bwd_kernel(Xyz2IcBwdArgs
             }
         }
         __syncthreads();
-        for (int i = tid; i < rows * na3; i += XB_THREADS) {
+        for (int i = tid; i < rows * na3; i += (int)blockDim.x) {
             int r = i / na3, c = i - r * na3;
             a.g_x[(b0 + r) * a.ldgx + c] = s_g[r * a.sx + c];
         }
@@ -288,11 +288,14 @@ extern "C" int bgk_ic_xyz2ic_backward(const float* x, int64_t ldx, const int32_t
     a.n_atoms = n + n_fixed; a.keep = keep; a.normalize = normalize_angles; a.enforce = enforce_boundaries; a.eps = eps;
     a.T = Twhiten; a.B = B; a.g_x = g_x; a.ldgx = ldgx;
     a.sx = (3 * a.n_atoms) | 1; a.sic = n | 1; a.sfx = keep | 1;
-    size_t shmem = sizeof(float) * (size_t)XB_THREADS * (size_t)(2 * a.sx + 3 * a.sic + a.sfx);
+    int ts = XB_THREADS;              /* halve the tile until one sample's atoms per thread fit the LDS (big molecules) */
+    while (ts > 1 && sizeof(float) * (size_t)ts * (size_t)(2 * a.sx + 3 * a.sic + a.sfx) > 160 * 1024) ts >>= 1;
+    size_t shmem = sizeof(float) * (size_t)ts * (size_t)(2 * a.sx + 3 * a.sic + a.sfx);
     if (shmem > 160 * 1024) { bgk_set_error("bgk_ic_xyz2ic_backward: %d atoms do not fit the LDS tile", a.n_atoms); return BGK_EUNSUPPORTED; }
-    int64_t n_tiles = (B + XB_THREADS - 1) / XB_THREADS;
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_xyz2ic_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int64_t n_tiles = (B + ts - 1) / ts;
     int grid = (int)(n_tiles < 256 * 12 ? n_tiles : 256 * 12);
-    hipLaunchKernelGGL(ic_xyz2ic_bwd_kernel, dim3(grid), dim3(XB_THREADS), shmem, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ic_xyz2ic_bwd_kernel, dim3(grid), dim3(ts), shmem, (hipStream_t)stream, a);
     return bgk_launch_status("bgk_ic_xyz2ic_backward");
 }
 

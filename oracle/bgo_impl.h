@@ -723,7 +723,7 @@ void FN(bgo_ic_ic2xyz_backward)(const REAL* bonds, const REAL* angles, const REA
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; ++b) {
         const REAL* xr = x + b * ldx;
-        REAL gp[3 * 128];
+        REAL* gp = (REAL*)malloc(sizeof(REAL) * 3 * (size_t)n_atoms);      /* any molecule size */
         for (int c = 0; c < 3 * n_atoms; ++c) gp[c] = g_x[b * ldgx + c];
         const REAL gl = g_dlogp[b];
         for (int i = n - 1; i >= 0; --i) {
@@ -788,6 +788,7 @@ void FN(bgo_ic_ic2xyz_backward)(const REAL* bonds, const REAL* angles, const REA
         } else {
             for (int c = 0; c < nf3; ++c) g_xfix[b * nf3 + c] = gp[3 * fixed[c / 3] + c % 3];
         }
+        free(gp);
     }
 }
 

@@ -1450,3 +1450,64 @@ def test_distribution_transfer_and_constrain_gaussian_on_gpu(hip_lib, dev):
     out.mean().backward(retain_graph=True)
     dlogp.mean().backward()
     assert inp.grad is not None and tn._mu.grad is not None and torch.isfinite(tn._mu.grad).all()
+
+
+@pytest.mark.parametrize("n_atoms", [150, 230, 500, 1500])
+def test_relative_ic_large_molecules(hip_lib, oracle, dev, n_atoms):
+    """molecules whose atoms do not fit the default 64-sample LDS tile (> 213 atoms): the IC kernels shrink the tile instead of
+    refusing (150 atoms = default tile, for comparison) -- forward, inverse and both backward kernels against the oracle on a
+    synthetic polymer chain with side branches, generated from well-conditioned internal coordinates"""
+    import bgflow_amd as bg
+    rng = np.random.RandomState(n_atoms)
+    z = np.zeros((n_atoms - 3, 4), dtype=np.int64)
+    for k, i in enumerate(range(3, n_atoms)):
+        z[k] = (i, i - 1, i - 2, i - 3) if i % 4 else (i, i - 2, i - 3, i - 4) if i >= 4 else (i, i - 1, i - 2, i - 3)
+    fixed = np.array([0, 1, 2])
+    B, n = 37, n_atoms - 3
+    bonds = (0.15 + 0.01 * rng.randn(B, n)).astype(np.float32)
+    angles = (0.5 + 0.1 * (rng.rand(B, n) - 0.5)).astype(np.float32)           # normalised: 0.45 .. 0.55 of pi
+    tors = rng.rand(B, n).astype(np.float32)
+    xfix = (np.array([0, 0, 0, 0.15, 0, 0, 0.2, 0.14, 0], dtype=np.float32)[None] + 0.005 * rng.randn(B, 9)).astype(np.float32)
+    ic = bg.RelativeInternalCoordinateTransformation(z, fixed, normalize_angles=True).to(dev)
+    with torch.no_grad():
+        xg, dli = ic(t(bonds, dev), t(angles, dev), t(tors, dev), t(xfix, dev), inverse=True)
+    ox, odli = oracle.ic_ic2xyz(bonds, angles, tors, xfix, z, fixed, dtype=np.float64)
+    ex = np.abs(xg.cpu().numpy() - ox)
+    assert ex.max() < 2e-6 * n_atoms + 1e-5, ex.max()                          # f32 round-off accumulating along the chain
+    assert np.abs(dli.cpu().numpy().reshape(-1) - odli.reshape(-1)).max() <= 1e-5 * np.abs(odli).max() + 1e-4
+    with torch.no_grad():
+        b, a, tt, xf, dl = ic(xg)
+    np.testing.assert_allclose(b.cpu().numpy(), bonds, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(a.cpu().numpy(), angles, rtol=0, atol=2e-5)
+    dt = np.abs(tt.cpu().numpy() - tors); dt = np.minimum(dt, 1.0 - dt)         # torsions are periodic on [0, 1)
+    assert dt.max() < 1e-4
+    # forward log-det against the oracle on the same xyz (dl = -dli only where no eps clamp fired: at 230+ atoms a few random
+    # samples have a clamped norm, in the oracle / reference exactly as here)
+    odl = oracle.ic_xyz2ic(xg.cpu().numpy(), z, fixed, dtype=np.float64)[4]
+    assert np.abs(dl.cpu().numpy().reshape(-1) - odl.reshape(-1)).max() <= 1e-5 * np.abs(odl).max() + 1e-3
+    assert float(np.median((dl + dli).abs().cpu().numpy())) <= 1e-5 * float(dl.abs().max()) + 1e-3
+    # backward kernels: IC -> xyz against the oracle's VJP, xyz -> IC against a finite difference along one direction
+    bg_, ag_, tg_, fg_ = (t(v, dev).requires_grad_(True) for v in (bonds, angles, tors, xfix))
+    xo, dlo = ic(bg_, ag_, tg_, fg_, inverse=True)
+    w = t(synth(11, B, 3 * n_atoms), dev)
+    ((xo * w).sum() + dlo.sum()).backward()
+    gb, ga, gt, gf = oracle.ic_ic2xyz_backward(bonds, angles, tors, ox, w.cpu().numpy(), np.ones(B), z, fixed, dtype=np.float64)
+    for got, want in ((bg_.grad, gb), (ag_.grad, ga), (tg_.grad, gt), (fg_.grad, gf)):
+        err = np.abs(got.cpu().numpy() - want)
+        # f32 reverse sweep over a chain of n placements: lever arms make early gradients 1e3..1e4, round-off grows with n
+        assert err.max() <= (2e-4 + 2e-6 * n_atoms) * np.abs(want).max() + 1e-4, (err.max(), np.abs(want).max())
+    # xyz -> IC backward: directional derivative against a central difference of the ORACLE's f64 forward (an f32 difference
+    # quotient of a sum over 10^4 terms is all noise)
+    x0 = xg.detach().clone().requires_grad_(True)
+    b2, a2, t2, f2, dl2 = ic(x0)
+    ((b2 * 3.0).sum() + a2.sum() + 0.1 * dl2.sum()).backward()
+    v = synth(12, B, 3 * n_atoms).astype(np.float64)
+    v /= np.linalg.norm(v)
+
+    def f(xx):
+        bb, aa, _, _, dd = oracle.ic_xyz2ic(xx, z, fixed, dtype=np.float64)
+        return float((bb * 3.0).sum() + aa.sum() + 0.1 * dd.sum())
+    x64, h = xg.cpu().numpy().astype(np.float64), 1e-6
+    fd = (f(x64 + h * v) - f(x64 - h * v)) / (2 * h)
+    an = float((x0.grad.cpu().numpy().astype(np.float64) * v).sum())
+    assert abs(fd - an) <= (2e-3 + 2e-6 * n_atoms) * abs(fd) + 1e-3, (fd, an)
