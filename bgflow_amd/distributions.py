@@ -83,6 +83,40 @@ class Sampler(torch.nn.Module):
         return self._sample_with_temperature(n_samples, temperature, *args, **kwargs)
 
 
+class _NormalEnergyFn(torch.autograd.Function):
+    """u(x) = 0.5 |x - mean|^2 / T + log Z on bgk_normal_energy; gradient w.r.t. x on bgk_normal_energy_backward"""
+
+    @staticmethod
+    def forward(ctx, x, mean, temperature, log_z):
+        from . import _lib
+        x2, ldx = _lib.rowmajor(x)
+        if mean is not None:
+            mean = mean.detach().to(device=x.device).contiguous()
+        B, d = x2.shape
+        u = torch.empty(B, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            st = _lib.lib().bgk_normal_energy(_lib.ptr(x2), ldx, _lib.ptr(mean), d, B, temperature, log_z, _lib.ptr(u),
+                                              _lib.stream_ptr(x.device))
+        _lib.check(st, "bgk_normal_energy")
+        ctx.save_for_backward(x2, mean if mean is not None else x2.new_empty(0))
+        ctx.cfg = (ldx, mean is not None, temperature)
+        return u[:, None]
+
+    @staticmethod
+    def backward(ctx, g_u):
+        from . import _lib
+        x2, mean = ctx.saved_tensors
+        ldx, has_mean, temperature = ctx.cfg
+        B, d = x2.shape
+        g = g_u.reshape(-1).to(torch.float32).contiguous()
+        g_x = torch.empty((B, d), dtype=torch.float32, device=x2.device)
+        with torch.cuda.device(x2.device):
+            st = _lib.lib().bgk_normal_energy_backward(_lib.ptr(x2), ldx, _lib.ptr(mean) if has_mean else None, d, B, temperature,
+                                                       _lib.ptr(g), _lib.ptr(g_x), d, _lib.stream_ptr(x2.device))
+        _lib.check(st, "bgk_normal_energy_backward")
+        return g_x, None, None, None
+
+
 class NormalDistribution(Energy, Sampler):
     """Isotropic (optionally shifted) normal; ``cov`` support is limited to diagonalisable
     covariances like the reference (normal.py:17-92)."""
@@ -116,6 +150,11 @@ class NormalDistribution(Energy, Sampler):
         return log_z
 
     def energy(self, x, temperature=1.0):
+        if (not self._has_cov and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and self._mean.dtype == torch.float32
+                and isinstance(temperature, (int, float)) and temperature > 0 and x.shape[0] > 0):
+            # one launch (bgk_normal_energy) instead of sub / div / pow / sum / add, one for the gradient instead of five
+            mean = self._mean if self._has_mean else None
+            return _NormalEnergyFn.apply(x, mean, float(temperature), float(self.dim / 2 * np.log(2 * np.pi * temperature)))
         if self._has_mean:
             x = x - self._mean
         if self._has_cov:

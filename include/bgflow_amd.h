@@ -337,6 +337,15 @@ int bgk_grad_nan_flag(const float* g, int64_t n, int32_t* flag, void* stream);
 int bgk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, const int32_t* skip_flag, int32_t* skipped_count, void* stream);
 
+/* Energy of the isotropic, optionally shifted normal distribution (bgflow/distribution/normal.py:61-72, NormalDistribution._energy
+ * without `cov`; the target end of the KL integrand u(F(z)) - log|det J|, bgflow/bg.py:13-17, for the synthetic Gaussian targets,
+ * and the prior energy of cfg 1 / cfg 2):  u[b] = 0.5 sum_j (x[b,j] - mean[j])^2 / temperature + log_z   (mean may be NULL;
+ * log_z = d / 2 log(2 pi T) from the caller), and its VJP  g_x[b,j] = g_u[b] (x[b,j] - mean[j]) / temperature. */
+int bgk_normal_energy(const float* x, int64_t ldx, const float* mean, int32_t d, int64_t B,
+                      double temperature, double log_z, float* u, void* stream);
+int bgk_normal_energy_backward(const float* x, int64_t ldx, const float* mean, int32_t d, int64_t B,
+                               double temperature, const float* g_u, float* g_x, int64_t ldg, void* stream);
+
 /* Weight and bias gradients of the conditioner MLP [n_in, 128, 128, P] of one coupling layer (autograd of nn/dense.py:47-48 in
  * the training step: dW = g^T h, db = sum over the batch of g) from the tensors bgk_rqs_backward / bgk_dense_backward_dx wrote:
  *   (g_params [B, P], h1) -> gW2 [P, 128], gb2 [P];  (g_z1, h0) -> gW1 [128, 128], gb1 [128];

@@ -1511,3 +1511,31 @@ def test_relative_ic_large_molecules(hip_lib, oracle, dev, n_atoms):
     fd = (f(x64 + h * v) - f(x64 - h * v)) / (2 * h)
     an = float((x0.grad.cpu().numpy().astype(np.float64) * v).sum())
     assert abs(fd - an) <= (2e-3 + 2e-6 * n_atoms) * abs(fd) + 1e-3, (fd, an)
+
+
+@pytest.mark.parametrize("d,B,has_mean,temperature", [(66, 4133, True, 1.0), (64, 1, False, 1.0), (2, 1000, True, 2.5), (9, 257, False, 0.5)])
+def test_normal_energy_kernel(hip_lib, dev, d, B, has_mean, temperature):
+    """bgk_normal_energy / _backward (target end of the KL integrand, normal.py:61-72) against the torch op chain in f64"""
+    import bgflow_amd as bg
+    g = torch.Generator(device=dev).manual_seed(d + B)
+    mean = torch.randn(d, device=dev, generator=g) if has_mean else None
+    dist = bg.NormalDistribution(d, mean).to(dev)
+    x = (3.0 * torch.randn(B, d, device=dev, generator=g)).requires_grad_(True)
+    u = dist.energy(x, temperature=temperature)
+    w = torch.randn(B, 1, device=dev, generator=g)
+    (u * w).sum().backward()
+    x64 = x.detach().double().requires_grad_(True)
+    xc = x64 - mean.double() if has_mean else x64
+    u64 = 0.5 * (xc / temperature ** 0.5).pow(2).sum(-1, keepdim=True) + d / 2 * np.log(2 * np.pi * temperature)
+    (u64 * w.double()).sum().backward()
+    assert u.shape == (B, 1)
+    np.testing.assert_allclose(u.detach().cpu().numpy(), u64.detach().cpu().numpy(), rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), x64.grad.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    # a strided view (columns of a wider matrix) and the no-grad path
+    wide = torch.randn(B, d + 5, device=dev, generator=g)
+    with torch.no_grad():
+        u2 = dist.energy(wide[:, 2:2 + d], temperature=temperature)
+        ref = dist.energy(wide[:, 2:2 + d].double().cpu(), temperature=temperature) if False else None
+    v = wide[:, 2:2 + d].double() - (mean.double() if has_mean else 0.0)
+    np.testing.assert_allclose(u2.cpu().numpy(), (0.5 * v.pow(2).sum(-1, keepdim=True) / temperature + d / 2 * np.log(2 * np.pi * temperature)).cpu().numpy(),
+                               rtol=2e-6, atol=1e-5)
