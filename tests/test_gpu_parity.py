@@ -615,10 +615,10 @@ def test_rqs_backward_kernel(hip_lib, oracle, golden, dev, name, d, circ, invers
     assert np.abs(gp - G[tag + "_gp64"]).max() <= 1e-4 * np.abs(G[tag + "_gp64"]).max()
 
 
-@pytest.mark.parametrize("Kb", [4, 12, 16, 32])
+@pytest.mark.parametrize("Kb", [4, 12, 16, 32, 6, 10])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_rqs_backward_kernel_other_bin_counts(hip_lib, oracle, dev, Kb, inverse):
-    """bgk_rqs_backward for K != 8 against (i) the oracle's analytic VJP and (ii) torch autograd (f64) through the torch
+    """bgk_rqs_backward for K != 8 (K = 6, 10: no kernel instance -> autograd through the same map on device torch ops) against (i) the oracle's analytic VJP and (ii) torch autograd (f64) through the torch
     restatement of the nflows spline (oracle/torch_flow.py::rq_spline) -- an independent derivation"""
     import bgflow_amd as bg
     from oracle import torch_flow as tf
