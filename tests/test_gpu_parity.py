@@ -638,8 +638,9 @@ def test_rqs_backward_kernel_other_bin_counts(hip_lib, oracle, dev, Kb, inverse)
     ((z * t(a, dev)).sum() + (dl * t(bw, dev)).sum()).backward()
     gy, gp = yy.grad.cpu().numpy(), p.grad.cpu().numpy()
     gyo, gpo = oracle.rqs_backward(y, params, a, bw, is_circular=circ, inverse=inverse, dtype=np.float32)
-    np.testing.assert_allclose(gy, gyo, rtol=0, atol=2e-5 * np.abs(gyo).max())
-    np.testing.assert_allclose(gp, gpo, rtol=0, atol=2e-5 * np.abs(gpo).max())
+    tol = 2e-5 if Kb % 4 == 0 else 1e-4          # K = 6, 10: stock f32 torch ops (softmax / cumsum / gather) instead of the kernel
+    np.testing.assert_allclose(gy, gyo, rtol=0, atol=tol * np.abs(gyo).max())
+    np.testing.assert_allclose(gp, gpo, rtol=0, atol=tol * np.abs(gpo).max())
     # torch autograd in f64 through the same parameter unpacking as ConditionalSplineTransformer._compute_params (spline.py:109-126)
     p64 = torch.tensor(params, dtype=torch.float64, requires_grad=True)
     y64 = torch.tensor(y, dtype=torch.float64, requires_grad=True)
