@@ -172,6 +172,13 @@ def rqs_transform(y, params, nc_slot, n_bins, inverse, left, right, bottom, top,
     y2, ldy = _lib.rowmajor(y2)
     B, d = y2.shape
     P = params.shape[-1]
+    if n_bins > 64 or 4 * 4 * (P | 1) > 160 * 1024:
+        # outside the kernel's envelope (more than 64 bins, or a parameter row that leaves no room for a 4-sample LDS tile):
+        # the same map on device torch ops (differentiable by autograd; no bin-index output)
+        if want_bin_idx:
+            raise ValueError("return_bin_indices is not available for n_bins > 64 / parameter rows beyond the kernel's LDS tile")
+        out, dl = _rqs_spline_torch(y2, params.reshape(-1, P), nc_slot, (n_bins, inverse, left, right, bottom, top, settings))
+        return out.reshape(*lead, d), dl.reshape(*lead, 1)
     p2, ldp = _lib.rowmajor(params.reshape(-1, P))
     out = torch.empty((B, d), dtype=torch.float32, device=y.device)
     dlogp = torch.empty((B,), dtype=torch.float32, device=y.device)
@@ -389,7 +396,7 @@ class ConditionalSplineTransformer(Transformer):
             raise RuntimeError(
                 f"params_net output width {P} does not match 3 * n_bins * {y_dim} + {n_nc} "
                 f"(split_with_sizes in the reference, transformer/spline.py:113-117)")
-        if grad:
+        if grad and not (n_bins > 64 or 4 * 4 * (P | 1) > 160 * 1024):     # beyond the kernel envelope rqs_transform runs torch ops: plain autograd
             return _RQSFn.apply(y, params, nc_dev, n_bins, inverse, self._left, self._right, self._bottom,
                                 self._top, self._default_settings, oob)
         res = rqs_transform(y, params, nc_dev, n_bins, inverse, self._left, self._right, self._bottom,

@@ -87,6 +87,8 @@ def rqs(y, params, is_circular=False, inverse=False, left=0.0, right=1.0, bottom
     n_nc = int((slots >= 0).sum())
     P = params.shape[1]
     K = (P - n_nc) // (3 * d) if n_bins is None else n_bins
+    if K > 64:
+        raise ValueError("the C oracle holds its knot arrays on the stack (BGO_MAX_BINS = 64)")
     assert 3 * K * d + n_nc == P, f"params width {P} does not match d={d}, K={K}, n_nc={n_nc}"
     out = np.empty((B, d), dtype)
     dlogp = np.empty((B,), dtype)
@@ -116,6 +118,8 @@ def rqs_backward(y, params, g_out, g_dlogp, is_circular=False, inverse=False, le
     n_nc = int((slots >= 0).sum())
     P = params.shape[1]
     K = (P - n_nc) // (3 * d) if n_bins is None else n_bins
+    if K > 64:
+        raise ValueError("the C oracle holds its knot arrays on the stack (BGO_MAX_BINS = 64)")
     g_y = np.empty((B, d), dtype)
     g_p = np.empty((B, P), dtype)
     getattr(lib(), "bgo_rqs_backward" + sfx)(

@@ -1540,3 +1540,41 @@ def test_normal_energy_kernel(hip_lib, dev, d, B, has_mean, temperature):
     v = wide[:, 2:2 + d].double() - (mean.double() if has_mean else 0.0)
     np.testing.assert_allclose(u2.cpu().numpy(), (0.5 * v.pow(2).sum(-1, keepdim=True) / temperature + d / 2 * np.log(2 * np.pi * temperature)).cpu().numpy(),
                                rtol=2e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_spline_beyond_kernel_envelope_runs_on_torch_ops(hip_lib, dev, inverse):
+    """n_bins = 80 (> 64: no kernel) through ConditionalSplineTransformer on the device: forward and gradients from the torch-op
+    restatement in bgflow_amd/transformer.py, checked against the independent torch restatement of the nflows spline in oracle/"""
+    import bgflow_amd as bg
+    from oracle import torch_flow as tf
+    Kb, d, B = 80, 5, 64
+    circ = np.array([1, 0, 1, 0, 0], bool)
+    n_nc = int((~circ).sum())
+    P = 3 * Kb * d + n_nc
+    params, y = synth(300 + Kb, B, P, scale=0.7), synth(400 + Kb, B, d, uniform=True)
+    p = t(params, dev).requires_grad_(True)
+    yy = t(y, dev).requires_grad_(True)
+
+    class Fixed(torch.nn.Module):
+        def forward(self, x):
+            return p
+    tr = bg.ConditionalSplineTransformer(Fixed(), is_circular=torch.tensor(circ))
+    z, dl = tr(torch.zeros(B, 1, device=dev), yy, inverse=inverse)
+    (z.sum() + dl.sum()).backward()
+    p64 = torch.tensor(params, dtype=torch.float64, requires_grad=True)
+    y64 = torch.tensor(y, dtype=torch.float64, requires_grad=True)
+    w, h, sl, s_nc = torch.split(p64, [d * Kb, d * Kb, d * Kb, n_nc], dim=-1)
+    w, h, sl = (v.reshape(B, d, Kb) for v in (w, h, sl))
+    cm = torch.tensor(circ)
+    nc_full = torch.zeros(B, d, dtype=torch.float64).index_put((torch.arange(B)[:, None], torch.nonzero(~cm).reshape(1, -1)), s_nc)
+    last = torch.where(cm[None, :], sl[..., 0], nc_full)
+    st = tr._default_settings
+    out, ld = tf.rq_spline(y64.clamp(0.0, 1.0), w, h, torch.cat([sl, last[..., None]], -1), not inverse, 0.0, 1.0, 0.0, 1.0,
+                           st["min_bin_width"], st["min_bin_height"], st["min_derivative"], st.get("enable_identity_init", False))
+    (out.sum() + ld.sum()).backward()
+    assert float((z.detach().cpu().double() - out.detach()).abs().max()) < 2e-6
+    assert float((dl.detach().cpu().double().reshape(-1) - ld.detach().sum(-1)).abs().max()) < 2e-4
+    for got, want in ((yy.grad, y64.grad), (p.grad, p64.grad)):
+        err = (got.cpu().double() - want).abs()
+        assert float(err.max()) <= 1e-3 * float(want.abs().max()) and float(err.quantile(0.99)) <= 1e-4 * float(want.abs().max())
