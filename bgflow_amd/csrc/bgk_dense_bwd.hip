@@ -183,9 +183,14 @@ struct PackT {
     _Float16* out;
 };
 
-__global__ __launch_bounds__(256) void pack_t_kernel(PackT L, const float* cs, int layer) {
+/* the three layers in one launch: workgroups [first[q], first[q + 1]) pack layer q */
+struct PackTGroup { PackT L[3]; int first[4]; };
+
+__global__ __launch_bounds__(256) void pack_t_kernel(PackTGroup g, const float* cs) {
+    const int layer = (int)blockIdx.x >= g.first[2] ? 2 : ((int)blockIdx.x >= g.first[1] ? 1 : 0);
+    const PackT& L = g.L[layer];
     const int blocks = L.S * L.NT * 2 + L.NT;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)((int)blockIdx.x - g.first[layer]) * 256 + threadIdx.x;
     if (t >= (int64_t)blocks * 64) return;
     const int lane = (int)(t & 63), blk = (int)(t >> 6);
     const int i = lane & 31, kb = lane >> 5;
@@ -219,11 +224,16 @@ extern "C" int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W
     const PackT L2{W2, P, 128, 4, S2, 1, (_Float16*)T2};       /* M[hidden i][k] = W2[k][i], k = output column of the MLP */
     const PackT L1{W1, 128, 128, 4, 8, 0, (_Float16*)T1};      /* M[i][k] = W1[unit(k)][i] */
     const PackT L0{W0, 128, n_in, FT, 8, 0, (_Float16*)T0};    /* M[feature i][k] = W0[unit(k)][i] */
-    const PackT* Ls[3] = {&L0, &L1, &L2};
+    PackTGroup g;
+    g.L[0] = L0; g.L[1] = L1; g.L[2] = L2;
+    int n_wg = 0;
     for (int l = 0; l < 3; ++l) {
-        const int64_t total = (int64_t)(Ls[l]->S * Ls[l]->NT * 2 + Ls[l]->NT) * 64;
-        hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *Ls[l], cs, l);
+        const int64_t total = (int64_t)(g.L[l].S * g.L[l].NT * 2 + g.L[l].NT) * 64;
+        g.first[l] = n_wg;
+        n_wg += (int)((total + 255) / 256);
     }
+    g.first[3] = n_wg;
+    hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, g, cs);
     return bgk_launch_status("bgk_pack_dense_h2_t");
 }
 

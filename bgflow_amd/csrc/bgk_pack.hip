@@ -71,9 +71,14 @@ __global__ void pack_scale_kernel(PackLayer L0, PackLayer L1, PackLayer L2, floa
     cs[2 * layer + 1] = ldexpf(1.0f, -e);
 }
 
-__global__ __launch_bounds__(256) void pack_blocks_kernel(PackLayer L, const float* cs, int layer) {
+/* all three layers in one launch: workgroups [first[q], first[q + 1]) pack layer q */
+struct PackGroup { PackLayer L[3]; int first[4]; };
+
+__global__ __launch_bounds__(256) void pack_blocks_kernel(PackGroup g, const float* cs) {
+    const int layer = (int)blockIdx.x >= g.first[2] ? 2 : ((int)blockIdx.x >= g.first[1] ? 1 : 0);
+    const PackLayer& L = g.L[layer];
     const int blocks_per_group = L.S * L.NT * 2 + (L.natural ? 0 : L.NT);
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = (int64_t)((int)blockIdx.x - g.first[layer]) * 256 + threadIdx.x;
     const int64_t total = (int64_t)L.n_groups * blocks_per_group * 64;
     if (t >= total) return;
     const int lane = (int)(t & 63);
@@ -114,10 +119,19 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(PackLayer L, const flo
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
 }
 
-void launch_pack(const PackLayer& L, const float* cs, int layer, hipStream_t st) {
-    const int blocks_per_group = L.S * L.NT * 2 + (L.natural ? 0 : L.NT);
-    const int64_t total = (int64_t)L.n_groups * blocks_per_group * 64;
-    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, L, cs, layer);
+void launch_pack(const PackLayer& L0, const PackLayer& L1, const PackLayer& L2, const float* cs, hipStream_t st) {
+    PackGroup g;
+    g.L[0] = L0; g.L[1] = L1; g.L[2] = L2;
+    int blocks = 0;
+    for (int q = 0; q < 3; ++q) {
+        const PackLayer& L = g.L[q];
+        const int blocks_per_group = L.S * L.NT * 2 + (L.natural ? 0 : L.NT);
+        const int64_t total = (int64_t)L.n_groups * blocks_per_group * 64;
+        g.first[q] = blocks;
+        blocks += (int)((total + 255) / 256);
+    }
+    g.first[3] = blocks;
+    hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, cs);
 }
 
 }  // namespace
@@ -139,8 +153,6 @@ extern "C" int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in,
     if (hipMemsetAsync(cs, 0, 6 * sizeof(float), st) != hipSuccess) { bgk_set_error("bgk_pack_dense_h2: memset failed"); return BGK_EINVAL; }
     hipLaunchKernelGGL(pack_max_kernel, dim3(3 * PACK_SPLIT), dim3(256), 0, st, L0, L1, L2, cs);
     hipLaunchKernelGGL(pack_scale_kernel, dim3(1), dim3(64), 0, st, L0, L1, L2, cs);
-    launch_pack(L0, cs, 0, st);
-    launch_pack(L1, cs, 1, st);
-    launch_pack(L2, cs, 2, st);
+    launch_pack(L0, L1, L2, cs, st);
     return bgk_launch_status("bgk_pack_dense_h2");
 }
