@@ -713,7 +713,8 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
         z0 = torch.empty((B, 128), dtype=torch.float32, device=dev)
         z1 = torch.empty((B, 128), dtype=torch.float32, device=dev)
-        params = torch.empty((B, P), dtype=torch.float32, device=dev)
+        ldp = (P + 3) // 4 * 4                       # 16-byte aligned rows for the backward kernels' vector loads
+        params = torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :P]
         left, right, bottom, top, s = tcfg
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_coupling_rqs_dense_h2_train(
@@ -721,7 +722,7 @@ class _FusedSplineTrainFn(torch.autograd.Function):
                 _lib.ptr(plan.get("cs")), 128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
                 left, right, bottom, top, s["min_bin_width"], s["min_bin_height"], s["min_derivative"],
                 int(s.get("enable_identity_init", False)), _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.ptr(oob),
-                _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), P, _lib.ptr(plan["src_col_dev"]), _lib.stream_ptr(dev))
+                _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), ldp, _lib.ptr(plan["src_col_dev"]), _lib.stream_ptr(dev))
         _lib.check(st, "bgk_coupling_rqs_dense_h2_train")
         ctx.save_for_backward(x, y, W0, W1, W2, z0, z1, params, nc_dev)
         ctx.params = (W0, b0, W1, b1, W2, b2)   # the nn.Parameters themselves (flat-bucket gradient destinations hang on them)

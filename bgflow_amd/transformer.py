@@ -221,13 +221,16 @@ def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp):
     g_out2 = g_out.reshape(-1, d).contiguous()
     g_dl = g_dlogp.reshape(-1).contiguous()
     g_y = torch.empty((B, d), dtype=torch.float32, device=y.device)
-    g_p = torch.empty((B, P), dtype=torch.float32, device=y.device)
+    # rows padded to a multiple of 4 floats: the 16-byte accesses of this kernel and of bgk_dense_backward_dx stay aligned
+    # (P = 425 gives 1700-byte rows otherwise)
+    ldgp = (P + 3) // 4 * 4
+    g_p = torch.empty((B, ldgp), dtype=torch.float32, device=y.device)[:, :P]
     with torch.cuda.device(y.device):
         st = _lib.lib().bgk_rqs_backward(
             _lib.ptr(y2), ldy, _lib.ptr(p2), ldp, P, _lib.ptr(nc_slot), B, d, n_bins, int(inverse),
             left, right, bottom, top, settings["min_bin_width"], settings["min_bin_height"],
             settings["min_derivative"], int(settings.get("enable_identity_init", False)),
-            _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), P,
+            _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), ldgp,
             _lib.stream_ptr(y.device))
     if st == -2:       # a bin count the backward kernel is not instantiated for: autograd through the same map on device torch ops
         gy, gp = _rqs_backward_torch(y2, p2, nc_slot, cfg, g_out2, g_dl)
