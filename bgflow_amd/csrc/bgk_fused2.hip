@@ -523,13 +523,31 @@ __device__ __forceinline__ void chunk_to_lds(const f32x16 (&h)[4], float* s_p, i
 }
 
 /* chunk c: registers -> LDS (transposition), then the spline of this chunk threaded through the next chunk's GEMM */
+#if BGK_V2_SAVE
+/* parameters of chunk c (in s_p; UNSCALED accumulator values: true parameter = value * c2) -> params[b][col]: lane = packed row (two
+ * passes of 64), one sample row per store instruction: contiguous 32-byte runs (the 8 bins of a (dim, component)).  Called right
+ * after the chunk reached LDS and AFTER the next GEMM's first operand loads were requested: vmcnt is one in-order counter for
+ * loads and stores on gfx9, so a load requested behind these 64 stores would wait for every one of them to be acknowledged. */
+__device__ __forceinline__ void save_chunk_params(const V2Args& a, const float* s_p, int c, int lane, int64_t b0, int rows) {
+    const int col_lo = a.src_col[c * 128 + lane], col_hi = a.src_col[c * 128 + 64 + lane];
+    for (int jj = 0; jj < rows; ++jj) {
+        float* prow = a.params + (b0 + jj) * a.ldp;
+        if (col_lo >= 0) prow[col_lo] = s_p[lane * ST + jj] * a.c2;
+        if (col_hi >= 0) prow[col_hi] = s_p[(64 + lane) * ST + jj] * a.c2;
+    }
+}
+#endif
+
 template <int INV, int NT>
 __device__ __forceinline__ void chunk_piped(const V2Args& a, const SpK& k, float* s_p, float* s_y, int c, int hh, int j, int rows,
                                             float& run, int& oob_local, int (&bins)[3], f32x16 (&h)[4], const BFrag& bf,
-                                            TFrag (&ring)[RD], unsigned voff) {
+                                            TFrag (&ring)[RD], unsigned voff, int64_t b0) {
     Live<NT> g{h, bf, a.A2 + (size_t)(c + 1) * GBLK * 64, voff, ring};
     g.start();                       /* the next GEMM's first A fragments travel while this chunk goes through LDS */
     chunk_to_lds(h, s_p, hh, j);
+#if BGK_V2_SAVE
+    save_chunk_params(a, s_p, c, (int)threadIdx.x & 63, b0, rows);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #if (BGK_V2_ABL & 1)
     g.template events<0, Live<NT>::NEV>();
@@ -649,21 +667,22 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         }
     }
 
-#if BGK_V2_SAVE
-    /* z0 = layer-0 pre-activations, as full rows through the (now free) parameter-chunk buffer: [32][132] = 128 * ST floats */
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h[m][r] *= a.c0;
-    h2_store_rows128(h, a.z0, s_p, b0, rows, lane);
-    const float c0_act = 1.0f;
-#else
-    const float c0_act = a.c0;
-#endif
     /* ---- layer 1: events of k-steps 2t, 2t + 1 behind the activation of tile t + 1 ---- */
     {
         Live<4> g{acc, bf, a.A1, voff, ring};
         g.start();
+#if BGK_V2_SAVE
+        /* z0 = layer-0 pre-activations, as full rows through the (now free) parameter-chunk buffer: [32][132] = 128 * ST floats;
+         * after the ring start: the first MFMAs then wait for their operand loads only, not for these 16 stores (vmcnt is in order) */
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[m][r] *= a.c0;
+        h2_store_rows128(h, a.z0, s_p, b0, rows, lane);
+        const float c0_act = 1.0f;
+#else
+        const float c0_act = a.c0;
+#endif
         NoLive none;
         act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, h[0], c0_act, bf);
         __builtin_amdgcn_sched_barrier(0);
@@ -673,22 +692,23 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         __builtin_amdgcn_sched_barrier(0);
         g.template events<72, Live<4>::NEV>();
     }
-#if BGK_V2_SAVE
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] *= a.c1;
-    h2_store_rows128(acc, a.z1, s_p, b0, rows, lane);
-    const float c1_act = 1.0f;
-#else
-    const float c1_act = a.c1;
-#endif
+
     /* ---- layer 2, chunk 0: the same behind the activation of the layer-1 tiles ---- */
     float run = 0.0f;
     int oob_local = 0;
     {
         Live<4> g{h, bf, a.A2, voff, ring};
         g.start();
+#if BGK_V2_SAVE
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] *= a.c1;
+        h2_store_rows128(acc, a.z1, s_p, b0, rows, lane);
+        const float c1_act = 1.0f;
+#else
+        const float c1_act = a.c1;
+#endif
         NoLive none;
         act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, acc[0], c1_act, bf);
         __builtin_amdgcn_sched_barrier(0);
@@ -703,12 +723,15 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         int bins[3] = {0, 0, 0};
         const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
         if (c + 2 < a.n_chunks || (c + 2 == a.n_chunks && a.last_tiles > 2)) {
-            chunk_piped<INV, 4>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff);
+            chunk_piped<INV, 4>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff, b0);
         } else if (c + 2 == a.n_chunks) {
-            chunk_piped<INV, 2>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff);
+            chunk_piped<INV, 2>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff, b0);
         } else {
             NoLive none;
             chunk_to_lds(h, s_p, hh, j);
+#if BGK_V2_SAVE
+            save_chunk_params(a, s_p, c, lane, b0, rows);
+#endif
 #if (BGK_V2_ABL & 1)
             run += s_p[(threadIdx.x & 127) * ST + j];
 #else
@@ -724,18 +747,6 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
                 if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
             }
         }
-#if BGK_V2_SAVE
-        {   /* parameters of this chunk (still in s_p; the chunk holds UNSCALED accumulator values: true parameter = value * c2)
-             * -> params[b][col]: lane = packed row (two passes of 64), one sample row per store instruction: contiguous 32-byte
-             * runs (the 8 bins of a (dim, component)) */
-            const int col_lo = a.src_col[c * 128 + lane], col_hi = a.src_col[c * 128 + 64 + lane];
-            for (int jj = 0; jj < rows; ++jj) {
-                float* prow = a.params + (b0 + jj) * a.ldp;
-                if (col_lo >= 0) prow[col_lo] = s_p[lane * ST + jj] * a.c2;
-                if (col_hi >= 0) prow[col_hi] = s_p[(64 + lane) * ST + jj] * a.c2;
-            }
-        }
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
