@@ -1236,6 +1236,10 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
                                                act, y, ldy, B, d, circ_mask, inverse, left, right, bottom, top, min_bin_width,
                                                min_bin_height, min_derivative, identity_init, out, ldo, dlogp, accumulate, bin_idx,
                                                oob_count, stream);
+    if (bgk_h2_variant == 2 && z0 == nullptr && operand_dtype == 1 && K == KB)   /* reduced-precision bf16 mode on the second-generation kernel */
+        return bgk_launch_rqs_dense_h2v2_bf16(what, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, act, y, ldy, B, d, circ_mask,
+                                              inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
+                                              identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream);
     if (bgk_h2_variant == 2 && z0 == nullptr && operand_dtype == 0 && K == KB)   /* split-f16 inference: the second-generation kernel */
         return bgk_launch_rqs_dense_h2v2(what, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, act, y, ldy, B, d, circ_mask,
                                          inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,

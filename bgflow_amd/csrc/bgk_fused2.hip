@@ -37,6 +37,15 @@
 #include "bgk_mfma_h2.h"             /* h2_store_rows128 */
 #define coupling_rqs_dense_h2v2_kernel coupling_rqs_dense_h2v2_train_kernel
 #endif
+#ifndef BGK_V2_BF16
+#define BGK_V2_BF16 0                /* 1 (bgk_fused2_bf16.hip): REDUCED-PRECISION mode "bf16" -- bf16 weights and GEMM inputs, ONE
+                                      * v_mfma_f32_32x32x16_bf16 per product instead of the three f16 ones; spline arithmetic unchanged */
+#endif
+#if BGK_V2_BF16
+#define coupling_rqs_dense_h2v2_kernel coupling_rqs_dense_h2v2_bf16_kernel
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#endif
+constexpr int NPROD = BGK_V2_BF16 ? 1 : 3;      /* matrix instructions per (k-step, tile) */
 
 namespace {
 
@@ -129,7 +138,7 @@ __device__ __forceinline__ void ld_pair(u32x4& hi, u32x4& lo, const uint4* base,
 template <int NT>
 struct Live {
     static constexpr int NTS = KS * NT;           /* product tile-steps */
-    static constexpr int NEV = 3 * NTS + NT;      /* events */
+    static constexpr int NEV = NPROD * NTS + NT;  /* events */
     f32x16 (&out)[4];
     const BFrag& b;
     const uint4* W;
@@ -154,7 +163,9 @@ struct Live {
 #endif
         if constexpr (T < NTS) {
             constexpr int s = T / NT, m = T % NT;
-#if BGK_V2_BUF
+#if BGK_V2_BF16
+            ring[T % RD].hi = blk<(s * 4 + m) * 2>();          /* the bf16 values sit in the "hi" blocks of the same layout */
+#elif BGK_V2_BUF
             ring[T % RD].hi = blk<(s * 4 + m) * 2>();
             ring[T % RD].lo = blk<(s * 4 + m) * 2 + 1>();
 #else
@@ -179,6 +190,23 @@ struct Live {
     template <int E>
     __device__ __forceinline__ void event() {
         __builtin_amdgcn_sched_barrier(0);      /* pin the MFMA and the ring refill: the scheduler would sink the loads to their uses */
+#if BGK_V2_BF16
+        if constexpr (E < NTS) {
+            constexpr int T = E, s = T / NT, m = T % NT;
+            const s16x8 a = __builtin_bit_cast(s16x8, ring[T % RD].hi), bb = __builtin_bit_cast(s16x8, b.hi[s]);
+            if constexpr (s == 0) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, z, 0, 0, 0);
+            } else {
+                out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, out[m], 0, 0, 0);
+            }
+            load<T + RD>();
+        } else if constexpr (E < NEV) {
+            constexpr int m = E - NTS, T = NTS + m;
+            const s16x8 one2 = {(short)0x3f80, (short)0x3f80, 0, 0, 0, 0, 0, 0};
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, ring[T % RD].hi), one2, out[m], 0, 0, 0);
+        }
+#else
         if constexpr (E < 3 * NTS) {
             constexpr int T = E / 3, p = E % 3, s = T / NT, m = T % NT;
             const TFrag& f = ring[T % RD];
@@ -196,6 +224,7 @@ struct Live {
             const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
             out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[T % RD].hi), one2, out[m], 0, 0, 0);
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int E0, int E1>
@@ -253,7 +282,14 @@ __device__ __forceinline__ void act_split_pair(H& hk, const f32x16& t, float c, 
         a0 = __builtin_fminf(a0, 65000.0f); a1 = __builtin_fminf(a1, 65000.0f);
     }
     constexpr int s = 2 * T + (r >> 3), e = r & 7;
-#if BGK_V2_ASMSPLIT
+#if BGK_V2_BF16
+    typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const bf2v pb = __builtin_convertvector((f2v){a0, a1}, bf2v);           /* v_cvt_pk_bf16_f32, round to nearest even */
+    const h2v ph = __builtin_bit_cast(h2v, pb);
+    bf.hi[s][e] = ph[0]; bf.hi[s][e + 1] = ph[1];
+#elif BGK_V2_ASMSPLIT
     /* hi pair = v_cvt_pk_f16_f32 (RNE); lo = f16(a - hi) by the mixed-precision FMA reading hi as an f16 operand and writing one half
      * of the destination: a - hi is exact in f32, so the single rounding equals (_Float16)(a - (float)hi).  3 instructions per pair. */
     unsigned uh, ul;
@@ -651,6 +687,17 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
             fa[m][0] = a.A0[((s * 4 + m) * 2 + 0) * 64 + lane];
             fa[m][1] = a.A0[((s * 4 + m) * 2 + 1) * 64 + lane];
         }
+#if BGK_V2_BF16
+        s16x8 bb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = s_p[(16 * s + 8 * hh + e) * SROW + j];
+            bb[e] = __builtin_bit_cast(short, (__bf16)v);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            h[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, fa[m][0]), bb, h[m], 0, 0, 0);
+#else
         h16x8 bhi, blo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -665,6 +712,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
             h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[m][0]), blo, h[m], 0, 0, 0);
             h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[m][0]), bhi, h[m], 0, 0, 0);
         }
+#endif
     }
 
     /* ---- layer 1: events of k-steps 2t, 2t + 1 behind the activation of tile t + 1 ---- */
@@ -690,7 +738,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, h[2], c0_act, bf);
         act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, h[3], c0_act, bf);
         __builtin_amdgcn_sched_barrier(0);
-        g.template events<72, Live<4>::NEV>();
+        g.template events<(72 * Live<4>::NEV) / 100, Live<4>::NEV>();
     }
 
     /* ---- layer 2, chunk 0: the same behind the activation of the layer-1 tiles ---- */
@@ -716,7 +764,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, acc[2], c1_act, bf);
         act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, acc[3], c1_act, bf);
         __builtin_amdgcn_sched_barrier(0);
-        g.template events<72, Live<4>::NEV>();
+        g.template events<(72 * Live<4>::NEV) / 100, Live<4>::NEV>();
     }
     /* ---- chunks: h -> LDS; spline(c) threaded through GEMM(c + 1) ---- */
     for (int c = 0; c < a.n_chunks; ++c) {
@@ -783,13 +831,15 @@ uint32_t magic_div(int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) /
 
 }  // namespace
 
-#if !BGK_V2_SAVE
+#if !BGK_V2_SAVE && !BGK_V2_BF16
 int bgk_h2_variant = 2;
 #endif
 
 #if BGK_V2_SAVE
 int bgk_launch_rqs_dense_h2v2_train(const char* what, float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col,
                                     const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+#elif BGK_V2_BF16
+int bgk_launch_rqs_dense_h2v2_bf16(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
 #else
 int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
 #endif
