@@ -786,8 +786,8 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
         return None
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
     if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device \
-            or plan["n_bins"] != 8:           # the training variant (saved pre-activations + parameters) exists for K = 8
-        return None
+            or plan["n_bins"] not in (4, 8, 16):   # the training variant (saved pre-activations + parameters): K = 8 on the
+        return None                                # second-generation kernel, K = 4 | 16 on the first-generation one
     _lib.require_hip(x, y)
     if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:
         plan["src_col_dev"] = _src_col_table(y.shape[-1], plan["n_bins"], nc_host, y.device)

@@ -1083,6 +1083,33 @@ def test_fused_training_forward_other_activations(hip_lib, dev, act):
 
 
 
+@pytest.mark.parametrize("K", [4, 16])
+@pytest.mark.parametrize("circular,inverse", [(False, False), (True, True)])
+def test_fused_training_forward_other_bin_counts(hip_lib, dev, K, circular, inverse):
+    """the differentiable one-launch forward for K = 4 | 16 bins (first-generation kernel with the saved pre-activations and
+    parameters) against the generic autograd path: outputs and every gradient (`conditioner_factory.py:76-80` lets users pick K)"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    B, d, d_c = 643, 9, 17
+    res = {}
+    for fused in (True, False):
+        net = bg.DenseNet([2 * d_c if circular else d_c, 128, 128, 3 * K * d + (0 if circular else d)], torch.nn.SiLU())
+        if circular:
+            net = bg.WrapPeriodic(net, indices=np.arange(d_c))
+        tr = bg.ConditionalSplineTransformer(net, is_circular=circular)
+        layer = hash_init_(bg.CouplingFlow(tr, transformed_indices=(1,), cond_indices=(0,))).to(dev)
+        tr.allow_fused = fused
+        x = t(synth(21, B, d_c, uniform=True), dev).requires_grad_(True)
+        y = t(synth(22, B, d, uniform=True), dev).requires_grad_(True)
+        xo, yo, dl = layer(x, y, inverse=inverse)
+        ((yo * t(synth(23, B, d), dev)).sum() + (dl * t(synth(24, B, 1), dev)).sum()).backward()
+        res[fused] = [yo.detach(), dl.detach(), x.grad, y.grad] + [p.grad for p in layer.parameters()]
+        if fused:
+            assert tr._fused_cache.get("src_col_dev") is not None and tr._fused_cache.get("n_bins") == K, "the fused training path must have run"
+    for a, b in zip(res[True], res[False]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=3e-4 * float(b.abs().max()) + 2e-5)
+
+
 def test_stochastic_augmentation_on_gpu(hip_lib, golden, dev):
     """a17: the augmentation layer of cfg 5 on device tensors against the reference golden (augment.py:27-55)"""
     from test_host_logic import _check_augmentation
