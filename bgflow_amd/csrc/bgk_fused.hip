@@ -1219,9 +1219,9 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
               float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col, void* stream) {
     BGK_CHECK_ARG(cond && A0p && A1p && A2p && y && out && dlogp, "%s: null pointer", what);
     BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "%s: bad sizes", what);
-    const bool other_k = (K == 4 || K == 16) && operand_dtype == 0;     /* K != 8: split-f16 only (inference and training forward) */
+    const bool other_k = (K == 4 || K == 12 || K == 16 || K == 32) && operand_dtype == 0;     /* K != 8: split-f16 only (inference and training forward) */
     if (H0 != HID || H1 != HID || (K != KB && !other_k) || d > 64 || act < 1 || act > 3) {
-        bgk_set_error("%s: only hidden=(128,128), n_bins=8 (4 | 16: inference in split-f16 form), d<=64, act in {SiLU,ReLU,Tanh} are fused "
+        bgk_set_error("%s: only hidden=(128,128), n_bins=8 (4 | 12 | 16 | 32: split-f16 form only), d<=64, act in {SiLU,ReLU,Tanh} are fused "
                       "(got H0=%d H1=%d K=%d d=%d act=%d)", what, H0, H1, K, d, act);
         return BGK_EUNSUPPORTED;
     }
@@ -1277,8 +1277,9 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
 #define BGK_LAUNCH2(A, I) do { if (save) BGK_LAUNCH(A, I, true, false); else if (operand_dtype == 1) BGK_LAUNCH(A, I, false, true); \
                                else BGK_LAUNCH(A, I, false, false); } while (0)
 #define BGK_LAUNCHK(A, I, S, KK) hipLaunchKernelGGL((coupling_rqs_dense_h2_kernel<A, I, S, false, KK>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
-#define BGK_LAUNCHK2(A, I) do { if (K == 4) { if (save) BGK_LAUNCHK(A, I, true, 4); else BGK_LAUNCHK(A, I, false, 4); } \
-                                else { if (save) BGK_LAUNCHK(A, I, true, 16); else BGK_LAUNCHK(A, I, false, 16); } } while (0)
+#define BGK_LAUNCHK3(A, I, KK) do { if (save) BGK_LAUNCHK(A, I, true, KK); else BGK_LAUNCHK(A, I, false, KK); } while (0)
+#define BGK_LAUNCHK2(A, I) do { if (K == 4) BGK_LAUNCHK3(A, I, 4); else if (K == 12) BGK_LAUNCHK3(A, I, 12); \
+                                else if (K == 16) BGK_LAUNCHK3(A, I, 16); else BGK_LAUNCHK3(A, I, 32); } while (0)
     if (K != KB) {
         if (act == 1) { if (inverse) BGK_LAUNCHK2(1, 1); else BGK_LAUNCHK2(1, 0); }
         else if (act == 2) { if (inverse) BGK_LAUNCHK2(2, 1); else BGK_LAUNCHK2(2, 0); }
@@ -1288,6 +1289,7 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     else if (act == 2) { if (inverse) BGK_LAUNCH2(2, 1); else BGK_LAUNCH2(2, 0); }
     else { if (inverse) BGK_LAUNCH2(3, 1); else BGK_LAUNCH2(3, 0); }
 #undef BGK_LAUNCHK2
+#undef BGK_LAUNCHK3
 #undef BGK_LAUNCHK
 #undef BGK_LAUNCH2
 #undef BGK_LAUNCH

@@ -526,8 +526,8 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     n_bins = (P - n_nc) // (3 * y_dim)
     if 3 * n_bins * y_dim + n_nc != P:
         return None
-    if n_bins != 8 and not (n_bins in (4, 16) and mode == "f16x2"):
-        return None            # K = 4 | 16: inference in split-f16 form only (bgk_coupling_rqs_dense_h2); anything else: generic path
+    if n_bins != 8 and not (n_bins in (4, 12, 16, 32) and mode == "f16x2"):
+        return None            # K = 4 | 12 | 16 | 32: split-f16 form only (first-generation kernel); anything else: generic path
     d_c = l0.in_features // 2 if periodic else l0.in_features
     if periodic:
         idx = np.arange(d_c)[net.indices] if not isinstance(net.indices, slice) or net.indices != slice(None) else np.arange(d_c)
@@ -786,8 +786,8 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
         return None
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
     if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device \
-            or plan["n_bins"] not in (4, 8, 16):   # the training variant (saved pre-activations + parameters): K = 8 on the
-        return None                                # second-generation kernel, K = 4 | 16 on the first-generation one
+            or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
+        return None                                        # second-generation kernel, the others on the first-generation one
     _lib.require_hip(x, y)
     if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:
         plan["src_col_dev"] = _src_col_table(y.shape[-1], plan["n_bins"], nc_host, y.device)

@@ -485,7 +485,7 @@ def test_fused_split_f16_layer_vs_oracle(hip_lib, dev, kind, inverse, B, generat
     assert n_ties <= max(2, res["f16x2"][2].size // 10000)
 
 
-@pytest.mark.parametrize("K", [4, 16])
+@pytest.mark.parametrize("K", [4, 12, 16, 32])
 @pytest.mark.parametrize("kind", ["T|F", "F|T", "B|A"])
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("B", [31, 4133])
@@ -1083,7 +1083,7 @@ def test_fused_training_forward_other_activations(hip_lib, dev, act):
 
 
 
-@pytest.mark.parametrize("K", [4, 16])
+@pytest.mark.parametrize("K", [4, 12, 16, 32])
 @pytest.mark.parametrize("circular,inverse", [(False, False), (True, True)])
 def test_fused_training_forward_other_bin_counts(hip_lib, dev, K, circular, inverse):
     """the differentiable one-launch forward for K = 4 | 16 bins (first-generation kernel with the saved pre-activations and
