@@ -70,8 +70,11 @@ constexpr int GBLK = KS * 8 + 4;      /* 1 KiB blocks per packed 128-row GEMM in
 #ifndef BGK_V2_ASMSPLIT
 #define BGK_V2_ASMSPLIT 1            /* f16 hi / lo split of the activations: v_cvt_pk_f16_f32 + 2 x v_fma_mix (3 instructions per pair) */
 #endif
+#ifndef BGK_V2_ACT2
+#define BGK_V2_ACT2 1                /* hidden activations: the two values of a pair interleaved (0: one chain after the other) */
+#endif
 #ifndef BGK_V2_KARG
-#define BGK_V2_KARG 1
+#define BGK_V2_KARG 2                /* spline constants: 0 SGPR-resident, 1 scalar loads at their uses, 2 per direction (see rqs_fast) */
 #endif
 #ifndef BGK_V2_RD
 #define BGK_V2_RD 4
@@ -274,10 +277,31 @@ __device__ __forceinline__ float act_hw(float x) {
 template <int ACT, int T, int P, class H>
 __device__ __forceinline__ void act_split_pair(H& hk, const f32x16& t, float c, BFrag& bf) {
     constexpr int r = 2 * P;
+#if BGK_V2_ACT2 && !(BGK_V2_ABL & 2)
+    /* both values of the pair advance together: exp2 of both | MFMA | reciprocals + products of both | MFMA.  The two chains are
+     * independent, so no consumer sits directly behind its transcendental (no hazard nop, no wait for the transcendental's latency) */
+    float a0, a1;
+    if constexpr (ACT == 2) {
+        a0 = t[r] * c; a1 = t[r + 1] * c;
+        hk.template at<3 * P>();
+        a0 = a0 > 0.0f ? a0 : 0.0f; a1 = a1 > 0.0f ? a1 : 0.0f;
+        hk.template at<3 * P + 1>();
+    } else {
+        const float x0 = t[r] * c, x1 = t[r + 1] * c;
+        constexpr float kk = ACT == 1 ? -1.44269504088896341f : 2.88539008177792681f;
+        const float e0 = __builtin_amdgcn_exp2f(x0 * kk), e1 = __builtin_amdgcn_exp2f(x1 * kk);
+        hk.template at<3 * P>();
+        const float q0 = __builtin_amdgcn_rcpf(1.0f + e0), q1 = __builtin_amdgcn_rcpf(1.0f + e1);
+        if constexpr (ACT == 1) { a0 = x0 * q0; a1 = x1 * q1; }
+        else { a0 = 1.0f - 2.0f * q0; a1 = 1.0f - 2.0f * q1; }
+        hk.template at<3 * P + 1>();
+    }
+#else
     float a0 = act_hw<ACT>(t[r] * c);
     hk.template at<3 * P>();
     float a1 = act_hw<ACT>(t[r + 1] * c);
     hk.template at<3 * P + 1>();
+#endif
     if constexpr (ACT != 3) {       /* SiLU / ReLU outputs are bounded below; keep the f16 conversion finite above */
         a0 = __builtin_fminf(a0, 65000.0f); a1 = __builtin_fminf(a1, 65000.0f);
     }
@@ -331,16 +355,26 @@ __device__ __forceinline__ float rcp_nr(float d) {
     return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
 }
 
+template <bool KARG> struct ScSrc;
+template <> struct ScSrc<true> {
+    kargs_t ka;
+    __device__ __forceinline__ ScSrc(const V2Args&) { ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(ka)); }
+    __device__ __forceinline__ const __attribute__((address_space(4))) SpC& get() const { return ka->sc; }
+};
+template <> struct ScSrc<false> {
+    const V2Args& a;
+    __device__ __forceinline__ ScSrc(const V2Args& a_) : a(a_) {}
+    __device__ __forceinline__ const SpC& get() const { return a.sc; }
+};
+
 template <int INV, class H>
 __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const float* pb, const float* ps, bool circ,
                                           const V2Args& a, const SpK& k, float* lad, int* bin, int* oob) {
-#if BGK_V2_KARG     /* the spline constants (re)read from the kernel argument block by scalar loads inside the element */
-    kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-#define SC ka->sc
-#else
-#define SC a.sc
-#endif
+    /* the spline constants: (re)read from the kernel argument block by scalar loads inside the element (inverse instance: fewer
+     * live SGPRs win there), or kept in SGPRs for the whole tile (forward instance: ~470 fewer s_load + s_waitcnt per tile; A/B
+     * on one box: forward -2 % with registers, inverse +2 %) */
+    const ScSrc<(BGK_V2_KARG == 2 ? INV != 0 : BGK_V2_KARG != 0)> scs(a);
+#define SC scs.get()
     float va[KB], vb[KB];
 #pragma unroll
     for (int i = 0; i < KB; ++i) va[i] = pa[i * ST];

@@ -5,4 +5,5 @@
  * its spline, chunk row stride 33).  Replaces coupling_rqs_dense_h2_kernel<.., SAVE = true> (bgk_fused.hip) behind
  * bgk_coupling_rqs_dense_h2_train for K = 8. */
 #define BGK_V2_SAVE 1
+#define BGK_V2_KARG 1       /* spline constants by scalar loads at their uses: this variant's extra pointers leave no SGPRs for them */
 #include "bgk_fused2.hip"
