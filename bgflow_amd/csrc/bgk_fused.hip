@@ -1231,16 +1231,18 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
     if (B == 0) return 0;
-    if (bgk_h2_variant == 2 && z0 != nullptr && operand_dtype == 0 && K == KB && src_col && params && z1)   /* training forward */
+    /* second-generation kernels: their staging index math uses 24-bit multiplies (row strides below 2^24 floats) */
+    const bool v2_ok = bgk_h2_variant == 2 && K == KB && ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24);
+    if (v2_ok && z0 != nullptr && operand_dtype == 0 && src_col && params && z1)   /* training forward */
         return bgk_launch_rqs_dense_h2v2_train(what, z0, z1, params, ldp, src_col, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev,
                                                act, y, ldy, B, d, circ_mask, inverse, left, right, bottom, top, min_bin_width,
                                                min_bin_height, min_derivative, identity_init, out, ldo, dlogp, accumulate, bin_idx,
                                                oob_count, stream);
-    if (bgk_h2_variant == 2 && z0 == nullptr && operand_dtype == 1 && K == KB)   /* reduced-precision bf16 mode on the second-generation kernel */
+    if (v2_ok && z0 == nullptr && operand_dtype == 1)   /* reduced-precision bf16 mode on the second-generation kernel */
         return bgk_launch_rqs_dense_h2v2_bf16(what, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, act, y, ldy, B, d, circ_mask,
                                               inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
                                               identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream);
-    if (bgk_h2_variant == 2 && z0 == nullptr && operand_dtype == 0 && K == KB)   /* split-f16 inference: the second-generation kernel */
+    if (v2_ok && z0 == nullptr && operand_dtype == 0)   /* split-f16 inference: the second-generation kernel */
         return bgk_launch_rqs_dense_h2v2(what, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, act, y, ldy, B, d, circ_mask,
                                          inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
                                          identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream);

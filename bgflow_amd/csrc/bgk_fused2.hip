@@ -138,7 +138,7 @@ __device__ __forceinline__ void ld_pair(u32x4& hi, u32x4& lo, const uint4* base,
  * tile-step T = s * NT + m (k-step s, tile m), then NT bias tile-steps; event E = 3 T + p: p = 0 lo*hi, 1 hi*lo, 2 hi*hi
  * (small terms first), bias events one MFMA each.  The ring slot of tile-step T is refilled with T + RD right after its
  * last MFMA has been issued. */
-template <int NT>
+template <int NT, int MS = 4>                     /* MS: tiles per k-step in the packed operand (spline layers: 4; affine output layer: NT) */
 struct Live {
     static constexpr int NTS = KS * NT;           /* product tile-steps */
     static constexpr int NEV = NPROD * NTS + NT;  /* events */
@@ -167,15 +167,15 @@ struct Live {
         if constexpr (T < NTS) {
             constexpr int s = T / NT, m = T % NT;
 #if BGK_V2_BF16
-            ring[T % RD].hi = blk<(s * 4 + m) * 2>();          /* the bf16 values sit in the "hi" blocks of the same layout */
+            ring[T % RD].hi = blk<(s * MS + m) * 2>();         /* the bf16 values sit in the "hi" blocks of the same layout */
 #elif BGK_V2_BUF
-            ring[T % RD].hi = blk<(s * 4 + m) * 2>();
-            ring[T % RD].lo = blk<(s * 4 + m) * 2 + 1>();
+            ring[T % RD].hi = blk<(s * MS + m) * 2>();
+            ring[T % RD].lo = blk<(s * MS + m) * 2 + 1>();
 #else
-            ld_pair<(s * 4 + m) * 2>(ring[T % RD].hi, ring[T % RD].lo, W, voff);
+            ld_pair<(s * MS + m) * 2>(ring[T % RD].hi, ring[T % RD].lo, W, voff);
 #endif
         } else if constexpr (T < NTS + NT) {
-            ring[T % RD].hi = blk<KS * 8 + (T - NTS)>();
+            ring[T % RD].hi = blk<KS * MS * 2 + (T - NTS)>();
         }
     }
     template <int T0, int T1>
@@ -665,23 +665,23 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int i = base + u * 64 + lane;
-            const int r = (int)__umulhi((unsigned)i, a.magic_dc), c = i - r * a.d_c;
-            oc[u] = i < n_c ? c * SROW + r : -1;
+            const int r = (int)(__umul24((unsigned)i, a.magic_dc) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)a.d_c);
+            oc[u] = i < n_c ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
 #if (BGK_V2_ABL & 8)
             vc[u] = 0.25f;
 #else
-            vc[u] = (i < n_c && r < rows) ? cond_t[r * ldc32 + c] : 0.0f;
+            vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
 #endif
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int i = base + u * 64 + lane;
-            const int r = (int)__umulhi((unsigned)i, a.magic_d), c = i - r * d;
-            oy[u] = i < n_y ? c * SROW + r : -1;
+            const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
+            oy[u] = i < n_y ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
 #if (BGK_V2_ABL & 8)
             vy[u] = 0.5f;
 #else
-            vy[u] = (i < n_y && r < rows) ? y_t[r * ldy32 + c] : 0.5f;
+            vy[u] = (i < n_y && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.5f;
 #endif
         }
 #pragma unroll
@@ -839,8 +839,8 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
     if (lane < d) out_t[lane] = s_y[lane * SROW];
 #else
     for (int i = lane; i < rows * d; i += 64) {
-        const int r = (int)__umulhi((unsigned)i, a.magic_d), cc = i - r * d;
-        out_t[r * ldo32 + cc] = s_y[cc * SROW + r];
+        const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), cc = i - (int)__umul24((unsigned)r, (unsigned)d);
+        out_t[(int)__umul24((unsigned)r, (unsigned)ldo32) + cc] = s_y[(int)__umul24((unsigned)cc, (unsigned)SROW) + r];
     }
 #endif
     if (a.oob_count && __builtin_amdgcn_ballot_w64(oob_local != 0)) {     /* rare: inputs outside the spline domain */
@@ -861,7 +861,262 @@ SetK make_set(double low, double high, double min_bin, int K) {
     return s;
 }
 
-uint32_t magic_div(int d) { return (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
+/* i / d for i < 4096, d <= 127 as (i * M) >> 20 with the full-rate 24-bit multiply (v_mul_u32_u24; the 32-bit v_mul_lo / v_mul_hi
+ * run at quarter rate): M = ceil(2^20 / d), error i (M d - 2^20) / (d 2^20) < 4096 / 2^20 < 1 / d, product < 2^32.  The row
+ * strides multiplied the same way must stay below 2^24 (launch_h2 checks) */
+uint32_t magic_div(int d) { return (uint32_t)(((1u << 20) + (uint32_t)d - 1) / (uint32_t)d); }
+
+
+#if !BGK_V2_SAVE && !BGK_V2_BF16
+/* ---- affine (RealNVP) coupling layer with two (128,128) conditioner networks on the same event-threaded GEMM stream ----------
+ * CouplingFlow(AffineTransformer(shift = DenseNet, scale = DenseNet)), nn/flow/transformer/affine.py:41-70.  Same contract and packed
+ * operands as coupling_affine_dense_kernel<4, OT> (bgk_fused_affine.hip), which streams its A fragments through a 2-deep ring with
+ * GEMM and activation phases alternating (0.85 ms per layer of cfg 5 at 2^20 samples, 22 % of it on the matrix pipe).  Here, per
+ * network:  layer 0 from the staged conditioner tile;  layer-1 events threaded through the activation of the layer-0 tiles;  the
+ * output layer's events (OT tiles per k-step) through the activation of the layer-1 tiles.  The shift network's result waits in LDS
+ * (each lane parks and re-reads its own 16 OT values) while the scale network runs on the same registers. */
+struct AffV2Net { const uint4* A0; const uint4* A1; const uint4* A2; float c0, c1, c2; };
+struct AffV2Args {
+    const float* cond; int64_t ldc; int d_c; int periodic; uint32_t magic_dc; int S0;
+    AffV2Net shift, scale; int has_shift, has_scale;
+    const float* log_alpha; int preserve_volume, is_circular, inverse;
+    const float* y; int64_t ldy; int64_t B; int d;
+    float* out; int64_t ldo; float* dlogp; int accumulate;
+    int vec4;                    /* y / out rows 16-byte aligned */
+    int lds_per_wave;
+};
+
+/* layer 0: X = A0' * [features; 1]  (bias = weight column of the constant-1 feature); B operand from LDS, split on the fly.
+ * The A fragments of k-step s + 1 are requested before the MFMAs of k-step s (two fragment sets, loop unrolled by two). */
+struct AffFrag0 { uint4 v[4][2]; };
+__device__ __forceinline__ void aff_l0_request(AffFrag0& f, const uint4* A0, int s, int lane) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f.v[m][0] = A0[((s * 4 + m) * 2 + 0) * 64 + lane];
+        f.v[m][1] = A0[((s * 4 + m) * 2 + 1) * 64 + lane];
+    }
+}
+__device__ __forceinline__ void aff_l0_step(f32x16 (&X)[4], const AffFrag0& f, const float* s_p, int s, int j, int hh) {
+    h16x8 bhi, blo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = s_p[(16 * s + 8 * hh + e) * SROW + j];
+        const _Float16 hv = (_Float16)v;
+        bhi[e] = hv;
+        blo[e] = (_Float16)(v - (float)hv);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        X[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.v[m][1]), bhi, X[m], 0, 0, 0);
+        X[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.v[m][0]), blo, X[m], 0, 0, 0);
+        X[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.v[m][0]), bhi, X[m], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void aff_layer0(const AffV2Net& n, int S0, const float* s_p, int lane, int j, int hh, f32x16 (&X)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[m][r] = 0.0f;
+    AffFrag0 fa, fb;
+    aff_l0_request(fa, n.A0, 0, lane);
+    for (int s = 0; s < S0; s += 2) {
+        if (s + 1 < S0) aff_l0_request(fb, n.A0, s + 1, lane);
+        aff_l0_step(X, fa, s_p, s, j, hh);
+        if (s + 1 < S0) {
+            if (s + 2 < S0) aff_l0_request(fa, n.A0, s + 2, lane);
+            aff_l0_step(X, fb, s_p, s + 1, j, hh);
+        }
+    }
+}
+
+/* layers 1 and 2: X (layer-0 pre-activations) -> Y (layer 1) -> X[0 .. OT) (unscaled network output) */
+template <int ACT, int OT>
+__device__ __forceinline__ void aff_layers12(const AffV2Net& n, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff) {
+    NoLive none;
+    {
+        Live<4> g{Y, bf, n.A1, voff, ring};
+        g.start();
+        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, X[0], n.c0, bf);
+        __builtin_amdgcn_sched_barrier(0);
+        act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, X[1], n.c0, bf);       /* hook i = event i (100 events) */
+        act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, X[2], n.c0, bf);
+        act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, X[3], n.c0, bf);
+        __builtin_amdgcn_sched_barrier(0);
+        g.template events<(72 * Live<4>::NEV) / 100, Live<4>::NEV>();
+    }
+    {
+        typedef Live<OT, OT> GO;                                                   /* 25 OT events: 6 OT per activated tile */
+        GO g{X, bf, n.A2, voff, ring};
+        g.start();
+        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, Y[0], n.c1, bf);
+        __builtin_amdgcn_sched_barrier(0);
+        act_split_tile<ACT, 1>(Hooks<GO, 0, 100>{g}, Y[1], n.c1, bf);
+        act_split_tile<ACT, 2>(Hooks<GO, 24, 100>{g}, Y[2], n.c1, bf);
+        act_split_tile<ACT, 3>(Hooks<GO, 48, 100>{g}, Y[3], n.c1, bf);
+        __builtin_amdgcn_sched_barrier(0);
+        g.template events<(72 * GO::NEV) / 100, GO::NEV>();
+    }
+}
+
+/* tanh for the OUTPUT layer (log sigma): hardware exp2 + Newton-refined rcp above 0.625 (abs error ~1e-7), odd polynomial below
+ * (the form of the other fused affine kernels, bgk_fused_affine.hip::r_tanh_out) */
+__device__ __forceinline__ float aff_tanh_out(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float dn = 1.0f + __builtin_amdgcn_exp2f(ax * 2.88539008177792681f);
+    const float big = __builtin_copysignf(__builtin_fmaf(-2.0f, rcp_nr(dn), 1.0f), x);
+    const float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = __builtin_fmaf(p, z, 2.06390887954e-2f);
+    p = __builtin_fmaf(p, z, -5.37397155531e-2f);
+    p = __builtin_fmaf(p, z, 1.33314422036e-1f);
+    p = __builtin_fmaf(p, z, -3.33332819422e-1f);
+    const float small = __builtin_fmaf(p * z, x, x);
+    return ax >= 0.625f ? big : small;
+}
+
+template <int ACT, int OT>
+__global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(AffV2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6;
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* the featurised conditioner tile [16 S0][SROW]; later the parked shift values */
+    const int d = a.d;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * FW + wave;
+    if (tile >= n_tiles) return;
+    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
+    const int ldc32 = (int)a.ldc;
+    const int n_c = 32 * a.d_c;
+    const int lane = (int)threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+    const unsigned voff = (unsigned)lane * 16u;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    const float* cond_t = a.cond + b0 * a.ldc;
+
+    /* ---- stage the (featurised) conditioner input [feature][sample], the constant-1 row, zero pad rows ---- */
+    constexpr int SB = 10;
+    for (int base = 0; base < n_c; base += 64 * SB) {
+        float vc[SB];
+        int oc[SB];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = base + u * 64 + lane;
+            const int r = (int)(__umul24((unsigned)i, a.magic_dc) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)a.d_c);
+            oc[u] = i < n_c ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
+            vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            if (oc[u] >= 0) {
+                if (a.periodic) {                                        /* WrapPeriodic featuriser (nn/periodic.py:30-37) */
+                    float sv, cv;
+                    bgk_sincos2pif(vc[u], &sv, &cv);
+                    s_p[oc[u]] = cv;
+                    s_p[a.d_c * SROW + oc[u]] = sv;
+                } else {
+                    s_p[oc[u]] = __builtin_amdgcn_fmed3f(vc[u], -65000.0f, 65000.0f);
+                }
+            }
+        }
+    }
+    for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
+        s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    f32x16 h[4], acc[4];
+    TFrag ring[RD];
+    BFrag bf;
+    /* ---- shift network: result (unscaled) in h[0 .. OT) ---- */
+    if (a.has_shift) {
+        aff_layer0(a.shift, a.S0, s_p, lane, j, hh, h);
+        aff_layers12<ACT, OT>(a.shift, h, acc, bf, ring, voff);
+    }
+    /* ---- scale network: layer 0 into acc while h still holds the shift values; then they are parked in the (now free) tile ---- */
+    if (a.has_scale) aff_layer0(a.scale, a.S0, s_p, lane, j, hh, acc);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (a.has_shift) {
+#pragma unroll
+        for (int m = 0; m < OT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_p[(m * 16 + r) * 64 + lane] = h[m][r] * a.shift.c2;
+    }
+    if (a.has_scale) aff_layers12<ACT, OT>(a.scale, acc, h, bf, ring, voff);       /* result in acc[0 .. OT) */
+
+    /* ---- affine tail (affine.py:41-70); the y values are requested first: their HBM round trip runs under the tanh code ---- */
+    const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
+    const float* yr = a.y + (b0 + (j < rows ? j : rows - 1)) * a.ldy;      /* rows past the batch end read a valid row, nothing is stored */
+    float yv[OT][16];
+#pragma unroll
+    for (int m = 0; m < OT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int dim0 = drow(m, 4 * q, hh);
+            if (a.vec4 && dim0 + 4 <= d) {
+                const float4 t4 = *reinterpret_cast<const float4*>(yr + dim0);
+                yv[m][4 * q] = t4.x; yv[m][4 * q + 1] = t4.y; yv[m][4 * q + 2] = t4.z; yv[m][4 * q + 3] = t4.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) yv[m][4 * q + u] = dim0 + u < d ? yr[dim0 + u] : 0.0f;
+            }
+        }
+    float lsum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < OT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float l = (a.has_scale && drow(m, r, hh) < d) ? aff_tanh_out(acc[m][r] * a.scale.c2) * alpha : 0.0f;
+            acc[m][r] = l;
+            lsum += l;
+        }
+    float total = lsum + __shfl_xor(lsum, 32);
+    if (a.preserve_volume && a.has_scale) {
+        const float mean = total / (float)d;
+        lsum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < OT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ls = drow(m, r, hh) < d ? acc[m][r] - mean : 0.0f;
+                acc[m][r] = ls;
+                lsum += ls;
+            }
+        total = lsum + __shfl_xor(lsum, 32);
+    }
+    if (j < rows) {
+        float* orow = a.out + (b0 + j) * a.ldo;
+#pragma unroll
+        for (int m = 0; m < OT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int dim0 = drow(m, 4 * q, hh);
+                if (dim0 >= d) continue;
+                const bool full = a.vec4 && dim0 + 4 <= d;
+                float o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * q + u;
+                    const float mm = a.has_shift ? s_p[(m * 16 + r) * 64 + lane] : 0.0f;
+                    const float ls = acc[m][r];
+                    const float sg = __builtin_amdgcn_exp2f((a.inverse ? -ls : ls) * 1.44269504088896341f);     /* |ls| <= exp(log_alpha): 1 ulp */
+                    float t = a.inverse ? sg * (yv[m][r] - mm) : sg * yv[m][r] + mm;
+                    if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
+                    o[u] = t;
+                }
+                if (full) {
+                    *reinterpret_cast<float4*>(orow + dim0) = make_float4(o[0], o[1], o[2], o[3]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (dim0 + u < d) orow[dim0 + u] = o[u];
+                }
+            }
+        if (hh == 0) {
+            const float dl = a.inverse ? -total : total;
+            if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
+        }
+    }
+}
+#endif   /* affine layer */
 
 }  // namespace
 
@@ -919,3 +1174,42 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
 #undef BGK_LAUNCH
     return bgk_launch_status(what);
 }
+
+#if !BGK_V2_SAVE && !BGK_V2_BF16
+/* hidden (128,128), both networks with the same activation (SiLU | ReLU | Tanh): called by bgk_fused_affine.hip::affine_dense_launch */
+int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                               const void* sA0, const void* sA1, const void* sA2, float sc0, float sc1, float sc2,
+                               const void* tA0, const void* tA1, const void* tA2, float tc0, float tc1, float tc2,
+                               int32_t act, const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
+                               const float* y, int64_t ldy, int64_t B, int32_t d,
+                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    const char* what = "bgk_coupling_affine_dense_h2";
+    AffV2Args a;
+    const int n_in = periodic ? 2 * d_c : d_c;
+    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic; a.magic_dc = magic_div(d_c); a.S0 = (n_in + 1 + 15) / 16;
+    a.shift = AffV2Net{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA2, sc0, sc1, sc2};
+    a.scale = AffV2Net{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA2, tc0, tc1, tc2};
+    a.has_shift = sA0 != nullptr; a.has_scale = tA0 != nullptr;
+    a.log_alpha = log_alpha; a.preserve_volume = preserve_volume; a.is_circular = is_circular; a.inverse = inverse;
+    a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
+    a.vec4 = (ldy % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)y | (uintptr_t)out) % 16 == 0);
+    const int OT = (d + 31) / 32;
+    const int tile_f = 16 * a.S0 * SROW, park_f = 16 * OT * 64;
+    a.lds_per_wave = tile_f > park_f ? tile_f : park_f;
+    const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
+    const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
+    BGK_CHECK_ARG(ldc < (1 << 24) && (int64_t)32 * d_c < 4096 && act >= 1 && act <= 3 && OT >= 1 && OT <= 3, "%s: outside the kernel's envelope", what);
+    if (shmem > 64 * 1024) {
+        bgk_set_error("%s: conditioner input of %d features too wide", what, n_in);
+        return BGK_EUNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCH(A, O) hipLaunchKernelGGL((coupling_affine_dense_v2_kernel<A, O>), dim3((int)n_wg), dim3(FTHREADS), shmem, st, a)
+#define BGK_LAUNCH_O(A) do { if (OT == 1) BGK_LAUNCH(A, 1); else if (OT == 2) BGK_LAUNCH(A, 2); else BGK_LAUNCH(A, 3); } while (0)
+    if (act == 1) BGK_LAUNCH_O(1); else if (act == 2) BGK_LAUNCH_O(2); else BGK_LAUNCH_O(3);
+#undef BGK_LAUNCH_O
+#undef BGK_LAUNCH
+    return bgk_launch_status(what);
+}
+#endif

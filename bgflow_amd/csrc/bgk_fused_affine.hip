@@ -9,8 +9,10 @@
  * A wave owns 32 samples; 4 independent waves per workgroup; no LDS beyond the staged conditioner input.
  */
 #include "bgk_mfma_h2.h"
+#include "bgk_fused2.h"
 
-int bgk_affine_variant = 2;      /* 1: streaming kernel only, 2: weight-resident kernel where the operands fit LDS (bgk_set_option 2) */
+int bgk_affine_variant = 2;      /* 1: streaming kernel only, 2: weight-resident kernel where the operands fit LDS (hidden 64) and the
+                                  * event-threaded kernel of bgk_fused2.hip for hidden (128,128) (bgk_set_option 2) */
 
 namespace {
 
@@ -581,6 +583,13 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
 #undef BGK_LAUNCH_R
             return bgk_launch_status("bgk_coupling_affine_dense_h2");
         }
+    }
+    if (hidden == 128 && bgk_affine_variant == 2 && !sA1b && !tA1b && a.S0 <= 7 && ldc < (1 << 24)) {
+        /* two hidden layers of 128, one activation: MFMA events threaded through the activation code (bgk_fused2.hip) */
+        const int act = has_shift ? s_act : t_act;
+        if ((!has_shift || !has_scale || s_act == t_act) && act >= 1 && act <= 3)
+            return bgk_launch_affine_dense_v2(cond, ldc, d_c, periodic, sA0, sA1, sA2, sc0, sc1, sc2, tA0, tA1, tA2, tc0, tc1, tc2, act,
+                                              log_alpha, preserve_volume, is_circular, inverse, y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
     }
 #define BGK_LAUNCH(H, O) hipLaunchKernelGGL((coupling_affine_dense_kernel<H, O>), dim3((int)n_wg), dim3(AW * 64), shmem, st, a)
     if (hidden == 64) { if (OT == 1) BGK_LAUNCH(2, 1); else if (OT == 2) BGK_LAUNCH(2, 2); else BGK_LAUNCH(2, 3); }
