@@ -658,7 +658,10 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
      * All global loads of a batch (SB per array and lane) are issued before anything waits on them: one HBM round trip per batch
      * instead of one per 64 elements.  (A persistent-wave variant with register prefetch of the next tile's inputs measured 6 %
      * SLOWER than letting the dispatcher overlap the prologue of fresh workgroups with the tails of retiring ones.) ---- */
-    constexpr int SB = 10;
+#ifndef BGK_V2_SB
+#define BGK_V2_SB 10
+#endif
+    constexpr int SB = BGK_V2_SB;
     for (int base = 0; base < (n_c > n_y ? n_c : n_y); base += 64 * SB) {
         float vc[SB], vy[SB];
         int oc[SB], oy[SB];
@@ -874,7 +877,9 @@ uint32_t magic_div(int d) { return (uint32_t)(((1u << 20) + (uint32_t)d - 1) / (
  * GEMM and activation phases alternating (0.85 ms per layer of cfg 5 at 2^20 samples, 22 % of it on the matrix pipe).  Here, per
  * network:  layer 0 from the staged conditioner tile;  layer-1 events threaded through the activation of the layer-0 tiles;  the
  * output layer's events (OT tiles per k-step) through the activation of the layer-1 tiles.  The shift network's result waits in LDS
- * (each lane parks and re-reads its own 16 OT values) while the scale network runs on the same registers. */
+ * ([dim][sample], in the conditioner tile's place) while the scale network runs on the same registers; y and the result pass
+ * through a [dim][sample] LDS tile, so that global rows are read and written coalesced (one row-strided 4-byte access per lane and
+ * dim costs 64 cache-line requests per instruction). */
 struct AffV2Net { const uint4* A0; const uint4* A1; const uint4* A2; float c0, c1, c2; };
 struct AffV2Args {
     const float* cond; int64_t ldc; int d_c; int periodic; uint32_t magic_dc; int S0;
@@ -882,8 +887,8 @@ struct AffV2Args {
     const float* log_alpha; int preserve_volume, is_circular, inverse;
     const float* y; int64_t ldy; int64_t B; int d;
     float* out; int64_t ldo; float* dlogp; int accumulate;
-    int vec4;                    /* y / out rows 16-byte aligned */
-    int lds_per_wave;
+    uint32_t magic_d;
+    int lds_tile, lds_per_wave;  /* floats: conditioner / shift tile, whole wave slice (+ y / out tile) */
 };
 
 /* layer 0: X = A0' * [features; 1]  (bias = weight column of the constant-1 feature); B operand from LDS, split on the fly.
@@ -978,31 +983,45 @@ template <int ACT, int OT>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(AffV2Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6;
-    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* the featurised conditioner tile [16 S0][SROW]; later the parked shift values */
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* the featurised conditioner tile [16 S0][SROW]; later the shift values [d][SROW] */
+    float* s_y = s_p + a.lds_tile;                        /* y / out tile [d][SROW]: coalesced global rows <-> one (dim, sample) per lane */
     const int d = a.d;
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * FW + wave;
     if (tile >= n_tiles) return;
     const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
-    const int ldc32 = (int)a.ldc;
-    const int n_c = 32 * a.d_c;
+    const int ldc32 = (int)a.ldc, ldy32 = (int)a.ldy, ldo32 = (int)a.ldo;
+    const int n_c = 32 * a.d_c, n_y = 32 * d;
     const int lane = (int)threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
     const unsigned voff = (unsigned)lane * 16u;
     const int64_t b0 = tile * 32;
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
     const float* cond_t = a.cond + b0 * a.ldc;
+    const float* y_t = a.y + b0 * a.ldy;
+    float* out_t = a.out + b0 * a.ldo;
 
-    /* ---- stage the (featurised) conditioner input [feature][sample], the constant-1 row, zero pad rows ---- */
-    constexpr int SB = 10;
-    for (int base = 0; base < n_c; base += 64 * SB) {
-        float vc[SB];
-        int oc[SB];
+    /* ---- stage the (featurised) conditioner input [feature][sample] (+ the constant-1 row, zero pad rows) and y [dim][sample];
+     * all global loads of a batch are issued before anything waits on them (as in the spline kernel above) ---- */
+#ifndef BGK_AFF_SB
+#define BGK_AFF_SB 34       /* loads in flight per lane and array: one HBM round trip for up to 68 dims (nothing else is live yet) */
+#endif
+    constexpr int SB = BGK_AFF_SB;
+    for (int base = 0; base < (n_c > n_y ? n_c : n_y); base += 64 * SB) {
+        float vc[SB], vy[SB];
+        int oc[SB], oy[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int i = base + u * 64 + lane;
             const int r = (int)(__umul24((unsigned)i, a.magic_dc) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)a.d_c);
             oc[u] = i < n_c ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
             vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int i = base + u * 64 + lane;
+            const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
+            oy[u] = i < n_y ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
+            vy[u] = (i < n_y && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
@@ -1017,6 +1036,9 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < SB; ++u)
+            if (oy[u] >= 0) s_y[oy[u]] = vy[u];
     }
     for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
         s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
@@ -1039,27 +1061,15 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
 #pragma unroll
         for (int m = 0; m < OT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_p[(m * 16 + r) * 64 + lane] = h[m][r] * a.shift.c2;
+            for (int r = 0; r < 16; ++r) {
+                const int dim = drow(m, r, hh);
+                if (dim < d) s_p[dim * SROW + j] = h[m][r] * a.shift.c2;
+            }
     }
     if (a.has_scale) aff_layers12<ACT, OT>(a.scale, acc, h, bf, ring, voff);       /* result in acc[0 .. OT) */
 
-    /* ---- affine tail (affine.py:41-70); the y values are requested first: their HBM round trip runs under the tanh code ---- */
+    /* ---- affine tail (affine.py:41-70): lane (j, hh) owns sample j, dims drow(m, r, hh) ---- */
     const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
-    const float* yr = a.y + (b0 + (j < rows ? j : rows - 1)) * a.ldy;      /* rows past the batch end read a valid row, nothing is stored */
-    float yv[OT][16];
-#pragma unroll
-    for (int m = 0; m < OT; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int dim0 = drow(m, 4 * q, hh);
-            if (a.vec4 && dim0 + 4 <= d) {
-                const float4 t4 = *reinterpret_cast<const float4*>(yr + dim0);
-                yv[m][4 * q] = t4.x; yv[m][4 * q + 1] = t4.y; yv[m][4 * q + 2] = t4.z; yv[m][4 * q + 3] = t4.w;
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) yv[m][4 * q + u] = dim0 + u < d ? yr[dim0 + u] : 0.0f;
-            }
-        }
     float lsum = 0.0f;
 #pragma unroll
     for (int m = 0; m < OT; ++m)
@@ -1083,37 +1093,30 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
             }
         total = lsum + __shfl_xor(lsum, 32);
     }
-    if (j < rows) {
-        float* orow = a.out + (b0 + j) * a.ldo;
 #pragma unroll
-        for (int m = 0; m < OT; ++m)
+    for (int m = 0; m < OT; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int dim0 = drow(m, 4 * q, hh);
-                if (dim0 >= d) continue;
-                const bool full = a.vec4 && dim0 + 4 <= d;
-                float o[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = 4 * q + u;
-                    const float mm = a.has_shift ? s_p[(m * 16 + r) * 64 + lane] : 0.0f;
-                    const float ls = acc[m][r];
-                    const float sg = __builtin_amdgcn_exp2f((a.inverse ? -ls : ls) * 1.44269504088896341f);     /* |ls| <= exp(log_alpha): 1 ulp */
-                    float t = a.inverse ? sg * (yv[m][r] - mm) : sg * yv[m][r] + mm;
-                    if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
-                    o[u] = t;
-                }
-                if (full) {
-                    *reinterpret_cast<float4*>(orow + dim0) = make_float4(o[0], o[1], o[2], o[3]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) if (dim0 + u < d) orow[dim0 + u] = o[u];
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int dim = drow(m, r, hh);
+            if (dim < d) {
+                const float yv = s_y[dim * SROW + j];
+                const float mm = a.has_shift ? s_p[dim * SROW + j] : 0.0f;
+                const float ls = acc[m][r];
+                const float sg = __builtin_amdgcn_exp2f((a.inverse ? -ls : ls) * 1.44269504088896341f);     /* |ls| <= exp(log_alpha): 1 ulp */
+                float t = a.inverse ? sg * (yv - mm) : sg * yv + mm;
+                if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
+                s_y[dim * SROW + j] = t;
             }
-        if (hh == 0) {
-            const float dl = a.inverse ? -total : total;
-            if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
         }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (hh == 0 && j < rows) {
+        const float dl = a.inverse ? -total : total;
+        if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
+    }
+    for (int i = lane; i < rows * d; i += 64) {
+        const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), cc = i - (int)__umul24((unsigned)r, (unsigned)d);
+        out_t[(int)__umul24((unsigned)r, (unsigned)ldo32) + cc] = s_y[(int)__umul24((unsigned)cc, (unsigned)SROW) + r];
     }
 }
 #endif   /* affine layer */
@@ -1192,20 +1195,24 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
     a.has_shift = sA0 != nullptr; a.has_scale = tA0 != nullptr;
     a.log_alpha = log_alpha; a.preserve_volume = preserve_volume; a.is_circular = is_circular; a.inverse = inverse;
     a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
-    a.vec4 = (ldy % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)y | (uintptr_t)out) % 16 == 0);
+    a.magic_d = magic_div(d);
     const int OT = (d + 31) / 32;
-    const int tile_f = 16 * a.S0 * SROW, park_f = 16 * OT * 64;
-    a.lds_per_wave = tile_f > park_f ? tile_f : park_f;
+    const int tile_f = 16 * a.S0 * SROW, park_f = d * SROW;
+    a.lds_tile = tile_f > park_f ? tile_f : park_f;
+    a.lds_per_wave = a.lds_tile + d * SROW;
     const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
-    BGK_CHECK_ARG(ldc < (1 << 24) && (int64_t)32 * d_c < 4096 && act >= 1 && act <= 3 && OT >= 1 && OT <= 3, "%s: outside the kernel's envelope", what);
-    if (shmem > 64 * 1024) {
-        bgk_set_error("%s: conditioner input of %d features too wide", what, n_in);
+    BGK_CHECK_ARG(ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24) && (int64_t)32 * d_c < 4096 && (int64_t)32 * d < 4096
+                  && act >= 1 && act <= 3 && OT >= 1 && OT <= 3, "%s: outside the kernel's envelope", what);
+    if (shmem > 160 * 1024) {
+        bgk_set_error("%s: %d input features / %d dims do not fit the LDS tiles", what, n_in, d);
         return BGK_EUNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-#define BGK_LAUNCH(A, O) hipLaunchKernelGGL((coupling_affine_dense_v2_kernel<A, O>), dim3((int)n_wg), dim3(FTHREADS), shmem, st, a)
+#define BGK_LAUNCH(A, O) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coupling_affine_dense_v2_kernel<A, O>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                              hipLaunchKernelGGL((coupling_affine_dense_v2_kernel<A, O>), dim3((int)n_wg), dim3(FTHREADS), shmem, st, a); } while (0)
 #define BGK_LAUNCH_O(A) do { if (OT == 1) BGK_LAUNCH(A, 1); else if (OT == 2) BGK_LAUNCH(A, 2); else BGK_LAUNCH(A, 3); } while (0)
     if (act == 1) BGK_LAUNCH_O(1); else if (act == 2) BGK_LAUNCH_O(2); else BGK_LAUNCH_O(3);
 #undef BGK_LAUNCH_O

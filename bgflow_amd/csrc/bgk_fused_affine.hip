@@ -584,7 +584,9 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
             return bgk_launch_status("bgk_coupling_affine_dense_h2");
         }
     }
-    if (hidden == 128 && bgk_affine_variant == 2 && !sA1b && !tA1b && a.S0 <= 7 && ldc < (1 << 24)) {
+    const int v2_tile = 16 * a.S0 * ASROW > d * ASROW ? 16 * a.S0 * ASROW : d * ASROW;       /* floats per wave: conditioner / shift tile + y tile */
+    if (hidden == 128 && bgk_affine_variant == 2 && !sA1b && !tA1b && (size_t)(v2_tile + d * ASROW) * 16 <= 80 * 1024
+        && ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24)) {
         /* two hidden layers of 128, one activation: MFMA events threaded through the activation code (bgk_fused2.hip) */
         const int act = has_shift ? s_act : t_act;
         if ((!has_shift || !has_scale || s_act == t_act) && act >= 1 && act <= 3)
