@@ -35,8 +35,9 @@ const char* bgk_last_error(void);            /* thread-local, host string */
  *   option 1: generation of the split-f16 inference coupling kernel behind bgk_coupling_rqs_dense_h2:
  *             2 (default) = coupling_rqs_dense_h2v2_kernel (MFMA stream threaded through the VALU work, bgk_fused2.hip),
  *             1 = the first-generation kernel (bgk_fused.hip).
- *   option 2: kernel behind bgk_coupling_affine_dense_h2 for hidden = (64, 64): 2 (default) = weight-resident kernel (both
- *             conditioners' packed operands staged once per workgroup in LDS), 1 = the streaming kernel (operands from L2).
+ *   option 2: kernel behind bgk_coupling_affine_dense_h2: 2 (default) = for hidden (64, 64) the weight-resident kernel (both
+ *             conditioners' packed operands staged once per workgroup in LDS), for hidden (128, 128) the event-threaded kernel
+ *             of bgk_fused2.hip; 1 = the streaming kernel (operands from L2, GEMM and activation phases alternate).
  * Returns the previous value, BGK_EINVAL for an unknown option / value. */
 int bgk_set_option(int32_t option, int32_t value);
 
