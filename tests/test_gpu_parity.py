@@ -891,18 +891,33 @@ def _affine_layer(kind, dev=None):
         tr = bg.AffineTransformer(bg.DenseNet([9, 128, 128, 33], torch.nn.Tanh()), bg.DenseNet([9, 128, 128, 33], torch.nn.ReLU()),
                                   preserve_volume=True)
         dims = (9, 33)
+    # the event-threaded H = 128 kernel (bgk_fused2.hip): its other instantiations and branches
+    elif kind == "v2_relu_pv":      # ReLU networks, two output tiles, volume preserving
+        tr = bg.AffineTransformer(bg.DenseNet([9, 128, 128, 33], torch.nn.ReLU()), bg.DenseNet([9, 128, 128, 33], torch.nn.ReLU()),
+                                  preserve_volume=True)
+        dims = (9, 33)
+    elif kind == "v2_tanh_wide":    # Tanh networks, 101 input features (7 k-steps of layer 0), one output tile
+        tr = bg.AffineTransformer(bg.DenseNet([100, 128, 128, 20], torch.nn.Tanh()), bg.DenseNet([100, 128, 128, 20], torch.nn.Tanh()))
+        dims = (100, 20)
+    elif kind == "v2_shift_circ":   # shift network only, circular output
+        tr = bg.AffineTransformer(bg.DenseNet([5, 128, 128, 7], torch.nn.SiLU()), None, is_circular=True)
+        dims = (5, 7)
+    elif kind == "v2_scale_only":   # scale network only, 96 dims (three full output tiles)
+        tr = bg.AffineTransformer(None, bg.DenseNet([12, 128, 128, 96], torch.nn.SiLU()))
+        dims = (12, 96)
     layer = hash_init_(bg.CouplingFlow(tr, transformed_indices=(1,), cond_indices=(0,)))
     return (layer.to(dev) if dev is not None else layer), dims
 
 
-@pytest.mark.parametrize("kind", ["cfg2", "aug66", "periodic", "nice_circ", "pv", "deep128", "deep64"])
+@pytest.mark.parametrize("kind", ["cfg2", "aug66", "periodic", "nice_circ", "pv", "deep128", "deep64",
+                                  "v2_relu_pv", "v2_tanh_wide", "v2_shift_circ", "v2_scale_only"])
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("B", [1, 31, 4133])
 def test_fused_affine_layer_vs_oracle(hip_lib, dev, kind, inverse, B):
     from oracle import flow_oracle as fo
     layer_cpu, dims = _affine_layer(kind)
     layer, _ = _affine_layer(kind, dev)
-    xs = [synth(B + 3 * i, B, d, uniform=(kind == "nice_circ" or (kind == "periodic" and i == 0))) for i, d in enumerate(dims)]
+    xs = [synth(B + 3 * i, B, d, uniform=(kind in ("nice_circ", "v2_shift_circ") or (kind == "periodic" and i == 0))) for i, d in enumerate(dims)]
     with torch.no_grad():
         x_out, y_out, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
     assert layer.transformer._fused_cache, "the fused affine path must have run"
