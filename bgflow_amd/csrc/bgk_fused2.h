@@ -30,11 +30,12 @@ int bgk_launch_rqs_dense_h2v2_bf16(const char* what, const float* cond, int64_t 
                                    float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
                                    void* stream);
 
-/* affine coupling layer with (128,128) conditioners on the same event-threaded GEMM stream (bgk_fused2.hip) */
+/* affine coupling layer with conditioners of width 128 (two or three hidden layers) on the same event-threaded GEMM stream
+ * (bgk_fused2.hip); BGK_EUNSUPPORTED for activation pairs it has no instance for */
 int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
-                               const void* sA0, const void* sA1, const void* sA2, float sc0, float sc1, float sc2,
-                               const void* tA0, const void* tA1, const void* tA2, float tc0, float tc1, float tc2,
-                               int32_t act, const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
+                               const void* sA0, const void* sA1, const void* sA1b, const void* sA2, float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
+                               const void* tA0, const void* tA1, const void* tA1b, const void* tA2, float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
+                               const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                                const float* y, int64_t ldy, int64_t B, int32_t d,
                                float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
 

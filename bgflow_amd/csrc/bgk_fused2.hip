@@ -871,7 +871,7 @@ uint32_t magic_div(int d) { return (uint32_t)(((1u << 20) + (uint32_t)d - 1) / (
 
 
 #if !BGK_V2_SAVE && !BGK_V2_BF16
-/* ---- affine (RealNVP) coupling layer with two (128,128) conditioner networks on the same event-threaded GEMM stream ----------
+/* ---- affine (RealNVP) coupling layer with two conditioner networks of width 128 on the same event-threaded GEMM stream ----------
  * CouplingFlow(AffineTransformer(shift = DenseNet, scale = DenseNet)), nn/flow/transformer/affine.py:41-70.  Same contract and packed
  * operands as coupling_affine_dense_kernel<4, OT> (bgk_fused_affine.hip), which streams its A fragments through a 2-deep ring with
  * GEMM and activation phases alternating (0.85 ms per layer of cfg 5 at 2^20 samples, 22 % of it on the matrix pipe).  Here, per
@@ -880,7 +880,7 @@ uint32_t magic_div(int d) { return (uint32_t)(((1u << 20) + (uint32_t)d - 1) / (
  * ([dim][sample], in the conditioner tile's place) while the scale network runs on the same registers; y and the result pass
  * through a [dim][sample] LDS tile, so that global rows are read and written coalesced (one row-strided 4-byte access per lane and
  * dim costs 64 cache-line requests per instruction). */
-struct AffV2Net { const uint4* A0; const uint4* A1; const uint4* A2; float c0, c1, c2; };
+struct AffV2Net { const uint4* A0; const uint4* A1; const uint4* A1b; const uint4* A2; float c0, c1, c1b, c2; };   /* A1b: third hidden layer or NULL */
 struct AffV2Args {
     const float* cond; int64_t ldc; int d_c; int periodic; uint32_t magic_dc; int S0;
     AffV2Net shift, scale; int has_shift, has_scale;
@@ -934,32 +934,44 @@ __device__ __forceinline__ void aff_layer0(const AffV2Net& n, int S0, const floa
     }
 }
 
-/* layers 1 and 2: X (layer-0 pre-activations) -> Y (layer 1) -> X[0 .. OT) (unscaled network output) */
-template <int ACT, int OT>
-__device__ __forceinline__ void aff_layers12(const AffV2Net& n, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff) {
+/* one H x H layer: Y = A' * act(c X) + b', its events threaded through the activation of X's tiles 1..3 */
+template <int ACT>
+__device__ __forceinline__ void aff_hidden(const uint4* A, float c, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff) {
     NoLive none;
-    {
-        Live<4> g{Y, bf, n.A1, voff, ring};
-        g.start();
-        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, X[0], n.c0, bf);
-        __builtin_amdgcn_sched_barrier(0);
-        act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, X[1], n.c0, bf);       /* hook i = event i (100 events) */
-        act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, X[2], n.c0, bf);
-        act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, X[3], n.c0, bf);
-        __builtin_amdgcn_sched_barrier(0);
-        g.template events<(72 * Live<4>::NEV) / 100, Live<4>::NEV>();
-    }
-    {
-        typedef Live<OT, OT> GO;                                                   /* 25 OT events: 6 OT per activated tile */
-        GO g{X, bf, n.A2, voff, ring};
-        g.start();
-        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, Y[0], n.c1, bf);
-        __builtin_amdgcn_sched_barrier(0);
-        act_split_tile<ACT, 1>(Hooks<GO, 0, 100>{g}, Y[1], n.c1, bf);
-        act_split_tile<ACT, 2>(Hooks<GO, 24, 100>{g}, Y[2], n.c1, bf);
-        act_split_tile<ACT, 3>(Hooks<GO, 48, 100>{g}, Y[3], n.c1, bf);
-        __builtin_amdgcn_sched_barrier(0);
-        g.template events<(72 * GO::NEV) / 100, GO::NEV>();
+    Live<4> g{Y, bf, A, voff, ring};
+    g.start();
+    act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, X[0], c, bf);
+    __builtin_amdgcn_sched_barrier(0);
+    act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, X[1], c, bf);       /* hook i = event i (100 events) */
+    act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, X[2], c, bf);
+    act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, X[3], c, bf);
+    __builtin_amdgcn_sched_barrier(0);
+    g.template events<(72 * Live<4>::NEV) / 100, Live<4>::NEV>();
+}
+/* the output layer: Y[0 .. OT) = A2' * act(c X) + b2' (unscaled), OT tiles per k-step */
+template <int ACT, int OT>
+__device__ __forceinline__ void aff_output(const uint4* A, float c, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff) {
+    NoLive none;
+    typedef Live<OT, OT> GO;                                                   /* 25 OT events: 6 OT per activated tile */
+    GO g{Y, bf, A, voff, ring};
+    g.start();
+    act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, X[0], c, bf);
+    __builtin_amdgcn_sched_barrier(0);
+    act_split_tile<ACT, 1>(Hooks<GO, 0, 100>{g}, X[1], c, bf);
+    act_split_tile<ACT, 2>(Hooks<GO, 24, 100>{g}, X[2], c, bf);
+    act_split_tile<ACT, 3>(Hooks<GO, 48, 100>{g}, X[3], c, bf);
+    __builtin_amdgcn_sched_barrier(0);
+    g.template events<(72 * GO::NEV) / 100, GO::NEV>();
+}
+/* the layers behind layer 0.  Two hidden layers: X -> Y -> X[0 .. OT);  three (DEEP): X -> Y -> X -> Y[0 .. OT) */
+template <int ACT, int OT, bool DEEP>
+__device__ __forceinline__ void aff_layers(const AffV2Net& n, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff) {
+    aff_hidden<ACT>(n.A1, n.c0, X, Y, bf, ring, voff);
+    if constexpr (DEEP) {
+        aff_hidden<ACT>(n.A1b, n.c1, Y, X, bf, ring, voff);
+        aff_output<ACT, OT>(n.A2, n.c1b, X, Y, bf, ring, voff);
+    } else {
+        aff_output<ACT, OT>(n.A2, n.c1, Y, X, bf, ring, voff);
     }
 }
 
@@ -979,7 +991,7 @@ __device__ __forceinline__ float aff_tanh_out(float x) {
     return ax >= 0.625f ? big : small;
 }
 
-template <int ACT, int OT>
+template <int ACT_S, int ACT_T, int OT, bool DEEP>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(AffV2Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6;
@@ -1048,13 +1060,15 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
     f32x16 h[4], acc[4];
     TFrag ring[RD];
     BFrag bf;
-    /* ---- shift network: result (unscaled) in h[0 .. OT) ---- */
+    /* ---- shift network: result (unscaled) in mu = h[0 .. OT) (three hidden layers: acc[0 .. OT)) ---- */
+    f32x16 (&mu)[4] = DEEP ? acc : h;
+    f32x16 (&t0)[4] = DEEP ? h : acc;          /* the scale network's layer-0 output: the array that does not hold mu */
     if (a.has_shift) {
         aff_layer0(a.shift, a.S0, s_p, lane, j, hh, h);
-        aff_layers12<ACT, OT>(a.shift, h, acc, bf, ring, voff);
+        aff_layers<ACT_S, OT, DEEP>(a.shift, h, acc, bf, ring, voff);
     }
-    /* ---- scale network: layer 0 into acc while h still holds the shift values; then they are parked in the (now free) tile ---- */
-    if (a.has_scale) aff_layer0(a.scale, a.S0, s_p, lane, j, hh, acc);
+    /* ---- scale network: layer 0 while the other array still holds the shift values; then they are parked in the (now free) tile ---- */
+    if (a.has_scale) aff_layer0(a.scale, a.S0, s_p, lane, j, hh, t0);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.has_shift) {
@@ -1063,10 +1077,10 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dim = drow(m, r, hh);
-                if (dim < d) s_p[dim * SROW + j] = h[m][r] * a.shift.c2;
+                if (dim < d) s_p[dim * SROW + j] = mu[m][r] * a.shift.c2;
             }
     }
-    if (a.has_scale) aff_layers12<ACT, OT>(a.scale, acc, h, bf, ring, voff);       /* result in acc[0 .. OT) */
+    if (a.has_scale) aff_layers<ACT_T, OT, DEEP>(a.scale, t0, mu, bf, ring, voff);       /* result in acc[0 .. OT) either way */
 
     /* ---- affine tail (affine.py:41-70): lane (j, hh) owns sample j, dims drow(m, r, hh) ---- */
     const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
@@ -1179,20 +1193,26 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
 }
 
 #if !BGK_V2_SAVE && !BGK_V2_BF16
-/* hidden (128,128), both networks with the same activation (SiLU | ReLU | Tanh): called by bgk_fused_affine.hip::affine_dense_launch */
+/* hidden width 128, two or three hidden layers; activations (shift, scale): both SiLU, both ReLU, both Tanh, or ReLU / Tanh.
+ * Returns BGK_EUNSUPPORTED (no error text) for any other combination: bgk_fused_affine.hip::affine_dense_launch then runs its
+ * streaming kernel. */
 int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
-                               const void* sA0, const void* sA1, const void* sA2, float sc0, float sc1, float sc2,
-                               const void* tA0, const void* tA1, const void* tA2, float tc0, float tc1, float tc2,
-                               int32_t act, const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
+                               const void* sA0, const void* sA1, const void* sA1b, const void* sA2, float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
+                               const void* tA0, const void* tA1, const void* tA1b, const void* tA2, float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
+                               const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                                const float* y, int64_t ldy, int64_t B, int32_t d,
                                float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
     const char* what = "bgk_coupling_affine_dense_h2";
     AffV2Args a;
     const int n_in = periodic ? 2 * d_c : d_c;
     a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic; a.magic_dc = magic_div(d_c); a.S0 = (n_in + 1 + 15) / 16;
-    a.shift = AffV2Net{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA2, sc0, sc1, sc2};
-    a.scale = AffV2Net{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA2, tc0, tc1, tc2};
+    a.shift = AffV2Net{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA1b, (const uint4*)sA2, sc0, sc1, sc1b, sc2};
+    a.scale = AffV2Net{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA1b, (const uint4*)tA2, tc0, tc1, tc1b, tc2};
     a.has_shift = sA0 != nullptr; a.has_scale = tA0 != nullptr;
+    const bool deep = a.has_shift ? sA1b != nullptr : tA1b != nullptr;
+    if (a.has_shift && a.has_scale && (sA1b != nullptr) != (tA1b != nullptr)) return BGK_EUNSUPPORTED;
+    const int as = a.has_shift ? s_act : t_act, at = a.has_scale ? t_act : s_act;
+    if (!((as == at && as >= 1 && as <= 3) || (as == 2 && at == 3))) return BGK_EUNSUPPORTED;
     a.log_alpha = log_alpha; a.preserve_volume = preserve_volume; a.is_circular = is_circular; a.inverse = inverse;
     a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
     a.magic_d = magic_div(d);
@@ -1204,17 +1224,19 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
     const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
     BGK_CHECK_ARG(ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24) && (int64_t)32 * d_c < 4096 && (int64_t)32 * d < 4096
-                  && act >= 1 && act <= 3 && OT >= 1 && OT <= 3, "%s: outside the kernel's envelope", what);
+                  && OT >= 1 && OT <= 3, "%s: outside the kernel's envelope", what);
     if (shmem > 160 * 1024) {
         bgk_set_error("%s: %d input features / %d dims do not fit the LDS tiles", what, n_in, d);
         return BGK_EUNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-#define BGK_LAUNCH(A, O) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coupling_affine_dense_v2_kernel<A, O>), \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                              hipLaunchKernelGGL((coupling_affine_dense_v2_kernel<A, O>), dim3((int)n_wg), dim3(FTHREADS), shmem, st, a); } while (0)
-#define BGK_LAUNCH_O(A) do { if (OT == 1) BGK_LAUNCH(A, 1); else if (OT == 2) BGK_LAUNCH(A, 2); else BGK_LAUNCH(A, 3); } while (0)
-    if (act == 1) BGK_LAUNCH_O(1); else if (act == 2) BGK_LAUNCH_O(2); else BGK_LAUNCH_O(3);
+#define BGK_LAUNCH(S, T, O, D) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coupling_affine_dense_v2_kernel<S, T, O, D>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                                    hipLaunchKernelGGL((coupling_affine_dense_v2_kernel<S, T, O, D>), dim3((int)n_wg), dim3(FTHREADS), shmem, st, a); } while (0)
+#define BGK_LAUNCH_D(S, T, O) do { if (deep) BGK_LAUNCH(S, T, O, true); else BGK_LAUNCH(S, T, O, false); } while (0)
+#define BGK_LAUNCH_O(S, T) do { if (OT == 1) BGK_LAUNCH_D(S, T, 1); else if (OT == 2) BGK_LAUNCH_D(S, T, 2); else BGK_LAUNCH_D(S, T, 3); } while (0)
+    if (as == 1) BGK_LAUNCH_O(1, 1); else if (as == 3) BGK_LAUNCH_O(3, 3); else if (at == 2) BGK_LAUNCH_O(2, 2); else BGK_LAUNCH_O(2, 3);
+#undef BGK_LAUNCH_D
 #undef BGK_LAUNCH_O
 #undef BGK_LAUNCH
     return bgk_launch_status(what);

@@ -585,13 +585,13 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
         }
     }
     const int v2_tile = 16 * a.S0 * ASROW > d * ASROW ? 16 * a.S0 * ASROW : d * ASROW;       /* floats per wave: conditioner / shift tile + y tile */
-    if (hidden == 128 && bgk_affine_variant == 2 && !sA1b && !tA1b && (size_t)(v2_tile + d * ASROW) * 16 <= 80 * 1024
+    if (hidden == 128 && bgk_affine_variant == 2 && (size_t)(v2_tile + d * ASROW) * 16 <= 80 * 1024
         && ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24)) {
-        /* two hidden layers of 128, one activation: MFMA events threaded through the activation code (bgk_fused2.hip) */
-        const int act = has_shift ? s_act : t_act;
-        if ((!has_shift || !has_scale || s_act == t_act) && act >= 1 && act <= 3)
-            return bgk_launch_affine_dense_v2(cond, ldc, d_c, periodic, sA0, sA1, sA2, sc0, sc1, sc2, tA0, tA1, tA2, tc0, tc1, tc2, act,
-                                              log_alpha, preserve_volume, is_circular, inverse, y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
+        /* width 128: MFMA events threaded through the activation code (bgk_fused2.hip); it declines activation pairs it has no instance for */
+        const int st2 = bgk_launch_affine_dense_v2(cond, ldc, d_c, periodic, sA0, sA1, sA1b, sA2, sc0, sc1, sc1b, sc2, s_act,
+                                                   tA0, tA1, tA1b, tA2, tc0, tc1, tc1b, tc2, t_act, log_alpha, preserve_volume, is_circular,
+                                                   inverse, y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
+        if (st2 != BGK_EUNSUPPORTED) return st2;
     }
 #define BGK_LAUNCH(H, O) hipLaunchKernelGGL((coupling_affine_dense_kernel<H, O>), dim3((int)n_wg), dim3(AW * 64), shmem, st, a)
     if (hidden == 64) { if (OT == 1) BGK_LAUNCH(2, 1); else if (OT == 2) BGK_LAUNCH(2, 2); else BGK_LAUNCH(2, 3); }
