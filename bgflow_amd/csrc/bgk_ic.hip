@@ -358,6 +358,9 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
     /* e / n and e / keep for e < 2^16 by multiply-high: floor(e m / 2^32) with m = ceil(2^32 / n) is exact while e n < 2^32 */
     const unsigned magic_n = (unsigned)((0x100000000ull + (unsigned)n - 1) / (unsigned)n);
     const unsigned magic_k = (unsigned)((0x100000000ull + (unsigned)keep - 1) / (unsigned)keep);
+    const int na3 = 3 * a.n_atoms;
+    const unsigned magic_a = (unsigned)((0x100000000ull + (unsigned)na3 - 1) / (unsigned)na3);
+    const int ldic32 = (int)a.ldic, ldf32 = (int)a.ldf, ldx32 = (int)a.ldx;
     int warn = 0;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t b0 = tile * TS;
@@ -373,10 +376,10 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
                     int off[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int e = (it0 + u) * TS + tid, r = (int)__umulhi((unsigned)e, magic_n), c = e - r * n;
+                        const int e = (it0 + u) * TS + tid, r = (int)__umulhi((unsigned)e, magic_n), c = e - (int)__umul24((unsigned)r, (unsigned)n);
                         const bool ok = e < rows * n;
-                        v[u] = ok ? src[(int64_t)r * a.ldic + c] : 0.0f;
-                        off[u] = ok ? r * a.sx + s_cb[c] + f : -1;
+                        v[u] = ok ? src[(int)__umul24((unsigned)r, (unsigned)ldic32) + c] : 0.0f;      /* 24-bit multiplies: full rate (r < 64; strides checked by the launcher) */
+                        off[u] = ok ? (int)__umul24((unsigned)r, (unsigned)a.sx) + s_cb[c] + f : -1;
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) if (off[u] >= 0) s_x[off[u]] = v[u];
@@ -388,10 +391,10 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
                 int off[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const int e = u * TS + tid, r = (int)__umulhi((unsigned)e, magic_k), c = e - r * keep;
+                    const int e = u * TS + tid, r = (int)__umulhi((unsigned)e, magic_k), c = e - (int)__umul24((unsigned)r, (unsigned)keep);
                     const bool ok = e < rows * keep;
-                    v[u] = ok ? src[(int64_t)r * a.ldf + c] : 0.0f;
-                    off[u] = ok ? r * a.sx + s_off[c] : -1;
+                    v[u] = ok ? src[(int)__umul24((unsigned)r, (unsigned)ldf32) + c] : 0.0f;
+                    off[u] = ok ? (int)__umul24((unsigned)r, (unsigned)a.sx) + s_off[c] : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) if (off[u] >= 0) s_x[off[u]] = v[u];
@@ -466,10 +469,12 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
             if (a.accumulate) a.dlogp[b] += acc; else a.dlogp[b] = acc;
         }
         __syncthreads();
-        const int na3 = 3 * a.n_atoms;
-        for (int i = tid; i < rows * na3; i += (int)blockDim.x) {
-            int r = i / na3, c = i - r * na3;
-            a.x[(b0 + r) * a.ldx + c] = s_x[r * a.sx + c];
+        {   /* full rows out: i / na3 by multiply-high (exact while i na3 < 2^32), the products by the full-rate 24-bit multiply */
+            float* x_t = a.x + b0 * a.ldx;
+            for (int i = tid; i < rows * na3; i += (int)blockDim.x) {
+                const int r = (int)__umulhi((unsigned)i, magic_a), c = i - (int)__umul24((unsigned)r, (unsigned)na3);
+                x_t[(int)__umul24((unsigned)r, (unsigned)ldx32) + c] = s_x[(int)__umul24((unsigned)r, (unsigned)a.sx) + c];
+            }
         }
         __syncthreads();
     }
@@ -762,6 +767,7 @@ extern "C" int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const fl
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_icdf_ic2xyz: bad sizes");
     BGK_CHECK_ARG(x && place && fixed && bonds && angles && torsions && xfix && dlogp, "bgk_icdf_ic2xyz: null pointer");
     BGK_CHECK_ARG(Tblacken ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_icdf_ic2xyz: bad whitening arguments");
+    BGK_CHECK_ARG(ldic < (1 << 24) && ldf < (1 << 24) && ldx < (1 << 24), "bgk_icdf_ic2xyz: row stride too large");
     if (B == 0) return 0;
     IcGenArgs g{};
     IcArgs& a = g.ic;
