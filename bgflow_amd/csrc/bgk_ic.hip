@@ -410,16 +410,21 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
             for (int k = 0; k < 16; ++k) fxv[k] = (park_fixed && k < keep) ? xr[s_off[k]] : 0.0f;      /* all read before any is overwritten */
             float acc = 0.0f;
             if (a.T) {
-                for (int c = 0; c < nf3; ++c) xr[s_off[c]] = s_mean[c];
                 if (park_fixed) {
+                    /* the whitened coordinates first (registers), then each output coordinate as one running sum in k order -- the
+                     * same additions as the read-modify-write form below, without 9 dependent LDS round trips per coordinate */
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        if (k < keep) {
-                            const float zk = icdf_channel(fxv[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
-                            for (int c = 0; c < nf3; ++c) xr[s_off[c]] += zk * s_T[k * nf3 + c];
-                        }
+                    for (int k = 0; k < 16; ++k)
+                        if (k < keep) fxv[k] = icdf_channel(fxv[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
+                    for (int c = 0; c < nf3; ++c) {
+                        float xc = s_mean[c];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            if (k < keep) xc += fxv[k] * s_T[k * nf3 + c];
+                        xr[s_off[c]] = xc;
                     }
                 } else {
+                    for (int c = 0; c < nf3; ++c) xr[s_off[c]] = s_mean[c];
                     for (int k = 0; k < keep; ++k) {
                         const float zk = icdf_channel(fx[k], s_dsc + 6 * (3 * n + k), g.use_eps, g.cdf_eps, acc);
                         for (int c = 0; c < nf3; ++c) xr[s_off[c]] += zk * s_T[k * nf3 + c];
