@@ -42,6 +42,41 @@ def test_pack_rqs_columns_host_function(hip_lib):
     assert src[128] == 5 * K                                                # chunk 1 starts with dim 5
 
 
+@pytest.mark.parametrize("K,dims_per_chunk", [(4, 9), (8, 5), (12, 3), (16, 2), (32, 1)])
+def test_pack_rqs_columns_other_bin_counts(hip_lib, K, dims_per_chunk):
+    """the 128-column parameter chunks of the fused spline kernels hold floor(128 / (3 K + 1)) dims; every reference column
+    appears exactly once, padding is -1 (transformer/spline.py:113-126 column order [w | h | s | s_nc])"""
+    d = 11
+    slots = np.arange(d, dtype=np.int32)                       # all dims non-circular: one extra slope column each
+    ncp = hip_lib.bgk_pack_rqs_columns(d, K, None, None)
+    n_chunks = -(-d // dims_per_chunk)
+    assert ncp == 128 * n_chunks
+    src = np.empty(ncp, dtype=np.int32)
+    hip_lib.bgk_pack_rqs_columns(d, K, slots.ctypes.data, src.ctypes.data)
+    P = 3 * K * d + d
+    used = src[src >= 0]
+    assert len(used) == P and sorted(used) == list(range(P))
+    ppd = 3 * K + 1
+    for c in range(n_chunks):
+        live = min(dims_per_chunk, d - c * dims_per_chunk) * ppd
+        assert (src[128 * c:128 * c + live] >= 0).all() and (src[128 * c + live:128 * (c + 1)] == -1).all()
+    dim = dims_per_chunk if n_chunks > 1 else 0                # first dim of chunk 1: its widths start at column K * dim
+    assert src[128 if n_chunks > 1 else 0] == K * dim
+
+
+@pytest.mark.parametrize("K,fusable", [(4, True), (8, True), (12, True), (16, True), (32, True), (6, False), (10, False), (64, False)])
+def test_fused_plan_bin_counts(hip_lib, K, fusable):
+    """which bin counts the one-launch spline coupling kernels take (the others run conditioner + generic spline kernel)"""
+    from bgflow_amd import dense
+    d, d_c = 3, 5
+    tr = bg.ConditionalSplineTransformer(bg.DenseNet([d_c, 128, 128, 3 * K * d + d], torch.nn.SiLU()), is_circular=False)
+    nc_host = np.arange(d, dtype=np.int32)
+    plan = dense._fused_plan(tr, d, nc_host)
+    assert (plan is not None) == fusable
+    if fusable:
+        assert plan["n_bins"] == K and plan["d_c"] == d_c and plan["mode"] == "f16x2"
+
+
 def test_kernels_refuse_cpu_tensors(hip_lib):
     tr = bg.ConditionalSplineTransformer(torch.nn.Linear(3, 3 * 8 * 2 + 2))
     with pytest.raises(RuntimeError, match="HIP"):
