@@ -200,6 +200,29 @@ def g_rqs_unit():
     save("g_rqs_unit", **cases)
 
 
+def g_rqs_bins():
+    """other bin counts (the transformer infers K from the parameter width, transformer/spline.py:113-126): the fused kernels
+    take K = 4 | 12 | 16 | 32 besides the default 8, the generic kernel any K.  inputs: synth(300 + K + 100 * circular, B, P,
+    scale=.5), synth(400 + K, B, d, uniform=True)"""
+    cases = {}
+    d, B = 5, 96
+    for K in (4, 6, 12, 16, 32):
+        for circ in (False, True):
+            P = 3 * K * d + (0 if circ else d)
+            params = rng_f32(300 + K + 100 * int(circ), B, P, scale=0.5)
+            y = rng_f32(400 + K, B, d, uniform=True)
+            for inverse in (False, True):
+                tag = f"K{K}_{'c' if circ else 'nc'}_{'inv' if inverse else 'fwd'}"
+                z32, dl32, last32, _ = run_spline(params, y, circ, inverse, torch.float32)
+                z64, dl64, last64, _ = run_spline(params, y, circ, inverse, torch.float64)
+                assert last64["bin_idx"].max() == K - 1 or last64["bin_idx"].max() < K
+                cases[f"{tag}_z32"] = z32; cases[f"{tag}_dlogp32"] = dl32
+                cases[f"{tag}_z64"] = z64; cases[f"{tag}_dlogp64"] = dl64
+                cases[f"{tag}_idx32"] = last32["bin_idx"].astype(np.int32)
+                cases[f"{tag}_idx64"] = last64["bin_idx"].astype(np.int32)
+    save("g_rqs_bins", **cases)
+
+
 # ---------------------------------------------------------------------------------------------
 # G-affine (unit + README flow + cfg-2 flow)
 # ---------------------------------------------------------------------------------------------
@@ -663,9 +686,11 @@ def g_grads2():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rqs", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2"]
+    which = sys.argv[1:] or ["rqs", "bins", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2"]
     if "rqs" in which:
         g_rqs_unit()
+    if "bins" in which:
+        g_rqs_bins()
     if "affine" in which:
         g_affine()
     if "ic" in which:

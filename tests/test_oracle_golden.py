@@ -48,6 +48,37 @@ def test_rqs_unit_f32(oracle, golden, name, d, circ, inverse):
     assert np.abs(dl - G[tag + "_dlogp32"]).max() <= 1e-5 * scale + 1e-5
 
 
+@pytest.mark.parametrize("Kb", [4, 6, 12, 16, 32])
+@pytest.mark.parametrize("circ", [False, True])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_rqs_other_bin_counts(oracle, golden, Kb, circ, inverse):
+    """bin counts other than the default 8 (the transformer infers K from the parameter width, transformer/spline.py:113-126):
+    the oracle against the reference in f64 (double rounding) and in f32 (within the reference's own f32 noise; bin indices
+    equal, or the sample sits within rounding distance of a knot)"""
+    G = golden("g_rqs_bins")
+    d, B = 5, 96
+    P = 3 * Kb * d + (0 if circ else d)
+    params = synth(300 + Kb + 100 * int(circ), B, P, scale=0.5)
+    y = synth(400 + Kb, B, d, uniform=True)
+    tag = f"K{Kb}_{'c' if circ else 'nc'}_{'inv' if inverse else 'fwd'}"
+    is_circ = np.full(d, circ, bool)
+    z, dl, det = oracle.rqs(y, params, is_circular=is_circ, inverse=inverse, n_bins=Kb, dtype=np.float64, want_details=True)
+    assert np.array_equal(det["bin_idx"], G[tag + "_idx64"])
+    np.testing.assert_allclose(z, G[tag + "_z64"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(dl, G[tag + "_dlogp64"], rtol=1e-12, atol=1e-12)
+    z, dl, det = oracle.rqs(y, params, is_circular=is_circ, inverse=inverse, n_bins=Kb, dtype=np.float32, want_details=True)
+    mism = det["bin_idx"] != G[tag + "_idx32"]
+    if mism.any():
+        dist = np.abs(det["knots"] - y[..., None]).min(-1)
+        assert (dist[mism] <= 2.4e-7).all() and mism.sum() <= 2, f"non-tie bin mismatches: {mism.sum()}"
+    ok = ~mism.any(-1)
+    ref_noise_z = np.abs(G[tag + "_z32"] - G[tag + "_z64"]).max()
+    ref_noise_dl = np.abs(G[tag + "_dlogp32"] - G[tag + "_dlogp64"]).max()
+    # outputs live in [0, 1]: a few f32 ulps (96 samples: the reference's own f32 noise on them can be as low as 2e-7)
+    assert np.abs(z[ok] - G[tag + "_z64"][ok]).max() <= max(3 * ref_noise_z, 1.5e-6)
+    assert np.abs(dl[ok] - G[tag + "_dlogp64"][ok]).max() <= 3 * ref_noise_dl + 1e-6
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 def test_rqs_edges(oracle, golden, inverse):
     """domain ends, exact knots and knots +-1 ulp: indices must agree with the reference except for
