@@ -685,8 +685,34 @@ def g_grads2():
     save("g_grads2", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# DistributionTransferFlow / ConstrainGaussianFlow (nn/flow/cdf.py:49-121), f64
+# ---------------------------------------------------------------------------------------------
+def g_cdf_flows():
+    """inputs: x = synth(501, 64, 6, scale=1.5) + 0.8; mu = synth(502, 6) * 0.3 + 1, sigma = |synth(503, 6)| * 0.4 + 0.6"""
+    from bgflow.nn.flow.cdf import DistributionTransferFlow, ConstrainGaussianFlow
+    out = {}
+    x = torch.tensor(synth(501, 64, 6, scale=1.5).astype(np.float64) + 0.8)
+    mu = torch.tensor(synth(502, 6).astype(np.float64) * 0.3 + 1.0)
+    sigma = torch.tensor(np.abs(synth(503, 6).astype(np.float64)) * 0.4 + 0.6)
+    flow = ConstrainGaussianFlow(mu=mu, sigma=sigma, lower_bound=0.1, upper_bound=3.0)
+    y, dl = flow.forward(x)
+    xb, dlb = flow.forward(y, inverse=True)
+    out.update(cg_y=y.numpy(), cg_dlogp=dl.numpy(), cg_back=xb.numpy(), cg_back_dlogp=dlb.numpy())
+    flow = ConstrainGaussianFlow(mu=mu, sigma=sigma, lower_bound=0.0, mu_out=mu + 0.25, sigma_out=0.5 * sigma)
+    y, dl = flow.forward(x)
+    out.update(cg2_y=y.numpy(), cg2_dlogp=dl.numpy())
+    src = torch.distributions.Normal(mu, sigma)
+    dst = torch.distributions.Normal(torch.zeros(6, dtype=torch.float64), 2.0 * torch.ones(6, dtype=torch.float64))
+    flow = DistributionTransferFlow(src, dst)
+    y, dl = flow.forward(x)
+    xb, dlb = flow.forward(y, inverse=True)
+    out.update(dt_y=y.numpy(), dt_dlogp=dl.numpy(), dt_back=xb.numpy(), dt_back_dlogp=dlb.numpy())
+    save("g_cdf_flows", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rqs", "bins", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2"]
+    which = sys.argv[1:] or ["rqs", "bins", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2", "cdfflows"]
     if "rqs" in which:
         g_rqs_unit()
     if "bins" in which:
@@ -705,3 +731,5 @@ if __name__ == "__main__":
         g_grads()
     if "grads2" in which:
         g_grads2()
+    if "cdfflows" in which:
+        g_cdf_flows()

@@ -12,6 +12,7 @@ import torch
 
 import bgflow_amd as bg
 from bgflow_amd import _lib
+from bgflow_amd.utils import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -636,6 +637,31 @@ def test_distribution_transfer_and_constrain_gaussian_flows():
     assert torch.allclose(x, y, atol=1e-4, rtol=0.0) and torch.allclose(dlogp, torch.zeros_like(dlogp), atol=1e-4, rtol=0.0)
     x2, dlogp = generous.forward(y, inverse=True)
     assert torch.allclose(x2, y, atol=1e-4, rtol=0.0) and torch.allclose(dlogp, torch.zeros_like(dlogp), atol=1e-4, rtol=0.0)
+
+
+def test_transfer_flows_match_reference_golden(golden):
+    """DistributionTransferFlow / ConstrainGaussianFlow against vectors generated by importing the reference
+    (tests/golden/make_goldens.py::g_cdf_flows, nn/flow/cdf.py:49-121), f64 on the CPU path"""
+    G = golden("g_cdf_flows")
+    x = torch.tensor(synth(501, 64, 6, scale=1.5).astype(np.float64) + 0.8)
+    mu = torch.tensor(synth(502, 6).astype(np.float64) * 0.3 + 1.0)
+    sigma = torch.tensor(np.abs(synth(503, 6).astype(np.float64)) * 0.4 + 0.6)
+    flow = bg.ConstrainGaussianFlow(mu=mu, sigma=sigma, lower_bound=0.1, upper_bound=3.0)
+    y, dl = flow.forward(x)
+    xb, dlb = flow.forward(y, inverse=True)
+    for got, key in ((y, "cg_y"), (dl, "cg_dlogp"), (xb, "cg_back"), (dlb, "cg_back_dlogp")):
+        np.testing.assert_allclose(got.numpy(), G[key], rtol=1e-10, atol=1e-10)
+    flow = bg.ConstrainGaussianFlow(mu=mu, sigma=sigma, lower_bound=0.0, mu_out=mu + 0.25, sigma_out=0.5 * sigma)
+    y, dl = flow.forward(x)
+    np.testing.assert_allclose(y.numpy(), G["cg2_y"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(dl.numpy(), G["cg2_dlogp"], rtol=1e-10, atol=1e-10)
+    src = torch.distributions.Normal(mu, sigma)
+    dst = torch.distributions.Normal(torch.zeros(6, dtype=torch.float64), 2.0 * torch.ones(6, dtype=torch.float64))
+    flow = bg.DistributionTransferFlow(src, dst)
+    y, dl = flow.forward(x)
+    xb, dlb = flow.forward(y, inverse=True)
+    for got, key in ((y, "dt_y"), (dl, "dt_dlogp"), (xb, "dt_back"), (dlb, "dt_back_dlogp")):
+        np.testing.assert_allclose(got.numpy(), G[key], rtol=1e-10, atol=1e-10)
 
 
 def test_ic_helper_functions_and_wrap_distances():
