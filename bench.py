@@ -101,22 +101,35 @@ def coupling_stats(block, gemm_mode):
     return 4.0 * (4 * d + 2), macs, None
 
 
-def timed_steps(gen, zs, steps):
-    """K passes of the flow with HIP events around every block (recorded on the current stream = the stream the kernels are
-    launched on).  Returns [(block index, start event, end event), ...]."""
-    evs = []
+class _SegmentTimer:
+    """HIP events (recorded on the current stream = the stream the kernels are launched on) around every segment of
+    SequentialFlow.run -- the pass itself is the product code path (one running log-det buffer, written by the kernels)."""
+
+    def __init__(self):
+        self.events = []
+
+    def __call__(self, i, label):
+        timer = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                self_inner.e0, self_inner.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self_inner.e0.record()
+
+            def __exit__(self_inner, *exc):
+                self_inner.e1.record()
+                timer.events.append((i, self_inner.e0, self_inner.e1))
+                return False
+        return _Ctx()
+
+
+def timed_steps(gen, zs, steps, inverse=False):
+    """K passes of the flow with HIP events around every segment.  Returns [(segment index, start event, end event), ...]."""
+    timer = _SegmentTimer()
     with torch.no_grad():
         for _ in range(steps):
-            xs = tuple(zs)
-            total = 0.0
-            for i, (_, block) in enumerate(gen.flow.segments()):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                *xs, dd = block(*xs)
-                e1.record()
-                total = total + dd
-                evs.append((i, e0, e1))
-    return evs
+            gen.flow.run(tuple(zs), inverse=inverse, around=timer)
+    return timer.events
 
 
 def event_ms_per_call(fn, steps, warmup):
@@ -133,15 +146,10 @@ def event_ms_per_call(fn, steps, warmup):
     return e0.elapsed_time(e1) / steps
 
 
-def flow_pass(gen, zs):
+def flow_pass(gen, zs, inverse=False):
     def run():
         with torch.no_grad():
-            xs = tuple(zs)
-            total = 0.0
-            for _, block in gen.flow.segments():
-                *xs, dd = block(*xs)
-                total = total + dd
-        return total
+            return gen.flow(*zs, inverse=inverse)
     return run
 
 

@@ -51,6 +51,16 @@ _SIGNATURES = {
                                                  vp, i64, i64, i32, i32, ctypes.c_uint64, i32,
                                                  f64, f64, f64, f64, f64, f64, f64, i32,
                                                  vp, i64, vp, i32, vp, vp, vp]),
+    "bgk_coupling_rqs_dense_h2_mc": (ctypes.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, vp, i32, i32, i32, i32,
+                                                    vp, i64, i64, i32, i32, ctypes.c_uint64, i32,
+                                                    f64, f64, f64, f64, f64, f64, f64, i32,
+                                                    vp, i64, vp, i32, vp, vp, vp]),
+    "bgk_coupling_affine_dense_h2_mc": (ctypes.c_int, [vp, vp, vp, i32, i32,
+                                                       vp, vp, vp, f32, f32, f32, i32, vp, vp, vp, f32, f32, f32, i32,
+                                                       i32, vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32, vp]),
+    "bgk_coupling_affine_dense_h3_mc": (ctypes.c_int, [vp, vp, vp, i32, i32,
+                                                       vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp, vp, vp, f32, f32, f32, f32, i32,
+                                                       i32, vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32, vp]),
     "bgk_pack_dense_h2": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "bgk_coupling_rqs_dense_h2_train": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, vp, i32, i32, i32,
                                                        vp, i64, i64, i32, i32, ctypes.c_uint64, i32,
@@ -122,6 +132,17 @@ def require_hip(*tensors):
 
 def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def cond_segments(parts):
+    """host tables (device pointers, row strides, widths) of 1..3 conditioning tensors for the *_mc entry points; the returned
+    tuple keeps the ctypes arrays and the (possibly re-laid-out) tensors alive for the duration of the call"""
+    rows = [rowmajor(t) for t in parts]
+    n = len(rows)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in rows])
+    lds = (ctypes.c_int64 * n)(*[ld for _, ld in rows])
+    widths = (ctypes.c_int32 * n)(*[t.shape[1] for t, _ in rows])
+    return ptrs, lds, widths, n, rows
 
 
 def stream_ptr(device=None):

@@ -39,13 +39,15 @@ def log_weights(*x, prior, flow, target, temperature=1.0, normalize=True):
 
 def log_weights_from_samples(prior, flow, target, num_samples, batch_size, temperature=1.0, normalize=True):
     """Importance weights of ``num_samples // batch_size`` freshly sampled batches (bg.py:31-52): the batches run through the
-    flow one after the other (bounded memory), weights are normalised over all of them.  Unlike the reference, priors / flows
-    with several tensors per sample are handled too (its ``x_batch, dlogp_batch = flow(*z_batch)`` assumes one)."""
+    flow one after the other (bounded memory), weights are normalised over all of them.  Call pattern of the reference: the
+    prior is sampled and the flow is run WITHOUT the temperature (``prior.sample(batch_size)``, ``flow(*z)``); the temperature
+    only enters the energies of ``log_weights_given_latent``.  Unlike the reference, flows with several output tensors per
+    sample are handled too (its ``x_batch, dlogp_batch = flow(*z_batch)`` assumes one)."""
     zs, xs, dls = [], [], []
     with torch.no_grad():
         for _ in range(num_samples // batch_size):
-            z = pack_tensor_in_tuple(prior.sample(batch_size, temperature=temperature))
-            *x, dlogp = flow(*z, temperature=temperature)
+            z = pack_tensor_in_tuple(prior.sample(batch_size))
+            *x, dlogp = flow(*z)
             zs.append(z); xs.append(tuple(x)); dls.append(dlogp)
         z_cat = tuple(torch.cat([z[i] for z in zs], dim=0) for i in range(len(zs[0])))
         x_cat = tuple(torch.cat([x[i] for x in xs], dim=0) for i in range(len(xs[0])))

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .flow import Flow, InverseFlow, SequentialFlow
+from .flow import ACC_KW, Flow, InverseFlow, SequentialFlow
 
 __all__ = ["CDFTransform", "DistributionTransferFlow", "ConstrainGaussianFlow"]
 
@@ -84,16 +84,22 @@ class _CdfFn(torch.autograd.Function):
         return g_x, None, None, None
 
 
-def _launch(x, desc, inverse, eps):
+def _launch(x, desc, inverse, eps, acc=None):
     x2, ldx = _lib.rowmajor(x)
     B, d = x2.shape
     out = torch.empty((B, d), dtype=torch.float32, device=x.device)
-    dlogp = torch.empty((B,), dtype=torch.float32, device=x.device)
+    if acc is None:
+        dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=x.device), 0
+    else:                      # the pass's running log-det buffer (flow._LogDetAcc): the kernel adds to it
+        dlogp, accumulate = acc.peek()
     with torch.cuda.device(x.device):
         st = _lib.lib().bgk_cdf_transform(_lib.ptr(x2), ldx, _lib.ptr(desc), B, d, int(inverse),
                                           int(eps is not None), float(eps or 0.0), _lib.ptr(out), d,
-                                          _lib.ptr(dlogp), 0, _lib.stream_ptr(x.device))
+                                          _lib.ptr(dlogp), int(bool(accumulate)), _lib.stream_ptr(x.device))
     _lib.check(st, "bgk_cdf_transform")
+    if acc is not None:
+        acc.commit()
+        return out, acc
     return out, dlogp[:, None]
 
 
@@ -107,7 +113,9 @@ class CDFTransform(Flow):
         self._eps = eps
         self._desc_cache = {}
 
-    def _kernel(self, x, inverse):
+    _bgk_acc = True
+
+    def _kernel(self, x, inverse, acc=None):
         if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
             return None
         grad = torch.is_grad_enabled()
@@ -119,7 +127,7 @@ class CDFTransform(Flow):
             return None
         if grad and x.requires_grad:
             return _CdfFn.apply(x, desc, inverse, self._eps)
-        return _launch(x, desc, inverse, self._eps)
+        return _launch(x, desc, inverse, self._eps, acc=acc)
 
     def kernel_descriptor(self, d, device):
         """the [d, 6] device descriptor of this layer's marginal for the kernels (bgk_cdf_transform, bgk_icdf_ic2xyz), or None
@@ -138,7 +146,7 @@ class CDFTransform(Flow):
         self._desc_cache = {}
 
     def _forward(self, x, *args, **kwargs):
-        fast = self._kernel(x, False)
+        fast = self._kernel(x, False, acc=kwargs.get(ACC_KW))
         if fast is not None:
             return fast
         y = self.distribution.cdf(x)
@@ -150,7 +158,7 @@ class CDFTransform(Flow):
         return y, logdet.sum(dim=-1, keepdim=True)
 
     def _inverse(self, x, *args, **kwargs):
-        fast = self._kernel(x, True)
+        fast = self._kernel(x, True, acc=kwargs.get(ACC_KW))
         if fast is not None:
             return fast
         if self._eps is not None:
@@ -174,6 +182,7 @@ class ConstrainGaussianFlow(Flow):
     """Squeeze a Gaussian variable N(mu, sigma) into [lower_bound, upper_bound]: Gaussian cdf, then the icdf of the truncated
     Gaussian N(mu_out or mu, sigma_out or sigma) on that interval; the forward output is clamped to the interval against
     round-off (bgflow/nn/flow/cdf.py:66-121; same argument names and defaults)."""
+    _bgk_acc = True
 
     def __init__(self, mu, sigma=torch.tensor(1.0), lower_bound=0.0, upper_bound=np.inf, assert_range=True, mu_out=None,
                  sigma_out=None, eps=1e-7):

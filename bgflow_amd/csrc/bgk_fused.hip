@@ -1216,7 +1216,8 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
               uint64_t circ_mask, int32_t inverse, double left, double right, double bottom, double top,
               double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
               float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
-              float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col, void* stream) {
+              float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col, void* stream, const BgkCondSegs* segs = nullptr) {
+    if (segs && segs->n >= 1) { cond = segs->ptr[0]; ldc = segs->ld[0]; }
     BGK_CHECK_ARG(cond && A0p && A1p && A2p && y && out && dlogp, "%s: null pointer", what);
     BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "%s: bad sizes", what);
     const bool other_k = (K == 4 || K == 12 || K == 16 || K == 32) && operand_dtype == 0;     /* K != 8: split-f16 only (inference and training forward) */
@@ -1233,19 +1234,20 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     if (B == 0) return 0;
     /* second-generation kernels: their staging index math uses 24-bit multiplies (row strides below 2^24 floats) */
     const bool v2_ok = bgk_h2_variant == 2 && K == KB && ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24);
+    if (segs && segs->n > 1 && !v2_ok) return BGK_EUNSUPPORTED;     /* several conditioning tensors: second-generation kernels only */
     if (v2_ok && z0 != nullptr && operand_dtype == 0 && src_col && params && z1)   /* training forward */
         return bgk_launch_rqs_dense_h2v2_train(what, z0, z1, params, ldp, src_col, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev,
                                                act, y, ldy, B, d, circ_mask, inverse, left, right, bottom, top, min_bin_width,
                                                min_bin_height, min_derivative, identity_init, out, ldo, dlogp, accumulate, bin_idx,
-                                               oob_count, stream);
+                                               oob_count, stream, segs);
     if (v2_ok && z0 == nullptr && operand_dtype == 1)   /* reduced-precision bf16 mode on the second-generation kernel */
         return bgk_launch_rqs_dense_h2v2_bf16(what, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, act, y, ldy, B, d, circ_mask,
                                               inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
-                                              identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream);
+                                              identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream, segs);
     if (v2_ok && z0 == nullptr && operand_dtype == 0)   /* split-f16 inference: the second-generation kernel */
         return bgk_launch_rqs_dense_h2v2(what, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, act, y, ldy, B, d, circ_mask,
                                          inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
-                                         identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream);
+                                         identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count, stream, segs);
     FusedArgsH2 ah;
     FusedArgs& a = ah.f;
     a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
@@ -1314,6 +1316,28 @@ extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t
                      circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
                      identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count,
                      nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int bgk_coupling_rqs_dense_h2_mc(const float* const* cond, const int64_t* ldc, const int32_t* width, int32_t n_cond, int32_t periodic,
+                                            const void* A0p, const void* A1p, const void* A2p,
+                                            float c0, float c1, float c2, const float* cs_dev, int32_t operand_dtype,
+                                            int32_t H0, int32_t H1, int32_t act, const float* y,
+                                            int64_t ldy, int64_t B, int32_t d, int32_t K, uint64_t circ_mask,
+                                            int32_t inverse,
+                                            double left, double right, double bottom, double top,
+                                            double min_bin_width, double min_bin_height,
+                                            double min_derivative, int32_t identity_init, float* out,
+                                            int64_t ldo, float* dlogp, int32_t accumulate,
+                                            int32_t* bin_idx, int32_t* oob_count, void* stream) {
+    BGK_CHECK_ARG(cond && ldc && width && n_cond >= 1 && n_cond <= BGK_MAX_COND, "bgk_coupling_rqs_dense_h2_mc: 1..%d conditioning tensors", BGK_MAX_COND);
+    BgkCondSegs segs{};
+    int d_c = 0;
+    for (int i = 0; i < n_cond; ++i) { segs.ptr[i] = cond[i]; segs.ld[i] = ldc[i]; segs.w[i] = width[i]; d_c += width[i]; }
+    segs.n = n_cond;
+    return launch_h2("bgk_coupling_rqs_dense_h2_mc", cond[0], ldc[0], d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, operand_dtype, H0, H1, act, y, ldy,
+                     B, d, K, circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
+                     identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count,
+                     nullptr, nullptr, nullptr, 0, nullptr, stream, &segs);
 }
 
 extern "C" int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,

@@ -3,13 +3,18 @@
 #define BGK_FUSED2_H
 #include <stdint.h>
 
+#define BGK_MAX_COND 3
+/* several conditioning tensors [B, w_i] standing for their concatenation (host-side table of device pointers; NULL / n <= 1: the
+ * single (cond, ldc, d_c) tensor of the launcher's own arguments) */
+struct BgkCondSegs { const float* ptr[BGK_MAX_COND]; int64_t ld[BGK_MAX_COND]; int32_t w[BGK_MAX_COND]; int32_t n; };
+
 int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                               const void* A0p, const void* A1p, const void* A2p, float c0, float c1, float c2, const float* cs_dev,
                               int32_t act, const float* y, int64_t ldy, int64_t B, int32_t d, uint64_t circ_mask, int32_t inverse,
                               double left, double right, double bottom, double top,
                               double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
-                              void* stream);
+                              void* stream, const BgkCondSegs* segs = nullptr);
 
 /* the training forward (bgk_fused2_train.hip): same kernel + z0, z1 [B, 128] and params [B, P] written for the backward */
 int bgk_launch_rqs_dense_h2v2_train(const char* what, float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col,
@@ -19,7 +24,7 @@ int bgk_launch_rqs_dense_h2v2_train(const char* what, float* z0, float* z1, floa
                                     double left, double right, double bottom, double top,
                                     double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
                                     float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
-                                    void* stream);
+                                    void* stream, const BgkCondSegs* segs = nullptr);
 
 /* reduced-precision mode "bf16" (bgk_fused2_bf16.hip): same kernel, one bf16 MFMA per product */
 int bgk_launch_rqs_dense_h2v2_bf16(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
@@ -28,7 +33,7 @@ int bgk_launch_rqs_dense_h2v2_bf16(const char* what, const float* cond, int64_t 
                                    double left, double right, double bottom, double top,
                                    double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
                                    float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
-                                   void* stream);
+                                   void* stream, const BgkCondSegs* segs = nullptr);
 
 /* affine coupling layer with conditioners of width 128 (two or three hidden layers) on the same event-threaded GEMM stream
  * (bgk_fused2.hip); BGK_EUNSUPPORTED for activation pairs it has no instance for */
@@ -37,7 +42,7 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
                                const void* tA0, const void* tA1, const void* tA1b, const void* tA2, float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
                                const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                                const float* y, int64_t ldy, int64_t B, int32_t d,
-                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
+                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream, const BgkCondSegs* segs = nullptr);
 
 /* 2 (default): coupling_rqs_dense_h2v2_kernel for the split-f16 path (inference and training forward); 1: the first-generation kernel */
 extern int bgk_h2_variant;

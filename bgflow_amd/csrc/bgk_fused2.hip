@@ -85,6 +85,13 @@ constexpr int GBLK = KS * 8 + 4;      /* 1 KiB blocks per packed 128-row GEMM in
 constexpr int RD = BGK_V2_RD;         /* A-fragment ring depth in tile-steps */
 constexpr int EH = 34;                /* hook points per spline element */
 
+/* conditioning input as up to BGK_MAX_COND tensors [B, w_i] that stand for their concatenation (CouplingFlow's torch.cat of the
+ * conditioning tensors, nn/flow/coupling.py:162-165, without the copy): segment i fills feature rows off[i] .. off[i] + w[i] */
+struct CondSegs {
+    const float* ptr[BGK_MAX_COND]; int64_t ld[BGK_MAX_COND]; int w[BGK_MAX_COND]; int off[BGK_MAX_COND]; uint32_t magic[BGK_MAX_COND];
+    int n;
+};
+
 struct SetK { float gnum, low, high, dstep; float kc[7]; };   /* gnum = span * scale, dstep = span * min_bin, kc[k] = low + dstep (k + 1) */
 
 struct SpC {                          /* spline constants */
@@ -94,7 +101,8 @@ struct SpC {                          /* spline constants */
 };
 
 struct V2Args {
-    const float* cond; int64_t ldc; int d_c; int periodic; uint32_t magic_dc;
+    CondSegs cs;                      /* the conditioning tensor(s): up to BGK_MAX_COND column blocks, each with its own rows */
+    int d_c; int periodic;            /* total conditioning width; 1 = featurise as [cos 2 pi c | sin 2 pi c] */
     const float* y; int64_t ldy; float* out; int64_t ldo; int d; uint32_t magic_d;
     int64_t B; float* dlogp; int accumulate; int32_t* bin_idx; int32_t* oob_count;
     const uint4* A0; const uint4* A1; const uint4* A2; int S0; int n_chunks; int last_tiles;
@@ -642,16 +650,15 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
     if (tile >= n_tiles) return;
     const SpK k{a.c2 * 1.44269504088896341f, a.c2 * a.sc.beta * 1.44269504088896341f, a.c2};
     const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
-    const int ldc32 = (int)a.ldc, ldy32 = (int)a.ldy, ldo32 = (int)a.ldo;
-    const int n_c = 32 * a.d_c, n_y = 32 * d;
+    const int ldy32 = (int)a.ldy, ldo32 = (int)a.ldo;
+    const int n_y = 32 * d;
 
   {
     const int lane = (int)threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
     const unsigned voff = (unsigned)lane * 16u;
     const int64_t b0 = tile * 32;
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
-    const float* cond_t = a.cond + b0 * a.ldc;     /* wave-uniform tile bases, 32-bit per-lane offsets */
-    const float* y_t = a.y + b0 * a.ldy;
+    const float* y_t = a.y + b0 * a.ldy;            /* wave-uniform tile bases, 32-bit per-lane offsets */
     float* out_t = a.out + b0 * a.ldo;
 
     /* ---- stage the (featurised) conditioner input [feature][sample], a constant-1 row for the bias, zero pad rows.
@@ -662,14 +669,22 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
 #define BGK_V2_SB 10
 #endif
     constexpr int SB = BGK_V2_SB;
-    for (int base = 0; base < (n_c > n_y ? n_c : n_y); base += 64 * SB) {
+    /* the segment table is indexed at run time: read it from the kernel-argument block (constant address space, scalar loads) --
+     * indexing the by-value argument struct would make the compiler copy the whole struct to scratch memory */
+    const kargs_t kseg = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int sg = 0; sg < a.cs.n; ++sg) {           /* conditioning tensor sg (one for a single-tensor coupling); y travels with the first */
+    const float* cond_t = kseg->cs.ptr[sg] + b0 * kseg->cs.ld[sg];
+    const int ldc32 = (int)kseg->cs.ld[sg], w_c = kseg->cs.w[sg], n_c = 32 * w_c, row0 = kseg->cs.off[sg] * SROW;
+    const uint32_t magic_c = kseg->cs.magic[sg];
+    const int n_ys = sg == 0 ? n_y : 0;
+    for (int base = 0; base < (n_c > n_ys ? n_c : n_ys); base += 64 * SB) {
         float vc[SB], vy[SB];
         int oc[SB], oy[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int i = base + u * 64 + lane;
-            const int r = (int)(__umul24((unsigned)i, a.magic_dc) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)a.d_c);
-            oc[u] = i < n_c ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
+            const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
+            oc[u] = i < n_c ? row0 + (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
 #if (BGK_V2_ABL & 8)
             vc[u] = 0.25f;
 #else
@@ -680,11 +695,11 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         for (int u = 0; u < SB; ++u) {
             const int i = base + u * 64 + lane;
             const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
-            oy[u] = i < n_y ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
+            oy[u] = i < n_ys ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
 #if (BGK_V2_ABL & 8)
             vy[u] = 0.5f;
 #else
-            vy[u] = (i < n_y && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.5f;
+            vy[u] = (i < n_ys && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.5f;
 #endif
         }
 #pragma unroll
@@ -703,6 +718,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
 #pragma unroll
         for (int u = 0; u < SB; ++u)
             if (oy[u] >= 0) s_y[oy[u]] = vy[u];
+    }
     }
     for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
         s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
@@ -869,6 +885,27 @@ SetK make_set(double low, double high, double min_bin, int K) {
  * strides multiplied the same way must stay below 2^24 (launch_h2 checks) */
 uint32_t magic_div(int d) { return (uint32_t)(((1u << 20) + (uint32_t)d - 1) / (uint32_t)d); }
 
+/* fill the kernel's segment table: `segs` (several conditioning tensors) or the single tensor (cond, ldc, d_c); false = bad input */
+bool make_cond_segs(CondSegs& cs, const float* cond, int64_t ldc, int d_c, const BgkCondSegs* segs) {
+    for (int i = 0; i < BGK_MAX_COND; ++i) { cs.ptr[i] = nullptr; cs.ld[i] = 0; cs.w[i] = 0; cs.off[i] = 0; cs.magic[i] = 0; }
+    if (!segs || segs->n <= 1) {
+        const float* p = segs && segs->n == 1 ? segs->ptr[0] : cond;
+        const int64_t ld = segs && segs->n == 1 ? segs->ld[0] : ldc;
+        if (!p || d_c <= 0 || ld >= (1 << 24)) return false;
+        cs.n = 1; cs.ptr[0] = p; cs.ld[0] = ld; cs.w[0] = d_c; cs.magic[0] = magic_div(d_c);
+        return true;
+    }
+    if (segs->n > BGK_MAX_COND) return false;
+    int off = 0;
+    for (int i = 0; i < segs->n; ++i) {
+        if (!segs->ptr[i] || segs->w[i] <= 0 || segs->ld[i] < segs->w[i] || segs->ld[i] >= (1 << 24)) return false;
+        cs.ptr[i] = segs->ptr[i]; cs.ld[i] = segs->ld[i]; cs.w[i] = segs->w[i]; cs.off[i] = off; cs.magic[i] = magic_div(segs->w[i]);
+        off += segs->w[i];
+    }
+    cs.n = segs->n;
+    return off == d_c;
+}
+
 
 #if !BGK_V2_SAVE && !BGK_V2_BF16
 /* ---- affine (RealNVP) coupling layer with two conditioner networks of width 128 on the same event-threaded GEMM stream ----------
@@ -882,7 +919,7 @@ uint32_t magic_div(int d) { return (uint32_t)(((1u << 20) + (uint32_t)d - 1) / (
  * dim costs 64 cache-line requests per instruction). */
 struct AffV2Net { const uint4* A0; const uint4* A1; const uint4* A1b; const uint4* A2; float c0, c1, c1b, c2; };   /* A1b: third hidden layer or NULL */
 struct AffV2Args {
-    const float* cond; int64_t ldc; int d_c; int periodic; uint32_t magic_dc; int S0;
+    CondSegs cs; int d_c; int periodic; int S0;
     AffV2Net shift, scale; int has_shift, has_scale;
     const float* log_alpha; int preserve_volume, is_circular, inverse;
     const float* y; int64_t ldy; int64_t B; int d;
@@ -1002,13 +1039,12 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
     const int64_t tile = (int64_t)blockIdx.x * FW + wave;
     if (tile >= n_tiles) return;
     const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
-    const int ldc32 = (int)a.ldc, ldy32 = (int)a.ldy, ldo32 = (int)a.ldo;
-    const int n_c = 32 * a.d_c, n_y = 32 * d;
+    const int ldy32 = (int)a.ldy, ldo32 = (int)a.ldo;
+    const int n_y = 32 * d;
     const int lane = (int)threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
     const unsigned voff = (unsigned)lane * 16u;
     const int64_t b0 = tile * 32;
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
-    const float* cond_t = a.cond + b0 * a.ldc;
     const float* y_t = a.y + b0 * a.ldy;
     float* out_t = a.out + b0 * a.ldo;
 
@@ -1018,22 +1054,29 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
 #define BGK_AFF_SB 34       /* loads in flight per lane and array: one HBM round trip for up to 68 dims (nothing else is live yet) */
 #endif
     constexpr int SB = BGK_AFF_SB;
-    for (int base = 0; base < (n_c > n_y ? n_c : n_y); base += 64 * SB) {
+    typedef const __attribute__((address_space(4))) AffV2Args* akargs_t;      /* run-time indexed: scalar loads from the argument block */
+    const akargs_t kseg = (akargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    for (int sg = 0; sg < a.cs.n; ++sg) {           /* conditioning tensor sg; y travels with the first */
+    const float* cond_t = kseg->cs.ptr[sg] + b0 * kseg->cs.ld[sg];
+    const int ldc32 = (int)kseg->cs.ld[sg], w_c = kseg->cs.w[sg], n_c = 32 * w_c, row0 = kseg->cs.off[sg] * SROW;
+    const uint32_t magic_c = kseg->cs.magic[sg];
+    const int n_ys = sg == 0 ? n_y : 0;
+    for (int base = 0; base < (n_c > n_ys ? n_c : n_ys); base += 64 * SB) {
         float vc[SB], vy[SB];
         int oc[SB], oy[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int i = base + u * 64 + lane;
-            const int r = (int)(__umul24((unsigned)i, a.magic_dc) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)a.d_c);
-            oc[u] = i < n_c ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
+            const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
+            oc[u] = i < n_c ? row0 + (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
             vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int i = base + u * 64 + lane;
             const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
-            oy[u] = i < n_y ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
-            vy[u] = (i < n_y && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.0f;
+            oy[u] = i < n_ys ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
+            vy[u] = (i < n_ys && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
@@ -1051,6 +1094,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
 #pragma unroll
         for (int u = 0; u < SB; ++u)
             if (oy[u] >= 0) s_y[oy[u]] = vy[u];
+    }
     }
     for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
         s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
@@ -1154,10 +1198,11 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
                               double left, double right, double bottom, double top,
                               double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
-                              void* stream) {
+                              void* stream, const BgkCondSegs* segs) {
     V2Args a;
     const int n_in = periodic ? 2 * d_c : d_c;
-    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic; a.magic_dc = magic_div(d_c);
+    BGK_CHECK_ARG(make_cond_segs(a.cs, cond, ldc, d_c, segs), "%s: bad conditioning segments", what);
+    a.d_c = d_c; a.periodic = periodic;
     a.y = y; a.ldy = ldy; a.out = out; a.ldo = ldo; a.d = d; a.magic_d = magic_div(d);
     a.B = B; a.dlogp = dlogp; a.accumulate = accumulate; a.bin_idx = bin_idx; a.oob_count = oob_count;
     a.A0 = reinterpret_cast<const uint4*>(A0p); a.A1 = reinterpret_cast<const uint4*>(A1p); a.A2 = reinterpret_cast<const uint4*>(A2p);
@@ -1181,7 +1226,7 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
     const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
     BGK_CHECK_ARG((int64_t)32 * (d > d_c ? d : d_c) < (1 << 16), "%s: tile index range", what);
-    BGK_CHECK_ARG(ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24), "%s: row stride too large", what);
+    BGK_CHECK_ARG(ldy < (1 << 24) && ldo < (1 << 24), "%s: row stride too large", what);
     const int grid = (int)n_wg;
     hipStream_t st = (hipStream_t)stream;
 #define BGK_LAUNCH(A, I) hipLaunchKernelGGL((coupling_rqs_dense_h2v2_kernel<A, I>), dim3(grid), dim3(FTHREADS), shmem, st, a)
@@ -1201,11 +1246,12 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
                                const void* tA0, const void* tA1, const void* tA1b, const void* tA2, float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
                                const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                                const float* y, int64_t ldy, int64_t B, int32_t d,
-                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream, const BgkCondSegs* segs) {
     const char* what = "bgk_coupling_affine_dense_h2";
     AffV2Args a;
     const int n_in = periodic ? 2 * d_c : d_c;
-    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic; a.magic_dc = magic_div(d_c); a.S0 = (n_in + 1 + 15) / 16;
+    BGK_CHECK_ARG(make_cond_segs(a.cs, cond, ldc, d_c, segs), "%s: bad conditioning segments", what);
+    a.d_c = d_c; a.periodic = periodic; a.S0 = (n_in + 1 + 15) / 16;
     a.shift = AffV2Net{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA1b, (const uint4*)sA2, sc0, sc1, sc1b, sc2};
     a.scale = AffV2Net{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA1b, (const uint4*)tA2, tc0, tc1, tc1b, tc2};
     a.has_shift = sA0 != nullptr; a.has_scale = tA0 != nullptr;
@@ -1223,7 +1269,7 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
     const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
-    BGK_CHECK_ARG(ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24) && (int64_t)32 * d_c < 4096 && (int64_t)32 * d < 4096
+    BGK_CHECK_ARG(ldy < (1 << 24) && ldo < (1 << 24) && (int64_t)32 * d_c < 4096 && (int64_t)32 * d < 4096
                   && OT >= 1 && OT <= 3, "%s: outside the kernel's envelope", what);
     if (shmem > 160 * 1024) {
         bgk_set_error("%s: %d input features / %d dims do not fit the LDS tiles", what, n_in, d);

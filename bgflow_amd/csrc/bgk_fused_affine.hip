@@ -529,7 +529,9 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
                                int32_t hidden, const float* log_alpha, int32_t preserve_volume,
                                int32_t is_circular, int32_t inverse,
                                const float* y, int64_t ldy, int64_t B, int32_t d,
-                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream, const BgkCondSegs* segs = nullptr) {
+    const bool multi = segs && segs->n > 1;       /* several conditioning tensors: the event-threaded width-128 kernel only */
+    if (segs && segs->n >= 1) { cond = segs->ptr[0]; ldc = segs->ld[0]; }
     BGK_CHECK_ARG(cond && y && out && dlogp, "bgk_coupling_affine_dense_h2: null pointer");
     BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "bgk_coupling_affine_dense_h2: bad sizes");
     const int has_shift = sA0 != nullptr, has_scale = tA0 != nullptr;
@@ -559,6 +561,7 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
     a.cvec4 = (ldc % 4 == 0) && ((uintptr_t)cond % 16 == 0);
     const int OT = (d + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    if (multi && !(hidden == 128 && bgk_affine_variant == 2)) return BGK_EUNSUPPORTED;
     if (hidden == 64 && bgk_affine_variant == 2 && !sA1b && !tA1b) {
         /* weight-resident kernel: operands of both networks in LDS */
         const int n0 = res_blocks16(a.S0, RES_HT, false), n1 = res_blocks16(2 * RES_HT, RES_HT, true), n2 = res_blocks16(2 * RES_HT, OT, true);
@@ -590,9 +593,10 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
         /* width 128: MFMA events threaded through the activation code (bgk_fused2.hip); it declines activation pairs it has no instance for */
         const int st2 = bgk_launch_affine_dense_v2(cond, ldc, d_c, periodic, sA0, sA1, sA1b, sA2, sc0, sc1, sc1b, sc2, s_act,
                                                    tA0, tA1, tA1b, tA2, tc0, tc1, tc1b, tc2, t_act, log_alpha, preserve_volume, is_circular,
-                                                   inverse, y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
+                                                   inverse, y, ldy, B, d, out, ldo, dlogp, accumulate, stream, segs);
         if (st2 != BGK_EUNSUPPORTED) return st2;
     }
+    if (multi) return BGK_EUNSUPPORTED;
 #define BGK_LAUNCH(H, O) hipLaunchKernelGGL((coupling_affine_dense_kernel<H, O>), dim3((int)n_wg), dim3(AW * 64), shmem, st, a)
     if (hidden == 64) { if (OT == 1) BGK_LAUNCH(2, 1); else if (OT == 2) BGK_LAUNCH(2, 2); else BGK_LAUNCH(2, 3); }
     else { if (OT == 1) BGK_LAUNCH(4, 1); else if (OT == 2) BGK_LAUNCH(4, 2); else BGK_LAUNCH(4, 3); }
@@ -627,4 +631,52 @@ extern "C" int bgk_coupling_affine_dense_h3(const float* cond, int64_t ldc, int3
     return affine_dense_launch(cond, ldc, d_c, periodic, sA0, sA1, sA1b, sA2, sc0, sc1, sc1b, sc2, s_act,
                                tA0, tA1, tA1b, tA2, tc0, tc1, tc1b, tc2, t_act, hidden, log_alpha, preserve_volume, is_circular, inverse,
                                y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
+}
+
+/* the same layers with the conditioning input given as 1..BGK_MAX_COND tensors [B, width_i] that stand for their concatenation along
+ * the feature axis (CouplingFlow's torch.cat over cond_indices, nn/flow/coupling.py:162-165, without the copy): cond / ldc / width
+ * are HOST arrays of n_cond device pointers / row strides / widths */
+static int affine_mc(const float* const* cond, const int64_t* ldc, const int32_t* width, int32_t n_cond, BgkCondSegs& segs, int& d_c) {
+    BGK_CHECK_ARG(cond && ldc && width && n_cond >= 1 && n_cond <= BGK_MAX_COND, "bgk_coupling_affine_dense_*_mc: 1..%d conditioning tensors", BGK_MAX_COND);
+    d_c = 0;
+    for (int i = 0; i < n_cond; ++i) { segs.ptr[i] = cond[i]; segs.ld[i] = ldc[i]; segs.w[i] = width[i]; d_c += width[i]; }
+    segs.n = n_cond;
+    return 0;
+}
+
+extern "C" int bgk_coupling_affine_dense_h2_mc(const float* const* cond, const int64_t* ldc, const int32_t* width, int32_t n_cond, int32_t periodic,
+                                               const void* sA0, const void* sA1, const void* sA2,
+                                               float sc0, float sc1, float sc2, int32_t s_act,
+                                               const void* tA0, const void* tA1, const void* tA2,
+                                               float tc0, float tc1, float tc2, int32_t t_act,
+                                               int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                               int32_t is_circular, int32_t inverse,
+                                               const float* y, int64_t ldy, int64_t B, int32_t d,
+                                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    BgkCondSegs segs{};
+    int d_c = 0;
+    const int st = affine_mc(cond, ldc, width, n_cond, segs, d_c);
+    if (st) return st;
+    return affine_dense_launch(cond[0], ldc[0], d_c, periodic, sA0, sA1, nullptr, sA2, sc0, sc1, 1.0f, sc2, s_act,
+                               tA0, tA1, nullptr, tA2, tc0, tc1, 1.0f, tc2, t_act, hidden, log_alpha, preserve_volume, is_circular, inverse,
+                               y, ldy, B, d, out, ldo, dlogp, accumulate, stream, &segs);
+}
+
+extern "C" int bgk_coupling_affine_dense_h3_mc(const float* const* cond, const int64_t* ldc, const int32_t* width, int32_t n_cond, int32_t periodic,
+                                               const void* sA0, const void* sA1, const void* sA1b, const void* sA2,
+                                               float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
+                                               const void* tA0, const void* tA1, const void* tA1b, const void* tA2,
+                                               float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
+                                               int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                               int32_t is_circular, int32_t inverse,
+                                               const float* y, int64_t ldy, int64_t B, int32_t d,
+                                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    BGK_CHECK_ARG((sA0 == nullptr || sA1b) && (tA0 == nullptr || tA1b), "bgk_coupling_affine_dense_h3_mc: missing third hidden layer");
+    BgkCondSegs segs{};
+    int d_c = 0;
+    const int st = affine_mc(cond, ldc, width, n_cond, segs, d_c);
+    if (st) return st;
+    return affine_dense_launch(cond[0], ldc[0], d_c, periodic, sA0, sA1, sA1b, sA2, sc0, sc1, sc1b, sc2, s_act,
+                               tA0, tA1, tA1b, tA2, tc0, tc1, tc1b, tc2, t_act, hidden, log_alpha, preserve_volume, is_circular, inverse,
+                               y, ldy, B, d, out, ldo, dlogp, accumulate, stream, &segs);
 }

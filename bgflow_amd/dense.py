@@ -158,6 +158,24 @@ class WrapDistances(torch.nn.Module):
 _ACT_CODES = {torch.nn.SiLU: 1, torch.nn.ReLU: 2, torch.nn.Tanh: 3}
 
 
+def _reject(transformer, reason):
+    """A coupling whose conditioner LOOKS fusable (a DenseNet, optionally behind WrapPeriodic) leaves the one-launch kernels'
+    envelope: say so once per transformer and reason -- the generic path (library GEMMs + the stand-alone transformer kernel) is
+    several times slower (49 vs 8.5 ms per cfg-3 pass, profiles/README.md r01), and K > 64 runs on device torch ops."""
+    seen = transformer.__dict__.setdefault("_fused_rejections", set())
+    if reason not in seen:
+        seen.add(reason)
+        import warnings
+        warnings.warn(f"{type(transformer).__name__}: not running as ONE fused kernel ({reason}); falling back to conditioner GEMMs + "
+                      f"the stand-alone transformer kernel", RuntimeWarning, stacklevel=3)
+    return None
+
+
+def _looks_dense(net):
+    inner = net.net if type(net) is WrapPeriodic else net
+    return type(inner) is DenseNet
+
+
 def _fusable_dense(net):
     """Return (linears, act_code) if ``net`` is Linear-act-Linear-act-Linear with one supported
     activation type, else None."""
@@ -364,6 +382,9 @@ def _affine_plan(transformer, y_dim):
         periodic = per
         spec = _fusable_dense_deep(n)
         if spec is None:
+            if type(n) is DenseNet:
+                return _reject(transformer, "the fused affine kernels take DenseNets with two or three hidden layers, biases and one of "
+                                            "SiLU / ReLU / Tanh")
             return None
         specs.append(spec)
     live = [sp for sp in specs if sp is not None]
@@ -373,7 +394,8 @@ def _affine_plan(transformer, y_dim):
                 or any(m.out_features != H for m in lins[:-1]) or any(m.in_features != H for m in lins[1:]):
             return None
     if H not in (64, 128) or y_dim > 96 or n_in > 127 or (periodic and n_in % 2):
-        return None
+        return _reject(transformer, f"hidden width {H} / {y_dim} transformed dims / {n_in} input features: fused for width 64 | 128, "
+                                    f"<= 96 dims, <= 127 input features")
     params = [p for (ls, _) in live for lin in ls for p in (lin.weight, lin.bias)]
     version = tuple((p.data_ptr(), p._version) for p in params)
     cache = transformer._fused_cache
@@ -384,24 +406,36 @@ def _affine_plan(transformer, y_dim):
     return cache
 
 
-def fused_affine_coupling(transformer, x, y, inverse, out=None, dlogp=None, accumulate=False):
+def _cond_parts(x):
+    """the conditioning tensors of a coupling: [x] or the parts of a flow.CatView (<= 3 of them go to the kernels unconcatenated)"""
+    from .flow import CatView
+    if isinstance(x, CatView):
+        return list(x.parts) if len(x.parts) <= 3 else [x.cat()]
+    return [x]
+
+
+def fused_affine_coupling(transformer, x, y, inverse, out=None, dlogp=None, accumulate=False, acc=None):
     """Try the one-launch affine coupling layer (bgk_coupling_affine_dense_h2).  Returns (y', dlogp) or None when
     the conditioners are not fusable DenseNets (the caller then runs the nets + bgk_affine_transform).
     ``out`` ([B, d] rows, any row stride; may alias ``y``: every element is read and written by the same lane) and
     ``dlogp`` ([B] contiguous, ``accumulate``: added to instead of overwritten) let a caller chain layers without copies."""
     if _gemm_mode(transformer) == "f32":
-        return None            # there is no exact-f32 fused affine kernel: "f32" selects the generic path ("bf16": split-f16)
+        return _reject(transformer, "gemm_mode 'f32' has no fused affine kernel")     # "f32" selects the generic path ("bf16": split-f16)
     if x.dim() != 2 or y.dim() != 2 or not x.is_cuda or x.dtype != torch.float32:
         return None
     plan = _affine_plan(transformer, y.shape[-1])
     if plan is None or x.shape[-1] != plan["d_c"]:
         return None
-    _lib.require_hip(x, y)
-    x2, ldc = _lib.rowmajor(x)
+    parts = _cond_parts(x)
+    if len(parts) > 1 and plan["hidden"] != 128:
+        parts = [x.cat()]                 # several conditioning tensors: the width-128 kernel only
+    _lib.require_hip(y, *parts)
     y2, ldy = _lib.rowmajor(y)
     B, d = y2.shape
     if out is None:
         out = torch.empty((B, d), dtype=torch.float32, device=y.device)
+    if acc is not None:
+        dlogp, accumulate = acc.peek()
     if dlogp is None:
         dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=y.device), False
     ldo = out.stride(0)
@@ -421,15 +455,27 @@ def fused_affine_coupling(transformer, x, y, inverse, out=None, dlogp=None, accu
             else:
                 args += [_lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2, act]
     log_alpha = transformer._log_alpha.detach().to(device=y.device, dtype=torch.float32)
-    entry_point = _lib.lib().bgk_coupling_affine_dense_h3 if deep else _lib.lib().bgk_coupling_affine_dense_h2
-    with torch.cuda.device(y.device):
-        st = entry_point(
-            _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), *args, plan["hidden"], _lib.ptr(log_alpha),
-            int(transformer._preserve_volume), int(transformer._is_circular), int(inverse),
+    lib = _lib.lib()
+    tail = (*args, plan["hidden"], _lib.ptr(log_alpha), int(transformer._preserve_volume), int(transformer._is_circular), int(inverse),
             _lib.ptr(y2), ldy, B, d, _lib.ptr(out), ldo, _lib.ptr(dlogp), int(bool(accumulate)), _lib.stream_ptr(y.device))
+    with torch.cuda.device(y.device):
+        st = -2
+        if len(parts) > 1:
+            ptrs, lds, widths, n, keep = _lib.cond_segments(parts)
+            st = (lib.bgk_coupling_affine_dense_h3_mc if deep else lib.bgk_coupling_affine_dense_h2_mc)(
+                ptrs, lds, widths, n, int(plan["periodic"]), *tail)
+            if st == -2:
+                parts = [x.cat()]         # a kernel without the segment table: concatenate after all
+        if st == -2:
+            x2, ldc = _lib.rowmajor(parts[0])
+            st = (lib.bgk_coupling_affine_dense_h3 if deep else lib.bgk_coupling_affine_dense_h2)(
+                _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), *tail)
     if st == -2:
-        return None
+        return _reject(transformer, "shape outside the fused affine kernels' envelope: " + _lib.lib().bgk_last_error().decode(errors="replace"))
     _lib.check(st, "bgk_coupling_affine_dense_h3" if deep else "bgk_coupling_affine_dense_h2")
+    if acc is not None:
+        acc.commit()
+        return out, acc
     return out, dlogp[:, None]
 
 
@@ -510,29 +556,37 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     periodic = False
     if type(net) is WrapPeriodic:
         if not (net.left == 0.0 and net.right == 1.0):
-            return None
+            return _reject(transformer, "WrapPeriodic on an interval other than [0, 1]") if _looks_dense(net) else None
         inner = net.net
         periodic = True
     else:
         inner = net
     spec = _fusable_dense(inner)
     if spec is None:
+        if type(inner) is DenseNet:
+            return _reject(transformer, "the fused spline kernels take a DenseNet with exactly two hidden layers, biases and one of "
+                                        "SiLU / ReLU / Tanh")
         return None
     (l0, l1, l2), act = spec
-    if l0.out_features != 128 or l1.out_features != 128 or y_dim > 64:
-        return None
+    if l0.out_features != 128 or l1.out_features != 128:
+        return _reject(transformer, f"hidden layers ({l0.out_features}, {l1.out_features}): only (128, 128) is fused")
+    if y_dim > 64:
+        return _reject(transformer, f"{y_dim} transformed dims: at most 64 are fused")
     n_nc = int((nc_slot_host >= 0).sum())
     P = l2.out_features
     n_bins = (P - n_nc) // (3 * y_dim)
     if 3 * n_bins * y_dim + n_nc != P:
         return None
     if n_bins != 8 and not (n_bins in (4, 12, 16, 32) and mode == "f16x2"):
-        return None            # K = 4 | 12 | 16 | 32: split-f16 form only (first-generation kernel); anything else: generic path
+        # K = 4 | 12 | 16 | 32: split-f16 form only (first-generation kernel); anything else: generic path
+        return _reject(transformer, f"{n_bins} bins in gemm_mode '{mode}': fused for 8 bins, and for 4 / 12 / 16 / 32 bins in mode 'f16x2'"
+                                    + ("; more than 64 bins run on device torch ops" if n_bins > 64 else ""))
     d_c = l0.in_features // 2 if periodic else l0.in_features
     if periodic:
         idx = np.arange(d_c)[net.indices] if not isinstance(net.indices, slice) or net.indices != slice(None) else np.arange(d_c)
         if len(idx) != d_c or 2 * d_c != l0.in_features or not np.array_equal(np.asarray(idx), np.arange(d_c)):
-            return None   # only "all conditioner inputs periodic, in natural order" is fused (the kernel featurises columns 0..d_c-1)
+            # only "all conditioner inputs periodic, in natural order" is fused (the kernel featurises columns 0..d_c-1)
+            return _reject(transformer, "WrapPeriodic over a subset / permutation of the conditioner inputs")
     params = [p for lin in (l0, l1, l2) for p in (lin.weight, lin.bias)]
     version = tuple((p.data_ptr(), p._version) for p in params)
     cache = transformer._fused_cache
@@ -560,7 +614,7 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     return cache
 
 
-def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter, want_bin_idx=False):
+def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter, want_bin_idx=False, acc=None):
     """Try the one-launch coupling layer (bgk_coupling_rqs_dense).  Returns (y', dlogp[, bin_idx]) or
     None when the conditioner is not a fusable DenseNet (the caller then runs conditioner +
     bgk_rqs_transform)."""
@@ -569,34 +623,49 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
     plan = _fused_plan(transformer, y.shape[-1], nc_slot_host)
     if plan is None or x.shape[-1] != plan["d_c"]:
         return None
-    _lib.require_hip(x, y)
+    parts = _cond_parts(x)
+    if len(parts) > 1 and (plan["mode"] == "f32" or plan["n_bins"] != 8):
+        parts = [x.cat()]                 # several conditioning tensors: the second-generation kernel only
+    _lib.require_hip(y, *parts)
     W0p, W1p, W2p = plan["packed"][:3]
     if W0p.device != y.device:
         return None
-    x2, ldc = _lib.rowmajor(x)
     y2, ldy = _lib.rowmajor(y)
     B, d = y2.shape
     out = torch.empty((B, d), dtype=torch.float32, device=y.device)
-    dlogp = torch.empty((B,), dtype=torch.float32, device=y.device)
+    if acc is not None:
+        dlogp, accumulate = acc.peek()
+    else:
+        dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=y.device), False
     bins = torch.empty((B, d), dtype=torch.int32, device=y.device) if want_bin_idx else None
     s = transformer._default_settings
     tail = (128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
             transformer._left, transformer._right, transformer._bottom, transformer._top,
             s["min_bin_width"], s["min_bin_height"], s["min_derivative"], int(s.get("enable_identity_init", False)),
-            _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.ptr(bins), _lib.ptr(oob_counter), _lib.stream_ptr(y.device))
+            _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)), _lib.ptr(bins), _lib.ptr(oob_counter), _lib.stream_ptr(y.device))
     with torch.cuda.device(y.device):
         if plan["mode"] == "f32":
+            x2, ldc = _lib.rowmajor(parts[0])
             st = _lib.lib().bgk_coupling_rqs_dense(
                 _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p), *tail)
         else:
             c0, c1, c2 = plan["packed"][3]
-            st = _lib.lib().bgk_coupling_rqs_dense_h2(
-                _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p),
-                c0, c1, c2, _lib.ptr(plan.get("cs")), int(plan["mode"] == "bf16"), *tail)
+            ops = (_lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p), c0, c1, c2, _lib.ptr(plan.get("cs")), int(plan["mode"] == "bf16"))
+            st = -2
+            if len(parts) > 1:
+                ptrs, lds, widths, n, keep = _lib.cond_segments(parts)
+                st = _lib.lib().bgk_coupling_rqs_dense_h2_mc(ptrs, lds, widths, n, int(plan["periodic"]), *ops, *tail)
+                if st == -2:
+                    parts = [x.cat()]
+            if st == -2:
+                x2, ldc = _lib.rowmajor(parts[0])
+                st = _lib.lib().bgk_coupling_rqs_dense_h2(_lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), *ops, *tail)
     if st == -2:
-        return None
+        return _reject(transformer, "shape outside the fused spline kernels' envelope: " + _lib.lib().bgk_last_error().decode(errors="replace"))
     _lib.check(st, "bgk_coupling_rqs_dense")
-    res = (out, dlogp[:, None])
+    if acc is not None:
+        acc.commit()
+    res = (out, acc if acc is not None else dlogp[:, None])
     return res + (bins,) if want_bin_idx else res
 
 
@@ -653,12 +722,31 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
 
 FUSED_WEIGHT_GRAD = True     # weight / bias gradients on bgk_dense_weight_grad (False: split-K bmm + bgk_column_sum)
 
+_DIRECT_GRADS = [False]
+
+
+class direct_grad_accumulation:
+    """Context manager: inside it, the backward of the fused training layers ADDS its weight / bias gradients straight into the
+    flat gradient bucket of a ``training.FlatAdam`` (and returns None to autograd for them) instead of handing them to
+    AccumulateGrad.  Only the optimizer's own ``backward`` / ``KLTrainer.train`` switch it on: any other differentiation through
+    the flow (``torch.autograd.grad``, ``Energy.force``, gradient penalties) gets ordinary gradients and leaves ``.grad`` alone."""
+
+    def __enter__(self):
+        self._prev = _DIRECT_GRADS[0]
+        _DIRECT_GRADS[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _DIRECT_GRADS[0] = self._prev
+        return False
+
 
 def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, params=None, h_act=0):
     """bgk_dense_weight_grad: (gW0, gb0, gW1, gb1, gW2, gb2) of one coupling layer's conditioner.
-    ``params`` = (W0, b0, W1, b1, W2, b2): when ALL of them carry a flat-bucket gradient destination (``_bgk_grad_dst``, set by
-    training.FlatAdam) the kernel accumulates straight into the bucket and None is returned for every gradient -- no
-    per-parameter AccumulateGrad add kernels (96 tiny launches per cfg-3 step).  ``h_act`` != 0: ``h1`` / ``h0`` are the saved
+    ``params`` = (W0, b0, W1, b1, W2, b2): inside ``direct_grad_accumulation()`` (entered by FlatAdam.backward / KLTrainer only),
+    when ALL of them carry a flat-bucket gradient destination (``_bgk_grad_dst``, set by training.FlatAdam), the kernel accumulates
+    straight into the bucket and None is returned for every gradient -- no per-parameter AccumulateGrad add kernels (96 tiny
+    launches per cfg-3 step).  ``h_act`` != 0: ``h1`` / ``h0`` are the saved
     pre-activations and the kernel applies activation ``h_act`` while loading them."""
     dev = g_p.device
     B, P = g_p.shape
@@ -669,7 +757,7 @@ def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, p
     ws = bufs.get("wgrad_ws")
     if ws is None or ws.numel() < need_ws or ws.device != dev:
         ws = bufs["wgrad_ws"] = torch.empty(need_ws, dtype=torch.float32, device=dev)
-    direct = params is not None and all(need[2:8]) and all(
+    direct = _DIRECT_GRADS[0] and params is not None and all(need[2:8]) and all(
         getattr(p, "_bgk_grad_dst", None) is not None and p.grad is not None and p.grad.data_ptr() == p._bgk_grad_dst.data_ptr()
         for p in params)      # only while p.grad IS the bucket view (a zero_grad(set_to_none=True) elsewhere switches this off)
     if direct:

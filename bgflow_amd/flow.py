@@ -37,6 +37,106 @@ def _zero_dlogp(x):
     return torch.zeros(*x.shape[:-1], 1, dtype=x.dtype, device=x.device)
 
 
+ACC_KW = "_bgk_logdet"      # private kwarg: the running log|det J| buffer of the enclosing SequentialFlow pass
+
+
+class _LogDetAcc:
+    """The running log|det J| of one SequentialFlow pass: ONE [B] f32 buffer that every kernel-backed block adds its log-det to
+    inside its own kernel (``accumulate`` of the C ABI) -- the reference's ``dlogp += ddlogp`` (sequential.py:58) without a
+    per-block [B, 1] tensor, without the elementwise add launch per block and without the zero tensors of the plumbing blocks.
+    A block that received the accumulator through the ``_bgk_logdet`` kwarg and wrote into it returns the accumulator ITSELF in
+    place of its dlogp tensor; any other return value is a normal [B, 1] tensor and is added by ``add``.  Only used when no
+    gradient is needed (the autograd Functions of the training path return fresh tensors)."""
+    __slots__ = ("buf", "started")
+
+    def __init__(self, batch, device):
+        self.buf = torch.empty(batch, dtype=torch.float32, device=device)
+        self.started = False
+
+    def target(self):
+        """(buffer, accumulate flag) for a kernel launch: the first writer overwrites, the others add"""
+        acc = self.started
+        self.started = True
+        return self.buf, acc
+
+    def peek(self):
+        """like ``target`` without marking the buffer written; ``commit()`` after the launch succeeded"""
+        return self.buf, self.started
+
+    def commit(self):
+        self.started = True
+
+    def add(self, t):
+        if t is self or t is None:
+            return
+        t = t.reshape(-1) if torch.is_tensor(t) else t
+        if self.started:
+            self.buf.add_(t)
+        elif torch.is_tensor(t):
+            self.buf.copy_(t)
+            self.started = True
+        else:
+            self.buf.fill_(float(t))
+            self.started = True
+
+    def result(self):
+        if not self.started:
+            self.buf.zero_()
+            self.started = True
+        return self.buf[:, None]
+
+
+class CatView:
+    """Several [B, w_i] f32 HIP tensors that stand for their concatenation along the last axis (``torch.cat(..., -1)`` of
+    coupling.py:162-165) without being copied: the fused coupling kernels stage up to three conditioning tensors straight from
+    their own rows.  ``cat()`` materialises the concatenation for code that needs one tensor."""
+    __slots__ = ("parts", "_cat")
+
+    def __init__(self, parts):
+        self.parts = tuple(parts)
+        self._cat = None
+
+    @property
+    def shape(self):
+        return torch.Size([self.parts[0].shape[0], sum(t.shape[1] for t in self.parts)])
+
+    device = property(lambda self: self.parts[0].device)
+    dtype = property(lambda self: self.parts[0].dtype)
+    is_cuda = property(lambda self: self.parts[0].is_cuda)
+    requires_grad = False
+
+    def dim(self):
+        return 2
+
+    def cat(self):
+        if self._cat is None:
+            self._cat = torch.cat(self.parts, dim=-1)
+        return self._cat
+
+
+def as_tensor(x):
+    """a CatView's concatenation, any tensor unchanged"""
+    return x.cat() if isinstance(x, CatView) else x
+
+
+def _acc_kwargs(flow, kwargs):
+    """kwargs for ``flow``: the accumulator travels only into blocks that declare ``_bgk_acc`` (the classes of this package); a user
+    block with a strict signature never sees the private kwarg"""
+    if ACC_KW in kwargs and not getattr(flow, "_bgk_acc", False):
+        kwargs = {k: v for k, v in kwargs.items() if k != ACC_KW}
+    return kwargs
+
+
+def _acc_eligible(xs):
+    """a pass can run on one accumulator when its first input is a 2-d f32 HIP tensor and nothing needs a gradient"""
+    x = xs[0] if xs else None
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return False
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in xs):
+        return False
+    return True
+
+
 class SequentialFlow(Flow):
     """Chain of blocks; log-dets are summed, blocks run reversed for ``inverse=True``
     (sequential.py:26-59)."""
@@ -48,14 +148,44 @@ class SequentialFlow(Flow):
     FUSE_GENERATION_TAIL = True   # icdf domain maps + IC -> xyz as one kernel in the sampling direction (bgk_icdf_ic2xyz)
     FUSE_COUPLING_STACKS = True   # Split -> (affine Coupling | Swap)* -> Merge on ONE [B, D] buffer: no cat / per-layer outputs
 
+    _bgk_acc = True
+    ACCUMULATE_IN_KERNELS = True   # one running log-det buffer, written by the kernels themselves, when no gradient is needed
+
     def forward(self, *xs, inverse=False, **kwargs):
-        # same accumulation as the reference (sequential.py:49,58): start from the python float 0.0,
-        # `dlogp += ddlogp` (new tensor for the first block, in place afterwards)
-        total = 0.0
-        for _, seg in self.segments(inverse=inverse):
-            *xs, ddlogp = seg(*xs, inverse=inverse, **kwargs)
-            total += ddlogp
-        return (*xs, total)
+        return self.run(xs, inverse=inverse, kwargs=kwargs)
+
+    def run(self, xs, inverse=False, kwargs=None, around=None):
+        """The pass itself.  ``around(i, label)``, if given, returns a context manager entered around segment i (bench.py times the
+        segments with HIP events that way, on the same code path as ``forward``)."""
+        kwargs = dict(kwargs or {})
+        outer = kwargs.pop(ACC_KW, None)
+        acc = outer
+        if acc is None and self.ACCUMULATE_IN_KERNELS and _acc_eligible(xs) and not (
+                torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            acc = _LogDetAcc(xs[0].shape[0], xs[0].device)
+        if acc is None:
+            # same accumulation as the reference (sequential.py:49,58): start from the python float 0.0,
+            # `dlogp += ddlogp` (new tensor for the first block, in place afterwards)
+            total = 0.0
+            for i, (label, seg) in enumerate(self.segments(inverse=inverse)):
+                if around is None:
+                    *xs, ddlogp = seg(*xs, inverse=inverse, **kwargs)
+                else:
+                    with around(i, label):
+                        *xs, ddlogp = seg(*xs, inverse=inverse, **kwargs)
+                total += ddlogp
+            return (*xs, total)
+        kwargs[ACC_KW] = acc
+        for i, (label, seg) in enumerate(self.segments(inverse=inverse)):
+            kw = _acc_kwargs(seg, kwargs)
+            if around is None:
+                *xs, ddlogp = seg(*xs, inverse=inverse, **kw)
+                acc.add(ddlogp)
+            else:
+                with around(i, label):
+                    *xs, ddlogp = seg(*xs, inverse=inverse, **kw)
+                    acc.add(ddlogp)
+        return (*xs, acc if outer is not None else acc.result())
 
     def segments(self, inverse=False):
         """[(label, callable)] in execution order: the blocks themselves, except that in the sampling direction a tail of
@@ -184,21 +314,30 @@ class _FusedCouplingStack:
     dlogp additions, nor the closing concatenation exist.  Falls back to the blocks themselves when gradients are needed, the input
     is not a contiguous f32 HIP matrix, or a layer's conditioners are outside the fused envelope."""
 
+    _bgk_acc = True
+
     def __init__(self, blocks):
         self._blocks = blocks
 
     def _blocks_path(self, *xs, inverse=False, **kwargs):
+        acc = kwargs.get(ACC_KW)
         total = 0.0
         for block in self._blocks:
-            *xs, dd = block(*xs, inverse=inverse, **kwargs)
-            total = total + dd
-        return (*xs, total)
+            *xs, dd = block(*xs, inverse=inverse, **_acc_kwargs(block, kwargs))
+            if acc is not None:
+                acc.add(dd)
+            else:
+                total = total + dd
+        return (*xs, acc if acc is not None else total)
 
     def __call__(self, *xs, inverse=False, **kwargs):
         from .dense import fused_affine_coupling, _affine_plan, _gemm_mode
+        acc = kwargs.get(ACC_KW)
+        kwargs_rest = {k: v for k, v in kwargs.items() if k != ACC_KW}
         x = xs[0] if len(xs) == 1 else None
-        ok = (x is not None and not kwargs and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
-              and x.is_contiguous() and x.shape[0] > 0)
+        # a pure `temperature` kwarg does not reach the affine transformers' arithmetic (bg.py:16,21 inject it into every flow call)
+        ok = (x is not None and not set(kwargs_rest) - {"temperature"} and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
+              and x.dim() == 2 and x.is_contiguous() and x.shape[0] > 0)
         couplings = [b for b in self._blocks if type(b) is CouplingFlow]
         if ok and torch.is_grad_enabled():
             ok = not (x.requires_grad or any(p.requires_grad for b in couplings for p in b.parameters()))
@@ -225,10 +364,13 @@ class _FusedCouplingStack:
             return self._blocks_path(*xs, inverse=inverse, **kwargs)
         B = x.shape[0]
         work = torch.empty_like(x)
-        dlogp = torch.empty(B, dtype=torch.float32, device=x.device)
+        if acc is not None:
+            dlogp, started = acc.target()
+        else:
+            dlogp, started = torch.empty(B, dtype=torch.float32, device=x.device), False
         cols = (slice(0, s0), slice(s0, D))
         where = [x, x]                                      # buffer currently holding each column range
-        part, first = [0, 1], True
+        part, first = [0, 1], not started
         for b in self._blocks[1:-1]:
             if type(b) is SwapFlow:
                 part.reverse()
@@ -237,6 +379,8 @@ class _FusedCouplingStack:
             res = fused_affine_coupling(b.transformer, where[pc][:, cols[pc]], where[py][:, cols[py]], inverse,
                                         out=work[:, cols[py]], dlogp=dlogp, accumulate=not first)
             if res is None:                                 # cannot happen after the dry run; keep the semantics anyway
+                if acc is not None:
+                    raise RuntimeError("fused coupling stack: a layer left the fused envelope after the dry run")
                 return self._blocks_path(*xs, inverse=inverse, **kwargs)
             where[py], first = work, False
         for p in (0, 1):
@@ -244,22 +388,28 @@ class _FusedCouplingStack:
                 work[:, cols[p]].copy_(x[:, cols[p]])
         if part != [0, 1]:                                  # odd number of swaps: the merge concatenates (part 1, part 0)
             work = torch.cat([work[:, cols[1]], work[:, cols[0]]], dim=-1)
-        return work, dlogp[:, None]
+        return work, (acc if acc is not None else dlogp[:, None])
 
 
 class _FusedGenerationTail:
     """callable standing in for the tail blocks [icdf maps..., IC -> xyz] of a SequentialFlow (sampling direction).  Falls back
     to the blocks themselves when an input needs gradients, is not an f32 HIP tensor, or a marginal has no kernel descriptor."""
 
+    _bgk_acc = True
+
     def __init__(self, flow, tail):
         self._flow, (self._start, self._maps, self._ic, self._eps, self._others) = flow, tail
 
     def _blocks_path(self, *xs, **kwargs):
+        acc = kwargs.get(ACC_KW)
         total = 0.0
         for block in list(self._flow._blocks)[self._start:]:
-            *xs, dd = block(*xs, **kwargs)
-            total = total + dd
-        return (*xs, total)
+            *xs, dd = block(*xs, **_acc_kwargs(block, kwargs))
+            if acc is not None:
+                acc.add(dd)
+            else:
+                total = total + dd
+        return (*xs, acc if acc is not None else total)
 
     def __call__(self, *xs, inverse=False, **kwargs):
         assert not inverse
@@ -274,11 +424,17 @@ class _FusedGenerationTail:
                     ok = False
         if not ok:
             return self._blocks_path(*xs, **kwargs)
+        acc = kwargs.get(ACC_KW)
         total = 0.0
         for block in self._others:                      # maps on slots the coordinate transform does not touch
-            *xs, dd = block(*xs, **kwargs)
-            total = total + dd
-        x, dlogp = self._ic._generate_fused(xs[0], xs[1], xs[2], xs[3], descs, self._eps)
+            *xs, dd = block(*xs, **_acc_kwargs(block, kwargs))
+            if acc is not None:
+                acc.add(dd)
+            else:
+                total = total + dd
+        x, dlogp = self._ic._generate_fused(xs[0], xs[1], xs[2], xs[3], descs, self._eps, acc=acc)
+        if acc is not None:
+            return (x, *xs[4:], acc)
         return (x, *xs[4:], dlogp + total if self._others else dlogp)
 
 
@@ -289,11 +445,13 @@ class InverseFlow(Flow):
         super().__init__()
         self._delegate = delegate
 
+    _bgk_acc = True
+
     def _forward(self, *xs, **kwargs):
-        return self._delegate._inverse(*xs, **kwargs)
+        return self._delegate._inverse(*xs, **_acc_kwargs(self._delegate, kwargs))
 
     def _inverse(self, *xs, **kwargs):
-        return self._delegate._forward(*xs, **kwargs)
+        return self._delegate._forward(*xs, **_acc_kwargs(self._delegate, kwargs))
 
 
 class SplitFlow(Flow):
@@ -309,16 +467,20 @@ class SplitFlow(Flow):
         self._indices = sizes_or_indices if by_index else None
         self._split_dim = dim
 
+    _bgk_acc = True
+
     def _forward(self, x, **kwargs):
         parts = self._split_with_sizes(x) if self._indices is None else self._split_with_indices(x)
-        return (*parts, self._dlogp(x))
+        acc = kwargs.get(ACC_KW)
+        return (*parts, acc if acc is not None else self._dlogp(x))
 
     def _inverse(self, *xs, **kwargs):
         if self._indices is None:
             y = torch.cat(xs, dim=self._split_dim)
         else:
             y = self._cat_with_indices(*xs)
-        return y, self._dlogp(xs[0])
+        acc = kwargs.get(ACC_KW)
+        return y, (acc if acc is not None else self._dlogp(xs[0]))
 
     def _dlogp(self, x):
         return torch.zeros_like(x.narrow(self._split_dim, 0, 1))
@@ -371,16 +533,18 @@ class MergeFlow(InverseFlow):
 class SwapFlow(Flow):
     """Exchange the first two tensors (coupling.py:113-130)."""
 
-    def _swap(self, *xs):
+    _bgk_acc = True
+
+    def _swap(self, *xs, acc=None):
         if len(xs) == 1:
             warnings.warn("applying swapping on a single tensor has no effect")
-        return (xs[1], xs[0], *xs[2:], _zero_dlogp(xs[0]))
+        return (xs[1], xs[0], *xs[2:], acc if acc is not None else _zero_dlogp(xs[0]))
 
     def _forward(self, *xs, **kwargs):
-        return self._swap(*xs)
+        return self._swap(*xs, acc=kwargs.get(ACC_KW))
 
     def _inverse(self, *xs, **kwargs):
-        return self._swap(*xs)
+        return self._swap(*xs, acc=kwargs.get(ACC_KW))
 
 
 class CouplingFlow(Flow):
@@ -397,17 +561,26 @@ class CouplingFlow(Flow):
             raise ValueError(f"Indices {clash} cannot be both transformed and conditioned on.")
         self.cat_dim = cat_dim
 
-    def _gather(self, x, indices):
+    _bgk_acc = True
+    MULTI_COND_IN_KERNEL = True    # several conditioning tensors go to the fused kernels as they are (False: torch.cat first)
+
+    def _gather(self, x, indices, lazy=False):
         # a single tensor needs no concatenation copy (the kernels take strided rows)
         if len(indices) == 1:
             return x[indices[0]]
-        return torch.cat([x[i] for i in indices], dim=self.cat_dim)
+        parts = [x[i] for i in indices]
+        if lazy and self.MULTI_COND_IN_KERNEL and self.cat_dim in (-1, parts[0].dim() - 1) and all(
+                torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 for t in parts) and not (
+                torch.is_grad_enabled() and any(t.requires_grad for t in parts)):
+            return CatView(parts)         # the fused kernels read up to 3 conditioning tensors in place (no torch.cat launch)
+        return torch.cat(parts, dim=self.cat_dim)
 
     def _couple(self, x, inverse, kwargs):
         lengths = [x[i].shape[self.cat_dim] for i in self.transformed_indices]
         inputs = self._gather(x, self.transformed_indices)
-        cond = self._gather(x, self.cond_indices)
+        cond = self._gather(x, self.cond_indices, lazy=getattr(self.transformer, "_bgk_multi_cond", False))
         x = list(x)
+        kwargs = _acc_kwargs(self.transformer, kwargs)
         if inverse:
             y, dlogp = self.transformer.forward(cond, inputs, **kwargs, inverse=True)
         else:
@@ -436,10 +609,12 @@ class WrapFlow(Flow):
         self._out_indices = indices if out_indices is None else out_indices
         self._argsort_out_indices = np.argsort(self._out_indices)
 
+    _bgk_acc = True
+
     @staticmethod
     def _route(flow, xs, take, put, put_order, kwargs):
         rest = [x for i, x in enumerate(xs) if i not in take]
-        *ys, dlogp = flow(*(xs[i] for i in take), **kwargs)
+        *ys, dlogp = flow(*(xs[i] for i in take), **_acc_kwargs(flow, kwargs))
         for k in put_order:
             rest.insert(put[k], ys[k])
         return (*rest, dlogp)
@@ -455,6 +630,8 @@ class WrapFlow(Flow):
 class SetConstantFlow(Flow):
     """Forward inserts constant tensors (repeated over the batch) at ``indices``; inverse drops
     them (coupling.py:227-272)."""
+
+    _bgk_acc = True
 
     def __init__(self, indices, values, n_event_dims0=1):
         super().__init__()
@@ -477,11 +654,15 @@ class SetConstantFlow(Flow):
         ys = list(xs)
         for i, v in zip(self.indices, self.values):
             ys.insert(i, v.repeat([*batch, *([1] * v.dim())]))
-        dlogp = torch.zeros(batch + [1], device=xs[0].device, dtype=xs[0].dtype)
+        acc = kwargs.get(ACC_KW)
+        dlogp = acc if acc is not None else torch.zeros(batch + [1], device=xs[0].device, dtype=xs[0].dtype)
         return (*ys, dlogp)
 
     def _inverse(self, *xs, **kwargs):
         ys = tuple(x for i, x in enumerate(xs) if i not in self.indices)
+        acc = kwargs.get(ACC_KW)
+        if acc is not None:
+            return (*ys, acc)
         batch = list(ys[0].shape[:self.n_event_dims0])
         dlogp = torch.zeros(batch + [1], device=ys[0].device, dtype=ys[0].dtype)
         return (*ys, dlogp)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .flow import Flow
+from .flow import ACC_KW, Flow
 
 __all__ = [
     "decompose_z_matrix", "RelativeInternalCoordinateTransformation", "MixedCoordinateTransformation",
@@ -100,6 +100,33 @@ class _DeviceTables:
         if key not in self._dev:
             self._dev[key] = torch.as_tensor(self._host[name]).to(device)
         return self._dev[key]
+
+
+
+def _dl_target(acc, B, dev):
+    """([B] log-det buffer, accumulate flag): the pass's running buffer (flow._LogDetAcc) or a fresh tensor"""
+    if acc is None:
+        return torch.empty((B,), dtype=torch.float32, device=dev), 0
+    buf, started = acc.peek()
+    assert buf.shape[0] == B and buf.device == dev, "running log-det buffer does not match the batch"
+    return buf, int(started)
+
+
+def _dl_merge(acc, a, b):
+    """sum of two launches' log-dets, either of which may already sit in the running buffer"""
+    if acc is None or (a is not acc and b is not acc):
+        return a + b
+    for t in (a, b):
+        if t is not acc:
+            acc.add(t)
+    return acc
+
+
+def _dl_result(acc, dlogp):
+    if acc is None:
+        return dlogp[:, None]
+    acc.commit()
+    return acc
 
 
 def _contig_rows(*ts):
@@ -271,13 +298,15 @@ class RelativeInternalCoordinateTransformation(Flow):
             warnings.warn(f"singular geometry: {total} norm / division clamps at eps={self._eps}")
         return total
 
-    def _xyz2ic(self, x, whiten=None):
+    _bgk_acc = True
+
+    def _xyz2ic(self, x, whiten=None, acc=None):
         _lib.require_hip(x)
         if torch.is_grad_enabled() and x.requires_grad:
             return _XYZ2ICFn.apply(self, x, whiten)
-        return self._xyz2ic_launch(x, whiten)
+        return self._xyz2ic_launch(x, whiten, acc=acc)
 
-    def _xyz2ic_launch(self, x, whiten=None):
+    def _xyz2ic_launch(self, x, whiten=None, acc=None):
         dev = x.device
         x2, ldx = _lib.rowmajor(x.reshape(x.shape[0], -1))
         B, n, nf = x2.shape[0], self._n, self._n_fixed
@@ -290,24 +319,24 @@ class RelativeInternalCoordinateTransformation(Flow):
             mean, T, jac = whiten
             keep = T.shape[1]
         xfix = torch.empty((B, keep), dtype=torch.float32, device=dev)
-        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        dlogp, accumulate = _dl_target(acc, B, dev)
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_ic_xyz2ic(
                 _lib.ptr(x2), ldx, _lib.ptr(self._tables.get("zmat", dev)), n,
                 _lib.ptr(self._tables.get("fixed", dev)), nf, int(self._normalize_angles), float(self._eps),
                 int(self._enforce_boundaries), _lib.ptr(mean), _lib.ptr(T), keep, float(jac), B,
                 _lib.ptr(ics[0]), _lib.ptr(ics[1]), _lib.ptr(ics[2]), n, _lib.ptr(xfix), keep,
-                _lib.ptr(dlogp), 0, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+                _lib.ptr(dlogp), accumulate, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
         _lib.check(st, "bgk_ic_xyz2ic")
-        return ics[0], ics[1], ics[2], xfix, dlogp[:, None]
+        return ics[0], ics[1], ics[2], xfix, _dl_result(acc, dlogp)
 
-    def _ic2xyz(self, bonds, angles, torsions, xfix, blacken=None):
+    def _ic2xyz(self, bonds, angles, torsions, xfix, blacken=None, acc=None):
         _lib.require_hip(bonds, angles, torsions, xfix)
         if torch.is_grad_enabled() and any(t.requires_grad for t in (bonds, angles, torsions, xfix)):
             return _IC2XYZFn.apply(self, bonds, angles, torsions, xfix.reshape(xfix.shape[0], -1), blacken)
-        return self._ic2xyz_launch(bonds, angles, torsions, xfix, blacken)
+        return self._ic2xyz_launch(bonds, angles, torsions, xfix, blacken, acc=acc)
 
-    def _ic2xyz_launch(self, bonds, angles, torsions, xfix, blacken=None):
+    def _ic2xyz_launch(self, bonds, angles, torsions, xfix, blacken=None, acc=None):
         dev = bonds.device
         B, n, nf = bonds.shape[0], self._n, self._n_fixed
         assert bonds.shape[-1] == n
@@ -323,18 +352,18 @@ class RelativeInternalCoordinateTransformation(Flow):
             keep = T.shape[0]
         assert f2.shape[1] == keep
         x = torch.empty((B, 3 * (n + nf)), dtype=torch.float32, device=dev)
-        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        dlogp, accumulate = _dl_target(acc, B, dev)
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_ic_ic2xyz(
                 _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), ldic, _lib.ptr(f2), ldf,
                 _lib.ptr(self._tables.get("place", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
                 int(self._normalize_angles), float(self._eps), int(self._enforce_boundaries),
                 _lib.ptr(mean), _lib.ptr(T), keep, float(jac), B, _lib.ptr(x), x.shape[1],
-                _lib.ptr(dlogp), 0, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+                _lib.ptr(dlogp), accumulate, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
         _lib.check(st, "bgk_ic_ic2xyz")
-        return x, dlogp[:, None]
+        return x, _dl_result(acc, dlogp)
 
-    def _icdf_ic2xyz(self, bonds, angles, torsions, xfix, descs, eps, blacken=None):
+    def _icdf_ic2xyz(self, bonds, angles, torsions, xfix, descs, eps, blacken=None, acc=None):
         """IC -> xyz with the icdf domain maps of the four inputs fused in (bgk_icdf_ic2xyz); ``descs`` = per-field [d, 6]
         descriptor tensors (cdf.CDFTransform.kernel_descriptor) or None for a field that is used as is.  No autograd."""
         _lib.require_hip(bonds, angles, torsions, xfix)
@@ -350,7 +379,7 @@ class RelativeInternalCoordinateTransformation(Flow):
             keep = T.shape[0]
         assert f2.shape[1] == keep
         x = torch.empty((B, 3 * (n + nf)), dtype=torch.float32, device=dev)
-        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        dlogp, accumulate = _dl_target(acc, B, dev)
         db, da, dt, df = descs
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_icdf_ic2xyz(
@@ -359,18 +388,18 @@ class RelativeInternalCoordinateTransformation(Flow):
                 _lib.ptr(self._tables.get("place", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
                 int(self._normalize_angles), float(self._eps), int(self._enforce_boundaries),
                 _lib.ptr(mean), _lib.ptr(T), keep, float(jac), B, _lib.ptr(x), x.shape[1],
-                _lib.ptr(dlogp), 0, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+                _lib.ptr(dlogp), accumulate, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
         _lib.check(st, "bgk_icdf_ic2xyz")
-        return x, dlogp[:, None]
+        return x, _dl_result(acc, dlogp)
 
-    def _generate_fused(self, bonds, angles, torsions, x_fixed, descs, eps):
-        return self._icdf_ic2xyz(bonds, angles, torsions, x_fixed, descs, eps)
+    def _generate_fused(self, bonds, angles, torsions, x_fixed, descs, eps, acc=None):
+        return self._icdf_ic2xyz(bonds, angles, torsions, x_fixed, descs, eps, acc=acc)
 
     def _forward(self, x, with_pose=True, *args, **kwargs):
-        return self._xyz2ic(x)
+        return self._xyz2ic(x, acc=kwargs.get(ACC_KW))
 
     def _inverse(self, bonds, angles, torsions, x_fixed, **kwargs):
-        return self._ic2xyz(bonds, angles, torsions, x_fixed)
+        return self._ic2xyz(bonds, angles, torsions, x_fixed, acc=kwargs.get(ACC_KW))
 
 
 def _pca(X0, keepdims=None):
@@ -454,14 +483,16 @@ class MixedCoordinateTransformation(Flow):
         mean = w.X0mean.to(device=device, dtype=torch.float32).contiguous()
         return mean, T, float(w.jacobian_xz)
 
+    _bgk_acc = True
+
     def _forward(self, x, *args, **kwargs):
-        return self._rel_ic._xyz2ic(x, whiten=self._wh("whiten", x.device))
+        return self._rel_ic._xyz2ic(x, whiten=self._wh("whiten", x.device), acc=kwargs.get(ACC_KW))
 
     def _inverse(self, bonds, angles, torsions, z_fixed, *args, **kwargs):
-        return self._rel_ic._ic2xyz(bonds, angles, torsions, z_fixed, blacken=self._wh("blacken", bonds.device))
+        return self._rel_ic._ic2xyz(bonds, angles, torsions, z_fixed, blacken=self._wh("blacken", bonds.device), acc=kwargs.get(ACC_KW))
 
-    def _generate_fused(self, bonds, angles, torsions, z_fixed, descs, eps):
-        return self._rel_ic._icdf_ic2xyz(bonds, angles, torsions, z_fixed, descs, eps, blacken=self._wh("blacken", bonds.device))
+    def _generate_fused(self, bonds, angles, torsions, z_fixed, descs, eps, acc=None):
+        return self._rel_ic._icdf_ic2xyz(bonds, angles, torsions, z_fixed, descs, eps, blacken=self._wh("blacken", bonds.device), acc=acc)
 
 
 def slice_initial_atoms(z_matrix):
@@ -484,32 +515,34 @@ class ReferenceSystemTransformation(Flow):
         self._enforce_boundaries = enforce_boundaries
         self._raise_warnings = raise_warnings
 
-    def _launch(self, packed, inverse):
+    _bgk_acc = True
+
+    def _launch(self, packed, inverse, acc=None):
         _lib.require_hip(packed)
         packed = packed.contiguous()
         if torch.is_grad_enabled() and packed.requires_grad:
             return _RefSysFn.apply(self, packed, inverse)
-        return self._launch_nograd(packed, inverse)
+        return self._launch_nograd(packed, inverse, acc=acc)
 
-    def _launch_nograd(self, packed, inverse):
+    def _launch_nograd(self, packed, inverse, acc=None):
         B = packed.shape[0]
         out = torch.empty_like(packed)
-        dlogp = torch.empty((B,), dtype=torch.float32, device=packed.device)
+        dlogp, accumulate = _dl_target(acc, B, packed.device)
         with torch.cuda.device(packed.device):
             st = _lib.lib().bgk_ic_refsys(_lib.ptr(packed), B, int(inverse), int(self._normalize_angles), float(self._eps),
-                                          int(self._enforce_boundaries), _lib.ptr(out), _lib.ptr(dlogp), 0,
+                                          int(self._enforce_boundaries), _lib.ptr(out), _lib.ptr(dlogp), accumulate,
                                           _lib.stream_ptr(packed.device))
         _lib.check(st, "bgk_ic_refsys")
-        return out, dlogp[:, None]
+        return out, _dl_result(acc, dlogp)
 
     def _forward(self, x0, x1, x2, *args, **kwargs):
         B = x0.shape[0]
-        out, dlogp = self._launch(torch.cat([x0.reshape(B, 3), x1.reshape(B, 3), x2.reshape(B, 3)], dim=-1), False)
+        out, dlogp = self._launch(torch.cat([x0.reshape(B, 3), x1.reshape(B, 3), x2.reshape(B, 3)], dim=-1), False, acc=kwargs.get(ACC_KW))
         return out[:, None, 0:3], out[:, 6:9], out[:, 3:4], out[:, 4:5], out[:, 5:6], dlogp
 
     def _inverse(self, x0, orientation, d01, d12, a012, *args, **kwargs):
         B = x0.shape[0]
-        out, dlogp = self._launch(torch.cat([x0.reshape(B, 3), d01, d12, a012, orientation], dim=-1), True)
+        out, dlogp = self._launch(torch.cat([x0.reshape(B, 3), d01, d12, a012, orientation], dim=-1), True, acc=kwargs.get(ACC_KW))
         return out[:, None, 0:3], out[:, None, 3:6], out[:, None, 6:9], dlogp
 
 
@@ -546,17 +579,21 @@ class GlobalInternalCoordinateTransformation(Flow):
         fix = self._rel_ic.fixed_atoms
         return np.vstack([np.array([[fix[2], fix[1], fix[0]]]), self._rel_ic.angle_indices])
 
+    _bgk_acc = True
+
     def _forward(self, x, *args, **kwargs):
         B = x.shape[0]
-        bonds, angles, torsions, x_fixed, dlogp_rel = self._rel_ic._xyz2ic(x.reshape(B, -1))
-        ref, dlogp_ref = self._ref_ic._launch(x_fixed.reshape(B, 9), False)
+        acc = kwargs.get(ACC_KW)
+        bonds, angles, torsions, x_fixed, dlogp_rel = self._rel_ic._xyz2ic(x.reshape(B, -1), acc=acc)
+        ref, dlogp_ref = self._ref_ic._launch(x_fixed.reshape(B, 9), False, acc=acc)
         bonds = torch.cat([ref[:, 3:5], bonds], dim=-1)
         angles = torch.cat([ref[:, 5:6], angles], dim=-1)
-        return bonds, angles, torsions, ref[:, None, 0:3], ref[:, 6:9], dlogp_rel + dlogp_ref
+        return bonds, angles, torsions, ref[:, None, 0:3], ref[:, 6:9], _dl_merge(acc, dlogp_rel, dlogp_ref)
 
     def _inverse(self, bonds, angles, torsions, x0, R, *args, **kwargs):
         B = bonds.shape[0]
+        acc = kwargs.get(ACC_KW)
         packed = torch.cat([x0.reshape(B, 3), bonds[:, 0:2], angles[:, 0:1], R], dim=-1)
-        x_init, dlogp_ref = self._ref_ic._launch(packed, True)
-        x, dlogp_rel = self._rel_ic._ic2xyz(bonds[:, 2:], angles[:, 1:], torsions, x_init)
-        return x, dlogp_rel + dlogp_ref
+        x_init, dlogp_ref = self._ref_ic._launch(packed, True, acc=acc)
+        x, dlogp_rel = self._rel_ic._ic2xyz(bonds[:, 2:], angles[:, 1:], torsions, x_init, acc=acc)
+        return x, _dl_merge(acc, dlogp_rel, dlogp_ref)

@@ -19,41 +19,75 @@ import numpy as np
 import torch
 
 from . import _lib, dp
+from .distributions import Sampler
 
 __all__ = ["LossReporter", "KLTrainer", "FlatAdam", "DataSetSampler"]
 
 
-class DataSetSampler(torch.nn.Module):
-    """Sample batches from a data set without replacement, reshuffling when exhausted (distribution/sampling/dataset.py)."""
+class DataSetSampler(Sampler, torch.utils.data.Dataset):
+    """Sample batches from a data set without replacement, reshuffling when exhausted (distribution/sampling/dataset.py:58-157):
+    same constructor (``*data, shuffle, device, dtype``), ``data`` attribute, ``__len__`` / ``__getitem__``, ``reshuffle_`` and
+    ``resize_`` as the reference.  The permutation lives on the data's device (the reference indexes with a host numpy
+    permutation: one H2D copy of the index batch per call)."""
 
-    def __init__(self, *data, shuffle=True):
+    def __init__(self, *data, shuffle=True, device=None, dtype=None):
         super().__init__()
-        assert all(d.shape[0] == data[0].shape[0] for d in data)
-        self._data = list(data)
+        if not all(len(d) == len(data[0]) for d in data):
+            raise ValueError("All data items must have the same length.")
+        self.data = list(data)
+        self._device = data[0].device if device is None else torch.device(device)
+        self._dtype = data[0].dtype if dtype is None else dtype
         self._shuffle = shuffle
         self._perm = None
         self._pos = 0
 
     def __len__(self):
-        return self._data[0].shape[0]
+        return self.data[0].shape[0]
+
+    def __getitem__(self, idx):
+        return tuple(d[idx] for d in self.data)
+
+    def _new_order(self):
+        N, dev = len(self), self.data[0].device
+        self._perm = torch.randperm(N, device=dev) if self._shuffle else torch.arange(N, device=dev)
+        self._pos = 0
 
     def _next_indices(self, n):
         N = len(self)
         out = []
         while n > 0:
             if self._perm is None or self._pos >= N:
-                self._perm = torch.randperm(N, device=self._data[0].device) if self._shuffle else torch.arange(N, device=self._data[0].device)
-                self._pos = 0
+                self._new_order()
             take = min(n, N - self._pos)
             out.append(self._perm[self._pos:self._pos + take])
             self._pos += take
             n -= take
         return torch.cat(out) if len(out) > 1 else out[0]
 
-    def sample(self, n_samples, **kwargs):
+    def _sample(self, n_samples, *args, **kwargs):
         idx = self._next_indices(n_samples)
-        res = tuple(d[idx] for d in self._data)
+        res = tuple(d[idx].to(device=self._device, dtype=self._dtype) for d in self.data)
         return res[0] if len(res) == 1 else res
+
+    def _sample_with_temperature(self, n_samples, temperature, *args, **kwargs):
+        return self._sample(n_samples)
+
+    def reshuffle_(self):
+        """new random access order, in place (dataset.py:119-123)"""
+        self._new_order()
+        return self
+
+    def resize_(self, new_size):
+        """Resize the data set to ``new_size`` by drawing rows with replacement and reinitialise the access order; returns the
+        row indices used (dataset.py:125-149)"""
+        if new_size == len(self):
+            return np.arange(len(self))
+        indices = np.random.randint(low=0, high=len(self), size=new_size)
+        idx_t = torch.as_tensor(indices, device=self.data[0].device)
+        self.data = [d[idx_t] for d in self.data]
+        self._perm = None
+        self._pos = 0
+        return indices
 
 
 class LossReporter:
@@ -117,6 +151,11 @@ class FlatAdam(torch.optim.Optimizer):
                 p._bgk_grad_dst = self.grad[off:off + k].view_as(p)
                 off += k
 
+    def add_param_group(self, param_group):
+        if getattr(self, "flat", None) is not None:
+            raise ValueError("FlatAdam: the flat bucket is laid out at construction; parameter groups cannot be added afterwards")
+        super().add_param_group(param_group)
+
     def zero_grad(self, set_to_none=False):
         """one memset; the per-parameter .grad views stay attached (autograd accumulates into them in place)"""
         self.grad.zero_()
@@ -126,6 +165,13 @@ class FlatAdam(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + k].view_as(p)
             off += k
+
+    def backward(self, loss, **kwargs):
+        """``loss.backward()`` with the fused layers' weight gradients accumulated straight into the bucket (the only place, besides
+        KLTrainer.train, where that shortcut is switched on: dense.direct_grad_accumulation)"""
+        from .dense import direct_grad_accumulation
+        with direct_grad_accumulation():
+            loss.backward(**kwargs)
 
     def allreduce_gradients(self):
         """data-parallel training: ONE all-reduce of the gradient bucket (sum over ranks)"""
@@ -143,6 +189,8 @@ class FlatAdam(torch.optim.Optimizer):
                 self.grad[off:off + k].copy_(p.grad.reshape(-1))
                 p.grad = self.grad[off:off + k].view_as(p)
             off += k
+        # `_step` counts the calls; the kernel's Adam time step is `_step - skipped` with the skip count read ON THE DEVICE, so a
+        # step skipped for a NaN gradient does not advance the bias corrections (the reference does not call optim.step() then)
         self._step += 1
         lib = _lib.lib()
         dev = self.flat.device
@@ -161,6 +209,27 @@ class FlatAdam(torch.optim.Optimizer):
     def skipped_steps(self):
         """number of optimizer steps skipped because a gradient was NaN (host sync)"""
         return int(self._skipped.item())
+
+    def state_dict(self):
+        """torch's layout (``state`` / ``param_groups``) plus the flat moments and the step counters (they live outside
+        ``Optimizer.state``: one tensor per moment, not one per parameter)"""
+        sd = super().state_dict()
+        sd["flat_adam"] = dict(exp_avg=self.exp_avg.detach().clone(), exp_avg_sq=self.exp_avg_sq.detach().clone(),
+                               step=int(self._step), skipped=int(self._skipped.item()))
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        extra = state_dict.pop("flat_adam", None)
+        super().load_state_dict(state_dict)
+        if extra is None:
+            raise ValueError("FlatAdam.load_state_dict: the checkpoint carries no 'flat_adam' entry (moments / step count)")
+        if extra["exp_avg"].numel() != self.exp_avg.numel():
+            raise ValueError("FlatAdam.load_state_dict: bucket size mismatch")
+        self.exp_avg.copy_(extra["exp_avg"].to(self.exp_avg.device))
+        self.exp_avg_sq.copy_(extra["exp_avg_sq"].to(self.exp_avg_sq.device))
+        self._step = int(extra["step"])
+        self._skipped.fill_(int(extra["skipped"]))
 
 
 class KLTrainer(object):
@@ -212,6 +281,9 @@ class KLTrainer(object):
             testdata = DataSetSampler(testdata)
         flat = isinstance(self.optim, FlatAdam)
         params = [p for p in self.bg.parameters()]
+        from .dense import direct_grad_accumulation
+        import contextlib
+        direct = direct_grad_accumulation if flat else contextlib.nullcontext
         for it in progress_bar(range(n_iter)):
             for interval, scheduler in schedulers:
                 if it % interval == 0:
@@ -222,7 +294,8 @@ class KLTrainer(object):
                 kll = self._mean(self.bg.kldiv(batchsize, temperature=temperature))
                 reports.append(kll)
                 if w_energy > 0:
-                    (w_energy / (w_likelihood + w_energy) * kll).backward(retain_graph=True)
+                    with direct():
+                        (w_energy / (w_likelihood + w_energy) * kll).backward(retain_graph=True)
             if self.train_likelihood:
                 batch = data.sample(batchsize)
                 if isinstance(batch, torch.Tensor):
@@ -230,7 +303,8 @@ class KLTrainer(object):
                 nll = self._mean(self.bg.energy(*batch, temperature=temperature))
                 reports.append(nll)
                 if w_likelihood > 0:
-                    (w_likelihood / (w_likelihood + w_energy) * nll).backward(retain_graph=True)
+                    with direct():
+                        (w_likelihood / (w_likelihood + w_energy) * nll).backward(retain_graph=True)
             if self.test_likelihood:
                 testnll = torch.zeros_like(nll)
                 if testdata is not None:

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .flow import Flow
+from .flow import ACC_KW, CatView, Flow, as_tensor
 
 def _invalidate_fused_cache(self):
     """Forget the packed-operand cache of the fused kernels.  The cache is keyed on the parameters' (data_ptr, _version): optimizer
@@ -24,6 +24,7 @@ def _invalidate_fused_cache(self):
 
 __all__ = ["Transformer", "AffineTransformer", "ConditionalSplineTransformer"]
 
+_WARNED_TORCH_SPLINE = False
 DEFAULT_MIN_BIN_WIDTH = 1e-3
 DEFAULT_MIN_BIN_HEIGHT = 1e-3
 DEFAULT_MIN_DERIVATIVE = 1e-3
@@ -49,8 +50,18 @@ def _flat2d(t):
 # ------------------------------------------------------------------------------------------------
 # affine
 # ------------------------------------------------------------------------------------------------
-def affine_transform(y, mu, s_raw, log_alpha, preserve_volume, is_circular, inverse):
-    """Launch bgk_affine_transform.  y, mu, s_raw: [..., d] (mu / s_raw may be None)."""
+def _dlogp_target(acc, B, device):
+    """([B] buffer, accumulate flag) of a launch: the pass's running log-det buffer (flow._LogDetAcc) or a fresh tensor"""
+    if acc is None:
+        return torch.empty((B,), dtype=torch.float32, device=device), 0
+    buf, started = acc.peek()
+    assert buf.shape[0] == B and buf.device == device, "running log-det buffer does not match the batch"
+    return buf, int(started)
+
+
+def affine_transform(y, mu, s_raw, log_alpha, preserve_volume, is_circular, inverse, acc=None):
+    """Launch bgk_affine_transform.  y, mu, s_raw: [..., d] (mu / s_raw may be None).  ``acc``: the pass's running log-det
+    (the kernel adds to it; returned in place of the dlogp tensor)."""
     _lib.require_hip(y, mu, s_raw, log_alpha)
     y2, lead = _flat2d(y)
     y2, ldy = _lib.rowmajor(y2)
@@ -62,13 +73,16 @@ def affine_transform(y, mu, s_raw, log_alpha, preserve_volume, is_circular, inve
     if s_raw is not None:
         s2, lds = _lib.rowmajor(s_raw.reshape(-1, d))
     out = torch.empty((B, d), dtype=torch.float32, device=y.device)
-    dlogp = torch.empty((B,), dtype=torch.float32, device=y.device)
+    dlogp, accumulate = _dlogp_target(acc, B, y.device)
     with torch.cuda.device(y.device):
         st = _lib.lib().bgk_affine_transform(
             _lib.ptr(y2), ldy, _lib.ptr(mu2), ldmu, _lib.ptr(s2), lds, _lib.ptr(log_alpha),
             int(preserve_volume), int(is_circular), int(inverse), B, d, _lib.ptr(out), d,
-            _lib.ptr(dlogp), 0, _lib.stream_ptr(y.device))
+            _lib.ptr(dlogp), accumulate, _lib.stream_ptr(y.device))
     _lib.check(st, "bgk_affine_transform")
+    if acc is not None:
+        acc.commit()
+        return out.reshape(*lead, d), acc
     return out.reshape(*lead, d), dlogp.reshape(*lead, 1)
 
 
@@ -133,14 +147,20 @@ class AffineTransformer(Transformer):
         self._fused_cache = {}
         self.allow_fused = True           # set False to force conditioner networks + bgk_affine_transform
 
-    def _run(self, x, y, cond, inverse):
+    _bgk_acc = True
+    _bgk_multi_cond = True
+
+    def _run(self, x, y, cond, inverse, acc=None):
         grad = torch.is_grad_enabled() and (
             y.requires_grad or x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if grad:
+            acc = None                        # the autograd Functions return fresh tensors
         if not grad and self.allow_fused and not cond:
             from .dense import fused_affine_coupling   # late import (dense imports nothing from here)
-            fused = fused_affine_coupling(self, x, y, inverse)
+            fused = fused_affine_coupling(self, x, y, inverse, acc=acc)
             if fused is not None:
                 return fused
+        x = as_tensor(x)
         mu = self._shift_transformation(x, *cond) if self._shift_transformation is not None else None
         s_raw = self._scale_transformation(x, *cond) if self._scale_transformation is not None else None
         if mu is not None:
@@ -152,21 +172,23 @@ class AffineTransformer(Transformer):
             t is not None and t.requires_grad for t in (y, mu, s_raw, log_alpha))
         if needs_grad:
             return _AffineFn.apply(y, mu, s_raw, log_alpha, self._preserve_volume, self._is_circular, inverse)
-        return affine_transform(y, mu, s_raw, log_alpha, self._preserve_volume, self._is_circular, inverse)
+        return affine_transform(y, mu, s_raw, log_alpha, self._preserve_volume, self._is_circular, inverse,
+                                acc=acc if y.dim() == 2 else None)
 
     def _forward(self, x, y, *cond, **kwargs):
-        return self._run(x, y, cond, False)
+        return self._run(x, y, cond, False, acc=kwargs.get(ACC_KW))
 
     def _inverse(self, x, y, *cond, **kwargs):
-        return self._run(x, y, cond, True)
+        return self._run(x, y, cond, True, acc=kwargs.get(ACC_KW))
 
 
 # ------------------------------------------------------------------------------------------------
 # rational-quadratic spline
 # ------------------------------------------------------------------------------------------------
 def rqs_transform(y, params, nc_slot, n_bins, inverse, left, right, bottom, top, settings,
-                  want_bin_idx=False, oob_counter=None):
-    """Launch bgk_rqs_transform.  y [..., d], params [..., P]; returns (out, dlogp[...,1][, bin_idx])."""
+                  want_bin_idx=False, oob_counter=None, acc=None):
+    """Launch bgk_rqs_transform.  y [..., d], params [..., P]; returns (out, dlogp[...,1][, bin_idx]).  ``acc``: the pass's
+    running log-det buffer (returned in place of dlogp)."""
     _lib.require_hip(y, params, nc_slot)
     y2, lead = _flat2d(y)
     y2, ldy = _lib.rowmajor(y2)
@@ -177,21 +199,32 @@ def rqs_transform(y, params, nc_slot, n_bins, inverse, left, right, bottom, top,
         # the same map on device torch ops (differentiable by autograd; no bin-index output)
         if want_bin_idx:
             raise ValueError("return_bin_indices is not available for n_bins > 64 / parameter rows beyond the kernel's LDS tile")
+        global _WARNED_TORCH_SPLINE
+        if not _WARNED_TORCH_SPLINE:
+            _WARNED_TORCH_SPLINE = True
+            warnings.warn(f"rational-quadratic spline with {n_bins} bins / {P} parameters per sample is beyond the HIP kernels' envelope "
+                          f"(<= 64 bins, parameter row within the LDS tile): running on device torch ops", RuntimeWarning, stacklevel=3)
         out, dl = _rqs_spline_torch(y2, params.reshape(-1, P), nc_slot, (n_bins, inverse, left, right, bottom, top, settings))
         return out.reshape(*lead, d), dl.reshape(*lead, 1)
     p2, ldp = _lib.rowmajor(params.reshape(-1, P))
     out = torch.empty((B, d), dtype=torch.float32, device=y.device)
-    dlogp = torch.empty((B,), dtype=torch.float32, device=y.device)
+    if y.dim() != 2:
+        acc = None
+    dlogp, accumulate = _dlogp_target(acc, B, y.device)
     bins = torch.empty((B, d), dtype=torch.int32, device=y.device) if want_bin_idx else None
     with torch.cuda.device(y.device):
         st = _lib.lib().bgk_rqs_transform(
             _lib.ptr(y2), ldy, _lib.ptr(p2), ldp, P, _lib.ptr(nc_slot), B, d, n_bins, int(inverse),
             left, right, bottom, top, settings["min_bin_width"], settings["min_bin_height"],
             settings["min_derivative"], int(settings.get("enable_identity_init", False)),
-            _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.ptr(bins), _lib.ptr(oob_counter),
+            _lib.ptr(out), d, _lib.ptr(dlogp), accumulate, _lib.ptr(bins), _lib.ptr(oob_counter),
             _lib.stream_ptr(y.device))
     _lib.check(st, "bgk_rqs_transform")
-    res = (out.reshape(*lead, d), dlogp.reshape(*lead, 1))
+    if acc is not None:
+        acc.commit()
+        res = (out.reshape(*lead, d), acc)
+    else:
+        res = (out.reshape(*lead, d), dlogp.reshape(*lead, 1))
     return res + (bins.reshape(*lead, d),) if want_bin_idx else res
 
 
@@ -374,19 +407,25 @@ class ConditionalSplineTransformer(Transformer):
         return total
 
     # -- forward / inverse ------------------------------------------------------------------
-    def _run(self, x, y, inverse):
+    _bgk_acc = True
+    _bgk_multi_cond = True
+
+    def _run(self, x, y, inverse, acc=None):
         from .dense import fused_spline_coupling, fused_spline_coupling_train   # late import
         y_dim = y.shape[-1]
         nc_dev, nc_host = self._nc_slot(y_dim, y.device)
         oob = self._oob_counter(y.device)
         grad = torch.is_grad_enabled() and (
             y.requires_grad or x.requires_grad or any(p.requires_grad for p in self._params_net.parameters()))
+        if grad:
+            acc = None                        # the autograd Functions return fresh tensors
         if not grad and self.allow_fused:
-            fused = fused_spline_coupling(self, x, y, nc_host, inverse, oob, want_bin_idx=self.return_bin_indices)
+            fused = fused_spline_coupling(self, x, y, nc_host, inverse, oob, want_bin_idx=self.return_bin_indices, acc=acc)
             if fused is not None:
                 if self.return_bin_indices:
                     self.last_bin_indices = fused[2]
                 return fused[0], fused[1]
+        x = as_tensor(x)
         if grad and self.allow_fused and not self.return_bin_indices:
             fused = fused_spline_coupling_train(self, x, y, nc_dev, nc_host, inverse, oob)
             if fused is not None:
@@ -404,16 +443,16 @@ class ConditionalSplineTransformer(Transformer):
                                 self._top, self._default_settings, oob)
         res = rqs_transform(y, params, nc_dev, n_bins, inverse, self._left, self._right, self._bottom,
                             self._top, self._default_settings, want_bin_idx=self.return_bin_indices,
-                            oob_counter=oob)
+                            oob_counter=oob, acc=acc)
         if self.return_bin_indices:
             self.last_bin_indices = res[2]
         return res[0], res[1]
 
     def _forward(self, x, y, *args, **kwargs):
-        return self._run(x, y, False)
+        return self._run(x, y, False, acc=kwargs.get(ACC_KW))
 
     def _inverse(self, x, y, *args, **kwargs):
-        return self._run(x, y, True)
+        return self._run(x, y, True, acc=kwargs.get(ACC_KW))
 
 
 AffineTransformer.invalidate_fused_cache = _invalidate_fused_cache

@@ -303,6 +303,41 @@ int bgk_coupling_affine_dense_h3(const float* cond, int64_t ldc, int32_t d_c, in
                                  const float* y, int64_t ldy, int64_t B, int32_t d,
                                  float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
 
+/* The fused coupling layers with SEVERAL conditioning tensors: CouplingFlow concatenates the tensors at cond_indices before it
+ * calls the transformer (torch.cat, nn/flow/coupling.py:162-165; e.g. cfg 5's AUGMENTED | (FIXED, BONDS, ANGLES) layers).  Here
+ * cond / ldc / width are HOST arrays of n_cond (1..3) device pointers [B, width_i], row strides and widths; the kernels stage
+ * every tensor from its own rows, the concatenation is never materialised.  Everything else as in the single-tensor entry points
+ * (d_c = sum of the widths).  BGK_EUNSUPPORTED for n_cond > 1 on kernels without the segment table (first-generation spline
+ * kernel / K != 8, hidden width 64, exact-f32 mode): the caller concatenates and uses the single-tensor entry point. */
+int bgk_coupling_rqs_dense_h2_mc(const float* const* cond, const int64_t* ldc, const int32_t* width, int32_t n_cond, int32_t periodic,
+                                 const void* A0p, const void* A1p, const void* A2p,
+                                 float c0, float c1, float c2, const float* cs_dev, int32_t operand_dtype,
+                                 int32_t H0, int32_t H1, int32_t act,
+                                 const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
+                                 uint64_t circ_mask, int32_t inverse,
+                                 double left, double right, double bottom, double top,
+                                 double min_bin_width, double min_bin_height, double min_derivative,
+                                 int32_t identity_init,
+                                 float* out, int64_t ldo, float* dlogp, int32_t accumulate,
+                                 int32_t* bin_idx, int32_t* oob_count, void* stream);
+int bgk_coupling_affine_dense_h2_mc(const float* const* cond, const int64_t* ldc, const int32_t* width, int32_t n_cond, int32_t periodic,
+                                    const void* sA0, const void* sA1, const void* sA2,
+                                    float sc0, float sc1, float sc2, int32_t s_act,
+                                    const void* tA0, const void* tA1, const void* tA2,
+                                    float tc0, float tc1, float tc2, int32_t t_act,
+                                    int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                    int32_t is_circular, int32_t inverse,
+                                    const float* y, int64_t ldy, int64_t B, int32_t d,
+                                    float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
+int bgk_coupling_affine_dense_h3_mc(const float* const* cond, const int64_t* ldc, const int32_t* width, int32_t n_cond, int32_t periodic,
+                                    const void* sA0, const void* sA1, const void* sA1b, const void* sA2,
+                                    float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
+                                    const void* tA0, const void* tA1, const void* tA1b, const void* tA2,
+                                    float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
+                                    int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                    int32_t is_circular, int32_t inverse,
+                                    const float* y, int64_t ldy, int64_t B, int32_t d,
+                                    float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
 
 /* Device-side packing of a DenseNet [n_in, H, H, rows2] into split-f16 MFMA operands (no host synchronisation; used
  * whenever the weights change, i.e. every training step).  Layer 2's packed rows are row_map2_dev[packed row] (source
@@ -332,8 +367,9 @@ int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z
 /* Optimizer step on the flat parameter bucket (f-2: the optimizer of KLTrainer.train, nn/training/trainers.py:148-201).
  * bgk_grad_nan_flag sets flag[0] = any(isnan(g)) on the device (the reference's "found nan in grad; skipping optimization
  * step" check, trainers.py:198-201, without a host round trip); bgk_adam_step is torch.optim.Adam's update (step = 1, 2, ...:
- * bias corrections 1 - beta^step computed on the host in double) over [n] contiguous floats, a no-op that increments
- * skipped_count[0] when skip_flag[0] != 0 (either pointer may be NULL). */
+ * `step` counts the calls; the time step of the bias corrections 1 - beta^t is t = step - skipped_count[0], read on the device, so a
+ * skipped call does not advance it -- like the reference, which does not call optim.step() then) over [n] contiguous floats, a
+ * no-op that increments skipped_count[0] when skip_flag[0] != 0 (either pointer may be NULL). */
 int bgk_grad_nan_flag(const float* g, int64_t n, int32_t* flag, void* stream);
 int bgk_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, const int32_t* skip_flag, int32_t* skipped_count, void* stream);
