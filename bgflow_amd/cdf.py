@@ -49,6 +49,59 @@ def _descriptor(dist, d):
         return None
 
 
+def _reverted_cdf_series(alpha):
+    """c2..c5 of h = s + c2 s^2 + ... + c5 s^5, the solution of Phi(alpha + h) - Phi(alpha) = s pdf(alpha) for small s (reverted
+    Taylor series of the standard normal cdf around alpha; derivatives of the pdf: -a phi, (a^2 - 1) phi, -(a^3 - 3a) phi, ...)"""
+    a2, a3 = -alpha / 2.0, (alpha ** 2 - 1.0) / 6.0
+    a4, a5 = -(alpha ** 3 - 3.0 * alpha) / 24.0, (alpha ** 4 - 6.0 * alpha ** 2 + 3.0) / 120.0
+    return (-a2, 2.0 * a2 ** 2 - a3, -5.0 * a2 ** 3 + 5.0 * a2 * a3 - a4,
+            14.0 * a2 ** 4 - 21.0 * a2 ** 2 * a3 + 3.0 * a3 ** 2 + 6.0 * a2 * a4 - a5)
+
+
+TAIL_DESC = 20     # floats per channel of the sampling-tail kernel's descriptor (csrc/bgk_tail.hip)
+
+
+def _tail_descriptor(dist, d):
+    """[d, 20] float32 descriptor of a marginal for bgk_icdf_ic2xyz_reg (layout: csrc/bgk_tail.hip), all constants in f64 on the
+    host: the affine maps around erfinv folded into one fma each, the element-independent part of -log_prob, and -- for a
+    truncated normal -- the reverted cdf series around each finite bound (the kernel evaluates the DISTANCE to the bound directly
+    there instead of mu + sigma z).  None for an unsupported distribution."""
+    from scipy import special as sps
+    base = _descriptor(dist, d)
+    if base is None:
+        return None
+    b = base.double().numpy()
+    out = np.zeros((d, TAIL_DESC), np.float64)
+    kinds = np.zeros(d, np.int32)
+    half_log_2pi = 0.9189385332046727
+    for j in range(d):
+        kind = int(b[j, 0])
+        kinds[j] = kind
+        if kind == 0:
+            low, high = b[j, 1], b[j, 2]
+            out[j, 1], out[j, 2], out[j, 5] = low, high - low, np.log(high - low)
+            continue
+        mu, sigma = b[j, 1], b[j, 2]
+        clo, Z = (0.0, 1.0) if kind == 1 else (b[j, 3], b[j, 4])
+        out[j, 1], out[j, 2], out[j, 3], out[j, 4] = mu, sigma * np.sqrt(2.0), 2.0 * Z, 2.0 * clo - 1.0
+        out[j, 5] = np.log(Z * sigma) + half_log_2pi
+        out[j, 6], out[j, 13] = 1.0 / (sigma * np.sqrt(2.0)), sigma
+        out[j, 7] = out[j, 14] = 1e30                                     # no bound: the series window is never entered
+        if kind == 2:
+            for lower, off in ((True, 7), (False, 14)):
+                c = clo if lower else clo + Z
+                if not (1e-300 < c < 1.0 - 1e-16):
+                    continue
+                x0 = sps.ndtri(c)
+                pdf = np.exp(-0.5 * x0 * x0) / np.sqrt(2.0 * np.pi)
+                out[j, off] = Z / pdf
+                out[j, off + 1:off + 5] = _reverted_cdf_series(x0 if lower else -x0)
+                out[j, 12 if lower else 19] = mu + sigma * x0
+    out32 = out.astype(np.float32)
+    out32[:, 0] = kinds.view(np.float32)                                  # the kind travels as int32 bits
+    return torch.from_numpy(out32).contiguous()
+
+
 def _source_tensors(dist):
     """the tensors a descriptor is built from (parameters / buffers of the marginal), for cache validation"""
     out = []
@@ -138,8 +191,19 @@ class CDFTransform(Flow):
         key = (d, str(device), tuple((t.data_ptr(), t._version, str(t.device)) for t in src))
         if self._desc_cache.get("key") != key:
             desc = _descriptor(self.distribution, d)
-            self._desc_cache = {"key": key, "desc": None if desc is None else desc.to(device)}
+            self._desc_cache.update({"key": key, "desc": None if desc is None else desc.to(device)})
         return self._desc_cache["desc"]
+
+    def tail_descriptor(self, d, device):
+        """the [d, 20] device descriptor of the sampling-tail kernel (bgk_icdf_ic2xyz_reg), cached like ``kernel_descriptor``"""
+        src = _source_tensors(self.distribution)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in src):
+            return None
+        key = (d, str(device), tuple((t.data_ptr(), t._version, str(t.device)) for t in src))
+        if self._desc_cache.get("key20") != key:
+            desc = _tail_descriptor(self.distribution, d)
+            self._desc_cache["key20"], self._desc_cache["desc20"] = key, (None if desc is None else desc.to(device))
+        return self._desc_cache["desc20"]
 
     def invalidate_kernel_cache(self):
         """forget the cached descriptor (after in-place edits through ``.data``, which bump no version counter)"""

@@ -192,6 +192,14 @@ class SequentialFlow(Flow):
         builder domain maps ``WrapFlow(InverseFlow(CDFTransform))`` followed by ``WrapFlow(InverseFlow(<IC transform>))``
         (generator_builder.py:443-459 + add_map_to_cartesian) runs as ONE fused kernel when the inputs need no gradients."""
         blocks = list(self._blocks)
+        # the segment list (and what the fused segments cache: descriptor tables) is rebuilt only when the blocks or the switches change
+        key = (bool(inverse), self.FUSE_GENERATION_TAIL, self.FUSE_COUPLING_STACKS, tuple(id(b) for b in blocks))
+        cache = self.__dict__.setdefault("_segment_cache", {})
+        if cache.get("key") != key:
+            cache["key"], cache["segments"] = key, self._build_segments(blocks, inverse)
+        return cache["segments"]
+
+    def _build_segments(self, blocks, inverse):
         if inverse:
             return self._with_coupling_stacks(list(reversed(blocks)), True)
         tail = self._generation_tail() if self.FUSE_GENERATION_TAIL else None
@@ -400,6 +408,42 @@ class _FusedGenerationTail:
     def __init__(self, flow, tail):
         self._flow, (self._start, self._maps, self._ic, self._eps, self._others) = flow, tail
 
+    def _desc20(self, xs):
+        """[3 n + keep, 20] descriptor table of the register-resident tail kernel: bonds | angles | torsions rows IN PLACEMENT ORDER
+        (row f n + i = the channel of field f that placement i consumes), then the fixed rows; a field without a map gets kind -1
+        rows.  Cached on the per-map descriptors' identity; None if a marginal has no descriptor or the transform no placement
+        table."""
+        from .cdf import TAIL_DESC
+        rel = getattr(self._ic, "_rel_ic", self._ic)
+        order = getattr(rel, "_placement_zrows", None)
+        if order is None:
+            return None
+        parts, key = [], []
+        for slot in range(4):
+            d = xs[slot].shape[-1]
+            cdf = self._maps.get(slot)
+            if cdf is None:
+                t = torch.zeros(d, TAIL_DESC, dtype=torch.float32, device=xs[slot].device)
+                t[:, 0] = torch.tensor(-1, dtype=torch.int32).view(torch.float32)
+            else:
+                t = cdf.tail_descriptor(d, xs[slot].device)
+                if t is None:
+                    return None
+            parts.append(t)
+            key.append((id(t), d))
+        key = tuple(key)
+        if getattr(self, "_desc20_key", None) != key:
+            idx = torch.as_tensor(order, device=parts[0].device)
+            if any(p.shape[0] != len(order) for p in parts[:3]):
+                return None
+            self._desc20_key = key
+            self._desc20_tab = torch.cat([parts[0][idx], parts[1][idx], parts[2][idx], parts[3]], dim=0).contiguous()
+            # field-uniform marginals (one distribution per field, the builder's case): a [4, 20] table selects the elementwise kernel
+            uniform = all(bool((p == p[:1]).all()) for p in parts)
+            self._desc20_tab.uniform4 = torch.cat([p[:1] for p in parts], dim=0).contiguous() if uniform else None
+            self._desc20_parts = parts            # keep the per-map tensors alive: their ids are the cache key
+        return self._desc20_tab
+
     def _blocks_path(self, *xs, **kwargs):
         acc = kwargs.get(ACC_KW)
         total = 0.0
@@ -432,7 +476,7 @@ class _FusedGenerationTail:
                 acc.add(dd)
             else:
                 total = total + dd
-        x, dlogp = self._ic._generate_fused(xs[0], xs[1], xs[2], xs[3], descs, self._eps, acc=acc)
+        x, dlogp = self._ic._generate_fused(xs[0], xs[1], xs[2], xs[3], descs, self._eps, acc=acc, desc20=self._desc20(xs))
         if acc is not None:
             return (x, *xs[4:], acc)
         return (x, *xs[4:], dlogp + total if self._others else dlogp)

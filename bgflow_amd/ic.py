@@ -262,7 +262,11 @@ class RelativeInternalCoordinateTransformation(Flow):
         self._raise_warnings = raise_warnings
         self._tables = _DeviceTables()
         self._tables.set("zmat", np.ascontiguousarray(z[:, :4], dtype=np.int32))
-        self._tables.set("place", _placement_table(z, f))
+        place = _placement_table(z, f)
+        self._tables.set("place", place)
+        # the register-resident tail kernel reads one 32-byte record per placement (bgk_tail.hip::Rec)
+        self._tables.set("place8", np.ascontiguousarray(np.concatenate([place, np.zeros((len(place), 3), np.int32)], axis=1)))
+        self._placement_zrows = place[:, 4].astype(np.int64)      # Z row consumed by placement i
         self._tables.set("fixed", np.ascontiguousarray(f, dtype=np.int32))
         self._n, self._n_fixed = len(z), len(f)
         self._warn = {}
@@ -363,7 +367,10 @@ class RelativeInternalCoordinateTransformation(Flow):
         _lib.check(st, "bgk_ic_ic2xyz")
         return x, _dl_result(acc, dlogp)
 
-    def _icdf_ic2xyz(self, bonds, angles, torsions, xfix, descs, eps, blacken=None, acc=None):
+    UNIFORM_TAIL = True      # ... and on its elementwise variant when every field has one marginal for all its channels
+    REGISTER_TAIL = True     # sampling tail on the register-resident kernel (bgk_icdf_ic2xyz_reg) where its envelope allows
+
+    def _icdf_ic2xyz(self, bonds, angles, torsions, xfix, descs, eps, blacken=None, acc=None, desc20=None):
         """IC -> xyz with the icdf domain maps of the four inputs fused in (bgk_icdf_ic2xyz); ``descs`` = per-field [d, 6]
         descriptor tensors (cdf.CDFTransform.kernel_descriptor) or None for a field that is used as is.  No autograd."""
         _lib.require_hip(bonds, angles, torsions, xfix)
@@ -380,6 +387,31 @@ class RelativeInternalCoordinateTransformation(Flow):
         assert f2.shape[1] == keep
         x = torch.empty((B, 3 * (n + nf)), dtype=torch.float32, device=dev)
         dlogp, accumulate = _dl_target(acc, B, dev)
+        if (desc20 is not None and self.REGISTER_TAIL and self._normalize_angles and n + nf <= 32 and keep <= 16 and B > 0
+                and ldic == n and ldf == keep and all(v.is_contiguous() for v in (b2, a2, t2, f2))):
+            # second-generation tail (csrc/bgk_tail.hip): positions in registers, contiguous field tiles
+            const_ld = n * (np.log(np.pi) + np.log(2.0 * np.pi)) - (float(jac) if T is not None else 0.0)
+            desc4 = getattr(desc20, "uniform4", None)
+            st = -2
+            if desc4 is not None and self.UNIFORM_TAIL:
+                with torch.cuda.device(dev):
+                    st = _lib.lib().bgk_icdf_ic2xyz_uni(
+                        _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), _lib.ptr(f2), _lib.ptr(desc4), int(eps is not None), float(eps or 0.0),
+                        _lib.ptr(self._tables.get("place8", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
+                        float(self._eps), int(self._enforce_boundaries), _lib.ptr(mean), _lib.ptr(T), keep, float(const_ld), B,
+                        _lib.ptr(x), x.shape[1], _lib.ptr(dlogp), accumulate, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+                if st != -2:
+                    _lib.check(st, "bgk_icdf_ic2xyz_uni")
+                    return x, _dl_result(acc, dlogp)
+            with torch.cuda.device(dev):
+                st = _lib.lib().bgk_icdf_ic2xyz_reg(
+                    _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), _lib.ptr(f2), _lib.ptr(desc20), int(eps is not None), float(eps or 0.0),
+                    _lib.ptr(self._tables.get("place8", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
+                    float(self._eps), int(self._enforce_boundaries), _lib.ptr(mean), _lib.ptr(T), keep, float(const_ld), B,
+                    _lib.ptr(x), x.shape[1], _lib.ptr(dlogp), accumulate, _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+            if st != -2:
+                _lib.check(st, "bgk_icdf_ic2xyz_reg")
+                return x, _dl_result(acc, dlogp)
         db, da, dt, df = descs
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_icdf_ic2xyz(
@@ -392,8 +424,8 @@ class RelativeInternalCoordinateTransformation(Flow):
         _lib.check(st, "bgk_icdf_ic2xyz")
         return x, _dl_result(acc, dlogp)
 
-    def _generate_fused(self, bonds, angles, torsions, x_fixed, descs, eps, acc=None):
-        return self._icdf_ic2xyz(bonds, angles, torsions, x_fixed, descs, eps, acc=acc)
+    def _generate_fused(self, bonds, angles, torsions, x_fixed, descs, eps, acc=None, desc20=None):
+        return self._icdf_ic2xyz(bonds, angles, torsions, x_fixed, descs, eps, acc=acc, desc20=desc20)
 
     def _forward(self, x, with_pose=True, *args, **kwargs):
         return self._xyz2ic(x, acc=kwargs.get(ACC_KW))
@@ -491,8 +523,9 @@ class MixedCoordinateTransformation(Flow):
     def _inverse(self, bonds, angles, torsions, z_fixed, *args, **kwargs):
         return self._rel_ic._ic2xyz(bonds, angles, torsions, z_fixed, blacken=self._wh("blacken", bonds.device), acc=kwargs.get(ACC_KW))
 
-    def _generate_fused(self, bonds, angles, torsions, z_fixed, descs, eps, acc=None):
-        return self._rel_ic._icdf_ic2xyz(bonds, angles, torsions, z_fixed, descs, eps, blacken=self._wh("blacken", bonds.device), acc=acc)
+    def _generate_fused(self, bonds, angles, torsions, z_fixed, descs, eps, acc=None, desc20=None):
+        return self._rel_ic._icdf_ic2xyz(bonds, angles, torsions, z_fixed, descs, eps, blacken=self._wh("blacken", bonds.device), acc=acc,
+                                         desc20=desc20)
 
 
 def slice_initial_atoms(z_matrix):

@@ -158,6 +158,35 @@ int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const float* torsio
                     const float* wh_mean, const float* Tblacken, int32_t keep, float jac_xz, int64_t B,
                     float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream);
 
+/* The same tail on the register-resident kernel (csrc/bgk_tail.hip; the shipped path of builder flows up to 32 atoms): the growing
+ * position table lives in registers (wave-uniform atom indices -> uniform register indexing), all uniform tables come through scalar
+ * loads, field tiles are contiguous [B, n] / [B, keep] blocks (row stride = width), angles are normalised.
+ *   place8 [n, 8] int32: one record per placement (atom, p1, p2, p3, zrow, 0, 0, 0)
+ *   desc20 [3 n + keep, 20]: per-channel descriptors, the bonds | angles | torsions rows in PLACEMENT order (row f n + i = the channel
+ *          of field f that placement i consumes), then the keep fixed rows; built on the host in f64
+ *          (bgflow_amd/cdf.py::_tail_descriptor; layout documented in bgk_tail.hip): kind as int32 bits, the affine maps around erfinv
+ *          folded into one fma each, and for truncated-normal marginals the reverted cdf series around each finite bound, with which
+ *          the kernel evaluates the distance to the bound directly (no cancellation mu + sigma z for near-degenerate samples)
+ *   const_ld: n (ln pi + ln 2 pi) - jac_xz (the constant part of the log-det)
+ * Returns BGK_EUNSUPPORTED for n + n_fixed > 32 or keep > 16: the caller uses bgk_icdf_ic2xyz. */
+int bgk_icdf_ic2xyz_reg(const float* bonds, const float* angles, const float* torsions, const float* xfix,
+                        const float* desc20, int32_t use_eps, float cdf_eps,
+                        const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                        float eps, int32_t enforce_boundaries,
+                        const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
+                        float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream);
+
+/* ... and for FIELD-UNIFORM marginals (every channel of a field shares one descriptor: what the builder installs) the variant whose
+ * icdf maps run elementwise over the field tiles in their memory layout: tiles reach LDS by DMA (global_load_lds), descriptors stay in
+ * SGPRs, finished rows leave through LDS as 16-byte coalesced stores.  desc4 [4, 20] = the bonds / angles / torsions / fixed descriptor;
+ * x contiguous (ldx = 3 (n + n_fixed)), all tensors 16-byte aligned; BGK_EUNSUPPORTED otherwise (use bgk_icdf_ic2xyz_reg). */
+int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, const float* torsions, const float* xfix,
+                        const float* desc4, int32_t use_eps, float cdf_eps,
+                        const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                        float eps, int32_t enforce_boundaries,
+                        const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
+                        float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream);
+
 /* Backward (VJP) of bgk_ic_ic2xyz for first-order losses (replaces torch autograd through
  * ic2xyz_deriv / det3x3, ic.py:435-513): x is the forward OUTPUT; g_x [B, 3*n_atoms], g_dlogp [B]
  * -> g_bonds / g_angles / g_torsions [B, n] (ldgic), g_xfix [B, keep] (ldgf).  The log-det term uses
