@@ -16,8 +16,13 @@ Rank 0 prints ONE JSON line:
                         dense f16 peak; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes (a profile
                         constant, labelled as such); `step_view` = the whole step in the same accounting
   cpu_baseline          the reference's op chain on the host cores (rank 0, N = 1): `value` = stock torch-CPU ops, all physical
-                        cores (oracle/torch_flow.py, kind "port"); the scalar C oracle is timed beside it; `parity_sample` compares
-                        the GPU path with the C oracle on the first samples (log-det error, bin-index ties)
+                        cores, processes pinned (oracle/torch_flow.py, kind "port"); `inverse` and `kl` = the NLL direction and KL
+                        training steps on the same cores; the scalar C oracle is timed beside it; `parity_sample` = GPU / f32 C
+                        oracle / torch f32 chain against the f64 oracle on 2^14 random samples (log-det error statistics, the share
+                        of samples beyond 1e-5, bin-index ties)
+  inverse               the NLL direction of the same flow on the GPU (samples/s)
+  rccl                  (N > 1) backend, world size, the device behind every rank, a same-run one-rank pass and the weak-scaling
+                        efficiency against it, the [sum loss, n] all-reduce alone
   exact_f32_mode, cfg2, cfg5, kl   side measurements (HIP events, >= 10 steps each)
 """
 import argparse
@@ -190,6 +195,23 @@ def host_cpu():
     return model, n_phys, avail
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max / v1 cfs quota), or None if unlimited.  On the pool's
+    boxes the container sees all 256 logical CPUs but is throttled to 16: more runnable threads than that only add throttling stalls
+    (one 8-thread process alone: 5.9e4 samples/s; eight of them concurrently: 7.6e4 in total)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_flow(workload):
     from bgflow_amd import configs
     return {"cfg3": configs.make_ala2_spline_generator, "cfg5": configs.make_ala2_augmented_generator,
@@ -197,34 +219,94 @@ def _cpu_flow(workload):
 
 
 def _cpu_worker(job):
-    """one process of the multi-process torch-CPU leg: seconds per pass (best of 3) over its own chunk"""
-    workload, chunk, threads, seed = job
+    """one process of a multi-process torch-CPU leg, pinned to its own cores: seconds per pass (best of `reps`) over its own chunk.
+    mode "fwd": sampling direction (forward + log|det J|); "inv": NLL direction; "kl": one KL training step (forward with autograd
+    through the reference's op chain, backward, torch.optim.Adam step)"""
+    workload, chunk, threads, seed, cores, mode, reps = job
+    if cores:
+        try:
+            os.sched_setaffinity(0, set(cores))
+        except OSError:
+            pass
     torch.set_num_threads(threads)
     from oracle import torch_flow as tfl
     gen = _cpu_flow(workload)
     g = torch.Generator().manual_seed(seed)
     dims = {"cfg3": (17, 17, 17, 9), "cfg5": (17, 17, 17, 9, 66), "cfg2": (64,)}[workload]
     ut = [torch.rand(chunk, d, generator=g) if workload != "cfg2" else torch.randn(chunk, d, generator=g) for d in dims]
-    tfl.run_flow(gen.flow, ut)
+    if mode == "inv":
+        xs, _ = tfl.run_flow(gen.flow, ut)
+        run = lambda: tfl.run_flow(gen.flow, xs, inverse=True)         # noqa: E731
+    elif mode == "kl":
+        params = [p for p in gen.flow.parameters()]
+        opt = torch.optim.Adam(params, lr=1e-5)
+
+        def run():
+            opt.zero_grad()
+            xs, dl = tfl.run_flow(gen.flow, ut, grad=True)
+            loss = (gen._target.energy(*xs) - dl)
+            loss = loss[torch.isfinite(loss)].mean()
+            loss.backward()
+            opt.step()
+    else:
+        run = lambda: tfl.run_flow(gen.flow, ut)                       # noqa: E731
+    run()
     best = float("inf")
-    for _ in range(3):
+    for _ in range(reps):
         t0 = time.perf_counter()
-        tfl.run_flow(gen.flow, ut)
+        run()
         best = min(best, time.perf_counter() - t0)
     return best
 
 
-def cpu_baseline(workload, gen_gpu, dev, n_c_samples):
+def _cpu_leg(workload, mode, chunk, shapes, phys, reps, timeout=60):
+    """Run `mode` with every (processes x threads) shape in `shapes`, all processes concurrently, each pinned (sched_setaffinity
+    before its OpenMP pool exists) to its own block of physical cores (consecutive ids = one CCD / NUMA node on the EPYC hosts of
+    the pool).  Returns the per-shape results and the name of the best one."""
+    import multiprocessing as mp
+    legs = {}
+    for workers, threads in shapes:
+        name = f"{workers}x{threads}"
+        pool = None
+        try:
+            jobs = [(workload, chunk, threads, 1234 + i, phys[i * threads:(i + 1) * threads], mode, reps) for i in range(workers)]
+            pool = mp.get_context("spawn").Pool(workers)
+            res = pool.map_async(_cpu_worker, jobs).get(timeout=timeout)     # a stuck worker is killed below, never waited for
+            tmax = max(res)
+            legs[name] = dict(value=workers * chunk / tmax, cores=workers * threads, slowest_pass_s=tmax,
+                              sample=f"{workers} process(es) x {threads} intra-op threads, each pinned to its own cores, best of {reps} passes "
+                                     f"over its own chunk of {chunk} samples, all concurrently")
+        except Exception as e:   # the baseline must never take the bench line down
+            legs[name] = dict(value=None, error=repr(e)[:200])
+        finally:
+            if pool is not None:
+                pool.terminate()
+                pool.join()
+    ok = [k for k in legs if legs[k].get("value")]
+    return legs, (max(ok, key=lambda k: legs[k]["value"]) if ok else None)
+
+
+def _err_stats(a, ref):
+    r = np.abs(np.asarray(a, np.float64).reshape(-1) - ref.reshape(-1)) / np.maximum(np.abs(ref.reshape(-1)), 1.0)
+    return dict(median=float(np.median(r)), p99=float(np.quantile(r, 0.99)), max=float(r.max()), frac_gt_1e5=float((r > 1e-5).mean()))
+
+
+def cpu_baseline(workload, gen_gpu, dev, n_c_samples, kl_batch):
     """The reference's op chain on the host cores (the reference itself cannot travel to the GPU box):
-       leg 1 (value): stock torch-CPU ops -- vectorised aten, all physical cores, chunks of 2^15 samples, best of 5;
-       leg 2: the scalar C oracle (OpenMP over samples; the parity checker, latency-bound by design);
-       parity_sample: the GPU path against the C oracle on the first 2^14 samples."""
+       value / forward: stock torch-CPU ops (oracle/torch_flow.py), vectorised aten, all physical cores -- the best of
+                        {1 x N, N/8 x 8, N/16 x 16} (processes x threads, every process pinned to its own cores), chunks of 2^15
+                        samples; the rate of ONE 8-thread process running alone is reported beside it;
+       inverse:         the NLL direction on the best shape;   kl: KL training steps (autograd through the same op chain + Adam);
+       c_oracle:        the scalar C oracle (OpenMP over samples; the parity checker, latency-bound by design);
+       parity_sample:   the GPU path, the f32 C oracle and the torch f32 chain against the f64 oracle on 2^14 random samples."""
     from bgflow_amd import configs
     from oracle import flow_oracle as fo
     from oracle import oracle as orc
     from oracle import torch_flow as tfl
     orc.build()
     model, n_phys, n_avail = host_cpu()
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(n_avail))
+    phys = avail[:n_phys]               # logical ids 0 .. n_phys - 1 are distinct physical cores on the pool's hosts (siblings: + n_phys)
     if workload == "cfg3":
         gen = configs.make_ala2_spline_generator()
         dims = (17, 17, 17, 9)
@@ -239,44 +321,45 @@ def cpu_baseline(workload, gen_gpu, dev, n_c_samples):
         gen = configs.make_affine8_generator()
         rng = np.random.default_rng(1234)
         u = [rng.standard_normal((n_c_samples, 64), dtype=np.float32)]
-    # ---- leg 1: torch CPU.  Two ways of using all physical cores: one process with n_phys intra-op threads, and
-    # n_phys / 8 processes x 8 threads on independent chunks (the reference's ops are small: they scale poorly past ~8 threads)
     chunk = 1 << 15
-    legs = {}
-    prev = torch.get_num_threads()
-    torch.set_num_threads(n_phys)
-    ut = [torch.as_tensor(v[:chunk]) for v in u]
-    tfl.run_flow(gen.flow, ut)                                       # warm-up
-    best = float("inf")
-    t_leg = time.perf_counter()
-    for _ in range(5):
-        t0 = time.perf_counter()
-        tfl.run_flow(gen.flow, ut)
-        best = min(best, time.perf_counter() - t0)
-        if time.perf_counter() - t_leg > 10.0:
-            break
-    torch.set_num_threads(prev)
-    legs["one_process"] = dict(value=chunk / best, cores=n_phys, sample=f"best of <=5 passes over one chunk of {chunk} samples "
-                               f"({best:.2f} s each), {n_phys} intra-op threads")
-    workers = max(1, n_phys // 8)
-    if workers > 1:
-        try:
-            import concurrent.futures as cf
-            import multiprocessing as mp
-            with cf.ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as ex:
-                res = list(ex.map(_cpu_worker, [(workload, chunk, 8, 1234 + i) for i in range(workers)], timeout=120))
-            tmax = max(r for r in res)
-            legs["multi_process"] = dict(value=workers * chunk / tmax, cores=workers * 8,
-                                         sample=f"{workers} processes x 8 intra-op threads, each best of 3 passes over its own chunk of {chunk} "
-                                                f"samples, all concurrently (slowest worker {tmax:.2f} s per pass)")
-        except Exception as e:   # the baseline must never take the bench line down
-            legs["multi_process"] = dict(value=None, error=repr(e)[:200])
-    pick = max((k for k in legs if legs[k].get("value")), key=lambda k: legs[k]["value"])
-    torch_leg = dict(value=legs[pick]["value"], unit="samples/s", cores=legs[pick]["cores"], kind="port",
-                     sample=f"forward + log|det J|, f32, torch.no_grad; oracle/torch_flow.py = the reference's op chain on stock aten ops (coordinate "
-                            f"transform: C oracle); best of the two all-core configurations ({pick}): " + legs[pick]["sample"],
-                     torch_cpu_configurations=legs)
-    # ---- leg 2: C oracle
+    quota = cpu_quota()
+    usable = n_phys if quota is None else max(1, min(n_phys, int(round(quota))))     # threads worth running at once
+    shapes = [(1, usable)]
+    for t in (8, 4):
+        if usable // t > 1:
+            shapes.append((usable // t, t))
+    if quota is not None and 2 * usable <= n_phys:
+        shapes.append((2 * usable // 8, 8))        # mild oversubscription of the quota (throttling vs idle time: measured, not assumed)
+    legs, pick = _cpu_leg(workload, "fwd", chunk, shapes, phys, reps=2)
+    alone, _ = _cpu_leg(workload, "fwd", chunk, [(1, min(8, n_phys))], phys, reps=2)
+    legs["1x8_alone"] = alone.get(f"1x{min(8, n_phys)}")
+    if pick is None:
+        torch_leg = dict(value=None, unit="samples/s", cores=n_phys, kind="port", sample="torch-CPU leg failed", torch_cpu_configurations=legs)
+        best_shape = (1, n_phys)
+    else:
+        best_shape = tuple(int(v) for v in pick.split("x"))
+        torch_leg = dict(value=legs[pick]["value"], unit="samples/s", cores=legs[pick]["cores"], kind="port",
+                         sample=f"forward + log|det J|, f32, torch.no_grad; oracle/torch_flow.py = the reference's op chain on stock aten ops "
+                                f"(coordinate transform: C oracle); host: {n_phys} physical cores, container CPU quota "
+                                f"{'none' if quota is None else quota} CPUs; best of the shapes tried ({pick}): " + legs[pick]["sample"],
+                         torch_cpu_configurations=legs)
+    # ---- the other half of the metric on the host cores: NLL direction and KL training steps
+    extra = {}
+    if workload != "cfg2":
+        inv, p2 = _cpu_leg(workload, "inv", chunk, [best_shape], phys, reps=2)
+        if p2:
+            extra["inverse"] = dict(value=inv[p2]["value"], unit="samples/s", cores=inv[p2]["cores"], kind="port",
+                                    sample="NLL direction (xyz -> IC -> cdf maps -> 16 inverse couplings), " + inv[p2]["sample"])
+        klc = 1 << 13
+        kl, p3 = _cpu_leg(workload, "kl", klc, [best_shape], phys, reps=1)
+        if p3:
+            sps = kl[p3]["value"]
+            extra["kl"] = dict(samples_per_s=sps, steps_per_s_at_gpu_batch=sps / kl_batch, gpu_batch=kl_batch, unit="steps/s", cores=kl[p3]["cores"],
+                               kind="port",
+                               sample=f"KL step = forward with autograd through the reference's op chain (torch ops incl. IC -> xyz) + backward + "
+                                      f"torch.optim.Adam; {best_shape[0]} data-parallel process(es) x {best_shape[1]} threads on chunks of {klc} samples "
+                                      f"({kl[p3]['slowest_pass_s']:.2f} s per step); steps/s at the GPU's batch = aggregate samples/s / {kl_batch}")
+    # ---- C oracle
     fo.run_flow(gen.flow, [v[:256] for v in u], dtype=np.float32)
     passes, dt = 0, 0.0
     while dt < 6.0 and passes < 4:
@@ -287,7 +370,7 @@ def cpu_baseline(workload, gen_gpu, dev, n_c_samples):
     c_leg = dict(value=passes * n_c_samples / dt, unit="samples/s", cores=orc.num_threads(), kind="port",
                  sample=f"{passes} pass(es) over {n_c_samples} samples ({dt:.1f} s); scalar C restatement (oracle/bgo_oracle.c, k-ordered fmaf "
                         f"chains, OpenMP over samples): the bit-exact parity checker, not a throughput reference")
-    # ---- parity sample: GPU path vs the C oracle, layer by layer on the oracle's inputs
+    # ---- parity sample: GPU path vs the oracles, layer by layer on the oracle's inputs, and whole flow vs the f64 oracle
     parity = None
     if workload == "cfg3" and gen_gpu is not None:
         import bgflow_amd as bg
@@ -296,6 +379,8 @@ def cpu_baseline(workload, gen_gpu, dev, n_c_samples):
         v = [w[:n] for w in u]
         pb, trace = [], []
         _, dl32 = fo.run_flow(gen.flow, v, dtype=np.float32, per_block=pb, trace=trace)
+        _, dl64 = fo.run_flow(gen.flow, [w.astype(np.float64) for w in v], dtype=np.float64)
+        _, dlt = tfl.run_flow(gen.flow, [torch.as_tensor(w) for w in v])
         n_mis = n_el = 0
         far = 0.0
         k = 0
@@ -315,14 +400,18 @@ def cpu_baseline(workload, gen_gpu, dev, n_c_samples):
                     y = np.asarray(ins[block.transformed_indices[0]])
                     far = max(far, float(np.abs(det["knots"] - y[..., None]).min(-1)[mis].max()))
             *_, dl = gen_gpu.flow(*[torch.as_tensor(w).to(dev) for w in v])
-        r = np.abs(dl.cpu().numpy() - dl32) / np.abs(dl32)
+        s_gpu, s_c32, s_t32 = _err_stats(dl.cpu().numpy(), dl64), _err_stats(dl32, dl64), _err_stats(dlt.numpy(), dl64)
         parity = dict(samples=n, elements=n_el, bin_index_differences=n_mis, tie_rate=n_mis / max(n_el, 1),
                       max_distance_to_knot_of_differences=far,
-                      dlogp_rel_vs_f32_oracle=dict(median=float(np.median(r)), p99=float(np.quantile(r, 0.99)), max=float(r.max())),
-                      note="GPU (shipped mode) vs the f32 C oracle, every coupling fed the oracle's inputs; a bin index may differ only "
-                           "where x is within rounding distance (<= 2.4e-7) of a knot; random inputs include icdf tails (the contract "
-                           "tolerance 1e-5 is asserted on the reference's golden vectors in tests/ and smoke())")
-    return dict(torch_leg, cpu=model, logical_cpus=n_avail, c_oracle=c_leg, parity_sample=parity)
+                      dlogp_rel_vs_f64_oracle=dict(gpu=s_gpu, c_oracle_f32=s_c32, torch_cpu_f32_chain=s_t32,
+                                                   gpu_frac_over_reference_chain=s_gpu["frac_gt_1e5"] / max(s_t32["frac_gt_1e5"], 1e-12),
+                                                   gpu_frac_over_c_oracle=s_gpu["frac_gt_1e5"] / max(s_c32["frac_gt_1e5"], 1e-12)),
+                      note="per-sample |dlogp - dlogp64| / max(|dlogp64|, 1) on uniform prior samples (icdf tails included): GPU (shipped mode), "
+                           "the f32 C oracle (icdf evaluated through f64) and the reference's f32 op chain on torch-CPU, all against the f64 oracle; "
+                           "frac_gt_1e5 = share of samples beyond the north-star tolerance (no f32 evaluation holds it on every sample); bin "
+                           "indices: every coupling fed the oracle's inputs, a difference is legal only within rounding distance (<= 2.4e-7) of a knot")
+    return dict(torch_leg, cpu=model, logical_cpus=n_avail, physical_cores=n_phys, cgroup_cpu_quota=quota, c_oracle=c_leg, parity_sample=parity,
+                **extra)
 
 
 def main():
@@ -357,6 +446,16 @@ def main():
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    rccl = None
+    if world > 1:
+        # what the collectives really run on: backend, world size and the device behind every rank (gathered over the group)
+        props = torch.cuda.get_device_properties(dev)
+        mine = dict(rank=rank, local_rank=local, device=torch.cuda.get_device_name(dev), index=dev.index,
+                    uuid=str(getattr(props, "uuid", "")), pci_bus_id=getattr(props, "pci_bus_id", None), host=socket.gethostname())
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        rccl = dict(backend=torch.distributed.get_backend(), world_size=torch.distributed.get_world_size(), devices=gathered,
+                    distinct_devices=len({(g["host"], g["uuid"] or g["index"]) for g in gathered}))
     if args.gemm:
         _dense.GEMM_MODE = args.gemm
     gemm_mode = _dense.GEMM_MODE
@@ -387,6 +486,37 @@ def main():
         per_rank = [args.batch * args.steps / float(v.item()) for v in allt]
     solo = rank == 0 and world == 1
     E, W = args.extra_steps, 2
+    if world > 1:
+        # same-run single-rank pass (the other ranks idle at the barrier): weak-scaling efficiency = (value_N / N) / value_1
+        torch.distributed.barrier()
+        if rank == 0:
+            ms1 = event_ms_per_call(flow_pass(gen, zs), max(3, args.steps // 2), 1)
+            rccl["one_rank_alone_samples_per_s"] = args.batch / (1e-3 * ms1)
+        torch.distributed.barrier()
+        # the only data-path collective of a KL / NLL evaluation, alone: all-reduce of the [sum loss, n] pair
+        pair = torch.zeros(2, dtype=torch.float64, device=dev)
+        for _ in range(5):
+            torch.distributed.all_reduce(pair)
+        torch.cuda.synchronize(dev)
+        t_ar = time.perf_counter()
+        for _ in range(50):
+            torch.distributed.all_reduce(pair)
+        torch.cuda.synchronize(dev)
+        rccl["loss_pair_allreduce_us"] = 1e6 * (time.perf_counter() - t_ar) / 50
+
+    # ---- the other direction of the path: x -> (xyz -> IC, cdf maps, 16 inverse couplings) -> z, log|det J| (the NLL direction)
+    inverse_leg = None
+    if args.workload != "cfg2" and rank == 0:
+        try:
+            with torch.no_grad():
+                *xg, _ = gen.flow(*zs)
+            ms = event_ms_per_call(flow_pass(gen, xg, inverse=True), E, W)
+            inverse_leg = dict(value=args.batch / (1e-3 * ms), unit="samples/s", ms_per_step=ms, steps=E, batch=args.batch, timer="HIP events",
+                               segments=[lbl for lbl, _ in gen.flow.segments(inverse=True)],
+                               note="inverse (NLL) direction of the same flow on this rank: Flow.forward(x, inverse=True) -> (z, dlogp)")
+            del xg
+        except Exception as e:      # a side measurement must never take the headline line down
+            inverse_leg = dict(error=repr(e)[:300])
 
     # ---- extra: the same workload with the conditioner GEMMs in exact-f32 MFMA mode (bit-identical to the CPU oracle)
     exact = None
@@ -458,7 +588,7 @@ def main():
                 opt.zero_grad()
                 *x, dlogp = gen.flow(*zk)
                 loss = dp.global_mean(gen._target.energy(*x) - dlogp, drop_nonfinite=True)
-                loss.backward()
+                opt.backward(loss)                     # loss.backward() with the weight gradients accumulated straight into the bucket
                 opt.allreduce_gradients()              # ONE collective on the bucket
                 opt.step()                             # skips itself on the device if a gradient is NaN
                 last[0] = loss
@@ -544,8 +674,16 @@ def main():
         roof["block_labels"] = [lbl for lbl, _ in segs]
         out = dict(metric="flow samples/s (fwd+log|detJ|) at batch 2^20", value=value, unit="samples/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
-                   scaling="weak", vs_baseline=None, dtype="bf16" if gemm_mode == "bf16" else "f32", data="synthetic",
-                   config=dict(workload=desc, batch_per_gpu=args.batch, global_batch=args.batch * world,
+                   scaling="weak", vs_baseline=None,
+                   dtype={"bf16": "bf16", "f32": "f32", "f16x2": "f32 (split-f16 conditioner GEMMs: hi+lo f16 operand pairs, f32 accumulate)"}[gemm_mode],
+                   arithmetic={"bf16": "spline / log-det / coordinate arithmetic f32; conditioner GEMMs bf16 inputs, f32 accumulate (reduced precision)",
+                               "f32": "f32 throughout (f32-input MFMA = exact fma chain)",
+                               "f16x2": "f32 throughout, except that the conditioner GEMM operands are represented as hi + lo f16 pairs (22-24 "
+                                        "significant bits, 3 MFMAs per product, f32 accumulate); hardware exp2 / log2 / rcp with Newton steps"}[gemm_mode],
+                   data="synthetic",
+                   config=dict(workload=desc + ("" if world == 1 else f"; weak scaling: {args.batch} samples per rank x {world} ranks = "
+                                                f"{args.batch * world} global (BASELINE cfg 4 is this flow at 2^22 global = 2^19 per rank on 8 GPUs)"),
+                               batch_per_gpu=args.batch, global_batch=args.batch * world,
                                parallelism=f"dp{world}",
                                conditioner_gemm={"f16x2": "split-f16: f32 operands as hi+lo f16 pairs, 3 MFMAs per product, f32 accumulate "
                                                           "(f32-class accuracy: per-sample log-det within 1e-5 of the reference's f64 goldens)",
@@ -554,8 +692,14 @@ def main():
                                                          "spline / log-det arithmetic f32"}[gemm_mode]),
                    per_rank_samples_per_s=per_rank,
                    roofline=roof)
+        if rccl is not None:
+            if "one_rank_alone_samples_per_s" in rccl:
+                rccl["scaling_efficiency"] = (value / world) / rccl["one_rank_alone_samples_per_s"]
+            out["rccl"] = rccl
+        if inverse_leg is not None:
+            out["inverse"] = inverse_leg
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, gen, dev, args.cpu_samples)
+            out["cpu_baseline"] = cpu_baseline(args.workload, gen, dev, args.cpu_samples, args.kl_batch)
         if exact is not None:
             out["exact_f32_mode"] = exact
         if cfg2 is not None:

@@ -154,13 +154,70 @@ def cdf_block(block, x, inverse):
     return y, -logp(y).sum(dim=-1, keepdim=True)
 
 
-def run_block(block, xs, inverse):
+def ic2xyz_torch(ic, bonds, angles, torsions, zfix):
+    """IC -> xyz with torch ops, differentiable by autograd: the op chain of RelativeInternalCoordinateTransformation._inverse /
+    MixedCoordinateTransformation._inverse (nn/flow/crd_transform/ic.py:435-513, 862-884; ic2xyz_deriv ic_helper.py:372-452;
+    blackening pca.py:85-93), one vectorised step per dependency block of the Z-matrix like the reference.  Used by the CPU
+    KL-step baseline (the C oracle has no autograd)."""
+    rel = getattr(ic, "_rel_ic", ic)
+    B, n = bonds.shape[0], bonds.shape[1]
+    place = torch.as_tensor(np.asarray(rel._tables._host["place"]), dtype=torch.long)
+    fixed = torch.as_tensor(np.asarray(rel._tables._host["fixed"]), dtype=torch.long)
+    dl = torch.zeros(B, 1, dtype=bonds.dtype)
+    if hasattr(ic, "_whiten"):
+        w = ic._whiten
+        xf = zfix @ w.Tblacken.to(zfix) + w.X0mean.to(zfix)
+        dl = dl - w.jacobian_xz.to(zfix)
+    else:
+        xf = zfix
+    eps = float(rel._eps)
+    if rel._normalize_angles:
+        angles = angles * np.pi
+        torsions = torsions * (2 * np.pi) - np.pi
+        dl = dl + n * (np.log(np.pi) + np.log(2 * np.pi))
+    pos = torch.zeros(B, n + len(fixed), 3, dtype=bonds.dtype)
+    pos[:, fixed] = xf.reshape(B, -1, 3)
+    start = 0
+    for blk in rel._z_blocks:
+        rows = place[start:start + len(blk)]
+        start += len(blk)
+        at, i1, i2, i3, zr = rows[:, 0], rows[:, 1], rows[:, 2], rows[:, 3], rows[:, 4]
+        p1, p2, p3 = pos[:, i1], pos[:, i2], pos[:, i3]
+        d, a, t = bonds[:, zr, None], angles[:, zr, None], torsions[:, zr, None]
+        v1, v2 = p1 - p2, p1 - p3
+        nv = torch.cross(v1, v2, dim=-1)
+        nn = torch.cross(v1, nv, dim=-1)
+        nh = nv / nv.norm(dim=-1, keepdim=True).clamp_min(eps)
+        nnh = nn / nn.norm(dim=-1, keepdim=True).clamp_min(eps)
+        v3 = -torch.sin(t) * nh + torch.cos(t) * nnh
+        v3n = v3.norm(dim=-1, keepdim=True).clamp_min(eps)
+        v3h = v3 / v3n
+        v1h = v1 / v1.norm(dim=-1, keepdim=True).clamp_min(eps)
+        new = p1 + v3h * d * torch.sin(a) - v1h * d * torch.cos(a)
+        Jd = v3h * torch.sin(a) - v1h * torch.cos(a)
+        Ja = v3h * d * torch.cos(a) + v1h * d * torch.sin(a)
+        Jt3 = -torch.cos(t) * nh - torch.sin(t) * nnh
+        Jt = (d * torch.sin(a) / v3n) * (Jt3 - v3h * (v3h * Jt3).sum(-1, keepdim=True))
+        J = torch.stack([Jd, Ja, Jt], dim=-1)
+        det = (torch.cross(J[..., 0, :], J[..., 1, :], dim=-1) * J[..., 2, :]).sum(-1)
+        dl = dl + torch.log(det.abs()).sum(-1, keepdim=True)
+        pos = pos.clone()
+        pos[:, at] = new
+    return pos.reshape(B, -1), dl
+
+
+def run_block(block, xs, inverse, grad=False):
     """xs: list of torch CPU tensors -> (list, dlogp [B,1])"""
+    if grad and not inverse and _name(block) in ("MixedCoordinateTransformation", "RelativeInternalCoordinateTransformation"):
+        raise NotImplementedError("differentiable xyz -> IC is not restated (the KL step only needs IC -> xyz)")
+    if grad and inverse and _name(block) in ("MixedCoordinateTransformation", "RelativeInternalCoordinateTransformation"):
+        x, dl = ic2xyz_torch(block, *xs)
+        return [x], dl
     n = _name(block)
     if n == "SequentialFlow":
-        return run_flow(block, xs, inverse)
+        return run_flow(block, xs, inverse, grad=grad)
     if n == "InverseFlow":
-        return run_block(block._delegate, xs, not inverse)
+        return run_block(block._delegate, xs, not inverse, grad=grad)
     if n == "CouplingFlow":
         cond = torch.cat([xs[i] for i in block.cond_indices], dim=-1)
         y = torch.cat([xs[i] for i in block.transformed_indices], dim=-1)
@@ -176,7 +233,7 @@ def run_block(block, xs, inverse):
         take = list(block._out_indices if inverse else block._indices)
         put = list(block._indices if inverse else block._out_indices)
         rest = [x for i, x in enumerate(xs) if i not in take]
-        ys, dl = run_block(block._flow, [xs[i] for i in take], inverse)
+        ys, dl = run_block(block._flow, [xs[i] for i in take], inverse, grad=grad)
         for k in np.argsort(put):
             rest.insert(put[k], ys[k])
         return rest, dl
@@ -189,12 +246,13 @@ def run_block(block, xs, inverse):
     return [torch.as_tensor(np.asarray(y)) for y in ys], torch.as_tensor(np.asarray(dl))
 
 
-def run_flow(flow, xs, inverse=False):
+def run_flow(flow, xs, inverse=False, grad=False):
+    """``grad=True``: build the autograd graph (conditioner parameters that require gradients; sampling direction only)"""
     xs = list(xs)
     blocks = list(flow._blocks)[::-1] if inverse else list(flow._blocks)
     total = 0.0
-    with torch.no_grad():
+    with torch.set_grad_enabled(bool(grad)):
         for block in blocks:
-            xs, dl = run_block(block, xs, inverse)
+            xs, dl = run_block(block, xs, inverse, grad=grad)
             total = total + dl
     return xs, total
