@@ -587,7 +587,7 @@ def main():
             def kl_step():
                 opt.zero_grad()
                 *x, dlogp = gen.flow(*zk)
-                loss = dp.global_mean(gen._target.energy(*x) - dlogp, drop_nonfinite=True)
+                loss = dp.global_kl_mean(gen._target, x, dlogp, drop_nonfinite=True)      # loss sums inside the target-energy kernel
                 opt.backward(loss)                     # loss.backward() with the weight gradients accumulated straight into the bucket
                 opt.allreduce_gradients()              # ONE collective on the bucket
                 opt.step()                             # skips itself on the device if a gradient is NaN

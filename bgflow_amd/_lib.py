@@ -82,6 +82,9 @@ _SIGNATURES = {
     "bgk_column_sum": (ctypes.c_int, [vp, i64, i64, i32, vp, i32, vp, vp]),
     "bgk_normal_energy": (ctypes.c_int, [vp, i64, vp, i32, i64, f64, f64, vp, vp]),
     "bgk_normal_energy_backward": (ctypes.c_int, [vp, i64, vp, i32, i64, f64, vp, vp, i64, vp]),
+    "bgk_energy_fields": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i32, i64, f64, f64, f64, vp, vp, i32, vp, i32, vp, vp]),
+    "bgk_energy_fields_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i32, i64, f64, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "bgk_philox_fields": (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint32, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, f64, i64, vp, vp]),
     "bgk_grad_nan_flag": (ctypes.c_int, [vp, i64, vp, vp]),
     "bgk_adam_step": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp, vp]),
     "bgk_dense_weight_grad_workspace": (i64, [i64, i32, i32]),

@@ -104,6 +104,15 @@ class BoltzmannGenerator(Energy, Sampler):
     def kldiv(self, n_samples, temperature=1.0):
         return unnormalized_kl_div(self._prior, self._flow, self._target, n_samples, temperature=temperature)
 
+    def kldiv_mean(self, n_samples, temperature=1.0, drop_nonfinite=False):
+        """mean of ``kldiv`` over the batch (and over all data-parallel ranks): the scalar KLTrainer minimises (trainers.py:158-163),
+        with the per-sample loss and its sum formed inside the target-energy kernel (no [B, 1] loss tensor, one all-reduce of a
+        ready 2-vector).  Not in the reference API: ``kldiv(n).mean()`` is the same number."""
+        from . import dp
+        z = pack_tensor_in_tuple(self._prior.sample(n_samples, temperature=temperature))
+        *x, dlogp = self._flow(*z, temperature=temperature)
+        return dp.global_kl_mean(self._target, x, dlogp, temperature=temperature, drop_nonfinite=drop_nonfinite)
+
     def log_weights(self, *x, temperature=1.0, normalize=True):
         return log_weights(*x, prior=self._prior, flow=self._flow, target=self._target,
                            temperature=temperature, normalize=normalize)

@@ -13,7 +13,7 @@ from .utils import pack_tensor_in_tuple
 
 __all__ = [
     "Energy", "Sampler", "NormalDistribution", "TruncatedNormalDistribution", "SloppyUniform",
-    "UniformDistribution", "ProductDistribution", "DoubleWellEnergy",
+    "UniformDistribution", "ProductDistribution", "DoubleWellEnergy", "kernel_energy", "kl_loss_sums", "philox_sample",
 ]
 
 
@@ -83,46 +83,196 @@ class Sampler(torch.nn.Module):
         return self._sample_with_temperature(n_samples, temperature, *args, **kwargs)
 
 
-class _NormalEnergyFn(torch.autograd.Function):
-    """u(x) = 0.5 |x - mean|^2 / T + log Z on bgk_normal_energy; gradient w.r.t. x on bgk_normal_energy_backward"""
+# ---- kernel-backed energies (csrc/bgk_energy.hip) ---------------------------------------------------------------------------
+# A "field" = one tensor of a sample with an energy of one of the kernel's kinds: (kind, mean tensor or None, (a, b, c), constant
+# added INSIDE the temperature division).  A distribution that can describe itself that way implements ``_kernel_fields()``.
+def _fields_args(specs, xs):
+    """ctypes tables for bgk_energy_fields(_backward): specs = [(kind, param, (a, b, c), c_in)], xs = matching [B, d] f32 HIP tensors"""
+    import ctypes
+    from . import _lib
+    n = len(specs)
+    rows = [_lib.rowmajor(x) for x in xs]
+    params = [None if sp[1] is None else sp[1].detach().to(device=xs[0].device, dtype=torch.float32).contiguous() for sp in specs]
+    X = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in rows])
+    LD = (ctypes.c_int64 * n)(*[ld for _, ld in rows])
+    D = (ctypes.c_int32 * n)(*[t.shape[1] for t, _ in rows])
+    K = (ctypes.c_int32 * n)(*[sp[0] for sp in specs])
+    P = (ctypes.c_void_p * n)(*[None if p is None else p.data_ptr() for p in params])
+    C = (ctypes.c_float * (3 * n))(*[float(v) for sp in specs for v in sp[2]])
+    return (X, LD, D, K, P, C, n), (rows, params)
+
+
+def _fields_ok(xs, dims):
+    return (len(xs) == len(dims) and all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+                                         and x.shape[1] == d and x.shape[0] == xs[0].shape[0] for x, d in zip(xs, dims))
+            and xs[0].shape[0] > 0 and len(xs) <= 8)
+
+
+class _EnergyFieldsFn(torch.autograd.Function):
+    """u = (sum_f e_f(x_f) + c_in) / T + c_out on bgk_energy_fields; gradients of all fields in one launch of
+    bgk_energy_fields_backward"""
 
     @staticmethod
-    def forward(ctx, x, mean, temperature, log_z):
+    def forward(ctx, specs, temperature, c_in, c_out, *xs):
         from . import _lib
-        x2, ldx = _lib.rowmajor(x)
-        if mean is not None:
-            mean = mean.detach().to(device=x.device).contiguous()
-        B, d = x2.shape
-        u = torch.empty(B, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            st = _lib.lib().bgk_normal_energy(_lib.ptr(x2), ldx, _lib.ptr(mean), d, B, temperature, log_z, _lib.ptr(u),
-                                              _lib.stream_ptr(x.device))
-        _lib.check(st, "bgk_normal_energy")
-        ctx.save_for_backward(x2, mean if mean is not None else x2.new_empty(0))
-        ctx.cfg = (ldx, mean is not None, temperature)
+        args, keep = _fields_args(specs, xs)
+        B, dev = xs[0].shape[0], xs[0].device
+        u = torch.empty(B, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_energy_fields(*args, B, float(temperature), float(c_in), float(c_out), _lib.ptr(u), None, 0, None, 0, None,
+                                              _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_energy_fields")
+        ctx.save_for_backward(*[t for t, _ in keep[0]])
+        ctx.cfg = (specs, float(temperature))
         return u[:, None]
 
     @staticmethod
     def backward(ctx, g_u):
+        import ctypes
         from . import _lib
-        x2, mean = ctx.saved_tensors
-        ldx, has_mean, temperature = ctx.cfg
-        B, d = x2.shape
+        specs, temperature = ctx.cfg
+        xs = ctx.saved_tensors
+        args, keep = _fields_args(specs, xs)
+        B, dev, n = xs[0].shape[0], xs[0].device, len(xs)
         g = g_u.reshape(-1).to(torch.float32).contiguous()
-        g_x = torch.empty((B, d), dtype=torch.float32, device=x2.device)
-        with torch.cuda.device(x2.device):
-            st = _lib.lib().bgk_normal_energy_backward(_lib.ptr(x2), ldx, _lib.ptr(mean) if has_mean else None, d, B, temperature,
-                                                       _lib.ptr(g), _lib.ptr(g_x), d, _lib.stream_ptr(x2.device))
-        _lib.check(st, "bgk_normal_energy_backward")
-        return g_x, None, None, None
+        need = ctx.needs_input_grad[4:]
+        gx = [torch.empty_like(x, memory_format=torch.contiguous_format) if nd and sp[0] != 2 else None for x, nd, sp in zip(xs, need, specs)]
+        G = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in gx])
+        LG = (ctypes.c_int64 * n)(*[0 if t is None else t.shape[1] for t in gx])
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_energy_fields_backward(*args, B, temperature, _lib.ptr(g), None, None, None, 0, None, G, LG,
+                                                       _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_energy_fields_backward")
+        return (None, None, None, None, *[t if t is not None else (torch.zeros_like(x) if nd else None) for t, x, nd in zip(gx, xs, need)])
 
 
-class NormalDistribution(Energy, Sampler):
+class _KLSumsFn(torch.autograd.Function):
+    """[sum_b (u(x_b) - dlogp_b), number of samples kept] (f64 [2]) with the loss partial sums formed by the energy kernel itself;
+    backward: one launch for the gradients of every field and of dlogp"""
+
+    @staticmethod
+    def forward(ctx, specs, temperature, c_in, c_out, drop_nonfinite, dlogp, *xs):
+        from . import _lib
+        args, keep = _fields_args(specs, xs)
+        B, dev = xs[0].shape[0], xs[0].device
+        u = torch.empty(B, dtype=torch.float32, device=dev)
+        dl = dlogp.detach().reshape(-1).to(torch.float32).contiguous()
+        nblk = 2048
+        partial = torch.empty((nblk, 2), dtype=torch.float32, device=dev)
+        sums = torch.empty(2, dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_energy_fields(*args, B, float(temperature), float(c_in), float(c_out), _lib.ptr(u), _lib.ptr(dl),
+                                              int(bool(drop_nonfinite)), _lib.ptr(partial), nblk, _lib.ptr(sums), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_energy_fields")
+        ctx.save_for_backward(u, dl, *[t for t, _ in keep[0]])
+        ctx.cfg = (specs, float(temperature), bool(drop_nonfinite), dlogp.shape)
+        ctx.mark_non_differentiable(u)
+        return sums, u[:, None]
+
+    @staticmethod
+    def backward(ctx, g_sums, _g_u):
+        import ctypes
+        from . import _lib
+        specs, temperature, drop, dl_shape = ctx.cfg
+        u, dl, *xs = ctx.saved_tensors
+        args, keep = _fields_args(specs, xs)
+        B, dev, n = xs[0].shape[0], xs[0].device, len(xs)
+        gs = g_sums[0:1].to(torch.float32).contiguous()
+        need = ctx.needs_input_grad[6:]
+        gx = [torch.empty_like(x, memory_format=torch.contiguous_format) if nd and sp[0] != 2 else None for x, nd, sp in zip(xs, need, specs)]
+        g_dl = torch.empty(B, dtype=torch.float32, device=dev) if ctx.needs_input_grad[5] else None
+        G = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in gx])
+        LG = (ctypes.c_int64 * n)(*[0 if t is None else t.shape[1] for t in gx])
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_energy_fields_backward(*args, B, temperature, None, _lib.ptr(gs), _lib.ptr(u), _lib.ptr(dl), int(drop),
+                                                       _lib.ptr(g_dl), G, LG, _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_energy_fields_backward")
+        return (None, None, None, None, None, None if g_dl is None else g_dl.reshape(dl_shape),
+                *[t if t is not None else (torch.zeros_like(x) if nd else None) for t, x, nd in zip(gx, xs, need)])
+
+
+def kernel_energy(dist, xs, temperature=1.0):
+    """``dist.energy(*xs, temperature)`` as ONE launch when ``dist`` can describe itself by kernel fields and the inputs are 2-d f32
+    HIP tensors, else None"""
+    describe = getattr(dist, "_kernel_fields", None)
+    plan = describe(temperature) if describe is not None else None
+    if plan is None:
+        return None
+    specs, dims, c_in, c_out, t_eff = plan
+    if not (_fields_ok(xs, dims) and isinstance(temperature, (int, float)) and temperature > 0):
+        return None
+    return _EnergyFieldsFn.apply(specs, t_eff, c_in, c_out, *xs)
+
+
+def kl_loss_sums(target, xs, dlogp, temperature=1.0, drop_nonfinite=False):
+    """(sums, u): sums = f64 [2] = [sum_b (u_target(x_b) - dlogp_b), samples kept] with autograd to x and dlogp, formed inside the
+    target-energy kernel (no per-sample loss tensor, no isfinite / where / sum launches); None if the target has no kernel fields"""
+    describe = getattr(target, "_kernel_fields", None)
+    plan = describe(temperature) if describe is not None else None
+    if plan is None:
+        return None
+    specs, dims, c_in, c_out, t_eff = plan
+    if not (_fields_ok(xs, dims) and isinstance(temperature, (int, float)) and temperature > 0 and torch.is_tensor(dlogp)
+            and dlogp.is_cuda and dlogp.numel() == xs[0].shape[0]):
+        return None
+    return _KLSumsFn.apply(specs, t_eff, c_in, c_out, bool(drop_nonfinite), dlogp, *xs)
+
+
+# ---- counter-based prior sampling (csrc/bgk_philox.hip), opt-in -----------------------------------------------------------------
+def philox_sample(fields, n_samples, device, seed, offset, row0=0, want_energy=False, c_out=0.0):
+    """fields = [(kind, d, p0, p1, scale, e_const)] (kind 0 uniform on [p0, p1], 1 normal p0 + scale n) -> (tensors, energy or None)"""
+    import ctypes
+    from . import _lib
+    n = len(fields)
+    outs = [torch.empty((n_samples, f[1]), dtype=torch.float32, device=device) for f in fields]
+    if n_samples == 0:
+        return outs, (torch.zeros((0, 1), dtype=torch.float32, device=device) if want_energy else None)
+    prm = [[None if t is None else t.detach().to(device=device, dtype=torch.float32).contiguous() for t in (f[2], f[3])] for f in fields]
+    O = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+    LD = (ctypes.c_int64 * n)(*[t.shape[1] for t in outs])
+    D = (ctypes.c_int32 * n)(*[f[1] for f in fields])
+    K = (ctypes.c_int32 * n)(*[f[0] for f in fields])
+    P0 = (ctypes.c_void_p * n)(*[None if p[0] is None else p[0].data_ptr() for p in prm])
+    P1 = (ctypes.c_void_p * n)(*[None if p[1] is None else p[1].data_ptr() for p in prm])
+    SC = (ctypes.c_float * n)(*[float(f[4]) for f in fields])
+    EC = (ctypes.c_float * n)(*[float(f[5]) for f in fields])
+    energy = torch.empty(n_samples, dtype=torch.float32, device=device) if want_energy else None
+    with torch.cuda.device(device):
+        st = _lib.lib().bgk_philox_fields(int(seed) & (2 ** 64 - 1), int(offset) & 0xffffffff, int(row0), n, O, LD, D, K, P0, P1, SC, EC,
+                                          float(c_out), n_samples, _lib.ptr(energy), _lib.stream_ptr(device))
+    _lib.check(st, "bgk_philox_fields")
+    return outs, (None if energy is None else energy[:, None])
+
+
+class _FusedSampling:
+    """Opt-in (``sample_fused=True``) sampling on bgk_philox_fields: seed = ``torch.initial_seed()`` (so ``torch.manual_seed``
+    still selects the stream) mixed with the data-parallel rank, offset = a per-object call counter.  The prior energy of the
+    sample comes out of the same launch and is handed back by ``energy`` when it is asked about exactly these tensors."""
+    sample_fused = False
+
+    def _fused_sample(self, fields, n_samples, device, temperature, c_out=0.0):
+        from . import dp
+        off = self.__dict__.get("_philox_calls", 0)
+        self.__dict__["_philox_calls"] = off + 1
+        outs, energy = philox_sample(fields, n_samples, device, dp.rank_seed(torch.initial_seed()), off, want_energy=True, c_out=c_out)
+        self.__dict__["_philox_last"] = (tuple(id(t) for t in outs), float(temperature), energy, outs)
+        return outs
+
+    def _fused_energy(self, xs, temperature):
+        last = self.__dict__.get("_philox_last")
+        if last is not None and last[0] == tuple(id(t) for t in xs) and last[1] == float(temperature):
+            return last[2]
+        return None
+
+
+class NormalDistribution(Energy, Sampler, _FusedSampling):
     """Isotropic (optionally shifted) normal; ``cov`` support is limited to diagonalisable
-    covariances like the reference (normal.py:17-92)."""
+    covariances like the reference (normal.py:17-92).  ``sample_fused=True`` (not in the reference): samples come from the
+    counter-based kernel generator instead of ``torch.randn``."""
 
-    def __init__(self, dim, mean=None, cov=None):
+    def __init__(self, dim, mean=None, cov=None, sample_fused=False):
         super().__init__(dim=dim)
+        self.sample_fused = sample_fused
         self._has_mean = mean is not None
         if self._has_mean:
             assert len(mean.shape) == 1 and mean.shape[-1] == self.dim
@@ -149,12 +299,20 @@ class NormalDistribution(Energy, Sampler):
             log_z = log_z + 0.5 * self._log_diag.sum()
         return log_z
 
+    def _kernel_fields(self, temperature=1.0):
+        """(specs, dims, c_in, c_out, T): u = 0.5 |x - mean|^2 / T + d / 2 log(2 pi T)"""
+        if self._has_cov or self._mean.dtype != torch.float32 or not isinstance(temperature, (int, float)) or temperature <= 0:
+            return None
+        return ([(0, self._mean if self._has_mean else None, (0.0, 0.0, 0.0), 0.0)], [self.dim], 0.0,
+                float(self.dim / 2 * np.log(2 * np.pi * temperature)), float(temperature))
+
     def energy(self, x, temperature=1.0):
-        if (not self._has_cov and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and self._mean.dtype == torch.float32
-                and isinstance(temperature, (int, float)) and temperature > 0 and x.shape[0] > 0):
-            # one launch (bgk_normal_energy) instead of sub / div / pow / sum / add, one for the gradient instead of five
-            mean = self._mean if self._has_mean else None
-            return _NormalEnergyFn.apply(x, mean, float(temperature), float(self.dim / 2 * np.log(2 * np.pi * temperature)))
+        cached = self._fused_energy((x,), temperature) if isinstance(temperature, (int, float)) else None
+        if cached is not None:
+            return cached
+        fast = kernel_energy(self, (x,), temperature) if torch.is_tensor(x) and x.dim() == 2 else None
+        if fast is not None:           # one launch (bgk_energy_fields) instead of sub / div / pow / sum / add, one for the gradient
+            return fast
         if self._has_mean:
             x = x - self._mean
         if self._has_cov:
@@ -162,7 +320,18 @@ class NormalDistribution(Energy, Sampler):
         x = x / (temperature ** 0.5)
         return 0.5 * x.pow(2).sum(dim=-1, keepdim=True) + self._log_Z(temperature)
 
+    def _philox_field(self, temperature=1.0):
+        """(kind, d, p0, p1, scale, e_const) of bgk_philox_fields for this prior at `temperature`, or None"""
+        if self._has_cov or self._mean.dtype != torch.float32 or not isinstance(temperature, (int, float)) or temperature <= 0:
+            return None
+        return (1, self.dim, self._mean if self._has_mean else None, None, float(temperature) ** 0.5,
+                float(self.dim / 2 * np.log(2 * np.pi * temperature)))
+
     def _sample_with_temperature(self, n_samples, temperature=1.0):
+        if self.sample_fused and self._mean.is_cuda:
+            field = self._philox_field(temperature)
+            if field is not None:
+                return self._fused_sample([field], n_samples, self._mean.device, temperature)[0]
         s = torch.randn(n_samples, self.dim, dtype=self._mean.dtype, device=self._mean.device)
         if self._has_cov:
             s = (s * torch.exp(0.5 * self._log_diag)) @ self._rot.t()
@@ -273,56 +442,125 @@ class SloppyUniform(torch.nn.Module):
         return self._uniform().sample(sample_shape)
 
 
-class UniformDistribution(Energy, Sampler):
-    """Independent uniform prior (distributions.py:100-117)."""
+class UniformDistribution(Energy, Sampler, _FusedSampling):
+    """Independent uniform prior (distributions.py:100-117).  ``sample_fused=True`` (not in the reference): samples from the
+    counter-based kernel generator."""
 
-    def __init__(self, low, high, tol=1e-5, validate_args=None, n_event_dims=1):
+    def __init__(self, low, high, tol=1e-5, validate_args=None, n_event_dims=1, sample_fused=False):
         super().__init__(dim=low.shape[-n_event_dims:] if n_event_dims > 0 else low.shape)
         self.uniform = SloppyUniform(low, high, validate_args, tol=tol)
+        self.sample_fused = sample_fused
+
+    def _const(self, d):
+        return torch.log(self.uniform.high - self.uniform.low).expand(d).sum()
 
     def _energy(self, x):
         # The reference evaluates -log_prob and, whenever a value lies outside the (tolerant) support, falls back to the energy
         # of a fresh in-support sample for the whole batch (distributions.py:108-114): in either case the result is the
         # constant sum_j log(high_j - low_j) -- finite by construction (never +inf), and no host-side support check is needed.
-        const = torch.log(self.uniform.high - self.uniform.low).expand(x.shape[-1:]).sum()
+        # A constant needs no kernel: the [B, 1] result is an expanded view of one device scalar (zero bytes moved).
+        const = self._const(x.shape[-1:])
         return const.expand(*x.shape[:-1], 1).to(x.dtype)
 
+    def _kernel_fields(self, temperature=1.0):
+        if len(self.event_shape) != 1 or not isinstance(temperature, (int, float)) or temperature <= 0:
+            return None
+        d = self.event_shape[0]
+        return ([(2, None, (float(self._const((d,))), 0.0, 0.0), 0.0)], [d], 0.0, 0.0, float(temperature))
+
+    def _philox_field(self, temperature=1.0):
+        if len(self.event_shape) != 1 or self.uniform.low.dtype != torch.float32:
+            return None
+        d = self.event_shape[0]
+        return (0, d, self.uniform.low.expand(d), self.uniform.high.expand(d), 1.0, float(self._const((d,))) / float(temperature))
+
     def _sample(self, n_samples):
+        if self.sample_fused and self.uniform.low.is_cuda:
+            field = self._philox_field()
+            if field is not None:
+                return self._fused_sample([field], n_samples, self.uniform.low.device, 1.0)[0]
         return self.uniform.sample(torch.Size([n_samples]))
 
     def _sample_with_temperature(self, n_samples, temperature):
         return self._sample(n_samples)
 
 
-class ProductDistribution(Energy, Sampler):
-    """Independent product of distributions over several tensors (product.py:13-117)."""
+class ProductDistribution(Energy, Sampler, _FusedSampling):
+    """Independent product of distributions over several tensors (product.py:13-117).  With kernel-describable components (normal
+    without cov, uniform, double well) the energy of all tensors is ONE launch (bgk_energy_fields); ``sample_fused=True`` (not in
+    the reference) draws all tensors and the prior energy in one launch of the counter-based generator."""
 
-    def __init__(self, components, cat_dim=None):
+    def __init__(self, components, cat_dim=None, sample_fused=False):
         shapes = [c.event_shapes[0] if cat_dim is None else c.event_shapes[0] for c in components]
         super().__init__(dim=shapes if cat_dim is None else [sum(s[0] for s in shapes)])
         self._components = torch.nn.ModuleList(components)
         self._cat_dim = cat_dim
         self._lengths = [s[0] for s in shapes]
+        self.sample_fused = sample_fused
+
+    def _kernel_fields(self, temperature=1.0):
+        """the components' fields; product.py:36-44 + energy/base.py:124-146: every component at T = 1 (its own log Z included),
+        the SUM divided by the temperature"""
+        if self._cat_dim is not None or not isinstance(temperature, (int, float)) or temperature <= 0:
+            return None
+        specs, dims, c_in = [], [], 0.0
+        for c in self._components:
+            describe = getattr(c, "_kernel_fields", None)
+            plan = describe(1.0) if describe is not None else None
+            if plan is None or len(plan[0]) != 1:
+                return None
+            specs.append(plan[0][0]); dims.append(plan[1][0])
+            c_in += plan[2] + plan[3]                       # the component's constants belong inside the division by T
+        return specs, dims, c_in, 0.0, float(temperature)
 
     def energy(self, *xs, temperature=1.0):
         if self._cat_dim is not None:
             xs = torch.split(xs[0], self._lengths, dim=self._cat_dim)
+        cached = self._fused_energy(xs, temperature) if isinstance(temperature, (int, float)) else None
+        if cached is not None:
+            return cached
+        fast = kernel_energy(self, xs, temperature)
+        if fast is not None:
+            return fast
         # like the reference (product.py:36-44 + energy/base.py:124-146): the components are evaluated at T = 1 and their SUM is
         # divided by the temperature
         es = [c.energy(x) for c, x in zip(self._components, xs)]
         return sum(es[1:], es[0]) / temperature
 
     def sample(self, n_samples, temperature=1.0):
+        if self.sample_fused and self._cat_dim is None and isinstance(temperature, (int, float)):
+            fields = [getattr(c, "_philox_field", lambda t: None)(temperature) for c in self._components]
+            dev = next((b.device for b in self.buffers()), None)
+            if all(f is not None for f in fields) and dev is not None and dev.type == "cuda" and len(fields) <= 8:
+                # the energy the launch reports = product energy of the sample: sum_f [0.5 n^2 + log Z_f(1) / T] (uniform: const / T)
+                fixed = []
+                for f, c in zip(fields, self._components):
+                    if f[0] == 1:
+                        f = (*f[:5], float(c.dim / 2 * np.log(2 * np.pi)) / float(temperature))
+                    fixed.append(f)
+                return tuple(self._fused_sample(fixed, n_samples, dev, temperature))
         parts = tuple(c.sample(n_samples, temperature=temperature) for c in self._components)
         return torch.cat(parts, dim=self._cat_dim) if self._cat_dim is not None else parts
 
 
 class DoubleWellEnergy(Energy):
-    """u(x) = a x0 + b x0^2 + c x0^4 + 0.5 |x_rest|^2 (energy/double_well.py:10-22)."""
+    """u(x) = a x0 + b x0^2 + c x0^4 + 0.5 |x_rest|^2 (energy/double_well.py:10-22); one launch forward and one backward on
+    bgk_energy_fields for 2-d f32 HIP inputs (cfg 2's target: the KL step has no aten energy ops left)."""
 
     def __init__(self, dim, a=0, b=-4.0, c=1.0):
         super().__init__(dim)
         self._a, self._b, self._c = a, b, c
+
+    def _kernel_fields(self, temperature=1.0):
+        if not isinstance(temperature, (int, float)) or temperature <= 0:
+            return None
+        return ([(1, None, (float(self._a), float(self._b), float(self._c)), 0.0)], [self.dim], 0.0, 0.0, float(temperature))
+
+    def energy(self, *xs, temperature=1.0, **kwargs):
+        fast = kernel_energy(self, xs, temperature) if not kwargs else None
+        if fast is not None:
+            return fast
+        return super().energy(*xs, temperature=temperature, **kwargs)
 
     def _energy(self, x):
         d = x[..., [0]]

@@ -11,7 +11,8 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["init_from_env", "is_distributed", "shard_size", "global_mean", "allreduce_gradients_", "rank_seed",
+__all__ = ["init_from_env", "is_distributed", "shard_size", "global_mean", "global_mean_from_sums", "global_kl_mean",
+           "allreduce_gradients_", "rank_seed",
            "global_logsumexp", "global_normalized_log_weights", "global_effective_sample_size"]
 
 
@@ -73,6 +74,29 @@ def global_mean(per_sample_loss, drop_nonfinite=False):
     mean_value = (stats[0] / n_global).to(local_sum.dtype)
     # value = global mean; gradient flows through the local sum only
     return mean_value + (local_sum - local_sum.detach()) / n_global.to(local_sum.dtype)
+
+
+def global_mean_from_sums(sums):
+    """Mean over ALL ranks from a local f64 pair [sum of the per-sample losses, number of samples kept] (what the target-energy
+    kernel writes, distributions.kl_loss_sums): ONE all-reduce of the pair itself; differentiable through the local sum (each rank's
+    gradient is its own share 1 / n_global)."""
+    local_sum, n_local = sums[0], sums[1]
+    if not is_distributed():
+        return (local_sum / n_local.detach()).to(torch.float32)
+    stats = sums.detach().clone()
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    n_global = stats[1]
+    return ((stats[0] + (local_sum - local_sum.detach())) / n_global).to(torch.float32)
+
+
+def global_kl_mean(target, xs, dlogp, temperature=1.0, drop_nonfinite=False):
+    """mean over all ranks of the KL integrand u_target(x) - dlogp (bg.py:13-17): loss sums inside the target-energy kernel when the
+    target has kernel fields, else ``global_mean`` of the per-sample tensor"""
+    from .distributions import kl_loss_sums
+    res = kl_loss_sums(target, tuple(xs), dlogp, temperature=temperature, drop_nonfinite=drop_nonfinite)
+    if res is None:
+        return global_mean(target.energy(*xs, temperature=temperature) - dlogp, drop_nonfinite=drop_nonfinite)
+    return global_mean_from_sums(res[0])
 
 
 def allreduce_gradients_(parameters):

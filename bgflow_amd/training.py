@@ -291,7 +291,10 @@ class KLTrainer(object):
             self.optim.zero_grad()
             reports = []
             if self.train_energy:
-                kll = self._mean(self.bg.kldiv(batchsize, temperature=temperature))
+                if hasattr(self.bg, "kldiv_mean"):      # loss sums inside the target-energy kernel (same value as kldiv(...).mean())
+                    kll = self.bg.kldiv_mean(batchsize, temperature=temperature)
+                else:
+                    kll = self._mean(self.bg.kldiv(batchsize, temperature=temperature))
                 reports.append(kll)
                 if w_energy > 0:
                     with direct():

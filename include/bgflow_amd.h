@@ -412,6 +412,41 @@ int bgk_normal_energy(const float* x, int64_t ldx, const float* mean, int32_t d,
 int bgk_normal_energy_backward(const float* x, int64_t ldx, const float* mean, int32_t d, int64_t B,
                                double temperature, const float* g_u, float* g_x, int64_t ldg, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Priors and targets around the flow, one launch over all tensors of a sample.
+ * bgk_energy_fields: u[b] = (sum_f e_f(x_f[b]) + c_in) / temperature + c_out over n_fields <= BGK_MAX_ENERGY_FIELDS tensors
+ *   (HOST arrays x / ldx / d / kind / param / coef[3 n_fields] of device pointers, row strides, widths, ...):
+ *   kind 0  0.5 sum_j (x_j - param_j)^2            NormalDistribution without cov (distribution/normal.py:61-72; param = mean or NULL)
+ *   kind 1  a x_0 + b x_0^2 + c x_0^4 + 0.5 sum_{j>=1} x_j^2   DoubleWellEnergy (distribution/energy/double_well.py:17-22; coef = a, b, c)
+ *   kind 2  the constant coef[0]                    UniformDistribution (distribution/distributions.py:100-117); x not read
+ *   ProductEnergy / ProductDistribution (distribution/product.py:13-117) = the list of its components' fields.
+ *   loss_sums != NULL (needs dlogp [B], workspace partial [nblk, 2] floats): additionally the KL integrand u - dlogp (bg.py:13-17) is
+ *   summed over the batch, loss_sums[0] = sum, loss_sums[1] = number of samples kept (non-finite ones dropped if drop_nonfinite),
+ *   both double, fixed summation order -- what dp.global_mean all-reduces.
+ * bgk_energy_fields_backward: g_x_f = g_row (de_f / dx) / temperature for every field with g_x[f] != NULL; g_row = g_u[b], or, in the
+ *   loss-sum form (g_u == NULL), g_scalar[0] for the kept samples, with g_dlogp[b] = -g_row.
+ * bgk_normal_energy(_backward): the single-field forms (ABI of round 2). */
+#define BGK_MAX_ENERGY_FIELDS 8
+int bgk_energy_fields(const float* const* x, const int64_t* ldx, const int32_t* d, const int32_t* kind,
+                      const float* const* param, const float* coef, int32_t n_fields, int64_t B,
+                      double temperature, double c_in, double c_out, float* u,
+                      const float* dlogp, int32_t drop_nonfinite, float* partial, int32_t nblk, double* loss_sums, void* stream);
+int bgk_energy_fields_backward(const float* const* x, const int64_t* ldx, const int32_t* d, const int32_t* kind,
+                               const float* const* param, const float* coef, int32_t n_fields, int64_t B,
+                               double temperature, const float* g_u,
+                               const float* g_scalar, const float* u, const float* dlogp, int32_t drop_nonfinite, float* g_dlogp,
+                               float* const* g_x, const int64_t* ldg, void* stream);
+
+/* Prior sampling in one launch from a counter-based generator (Philox4x32-10; counter = (global row, field, 4-column block, offset),
+ * key = seed: independent of launch geometry and of the sharding of a batch, row0 = first global row of this launch), replacing
+ * torch.randn / Uniform.sample + the shift / scale ops of NormalDistribution._sample_with_temperature (distribution/normal.py:74-92),
+ * UniformDistribution._sample (distributions.py:116-117) and ProductDistribution.sample (product.py:84-117); an opt-in path of the
+ * python priors (sample_fused=True).  kind 0: low + u (high - low) with p0 = low, p1 = high (NULL: 0 / 1); kind 1: p0 (mean or NULL) +
+ * scale * n.  energy != NULL: energy[b] = sum_f (0.5 sum_j n_j^2 [kind 1] + e_const[f]) + c_out = the prior energy of the sample. */
+int bgk_philox_fields(uint64_t seed, uint32_t offset, int64_t row0, int32_t n_fields, float* const* out, const int64_t* ldo,
+                      const int32_t* d, const int32_t* kind, const float* const* p0, const float* const* p1,
+                      const float* scale, const float* e_const, double c_out, int64_t B, float* energy, void* stream);
+
 /* Weight and bias gradients of the conditioner MLP [n_in, 128, 128, P] of one coupling layer (autograd of nn/dense.py:47-48 in
  * the training step: dW = g^T h, db = sum over the batch of g) from the tensors bgk_rqs_backward / bgk_dense_backward_dx wrote:
  *   (g_params [B, P], h1) -> gW2 [P, 128], gb2 [P];  (g_z1, h0) -> gW1 [128, 128], gb1 [128];

@@ -711,8 +711,56 @@ def g_cdf_flows():
     save("g_cdf_flows", **out)
 
 
+def g_energies():
+    """f-3: energies of the priors / targets around the flow and the importance-weight bookkeeping, from the reference classes:
+    DoubleWellEnergy (distribution/energy/double_well.py:10-22) incl. its force, NormalDistribution (normal.py:17-92),
+    UniformDistribution (distributions.py:100-117), ProductDistribution / ProductEnergy (product.py:13-117),
+    log_weights_given_latent / effective_sample_size (bg.py:54-74)."""
+    from bgflow.distribution.energy.double_well import DoubleWellEnergy
+    from bgflow.distribution.normal import NormalDistribution
+    from bgflow.distribution.distributions import UniformDistribution
+    from bgflow.distribution.product import ProductDistribution
+    from bgflow.bg import log_weights_given_latent, effective_sample_size
+    out = {}
+    B = 96
+    x64 = torch.tensor(rng_f32(901, B, 64, scale=1.5)).double()
+    for tag, kw in (("dw", {}), ("dw_abc", dict(a=0.7, b=-2.5, c=0.4))):
+        for dt, suffix in ((torch.float64, "64"), (torch.float32, "32")):
+            e = DoubleWellEnergy(64, **kw)
+            x = x64.to(dt)
+            out[f"{tag}_u{suffix}"] = e.energy(x).detach().numpy()
+            out[f"{tag}_uT{suffix}"] = e.energy(x, temperature=2.5).detach().numpy()
+            out[f"{tag}_force{suffix}"] = e.force(x.clone(), temperature=2.5).detach().numpy()
+    out["dw_x"] = x64.float().numpy()
+    mean = torch.tensor(rng_f32(902, 66, scale=0.3)).double()
+    y64 = torch.tensor(rng_f32(903, B, 66)).double()
+    a64 = torch.tensor(rng_f32(904, B, 66)).double()
+    un64 = torch.tensor(rng_f32(905, B, 17, uniform=True)).double()
+    low, high = torch.zeros(17).double(), torch.tensor(np.linspace(1.0, 3.0, 17).astype(np.float32)).double()   # f32-representable
+    un64 = (un64 * high).float().double()                      # the stored inputs are f32: use exactly those values in both precisions
+    for dt, suffix in ((torch.float64, "64"), (torch.float32, "32")):
+        comps = [NormalDistribution(66, mean=mean.to(dt)), NormalDistribution(66), UniformDistribution(low.to(dt), high.to(dt))]
+        prod = ProductDistribution(comps)
+        xs = (y64.to(dt), a64.to(dt), un64.to(dt))
+        out[f"norm_u{suffix}"] = comps[0].energy(xs[0], temperature=1.7).numpy()
+        out[f"unif_u{suffix}"] = comps[2].energy(xs[2]).numpy()
+        out[f"prod_u{suffix}"] = prod.energy(*xs).numpy()
+        out[f"prod_uT{suffix}"] = prod.energy(*xs, temperature=1.7).numpy()
+        # importance weights of a toy generator: latent z ~ N(0, 1), x = z (identity flow, dlogp = 0) against the shifted normal
+        prior, target = NormalDistribution(66), NormalDistribution(66, mean=mean.to(dt))
+        dl = torch.tensor(rng_f32(906, B, 1, scale=0.2)).to(dt)
+        lw = log_weights_given_latent(xs[0], xs[1], dl, prior, target, temperature=1.3, normalize=True)
+        out[f"logw{suffix}"] = lw.numpy()
+        out[f"ess{suffix}"] = effective_sample_size(lw).numpy()
+    out.update(norm_mean=mean.float().numpy(), prod_y=y64.float().numpy(), prod_a=a64.float().numpy(),
+               prod_un=un64.float().numpy(), unif_low=low.float().numpy(), unif_high=high.float().numpy(), logw_dl=dl.float().numpy())
+    save("g_energies", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rqs", "bins", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2", "cdfflows"]
+    which = sys.argv[1:] or ["rqs", "bins", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2", "cdfflows", "energies"]
+    if "energies" in which:
+        g_energies()
     if "rqs" in which:
         g_rqs_unit()
     if "bins" in which:

@@ -226,3 +226,183 @@ def test_envelope_warnings(hip_lib, dev):
             layer(*xs)
     msgs = [str(x.message) for x in w if "fused" in str(x.message)]
     assert len(msgs) == 1 and "(256, 256)" in msgs[0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# f-3: priors / targets / weights on kernels
+# ---------------------------------------------------------------------------------------------------
+def test_energy_kernels_vs_reference_goldens(hip_lib, golden, dev):
+    """DoubleWellEnergy, NormalDistribution, UniformDistribution, ProductDistribution energies (one launch each, bgk_energy_fields) and
+    the double-well force (bgk_energy_fields_backward) against values generated from the reference classes"""
+    import bgflow_amd as bg
+    G = golden("g_energies")
+    x = t(G["dw_x"], dev)
+    for tag, kw in (("dw", {}), ("dw_abc", dict(a=0.7, b=-2.5, c=0.4))):
+        e = bg.DoubleWellEnergy(64, **kw)
+        for key, T in (("_u", 1.0), ("_uT", 2.5)):
+            u = e.energy(x, temperature=T)
+            assert u.shape == (x.shape[0], 1)
+            scale = np.abs(G[tag + key + "64"]).max()
+            assert np.abs(u.cpu().numpy() - G[tag + key + "64"]).max() <= 3 * np.abs(G[tag + key + "32"] - G[tag + key + "64"]).max() + 2e-7 * scale
+        f = e.force(x.clone(), temperature=2.5)
+        np.testing.assert_allclose(f.cpu().numpy(), G[tag + "_force64"], rtol=2e-6, atol=2e-6)
+    mean = t(G["norm_mean"], dev)
+    comps = [bg.NormalDistribution(66, mean=mean), bg.NormalDistribution(66).to(dev),
+             bg.UniformDistribution(t(G["unif_low"], dev), t(G["unif_high"], dev))]
+    xs = tuple(t(G[k], dev) for k in ("prod_y", "prod_a", "prod_un"))
+    prod = bg.ProductDistribution(comps)
+    for got, key in ((comps[0].energy(xs[0], temperature=1.7), "norm_u"), (comps[2].energy(xs[2]), "unif_u"),
+                     (prod.energy(*xs), "prod_u"), (prod.energy(*xs, temperature=1.7), "prod_uT")):
+        ref64, ref32 = G[key + "64"], G[key + "32"]
+        assert np.abs(got.cpu().numpy() - ref64).max() <= 3 * np.abs(ref32 - ref64).max() + 3e-7 * np.abs(ref64).max(), key
+    # gradient of the product energy w.r.t. every tensor = autograd of the torch ops
+    xr = [v.clone().requires_grad_(True) for v in xs]
+    prod.energy(*xr, temperature=1.7).sum().backward()
+    xc = [v.detach().cpu().double().requires_grad_(True) for v in xs]
+    cpu = bg.ProductDistribution([bg.NormalDistribution(66, mean=mean.cpu().double()), bg.NormalDistribution(66).double(),
+                                  bg.UniformDistribution(torch.tensor(G["unif_low"]).double(), torch.tensor(G["unif_high"]).double())])
+    cpu.energy(*xc, temperature=1.7).sum().backward()
+    for a, b in zip(xr[:2], xc[:2]):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("d,B", [(512, 1000), (4000, 257), (66, 1 << 18)])
+def test_normal_energy_any_width(hip_lib, dev, d, B):
+    """the energy kernel stages rows in column chunks: widths far beyond one LDS tile (a 1300-atom Cartesian target) work"""
+    import bgflow_amd as bg
+    g = torch.Generator(device=dev).manual_seed(d)
+    x = torch.randn(B, d, device=dev, generator=g)
+    mean = torch.randn(d, device=dev, generator=g)
+    nd = bg.NormalDistribution(d, mean=mean)
+    u = nd.energy(x, temperature=1.3)
+    ref = 0.5 * ((x.double() - mean.double()) ** 2).sum(-1, keepdim=True) / 1.3 + d / 2 * np.log(2 * np.pi * 1.3)
+    assert float(((u.double() - ref).abs() / ref.abs()).max()) <= 2e-6
+
+
+def test_kl_loss_sums_in_the_energy_kernel(hip_lib, dev):
+    """[sum (u - dlogp), n] formed by the target-energy kernel == the torch formula, with and without dropped samples, and the
+    gradients to x and dlogp"""
+    import bgflow_amd as bg
+    from bgflow_amd import dp
+    from bgflow_amd.distributions import kl_loss_sums
+    g = torch.Generator(device=dev).manual_seed(3)
+    B = 70001
+    mean = torch.randn(66, device=dev, generator=g)
+    target = bg.NormalDistribution(66, mean=mean)
+    x = torch.randn(B, 66, device=dev, generator=g)
+    dl = torch.randn(B, 1, device=dev, generator=g) * 3
+    dl[5] = float("-inf"); dl[B - 1] = float("nan")
+    for drop in (True, False):
+        xr, dr = x.clone().requires_grad_(True), dl.clone().requires_grad_(True)
+        sums, u = kl_loss_sums(target, (xr,), dr, temperature=1.0, drop_nonfinite=drop)
+        loss = (0.5 * ((x.double() - mean.double()) ** 2).sum(-1, keepdim=True) + 33 * np.log(2 * np.pi)) - dl.double()
+        ok = torch.isfinite(loss) if drop else torch.ones_like(loss, dtype=torch.bool)
+        if drop:
+            assert float(sums[1]) == float(ok.sum())
+            assert abs(float(sums[0]) - float(loss[ok].sum())) <= 2e-6 * float(loss[ok].abs().sum())
+            mean_loss = dp.global_mean_from_sums(sums)
+            mean_loss.backward()
+            n = float(ok.sum())
+            gx_ref = torch.where(ok, (x - mean) / n, torch.zeros_like(x))
+            np.testing.assert_allclose(xr.grad.cpu().numpy(), gx_ref.cpu().numpy(), rtol=1e-5, atol=1e-9)
+            gd_ref = torch.where(ok, torch.full_like(dl, -1.0 / n), torch.zeros_like(dl))
+            np.testing.assert_allclose(dr.grad.cpu().numpy(), gd_ref.cpu().numpy(), rtol=1e-5, atol=1e-12)
+        else:
+            assert float(sums[1]) == B and not np.isfinite(float(sums[0]))
+    # BoltzmannGenerator.kldiv_mean == kldiv(...).mean() on the same samples
+    from bgflow_amd import configs
+    gen = configs.make_ala2_spline_generator(dev)
+    torch.manual_seed(7)
+    with torch.no_grad():
+        a = float(gen.kldiv_mean(4096, drop_nonfinite=True))
+        torch.manual_seed(7)
+        k = gen.kldiv(4096)
+        b = float(k[torch.isfinite(k)].mean())
+    assert abs(a - b) <= 1e-5 * abs(b)
+
+
+def test_fused_philox_prior_sampling(hip_lib, dev):
+    """opt-in `sample_fused=True`: all tensors of a ProductDistribution sample + the prior energy from one launch of the counter-based
+    generator; uniforms bit-exact against the numpy Philox restatement, normals to 2e-6; reproducible under torch.manual_seed"""
+    import bgflow_amd as bg
+    from oracle import philox
+    mean = torch.linspace(-1, 1, 66, device=dev)
+    low, high = torch.zeros(17, device=dev), torch.linspace(1.0, 3.0, 17, device=dev)
+    prior = bg.ProductDistribution([bg.UniformDistribution(low, high), bg.NormalDistribution(66, mean=mean), bg.NormalDistribution(9).to(dev)],
+                                   sample_fused=True)
+    torch.manual_seed(1234)
+    B = 5003
+    u, x, z = prior.sample(B, temperature=1.5)
+    assert u.shape == (B, 17) and x.shape == (B, 66) and z.shape == (B, 9)
+    seed = torch.initial_seed()
+    ru = philox.sample_field(seed, 0, 0, B, 17, 0)
+    assert np.array_equal(u.cpu().numpy(), (low.cpu().numpy() + ru * (high - low).cpu().numpy()).astype(np.float32))
+    rx = philox.sample_field(seed, 0, 1, B, 66, 1)
+    np.testing.assert_allclose(x.cpu().numpy(), mean.cpu().numpy() + np.sqrt(1.5) * rx, rtol=0, atol=4e-6)
+    rz = philox.sample_field(seed, 0, 2, B, 9, 1)
+    np.testing.assert_allclose(z.cpu().numpy(), np.sqrt(1.5) * rz, rtol=0, atol=4e-6)
+    # the energy that came out of the sampling launch == the energy evaluated on the tensors
+    e_fused = prior.energy(u, x, z, temperature=1.5)
+    prior._philox_last = None
+    e_eval = prior.energy(u, x, z, temperature=1.5)
+    np.testing.assert_allclose(e_fused.cpu().numpy(), e_eval.cpu().numpy(), rtol=3e-6, atol=1e-4)
+    # a second call advances the stream; the same seed reproduces it
+    u2, _, _ = prior.sample(B, temperature=1.5)
+    assert not torch.equal(u, u2)
+    prior2 = bg.ProductDistribution([bg.UniformDistribution(low, high), bg.NormalDistribution(66, mean=mean), bg.NormalDistribution(9).to(dev)],
+                                    sample_fused=True)
+    torch.manual_seed(1234)
+    u3, x3, z3 = prior2.sample(B, temperature=1.5)
+    assert torch.equal(u, u3) and torch.equal(x, x3) and torch.equal(z, z3)
+    # default priors are untouched: torch's generator
+    plain = bg.NormalDistribution(9).to(dev)
+    torch.manual_seed(5); a = plain.sample(100)
+    torch.manual_seed(5); b = torch.randn(100, 9, device=dev)
+    assert torch.equal(a, b)
+
+
+def test_flat_adam_step_count_checkpoint_and_direct_gradients(hip_lib, dev):
+    """advisor items: a step skipped for a NaN gradient does not advance Adam's time step; state_dict / load_state_dict carry the
+    moments; add_param_group is rejected; torch.autograd.grad through a fused training layer never touches .grad"""
+    from bgflow_amd.training import FlatAdam
+    from bgflow_amd import configs
+    torch.manual_seed(0)
+    pa = [torch.nn.Parameter(torch.randn(7, 5, device=dev)), torch.nn.Parameter(torch.randn(5, device=dev))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = FlatAdam(pa, lr=1e-2, betas=(0.9, 0.99)), torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99))
+    for it in range(5):
+        oa.zero_grad(); ob.zero_grad()
+        for ps in (pa, pb):
+            sum(((p - 0.1 * (i + 1)) ** 2).sum() for i, p in enumerate(ps)).backward()
+        if it == 2:                      # poisoned gradient: FlatAdam skips on the device, the reference loop would not call step()
+            pa[1].grad[0] = float("nan")
+            oa.step()
+            continue
+        oa.step(); ob.step()
+    assert oa.skipped_steps() == 1
+    for a, b in zip(pa, pb):             # four effective steps on both sides: same bias corrections
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=3e-6, atol=1e-7)
+    sd = oa.state_dict()
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oc = FlatAdam(pc, lr=1e-2, betas=(0.9, 0.99))
+    oc.load_state_dict(sd)
+    assert torch.equal(oc.exp_avg, oa.exp_avg) and torch.equal(oc.exp_avg_sq, oa.exp_avg_sq) and oc._step == oa._step and oc.skipped_steps() == 1
+    with pytest.raises(ValueError):
+        oa.add_param_group(dict(params=[torch.nn.Parameter(torch.zeros(2, device=dev))]))
+    # autograd.grad through the fused training forward: gradients are RETURNED, the bucket is not written
+    gen = configs.make_ala2_spline_generator(dev)
+    opt = FlatAdam([p for p in gen.flow.parameters()], lr=1e-5)
+    opt.zero_grad()
+    z = _prior("cfg3", 512, dev, seed=21)
+    *x, dl = gen.flow(*z)
+    w = gen.flow[0].transformer._params_net._layers[0].weight
+    (gw,) = torch.autograd.grad(dl.sum(), [w])
+    assert gw is not None and float(gw.abs().max()) > 0 and float(opt.grad.abs().max()) == 0.0
+    *x, dl = gen.flow(*z)
+    opt.backward(dl.sum())
+    off = 0
+    for p in opt._params:
+        if p is w:
+            break
+        off += p.numel()
+    np.testing.assert_allclose(opt.grad[off:off + w.numel()].view_as(w).cpu().numpy(), gw.cpu().numpy(), rtol=2e-5, atol=1e-6)

@@ -376,3 +376,47 @@ def test_torch_cpu_restatement_matches_reference_goldens(golden):
         e = np.abs(dli.numpy() - G["dlogp_inv32"]).reshape(-1)
         assert np.median(e) <= 1e-4 and np.quantile(e, 0.9) <= 1e-3 and e.max() <= 1e-3 * scale   # cdf maps: steep near the domain ends
         assert np.abs(torch.cat(list(zs), -1).numpy() - G["z_back32"]).max() <= 1e-4
+
+
+def test_philox_oracle_known_answers():
+    """oracle/philox.py against Random123's known-answer vectors for Philox4x32-10 (kat_vectors: counter / key all zero, all ones,
+    digits of pi): the generator of the opt-in fused prior sampler (csrc/bgk_philox.hip) is pinned before it is used as a checker"""
+    from oracle import philox
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox.philox4x32_10(ctr, key)
+        assert tuple(int(v) for v in got) == want
+    u = philox.sample_field(1234, 0, 0, 1000, 17, 0)
+    assert u.dtype == np.float32 and u.min() > 0.0 and u.max() < 1.0 and abs(float(u.mean()) - 0.5) < 0.01
+    nrm = philox.sample_field(1234, 0, 1, 4000, 66, 1)
+    assert abs(float(nrm.mean())) < 0.01 and abs(float(nrm.std()) - 1.0) < 0.01
+
+
+def test_energies_and_weights_host_path_vs_reference_goldens(golden):
+    """f-3 on the host path (torch-CPU ops of bgflow_amd.distributions / bg): DoubleWellEnergy, NormalDistribution, UniformDistribution,
+    ProductDistribution energies, forces, log weights and ESS against values generated from the reference classes"""
+    import torch
+    import bgflow_amd as bg
+    from bgflow_amd.bg import log_weights_given_latent, effective_sample_size
+    G = golden("g_energies")
+    x = torch.tensor(G["dw_x"]).double()
+    for tag, kw in (("dw", {}), ("dw_abc", dict(a=0.7, b=-2.5, c=0.4))):
+        e = bg.DoubleWellEnergy(64, **kw)
+        np.testing.assert_allclose(e.energy(x).numpy(), G[tag + "_u64"], rtol=1e-12)
+        np.testing.assert_allclose(e.energy(x, temperature=2.5).numpy(), G[tag + "_uT64"], rtol=1e-12)
+        np.testing.assert_allclose(e.force(x.clone(), temperature=2.5).numpy(), G[tag + "_force64"], rtol=1e-12, atol=1e-12)
+    mean = torch.tensor(G["norm_mean"]).double()
+    comps = [bg.NormalDistribution(66, mean=mean), bg.NormalDistribution(66),       # (f32 buffers like the fixture's: log Z rounds to f32)
+             bg.UniformDistribution(torch.tensor(G["unif_low"]).double(), torch.tensor(G["unif_high"]).double())]
+    xs = tuple(torch.tensor(G[k]).double() for k in ("prod_y", "prod_a", "prod_un"))
+    prod = bg.ProductDistribution(comps)
+    np.testing.assert_allclose(comps[0].energy(xs[0], temperature=1.7).numpy(), G["norm_u64"], rtol=1e-10)
+    np.testing.assert_allclose(comps[2].energy(xs[2]).numpy(), G["unif_u64"], rtol=1e-10)
+    np.testing.assert_allclose(prod.energy(*xs).numpy(), G["prod_u64"], rtol=1e-10)
+    np.testing.assert_allclose(prod.energy(*xs, temperature=1.7).numpy(), G["prod_uT64"], rtol=1e-10)
+    lw = log_weights_given_latent(xs[0], xs[1], torch.tensor(G["logw_dl"]).double(), bg.NormalDistribution(66),
+                                  bg.NormalDistribution(66, mean=mean), temperature=1.3, normalize=True)
+    np.testing.assert_allclose(lw.numpy(), G["logw64"], rtol=1e-6, atol=1e-6)      # (the golden's dlogp went through f32 once)
+    np.testing.assert_allclose(effective_sample_size(lw).numpy(), G["ess64"], rtol=1e-5)
