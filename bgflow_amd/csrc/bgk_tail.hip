@@ -85,6 +85,7 @@ struct TailArgs {
     float eps, const_ld;                 /* const_ld: n (ln pi + ln 2 pi) - jac_xz, f64 on the host */
     int64_t B; float* x; int64_t ldx; float* dlogp; int accumulate; int32_t* warn_count;
     int lds_per_wave;
+    float* o_bonds; float* o_angles; float* o_torsions; float* o_fixed;      /* outputs of the inverse-direction kernel */
 };
 
 /* erfinv(x), |x| < 1: M. Giles, "Approximating the erfinv function" (GPU Computing Gems 2, 2010), single-precision version:
@@ -188,6 +189,10 @@ __device__ __forceinline__ void sincos2pi(float x, float& so, float& co) {
     co = neg_c ? -b : b;
 }
 
+__device__ __forceinline__ float rcp1(float d) {                          /* 1 / d, one Newton step: ~1 ulp */
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
 __device__ __forceinline__ float rsq_nr(float q) {                       /* 1 / sqrt(q), one Newton step: ~1 ulp */
     const float r = __builtin_amdgcn_rsqf(q);
     return r * __builtin_fmaf(-0.5f * q, r * r, 1.5f);
@@ -603,6 +608,251 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
     if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
 }
 
+
+/* ==== the inverse (NLL) direction of the tail: xyz -> IC + whitening + the four cdf domain maps in one launch ===================
+ * RelativeInternalCoordinateTransformation._forward / MixedCoordinateTransformation._forward (nn/flow/crd_transform/ic.py:386-433,
+ * 838-860; dist / angle / torsion of ic_helper.py:148-293; whitening pca.py:74-83) followed by CDFTransform._forward x 4
+ * (nn/flow/cdf.py:28-35) -- five launches of the block path (bgk_ic_xyz2ic + 4 x bgk_cdf_transform) and a [B, 60] round trip.
+ * Same layout ideas as the sampling direction: the x tile arrives by DMA, every lane lifts its row into registers (px / py / pz,
+ * uniform register indexing by the Z-matrix rows), the Z rows are independent of each other (instruction-level parallelism across
+ * rows), results go to LDS row-major = the memory image of the contiguous [B, n] output tiles and leave as coalesced stores.
+ * Arithmetic: the angle is atan2(|r12 x r32|, r12 . r32) instead of acos of the normalised dot product (same value, but accurate
+ * for small and near-straight angles, where acos amplifies the rounding of the cosine by 1 / sin a); log|det J| of a row in closed
+ * form -(2 ln d + ln sin a) (what the explicit 3 x 3 determinant of the reference evaluates to away from its eps clamps; rows
+ * that hit a clamp are recomputed with the reference's explicit arithmetic); erf (N. Juffa's single-precision form, < 1 ulp) and
+ * atan (Cephes) as branch-free polynomials.  Field-uniform marginals only (desc4); otherwise the block path runs. */
+__device__ __forceinline__ float erf_fast(float a) {
+    const float t = __builtin_fabsf(a), s = a * a;
+    float r = __builtin_fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = __builtin_fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = __builtin_fmaf(r, s, u);
+    r = __builtin_fmaf(r, t, -1.06777877e-1f);
+    r = __builtin_fmaf(r, t, -6.34846687e-1f);
+    r = __builtin_fmaf(r, t, -1.28717512e-1f);
+    r = __builtin_fmaf(r, t, -t);
+    const float big = __builtin_copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896341f), a);
+    float q = -5.96761703e-4f;
+    q = __builtin_fmaf(q, s, 4.99119423e-3f);
+    q = __builtin_fmaf(q, s, -2.67681349e-2f);
+    q = __builtin_fmaf(q, s, 1.12819925e-1f);
+    q = __builtin_fmaf(q, s, -3.76125336e-1f);
+    q = __builtin_fmaf(q, s, 1.28379166e-1f);
+    const float small = __builtin_fmaf(q, a, a);
+    return t > 0.927734375f ? big : small;
+}
+
+/* atan2(y, x) in (-pi, pi]: atan of min / max on [0, 1] (Cephes atanf: reduction at tan(pi / 8), odd polynomial), octant fix-ups */
+__device__ __forceinline__ float atan2_fast(float y, float x) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    const float q = mn * rcp1(mx);                                      /* in [0, 1]; 0 / 0 -> handled by the callers' clamps */
+    const bool big = q > 0.41421356237309503f;
+    const float xr = big ? (q - 1.0f) * rcp1(q + 1.0f) : q;
+    const float z = xr * xr;
+    float p = __builtin_fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = __builtin_fmaf(p, z, 1.99777106478e-1f);
+    p = __builtin_fmaf(p, z, -3.33329491539e-1f);
+    float r = __builtin_fmaf(p * z, xr, xr);
+    r = big ? r + 0.78539816339744831f : r;
+    r = ay > ax ? 1.57079632679489662f - r : r;
+    r = x < 0.0f ? 3.14159265358979324f - r : r;
+    return __builtin_copysignf(r, y);
+}
+
+/* u = cdf(v) of one field-uniform channel (CDFTransform._forward: clamp to [eps, 1 - eps], log-det = log_prob(v) >= -1 / eps) */
+__device__ __forceinline__ float cdf_chan(float v, const Desc& dsc, float inv_xs, const CdfClamp& cl, float& ld_acc) {
+    const float* ds = dsc.f;
+    const int kind = __builtin_bit_cast(int, ds[0]);
+    if (kind < 0) return v;
+    float u, ld;
+    if (kind == 0) {
+        u = __builtin_amdgcn_fmed3f((v - ds[1]) * inv_xs, 0.0f, 1.0f);   /* inv_xs = 1 / (high - low) for a uniform channel */
+        ld = -ds[5];
+    } else {
+        const float e = (v - ds[1]) * ds[6];                             /* (v - mu) / (sigma sqrt2) */
+        u = (erf_fast(e) - ds[4]) * inv_xs;                              /* (Phi - cdf_lower) / Z with xs = 2 Z, xo = 2 cdf_lower - 1 */
+        ld = -__builtin_fmaf(e, e, ds[5]);
+    }
+    ld_acc += __builtin_fmaxf(ld, cl.ld_min);
+    return __builtin_amdgcn_fmed3f(u, cl.lo, cl.hi);
+}
+
+/* one Z row exactly like the reference (dist_deriv / angle_deriv / torsion_deriv with their eps clamps and the explicit 3 x 3
+ * determinant, ic_helper.py:148-293) -- only for lanes that hit a clamp */
+__device__ __forceinline__ void zrow_reference(V3 x1, V3 x2, V3 x3, V3 x4, float eps, int enforce, float* d_out, float* a_out, float* t_out,
+                                               float* ld_out, int* warn) {
+    auto cl = [&](float v) { if (v < eps) { *warn += 1; if (enforce) v = eps; } return v; };
+    auto nrm = [](V3 v) { return __builtin_sqrtf(v.x * v.x + v.y * v.y + v.z * v.z); };
+    const V3 r = sub(x2, x1);
+    const float rn = cl(nrm(r));
+    const V3 Jb = {-r.x / rn, -r.y / rn, -r.z / rn};
+    const V3 r12 = sub(x1, x2), r32 = sub(x3, x2);
+    const float n12 = cl(nrm(r12)), n32 = cl(nrm(r32));
+    const V3 u12 = {r12.x / n12, r12.y / n12, r12.z / n12}, u32 = {r32.x / n32, r32.y / n32, r32.z / n32};
+    float cosa = u12.x * u32.x + u12.y * u32.y + u12.z * u32.z;
+    const float u12v[3] = {u12.x, u12.y, u12.z}, u32v[3] = {u32.x, u32.y, u32.z};
+    float Jav[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sacc += u32v[k] * (((k == c ? 1.0f : 0.0f) - u12v[k] * u12v[c]) / n12);
+        Jav[c] = sacc;
+    }
+    if (enforce) cosa = __builtin_fminf(__builtin_fmaxf(cosa, -1.0f + eps), 1.0f - eps);
+    const float ang = acosf(cosa), sq = __builtin_sqrtf(1.0f - cosa * cosa);
+    const V3 Ja = {-Jav[0] / sq, -Jav[1] / sq, -Jav[2] / sq};
+    const V3 b0 = r12, b1 = r32, b2 = sub(x4, x3);
+    const float b1n = cl(nrm(b1));
+    const V3 u = {b1.x / b1n, b1.y / b1n, b1.z / b1n};
+    const float b0u = b0.x * u.x + b0.y * u.y + b0.z * u.z, b2u = b2.x * u.x + b2.y * u.y + b2.z * u.z;
+    const V3 v = {b0.x - b0u * u.x, b0.y - b0u * u.y, b0.z - b0u * u.z}, w = {b2.x - b2u * u.x, b2.y - b2u * u.y, b2.z - b2u * u.z};
+    const float xx = v.x * w.x + v.y * w.y + v.z * w.z;
+    const V3 uxv = {u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+    const float yy = uxv.x * w.x + uxv.y * w.y + uxv.z * w.z;
+    const float tor = atan2f(yy, xx);
+    const float q = cl(xx * xx + yy * yy);
+    const float dadx = -yy / q, dady = xx / q;
+    const V3 wxu = {w.y * u.z - w.z * u.y, w.z * u.x - w.x * u.z, w.x * u.y - w.y * u.x};
+    const V3 g = {dadx * w.x + dady * wxu.x, dadx * w.y + dady * wxu.y, dadx * w.z + dady * wxu.z};
+    const float gu = g.x * u.x + g.y * u.y + g.z * u.z;
+    const V3 Jt = {g.x - gu * u.x, g.y - gu * u.y, g.z - gu * u.z};
+    const V3 c01 = {Jb.y * Ja.z - Jb.z * Ja.y, Jb.z * Ja.x - Jb.x * Ja.z, Jb.x * Ja.y - Jb.y * Ja.x};
+    *ld_out = bgk_logf(__builtin_fabsf(c01.x * Jt.x + c01.y * Jt.y + c01.z * Jt.z));
+    *d_out = rn; *a_out = ang; *t_out = tor;
+}
+
+template <int NA>
+__global__ __launch_bounds__(TW * 64) void xyz2ic_cdf_uni_kernel(TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * TW + wave;
+    if (tile >= ((a.B + 63) >> 6)) return;
+    const int n = a.n, keep = a.keep, nf3 = 3 * a.n_fixed, n_atoms = n + a.n_fixed, ldr = 3 * n_atoms;
+    float* S = smem + (size_t)wave * a.lds_per_wave;  /* x tile [64][3 n_atoms]; afterwards bonds | angles | torsions | fixed tiles */
+    float* R0 = S;
+    float* R1 = R0 + 64 * n;
+    float* R2 = R1 + 64 * n;
+    float* R3 = R2 + 64 * n;
+    const int64_t b0 = tile * 64;
+    const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+    const cf32_t desc = (cf32_t)a.desc;               /* [4][DSC]: bonds, angles, torsions, fixed */
+    const ci32_t recs = (ci32_t)a.place;              /* Z rows: [n][8] = (a, b, c, d, 0, 0, 0, 0) */
+    const CdfClamp cl = a.cl;
+
+    dma_tile(S, a.x + b0 * ldr, ldr, rows, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float px[NA], py[NA], pz[NA];
+    {
+        const float* row = S + lane * ldr;
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (k < n_atoms) { px[k] = row[3 * k]; py[k] = row[3 * k + 1]; pz[k] = row[3 * k + 2]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                  /* every lane holds its row: the tile's place in LDS is free */
+    float acc = a.const_ld;                           /* -n (ln pi + ln 2 pi) + jac_xz */
+
+    /* ---- fixed atoms: whitening + cdf map ---- */
+    {
+        const Desc df = load_desc(desc, 3);
+        const float inv_f = rcp1(__builtin_bit_cast(int, df.f[0]) == 0 ? df.f[2] : df.f[3]);
+        const cf32_t T = (cf32_t)a.T, mean = (cf32_t)a.mean;
+        float fz[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) fz[k] = 0.0f;
+        for (int fa = 0; fa < a.n_fixed; ++fa) {
+            const int at = ((ci32_t)a.fixed)[fa];
+            const float cx = px[at], cy = py[at], cz = pz[at];
+            if (T) {
+                const float dx = cx - mean[3 * fa], dy = cy - mean[3 * fa + 1], dz = cz - mean[3 * fa + 2];
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < keep) {
+                        fz[k] = __builtin_fmaf(dx, T[(3 * fa) * keep + k], fz[k]);
+                        fz[k] = __builtin_fmaf(dy, T[(3 * fa + 1) * keep + k], fz[k]);
+                        fz[k] = __builtin_fmaf(dz, T[(3 * fa + 2) * keep + k], fz[k]);
+                    }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    fz[k] = (k == 3 * fa) ? cx : fz[k];
+                    fz[k] = (k == 3 * fa + 1) ? cy : fz[k];
+                    fz[k] = (k == 3 * fa + 2) ? cz : fz[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < keep) R3[lane * keep + k] = cdf_chan(fz[k], df, inv_f, cl, acc);
+    }
+
+    /* ---- Z rows (independent of each other) ---- */
+    int warn = 0;
+    const float eps2 = a.eps * a.eps;
+    const Desc db = load_desc(desc, 0), da = load_desc(desc, 1), dt = load_desc(desc, 2);
+    const float inv_b = rcp1(__builtin_bit_cast(int, db.f[0]) == 0 ? db.f[2] : db.f[3]);
+    const float inv_a = rcp1(__builtin_bit_cast(int, da.f[0]) == 0 ? da.f[2] : da.f[3]);
+    const float inv_t = rcp1(__builtin_bit_cast(int, dt.f[0]) == 0 ? dt.f[2] : dt.f[3]);
+    Rec r = load_rec(recs, 0);
+    for (int i = 0; i < n; ++i) {
+        const Rec rn = load_rec(recs, i + 1 < n ? i + 1 : i);
+        const V3 x1 = {px[r.at], py[r.at], pz[r.at]}, x2 = {px[r.i1], py[r.i1], pz[r.i1]};
+        const V3 x3 = {px[r.i2], py[r.i2], pz[r.i2]}, x4 = {px[r.i3], py[r.i3], pz[r.i3]};
+        r = rn;
+        const V3 r12 = sub(x1, x2), r32 = sub(x3, x2), b2 = sub(x4, x3);
+        const float q12 = dot(r12, r12), q32 = dot(r32, r32);
+        const float i12 = rsq_nr(q12), i32 = rsq_nr(q32);
+        float d = q12 * i12;                                             /* |x2 - x1| */
+        const V3 cr = cross(r12, r32);
+        const float qc = dot(cr, cr);
+        const float sn = qc * rsq_nr(qc) * (i12 * i32);                  /* sin a = |r12 x r32| / (|r12| |r32|) */
+        const float cs = dot(r12, r32) * (i12 * i32);                    /* cos a */
+        float ang = atan2_fast(sn, cs);
+        /* torsion (ic_helper.py:213-293): u = r32 / |r32|, v = r12 - (r12.u) u, w = b2 - (b2.u) u, t = atan2((u x v).w, v.w) */
+        const V3 u = {r32.x * i32, r32.y * i32, r32.z * i32};
+        const float b0u = dot(r12, u), b2u = dot(b2, u);
+        const V3 v = {__builtin_fmaf(-b0u, u.x, r12.x), __builtin_fmaf(-b0u, u.y, r12.y), __builtin_fmaf(-b0u, u.z, r12.z)};
+        const V3 w = {__builtin_fmaf(-b2u, u.x, b2.x), __builtin_fmaf(-b2u, u.y, b2.y), __builtin_fmaf(-b2u, u.z, b2.z)};
+        const float xx = dot(v, w), yy = dot(cross(u, v), w);
+        float tor = atan2_fast(yy, xx);
+        float ld = -LN2_F * __builtin_amdgcn_logf(q12 * sn);             /* -(2 ln d + ln sin a) */
+        const bool bad = (q12 < eps2) || (q32 < eps2) || (__builtin_fabsf(cs) > 1.0f - a.eps) || (xx * xx + yy * yy < a.eps);
+        if (__builtin_amdgcn_ballot_w64(bad)) {                          /* rare: degenerate geometry, the reference's clamps */
+            if (bad) zrow_reference(x1, x2, x3, x4, a.eps, a.enforce, &d, &ang, &tor, &ld, &warn);
+        }
+        acc += ld;
+        ang = ang * 0.318309886183790672f;                               /* / pi */
+        tor = __builtin_fmaf(tor, 0.159154943091895336f, 0.5f);          /* (t + pi) / (2 pi) */
+        R0[lane * n + i] = cdf_chan(d, db, inv_b, cl, acc);
+        R1[lane * n + i] = cdf_chan(ang, da, inv_a, cl, acc);
+        R2[lane * n + i] = cdf_chan(tor, dt, inv_t, cl, acc);
+    }
+    if (lane < rows) {
+        const int64_t b = b0 + lane;
+        if (a.accumulate) a.dlogp[b] += acc; else a.dlogp[b] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    /* ---- the four tiles leave as their memory images ---- */
+    {
+        float* outs[4] = {a.o_bonds + b0 * n, a.o_angles + b0 * n, a.o_torsions + b0 * n, a.o_fixed + b0 * keep};
+        const float* srcs[4] = {R0, R1, R2, R3};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int w = f < 3 ? n : keep;
+            const int total = rows * w, total4 = total >> 2;
+            const float4* s4 = reinterpret_cast<const float4*>(srcs[f]);
+            float4* g4 = reinterpret_cast<float4*>(outs[f]);
+            for (int q = lane; q < total4; q += 64) g4[q] = s4[q];
+            for (int q = (total4 << 2) + lane; q < total; q += 64) outs[f][q] = srcs[f][q];
+        }
+    }
+    if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
+}
+
 }  // namespace
 
 extern "C" int bgk_icdf_ic2xyz_reg(const float* bonds, const float* angles, const float* torsions, const float* xfix,
@@ -668,4 +918,43 @@ extern "C" int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, cons
     if (n_atoms <= 24) BGK_LAUNCH(24); else BGK_LAUNCH(32);
 #undef BGK_LAUNCH
     return bgk_launch_status("bgk_icdf_ic2xyz_uni");
+}
+
+/* The inverse (NLL) direction of the builder tail in one launch: x [B, 3 (n + n_fixed)] -> cdf-mapped bonds / angles / torsions [B, n]
+ * and (whitened) fixed coordinates [B, keep], all contiguous, + log|det J| (replaces bgk_ic_xyz2ic + 4 x bgk_cdf_transform:
+ * RelativeInternalCoordinateTransformation._forward / MixedCoordinateTransformation._forward, crd_transform/ic.py:386-433, 838-860,
+ * then CDFTransform._forward x 4, nn/flow/cdf.py:28-35).  zmat8 [n, 8] int32 rows (a, b, c, d, 0, 0, 0, 0); desc4 [4, 20] as in
+ * bgk_icdf_ic2xyz_uni (field-uniform marginals); Twhiten [3 n_fixed, keep]; const_ld = -n (ln pi + ln 2 pi) + jac_xz. */
+extern "C" int bgk_xyz2ic_cdf_uni(const float* x, const float* desc4, int32_t use_eps, float cdf_eps,
+                                  const int32_t* zmat8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                                  float eps, int32_t enforce_boundaries,
+                                  const float* wh_mean, const float* Twhiten, int32_t keep, double const_ld, int64_t B,
+                                  float* bonds, float* angles, float* torsions, float* xfix,
+                                  float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream) {
+    BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_xyz2ic_cdf_uni: bad sizes");
+    BGK_CHECK_ARG(x && zmat8 && fixed && bonds && angles && torsions && xfix && dlogp && desc4, "bgk_xyz2ic_cdf_uni: null pointer");
+    BGK_CHECK_ARG(Twhiten ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_xyz2ic_cdf_uni: bad whitening arguments");
+    const int n_atoms = n + n_fixed;
+    if (n_atoms > 32 || keep > KMAX || 3 * n + keep > 3 * n_atoms) return BGK_EUNSUPPORTED;
+    if ((((uintptr_t)bonds | (uintptr_t)angles | (uintptr_t)torsions | (uintptr_t)xfix | (uintptr_t)x) & 15) != 0) return BGK_EUNSUPPORTED;
+    if (B == 0) return 0;
+    TailArgs a{};
+    a.x = const_cast<float*>(x); a.desc = desc4; a.place = zmat8; a.fixed = fixed;
+    a.mean = wh_mean; a.T = Twhiten; a.n = n; a.n_fixed = n_fixed; a.keep = keep; a.enforce = enforce_boundaries;
+    const float inf = __builtin_inff();
+    a.cl = use_eps ? CdfClamp{cdf_eps, 1.0f - cdf_eps, -1.0f / cdf_eps} : CdfClamp{-inf, inf, -inf};
+    a.eps = eps; a.const_ld = (float)const_ld;
+    a.B = B; a.ldx = 3 * n_atoms; a.dlogp = dlogp; a.accumulate = accumulate; a.warn_count = warn_count;
+    a.o_bonds = bonds; a.o_angles = angles; a.o_torsions = torsions; a.o_fixed = xfix;
+    a.lds_per_wave = 64 * 3 * n_atoms;
+    const size_t shmem = sizeof(float) * (size_t)TW * a.lds_per_wave;
+    if (shmem > 160 * 1024) return BGK_EUNSUPPORTED;
+    const int64_t n_wg = (((B + 63) >> 6) + TW - 1) / TW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_xyz2ic_cdf_uni: batch too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCH(NA_) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xyz2ic_cdf_uni_kernel<NA_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                             hipLaunchKernelGGL(xyz2ic_cdf_uni_kernel<NA_>, dim3((unsigned)n_wg), dim3(TW * 64), shmem, st, a); } while (0)
+    if (n_atoms <= 24) BGK_LAUNCH(24); else BGK_LAUNCH(32);
+#undef BGK_LAUNCH
+    return bgk_launch_status("bgk_xyz2ic_cdf_uni");
 }

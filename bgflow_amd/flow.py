@@ -200,9 +200,12 @@ class SequentialFlow(Flow):
         return cache["segments"]
 
     def _build_segments(self, blocks, inverse):
-        if inverse:
-            return self._with_coupling_stacks(list(reversed(blocks)), True)
         tail = self._generation_tail() if self.FUSE_GENERATION_TAIL else None
+        if inverse:
+            if tail is None:
+                return self._with_coupling_stacks(list(reversed(blocks)), True)
+            # the NLL direction enters through the tail: xyz -> IC + the cdf maps as one fused segment, then the rest reversed
+            return [("xyz2ic+cdf", _FusedInferenceHead(self, tail))] + self._with_coupling_stacks(list(reversed(blocks[:tail[0]])), True)
         if tail is None:
             return self._with_coupling_stacks(blocks, False)
         start = tail[0]
@@ -480,6 +483,60 @@ class _FusedGenerationTail:
         if acc is not None:
             return (x, *xs[4:], acc)
         return (x, *xs[4:], dlogp + total if self._others else dlogp)
+
+
+class _FusedInferenceHead:
+    """callable standing in for the tail blocks [icdf maps..., IC -> xyz] of a SequentialFlow run in the INVERSE (NLL) direction:
+    x -> xyz -> IC + whitening + the four cdf maps in one launch (bgk_xyz2ic_cdf_uni).  Falls back to the blocks themselves (reversed)
+    when the input needs gradients, is not a contiguous f32 HIP matrix, or the marginals are not field-uniform."""
+    _bgk_acc = True
+
+    def __init__(self, flow, tail):
+        self._flow, (self._start, self._maps, self._ic, self._eps, self._others) = flow, tail
+        self._tail_fwd = _FusedGenerationTail(flow, tail)       # shares the descriptor cache logic
+
+    def _blocks_path(self, *xs, **kwargs):
+        acc = kwargs.get(ACC_KW)
+        total = 0.0
+        for block in reversed(list(self._flow._blocks)[self._start:]):
+            *xs, dd = block(*xs, inverse=True, **_acc_kwargs(block, kwargs))
+            if acc is not None:
+                acc.add(dd)
+            else:
+                total = total + dd
+        return (*xs, acc if acc is not None else total)
+
+    def _desc4(self, x):
+        rel = getattr(self._ic, "_rel_ic", self._ic)
+        n, keep = rel._n, self._ic.dim_fixed
+        dummy = [torch.empty(0, n, device=x.device)] * 3 + [torch.empty(0, keep, device=x.device)]
+        tab = self._tail_fwd._desc20(dummy)
+        return None if tab is None else getattr(tab, "uniform4", None)
+
+    def __call__(self, *xs, inverse=True, **kwargs):
+        assert inverse
+        x = xs[0] if xs else None
+        ok = (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+              and not (torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in xs)) and hasattr(self._ic, "_infer_fused"))
+        desc4 = self._desc4(x) if ok else None
+        if desc4 is None:
+            return self._blocks_path(*xs, **kwargs)
+        acc = kwargs.get(ACC_KW)
+        res = self._ic._infer_fused(x, desc4, self._eps, acc=acc)
+        if res is None:
+            return self._blocks_path(*xs, **kwargs)
+        b, a, t, zf, dlogp = res
+        out = (b, a, t, zf, *xs[1:])
+        total = 0.0
+        for block in reversed(self._others):                # maps on slots the coordinate transform does not touch
+            *out, dd = block(*out, inverse=True, **_acc_kwargs(block, kwargs))
+            if acc is not None:
+                acc.add(dd)
+            else:
+                total = total + dd
+        if acc is not None:
+            return (*out, acc)
+        return (*out, dlogp + total if self._others else dlogp)
 
 
 class InverseFlow(Flow):

@@ -267,6 +267,7 @@ class RelativeInternalCoordinateTransformation(Flow):
         # the register-resident tail kernel reads one 32-byte record per placement (bgk_tail.hip::Rec)
         self._tables.set("place8", np.ascontiguousarray(np.concatenate([place, np.zeros((len(place), 3), np.int32)], axis=1)))
         self._placement_zrows = place[:, 4].astype(np.int64)      # Z row consumed by placement i
+        self._tables.set("zmat8", np.ascontiguousarray(np.concatenate([z[:, :4].astype(np.int32), np.zeros((len(z), 4), np.int32)], axis=1)))
         self._tables.set("fixed", np.ascontiguousarray(f, dtype=np.int32))
         self._n, self._n_fixed = len(z), len(f)
         self._warn = {}
@@ -427,6 +428,39 @@ class RelativeInternalCoordinateTransformation(Flow):
     def _generate_fused(self, bonds, angles, torsions, x_fixed, descs, eps, acc=None, desc20=None):
         return self._icdf_ic2xyz(bonds, angles, torsions, x_fixed, descs, eps, acc=acc, desc20=desc20)
 
+    def _xyz2ic_cdf(self, x, desc4, eps, whiten=None, acc=None):
+        """xyz -> IC with the four cdf domain maps fused in (bgk_xyz2ic_cdf_uni: the NLL direction of a builder flow's tail); None when
+        the launch is outside the kernel's envelope.  No autograd."""
+        dev = x.device
+        n, nf = self._n, self._n_fixed
+        x2 = x.reshape(x.shape[0], -1)
+        B = x2.shape[0]
+        if whiten is None:
+            mean = T = None
+            keep, jac = 3 * nf, 0.0
+        else:
+            mean, T, jac = whiten
+            keep = T.shape[1]
+        if not (self._normalize_angles and x2.is_contiguous() and x2.shape[1] == 3 * (n + nf) and B > 0 and n + nf <= 32 and keep <= 16):
+            return None
+        ics = torch.empty((3, B, n), dtype=torch.float32, device=dev)
+        xfix = torch.empty((B, keep), dtype=torch.float32, device=dev)
+        dlogp, accumulate = _dl_target(acc, B, dev)
+        const_ld = -n * (np.log(np.pi) + np.log(2.0 * np.pi)) + (float(jac) if T is not None else 0.0)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_xyz2ic_cdf_uni(
+                _lib.ptr(x2), _lib.ptr(desc4), int(eps is not None), float(eps or 0.0), _lib.ptr(self._tables.get("zmat8", dev)), n,
+                _lib.ptr(self._tables.get("fixed", dev)), nf, float(self._eps), int(self._enforce_boundaries), _lib.ptr(mean), _lib.ptr(T), keep,
+                float(const_ld), B, _lib.ptr(ics[0]), _lib.ptr(ics[1]), _lib.ptr(ics[2]), _lib.ptr(xfix), _lib.ptr(dlogp), accumulate,
+                _lib.ptr(self._warn_counter(dev)), _lib.stream_ptr(dev))
+        if st == -2:
+            return None
+        _lib.check(st, "bgk_xyz2ic_cdf_uni")
+        return ics[0], ics[1], ics[2], xfix, _dl_result(acc, dlogp)
+
+    def _infer_fused(self, x, desc4, eps, acc=None):
+        return self._xyz2ic_cdf(x, desc4, eps, acc=acc)
+
     def _forward(self, x, with_pose=True, *args, **kwargs):
         return self._xyz2ic(x, acc=kwargs.get(ACC_KW))
 
@@ -522,6 +556,9 @@ class MixedCoordinateTransformation(Flow):
 
     def _inverse(self, bonds, angles, torsions, z_fixed, *args, **kwargs):
         return self._rel_ic._ic2xyz(bonds, angles, torsions, z_fixed, blacken=self._wh("blacken", bonds.device), acc=kwargs.get(ACC_KW))
+
+    def _infer_fused(self, x, desc4, eps, acc=None):
+        return self._rel_ic._xyz2ic_cdf(x, desc4, eps, whiten=self._wh("whiten", x.device), acc=acc)
 
     def _generate_fused(self, bonds, angles, torsions, z_fixed, descs, eps, acc=None, desc20=None):
         return self._rel_ic._icdf_ic2xyz(bonds, angles, torsions, z_fixed, descs, eps, blacken=self._wh("blacken", bonds.device), acc=acc,

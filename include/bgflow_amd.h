@@ -187,6 +187,20 @@ int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, const float* to
                         const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
                         float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream);
 
+/* The INVERSE (NLL) direction of the builder tail in one launch: x [B, 3 (n + n_fixed)] -> cdf-mapped bonds / angles / torsions [B, n]
+ * and (whitened) fixed coordinates [B, keep], all contiguous and 16-byte aligned, + log|det J|.  Replaces bgk_ic_xyz2ic + 4 x
+ * bgk_cdf_transform, i.e. RelativeInternalCoordinateTransformation._forward / MixedCoordinateTransformation._forward
+ * (crd_transform/ic.py:386-433, 838-860; ic_helper.py:148-293; pca.py:74-83) followed by CDFTransform._forward x 4 (nn/flow/cdf.py:28-35).
+ * zmat8 [n, 8] int32 rows (a, b, c, d, 0, 0, 0, 0); desc4 [4, 20] as in bgk_icdf_ic2xyz_uni (field-uniform marginals); Twhiten
+ * [3 n_fixed, keep]; const_ld = -n (ln pi + ln 2 pi) + jac_xz.  BGK_EUNSUPPORTED outside the envelope (n + n_fixed <= 32, keep <= 16,
+ * 3 n + keep <= 3 (n + n_fixed)): the caller runs the separate kernels. */
+int bgk_xyz2ic_cdf_uni(const float* x, const float* desc4, int32_t use_eps, float cdf_eps,
+                       const int32_t* zmat8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                       float eps, int32_t enforce_boundaries,
+                       const float* wh_mean, const float* Twhiten, int32_t keep, double const_ld, int64_t B,
+                       float* bonds, float* angles, float* torsions, float* xfix,
+                       float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream);
+
 /* Backward (VJP) of bgk_ic_ic2xyz for first-order losses (replaces torch autograd through
  * ic2xyz_deriv / det3x3, ic.py:435-513): x is the forward OUTPUT; g_x [B, 3*n_atoms], g_dlogp [B]
  * -> g_bonds / g_angles / g_torsions [B, n] (ldgic), g_xfix [B, keep] (ldgf).  The log-det term uses
