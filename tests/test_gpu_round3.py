@@ -449,3 +449,22 @@ def test_fused_inference_head_equals_blocks_and_oracle(hip_lib, oracle, dev, cfg
         ez = np.abs(zb[k][rows_t].cpu().numpy() - z64[k]).max(-1)
         ez32 = np.abs(z32[k] - z64[k]).max(-1)
         assert np.median(ez) <= 3 * np.median(ez32) + 2e-6
+
+
+def test_two_rank_rccl_kl_step(hip_lib, dev):
+    """2 processes x 2 GPUs over RCCL (skipped on a one-GPU box): the sharded KL step of tests/_two_rank_worker.py"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_two_rank_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "TWO_RANK_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
