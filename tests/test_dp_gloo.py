@@ -33,6 +33,21 @@ def _worker(rank, world, port, out):
     loss = dp.global_mean(per_sample)
     loss.backward()
     dp.allreduce_gradients_([theta])
+    # the [sum, n] pair the target-energy kernel writes (distributions.kl_loss_sums), all-reduced as it is: same global mean,
+    # gradient = each rank's own share 1 / n_global
+    theta2 = torch.nn.Parameter(torch.tensor([0.5, -1.0]))
+    ps2 = ((x * theta2).sum(-1, keepdim=True)) ** 2
+    sums = torch.stack([ps2.sum().double(), torch.tensor(float(n_local), dtype=torch.float64)])
+    loss2 = dp.global_mean_from_sums(sums)
+    loss2.backward()
+    dp.allreduce_gradients_([theta2])
+    assert abs(float(loss2.detach()) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach()))
+    assert torch.allclose(theta2.grad, theta.grad, rtol=1e-5, atol=1e-6)
+    # and the KL mean through a target without kernel fields (CPU tensors): the per-sample path with one all-reduce
+    import bgflow_amd as bg
+    tgt = bg.NormalDistribution(2)
+    klm = dp.global_kl_mean(tgt, (x,), torch.zeros(n_local, 1))
+    assert abs(float(klm) - float(dp.global_mean(tgt.energy(x)))) <= 1e-6
     logw = x[:, 0] * 3.0
     # plain lists, not tensors: tensor storages travel through the queue as file descriptors served by THIS process,
     # which may already have exited when the parent reads them
