@@ -79,6 +79,12 @@ constexpr int GBLK = KS * 8 + 4;      /* 1 KiB blocks per packed 128-row GEMM in
 #ifndef BGK_V2_RD
 #define BGK_V2_RD 4
 #endif
+#ifndef BGK_V2_PINSEL
+#define BGK_V2_PINSEL 1
+#endif
+#ifndef BGK_V2_BSEARCH
+#define BGK_V2_BSEARCH 1             /* bin search: 1 = 3-level binary search with windowed selects, 0 = linear count + select chains */
+#endif
 #ifndef BGK_V2_BUF
 #define BGK_V2_BUF 1                  /* A stream through buffer loads: one s_mov per 4 KiB group instead of a 64-bit SALU add per tile-step */
 #endif
@@ -423,6 +429,80 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     kn[5] = __builtin_fmaf(E[5], gA, SC.sa.kc[5]);
     kn[6] = __builtin_fmaf(E[6], gA, SC.sa.kc[6]);
     hk.template at<6>();
+#if BGK_V2_BSEARCH
+    /* Bin search as a 3-level binary search on the (monotone) knots: idx = #{k : x >= kn[k]} exactly as the linear count (the knots are
+     * non-decreasing: fma of non-decreasing prefix sums with a positive gain onto increasing offsets), with the window of candidate
+     * knots / other-set prefix sums halved by selects at every level: 3 compares + 20 selects instead of 7 + 36. */
+    /* (knots and end points as opaque register values: with a load or an fma on one arm only, the compiler turns the selects into
+     * divergent branches, which also cuts the pinned MFMA / VALU interleaving) */
+    float low_a = SC.sa.low, high_a = SC.sa.high;
+    asm volatile("" : "+s"(low_a), "+s"(high_a));
+#pragma unroll
+    for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(kn[i]));
+    const bool g3 = x >= kn[3];
+    hk.template at<7>();
+    float w0 = g3 ? kn[3] : low_a, w1 = g3 ? kn[4] : kn[0], w2 = g3 ? kn[5] : kn[1], w3 = g3 ? kn[6] : kn[2];
+    hk.template at<8>();
+    float w4 = g3 ? high_a : kn[3];
+    const bool gm = x >= w2;
+    const float v0 = gm ? w2 : w0, v1 = gm ? w3 : w1, v2 = gm ? w4 : w2;
+    hk.template at<9>();
+    const bool gl = x >= v1;
+    const float lo = gl ? v1 : v0, hi = gl ? v2 : v1;
+    float idxf = g3 ? 4.0f : 0.0f;
+    hk.template at<10>();
+    idxf += gm ? 2.0f : 0.0f;
+    idxf += gl ? 1.0f : 0.0f;
+    const int idx = (int)idxf;
+    *bin = idx;
+    hk.template at<11>();
+    /* the two slopes of the bin (dynamic LDS rows; circular dims wrap the last knot's slope to row 0) */
+    const int j1 = circ ? ((idx + 1) & 7) : (idx + 1);
+    const float s_lo = ps[idx * ST], s_hi = ps[j1 * ST];
+    const float A_i = hi - lo;
+    /* ---- other set: only knot[idx], knot[idx + 1] ---- */
+    float mB = __builtin_fmaxf(__builtin_fmaxf(vb[0], vb[1]), vb[2]);
+    hk.template at<12>();
+    mB = __builtin_fmaxf(__builtin_fmaxf(mB, vb[3]), vb[4]);
+    mB = __builtin_fmaxf(__builtin_fmaxf(mB, vb[5]), vb[6]);
+    mB = __builtin_fmaxf(mB, vb[7]);
+    const float nmB = -(mB * k.kL);
+    float F[KB];
+    F[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[0], k.kL, nmB));
+    hk.template at<13>();
+    F[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[1], k.kL, nmB));
+    F[2] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[2], k.kL, nmB));
+    F[3] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[3], k.kL, nmB));
+    hk.template at<14>();
+    F[4] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[4], k.kL, nmB));
+    F[5] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[5], k.kL, nmB));
+    F[6] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[6], k.kL, nmB));
+    hk.template at<15>();
+    F[7] = __builtin_amdgcn_exp2f(__builtin_fmaf(vb[7], k.kL, nmB));
+    F[1] += F[0]; F[2] += F[1]; F[3] += F[2];
+    hk.template at<16>();
+    F[4] += F[3]; F[5] += F[4]; F[6] += F[5]; F[7] += F[6];
+    const float rB = __builtin_amdgcn_rcpf(F[7]);
+    hk.template at<17>();
+    const float gB = SC.sb.gnum * __builtin_fmaf(__builtin_fmaf(-F[7], rB, 1.0f), rB, rB);
+    /* prefix sums (0, F0 .. F7) of the other set, windowed by the same three decisions */
+    const float f0 = g3 ? F[3] : 0.0f, f1 = g3 ? F[4] : F[0], f2 = g3 ? F[5] : F[1];
+    hk.template at<18>();
+    const float f3 = g3 ? F[6] : F[2], f4 = g3 ? F[7] : F[3];
+    const float u0 = gm ? f2 : f0, u1 = gm ? f3 : f1, u2 = gm ? f4 : f2;
+    hk.template at<19>();
+    const float Flo = gl ? u1 : u0;
+    float Fhi = gl ? u2 : u1;
+    hk.template at<20>();
+    const float cb = __builtin_fmaf(idxf, SC.sb.dstep, SC.sb.low);
+    hk.template at<21>();
+    const float b_i = __builtin_fmaf(Flo, gB, cb);
+    float b_ip1 = __builtin_fmaf(Fhi, gB, cb + SC.sb.dstep);
+    float top_b = SC.sb.high;
+    asm volatile("" : "+s"(top_b));                         /* (a load on one arm would turn the select into a branch) */
+    b_ip1 = (g3 && gm && gl) ? top_b : b_ip1;
+    const float B_i = b_ip1 - b_i;
+#else
     const bool g0 = x >= kn[0], g1 = x >= kn[1], g2 = x >= kn[2], g3 = x >= kn[3], g4 = x >= kn[4], g5 = x >= kn[5], g6 = x >= kn[6];
     hk.template at<7>();
     int idx = (g0 ? 1 : 0) + (g1 ? 1 : 0) + (g2 ? 1 : 0) + (g3 ? 1 : 0) + (g4 ? 1 : 0) + (g5 ? 1 : 0) + (g6 ? 1 : 0);
@@ -481,6 +561,7 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     float b_ip1 = __builtin_fmaf(Fhi, gB, cb + SC.sb.dstep);
     b_ip1 = g6 ? SC.sb.high : b_ip1;
     const float B_i = b_ip1 - b_i;
+#endif
     /* ---- derivatives: min_d + softplus(beta s) / beta ---- */
     const float z0 = s_lo * k.kz;                           /* log2(e) beta s_true */
     hk.template at<22>();
@@ -490,6 +571,9 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     const float sm0 = ez0 * __builtin_fmaf(ez0, -0.5f, 1.0f) * 1.44269504088896341f;   /* log1p for tiny arguments */
     hk.template at<23>();
     float l0 = (ez0 < 2.44140625e-4f ? sm0 : lg0) * SC.kout;
+#if BGK_V2_PINSEL
+    asm volatile("" : "+v"(l0));                            /* keeps the identity select below a select where SC.kout is a scalar load */
+#endif
     l0 = z0 > 28.8539008177792681f ? s_lo * k.c2 : l0;      /* beta s > 20: identity (torch softplus threshold) */
     const float d_i = SC.min_d + l0;
     const float z1 = s_hi * k.kz;
@@ -500,6 +584,9 @@ __device__ __forceinline__ float rqs_fast(H hk, float x, const float* pa, const 
     const float sm1 = ez1 * __builtin_fmaf(ez1, -0.5f, 1.0f) * 1.44269504088896341f;
     hk.template at<25>();
     float l1 = (ez1 < 2.44140625e-4f ? sm1 : lg1) * SC.kout;
+#if BGK_V2_PINSEL
+    asm volatile("" : "+v"(l1));                            /* keeps the identity select below a select where SC.kout is a scalar load */
+#endif
     l1 = z1 > 28.8539008177792681f ? s_hi * k.c2 : l1;
     const float d_ip1 = SC.min_d + l1;
     float cw_i, W_i, ch_i, H_i;
