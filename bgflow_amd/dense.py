@@ -393,17 +393,41 @@ def _affine_plan(transformer, y_dim):
         if len(lins) != depth or lins[0].in_features != n_in or lins[-1].out_features != y_dim \
                 or any(m.out_features != H for m in lins[:-1]) or any(m.in_features != H for m in lins[1:]):
             return None
-    if H not in (64, 128) or y_dim > 96 or n_in > 127 or (periodic and n_in % 2):
-        return _reject(transformer, f"hidden width {H} / {y_dim} transformed dims / {n_in} input features: fused for width 64 | 128, "
+    if H > 128 or y_dim > 96 or n_in > 127 or (periodic and n_in % 2):
+        return _reject(transformer, f"hidden width {H} / {y_dim} transformed dims / {n_in} input features: fused for widths up to 128, "
                                     f"<= 96 dims, <= 127 input features")
+    H_run = 64 if H <= 64 else 128                      # other widths run zero-padded to the kernels' 64 / 128 rows
+    if H_run != H:
+        specs = [None if sp is None else (_pad_hidden(sp[0], H_run), sp[1]) for sp in specs]
     params = [p for (ls, _) in live for lin in ls for p in (lin.weight, lin.bias)]
     version = tuple((p.data_ptr(), p._version) for p in params)
     cache = transformer._fused_cache
     if cache.get("version") != version or cache.get("y_dim") != y_dim:
         cache.clear()
-        cache.update(version=version, y_dim=y_dim, hidden=H, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), depth=depth,
+        cache.update(version=version, y_dim=y_dim, hidden=H_run, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), depth=depth,
                      packed=[None if sp is None else (pack_dense_for_affine_h2(sp[0]), sp[1]) for sp in specs])
     return cache
+
+
+class _PaddedLinear:
+    """weight / bias of a Linear zero-padded to (out_to, in_to): the stand-in the packers read.  Padded hidden units have weight 0
+    and bias 0, so they hold act(0) = 0 (SiLU / ReLU / Tanh) and feed zero columns of the next layer: same function."""
+
+    def __init__(self, lin, out_to, in_to):
+        W, b = lin.weight.detach(), lin.bias.detach()
+        self.weight = torch.zeros((out_to, in_to), dtype=W.dtype, device=W.device)
+        self.weight[:W.shape[0], :W.shape[1]] = W
+        self.bias = torch.zeros((out_to,), dtype=b.dtype, device=b.device)
+        self.bias[:b.shape[0]] = b
+        self.in_features, self.out_features = in_to, out_to
+
+
+def _pad_hidden(linears, H):
+    """the Linear chain with every hidden width zero-padded to H (input and output widths unchanged)"""
+    n = len(linears)
+    return tuple(_PaddedLinear(lin, H if i < n - 1 else lin.out_features, H if i > 0 else lin.in_features)
+                 for i, lin in enumerate(linears))
+
 
 
 def _cond_parts(x):
@@ -568,8 +592,9 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
                                         "SiLU / ReLU / Tanh")
         return None
     (l0, l1, l2), act = spec
-    if l0.out_features != 128 or l1.out_features != 128:
-        return _reject(transformer, f"hidden layers ({l0.out_features}, {l1.out_features}): only (128, 128) is fused")
+    if l0.out_features > 128 or l1.out_features > 128:
+        return _reject(transformer, f"hidden layers ({l0.out_features}, {l1.out_features}): widths up to 128 are fused")
+    padded = (l0.out_features, l1.out_features) != (128, 128)    # narrower hidden layers run zero-padded to the kernels' 128 rows
     if y_dim > 64:
         return _reject(transformer, f"{y_dim} transformed dims: at most 64 are fused")
     n_nc = int((nc_slot_host >= 0).sum())
@@ -597,7 +622,9 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
         stale = True
     if stale:
         common = dict(version=version, y_dim=y_dim, mode=mode, device=dev, act=act, periodic=periodic, d_c=d_c, n_bins=n_bins,
-                      circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
+                      padded=padded, circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
+        if padded:
+            l0, l1, l2 = _pad_hidden((l0, l1, l2), 128)
         if mode == "bf16" and dev.type != "cuda":
             return None
         if mode == "bf16" or (mode == "f16x2" and DEVICE_PACK and dev.type == "cuda"):
@@ -874,7 +901,7 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
         return None
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
     if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device \
-            or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
+            or plan.get("padded") or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
         return None                                        # second-generation kernel, the others on the first-generation one
     _lib.require_hip(x, y)
     if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel stats of the default bench command + HBM traffic / SQ counters
 # of the dominant kernel.  Outputs land in gpurun_out/prof_$1; copy the summaries to profiles/ afterwards (tools/profile_copy.sh).
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -9,6 +9,11 @@ SHORT="--no-cpu-baseline --kl-steps 0"
 # 1. kernel trace + stats of the bench command (default flags except the CPU leg / KL extra, which launch no hot-path kernels)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py $SHORT > $OUT/bench_under_rocprof.log 2>&1
 grep '"metric"' $OUT/bench_under_rocprof.log > $OUT/bench_line_under_rocprof.json
+# 1b. the headline workload alone (no cfg 2 / cfg 5 / exact-f32 legs): the dominant kernel's average here is the one bench.py's
+#     roofline.avg_launch_ms must agree with (the full command's average mixes in cfg 5's wider layers)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg3 -o cfg3 -- python bench.py $SHORT --no-extras > $OUT/cfg3_under_rocprof.log 2>&1
+grep '"metric"' $OUT/cfg3_under_rocprof.log > $OUT/cfg3_line_under_rocprof.json
+cp $(find $OUT/stats_cfg3 -name "*kernel_stats.csv" | head -1) $OUT/cfg3_kernel_stats.csv
 # 2. PMC passes (separate runs, counters only) over the headline workload, 2 steps: HBM traffic of every kernel
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python bench.py $SHORT --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python bench.py $SHORT --no-extras --steps 2 --warmup 1 > /dev/null 2>&1
