@@ -228,6 +228,64 @@ def test_envelope_warnings(hip_lib, dev):
     assert len(msgs) == 1 and "(256, 256)" in msgs[0]
 
 
+@pytest.mark.parametrize("hidden", [(64, 64), (32, 96), (100, 100)])
+@pytest.mark.parametrize("mode", ["f16x2", "f32", "bf16"])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_spline_coupling_with_narrow_hidden_layers_runs_fused(hip_lib, dev, hidden, mode, inverse):
+    """hidden widths below 128 run on the one-launch kernels zero-padded to 128 (padded units hold act(0) = 0): same function as the
+    conditioner evaluated layer by layer, checked against the f64 oracle"""
+    import warnings
+    from bgflow_amd import configs
+    from bgflow_amd.utils import hash_init_, synth
+    from oracle import flow_oracle as fo
+    dims = {"BONDS": 17, "ANGLES": 17, "TORSIONS": 17, "FIXED": 9}
+    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+    for what, on in (("TORSIONS", "FIXED"), ("BONDS", "TORSIONS")):
+        layer_cpu = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, hidden=hidden))
+        layer = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, hidden=hidden)).to(dev)
+        layer.transformer.gemm_mode = mode
+        B = 1037
+        xs = [synth(B + 7 * i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9))]
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                     # a rejection (RuntimeWarning) would mean the generic path ran
+            with torch.no_grad():
+                *outs, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
+        assert layer.transformer._fused_cache.get("padded"), "the zero-padded fused path must have run"
+        ti = slot[what]
+        outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, [])
+        tol = 1e-2 if mode == "bf16" else 2e-5                 # bf16: the reduced-precision mode (weights and GEMM inputs in bf16)
+        np.testing.assert_allclose(outs[ti].cpu().numpy(), outs64[ti], rtol=0, atol=tol)
+        np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=tol, atol=tol)
+    # training falls back to the layer-by-layer conditioner (the weight-gradient kernels take width 128 only): gradients flow
+    layer.transformer.gemm_mode = "f16x2"
+    xs_t = [t(v, dev) for v in xs]
+    *_, dl_t = layer(*xs_t, inverse=inverse)
+    dl_t.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("H,acts", [(32, ("ReLU", "Tanh")), (48, ("SiLU", "SiLU")), (96, ("SiLU", "SiLU")), (100, ("ReLU", "Tanh"))])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_coupling_with_other_hidden_widths_runs_fused(hip_lib, dev, H, acts, inverse):
+    """hidden widths other than 64 / 128 run on the affine kernels zero-padded (<= 64 on the weight-resident kernel, else width 128)"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_, synth
+    from oracle import flow_oracle as fo
+    mk = lambda: hash_init_(bg.CouplingFlow(bg.AffineTransformer(                               # noqa: E731
+        bg.DenseNet([12, H, H, 20], getattr(torch.nn, acts[0])()), bg.DenseNet([12, H, H, 20], getattr(torch.nn, acts[1])())),
+        transformed_indices=(1,), cond_indices=(0,)))
+    layer_cpu, layer = mk(), mk().to(dev)
+    B = 2111
+    xs = [synth(B + 3 * i, B, d) for i, d in enumerate((12, 20))]
+    with torch.no_grad():
+        _, y, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
+    assert layer.transformer._fused_cache and layer.transformer._fused_cache["hidden"] == (64 if H <= 64 else 128)
+    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, [])
+    np.testing.assert_allclose(y.cpu().numpy(), outs64[1], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=2e-5, atol=2e-5)
+
+
 # ---------------------------------------------------------------------------------------------------
 # f-3: priors / targets / weights on kernels
 # ---------------------------------------------------------------------------------------------------
