@@ -92,8 +92,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     {
-        /* the gradient rows are far apart in memory (one 32-byte piece of 32 different rows per load instruction): keep
-         * four k16-steps of B values in flight in a register ring so that the HBM / L2 latency hides behind the MFMAs */
+        /* the gradient rows are far apart in memory (one 32-byte piece of 32 different rows per load instruction) */
         const float* grow = a.g + (b0 + (j < rows ? j : 0)) * a.ldg;
         const bool live = j < rows;
         auto load_g = [&](int s, float (&v)[8]) {
@@ -107,20 +106,35 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
                 for (int e = 0; e < 8; ++e) v[e] = (live && k0 + e < a.P) ? grow[k0 + e] : 0.0f;
             }
         };
-        float ring[4][8];
+        /* Loads return in order on this part: an operand load (L2 hit) queued behind a gradient load (HBM) waits for it, so a
+         * gradient ring refilled one k-step at a time stalls EVERY step for most of an HBM round trip, whatever its depth.  Here the
+         * operand fragments of step s + 1 are requested before the MFMAs of step s (two fragment sets), and the gradient values of
+         * the next DG k-steps as one batch right behind the group's last operand request: the operand loads never queue behind a
+         * fresh gradient request, and a group waits for its gradients once. */
+#ifndef BGK_DBWD_DG
+#define BGK_DBWD_DG 4
+#endif
+        constexpr int DG = BGK_DBWD_DG;
+        static_assert(DG % 2 == 0, "fragment set parity follows the position in the group");
+        float ring[DG][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) load_g(u, ring[u]);
-        for (int s0 = 0; s0 < a.S2; s0 += 4) {
+        for (int u = 0; u < DG; ++u) load_g(u, ring[u]);
+        H2A<4> fr[2];
+        h2a_load<4>(fr[0], a.T2, 0, lane);
+        for (int s0 = 0; s0 < a.S2; s0 += DG) {
+            h2_h16x8 bhi[DG], blo[DG];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < DG; ++u) h2_split8(ring[u], bhi[u], blo[u]);
+#pragma unroll
+            for (int u = 0; u < DG; ++u) {
                 const int s = s0 + u;
                 if (s < a.S2) {
-                    H2A<4> fr;
-                    h2a_load<4>(fr, a.T2, s, lane);
-                    h2_h16x8 bhi, blo;
-                    h2_split8(ring[u], bhi, blo);
-                    load_g(s + 4, ring[u]);
-                    h2_mfma3<4>(acc, fr, bhi, blo);
+                    if (s + 1 < a.S2) h2a_load<4>(fr[(u + 1) & 1], a.T2, s + 1, lane);
+                    if (u == DG - 1 || s + 1 == a.S2) {
+#pragma unroll
+                        for (int v = 0; v < DG; ++v) load_g(s0 + DG + v, ring[v]);
+                    }
+                    h2_mfma3<4>(acc, fr[u & 1], bhi[u], blo[u]);
                 }
             }
         }
