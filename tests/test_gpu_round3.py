@@ -265,6 +265,31 @@ def test_spline_coupling_with_narrow_hidden_layers_runs_fused(hip_lib, dev, hidd
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters() if p.requires_grad)
 
 
+@pytest.mark.parametrize("d,d_c,circ", [(40, 12, False), (64, 30, False), (64, 9, True), (33, 66, False)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_spline_coupling_many_transformed_dims(hip_lib, dev, d, d_c, circ, inverse):
+    """the upper end of the fused spline kernel's envelope: up to 64 transformed dims (13 parameter chunks, one workgroup per CU) and a
+    conditioner input wider than the layer-0 tile of the builder's layers"""
+    import warnings
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_, synth
+    from oracle import flow_oracle as fo
+    P = 3 * 8 * d + (0 if circ else d)
+    mk = lambda: hash_init_(bg.CouplingFlow(bg.ConditionalSplineTransformer(                       # noqa: E731
+        bg.DenseNet([d_c, 128, 128, P], activation=torch.nn.SiLU()), is_circular=circ), transformed_indices=(1,), cond_indices=(0,)))
+    layer_cpu, layer = mk(), mk().to(dev)
+    B = 777
+    xs = [synth(B, B, d_c), synth(B + 5, B, d, uniform=True)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with torch.no_grad():
+            _, y, dl = layer(*[t(v, dev) for v in xs], inverse=inverse)
+    assert layer.transformer._fused_cache, "the fused path must have run"
+    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, [])
+    np.testing.assert_allclose(y.cpu().numpy(), outs64[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=5e-5, atol=5e-5)
+
+
 @pytest.mark.parametrize("H,acts", [(32, ("ReLU", "Tanh")), (48, ("SiLU", "SiLU")), (96, ("SiLU", "SiLU")), (100, ("ReLU", "Tanh"))])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_affine_coupling_with_other_hidden_widths_runs_fused(hip_lib, dev, H, acts, inverse):
