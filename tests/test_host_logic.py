@@ -689,3 +689,45 @@ def test_ic_helper_functions_and_wrap_distances():
     wd = bg.WrapDistances(Probe(), indices=np.arange(1, 10))
     wd(x)
     assert torch.allclose(seen["f"], torch.tensor([[7.0, 9.0, 3.0, 4.0, 5.0]]))
+
+
+def test_logdet_accumulator_and_catview_host_semantics():
+    """flow._LogDetAcc / flow.CatView: the plumbing behind the running log-det and the unconcatenated conditioner inputs (CPU tensors:
+    no kernel involved)"""
+    from bgflow_amd.flow import _LogDetAcc, CatView, as_tensor
+    acc = _LogDetAcc(5, torch.device("cpu"))
+    buf, accumulate = acc.peek()
+    assert accumulate is False and not acc.started            # peek does not mark the buffer written
+    acc.add(None)
+    acc.add(acc)                                              # a block that wrote in its own kernel returns the accumulator itself
+    assert not acc.started
+    acc.add(torch.arange(5.0).reshape(5, 1))                  # a third-party block's [B, 1] term: first writer copies
+    acc.add(2.0)                                              # scalar terms (SetConstantFlow-style) are added
+    buf2, accumulate = acc.target()
+    assert accumulate is True and buf2 is buf
+    assert torch.equal(acc.result(), (torch.arange(5.0) + 2.0)[:, None])
+    fresh = _LogDetAcc(3, torch.device("cpu"))
+    assert torch.equal(fresh.result(), torch.zeros(3, 1))     # a pass without any log-det term is zero, not garbage
+    a, b = torch.randn(4, 3), torch.randn(4, 2)
+    cv = CatView([a, b])
+    assert cv.shape[-1] == 5 and torch.equal(cv.cat(), torch.cat([a, b], -1)) and torch.equal(as_tensor(cv), cv.cat())
+    assert as_tensor(a) is a
+
+
+def test_zero_padded_hidden_layers_compute_the_same_function():
+    """dense._pad_hidden: the stand-in layers the packers read for hidden widths below the kernels' 64 / 128 rows"""
+    import bgflow_amd as bg
+    from bgflow_amd.dense import _pad_hidden
+    for act in (torch.nn.SiLU(), torch.nn.ReLU(), torch.nn.Tanh()):
+        net = bg.DenseNet([9, 32, 96, 40], activation=act)
+        lins = [m for m in net._layers if isinstance(m, torch.nn.Linear)]
+        padded = _pad_hidden(lins, 128)
+        assert [tuple(p.weight.shape) for p in padded] == [(128, 9), (128, 128), (40, 128)]
+        x = torch.randn(6, 9)
+        h = x
+        for i, p in enumerate(padded):
+            h = h @ p.weight.T + p.bias
+            if i < 2:
+                h = act(h)
+                assert torch.count_nonzero(h[:, lins[i].out_features:]) == 0      # padded units hold act(0) = 0
+        assert torch.allclose(h, net(x), atol=1e-6)
