@@ -397,13 +397,13 @@ def _affine_plan(transformer, y_dim):
         return _reject(transformer, f"hidden width {H} / {y_dim} transformed dims / {n_in} input features: fused for widths up to 128, "
                                     f"<= 96 dims, <= 127 input features")
     H_run = 64 if H <= 64 else 128                      # other widths run zero-padded to the kernels' 64 / 128 rows
-    if H_run != H:
-        specs = [None if sp is None else (_pad_hidden(sp[0], H_run), sp[1]) for sp in specs]
     params = [p for (ls, _) in live for lin in ls for p in (lin.weight, lin.bias)]
     version = tuple((p.data_ptr(), p._version) for p in params)
     cache = transformer._fused_cache
     if cache.get("version") != version or cache.get("y_dim") != y_dim:
         cache.clear()
+        if H_run != H:                                  # (only when the weights changed: the padded copies live in the packed operands)
+            specs = [None if sp is None else (_pad_hidden(sp[0], H_run), sp[1]) for sp in specs]
         cache.update(version=version, y_dim=y_dim, hidden=H_run, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), depth=depth,
                      packed=[None if sp is None else (pack_dense_for_affine_h2(sp[0]), sp[1]) for sp in specs])
     return cache
