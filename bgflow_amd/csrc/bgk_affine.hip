@@ -78,6 +78,7 @@ extern "C" int bgk_affine_transform(const float* y, int64_t ldy, const float* mu
                                     int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                                     int64_t B, int32_t d, float* out, int64_t ldo, float* dlogp,
                                     int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && d > 0, "bgk_affine_transform: bad sizes B=%lld d=%d", (long long)B, d);
     BGK_CHECK_ARG(y && out && dlogp, "bgk_affine_transform: null pointer");
     BGK_CHECK_ARG(!(s_raw && !log_alpha), "bgk_affine_transform: s_raw given without log_alpha");

@@ -107,6 +107,7 @@ extern "C" int bgk_affine_backward(const float* y, int64_t ldy, const float* mu,
                                    const float* g_dlogp, float* g_y, int64_t ldgy, float* g_mu,
                                    int64_t ldgmu, float* g_s, int64_t ldgs, float* g_log_alpha,
                                    void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     (void)is_circular;   /* d(o mod 1)/do = 1 */
     BGK_CHECK_ARG(B >= 0 && d > 0 && d <= 8192, "bgk_affine_backward: bad sizes B=%lld d=%d", (long long)B, d);
     BGK_CHECK_ARG(y && g_out && g_dlogp && g_y, "bgk_affine_backward: null pointer");

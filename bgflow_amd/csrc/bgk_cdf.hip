@@ -92,6 +92,7 @@ __global__ __launch_bounds__(CDF_THREADS) void cdf_kernel(CdfArgs a) {
 extern "C" int bgk_cdf_transform(const float* x, int64_t ldx, const float* desc, int64_t B, int32_t d,
                                  int32_t inverse, int32_t use_eps, float eps, float* out, int64_t ldo,
                                  float* dlogp, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && d > 0 && d <= 8192 && x && desc && out && dlogp, "bgk_cdf_transform: bad arguments");
     if (B == 0) return 0;
     CdfArgs a{x, ldx, desc, B, d, inverse, use_eps, eps, out, ldo, dlogp, accumulate, 0};
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(CDF_THREADS) void cdf_bwd_kernel(CdfBwdArgs a) {
 extern "C" int bgk_cdf_backward(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* desc, int64_t B, int32_t d,
                                 int32_t inverse, int32_t use_eps, float eps, const float* g_y, int64_t ldgy,
                                 const float* g_dlogp, float* g_x, int64_t ldgx, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && d > 0 && x && y && desc && g_y && g_dlogp && g_x, "bgk_cdf_backward: bad arguments");
     if (B == 0) return 0;
     CdfBwdArgs a{x, ldx, y, ldy, desc, B, d, inverse, use_eps, eps, g_y, ldgy, g_dlogp, g_x, ldgx};

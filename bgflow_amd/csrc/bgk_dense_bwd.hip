@@ -256,6 +256,7 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
                                      const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
                                      int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
                                      float* g_cond, int64_t ldgc, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(g && z1 && z0 && T0 && T1 && T2 && cs && g_z1 && g_z0, "bgk_dense_backward_dx: null pointer");
     BGK_CHECK_ARG((h1 == nullptr) == (h0 == nullptr), "bgk_dense_backward_dx: h1 and h0 are written both or not at all");
     BGK_CHECK_ARG(B >= 0 && P > 0 && ldg >= P && d_c > 0 && act >= 1 && act <= 3, "bgk_dense_backward_dx: bad sizes");

@@ -177,16 +177,16 @@ extern "C" int bgk_energy_fields(const float* const* x, const int64_t* ldx, cons
                                  double temperature, double c_in, double c_out, float* u,
                                  const float* dlogp, int32_t drop_nonfinite, float* partial, int32_t nblk, double* loss_sums,
                                  void* stream) {
-    BGK_CHECK_ARG(u && B >= 0 && temperature > 0.0, "bgk_energy_fields: bad arguments");
+    BGK_CHECK_ARG((u || B == 0) && B >= 0 && temperature > 0.0, "bgk_energy_fields: bad arguments");
     BGK_CHECK_ARG(!loss_sums || (dlogp && partial && nblk >= 1), "bgk_energy_fields: the loss sums need dlogp and a [nblk, 2] workspace");
-    EArgs a{};
-    const int st = fill_fields("bgk_energy_fields", a.f, n_fields, x, ldx, d, kind, param, coef);
-    if (st) return st;
     hipStream_t s = (hipStream_t)stream;
-    if (B == 0) {
+    if (B == 0) {               /* an empty batch (its tensors have no storage: null pointers): the loss sums are zero */
         if (loss_sums) { hipError_t e = hipMemsetAsync(loss_sums, 0, 2 * sizeof(double), s); if (e != hipSuccess) return (int)e; }
         return 0;
     }
+    EArgs a{};
+    const int st = fill_fields("bgk_energy_fields", a.f, n_fields, x, ldx, d, kind, param, coef);
+    if (st) return st;
     a.n = n_fields; a.B = B; a.inv_t = (float)(1.0 / temperature); a.c_in = (float)c_in; a.c_out = (float)c_out; a.u = u;
     a.dlogp = loss_sums ? dlogp : nullptr; a.drop_nonfinite = drop_nonfinite; a.partial = loss_sums ? partial : nullptr;
     const int64_t n_tiles = (B + NE_ROWS - 1) / NE_ROWS;
@@ -204,10 +204,10 @@ extern "C" int bgk_energy_fields_backward(const float* const* x, const int64_t* 
                                           float* const* g_x, const int64_t* ldg, void* stream) {
     BGK_CHECK_ARG(B >= 0 && temperature > 0.0 && g_x && ldg, "bgk_energy_fields_backward: bad arguments");
     BGK_CHECK_ARG(g_u || (g_scalar && u && dlogp), "bgk_energy_fields_backward: need g_u [B] or (g_scalar, u, dlogp)");
+    if (B == 0) return 0;
     EField tmp[NE_MAXF];
     const int st = fill_fields("bgk_energy_fields_backward", tmp, n_fields, x, ldx, d, kind, param, coef);
     if (st) return st;
-    if (B == 0) return 0;
     EBwdArgs a{};
     int64_t total = 0;
     for (int i = 0; i < n_fields; ++i) {
@@ -226,6 +226,7 @@ extern "C" int bgk_energy_fields_backward(const float* const* x, const int64_t* 
 /* the single-field forms of round 2 (ABI kept) */
 extern "C" int bgk_normal_energy(const float* x, int64_t ldx, const float* mean, int32_t d, int64_t B,
                                  double temperature, double log_z, float* u, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(x && u, "bgk_normal_energy: null pointer");
     const int32_t kind = 0;
     return bgk_energy_fields(&x, &ldx, &d, &kind, &mean, nullptr, 1, B, temperature, 0.0, log_z, u, nullptr, 0, nullptr, 0, nullptr, stream);
@@ -233,6 +234,7 @@ extern "C" int bgk_normal_energy(const float* x, int64_t ldx, const float* mean,
 
 extern "C" int bgk_normal_energy_backward(const float* x, int64_t ldx, const float* mean, int32_t d, int64_t B,
                                           double temperature, const float* g_u, float* g_x, int64_t ldg, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(x && g_u && g_x, "bgk_normal_energy_backward: null pointer");
     const int32_t kind = 0;
     return bgk_energy_fields_backward(&x, &ldx, &d, &kind, &mean, nullptr, 1, B, temperature, g_u, nullptr, nullptr, nullptr, 0, nullptr,

@@ -1172,6 +1172,7 @@ extern "C" int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_
                                       double min_derivative, int32_t identity_init, float* out,
                                       int64_t ldo, float* dlogp, int32_t accumulate,
                                       int32_t* bin_idx, int32_t* oob_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(cond && W0p && W1p && W2p && y && out && dlogp, "bgk_coupling_rqs_dense: null pointer");
     BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "bgk_coupling_rqs_dense: bad sizes");
     if (H0 != HID || H1 != HID || K != KB || d > 64 || act < 1 || act > 3) {
@@ -1312,6 +1313,7 @@ extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t
                                          double min_derivative, int32_t identity_init, float* out,
                                          int64_t ldo, float* dlogp, int32_t accumulate,
                                          int32_t* bin_idx, int32_t* oob_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     return launch_h2("bgk_coupling_rqs_dense_h2", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, operand_dtype, H0, H1, act, y, ldy, B, d, K,
                      circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
                      identity_init, out, ldo, dlogp, accumulate, bin_idx, oob_count,
@@ -1329,6 +1331,7 @@ extern "C" int bgk_coupling_rqs_dense_h2_mc(const float* const* cond, const int6
                                             double min_derivative, int32_t identity_init, float* out,
                                             int64_t ldo, float* dlogp, int32_t accumulate,
                                             int32_t* bin_idx, int32_t* oob_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(cond && ldc && width && n_cond >= 1 && n_cond <= BGK_MAX_COND, "bgk_coupling_rqs_dense_h2_mc: 1..%d conditioning tensors", BGK_MAX_COND);
     BgkCondSegs segs{};
     int d_c = 0;
@@ -1352,6 +1355,7 @@ extern "C" int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, i
                                                int64_t ldo, float* dlogp, int32_t accumulate,
                                                int32_t* oob_count, float* z0, float* z1, float* params, int64_t ldp,
                                                const int32_t* src_col_dev, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(z0 && z1 && params && src_col_dev, "bgk_coupling_rqs_dense_h2_train: null save buffer");
     const int n_nc = d - __builtin_popcountll(circ_mask & (d >= 64 ? ~0ull : ((1ull << d) - 1)));
     BGK_CHECK_ARG(ldp >= 3 * K * d + n_nc, "bgk_coupling_rqs_dense_h2_train: params row stride %lld too small", (long long)ldp);

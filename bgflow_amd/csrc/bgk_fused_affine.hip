@@ -613,6 +613,7 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
                                             int32_t is_circular, int32_t inverse,
                                             const float* y, int64_t ldy, int64_t B, int32_t d,
                                             float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     return affine_dense_launch(cond, ldc, d_c, periodic, sA0, sA1, nullptr, sA2, sc0, sc1, 1.0f, sc2, s_act,
                                tA0, tA1, nullptr, tA2, tc0, tc1, 1.0f, tc2, t_act, hidden, log_alpha, preserve_volume, is_circular, inverse,
                                y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
@@ -627,6 +628,7 @@ extern "C" int bgk_coupling_affine_dense_h3(const float* cond, int64_t ldc, int3
                                             int32_t is_circular, int32_t inverse,
                                             const float* y, int64_t ldy, int64_t B, int32_t d,
                                             float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG((sA0 == nullptr || sA1b) && (tA0 == nullptr || tA1b), "bgk_coupling_affine_dense_h3: missing third hidden layer");
     return affine_dense_launch(cond, ldc, d_c, periodic, sA0, sA1, sA1b, sA2, sc0, sc1, sc1b, sc2, s_act,
                                tA0, tA1, tA1b, tA2, tc0, tc1, tc1b, tc2, t_act, hidden, log_alpha, preserve_volume, is_circular, inverse,
@@ -653,6 +655,7 @@ extern "C" int bgk_coupling_affine_dense_h2_mc(const float* const* cond, const i
                                                int32_t is_circular, int32_t inverse,
                                                const float* y, int64_t ldy, int64_t B, int32_t d,
                                                float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BgkCondSegs segs{};
     int d_c = 0;
     const int st = affine_mc(cond, ldc, width, n_cond, segs, d_c);
@@ -671,6 +674,7 @@ extern "C" int bgk_coupling_affine_dense_h3_mc(const float* const* cond, const i
                                                int32_t is_circular, int32_t inverse,
                                                const float* y, int64_t ldy, int64_t B, int32_t d,
                                                float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG((sA0 == nullptr || sA1b) && (tA0 == nullptr || tA1b), "bgk_coupling_affine_dense_h3_mc: missing third hidden layer");
     BgkCondSegs segs{};
     int d_c = 0;

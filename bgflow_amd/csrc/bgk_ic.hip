@@ -727,6 +727,7 @@ extern "C" int bgk_ic_xyz2ic(const float* x, int64_t ldx, const int32_t* zmat, i
                              float* bonds, float* angles, float* torsions, int64_t ldic,
                              float* xfix, int64_t ldf, float* dlogp, int32_t accumulate,
                              int32_t* warn_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_ic_xyz2ic: bad sizes");
     BGK_CHECK_ARG(x && zmat && fixed && bonds && angles && torsions && xfix && dlogp, "bgk_ic_xyz2ic: null pointer");
     BGK_CHECK_ARG(Twhiten ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_ic_xyz2ic: bad whitening arguments");
@@ -747,6 +748,7 @@ extern "C" int bgk_ic_ic2xyz(const float* bonds, const float* angles, const floa
                              const float* wh_mean, const float* Tblacken, int32_t keep,
                              float jac_xz, int64_t B, float* x, int64_t ldx, float* dlogp,
                              int32_t accumulate, int32_t* warn_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_ic_ic2xyz: bad sizes");
     BGK_CHECK_ARG(x && place && fixed && bonds && angles && torsions && xfix && dlogp, "bgk_ic_ic2xyz: null pointer");
     BGK_CHECK_ARG(Tblacken ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_ic_ic2xyz: bad whitening arguments");
@@ -769,6 +771,7 @@ extern "C" int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const fl
                                int32_t normalize_angles, float eps, int32_t enforce_boundaries,
                                const float* wh_mean, const float* Tblacken, int32_t keep, float jac_xz, int64_t B,
                                float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_icdf_ic2xyz: bad sizes");
     BGK_CHECK_ARG(x && place && fixed && bonds && angles && torsions && xfix && dlogp, "bgk_icdf_ic2xyz: null pointer");
     BGK_CHECK_ARG(Tblacken ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_icdf_ic2xyz: bad whitening arguments");
@@ -804,6 +807,7 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
                                       int64_t B, const float* g_x, int64_t ldgx, const float* g_dlogp,
                                       float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,
                                       float* g_xfix, int64_t ldgf, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_ic_ic2xyz_backward: bad sizes");
     BGK_CHECK_ARG(bonds && angles && torsions && x && place && fixed && g_x && g_dlogp && g_bonds && g_angles &&
                   g_torsions && g_xfix, "bgk_ic_ic2xyz_backward: null pointer");
@@ -828,6 +832,7 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
 
 extern "C" int bgk_ic_refsys(const float* in, int64_t B, int32_t inverse, int32_t normalize_angles, float eps,
                              int32_t enforce_boundaries, float* out, float* dlogp, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && in && out && dlogp, "bgk_ic_refsys: bad arguments");
     if (B == 0) return 0;
     RefSysArgs a{in, out, dlogp, B, inverse, normalize_angles, enforce_boundaries, accumulate, eps};

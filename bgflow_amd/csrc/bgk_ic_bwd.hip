@@ -278,6 +278,7 @@ extern "C" int bgk_ic_xyz2ic_backward(const float* x, int64_t ldx, const int32_t
                                       const float* g_bonds, const float* g_angles, const float* g_torsions, int64_t ldgic,
                                       const float* g_xfix, int64_t ldgf, const float* g_dlogp,
                                       float* g_x, int64_t ldgx, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_ic_xyz2ic_backward: bad sizes");
     BGK_CHECK_ARG(x && zmat && fixed && g_bonds && g_angles && g_torsions && g_xfix && g_dlogp && g_x, "bgk_ic_xyz2ic_backward: null pointer");
     BGK_CHECK_ARG(Twhiten ? keep > 0 : keep == 3 * n_fixed, "bgk_ic_xyz2ic_backward: bad whitening arguments");
@@ -301,6 +302,7 @@ extern "C" int bgk_ic_xyz2ic_backward(const float* x, int64_t ldx, const int32_t
 
 extern "C" int bgk_ic_refsys_backward(const float* in, const float* g_out, const float* g_dlogp, int64_t B, int32_t inverse,
                                       int32_t normalize_angles, float eps, int32_t enforce_boundaries, float* g_in, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && in && g_out && g_dlogp && g_in, "bgk_ic_refsys_backward: bad arguments");
     if (B == 0) return 0;
     RefBwdArgs a{in, g_out, g_dlogp, g_in, B, inverse, normalize_angles, enforce_boundaries, eps};

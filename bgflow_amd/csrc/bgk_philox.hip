@@ -111,6 +111,7 @@ __global__ __launch_bounds__(PW * 64) void philox_fields_kernel(PArgs a) {
 extern "C" int bgk_philox_fields(uint64_t seed, uint32_t offset, int64_t row0, int32_t n_fields, float* const* out, const int64_t* ldo,
                                  const int32_t* d, const int32_t* kind, const float* const* p0, const float* const* p1,
                                  const float* scale, const float* e_const, double c_out, int64_t B, float* energy, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(n_fields >= 1 && n_fields <= PH_MAXF && out && ldo && d && kind && B >= 0 && row0 >= 0, "bgk_philox_fields: bad arguments");
     if (B == 0) return 0;
     PArgs a{};

@@ -54,6 +54,10 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 extern "C" int bgk_column_sum(const float* x, int64_t ldx, int64_t B, int32_t P, float* partial, int32_t nblk,
                               float* out, void* stream) {
+    if (B == 0) {               /* the sum over an empty batch is zero (x has no storage: null pointer) */
+        if (out && P > 0 && hipMemsetAsync(out, 0, sizeof(float) * (size_t)P, (hipStream_t)stream) != hipSuccess) return BGK_EINVAL;
+        return 0;
+    }
     BGK_CHECK_ARG(x && partial && out, "bgk_column_sum: null pointer");
     BGK_CHECK_ARG(B >= 0 && P > 0 && nblk > 0 && ldx >= P, "bgk_column_sum: bad sizes");
     hipStream_t st = (hipStream_t)stream;

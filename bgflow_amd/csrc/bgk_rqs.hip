@@ -182,6 +182,7 @@ extern "C" int bgk_rqs_transform(const float* y, int64_t ldy, const float* param
                                  double min_derivative, int32_t identity_init, float* out,
                                  int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx,
                                  int32_t* oob_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && d > 0 && K > 0, "bgk_rqs_transform: bad sizes B=%lld d=%d K=%d", (long long)B, d, K);
     BGK_CHECK_ARG(K <= 64, "bgk_rqs_transform: n_bins=%d > 64 unsupported", K);
     BGK_CHECK_ARG(y && params && nc_slot && out && dlogp, "bgk_rqs_transform: null pointer");

@@ -221,6 +221,7 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
                                 int32_t identity_init, const float* g_out, int64_t ldgo,
                                 const float* g_dlogp, float* g_y, int64_t ldgy, float* g_params,
                                 int64_t ldgp, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && d > 0 && K > 0, "bgk_rqs_backward: bad sizes");
     BGK_CHECK_ARG(y && params && nc_slot && g_out && g_dlogp && g_y && g_params, "bgk_rqs_backward: null pointer");
     BGK_CHECK_ARG(P >= 3 * K * d && P <= 3 * K * d + d && ldp >= P && ldgp >= P, "bgk_rqs_backward: bad params width %d", P);

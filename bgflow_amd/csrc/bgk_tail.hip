@@ -438,9 +438,18 @@ __device__ __forceinline__ void dma_tile(float* dst, const float* __restrict__ s
         const int e = c * 64 + lane * 4;
         __builtin_amdgcn_global_load_lds((gvp_t)(src + (e + 3 < valid ? e : 0)), (lvp_t)(dst + c * 64), 16, 0, 0);
     }
+    const int covered = c * 64;                       /* floats the 16-byte requests above cover */
     for (; c < w; ++c) {                              /* 256 B per instruction */
         const int e = c * 64 + lane;
         __builtin_amdgcn_global_load_lds((gvp_t)(src + (e < valid ? e : 0)), (lvp_t)(dst + c * 64), 4, 0, 0);
+    }
+    /* a partial tile whose valid length is not a multiple of 4: the 16-byte piece straddling its end was redirected to the tile's
+     * start as a whole (reading it would run past the tensor); its 1..3 valid floats follow here, one dword each (requests of a wave
+     * land in order, so these overwrite the redirected piece) */
+    const int edge = valid & ~3;
+    if (edge < valid && edge < covered) {
+        const int e = edge + lane;
+        if (e < valid) __builtin_amdgcn_global_load_lds((gvp_t)(src + e), (lvp_t)(dst + edge), 4, 0, 0);
     }
 }
 
@@ -861,6 +870,7 @@ extern "C" int bgk_icdf_ic2xyz_reg(const float* bonds, const float* angles, cons
                                    float eps, int32_t enforce_boundaries,
                                    const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
                                    float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_icdf_ic2xyz_reg: bad sizes");
     BGK_CHECK_ARG(x && place && fixed && bonds && angles && torsions && xfix && dlogp && desc20, "bgk_icdf_ic2xyz_reg: null pointer");
     BGK_CHECK_ARG(Tblacken ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_icdf_ic2xyz_reg: bad whitening arguments");
@@ -892,6 +902,7 @@ extern "C" int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, cons
                                    float eps, int32_t enforce_boundaries,
                                    const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
                                    float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_icdf_ic2xyz_uni: bad sizes");
     BGK_CHECK_ARG(x && place8 && fixed && bonds && angles && torsions && xfix && dlogp && desc4, "bgk_icdf_ic2xyz_uni: null pointer");
     BGK_CHECK_ARG(Tblacken ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_icdf_ic2xyz_uni: bad whitening arguments");
@@ -931,6 +942,7 @@ extern "C" int bgk_xyz2ic_cdf_uni(const float* x, const float* desc4, int32_t us
                                   const float* wh_mean, const float* Twhiten, int32_t keep, double const_ld, int64_t B,
                                   float* bonds, float* angles, float* torsions, float* xfix,
                                   float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_xyz2ic_cdf_uni: bad sizes");
     BGK_CHECK_ARG(x && zmat8 && fixed && bonds && angles && torsions && xfix && dlogp && desc4, "bgk_xyz2ic_cdf_uni: null pointer");
     BGK_CHECK_ARG(Twhiten ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_xyz2ic_cdf_uni: bad whitening arguments");

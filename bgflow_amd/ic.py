@@ -192,12 +192,12 @@ class _XYZ2ICFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         rel, whiten = ctx.rel, ctx.whiten
         dev = x.device
-        x2, ldx = _lib.rowmajor(x.reshape(x.shape[0], -1))
+        x2, ldx = _lib.rowmajor(x.flatten(1))
         B, n, nf = x2.shape[0], rel._n, rel._n_fixed
         (gb2, ga2, gt2), ldgic = _contig_rows(g_b, g_a, g_t)
         T = None if whiten is None else whiten[1]
         keep = 3 * nf if T is None else T.shape[1]
-        gf2, ldgf = _lib.rowmajor(g_f.reshape(B, -1).contiguous())
+        gf2, ldgf = _lib.rowmajor(g_f.flatten(1).contiguous())
         g_dl = g_dlogp.reshape(-1).contiguous()
         g_x = torch.empty((B, 3 * (n + nf)), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -313,7 +313,7 @@ class RelativeInternalCoordinateTransformation(Flow):
 
     def _xyz2ic_launch(self, x, whiten=None, acc=None):
         dev = x.device
-        x2, ldx = _lib.rowmajor(x.reshape(x.shape[0], -1))
+        x2, ldx = _lib.rowmajor(x.flatten(1))
         B, n, nf = x2.shape[0], self._n, self._n_fixed
         assert x2.shape[1] == 3 * (n + nf), "x must be [batch, 3 * n_atoms]"
         ics = torch.empty((3, B, n), dtype=torch.float32, device=dev)
@@ -338,7 +338,7 @@ class RelativeInternalCoordinateTransformation(Flow):
     def _ic2xyz(self, bonds, angles, torsions, xfix, blacken=None, acc=None):
         _lib.require_hip(bonds, angles, torsions, xfix)
         if torch.is_grad_enabled() and any(t.requires_grad for t in (bonds, angles, torsions, xfix)):
-            return _IC2XYZFn.apply(self, bonds, angles, torsions, xfix.reshape(xfix.shape[0], -1), blacken)
+            return _IC2XYZFn.apply(self, bonds, angles, torsions, xfix.flatten(1), blacken)
         return self._ic2xyz_launch(bonds, angles, torsions, xfix, blacken, acc=acc)
 
     def _ic2xyz_launch(self, bonds, angles, torsions, xfix, blacken=None, acc=None):
@@ -348,7 +348,7 @@ class RelativeInternalCoordinateTransformation(Flow):
         assert angles.shape[-1] == n
         assert torsions.shape[-1] == n
         (b2, a2, t2), ldic = _contig_rows(bonds, angles, torsions)
-        f2, ldf = _lib.rowmajor(xfix.reshape(B, -1))
+        f2, ldf = _lib.rowmajor(xfix.flatten(1))
         if blacken is None:
             mean = T = None
             keep, jac = 3 * nf, 0.0
@@ -378,7 +378,7 @@ class RelativeInternalCoordinateTransformation(Flow):
         dev = bonds.device
         B, n, nf = bonds.shape[0], self._n, self._n_fixed
         (b2, a2, t2), ldic = _contig_rows(bonds, angles, torsions)
-        f2, ldf = _lib.rowmajor(xfix.reshape(B, -1))
+        f2, ldf = _lib.rowmajor(xfix.flatten(1))
         if blacken is None:
             mean = T = None
             keep, jac = 3 * nf, 0.0
@@ -433,7 +433,7 @@ class RelativeInternalCoordinateTransformation(Flow):
         the launch is outside the kernel's envelope.  No autograd."""
         dev = x.device
         n, nf = self._n, self._n_fixed
-        x2 = x.reshape(x.shape[0], -1)
+        x2 = x.flatten(1)
         B = x2.shape[0]
         if whiten is None:
             mean = T = None
@@ -654,7 +654,7 @@ class GlobalInternalCoordinateTransformation(Flow):
     def _forward(self, x, *args, **kwargs):
         B = x.shape[0]
         acc = kwargs.get(ACC_KW)
-        bonds, angles, torsions, x_fixed, dlogp_rel = self._rel_ic._xyz2ic(x.reshape(B, -1), acc=acc)
+        bonds, angles, torsions, x_fixed, dlogp_rel = self._rel_ic._xyz2ic(x.flatten(1), acc=acc)
         ref, dlogp_ref = self._ref_ic._launch(x_fixed.reshape(B, 9), False, acc=acc)
         bonds = torch.cat([ref[:, 3:5], bonds], dim=-1)
         angles = torch.cat([ref[:, 5:6], angles], dim=-1)

@@ -551,3 +551,51 @@ def test_two_rank_rccl_kl_step(hip_lib, dev):
            "--master-port", str(port), os.path.join(root, "tests", "_two_rank_worker.py")]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "TWO_RANK_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
+def test_empty_and_single_sample_batches(hip_lib, dev, cfg):
+    """B = 0 and B = 1 through every kernel of a flow, both directions (fused tail / head, running log-det, coupling stacks): an empty
+    batch returns empty tensors of the right widths, a single sample equals row 0 of a larger batch"""
+    gen = _make(cfg, dev)
+    xs8 = _prior(cfg, 8, dev, seed=3)
+    with torch.no_grad():
+        *ys8, dl8 = gen.flow(*xs8)
+        for B in (0, 1):
+            xs = tuple(x[:B].contiguous() for x in xs8)
+            *ys, dl = gen.flow(*xs)
+            assert dl.shape == (B, 1) and all(y.shape == (B, y8.shape[1]) for y, y8 in zip(ys, ys8))
+            if B:
+                assert torch.allclose(dl, dl8[:1], rtol=1e-6, atol=1e-6) and all(torch.allclose(y, y8[:1], atol=1e-6) for y, y8 in zip(ys, ys8))
+            *zs, dli = gen.flow(*[y.clone() for y in ys], inverse=True)
+            assert dli.shape == (B, 1) and all(z.shape == (B, x8.shape[1]) for z, x8 in zip(zs, xs8))
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 63, 65, 127, 1001, 4133])
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg5"])
+def test_ragged_batches_through_the_fused_tail_and_head(hip_lib, dev, cfg, B):
+    """batch sizes that are no multiple of the 64-sample tiles (nor of the 16-byte DMA pieces): the fused sampling tail and its
+    inverse-direction twin against the same blocks run one by one, every row"""
+    gen = _make(cfg, dev)
+    xs = _prior(cfg, B, dev, seed=B)
+    with torch.no_grad():
+        *ys, dl = gen.flow(*xs)
+        *zs, dli = gen.flow(*[y.clone() for y in ys], inverse=True)
+        gen.flow.FUSE_GENERATION_TAIL = False
+        try:
+            *ys_b, dl_b = gen.flow(*xs)
+            *zs_b, dli_b = gen.flow(*[y.clone() for y in ys], inverse=True)
+        finally:
+            gen.flow.FUSE_GENERATION_TAIL = True
+    # The two paths use different (equally accurate) erfinv / sincos / atan2 forms, and a uniform prior sample now and then lands
+    # on a near-degenerate geometry (tiny bond, flat angle) that amplifies the last-ulp difference: a few rows may differ visibly.
+    # A mis-staged tile edge is wrong by O(1) in the LAST rows of the batch, always: those must agree, and bad rows must stay rare.
+    def row_err(a, b):
+        a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+        return (np.abs(a - b) / (1e-3 + 1e-4 * np.abs(b))).reshape(a.shape[0], -1).max(-1)
+    err_f = np.max([row_err(a, b) for a, b in zip(ys, ys_b)], axis=0)
+    err_f = np.maximum(err_f, row_err(dl, dl_b) / 10.0)
+    err_i = np.max([row_err(a, b) for a, b in zip(zs, zs_b)], axis=0)
+    for name, err in (("forward", err_f), ("inverse", err_i)):
+        assert (err > 1.0).mean() <= 0.02, f"{name}: {int((err > 1.0).sum())} of {B} rows differ"
+        assert (err[-min(B, 4):] <= 1.0).all(), f"{name}: the last rows of the batch differ: {err[-4:]}"
