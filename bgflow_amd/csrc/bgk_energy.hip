@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NE_THREADS) void energy_fields_kernel(EArgs a) {
                 const int w = (d - c0) < NE_CW ? (d - c0) : NE_CW;
                 const uint32_t magic = w == NE_CW ? ka->f[fi].magic_cw : ka->f[fi].magic_last;
                 for (int i = tid; i < rows * w; i += NE_THREADS) {
-                    const int r = (int)__umulhi((unsigned)i, magic), c = i - r * w, col = c0 + c;
+                    const int r = w == 1 ? i : (int)__umulhi((unsigned)i, magic), c = i - r * w, col = c0 + c;   /* (2^32 / 1 has no 32-bit magic) */
                     float v = x[(b0 + r) * ldx + col];
                     float s;
                     if (kind == 0) {

@@ -599,3 +599,50 @@ def test_ragged_batches_through_the_fused_tail_and_head(hip_lib, dev, cfg, B):
     for name, err in (("forward", err_f), ("inverse", err_i)):
         assert (err > 1.0).mean() <= 0.02, f"{name}: {int((err > 1.0).sum())} of {B} rows differ"
         assert (err[-min(B, 4):] <= 1.0).all(), f"{name}: the last rows of the batch differ: {err[-4:]}"
+
+
+@pytest.mark.parametrize("B", [1, 3, 65, 1001])
+@pytest.mark.parametrize("variant", ["register", "lds_table"])
+def test_ragged_batches_through_the_other_tail_kernels(hip_lib, dev, B, variant):
+    """the per-channel-descriptor tail kernel (bgk_icdf_ic2xyz_reg) and the round-2 kernel (bgk_icdf_ic2xyz), reached by switching the
+    newer ones off, on batch sizes that fill no tile"""
+    from bgflow_amd import ic as icmod
+    gen = _make("cfg3", dev)
+    xs = _prior("cfg3", B, dev, seed=100 + B)
+    cls = icmod.RelativeInternalCoordinateTransformation
+    saved = (cls.UNIFORM_TAIL, cls.REGISTER_TAIL)
+    try:
+        cls.UNIFORM_TAIL = False
+        cls.REGISTER_TAIL = variant == "register"
+        with torch.no_grad():
+            *ys, dl = gen.flow(*xs)
+            gen.flow.FUSE_GENERATION_TAIL = False
+            *ys_b, dl_b = gen.flow(*xs)
+    finally:
+        cls.UNIFORM_TAIL, cls.REGISTER_TAIL = saved
+        gen.flow.FUSE_GENERATION_TAIL = True
+    err = (np.abs(ys[0].cpu().numpy() - ys_b[0].cpu().numpy()) / (1e-3 + 1e-4 * np.abs(ys_b[0].cpu().numpy()))).max(-1)
+    assert (err > 1.0).mean() <= 0.02 and (err[-min(B, 4):] <= 1.0).all(), f"rows differ: {np.nonzero(err > 1.0)[0][:8]}"
+    assert (np.abs(dl.cpu().numpy() - dl_b.cpu().numpy()) / np.maximum(np.abs(dl_b.cpu().numpy()), 1.0) <= 1e-2).mean() >= 0.98
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 65, 1000])
+def test_energy_kernels_on_ragged_batches_and_strided_rows(hip_lib, dev, B):
+    """bgk_energy_fields on row views of wider tensors (row stride != width), small and ragged batches, several fields at once"""
+    import bgflow_amd as bg
+    g = torch.Generator(device=dev).manual_seed(B)
+    wide = torch.randn(B, 200, device=dev, generator=g)
+    xa, xb, xc = wide[:, 3:20], wide[:, 20:117], wide[:, 120:121]          # widths 17, 97 (two column chunks), 1
+    mean = torch.randn(97, device=dev, generator=g)
+    comps = [bg.NormalDistribution(17).to(dev), bg.NormalDistribution(97, mean=mean), bg.NormalDistribution(1).to(dev)]
+    prod = bg.ProductDistribution(comps)
+    u = prod.energy(xa, xb, xc, temperature=0.7)
+    # the reference's ProductDistribution has no temperature-aware components: Energy.energy divides the T = 1 sum (product.py:119-131)
+    ref = sum(0.5 * ((x.double() - m) ** 2).sum(-1, keepdim=True) + x.shape[1] / 2 * np.log(2 * np.pi)
+              for x, m in ((xa, 0.0), (xb, mean.double()), (xc, 0.0))) / 0.7
+    assert u.shape == (B, 1) and float(((u.double() - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 2e-6
+    dw = bg.DoubleWellEnergy(17, a=0.3, b=-2.0, c=0.7)
+    ud = dw.energy(xa, temperature=1.9)
+    xd = xa.double()
+    refd = (0.3 * xd[:, :1] - 2.0 * xd[:, :1] ** 2 + 0.7 * xd[:, :1] ** 4 + 0.5 * (xd[:, 1:] ** 2).sum(-1, keepdim=True)) / 1.9
+    assert float(((ud.double() - refd).abs() / refd.abs().clamp_min(1.0)).max()) <= 2e-6
