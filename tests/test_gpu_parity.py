@@ -978,10 +978,10 @@ def test_nll_training_step_cfg3(hip_lib, golden, dev):
 
 @pytest.mark.parametrize("kind", ["T|F", "F|T", "B|A"])
 @pytest.mark.parametrize("inverse", [False, True])
-def test_fused_training_forward_gradients(hip_lib, dev, kind, inverse):
+@pytest.mark.parametrize("B", [1, 33, 777])
+def test_fused_training_forward_gradients(hip_lib, dev, kind, inverse, B):
     """differentiable one-launch forward (bgk_coupling_rqs_dense_h2_train + MLP backward on the saved tensors) vs the
     generic autograd path (torch conditioner + bgk_rqs_transform / bgk_rqs_backward): outputs and every gradient"""
-    B = 777
     res = {}
     for fused in (True, False):
         layer, ti = _layer(kind, dev)
