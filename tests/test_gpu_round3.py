@@ -681,3 +681,44 @@ def test_smallest_shapes_through_the_fused_couplings(hip_lib, dev, B, inverse):
             o64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, [])
             np.testing.assert_allclose(y.cpu().numpy(), o64[1], rtol=2e-5, atol=2e-5)
             np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B", [3, 65, 1001])
+def test_tail_with_per_channel_marginals(hip_lib, dev, B):
+    """data-derived marginals (a mean and a width PER CHANNEL, icmarginals.py:41-77 with `InternalCoordinateMarginals` fitted to data):
+    the descriptors differ inside a field, so the sampling tail runs on the per-channel kernel (bgk_icdf_ic2xyz_reg) -- against the
+    same blocks one by one; the inverse direction has no fused kernel for this case and must agree trivially"""
+    import bgflow_amd as bg
+    from bgflow_amd import configs
+    gen = _make("cfg3", dev)
+    blocks = list(gen.flow._blocks)
+    rs = np.random.RandomState(5)
+    vec = lambda lo, hi, n: torch.as_tensor(lo + (hi - lo) * rs.rand(n), dtype=torch.float32, device=dev)     # noqa: E731
+    one = lambda v: torch.as_tensor(v, dtype=torch.float32, device=dev)                                        # noqa: E731
+    marginals = {
+        0: bg.TruncatedNormalDistribution(mu=vec(0.9, 1.6, 17), sigma=vec(0.02, 0.3, 17), lower_bound=one(1e-5), upper_bound=one(np.inf)),
+        1: bg.TruncatedNormalDistribution(mu=vec(0.3, 0.7, 17), sigma=vec(0.05, 0.4, 17), lower_bound=one(1e-5), upper_bound=one(1.0)),
+        2: configs.SloppyUniform(low=torch.zeros(17, device=dev), high=torch.ones(17, device=dev)),
+        3: configs._NormalMarginal(vec(-1.0, 1.0, 9), vec(5.0, 20.0, 9)).to(dev),
+    }
+    n_maps = sum(type(getattr(getattr(b, "_flow", None), "_delegate", None)).__name__ == "CDFTransform" for b in blocks)
+    assert n_maps == 4
+    blocks = blocks[:-1 - n_maps] + [bg.WrapFlow(bg.InverseFlow(bg.CDFTransform(marginals[s_])), (s_,)) for s_ in range(4)] + blocks[-1:]
+    flow = bg.SequentialFlow(blocks)                              # fresh segment / descriptor caches
+    xs = _prior("cfg3", B, dev, seed=B)
+    with torch.no_grad():
+        *ys, dl = flow(*xs)
+        labels = [lbl for lbl, _ in flow.segments()]
+        flow.FUSE_GENERATION_TAIL = False
+        *ys_b, dl_b = flow(*xs)
+        flow.FUSE_GENERATION_TAIL = True
+        *zs, dli = flow(*[y.clone() for y in ys_b], inverse=True)
+        flow.FUSE_GENERATION_TAIL = False
+        *zs_b, dli_b = flow(*[y.clone() for y in ys_b], inverse=True)
+    assert labels[-1] == "icdf+ic2xyz"
+    err = (np.abs(ys[0].cpu().numpy() - ys_b[0].cpu().numpy()) / (1e-3 + 1e-4 * np.abs(ys_b[0].cpu().numpy()))).max(-1)
+    assert (err > 1.0).mean() <= 0.02 and (err[-min(B, 4):] <= 1.0).all(), f"rows differ: {np.nonzero(err > 1.0)[0][:8]}"
+    assert (np.abs(dl.cpu().numpy() - dl_b.cpu().numpy()) / np.maximum(np.abs(dl_b.cpu().numpy()), 1.0) <= 1e-2).mean() >= 0.98
+    for a, b in zip(zs, zs_b):
+        erri = (np.abs(a.cpu().numpy() - b.cpu().numpy()) / (1e-3 + 1e-4 * np.abs(b.cpu().numpy()))).max(-1)
+        assert (erri > 1.0).mean() <= 0.02
