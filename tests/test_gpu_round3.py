@@ -722,3 +722,21 @@ def test_tail_with_per_channel_marginals(hip_lib, dev, B):
     for a, b in zip(zs, zs_b):
         erri = (np.abs(a.cpu().numpy() - b.cpu().numpy()) / (1e-3 + 1e-4 * np.abs(b.cpu().numpy()))).max(-1)
         assert (erri > 1.0).mean() <= 0.02
+
+
+def test_one_launch_of_four_million_samples_equals_its_chunks(hip_lib, dev):
+    """B = 2^22 + 77 in ONE launch per kernel (cfg 4's global batch on one GPU: 2.8e8 coordinates, 64-bit row offsets everywhere)
+    against the same rows run as four chunks: identical bits, both directions"""
+    gen = _make("cfg3", dev)
+    B = (1 << 22) + 77
+    xs = _prior("cfg3", B, dev, seed=4)
+    cuts = [0, 1 << 20, (1 << 21) + 13, 3 << 20, B]
+    with torch.no_grad():
+        *ys, dl = gen.flow(*xs)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            *yc, dlc = gen.flow(*[x[a:b].contiguous() for x in xs])
+            assert torch.equal(yc[0], ys[0][a:b]) and torch.equal(dlc, dl[a:b]), f"rows {a}:{b} differ"
+        x_last = ys[0][-(1 << 20):].contiguous()
+        *zs, dli = gen.flow(ys[0], inverse=True)
+        *zc, dlic = gen.flow(x_last, inverse=True)
+        assert all(torch.equal(u, v[-(1 << 20):]) for u, v in zip(zc, zs)) and torch.equal(dlic, dli[-(1 << 20):])
