@@ -1181,7 +1181,10 @@ extern "C" int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_
         return BGK_EUNSUPPORTED;
     }
     const int n_in = periodic ? 2 * d_c : d_c;
-    BGK_CHECK_ARG((n_in + 9) * SROW <= LDS_P, "bgk_coupling_rqs_dense: conditioner input of %d features too wide", n_in);
+    if ((n_in + 9) * SROW > LDS_P) {     /* outside the envelope, not an error: the caller runs the conditioner layer by layer */
+        bgk_set_error("bgk_coupling_rqs_dense: conditioner input of %d features does not fit the layer-0 tile", n_in);
+        return BGK_EUNSUPPORTED;
+    }
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
     if (B == 0) return 0;
@@ -1229,7 +1232,10 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     }
     const int n_in = periodic ? 2 * d_c : d_c;
     const int S0 = (n_in + 1 + 15) / 16;
-    BGK_CHECK_ARG(16 * S0 * SROW <= LDS_P, "%s: conditioner input of %d features too wide", what, n_in);
+    if (16 * S0 * SROW > LDS_P) {        /* outside the envelope, not an error: the caller runs the conditioner layer by layer */
+        bgk_set_error("%s: conditioner input of %d features does not fit the layer-0 tile (at most 111)", what, n_in);
+        return BGK_EUNSUPPORTED;
+    }
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
     if (B == 0) return 0;

@@ -740,3 +740,46 @@ def test_one_launch_of_four_million_samples_equals_its_chunks(hip_lib, dev):
         *zs, dli = gen.flow(ys[0], inverse=True)
         *zc, dlic = gen.flow(x_last, inverse=True)
         assert all(torch.equal(u, v[-(1 << 20):]) for u, v in zip(zc, zs)) and torch.equal(dlic, dli[-(1 << 20):])
+
+
+@pytest.mark.parametrize("widths", [(1, 2, 5), (1, 1, 1), (31, 1), (2, 63)])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_segment_tables_with_narrow_and_odd_widths(hip_lib, dev, widths, periodic):
+    """conditioner input from 2 - 3 tensors of widths down to 1 (segment staging: per-segment magic division, row offsets): same bits as
+    the concatenated input, spline and affine couplings, ragged batch"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    B, d = 1031, 7
+    n_c = sum(widths)
+    g = torch.Generator(device=dev).manual_seed(n_c)
+    conds = [torch.rand(B, w, device=dev, generator=g) for w in widths]
+    y = torch.rand(B, d, device=dev, generator=g)
+    front = (lambda n: bg.WrapPeriodic(n)) if periodic else (lambda n: n)
+    n_in = n_c * (2 if periodic else 1)
+    layers = [
+        bg.CouplingFlow(bg.ConditionalSplineTransformer(front(bg.DenseNet([n_in, 128, 128, 3 * 8 * d + d], activation=torch.nn.SiLU())),
+                                                        is_circular=False), transformed_indices=(len(widths),), cond_indices=tuple(range(len(widths)))),
+        bg.CouplingFlow(bg.AffineTransformer(front(bg.DenseNet([n_in, 128, 128, d], torch.nn.SiLU())), front(bg.DenseNet([n_in, 128, 128, d], torch.nn.SiLU()))),
+                        transformed_indices=(len(widths),), cond_indices=tuple(range(len(widths)))),
+    ]
+    import warnings
+    for li, layer in enumerate(layers):
+        layer = hash_init_(layer).to(dev)
+        limit = 111 if li == 0 else 127          # features the layer-0 tile of the spline / affine kernels holds: wider inputs run
+        beyond = n_in > limit                    # layer by layer, with one warning
+        for inverse in (False, True):
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                with torch.no_grad():
+                    *a, dla = layer(*conds, y, inverse=inverse)
+                    bg.CouplingFlow.MULTI_COND_IN_KERNEL = False
+                    try:
+                        *b, dlb = layer(*conds, y, inverse=inverse)
+                    finally:
+                        bg.CouplingFlow.MULTI_COND_IN_KERNEL = True
+            said = [str(x.message) for x in w if "fused" in str(x.message)]
+            if beyond:
+                assert inverse or (len(said) == 1 and str(limit) in said[0]), said      # said once, with the reason; no exception
+            else:
+                assert not said and layer.transformer._fused_cache, "the fused path must have run"
+            assert torch.equal(a[-1], b[-1]) and torch.equal(dla, dlb), f"{type(layer.transformer).__name__} inverse={inverse}"
