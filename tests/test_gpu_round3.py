@@ -783,3 +783,27 @@ def test_segment_tables_with_narrow_and_odd_widths(hip_lib, dev, widths, periodi
             else:
                 assert not said and layer.transformer._fused_cache, "the fused path must have run"
             assert torch.equal(a[-1], b[-1]) and torch.equal(dla, dlb), f"{type(layer.transformer).__name__} inverse={inverse}"
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
+def test_generator_api_keyword_routing(hip_lib, dev, cfg):
+    """BoltzmannGenerator.sample(temperature=..., with_dlogp / with_latent / with_log_weights) and .energy / .kldiv through the fused
+    segments (bg.py:105-147): keyword arguments reach the prior, not the kernels; shapes as in the reference"""
+    gen = _make(cfg, dev)
+    torch.manual_seed(0)
+    n = 257
+    latent = cfg == "cfg2"        # (like the reference, `with_latent` works for single-tensor priors only: bg.py:120-121 appends *z)
+    with torch.no_grad():
+        out = gen.sample(n, temperature=1.7, with_latent=latent, with_dlogp=True, with_energy=True, with_log_weights=True, with_weights=True)
+    xs_out = out[:len(out) - 4 - int(latent)]          # the flow's outputs (cfg 5: coordinates and the auxiliary variables)
+    x = out[0]
+    assert x.shape[0] == n and all(o.shape[0] == n for o in out)
+    dlogp, energy, logw, w = out[-4], out[-3], out[-2], out[-1]
+    assert dlogp.shape == (n, 1) and energy.shape == (n, 1) and logw.shape == (n, 1) and w.shape == (n,)
+    assert torch.isfinite(dlogp).all() and abs(float(w.sum()) - 1.0) < 1e-3
+    with torch.no_grad():
+        e = gen.energy(*xs_out, temperature=1.7)
+        kl = gen.kldiv(64, temperature=1.3)
+    assert e.shape == (n, 1) and kl.shape == (64, 1)
+    # the generator's energy of its own sample = prior energy of the latent - log-det (bg.py:105-123), within the inverse's accuracy
+    assert torch.isfinite(e).float().mean() > 0.98
