@@ -807,3 +807,31 @@ def test_generator_api_keyword_routing(hip_lib, dev, cfg):
     assert e.shape == (n, 1) and kl.shape == (64, 1)
     # the generator's energy of its own sample = prior energy of the latent - log-det (bg.py:105-123), within the inverse's accuracy
     assert torch.isfinite(e).float().mean() > 0.98
+
+
+@pytest.mark.parametrize("d_c,periodic", [(100, False), (50, True), (97, False), (111, False)])
+def test_training_gradients_with_wide_conditioner_inputs(hip_lib, dev, d_c, periodic):
+    """conditioner inputs of 97 .. 111 features: the fused training forward takes them, the input-gradient kernel stops at 96 (the chain
+    then runs on GEMMs): every gradient against the layer-by-layer autograd path"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    B, d = 333, 11
+    n_in = d_c * (2 if periodic else 1)
+    res = {}
+    for fused in (True, False):
+        net = bg.DenseNet([n_in, 128, 128, 3 * 8 * d + d], activation=torch.nn.SiLU())
+        net = bg.WrapPeriodic(net) if periodic else net
+        layer = hash_init_(bg.CouplingFlow(bg.ConditionalSplineTransformer(net, is_circular=False), transformed_indices=(1,),
+                                           cond_indices=(0,))).to(dev)
+        layer.transformer.allow_fused = fused
+        g = torch.Generator(device=dev).manual_seed(7)
+        c = torch.rand(B, d_c, device=dev, generator=g).requires_grad_(True)
+        y = torch.rand(B, d, device=dev, generator=g).requires_grad_(True)
+        w = torch.randn(B, d, device=dev, generator=g)
+        _, out, dl = layer(c, y)
+        if fused:
+            assert layer.transformer._fused_cache.get("src_col_dev") is not None, "the fused training forward must have run"
+        ((out * w).sum() + dl.sum()).backward()
+        res[fused] = [out.detach(), dl.detach(), c.grad, y.grad] + [p.grad for p in layer.parameters()]
+    for a, b in zip(res[True], res[False]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=3e-4 * float(b.abs().max()) + 1e-6)
