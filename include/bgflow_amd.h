@@ -14,6 +14,11 @@
  * (ld*), unit column stride; `dlogp` vectors are [B] contiguous (the [B,1] tensors of bgflow).
  * `accumulate` != 0 adds the layer's log|det J| to dlogp (SequentialFlow's `dlogp += ddlogp`,
  * nn/flow/sequential.py:58) instead of overwriting it.
+ *
+ * Empty batches: with B == 0 every entry point that takes a batch size returns 0 before it looks at a pointer (the tensors of an
+ * empty batch have no storage); reductions over the batch write their neutral element (bgk_column_sum: zeros; the loss sums of
+ * bgk_energy_fields: {0, 0}).  BGK_EUNSUPPORTED means "outside this kernel's envelope" (a width, bin count or molecule size it has no
+ * instance for): the caller is expected to take its next path down, not to report an error.
  */
 #ifndef BGFLOW_AMD_H
 #define BGFLOW_AMD_H
