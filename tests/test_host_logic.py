@@ -457,6 +457,9 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
     # empty batches are a no-op
     assert L.bgk_rqs_transform(P1, 17, P1, 425, 425, P1, 0, 17, 8, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None) == 0
     assert L.bgk_affine_transform(P1, 4, P1, 4, P1, 4, P1, 0, 0, 0, 0, 4, P1, 4, P1, 0, None) == 0
+    # ... even with the NULL pointers empty tensors have (torch: data_ptr() == 0 for numel() == 0)
+    assert L.bgk_rqs_transform(None, 17, None, 425, 425, P1, 0, 17, 8, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, None, 17, None, 0, None, None, None) == 0
+    assert L.bgk_affine_transform(None, 4, None, 4, None, 4, P1, 0, 0, 0, 0, 4, None, 4, None, 0, None) == 0
     # bad sizes / null pointers -> BGK_EINVAL with a message
     assert L.bgk_rqs_transform(P1, 17, P1, 425, 425, P1, -1, 17, 8, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None) == -1
     assert "bad sizes" in err()
