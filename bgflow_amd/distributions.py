@@ -9,7 +9,7 @@ domain-mapping layers), ``UniformDistribution`` / ``SloppyUniform`` (distributio
 import numpy as np
 import torch
 
-from .utils import pack_tensor_in_tuple
+from .utils import pack_tensor_in_tuple  # noqa: F401  (re-exported: bgflow.distribution modules expose it)
 
 __all__ = [
     "Energy", "Sampler", "NormalDistribution", "TruncatedNormalDistribution", "SloppyUniform",

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .flow import ACC_KW, CatView, Flow, as_tensor
+from .flow import ACC_KW, Flow, as_tensor
 
 def _invalidate_fused_cache(self):
     """Forget the packed-operand cache of the fused kernels.  The cache is keyed on the parameters' (data_ptr, _version): optimizer
