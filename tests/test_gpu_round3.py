@@ -835,3 +835,27 @@ def test_training_gradients_with_wide_conditioner_inputs(hip_lib, dev, d_c, peri
         res[fused] = [out.detach(), dl.detach(), c.grad, y.grad] + [p.grad for p in layer.parameters()]
     for a, b in zip(res[True], res[False]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=0, atol=3e-4 * float(b.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("d", [1, 2, 66, 1500, 3000])
+def test_cdf_maps_of_any_width(hip_lib, dev, d):
+    """CDFTransform over per-column normal marginals, one column to 3000 (beyond 1800 columns the kernel keeps its column constants in
+    global memory), a batch that fills no tile: both directions against torch.distributions in f64"""
+    import bgflow_amd as bg
+    from bgflow_amd import configs
+    B = 77
+    g = torch.Generator(device=dev).manual_seed(d)
+    loc = torch.randn(d, device=dev, generator=g)
+    scale = 0.5 + torch.rand(d, device=dev, generator=g)
+    layer = bg.CDFTransform(configs._NormalMarginal(loc, scale)).to(dev)
+    u = torch.rand(B, d, device=dev, generator=g).clamp(1e-4, 1 - 1e-4)
+    ref = torch.distributions.Normal(loc.double(), scale.double())
+    with torch.no_grad():
+        y, dl = layer(u, inverse=True)
+        assert layer._desc_cache.get("desc") is not None, "the kernel path must have run"
+        y_t = ref.icdf(u.double())
+        np.testing.assert_allclose(y.cpu().numpy(), y_t.cpu().numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dl.cpu().numpy(), (-ref.log_prob(y_t)).sum(-1, keepdim=True).cpu().numpy(), rtol=3e-5, atol=3e-4)
+        ub, dlb = layer(y)
+        np.testing.assert_allclose(ub.cpu().numpy(), u.cpu().numpy(), rtol=0, atol=3e-6)
+        np.testing.assert_allclose(dlb.cpu().numpy(), ref.log_prob(y.double()).sum(-1, keepdim=True).cpu().numpy(), rtol=3e-5, atol=3e-4)
