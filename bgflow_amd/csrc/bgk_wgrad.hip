@@ -185,14 +185,16 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgGroup grp_args) 
     if (g_ok) a.part_b[((int64_t)slab * 2 + gkb) * a.n + gcol] = bsum;
 }
 
-/* fixed-order sum of the slab partials: 8 lanes per output element each sum every 8th slab (4 accumulators), combined
- * by a fixed shuffle tree -- 8x the parallelism of one thread per element (the partial sets are only a few MB: latency-bound) */
+/* fixed-order sum of the slab partials: 8 lanes per output element each sum every 8th slab (2 accumulators), combined in ascending
+ * order through LDS.  The 8 lanes of an element sit in 8 different half-waves: a half-wave reads 32 CONSECUTIVE elements of one slab
+ * (128 B, coalesced) -- with the 8 lanes adjacent every load touched 8 slabs x 32 B. */
 struct RedOne { const float* part_w; const float* part_b; int n_slabs, n, k; float* gW; float* gb; };
-struct RedGroup { RedOne r[3]; int64_t first[4]; };      /* first[q]: first output element (8 lanes each) of GEMM q */
+struct RedGroup { RedOne r[3]; int64_t first[4]; };      /* first[q]: first output element of GEMM q */
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(RedGroup rg, int accumulate) {
-    const int sub = threadIdx.x & 7;
-    const int64_t gi = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    __shared__ float s_part[8][32];
+    const int sub = threadIdx.x >> 5, el = threadIdx.x & 31;
+    const int64_t gi = (int64_t)blockIdx.x * 32 + el;
     const int q = gi >= rg.first[2] ? 2 : (gi >= rg.first[1] ? 1 : 0);
     const RedOne& o = rg.r[q];
     const int64_t i = gi - rg.first[q];
@@ -214,12 +216,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(RedGroup rg, int accu
         if (s < 2 * n_slabs) a0 += o.part_b[(int64_t)s * n + col];
         acc = a0 + a1;
     }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 4);
+    s_part[sub][el] = acc;
+    __syncthreads();
     if (sub == 0) {
-        if (i < nk && i < total) o.gW[i] = accumulate ? o.gW[i] + acc : acc;
-        else if (i < total) o.gb[i - nk] = accumulate ? o.gb[i - nk] + acc : acc;
+        float t = s_part[0][el];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += s_part[u][el];
+        if (i < nk && i < total) o.gW[i] = accumulate ? o.gW[i] + t : t;
+        else if (i < total) o.gb[i - nk] = accumulate ? o.gb[i - nk] + t : t;
     }
 }
 
@@ -266,7 +270,7 @@ int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t w
     grp.first[3] = blocks;
     red.first[3] = outs;
     hipLaunchKernelGGL(wgrad_kernel, dim3(blocks), dim3(WG_THREADS), 2 * 2 * ARR, st, grp);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs * 8 + 255) / 256)), dim3(256), 0, st, red, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((outs + 31) / 32)), dim3(256), 0, st, red, accumulate);
     return 0;
 }
 
