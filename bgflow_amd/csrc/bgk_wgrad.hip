@@ -231,7 +231,10 @@ int slabs_for(int64_t B, int n) {
     /* ~2 workgroups per CU, slabs of at least 1024 rows, a multiple of 8 slabs (XCD-aware block map) */
     const int n_blocks = (n + COLS - 1) / COLS;
     int n_slabs = (int)((B + 1023) / 1024);
-    const int want = (512 + n_blocks - 1) / n_blocks;
+#ifndef BGK_WG_TARGET
+#define BGK_WG_TARGET 512            /* workgroups per GEMM (~2 per CU) */
+#endif
+    const int want = (BGK_WG_TARGET + n_blocks - 1) / n_blocks;
     n_slabs = n_slabs > want ? want : n_slabs;
     return ((n_slabs + 7) / 8) * 8;
 }
