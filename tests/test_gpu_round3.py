@@ -875,3 +875,45 @@ def test_philox_fields_small_and_ragged_shapes(hip_lib, dev, B, d):
     assert np.array_equal(u.cpu().numpy(), (2.0 * philox.sample_field(seed, 0, 0, B, d, 0)).astype(np.float32))
     np.testing.assert_allclose(z.cpu().numpy(), philox.sample_field(seed, 0, 1, B, d, 1), rtol=0, atol=4e-6)
     assert torch.isfinite(prior.energy(u, z)).all()
+
+
+@pytest.mark.parametrize("n_atoms", [5, 8, 24, 25, 32, 33, 40])
+def test_tail_and_head_on_other_molecule_sizes(hip_lib, dev, n_atoms):
+    """the fused sampling tail / inference head across the kernels' atom-count instances (<= 24: the elementwise kernels; <= 32: the
+    per-channel register kernel; beyond: the round-2 kernel / the blocks) on a synthetic chain, ragged batch: against the blocks"""
+    import bgflow_amd as bg
+    from bgflow_amd import configs
+    z = np.zeros((n_atoms - 3, 4), dtype=np.int64)
+    for k, i in enumerate(range(3, n_atoms)):
+        z[k] = (i, i - 1, i - 2, i - 3) if (i % 4 or i < 4) else (i, i - 2, i - 3, i - 4)
+    n = n_atoms - 3
+    ic = bg.RelativeInternalCoordinateTransformation(z, np.array([0, 1, 2]), normalize_angles=True)
+    one = lambda v, m: torch.full((m,), float(v))          # noqa: E731
+    marginals = {
+        0: bg.TruncatedNormalDistribution(mu=one(0.15, n), sigma=one(0.01, n), lower_bound=torch.tensor(1e-5), upper_bound=torch.tensor(np.inf)),
+        1: bg.TruncatedNormalDistribution(mu=one(0.5, n), sigma=one(0.05, n), lower_bound=torch.tensor(1e-5), upper_bound=torch.tensor(1.0)),
+        2: configs.SloppyUniform(low=one(0.0, n), high=one(1.0, n)),
+        3: configs._NormalMarginal(torch.tensor([0, 0, 0, 0.15, 0, 0, 0.2, 0.14, 0.0]), one(0.005, 9)),
+    }
+    flow = bg.SequentialFlow([bg.WrapFlow(bg.InverseFlow(bg.CDFTransform(marginals[s_])), (s_,)) for s_ in range(4)]
+                             + [bg.WrapFlow(bg.InverseFlow(ic), indices=[0, 1, 2, 3], out_indices=(0,))]).to(dev)
+    B = 77
+    g = torch.Generator(device=dev).manual_seed(n_atoms)
+    xs = [torch.rand(B, w, device=dev, generator=g).clamp(0.02, 0.98) for w in (n, n, n, 9)]
+    with torch.no_grad():
+        x, dl = flow(*xs)
+        *zs, dli = flow(x, inverse=True)
+        flow.FUSE_GENERATION_TAIL = False
+        x_b, dl_b = flow(*xs)
+        *zs_b, dli_b = flow(x, inverse=True)
+    assert x.shape == (B, 3 * n_atoms)
+    np.testing.assert_allclose(x.cpu().numpy(), x_b.cpu().numpy(), rtol=0, atol=2e-5 * n_atoms)
+    np.testing.assert_allclose(dl.cpu().numpy(), dl_b.cpu().numpy(), rtol=2e-5, atol=2e-3)
+    for a, b in zip(zs, zs_b):
+        da = np.abs(a.cpu().numpy() - b.cpu().numpy())
+        assert np.minimum(da, 1.0 - da).max() <= 2e-4          # (torsions are periodic)
+    np.testing.assert_allclose(dli.cpu().numpy(), dli_b.cpu().numpy(), rtol=1e-4, atol=2e-2)
+    # and the round trip closes
+    for a, b in zip(zs, xs):
+        da = np.abs(a.cpu().numpy() - b.cpu().numpy())
+        assert np.minimum(da, 1.0 - da).max() <= 5e-3
