@@ -85,6 +85,21 @@ constexpr int GBLK = KS * 8 + 4;      /* 1 KiB blocks per packed 128-row GEMM in
 #ifndef BGK_V2_BSEARCH
 #define BGK_V2_BSEARCH 1             /* bin search: 1 = 3-level binary search with windowed selects, 0 = linear count + select chains */
 #endif
+#ifndef BGK_V2_OVFL
+#define BGK_V2_OVFL 1                 /* 1: the kernel sets MODE.FP16_OVFL -- f16 conversions saturate at +-65504 instead of producing inf (whose lo part
+                                       * would be inf - inf), so the activation code carries no clamp instructions */
+#endif
+#ifndef BGK_V2_TS
+#define BGK_V2_TS 0                   /* profiling build (tools/r04_phase_ts.py): lane 0 of every wave stores s_memtime at phase boundaries into bin_idx[tile * 32 * d + k] instead of the bin indices */
+#endif
+#if BGK_V2_TS
+#define V2_TS(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0 && a.bin_idx) a.bin_idx[b0 * d + (k)] = (int)(unsigned)t_; } while (0)
+#else
+#define V2_TS(k) do { } while (0)
+#endif
+#ifndef BGK_V2_EORD
+#define BGK_V2_EORD 0                 /* event order of a GEMM: 0 = the three products of a tile-step back to back, 1 = part-major over the tiles of a k-step */
+#endif
 #ifndef BGK_V2_BUF
 #define BGK_V2_BUF 1                  /* A stream through buffer loads: one s_mov per 4 KiB group instead of a 64-bit SALU add per tile-step */
 #endif
@@ -116,6 +131,10 @@ struct V2Args {
     uint64_t circ_mask;
     SpC sc;
     int lds_per_wave;
+    /* tile images in LDS (row-major, one row per sample): the conditioner features [32][nfs] at the head of the parameter-chunk
+     * buffer, y / out [32][ys].  stage: 0 = per-lane loads (any strides / several tensors / periodic), 1 = the contiguous [32][d_c]
+     * tile copied by the DMA path IS the feature tile (nfs = d_c), 2 = DMA of the raw tile + an elementwise cos / sin pass */
+    int nfs, ys, stage, y_dma, out_lin;
 #if BGK_V2_SAVE
     float* z0; float* z1;             /* scaled pre-activations [B, 128] */
     float* params; int64_t ldp;       /* spline parameters [B, P] in the reference's column order */
@@ -173,6 +192,16 @@ struct Live {
         return ld_block<BLK>(W, voff);
 #endif
     }
+    /* the hi / the lo block of tile-step T alone (event order 1 refills the two halves of a ring slot at different times) */
+    template <int T>
+    __device__ __forceinline__ void load_hi() {
+        if constexpr (T < NTS) ring[T % RD].hi = blk<((T / NT) * MS + T % NT) * 2>();
+        else if constexpr (T < NTS + NT) ring[T % RD].hi = blk<KS * MS * 2 + (T - NTS)>();
+    }
+    template <int T>
+    __device__ __forceinline__ void load_lo() {
+        if constexpr (T < NTS) ring[T % RD].lo = blk<((T / NT) * MS + T % NT) * 2 + 1>();
+    }
     template <int T>
     __device__ __forceinline__ void load() {
 #ifdef BGK_V2_ABL_NOLOAD     /* timing experiment: only the prologue of each GEMM loads A (wrong results) */
@@ -222,6 +251,32 @@ struct Live {
             constexpr int m = E - NTS, T = NTS + m;
             const s16x8 one2 = {(short)0x3f80, (short)0x3f80, 0, 0, 0, 0, 0, 0};
             out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, ring[T % RD].hi), one2, out[m], 0, 0, 0);
+        }
+#elif BGK_V2_EORD
+        /* event order 1: within a group of G consecutive tile-steps the products run part-major -- lo*hi of the G tiles, hi*lo of
+         * the G tiles, hi*hi of the G tiles -- so that consecutive MFMAs never write the same accumulator: a dependent MFMA that is
+         * not issued back to back with its predecessor (VALU work is threaded between the events) waits for the predecessor's
+         * write-back instead of using the matrix pipe's accumulator forwarding (MI355X_MICROARCH.md: +43 cycles).  The lo half of a
+         * ring slot is free after the first part, the hi half after the third: they are refilled separately. */
+        if constexpr (E < 3 * NTS) {
+            constexpr int G = (RD < NT ? RD : NT);
+            static_assert(NTS % G == 0, "groups tile the product tile-steps");
+            constexpr int grp = E / (3 * G), rem = E % (3 * G), p = rem / G, T = grp * G + rem % G, s = T / NT, m = T % NT;
+            const TFrag& f = ring[T % RD];
+            const h16x8 a = __builtin_bit_cast(h16x8, p == 0 ? f.lo : f.hi);
+            const h16x8 bb = p == 1 ? b.lo[s] : b.hi[s];
+            if constexpr (s == 0 && p == 0) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bb, z, 0, 0, 0);
+            } else {
+                out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bb, out[m], 0, 0, 0);
+            }
+            if constexpr (p == 0) load_lo<T + RD>();
+            if constexpr (p == 2) load_hi<T + RD>();
+        } else if constexpr (E < NEV) {
+            constexpr int m = E - 3 * NTS, T = NTS + m;
+            const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[T % RD].hi), one2, out[m], 0, 0, 0);
         }
 #else
         if constexpr (E < 3 * NTS) {
@@ -301,13 +356,19 @@ __device__ __forceinline__ void act_split_pair(H& hk, const f32x16& t, float c, 
         a0 = a0 > 0.0f ? a0 : 0.0f; a1 = a1 > 0.0f ? a1 : 0.0f;
         hk.template at<3 * P + 1>();
     } else {
-        const float x0 = t[r] * c, x1 = t[r + 1] * c;
+        /* t = UNSCALED accumulator value, x = t c.  SiLU: x / (1 + e^-x) = t / ((1 + e) / c): the unscale factor rides on the exponent's
+         * constant and on the fma that forms the denominator (5 instructions per value instead of 7); tanh needs x only inside the exponent */
         constexpr float kk = ACT == 1 ? -1.44269504088896341f : 2.88539008177792681f;
-        const float e0 = __builtin_amdgcn_exp2f(x0 * kk), e1 = __builtin_amdgcn_exp2f(x1 * kk);
+        const float ck = c * kk, rc = 1.0f / c;
+        const float e0 = __builtin_amdgcn_exp2f(t[r] * ck), e1 = __builtin_amdgcn_exp2f(t[r + 1] * ck);
         hk.template at<3 * P>();
-        const float q0 = __builtin_amdgcn_rcpf(1.0f + e0), q1 = __builtin_amdgcn_rcpf(1.0f + e1);
-        if constexpr (ACT == 1) { a0 = x0 * q0; a1 = x1 * q1; }
-        else { a0 = 1.0f - 2.0f * q0; a1 = 1.0f - 2.0f * q1; }
+        if constexpr (ACT == 1) {
+            const float q0 = __builtin_amdgcn_rcpf(__builtin_fmaf(e0, rc, rc)), q1 = __builtin_amdgcn_rcpf(__builtin_fmaf(e1, rc, rc));
+            a0 = t[r] * q0; a1 = t[r + 1] * q1;
+        } else {
+            const float q0 = __builtin_amdgcn_rcpf(1.0f + e0), q1 = __builtin_amdgcn_rcpf(1.0f + e1);
+            a0 = 1.0f - 2.0f * q0; a1 = 1.0f - 2.0f * q1;
+        }
         hk.template at<3 * P + 1>();
     }
 #else
@@ -316,9 +377,11 @@ __device__ __forceinline__ void act_split_pair(H& hk, const f32x16& t, float c, 
     float a1 = act_hw<ACT>(t[r + 1] * c);
     hk.template at<3 * P + 1>();
 #endif
+#if !BGK_V2_OVFL
     if constexpr (ACT != 3) {       /* SiLU / ReLU outputs are bounded below; keep the f16 conversion finite above */
         a0 = __builtin_fminf(a0, 65000.0f); a1 = __builtin_fminf(a1, 65000.0f);
     }
+#endif
     constexpr int s = 2 * T + (r >> 3), e = r & 7;
 #if BGK_V2_BF16
     typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
@@ -656,10 +719,10 @@ __device__ __forceinline__ void spline_slot(G& g, const V2Args& a, const SpK& k,
     const bool circ = (a.circ_mask >> dim) & 1ull;
     int bin, oob;
     float lad;
-    const float x = s_y[dim * SROW + j];
+    const float x = s_y[j * a.ys + dim];
     Hooks<G, IT * EH, NHK> hk{g};
     const float o = rqs_fast<INV>(hk, x, INV ? pw : ph, INV ? ph : pw, ps, circ, a, k, &lad, &bin, &oob);
-    s_y[(valid ? dim : a.d) * SROW + j] = o;
+    s_y[valid ? j * a.ys + dim : 32 * a.ys + j] = o;         /* (32 spare floats behind the tile take the results of invalid slots) */
     oob_local += (valid && j < rows) ? oob : 0;
     bins[IT] = bin;
     lad = valid ? lad : 0.0f;
@@ -724,13 +787,81 @@ __device__ __forceinline__ void chunk_piped(const V2Args& a, const SpK& k, float
 #endif
 }
 
+/* linear DMA copy of a wave's contiguous, 16-byte aligned tile of n floats (a multiple of 4) into LDS; only the first `valid`
+ * floats exist in memory (last tile of a batch): the others are left alone (lanes masked) -- nothing downstream depends on them */
+typedef const __attribute__((address_space(1))) void* gvp_t;
+typedef __attribute__((address_space(3))) void* lvp_t;
+__device__ __forceinline__ void dma_tile32(float* dst, const float* __restrict__ src, int n, int valid, int lane) {
+    for (int c = 0; c < n; c += 256) {                /* 1 KiB per instruction */
+        const int e = c + lane * 4;
+        if (e + 3 < valid) __builtin_amdgcn_global_load_lds((gvp_t)(src + e), (lvp_t)(dst + c), 16, 0, 0);
+    }
+    if (valid & 3) {                                  /* partial tile whose length is no multiple of 4: its last 1..3 floats, one dword each */
+        const int edge = valid & ~3;
+        if (lane < (valid & 3)) __builtin_amdgcn_global_load_lds((gvp_t)(src + edge + lane), (lvp_t)(dst + edge), 4, 0, 0);
+    }
+}
+
+/* layer 0: A fragments of one k-step (4 tiles x {hi, lo}) */
+struct L0Frag { uint4 v[4][2]; };
+__device__ __forceinline__ void l0_request(L0Frag& f, const uint4* A0, int s, int lane) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f.v[m][0] = A0[((s * 4 + m) * 2 + 0) * 64 + lane];
+#if !BGK_V2_BF16
+        f.v[m][1] = A0[((s * 4 + m) * 2 + 1) * 64 + lane];
+#endif
+    }
+}
+/* one k-step: f = the lane's 8 consecutive features; `last`: the k-step that holds the constant-1 (bias) feature, rel0 = index of
+ * element 0 relative to it */
+__device__ __forceinline__ void l0_step(f32x16 (&h)[4], const L0Frag& fr, const float* f, bool last, int rel0) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = f[e];
+    if (last) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rel0 + e == 0 ? 1.0f : (rel0 + e > 0 ? 0.0f : v[e]);
+    }
+#if BGK_V2_BF16
+    s16x8 bb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bb[e] = __builtin_bit_cast(short, (__bf16)v[e]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        h[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, fr.v[m][0]), bb, h[m], 0, 0, 0);
+#else
+    h16x8 bhi, blo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#if BGK_V2_OVFL
+        const float c = v[e];
+#else
+        const float c = __builtin_amdgcn_fmed3f(v[e], -65000.0f, 65000.0f);
+#endif
+        const _Float16 hv = (_Float16)c;
+        bhi[e] = hv;
+        blo[e] = (_Float16)(c - (float)hv);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fr.v[m][1]), bhi, h[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fr.v[m][0]), blo, h[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fr.v[m][0]), bhi, h[m], 0, 0, 0);
+#endif
+}
+
 template <int ACT, int INV>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2Args a) {
     if (a.cs_dev) { a.c0 = a.cs_dev[1]; a.c1 = a.cs_dev[3]; a.c2 = a.cs_dev[5]; }   /* wave-uniform scalar loads */
+#if BGK_V2_OVFL
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");                 /* MODE.FP16_OVFL */
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6;
-    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* parameter chunk [128][32]; first the layer-0 input [16 S0][SROW] */
-    float* s_y = s_p + 128 * ST;                          /* y / out tile [d + 1][SROW] */
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* parameter chunk [128][ST]; first the conditioner feature tile [32][nfs] */
+    float* s_y = s_p + 128 * ST;                          /* y / out tile [32][ys] + 32 spare floats */
     const int d = a.d;
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * FW + wave;
@@ -747,118 +878,131 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
     const float* y_t = a.y + b0 * a.ldy;            /* wave-uniform tile bases, 32-bit per-lane offsets */
     float* out_t = a.out + b0 * a.ldo;
+    V2_TS(0);
 
-    /* ---- stage the (featurised) conditioner input [feature][sample], a constant-1 row for the bias, zero pad rows.
-     * All global loads of a batch (SB per array and lane) are issued before anything waits on them: one HBM round trip per batch
-     * instead of one per 64 elements.  (A persistent-wave variant with register prefetch of the next tile's inputs measured 6 %
-     * SLOWER than letting the dispatcher overlap the prologue of fresh workgroups with the tails of retiring ones.) ---- */
-#ifndef BGK_V2_SB
-#define BGK_V2_SB 10
-#endif
-    constexpr int SB = BGK_V2_SB;
-    /* the segment table is indexed at run time: read it from the kernel-argument block (constant address space, scalar loads) --
-     * indexing the by-value argument struct would make the compiler copy the whole struct to scratch memory */
-    const kargs_t kseg = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-    for (int sg = 0; sg < a.cs.n; ++sg) {           /* conditioning tensor sg (one for a single-tensor coupling); y travels with the first */
-    const float* cond_t = kseg->cs.ptr[sg] + b0 * kseg->cs.ld[sg];
-    const int ldc32 = (int)kseg->cs.ld[sg], w_c = kseg->cs.w[sg], n_c = 32 * w_c, row0 = kseg->cs.off[sg] * SROW;
-    const uint32_t magic_c = kseg->cs.magic[sg];
-    const int n_ys = sg == 0 ? n_y : 0;
-    for (int base = 0; base < (n_c > n_ys ? n_c : n_ys); base += 64 * SB) {
-        float vc[SB], vy[SB];
-        int oc[SB], oy[SB];
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int i = base + u * 64 + lane;
-            const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
-            oc[u] = i < n_c ? row0 + (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
-#if (BGK_V2_ABL & 8)
-            vc[u] = 0.25f;
-#else
-            vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int i = base + u * 64 + lane;
-            const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
-            oy[u] = i < n_ys ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
-#if (BGK_V2_ABL & 8)
-            vy[u] = 0.5f;
-#else
-            vy[u] = (i < n_ys && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.5f;
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            if (oc[u] >= 0) {
-                if (a.periodic) {
-                    float sv, cv;
-                    bgk_sincos2pif(vc[u], &sv, &cv);
-                    s_p[oc[u]] = cv;
-                    s_p[a.d_c * SROW + oc[u]] = sv;
-                } else {
-                    s_p[oc[u]] = __builtin_amdgcn_fmed3f(vc[u], -65000.0f, 65000.0f);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u)
-            if (oy[u] >= 0) s_y[oy[u]] = vy[u];
-    }
-    }
-    for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
-        s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    /* ---- layer 0 (bias = weight column of the constant-1 feature); B operand from LDS, split on the fly ---- */
+    /* ---- stage the tile's inputs as row-major images (one row per sample) in LDS: y -> s_y [32][ys], the (featurised) conditioner
+     * input -> s_p [32][nfs].  Contiguous, 16-byte aligned tensors (what a flow over separate field tensors hands over) travel by
+     * the DMA path: a linear copy, no staging registers, no index arithmetic, every request in flight from the first cycle.  The
+     * requests are followed at once by the operand loads that do not depend on the inputs (layer 0's first A fragments, the
+     * first ring slots of layer 1), so that one wait covers all of them.  (Round 3 staged [feature][sample] tiles through
+     * registers: ~50 instructions per element of index arithmetic, exec-masked LDS writes and branches -- 10 k of the 58 k cycles
+     * a wave spends on its tile, tools/r04_phase_ts.py.) ---- */
+    const int nfs = a.nfs, ys = a.ys;
+    if (a.y_dma) dma_tile32(s_y, y_t, n_y, rows * d, lane);
+    if (a.stage == 1) dma_tile32(s_p, a.cs.ptr[0] + b0 * a.cs.ld[0], 32 * a.d_c, rows * a.d_c, lane);
+    else if (a.stage == 2) dma_tile32(s_p + 32 * nfs, a.cs.ptr[0] + b0 * a.cs.ld[0], 32 * a.d_c, rows * a.d_c, lane);
     f32x16 h[4], acc[4];
     TFrag ring[RD];
     BFrag bf;
+    L0Frag fa, fb;
+    l0_request(fa, a.A0, 0, lane);
+    Live<4> g1{acc, bf, a.A1, voff, ring};
+    g1.start();
+#ifndef BGK_V2_SB
+#define BGK_V2_SB 8
+#endif
+    constexpr int SB = BGK_V2_SB;
+    if (!a.y_dma) {                                  /* y with a row stride / unaligned: per-lane loads, SB in flight per lane */
+        for (int base = 0; base < n_y; base += 64 * SB) {
+            float vy[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int i = base + u * 64 + lane;
+                const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
+                vy[u] = (i < n_y && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.5f;
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int i = base + u * 64 + lane;
+                const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
+                if (i < n_y) s_y[(int)__umul24((unsigned)r, (unsigned)ys) + c] = vy[u];
+            }
+        }
+    }
+    if (a.stage == 0) {
+        /* the general path: several conditioning tensors, row strides, unaligned bases.  The segment table is indexed at run time:
+         * read it from the kernel-argument block (constant address space, scalar loads) -- indexing the by-value argument struct
+         * would make the compiler copy the whole struct to scratch memory */
+        const kargs_t kseg = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+        for (int sg = 0; sg < a.cs.n; ++sg) {
+            const float* cond_t = kseg->cs.ptr[sg] + b0 * kseg->cs.ld[sg];
+            const int ldc32 = (int)kseg->cs.ld[sg], w_c = kseg->cs.w[sg], n_c = 32 * w_c, col0 = kseg->cs.off[sg];
+            const uint32_t magic_c = kseg->cs.magic[sg];
+            for (int base = 0; base < n_c; base += 64 * SB) {
+                float vc[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int i = base + u * 64 + lane;
+                    const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
+                    vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int i = base + u * 64 + lane;
+                    const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
+                    if (i < n_c) {
+                        float* f = s_p + (int)__umul24((unsigned)r, (unsigned)nfs) + col0 + c;
+                        if (a.periodic) {
+                            float sv, cv;
+                            bgk_sincos2pif(vc[u], &sv, &cv);
+                            f[0] = cv;
+                            f[a.d_c] = sv;
+                        } else {
+                            f[0] = vc[u];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    V2_TS(12);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* DMA pieces land in request order: everything above has arrived */
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    V2_TS(13);
+    if (a.stage == 2) {
+        /* [cos 2 pi c | sin 2 pi c] of the raw tile (behind the feature tile) in its memory order: element i = (sample i / d_c, column i % d_c) */
+        const float* raw = s_p + 32 * nfs;
+        const uint32_t magic_c = a.cs.magic[0];
+        for (int i = lane; i < 32 * a.d_c; i += 64) {
+            const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)a.d_c);
+            float sv, cv;
+            bgk_sincos2pif(raw[i], &sv, &cv);
+            float* f = s_p + (int)__umul24((unsigned)r, (unsigned)nfs) + c;
+            f[0] = cv;
+            f[a.d_c] = sv;
+        }
+    }
+    if (a.stage != 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    V2_TS(1);
+
+    /* ---- layer 0; B operand = 8 consecutive features of the lane's sample row, split on the fly.  The bias is the weight column of
+     * a constant-1 feature n_in, which sits in the last k-step: it (and zeros behind it) are selected into the operand there, the
+     * tile itself holds the n_in real features only.  A fragments of k-step s + 1 are requested before the MFMAs of k-step s. ---- */
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
-    for (int s = 0; s < a.S0; ++s) {
-        uint4 fa[4][2];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            fa[m][0] = a.A0[((s * 4 + m) * 2 + 0) * 64 + lane];
-            fa[m][1] = a.A0[((s * 4 + m) * 2 + 1) * 64 + lane];
+    {
+        const float* frow = s_p + j * nfs + 8 * hh;
+        const int rel0 = 16 * (a.S0 - 1) + 8 * hh - n_in;       /* feature index of element 0 of the last k-step, relative to the constant-1 feature */
+        for (int s = 0; s < a.S0; s += 2) {
+            if (s + 1 < a.S0) l0_request(fb, a.A0, s + 1, lane);
+            l0_step(h, fa, frow + 16 * s, s + 1 == a.S0, rel0);
+            if (s + 1 < a.S0) {
+                if (s + 2 < a.S0) l0_request(fa, a.A0, s + 2, lane);
+                l0_step(h, fb, frow + 16 * (s + 1), s + 2 == a.S0, rel0);
+            }
         }
-#if BGK_V2_BF16
-        s16x8 bb;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = s_p[(16 * s + 8 * hh + e) * SROW + j];
-            bb[e] = __builtin_bit_cast(short, (__bf16)v);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            h[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, fa[m][0]), bb, h[m], 0, 0, 0);
-#else
-        h16x8 bhi, blo;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float v = s_p[(16 * s + 8 * hh + e) * SROW + j];
-            const _Float16 hv = (_Float16)v;
-            bhi[e] = hv;
-            blo[e] = (_Float16)(v - (float)hv);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[m][1]), bhi, h[m], 0, 0, 0);
-            h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[m][0]), blo, h[m], 0, 0, 0);
-            h[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, fa[m][0]), bhi, h[m], 0, 0, 0);
-        }
-#endif
     }
 
+    V2_TS(2);
     /* ---- layer 1: events of k-steps 2t, 2t + 1 behind the activation of tile t + 1 ---- */
     {
-        Live<4> g{acc, bf, a.A1, voff, ring};
-        g.start();
+        Live<4>& g = g1;
 #if BGK_V2_SAVE
         /* z0 = layer-0 pre-activations, as full rows through the (now free) parameter-chunk buffer: [32][132] = 128 * ST floats;
          * after the ring start: the first MFMAs then wait for their operand loads only, not for these 16 stores (vmcnt is in order) */
@@ -874,13 +1018,16 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         NoLive none;
         act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, h[0], c0_act, bf);
         __builtin_amdgcn_sched_barrier(0);
+        V2_TS(14);
         act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, h[1], c0_act, bf);      /* hook i = event i (100 events) */
         act_split_tile<ACT, 2>(Hooks<Live<4>, 24, 100>{g}, h[2], c0_act, bf);
         act_split_tile<ACT, 3>(Hooks<Live<4>, 48, 100>{g}, h[3], c0_act, bf);
         __builtin_amdgcn_sched_barrier(0);
+        V2_TS(15);
         g.template events<(72 * Live<4>::NEV) / 100, Live<4>::NEV>();
     }
 
+    V2_TS(3);
     /* ---- layer 2, chunk 0: the same behind the activation of the layer-1 tiles ---- */
     float run = 0.0f;
     int oob_local = 0;
@@ -906,6 +1053,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         __builtin_amdgcn_sched_barrier(0);
         g.template events<(72 * Live<4>::NEV) / 100, Live<4>::NEV>();
     }
+    V2_TS(4);
     /* ---- chunks: h -> LDS; spline(c) threaded through GEMM(c + 1) ---- */
     for (int c = 0; c < a.n_chunks; ++c) {
         int bins[3] = {0, 0, 0};
@@ -928,6 +1076,9 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
             if (nd > 4) spline_slot<INV, 2, 1>(none, a, k, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
 #endif
         }
+#if BGK_V2_TS
+        V2_TS(5 + c);
+#else
         if (a.bin_idx) {
 #pragma unroll
             for (int it = 0; it < 3; ++it) {
@@ -935,24 +1086,28 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
                 if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
             }
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     if (hh == 0 && j < rows) {
         if (a.accumulate) a.dlogp[b0 + j] += run; else a.dlogp[b0 + j] = run;
     }
-#if (BGK_V2_ABL & 8)
-    if (lane < d) out_t[lane] = s_y[lane * SROW];
-#else
-    for (int i = lane; i < rows * d; i += 64) {
-        const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), cc = i - (int)__umul24((unsigned)r, (unsigned)d);
-        out_t[(int)__umul24((unsigned)r, (unsigned)ldo32) + cc] = s_y[(int)__umul24((unsigned)cc, (unsigned)SROW) + r];
+    if (a.out_lin) {                                  /* the tile image is the memory image: 16-byte pieces, the last 1..3 floats of a partial tile singly */
+        const int n = rows * d;
+        for (int i = lane * 4; i + 3 < n; i += 256) *reinterpret_cast<float4*>(out_t + i) = *reinterpret_cast<const float4*>(s_y + i);
+        if (lane < (n & 3)) out_t[(n & ~3) + lane] = s_y[(n & ~3) + lane];
+    } else {
+        for (int i = lane; i < rows * d; i += 64) {
+            const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), cc = i - (int)__umul24((unsigned)r, (unsigned)d);
+            out_t[(int)__umul24((unsigned)r, (unsigned)ldo32) + cc] = s_y[(int)__umul24((unsigned)r, (unsigned)ys) + cc];
+        }
     }
-#endif
     if (a.oob_count && __builtin_amdgcn_ballot_w64(oob_local != 0)) {     /* rare: inputs outside the spline domain */
         for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
         if (lane == 0) atomicAdd(a.oob_count, oob_local);
     }
+    V2_TS(5 + a.n_chunks);
   }
 }
 
@@ -1117,6 +1272,9 @@ __device__ __forceinline__ float aff_tanh_out(float x) {
 
 template <int ACT_S, int ACT_T, int OT, bool DEEP>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(AffV2Args a) {
+#if BGK_V2_OVFL
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");                 /* MODE.FP16_OVFL (act_split_pair carries no clamps) */
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6;
     float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* the featurised conditioner tile [16 S0][SROW]; later the shift values [d][SROW] */
@@ -1305,7 +1463,18 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
     a.sc.sb = inverse ? sh : sw;
     const double beta = identity_init ? (0.6931471805599453 / (1.0 - min_derivative)) : 1.0;
     a.sc.beta = (float)beta; a.sc.kout = (float)(0.6931471805599453 / (double)(float)beta); a.sc.min_d = (float)min_derivative;
-    a.lds_per_wave = 128 * ST + (d + 1) * SROW;
+    /* tile images: DMA copies need a contiguous, 16-byte aligned tensor and a row length whose LDS bank pattern is harmless (rows of
+     * a tile are read one per lane: a row stride that is a multiple of 8 dwords would serialise every access 8-fold or worse) */
+    const bool one = a.cs.n == 1;
+    const auto dma_ok = [](const float* p, int64_t ld, int w) { return ld == w && ((uintptr_t)p & 15) == 0 && (w & 7) != 0; };
+    a.y_dma = dma_ok(y, ldy, d) ? 1 : 0;
+    a.ys = a.y_dma ? d : (d | 1);
+    a.out_lin = (a.y_dma && ldo == d && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+    const bool c_dma = one && dma_ok(a.cs.ptr[0], a.cs.ld[0], d_c);
+    a.stage = (c_dma && !periodic) ? 1 : ((c_dma && periodic && 32 * ((n_in | 1) + d_c) <= 128 * ST) ? 2 : 0);
+    a.nfs = a.stage == 1 ? d_c : (n_in | 1);
+    BGK_CHECK_ARG(32 * a.nfs + 16 <= 128 * ST, "%s: %d conditioner input features do not fit the LDS tile", what, n_in);
+    a.lds_per_wave = ((128 * ST + 32 * a.ys + 32 + 3) / 4) * 4;
 #if BGK_V2_SAVE
     a.z0 = z0; a.z1 = z1; a.params = params; a.ldp = ldp; a.src_col = src_col;
 #endif
