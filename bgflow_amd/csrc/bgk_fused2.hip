@@ -802,6 +802,121 @@ __device__ __forceinline__ void dma_tile32(float* dst, const float* __restrict__
     }
 }
 
+/* ---- staging of a tile's inputs as row-major images (one row per sample) in LDS: y -> s_y [32][ys], the (featurised) conditioner
+ * input -> s_p [32][nfs].  Contiguous, 16-byte aligned tensors (what a flow over separate field tensors hands over) travel by the
+ * DMA path: a linear copy, no staging registers, no index arithmetic, every request in flight from the first cycle.  stage_issue
+ * only issues those requests; the caller follows them with the operand loads that do not depend on the inputs (layer 0's first A
+ * fragments, the first ring slots of layer 1), so that the one wait inside stage_finish covers all of them.  (Round 3 staged
+ * [feature][sample] tiles through registers: ~50 instructions per element of index arithmetic, exec-masked LDS writes and branches --
+ * 10 k of the 58 k cycles a wave spends on its tile, tools/r04_phase_ts.py.)
+ * stage: 0 = per-lane loads (any strides / several tensors / periodic), 1 = the contiguous [32][d_c] tile copied by the DMA path IS
+ * the feature tile (nfs = d_c), 2 = DMA of the raw tile behind the feature tile + an elementwise cos / sin pass. */
+struct StageTiles { int d_c, periodic, nfs, ys, stage, y_dma, d; uint32_t magic_d; int rows, lane; };
+
+__device__ __forceinline__ void stage_issue(const StageTiles& t, const CondSegs& cs, int64_t b0, const float* y_t, float* s_p, float* s_y) {
+    if (t.y_dma) dma_tile32(s_y, y_t, 32 * t.d, t.rows * t.d, t.lane);
+    if (t.stage == 1) dma_tile32(s_p, cs.ptr[0] + b0 * cs.ld[0], 32 * t.d_c, t.rows * t.d_c, t.lane);
+    else if (t.stage == 2) dma_tile32(s_p + 32 * t.nfs, cs.ptr[0] + b0 * cs.ld[0], 32 * t.d_c, t.rows * t.d_c, t.lane);
+}
+
+#ifndef BGK_V2_SB
+#define BGK_V2_SB 8
+#endif
+/* KA: the kernel's argument struct (its CondSegs member `cs` first): the segment table of the general path is indexed at run time and
+ * read from the kernel-argument block by scalar loads -- indexing the by-value struct would make the compiler copy it to scratch */
+template <class KA>
+__device__ __forceinline__ void stage_finish(const StageTiles& t, const CondSegs& cs, int64_t b0, const float* y_t, int ldy32,
+                                             float* s_p, float* s_y, float y_fill) {
+    constexpr int SB = BGK_V2_SB;
+    const int lane = t.lane, rows = t.rows, d = t.d, nfs = t.nfs, n_y = 32 * t.d;
+    if (!t.y_dma) {                                  /* y with a row stride / unaligned: per-lane loads, SB in flight per lane */
+        for (int base = 0; base < n_y; base += 64 * SB) {
+            float vy[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int i = base + u * 64 + lane;
+                const int r = (int)(__umul24((unsigned)i, t.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
+                vy[u] = (i < n_y && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : y_fill;
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int i = base + u * 64 + lane;
+                const int r = (int)(__umul24((unsigned)i, t.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
+                if (i < n_y) s_y[(int)__umul24((unsigned)r, (unsigned)t.ys) + c] = vy[u];
+            }
+        }
+    }
+    if (t.stage == 0) {
+        typedef const __attribute__((address_space(4))) KA* ka_t;
+        const ka_t kseg = (ka_t)__builtin_amdgcn_kernarg_segment_ptr();
+        for (int sg = 0; sg < cs.n; ++sg) {
+            const float* cond_t = kseg->cs.ptr[sg] + b0 * kseg->cs.ld[sg];
+            const int ldc32 = (int)kseg->cs.ld[sg], w_c = kseg->cs.w[sg], n_c = 32 * w_c, col0 = kseg->cs.off[sg];
+            const uint32_t magic_c = kseg->cs.magic[sg];
+            for (int base = 0; base < n_c; base += 64 * SB) {
+                float vc[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int i = base + u * 64 + lane;
+                    const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
+                    vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int i = base + u * 64 + lane;
+                    const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
+                    if (i < n_c) {
+                        float* f = s_p + (int)__umul24((unsigned)r, (unsigned)nfs) + col0 + c;
+                        if (t.periodic) {                               /* WrapPeriodic featuriser (nn/periodic.py:30-37) */
+                            float sv, cv;
+                            bgk_sincos2pif(vc[u], &sv, &cv);
+                            f[0] = cv;
+                            f[t.d_c] = sv;
+                        } else {
+                            f[0] = vc[u];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* DMA pieces land in request order: everything requested so far has arrived */
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (t.stage == 2) {
+        /* [cos 2 pi c | sin 2 pi c] of the raw tile (behind the feature tile) in its memory order: element i = (sample i / d_c, column i % d_c) */
+        const float* raw = s_p + 32 * nfs;
+        const uint32_t magic_c = cs.magic[0];
+        for (int i = lane; i < 32 * t.d_c; i += 64) {
+            const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)t.d_c);
+            float sv, cv;
+            bgk_sincos2pif(raw[i], &sv, &cv);
+            float* f = s_p + (int)__umul24((unsigned)r, (unsigned)nfs) + c;
+            f[0] = cv;
+            f[t.d_c] = sv;
+        }
+    }
+    if (t.stage != 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* the finished tile image -> out rows.  lin: the image IS the memory image (contiguous, aligned rows): 16-byte pieces, the last 1..3
+ * floats of a partial tile singly */
+__device__ __forceinline__ void store_tile32(float* out_t, int ldo32, const float* s_y, int ys, int d, uint32_t magic_d, int rows, int lane, int lin) {
+    const int n = rows * d;
+    if (lin) {
+        for (int i = lane * 4; i + 3 < n; i += 256) *reinterpret_cast<float4*>(out_t + i) = *reinterpret_cast<const float4*>(s_y + i);
+        if (lane < (n & 3)) out_t[(n & ~3) + lane] = s_y[(n & ~3) + lane];
+    } else {
+        for (int i = lane; i < n; i += 64) {
+            const int r = (int)(__umul24((unsigned)i, magic_d) >> 20), cc = i - (int)__umul24((unsigned)r, (unsigned)d);
+            out_t[(int)__umul24((unsigned)r, (unsigned)ldo32) + cc] = s_y[(int)__umul24((unsigned)r, (unsigned)ys) + cc];
+        }
+    }
+}
+
 /* layer 0: A fragments of one k-step (4 tiles x {hi, lo}) */
 struct L0Frag { uint4 v[4][2]; };
 __device__ __forceinline__ void l0_request(L0Frag& f, const uint4* A0, int s, int lane) {
@@ -888,9 +1003,8 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
      * registers: ~50 instructions per element of index arithmetic, exec-masked LDS writes and branches -- 10 k of the 58 k cycles
      * a wave spends on its tile, tools/r04_phase_ts.py.) ---- */
     const int nfs = a.nfs, ys = a.ys;
-    if (a.y_dma) dma_tile32(s_y, y_t, n_y, rows * d, lane);
-    if (a.stage == 1) dma_tile32(s_p, a.cs.ptr[0] + b0 * a.cs.ld[0], 32 * a.d_c, rows * a.d_c, lane);
-    else if (a.stage == 2) dma_tile32(s_p + 32 * nfs, a.cs.ptr[0] + b0 * a.cs.ld[0], 32 * a.d_c, rows * a.d_c, lane);
+    const StageTiles stg{a.d_c, a.periodic, nfs, ys, a.stage, a.y_dma, d, a.magic_d, rows, lane};
+    stage_issue(stg, a.cs, b0, y_t, s_p, s_y);
     f32x16 h[4], acc[4];
     TFrag ring[RD];
     BFrag bf;
@@ -898,85 +1012,8 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
     l0_request(fa, a.A0, 0, lane);
     Live<4> g1{acc, bf, a.A1, voff, ring};
     g1.start();
-#ifndef BGK_V2_SB
-#define BGK_V2_SB 8
-#endif
-    constexpr int SB = BGK_V2_SB;
-    if (!a.y_dma) {                                  /* y with a row stride / unaligned: per-lane loads, SB in flight per lane */
-        for (int base = 0; base < n_y; base += 64 * SB) {
-            float vy[SB];
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int i = base + u * 64 + lane;
-                const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
-                vy[u] = (i < n_y && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.5f;
-            }
-#pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int i = base + u * 64 + lane;
-                const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
-                if (i < n_y) s_y[(int)__umul24((unsigned)r, (unsigned)ys) + c] = vy[u];
-            }
-        }
-    }
-    if (a.stage == 0) {
-        /* the general path: several conditioning tensors, row strides, unaligned bases.  The segment table is indexed at run time:
-         * read it from the kernel-argument block (constant address space, scalar loads) -- indexing the by-value argument struct
-         * would make the compiler copy the whole struct to scratch memory */
-        const kargs_t kseg = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-        for (int sg = 0; sg < a.cs.n; ++sg) {
-            const float* cond_t = kseg->cs.ptr[sg] + b0 * kseg->cs.ld[sg];
-            const int ldc32 = (int)kseg->cs.ld[sg], w_c = kseg->cs.w[sg], n_c = 32 * w_c, col0 = kseg->cs.off[sg];
-            const uint32_t magic_c = kseg->cs.magic[sg];
-            for (int base = 0; base < n_c; base += 64 * SB) {
-                float vc[SB];
-#pragma unroll
-                for (int u = 0; u < SB; ++u) {
-                    const int i = base + u * 64 + lane;
-                    const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
-                    vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
-                }
-#pragma unroll
-                for (int u = 0; u < SB; ++u) {
-                    const int i = base + u * 64 + lane;
-                    const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
-                    if (i < n_c) {
-                        float* f = s_p + (int)__umul24((unsigned)r, (unsigned)nfs) + col0 + c;
-                        if (a.periodic) {
-                            float sv, cv;
-                            bgk_sincos2pif(vc[u], &sv, &cv);
-                            f[0] = cv;
-                            f[a.d_c] = sv;
-                        } else {
-                            f[0] = vc[u];
-                        }
-                    }
-                }
-            }
-        }
-    }
     V2_TS(12);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          /* DMA pieces land in request order: everything above has arrived */
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    V2_TS(13);
-    if (a.stage == 2) {
-        /* [cos 2 pi c | sin 2 pi c] of the raw tile (behind the feature tile) in its memory order: element i = (sample i / d_c, column i % d_c) */
-        const float* raw = s_p + 32 * nfs;
-        const uint32_t magic_c = a.cs.magic[0];
-        for (int i = lane; i < 32 * a.d_c; i += 64) {
-            const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)a.d_c);
-            float sv, cv;
-            bgk_sincos2pif(raw[i], &sv, &cv);
-            float* f = s_p + (int)__umul24((unsigned)r, (unsigned)nfs) + c;
-            f[0] = cv;
-            f[a.d_c] = sv;
-        }
-    }
-    if (a.stage != 1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
+    stage_finish<V2Args>(stg, a.cs, b0, y_t, ldy32, s_p, s_y, 0.5f);
     V2_TS(1);
 
     /* ---- layer 0; B operand = 8 consecutive features of the lane's sample row, split on the fly.  The bias is the weight column of
@@ -1093,22 +1130,29 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
     if (hh == 0 && j < rows) {
         if (a.accumulate) a.dlogp[b0 + j] += run; else a.dlogp[b0 + j] = run;
     }
-    if (a.out_lin) {                                  /* the tile image is the memory image: 16-byte pieces, the last 1..3 floats of a partial tile singly */
-        const int n = rows * d;
-        for (int i = lane * 4; i + 3 < n; i += 256) *reinterpret_cast<float4*>(out_t + i) = *reinterpret_cast<const float4*>(s_y + i);
-        if (lane < (n & 3)) out_t[(n & ~3) + lane] = s_y[(n & ~3) + lane];
-    } else {
-        for (int i = lane; i < rows * d; i += 64) {
-            const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), cc = i - (int)__umul24((unsigned)r, (unsigned)d);
-            out_t[(int)__umul24((unsigned)r, (unsigned)ldo32) + cc] = s_y[(int)__umul24((unsigned)r, (unsigned)ys) + cc];
-        }
-    }
+    store_tile32(out_t, ldo32, s_y, ys, d, a.magic_d, rows, lane, a.out_lin);
     if (a.oob_count && __builtin_amdgcn_ballot_w64(oob_local != 0)) {     /* rare: inputs outside the spline domain */
         for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
         if (lane == 0) atomicAdd(a.oob_count, oob_local);
     }
     V2_TS(5 + a.n_chunks);
   }
+}
+
+/* tile images: DMA copies need a contiguous, 16-byte aligned tensor and a row length whose LDS bank pattern is harmless (the rows of a
+ * tile are read one per lane: a row stride that is a multiple of 8 dwords would serialise every access 8-fold or worse) */
+struct TilePlan { int nfs, ys, stage, y_dma, out_lin; };
+TilePlan plan_tiles(const CondSegs& cs, int d_c, int periodic, const float* y, int64_t ldy, const float* out, int64_t ldo, int d, int tile_floats) {
+    const int n_in = periodic ? 2 * d_c : d_c;
+    const auto dma_ok = [](const float* p, int64_t ld, int w) { return ld == w && ((uintptr_t)p & 15) == 0 && (w & 7) != 0; };
+    TilePlan t;
+    t.y_dma = dma_ok(y, ldy, d) ? 1 : 0;
+    t.ys = t.y_dma ? d : (d | 1);
+    t.out_lin = (t.y_dma && ldo == d && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+    const bool c_dma = cs.n == 1 && dma_ok(cs.ptr[0], cs.ld[0], d_c);
+    t.stage = (c_dma && !periodic) ? 1 : ((c_dma && periodic && 32 * ((n_in | 1) + d_c) <= tile_floats) ? 2 : 0);
+    t.nfs = t.stage == 1 ? d_c : (n_in | 1);
+    return t;
 }
 
 SetK make_set(double low, double high, double min_bin, int K) {
@@ -1168,47 +1212,27 @@ struct AffV2Args {
     float* out; int64_t ldo; float* dlogp; int accumulate;
     uint32_t magic_d;
     int lds_tile, lds_per_wave;  /* floats: conditioner / shift tile, whole wave slice (+ y / out tile) */
+    int nfs, ys, stage, y_dma, out_lin;   /* the tile images (see StageTiles) */
 };
 
-/* layer 0: X = A0' * [features; 1]  (bias = weight column of the constant-1 feature); B operand from LDS, split on the fly.
- * The A fragments of k-step s + 1 are requested before the MFMAs of k-step s (two fragment sets, loop unrolled by two). */
-struct AffFrag0 { uint4 v[4][2]; };
-__device__ __forceinline__ void aff_l0_request(AffFrag0& f, const uint4* A0, int s, int lane) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        f.v[m][0] = A0[((s * 4 + m) * 2 + 0) * 64 + lane];
-        f.v[m][1] = A0[((s * 4 + m) * 2 + 1) * 64 + lane];
-    }
-}
-__device__ __forceinline__ void aff_l0_step(f32x16 (&X)[4], const AffFrag0& f, const float* s_p, int s, int j, int hh) {
-    h16x8 bhi, blo;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float v = s_p[(16 * s + 8 * hh + e) * SROW + j];
-        const _Float16 hv = (_Float16)v;
-        bhi[e] = hv;
-        blo[e] = (_Float16)(v - (float)hv);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        X[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.v[m][1]), bhi, X[m], 0, 0, 0);
-        X[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.v[m][0]), blo, X[m], 0, 0, 0);
-        X[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, f.v[m][0]), bhi, X[m], 0, 0, 0);
-    }
-}
-__device__ __forceinline__ void aff_layer0(const AffV2Net& n, int S0, const float* s_p, int lane, int j, int hh, f32x16 (&X)[4]) {
+/* layer 0: X = A0' * [features; 1] (l0_step); the A fragments of k-step s + 1 are requested before the MFMAs of k-step s (two fragment
+ * sets, loop unrolled by two).  requested: `fa` already holds (or has in flight) the fragments of k-step 0. */
+__device__ __forceinline__ void aff_layer0(const AffV2Net& n, int S0, const float* s_p, int nfs, int n_in, int lane, int j, int hh,
+                                           f32x16 (&X)[4], L0Frag& fa, bool requested) {
+    L0Frag fb;
+    if (!requested) l0_request(fa, n.A0, 0, lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) X[m][r] = 0.0f;
-    AffFrag0 fa, fb;
-    aff_l0_request(fa, n.A0, 0, lane);
+    const float* frow = s_p + j * nfs + 8 * hh;
+    const int rel0 = 16 * (S0 - 1) + 8 * hh - n_in;
     for (int s = 0; s < S0; s += 2) {
-        if (s + 1 < S0) aff_l0_request(fb, n.A0, s + 1, lane);
-        aff_l0_step(X, fa, s_p, s, j, hh);
+        if (s + 1 < S0) l0_request(fb, n.A0, s + 1, lane);
+        l0_step(X, fa, frow + 16 * s, s + 1 == S0, rel0);
         if (s + 1 < S0) {
-            if (s + 2 < S0) aff_l0_request(fa, n.A0, s + 2, lane);
-            aff_l0_step(X, fb, s_p, s + 1, j, hh);
+            if (s + 2 < S0) l0_request(fa, n.A0, s + 2, lane);
+            l0_step(X, fb, frow + 16 * (s + 1), s + 2 == S0, rel0);
         }
     }
 }
@@ -1277,8 +1301,8 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6;
-    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* the featurised conditioner tile [16 S0][SROW]; later the shift values [d][SROW] */
-    float* s_y = s_p + a.lds_tile;                        /* y / out tile [d][SROW]: coalesced global rows <-> one (dim, sample) per lane */
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* the conditioner feature tile [32][nfs] (+ the raw tile behind it); later the shift values [d][SROW] */
+    float* s_y = s_p + a.lds_tile;                        /* y / out tile [32][ys]: the memory image of the rows */
     const int d = a.d;
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * FW + wave;
@@ -1293,58 +1317,14 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
     const float* y_t = a.y + b0 * a.ldy;
     float* out_t = a.out + b0 * a.ldo;
 
-    /* ---- stage the (featurised) conditioner input [feature][sample] (+ the constant-1 row, zero pad rows) and y [dim][sample];
-     * all global loads of a batch are issued before anything waits on them (as in the spline kernel above) ---- */
-#ifndef BGK_AFF_SB
-#define BGK_AFF_SB 34       /* loads in flight per lane and array: one HBM round trip for up to 68 dims (nothing else is live yet) */
-#endif
-    constexpr int SB = BGK_AFF_SB;
-    typedef const __attribute__((address_space(4))) AffV2Args* akargs_t;      /* run-time indexed: scalar loads from the argument block */
-    const akargs_t kseg = (akargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-    for (int sg = 0; sg < a.cs.n; ++sg) {           /* conditioning tensor sg; y travels with the first */
-    const float* cond_t = kseg->cs.ptr[sg] + b0 * kseg->cs.ld[sg];
-    const int ldc32 = (int)kseg->cs.ld[sg], w_c = kseg->cs.w[sg], n_c = 32 * w_c, row0 = kseg->cs.off[sg] * SROW;
-    const uint32_t magic_c = kseg->cs.magic[sg];
-    const int n_ys = sg == 0 ? n_y : 0;
-    for (int base = 0; base < (n_c > n_ys ? n_c : n_ys); base += 64 * SB) {
-        float vc[SB], vy[SB];
-        int oc[SB], oy[SB];
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int i = base + u * 64 + lane;
-            const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)w_c);
-            oc[u] = i < n_c ? row0 + (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
-            vc[u] = (i < n_c && r < rows) ? cond_t[(int)__umul24((unsigned)r, (unsigned)ldc32) + c] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            const int i = base + u * 64 + lane;
-            const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)d);
-            oy[u] = i < n_ys ? (int)__umul24((unsigned)c, (unsigned)SROW) + r : -1;
-            vy[u] = (i < n_ys && r < rows) ? y_t[(int)__umul24((unsigned)r, (unsigned)ldy32) + c] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u) {
-            if (oc[u] >= 0) {
-                if (a.periodic) {                                        /* WrapPeriodic featuriser (nn/periodic.py:30-37) */
-                    float sv, cv;
-                    bgk_sincos2pif(vc[u], &sv, &cv);
-                    s_p[oc[u]] = cv;
-                    s_p[a.d_c * SROW + oc[u]] = sv;
-                } else {
-                    s_p[oc[u]] = __builtin_amdgcn_fmed3f(vc[u], -65000.0f, 65000.0f);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SB; ++u)
-            if (oy[u] >= 0) s_y[oy[u]] = vy[u];
-    }
-    }
-    for (int i = lane; i < (16 * a.S0 - n_in) * 32; i += 64)
-        s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    /* ---- stage the tile images (see StageTiles): y -> s_y [32][ys], conditioner features -> s_p [32][nfs]; the first network's
+     * layer-0 fragments travel with them ---- */
+    const int nfs = a.nfs, ys = a.ys;
+    const StageTiles stg{a.d_c, a.periodic, nfs, ys, a.stage, a.y_dma, d, a.magic_d, rows, lane};
+    stage_issue(stg, a.cs, b0, y_t, s_p, s_y);
+    L0Frag fa;
+    l0_request(fa, a.has_shift ? a.shift.A0 : a.scale.A0, 0, lane);
+    stage_finish<AffV2Args>(stg, a.cs, b0, y_t, ldy32, s_p, s_y, 0.0f);
 
     f32x16 h[4], acc[4];
     TFrag ring[RD];
@@ -1353,11 +1333,12 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
     f32x16 (&mu)[4] = DEEP ? acc : h;
     f32x16 (&t0)[4] = DEEP ? h : acc;          /* the scale network's layer-0 output: the array that does not hold mu */
     if (a.has_shift) {
-        aff_layer0(a.shift, a.S0, s_p, lane, j, hh, h);
+        aff_layer0(a.shift, a.S0, s_p, nfs, n_in, lane, j, hh, h, fa, true);
         aff_layers<ACT_S, OT, DEEP>(a.shift, h, acc, bf, ring, voff);
     }
-    /* ---- scale network: layer 0 while the other array still holds the shift values; then they are parked in the (now free) tile ---- */
-    if (a.has_scale) aff_layer0(a.scale, a.S0, s_p, lane, j, hh, t0);
+    /* ---- scale network: layer 0 while the other array still holds the shift values; then they are parked in the (now free) tile.
+     * (Its first fragments requested any earlier stay live across the GEMMs above: spills.) ---- */
+    if (a.has_scale) aff_layer0(a.scale, a.S0, s_p, nfs, n_in, lane, j, hh, t0, fa, !a.has_shift);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.has_shift) {
@@ -1402,13 +1383,13 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
         for (int r = 0; r < 16; ++r) {
             const int dim = drow(m, r, hh);
             if (dim < d) {
-                const float yv = s_y[dim * SROW + j];
+                const float yv = s_y[j * ys + dim];
                 const float mm = a.has_shift ? s_p[dim * SROW + j] : 0.0f;
                 const float ls = acc[m][r];
                 const float sg = __builtin_amdgcn_exp2f((a.inverse ? -ls : ls) * 1.44269504088896341f);     /* |ls| <= exp(log_alpha): 1 ulp */
                 float t = a.inverse ? sg * (yv - mm) : sg * yv + mm;
                 if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
-                s_y[dim * SROW + j] = t;
+                s_y[j * ys + dim] = t;
             }
         }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1417,10 +1398,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
         const float dl = a.inverse ? -total : total;
         if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
     }
-    for (int i = lane; i < rows * d; i += 64) {
-        const int r = (int)(__umul24((unsigned)i, a.magic_d) >> 20), cc = i - (int)__umul24((unsigned)r, (unsigned)d);
-        out_t[(int)__umul24((unsigned)r, (unsigned)ldo32) + cc] = s_y[(int)__umul24((unsigned)cc, (unsigned)SROW) + r];
-    }
+    store_tile32(out_t, ldo32, s_y, ys, d, a.magic_d, rows, lane, a.out_lin);
 }
 #endif   /* affine layer */
 
@@ -1463,16 +1441,8 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
     a.sc.sb = inverse ? sh : sw;
     const double beta = identity_init ? (0.6931471805599453 / (1.0 - min_derivative)) : 1.0;
     a.sc.beta = (float)beta; a.sc.kout = (float)(0.6931471805599453 / (double)(float)beta); a.sc.min_d = (float)min_derivative;
-    /* tile images: DMA copies need a contiguous, 16-byte aligned tensor and a row length whose LDS bank pattern is harmless (rows of
-     * a tile are read one per lane: a row stride that is a multiple of 8 dwords would serialise every access 8-fold or worse) */
-    const bool one = a.cs.n == 1;
-    const auto dma_ok = [](const float* p, int64_t ld, int w) { return ld == w && ((uintptr_t)p & 15) == 0 && (w & 7) != 0; };
-    a.y_dma = dma_ok(y, ldy, d) ? 1 : 0;
-    a.ys = a.y_dma ? d : (d | 1);
-    a.out_lin = (a.y_dma && ldo == d && ((uintptr_t)out & 15) == 0) ? 1 : 0;
-    const bool c_dma = one && dma_ok(a.cs.ptr[0], a.cs.ld[0], d_c);
-    a.stage = (c_dma && !periodic) ? 1 : ((c_dma && periodic && 32 * ((n_in | 1) + d_c) <= 128 * ST) ? 2 : 0);
-    a.nfs = a.stage == 1 ? d_c : (n_in | 1);
+    const TilePlan tp = plan_tiles(a.cs, d_c, periodic, y, ldy, out, ldo, d, 128 * ST);
+    a.nfs = tp.nfs; a.ys = tp.ys; a.stage = tp.stage; a.y_dma = tp.y_dma; a.out_lin = tp.out_lin;
     BGK_CHECK_ARG(32 * a.nfs + 16 <= 128 * ST, "%s: %d conditioner input features do not fit the LDS tile", what, n_in);
     a.lds_per_wave = ((128 * ST + 32 * a.ys + 32 + 3) / 4) * 4;
 #if BGK_V2_SAVE
@@ -1519,9 +1489,11 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
     a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
     a.magic_d = magic_div(d);
     const int OT = (d + 31) / 32;
-    const int tile_f = 16 * a.S0 * SROW, park_f = d * SROW;
-    a.lds_tile = tile_f > park_f ? tile_f : park_f;
-    a.lds_per_wave = a.lds_tile + d * SROW;
+    TilePlan tp = plan_tiles(a.cs, d_c, periodic, y, ldy, out, ldo, d, 32 * 128);
+    a.nfs = tp.nfs; a.ys = tp.ys; a.stage = tp.stage; a.y_dma = tp.y_dma; a.out_lin = tp.out_lin;
+    const int tile_f = 32 * a.nfs + (a.stage == 2 ? 32 * d_c : 0) + 16, park_f = d * SROW;
+    a.lds_tile = (((tile_f > park_f ? tile_f : park_f) + 3) / 4) * 4;
+    a.lds_per_wave = a.lds_tile + ((32 * a.ys + 3) / 4) * 4;
     const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);

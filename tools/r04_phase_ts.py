@@ -30,7 +30,7 @@ for kind in ("B|A", "T|F", "F|T"):
         raw = l.transformer.last_bin_indices.view(-1, 32 * d)[:, :16].cpu().numpy().astype(np.int64)
         ts = raw[:, : 6 + nck]
         ex = lambda a, b: ((raw[:, a] - raw[:, b]) % (1 << 32)).mean()
-        print(f"   [stage: loads issued {ex(12, 0):.0f} | wait for them {ex(13, 12):.0f} | LDS writes + pad rows {ex(1, 13):.0f}]  [layer1: ring start + tile-0 activation {ex(14, 2):.0f} | threaded tiles 1-3 {ex(15, 14):.0f} | tail events {ex(3, 15):.0f}]")
+        print(f"   [stage: loads issued {ex(12, 0):.0f} | wait + cos-sin pass {ex(1, 12):.0f} ]  [layer1: ring start + tile-0 activation {ex(14, 2):.0f} | threaded tiles 1-3 {ex(15, 14):.0f} | tail events {ex(3, 15):.0f}]")
         dt = (ts[:, 1:] - ts[:, :-1]) % (1 << 32)
         tot = (ts[:, -1] - ts[:, 0]) % (1 << 32)
         span = None
