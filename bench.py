@@ -173,6 +173,44 @@ def measured_traffic(kernel, batch):
     return None, None
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two short passes of the same workload under rocprofv3 --pmc
+    (FETCH_SIZE and WRITE_SIZE in separate passes, counters only -- never combined with a trace domain), collected and corrected as
+    MI355X_MICROARCH.md prescribes (KiB units; FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950 -> x 2).
+    Returns (bytes per launch, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--batch", str(args.batch), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras", "--kl-steps", "0"] + (["--gemm", args.gemm] if args.gemm else [])
+    means = {}
+    root = tempfile.mkdtemp(prefix="bgk_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(root, counter)
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--"] + cmd,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=root, timeout=600)
+            vals = []
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} rows for {kernel} (rocprofv3 exit code {r.returncode})"
+            means[counter] = (sum(vals) / len(vals), len(vals))
+    except Exception as e:        # a side measurement must never take the headline line down
+        return None, repr(e)[:200]
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    hbm = 1024.0 * (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0])
+    return hbm, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --workload {args.workload} "
+                 f"--batch {args.batch} --steps 2`, mean over {means['FETCH_SIZE'][1]} launches of {kernel}; bytes = 1024 (2 FETCH_SIZE + WRITE_SIZE) "
+                 "[KiB units, gfx950 x2 rule for wide coalesced reads]")
+
+
 def host_cpu():
     model, cores = "unknown CPU", set()
     try:
@@ -422,7 +460,11 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--gemm", default=None, choices=["f32", "f16x2", "bf16"],
                     help="conditioner GEMM mode of the fused coupling kernel (default: bgflow_amd.dense.GEMM_MODE)")
-    ap.add_argument("--batch", type=int, default=1 << 20, help="samples per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="samples per GPU per step (default: 2^20; with --gpus 8: 2^19 = BASELINE cfg 4, 2^22 samples sharded over 8 GPUs)")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic in this run: two extra short passes of this workload under rocprofv3 --pmc (FETCH_SIZE, "
+                         "WRITE_SIZE; separate passes, no trace domain)")
     ap.add_argument("--cpu-samples", type=int, default=1 << 16, help="samples of the C-oracle leg of cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-f32, cfg-2 and cfg-5 side measurements")
@@ -430,6 +472,9 @@ def main():
     ap.add_argument("--kl-steps", type=int, default=10, help="extra: time this many KL-loss training steps (0 = skip)")
     ap.add_argument("--kl-batch", type=int, default=1 << 18, help="samples per GPU per KL step")
     args = ap.parse_args()
+    cfg4 = args.batch is None and args.gpus == 8 and args.workload == "cfg3"
+    if args.batch is None:
+        args.batch = (1 << 19) if cfg4 else (1 << 20)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -456,6 +501,9 @@ def main():
         torch.distributed.all_gather_object(gathered, mine)
         rccl = dict(backend=torch.distributed.get_backend(), world_size=torch.distributed.get_world_size(), devices=gathered,
                     distinct_devices=len({(g["host"], g["uuid"] or g["index"]) for g in gathered}))
+        if rccl["distinct_devices"] < world and not shared_gpu_test:
+            raise SystemExit(f"bench.py: {world} ranks on {rccl['distinct_devices']} distinct GPUs ({gathered}): a multi-GPU number needs one device "
+                             "per rank (LOCAL_RANK / visible devices are wrong)")
     if args.gemm:
         _dense.GEMM_MODE = args.gemm
     gemm_mode = _dense.GEMM_MODE
@@ -596,12 +644,26 @@ def main():
             torch.cuda.synchronize(dev)
             if world > 1:
                 torch.distributed.barrier()
+                # the step's two collectives, each alone: the [sum loss, n] pair (timed above) and the flat gradient bucket
+                for _ in range(3):
+                    opt.allreduce_gradients()
+                torch.cuda.synchronize(dev)
+                t_ar = time.perf_counter()
+                for _ in range(20):
+                    opt.allreduce_gradients()
+                torch.cuda.synchronize(dev)
+                rccl["grad_bucket_allreduce_us"] = 1e6 * (time.perf_counter() - t_ar) / 20
+                rccl["grad_bucket_bytes"] = int(opt.grad.numel() * 4)
+                torch.distributed.barrier()
             ms = event_ms_per_call(kl_step, args.kl_steps, 1)
             if world > 1:
                 tm = torch.tensor([ms], dtype=torch.float64, device=dev)
                 torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
                 ms = float(tm.item())
             kl = dict(steps_per_s=1e3 / ms, samples_per_s=args.kl_batch * world * 1e3 / ms, ms_per_step=ms, batch_per_gpu=args.kl_batch,
+                      collectives_per_step=(None if world == 1 else dict(loss_pair_allreduce_us=rccl.get("loss_pair_allreduce_us"),
+                                                                         grad_bucket_allreduce_us=rccl.get("grad_bucket_allreduce_us"),
+                                                                         grad_bucket_bytes=rccl.get("grad_bucket_bytes"))),
                       steps=args.kl_steps, timer="HIP events", loss=float(last[0].detach()),
                       note="fwd: one-launch coupling layers (training variant, saves pre-activations + spline parameters) + IC / CDF kernels; "
                            "bwd: bgk_rqs_backward / bgk_ic_ic2xyz_backward, conditioner input-gradient chain on bgk_dense_backward_dx, "
@@ -646,11 +708,18 @@ def main():
             kname, klabel = "coupling_rqs_dense_h2_kernel", "coupling_rqs_dense_h2_kernel<bf16> (REDUCED PRECISION conditioner GEMMs)"
         else:
             kname, klabel = "coupling_rqs_dense_kernel", "coupling_rqs_dense_kernel (fused DenseNet on the f32-input MFMA + RQ-spline coupling layer)"
-        traffic, traffic_src = measured_traffic(kname, args.batch)
+        traffic = traffic_note = None
+        if args.pmc and world == 1:
+            traffic, traffic_note = pmc_traffic(kname, args)
+        if traffic is None:
+            traffic, traffic_src = measured_traffic(kname, args.batch)
+            if traffic is not None:
+                traffic_note = (f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, per launch, scaled to "
+                                f"the batch -- a committed profile constant, not measured in this run (python bench.py --pmc measures it)"
+                                + (f"; the --pmc passes of this run failed: {traffic_note}" if traffic_note else ""))
         roof = dict(bound="hbm", achieved=alg_bytes_launch / avg_launch_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                     traffic=traffic,
-                    traffic_source=(f"{traffic_src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of this command, per launch, scaled to "
-                                    f"the batch -- a committed profile constant, not measured in this run") if traffic else None,
+                    traffic_source=traffic_note,
                     kernel=klabel, launches_per_step=n_launch, avg_launch_ms=1e3 * avg_launch_s,
                     algorithmic_bytes_per_launch=alg_bytes_launch,
                     note="achieved = SURVEY 8(d) algorithmic bytes of a coupling layer (4 (P + 2 d + 2) B per sample: conditioner output "
@@ -681,8 +750,12 @@ def main():
                                "f16x2": "f32 throughout, except that the conditioner GEMM operands are represented as hi + lo f16 pairs (22-24 "
                                         "significant bits, 3 MFMAs per product, f32 accumulate); hardware exp2 / log2 / rcp with Newton steps"}[gemm_mode],
                    data="synthetic",
-                   config=dict(workload=desc + ("" if world == 1 else f"; weak scaling: {args.batch} samples per rank x {world} ranks = "
-                                                f"{args.batch * world} global (BASELINE cfg 4 is this flow at 2^22 global = 2^19 per rank on 8 GPUs)"),
+                   config=dict(workload=(("cfg 4: " if cfg4 else "") + desc
+                                         + ("" if world == 1 else f"; data-parallel shard: {args.batch} samples per rank x {world} ranks = "
+                                            f"{args.batch * world} global"
+                                            + (" = BASELINE cfg 4 (2^22 samples over 8 GPUs, RCCL all-reduce of the KL loss pair and the gradient "
+                                               "bucket in the `kl` leg)" if cfg4 else
+                                               " (BASELINE cfg 4 is this flow at 2^22 global = 2^19 per rank on 8 GPUs: the default of --gpus 8)"))),
                                batch_per_gpu=args.batch, global_batch=args.batch * world,
                                parallelism=f"dp{world}",
                                conditioner_gemm={"f16x2": "split-f16: f32 operands as hi+lo f16 pairs, 3 MFMAs per product, f32 accumulate "

@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "libbgflow_amd.so")
 # -ffp-contract=off + correctly rounded div/sqrt: the f32 arithmetic of the kernels is then the same
 # sequence of IEEE ops as the CPU oracle's (bit-identical spline bin indices); see csrc/bgk_detmath.h.
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
     "-Wno-comment",
 ]
@@ -34,6 +34,25 @@ TU_FLAGS = {"bgk_fused2.hip": ["-fno-slp-vectorize"], "bgk_fused2_train.hip": ["
 
 
 INCLUDES_SOURCE = {"bgk_fused2_train.hip": ["bgk_fused2.hip"], "bgk_fused2_bf16.hip": ["bgk_fused2.hip"]}     # translation units that #include another .hip
+
+
+HEADER = os.path.join(HERE, "..", "include", "bgflow_amd.h")
+
+
+def abi_symbols(header=HEADER):
+    """names of the C-ABI prototypes declared in include/bgflow_amd.h -- the library's export list"""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
+    return sorted(set(re.findall(r"^[A-Za-z_][\w \t\*]*?\b(bgk_\w+)\s*\(", text, flags=re.M)))
+
+
+def _export_map():
+    """linker version script: exactly the header's prototypes are dynamic symbols; everything else (launchers shared between
+    translation units, option variables, hipcc's per-unit __hip_cuid_* markers) stays local"""
+    path = os.path.join(OBJ, "export.map")
+    with open(path, "w") as f:
+        f.write("{\n  global:\n" + "".join(f"    {n};\n" for n in abi_symbols()) + "  local:\n    *;\n};\n")
+    return path
 
 
 def sources():
@@ -82,7 +101,7 @@ def build_extension(force=False, verbose=False, out=None):
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources()))
     target = out or LIB
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + _export_map(), "-o", target] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .utils import param_state_key
 from .flow import ACC_KW, Flow, InverseFlow, SequentialFlow
 
 __all__ = ["CDFTransform", "DistributionTransferFlow", "ConstrainGaussianFlow"]
@@ -188,7 +189,7 @@ class CDFTransform(Flow):
         src = _source_tensors(self.distribution)
         if torch.is_grad_enabled() and any(t.requires_grad for t in src):
             return None
-        key = (d, str(device), tuple((t.data_ptr(), t._version, str(t.device)) for t in src))
+        key = (d, str(device), tuple((*param_state_key(t), str(t.device)) for t in src))
         if self._desc_cache.get("key") != key:
             desc = _descriptor(self.distribution, d)
             self._desc_cache.update({"key": key, "desc": None if desc is None else desc.to(device)})
@@ -199,7 +200,7 @@ class CDFTransform(Flow):
         src = _source_tensors(self.distribution)
         if torch.is_grad_enabled() and any(t.requires_grad for t in src):
             return None
-        key = (d, str(device), tuple((t.data_ptr(), t._version, str(t.device)) for t in src))
+        key = (d, str(device), tuple((*param_state_key(t), str(t.device)) for t in src))
         if self._desc_cache.get("key20") != key:
             desc = _tail_descriptor(self.distribution, d)
             self._desc_cache["key20"], self._desc_cache["desc20"] = key, (None if desc is None else desc.to(device))

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .utils import is_list_or_tuple
+from .utils import is_list_or_tuple, param_state_key
 
 __all__ = ["DenseNet", "MeanFreeDenseNet", "WrapPeriodic", "WrapDistances"]
 
@@ -398,7 +398,7 @@ def _affine_plan(transformer, y_dim):
                                     f"<= 96 dims, <= 127 input features")
     H_run = 64 if H <= 64 else 128                      # other widths run zero-padded to the kernels' 64 / 128 rows
     params = [p for (ls, _) in live for lin in ls for p in (lin.weight, lin.bias)]
-    version = tuple((p.data_ptr(), p._version) for p in params)
+    version = tuple(param_state_key(p) for p in params)
     cache = transformer._fused_cache
     if cache.get("version") != version or cache.get("y_dim") != y_dim:
         cache.clear()
@@ -613,7 +613,7 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
             # only "all conditioner inputs periodic, in natural order" is fused (the kernel featurises columns 0..d_c-1)
             return _reject(transformer, "WrapPeriodic over a subset / permutation of the conditioner inputs")
     params = [p for lin in (l0, l1, l2) for p in (lin.weight, lin.bias)]
-    version = tuple((p.data_ptr(), p._version) for p in params)
+    version = tuple(param_state_key(p) for p in params)
     cache = transformer._fused_cache
     dev = l0.weight.device
     stale = cache.get("version") != version

@@ -166,8 +166,9 @@ class _KLSumsFn(torch.autograd.Function):
         _lib.check(st, "bgk_energy_fields")
         ctx.save_for_backward(u, dl, *[t for t, _ in keep[0]])
         ctx.cfg = (specs, float(temperature), bool(drop_nonfinite), dlogp.shape)
-        ctx.mark_non_differentiable(u)
-        return sums, u[:, None]
+        u2 = u[:, None]
+        ctx.mark_non_differentiable(u2)            # (the mark must sit on the tensor that is returned, not on its base)
+        return sums, u2
 
     @staticmethod
     def backward(ctx, g_sums, _g_u):
@@ -191,11 +192,23 @@ class _KLSumsFn(torch.autograd.Function):
                 *[t if t is not None else (torch.zeros_like(x) if nd else None) for t, x, nd in zip(gx, xs, need)])
 
 
+def _kernel_plan(dist, temperature):
+    """``dist._kernel_fields(temperature)`` -- unless a subclass overrides ``energy`` / ``_energy`` of the class that describes the
+    kernel fields: such an override (a custom target, a clipped or regularised energy) must run through its own code"""
+    describe = getattr(dist, "_kernel_fields", None)
+    if describe is None:
+        return None
+    owner = next(c for c in type(dist).__mro__ if "_kernel_fields" in c.__dict__)
+    for name in ("energy", "_energy"):
+        if getattr(type(dist), name, None) is not getattr(owner, name, None):
+            return None
+    return describe(temperature)
+
+
 def kernel_energy(dist, xs, temperature=1.0):
     """``dist.energy(*xs, temperature)`` as ONE launch when ``dist`` can describe itself by kernel fields and the inputs are 2-d f32
     HIP tensors, else None"""
-    describe = getattr(dist, "_kernel_fields", None)
-    plan = describe(temperature) if describe is not None else None
+    plan = _kernel_plan(dist, temperature)
     if plan is None:
         return None
     specs, dims, c_in, c_out, t_eff = plan
@@ -207,8 +220,7 @@ def kernel_energy(dist, xs, temperature=1.0):
 def kl_loss_sums(target, xs, dlogp, temperature=1.0, drop_nonfinite=False):
     """(sums, u): sums = f64 [2] = [sum_b (u_target(x_b) - dlogp_b), samples kept] with autograd to x and dlogp, formed inside the
     target-energy kernel (no per-sample loss tensor, no isfinite / where / sum launches); None if the target has no kernel fields"""
-    describe = getattr(target, "_kernel_fields", None)
-    plan = describe(temperature) if describe is not None else None
+    plan = _kernel_plan(target, temperature)
     if plan is None:
         return None
     specs, dims, c_in, c_out, t_eff = plan
@@ -244,25 +256,59 @@ def philox_sample(fields, n_samples, device, seed, offset, row0=0, want_energy=F
     return outs, (None if energy is None else energy[:, None])
 
 
-class _FusedSampling:
-    """Opt-in (``sample_fused=True``) sampling on bgk_philox_fields: seed = ``torch.initial_seed()`` (so ``torch.manual_seed``
-    still selects the stream) mixed with the data-parallel rank, offset = a per-object call counter.  The prior energy of the
-    sample comes out of the same launch and is handed back by ``energy`` when it is asked about exactly these tensors."""
+_PHILOX_STREAMS = [0]          # process-wide count of fused-sampling objects: every object draws from its own Philox stream
+PHILOX_MAX_WIDTH = 160         # widest field bgk_philox_fields assembles in its LDS tile (4 waves x 64 rows x d floats)
+
+
+class _FusedSampling(torch.nn.Module):
+    """Opt-in (``sample_fused=True``) sampling on bgk_philox_fields.  Key = ``torch.initial_seed()`` (so ``torch.manual_seed`` still
+    selects the stream) mixed with the data-parallel rank AND a per-object stream id (assigned in construction order on first use):
+    two priors of equal shape in one process draw independent numbers.  Offset = a per-object call counter.  Stream id and counter
+    travel in ``state_dict`` once the object has sampled (key ``_philox_state``; absent otherwise, so reference state_dicts load
+    unchanged): a resumed run continues the stream instead of replaying it.  The prior energy of a sample comes out of the same
+    launch and is handed back by ``energy`` when it is asked about exactly these, unmodified tensors."""
     sample_fused = False
 
+    def _philox_ids(self):
+        st = self.__dict__.get("_philox_state")
+        if st is None:
+            st = self.__dict__["_philox_state"] = [_PHILOX_STREAMS[0], 0]      # [stream id, calls]
+            _PHILOX_STREAMS[0] += 1
+        return st
+
     def _fused_sample(self, fields, n_samples, device, temperature, c_out=0.0):
+        import weakref
         from . import dp
-        off = self.__dict__.get("_philox_calls", 0)
-        self.__dict__["_philox_calls"] = off + 1
-        outs, energy = philox_sample(fields, n_samples, device, dp.rank_seed(torch.initial_seed()), off, want_energy=True, c_out=c_out)
-        self.__dict__["_philox_last"] = (tuple(id(t) for t in outs), float(temperature), energy, outs)
+        st = self._philox_ids()
+        seed = (dp.rank_seed(torch.initial_seed()) + 0x9E3779B97F4A7C15 * (st[0] + 1)) & (2 ** 64 - 1)
+        off, st[1] = st[1], st[1] + 1
+        outs, energy = philox_sample(fields, n_samples, device, seed, off, want_energy=True, c_out=c_out)
+        # the energy is valid for exactly these tensor objects in exactly this state: weak references (no sample batch is pinned)
+        # + their version counters (any in-place edit invalidates the cache)
+        self.__dict__["_philox_last"] = ([weakref.ref(t) for t in outs], [t._version for t in outs], float(temperature), energy)
         return outs
 
     def _fused_energy(self, xs, temperature):
         last = self.__dict__.get("_philox_last")
-        if last is not None and last[0] == tuple(id(t) for t in xs) and last[1] == float(temperature):
-            return last[2]
-        return None
+        if last is None or len(last[0]) != len(xs) or last[2] != float(temperature):
+            return None
+        for ref, ver, x in zip(last[0], last[1], xs):
+            if ref() is not x or x._version != ver or (torch.is_grad_enabled() and x.requires_grad):
+                return None                       # another tensor, an edited one, or one whose energy must carry a graph
+        return last[3].clone()
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        st = self.__dict__.get("_philox_state")
+        if st is not None and st[1] > 0:
+            destination[prefix + "_philox_state"] = torch.tensor(st, dtype=torch.int64)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        st = state_dict.pop(prefix + "_philox_state", None)
+        if st is not None:
+            self.__dict__["_philox_state"] = [int(st[0]), int(st[1])]
+            _PHILOX_STREAMS[0] = max(_PHILOX_STREAMS[0], int(st[0]) + 1)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 
 class NormalDistribution(Energy, Sampler, _FusedSampling):
@@ -321,7 +367,10 @@ class NormalDistribution(Energy, Sampler, _FusedSampling):
         return 0.5 * x.pow(2).sum(dim=-1, keepdim=True) + self._log_Z(temperature)
 
     def _philox_field(self, temperature=1.0):
-        """(kind, d, p0, p1, scale, e_const) of bgk_philox_fields for this prior at `temperature`, or None"""
+        """(kind, d, p0, p1, scale, e_const) of bgk_philox_fields for this prior at `temperature`, or None (then torch's generator
+        samples: covariances, other dtypes, fields wider than the kernel's LDS tile)"""
+        if self.dim > PHILOX_MAX_WIDTH:
+            return None
         if self._has_cov or self._mean.dtype != torch.float32 or not isinstance(temperature, (int, float)) or temperature <= 0:
             return None
         return (1, self.dim, self._mean if self._has_mean else None, None, float(temperature) ** 0.5,
@@ -466,13 +515,23 @@ class UniformDistribution(Energy, Sampler, _FusedSampling):
         if len(self.event_shape) != 1 or not isinstance(temperature, (int, float)) or temperature <= 0:
             return None
         d = self.event_shape[0]
-        return ([(2, None, (float(self._const((d,))), 0.0, 0.0), 0.0)], [d], 0.0, 0.0, float(temperature))
+        return ([(2, None, (self._const_host(d), 0.0, 0.0), 0.0)], [d], 0.0, 0.0, float(temperature))
+
+    def _const_host(self, d):
+        """sum_j log(high_j - low_j) as a host float, read back ONCE per state of the bounds (a device-to-host sync per energy /
+        sample call would sit in the NLL / KL hot path)"""
+        lo, hi = self.uniform.low, self.uniform.high
+        key = (d, lo.data_ptr(), hi.data_ptr(), lo._version, hi._version)
+        hit = self.__dict__.get("_const_cache")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_const_cache"] = (key, float(self._const((d,))))
+        return hit[1]
 
     def _philox_field(self, temperature=1.0):
-        if len(self.event_shape) != 1 or self.uniform.low.dtype != torch.float32:
+        if len(self.event_shape) != 1 or self.uniform.low.dtype != torch.float32 or self.event_shape[0] > PHILOX_MAX_WIDTH:
             return None
         d = self.event_shape[0]
-        return (0, d, self.uniform.low.expand(d), self.uniform.high.expand(d), 1.0, float(self._const((d,))) / float(temperature))
+        return (0, d, self.uniform.low.expand(d), self.uniform.high.expand(d), 1.0, self._const_host(d) / float(temperature))
 
     def _sample(self, n_samples):
         if self.sample_fused and self.uniform.low.is_cuda:
@@ -505,8 +564,7 @@ class ProductDistribution(Energy, Sampler, _FusedSampling):
             return None
         specs, dims, c_in = [], [], 0.0
         for c in self._components:
-            describe = getattr(c, "_kernel_fields", None)
-            plan = describe(1.0) if describe is not None else None
+            plan = _kernel_plan(c, 1.0)
             if plan is None or len(plan[0]) != 1:
                 return None
             specs.append(plan[0][0]); dims.append(plan[1][0])

@@ -140,6 +140,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self._skipped = torch.zeros(1, dtype=torch.int32, device=dev)
         self._step = 0
+        self.generation = 0          # number of updates this optimizer has written through the bucket
         off = 0
         with torch.no_grad():
             for p in ps:
@@ -202,9 +203,11 @@ class FlatAdam(torch.optim.Optimizer):
                                          self.flat.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                          float(g["weight_decay"]), self._step, _lib.ptr(self._flag) if skip_on_nan else None,
                                          _lib.ptr(self._skipped), _lib.stream_ptr(dev)), "bgk_adam_step")
-        # the kernel wrote through the bucket: bump the parameters' version counters (the packed-operand caches of the fused
-        # kernels are keyed on (data_ptr, _version), exactly as if torch's Adam had updated the parameters in place)
-        torch._C._autograd._unsafe_set_version_counter(self._params, [p._version + 1 for p in self._params])
+        # the kernel wrote through the bucket, which torch's version counters do not see: bump the generation counter the
+        # packed-operand caches of the fused kernels are keyed on (dense.param_state_key)
+        self.generation += 1
+        for p in self._params:
+            p._bgk_generation = self.generation
 
     def skipped_steps(self):
         """number of optimizer steps skipped because a gradient was NaN (host sync)"""
@@ -266,56 +269,80 @@ class KLTrainer(object):
     def _mean(per_sample):
         return dp.global_mean(per_sample) if dp.is_distributed() else per_sample.mean()
 
+    # ---- one optimisation step = loss terms (each: evaluate -> report -> weighted backward into the flat gradient bucket) + one
+    # parameter update.  The terms and the update are built once per train() call; the loop only runs them.
+    def _kl_term(self, batchsize, temperature):
+        """reverse-KL term (trainers.py:158-163).  The generator's own ``kldiv`` unless it is the package's implementation: then
+        ``kldiv_mean`` forms the loss sums inside the target-energy kernel (same value, no per-sample tensor, one ready 2-vector for the
+        data-parallel all-reduce).  A subclass that overrides ``kldiv`` (a regulariser, another target) is evaluated through its code."""
+        from .bg import BoltzmannGenerator
+        fused = isinstance(self.bg, BoltzmannGenerator) and type(self.bg).kldiv is BoltzmannGenerator.kldiv \
+            and type(self.bg).kldiv_mean is BoltzmannGenerator.kldiv_mean
+        if fused:
+            return lambda: self.bg.kldiv_mean(batchsize, temperature=temperature)
+        return lambda: self._mean(self.bg.kldiv(batchsize, temperature=temperature))
+
+    def _nll_term(self, sampler, batchsize, temperature):
+        def term():
+            batch = sampler.sample(batchsize)
+            batch = (batch,) if isinstance(batch, torch.Tensor) else batch
+            return self._mean(self.bg.energy(*batch, temperature=temperature))
+        return term
+
+    def _update(self, params):
+        """gradient exchange + parameter update: FlatAdam = one all-reduce of the bucket and one fused launch that skips itself on the
+        device when a gradient is not finite (trainers.py:198-201 without the host sync); any other optimizer: the reference's check"""
+        if isinstance(self.optim, FlatAdam):
+            self.optim.allreduce_gradients()
+            self.optim.step()
+            return
+        dp.allreduce_gradients_(params)
+        if any(torch.any(torch.isnan(p.grad)) for p in params if p.grad is not None):
+            print("found nan in grad; skipping optimization step")
+        else:
+            self.optim.step()
+
     def train(self, n_iter, data=None, testdata=None, batchsize=128, w_likelihood=None, w_energy=None, w_custom=None,
               custom_loss_kwargs={}, n_print=0, temperature=1.0, schedulers=(), clip_forces=None, progress_bar=lambda x: x):
-        if w_likelihood is None:
-            w_likelihood = self.w_likelihood
-        if w_energy is None:
-            w_energy = self.w_energy
+        import contextlib
+        from .dense import direct_grad_accumulation
+        w_likelihood = self.w_likelihood if w_likelihood is None else w_likelihood
+        w_energy = self.w_energy if w_energy is None else w_energy
         if clip_forces is not None:
             warnings.warn("clip_forces is deprecated and will be ignored. Use GradientClippedEnergy instances instead",
                           DeprecationWarning)
-        if isinstance(data, torch.Tensor):
-            data = DataSetSampler(data)
-        if isinstance(testdata, torch.Tensor):
-            testdata = DataSetSampler(testdata)
-        flat = isinstance(self.optim, FlatAdam)
-        params = [p for p in self.bg.parameters()]
-        from .dense import direct_grad_accumulation
-        import contextlib
-        direct = direct_grad_accumulation if flat else contextlib.nullcontext
+        data = DataSetSampler(data) if isinstance(data, torch.Tensor) else data
+        testdata = DataSetSampler(testdata) if isinstance(testdata, torch.Tensor) else testdata
+        params = list(self.bg.parameters())
+        # weight gradients reduce straight into the optimizer's bucket when it is the flat one
+        direct = direct_grad_accumulation if isinstance(self.optim, FlatAdam) else contextlib.nullcontext
+        wsum = w_likelihood + w_energy
+        terms = []                                     # (evaluate, weight in the total loss or None = report only)
+        if self.train_energy:
+            terms.append((self._kl_term(batchsize, temperature), w_energy / wsum if w_energy > 0 else None))
+        if self.train_likelihood:
+            terms.append((self._nll_term(data, batchsize, temperature), w_likelihood / wsum if w_likelihood > 0 else None))
+
+        def backward(loss):
+            with direct():
+                loss.backward(retain_graph=True)
+
         for it in progress_bar(range(n_iter)):
             for interval, scheduler in schedulers:
                 if it % interval == 0:
                     scheduler.step()
             self.optim.zero_grad()
             reports = []
-            if self.train_energy:
-                if hasattr(self.bg, "kldiv_mean"):      # loss sums inside the target-energy kernel (same value as kldiv(...).mean())
-                    kll = self.bg.kldiv_mean(batchsize, temperature=temperature)
-                else:
-                    kll = self._mean(self.bg.kldiv(batchsize, temperature=temperature))
-                reports.append(kll)
-                if w_energy > 0:
-                    with direct():
-                        (w_energy / (w_likelihood + w_energy) * kll).backward(retain_graph=True)
-            if self.train_likelihood:
-                batch = data.sample(batchsize)
-                if isinstance(batch, torch.Tensor):
-                    batch = (batch,)
-                nll = self._mean(self.bg.energy(*batch, temperature=temperature))
-                reports.append(nll)
-                if w_likelihood > 0:
-                    with direct():
-                        (w_likelihood / (w_likelihood + w_energy) * nll).backward(retain_graph=True)
+            for evaluate, weight in terms:
+                value = evaluate()
+                reports.append(value)
+                if weight is not None:
+                    backward(weight * value)
             if self.test_likelihood:
-                testnll = torch.zeros_like(nll)
+                testnll = torch.zeros_like(reports[-1]) if reports else torch.zeros(())
                 if testdata is not None:
-                    testbatch = testdata.sample(batchsize)
-                    if isinstance(testbatch, torch.Tensor):
-                        testbatch = (testbatch,)
                     with torch.no_grad():
-                        testnll = self._mean(self.bg.energy(*testbatch, temperature=temperature))
+                        testnll = self._nll_term(testdata, batchsize, temperature)()
                 reports.append(testnll)
             if w_custom is not None:
                 cl = self.custom_loss(**custom_loss_kwargs)
@@ -326,15 +353,7 @@ class KLTrainer(object):
             self.reporter.report(*reports)
             if n_print > 0 and it % n_print == 0:
                 self.reporter.print(*reports)
-            if flat:
-                self.optim.allreduce_gradients()
-                self.optim.step()            # skips itself on the device when a gradient is NaN
-            else:
-                dp.allreduce_gradients_(params)
-                if any(torch.any(torch.isnan(p.grad)) for p in params if p.grad is not None):
-                    print("found nan in grad; skipping optimization step")
-                else:
-                    self.optim.step()
+            self._update(params)
 
     def losses(self, n_smooth=1):
         return self.reporter.losses(n_smooth=n_smooth)

@@ -5,7 +5,7 @@ from collections.abc import Iterable
 import numpy as np
 import torch
 
-__all__ = ["hash_init_", "synth", "is_list_or_tuple", "pack_tensor_in_tuple", "unpack_tensor_tuple", "pack_tensor_in_list",
+__all__ = ["hash_init_", "synth", "param_state_key", "is_list_or_tuple", "pack_tensor_in_tuple", "unpack_tensor_tuple", "pack_tensor_in_list",
            "as_numpy", "assert_numpy"]
 
 
@@ -88,3 +88,10 @@ def assert_numpy(x, arr_type=None):
         x = np.array(x)
     assert isinstance(x, np.ndarray)
     return x if arr_type is None else x.astype(arr_type)
+
+
+def param_state_key(p):
+    """what the packed-operand caches of the fused kernels are keyed on: the parameter's storage, torch's version counter (bumped by
+    every in-place update torch knows about) and a generation counter bumped by writers torch does not see (training.FlatAdam's
+    fused kernel writes through the flat bucket the parameters are views of)"""
+    return (p.data_ptr(), p._version, getattr(p, "_bgk_generation", 0))

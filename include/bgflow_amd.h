@@ -29,6 +29,10 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden and an export list generated from this header (bgflow_amd/build.py): the prototypes
+ * below are its complete dynamic symbol table (tests/test_host_logic.py::test_exported_symbols_are_the_headers_prototypes). */
+#pragma GCC visibility push(default)
+
 #define BGK_EINVAL (-1)      /* bad argument (shape / unsupported size)          */
 #define BGK_EUNSUPPORTED (-2) /* valid request the kernels do not cover (yet)    */
 
@@ -493,6 +497,8 @@ int bgk_column_sum(const float* x, int64_t ldx, int64_t B, int32_t P, float* par
  * layout, P = 3*K*d + n_nc) of every packed column, -1 for padding.  HOST function:
  * src_col is a host int32[NCp] buffer (pass NULL to query NCp only). */
 int32_t bgk_pack_rqs_columns(int32_t d, int32_t K, const int32_t* nc_slot_host, int32_t* src_col);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

@@ -734,3 +734,52 @@ def test_zero_padded_hidden_layers_compute_the_same_function():
                 h = act(h)
                 assert torch.count_nonzero(h[:, lins[i].out_features:]) == 0      # padded units hold act(0) = 0
         assert torch.allclose(h, net(x), atol=1e-6)
+
+
+def test_exported_symbols_are_the_headers_prototypes():
+    """libbgflow_amd.so is built with hidden visibility and an export list generated from include/bgflow_amd.h: its dynamic symbol table
+    is exactly the header's prototypes -- no launcher shared between translation units, no option variable, no hipcc marker leaks."""
+    import re
+    import subprocess
+    from bgflow_amd import _lib, build
+    want = set(build.abi_symbols())
+    assert len(want) >= 42 and "bgk_coupling_rqs_dense_h2" in want
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    have = {ln.split()[-1] for ln in out.splitlines() if re.match(r"^[0-9a-f]+ [A-Za-z] ", ln)}
+    assert have == want, f"only in the library: {sorted(have - want)}; only in the header: {sorted(want - have)}"
+
+
+def test_kl_trainer_runs_a_generators_own_kldiv():
+    """KLTrainer takes the fused ``kldiv_mean`` path only for the package's own ``BoltzmannGenerator.kldiv``; a subclass that overrides
+    ``kldiv`` (regulariser, other target) is evaluated through its code (advisor finding of round 3); likewise a subclass of a kernel-
+    describable energy that overrides ``_energy`` is not routed to the energy kernel."""
+    import bgflow_amd as bg
+    from bgflow_amd.distributions import _kernel_plan
+    from bgflow_amd.training import KLTrainer
+
+    class Reg(bg.BoltzmannGenerator):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+            self.w = torch.nn.Parameter(torch.tensor([2.0]))
+            self.calls = 0
+
+        def kldiv(self, n_samples, temperature=1.0):
+            self.calls += 1
+            return (self.w ** 2).expand(n_samples, 1)
+
+        def kldiv_mean(self, *a, **k):
+            raise AssertionError("the override was bypassed")
+
+    g = Reg()
+    tr = KLTrainer(g, optim=torch.optim.SGD(g.parameters(), lr=0.1), train_likelihood=False)
+    tr.train(3, batchsize=8)
+    assert g.calls == 3 and float(g.w) < 2.0
+    assert abs(tr.losses()[2][0][0] - 4.0) < 1e-6
+
+    class Shifted(bg.NormalDistribution):
+        def _energy(self, x):
+            return super()._energy(x) + 1.0
+
+    assert _kernel_plan(bg.NormalDistribution(5), 1.0) is not None
+    assert _kernel_plan(Shifted(5), 1.0) is None
+    assert _kernel_plan(bg.ProductDistribution([bg.NormalDistribution(5), Shifted(5)]), 1.0) is None
