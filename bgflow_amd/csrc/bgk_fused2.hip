@@ -757,6 +757,9 @@ __device__ __forceinline__ void chunk_to_lds(const f32x16 (&h)[4], float* s_p, i
  * after the chunk reached LDS and AFTER the next GEMM's first operand loads were requested: vmcnt is one in-order counter for
  * loads and stores on gfx9, so a load requested behind these 64 stores would wait for every one of them to be acknowledged. */
 __device__ __forceinline__ void save_chunk_params(const V2Args& a, const float* s_p, int c, int lane, int64_t b0, int rows) {
+#ifdef BGK_V2_ABL_NOPSAVE      /* timing experiment: the parameters are not written (wrong gradients) */
+    return;
+#endif
     const int col_lo = a.src_col[c * 128 + lane], col_hi = a.src_col[c * 128 + 64 + lane];
     for (int jj = 0; jj < rows; ++jj) {
         float* prow = a.params + (b0 + jj) * a.ldp;
@@ -1047,7 +1050,9 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[m][r] *= a.c0;
+#ifndef BGK_V2_ABL_NOZSAVE
         h2_store_rows128(h, a.z0, s_p, b0, rows, lane);
+#endif
         const float c0_act = 1.0f;
 #else
         const float c0_act = a.c0;
@@ -1076,7 +1081,9 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] *= a.c1;
+#ifndef BGK_V2_ABL_NOZSAVE
         h2_store_rows128(acc, a.z1, s_p, b0, rows, lane);
+#endif
         const float c1_act = 1.0f;
 #else
         const float c1_act = a.c1;

@@ -516,6 +516,260 @@ __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_kernel(Fu
     }
 }
 
+/* ---- weight-resident variant with DMA-staged tiles (round 4): the layers of a `Split -> (Coupling, Swap)* -> Merge` stack read and
+ * write column halves of one [B, D] buffer, i.e. 128-byte row pieces.  The kernel above fetches them with one 16-byte load per lane
+ * and ROW (64 cache lines per wave instruction, the tile's latency exposed once per tile: SQ_WAIT_ANY 44 % of the wave cycles).  Here
+ * the conditioner half and the y half of a 32-sample tile travel global -> LDS by the DMA path, whole lines per 8 lanes, and the
+ * NEXT tile's halves are requested while the current tile computes: the conditioner half as soon as layer 0 has consumed the
+ * current one, the y half as soon as the epilogue has read the current one back.  vmcnt bookkeeping (requests retire in order):
+ *   top of a tile        : outstanding = [C_t | stores of tile t-1 | Y_t]          -> vmcnt(NY)   = C_t has landed
+ *   before the epilogue  : outstanding = [Y_t | dlogp load | C_t+1]                -> vmcnt(NC)   = Y_t and the dlogp value are here
+ * LDS image of a half: 16-byte granule (row j, column c) sits at granule j G + (c + rot(j)) mod G, rot(j) = j G / 16 -- the DMA
+ * writes linearly (lane l of request i -> granule 64 i + l), so the rotation is applied to the global SOURCE address of each lane;
+ * it makes the per-lane-row ds_read_b128 / ds_write_b128 of the B-operand build and of the epilogue bank-conflict free (row
+ * stride 128 B = half the LDS width).  Envelope: d_c = d = 32 (G = 8), two hidden layers of 64, no periodic featuriser, 16-byte
+ * aligned rows; everything else runs on the kernels above.  Measured (tools/r04_cfg2_ab.sh, same box, ms per 8-layer flow at 2^20): this
+ * kernel 1.57, the kernel above 1.62; a three-waves-per-SIMD form of it (one tile buffer per wave, networks one after the other to
+ * fit 168 VGPRs: 25 spilled registers, the next conditioner half requested behind the stores) 1.83 -- not shipped.  Per-phase wave
+ * cycles (BGK_AFF_TS, tools/r04_cfg2_ts.py): of 21 k cycles per tile 0.6 k wait for the conditioner half, i.e. the memory latency is
+ * hidden; what remains is the alternation of pure-VALU (activation, split) and pure-MFMA phases at two waves per SIMD. ---- */
+typedef const __attribute__((address_space(1))) void* r_gvp_t;
+typedef __attribute__((address_space(3))) void* r_lvp_t;
+
+/* the NQ = 32 G / 64 requests of a half: request i, lane l -> LDS granule p = 64 i + l = (row p / G, slot p % G), which holds source column
+ * (slot - rot(row)) mod G.  With 64 % G == 0: row = i (64 / G) + l / G and rot(row) = 4 i + rot(l / G), so a lane keeps two small
+ * tile-independent values (its row within a request, its column for i = 0) and forms the offset of request i with two instructions */
+template <int G>
+struct ResLane { int rowl, c0; };
+template <int G>
+__device__ __forceinline__ ResLane<G> res_lane(int lane) {
+    const int rowl = lane / G;
+    return ResLane<G>{rowl, ((lane % G) - (rowl * G) / 16) & (G - 1)};
+}
+template <int G> __device__ __forceinline__ int res_row(const ResLane<G>& o, int i) { return i * (64 / G) + o.rowl; }
+template <int G> __device__ __forceinline__ int res_col4(const ResLane<G>& o, int i) { return 4 * ((o.c0 - 4 * i) & (G - 1)); }
+template <int G>
+__device__ __forceinline__ void res_dma_half(float* dst, const float* src, int ld, const ResLane<G>& o, int rows) {
+    const int lrow = o.rowl * ld;
+#pragma unroll
+    for (int i = 0; i < 32 * G / 64; ++i)
+        if (res_row<G>(o, i) < rows)
+            __builtin_amdgcn_global_load_lds((r_gvp_t)(src + i * (64 / G) * ld + lrow + res_col4<G>(o, i)), (r_lvp_t)(dst + 256 * i), 16, 0, 0);
+}
+template <int G>
+__device__ __forceinline__ int res_gran(int jrow, int c) { return (jrow * G + ((c + (jrow * G) / 16) & (G - 1))) * 4; }   /* float offset */
+
+/* v + (the value of the lane 32 away): v_permlane32_swap instead of a trip through the LDS crossbar (ds_bpermute).  Inline asm: hipcc 7.2's
+ * __builtin_amdgcn_permlane32_swap returns the first result for both elements; s_nop 1 = the VALU-write -> permlane-read wait states */
+__device__ __forceinline__ float res_half_sum(float v) {
+    float l0 = v, l1 = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(l0), "+v"(l1));
+    return l0 + l1;
+}
+
+#ifdef BGK_RES_SHFL
+#define BGK_RES_SUM(v) ((v) + __shfl_xor((v), 32))
+#else
+#define BGK_RES_SUM(v) res_half_sum(v)
+#endif
+
+template <int N> __device__ __forceinline__ void res_wait_vm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+#ifndef BGK_AFF_TS
+#define BGK_AFF_TS 0           /* profiling build (tools/r04_cfg2_ts.py): lane 0 of every wave overwrites the first floats of its tile's first output row with
+                                * s_memtime stamps at the phase boundaries */
+#endif
+#if BGK_AFF_TS
+#define AFF_TS(k) ts[k] = (unsigned)__builtin_amdgcn_s_memtime()
+#else
+#define AFF_TS(k) do { } while (0)
+#endif
+
+template <int RW, int G>
+__global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_dma_kernel(FusedAffArgs a, ResOff os, ResOff ot, int n16_s0, int n16_s1, int n16_s2,
+                                                                                  int n16_t0, int n16_t1, int n16_t2, int w16) {
+    constexpr int HT = RES_HT, OT = 1, NQ = 32 * G / 64;          /* NQ: DMA requests (and store instructions) per half */
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");                 /* MODE.FP16_OVFL: f16 conversions saturate at +-65504 */
+    extern __shared__ __attribute__((aligned(16))) r_u32x4 s_w[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* s_c = reinterpret_cast<float*>(s_w + w16) + wave * (2 * 32 * G * 4);       /* conditioner half, then the y half */
+    float* s_y = s_c + 32 * G * 4;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile_first = (int64_t)blockIdx.x * RW + wave, tile_step = (int64_t)gridDim.x * RW;
+    const ResLane<G> ol = res_lane<G>(lane);
+    const int ldc = (int)a.ldc, ldy = (int)a.ldy, ldo = (int)a.ldo;
+    if (tile_first < n_tiles) {                          /* the first tile's halves travel while the operands are staged */
+        const int64_t b0 = tile_first * 32;
+        const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+        res_dma_half<G>(s_c, a.cond + b0 * a.ldc, ldc, ol, rows);
+        res_dma_half<G>(s_y, a.y + b0 * a.ldy, ldy, ol, rows);
+    }
+    {
+        const r_u32x4* src[6] = {(const r_u32x4*)a.shift.A0, (const r_u32x4*)a.shift.A1, (const r_u32x4*)a.shift.A2,
+                                 (const r_u32x4*)a.scale.A0, (const r_u32x4*)a.scale.A1, (const r_u32x4*)a.scale.A2};
+        const int cnt[6] = {n16_s0, n16_s1, n16_s2, n16_t0, n16_t1, n16_t2};
+        const int off[6] = {os.a0, os.a1, os.a2, ot.a0, ot.a1, ot.a2};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            for (int i = tid; i < cnt[q]; i += RW * 64) s_w[off[q] + i] = src[q][i];
+    }
+    __syncthreads();
+    const int d = a.d, n_in = a.d_c;
+    const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
+    for (int64_t tile = tile_first; tile < n_tiles; tile += tile_step) {
+        const int64_t b0 = tile * 32;
+        const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+        const bool more = tile + tile_step < n_tiles;
+        const int64_t b1 = b0 + tile_step * 32;
+        const int rows1 = more ? (int)((a.B - b1) < 32 ? (a.B - b1) : 32) : 0;
+#if BGK_AFF_TS
+        unsigned ts[8];
+#endif
+        AFF_TS(0);
+        res_wait_vm<NQ>();                               /* C_t has landed (Y_t may still be in flight) */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        AFF_TS(1);
+        float dl_old = 0.0f;
+        if (a.accumulate && hh == 0 && j < rows) dl_old = a.dlogp[b0 + j];
+
+        /* ---- layer 0 of both networks: KR = G / 4 k-steps of real features + one bias-only k-step (the constant-1 feature is feature
+         * 4 G = 16 KR: element 0 of the lower half-wave).  All B granules of the lane's row are read up front; the A fragments of the
+         * next k-step are requested before the MFMAs of the current one. ---- */
+        constexpr int KR = G / 4;
+        h2_f32x16 hs[HT], ht[HT];
+        float4 tb[KR][2];
+#pragma unroll
+        for (int s = 0; s < KR; ++s) {
+            tb[s][0] = *reinterpret_cast<const float4*>(s_c + res_gran<G>(j, 4 * s + 2 * hh));
+            tb[s][1] = *reinterpret_cast<const float4*>(s_c + res_gran<G>(j, 4 * s + 2 * hh + 1));
+        }
+        h2_h16x8 bh[KR + 1], bl[KR + 1];
+#pragma unroll
+        for (int s = 0; s < KR; ++s) {
+            const float v[8] = {tb[s][0].x, tb[s][0].y, tb[s][0].z, tb[s][0].w, tb[s][1].x, tb[s][1].y, tb[s][1].z, tb[s][1].w};
+            r_u32x4 uh, ul;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {               /* (MODE.FP16_OVFL: the conversions saturate, no clamp instructions) */
+                unsigned hi, lo;
+                r_split_pair(v[e], v[e + 1], hi, lo);
+                uh[e >> 1] = hi; ul[e >> 1] = lo;
+            }
+            bh[s] = __builtin_bit_cast(h2_h16x8, uh); bl[s] = __builtin_bit_cast(h2_h16x8, ul);
+        }
+        bh[KR] = h2_h16x8{hh == 0 ? (_Float16)1.0f : (_Float16)0.0f, 0, 0, 0, 0, 0, 0, 0};
+        bl[KR] = h2_h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        auto layer0 = [&](h2_f32x16 (&h)[HT], const r_u32x4* W) {
+            RA<HT> fr[2];
+            ra_load<HT>(fr[0], W, 0, lane);
+#pragma unroll
+            for (int s = 0; s <= KR; ++s) {
+                if (s < KR) ra_load<HT>(fr[(s + 1) & 1], W, s + 1, lane);
+                if (s == 0) ra_mfma3<HT, true, false>(h, fr[s & 1], bh[s], bl[s]);
+                else if (s == KR) ra_mfma3<HT, false, true>(h, fr[s & 1], bh[s], bl[s]);
+                else ra_mfma3<HT, false, false>(h, fr[s & 1], bh[s], bl[s]);
+            }
+        };
+        if (a.has_shift) layer0(hs, s_w + os.a0);
+        if (a.has_scale) layer0(ht, s_w + ot.a0);
+        /* the conditioner half is consumed (its LDS reads have returned into the operand registers above): request the next tile's */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (more) res_dma_half<G>(s_c, a.cond + b1 * a.ldc, ldc, ol, rows1);
+        AFF_TS(2);
+
+        h2_f32x16 mu[OT], sr[OT];
+        if (a.has_shift) res_net_tail<HT, OT>(mu, hs, a.shift, s_w, os, lane);
+        else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mu[0][r] = 0.0f;
+        }
+        AFF_TS(3);
+        if (a.has_scale) res_net_tail<HT, OT>(sr, ht, a.scale, s_w, ot, lane);
+        else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sr[0][r] = 0.0f;
+        }
+
+        AFF_TS(4);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float l0 = (a.has_scale && h2_row(0, r, hh) < d) ? r_tanh_out(sr[0][r] * a.scale.c2) * alpha : 0.0f;
+            const float l1 = (a.has_scale && h2_row(0, r + 1, hh) < d) ? r_tanh_out(sr[0][r + 1] * a.scale.c2) * alpha : 0.0f;
+            sr[0][r] = l0; sr[0][r + 1] = l1;
+            lsum += l0;
+            lsum += l1;
+        }
+        float total = BGK_RES_SUM(lsum);
+        if (a.preserve_volume && a.has_scale) {
+            const float mean = total / (float)d;
+            lsum = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ls = h2_row(0, r, hh) < d ? sr[0][r] - mean : 0.0f;
+                sr[0][r] = ls;
+                lsum += ls;
+            }
+            total = BGK_RES_SUM(lsum);
+        }
+        /* ---- epilogue on the y half in LDS: lane (j, hh) owns dims 8 q + 4 hh .. + 3 of sample j = granule 2 q + hh ---- */
+        AFF_TS(5);
+        if (more) res_wait_vm<NQ>(); else res_wait_vm<0>();           /* Y_t and the dlogp value have arrived (C_t+1 may be in flight) */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (8 * q + 4 * hh >= d) continue;
+            float* gp = s_y + res_gran<G>(j, 2 * q + hh);
+            const float4 t4 = *reinterpret_cast<const float4*>(gp);
+            const float v[4] = {t4.x, t4.y, t4.z, t4.w};
+            float o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * q + u;
+                const float mm = a.has_shift ? mu[0][r] * a.shift.c2 : 0.0f;
+                const float ls = sr[0][r];
+                const float sg = __builtin_amdgcn_exp2f((a.inverse ? -ls : ls) * 1.44269504088896341f);     /* |ls| <= exp(log_alpha): 1 ulp */
+                float t = a.inverse ? sg * (v[u] - mm) : sg * v[u] + mm;
+                if (a.is_circular) { t = t - __builtin_truncf(t); if (t < 0.0f) t = t + 1.0f; }
+                o[u] = t;
+            }
+            *reinterpret_cast<float4*>(gp) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        /* the finished half leaves as whole 128-byte row pieces: granule p = 64 i + lane of the LDS image -> its row and source column */
+        float4 og[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) og[i] = *reinterpret_cast<const float4*>(s_y + 256 * i + 4 * lane);
+        float* out_t = a.out + b0 * a.ldo;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int c4 = res_col4<G>(ol, i);
+            if (res_row<G>(ol, i) < rows && c4 < d) *reinterpret_cast<float4*>(out_t + i * (64 / G) * ldo + ol.rowl * ldo + c4) = og[i];
+        }
+        if (hh == 0 && j < rows) {
+            const float dl = a.inverse ? -total : total;
+            a.dlogp[b0 + j] = dl_old + dl;
+        }
+        /* the y half is in registers / on its way out: request the next tile's (the LDS reads above have returned: og is live) */
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (more) res_dma_half<G>(s_y, a.y + b1 * a.ldy, ldy, ol, rows1);
+#if BGK_AFF_TS
+        AFF_TS(6);
+        if (lane == 0) for (int k = 0; k < 7; ++k) reinterpret_cast<unsigned*>(a.out + b0 * a.ldo)[k] = ts[k];
+#endif
+    }
+}
+
 /* 16-byte blocks of one packed layer: S k-steps x NT tiles x {hi, lo} + NT bias blocks (bias: hidden / output layers only) */
 inline int res_blocks16(int S, int NT, bool bias) { return (S * NT * 2 + (bias ? NT : 0)) * 64; }
 
@@ -570,6 +824,21 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
         if (has_shift) { os = ResOff{top, top + n0, top + n0 + n1}; top += n0 + n1 + n2; }
         if (has_scale) { ot = ResOff{top, top + n0, top + n0 + n1}; top += n0 + n1 + n2; }
         const size_t res_shmem = (size_t)top * 16;
+        /* both halves of the stack's row as DMA-staged LDS tiles, next tile prefetched (cfg 2's shape) */
+        constexpr int DRW = 8;
+        const size_t dma_shmem = res_shmem + (size_t)DRW * 2 * 32 * 8 * 16;
+        if (bgk_affine_variant == 2 && d_c == 32 && d == 32 && !periodic && a.cvec4 && a.vec4 && (ldc % 4 == 0) && dma_shmem <= 160 * 1024
+            && ldc < (1 << 20) && ldy < (1 << 20) && ldo < (1 << 20) && a.S0 == 3
+            && !getenv("BGK_AFFINE_NO_DMA")) {
+            const int64_t n_tiles = (B + 31) / 32;
+            int64_t grid = (n_tiles + DRW - 1) / DRW;
+            if (grid > 256) grid = 256;
+            const int c_s = has_shift, c_t = has_scale;
+            auto K = coupling_affine_resident_dma_kernel<DRW, 8>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(K, dim3((int)grid), dim3(DRW * 64), dma_shmem, st, a, os, ot, c_s * n0, c_s * n1, c_s * n2, c_t * n0, c_t * n1, c_t * n2, top);
+            return bgk_launch_status("bgk_coupling_affine_dense_h2");
+        }
         if (res_shmem <= 150 * 1024) {
             const int RW = OT == 1 ? 12 : 8;        /* waves per workgroup: 3 per SIMD where the kernel fits 168 VGPRs, else 2 */
             const int64_t n_tiles = (B + 31) / 32;
