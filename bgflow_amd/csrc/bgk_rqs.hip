@@ -173,6 +173,52 @@ __global__ __launch_bounds__(RQS_THREADS) void rqs_stream_kernel(RqsArgs a) {
     }
 }
 
+/* ---- any bin count / any parameter-row length: no LDS staging of the parameter rows --------------------------------------------
+ * rqs_kernel<0> needs at least four [P]-float rows in LDS (K <= 64 for the cfg-3 shapes).  Beyond that every lane walks the 3 K (+1)
+ * parameters of ITS element straight from memory: elements are enumerated dim-fastest, so the K-float runs of 64 consecutive lanes
+ * are 64 consecutive runs of a parameter row -- the k-th access of a wave touches addresses 4 K bytes apart (one cache line per 128
+ * / (4 K) lanes), every line is used completely over the K accesses and stays in L1 meanwhile.  Not a roofline kernel (the walk is
+ * repeated for max / sum / knots): it keeps wide splines off device torch ops. ---- */
+__global__ __launch_bounds__(RQS_THREADS) void rqs_direct_kernel(RqsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_lad[];   /* [RQS2_TS * d] */
+    const int d = a.d, K = a.K, tid = threadIdx.x;
+    const uint64_t magicd = (0x100000000ull + (uint64_t)d - 1) / (uint64_t)d;
+    const int64_t n_tiles = (a.B + RQS2_TS - 1) / RQS2_TS;
+    int oob_local = 0;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * RQS2_TS;
+        const int rows = (int)((a.B - b0) < RQS2_TS ? (a.B - b0) : RQS2_TS);
+        const int n = rows * d;
+        for (int e = tid; e < n; e += RQS_THREADS) {
+            const int s = (int)(((uint64_t)(uint32_t)e * magicd) >> 32), j = e - s * d;
+            const float* row = a.params + (b0 + s) * a.ldp;
+            const float* pw = row + (int64_t)j * K;
+            const float* ph = pw + (int64_t)d * K;
+            const float* ps = ph + (int64_t)d * K;
+            const int slot = a.nc_slot[j];
+            const float s_last = slot >= 0 ? row[(int64_t)3 * d * K + slot] : ps[0];
+            const float x = a.y[(b0 + s) * a.ldy + j];
+            float lad; int bin, oob;
+            const float o = bgk_rqs_element<0>(x, pw, ph, ps, 1, s_last, K, a.inverse, a.cfg, &lad, &bin, &oob);
+            a.out[(b0 + s) * a.ldo + j] = o;
+            if (a.bin_idx) a.bin_idx[(b0 + s) * d + j] = bin;
+            s_lad[e] = lad;
+            oob_local += oob;
+        }
+        __syncthreads();
+        for (int s = tid; s < rows; s += RQS_THREADS) {
+            float acc = 0.0f;
+            for (int j = 0; j < d; ++j) acc += s_lad[s * d + j];
+            if (a.accumulate) a.dlogp[b0 + s] += acc; else a.dlogp[b0 + s] = acc;
+        }
+        __syncthreads();
+    }
+    if (a.oob_count) {
+        for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
+        if ((tid & 63) == 0 && oob_local) atomicAdd(a.oob_count, oob_local);
+    }
+}
+
 }  // namespace
 
 extern "C" int bgk_rqs_transform(const float* y, int64_t ldy, const float* params, int64_t ldp,
@@ -184,7 +230,6 @@ extern "C" int bgk_rqs_transform(const float* y, int64_t ldy, const float* param
                                  int32_t* oob_count, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && d > 0 && K > 0, "bgk_rqs_transform: bad sizes B=%lld d=%d K=%d", (long long)B, d, K);
-    BGK_CHECK_ARG(K <= 64, "bgk_rqs_transform: n_bins=%d > 64 unsupported", K);
     BGK_CHECK_ARG(y && params && nc_slot && out && dlogp, "bgk_rqs_transform: null pointer");
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
@@ -206,7 +251,13 @@ extern "C" int bgk_rqs_transform(const float* y, int64_t ldy, const float* param
     int TS = (int)(budget / (sizeof(float) * (size_t)(a.Pp + 2 * d)));
     TS = TS > 64 ? 64 : TS;
     TS &= ~3;
-    BGK_CHECK_ARG(TS >= 4, "bgk_rqs_transform: parameter row of %d floats does not fit the LDS tile", a.P);
+    if (TS < 4 || K > 64) {     /* parameter rows beyond the LDS tile (K > 64 for ~17 dims): every lane walks its element's parameters in memory */
+        BGK_CHECK_ARG((size_t)RQS2_TS * d * sizeof(float) <= 64 * 1024, "bgk_rqs_transform: %d dims do not fit the log-det tile", d);
+        const int64_t nt2 = (B + RQS2_TS - 1) / RQS2_TS;
+        const int grid2 = (int)(nt2 < 256 * 16 ? nt2 : 256 * 16);
+        hipLaunchKernelGGL(rqs_direct_kernel, dim3(grid2), dim3(RQS_THREADS), sizeof(float) * (size_t)RQS2_TS * d, (hipStream_t)stream, a);
+        return bgk_launch_status("bgk_rqs_transform");
+    }
     a.TS = TS;
     size_t shmem = sizeof(float) * (size_t)TS * (size_t)(a.Pp + 2 * d);
     int64_t n_tiles = (B + TS - 1) / TS;

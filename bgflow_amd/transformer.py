@@ -24,7 +24,6 @@ def _invalidate_fused_cache(self):
 
 __all__ = ["Transformer", "AffineTransformer", "ConditionalSplineTransformer"]
 
-_WARNED_TORCH_SPLINE = False
 DEFAULT_MIN_BIN_WIDTH = 1e-3
 DEFAULT_MIN_BIN_HEIGHT = 1e-3
 DEFAULT_MIN_DERIVATIVE = 1e-3
@@ -194,18 +193,9 @@ def rqs_transform(y, params, nc_slot, n_bins, inverse, left, right, bottom, top,
     y2, ldy = _lib.rowmajor(y2)
     B, d = y2.shape
     P = params.shape[-1]
-    if n_bins > 64 or 4 * 4 * (P | 1) > 160 * 1024:
-        # outside the kernel's envelope (more than 64 bins, or a parameter row that leaves no room for a 4-sample LDS tile):
-        # the same map on device torch ops (differentiable by autograd; no bin-index output)
-        if want_bin_idx:
-            raise ValueError("return_bin_indices is not available for n_bins > 64 / parameter rows beyond the kernel's LDS tile")
-        global _WARNED_TORCH_SPLINE
-        if not _WARNED_TORCH_SPLINE:
-            _WARNED_TORCH_SPLINE = True
-            warnings.warn(f"rational-quadratic spline with {n_bins} bins / {P} parameters per sample is beyond the HIP kernels' envelope "
-                          f"(<= 64 bins, parameter row within the LDS tile): running on device torch ops", RuntimeWarning, stacklevel=3)
-        out, dl = _rqs_spline_torch(y2, params.reshape(-1, P), nc_slot, (n_bins, inverse, left, right, bottom, top, settings))
-        return out.reshape(*lead, d), dl.reshape(*lead, 1)
+    # (any bin count: rows that leave no room for an LDS tile -- more than 64 bins for ~17 dims -- run on the kernel's direct
+    # variant, every lane walking its element's parameters in memory; only the BACKWARD of bin counts other than 4 / 8 / 12 / 16 / 32
+    # uses device torch ops, see rqs_backward)
     p2, ldp = _lib.rowmajor(params.reshape(-1, P))
     out = torch.empty((B, d), dtype=torch.float32, device=y.device)
     if y.dim() != 2:
@@ -438,7 +428,8 @@ class ConditionalSplineTransformer(Transformer):
             raise RuntimeError(
                 f"params_net output width {P} does not match 3 * n_bins * {y_dim} + {n_nc} "
                 f"(split_with_sizes in the reference, transformer/spline.py:113-117)")
-        if grad and not (n_bins > 64 or 4 * 4 * (P | 1) > 160 * 1024):     # beyond the kernel envelope rqs_transform runs torch ops: plain autograd
+        if grad:           # forward on the kernel (any bin count); backward: bgk_rqs_backward, or autograd through the same map on
+            #                    device torch ops for the bin counts the backward kernel has no instance for (rqs_backward)
             return _RQSFn.apply(y, params, nc_dev, n_bins, inverse, self._left, self._right, self._bottom,
                                 self._top, self._default_settings, oob)
         res = rqs_transform(y, params, nc_dev, n_bins, inverse, self._left, self._right, self._bottom,

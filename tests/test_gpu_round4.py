@@ -203,3 +203,43 @@ def test_fused_priors_draw_independent_streams_and_keep_their_energy_cache_hones
     assert "_philox_state" not in bg.NormalDistribution(17, sample_fused=True).state_dict()
     wide = bg.NormalDistribution(200, sample_fused=True).to(dev)
     assert wide.sample(10).shape == (10, 200)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_spline_kernel_for_rows_beyond_the_lds_tile(hip_lib, oracle, dev, inverse):
+    """bgk_rqs_transform for parameter rows that leave no room for an LDS tile (every lane walks its element's parameters in memory):
+    (i) K = 32 bins x 60 dims (5820 floats per row): bit-identical to the C oracle (same deterministic element routine), bin indices
+    included; (ii) K = 80 / 200 bins (more than the C oracle holds): against the f64 torch restatement of the nflows spline in oracle/."""
+    from bgflow_amd.transformer import rqs_transform
+    from oracle import torch_flow as tf
+    from test_gpu_parity import synth, t
+    st = dict(min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, enable_identity_init=True)
+    # (i)
+    Kb, d, B = 32, 60, 301
+    circ = np.arange(d) % 3 == 0
+    n_nc = int((~circ).sum())
+    params, y = synth(900, B, 3 * Kb * d + n_nc, scale=0.8), synth(901, B, d, uniform=True)
+    slots = torch.as_tensor(oracle.nc_slots(circ, d)).to(dev)
+    out, dl, idx = rqs_transform(t(y, dev), t(params, dev), slots, Kb, inverse, 0.0, 1.0, 0.0, 1.0, st, want_bin_idx=True)
+    zo, dlo, det = oracle.rqs(y, params, is_circular=circ, inverse=inverse, n_bins=Kb, dtype=np.float32, want_details=True)
+    assert np.array_equal(idx.cpu().numpy(), det["bin_idx"])
+    assert np.array_equal(out.cpu().numpy(), zo)
+    np.testing.assert_allclose(dl.cpu().numpy(), dlo, rtol=0, atol=2e-5)
+    # (ii)
+    for Kb, d, B in ((80, 5, 257), (200, 17, 130)):
+        circ = np.arange(d) % 2 == 0
+        n_nc = int((~circ).sum())
+        params, y = synth(300 + Kb, B, 3 * Kb * d + n_nc, scale=0.7), synth(400 + Kb, B, d, uniform=True)
+        slots = torch.as_tensor(oracle.nc_slots(circ, d)).to(dev)
+        out, dl = rqs_transform(t(y, dev), t(params, dev), slots, Kb, inverse, 0.0, 1.0, 0.0, 1.0, st)
+        p64, y64 = torch.tensor(params, dtype=torch.float64), torch.tensor(y, dtype=torch.float64)
+        w, h, sl, s_nc = torch.split(p64, [d * Kb, d * Kb, d * Kb, n_nc], dim=-1)
+        w, h, sl = (v.reshape(B, d, Kb) for v in (w, h, sl))
+        cm = torch.tensor(circ)
+        nc_full = torch.zeros(B, d, dtype=torch.float64).index_put((torch.arange(B)[:, None], torch.nonzero(~cm).reshape(1, -1)), s_nc)
+        last = torch.where(cm[None, :], sl[..., 0], nc_full)
+        ref, ld = tf.rq_spline(y64, w, h, torch.cat([sl, last[..., None]], -1), not inverse, 0.0, 1.0, 0.0, 1.0,
+                               st["min_bin_width"], st["min_bin_height"], st["min_derivative"], True)
+        assert float((out.cpu().double() - ref).abs().max()) < 1e-6 + 6e-8 * Kb, f"K = {Kb}"      # f32 running sums over K bins
+        # (bin sizes ~ 1 / K are differences of f32 running sums: the log-det error grows with K^2 eps per dim)
+        assert float((dl.cpu().double().reshape(-1) - ld.sum(-1)).abs().max()) < 2e-8 * Kb * Kb * d + 2e-4, f"K = {Kb}"
