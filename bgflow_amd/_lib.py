@@ -82,6 +82,7 @@ _SIGNATURES = {
     "bgk_dense_backward_dx": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, i64,
                                              vp, vp, vp, vp, vp, i64, vp]),
     "bgk_column_sum": (ctypes.c_int, [vp, i64, i64, i32, vp, i32, vp, vp]),
+    "bgk_whiten": (ctypes.c_int, [vp, i64, vp, vp, vp, i32, i32, i64, vp, i64, vp]),
     "bgk_normal_energy": (ctypes.c_int, [vp, i64, vp, i32, i64, f64, f64, vp, vp]),
     "bgk_normal_energy_backward": (ctypes.c_int, [vp, i64, vp, i32, i64, f64, vp, vp, i64, vp]),
     "bgk_energy_fields": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, i32, i64, f64, f64, f64, vp, vp, i32, vp, i32, vp, vp]),

@@ -482,10 +482,35 @@ def _pca(X0, keepdims=None):
     return mean, V @ np.diag(1.0 / std), np.diag(std) @ V.T, std
 
 
+class _WhitenFn(torch.autograd.Function):
+    """out = (x - pre) T + post on bgk_whiten; backward: g_x = g_out T^T on the same kernel"""
+
+    @staticmethod
+    def forward(ctx, x, T, Tt, pre, post):
+        ctx.Tt = Tt
+        return _whiten_launch(x, T, pre, post)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _whiten_launch(g.contiguous(), ctx.Tt, None, None), None, None, None, None
+
+
+def _whiten_launch(x, T, pre, post):
+    x2, ldx = _lib.rowmajor(x)
+    B, n_in = x2.shape
+    n_out = T.shape[1]
+    out = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = _lib.lib().bgk_whiten(_lib.ptr(x2), ldx, _lib.ptr(T), _lib.ptr(pre), _lib.ptr(post), n_in, n_out, B, _lib.ptr(out), n_out,
+                                   _lib.stream_ptr(x.device))
+    _lib.check(st, "bgk_whiten")
+    return out
+
+
 class WhitenFlow(Flow):
-    """Static PCA whitening ``z = (x - mean) @ Twhiten`` with constant log-det (pca.py:37-107).
-    Stand-alone it is a tiny GEMM and runs stock torch ops; inside MixedCoordinateTransformation
-    the matvec is fused into the IC kernels.  Buffers: X0mean, Twhiten, Tblacken, std."""
+    """Static PCA whitening ``z = (x - mean) @ Twhiten`` with constant log-det (pca.py:37-107).  Stand-alone, blocks of up to 128
+    coordinates run on bgk_whiten (mean shift fused, VJP on the same kernel); larger ones are a plain library GEMM.  Inside
+    MixedCoordinateTransformation the product is fused into the IC kernels.  Buffers: X0mean, Twhiten, Tblacken, std."""
 
     def __init__(self, X0, keepdims=None, whiten_inverse=True):
         super().__init__()
@@ -502,12 +527,32 @@ class WhitenFlow(Flow):
             raise ValueError("Cannot construct whiten layer because trying to keep nonpositive eigenvalues.")
         self.jacobian_xz = -torch.sum(torch.log(self.std))
 
+    def _kernel(self, x, which):
+        """(x - X0mean) Twhiten | x Tblacken + X0mean on bgk_whiten, or None (not a 2-d f32 HIP tensor, block wider than 128)"""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2) or max(self.dim, self.keepdims) > 128:
+            return None
+        key = (str(x.device), self.Twhiten.data_ptr(), self.Twhiten._version, self.Tblacken._version, self.X0mean._version)
+        cache = self.__dict__.get("_kernel_mats")
+        if cache is None or cache[0] != key:
+            f = lambda t: t.detach().to(device=x.device, dtype=torch.float32).contiguous()      # noqa: E731
+            Tw, Tb, m = f(self.Twhiten), f(self.Tblacken), f(self.X0mean)
+            cache = self.__dict__["_kernel_mats"] = (key, dict(whiten=(Tw, Tw.t().contiguous(), m, None),
+                                                              blacken=(Tb, Tb.t().contiguous(), None, m)))
+        T, Tt, pre, post = cache[1][which]
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _WhitenFn.apply(x, T, Tt, pre, post)
+        return _whiten_launch(x, T, pre, post)
+
     def _whiten(self, x):
-        z = torch.matmul(x - self.X0mean, self.Twhiten)
+        z = self._kernel(x, "whiten")
+        if z is None:
+            z = torch.matmul(x - self.X0mean, self.Twhiten)
         return z, self.jacobian_xz.to(x) * torch.ones((x.shape[0], 1), dtype=x.dtype, device=x.device)
 
     def _blacken(self, z):
-        x = torch.matmul(z, self.Tblacken) + self.X0mean
+        x = self._kernel(z, "blacken")
+        if x is None:
+            x = torch.matmul(z, self.Tblacken) + self.X0mean
         return x, -self.jacobian_xz.to(z) * torch.ones((z.shape[0], 1), dtype=z.dtype, device=z.device)
 
     def _forward(self, x, *args, **kwargs):

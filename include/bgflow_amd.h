@@ -493,6 +493,14 @@ int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const f
 int bgk_column_sum(const float* x, int64_t ldx, int64_t B, int32_t P, float* partial, int32_t nblk,
                    float* out, void* stream);
 
+/* Static PCA whitening / blackening of a coordinate block on its own: out = (x - pre) T + post.
+ * Replaces WhitenFlow._whiten / _blacken (nn/flow/pca.py:74-93: torch.matmul(x - X0mean, Twhiten), torch.matmul(z, Tblacken) + X0mean);
+ * the constant log-det -+ sum log std is formed by the caller.  The VJP w.r.t. x is the same call on the transposed matrix.
+ *   x [B, n_in] (ldx), T [n_in, n_out] row-major, pre [n_in] or NULL, post [n_out] or NULL, out [B, n_out] (ldo).
+ * n_in, n_out <= 128; BGK_EUNSUPPORTED beyond (a plain library GEMM then). */
+int bgk_whiten(const float* x, int64_t ldx, const float* T, const float* pre, const float* post,
+               int32_t n_in, int32_t n_out, int64_t B, float* out, int64_t ldo, void* stream);
+
 /* number of packed columns NCp for (d, K) and the source column (in the reference's params
  * layout, P = 3*K*d + n_nc) of every packed column, -1 for padding.  HOST function:
  * src_col is a host int32[NCp] buffer (pass NULL to query NCp only). */

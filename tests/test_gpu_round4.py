@@ -243,3 +243,30 @@ def test_spline_kernel_for_rows_beyond_the_lds_tile(hip_lib, oracle, dev, invers
         assert float((out.cpu().double() - ref).abs().max()) < 1e-6 + 6e-8 * Kb, f"K = {Kb}"      # f32 running sums over K bins
         # (bin sizes ~ 1 / K are differences of f32 running sums: the log-det error grows with K^2 eps per dim)
         assert float((dl.cpu().double().reshape(-1) - ld.sum(-1)).abs().max()) < 2e-8 * Kb * Kb * d + 2e-4, f"K = {Kb}"
+
+
+@pytest.mark.parametrize("dim,keep,B", [(9, 9, 1000), (66, 60, 4133), (12, 5, 1), (128, 128, 257)])
+def test_standalone_whiten_flow_on_the_kernel(hip_lib, dev, dim, keep, B):
+    """WhitenFlow on its own (pca.py:74-93) runs bgk_whiten in both directions, gradients included: against the f64 matrix products of
+    the same buffers; round trip; constant log-det"""
+    import bgflow_amd as bg
+    rng = np.random.default_rng(dim)
+    data = torch.tensor(rng.normal(size=(500, dim)) @ rng.normal(size=(dim, dim)) * 0.3 + rng.normal(size=(dim,)), dtype=torch.float32)
+    for whiten_inverse in (False, True):
+        wf = bg.WhitenFlow(data, keepdims=keep, whiten_inverse=whiten_inverse).to(dev)
+        Tw, Tb, m = wf.Twhiten.double().cpu(), wf.Tblacken.double().cpu(), wf.X0mean.double().cpu()
+        x = torch.tensor(rng.normal(size=(B, dim)), dtype=torch.float32, device=dev, requires_grad=True)
+        z, dl = wf(x, inverse=whiten_inverse)                       # the whitening direction
+        ref = (x.detach().double().cpu() - m) @ Tw
+        assert z.shape == (B, keep) and float((z.detach().double().cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        assert torch.allclose(dl, wf.jacobian_xz.to(dl) * torch.ones_like(dl))
+        z.square().sum().backward()
+        gref = (2.0 * ref) @ Tw.t()
+        assert float((x.grad.double().cpu() - gref).abs().max()) <= 1e-4 * max(1.0, float(gref.abs().max()))
+        with torch.no_grad():
+            xb, dlb = wf(z.detach(), inverse=not whiten_inverse)    # blackening
+        refb = ref @ Tb + m
+        assert float((xb.double().cpu() - refb).abs().max()) <= 2e-5 * max(1.0, float(refb.abs().max()))
+        assert torch.allclose(dlb, -dl)
+        if keep == dim:
+            assert float((xb - x.detach()).abs().max()) <= 1e-3 * max(1.0, float(x.detach().abs().max()))
