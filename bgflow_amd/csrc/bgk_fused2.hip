@@ -805,6 +805,15 @@ __device__ __forceinline__ void dma_tile32(float* dst, const float* __restrict__
     }
 }
 
+/* sin / cos of 2 pi x for the periodic featuriser of these tolerance-class kernels: the hardware forms take their argument in
+ * revolutions (max abs error 1.24e-7 on [-2, 2], tools/ubench/hw_sincos.hip: the resolution of the split-f16 operands they feed);
+ * 3 instructions instead of the ~30 of the reproducible polynomial form (bgk_sincos2pif, kept by the exact-f32 kernel) */
+__device__ __forceinline__ void v2_sincos2pi(float x, float* s, float* c) {
+    const float f = __builtin_amdgcn_fractf(x);
+    *s = __builtin_amdgcn_sinf(f);
+    *c = __builtin_amdgcn_cosf(f);
+}
+
 /* ---- staging of a tile's inputs as row-major images (one row per sample) in LDS: y -> s_y [32][ys], the (featurised) conditioner
  * input -> s_p [32][nfs].  Contiguous, 16-byte aligned tensors (what a flow over separate field tensors hands over) travel by the
  * DMA path: a linear copy, no staging registers, no index arithmetic, every request in flight from the first cycle.  stage_issue
@@ -872,7 +881,7 @@ __device__ __forceinline__ void stage_finish(const StageTiles& t, const CondSegs
                         float* f = s_p + (int)__umul24((unsigned)r, (unsigned)nfs) + col0 + c;
                         if (t.periodic) {                               /* WrapPeriodic featuriser (nn/periodic.py:30-37) */
                             float sv, cv;
-                            bgk_sincos2pif(vc[u], &sv, &cv);
+                            v2_sincos2pi(vc[u], &sv, &cv);
                             f[0] = cv;
                             f[t.d_c] = sv;
                         } else {
@@ -893,7 +902,7 @@ __device__ __forceinline__ void stage_finish(const StageTiles& t, const CondSegs
         for (int i = lane; i < 32 * t.d_c; i += 64) {
             const int r = (int)(__umul24((unsigned)i, magic_c) >> 20), c = i - (int)__umul24((unsigned)r, (unsigned)t.d_c);
             float sv, cv;
-            bgk_sincos2pif(raw[i], &sv, &cv);
+            v2_sincos2pi(raw[i], &sv, &cv);
             float* f = s_p + (int)__umul24((unsigned)r, (unsigned)nfs) + c;
             f[0] = cv;
             f[t.d_c] = sv;

@@ -417,7 +417,8 @@ def test_fused_philox_prior_sampling(hip_lib, dev):
     B = 5003
     u, x, z = prior.sample(B, temperature=1.5)
     assert u.shape == (B, 17) and x.shape == (B, 66) and z.shape == (B, 9)
-    seed = torch.initial_seed()
+    sid = prior._philox_state[0]                  # the object's stream id (construction order of fused-sampling objects in this process)
+    seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (sid + 1)) & (2 ** 64 - 1)
     ru = philox.sample_field(seed, 0, 0, B, 17, 0)
     assert np.array_equal(u.cpu().numpy(), (low.cpu().numpy() + ru * (high - low).cpu().numpy()).astype(np.float32))
     rx = philox.sample_field(seed, 0, 1, B, 66, 1)
@@ -429,11 +430,15 @@ def test_fused_philox_prior_sampling(hip_lib, dev):
     prior._philox_last = None
     e_eval = prior.energy(u, x, z, temperature=1.5)
     np.testing.assert_allclose(e_fused.cpu().numpy(), e_eval.cpu().numpy(), rtol=3e-6, atol=1e-4)
-    # a second call advances the stream; the same seed reproduces it
+    # a second call advances the stream; another object draws from its own stream; the same seed + the same stream state reproduce it
     u2, _, _ = prior.sample(B, temperature=1.5)
     assert not torch.equal(u, u2)
     prior2 = bg.ProductDistribution([bg.UniformDistribution(low, high), bg.NormalDistribution(66, mean=mean), bg.NormalDistribution(9).to(dev)],
                                     sample_fused=True)
+    torch.manual_seed(1234)
+    u3, x3, z3 = prior2.sample(B, temperature=1.5)
+    assert not torch.equal(u, u3)
+    prior2._philox_state[:] = [sid, 0]
     torch.manual_seed(1234)
     u3, x3, z3 = prior2.sample(B, temperature=1.5)
     assert torch.equal(u, u3) and torch.equal(x, x3) and torch.equal(z, z3)
@@ -871,7 +876,7 @@ def test_philox_fields_small_and_ragged_shapes(hip_lib, dev, B, d):
     prior = bg.ProductDistribution([bg.UniformDistribution(low, high), bg.NormalDistribution(d).to(dev)], sample_fused=True)
     torch.manual_seed(99)
     u, z = prior.sample(B)
-    seed = torch.initial_seed()
+    seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (prior._philox_state[0] + 1)) & (2 ** 64 - 1)    # key = seed mixed with the object's stream id
     assert np.array_equal(u.cpu().numpy(), (2.0 * philox.sample_field(seed, 0, 0, B, d, 0)).astype(np.float32))
     np.testing.assert_allclose(z.cpu().numpy(), philox.sample_field(seed, 0, 1, B, d, 1), rtol=0, atol=4e-6)
     assert torch.isfinite(prior.energy(u, z)).all()
