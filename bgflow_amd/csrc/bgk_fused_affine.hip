@@ -112,6 +112,37 @@ __device__ __forceinline__ void ra_gemm_hidden(h2_f32x16 (&out)[NT], const RB<HT
         out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, ring[S & 1].v[m][0]), one2, out[m], 0, 0, 0);
 }
 
+/* the same with the fragments of k-step 0 already requested by the caller (`first`): the resident kernels request them BEFORE the
+ * activation code that produces the B operands, so the LDS round trip of the first k-step hides under that arithmetic */
+template <int NT, int HT>
+__device__ __forceinline__ void ra_gemm_hidden_pre(h2_f32x16 (&out)[NT], const RB<HT>& b, const r_u32x4* W, int lane, const RA<NT>& first) {
+    constexpr int S = 2 * HT;
+    RA<NT> ring[2];
+    ring[0] = first;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) ra_load<NT>(ring[(s + 1) & 1], W, s + 1, lane);
+        else {
+#pragma unroll
+            for (int m = 0; m < NT; ++m) ring[(s + 1) & 1].v[m][0] = W[(S * NT * 2 + m) * 64 + lane];
+        }
+#ifndef BGK_AFF_NOPIN
+        /* keep the next step's LDS reads IN FRONT of this step's MFMAs: left alone, the scheduler sinks every ds_read_b128 to its use
+         * (ds_read; s_waitcnt lgkmcnt(0); v_mfma -- the whole LDS latency exposed per k-step at two waves per SIMD) */
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (s == 0) ra_mfma3<NT, true, false>(out, ring[0], __builtin_bit_cast(h2_h16x8, b.hi[0]), __builtin_bit_cast(h2_h16x8, b.lo[0]));
+        else ra_mfma3<NT, false, false>(out, ring[s & 1], __builtin_bit_cast(h2_h16x8, b.hi[s]), __builtin_bit_cast(h2_h16x8, b.lo[s]));
+#ifndef BGK_AFF_NOPIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    const h2_h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+        out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, ring[S & 1].v[m][0]), one2, out[m], 0, 0, 0);
+}
+
 /* hidden activation of t * c with the hardware exp2 / rcp forms (bgk_detmath_pk.h explains why these are admissible for
  * HIDDEN activations), immediately split into f16 hi + lo: scalar (non-packed) VALU so that it overlaps other waves' MFMAs.
  * ACT 0 identity, 1 SiLU, 2 ReLU, 3 Tanh.  k = c (ACT 0, 2), c * log2(e) (1), 2 c log2(e) (3). */
@@ -324,6 +355,7 @@ struct ResOff { int a0, a1, a2; };          /* offsets (16-byte units) of a netw
 template <int HT, int OT>
 __device__ __forceinline__ void res_net_tail(h2_f32x16 (&res)[OT], h2_f32x16 (&h)[HT], const AffNet& n, const r_u32x4* s_w, ResOff o, int lane) {
     RB<HT> bf;
+#ifdef BGK_AFF_NOPRE
     r_act_split<HT>(bf, h, n.c0, n.act);
     BGK_AFF_PRIO(1);               /* matrix phases first: the other waves of the SIMD fill the gaps with their activation arithmetic */
     ra_gemm_hidden<HT, HT>(h, bf, s_w + o.a1, lane);
@@ -332,6 +364,20 @@ __device__ __forceinline__ void res_net_tail(h2_f32x16 (&res)[OT], h2_f32x16 (&h
     BGK_AFF_PRIO(1);
     ra_gemm_hidden<OT, HT>(res, bf, s_w + o.a2, lane);
     BGK_AFF_PRIO(0);
+#else
+    RA<HT> f1;
+    ra_load<HT>(f1, s_w + o.a1, 0, lane);          /* the GEMM's first fragments travel while the activation code runs */
+    r_act_split<HT>(bf, h, n.c0, n.act);
+    BGK_AFF_PRIO(1);               /* matrix phases first: the other waves of the SIMD fill the gaps with their activation arithmetic */
+    ra_gemm_hidden_pre<HT, HT>(h, bf, s_w + o.a1, lane, f1);
+    BGK_AFF_PRIO(0);
+    RA<OT> f2;
+    ra_load<OT>(f2, s_w + o.a2, 0, lane);
+    r_act_split<HT>(bf, h, n.c1, n.act);
+    BGK_AFF_PRIO(1);
+    ra_gemm_hidden_pre<OT, HT>(res, bf, s_w + o.a2, lane, f2);
+    BGK_AFF_PRIO(0);
+#endif
 }
 
 constexpr int RES_HT = 2;
@@ -671,9 +717,15 @@ __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_dma_kerne
 #pragma unroll
             for (int s = 0; s <= KR; ++s) {
                 if (s < KR) ra_load<HT>(fr[(s + 1) & 1], W, s + 1, lane);
+#ifndef BGK_AFF_NOPIN
+                __builtin_amdgcn_sched_barrier(0);       /* (see ra_gemm_hidden_pre) */
+#endif
                 if (s == 0) ra_mfma3<HT, true, false>(h, fr[s & 1], bh[s], bl[s]);
                 else if (s == KR) ra_mfma3<HT, false, true>(h, fr[s & 1], bh[s], bl[s]);
                 else ra_mfma3<HT, false, false>(h, fr[s & 1], bh[s], bl[s]);
+#ifndef BGK_AFF_NOPIN
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         };
         if (a.has_shift) layer0(hs, s_w + os.a0);
