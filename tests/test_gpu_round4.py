@@ -81,49 +81,89 @@ def test_inverse_parity_of_rows_of_a_full_size_launch(hip_lib, oracle, dev, cfg,
         assert float((a - b).abs().median()) < 1e-3
 
 
-def test_kl_gradient_at_the_bench_batch(hip_lib, dev):
-    """The flat KL gradient of cfg 3 at B = 2^18 (the batch of bench.py's `kl` leg): the bench's own path on the GPU -- fused training
-    forward, energy kernel with the loss sums, analytic backward kernels, split-K weight gradients -- against an f64 autograd
-    evaluation of the reference's op chain (oracle/torch_flow.py) on the SAME 2^18 prior samples, 32 chunks on the host.
-    Bounds: relative L2 error of the flat gradient <= 2e-4 (measured 1.3e-4: the backward GEMMs multiply bf16 hi + lo operand pairs,
-    ~16 significant bits per product, through 48 chained layers); every parameter tensor within 1e-3 of its own norm (max norm).
-    A split-K ordering or 24-bit index fault at 2^18 rows shows up as an O(1) error of a layer, not as 1e-4."""
-    from bgflow_amd import configs, dp
-    from oracle import torch_flow as tfl
-    B, n_chunks = 1 << 18, 32
-    gen = configs.make_ala2_spline_generator(dev)
-    gen_cpu = configs.make_ala2_spline_generator().double()
-    g = torch.Generator(device=dev).manual_seed(2024)
-    z = [torch.rand(B, d, device=dev, generator=g) for d in (17, 17, 17, 9)]
+def _kl_gradient_gpu(gen, z):
+    """flat KL gradient through the bench's own path: fused training forward, loss sums in the energy kernel, analytic backward
+    kernels, split-K weight gradients"""
+    from bgflow_amd import dp
+    for p in gen.flow.parameters():
+        p.grad = None
     *x, dlogp = gen.flow(*z)
     loss = dp.global_kl_mean(gen._target, x, dlogp)
     loss.backward()
-    got = {n: p.grad.detach().cpu().double() for n, p in gen.flow.named_parameters()}
-    assert all(torch.isfinite(v).all() for v in got.values())
-    # ---- f64 reference: d/dtheta mean_b [u(x_b) - dlogp_b], u = the target's quadratic form (unit normal about the reference geometry)
-    mean = gen._target._mean.detach().cpu().double() if hasattr(gen._target, "_mean") else None
-    assert mean is not None
-    params = dict(gen_cpu.flow.named_parameters())
-    z_cpu = [v.cpu().double() for v in z]
-    loss_ref = 0.0
+    return {n: p.grad.detach().cpu().double() for n, p in gen.flow.named_parameters()}, float(loss.detach())
+
+
+def _kl_gradient_f64(gen_cpu, mean, z_cpu, n_chunks):
+    """the same gradient by f64 autograd through the reference's op chain (oracle/torch_flow.py), `n_chunks` chunks on the host;
+    u = the target's quadratic form (unit normal about the reference geometry; its constant is no part of the gradient)"""
+    from oracle import torch_flow as tfl
+    for p in gen_cpu.flow.parameters():
+        p.grad = None
+    B = z_cpu[0].shape[0]
+    total = 0.0
     for c in range(n_chunks):
         sl = slice(c * (B // n_chunks), (c + 1) * (B // n_chunks))
         xs, dl = tfl.run_flow(gen_cpu.flow, [v[sl] for v in z_cpu], grad=True)
-        u = 0.5 * ((xs[0] - mean) ** 2).sum(-1, keepdim=True)
-        part = (u - dl).sum() / B
+        part = (0.5 * ((xs[0] - mean) ** 2).sum(-1, keepdim=True) - dl).sum() / B
         part.backward()
-        loss_ref += float(part.detach())
-    ref = {n: p.grad for n, p in params.items()}
-    assert set(ref) == set(got)
+        total += float(part.detach())
+    return {n: p.grad.clone() for n, p in gen_cpu.flow.named_parameters()}, total
+
+
+def _grad_errors(got, ref):
     num = sum(float(((got[n] - ref[n]) ** 2).sum()) for n in ref)
     den = sum(float((ref[n] ** 2).sum()) for n in ref)
-    rel_l2 = (num / den) ** 0.5
-    assert rel_l2 <= 2e-4, f"flat KL gradient at B = 2^18: relative L2 error {rel_l2:.2e}"
     worst = max((float((got[n] - ref[n]).abs().max()) / max(float(ref[n].norm()), 1e-30), n) for n in ref)
-    assert worst[0] <= 1e-3, f"parameter tensor {worst[1]}: max error {worst[0]:.2e} of its norm"
-    # the loss itself (the target's normalisation constant is no part of the f64 restatement above: compare up to it)
-    const = 0.5 * 66 * np.log(2 * np.pi)
-    assert abs(float(loss.detach()) - loss_ref) <= 1e-4 * abs(loss_ref) or abs(float(loss.detach()) - loss_ref - const) <= 1e-4 * abs(loss_ref)
+    return (num / den) ** 0.5, worst
+
+
+def test_kl_gradient_at_the_bench_batch(hip_lib, dev):
+    """The flat KL gradient of cfg 3 at B = 2^18 (the batch of bench.py's `kl` leg), in two steps that keep the CPU side bounded:
+      (i)  the ONE-pass gradient over 2^18 samples == the mean of the gradients of its 32 chunks of 8192 samples, all on the GPU
+           (a split-K ordering or 24-bit index fault that only shows at 2^18 rows is an O(1) error of a layer here);
+      (ii) the chunk gradients themselves against an f64 autograd evaluation of the reference's op chain (oracle/torch_flow.py) on the
+           same samples, for the first and the last chunk of the batch: relative L2 error of the flat gradient <= 4e-4 (the backward
+           GEMMs multiply bf16 hi + lo operand pairs, ~16 significant bits per product, through 48 chained layers; over all 2^18
+           samples the direct form below measures 1.3e-4), every parameter tensor within 1e-3 of its own norm (max norm).
+    BGK_FULL_KL_GRADIENT=1 runs the direct form as well: f64 reference over all 2^18 samples (32 chunks on the host, ~5 minutes)."""
+    import os
+    from bgflow_amd import configs
+    B, n_chunks = 1 << 18, 32
+    gen = configs.make_ala2_spline_generator(dev)
+    gen_cpu = configs.make_ala2_spline_generator().double()
+    mean = gen._target._mean.detach().cpu().double()
+    g = torch.Generator(device=dev).manual_seed(2024)
+    z = [torch.rand(B, d, device=dev, generator=g) for d in (17, 17, 17, 9)]
+    full, loss_full = _kl_gradient_gpu(gen, z)
+    assert all(torch.isfinite(v).all() for v in full.values())
+    # (i)
+    acc, loss_acc, chunk_grads = None, 0.0, {}
+    step = B // n_chunks
+    for c in range(n_chunks):
+        gc, lc = _kl_gradient_gpu(gen, [v[c * step:(c + 1) * step] for v in z])
+        acc = gc if acc is None else {n: acc[n] + gc[n] for n in gc}
+        loss_acc += lc / n_chunks
+        if c in (0, n_chunks - 1):
+            chunk_grads[c] = gc
+    mean_of_chunks = {n: v / n_chunks for n, v in acc.items()}
+    rel, worst = _grad_errors(full, mean_of_chunks)
+    # (both sides carry the ~1e-4 noise of the bf16 hi + lo products of the backward GEMMs, with different batch partitions: measured 5.8e-5)
+    assert rel <= 1.5e-4 and worst[0] <= 1e-3, f"one pass over 2^18 samples vs the mean of 32 chunk gradients: rel L2 {rel:.2e}, {worst[1]} {worst[0]:.2e}"
+    assert abs(loss_full - loss_acc) <= 1e-5 * abs(loss_acc)
+    # (ii)
+    for c, gc in chunk_grads.items():
+        ref, _ = _kl_gradient_f64(gen_cpu, mean, [v[c * step:(c + 1) * step].cpu().double() for v in z], 1)
+        assert set(ref) == set(gc)
+        rel, worst = _grad_errors(gc, ref)                           # both are gradients of the mean over the chunk
+        # (8192 samples average the product noise less than 2^18 do: measured 1.6e-4 / 2.2e-4; the full batch: 1.3e-4)
+        assert rel <= 4e-4, f"chunk {c}: flat KL gradient vs the f64 reference: relative L2 error {rel:.2e}"
+        assert worst[0] <= 1e-3, f"chunk {c}: parameter tensor {worst[1]}: max error {worst[0]:.2e} of its norm"
+    if os.environ.get("BGK_FULL_KL_GRADIENT") == "1":
+        ref, loss_ref = _kl_gradient_f64(gen_cpu, mean, [v.cpu().double() for v in z], n_chunks)
+        rel, worst = _grad_errors(full, ref)
+        assert rel <= 2e-4 and worst[0] <= 1e-3, f"flat KL gradient at B = 2^18 vs f64 over all samples: rel L2 {rel:.2e}, {worst[1]} {worst[0]:.2e}"
+        const = 0.5 * 66 * np.log(2 * np.pi)
+        assert abs(loss_full - loss_ref) <= 1e-4 * abs(loss_ref) or abs(loss_full - loss_ref - const) <= 1e-4 * abs(loss_ref)
 
 
 @pytest.mark.parametrize("B", [1, 31, 33, 4133])
