@@ -901,7 +901,7 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
         return None
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
     if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device \
-            or plan.get("padded") or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
+            or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
         return None                                        # second-generation kernel, the others on the first-generation one
     _lib.require_hip(x, y)
     if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:
@@ -910,6 +910,15 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
     inner = net.net if type(net) is WrapPeriodic else net
     (l0, l1, l2), _ = _fusable_dense(inner)
     tcfg = (transformer._left, transformer._right, transformer._bottom, transformer._top, transformer._default_settings)
-    return _FusedSplineTrainFn.apply(x, y, l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias, plan, tcfg,
-                                     nc_dev, inverse, oob_counter)
+    W0, b0, W1, b1, W2, b2 = l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias
+    if plan.get("padded"):
+        # hidden layers narrower than the kernels' 128 units: the operands packed for the forward are the zero-padded layers
+        # (_pad_hidden); the backward kernels get the same padded matrices as differentiable views of the parameters
+        # (F.pad: autograd slices the gradients back; padded units hold act(0) = 0 and feed zero columns, so their gradients are 0)
+        pad = torch.nn.functional.pad
+        h0, h1 = 128 - W0.shape[0], 128 - W1.shape[0]
+        W0, b0 = pad(W0, (0, 0, 0, h0)), pad(b0, (0, h0))
+        W1, b1 = pad(W1, (0, h0, 0, h1)), pad(b1, (0, h1))
+        W2 = pad(W2, (0, h1))
+    return _FusedSplineTrainFn.apply(x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob_counter)
 

@@ -310,3 +310,43 @@ def test_standalone_whiten_flow_on_the_kernel(hip_lib, dev, dim, keep, B):
         assert torch.allclose(dlb, -dl)
         if keep == dim:
             assert float((xb - x.detach()).abs().max()) <= 1e-3 * max(1.0, float(x.detach().abs().max()))
+
+
+@pytest.mark.parametrize("hidden", [(64, 64), (100, 100), (32, 96)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fused_training_with_narrow_hidden_layers(hip_lib, dev, hidden, inverse):
+    """conditioners with hidden layers narrower than 128 train on the fused kernels too (zero-padded operands, gradients sliced back by
+    autograd): same outputs and parameter / input gradients as the layer-by-layer path (library GEMMs + the stand-alone spline kernels)"""
+    from bgflow_amd import configs, dense
+    from bgflow_amd.utils import hash_init_
+    dims = {"BONDS": 17, "ANGLES": 17, "TORSIONS": 17, "FIXED": 9}
+    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+    B = 3000
+    g = torch.Generator(device=dev).manual_seed(11)
+    for what, on in (("TORSIONS", "FIXED"), ("FIXED", "TORSIONS"), ("BONDS", "ANGLES")):
+        layer = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, hidden=hidden)).to(dev)
+        res = {}
+        for fused in (True, False):
+            calls = []
+            orig = dense._FusedSplineTrainFn.apply
+            dense._FusedSplineTrainFn.apply = staticmethod(lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+            try:
+                layer.transformer.allow_fused = fused
+                layer.zero_grad()
+                xs = [torch.rand(B, d, device=dev, generator=torch.Generator(device=dev).manual_seed(5 + i)).requires_grad_(True)
+                      for i, d in enumerate((17, 17, 17, 9))]
+                *out, dl = layer(*xs, inverse=inverse)
+                (sum((o * o).sum() for o in out) + dl.sum()).backward()
+            finally:
+                dense._FusedSplineTrainFn.apply = orig
+                layer.transformer.allow_fused = True
+            assert bool(calls) == fused, "the fused training forward must (not) have run"
+            res[fused] = ([o.detach() for o in out], dl.detach(), [p.grad.clone() for p in layer.parameters()], [x.grad.clone() for x in xs if x.grad is not None])
+        (o1, d1, gp1, gx1), (o0, d0, gp0, gx0) = res[True], res[False]
+        for a, b in zip(o1, o0):
+            assert float((a - b).abs().max()) <= 2e-6
+        assert float((d1 - d0).abs().max()) <= 2e-5 * max(1.0, float(d0.abs().max()))
+        for a, b in zip(gp1 + gx1, gp0 + gx0):
+            assert a.shape == b.shape
+            assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-6), f"{what}|{on}: gradient of shape {tuple(a.shape)}"
