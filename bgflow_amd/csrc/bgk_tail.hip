@@ -132,7 +132,17 @@ __device__ __forceinline__ float icdf_chan(float v, const Desc& dsc, const CdfCl
 
 /* cos(2 pi x), sin(2 pi x): exact quadrant reduction + Cephes polynomials (bgk_detmath.h::bgk_sincos2pif), selects instead of
  * the quadrant branches */
+#ifndef BGK_TAIL_HWSIN
+#define BGK_TAIL_HWSIN 1       /* 1: the hardware sin / cos (argument in revolutions; max abs error 1.24e-7 on [-2, 2], tools/ubench/hw_sincos.hip):
+                                * 3 instructions instead of 26, twice per placement.  0: the reproducible polynomial form */
+#endif
 __device__ __forceinline__ void sincos2pi(float x, float& so, float& co) {
+#if BGK_TAIL_HWSIN
+    const float fr = __builtin_amdgcn_fractf(x);
+    so = __builtin_amdgcn_sinf(fr);
+    co = __builtin_amdgcn_cosf(fr);
+    return;
+#endif
     const float magic = 12582912.0f;
     const float t = __builtin_fmaf(x, 4.0f, magic);
     const float kq = t - magic;
