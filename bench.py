@@ -47,6 +47,14 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense f32-input MFMA peak (gemm_mode "f32" only
 ALG_BYTES = {"cfg3": 26800.0, "cfg2": 4672.0, "cfg5": 24384.0}
 
 
+def default_batch(gpus, workload):
+    """(samples per GPU per step, is BASELINE cfg 4) when --batch is not given: 2^20 per GPU (the batch the headline metric is quoted on);
+    the cfg-3 flow on 8 GPUs is BASELINE cfg 4 -- 2^22 samples sharded data-parallel, 2^19 per rank"""
+    if gpus == 8 and workload == "cfg3":
+        return 1 << 19, True
+    return 1 << 20, False
+
+
 def self_launch(args_list, n):
     """Re-exec under torch.distributed.run with one rank per GPU and relay rank 0's JSON line."""
     with socket.socket() as s:
@@ -472,9 +480,9 @@ def main():
     ap.add_argument("--kl-steps", type=int, default=10, help="extra: time this many KL-loss training steps (0 = skip)")
     ap.add_argument("--kl-batch", type=int, default=1 << 18, help="samples per GPU per KL step")
     args = ap.parse_args()
-    cfg4 = args.batch is None and args.gpus == 8 and args.workload == "cfg3"
+    cfg4 = args.batch is None and default_batch(args.gpus, args.workload)[1]
     if args.batch is None:
-        args.batch = (1 << 19) if cfg4 else (1 << 20)
+        args.batch = default_batch(args.gpus, args.workload)[0]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))

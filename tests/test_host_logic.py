@@ -783,3 +783,16 @@ def test_kl_trainer_runs_a_generators_own_kldiv():
     assert _kernel_plan(bg.NormalDistribution(5), 1.0) is not None
     assert _kernel_plan(Shifted(5), 1.0) is None
     assert _kernel_plan(bg.ProductDistribution([bg.NormalDistribution(5), Shifted(5)]), 1.0) is None
+
+
+def test_bench_default_batches_name_the_baseline_configs():
+    """bench.py without --batch: 2^20 samples per GPU, except the cfg-3 flow on 8 GPUs = BASELINE cfg 4 (2^22 over the node, 2^19 per rank)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.default_batch(1, "cfg3") == (1 << 20, False)
+    assert bench.default_batch(2, "cfg3") == (1 << 20, False) and bench.default_batch(4, "cfg3") == (1 << 20, False)
+    assert bench.default_batch(8, "cfg3") == (1 << 19, True)
+    assert bench.default_batch(8, "cfg2") == (1 << 20, False)
