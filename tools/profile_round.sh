@@ -41,7 +41,7 @@ bash tools/pmc_kl.sh > $OUT/kl_pmc.txt 2>&1
 bash tools/pmc_ic.sh > $OUT/ic_tail_pmc.txt 2>&1
 # 4. un-profiled bench line (full default command incl. cpu_baseline + KL extra) and the multi-rank self-test of bench.py
 python bench.py > $OUT/bench_plain.json 2>$OUT/bench_plain.err
-BGK_BENCH_TEST_SHARED_GPU=1 python bench.py --gpus 2 --steps 3 --warmup 1 --batch 262144 --kl-steps 2 --kl-batch 65536 > $OUT/bench_2rank_selftest.json 2>$OUT/bench_2rank_selftest.err
+BGK_BENCH_TEST_SHARED_GPU=1 python bench.py --gpus 2 --steps 3 --warmup 1 --batch 262144 --kl-steps 2 --kl-batch 65536 2>$OUT/bench_2rank_selftest.err | grep "\"metric\"" > $OUT/bench_2rank_selftest.json
 # 5. roofline.traffic measured inside the bench run (bench.py --pmc: its own rocprofv3 --pmc passes), cfg 5's two coupling kernels side by side
 python bench.py --pmc --no-cpu-baseline --no-extras --kl-steps 0 > $OUT/bench_pmc_line.json 2>$OUT/bench_pmc_line.err
 bash tools/pmc_cfg5.sh > $OUT/cfg5_pmc.txt 2>&1
