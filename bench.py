@@ -507,8 +507,12 @@ def main():
                     uuid=str(getattr(props, "uuid", "")), pci_bus_id=getattr(props, "pci_bus_id", None), host=socket.gethostname())
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, mine)
+        # distinct devices = distinct (host, device index) pairs -- what LOCAL_RANK selects.  The UUIDs / PCI bus ids are recorded too, but
+        # only reported: a runtime that hands out the same (or an empty) UUID for every device must not stop a correct run.
         rccl = dict(backend=torch.distributed.get_backend(), world_size=torch.distributed.get_world_size(), devices=gathered,
-                    distinct_devices=len({(g["host"], g["uuid"] or g["index"]) for g in gathered}))
+                    distinct_devices=len({(g["host"], g["index"]) for g in gathered}),
+                    distinct_uuids=len({(g["host"], g["uuid"]) for g in gathered if g["uuid"]}),
+                    distinct_pci_bus_ids=len({(g["host"], g["pci_bus_id"]) for g in gathered if g["pci_bus_id"] is not None}))
         if rccl["distinct_devices"] < world and not shared_gpu_test:
             raise SystemExit(f"bench.py: {world} ranks on {rccl['distinct_devices']} distinct GPUs ({gathered}): a multi-GPU number needs one device "
                              "per rank (LOCAL_RANK / visible devices are wrong)")
