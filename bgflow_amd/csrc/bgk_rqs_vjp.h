@@ -1,0 +1,178 @@
+/* bgk_rqs_vjp.h -- VJP of ONE rational-quadratic spline element (sample, dim) w.r.t. its input and its 3K (+1) unnormalised
+ * parameters, for first-order losses (device only).  Same math as oracle/bgo_impl.h::bgo_rqs_backward (autograd of
+ * nn/flow/transformer/spline.py:109-188 + nflows' rational_quadratic_spline).  Shared by bgk_rqs_bwd.hip (one launch per
+ * transformer) and bgk_dense_bwd.hip (fused with the conditioner's input-gradient chain): identical results by construction. */
+#ifndef BGK_RQS_VJP_H
+#define BGK_RQS_VJP_H
+
+#include "bgk_common.h"
+
+/* softmax probabilities p[k] and the K+1 knots of one parameter set */
+template <int KT>
+__device__ __forceinline__ void bgk_softmax_knots(const float (&u)[KT], float mn, float sc, float span, float low, float high,
+                                                  float (&p)[KT], float (&kn)[KT + 1]) {
+    float m = u[0];
+#pragma unroll
+    for (int k = 1; k < KT; ++k) m = u[k] > m ? u[k] : m;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { p[k] = bgk_expf(u[k] - m); s += p[k]; }
+    float c = 0.0f;
+    kn[0] = low;
+    const float rs = bgk_rcp_refined(s);      /* the forward's form of p / s (bgk_common.h): the correctly rounded quotient */
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        p[k] = bgk_div_r(p[k], s, rs);
+        c += mn + sc * p[k];
+        kn[k + 1] = span * c + low;
+    }
+    kn[KT] = high;
+}
+
+/* Behind the knots (which decide the bin and are bit-identical to the forward's) nothing here is compared bit for bit with
+ * anything: hardware reciprocal / exp2 / log2 / sqrt (1 ulp) instead of the correctly rounded sequences -- a third of the
+ * element's instructions. */
+__device__ __forceinline__ float bgk_vjp_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float bgk_vjp_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float bgk_vjp_softplus(float x, float beta, float rbeta) {
+    const float z = x * beta;
+    const float sp = __builtin_amdgcn_logf(1.0f + bgk_vjp_exp(z < 20.0f ? z : 20.0f)) * (0.693147180559945309f * rbeta);
+    return z > 20.0f ? x : sp;
+}
+__device__ __forceinline__ float bgk_vjp_sigmoid(float z) {
+    const float sg = bgk_vjp_rcp(1.0f + bgk_vjp_exp(z > -80.0f ? -z : 80.0f));
+    return z > 20.0f ? 1.0f : sg;
+}
+
+template <int KT>
+__device__ __forceinline__ float bgk_pick(const float (&a)[KT], int i) {
+    /* the empty asm keeps every candidate an opaque register value: the compiler otherwise turns the select chain into an
+     * indexed load from a scratch copy of the array (+ an s_waitcnt vmcnt(0) that drains every load in flight) */
+    float v = a[0];
+#pragma unroll
+    for (int k = 1; k < KT; ++k) {
+        float t = a[k];
+        asm("" : "+v"(t));
+        v = (i == k) ? t : v;
+    }
+    return v;
+}
+
+/* rw / rh / rs: the element's unnormalised widths, heights, slopes (knots 0..K-1); s_K: the slope at knot K (its own slot for a
+ * non-circular dim -- has_slot -- else rs[0]); x: the spline's input (pre-clamp); gy, gl: output and log-det cotangents.
+ * Out: ow / oh / os parameter gradients, g_slot (gradient of the slot; 0 without one), gx (input gradient, 0 outside the domain). */
+template <int K>
+__device__ __forceinline__ void bgk_rqs_vjp_element(const BgkRqsCfg& c, int inverse, const float (&rw)[K], const float (&rh)[K],
+                                                    const float (&rs)[K], float s_K, bool has_slot, float x, float gy, float gl,
+                                                    float (&ow)[K], float (&oh)[K], float (&os)[K], float& g_slot, float& gx_out) {
+    float pw[K], ph[K], cw[K + 1], ch[K + 1];
+    bgk_softmax_knots<K>(rw, c.min_w, c.w_scale, c.xspan, c.left, c.right, pw, cw);
+    bgk_softmax_knots<K>(rh, c.min_h, c.h_scale, c.yspan, c.bottom, c.top, ph, ch);
+    const bool clamped = (x < c.left) | (x > c.right);
+    x = x < c.left ? c.left : (x > c.right ? c.right : x);
+    int idx = -1;
+#pragma unroll
+    for (int k = 0; k <= K; ++k) {
+        float kn = inverse ? cw[k] : ch[k];
+        if (k == K) kn = kn + 1e-6f;
+        idx += (x >= kn) ? 1 : 0;
+    }
+    idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
+    const bool hi_last = (idx + 1 == K);
+    float cw_i = cw[0], cw_n = cw[1], ch_i = ch[0], ch_n = ch[1];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        cw_i = (idx == k) ? cw[k] : cw_i; cw_n = (idx == k) ? cw[k + 1] : cw_n;
+        ch_i = (idx == k) ? ch[k] : ch_i; ch_n = (idx == k) ? ch[k + 1] : ch_n;
+    }
+    const float s_lo = bgk_pick<K>(rs, idx);
+    float s_hi = s_K;
+#pragma unroll
+    for (int k = 1; k < K; ++k) s_hi = (idx + 1 == k) ? rs[k] : s_hi;
+    const float rbeta = bgk_vjp_rcp(c.beta);
+    const float d0 = c.min_d + bgk_vjp_softplus(s_lo, c.beta, rbeta), d1 = c.min_d + bgk_vjp_softplus(s_hi, c.beta, rbeta);
+    const float W_i = cw_n - cw_i, H_i = ch_n - ch_i;
+    const float iW = bgk_vjp_rcp(W_i);
+    const float delta = H_i * iW, S = d0 + d1 - 2.0f * delta;
+    float theta;
+    if (!inverse) {
+        float dx = x - ch_i;
+        float qa = dx * S + H_i * (delta - d0), qb = H_i * d0 - dx * S, qc = -delta * dx;
+        theta = (2.0f * qc) * bgk_vjp_rcp(-qb - __builtin_amdgcn_sqrtf(qb * qb - 4.0f * qa * qc));
+    } else {
+        theta = (x - cw_i) * iW;
+    }
+    const float t = theta * (1.0f - theta), tp = 1.0f - 2.0f * theta, omt = 1.0f - theta;
+    const float N = delta * theta * theta + d0 * t, den = delta + S * t;
+    const float iden = bgk_vjp_rcp(den), iden2 = iden * iden;
+    const float Q = N * iden;
+    const float N_th = 2.0f * delta * theta + d0 * tp, den_th = S * tp;
+    const float Q_th = (N_th * den - N * den_th) * iden2;
+    const float Q_de = (theta * theta * den - N * (1.0f - 2.0f * t)) * iden2;
+    const float Q_d0 = (t * den - N * t) * iden2;
+    const float Q_d1 = (-N * t) * iden2;
+    const float M = d1 * theta * theta + 2.0f * delta * t + d0 * omt * omt;
+    const float iM = bgk_vjp_rcp(M);
+    const float lf_th = (2.0f * d1 * theta + 2.0f * delta * tp - 2.0f * d0 * omt) * iM - 2.0f * den_th * iden;
+    const float lf_de = 2.0f * bgk_vjp_rcp(delta) + 2.0f * t * iM - 2.0f * (1.0f - 2.0f * t) * iden;
+    const float lf_d0 = omt * omt * iM - 2.0f * t * iden;
+    const float lf_d1 = theta * theta * iM - 2.0f * t * iden;
+    float G_de, G_d0, G_d1, G_H, G_W, G_cw, G_ch, gx;
+    if (inverse) {
+        const float G_th = gy * H_i * Q_th + gl * lf_th;
+        G_de = gy * H_i * Q_de + gl * lf_de;
+        G_d0 = gy * H_i * Q_d0 + gl * lf_d0;
+        G_d1 = gy * H_i * Q_d1 + gl * lf_d1;
+        G_H = gy * Q + G_de * iW;
+        G_W = -G_de * delta * iW - G_th * theta * iW;
+        G_ch = gy;
+        G_cw = -G_th * iW;
+        gx = G_th * iW;
+    } else {
+        const float A_th = gy * W_i - gl * lf_th;
+        const float iQth = bgk_vjp_rcp(Q_th);
+        const float inv = bgk_vjp_rcp(H_i) * iQth;
+        G_de = -gl * lf_de - A_th * Q_de * iQth;
+        G_d0 = -gl * lf_d0 - A_th * Q_d0 * iQth;
+        G_d1 = -gl * lf_d1 - A_th * Q_d1 * iQth;
+        G_H = G_de * iW - A_th * Q * inv;
+        G_W = -G_de * delta * iW + gy * theta;
+        G_cw = gy;
+        G_ch = -A_th * inv;
+        gx = A_th * inv;
+    }
+    const bool dead = (gy == 0.0f) & (gl == 0.0f);   /* masked-out sample: exact zeros, never 0 * inf */
+    if (dead) { G_de = G_d0 = G_d1 = G_H = G_W = G_cw = G_ch = gx = 0.0f; }
+    gx_out = clamped ? 0.0f : gx;
+    {
+        const float gA = (idx >= 1) ? (G_cw - G_W) : 0.0f, gB = (idx + 1 <= K - 1) ? G_W : 0.0f;
+        float gp[K], dot = 0.0f;
+#pragma unroll
+        for (int m = 0; m < K; ++m) { gp[m] = c.w_scale * c.xspan * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f)); dot += pw[m] * gp[m]; }
+#pragma unroll
+        for (int m = 0; m < K; ++m) ow[m] = pw[m] * (gp[m] - dot);
+    }
+    {
+        const float gA = (idx >= 1) ? (G_ch - G_H) : 0.0f, gB = (idx + 1 <= K - 1) ? G_H : 0.0f;
+        float gp[K], dot = 0.0f;
+#pragma unroll
+        for (int m = 0; m < K; ++m) { gp[m] = c.h_scale * c.yspan * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f)); dot += ph[m] * gp[m]; }
+#pragma unroll
+        for (int m = 0; m < K; ++m) oh[m] = ph[m] * (gp[m] - dot);
+    }
+    {
+        const float sg0 = bgk_vjp_sigmoid(s_lo * c.beta), sg1 = bgk_vjp_sigmoid(s_hi * c.beta);
+        const float g0 = G_d0 * sg0, g1 = G_d1 * sg1;
+        g_slot = (has_slot && hi_last) ? g1 : 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float g = 0.0f;
+            g += (k == idx) ? g0 : 0.0f;
+            g += (!hi_last && k == idx + 1) ? g1 : 0.0f;
+            g += (hi_last && !has_slot && k == 0) ? g1 : 0.0f;
+            os[k] = g;
+        }
+    }
+}
+
+#endif /* BGK_RQS_VJP_H */

@@ -8,6 +8,8 @@ transformer's conditioner is a ``DenseNet`` with two hidden layers (optionally i
 ``bgk_coupling_rqs_dense``: MLP on the f32 matrix cores + spline epilogue in one launch.
 state_dict keys match the reference (``_layers.{i}.weight/bias``, ``net._layers...``).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -747,6 +749,55 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
     return out[0], out[1], (out[2] if want_h else None), (out[3] if want_h else None), g_x
 
 
+# n_bins = 8: the spline's VJP inside the launch of the conditioner's input-gradient chain (bgk_spline_backward_dx).  OFF by default:
+# measured on MI355X at 2^18 samples it is SLOWER than bgk_rqs_backward + bgk_dense_backward_dx (0.63 vs 0.33 + 0.18 ms per layer,
+# DESIGN.md section 3): the chain kernel runs two waves per SIMD and every memory round trip of the element pipeline is exposed,
+# the stand-alone VJP kernel runs five and sits at the HBM rate.  BGK_SPLINE_BACKWARD_FUSED=1 selects it (parity-tested either way).
+FUSED_SPLINE_BACKWARD = os.environ.get("BGK_SPLINE_BACKWARD_FUSED", "0") == "1"
+
+
+def _spline_backward_dx(y, params, nc_dev, rcfg, g_out, g_dlogp, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs):
+    """bgk_pack_spline_t + bgk_spline_backward_dx: returns (g_y, g_params, g_z1, g_z0, g_x or None); the activations are never
+    written (the weight-gradient kernel recomputes them from z1 / z0)"""
+    n_bins, inverse, left, right, bottom, top, settings = rcfg
+    dev = y.device
+    d = y.shape[-1]
+    P = params.shape[-1]
+    n_in = W0.shape[1]
+    FT, S2 = (n_in + 31) // 32, 3 * ((d + 1) // 2) + (P - 24 * d + 15) // 16
+    key = ("spline", P, d, n_in, str(dev))
+    if bufs.get("skey") != key:
+        bufs.update(skey=key, sT0=torch.empty((8 * FT * 2 + FT, 64, 8), dtype=torch.float16, device=dev),
+                    sT1=torch.empty((8 * 8 + 4, 64, 8), dtype=torch.float16, device=dev),
+                    sT2=torch.empty((S2 * 8 + 4, 64, 8), dtype=torch.float16, device=dev))
+    T0, T1, T2 = bufs["sT0"], bufs["sT1"], bufs["sT2"]
+    y2, ldy = _lib.rowmajor(y)
+    p2, ldp = _lib.rowmajor(params)
+    x2, ldc = _lib.rowmajor(x.detach())
+    B, d_c = y2.shape[0], x2.shape[1]
+    g_out2 = g_out.contiguous()
+    g_dl = g_dlogp.reshape(-1).contiguous()
+    g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
+    ldgp = (P + 3) // 4 * 4
+    g_p = torch.empty((B, ldgp), dtype=torch.float32, device=dev)[:, :P]
+    out = torch.empty((2, B, 128), dtype=torch.float32, device=dev)
+    g_x = torch.empty((B, d_c), dtype=torch.float32, device=dev) if want_gx else None
+    ws = [w.detach().contiguous() for w in (W0, W1, W2)]
+    with torch.cuda.device(dev):
+        st = _lib.lib().bgk_pack_spline_t(_lib.ptr(ws[0]), n_in, _lib.ptr(ws[1]), _lib.ptr(ws[2]), P, d, _lib.ptr(cs),
+                                          _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_pack_spline_t")
+        st = _lib.lib().bgk_spline_backward_dx(
+            _lib.ptr(y2), ldy, _lib.ptr(p2), ldp, P, _lib.ptr(nc_dev), B, d, n_bins, int(inverse),
+            left, right, bottom, top, settings["min_bin_width"], settings["min_bin_height"], settings["min_derivative"],
+            int(settings.get("enable_identity_init", False)),
+            _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), ldgp,
+            _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic), _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.ptr(cs),
+            act_code, _lib.ptr(out[0]), _lib.ptr(out[1]), None, None, _lib.ptr(g_x), d_c, _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_spline_backward_dx")
+    return g_y, g_p, out[0], out[1], g_x
+
+
 FUSED_WEIGHT_GRAD = True     # weight / bias gradients on bgk_dense_weight_grad (False: split-K bmm + bgk_column_sum)
 
 _DIRECT_GRADS = [False]
@@ -852,12 +903,21 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         x, y, W0, W1, W2, z0, z1, params, nc_dev = ctx.saved_tensors
         act_code, periodic, rcfg = ctx.meta
         act, act_bwd = _act_fwd_bwd(act_code)
-        g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp)
         need = ctx.needs_input_grad
         cs = ctx.cs
-        fused_wg = FUSED_WEIGHT_GRAD and g_p.is_cuda and W0.shape[1] <= 128
+        fused_wg = FUSED_WEIGHT_GRAD and y.is_cuda and W0.shape[1] <= 128
         recompute_h = False
-        if cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= 96:
+        fused_dx = cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= 96
+        fused_vjp = fused_dx and fused_wg and FUSED_SPLINE_BACKWARD and rcfg[0] == 8 and y.shape[-1] <= 64
+        if not fused_vjp:
+            g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp)
+        if fused_vjp:
+            # one launch: the spline's VJP feeds the first GEMM of the chain from registers (g_params written, not read back)
+            recompute_h = True
+            g_y, g_p, g_z1, g_z0, g_x = _spline_backward_dx(y, params, nc_dev, rcfg, g_out, g_dlogp, z1, z0, x, W0, W1, W2, cs,
+                                                            act_code, periodic, need[0], ctx.tbufs)
+            h1 = h0 = None
+        elif fused_dx:
             # with the fused weight-gradient kernel downstream the activations h1 / h0 are not materialised: it re-applies the
             # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)
             recompute_h = fused_wg
