@@ -18,19 +18,40 @@ namespace {
 
 constexpr int DW = 4;
 constexpr int DSROW = 33;
+#ifndef BGK_DBWD_DG
+#define BGK_DBWD_DG 4
+#endif
+constexpr int DBWD_DG = BGK_DBWD_DG;      /* k-steps per gradient batch of the first GEMM */
+constexpr int DBWD_PAD = 4;               /* T2 holds a multiple of 4 k-steps (zero blocks behind ceil(P / 16)): part of the ABI */
+static_assert(DBWD_PAD % DBWD_DG == 0, "the first GEMM runs whole groups");
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned bgk_u4 __attribute__((ext_vector_type(4)));
+typedef float bgk_f4v __attribute__((ext_vector_type(4)));
 
 struct DenseBwdArgs {
     const float* g; int64_t ldg; int P;           /* gradient w.r.t. the MLP output [B, P] */
     const float* z1; const float* z0;             /* saved pre-activations [B, 128] */
     const float* cond; int64_t ldc; int d_c; int periodic;
-    const uint4 *T2, *T1, *T0; int S2;            /* transposed-weight operands; S2 = ceil(P / 16) */
+    const uint4 *T2, *T1, *T0; int S2;            /* transposed-weight operands; S2 = ceil(P / 16) rounded up to a multiple of 4 */
     const float* cs;                              /* {2^s, 2^-s} x 3 (layer 0, 1, 2) */
     int act; int64_t B;
     float* g_z1; float* g_z0; float* h1; float* h0;
     float* g_cond; int64_t ldgc;
     int lds_per_wave;
 };
+
+/* -DBGK_SBD_TS=1 (tools/r04_spline_bwd_ts.py): s_memtime stamps of the wave's phases, written over row b0 of g_z0 at the end */
+#ifndef BGK_SBD_TS
+#define BGK_SBD_TS 0
+#endif
+#ifndef BGK_DBWD_DRAIN
+#define BGK_DBWD_DRAIN 0      /* experiment: 1 drain the queue behind the z requests, 2 behind the g_z stores, 3 both */
+#endif
+#if BGK_SBD_TS
+#define SBD_TS(k) do { __builtin_amdgcn_sched_barrier(0); if (lane == 0) reinterpret_cast<unsigned*>(s_f)[(k) * H2_SLAB + 130] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SBD_TS(k) do { } while (0)
+#endif
 
 /* d = g * act'(z), h = act(z) for a pair (hardware exp / rcp) */
 __device__ __forceinline__ void act_grad2(int act, bgk_f2 z, bgk_f2 g, bgk_f2& gz, bgk_f2& h) {
@@ -51,26 +72,58 @@ __device__ __forceinline__ void act_grad2(int act, bgk_f2 z, bgk_f2 g, bgk_f2& g
 }
 
 /* acc (accumulator layout, 4 tiles) -> g_z = acc * c * act'(z), h = act(z); z is read as 16-byte groups, g_z / h leave as
- * full rows through the LDS slab */
+ * full rows through the LDS slab.  All sixteen z requests go out BEFORE the arithmetic (64 registers): left to the compiler
+ * they were issued a few at a time between the activation code, one exposed memory round trip after the other -- 50 k of the
+ * 170 k cycles a wave lived (s_memtime stamps, tools/r04_spline_bwd_ts.py), 19 k with the requests up front. */
 __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, int act, const float* z, float* gz_out, float* h_out,
-                                                   float* s_buf, int64_t b0, int lane, int rows) {
+                                                   float* s_buf, int64_t b0, int lane, int rows, int tsb = 22) {
+    float* const s_f = s_buf;
+    (void)s_f; (void)tsb;
     const int j = lane & 31, hh = lane >> 5;
     const int64_t row = (b0 + (j < rows ? j : 0)) * 128;
-    h2_f32x16 hv[4];
+    float4 zall[16];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zall[4 * m + q] = *reinterpret_cast<const float4*>(z + row + 32 * m + 8 * q + 4 * hh);
+    __builtin_amdgcn_sched_barrier(0);
+#if BGK_SBD_TS || BGK_DBWD_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SBD_TS(tsb);
+#endif
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int f0 = 32 * m + 8 * q + 4 * hh;
-            const float4 zz = *reinterpret_cast<const float4*>(z + row + f0);
+            const float4 zz = zall[4 * m + q];
             bgk_f2 g0, g1, a0, a1;
             act_grad2(act, (bgk_f2){zz.x, zz.y}, (bgk_f2){t[m][4 * q] * c, t[m][4 * q + 1] * c}, g0, a0);
             act_grad2(act, (bgk_f2){zz.z, zz.w}, (bgk_f2){t[m][4 * q + 2] * c, t[m][4 * q + 3] * c}, g1, a1);
             t[m][4 * q] = g0.x; t[m][4 * q + 1] = g0.y; t[m][4 * q + 2] = g1.x; t[m][4 * q + 3] = g1.y;
-            hv[m][4 * q] = a0.x; hv[m][4 * q + 1] = a0.y; hv[m][4 * q + 2] = a1.x; hv[m][4 * q + 3] = a1.y;
         }
-    if (h_out) h2_store_rows128(hv, h_out, s_buf, b0, rows, lane);     /* NULL: the weight-gradient kernel recomputes act(z) itself */
+#if BGK_SBD_TS
+    asm volatile("" :: "v"(t[0][0]), "v"(t[3][15]), "v"(t[1][7]), "v"(t[2][9]));
+    SBD_TS(tsb + 1);
+#endif
+    if (h_out) {      /* the activations themselves (NULL: the weight-gradient kernel recomputes act(z) while loading z) */
+        h2_f32x16 hv[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hv[m][4 * q] = zall[4 * m + q].x; hv[m][4 * q + 1] = zall[4 * m + q].y;
+                hv[m][4 * q + 2] = zall[4 * m + q].z; hv[m][4 * q + 3] = zall[4 * m + q].w;
+            }
+            h2_act_tile(hv[m], 1.0f, act);
+        }
+        h2_store_rows128(hv, h_out, s_buf, b0, rows, lane);
+    }
     h2_store_rows128(t, gz_out, s_buf, b0, rows, lane);
+#if BGK_SBD_TS || (BGK_DBWD_DRAIN & 2)
+    SBD_TS(tsb + 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SBD_TS(tsb + 3);
+#endif
 }
 
 /* everything behind the first GEMM: acc = W2^T g (unscaled) -> g_z1, g_z0 (+ h1, h0), g_cond */
@@ -79,6 +132,7 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
     const int j = lane & 31, hh = lane >> 5;
     const float c2 = a.cs[5], c1 = a.cs[3], c0 = a.cs[1];
     act_backward_tiles(acc, c2, a.act, a.z1, a.g_z1, a.h1, s_f, b0, lane, rows);
+    SBD_TS(19);
 
     /* ---- g_h0 = W1^T g_z1 ---- */
     H2B<4> bf;
@@ -88,7 +142,12 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     h2_gemm_hidden<4, 4>(acc, bf, a.T1, lane);
-    act_backward_tiles(acc, c1, a.act, a.z0, a.g_z0, a.h0, s_f, b0, lane, rows);
+#if BGK_SBD_TS
+    asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][15]));
+#endif
+    SBD_TS(20);
+    act_backward_tiles(acc, c1, a.act, a.z0, a.g_z0, a.h0, s_f, b0, lane, rows, 26);
+    SBD_TS(21);
 
     /* ---- g_feat = W0^T g_z0, then the featuriser's transpose ---- */
     if (a.g_cond == nullptr) return;
@@ -131,7 +190,7 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
 template <int FT>
 __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* uniform: buffer descriptor in SGPRs */
     const int j = lane & 31, hh = lane >> 5;
     float* s_f = smem + (size_t)wave * a.lds_per_wave;       /* [32][H2_SLAB] output slab; later the g_feat tile [32 FT][DSROW] */
     const int64_t n_tiles = (a.B + 31) / 32;
@@ -147,50 +206,52 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     {
-        /* the gradient rows are far apart in memory (one 32-byte piece of 32 different rows per load instruction) */
-        const float* grow = a.g + (b0 + (j < rows ? j : 0)) * a.ldg;
-        const bool live = j < rows;
+        /* The gradient rows are far apart in memory (one 32-byte piece of 32 different rows per load instruction).  Raw buffer loads
+         * on a descriptor of the tile: rows past the batch are out of range and read 0, so the loop below has no branch -- the
+         * compiler's wait insertion is exact only on straight-line code (at a join it assumes the path with the fewest operations in
+         * flight and drains the queue; the former per-lane tail path cost a vmcnt(0) per k-step).  Columns >= P (row padding, the
+         * k-steps that pad S2 to a multiple of the group) are masked to 0: the operand blocks there are 0 too, but 0 * NaN is not. */
+        const __amdgpu_buffer_rsrc_t rs_gt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + b0 * a.ldg), 0, (int)(rows * a.ldg * 4), 0x00020000);
+        const int gofs = j * (int)a.ldg * 4;
+        const int P = a.P;
         auto load_g = [&](int s, float (&v)[8]) {
             const int k0 = 16 * s + 8 * hh;
-            if (live && k0 + 8 <= a.P) {
-                const f4u u0 = *reinterpret_cast<const f4u*>(grow + k0), u1 = *reinterpret_cast<const f4u*>(grow + k0 + 4);
+            const bgk_f4v u0 = __builtin_bit_cast(bgk_f4v, __builtin_amdgcn_raw_buffer_load_b128(rs_gt, gofs + k0 * 4, 0, 0));
+            const bgk_f4v u1 = __builtin_bit_cast(bgk_f4v, __builtin_amdgcn_raw_buffer_load_b128(rs_gt, gofs + k0 * 4 + 16, 0, 0));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (live && k0 + e < a.P) ? grow[k0 + e] : 0.0f;
-            }
+            for (int e = 0; e < 4; ++e) { v[e] = k0 + e < P ? u0[e] : 0.0f; v[4 + e] = k0 + 4 + e < P ? u1[e] : 0.0f; }
         };
         /* Loads return in order on this part: an operand load (L2 hit) queued behind a gradient load (HBM) waits for it, so a
          * gradient ring refilled one k-step at a time stalls EVERY step for most of an HBM round trip, whatever its depth.  Here the
          * operand fragments of step s + 1 are requested before the MFMAs of step s (two fragment sets), and the gradient values of
          * the next DG k-steps as one batch right behind the group's last operand request: the operand loads never queue behind a
-         * fresh gradient request, and a group waits for its gradients once. */
-#ifndef BGK_DBWD_DG
-#define BGK_DBWD_DG 4
-#endif
-        constexpr int DG = BGK_DBWD_DG;
+         * fresh gradient request, and a group waits for its gradients once.  a.S2 is a multiple of DG (zero operand blocks). */
+        constexpr int DG = DBWD_DG;
         static_assert(DG % 2 == 0, "fragment set parity follows the position in the group");
+        const int S2 = a.S2;
+        H2A<4> fr[2];
+        h2a_load<4>(fr[0], a.T2, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
         float ring[DG][8];
 #pragma unroll
         for (int u = 0; u < DG; ++u) load_g(u, ring[u]);
-        H2A<4> fr[2];
-        h2a_load<4>(fr[0], a.T2, 0, lane);
-        for (int s0 = 0; s0 < a.S2; s0 += DG) {
+        __builtin_amdgcn_sched_barrier(0);
+        for (int s0 = 0; s0 < S2; s0 += DG) {
             h2_h16x8 bhi[DG], blo[DG];
 #pragma unroll
             for (int u = 0; u < DG; ++u) h2_split8(ring[u], bhi[u], blo[u]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < DG; ++u) {
                 const int s = s0 + u;
-                if (s < a.S2) {
-                    if (s + 1 < a.S2) h2a_load<4>(fr[(u + 1) & 1], a.T2, s + 1, lane);
-                    if (u == DG - 1 || s + 1 == a.S2) {
+                h2a_load<4>(fr[(u + 1) & 1], a.T2, s + 1 < S2 ? s + 1 : S2 - 1, lane);
+                if (u == DG - 1) {
 #pragma unroll
-                        for (int v = 0; v < DG; ++v) load_g(s0 + DG + v, ring[v]);
-                    }
-                    h2_mfma3<4>(acc, fr[u & 1], bhi[u], blo[u]);
+                    for (int v = 0; v < DG; ++v) load_g(s0 + DG + v, ring[v]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                h2_mfma3<4>(acc, fr[u & 1], bhi[u], blo[u]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -225,19 +286,6 @@ struct SplElem { float rw[8], rh[8], rs[8]; float sK, x, gy; int slot; };
  * of requests a loop iteration ends with (the element of slot 0, the first operand fragments, eight dropped stores).  Per slot:
  * request element t + 1 | VJP of element t (its loads are one slot old) | operand fragments of k-steps 3 t + 1, 3 t + 2 and
  * of the next slot's first k-step around the 36 MFMAs | the element's gradients out. */
-typedef unsigned bgk_u4 __attribute__((ext_vector_type(4)));
-typedef float bgk_f4v __attribute__((ext_vector_type(4)));
-
-/* -DBGK_SBD_TS=1 (tools/r04_spline_bwd_ts.py): s_memtime stamps of the wave's phases, written over row b0 of g_z0 at the end */
-#ifndef BGK_SBD_TS
-#define BGK_SBD_TS 0
-#endif
-#if BGK_SBD_TS
-#define SBD_TS(k) do { __builtin_amdgcn_sched_barrier(0); if (lane == 0) reinterpret_cast<unsigned*>(s_f)[(k) * H2_SLAB + 130] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SBD_TS(k) do { } while (0)
-#endif
-
 template <int FT>
 __global__ __launch_bounds__(DW * 64, 2) void spline_bwd_dx_kernel(SplineBwdArgs sa) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -373,7 +421,7 @@ __global__ __launch_bounds__(DW * 64, 2) void spline_bwd_dx_kernel(SplineBwdArgs
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SBD_TS(15);
     if (lane == 0)
-        for (int k = 0; k < 24; ++k) reinterpret_cast<unsigned*>(a.g_z0)[b0 * 128 + k] = reinterpret_cast<unsigned*>(s_f)[k * H2_SLAB + 130];
+        for (int k = 0; k < 32; ++k) reinterpret_cast<unsigned*>(a.g_z0)[b0 * 128 + k] = reinterpret_cast<unsigned*>(s_f)[k * H2_SLAB + 130];
 #endif
 }
 
@@ -431,7 +479,7 @@ __global__ __launch_bounds__(256) void pack_t_kernel(PackTGroup g, const float* 
 static int pack_t_launch(const float* W0, int n_in, const float* W1, const float* W2, int P, const float* cs, void* T0, void* T1,
                          void* T2, int d, int n_nc, hipStream_t st) {
     const int FT = (n_in + 31) / 32;
-    const int S2 = d > 0 ? 3 * ((d + 1) / 2) + (n_nc + 15) / 16 : (P + 15) / 16;
+    const int S2 = d > 0 ? 3 * ((d + 1) / 2) + (n_nc + 15) / 16 : ((P + 15) / 16 + DBWD_PAD - 1) / DBWD_PAD * DBWD_PAD;
     const PackT L2{W2, P, 128, 4, S2, d > 0 ? 2 : 1, (_Float16*)T2, d, n_nc};   /* M[hidden i][k] = W2[col(k)][i], col = output column of the MLP */
     const PackT L1{W1, 128, 128, 4, 8, 0, (_Float16*)T1, 0, 0};      /* M[i][k] = W1[unit(k)][i] */
     const PackT L0{W0, 128, n_in, FT, 8, 0, (_Float16*)T0, 0, 0};    /* M[feature i][k] = W0[unit(k)][i] */
@@ -481,7 +529,7 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     if (B == 0) return 0;
     DenseBwdArgs a;
     a.g = g; a.ldg = ldg; a.P = P; a.z1 = z1; a.z0 = z0; a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
-    a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.S2 = (P + 15) / 16; a.cs = cs; a.act = act; a.B = B;
+    a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.S2 = ((P + 15) / 16 + DBWD_PAD - 1) / DBWD_PAD * DBWD_PAD; a.cs = cs; a.act = act; a.B = B;
     a.g_z1 = g_z1; a.g_z0 = g_z0; a.h1 = h1; a.h0 = h0; a.g_cond = g_cond; a.ldgc = ldgc;
     const int FT = (n_in + 31) / 32;
     a.lds_per_wave = 32 * H2_SLAB > 32 * FT * DSROW ? 32 * H2_SLAB : 32 * FT * DSROW;   /* output slab, reused for the g_feat tile */

@@ -723,7 +723,7 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
     dev = g_p.device
     B, P = g_p.shape
     n_in = W0.shape[1]
-    FT, S2 = (n_in + 31) // 32, (P + 15) // 16
+    FT, S2 = (n_in + 31) // 32, ((P + 15) // 16 + 3) // 4 * 4      # T2: whole groups of 4 k-steps (zero blocks behind ceil(P / 16))
     key = (P, n_in, str(dev))
     if bufs.get("key") != key:
         bufs.clear()

@@ -407,7 +407,8 @@ int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
  * pre-activations z1, z0 it writes g_z1, g_z0 (gradients w.r.t. the pre-activations), h1, h0 (the activations; both NULL: not
  * written -- bgk_dense_weight_grad can recompute them from z1 / z0) -- the operands of the weight / bias gradient GEMMs -- and g_cond [B, d_c] (NULL to skip; periodic != 0: through the cos / sin
  * featuriser of nn/periodic.py:30-37, needs cond).  T0..T2: transposed-weight operands from bgk_pack_dense_h2_t with the
- * scale table cs of bgk_pack_dense_h2 for the same weights. */
+ * scale table cs of bgk_pack_dense_h2 for the same weights; sizes in 1 KiB blocks: T0 17 ceil(n_in / 32), T1 68,
+ * T2 8 S2 + 4 with S2 = ceil(P / 16) rounded up to a multiple of 4 (zero blocks behind the last column). */
 int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
                         const float* cs, void* T0, void* T1, void* T2, void* stream);
 int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,

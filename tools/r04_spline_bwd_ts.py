@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bgflow_amd import configs, dense
+dense.FUSED_SPLINE_BACKWARD = True
 from bgflow_amd.utils import hash_init_
 
 dev = torch.device("cuda:0")
@@ -38,9 +39,12 @@ for what, on in (("BONDS", "ANGLES"), ("TORSIONS", "FIXED"), ("FIXED", "TORSIONS
         loss.backward()
         e1.record()
         torch.cuda.synchronize()
-    raw = keep["g_z0"].view(torch.int32).view(-1, 32, 128)[:, 0, :24].cpu().numpy().astype(np.int64)
+    raw = keep["g_z0"].view(torch.int32).view(-1, 32, 128)[:, 0, :32].cpu().numpy().astype(np.int64)
     dt = lambda a, b: ((raw[:, a] - raw[:, b]) % (1 << 32))
     print(f"{what}|{on}: d = {d}, {raw.shape[0]} wave tiles, backward {e0.elapsed_time(e1):.3f} ms (all kernels); memtime ticks (100 MHz) per wave:")
     print(f"   whole wave {dt(15, 0).mean():8.0f}   prologue {dt(1, 0).mean():7.0f}   slots {dt(1 + T, 1).mean():8.0f}   knot-K k-steps {dt(14, 1 + T).mean():7.0f}   rest of the chain {dt(15, 14).mean():8.0f}")
     print("   per slot:", " ".join(f"{dt(2 + t, 1 + t).mean():.0f}" for t in range(min(T, 12))))
+    print(f"   chain: activation backward of z1 (loads, stores) {dt(19, 14).mean():.0f} | second GEMM {dt(20, 19).mean():.0f} | activation backward of z0 {dt(21, 20).mean():.0f} | third GEMM + g_cond + drain {dt(15, 21).mean():.0f}")
+    for nm, b, st in (("z1", 22, 14), ("z0", 26, 20)):
+        print(f"   activation backward of {nm}: loads issued -> all arrived {dt(b, st).mean():.0f} | arithmetic {dt(b + 1, b).mean():.0f} | slab + store issue {dt(b + 2, b + 1).mean():.0f} | stores acknowledged {dt(b + 3, b + 2).mean():.0f}")
     print(f"   slot 1: wait for its element {dt(16, 2).mean():.0f} | request + VJP {dt(17, 16).mean():.0f} | 36 MFMAs + operand loads {dt(18, 17).mean():.0f} | stores {dt(3, 18).mean():.0f}")
