@@ -681,6 +681,32 @@ def main():
                            "bwd: bgk_rqs_backward / bgk_ic_ic2xyz_backward, conditioner input-gradient chain on bgk_dense_backward_dx, "
                            "weight / bias gradients on bgk_dense_weight_grad; one all-reduce of [sum, n] + one all-reduce of the flat gradient bucket; "
                            "bgk_adam_step (device-side NaN skip, trainers.py:198-201)")
+            # the same step as ONE call of the generator: z drawn inside the step by the counter-based prior (one launch of
+            # bgk_philox_fields; key = torch seed of this rank), flow, target energy with the loss sums formed in its kernel
+            prior = gen._prior
+            if world == 1 and hasattr(prior, "sample_fused"):
+                had = prior.sample_fused
+                try:
+                    prior.sample_fused = True
+                    torch.manual_seed(dp.rank_seed(1234, rank))
+
+                    def kl_call():
+                        opt.zero_grad()
+                        loss = gen.kldiv_mean(args.kl_batch, drop_nonfinite=True)
+                        opt.backward(loss)
+                        opt.allreduce_gradients()
+                        opt.step()
+                        last[0] = loss
+                    kl_call()
+                    torch.cuda.synchronize(dev)
+                    ms1 = event_ms_per_call(kl_call, max(2, args.kl_steps // 2), 1)
+                    kl["single_call"] = dict(steps_per_s=1e3 / ms1, ms_per_step=ms1, steps=max(2, args.kl_steps // 2), loss=float(last[0].detach()),
+                                             note="gen.kldiv_mean(B) per step: Philox prior sample inside the step (sample_fused=True), "
+                                                  "flow, bgk_energy_fields with the [sum, n] loss sums, backward, Adam")
+                except Exception as e:
+                    kl["single_call"] = dict(error=repr(e)[:300])
+                finally:
+                    prior.sample_fused = had
         except Exception as e:      # single-process runs only: with several ranks a failing rank cannot be papered over
             if world > 1:
                 raise

@@ -437,11 +437,11 @@ struct PackT {
 /* the three layers in one launch: workgroups [first[q], first[q + 1]) pack layer q */
 struct PackTGroup { PackT L[3]; int first[4]; };
 
-__global__ __launch_bounds__(256) void pack_t_kernel(PackTGroup g, const float* cs) {
-    const int layer = (int)blockIdx.x >= g.first[2] ? 2 : ((int)blockIdx.x >= g.first[1] ? 1 : 0);
+__device__ __forceinline__ void pack_t_body(const PackTGroup& g, const float* cs, int bx) {
+    const int layer = bx >= g.first[2] ? 2 : (bx >= g.first[1] ? 1 : 0);
     const PackT& L = g.L[layer];
     const int blocks = L.S * L.NT * 2 + L.NT;
-    const int64_t t = (int64_t)((int)blockIdx.x - g.first[layer]) * 256 + threadIdx.x;
+    const int64_t t = (int64_t)(bx - g.first[layer]) * 256 + threadIdx.x;
     if (t >= (int64_t)blocks * 64) return;
     const int lane = (int)(t & 63), blk = (int)(t >> 6);
     const int i = lane & 31, kb = lane >> 5;
@@ -474,16 +474,28 @@ __global__ __launch_bounds__(256) void pack_t_kernel(PackTGroup g, const float* 
     *reinterpret_cast<uint4*>(L.out + ((int64_t)blk * 64 + lane) * 8) = *reinterpret_cast<const uint4*>(o);
 }
 
+__global__ __launch_bounds__(256) void pack_t_kernel(PackTGroup g, const float* cs) { pack_t_body(g, cs, (int)blockIdx.x); }
+
+/* the transposed operands of several conditioners in one launch (bgk_pack_dense_h2_t_many) */
+constexpr int PACKT_MANY = 16;
+struct PackTOne { PackTGroup g; const float* cs; };
+struct PackTMany { PackTOne c[PACKT_MANY]; };
+__global__ __launch_bounds__(256) void pack_t_many_kernel(PackTMany) {
+    const PackTMany* km = (const PackTMany*)__builtin_amdgcn_kernarg_segment_ptr();     /* run-time indexed: read in place */
+    const int ci = blockIdx.y;
+    if ((int)blockIdx.x >= km->c[ci].g.first[3]) return;
+    pack_t_body(km->c[ci].g, km->c[ci].cs, (int)blockIdx.x);
+}
+
 }  // namespace
 
-static int pack_t_launch(const float* W0, int n_in, const float* W1, const float* W2, int P, const float* cs, void* T0, void* T1,
-                         void* T2, int d, int n_nc, hipStream_t st) {
+static int pack_t_fill(PackTGroup& g, const float* W0, int n_in, const float* W1, const float* W2, int P, void* T0, void* T1,
+                       void* T2, int d, int n_nc) {
     const int FT = (n_in + 31) / 32;
     const int S2 = d > 0 ? 3 * ((d + 1) / 2) + (n_nc + 15) / 16 : ((P + 15) / 16 + DBWD_PAD - 1) / DBWD_PAD * DBWD_PAD;
     const PackT L2{W2, P, 128, 4, S2, d > 0 ? 2 : 1, (_Float16*)T2, d, n_nc};   /* M[hidden i][k] = W2[col(k)][i], col = output column of the MLP */
     const PackT L1{W1, 128, 128, 4, 8, 0, (_Float16*)T1, 0, 0};      /* M[i][k] = W1[unit(k)][i] */
     const PackT L0{W0, 128, n_in, FT, 8, 0, (_Float16*)T0, 0, 0};    /* M[feature i][k] = W0[unit(k)][i] */
-    PackTGroup g;
     g.L[0] = L0; g.L[1] = L1; g.L[2] = L2;
     int n_wg = 0;
     for (int l = 0; l < 3; ++l) {
@@ -492,8 +504,38 @@ static int pack_t_launch(const float* W0, int n_in, const float* W1, const float
         n_wg += (int)((total + 255) / 256);
     }
     g.first[3] = n_wg;
+    return n_wg;
+}
+
+static int pack_t_launch(const float* W0, int n_in, const float* W1, const float* W2, int P, const float* cs, void* T0, void* T1,
+                         void* T2, int d, int n_nc, hipStream_t st) {
+    PackTGroup g;
+    const int n_wg = pack_t_fill(g, W0, n_in, W1, W2, P, T0, T1, T2, d, n_nc);
     hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, g, cs);
     return 0;
+}
+
+/* bgk_pack_dense_h2_t of n conditioners in one launch per 16 (after an optimizer step: every coupling layer of the flow) */
+extern "C" int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_in, const float* const* W1,
+                                        const float* const* W2, const int32_t* P, const float* const* cs,
+                                        void* const* T0, void* const* T1, void* const* T2, void* stream) {
+    BGK_CHECK_ARG(n >= 0 && W0 && n_in && W1 && W2 && P && cs && T0 && T1 && T2, "bgk_pack_dense_h2_t_many: null pointer");
+    for (int base = 0; base < n; base += PACKT_MANY) {
+        const int cnt = n - base < PACKT_MANY ? n - base : PACKT_MANY;
+        PackTMany M;
+        int max_wg = 0;
+        for (int c = 0; c < cnt; ++c) {
+            const int i = base + c;
+            BGK_CHECK_ARG(W0[i] && W1[i] && W2[i] && cs[i] && T0[i] && T1[i] && T2[i] && n_in[i] > 0 && n_in[i] <= 96 && P[i] > 0,
+                          "bgk_pack_dense_h2_t_many: bad conditioner %d", i);
+            const int n_wg = pack_t_fill(M.c[c].g, W0[i], n_in[i], W1[i], W2[i], P[i], T0[i], T1[i], T2[i], 0, 0);
+            M.c[c].cs = cs[i];
+            max_wg = n_wg > max_wg ? n_wg : max_wg;
+        }
+        for (int c = cnt; c < PACKT_MANY; ++c) M.c[c] = M.c[0];
+        hipLaunchKernelGGL(pack_t_many_kernel, dim3((unsigned)max_wg, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, M);
+    }
+    return bgk_launch_status("bgk_pack_dense_h2_t_many");
 }
 
 extern "C" int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,

@@ -74,11 +74,11 @@ __global__ void pack_scale_kernel(PackLayer L0, PackLayer L1, PackLayer L2, floa
 /* all three layers in one launch: workgroups [first[q], first[q + 1]) pack layer q */
 struct PackGroup { PackLayer L[3]; int first[4]; };
 
-__global__ __launch_bounds__(256) void pack_blocks_kernel(PackGroup g, const float* cs) {
-    const int layer = (int)blockIdx.x >= g.first[2] ? 2 : ((int)blockIdx.x >= g.first[1] ? 1 : 0);
+__device__ __forceinline__ void pack_blocks_body(const PackGroup& g, const float* cs, int bx) {
+    const int layer = bx >= g.first[2] ? 2 : (bx >= g.first[1] ? 1 : 0);
     const PackLayer& L = g.L[layer];
     const int blocks_per_group = L.S * L.NT * 2 + (L.natural ? 0 : L.NT);
-    const int64_t t = (int64_t)((int)blockIdx.x - g.first[layer]) * 256 + threadIdx.x;
+    const int64_t t = (int64_t)(bx - g.first[layer]) * 256 + threadIdx.x;
     const int64_t total = (int64_t)L.n_groups * blocks_per_group * 64;
     if (t >= total) return;
     const int lane = (int)(t & 63);
@@ -119,8 +119,51 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(PackGroup g, const flo
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(o);
 }
 
-void launch_pack(const PackLayer& L0, const PackLayer& L1, const PackLayer& L2, const float* cs, hipStream_t st) {
-    PackGroup g;
+__global__ __launch_bounds__(256) void pack_blocks_kernel(PackGroup g, const float* cs) { pack_blocks_body(g, cs, (int)blockIdx.x); }
+
+/* ---- the packs of several conditioners in two launches (a training step re-packs every coupling layer after the optimizer
+ * step: 16 x (memset + 3 launches) of ~5 us each were 0.4 ms of a 17 ms step) ---- */
+constexpr int PACK_MANY = 16;                 /* conditioners per launch: 16 x 216 B of descriptors in the kernel arguments */
+struct PackOne { PackGroup g; float* cs; };
+struct PackMany { PackOne c[PACK_MANY]; };
+typedef const __attribute__((address_space(4))) PackMany* packmany_t;     /* run-time indexed: scalar loads from the argument block */
+
+/* one workgroup per (layer, conditioner): max |W|, |b| -> the scale pair, written directly (no atomics, no memset) */
+__global__ __launch_bounds__(1024) void pack_maxscale_many_kernel(PackMany) {
+    const packmany_t ka = (packmany_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const int layer = blockIdx.x, ci = blockIdx.y;
+    const float* W = ka->c[ci].g.L[layer].W;
+    const float* b = ka->c[ci].g.L[layer].b;
+    const int rows = ka->c[ci].g.L[layer].rows, nW = rows * ka->c[ci].g.L[layer].K, bf16 = ka->c[ci].g.L[layer].bf16;
+    float* cs = ka->c[ci].cs;
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < nW; i += 1024) m = fmaxf(m, fabsf(W[i]));
+    for (int i = threadIdx.x; i < rows; i += 1024) m = fmaxf(m, fabsf(b[i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+        if (!(m < 3.0e38f)) m = 3.4e38f;
+        int e = 0;
+        if (!bf16 && m > 0.0f && m < 3.0e38f) {
+            e = (int)floorf(log2f(32768.0f / m));
+            e = e < -16 ? -16 : (e > 24 ? 24 : e);
+        }
+        cs[2 * layer] = ldexpf(1.0f, e);
+        cs[2 * layer + 1] = ldexpf(1.0f, -e);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_blocks_many_kernel(PackMany) {
+    const PackMany* km = (const PackMany*)__builtin_amdgcn_kernarg_segment_ptr();      /* run-time indexed: read in place */
+    const int ci = blockIdx.y;
+    if ((int)blockIdx.x >= km->c[ci].g.first[3]) return;
+    pack_blocks_body(km->c[ci].g, km->c[ci].cs, (int)blockIdx.x);
+}
+
+int fill_group(PackGroup& g, const PackLayer& L0, const PackLayer& L1, const PackLayer& L2) {
     g.L[0] = L0; g.L[1] = L1; g.L[2] = L2;
     int blocks = 0;
     for (int q = 0; q < 3; ++q) {
@@ -131,6 +174,12 @@ void launch_pack(const PackLayer& L0, const PackLayer& L1, const PackLayer& L2, 
         blocks += (int)((total + 255) / 256);
     }
     g.first[3] = blocks;
+    return blocks;
+}
+
+void launch_pack(const PackLayer& L0, const PackLayer& L1, const PackLayer& L2, const float* cs, hipStream_t st) {
+    PackGroup g;
+    const int blocks = fill_group(g, L0, L1, L2);
     hipLaunchKernelGGL(pack_blocks_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, cs);
 }
 
@@ -155,4 +204,33 @@ extern "C" int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in,
     hipLaunchKernelGGL(pack_scale_kernel, dim3(1), dim3(64), 0, st, L0, L1, L2, cs);
     launch_pack(L0, L1, L2, cs, st);
     return bgk_launch_status("bgk_pack_dense_h2");
+}
+
+extern "C" int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const* b0, const int32_t* n_in,
+                                      const float* const* W1, const float* const* b1, const float* const* W2, const float* const* b2,
+                                      const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2,
+                                      void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream) {
+    BGK_CHECK_ARG(n >= 0 && W0 && b0 && n_in && W1 && b1 && W2 && b2 && rows2 && row_map2_dev && n_groups2 && A0 && A1 && A2 && cs,
+                  "bgk_pack_dense_h2_many: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += PACK_MANY) {
+        const int cnt = n - base < PACK_MANY ? n - base : PACK_MANY;
+        PackMany M;
+        int max_blocks = 0;
+        for (int c = 0; c < cnt; ++c) {
+            const int i = base + c;
+            BGK_CHECK_ARG(W0[i] && b0[i] && W1[i] && b1[i] && W2[i] && b2[i] && A0[i] && A1[i] && A2[i] && cs[i] && n_in[i] > 0 && rows2[i] > 0
+                          && n_groups2[i] > 0, "bgk_pack_dense_h2_many: bad conditioner %d", i);
+            PackLayer L0{W0[i], b0[i], 128, n_in[i], nullptr, 1, 4, (n_in[i] + 1 + 15) / 16, 1, (_Float16*)A0[i], 0};
+            PackLayer L1{W1[i], b1[i], 128, 128, nullptr, 1, 4, 8, 0, (_Float16*)A1[i], 0};
+            PackLayer L2{W2[i], b2[i], rows2[i], 128, row_map2_dev[i], n_groups2[i], 4, 8, 0, (_Float16*)A2[i], 0};
+            const int blocks = fill_group(M.c[c].g, L0, L1, L2);
+            M.c[c].cs = cs[i];
+            max_blocks = blocks > max_blocks ? blocks : max_blocks;
+        }
+        for (int c = cnt; c < PACK_MANY; ++c) M.c[c] = M.c[0];
+        hipLaunchKernelGGL(pack_maxscale_many_kernel, dim3(3, (unsigned)cnt), dim3(1024), 0, st, M);
+        hipLaunchKernelGGL(pack_blocks_many_kernel, dim3((unsigned)max_blocks, (unsigned)cnt), dim3(256), 0, st, M);
+    }
+    return bgk_launch_status("bgk_pack_dense_h2_many");
 }

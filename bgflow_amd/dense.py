@@ -8,7 +8,9 @@ transformer's conditioner is a ``DenseNet`` with two hidden layers (optionally i
 ``bgk_coupling_rqs_dense``: MLP on the f32 matrix cores + spline epilogue in one launch.
 state_dict keys match the reference (``_layers.{i}.weight/bias``, ``net._layers...``).
 """
+import ctypes
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -560,6 +562,80 @@ def pack_dense_for_fused_h2_device(linears, src_col_dev, n_chunks, bufs=None, bf
     return A0, A1, A2, cs
 
 
+BATCHED_REPACK = True     # training.FlatAdam.step re-packs the operands of every fused training layer in three launches
+
+_TRAIN_PLANS = weakref.WeakSet()      # transformers whose fused plan ran a training forward on device-packed split-f16 operands
+
+
+def _t_operand_bufs(bufs, P, n_in, dev):
+    """transposed-weight operands T0..T2 of bgk_dense_backward_dx for a conditioner [n_in, 128, 128, P] (allocated once per plan)"""
+    FT, S2 = (n_in + 31) // 32, ((P + 15) // 16 + 3) // 4 * 4      # T2: whole groups of 4 k-steps (zero blocks behind ceil(P / 16))
+    key = (P, n_in, str(dev))
+    if bufs.get("key") != key:
+        bufs.clear()
+        bufs.update(key=key, T0=torch.empty((8 * FT * 2 + FT, 64, 8), dtype=torch.float16, device=dev),
+                    T1=torch.empty((8 * 8 + 4, 64, 8), dtype=torch.float16, device=dev),
+                    T2=torch.empty((S2 * 8 + 4, 64, 8), dtype=torch.float16, device=dev))
+    return bufs["T0"], bufs["T1"], bufs["T2"]
+
+
+def repack_training_plans(param_ids=None):
+    """After an optimizer step: the forward operands (bgk_pack_dense_h2_many) and the transposed backward operands
+    (bgk_pack_dense_h2_t_many) of every fused layer that ran a training forward since the last call, in three launches per 16
+    layers instead of a memset + four launches per layer -- 0.4 ms of a 17 ms KL step of the 16-layer flow.  ``param_ids``: ids of
+    the parameters the caller just updated (layers with other parameters are left to the lazy per-layer path, as are zero-padded
+    narrow conditioners and the torch-packed modes).  Returns the number of layers re-packed."""
+    if not BATCHED_REPACK:
+        return 0
+    by_dev = {}
+    for tr in list(_TRAIN_PLANS):
+        cache = getattr(tr, "_fused_cache", None)
+        if not cache or not cache.pop("train_used", False) or cache.get("mode") != "f16x2" or "bufs" not in cache or cache.get("padded"):
+            continue
+        net = tr._params_net
+        inner = net.net if type(net) is WrapPeriodic else net
+        spec = _fusable_dense(inner)
+        if spec is None:
+            continue
+        (l0, l1, l2), _ = spec
+        params = [p for lin in (l0, l1, l2) for p in (lin.weight, lin.bias)]
+        if param_ids is not None and not all(id(p) in param_ids for p in params):
+            continue
+        if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+            continue
+        version = tuple(param_state_key(p) for p in params)
+        if cache.get("version") == version:
+            continue
+        by_dev.setdefault(params[0].device, []).append((cache, l0, l1, l2, params, version))
+    done = 0
+    for dev, items in by_dev.items():
+        n = len(items)
+        vps, i32s = (ctypes.c_void_p * n), (ctypes.c_int32 * n)
+        col = lambda f: vps(*[f(it) for it in items])       # noqa: E731
+        tb = [_t_operand_bufs(it[0].setdefault("tbufs", {}), it[3].out_features, it[1].in_features, dev) for it in items]
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_pack_dense_h2_many(
+                n, col(lambda it: it[4][0].data_ptr()), col(lambda it: it[4][1].data_ptr()), i32s(*[it[1].in_features for it in items]),
+                col(lambda it: it[4][2].data_ptr()), col(lambda it: it[4][3].data_ptr()),
+                col(lambda it: it[4][4].data_ptr()), col(lambda it: it[4][5].data_ptr()), i32s(*[it[3].out_features for it in items]),
+                col(lambda it: it[0]["src_col_dev"].data_ptr()), i32s(*[it[0]["src_col_dev"].numel() // 128 for it in items]),
+                col(lambda it: it[0]["bufs"][0].data_ptr()), col(lambda it: it[0]["bufs"][1].data_ptr()),
+                col(lambda it: it[0]["bufs"][2].data_ptr()), col(lambda it: it[0]["bufs"][3].data_ptr()), _lib.stream_ptr(dev))
+            _lib.check(st, "bgk_pack_dense_h2_many")
+            st = _lib.lib().bgk_pack_dense_h2_t_many(
+                n, col(lambda it: it[4][0].data_ptr()), i32s(*[it[1].in_features for it in items]),
+                col(lambda it: it[4][2].data_ptr()), col(lambda it: it[4][4].data_ptr()), i32s(*[it[3].out_features for it in items]),
+                col(lambda it: it[0]["bufs"][3].data_ptr()),
+                vps(*[t[0].data_ptr() for t in tb]), vps(*[t[1].data_ptr() for t in tb]), vps(*[t[2].data_ptr() for t in tb]),
+                _lib.stream_ptr(dev))
+            _lib.check(st, "bgk_pack_dense_h2_t_many")
+        for cache, _l0, _l1, _l2, _params, version in items:
+            cache["version"] = version
+            cache["tbufs"]["t_version"] = (version[0], version[2], version[4])
+        done += n
+    return done
+
+
 def _src_col_table(d, n_bins, nc_slot_host, device):
     ncp = _lib.lib().bgk_pack_rqs_columns(d, n_bins, None, None)
     src = np.empty(ncp, dtype=np.int32)
@@ -717,19 +793,14 @@ def _featurise(x, periodic):
 FUSED_MLP_BACKWARD = True    # input-gradient chain of the conditioner on bgk_dense_backward_dx (False: three GEMMs + torch act ops)
 
 
-def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs, want_h=True):
+def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs, want_h=True, t_version=None):
     """bgk_pack_dense_h2_t + bgk_dense_backward_dx: returns (g_z1, g_z0, h1, h0, g_x or None); ``want_h=False``: the activations
-    are not written (h1 = h0 = None: the weight-gradient kernel recomputes them from z1 / z0)"""
+    are not written (h1 = h0 = None: the weight-gradient kernel recomputes them from z1 / z0).  ``t_version``: state key of the three
+    weights; when ``bufs`` already holds the transposed operands of that state (repack_training_plans) the pack is skipped."""
     dev = g_p.device
     B, P = g_p.shape
     n_in = W0.shape[1]
-    FT, S2 = (n_in + 31) // 32, ((P + 15) // 16 + 3) // 4 * 4      # T2: whole groups of 4 k-steps (zero blocks behind ceil(P / 16))
-    key = (P, n_in, str(dev))
-    if bufs.get("key") != key:
-        bufs.clear()
-        bufs.update(key=key, T0=torch.empty((8 * FT * 2 + FT, 64, 8), dtype=torch.float16, device=dev),
-                    T1=torch.empty((8 * 8 + 4, 64, 8), dtype=torch.float16, device=dev),
-                    T2=torch.empty((S2 * 8 + 4, 64, 8), dtype=torch.float16, device=dev))
+    _t_operand_bufs(bufs, P, n_in, dev)
     T0, T1, T2 = bufs["T0"], bufs["T1"], bufs["T2"]
     g2, ldg = _lib.rowmajor(g_p)
     x2, ldc = _lib.rowmajor(x.detach())
@@ -738,9 +809,11 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
     g_x = torch.empty((B, d_c), dtype=torch.float32, device=dev) if want_gx else None
     ws = [w.detach().contiguous() for w in (W0, W1, W2)]
     with torch.cuda.device(dev):
-        st = _lib.lib().bgk_pack_dense_h2_t(_lib.ptr(ws[0]), n_in, _lib.ptr(ws[1]), _lib.ptr(ws[2]), P, _lib.ptr(cs),
-                                            _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_pack_dense_h2_t")
+        if t_version is None or bufs.get("t_version") != t_version:
+            st = _lib.lib().bgk_pack_dense_h2_t(_lib.ptr(ws[0]), n_in, _lib.ptr(ws[1]), _lib.ptr(ws[2]), P, _lib.ptr(cs),
+                                                _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.stream_ptr(dev))
+            _lib.check(st, "bgk_pack_dense_h2_t")
+            bufs["t_version"] = t_version
         st = _lib.lib().bgk_dense_backward_dx(_lib.ptr(g2), ldg, P, _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic),
                                               _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.ptr(cs), act_code, B,
                                               _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]) if want_h else None,
@@ -803,6 +876,32 @@ FUSED_WEIGHT_GRAD = True     # weight / bias gradients on bgk_dense_weight_grad 
 _DIRECT_GRADS = [False]
 
 
+DEFERRED_WGRAD_REDUCE = True    # inside direct_grad_accumulation(): one reduction launch for all layers when the context exits
+
+_PENDING_REDUCE = {}            # workspace data_ptr -> (device, B, P, n_in, workspace, the six destinations)
+
+
+def flush_weight_grad_reductions():
+    """reduce the partial weight-gradient sums of every layer whose bgk_dense_weight_grad ran with the reduction deferred
+    (bgk_dense_weight_grad_reduce_many: one launch per 16 layers), adding them to the flat gradient bucket"""
+    if not _PENDING_REDUCE:
+        return
+    by_dev = {}
+    for dev, *rest in _PENDING_REDUCE.values():
+        by_dev.setdefault(dev, []).append(rest)
+    _PENDING_REDUCE.clear()
+    for dev, items in by_dev.items():
+        n = len(items)
+        vps = ctypes.c_void_p * n
+        dst = lambda k: vps(*[it[4][k].data_ptr() for it in items])       # noqa: E731
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_dense_weight_grad_reduce_many(
+                n, (ctypes.c_int64 * n)(*[it[0] for it in items]), (ctypes.c_int32 * n)(*[it[1] for it in items]),
+                (ctypes.c_int32 * n)(*[it[2] for it in items]), vps(*[it[3].data_ptr() for it in items]),
+                dst(4), dst(5), dst(2), dst(3), dst(0), dst(1), 1, _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_dense_weight_grad_reduce_many")
+
+
 class direct_grad_accumulation:
     """Context manager: inside it, the backward of the fused training layers ADDS its weight / bias gradients straight into the
     flat gradient bucket of a ``training.FlatAdam`` (and returns None to autograd for them) instead of handing them to
@@ -816,6 +915,11 @@ class direct_grad_accumulation:
 
     def __exit__(self, *exc):
         _DIRECT_GRADS[0] = self._prev
+        if not self._prev:                      # the outermost context: the deferred reductions of this backward pass
+            if exc[0] is None:
+                flush_weight_grad_reductions()
+            else:
+                _PENDING_REDUCE.clear()
         return False
 
 
@@ -851,11 +955,17 @@ def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, p
     def wbuf(w, b, shape):   # a bias gradient without its weight gradient: give the kernel a scratch weight buffer
         return w if (w is not None or b is None) else torch.empty(shape, dtype=torch.float32, device=dev)
     w2, w1, w0 = wbuf(gW2, gb2, (P, 128)), wbuf(gW1, gb1, (128, 128)), wbuf(gW0, gb0, (128, n_in))
+    mode = int(direct)
+    if direct and DEFERRED_WGRAD_REDUCE:
+        if ws.data_ptr() in _PENDING_REDUCE:     # the same layer twice in one backward pass: its first partial set goes out first
+            flush_weight_grad_reductions()
+        _PENDING_REDUCE[ws.data_ptr()] = (dev, B, P, n_in, ws, (gW0, gb0, gW1, gb1, gW2, gb2))
+        mode = 2
     with torch.cuda.device(dev):
         st = lib.bgk_dense_weight_grad(_lib.ptr(g2), ldg, P, _lib.ptr(g_z1), _lib.ptr(g_z0), _lib.ptr(h1), _lib.ptr(h0), int(h_act),
                                        _lib.ptr(x2), ldc, x2.shape[1], int(periodic), B, _lib.ptr(ws), ws.numel(),
                                        _lib.ptr(w2), _lib.ptr(gb2), _lib.ptr(w1), _lib.ptr(gb1), _lib.ptr(w0), _lib.ptr(gb0),
-                                       int(direct), _lib.stream_ptr(dev))
+                                       mode, _lib.stream_ptr(dev))
     _lib.check(st, "bgk_dense_weight_grad")
     if direct:
         return (None,) * 6
@@ -922,7 +1032,7 @@ class _FusedSplineTrainFn(torch.autograd.Function):
             # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)
             recompute_h = fused_wg
             g_z1, g_z0, h1, h0, g_x = _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, need[0], ctx.tbufs,
-                                                         want_h=not recompute_h)
+                                                         want_h=not recompute_h, t_version=tuple(param_state_key(p) for p in ctx.params[::2]))
         else:
             h1 = act(z1)
             g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
@@ -966,6 +1076,8 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
     _lib.require_hip(x, y)
     if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:
         plan["src_col_dev"] = _src_col_table(y.shape[-1], plan["n_bins"], nc_host, y.device)
+    plan["train_used"] = True
+    _TRAIN_PLANS.add(transformer)
     net = transformer._params_net
     inner = net.net if type(net) is WrapPeriodic else net
     (l0, l1, l2), _ = _fusable_dense(inner)

@@ -132,6 +132,7 @@ class FlatAdam(torch.optim.Optimizer):
         assert len(self.param_groups) == 1, "FlatAdam: one parameter group"
         dev = ps[0].device
         self._params = ps
+        self._param_ids = {id(p) for p in ps}
         n = sum(p.numel() for p in ps)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -208,6 +209,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.generation += 1
         for p in self._params:
             p._bgk_generation = self.generation
+        # ... and re-pack those operands now, for all fused layers at once (three launches instead of five per layer at their next use)
+        from . import dense
+        dense.repack_training_plans(self._param_ids)
 
     def skipped_steps(self):
         """number of optimizer steps skipped because a gradient was NaN (host sync)"""

@@ -402,6 +402,14 @@ int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
                       const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2, int32_t operand_dtype,
                       void* A0, void* A1, void* A2, float* cs, void* stream);
 
+/* bgk_pack_dense_h2 (H = 128, NT2 = 4, split-f16 operands) for n conditioners in two launches per 16 of them: after an optimizer
+ * step every coupling layer of a flow is re-packed; one by one that is a memset + three ~5 us launches per layer (0.4 ms of a
+ * 17 ms KL step of the 16-layer flow).  Arrays of n host-side entries (device pointers inside); same results as n single calls. */
+int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const* b0, const int32_t* n_in,
+                           const float* const* W1, const float* const* b1, const float* const* W2, const float* const* b2,
+                           const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2,
+                           void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream);
+
 /* Input-gradient chain of the conditioner MLP [n_in, 128, 128, P] in one launch (autograd of nn/dense.py:47-48 in the
  * training step): from g [B, P] (gradient w.r.t. the MLP output, e.g. bgk_rqs_backward's g_params) and the saved
  * pre-activations z1, z0 it writes g_z1, g_z0 (gradients w.r.t. the pre-activations), h1, h0 (the activations; both NULL: not
@@ -411,6 +419,10 @@ int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in, int32_t H,
  * T2 8 S2 + 4 with S2 = ceil(P / 16) rounded up to a multiple of 4 (zero blocks behind the last column). */
 int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
                         const float* cs, void* T0, void* T1, void* T2, void* stream);
+/* bgk_pack_dense_h2_t for n conditioners in one launch per 16 of them (same results as n single calls) */
+int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_in, const float* const* W1,
+                             const float* const* W2, const int32_t* P, const float* const* cs,
+                             void* const* T0, void* const* T1, void* const* T2, void* stream);
 int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,
                           const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                           const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
@@ -502,11 +514,18 @@ int bgk_philox_fields(uint64_t seed, uint32_t offset, int64_t row0, int32_t n_fi
  *   a fifth less HBM traffic in that kernel).
  * Split over the batch into slabs whose partials are summed in fixed order (deterministic); workspace size in floats from
  * bgk_dense_weight_grad_workspace.  Replaces 3 split-K hipBLASLt GEMMs + 3 reductions + 6 column-sum launches per layer. */
+/* accumulate = 2: only the partial sums are formed (deterministic slabs in the workspace); bgk_dense_weight_grad_reduce_many then
+ * reduces the partial sets of n layers -- same B, P, n_in, workspace and destinations as their bgk_dense_weight_grad calls, all
+ * six destinations of a layer given -- in ONE launch per 16 layers (accumulate there: 0 overwrite, 1 add to the destinations): the
+ * backward pass of a 16-layer flow ends with one reduction instead of sixteen 25 us launches. */
 int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in);
 int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
                           const float* h1, const float* h0, int32_t h_act, const float* cond, int64_t ldc, int32_t d_c,
                           int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
                           float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate, void* stream);
+int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* P, const int32_t* n_in,
+                                      float* const* workspace, float* const* gW2, float* const* gb2, float* const* gW1,
+                                      float* const* gb1, float* const* gW0, float* const* gb0, int32_t accumulate, void* stream);
 
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).

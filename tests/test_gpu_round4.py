@@ -392,3 +392,59 @@ def test_spline_vjp_inside_the_input_gradient_launch(hip_lib, dev, inverse, B):
         for a, b in zip(gp1 + gx1, gp0 + gx0):
             assert a.shape == b.shape and bool(torch.isfinite(a).all())
             assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6), f"{what}|{on}: gradient of shape {tuple(a.shape)}"
+
+
+def test_batched_repack_after_the_optimizer_step(hip_lib, dev):
+    """FlatAdam.step re-packs the operands of every fused training layer in three launches (bgk_pack_dense_h2_many /
+    bgk_pack_dense_h2_t_many): bit-identical to the per-layer packs (bgk_pack_dense_h2, bgk_pack_dense_h2_t) of the same weights, the
+    plans are fresh afterwards (no pack at the next forward / backward), and a training run gives the same losses with and without it --
+    and with / without the weight-gradient reductions of all layers deferred to one launch (bgk_dense_weight_grad_reduce_many)"""
+    from bgflow_amd import _lib, configs, dense
+    from bgflow_amd.training import FlatAdam
+
+    def run(batched):
+        dense.BATCHED_REPACK = dense.DEFERRED_WGRAD_REDUCE = batched
+        try:
+            torch.manual_seed(0)
+            gen = configs.make_ala2_spline_generator(dev)
+            opt = FlatAdam(list(gen.flow.parameters()), lr=1e-3)
+            z = [torch.rand(777, d, device=dev, generator=torch.Generator(device=dev).manual_seed(3 + i)) for i, d in enumerate((17, 17, 17, 9))]
+            losses = []
+            for _ in range(3):
+                opt.zero_grad()
+                *x, dlogp = gen.flow(*z)
+                loss = (gen._target.energy(*x) - dlogp).mean()
+                opt.backward(loss)
+                opt.step()
+                losses.append(float(loss))
+            return gen, opt, losses
+        finally:
+            dense.BATCHED_REPACK = dense.DEFERRED_WGRAD_REDUCE = True
+
+    gen, opt, losses = run(True)
+    _, _, losses0 = run(False)
+    assert losses == losses0, "the batched packs are the per-layer packs: identical training trajectories"
+    mine = {id(p) for p in opt._params}
+    checked = 0
+    for tr in list(dense._TRAIN_PLANS):
+        cache = tr._fused_cache
+        if not all(id(p) in mine for p in tr._params_net.parameters()):
+            continue
+        assert cache.get("tbufs", {}).get("t_version") is not None
+        net = tr._params_net
+        inner = net.net if type(net) is dense.WrapPeriodic else net
+        (l0, l1, l2), _ = dense._fusable_dense(inner)
+        params = [p for lin in (l0, l1, l2) for p in (lin.weight, lin.bias)]
+        assert cache["version"] == tuple(dense.param_state_key(p) for p in params), "fresh after the step"
+        A = dense.pack_dense_for_fused_h2_device((l0, l1, l2), cache["src_col_dev"], cache["src_col_dev"].numel() // 128)
+        for a, b in zip(A, cache["bufs"]):
+            assert torch.equal(a, b)
+        tb = cache["tbufs"]
+        T = [torch.empty_like(tb[k]) for k in ("T0", "T1", "T2")]
+        st = _lib.lib().bgk_pack_dense_h2_t(_lib.ptr(l0.weight), l0.in_features, _lib.ptr(l1.weight), _lib.ptr(l2.weight), l2.out_features,
+                                            _lib.ptr(cache["bufs"][3]), _lib.ptr(T[0]), _lib.ptr(T[1]), _lib.ptr(T[2]), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_pack_dense_h2_t")
+        for a, k in zip(T, ("T0", "T1", "T2")):
+            assert torch.equal(a, tb[k])
+        checked += 1
+    assert checked == 16
