@@ -126,16 +126,21 @@ class _CdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y, g_dlogp):
         x, y = ctx.saved_tensors
-        x2, ldx = _lib.rowmajor(x)
-        gy2, ldgy = _lib.rowmajor(g_y.contiguous())
-        B, d = x2.shape
-        g_x = torch.empty((B, d), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            st = _lib.lib().bgk_cdf_backward(_lib.ptr(x2), ldx, _lib.ptr(y), d, _lib.ptr(ctx.desc), B, d, int(ctx.inverse),
-                                             int(ctx.eps is not None), float(ctx.eps or 0.0), _lib.ptr(gy2), ldgy,
-                                             _lib.ptr(g_dlogp.reshape(-1).contiguous()), _lib.ptr(g_x), d, _lib.stream_ptr(x.device))
-        _lib.check(st, "bgk_cdf_backward")
-        return g_x, None, None, None
+        return cdf_backward(x, y, ctx.desc, ctx.inverse, ctx.eps, g_y, g_dlogp), None, None, None
+
+
+def cdf_backward(x, y, desc, inverse, eps, g_y, g_dlogp):
+    """bgk_cdf_backward: gradient w.r.t. the map's input x from the cotangents of its output y (contiguous [B, d]) and of its log-det"""
+    x2, ldx = _lib.rowmajor(x)
+    gy2, ldgy = _lib.rowmajor(g_y.contiguous())
+    B, d = x2.shape
+    g_x = torch.empty((B, d), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = _lib.lib().bgk_cdf_backward(_lib.ptr(x2), ldx, _lib.ptr(y), d, _lib.ptr(desc), B, d, int(inverse),
+                                         int(eps is not None), float(eps or 0.0), _lib.ptr(gy2), ldgy,
+                                         _lib.ptr(g_dlogp.reshape(-1).contiguous()), _lib.ptr(g_x), d, _lib.stream_ptr(x.device))
+    _lib.check(st, "bgk_cdf_backward")
+    return g_x
 
 
 def _launch(x, desc, inverse, eps, acc=None):

@@ -559,18 +559,23 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
                           i3 = a.place[5 * i + 3], zr = a.place[5 * i + 4];
                 V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
                 float dd = s_b[tid * a.sic + zr], an = s_a[tid * a.sic + zr], t = s_t[tid * a.sic + zr];
-                if (a.normalize) { an = an * PI_F; t = t * (2.0f * PI_F) - PI_F; }
+                /* angles in revolutions for the hardware sin / cos (|error| <= 1.3e-7, tools/ubench/hw_sincos.hip); reciprocal
+                 * square roots and reciprocals on the hardware forms: a third of the OCML / IEEE instruction count of this chain,
+                 * which runs latency-bound (one 64-lane wave per 54 KB of LDS rows) */
+                const float an_rev = a.normalize ? 0.5f * an : an * (0.5f / PI_F);
+                const float t_rev = a.normalize ? t - 0.5f : t * (0.5f / PI_F);
                 V3 g = ld3(gp + 3 * at);
                 V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
                 V3 nv = cross(v1, v2), nn = cross(v1, nv);
-                float inv_nv = 1.0f / norm(nv), inv_nn = 1.0f / norm(nn), inv_v1 = 1.0f / norm(v1);
+                float inv_nv = __builtin_amdgcn_rsqf(dot(nv, nv)), inv_nn = __builtin_amdgcn_rsqf(dot(nn, nn)), inv_v1 = __builtin_amdgcn_rsqf(dot(v1, v1));
                 V3 nh = scale(nv, inv_nv), nnh = scale(nn, inv_nn), v1h = scale(v1, inv_v1);
-                float st = sinf(t), ct = cosf(t), sa = sinf(an), ca = cosf(an);
+                const float tf = __builtin_amdgcn_fractf(t_rev), af = __builtin_amdgcn_fractf(an_rev);
+                float st = __builtin_amdgcn_sinf(tf), ct = __builtin_amdgcn_cosf(tf), sa = __builtin_amdgcn_sinf(af), ca = __builtin_amdgcn_cosf(af);
                 V3 v3 = add(scale(nh, -st), scale(nnh, ct));
-                float inv_v3 = 1.0f / norm(v3);
+                float inv_v3 = __builtin_amdgcn_rsqf(dot(v3, v3));
                 V3 v3h = scale(v3, inv_v3);
-                float gd = dot(g, add(scale(v3h, sa), scale(v1h, -ca))) + gl * 2.0f / dd;
-                float ga = dot(g, add(scale(v3h, dd * ca), scale(v1h, dd * sa))) + gl * ca / sa;
+                float gd = dot(g, add(scale(v3h, sa), scale(v1h, -ca))) + gl * 2.0f * __builtin_amdgcn_rcpf(dd);
+                float ga = dot(g, add(scale(v3h, dd * ca), scale(v1h, dd * sa))) + gl * ca * __builtin_amdgcn_rcpf(sa);
                 V3 g_v3 = proj_out(scale(g, dd * sa), v3h, inv_v3);
                 float gt = dot(g_v3, add(scale(nh, -ct), scale(nnh, -st)));
                 V3 g_n = proj_out(scale(g_v3, -st), nh, inv_nv);

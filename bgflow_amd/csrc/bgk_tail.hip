@@ -431,7 +431,7 @@ __device__ __forceinline__ void dma_tile(float* dst, const float* __restrict__ s
     }
 }
 
-template <int NA>
+template <int NA, bool EMIT = false>
 __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -467,6 +467,7 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
             const int e = k * 64 + lane;
             float dummy = 0.0f;
             R3[e] = icdf_chan(R3[e], df, cl, dummy);
+            if (EMIT && e < rows * keep) a.o_fixed[b0 * keep + e] = R3[e];      /* training: the mapped field for the backward kernels */
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -524,6 +525,7 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
             const float d = icdf_chan(R0[e], db, cl, ld);
             const float an = icdf_chan(R1[e], da, cl, ld);
             const float tn = icdf_chan(R2[e], dt, cl, ld);
+            if (EMIT && e < rows * n) { a.o_bonds[b0 * n + e] = d; a.o_angles[b0 * n + e] = an; a.o_torsions[b0 * n + e] = tn; }
             float sa, ca;
             sincos2pi(0.5f * an, sa, ca);             /* sin / cos (pi a) */
             const float dsa = d * sa;
@@ -855,12 +857,13 @@ extern "C" int bgk_icdf_ic2xyz_reg(const float* bonds, const float* angles, cons
 /* the same tail for FIELD-UNIFORM marginals (every channel of a field shares one descriptor -- what the builder installs):
  * desc4 [4][20] = the bonds / angles / torsions / fixed descriptor; x must be contiguous (ldx = 3 (n + n_fixed)) and all five
  * tensors 16-byte aligned.  See icdf_ic2xyz_uni_kernel. */
-extern "C" int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, const float* torsions, const float* xfix,
-                                   const float* desc4, int32_t use_eps, float cdf_eps,
-                                   const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
-                                   float eps, int32_t enforce_boundaries,
-                                   const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
-                                   float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream) {
+static int icdf_ic2xyz_uni_launch(const float* bonds, const float* angles, const float* torsions, const float* xfix,
+                                  const float* desc4, int32_t use_eps, float cdf_eps,
+                                  const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                                  float eps, int32_t enforce_boundaries,
+                                  const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
+                                  float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count,
+                                  float* y_bonds, float* y_angles, float* y_torsions, float* y_fixed, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_icdf_ic2xyz_uni: bad sizes");
     BGK_CHECK_ARG(x && place8 && fixed && bonds && angles && torsions && xfix && dlogp && desc4, "bgk_icdf_ic2xyz_uni: null pointer");
@@ -876,6 +879,7 @@ extern "C" int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, cons
     a.cl = use_eps ? CdfClamp{cdf_eps, 1.0f - cdf_eps, -1.0f / cdf_eps} : CdfClamp{-inf, inf, -inf};
     a.eps = eps; a.const_ld = (float)const_ld;
     a.B = B; a.x = x; a.ldx = ldx; a.dlogp = dlogp; a.accumulate = accumulate; a.warn_count = warn_count;
+    a.o_bonds = y_bonds; a.o_angles = y_angles; a.o_torsions = y_torsions; a.o_fixed = y_fixed;
     const int W = n > keep ? n : keep;
     a.lds_per_wave = 64 * (4 * W > 3 * n_atoms ? 4 * W : 3 * n_atoms);
     const size_t shmem = sizeof(float) * (size_t)TW * a.lds_per_wave;
@@ -883,11 +887,39 @@ extern "C" int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, cons
     const int64_t n_wg = (((B + 63) >> 6) + TW - 1) / TW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_icdf_ic2xyz_uni: batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-#define BGK_LAUNCH(NA_) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(icdf_ic2xyz_uni_kernel<NA_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                             hipLaunchKernelGGL(icdf_ic2xyz_uni_kernel<NA_>, dim3((unsigned)n_wg), dim3(TW * 64), shmem, st, a); } while (0)
-    if (n_atoms <= 24) BGK_LAUNCH(24); else BGK_LAUNCH(32);
+#define BGK_LAUNCH(NA_, EM_) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(icdf_ic2xyz_uni_kernel<NA_, EM_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                                  hipLaunchKernelGGL((icdf_ic2xyz_uni_kernel<NA_, EM_>), dim3((unsigned)n_wg), dim3(TW * 64), shmem, st, a); } while (0)
+    if (y_bonds) { if (n_atoms <= 24) BGK_LAUNCH(24, true); else BGK_LAUNCH(32, true); }
+    else { if (n_atoms <= 24) BGK_LAUNCH(24, false); else BGK_LAUNCH(32, false); }
 #undef BGK_LAUNCH
     return bgk_launch_status("bgk_icdf_ic2xyz_uni");
+}
+
+extern "C" int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, const float* torsions, const float* xfix,
+                                   const float* desc4, int32_t use_eps, float cdf_eps,
+                                   const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                                   float eps, int32_t enforce_boundaries,
+                                   const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
+                                   float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream) {
+    return icdf_ic2xyz_uni_launch(bonds, angles, torsions, xfix, desc4, use_eps, cdf_eps, place8, n, fixed, n_fixed, eps, enforce_boundaries,
+                                  wh_mean, Tblacken, keep, const_ld, B, x, ldx, dlogp, accumulate, warn_count, nullptr, nullptr, nullptr,
+                                  nullptr, stream);
+}
+
+/* the same launch for a TRAINING forward: additionally writes the four mapped fields (the outputs of the icdf maps = the inputs of
+ * the coordinate transform), contiguous [B, n] x 3 and [B, keep] -- what bgk_ic_ic2xyz_backward and bgk_cdf_backward read, so the
+ * backward pass runs on the existing kernels while the forward stays one launch instead of five */
+extern "C" int bgk_icdf_ic2xyz_uni_train(const float* bonds, const float* angles, const float* torsions, const float* xfix,
+                                         const float* desc4, int32_t use_eps, float cdf_eps,
+                                         const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                                         float eps, int32_t enforce_boundaries,
+                                         const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
+                                         float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count,
+                                         float* y_bonds, float* y_angles, float* y_torsions, float* y_fixed, void* stream) {
+    BGK_CHECK_ARG(y_bonds && y_angles && y_torsions && y_fixed, "bgk_icdf_ic2xyz_uni_train: null pointer");
+    return icdf_ic2xyz_uni_launch(bonds, angles, torsions, xfix, desc4, use_eps, cdf_eps, place8, n, fixed, n_fixed, eps, enforce_boundaries,
+                                  wh_mean, Tblacken, keep, const_ld, B, x, ldx, dlogp, accumulate, warn_count, y_bonds, y_angles, y_torsions,
+                                  y_fixed, stream);
 }
 
 /* The inverse (NLL) direction of the builder tail in one launch: x [B, 3 (n + n_fixed)] -> cdf-mapped bonds / angles / torsions [B, n]

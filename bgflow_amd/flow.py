@@ -146,6 +146,7 @@ class SequentialFlow(Flow):
         self._blocks = torch.nn.ModuleList(blocks)
 
     FUSE_GENERATION_TAIL = True   # icdf domain maps + IC -> xyz as one kernel in the sampling direction (bgk_icdf_ic2xyz)
+    FUSE_TRAINING_TAIL = True     # ... also when the inputs need gradients: one-launch forward that keeps the mapped fields for the backward
     FUSE_COUPLING_STACKS = True   # Split -> (affine Coupling | Swap)* -> Merge on ONE [B, D] buffer: no cat / per-layer outputs
 
     _bgk_acc = True
@@ -402,6 +403,36 @@ class _FusedCouplingStack:
         return work, (acc if acc is not None else dlogp[:, None])
 
 
+class _FusedTailTrainFn(torch.autograd.Function):
+    """the generation tail [icdf maps..., IC -> xyz] as ONE launch in a training forward (bgk_icdf_ic2xyz_uni_train: it also writes
+    the mapped fields); backward on the kernels the block path uses -- bgk_ic_ic2xyz_backward, then bgk_cdf_backward per mapped field"""
+
+    @staticmethod
+    def forward(ctx, zb, za, zt, zf, tail, descs, desc20):
+        res = tail._ic._generate_fused_train(zb, za, zt, zf, tail._eps, desc20)
+        if res is None:
+            raise _TailOutsideEnvelope()
+        x, dlogp, ys, rel, blacken = res
+        ctx.rel, ctx.blacken, ctx.descs, ctx.eps = rel, blacken, descs, tail._eps
+        ctx.save_for_backward(zb, za, zt, zf, *ys, x)
+        return x, dlogp[:, None]
+
+    @staticmethod
+    def backward(ctx, g_x, g_dlogp):
+        from .cdf import cdf_backward
+        zb, za, zt, zf, yb, ya, yt, yf, x = ctx.saved_tensors
+        g_ys = ctx.rel._ic2xyz_backward(yb, ya, yt, x, ctx.blacken, g_x, g_dlogp)
+        outs = []
+        for z, y, g_y, desc in zip((zb, za, zt, zf), (yb, ya, yt, yf), g_ys, ctx.descs):
+            # a field without a domain map passes through (its y is a copy of z, its log-det contribution is 0)
+            outs.append(g_y if desc is None else cdf_backward(z.flatten(1), y, desc, True, ctx.eps, g_y, g_dlogp).view_as(z))
+        return (*outs, None, None, None)
+
+
+class _TailOutsideEnvelope(Exception):
+    pass
+
+
 class _FusedGenerationTail:
     """callable standing in for the tail blocks [icdf maps..., IC -> xyz] of a SequentialFlow (sampling direction).  Falls back
     to the blocks themselves when an input needs gradients, is not an f32 HIP tensor, or a marginal has no kernel descriptor."""
@@ -461,7 +492,11 @@ class _FusedGenerationTail:
     def __call__(self, *xs, inverse=False, **kwargs):
         assert not inverse
         ok = len(xs) >= 4 and all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 for x in xs[:4])
-        if ok and torch.is_grad_enabled() and any(x.requires_grad for x in xs):
+        train = ok and torch.is_grad_enabled() and any(x.requires_grad for x in xs[:4])
+        if ok and torch.is_grad_enabled() and any(torch.is_tensor(x) and x.requires_grad for x in xs[4:]):
+            ok = False
+        if train and not (self._flow.FUSE_TRAINING_TAIL and hasattr(self._ic, "_generate_fused_train") and not self._others
+                          and len(self._maps) == 4 and kwargs.get(ACC_KW) is None):
             ok = False
         descs = [None] * 4
         if ok:
@@ -469,6 +504,16 @@ class _FusedGenerationTail:
                 descs[slot] = cdf.kernel_descriptor(xs[slot].shape[-1], xs[slot].device)
                 if descs[slot] is None:
                     ok = False
+        if ok and train:
+            # training: one launch forward (it also writes the mapped fields), backward on the block path's kernels
+            desc20 = self._desc20(xs)
+            if desc20 is not None and getattr(desc20, "uniform4", None) is not None:
+                try:
+                    x, dlogp = _FusedTailTrainFn.apply(xs[0], xs[1], xs[2], xs[3], self, descs, desc20)
+                    return (x, *xs[4:], dlogp)
+                except _TailOutsideEnvelope:
+                    pass
+            ok = False
         if not ok:
             return self._blocks_path(*xs, **kwargs)
         acc = kwargs.get(ACC_KW)

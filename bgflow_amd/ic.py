@@ -157,24 +157,8 @@ class _IC2XYZFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_x, g_dlogp):
         bonds, angles, torsions, x = ctx.saved_tensors
-        rel, blacken = ctx.rel, ctx.blacken
-        dev = x.device
-        B, n, nf = bonds.shape[0], rel._n, rel._n_fixed
-        (b2, a2, t2), ldic = _contig_rows(bonds, angles, torsions)
-        g_x2, ldgx = _lib.rowmajor(g_x.contiguous())
-        g_dl = g_dlogp.reshape(-1).contiguous()
-        T = None if blacken is None else blacken[1]
-        keep = 3 * nf if T is None else T.shape[0]
-        g_ic = torch.empty((3, B, n), dtype=torch.float32, device=dev)
-        g_f = torch.empty((B, keep), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            st = _lib.lib().bgk_ic_ic2xyz_backward(
-                _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), ldic, _lib.ptr(x), x.shape[1],
-                _lib.ptr(rel._tables.get("place", dev)), n, _lib.ptr(rel._tables.get("fixed", dev)), nf,
-                int(rel._normalize_angles), _lib.ptr(T), keep, B, _lib.ptr(g_x2), ldgx, _lib.ptr(g_dl),
-                _lib.ptr(g_ic[0]), _lib.ptr(g_ic[1]), _lib.ptr(g_ic[2]), n, _lib.ptr(g_f), keep, _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_ic_ic2xyz_backward")
-        return None, g_ic[0], g_ic[1], g_ic[2], g_f, None
+        g_b, g_a, g_t, g_f = ctx.rel._ic2xyz_backward(bonds, angles, torsions, x, ctx.blacken, g_x, g_dlogp)
+        return None, g_b, g_a, g_t, g_f, None
 
 
 class _XYZ2ICFn(torch.autograd.Function):
@@ -371,6 +355,62 @@ class RelativeInternalCoordinateTransformation(Flow):
     UNIFORM_TAIL = True      # ... and on its elementwise variant when every field has one marginal for all its channels
     REGISTER_TAIL = True     # sampling tail on the register-resident kernel (bgk_icdf_ic2xyz_reg) where its envelope allows
 
+    def _icdf_ic2xyz_train(self, bonds, angles, torsions, xfix, eps, blacken, desc20):
+        """the fused tail as a TRAINING forward (bgk_icdf_ic2xyz_uni_train): (x, dlogp [B], (y_bonds, y_angles, y_torsions, y_fixed)) with
+        y = the mapped fields the backward kernels read, or None outside the elementwise kernel's envelope.  No autograd here
+        (flow._FusedTailTrainFn wraps it)."""
+        dev = bonds.device
+        B, n, nf = bonds.shape[0], self._n, self._n_fixed
+        desc4 = getattr(desc20, "uniform4", None) if desc20 is not None else None
+        if desc4 is None or not (self.REGISTER_TAIL and self.UNIFORM_TAIL and self._normalize_angles and n + nf <= 32 and B > 0):
+            return None
+        (b2, a2, t2), ldic = _contig_rows(bonds.detach(), angles.detach(), torsions.detach())
+        f2, ldf = _lib.rowmajor(xfix.detach().flatten(1))
+        if blacken is None:
+            mean = T = None
+            keep, jac = 3 * nf, 0.0
+        else:
+            mean, T, jac = blacken
+            keep = T.shape[0]
+        if not (keep <= 16 and f2.shape[1] == keep and ldic == n and ldf == keep and all(v.is_contiguous() for v in (b2, a2, t2, f2))):
+            return None
+        x = torch.empty((B, 3 * (n + nf)), dtype=torch.float32, device=dev)
+        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        ys = torch.empty((3, B, n), dtype=torch.float32, device=dev)
+        yf = torch.empty((B, keep), dtype=torch.float32, device=dev)
+        const_ld = n * (np.log(np.pi) + np.log(2.0 * np.pi)) - (float(jac) if T is not None else 0.0)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_icdf_ic2xyz_uni_train(
+                _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), _lib.ptr(f2), _lib.ptr(desc4), int(eps is not None), float(eps or 0.0),
+                _lib.ptr(self._tables.get("place8", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
+                float(self._eps), int(self._enforce_boundaries), _lib.ptr(mean), _lib.ptr(T), keep, float(const_ld), B,
+                _lib.ptr(x), x.shape[1], _lib.ptr(dlogp), 0, _lib.ptr(self._warn_counter(dev)),
+                _lib.ptr(ys[0]), _lib.ptr(ys[1]), _lib.ptr(ys[2]), _lib.ptr(yf), _lib.stream_ptr(dev))
+        if st == -2:
+            return None
+        _lib.check(st, "bgk_icdf_ic2xyz_uni_train")
+        return x, dlogp, (ys[0], ys[1], ys[2], yf)
+
+    def _ic2xyz_backward(self, y_bonds, y_angles, y_torsions, x, blacken, g_x, g_dlogp):
+        """bgk_ic_ic2xyz_backward: (g_bonds, g_angles, g_torsions, g_fixed) of the IC -> xyz map at the saved point"""
+        dev = x.device
+        B, n, nf = y_bonds.shape[0], self._n, self._n_fixed
+        (b2, a2, t2), ldic = _contig_rows(y_bonds, y_angles, y_torsions)
+        g_x2, ldgx = _lib.rowmajor(g_x.contiguous())
+        g_dl = g_dlogp.reshape(-1).contiguous()
+        T = None if blacken is None else blacken[1]
+        keep = 3 * nf if T is None else T.shape[0]
+        g_ic = torch.empty((3, B, n), dtype=torch.float32, device=dev)
+        g_f = torch.empty((B, keep), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_ic_ic2xyz_backward(
+                _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), ldic, _lib.ptr(x), x.shape[1],
+                _lib.ptr(self._tables.get("place", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
+                int(self._normalize_angles), _lib.ptr(T), keep, B, _lib.ptr(g_x2), ldgx, _lib.ptr(g_dl),
+                _lib.ptr(g_ic[0]), _lib.ptr(g_ic[1]), _lib.ptr(g_ic[2]), n, _lib.ptr(g_f), keep, _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_ic_ic2xyz_backward")
+        return g_ic[0], g_ic[1], g_ic[2], g_f
+
     def _icdf_ic2xyz(self, bonds, angles, torsions, xfix, descs, eps, blacken=None, acc=None, desc20=None):
         """IC -> xyz with the icdf domain maps of the four inputs fused in (bgk_icdf_ic2xyz); ``descs`` = per-field [d, 6]
         descriptor tensors (cdf.CDFTransform.kernel_descriptor) or None for a field that is used as is.  No autograd."""
@@ -427,6 +467,10 @@ class RelativeInternalCoordinateTransformation(Flow):
 
     def _generate_fused(self, bonds, angles, torsions, x_fixed, descs, eps, acc=None, desc20=None):
         return self._icdf_ic2xyz(bonds, angles, torsions, x_fixed, descs, eps, acc=acc, desc20=desc20)
+
+    def _generate_fused_train(self, bonds, angles, torsions, x_fixed, eps, desc20):
+        res = self._icdf_ic2xyz_train(bonds, angles, torsions, x_fixed, eps, None, desc20)
+        return None if res is None else (*res, self, None)
 
     def _xyz2ic_cdf(self, x, desc4, eps, whiten=None, acc=None):
         """xyz -> IC with the four cdf domain maps fused in (bgk_xyz2ic_cdf_uni: the NLL direction of a builder flow's tail); None when
@@ -608,6 +652,11 @@ class MixedCoordinateTransformation(Flow):
     def _generate_fused(self, bonds, angles, torsions, z_fixed, descs, eps, acc=None, desc20=None):
         return self._rel_ic._icdf_ic2xyz(bonds, angles, torsions, z_fixed, descs, eps, blacken=self._wh("blacken", bonds.device), acc=acc,
                                          desc20=desc20)
+
+    def _generate_fused_train(self, bonds, angles, torsions, z_fixed, eps, desc20):
+        blacken = self._wh("blacken", bonds.device)
+        res = self._rel_ic._icdf_ic2xyz_train(bonds, angles, torsions, z_fixed, eps, blacken, desc20)
+        return None if res is None else (*res, self._rel_ic, blacken)
 
 
 def slice_initial_atoms(z_matrix):

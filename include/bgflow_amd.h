@@ -195,6 +195,16 @@ int bgk_icdf_ic2xyz_uni(const float* bonds, const float* angles, const float* to
                         float eps, int32_t enforce_boundaries,
                         const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
                         float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count, void* stream);
+/* ... for a TRAINING forward (KLTrainer, trainers.py:158-170 through generator_builder.py:443-459's tail): the same launch also writes
+ * the four mapped fields y = icdf(z) (contiguous [B, n] x 3, [B, keep]) -- the inputs bgk_ic_ic2xyz_backward and bgk_cdf_backward
+ * need -- so the backward pass runs on those kernels while the forward is one launch instead of 4 x bgk_cdf_transform + bgk_ic_ic2xyz */
+int bgk_icdf_ic2xyz_uni_train(const float* bonds, const float* angles, const float* torsions, const float* xfix,
+                              const float* desc4, int32_t use_eps, float cdf_eps,
+                              const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                              float eps, int32_t enforce_boundaries,
+                              const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
+                              float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count,
+                              float* y_bonds, float* y_angles, float* y_torsions, float* y_fixed, void* stream);
 
 /* The INVERSE (NLL) direction of the builder tail in one launch: x [B, 3 (n + n_fixed)] -> cdf-mapped bonds / angles / torsions [B, n]
  * and (whitened) fixed coordinates [B, keep], all contiguous and 16-byte aligned, + log|det J|.  Replaces bgk_ic_xyz2ic + 4 x
