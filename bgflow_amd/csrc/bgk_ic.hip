@@ -11,6 +11,7 @@
  * like the reference, eps clamps included); transcendental functions are the precise OCML ones.
  */
 #include "bgk_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -610,6 +611,101 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
     }
 }
 
+/* The same reverse sweep with the positions in REGISTERS (3 x NA values, indexed by the wave-uniform atom ids of the placement
+ * table; the adjoints stay LDS rows: a second register set of that size is not promoted by the compiler) and ONE LDS region shared
+ * by the x tile (staging only) and the three IC tiles: the rows of the kernel above (2 x 67 + 3 x 23 + 10 floats per lane at ala2
+ * size = 54 KB per wave) let two waves live on a CU, and the sweep is a latency chain -- 0.40 ms for 2^18 samples = 0.5 TB/s.  Here
+ * 38 KB per wave: four waves per CU. */
+template <int NA>
+__global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_reg_kernel(IcBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = a.n, nf3 = 3 * a.n_fixed, n_atoms = a.n_atoms, na3 = 3 * a.n_atoms;
+    const int sreg = a.sx;                    /* launcher: max(3 n_atoms, 3 sic) | 1 */
+    float* s_r = smem;                        /* [64][sreg]: x rows (staging), then bonds | angles | torsions rows (-> their gradients) */
+    float* s_g = s_r + 64 * sreg;             /* [64][sreg] position adjoints */
+    float* s_f = s_g + 64 * sreg;             /* [64][sfx] g_xfix */
+    const int tid = threadIdx.x;
+    typedef const __attribute__((address_space(4))) int32_t* ci32_t;     /* scalar loads: the atom ids index the register arrays */
+    const ci32_t place = (ci32_t)a.place, fixed = (ci32_t)a.fixed;
+    const int64_t n_tiles = (a.B + 63) / 64;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * 64;
+        const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+        float px[NA], py[NA], pz[NA];
+        tile_load64(s_r, sreg, a.x + b0 * a.ldx, a.ldx, rows, na3);
+        tile_load64(s_g, sreg, a.g_x + b0 * a.ldgx, a.ldgx, rows, na3);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (k < n_atoms) { px[k] = s_r[tid * sreg + 3 * k]; py[k] = s_r[tid * sreg + 3 * k + 1]; pz[k] = s_r[tid * sreg + 3 * k + 2]; }
+        __syncthreads();
+        float* s_b = s_r;
+        float* s_a = s_r + a.sic;
+        float* s_t = s_r + 2 * a.sic;            /* row stride sreg for all three */
+        tile_load64(s_b, sreg, a.bonds + b0 * a.ldic, a.ldic, rows, n);
+        tile_load64(s_a, sreg, a.angles + b0 * a.ldic, a.ldic, rows, n);
+        tile_load64(s_t, sreg, a.torsions + b0 * a.ldic, a.ldic, rows, n);
+        __syncthreads();
+        if (tid < rows) {
+            float* gp = s_g + tid * sreg;
+            const float gl = a.g_dlogp[b0 + tid];
+            /* a sample whose upstream adjoints are all zero (e.g. masked out of the loss because its geometry is degenerate and its
+             * log-det is -inf) must get exactly zero gradients, not 0 * inf = NaN */
+            bool live = gl != 0.0f;
+            for (int c = 0; c < na3; ++c) live = live || (gp[c] != 0.0f);
+            for (int i = n - 1; i >= 0; --i) {
+                const int at = place[5 * i], i1 = place[5 * i + 1], i2 = place[5 * i + 2], i3 = place[5 * i + 3], zr = place[5 * i + 4];
+                float dd = s_b[tid * sreg + zr], an = s_a[tid * sreg + zr], t = s_t[tid * sreg + zr];
+                if (!live) { s_b[tid * sreg + zr] = 0.0f; s_a[tid * sreg + zr] = 0.0f; s_t[tid * sreg + zr] = 0.0f; continue; }
+                const float an_rev = a.normalize ? 0.5f * an : an * (0.5f / PI_F);
+                const float t_rev = a.normalize ? t - 0.5f : t * (0.5f / PI_F);
+                const V3 p1 = {px[i1], py[i1], pz[i1]}, p2 = {px[i2], py[i2], pz[i2]}, p3 = {px[i3], py[i3], pz[i3]};
+                const V3 g = ld3(gp + 3 * at);
+                V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
+                V3 nv = cross(v1, v2), nn = cross(v1, nv);
+                float inv_nv = __builtin_amdgcn_rsqf(dot(nv, nv)), inv_nn = __builtin_amdgcn_rsqf(dot(nn, nn)), inv_v1 = __builtin_amdgcn_rsqf(dot(v1, v1));
+                V3 nh = scale(nv, inv_nv), nnh = scale(nn, inv_nn), v1h = scale(v1, inv_v1);
+                const float tf = __builtin_amdgcn_fractf(t_rev), af = __builtin_amdgcn_fractf(an_rev);
+                float st = __builtin_amdgcn_sinf(tf), ct = __builtin_amdgcn_cosf(tf), sa = __builtin_amdgcn_sinf(af), ca = __builtin_amdgcn_cosf(af);
+                V3 v3 = add(scale(nh, -st), scale(nnh, ct));
+                float inv_v3 = __builtin_amdgcn_rsqf(dot(v3, v3));
+                V3 v3h = scale(v3, inv_v3);
+                float gd = dot(g, add(scale(v3h, sa), scale(v1h, -ca))) + gl * 2.0f * __builtin_amdgcn_rcpf(dd);
+                float ga = dot(g, add(scale(v3h, dd * ca), scale(v1h, dd * sa))) + gl * ca * __builtin_amdgcn_rcpf(sa);
+                V3 g_v3 = proj_out(scale(g, dd * sa), v3h, inv_v3);
+                float gt = dot(g_v3, add(scale(nh, -ct), scale(nnh, -st)));
+                V3 g_n = proj_out(scale(g_v3, -st), nh, inv_nv);
+                V3 g_nn = proj_out(scale(g_v3, ct), nnh, inv_nn);
+                V3 g_v1 = cross(nv, g_nn);
+                g_n = add(g_n, cross(g_nn, v1));
+                g_v1 = add(g_v1, cross(v2, g_n));
+                V3 g_v2 = cross(g_n, v1);
+                g_v1 = add(g_v1, proj_out(scale(g, -dd * ca), v1h, inv_v1));
+                gp[3 * i1] += g.x + g_v1.x + g_v2.x; gp[3 * i1 + 1] += g.y + g_v1.y + g_v2.y; gp[3 * i1 + 2] += g.z + g_v1.z + g_v2.z;
+                gp[3 * i2] -= g_v1.x; gp[3 * i2 + 1] -= g_v1.y; gp[3 * i2 + 2] -= g_v1.z;
+                gp[3 * i3] -= g_v2.x; gp[3 * i3 + 1] -= g_v2.y; gp[3 * i3 + 2] -= g_v2.z;
+                if (a.normalize) { ga = ga * PI_F; gt = gt * (2.0f * PI_F); }
+                s_b[tid * sreg + zr] = gd; s_a[tid * sreg + zr] = ga; s_t[tid * sreg + zr] = gt;
+            }
+            if (a.T) {
+                for (int k = 0; k < a.keep; ++k) {
+                    float s = 0.0f;
+                    for (int c = 0; c < nf3; ++c) s += gp[3 * fixed[c / 3] + c % 3] * a.T[k * nf3 + c];
+                    s_f[tid * a.sfx + k] = s;
+                }
+            } else {
+                for (int c = 0; c < nf3; ++c) s_f[tid * a.sfx + c] = gp[3 * fixed[c / 3] + c % 3];
+            }
+        }
+        __syncthreads();
+        tile_store64(a.g_bonds + b0 * a.ldgic, a.ldgic, s_b, sreg, rows, n);
+        tile_store64(a.g_angles + b0 * a.ldgic, a.ldgic, s_a, sreg, rows, n);
+        tile_store64(a.g_torsions + b0 * a.ldgic, a.ldgic, s_t, sreg, rows, n);
+        tile_store64(a.g_xfix + b0 * a.ldgf, a.ldgf, s_f, a.sfx, rows, a.keep);
+        __syncthreads();
+    }
+}
+
 /* ---- global reference frame of the first three atoms (ReferenceSystemTransformation) -------------
  * 9 floats in, 9 floats out per sample; log|det J_9x9| in closed form -(2 ln d01 + 2 ln d12 + ln sin a012)
  * (the reference uses a batched autograd Jacobian + 24-term permutation expansion; see oracle bgo_refsys). */
@@ -824,6 +920,17 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
     a.n_atoms = n + n_fixed; a.keep = keep; a.normalize = normalize_angles; a.T = Tblacken; a.B = B;
     a.g_bonds = g_bonds; a.g_angles = g_angles; a.g_torsions = g_torsions; a.ldgic = ldgic; a.g_xfix = g_xfix; a.ldgf = ldgf;
     a.sx = (3 * a.n_atoms) | 1; a.sic = n | 1; a.sfx = keep | 1;
+    if (a.n_atoms <= 32 && !getenv("BGK_IC_BWD_LDS")) {          /* positions in registers: 38 instead of 54 KB of LDS per wave */
+        const int sreg = (a.sx > 3 * a.sic ? a.sx : 3 * a.sic) | 1;
+        const size_t shm = sizeof(float) * 64 * (size_t)(2 * sreg + a.sfx);
+        IcBwdArgs b = a;
+        b.sx = sreg;                                             /* kernel: sreg = max(sx, 3 sic) -> pass it through sx */
+        int64_t nt = (B + 63) / 64;
+        int grid = (int)(nt < 256 * 28 ? nt : 256 * 28);
+        if (a.n_atoms <= 24) hipLaunchKernelGGL(ic_ic2xyz_bwd_reg_kernel<24>, dim3(grid), dim3(ICB_THREADS), shm, (hipStream_t)stream, b);
+        else hipLaunchKernelGGL(ic_ic2xyz_bwd_reg_kernel<32>, dim3(grid), dim3(ICB_THREADS), shm, (hipStream_t)stream, b);
+        return bgk_launch_status("bgk_ic_ic2xyz_backward");
+    }
     const size_t per = (size_t)(2 * a.sx + 3 * a.sic + a.sfx);
     const int ts = fit_tile(ICB_THREADS, per, 0);
     size_t shmem = sizeof(float) * (size_t)ts * per;
