@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .utils import is_list_or_tuple, param_state_key
+from .utils import is_list_or_tuple, param_pitch, param_state_key, row_pitch
 
 __all__ = ["DenseNet", "MeanFreeDenseNet", "WrapPeriodic", "WrapDistances"]
 
@@ -851,7 +851,7 @@ def _spline_backward_dx(y, params, nc_dev, rcfg, g_out, g_dlogp, z1, z0, x, W0, 
     g_out2 = g_out.contiguous()
     g_dl = g_dlogp.reshape(-1).contiguous()
     g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
-    ldgp = (P + 3) // 4 * 4
+    ldgp = row_pitch(P)
     g_p = torch.empty((B, ldgp), dtype=torch.float32, device=dev)[:, :P]
     out = torch.empty((2, B, 128), dtype=torch.float32, device=dev)
     g_x = torch.empty((B, d_c), dtype=torch.float32, device=dev) if want_gx else None
@@ -989,7 +989,7 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
         z0 = torch.empty((B, 128), dtype=torch.float32, device=dev)
         z1 = torch.empty((B, 128), dtype=torch.float32, device=dev)
-        ldp = (P + 3) // 4 * 4                       # 16-byte aligned rows for the backward kernels' vector loads
+        ldp = param_pitch(P)
         params = torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :P]
         left, right, bottom, top, s = tcfg
         with torch.cuda.device(dev):

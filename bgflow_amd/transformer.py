@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .utils import row_pitch
 from .flow import ACC_KW, Flow, as_tensor
 
 def _invalidate_fused_cache(self):
@@ -246,7 +247,7 @@ def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp):
     g_y = torch.empty((B, d), dtype=torch.float32, device=y.device)
     # rows padded to a multiple of 4 floats: the 16-byte accesses of this kernel and of bgk_dense_backward_dx stay aligned
     # (P = 425 gives 1700-byte rows otherwise)
-    ldgp = (P + 3) // 4 * 4
+    ldgp = row_pitch(P)
     g_p = torch.empty((B, ldgp), dtype=torch.float32, device=y.device)[:, :P]
     with torch.cuda.device(y.device):
         st = _lib.lib().bgk_rqs_backward(
