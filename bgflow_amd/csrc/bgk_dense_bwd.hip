@@ -520,6 +520,7 @@ extern "C" int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const
                                         const float* const* W2, const int32_t* P, const float* const* cs,
                                         void* const* T0, void* const* T1, void* const* T2, void* stream) {
     BGK_CHECK_ARG(n >= 0 && W0 && n_in && W1 && W2 && P && cs && T0 && T1 && T2, "bgk_pack_dense_h2_t_many: null pointer");
+    if (n == 0) return 0;       /* nothing to do (and no launch status to ask a GPU-less box for) */
     for (int base = 0; base < n; base += PACKT_MANY) {
         const int cnt = n - base < PACKT_MANY ? n - base : PACKT_MANY;
         PackTMany M;

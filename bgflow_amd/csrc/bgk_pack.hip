@@ -212,6 +212,7 @@ extern "C" int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const f
                                       void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream) {
     BGK_CHECK_ARG(n >= 0 && W0 && b0 && n_in && W1 && b1 && W2 && b2 && rows2 && row_map2_dev && n_groups2 && A0 && A1 && A2 && cs,
                   "bgk_pack_dense_h2_many: null pointer");
+    if (n == 0) return 0;       /* nothing to do (and no launch status to ask a GPU-less box for) */
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += PACK_MANY) {
         const int cnt = n - base < PACK_MANY ? n - base : PACK_MANY;

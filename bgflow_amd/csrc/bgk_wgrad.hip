@@ -325,6 +325,7 @@ extern "C" int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, co
                                                  float* const* gb1, float* const* gW0, float* const* gb0, int32_t accumulate, void* stream) {
     BGK_CHECK_ARG(n >= 0 && B && P && n_in && workspace && gW2 && gb2 && gW1 && gb1 && gW0 && gb0 && (accumulate == 0 || accumulate == 1),
                   "bgk_dense_weight_grad_reduce_many: bad arguments");
+    if (n == 0) return 0;       /* nothing to do (and no launch status to ask a GPU-less box for) */
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += RED_MANY) {
         const int cnt = n - base < RED_MANY ? n - base : RED_MANY;

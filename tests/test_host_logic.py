@@ -481,6 +481,55 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
                                           256, P1, 0, 0, 0, P1, 32, 8, 32, P1, 32, P1, 0, None) == -2
     assert L.bgk_dense_backward_dx(P1, 425, 425, P1, P1, P1, 120, 120, 0, P1, P1, P1, P1, 1, 8, P1, P1, P1, P1, None, 0, None) == -2
     assert L.bgk_column_sum(P1, 4, 8, 0, P1, 4, P1, None) == -1
+    # round 4 entry points: empty batches, envelope and argument checks before any launch
+    spl = lambda B, d, K, P, n_in_cols: L.bgk_spline_backward_dx(   # noqa: E731
+        P1, d, P1, P, P, P1, B, d, K, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, d, P1, P1, d, P1, P,
+        P1, P1, P1, n_in_cols, n_in_cols, 0, P1, P1, P1, P1, 1, P1, P1, None, None, None, 0, None)
+    assert spl(0, 17, 8, 425, 17) == 0
+    assert spl(8, 17, 4, 221, 17) == -2 and "n_bins = 8" in err()
+    assert spl(8, 17, 8, 500, 17) == -1 and "bad params width" in err()
+    assert spl(8, 17, 8, 425, 120) == -2 and "input features > 96" in err()
+    assert L.bgk_pack_spline_t(P1, 17, P1, P1, 425, 80, P1, P1, P1, P1, None) == -1 and "d <= 64" in err()
+    n1 = (ctypes.c_void_p * 1)(0x1000)
+    i1 = (ctypes.c_int32 * 1)(0)
+    assert L.bgk_pack_dense_h2_many(0, n1, n1, i1, n1, n1, n1, n1, i1, n1, i1, n1, n1, n1, n1, None) == 0      # no conditioner: no launch
+    assert L.bgk_pack_dense_h2_many(1, n1, n1, i1, n1, n1, n1, n1, i1, n1, i1, n1, n1, n1, n1, None) == -1 and "bad conditioner 0" in err()
+    assert L.bgk_pack_dense_h2_t_many(0, n1, i1, n1, n1, i1, n1, n1, n1, n1, None) == 0
+    assert L.bgk_pack_dense_h2_t_many(1, n1, i1, n1, n1, i1, n1, n1, n1, n1, None) == -1 and "bad conditioner 0" in err()
+    b1 = (ctypes.c_int64 * 1)(0)
+    assert L.bgk_dense_weight_grad_reduce_many(0, b1, i1, i1, n1, n1, n1, n1, n1, n1, n1, 1, None) == 0
+    assert L.bgk_dense_weight_grad_reduce_many(1, b1, i1, i1, n1, n1, n1, n1, n1, n1, n1, 1, None) == -1 and "bad layer 0" in err()
+    assert L.bgk_dense_weight_grad_reduce_many(1, b1, i1, i1, n1, n1, n1, n1, n1, n1, n1, 2, None) == -1
+    assert L.bgk_icdf_ic2xyz_uni_train(P1, P1, P1, P1, P1, 1, 1e-7, P1, 17, P1, 5, 1e-7, 1, P1, P1, 9, 0.0, 0,
+                                       P1, 66, P1, 0, None, P1, P1, P1, P1, None) == 0                      # empty batch
+    assert L.bgk_icdf_ic2xyz_uni_train(P1, P1, P1, P1, P1, 1, 1e-7, P1, 17, P1, 5, 1e-7, 1, P1, P1, 9, 0.0, 64,
+                                       P1, 66, P1, 0, None, None, P1, P1, P1, None) == -1 and "null pointer" in err()
+
+
+def test_training_glue_host_semantics():
+    """host side of the round-4 training glue, no GPU: row pitches, operand buffer sizes (T2 in whole groups of four k-steps, as the
+    header documents), the deferred weight-gradient reductions are dropped when a backward pass raises, and nothing is re-packed
+    when no fused layer has run"""
+    from bgflow_amd import dense
+    from bgflow_amd.utils import param_pitch, row_pitch
+    assert row_pitch(425) == 448 and row_pitch(448) == 448 and row_pitch(1) == 32
+    assert param_pitch(425) == 428 and param_pitch(408) == 408
+    bufs = {}
+    T0, T1, T2 = dense._t_operand_bufs(bufs, 425, 34, torch.device("cpu"))
+    assert T0.shape == (8 * 2 * 2 + 2, 64, 8) and T1.shape == (68, 64, 8) and T2.shape == (28 * 8 + 4, 64, 8)      # ceil(425 / 16) = 27 -> 28
+    assert dense._t_operand_bufs(bufs, 425, 34, torch.device("cpu"))[2] is T2                                      # cached per (P, n_in, device)
+    assert dense._t_operand_bufs(bufs, 408, 34, torch.device("cpu"))[2].shape == (28 * 8 + 4, 64, 8)               # 25.5 -> 26 -> 28
+    assert dense.repack_training_plans(set()) == 0
+    dense._PENDING_REDUCE.clear()
+    with pytest.raises(RuntimeError):
+        with dense.direct_grad_accumulation():
+            dense._PENDING_REDUCE[1] = (torch.device("cpu"), 8, 425, 17, None, (None,) * 6)
+            with dense.direct_grad_accumulation():      # a nested context leaves the flush to the outermost one
+                pass
+            assert 1 in dense._PENDING_REDUCE
+            raise RuntimeError("backward failed")
+    assert not dense._PENDING_REDUCE and not dense._DIRECT_GRADS[0]
+    dense.flush_weight_grad_reductions()                # nothing pending: no library call
 
 
 
