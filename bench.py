@@ -136,12 +136,17 @@ class _SegmentTimer:
         return _Ctx()
 
 
-def timed_steps(gen, zs, steps, inverse=False):
-    """K passes of the flow with HIP events around every segment.  Returns [(segment index, start event, end event), ...]."""
+N_INPUT_SETS = 2      # the timed loops rotate this many synthetic input sets (2^20 x 60 floats = 252 MB each: a set does not survive in
+#                       the 256 MiB Infinity Cache until it is used again, as the one reused set of the earlier rounds might have)
+
+
+def timed_steps(gen, zsets, steps, inverse=False, first=0):
+    """K passes of the flow with HIP events around every segment, pass k on input set (first + k) mod len(zsets).  Returns
+    [(segment index, start event, end event), ...]."""
     timer = _SegmentTimer()
     with torch.no_grad():
-        for _ in range(steps):
-            gen.flow.run(tuple(zs), inverse=inverse, around=timer)
+        for k in range(steps):
+            gen.flow.run(tuple(zsets[(first + k) % len(zsets)]), inverse=inverse, around=timer)
     return timer.events
 
 
@@ -159,8 +164,15 @@ def event_ms_per_call(fn, steps, warmup):
     return e0.elapsed_time(e1) / steps
 
 
-def flow_pass(gen, zs, inverse=False):
+def flow_pass(gen, zsets, inverse=False):
+    """callable: one pass of the flow, successive calls rotate through the input sets ``zsets`` (a list of input tuples)"""
+    if torch.is_tensor(zsets[0]):
+        zsets = [zsets]
+    k = [0]
+
     def run():
+        zs = zsets[k[0] % len(zsets)]
+        k[0] += 1
         with torch.no_grad():
             return gen.flow(*zs, inverse=inverse)
     return run
@@ -521,17 +533,18 @@ def main():
     gemm_mode = _dense.GEMM_MODE
     gen, sampler, desc = make_workload(args.workload, dev)
     g = torch.Generator(device=dev).manual_seed(dp.rank_seed(1234, rank))
-    zs = sampler(args.batch, g)
+    zsets = [sampler(args.batch, g) for _ in range(N_INPUT_SETS)]
+    zs = zsets[0]
 
     # ---- headline: W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize, max over ranks
-    for _ in range(args.warmup):
-        timed_steps(gen, zs, 1)
+    for w in range(args.warmup):
+        timed_steps(gen, zsets, 1, first=w)
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    evs = timed_steps(gen, zs, args.steps)
+    evs = timed_steps(gen, zsets, args.steps, first=args.warmup)
     torch.cuda.synchronize(dev)
     if world > 1:
         torch.distributed.barrier()
@@ -550,7 +563,7 @@ def main():
         # same-run single-rank pass (the other ranks idle at the barrier): weak-scaling efficiency = (value_N / N) / value_1
         torch.distributed.barrier()
         if rank == 0:
-            ms1 = event_ms_per_call(flow_pass(gen, zs), max(3, args.steps // 2), 1)
+            ms1 = event_ms_per_call(flow_pass(gen, zsets), max(3, args.steps // 2), 1)
             rccl["one_rank_alone_samples_per_s"] = args.batch / (1e-3 * ms1)
         torch.distributed.barrier()
         # the only data-path collective of a KL / NLL evaluation, alone: all-reduce of the [sum loss, n] pair
@@ -569,12 +582,12 @@ def main():
     if args.workload != "cfg2" and rank == 0:
         try:
             with torch.no_grad():
-                *xg, _ = gen.flow(*zs)
-            ms = event_ms_per_call(flow_pass(gen, xg, inverse=True), E, W)
+                xsets = [gen.flow(*z)[:-1] for z in zsets]
+            ms = event_ms_per_call(flow_pass(gen, xsets, inverse=True), E, W)
             inverse_leg = dict(value=args.batch / (1e-3 * ms), unit="samples/s", ms_per_step=ms, steps=E, batch=args.batch, timer="HIP events",
                                segments=[lbl for lbl, _ in gen.flow.segments(inverse=True)],
                                note="inverse (NLL) direction of the same flow on this rank: Flow.forward(x, inverse=True) -> (z, dlogp)")
-            del xg
+            del xsets
         except Exception as e:      # a side measurement must never take the headline line down
             inverse_leg = dict(error=repr(e)[:300])
 
@@ -583,7 +596,7 @@ def main():
     if args.workload == "cfg3" and gemm_mode != "f32" and solo and not args.no_extras:
         try:
             _dense.GEMM_MODE = "f32"
-            ms = event_ms_per_call(flow_pass(gen, zs), E, W)
+            ms = event_ms_per_call(flow_pass(gen, zsets), E, W)
             exact = dict(gemm="f32", value=args.batch / (1e-3 * ms), unit="samples/s", ms_per_step=ms, steps=E, timer="HIP events",
                          note="same flow, conditioner GEMMs on the f32-input MFMA (exact fma chain): bit-identical to the CPU oracle")
             _dense.GEMM_MODE = gemm_mode
@@ -598,7 +611,8 @@ def main():
     if args.workload == "cfg3" and solo and not args.no_extras:
         try:
             gen2, sampler2, desc2 = make_workload("cfg2", dev)
-            z2 = sampler2(1 << 20, torch.Generator(device=dev).manual_seed(1234))
+            g2 = torch.Generator(device=dev).manual_seed(1234)
+            z2 = [sampler2(1 << 20, g2) for _ in range(N_INPUT_SETS)]
             ms = event_ms_per_call(flow_pass(gen2, z2), E, W)
             cfg2 = dict(workload=desc2, value=(1 << 20) / (1e-3 * ms), unit="samples/s", ms_per_step=ms, steps=E, batch=1 << 20,
                         timer="HIP events",
@@ -614,7 +628,8 @@ def main():
     if args.workload == "cfg3" and solo and not args.no_extras:
         try:
             gen5, sampler5, desc5 = make_workload("cfg5", dev)
-            z5 = sampler5(1 << 20, torch.Generator(device=dev).manual_seed(1234))
+            g5 = torch.Generator(device=dev).manual_seed(1234)
+            z5 = [sampler5(1 << 20, g5) for _ in range(N_INPUT_SETS)]
             legs = {}
             for mode in (gemm_mode if gemm_mode != "bf16" else "f16x2", "bf16"):
                 _dense.GEMM_MODE = mode
@@ -641,10 +656,12 @@ def main():
             from bgflow_amd.training import FlatAdam
             params = [p for p in gen.flow.parameters()]
             opt = FlatAdam(params, lr=1e-5)            # flat parameter / gradient bucket, bgk_adam_step (what KLTrainer uses)
-            zk = sampler(args.kl_batch, g)
-            last = [None]
+            zks = [sampler(args.kl_batch, g) for _ in range(N_INPUT_SETS)]
+            last, kcount = [None], [0]
 
             def kl_step():
+                zk = zks[kcount[0] % len(zks)]
+                kcount[0] += 1
                 opt.zero_grad()
                 *x, dlogp = gen.flow(*zk)
                 loss = dp.global_kl_mean(gen._target, x, dlogp, drop_nonfinite=True)      # loss sums inside the target-energy kernel
@@ -788,6 +805,8 @@ def main():
                                "f16x2": "f32 throughout, except that the conditioner GEMM operands are represented as hi + lo f16 pairs (22-24 "
                                         "significant bits, 3 MFMAs per product, f32 accumulate); hardware exp2 / log2 / rcp with Newton steps"}[gemm_mode],
                    data="synthetic",
+                   inputs=f"{N_INPUT_SETS} synthetic input sets resident in HBM, rotated from step to step in every timed loop "
+                          f"(a set is larger than what is left of the Infinity Cache when its turn comes again)",
                    config=dict(workload=(("cfg 4: " if cfg4 else "") + desc
                                          + ("" if world == 1 else f"; data-parallel shard: {args.batch} samples per rank x {world} ranks = "
                                             f"{args.batch * world} global"

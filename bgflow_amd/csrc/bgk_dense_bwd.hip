@@ -12,7 +12,6 @@
  * hardware exp / rcp forms like the forward.
  */
 #include "bgk_mfma_h2.h"
-#include "bgk_rqs_vjp.h"
 
 namespace {
 
@@ -40,7 +39,7 @@ struct DenseBwdArgs {
     int lds_per_wave;
 };
 
-/* -DBGK_SBD_TS=1 (tools/r04_spline_bwd_ts.py): s_memtime stamps of the wave's phases, written over row b0 of g_z0 at the end */
+/* -DBGK_SBD_TS=1: s_memtime stamps of the wave's phases (14: first GEMM done, 19 - 29: the chain), written over row b0 of g_z0 at the end */
 #ifndef BGK_SBD_TS
 #define BGK_SBD_TS 0
 #endif
@@ -74,7 +73,7 @@ __device__ __forceinline__ void act_grad2(int act, bgk_f2 z, bgk_f2 g, bgk_f2& g
 /* acc (accumulator layout, 4 tiles) -> g_z = acc * c * act'(z), h = act(z); z is read as 16-byte groups, g_z / h leave as
  * full rows through the LDS slab.  All sixteen z requests go out BEFORE the arithmetic (64 registers): left to the compiler
  * they were issued a few at a time between the activation code, one exposed memory round trip after the other -- 50 k of the
- * 170 k cycles a wave lived (s_memtime stamps, tools/r04_spline_bwd_ts.py), 19 k with the requests up front. */
+ * 170 k cycles a wave lived (s_memtime stamps, -DBGK_SBD_TS=1), 19 k with the requests up front. */
 __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, int act, const float* z, float* gz_out, float* h_out,
                                                    float* s_buf, int64_t b0, int lane, int rows, int tsb = 22) {
     float* const s_f = s_buf;
@@ -255,166 +254,6 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
             }
         }
     }
-    dx_chain_tail<FT>(a, acc, s_f, b0, lane, rows);
-}
-
-/* ---- the spline's VJP fused in front of the chain (n_bins = 8) ----------------------------------------------------------------
- * bgk_rqs_backward writes g_params [B, P] and the kernel above reads it straight back; here a lane computes the VJP of the
- * elements (sample j, dim 2 t + hh), t = 0 .. ceil(d / 2) - 1, and its 8 width / 8 height / 8 slope gradients ARE the B-operand
- * halves of three k16-steps of the first GEMM -- provided the GEMM's k order follows the elements instead of the parameter
- * columns: k-step 3 t + q (q = 0 widths, 1 heights, 2 slopes), half hh = dim 2 t + hh; the knot-K slopes of the non-circular
- * dims ride in ceil(n_nc / 16) extra k-steps (through LDS: their column is not the owning lane's).  bgk_pack_spline_t orders
- * W2^T's columns accordingly.  g_params is still written (the weight-gradient kernel reads it) but not read back:
- * 4 P bytes per sample less traffic and one launch less per coupling layer. */
-struct SplineBwdArgs {
-    DenseBwdArgs m;                               /* m.g unused; m.T2 in element order; m.S2 = its k-steps */
-    const float* y; int64_t ldy;                  /* the spline's input [B, d] */
-    const float* params; int64_t ldp;             /* saved unnormalised parameters [B, P] */
-    const int32_t* nc_slot;
-    const float* g_out; int64_t ldgo; const float* g_dlogp;
-    float* g_y; int64_t ldgy; float* g_params; int64_t ldgp;
-    int d, n_nc, inverse;
-    BgkRqsCfg cfg;
-};
-
-struct SplElem { float rw[8], rh[8], rs[8]; float sK, x, gy; int slot; };
-
-/* Memory pipeline of the kernel below.  Loads and stores retire through ONE in-order counter, and the compiler's wait
- * insertion is exact only on straight-line code (at a control-flow join it assumes the path with the fewest operations in
- * flight, i.e. it drains).  So the slot loop has no branch: rows past the batch and the dim past d of an odd block are
- * out-of-range offsets of raw buffer accesses (loads return 0, stores are dropped), and the prologue issues the same sequence
- * of requests a loop iteration ends with (the element of slot 0, the first operand fragments, eight dropped stores).  Per slot:
- * request element t + 1 | VJP of element t (its loads are one slot old) | operand fragments of k-steps 3 t + 1, 3 t + 2 and
- * of the next slot's first k-step around the 36 MFMAs | the element's gradients out. */
-template <int FT>
-__global__ __launch_bounds__(DW * 64, 2) void spline_bwd_dx_kernel(SplineBwdArgs sa) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int K = 8;
-    constexpr int OOB = 0x40000000;                          /* beyond every tile's num_records */
-    const DenseBwdArgs& a = sa.m;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* uniform: the buffer descriptors live in SGPRs */
-    const int j = lane & 31, hh = lane >> 5;
-    float* s_f = smem + (size_t)wave * a.lds_per_wave;       /* knot-K slope gradients [32][H2_SLAB] (columns < 64; 128: bin) + the slot table */
-    int* s_slot = reinterpret_cast<int*>(s_f) + 64;          /* row 0, columns 64 .. 127 */
-    const int64_t n_tiles = (a.B + 31) / 32;
-    const int64_t tile = (int64_t)blockIdx.x * DW + wave;
-    if (tile >= n_tiles) return;
-    SBD_TS(0);
-    const int64_t b0 = tile * 32;
-    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
-    const int d = sa.d, T = (d + 1) >> 1;
-    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.params + b0 * sa.ldp), 0, (int)(rows * sa.ldp * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.g_params + b0 * sa.ldgp), 0, (int)(rows * sa.ldgp * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.y + b0 * sa.ldy), 0, (int)(rows * sa.ldy * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.g_out + b0 * sa.ldgo), 0, (int)(rows * sa.ldgo * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_gy = __builtin_amdgcn_make_buffer_rsrc((void*)(sa.g_y + b0 * sa.ldgy), 0, (int)(rows * sa.ldgy * 4), 0x00020000);
-    const int po = j * (int)sa.ldp * 4, go = j * (int)sa.ldgp * 4, yo = j * (int)sa.ldy * 4, goo = j * (int)sa.ldgo * 4, gyo = j * (int)sa.ldgy * 4;
-    const float gl = sa.g_dlogp[b0 + (j < rows ? j : 0)];
-    if (lane < d) s_slot[lane] = sa.nc_slot[lane];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    h2_f32x16 acc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
-
-    auto request = [&](int t, SplElem& e) {
-        const int dim = (2 * t + hh) < d ? (2 * t + hh) : d - 1;     /* the dim past an odd d: a valid element's data, results unused */
-        const int off = po + dim * (4 * K);
-        /* (whole-vector bit casts: __builtin_bit_cast(float, v[k]) of a vector element reads element 0 for every k with this compiler) */
-        auto ld4 = [&](int o) { return __builtin_bit_cast(bgk_f4v, __builtin_amdgcn_raw_buffer_load_b128(rs_p, o, 0, 0)); };
-        const bgk_f4v w0 = ld4(off), w1 = ld4(off + 16);
-        const bgk_f4v h0 = ld4(off + d * (4 * K)), h1 = ld4(off + d * (4 * K) + 16);
-        const bgk_f4v t0 = ld4(off + 2 * d * (4 * K)), t1 = ld4(off + 2 * d * (4 * K) + 16);
-        e.slot = s_slot[dim];
-        e.sK = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_p, e.slot >= 0 ? po + (3 * d * K + e.slot) * 4 : OOB, 0, 0));
-        e.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, yo + dim * 4, 0, 0));
-        e.gy = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_go, goo + dim * 4, 0, 0));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            e.rw[k] = w0[k]; e.rw[4 + k] = w1[k]; e.rh[k] = h0[k]; e.rh[4 + k] = h1[k]; e.rs[k] = t0[k]; e.rs[4 + k] = t1[k];
-        }
-    };
-    auto store8 = [&](const float (&v)[K], int off) {
-        const bgk_f4v lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bgk_u4, lo), rs_g, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bgk_u4, hi), rs_g, off + 16, 0, 0);
-    };
-    SplElem nxt;
-    H2A<4> fr0, fr1;
-    request(0, nxt);
-    h2a_load<4>(fr0, a.T2, 0, lane);
-    {
-        const float z[K] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        store8(z, OOB); store8(z, OOB); store8(z, OOB);
-        __builtin_amdgcn_raw_buffer_store_b32(0u, rs_gy, OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(0u, rs_g, OOB, 0, 0);
-    }
-    SBD_TS(1);
-    const int S2 = a.S2;
-    for (int t = 0; t < T; ++t) {
-        const SplElem cur = nxt;
-        __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-        if (t == 1) { asm volatile("" :: "v"(cur.rw[0]), "v"(cur.gy), "v"(cur.rs[7])); SBD_TS(16); }
-#endif
-        request(t + 1 < T ? t + 1 : T - 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool own = (2 * t + hh) < d;
-        const int dim = own ? (2 * t + hh) : d - 1;
-        float ow[K], oh[K], os[K], g_slot, gx;
-        bgk_rqs_vjp_element<K>(sa.cfg, sa.inverse, cur.rw, cur.rh, cur.rs, cur.slot >= 0 ? cur.sK : cur.rs[0], cur.slot >= 0,
-                               cur.x, cur.gy, gl, ow, oh, os, g_slot, gx);
-        __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-        if (t == 1) { asm volatile("" :: "v"(ow[0]), "v"(oh[7]), "v"(os[3]), "v"(gx)); SBD_TS(17); }
-#endif
-        h2_h16x8 bhi, blo;
-        h2a_load<4>(fr1, a.T2, 3 * t + 1, lane);       /* (barriers: the requests stay AHEAD of the MFMA group that hides them) */
-        __builtin_amdgcn_sched_barrier(0);
-        h2_split8(ow, bhi, blo);
-        h2_mfma3<4>(acc, fr0, bhi, blo);
-        __builtin_amdgcn_sched_barrier(0);
-        h2a_load<4>(fr0, a.T2, 3 * t + 2, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        h2_split8(oh, bhi, blo);
-        h2_mfma3<4>(acc, fr1, bhi, blo);
-        __builtin_amdgcn_sched_barrier(0);
-        h2_split8(os, bhi, blo);
-        h2_mfma3<4>(acc, fr0, bhi, blo);
-        __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-        if (t == 1) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][15])); SBD_TS(18); }
-#endif
-        h2a_load<4>(fr0, a.T2, 3 * t + 3 < S2 ? 3 * t + 3 : S2 - 1, lane);     /* the next slot's (or the first knot-K) k-step */
-        const int so = own ? go + dim * (4 * K) : OOB;
-        store8(ow, so); store8(oh, so + d * (4 * K)); store8(os, so + 2 * d * (4 * K));
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gx), rs_gy, own ? gyo + dim * 4 : OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, g_slot), rs_g, (own && cur.slot >= 0) ? go + (3 * d * K + cur.slot) * 4 : OOB, 0, 0);
-        s_f[j * H2_SLAB + ((own && cur.slot >= 0) ? cur.slot : 128)] = g_slot;
-        __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-        if (t < 12) SBD_TS(2 + t);
-#endif
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int s = 0; 16 * s < sa.n_nc; ++s) {
-        if (s > 0) h2a_load<4>(fr0, a.T2, 3 * T + s, lane);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int o = 16 * s + 8 * hh + e;
-            v[e] = o < sa.n_nc ? s_f[j * H2_SLAB + o] : 0.0f;
-        }
-        h2_h16x8 bhi, blo;
-        h2_split8(v, bhi, blo);
-        h2_mfma3<4>(acc, fr0, bhi, blo);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     SBD_TS(14);
     dx_chain_tail<FT>(a, acc, s_f, b0, lane, rows);
 #if BGK_SBD_TS
@@ -429,9 +268,8 @@ __global__ __launch_bounds__(DW * 64, 2) void spline_bwd_dx_kernel(SplineBwdArgs
  * the layer), k in natural order (natural = 1: ksrc = k) or in accumulator order (ksrc = hidden unit of slot k) */
 struct PackT {
     const float* W; int rows_src, cols_src;   /* the layer's weight [rows_src = out features, cols_src = in features] */
-    int NT, S, natural;        /* natural = 2: the spline's element order (spline_bwd_dx_kernel), d dims, n_nc knot-K slopes */
+    int NT, S, natural;
     _Float16* out;
-    int d, n_nc;
 };
 
 /* the three layers in one launch: workgroups [first[q], first[q + 1]) pack layer q */
@@ -454,17 +292,7 @@ __device__ __forceinline__ void pack_t_body(const PackTGroup& g, const float* cs
         const int col = 32 * m + i;                                  /* input feature of the layer */
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int k = L.natural ? 16 * s + 8 * kb + e : 32 * (s >> 1) + (e & 3) + 8 * (2 * (s & 1) + (e >> 2)) + 4 * kb;
-            if (L.natural == 2) {
-                const int T = (L.d + 1) >> 1;
-                if (s < 3 * T) {
-                    const int t = s / 3, q = s - 3 * t, dim = 2 * t + kb;
-                    k = dim < L.d ? (q * L.d + dim) * 8 + e : L.rows_src;
-                } else {
-                    const int o = 16 * (s - 3 * T) + 8 * kb + e;
-                    k = o < L.n_nc ? 3 * L.d * 8 + o : L.rows_src;
-                }
-            }
+            const int k = L.natural ? 16 * s + 8 * kb + e : 32 * (s >> 1) + (e & 3) + 8 * (2 * (s & 1) + (e >> 2)) + 4 * kb;
             float v = 0.0f;
             if (k < L.rows_src && col < L.cols_src) v = L.W[(int64_t)k * L.cols_src + col] * scale;
             const _Float16 h = (_Float16)v;
@@ -490,12 +318,12 @@ __global__ __launch_bounds__(256) void pack_t_many_kernel(PackTMany) {
 }  // namespace
 
 static int pack_t_fill(PackTGroup& g, const float* W0, int n_in, const float* W1, const float* W2, int P, void* T0, void* T1,
-                       void* T2, int d, int n_nc) {
+                       void* T2) {
     const int FT = (n_in + 31) / 32;
-    const int S2 = d > 0 ? 3 * ((d + 1) / 2) + (n_nc + 15) / 16 : ((P + 15) / 16 + DBWD_PAD - 1) / DBWD_PAD * DBWD_PAD;
-    const PackT L2{W2, P, 128, 4, S2, d > 0 ? 2 : 1, (_Float16*)T2, d, n_nc};   /* M[hidden i][k] = W2[col(k)][i], col = output column of the MLP */
-    const PackT L1{W1, 128, 128, 4, 8, 0, (_Float16*)T1, 0, 0};      /* M[i][k] = W1[unit(k)][i] */
-    const PackT L0{W0, 128, n_in, FT, 8, 0, (_Float16*)T0, 0, 0};    /* M[feature i][k] = W0[unit(k)][i] */
+    const int S2 = ((P + 15) / 16 + DBWD_PAD - 1) / DBWD_PAD * DBWD_PAD;
+    const PackT L2{W2, P, 128, 4, S2, 1, (_Float16*)T2};   /* M[hidden i][k] = W2[col(k)][i], col = output column of the MLP */
+    const PackT L1{W1, 128, 128, 4, 8, 0, (_Float16*)T1};      /* M[i][k] = W1[unit(k)][i] */
+    const PackT L0{W0, 128, n_in, FT, 8, 0, (_Float16*)T0};    /* M[feature i][k] = W0[unit(k)][i] */
     g.L[0] = L0; g.L[1] = L1; g.L[2] = L2;
     int n_wg = 0;
     for (int l = 0; l < 3; ++l) {
@@ -508,9 +336,9 @@ static int pack_t_fill(PackTGroup& g, const float* W0, int n_in, const float* W1
 }
 
 static int pack_t_launch(const float* W0, int n_in, const float* W1, const float* W2, int P, const float* cs, void* T0, void* T1,
-                         void* T2, int d, int n_nc, hipStream_t st) {
+                         void* T2, hipStream_t st) {
     PackTGroup g;
-    const int n_wg = pack_t_fill(g, W0, n_in, W1, W2, P, T0, T1, T2, d, n_nc);
+    const int n_wg = pack_t_fill(g, W0, n_in, W1, W2, P, T0, T1, T2);
     hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, g, cs);
     return 0;
 }
@@ -529,7 +357,7 @@ extern "C" int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const
             const int i = base + c;
             BGK_CHECK_ARG(W0[i] && W1[i] && W2[i] && cs[i] && T0[i] && T1[i] && T2[i] && n_in[i] > 0 && n_in[i] <= 96 && P[i] > 0,
                           "bgk_pack_dense_h2_t_many: bad conditioner %d", i);
-            const int n_wg = pack_t_fill(M.c[c].g, W0[i], n_in[i], W1[i], W2[i], P[i], T0[i], T1[i], T2[i], 0, 0);
+            const int n_wg = pack_t_fill(M.c[c].g, W0[i], n_in[i], W1[i], W2[i], P[i], T0[i], T1[i], T2[i]);
             M.c[c].cs = cs[i];
             max_wg = n_wg > max_wg ? n_wg : max_wg;
         }
@@ -543,18 +371,8 @@ extern "C" int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W
                                    const float* cs, void* T0, void* T1, void* T2, void* stream) {
     BGK_CHECK_ARG(W0 && W1 && W2 && cs && T0 && T1 && T2, "bgk_pack_dense_h2_t: null pointer");
     BGK_CHECK_ARG(n_in > 0 && n_in <= 96 && P > 0, "bgk_pack_dense_h2_t: bad sizes (n_in <= 96)");
-    pack_t_launch(W0, n_in, W1, W2, P, cs, T0, T1, T2, 0, 0, (hipStream_t)stream);
+    pack_t_launch(W0, n_in, W1, W2, P, cs, T0, T1, T2, (hipStream_t)stream);
     return bgk_launch_status("bgk_pack_dense_h2_t");
-}
-
-/* the same three operands with W2^T's columns in the element order of bgk_spline_backward_dx (n_bins = 8): T2 holds
- * 3 ceil(d / 2) + ceil((P - 24 d) / 16) k-steps (x 8 blocks + 4) */
-extern "C" int bgk_pack_spline_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P, int32_t d,
-                                 const float* cs, void* T0, void* T1, void* T2, void* stream) {
-    BGK_CHECK_ARG(W0 && W1 && W2 && cs && T0 && T1 && T2, "bgk_pack_spline_t: null pointer");
-    BGK_CHECK_ARG(n_in > 0 && n_in <= 96 && d > 0 && d <= 64 && P >= 24 * d && P <= 25 * d, "bgk_pack_spline_t: bad sizes (n_in <= 96, d <= 64, 24 d <= P <= 25 d)");
-    pack_t_launch(W0, n_in, W1, W2, P, cs, T0, T1, T2, d, P - 24 * d, (hipStream_t)stream);
-    return bgk_launch_status("bgk_pack_spline_t");
 }
 
 extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,
@@ -584,45 +402,4 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     else if (FT == 2) hipLaunchKernelGGL(dense_bwd_dx_kernel<2>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a);
     else hipLaunchKernelGGL(dense_bwd_dx_kernel<3>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a);
     return bgk_launch_status("bgk_dense_backward_dx");
-}
-
-extern "C" int bgk_spline_backward_dx(const float* y, int64_t ldy, const float* params, int64_t ldp, int32_t P,
-                                      const int32_t* nc_slot, int64_t B, int32_t d, int32_t K, int32_t inverse,
-                                      double left, double right, double bottom, double top,
-                                      double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
-                                      const float* g_out, int64_t ldgo, const float* g_dlogp, float* g_y, int64_t ldgy,
-                                      float* g_params, int64_t ldgp,
-                                      const float* z1, const float* z0, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
-                                      const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
-                                      float* g_z1, float* g_z0, float* h1, float* h0, float* g_cond, int64_t ldgc, void* stream) {
-    if (B == 0) return 0;
-    BGK_CHECK_ARG(y && params && nc_slot && g_out && g_dlogp && g_y && g_params, "bgk_spline_backward_dx: null pointer");
-    BGK_CHECK_ARG(z1 && z0 && T0 && T1 && T2 && cs && g_z1 && g_z0, "bgk_spline_backward_dx: null pointer");
-    BGK_CHECK_ARG((h1 == nullptr) == (h0 == nullptr), "bgk_spline_backward_dx: h1 and h0 are written both or not at all");
-    BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0 && act >= 1 && act <= 3, "bgk_spline_backward_dx: bad sizes");
-    BGK_CHECK_ARG(!(g_cond && periodic && !cond), "bgk_spline_backward_dx: the periodic featuriser needs the conditioner input");
-    if (K != 8 || d > 64) { bgk_set_error("bgk_spline_backward_dx: n_bins = 8 and <= 64 transformed dims (got %d, %d)", K, d); return BGK_EUNSUPPORTED; }
-    BGK_CHECK_ARG(P >= 3 * K * d && P <= 3 * K * d + d && ldp >= P && ldgp >= P, "bgk_spline_backward_dx: bad params width %d", P);
-    const int n_in = periodic ? 2 * d_c : d_c;
-    if (n_in > 96) { bgk_set_error("bgk_spline_backward_dx: %d input features > 96", n_in); return BGK_EUNSUPPORTED; }
-    SplineBwdArgs sa;
-    DenseBwdArgs& a = sa.m;
-    a.g = nullptr; a.ldg = 0; a.P = P; a.z1 = z1; a.z0 = z0; a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
-    a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.cs = cs; a.act = act; a.B = B;
-    a.g_z1 = g_z1; a.g_z0 = g_z0; a.h1 = h1; a.h0 = h0; a.g_cond = g_cond; a.ldgc = ldgc;
-    sa.y = y; sa.ldy = ldy; sa.params = params; sa.ldp = ldp; sa.nc_slot = nc_slot; sa.g_out = g_out; sa.ldgo = ldgo;
-    sa.g_dlogp = g_dlogp; sa.g_y = g_y; sa.ldgy = ldgy; sa.g_params = g_params; sa.ldgp = ldgp;
-    sa.d = d; sa.n_nc = P - 3 * K * d; sa.inverse = inverse;
-    a.S2 = 3 * ((d + 1) / 2) + (sa.n_nc + 15) / 16;
-    sa.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, K);
-    const int FT = (n_in + 31) / 32;
-    a.lds_per_wave = 32 * H2_SLAB > 32 * FT * DSROW ? 32 * H2_SLAB : 32 * FT * DSROW;
-    const size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;
-    const int64_t n_wg = ((B + 31) / 32 + DW - 1) / DW;
-    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_spline_backward_dx: batch too large for one launch");
-    hipStream_t st = (hipStream_t)stream;
-    if (FT == 1) hipLaunchKernelGGL(spline_bwd_dx_kernel<1>, dim3((int)n_wg), dim3(DW * 64), shmem, st, sa);
-    else if (FT == 2) hipLaunchKernelGGL(spline_bwd_dx_kernel<2>, dim3((int)n_wg), dim3(DW * 64), shmem, st, sa);
-    else hipLaunchKernelGGL(spline_bwd_dx_kernel<3>, dim3((int)n_wg), dim3(DW * 64), shmem, st, sa);
-    return bgk_launch_status("bgk_spline_backward_dx");
 }

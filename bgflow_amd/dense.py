@@ -562,6 +562,8 @@ def pack_dense_for_fused_h2_device(linears, src_col_dev, n_chunks, bufs=None, bf
     return A0, A1, A2, cs
 
 
+T_OPERAND_MAX_IN = 96     # widest conditioner input bgk_pack_dense_h2_t / bgk_dense_backward_dx take (three 32-feature output tiles)
+
 BATCHED_REPACK = True     # training.FlatAdam.step re-packs the operands of every fused training layer in three launches
 
 _TRAIN_PLANS = weakref.WeakSet()      # transformers whose fused plan ran a training forward on device-packed split-f16 operands
@@ -612,7 +614,6 @@ def repack_training_plans(param_ids=None):
         n = len(items)
         vps, i32s = (ctypes.c_void_p * n), (ctypes.c_int32 * n)
         col = lambda f: vps(*[f(it) for it in items])       # noqa: E731
-        tb = [_t_operand_bufs(it[0].setdefault("tbufs", {}), it[3].out_features, it[1].in_features, dev) for it in items]
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_pack_dense_h2_many(
                 n, col(lambda it: it[4][0].data_ptr()), col(lambda it: it[4][1].data_ptr()), i32s(*[it[1].in_features for it in items]),
@@ -622,16 +623,24 @@ def repack_training_plans(param_ids=None):
                 col(lambda it: it[0]["bufs"][0].data_ptr()), col(lambda it: it[0]["bufs"][1].data_ptr()),
                 col(lambda it: it[0]["bufs"][2].data_ptr()), col(lambda it: it[0]["bufs"][3].data_ptr()), _lib.stream_ptr(dev))
             _lib.check(st, "bgk_pack_dense_h2_many")
-            st = _lib.lib().bgk_pack_dense_h2_t_many(
-                n, col(lambda it: it[4][0].data_ptr()), i32s(*[it[1].in_features for it in items]),
-                col(lambda it: it[4][2].data_ptr()), col(lambda it: it[4][4].data_ptr()), i32s(*[it[3].out_features for it in items]),
-                col(lambda it: it[0]["bufs"][3].data_ptr()),
-                vps(*[t[0].data_ptr() for t in tb]), vps(*[t[1].data_ptr() for t in tb]), vps(*[t[2].data_ptr() for t in tb]),
-                _lib.stream_ptr(dev))
-            _lib.check(st, "bgk_pack_dense_h2_t_many")
-        for cache, _l0, _l1, _l2, _params, version in items:
+            # the transposed operands of the input-gradient chain exist for conditioner inputs of <= T_OPERAND_MAX_IN features only
+            # (wider layers run that chain as GEMMs, _FusedSplineTrainFn.backward): those layers get the forward operands alone
+            t_items = [it for it in items if it[1].in_features <= T_OPERAND_MAX_IN]
+            if t_items:
+                m = len(t_items)
+                tb = [_t_operand_bufs(it[0].setdefault("tbufs", {}), it[3].out_features, it[1].in_features, dev) for it in t_items]
+                tcol = lambda f: (ctypes.c_void_p * m)(*[f(it) for it in t_items])       # noqa: E731
+                st = _lib.lib().bgk_pack_dense_h2_t_many(
+                    m, tcol(lambda it: it[4][0].data_ptr()), (ctypes.c_int32 * m)(*[it[1].in_features for it in t_items]),
+                    tcol(lambda it: it[4][2].data_ptr()), tcol(lambda it: it[4][4].data_ptr()),
+                    (ctypes.c_int32 * m)(*[it[3].out_features for it in t_items]), tcol(lambda it: it[0]["bufs"][3].data_ptr()),
+                    (ctypes.c_void_p * m)(*[t[0].data_ptr() for t in tb]), (ctypes.c_void_p * m)(*[t[1].data_ptr() for t in tb]),
+                    (ctypes.c_void_p * m)(*[t[2].data_ptr() for t in tb]), _lib.stream_ptr(dev))
+                _lib.check(st, "bgk_pack_dense_h2_t_many")
+        for cache, l0, _l1, _l2, _params, version in items:
             cache["version"] = version
-            cache["tbufs"]["t_version"] = (version[0], version[2], version[4])
+            if l0.in_features <= T_OPERAND_MAX_IN:
+                cache["tbufs"]["t_version"] = (version[0], version[2], version[4])
         done += n
     return done
 
@@ -822,55 +831,6 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
     return out[0], out[1], (out[2] if want_h else None), (out[3] if want_h else None), g_x
 
 
-# n_bins = 8: the spline's VJP inside the launch of the conditioner's input-gradient chain (bgk_spline_backward_dx).  OFF by default:
-# measured on MI355X at 2^18 samples it is SLOWER than bgk_rqs_backward + bgk_dense_backward_dx (0.63 vs 0.33 + 0.18 ms per layer,
-# DESIGN.md section 3): the chain kernel runs two waves per SIMD and every memory round trip of the element pipeline is exposed,
-# the stand-alone VJP kernel runs five and sits at the HBM rate.  BGK_SPLINE_BACKWARD_FUSED=1 selects it (parity-tested either way).
-FUSED_SPLINE_BACKWARD = os.environ.get("BGK_SPLINE_BACKWARD_FUSED", "0") == "1"
-
-
-def _spline_backward_dx(y, params, nc_dev, rcfg, g_out, g_dlogp, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs):
-    """bgk_pack_spline_t + bgk_spline_backward_dx: returns (g_y, g_params, g_z1, g_z0, g_x or None); the activations are never
-    written (the weight-gradient kernel recomputes them from z1 / z0)"""
-    n_bins, inverse, left, right, bottom, top, settings = rcfg
-    dev = y.device
-    d = y.shape[-1]
-    P = params.shape[-1]
-    n_in = W0.shape[1]
-    FT, S2 = (n_in + 31) // 32, 3 * ((d + 1) // 2) + (P - 24 * d + 15) // 16
-    key = ("spline", P, d, n_in, str(dev))
-    if bufs.get("skey") != key:
-        bufs.update(skey=key, sT0=torch.empty((8 * FT * 2 + FT, 64, 8), dtype=torch.float16, device=dev),
-                    sT1=torch.empty((8 * 8 + 4, 64, 8), dtype=torch.float16, device=dev),
-                    sT2=torch.empty((S2 * 8 + 4, 64, 8), dtype=torch.float16, device=dev))
-    T0, T1, T2 = bufs["sT0"], bufs["sT1"], bufs["sT2"]
-    y2, ldy = _lib.rowmajor(y)
-    p2, ldp = _lib.rowmajor(params)
-    x2, ldc = _lib.rowmajor(x.detach())
-    B, d_c = y2.shape[0], x2.shape[1]
-    g_out2 = g_out.contiguous()
-    g_dl = g_dlogp.reshape(-1).contiguous()
-    g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
-    ldgp = row_pitch(P)
-    g_p = torch.empty((B, ldgp), dtype=torch.float32, device=dev)[:, :P]
-    out = torch.empty((2, B, 128), dtype=torch.float32, device=dev)
-    g_x = torch.empty((B, d_c), dtype=torch.float32, device=dev) if want_gx else None
-    ws = [w.detach().contiguous() for w in (W0, W1, W2)]
-    with torch.cuda.device(dev):
-        st = _lib.lib().bgk_pack_spline_t(_lib.ptr(ws[0]), n_in, _lib.ptr(ws[1]), _lib.ptr(ws[2]), P, d, _lib.ptr(cs),
-                                          _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_pack_spline_t")
-        st = _lib.lib().bgk_spline_backward_dx(
-            _lib.ptr(y2), ldy, _lib.ptr(p2), ldp, P, _lib.ptr(nc_dev), B, d, n_bins, int(inverse),
-            left, right, bottom, top, settings["min_bin_width"], settings["min_bin_height"], settings["min_derivative"],
-            int(settings.get("enable_identity_init", False)),
-            _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), ldgp,
-            _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic), _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.ptr(cs),
-            act_code, _lib.ptr(out[0]), _lib.ptr(out[1]), None, None, _lib.ptr(g_x), d_c, _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_spline_backward_dx")
-    return g_y, g_p, out[0], out[1], g_x
-
-
 FUSED_WEIGHT_GRAD = True     # weight / bias gradients on bgk_dense_weight_grad (False: split-K bmm + bgk_column_sum)
 
 _DIRECT_GRADS = [False]
@@ -978,7 +938,7 @@ class _FusedSplineTrainFn(torch.autograd.Function):
     + the MLP's backward as plain GEMMs on the saved tensors (bias gradients on bgk_column_sum)."""
 
     @staticmethod
-    def forward(ctx, x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob):
+    def forward(ctx, x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob, t_version=None):
         A0, A1, A2, (c0, c1, c2) = plan["packed"]
         x2, ldc = _lib.rowmajor(x)
         y2, ldy = _lib.rowmajor(y)
@@ -1004,6 +964,10 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         ctx.params = (W0, b0, W1, b1, W2, b2)   # the nn.Parameters themselves (flat-bucket gradient destinations hang on them)
         ctx.cs = plan.get("cs")                 # scale table of the operands packed for this forward (same weights in backward)
         ctx.tbufs = plan.setdefault("tbufs", {})
+        # state of the three weight PARAMETERS this forward ran on: the key of the transposed operands the backward packs / reuses.
+        # (W0..W2 themselves may be temporaries -- the zero-padded views of a narrow conditioner -- whose (data_ptr, version) repeats
+        # from step to step once the caching allocator recycles their storage: never key a cache on them.)
+        ctx.t_version = t_version
         ctx.meta = (plan["act"], bool(plan["periodic"]), (plan["n_bins"], inverse, left, right, bottom, top, dict(s)))
         return out, dlogp[:, None]
 
@@ -1017,22 +981,14 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         cs = ctx.cs
         fused_wg = FUSED_WEIGHT_GRAD and y.is_cuda and W0.shape[1] <= 128
         recompute_h = False
-        fused_dx = cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= 96
-        fused_vjp = fused_dx and fused_wg and FUSED_SPLINE_BACKWARD and rcfg[0] == 8 and y.shape[-1] <= 64
-        if not fused_vjp:
-            g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp)
-        if fused_vjp:
-            # one launch: the spline's VJP feeds the first GEMM of the chain from registers (g_params written, not read back)
-            recompute_h = True
-            g_y, g_p, g_z1, g_z0, g_x = _spline_backward_dx(y, params, nc_dev, rcfg, g_out, g_dlogp, z1, z0, x, W0, W1, W2, cs,
-                                                            act_code, periodic, need[0], ctx.tbufs)
-            h1 = h0 = None
-        elif fused_dx:
+        fused_dx = cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= T_OPERAND_MAX_IN
+        g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp)
+        if fused_dx:
             # with the fused weight-gradient kernel downstream the activations h1 / h0 are not materialised: it re-applies the
             # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)
             recompute_h = fused_wg
             g_z1, g_z0, h1, h0, g_x = _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, need[0], ctx.tbufs,
-                                                         want_h=not recompute_h, t_version=tuple(param_state_key(p) for p in ctx.params[::2]))
+                                                         want_h=not recompute_h, t_version=ctx.t_version)
         else:
             h1 = act(z1)
             g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
@@ -1061,7 +1017,7 @@ class _FusedSplineTrainFn(torch.autograd.Function):
             gb1 = column_sum(g_z1) if need[5] else None
             gW0 = _gram_tn(g_z0, feats.contiguous()) if need[2] else None
             gb0 = column_sum(g_z0) if need[3] else None
-        return (g_x, g_y if need[1] else None, gW0, gb0, gW1, gb1, gW2, gb2) + (None,) * 5
+        return (g_x, g_y if need[1] else None, gW0, gb0, gW1, gb1, gW2, gb2) + (None,) * 6
 
 
 def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob_counter):
@@ -1083,6 +1039,7 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
     (l0, l1, l2), _ = _fusable_dense(inner)
     tcfg = (transformer._left, transformer._right, transformer._bottom, transformer._top, transformer._default_settings)
     W0, b0, W1, b1, W2, b2 = l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias
+    t_version = tuple(param_state_key(p) for p in (W0, W1, W2))      # of the parameters, before any padding
     if plan.get("padded"):
         # hidden layers narrower than the kernels' 128 units: the operands packed for the forward are the zero-padded layers
         # (_pad_hidden); the backward kernels get the same padded matrices as differentiable views of the parameters
@@ -1092,5 +1049,5 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
         W0, b0 = pad(W0, (0, 0, 0, h0)), pad(b0, (0, h0))
         W1, b1 = pad(W1, (0, h0, 0, h1)), pad(b1, (0, h1))
         W2 = pad(W2, (0, h1))
-    return _FusedSplineTrainFn.apply(x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob_counter)
+    return _FusedSplineTrainFn.apply(x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob_counter, t_version)
 

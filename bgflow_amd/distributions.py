@@ -256,24 +256,55 @@ def philox_sample(fields, n_samples, device, seed, offset, row0=0, want_energy=F
     return outs, (None if energy is None else energy[:, None])
 
 
-_PHILOX_STREAMS = [0]          # process-wide count of fused-sampling objects: every object draws from its own Philox stream
+_PHILOX_STREAMS = [0]          # next automatically assigned stream id (construction-order fallback, see _FusedSampling)
+_PHILOX_LIVE = {}              # stream id -> weak reference of the live object that draws from it
 PHILOX_MAX_WIDTH = 160         # widest field bgk_philox_fields assembles in its LDS tile (4 waves x 64 rows x d floats)
+
+
+def _philox_claim(obj, stream):
+    """register ``obj`` as the owner of Philox stream ``stream``; a stream another LIVE object already draws from is a collision
+    (two priors would produce the same numbers): warn, once per pair"""
+    import warnings
+    import weakref
+    holder = _PHILOX_LIVE.get(stream)
+    other = holder() if holder is not None else None
+    if other is not None and other is not obj:
+        warnings.warn(f"Philox stream {stream} is already used by a live {type(other).__name__}: {type(obj).__name__} will draw the SAME "
+                      f"numbers under the same seed (give one of them another id with set_philox_stream)", RuntimeWarning, stacklevel=3)
+    _PHILOX_LIVE[stream] = weakref.ref(obj)
+    for k in [k for k, r in _PHILOX_LIVE.items() if r() is None]:
+        del _PHILOX_LIVE[k]
 
 
 class _FusedSampling(torch.nn.Module):
     """Opt-in (``sample_fused=True``) sampling on bgk_philox_fields.  Key = ``torch.initial_seed()`` (so ``torch.manual_seed`` still
-    selects the stream) mixed with the data-parallel rank AND a per-object stream id (assigned in construction order on first use):
-    two priors of equal shape in one process draw independent numbers.  Offset = a per-object call counter.  Stream id and counter
-    travel in ``state_dict`` once the object has sampled (key ``_philox_state``; absent otherwise, so reference state_dicts load
-    unchanged): a resumed run continues the stream instead of replaying it.  The prior energy of a sample comes out of the same
-    launch and is handed back by ``energy`` when it is asked about exactly these, unmodified tensors."""
+    selects the stream) mixed with the data-parallel rank AND a per-object stream id: two priors of equal shape in one process draw
+    independent numbers.  The id is either given (``set_philox_stream(k)``: reproducible whatever else the process samples -- the
+    builder numbers the priors it makes) or, on first use, the smallest id no live object holds (then it depends on which other
+    fused-sampling objects sampled before).  Offset = a per-object call counter.  Stream id and counter travel in ``state_dict`` once
+    the object has sampled (key ``_philox_state``; absent otherwise, so reference state_dicts load unchanged): a resumed run
+    continues the stream instead of replaying it; loading an id a live object already holds warns.  The prior energy of a sample
+    comes out of the same launch and is handed back by ``energy`` when it is asked about exactly these, unmodified tensors."""
     sample_fused = False
+
+    def set_philox_stream(self, stream, calls=0):
+        """draw from Philox stream ``stream`` (a non-negative int), continuing at call ``calls``"""
+        stream = int(stream)
+        if stream < 0:
+            raise ValueError("set_philox_stream: the stream id is a non-negative integer")
+        self.__dict__["_philox_state"] = [stream, int(calls)]
+        _philox_claim(self, stream)
+        return self
 
     def _philox_ids(self):
         st = self.__dict__.get("_philox_state")
         if st is None:
-            st = self.__dict__["_philox_state"] = [_PHILOX_STREAMS[0], 0]      # [stream id, calls]
-            _PHILOX_STREAMS[0] += 1
+            k = _PHILOX_STREAMS[0]
+            while k in _PHILOX_LIVE and _PHILOX_LIVE[k]() is not None:       # ids given out by hand / loaded from a checkpoint
+                k += 1
+            _PHILOX_STREAMS[0] = k + 1
+            st = self.__dict__["_philox_state"] = [k, 0]      # [stream id, calls]
+            _philox_claim(self, k)
         return st
 
     def _fused_sample(self, fields, n_samples, device, temperature, c_out=0.0):
@@ -307,7 +338,7 @@ class _FusedSampling(torch.nn.Module):
         st = state_dict.pop(prefix + "_philox_state", None)
         if st is not None:
             self.__dict__["_philox_state"] = [int(st[0]), int(st[1])]
-            _PHILOX_STREAMS[0] = max(_PHILOX_STREAMS[0], int(st[0]) + 1)
+            _philox_claim(self, int(st[0]))
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
 

@@ -121,6 +121,15 @@ class LossReporter:
         return np.array([self._np(raw[-n_recent:]) for raw in self._raw])
 
 
+def _bump_versions(params):
+    """mark ``params`` as modified in place for torch (a kernel wrote through the flat bucket they are views of)"""
+    bump = getattr(torch.autograd.graph, "increment_version", None)
+    if bump is None:                      # older torch: the private spelling
+        bump = torch._C._increment_version
+    for p in params:
+        bump(p)
+
+
 class FlatAdam(torch.optim.Optimizer):
     """Adam (torch.optim.Adam semantics: lr, betas, eps, L2 weight_decay) over one flat f32 bucket on a HIP device."""
 
@@ -204,11 +213,14 @@ class FlatAdam(torch.optim.Optimizer):
                                          self.flat.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                          float(g["weight_decay"]), self._step, _lib.ptr(self._flag) if skip_on_nan else None,
                                          _lib.ptr(self._skipped), _lib.stream_ptr(dev)), "bgk_adam_step")
-        # the kernel wrote through the bucket, which torch's version counters do not see: bump the generation counter the
-        # packed-operand caches of the fused kernels are keyed on (dense.param_state_key)
+        # the kernel wrote through the bucket, which torch's version counters do not see: bump them by hand -- caches keyed on
+        # ``_version`` (UniformDistribution._const_host, user code) and autograd's saved-tensor check (a backward through a graph
+        # retained across this step raises instead of silently using the new weights) then see the update like any in-place op --
+        # and the generation counter the packed-operand caches of the fused kernels are keyed on as well (dense.param_state_key)
         self.generation += 1
         for p in self._params:
             p._bgk_generation = self.generation
+        _bump_versions(self._params)
         # ... and re-pack those operands now, for all fused layers at once (three launches instead of five per layer at their next use)
         from . import dense
         dense.repack_training_plans(self._param_ids)

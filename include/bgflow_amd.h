@@ -439,26 +439,6 @@ int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z
                           int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
                           float* g_cond, int64_t ldgc, void* stream);
 
-/* bgk_rqs_backward + bgk_dense_backward_dx of one spline coupling layer in ONE launch (n_bins = 8, <= 64 transformed dims;
- * autograd of nn/flow/transformer/spline.py:109-188 chained into nn/dense.py:47-48): the spline's VJP is evaluated by the lane that
- * feeds its 24 parameter gradients to the first GEMM of the chain as matrix operands, so g_params [B, P] is written (for
- * bgk_dense_weight_grad) but never read back.  Arguments = those of the two functions (g_params takes the place of g); T0..T2 from
- * bgk_pack_spline_t: bgk_pack_dense_h2_t with W2^T's columns in the element order (per pair of dims: widths, heights, slopes;
- * the knot-K slopes of the non-circular dims last), T2 sized (3 ceil(d / 2) + ceil((P - 24 d) / 16)) * 8 + 4 KiB blocks.
- * Results: identical arithmetic to the two-launch path for g_y and g_params; g_z1 / g_z0 / g_cond differ by the summation order
- * of the first GEMM only. */
-int bgk_pack_spline_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P, int32_t d,
-                      const float* cs, void* T0, void* T1, void* T2, void* stream);
-int bgk_spline_backward_dx(const float* y, int64_t ldy, const float* params, int64_t ldp, int32_t P,
-                           const int32_t* nc_slot, int64_t B, int32_t d, int32_t K, int32_t inverse,
-                           double left, double right, double bottom, double top,
-                           double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
-                           const float* g_out, int64_t ldgo, const float* g_dlogp, float* g_y, int64_t ldgy,
-                           float* g_params, int64_t ldgp,
-                           const float* z1, const float* z0, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
-                           const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
-                           float* g_z1, float* g_z0, float* h1, float* h0, float* g_cond, int64_t ldgc, void* stream);
-
 /* Optimizer step on the flat parameter bucket (f-2: the optimizer of KLTrainer.train, nn/training/trainers.py:148-201).
  * bgk_grad_nan_flag sets flag[0] = any(isnan(g)) on the device (the reference's "found nan in grad; skipping optimization
  * step" check, trainers.py:198-201, without a host round trip); bgk_adam_step is torch.optim.Adam's update (step = 1, 2, ...:

@@ -352,48 +352,6 @@ def test_fused_training_with_narrow_hidden_layers(hip_lib, dev, hidden, inverse)
             assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-6), f"{what}|{on}: gradient of shape {tuple(a.shape)}"
 
 
-@pytest.mark.parametrize("inverse", [False, True])
-@pytest.mark.parametrize("B", [3001, 17])
-def test_spline_vjp_inside_the_input_gradient_launch(hip_lib, dev, inverse, B):
-    """n_bins = 8 training backward in one launch (the opt-in bgk_spline_backward_dx: the spline's VJP feeds the first GEMM of the conditioner's
-    input-gradient chain from registers) against the two-launch path (bgk_rqs_backward, then bgk_dense_backward_dx reading g_params
-    back): the same element arithmetic, so input gradients of the transformed block and the last layer's weight gradients agree to
-    rounding of the reductions; everything behind the first GEMM differs by its summation order only.  Odd and even numbers of
-    transformed dims, circular and non-circular ones (knot-K slopes in their own operand k-steps), periodic and plain conditioner
-    inputs, a ragged last tile."""
-    from bgflow_amd import configs, dense
-    from bgflow_amd.utils import hash_init_
-    dims = {"BONDS": 17, "ANGLES": 16, "TORSIONS": 17, "FIXED": 1}
-    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
-    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
-    for what, on in (("TORSIONS", "FIXED"), ("FIXED", "TORSIONS"), ("BONDS", "ANGLES"), ("ANGLES", "BONDS")):
-        layer = hash_init_(configs._spline_coupling(what, on, dims, circ, slot)).to(dev)
-        res = {}
-        default = dense.FUSED_SPLINE_BACKWARD
-        for fused in (True, False):
-            calls = []
-            orig = dense._spline_backward_dx
-            dense._spline_backward_dx = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-            dense.FUSED_SPLINE_BACKWARD = fused
-            try:
-                layer.zero_grad()
-                xs = [torch.rand(B, dims[f], device=dev, generator=torch.Generator(device=dev).manual_seed(5 + i)).requires_grad_(True)
-                      for i, f in enumerate(configs.IC_FIELDS)]
-                *out, dl = layer(*xs, inverse=inverse)
-                w = torch.linspace(0.5, 1.5, B, device=dev)[:, None]
-                (sum((o * o * w).sum() for o in out) + (dl * w).sum()).backward()
-            finally:
-                dense._spline_backward_dx = orig
-                dense.FUSED_SPLINE_BACKWARD = default
-            assert bool(calls) == fused, "the one-launch backward must (not) have run"
-            res[fused] = ([p.grad.clone() for p in layer.parameters()], [x.grad.clone() for x in xs if x.grad is not None])
-        (gp1, gx1), (gp0, gx0) = res[True], res[False]
-        assert len(gx1) == len(gx0) >= 2
-        for a, b in zip(gp1 + gx1, gp0 + gx0):
-            assert a.shape == b.shape and bool(torch.isfinite(a).all())
-            assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6), f"{what}|{on}: gradient of shape {tuple(a.shape)}"
-
-
 def test_batched_repack_after_the_optimizer_step(hip_lib, dev):
     """FlatAdam.step re-packs the operands of every fused training layer in three launches (bgk_pack_dense_h2_many /
     bgk_pack_dense_h2_t_many): bit-identical to the per-layer packs (bgk_pack_dense_h2, bgk_pack_dense_h2_t) of the same weights, the

@@ -482,14 +482,6 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
     assert L.bgk_dense_backward_dx(P1, 425, 425, P1, P1, P1, 120, 120, 0, P1, P1, P1, P1, 1, 8, P1, P1, P1, P1, None, 0, None) == -2
     assert L.bgk_column_sum(P1, 4, 8, 0, P1, 4, P1, None) == -1
     # round 4 entry points: empty batches, envelope and argument checks before any launch
-    spl = lambda B, d, K, P, n_in_cols: L.bgk_spline_backward_dx(   # noqa: E731
-        P1, d, P1, P, P, P1, B, d, K, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, d, P1, P1, d, P1, P,
-        P1, P1, P1, n_in_cols, n_in_cols, 0, P1, P1, P1, P1, 1, P1, P1, None, None, None, 0, None)
-    assert spl(0, 17, 8, 425, 17) == 0
-    assert spl(8, 17, 4, 221, 17) == -2 and "n_bins = 8" in err()
-    assert spl(8, 17, 8, 500, 17) == -1 and "bad params width" in err()
-    assert spl(8, 17, 8, 425, 120) == -2 and "input features > 96" in err()
-    assert L.bgk_pack_spline_t(P1, 17, P1, P1, 425, 80, P1, P1, P1, P1, None) == -1 and "d <= 64" in err()
     n1 = (ctypes.c_void_p * 1)(0x1000)
     i1 = (ctypes.c_int32 * 1)(0)
     assert L.bgk_pack_dense_h2_many(0, n1, n1, i1, n1, n1, n1, n1, i1, n1, i1, n1, n1, n1, n1, None) == 0      # no conditioner: no launch
