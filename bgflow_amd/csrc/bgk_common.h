@@ -55,6 +55,15 @@ static inline BgkRqsCfg bgk_make_rqs_cfg(double left, double right, double botto
     return c;
 }
 
+/* compensated running sum: with more than 64 bins the plain f32 running sums of the knots (K terms of ~1/K) lose ~K/2 ulp of the
+ * knot position, i.e. a relative error ~K^2 eps of a bin's size and of the log-det -- beyond what the torch ops (pairwise sums)
+ * give.  The bin counts the C oracle pins bit for bit (K <= 64) keep the oracle's plain sums. */
+struct BgkKahan {
+    float s, c;
+    __device__ __forceinline__ void add(float v) { const float y = v - c; const float t = s + y; c = (t - s) - y; s = t; }
+};
+constexpr int BGK_RQS_COMP_FROM = 65;     /* runtime-K elements with at least this many bins use compensated sums */
+
 /* One rational-quadratic spline element (device).  `pw`, `ph`, `ps` point at the K unnormalised
  * widths / heights / slopes of this (sample, dim) with element stride `st`; s_last is the slope at
  * knot K (periodic copy of s[0] or the non-circular extra slope).  Same operation order as
@@ -70,6 +79,7 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
                                                  int inverse, const BgkRqsCfg& c, float* lad,
                                                  int* bin, int* oob) {
     const int K = KT ? KT : Krt;
+    const bool comp = (KT == 0) && K >= BGK_RQS_COMP_FROM;
     /* clamp (InputOutsideDomain path, spline.py:145-155) */
     int o = (x < c.left) | (x > c.right);
     x = x < c.left ? c.left : (x > c.right ? c.right : x);
@@ -100,6 +110,10 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
         if (K & 1) eA[KT ? K - 1 : 0] = bgk_expf(pa[(K - 1) * st] - mA);
 #pragma unroll
         for (int k = 0; k < K; ++k) sA += eA[KT ? k : 0];
+    } else if (comp) {
+        BgkKahan acc = {0.0f, 0.0f};
+        for (int k = 0; k < K; ++k) acc.add(bgk_expf(pa[k * st] - mA));
+        sA = acc.s;
     } else {
         for (int k = 0; k < K; ++k) sA += bgk_expf(pa[k * st] - mA);
     }
@@ -108,12 +122,13 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
     float lo = lowA, hi = lowA;
     {
         float cum = 0.0f;
+        BgkKahan kc = {0.0f, 0.0f};
         bool hi_set = false;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             float p = bgk_div_r(KT ? eA[KT ? k : 0] : bgk_expf(pa[k * st] - mA), sA, rA);
             p = minA + scA * p;
-            cum += p;
+            if (comp) { kc.add(p); cum = kc.s; } else cum += p;
             float kn = spanA * cum + lowA;
             if (k == K - 1) kn = highA;
             float ks = (k == K - 1) ? kn + 1e-6f : kn;   /* in-place eps of nflows' searchsorted */
@@ -142,6 +157,10 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
         if (K & 1) eB[KT ? K - 1 : 0] = bgk_expf(pb[(K - 1) * st] - mB);
 #pragma unroll
         for (int k = 0; k < K; ++k) sB += eB[KT ? k : 0];
+    } else if (comp) {
+        BgkKahan acc = {0.0f, 0.0f};
+        for (int k = 0; k < K; ++k) acc.add(bgk_expf(pb[k * st] - mB));
+        sB = acc.s;
     } else {
         for (int k = 0; k < K; ++k) sB += bgk_expf(pb[k * st] - mB);
     }
@@ -149,11 +168,12 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
     float b_i = lowB, b_ip1 = lowB;
     {
         float cum = 0.0f;
+        BgkKahan kc = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             float p = bgk_div_r(KT ? eB[KT ? k : 0] : bgk_expf(pb[k * st] - mB), sB, rB);
             p = minB + scB * p;
-            cum += p;
+            if (comp) { kc.add(p); cum = kc.s; } else cum += p;
             float kn = spanB * cum + lowB;
             if (k == K - 1) kn = highB;
             if (k + 1 == idx) b_i = kn;

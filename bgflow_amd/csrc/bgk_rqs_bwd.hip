@@ -81,6 +81,63 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
     }
 }
 
+/* ---- any bin count: every lane walks the 3 K (+1) parameters of ITS element in memory (the backward twin of rqs_direct_kernel,
+ * bgk_rqs.hip) and writes the 3 K (+1) gradients the same way; elements dim-fastest, so the K-float runs of 64 lanes are
+ * consecutive in a row.  Four walks per set (maximum, sum of exps, knots, gradients): the lines stay in L1 / L2 meanwhile.  Keeps
+ * the backward of bin counts without a register-resident instance off device torch ops; not a roofline kernel. ---- */
+__global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_direct_kernel(RqsBwdArgs a) {
+    const int d = a.d, K = a.K, tid = threadIdx.x;
+    const BgkRqsCfg& c = a.cfg;
+    const bool comp = K >= BGK_RQS_COMP_FROM;
+    const uint64_t magicd = (0x100000000ull + (uint64_t)d - 1) / (uint64_t)d;
+    const int64_t n_tiles = (a.B + BWD_TS - 1) / BWD_TS;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * BWD_TS;
+        const int rows = (int)((a.B - b0) < BWD_TS ? (a.B - b0) : BWD_TS);
+        for (int e = tid; e < rows * d; e += BWD_THREADS) {
+            const int s = (int)(((uint64_t)(uint32_t)e * magicd) >> 32), j = e - s * d;
+            const float* row = a.params + (b0 + s) * a.ldp;
+            float* grow = a.g_params + (b0 + s) * a.ldgp;
+            const float* pw = row + (int64_t)j * K;
+            const float* ph = pw + (int64_t)d * K;
+            const float* ps = ph + (int64_t)d * K;
+            const int slot = a.nc_slot[j];
+            float x = a.y[(b0 + s) * a.ldy + j];
+            const float gy = a.g_out[(b0 + s) * a.ldgo + j], gl = a.g_dlogp[b0 + s];
+            const bool clamped = (x < c.left) | (x > c.right);
+            x = x < c.left ? c.left : (x > c.right ? c.right : x);
+            const BgkSoftmaxSet qw = bgk_softmax_set(pw, K, comp), qh = bgk_softmax_set(ph, K, comp);
+            int idx;
+            BgkKnotPair kw, kh;
+            if (a.inverse) {
+                kw = bgk_walk_search(qw, K, comp, c.min_w, c.w_scale, c.xspan, c.left, c.right, x, idx);
+                kh = bgk_walk_to(qh, K, comp, c.min_h, c.h_scale, c.yspan, c.bottom, c.top, idx);
+            } else {
+                kh = bgk_walk_search(qh, K, comp, c.min_h, c.h_scale, c.yspan, c.bottom, c.top, x, idx);
+                kw = bgk_walk_to(qw, K, comp, c.min_w, c.w_scale, c.xspan, c.left, c.right, idx);
+            }
+            const bool hi_last = idx + 1 == K, has_slot = slot >= 0;
+            const float s_lo = ps[idx];
+            const float s_hi = !hi_last ? ps[idx + 1] : (has_slot ? row[(int64_t)3 * d * K + slot] : ps[0]);
+            const BgkVjpBin b = bgk_rqs_vjp_bin(c, a.inverse, x, kw.k_i, kw.k_n, kh.k_i, kh.k_n, s_lo, s_hi, gy, gl);
+            a.g_y[(b0 + s) * a.ldgy + j] = clamped ? 0.0f : b.gx;
+            float* qgw = grow + (int64_t)j * K;
+            float* qgh = qgw + (int64_t)d * K;
+            float* qgs = qgh + (int64_t)d * K;
+            bgk_walk_grad(qw, K, c.w_scale, c.xspan, idx, kw, b.G_cw, b.G_W, qgw);
+            bgk_walk_grad(qh, K, c.h_scale, c.yspan, idx, kh, b.G_ch, b.G_H, qgh);
+            for (int k = 0; k < K; ++k) {
+                float g = 0.0f;
+                g += (k == idx) ? b.g0 : 0.0f;
+                g += (!hi_last && k == idx + 1) ? b.g1 : 0.0f;
+                g += (hi_last && !has_slot && k == 0) ? b.g1 : 0.0f;
+                qgs[k] = g;
+            }
+            if (has_slot) grow[(int64_t)3 * d * K + slot] = hi_last ? b.g1 : 0.0f;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params, int64_t ldp, int32_t P,
@@ -94,11 +151,7 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
     BGK_CHECK_ARG(B >= 0 && d > 0 && K > 0, "bgk_rqs_backward: bad sizes");
     BGK_CHECK_ARG(y && params && nc_slot && g_out && g_dlogp && g_y && g_params, "bgk_rqs_backward: null pointer");
     BGK_CHECK_ARG(P >= 3 * K * d && P <= 3 * K * d + d && ldp >= P && ldgp >= P, "bgk_rqs_backward: bad params width %d", P);
-    if (K != 4 && K != 8 && K != 12 && K != 16 && K != 32) {
-        bgk_set_error("bgk_rqs_backward: n_bins in {4, 8, 12, 16, 32} are implemented (got %d)", K);
-        return BGK_EUNSUPPORTED;
-    }
-    if (B == 0) return 0;
+    BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0, "Minimal bin width/height too large for the number of bins");
     RqsBwdArgs a;
     a.y = y; a.ldy = ldy; a.params = params; a.ldp = ldp; a.nc_slot = nc_slot; a.B = B; a.d = d; a.K = K; a.P = P;
     a.inverse = inverse; a.g_out = g_out; a.ldgo = ldgo; a.g_dlogp = g_dlogp; a.g_y = g_y; a.ldgy = ldgy;
@@ -114,7 +167,9 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
         case 8: hipLaunchKernelGGL(rqs_bwd_kernel<8>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
         case 12: hipLaunchKernelGGL(rqs_bwd_kernel<12>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
         case 16: hipLaunchKernelGGL(rqs_bwd_kernel<16>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
-        default: hipLaunchKernelGGL(rqs_bwd_kernel<32>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
+        case 32: hipLaunchKernelGGL(rqs_bwd_kernel<32>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
+        /* any other bin count: the parameters stay in memory and are walked */
+        default: hipLaunchKernelGGL(rqs_bwd_direct_kernel, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
     }
     return bgk_launch_status("bgk_rqs_backward");
 }

@@ -58,6 +58,73 @@ __device__ __forceinline__ float bgk_pick(const float (&a)[KT], int i) {
     return v;
 }
 
+/* The bin-local part of the VJP: from the bin's knots (cw_i, cw_n | ch_i, ch_n), its two unnormalised slopes and the clamped input
+ * x to the cotangents of the bin width / height W, H, of the left knots cw, ch (G_*), of the two slope PARAMETERS (g0, g1: through
+ * softplus) and of the input (gx).  Shared by the register-resident element routine and the memory-walking one. */
+struct BgkVjpBin { float G_W, G_cw, G_H, G_ch, g0, g1, gx; };
+
+__device__ __forceinline__ BgkVjpBin bgk_rqs_vjp_bin(const BgkRqsCfg& c, int inverse, float x, float cw_i, float cw_n, float ch_i,
+                                                    float ch_n, float s_lo, float s_hi, float gy, float gl) {
+    const float rbeta = bgk_vjp_rcp(c.beta);
+    const float d0 = c.min_d + bgk_vjp_softplus(s_lo, c.beta, rbeta), d1 = c.min_d + bgk_vjp_softplus(s_hi, c.beta, rbeta);
+    const float W_i = cw_n - cw_i, H_i = ch_n - ch_i;
+    const float iW = bgk_vjp_rcp(W_i);
+    const float delta = H_i * iW, S = d0 + d1 - 2.0f * delta;
+    float theta;
+    if (!inverse) {
+        float dx = x - ch_i;
+        float qa = dx * S + H_i * (delta - d0), qb = H_i * d0 - dx * S, qc = -delta * dx;
+        theta = (2.0f * qc) * bgk_vjp_rcp(-qb - __builtin_amdgcn_sqrtf(qb * qb - 4.0f * qa * qc));
+    } else {
+        theta = (x - cw_i) * iW;
+    }
+    const float t = theta * (1.0f - theta), tp = 1.0f - 2.0f * theta, omt = 1.0f - theta;
+    const float N = delta * theta * theta + d0 * t, den = delta + S * t;
+    const float iden = bgk_vjp_rcp(den), iden2 = iden * iden;
+    const float Q = N * iden;
+    const float N_th = 2.0f * delta * theta + d0 * tp, den_th = S * tp;
+    const float Q_th = (N_th * den - N * den_th) * iden2;
+    const float Q_de = (theta * theta * den - N * (1.0f - 2.0f * t)) * iden2;
+    const float Q_d0 = (t * den - N * t) * iden2;
+    const float Q_d1 = (-N * t) * iden2;
+    const float M = d1 * theta * theta + 2.0f * delta * t + d0 * omt * omt;
+    const float iM = bgk_vjp_rcp(M);
+    const float lf_th = (2.0f * d1 * theta + 2.0f * delta * tp - 2.0f * d0 * omt) * iM - 2.0f * den_th * iden;
+    const float lf_de = 2.0f * bgk_vjp_rcp(delta) + 2.0f * t * iM - 2.0f * (1.0f - 2.0f * t) * iden;
+    const float lf_d0 = omt * omt * iM - 2.0f * t * iden;
+    const float lf_d1 = theta * theta * iM - 2.0f * t * iden;
+    float G_de, G_d0, G_d1;
+    BgkVjpBin r;
+    if (inverse) {
+        const float G_th = gy * H_i * Q_th + gl * lf_th;
+        G_de = gy * H_i * Q_de + gl * lf_de;
+        G_d0 = gy * H_i * Q_d0 + gl * lf_d0;
+        G_d1 = gy * H_i * Q_d1 + gl * lf_d1;
+        r.G_H = gy * Q + G_de * iW;
+        r.G_W = -G_de * delta * iW - G_th * theta * iW;
+        r.G_ch = gy;
+        r.G_cw = -G_th * iW;
+        r.gx = G_th * iW;
+    } else {
+        const float A_th = gy * W_i - gl * lf_th;
+        const float iQth = bgk_vjp_rcp(Q_th);
+        const float inv = bgk_vjp_rcp(H_i) * iQth;
+        G_de = -gl * lf_de - A_th * Q_de * iQth;
+        G_d0 = -gl * lf_d0 - A_th * Q_d0 * iQth;
+        G_d1 = -gl * lf_d1 - A_th * Q_d1 * iQth;
+        r.G_H = G_de * iW - A_th * Q * inv;
+        r.G_W = -G_de * delta * iW + gy * theta;
+        r.G_cw = gy;
+        r.G_ch = -A_th * inv;
+        r.gx = A_th * inv;
+    }
+    const bool dead = (gy == 0.0f) & (gl == 0.0f);   /* masked-out sample: exact zeros, never 0 * inf */
+    if (dead) { G_d0 = G_d1 = r.G_H = r.G_W = r.G_cw = r.G_ch = r.gx = 0.0f; }
+    r.g0 = G_d0 * bgk_vjp_sigmoid(s_lo * c.beta);
+    r.g1 = G_d1 * bgk_vjp_sigmoid(s_hi * c.beta);
+    return r;
+}
+
 /* rw / rh / rs: the element's unnormalised widths, heights, slopes (knots 0..K-1); s_K: the slope at knot K (its own slot for a
  * non-circular dim -- has_slot -- else rs[0]); x: the spline's input (pre-clamp); gy, gl: output and log-det cotangents.
  * Out: ow / oh / os parameter gradients, g_slot (gradient of the slot; 0 without one), gx (input gradient, 0 outside the domain). */
@@ -89,63 +156,10 @@ __device__ __forceinline__ void bgk_rqs_vjp_element(const BgkRqsCfg& c, int inve
     float s_hi = s_K;
 #pragma unroll
     for (int k = 1; k < K; ++k) s_hi = (idx + 1 == k) ? rs[k] : s_hi;
-    const float rbeta = bgk_vjp_rcp(c.beta);
-    const float d0 = c.min_d + bgk_vjp_softplus(s_lo, c.beta, rbeta), d1 = c.min_d + bgk_vjp_softplus(s_hi, c.beta, rbeta);
-    const float W_i = cw_n - cw_i, H_i = ch_n - ch_i;
-    const float iW = bgk_vjp_rcp(W_i);
-    const float delta = H_i * iW, S = d0 + d1 - 2.0f * delta;
-    float theta;
-    if (!inverse) {
-        float dx = x - ch_i;
-        float qa = dx * S + H_i * (delta - d0), qb = H_i * d0 - dx * S, qc = -delta * dx;
-        theta = (2.0f * qc) * bgk_vjp_rcp(-qb - __builtin_amdgcn_sqrtf(qb * qb - 4.0f * qa * qc));
-    } else {
-        theta = (x - cw_i) * iW;
-    }
-    const float t = theta * (1.0f - theta), tp = 1.0f - 2.0f * theta, omt = 1.0f - theta;
-    const float N = delta * theta * theta + d0 * t, den = delta + S * t;
-    const float iden = bgk_vjp_rcp(den), iden2 = iden * iden;
-    const float Q = N * iden;
-    const float N_th = 2.0f * delta * theta + d0 * tp, den_th = S * tp;
-    const float Q_th = (N_th * den - N * den_th) * iden2;
-    const float Q_de = (theta * theta * den - N * (1.0f - 2.0f * t)) * iden2;
-    const float Q_d0 = (t * den - N * t) * iden2;
-    const float Q_d1 = (-N * t) * iden2;
-    const float M = d1 * theta * theta + 2.0f * delta * t + d0 * omt * omt;
-    const float iM = bgk_vjp_rcp(M);
-    const float lf_th = (2.0f * d1 * theta + 2.0f * delta * tp - 2.0f * d0 * omt) * iM - 2.0f * den_th * iden;
-    const float lf_de = 2.0f * bgk_vjp_rcp(delta) + 2.0f * t * iM - 2.0f * (1.0f - 2.0f * t) * iden;
-    const float lf_d0 = omt * omt * iM - 2.0f * t * iden;
-    const float lf_d1 = theta * theta * iM - 2.0f * t * iden;
-    float G_de, G_d0, G_d1, G_H, G_W, G_cw, G_ch, gx;
-    if (inverse) {
-        const float G_th = gy * H_i * Q_th + gl * lf_th;
-        G_de = gy * H_i * Q_de + gl * lf_de;
-        G_d0 = gy * H_i * Q_d0 + gl * lf_d0;
-        G_d1 = gy * H_i * Q_d1 + gl * lf_d1;
-        G_H = gy * Q + G_de * iW;
-        G_W = -G_de * delta * iW - G_th * theta * iW;
-        G_ch = gy;
-        G_cw = -G_th * iW;
-        gx = G_th * iW;
-    } else {
-        const float A_th = gy * W_i - gl * lf_th;
-        const float iQth = bgk_vjp_rcp(Q_th);
-        const float inv = bgk_vjp_rcp(H_i) * iQth;
-        G_de = -gl * lf_de - A_th * Q_de * iQth;
-        G_d0 = -gl * lf_d0 - A_th * Q_d0 * iQth;
-        G_d1 = -gl * lf_d1 - A_th * Q_d1 * iQth;
-        G_H = G_de * iW - A_th * Q * inv;
-        G_W = -G_de * delta * iW + gy * theta;
-        G_cw = gy;
-        G_ch = -A_th * inv;
-        gx = A_th * inv;
-    }
-    const bool dead = (gy == 0.0f) & (gl == 0.0f);   /* masked-out sample: exact zeros, never 0 * inf */
-    if (dead) { G_de = G_d0 = G_d1 = G_H = G_W = G_cw = G_ch = gx = 0.0f; }
-    gx_out = clamped ? 0.0f : gx;
+    const BgkVjpBin b = bgk_rqs_vjp_bin(c, inverse, x, cw_i, cw_n, ch_i, ch_n, s_lo, s_hi, gy, gl);
+    gx_out = clamped ? 0.0f : b.gx;
     {
-        const float gA = (idx >= 1) ? (G_cw - G_W) : 0.0f, gB = (idx + 1 <= K - 1) ? G_W : 0.0f;
+        const float gA = (idx >= 1) ? (b.G_cw - b.G_W) : 0.0f, gB = (idx + 1 <= K - 1) ? b.G_W : 0.0f;
         float gp[K], dot = 0.0f;
 #pragma unroll
         for (int m = 0; m < K; ++m) { gp[m] = c.w_scale * c.xspan * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f)); dot += pw[m] * gp[m]; }
@@ -153,7 +167,7 @@ __device__ __forceinline__ void bgk_rqs_vjp_element(const BgkRqsCfg& c, int inve
         for (int m = 0; m < K; ++m) ow[m] = pw[m] * (gp[m] - dot);
     }
     {
-        const float gA = (idx >= 1) ? (G_ch - G_H) : 0.0f, gB = (idx + 1 <= K - 1) ? G_H : 0.0f;
+        const float gA = (idx >= 1) ? (b.G_ch - b.G_H) : 0.0f, gB = (idx + 1 <= K - 1) ? b.G_H : 0.0f;
         float gp[K], dot = 0.0f;
 #pragma unroll
         for (int m = 0; m < K; ++m) { gp[m] = c.h_scale * c.yspan * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f)); dot += ph[m] * gp[m]; }
@@ -161,17 +175,101 @@ __device__ __forceinline__ void bgk_rqs_vjp_element(const BgkRqsCfg& c, int inve
         for (int m = 0; m < K; ++m) oh[m] = ph[m] * (gp[m] - dot);
     }
     {
-        const float sg0 = bgk_vjp_sigmoid(s_lo * c.beta), sg1 = bgk_vjp_sigmoid(s_hi * c.beta);
-        const float g0 = G_d0 * sg0, g1 = G_d1 * sg1;
-        g_slot = (has_slot && hi_last) ? g1 : 0.0f;
+        g_slot = (has_slot && hi_last) ? b.g1 : 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             float g = 0.0f;
-            g += (k == idx) ? g0 : 0.0f;
-            g += (!hi_last && k == idx + 1) ? g1 : 0.0f;
-            g += (hi_last && !has_slot && k == 0) ? g1 : 0.0f;
+            g += (k == idx) ? b.g0 : 0.0f;
+            g += (!hi_last && k == idx + 1) ? b.g1 : 0.0f;
+            g += (hi_last && !has_slot && k == 0) ? b.g1 : 0.0f;
             os[k] = g;
         }
+    }
+}
+
+/* ---- any bin count: the element's parameters stay in memory and are walked (bgk_rqs_bwd.hip::rqs_bwd_direct_kernel) -------------
+ * One softmax set in memory (u[0..K), unit stride): its maximum, the sum of its exps and -- second walk -- whatever the caller's
+ * visitor wants of (k, p_k = softmax probability, knot k + 1).  The knots repeat the FORWARD's sequence operation for operation
+ * (bgk_common.h::bgk_rqs_element<0>: deterministic exp, the correctly rounded quotient, plain running sums up to 64 bins,
+ * compensated ones beyond), so the bin found here is the bin the forward evaluated. */
+struct BgkSoftmaxSet { const float* u; float m, s, rs; };
+
+__device__ __forceinline__ BgkSoftmaxSet bgk_softmax_set(const float* u, int K, bool comp) {
+    BgkSoftmaxSet q;
+    q.u = u;
+    float m = u[0];
+    for (int k = 1; k < K; ++k) { const float v = u[k]; m = v > m ? v : m; }
+    q.m = m;
+    if (comp) {
+        BgkKahan acc = {0.0f, 0.0f};
+        for (int k = 0; k < K; ++k) acc.add(bgk_expf(u[k] - m));
+        q.s = acc.s;
+    } else {
+        float s = 0.0f;
+        for (int k = 0; k < K; ++k) s += bgk_expf(u[k] - m);
+        q.s = s;
+    }
+    q.rs = bgk_rcp_refined(q.s);
+    return q;
+}
+__device__ __forceinline__ float bgk_softmax_p(const BgkSoftmaxSet& q, int k) { return bgk_div_r(bgk_expf(q.u[k] - q.m), q.s, q.rs); }
+
+/* what the VJP needs of one knot set around bin idx: the knots idx and idx + 1, the probability mass below the bin and the bin's own */
+struct BgkKnotPair { float k_i, k_n, below, p_bin; };
+
+/* walk the searched set: finds the bin of x (same comparisons as the forward: knot K carries the +1e-6 of nflows' searchsorted) */
+__device__ __forceinline__ BgkKnotPair bgk_walk_search(const BgkSoftmaxSet& q, int K, bool comp, float mn, float sc, float span, float low,
+                                                       float high, float x, int& idx_out) {
+    BgkKnotPair r = {low, low, 0.0f, 0.0f};
+    int idx = -1 + (x >= low ? 1 : 0);
+    float cum = 0.0f;
+    BgkKahan kc = {0.0f, 0.0f};
+    bool hi_set = false;
+    for (int k = 0; k < K; ++k) {
+        const float p = bgk_softmax_p(q, k);
+        const float f = mn + sc * p;
+        if (comp) { kc.add(f); cum = kc.s; } else cum += f;
+        float kn = span * cum + low;
+        if (k == K - 1) kn = high;
+        const float ks = (k == K - 1) ? kn + 1e-6f : kn;
+        const bool ge = x >= ks;
+        idx += ge ? 1 : 0;
+        if (ge) { r.k_i = kn; r.below += p; }
+        if (!ge && !hi_set) { r.k_n = kn; r.p_bin = p; hi_set = true; }
+    }
+    idx_out = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
+    return r;
+}
+
+/* walk the other set up to the given bin */
+__device__ __forceinline__ BgkKnotPair bgk_walk_to(const BgkSoftmaxSet& q, int K, bool comp, float mn, float sc, float span, float low,
+                                                   float high, int idx) {
+    BgkKnotPair r = {low, low, 0.0f, 0.0f};
+    float cum = 0.0f;
+    BgkKahan kc = {0.0f, 0.0f};
+    for (int k = 0; k <= idx; ++k) {
+        const float p = bgk_softmax_p(q, k);
+        const float f = mn + sc * p;
+        if (comp) { kc.add(f); cum = kc.s; } else cum += f;
+        float kn = span * cum + low;
+        if (k == K - 1) kn = high;
+        if (k + 1 == idx) r.k_i = kn;
+        if (k == idx) { r.k_n = kn; r.p_bin = p; } else r.below += p;
+    }
+    return r;
+}
+
+/* gradient of the set's K unnormalised parameters, written to g[0..K): the cotangents of the bin's left knot (G_c) and size (G_s)
+ * reach parameter m through knot = span * cumsum(mn + sc * softmax) -- d/du_m = p_m (gp_m - sum_j p_j gp_j) with
+ * gp_m = sc * span * ([m < idx] (G_c - G_s) + [m <= idx] G_s), the interior-knot conditions of the register routine included */
+__device__ __forceinline__ void bgk_walk_grad(const BgkSoftmaxSet& q, int K, float sc, float span, int idx, const BgkKnotPair& kp,
+                                              float G_c, float G_s, float* g) {
+    const float gA = (idx >= 1) ? (G_c - G_s) : 0.0f, gB = (idx + 1 <= K - 1) ? G_s : 0.0f;
+    const float w = sc * span;
+    const float dot = w * (gA * kp.below + gB * (kp.below + kp.p_bin));
+    for (int m = 0; m < K; ++m) {
+        const float gp = w * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f));
+        g[m] = bgk_softmax_p(q, m) * (gp - dot);
     }
 }
 

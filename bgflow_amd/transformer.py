@@ -195,8 +195,7 @@ def rqs_transform(y, params, nc_slot, n_bins, inverse, left, right, bottom, top,
     B, d = y2.shape
     P = params.shape[-1]
     # (any bin count: rows that leave no room for an LDS tile -- more than 64 bins for ~17 dims -- run on the kernel's direct
-    # variant, every lane walking its element's parameters in memory; only the BACKWARD of bin counts other than 4 / 8 / 12 / 16 / 32
-    # uses device torch ops, see rqs_backward)
+    # variant, every lane walking its element's parameters in memory; the backward has the same two forms, see rqs_backward)
     p2, ldp = _lib.rowmajor(params.reshape(-1, P))
     out = torch.empty((B, d), dtype=torch.float32, device=y.device)
     if y.dim() != 2:
@@ -236,7 +235,8 @@ class _RQSFn(torch.autograd.Function):
 
 def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp):
     """Launch bgk_rqs_backward: VJP of rqs_transform w.r.t. (y, params); cfg = (n_bins, inverse, left, right, bottom,
-    top, settings)."""
+    top, settings).  Any bin count: 4 / 8 / 12 / 16 / 32 bins on the register-resident streaming kernel, every other count on the
+    kernel's direct variant (the parameters stay in memory and are walked) -- no device torch ops in the backward either."""
     n_bins, inverse, left, right, bottom, top, settings = cfg
     d, P = y.shape[-1], params.shape[-1]
     y2, ldy = _lib.rowmajor(y.reshape(-1, d))
@@ -256,74 +256,8 @@ def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp):
             settings["min_derivative"], int(settings.get("enable_identity_init", False)),
             _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), ldgp,
             _lib.stream_ptr(y.device))
-    if st == -2:       # a bin count the backward kernel is not instantiated for: autograd through the same map on device torch ops
-        gy, gp = _rqs_backward_torch(y2, p2, nc_slot, cfg, g_out2, g_dl)
-        return gy.reshape(y.shape), gp.reshape(params.shape)
     _lib.check(st, "bgk_rqs_backward")
     return g_y.reshape(y.shape), g_p.reshape(params.shape)
-
-
-def _rqs_spline_torch(y, params, nc_slot, cfg):
-    """The spline map of bgk_rqs_transform written with differentiable torch ops (any bin count; device tensors): softmax widths /
-    heights with minimum sizes, softplus slopes (+ min_derivative, identity-init beta), monotone rational-quadratic segment.
-    bgflow forward = nflows' inverse branch (transformer/spline.py:133-144).  Used for gradients only, when the backward kernel has
-    no instance for K; returns (out [B, d], dlogp [B])."""
-    K, inverse, left, right, bottom, top, st = cfg
-    B, d = y.shape
-    min_w, min_h, min_d = st["min_bin_width"], st["min_bin_height"], st["min_derivative"]
-    w_raw, h_raw, s_raw = (params[:, i * d * K:(i + 1) * d * K].reshape(B, d, K) for i in range(3))
-    slot = nc_slot.long()
-    extra = params[:, 3 * d * K:]
-    last = torch.where((slot >= 0)[None, :], extra[:, slot.clamp_min(0)] if extra.shape[1] else s_raw[..., 0] * 0, s_raw[..., 0])
-    s_all = torch.cat([s_raw, last[..., None]], dim=-1)
-
-    def knots(raw, lo, hi, mn):
-        frac = mn + (1.0 - mn * K) * torch.softmax(raw, dim=-1)
-        c = torch.cumsum(frac, dim=-1)
-        kn = torch.cat([torch.zeros_like(c[..., :1]), c], dim=-1) * (hi - lo) + lo
-        kn = torch.cat([kn[..., :1] * 0 + lo, kn[..., 1:-1], kn[..., :1] * 0 + hi], dim=-1)
-        return kn
-    cw, ch = knots(w_raw, left, right, min_w), knots(h_raw, bottom, top, min_h)
-    beta = np.log(2.0) / (1.0 - min_d) if st.get("enable_identity_init", False) else 1.0
-    dv = min_d + torch.nn.functional.softplus(s_all, beta=beta)
-    x = y.clamp(left, right) if not inverse else y.clamp(bottom, top)
-    search = ch if not inverse else cw
-    edge = search.detach().clone()
-    edge[..., -1] += 1e-6
-    idx = ((x[..., None] >= edge).sum(-1) - 1).clamp(0, K - 1)[..., None]
-    take = lambda t: t.gather(-1, idx)[..., 0]      # noqa: E731
-    cw_i, ch_i = take(cw[..., :-1]), take(ch[..., :-1])
-    W, H = take(cw[..., 1:] - cw[..., :-1]), take(ch[..., 1:] - ch[..., :-1])
-    d0, d1 = take(dv[..., :-1]), take(dv[..., 1:])
-    delta = H / W
-    S = d0 + d1 - 2.0 * delta
-    if not inverse:                                  # solve the segment's quadratic for theta
-        dx = x - ch_i
-        a = dx * S + H * (delta - d0)
-        b = H * d0 - dx * S
-        c = -delta * dx
-        theta = (2.0 * c) / (-b - torch.sqrt(b * b - 4.0 * a * c))
-        out = theta * W + cw_i
-    else:
-        theta = (x - cw_i) / W
-        out = ch_i + H * (delta * theta * theta + d0 * theta * (1.0 - theta)) / (delta + S * theta * (1.0 - theta))
-    t1 = theta * (1.0 - theta)
-    den = delta + S * t1
-    num = delta * delta * (d1 * theta * theta + 2.0 * delta * t1 + d0 * (1.0 - theta) ** 2)
-    lad = torch.log(num) - 2.0 * torch.log(den)
-    return out, (-lad if not inverse else lad).sum(-1)
-
-
-def _rqs_backward_torch(y, params, nc_slot, cfg, g_out, g_dlogp):
-    with torch.enable_grad():
-        yy = y.detach().clone().requires_grad_(True)
-        pp = params.detach().clone().requires_grad_(True)
-        out, dl = _rqs_spline_torch(yy, pp, nc_slot, cfg)
-        gy, gp = torch.autograd.grad((out * g_out).sum() + (dl * g_dlogp).sum(), (yy, pp))
-    K, inverse, left, right, bottom, top, _ = cfg
-    lo, hi = (left, right) if not inverse else (bottom, top)
-    outside = (y < lo) | (y > hi)                    # clamped inputs: no gradient w.r.t. y (like the kernel)
-    return torch.where(outside, torch.zeros_like(gy), gy), gp
 
 
 class ConditionalSplineTransformer(Transformer):
@@ -429,8 +363,7 @@ class ConditionalSplineTransformer(Transformer):
             raise RuntimeError(
                 f"params_net output width {P} does not match 3 * n_bins * {y_dim} + {n_nc} "
                 f"(split_with_sizes in the reference, transformer/spline.py:113-117)")
-        if grad:           # forward on the kernel (any bin count); backward: bgk_rqs_backward, or autograd through the same map on
-            #                    device torch ops for the bin counts the backward kernel has no instance for (rqs_backward)
+        if grad:           # forward and backward on the kernels (any bin count: bgk_rqs_transform / bgk_rqs_backward)
             return _RQSFn.apply(y, params, nc_dev, n_bins, inverse, self._left, self._right, self._bottom,
                                 self._top, self._default_settings, oob)
         res = rqs_transform(y, params, nc_dev, n_bins, inverse, self._left, self._right, self._bottom,

@@ -1586,10 +1586,11 @@ def test_normal_energy_kernel(hip_lib, dev, d, B, has_mean, temperature):
 
 
 @pytest.mark.parametrize("inverse", [False, True])
-def test_spline_beyond_kernel_envelope_runs_on_torch_ops(hip_lib, dev, inverse):
-    """n_bins = 80 (> 64: beyond the LDS-staged kernels and the backward kernel's instances) through ConditionalSplineTransformer on
-    the device: forward on the direct variant of bgk_rqs_transform, gradients by autograd through the torch-op restatement in
-    bgflow_amd/transformer.py; checked against the independent torch restatement of the nflows spline in oracle/"""
+def test_spline_beyond_the_register_resident_instances(hip_lib, dev, inverse):
+    """n_bins = 80 (> 64: beyond the LDS-staged kernels and the backward kernel's register-resident instances) through
+    ConditionalSplineTransformer on the device: forward AND backward on the direct variants of bgk_rqs_transform / bgk_rqs_backward
+    (round 5: compensated knot sums beyond 64 bins, no device torch ops); checked against the torch restatement of the nflows spline in
+    oracle/ evaluated in f64"""
     import bgflow_amd as bg
     from oracle import torch_flow as tf
     Kb, d, B = 80, 5, 64
@@ -1617,10 +1618,10 @@ def test_spline_beyond_kernel_envelope_runs_on_torch_ops(hip_lib, dev, inverse):
     out, ld = tf.rq_spline(y64.clamp(0.0, 1.0), w, h, torch.cat([sl, last[..., None]], -1), not inverse, 0.0, 1.0, 0.0, 1.0,
                            st["min_bin_width"], st["min_bin_height"], st["min_derivative"], st.get("enable_identity_init", False))
     (out.sum() + ld.sum()).backward()
-    # (forward on the kernel's direct variant: f32 running sums over 80 bins, ~6e-8 per term)
-    assert float((z.detach().cpu().double() - out.detach()).abs().max()) < 1e-6 + 6e-8 * Kb
-    # (bin sizes ~ 1 / K are differences of f32 running sums: relative error ~ K eps per bin, i.e. ~K^2 eps in the log-det)
-    assert float((dl.detach().cpu().double().reshape(-1) - ld.detach().sum(-1)).abs().max()) < 1e-5 * Kb
+    # (knots by compensated f32 sums: ~1 ulp each, whatever the bin count)
+    assert float((z.detach().cpu().double() - out.detach()).abs().max()) < 2e-6
+    # (a bin of size ~1 / K between two knots of 1 ulp each: relative error ~K eps per bin, twice that in its log-det term)
+    assert float((dl.detach().cpu().double().reshape(-1) - ld.detach().sum(-1)).abs().max()) < 2e-4
     for got, want in ((yy.grad, y64.grad), (p.grad, p64.grad)):
         err = (got.cpu().double() - want).abs()
         assert float(err.max()) <= 1e-3 * float(want.abs().max()) and float(err.quantile(0.99)) <= 1e-4 * float(want.abs().max())

@@ -280,9 +280,10 @@ def test_spline_kernel_for_rows_beyond_the_lds_tile(hip_lib, oracle, dev, invers
         last = torch.where(cm[None, :], sl[..., 0], nc_full)
         ref, ld = tf.rq_spline(y64, w, h, torch.cat([sl, last[..., None]], -1), not inverse, 0.0, 1.0, 0.0, 1.0,
                                st["min_bin_width"], st["min_bin_height"], st["min_derivative"], True)
-        assert float((out.cpu().double() - ref).abs().max()) < 1e-6 + 6e-8 * Kb, f"K = {Kb}"      # f32 running sums over K bins
-        # (bin sizes ~ 1 / K are differences of f32 running sums: the log-det error grows with K^2 eps per dim)
-        assert float((dl.cpu().double().reshape(-1) - ld.sum(-1)).abs().max()) < 2e-8 * Kb * Kb * d + 2e-4, f"K = {Kb}"
+        assert float((out.cpu().double() - ref).abs().max()) < 2e-6, f"K = {Kb}"      # compensated knot sums: ~1 ulp per knot
+        # (a bin of size ~1 / K between two knots of ~1 ulp each: relative error ~K eps per bin, twice that in its log-det term, d terms
+        # per sample: 2e-4 at K = 80 x 5 dims -- the tolerance of the torch ops this path replaced -- scaled with K d beyond)
+        assert float((dl.cpu().double().reshape(-1) - ld.sum(-1)).abs().max()) < 2e-4 * max(1.0, Kb * d / 400.0), f"K = {Kb}"
 
 
 @pytest.mark.parametrize("dim,keep,B", [(9, 9, 1000), (66, 60, 4133), (12, 5, 1), (128, 128, 257)])

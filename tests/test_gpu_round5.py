@@ -120,3 +120,91 @@ def test_philox_stream_ids_are_stable_when_given_and_collisions_warn(hip_lib, de
     auto.sample(1)
     assert auto._philox_state[0] != 1000                   # automatic ids skip the ones taken by hand
     del b, c
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("Kb,d,B", [(5, 7, 300), (6, 17, 1001), (24, 3, 129), (80, 5, 64), (200, 4, 33)])
+def test_spline_backward_for_any_bin_count(hip_lib, dev, Kb, d, B, inverse):
+    """bgk_rqs_backward for bin counts without a register-resident instance (every K other than 4 / 8 / 12 / 16 / 32, transformer/
+    spline.py:87-126 takes any): the direct variant walks the element's parameters in memory.  Gradients w.r.t. the input and every
+    parameter against f64 autograd through the torch restatement of the nflows spline in oracle/ -- mixed circular masks, a ragged
+    batch, inputs on and beyond the domain's ends (clamped: zero input gradient)."""
+    from bgflow_amd.transformer import rqs_backward, rqs_transform
+    from oracle import torch_flow as tf
+    from test_gpu_parity import synth, t
+    circ = np.arange(d) % 3 == 1
+    n_nc = int((~circ).sum())
+    P = 3 * Kb * d + n_nc
+    params, y = synth(700 + Kb, B, P, scale=0.9), synth(800 + Kb, B, d, uniform=True)
+    y[0, 0], y[1 % B, d - 1], y[2 % B, 0] = 0.0, 1.0, 1.25          # both ends of the domain and a clamped input
+    slots_h = np.full(d, -1, np.int32)
+    slots_h[~circ] = np.arange(n_nc, dtype=np.int32)
+    slots = torch.as_tensor(slots_h).to(dev)
+    st = dict(min_bin_width=1e-3, min_bin_height=1e-3, min_derivative=1e-3, enable_identity_init=True)
+    cfg = (Kb, inverse, 0.0, 1.0, 0.0, 1.0, st)
+    g_out, g_dl = synth(900 + Kb, B, d, scale=1.0), synth(901 + Kb, B, 1, scale=1.0)
+    gy, gp = rqs_backward(t(y, dev), t(params, dev), slots, cfg, t(g_out, dev), t(g_dl, dev))
+    # f64 reference
+    p64 = torch.tensor(params, dtype=torch.float64, requires_grad=True)
+    y64 = torch.tensor(y, dtype=torch.float64, requires_grad=True)
+    w, h, sl, s_nc = torch.split(p64, [d * Kb, d * Kb, d * Kb, n_nc], dim=-1)
+    w, h, sl = (v.reshape(B, d, Kb) for v in (w, h, sl))
+    cm = torch.tensor(circ)
+    nc_full = torch.zeros(B, d, dtype=torch.float64).index_put((torch.arange(B)[:, None], torch.nonzero(~cm).reshape(1, -1)), s_nc)
+    last = torch.where(cm[None, :], sl[..., 0], nc_full)
+    out, ld = tf.rq_spline(y64.clamp(0.0, 1.0), w, h, torch.cat([sl, last[..., None]], -1), not inverse, 0.0, 1.0, 0.0, 1.0,
+                           st["min_bin_width"], st["min_bin_height"], st["min_derivative"], True)
+    ((out * torch.tensor(g_out, dtype=torch.float64)).sum() + (ld.sum(-1, keepdim=True) * torch.tensor(g_dl, dtype=torch.float64)).sum()).backward()
+    assert float(gy[2 % B, 0]) == 0.0                               # clamped input: no gradient
+    for got, want, what in ((gy, y64.grad, "input"), (gp, p64.grad, "parameters")):
+        err = (got.cpu().double() - want).abs()
+        scale = float(want.abs().max())
+        assert bool(torch.isfinite(got).all())
+        assert float(err.max()) <= 1e-3 * scale and float(err.quantile(0.99)) <= 1e-4 * scale, \
+            f"K = {Kb}: {what} gradient, max error {float(err.max()):.2e} of {scale:.2e}"
+    # the forward of the same bin count on the same inputs (bins of forward and backward come from one knot sequence)
+    z, dl = rqs_transform(t(y, dev), t(params, dev), slots, Kb, inverse, 0.0, 1.0, 0.0, 1.0, st)
+    assert float((z.cpu().double() - out.detach()).abs().max()) < 2e-6
+
+
+def test_hardware_sincos_of_the_generation_tail_on_a_long_chain(hip_lib, oracle, dev):
+    """advisor (round 4, low): the generation-tail kernels take the placements' sin / cos from v_sin_f32 / v_cos_f32 (argument in
+    revolutions, max abs error 1.24e-7 -- tools/ubench/hw_sincos.hip) instead of the reproducible polynomial: NOT bit-identical to
+    the oracle any more (deviations).  What it costs in accuracy, on the worst case the one-launch tail takes: a
+    pure 24-atom chain (every atom placed on the three before it, so placement errors travel down the whole chain).  Coordinates
+    against the f64 oracle: within 2e-5 nm absolute, and no worse than 4 x the block-by-block path (deterministic polynomial sin / cos)
+    on the same inputs."""
+    import bgflow_amd as bg
+    from bgflow_amd import configs
+    from oracle import flow_oracle as fo
+    n_atoms = 24
+    z = np.array([(i, i - 1, i - 2, i - 3) for i in range(3, n_atoms)], dtype=np.int64)
+    n = n_atoms - 3
+    ic = bg.RelativeInternalCoordinateTransformation(z, np.array([0, 1, 2]), normalize_angles=True)
+    one = lambda v, m: torch.full((m,), float(v))          # noqa: E731
+    marginals = {
+        0: bg.TruncatedNormalDistribution(mu=one(0.15, n), sigma=one(0.01, n), lower_bound=torch.tensor(1e-5), upper_bound=torch.tensor(np.inf)),
+        1: bg.TruncatedNormalDistribution(mu=one(0.5, n), sigma=one(0.05, n), lower_bound=torch.tensor(1e-5), upper_bound=torch.tensor(1.0)),
+        2: configs.SloppyUniform(low=one(0.0, n), high=one(1.0, n)),
+        3: configs._NormalMarginal(torch.tensor([0, 0, 0, 0.15, 0, 0, 0.2, 0.14, 0.0]), one(0.005, 9)),
+    }
+    blocks = [bg.WrapFlow(bg.InverseFlow(bg.CDFTransform(marginals[s_])), (s_,)) for s_ in range(4)] \
+        + [bg.WrapFlow(bg.InverseFlow(ic), indices=[0, 1, 2, 3], out_indices=(0,))]
+    flow_cpu = bg.SequentialFlow(blocks)
+    B = 4096
+    g = torch.Generator().manual_seed(24)
+    xs = [torch.rand(B, w, generator=g).clamp(0.02, 0.98) for w in (n, n, n, 9)]
+    x64, dl64 = fo.run_flow(flow_cpu, [v.numpy().astype(np.float64) for v in xs], dtype=np.float64)
+    x64 = x64[0] if isinstance(x64, (list, tuple)) else x64
+    flow = flow_cpu.to(dev)
+    with torch.no_grad():
+        x, dl = flow(*[v.to(dev) for v in xs])
+        assert any(lbl == "icdf+ic2xyz" for lbl, _ in flow.segments()), "the one-launch tail must have run"
+        flow.FUSE_GENERATION_TAIL = False
+        x_b, dl_b = flow(*[v.to(dev) for v in xs])
+    err = np.abs(x.cpu().numpy().astype(np.float64) - x64).max()
+    err_b = np.abs(x_b.cpu().numpy().astype(np.float64) - x64).max()
+    assert err <= 2e-5, f"24-atom chain through the one-launch tail: max coordinate error {err:.2e} nm vs f64 (blocks: {err_b:.2e})"
+    assert err <= 4 * err_b + 2e-6, f"hardware sin / cos: {err:.2e} against {err_b:.2e} for the polynomial form"
+    rel = np.abs(dl.cpu().numpy().reshape(-1) - np.asarray(dl64).reshape(-1)) / np.maximum(np.abs(np.asarray(dl64).reshape(-1)), 1.0)
+    assert np.median(rel) <= 2e-6 and rel.max() <= 1e-4
