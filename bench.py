@@ -694,6 +694,14 @@ def main():
                                                                          grad_bucket_allreduce_us=rccl.get("grad_bucket_allreduce_us"),
                                                                          grad_bucket_bytes=rccl.get("grad_bucket_bytes"))),
                       steps=args.kl_steps, timer="HIP events", loss=float(last[0].detach()),
+                      arithmetic="forward as the headline (f32; conditioner GEMMs on f16 hi + lo operand pairs, 22 - 24 significant bits, f32 "
+                                 "accumulate).  Backward GEMMs (input-gradient chain bgk_dense_backward_dx, weight gradients "
+                                 "bgk_dense_weight_grad): the same f16 hi + lo split, 3 MFMAs per product, with every gradient operand under a "
+                                 "power-of-two scale taken from its largest magnitude (per tensor, published by the kernel that wrote it; per "
+                                 "32-sample tile inside the chain) -- 22 significant bits per product whatever the loss scale; rounds 1 - 4 "
+                                 "multiplied bf16 hi + lo pairs there (16 bits per product; flat-gradient error vs f64 1.3e-4, now pinned at "
+                                 "<= 3e-5 by tests/test_gpu_round4.py::test_kl_gradient_at_the_bench_batch); spline VJP, activation derivatives, "
+                                 "coordinate-transform backward: f32 with hardware exp2 / log2 / rcp / sin / cos forms (1 ulp)",
                       note="fwd: one-launch coupling layers (training variant, saves pre-activations + spline parameters) + IC / CDF kernels; "
                            "bwd: bgk_rqs_backward / bgk_ic_ic2xyz_backward, conditioner input-gradient chain on bgk_dense_backward_dx, "
                            "weight / bias gradients on bgk_dense_weight_grad; one all-reduce of [sum, n] + one all-reduce of the flat gradient bucket; "

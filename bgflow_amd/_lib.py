@@ -24,7 +24,7 @@ _SIGNATURES = {
                                          vp, i64, vp, i32, vp, vp, vp]),
     "bgk_rqs_backward": (ctypes.c_int, [vp, i64, vp, i64, i32, vp, i64, i32, i32, i32,
                                         f64, f64, f64, f64, f64, f64, f64, i32,
-                                        vp, i64, vp, vp, i64, vp, i64, vp]),
+                                        vp, i64, vp, vp, i64, vp, i64, vp, vp]),
     "bgk_affine_transform": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i64, i32,
                                             vp, i64, vp, i32, vp]),
     "bgk_affine_backward": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i64, i32,
@@ -82,11 +82,12 @@ _SIGNATURES = {
                                                     i32, vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32, vp]),
     "bgk_pack_dense_h2_t": (ctypes.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "bgk_dense_backward_dx": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, i64,
-                                             vp, vp, vp, vp, vp, i64, vp]),
+                                             vp, vp, vp, vp, vp, i64, vp, vp, vp]),
     "bgk_dense_weight_grad_reduce_many": (ctypes.c_int, [i32] + [vp] * 10 + [i32, vp]),
     "bgk_pack_dense_h2_many": (ctypes.c_int, [i32] + [vp] * 14 + [vp]),
     "bgk_pack_dense_h2_t_many": (ctypes.c_int, [i32] + [vp] * 9 + [vp]),
     "bgk_column_sum": (ctypes.c_int, [vp, i64, i64, i32, vp, i32, vp, vp]),
+    "bgk_absmax": (ctypes.c_int, [vp, i64, i64, i32, vp, vp]),
     "bgk_whiten": (ctypes.c_int, [vp, i64, vp, vp, vp, i32, i32, i64, vp, i64, vp]),
     "bgk_normal_energy": (ctypes.c_int, [vp, i64, vp, i32, i64, f64, f64, vp, vp]),
     "bgk_normal_energy_backward": (ctypes.c_int, [vp, i64, vp, i32, i64, f64, vp, vp, i64, vp]),
@@ -97,7 +98,7 @@ _SIGNATURES = {
     "bgk_adam_step": (ctypes.c_int, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp, vp]),
     "bgk_dense_weight_grad_workspace": (i64, [i64, i32, i32]),
     "bgk_dense_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, i32, i32, i64, vp, i64,
-                                             vp, vp, vp, vp, vp, vp, i32, vp]),
+                                             vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "bgk_pack_rqs_columns": (i32, [i32, i32, vp, vp]),
 }
 

@@ -37,6 +37,8 @@ struct DenseBwdArgs {
     float* g_z1; float* g_z0; float* h1; float* h0;
     float* g_cond; int64_t ldgc;
     int lds_per_wave;
+    const float* g_absmax;                        /* [1] largest |g| of the launch (device; NULL: g enters the first GEMM unscaled) */
+    float* gz_absmax;                             /* [2] raised to the largest |g_z1|, |g_z0| written (NULL: not wanted) */
 };
 
 /* -DBGK_SBD_TS=1: s_memtime stamps of the wave's phases (14: first GEMM done, 19 - 29: the chain), written over row b0 of g_z0 at the end */
@@ -125,17 +127,25 @@ __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, i
 #endif
 }
 
-/* everything behind the first GEMM: acc = W2^T g (unscaled) -> g_z1, g_z0 (+ h1, h0), g_cond */
+/* everything behind the first GEMM: acc = W2^T (g * 2^s) (weights' own scale still on) -> g_z1, g_z0 (+ h1, h0), g_cond.
+ * The gradient tiles that feed the next GEMM are split into f16 hi + lo parts under a power-of-two scale taken from the TILE's own
+ * largest magnitude (a wave-wide maximum: 32 v_max3 + 6 cross-lane steps per GEMM): whatever the loss scale and the batch size
+ * (g ~ 1 / B), every product carries 22 significant bits like the forward's.  inv_g: reciprocal of the first GEMM's scale. */
 template <int FT>
-__device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (&acc)[4], float* s_f, int64_t b0, int lane, int rows) {
+__device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (&acc)[4], float inv_g, float* s_f, int64_t b0, int lane, int rows) {
     const int j = lane & 31, hh = lane >> 5;
     const float c2 = a.cs[5], c1 = a.cs[3], c0 = a.cs[1];
-    act_backward_tiles(acc, c2, a.act, a.z1, a.g_z1, a.h1, s_f, b0, lane, rows);
+    act_backward_tiles(acc, c2 * inv_g, a.act, a.z1, a.g_z1, a.h1, s_f, b0, lane, rows);
     SBD_TS(19);
 
     /* ---- g_h0 = W1^T g_z1 ---- */
     H2B<4> bf;
-    h2_make_b<4>(bf, acc);
+    float inv1, inv0;
+    {
+        const float m1 = h2_wave_absmax<4>(acc);
+        if (a.gz_absmax && lane == 0) h2_publish_absmax(a.gz_absmax, m1);
+        h2_make_b_scaled<4>(bf, acc, h2_pow2_scale(m1, inv1));
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -145,12 +155,15 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
     asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][15]));
 #endif
     SBD_TS(20);
-    act_backward_tiles(acc, c1, a.act, a.z0, a.g_z0, a.h0, s_f, b0, lane, rows, 26);
+    act_backward_tiles(acc, c1 * inv1, a.act, a.z0, a.g_z0, a.h0, s_f, b0, lane, rows, 26);
     SBD_TS(21);
-
-    /* ---- g_feat = W0^T g_z0, then the featuriser's transpose ---- */
-    if (a.g_cond == nullptr) return;
-    h2_make_b<4>(bf, acc);
+    {
+        const float m0 = h2_wave_absmax<4>(acc);
+        if (a.gz_absmax && lane == 0) h2_publish_absmax(a.gz_absmax + 1, m0);
+        /* ---- g_feat = W0^T g_z0, then the featuriser's transpose ---- */
+        if (a.g_cond == nullptr) return;
+        h2_make_b_scaled<4>(bf, acc, h2_pow2_scale(m0, inv0));
+    }
     h2_f32x16 gf[FT];
 #pragma unroll
     for (int m = 0; m < FT; ++m)
@@ -165,14 +178,14 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = h2_row(m, r, hh);
-                    if (f < a.d_c) orow[f] = gf[m][r] * c0;
+                    if (f < a.d_c) orow[f] = gf[m][r] * (c0 * inv0);
                 }
         }
     } else {
 #pragma unroll
         for (int m = 0; m < FT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_f[h2_row(m, r, hh) * DSROW + j] = gf[m][r] * c0;
+            for (int r = 0; r < 16; ++r) s_f[h2_row(m, r, hh) * DSROW + j] = gf[m][r] * (c0 * inv0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         /* feats = [cos 2 pi x, sin 2 pi x]  ->  g_x = 2 pi (cos * g_sin - sin * g_cos) */
@@ -204,6 +217,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+    float sg, inv_sg;
     {
         /* The gradient rows are far apart in memory (one 32-byte piece of 32 different rows per load instruction).  Raw buffer loads
          * on a descriptor of the tile: rows past the batch are out of range and read 0, so the loop below has no branch -- the
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
         constexpr int DG = DBWD_DG;
         static_assert(DG % 2 == 0, "fragment set parity follows the position in the group");
         const int S2 = a.S2;
+        sg = h2_pow2_scale(a.g_absmax ? a.g_absmax[0] : 0.0f, inv_sg);      /* per-tensor power of two: max |g| -> [2^14, 2^15) */
         H2A<4> fr[2];
         h2a_load<4>(fr[0], a.T2, 0, lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
         for (int s0 = 0; s0 < S2; s0 += DG) {
             h2_h16x8 bhi[DG], blo[DG];
 #pragma unroll
-            for (int u = 0; u < DG; ++u) h2_split8(ring[u], bhi[u], blo[u]);
+            for (int u = 0; u < DG; ++u) h2_split8_scaled(ring[u], sg, bhi[u], blo[u]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < DG; ++u) {
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
         }
     }
     SBD_TS(14);
-    dx_chain_tail<FT>(a, acc, s_f, b0, lane, rows);
+    dx_chain_tail<FT>(a, acc, inv_sg, s_f, b0, lane, rows);
 #if BGK_SBD_TS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SBD_TS(15);
@@ -379,7 +394,7 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
                                      const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                      const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
                                      int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
-                                     float* g_cond, int64_t ldgc, void* stream) {
+                                     float* g_cond, int64_t ldgc, const float* g_absmax, float* gz_absmax, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(g && z1 && z0 && T0 && T1 && T2 && cs && g_z1 && g_z0, "bgk_dense_backward_dx: null pointer");
     BGK_CHECK_ARG((h1 == nullptr) == (h0 == nullptr), "bgk_dense_backward_dx: h1 and h0 are written both or not at all");
@@ -392,6 +407,7 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     a.g = g; a.ldg = ldg; a.P = P; a.z1 = z1; a.z0 = z0; a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
     a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.S2 = ((P + 15) / 16 + DBWD_PAD - 1) / DBWD_PAD * DBWD_PAD; a.cs = cs; a.act = act; a.B = B;
     a.g_z1 = g_z1; a.g_z0 = g_z0; a.h1 = h1; a.h0 = h0; a.g_cond = g_cond; a.ldgc = ldgc;
+    a.g_absmax = g_absmax; a.gz_absmax = gz_absmax;
     const int FT = (n_in + 31) / 32;
     a.lds_per_wave = 32 * H2_SLAB > 32 * FT * DSROW ? 32 * H2_SLAB : 32 * FT * DSROW;   /* output slab, reused for the g_feat tile */
     const size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;

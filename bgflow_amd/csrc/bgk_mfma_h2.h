@@ -43,6 +43,57 @@ __device__ __forceinline__ void h2_split8(const float (&v)[8], h2_h16x8& hi, h2_
     }
 }
 
+/* f32 pair -> f16 hi pair + f16 lo pair in 3 instructions: v_cvt_pk_f16_f32 (RNE), then lo = f16(a - hi) with the mixed-precision
+ * FMA reading hi as an f16 operand and writing one half of the destination each */
+__device__ __forceinline__ void h2_split_pair(float a0, float a1, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a0), "v"(a1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
+}
+
+/* 8 values x a power-of-two scale -> hi / lo operand halves, no clamp: the caller's scale puts the largest magnitude of the
+ * tensor (tile) into [2^14, 2^15), so nothing overflows and every value down to 2^-17 of that maximum keeps a normal lo part --
+ * gradients of 1e-6 are represented to 22 bits like the O(1) activations of the forward (round 5; unscaled they were f16
+ * subnormals).  Non-finite values stay non-finite (inf -> lo = NaN): a poisoned gradient poisons the step, which then skips itself. */
+__device__ __forceinline__ void h2_split8_scaled(const float (&v)[8], float sc, h2_h16x8& hi, h2_h16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h2_split_pair(v[2 * e] * sc, v[2 * e + 1] * sc, h[e], l[e]);
+    hi = __builtin_bit_cast(h2_h16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(h2_h16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+/* the power of two that brings a maximum magnitude m >= 0 into [2^14, 2^15), and its reciprocal; 1 for m = 0, subnormal or not
+ * finite; exponents beyond +-100 are clamped (the reciprocal stays a normal number) */
+__device__ __forceinline__ float h2_pow2_scale(float m, float& inv) {
+    const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
+    int sb = 268 - e;                              /* biased exponent of 2^(14 - (e - 127)) */
+    sb = sb < 27 ? 27 : (sb > 227 ? 227 : sb);
+    sb = (e == 0 || e == 255) ? 127 : sb;
+    inv = __builtin_bit_cast(float, (unsigned)(254 - sb) << 23);
+    return __builtin_bit_cast(float, (unsigned)sb << 23);
+}
+
+/* largest magnitude of a tile set over the whole wave (NaNs are ignored by the maximum; an inf gives inf) */
+template <int NT>
+__device__ __forceinline__ float h2_wave_absmax(const h2_f32x16 (&t)[NT]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = __builtin_fmaxf(m, __builtin_fabsf(t[i][r]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+    return m;
+}
+
+/* dst[0] = max(dst[0], m) for non-negative floats (their bit patterns order like unsigned integers); the plain read first keeps
+ * the atomic traffic to the handful of waves that actually raise the maximum */
+__device__ __forceinline__ void h2_publish_absmax(float* dst, float m) {
+    const unsigned mb = __builtin_bit_cast(unsigned, m);
+    if (mb > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), mb);
+}
+
 template <int NT>
 __device__ __forceinline__ void h2_mfma3(h2_f32x16 (&out)[NT], const H2A<NT>& a, const h2_h16x8& bhi, const h2_h16x8& blo) {
 #pragma unroll
@@ -65,6 +116,18 @@ __device__ __forceinline__ void h2_make_b(H2B<HT>& b, const h2_f32x16 (&in)[HT])
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = in[s >> 1][8 * (s & 1) + e];
         h2_split8(v, b.hi[s], b.lo[s]);
+    }
+}
+
+/* the same with the values multiplied by a power-of-two scale first (gradient tiles: see h2_split8_scaled) */
+template <int HT>
+__device__ __forceinline__ void h2_make_b_scaled(H2B<HT>& b, const h2_f32x16 (&in)[HT], float sc) {
+#pragma unroll
+    for (int s = 0; s < 2 * HT; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = in[s >> 1][8 * (s & 1) + e];
+        h2_split8_scaled(v, sc, b.hi[s], b.lo[s]);
     }
 }
 

@@ -50,7 +50,31 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     if (seg == 0 && col < P) out[col] = (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]);
 }
 
+/* largest magnitude of a row-major [B, P] matrix, raised into out[0] (non-negative floats order like their bit patterns) */
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t ldx, int64_t B, int P, float* out) {
+    float m = 0.0f;
+    const int64_t n = B * (int64_t)P;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / P;
+        m = __builtin_fmaxf(m, __builtin_fabsf(x[r * ldx + (i - r * P)]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+    const unsigned mb = __builtin_bit_cast(unsigned, m);
+    if ((threadIdx.x & 63) == 0 && mb > *reinterpret_cast<volatile unsigned*>(out)) atomicMax(reinterpret_cast<unsigned*>(out), mb);
+}
+
 }  // namespace
+
+extern "C" int bgk_absmax(const float* x, int64_t ldx, int64_t B, int32_t P, float* out, void* stream) {
+    if (B == 0) return 0;
+    BGK_CHECK_ARG(x && out, "bgk_absmax: null pointer");
+    BGK_CHECK_ARG(B >= 0 && P > 0 && ldx >= P, "bgk_absmax: bad sizes");
+    const int64_t n = B * (int64_t)P;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, B, (int)P, out);
+    return bgk_launch_status("bgk_absmax");
+}
 
 extern "C" int bgk_column_sum(const float* x, int64_t ldx, int64_t B, int32_t P, float* partial, int32_t nblk,
                               float* out, void* stream) {

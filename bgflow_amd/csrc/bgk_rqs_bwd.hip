@@ -21,6 +21,8 @@ struct RqsBwdArgs {
     const float* g_dlogp;
     float* g_y; int64_t ldgy;
     float* g_params; int64_t ldgp;
+    float* g_absmax;             /* [1] raised to the largest |g_params| written (NULL: not wanted): the power-of-two scale of the
+                                  * backward GEMMs that consume g_params (bgk_dense_backward_dx, bgk_dense_weight_grad) */
     int TS, Pp;
     uint32_t magicP;
     BgkRqsCfg cfg;
@@ -32,6 +34,16 @@ struct RqsBwdArgs {
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int BWD_TS = 128;
 
+/* the wave's largest gradient magnitude -> dst[0] (non-negative floats order like their bit patterns; NaNs do not take part: the
+ * maximum describes the finite values the consumers scale) */
+__device__ __forceinline__ void publish_absmax(float* dst, float m) {
+    if (dst == nullptr) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+    const unsigned mb = __builtin_bit_cast(unsigned, m);
+    if ((threadIdx.x & 63) == 0 && mb > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), mb);
+}
+
 template <int KT>
 __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
     constexpr int K = KT;
@@ -40,6 +52,7 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
     const BgkRqsCfg& c = a.cfg;
     const uint64_t magicd = (0x100000000ull + (uint64_t)d - 1) / (uint64_t)d;
     const int64_t n_tiles = (a.B + BWD_TS - 1) / BWD_TS;
+    float gmax = 0.0f;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t b0 = tile * BWD_TS;
         const int rows = (int)((a.B - b0) < BWD_TS ? (a.B - b0) : BWD_TS);
@@ -66,6 +79,9 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
             bgk_rqs_vjp_element<K>(c, a.inverse, rw, rh, rs, s_K, slot >= 0, x, gy, gl, ow, oh, os, g_slot, gx);
             a.g_y[(b0 + s) * a.ldgy + j] = gx;
             if (slot >= 0) grow[3 * d * K + slot] = g_slot;
+            gmax = __builtin_fmaxf(gmax, __builtin_fabsf(g_slot));
+#pragma unroll
+            for (int k = 0; k < K; ++k) gmax = __builtin_fmaxf(gmax, __builtin_fmaxf(__builtin_fabsf(ow[k]), __builtin_fmaxf(__builtin_fabsf(oh[k]), __builtin_fabsf(os[k]))));
             {
                 float* qw = grow + j * K;
                 float* qh = qw + d * K;
@@ -79,6 +95,7 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
             }
         }
     }
+    publish_absmax(a.g_absmax, gmax);
 }
 
 /* ---- any bin count: every lane walks the 3 K (+1) parameters of ITS element in memory (the backward twin of rqs_direct_kernel,
@@ -91,6 +108,7 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_direct_kernel(RqsBwdArgs 
     const bool comp = K >= BGK_RQS_COMP_FROM;
     const uint64_t magicd = (0x100000000ull + (uint64_t)d - 1) / (uint64_t)d;
     const int64_t n_tiles = (a.B + BWD_TS - 1) / BWD_TS;
+    float gmax = 0.0f;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t b0 = tile * BWD_TS;
         const int rows = (int)((a.B - b0) < BWD_TS ? (a.B - b0) : BWD_TS);
@@ -124,8 +142,9 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_direct_kernel(RqsBwdArgs 
             float* qgw = grow + (int64_t)j * K;
             float* qgh = qgw + (int64_t)d * K;
             float* qgs = qgh + (int64_t)d * K;
-            bgk_walk_grad(qw, K, c.w_scale, c.xspan, idx, kw, b.G_cw, b.G_W, qgw);
-            bgk_walk_grad(qh, K, c.h_scale, c.yspan, idx, kh, b.G_ch, b.G_H, qgh);
+            gmax = __builtin_fmaxf(gmax, bgk_walk_grad(qw, K, c.w_scale, c.xspan, idx, kw, b.G_cw, b.G_W, qgw));
+            gmax = __builtin_fmaxf(gmax, bgk_walk_grad(qh, K, c.h_scale, c.yspan, idx, kh, b.G_ch, b.G_H, qgh));
+            gmax = __builtin_fmaxf(gmax, __builtin_fmaxf(__builtin_fabsf(b.g0), __builtin_fabsf(b.g1)));
             for (int k = 0; k < K; ++k) {
                 float g = 0.0f;
                 g += (k == idx) ? b.g0 : 0.0f;
@@ -136,6 +155,7 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_direct_kernel(RqsBwdArgs 
             if (has_slot) grow[(int64_t)3 * d * K + slot] = hi_last ? b.g1 : 0.0f;
         }
     }
+    publish_absmax(a.g_absmax, gmax);
 }
 
 }  // namespace
@@ -146,7 +166,7 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
                                 double min_bin_width, double min_bin_height, double min_derivative,
                                 int32_t identity_init, const float* g_out, int64_t ldgo,
                                 const float* g_dlogp, float* g_y, int64_t ldgy, float* g_params,
-                                int64_t ldgp, void* stream) {
+                                int64_t ldgp, float* g_absmax, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && d > 0 && K > 0, "bgk_rqs_backward: bad sizes");
     BGK_CHECK_ARG(y && params && nc_slot && g_out && g_dlogp && g_y && g_params, "bgk_rqs_backward: null pointer");
@@ -155,7 +175,7 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
     RqsBwdArgs a;
     a.y = y; a.ldy = ldy; a.params = params; a.ldp = ldp; a.nc_slot = nc_slot; a.B = B; a.d = d; a.K = K; a.P = P;
     a.inverse = inverse; a.g_out = g_out; a.ldgo = ldgo; a.g_dlogp = g_dlogp; a.g_y = g_y; a.ldgy = ldgy;
-    a.g_params = g_params; a.ldgp = ldgp;
+    a.g_params = g_params; a.ldgp = ldgp; a.g_absmax = g_absmax;
     a.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, K);
     a.Pp = P | 1; a.TS = BWD_TS; a.magicP = 0;
     int64_t n_tiles = (B + BWD_TS - 1) / BWD_TS;

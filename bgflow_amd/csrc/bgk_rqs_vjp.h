@@ -261,16 +261,21 @@ __device__ __forceinline__ BgkKnotPair bgk_walk_to(const BgkSoftmaxSet& q, int K
 
 /* gradient of the set's K unnormalised parameters, written to g[0..K): the cotangents of the bin's left knot (G_c) and size (G_s)
  * reach parameter m through knot = span * cumsum(mn + sc * softmax) -- d/du_m = p_m (gp_m - sum_j p_j gp_j) with
- * gp_m = sc * span * ([m < idx] (G_c - G_s) + [m <= idx] G_s), the interior-knot conditions of the register routine included */
-__device__ __forceinline__ void bgk_walk_grad(const BgkSoftmaxSet& q, int K, float sc, float span, int idx, const BgkKnotPair& kp,
-                                              float G_c, float G_s, float* g) {
+ * gp_m = sc * span * ([m < idx] (G_c - G_s) + [m <= idx] G_s), the interior-knot conditions of the register routine included;
+ * returns the largest magnitude written */
+__device__ __forceinline__ float bgk_walk_grad(const BgkSoftmaxSet& q, int K, float sc, float span, int idx, const BgkKnotPair& kp,
+                                               float G_c, float G_s, float* g) {
     const float gA = (idx >= 1) ? (G_c - G_s) : 0.0f, gB = (idx + 1 <= K - 1) ? G_s : 0.0f;
     const float w = sc * span;
     const float dot = w * (gA * kp.below + gB * (kp.below + kp.p_bin));
+    float amax = 0.0f;
     for (int m = 0; m < K; ++m) {
         const float gp = w * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f));
-        g[m] = bgk_softmax_p(q, m) * (gp - dot);
+        const float v = bgk_softmax_p(q, m) * (gp - dot);
+        g[m] = v;
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
     }
+    return amax;          /* largest magnitude written */
 }
 
 #endif /* BGK_RQS_VJP_H */

@@ -11,19 +11,21 @@
  * form used here.
  * Decomposition: workgroup = 128 rows of the output (4 waves x one 32-row tile) x all k <= 128 columns x one slab of batch
  * rows (split-K); per step of 16 batch rows every thread fetches 8 consecutive batch rows of ONE column of g and of h
- * (each wave-level load = 32 | 64 consecutive floats of a row: coalesced), splits them into bf16 hi + lo (bf16 keeps the f32
- * exponent: gradients of 1e-8 stay normal; hi*hi + hi*lo + lo*hi leaves a 2^-16 relative error per product, below the f32
- * accumulation noise of a 2^18-term sum).  The g values a thread fetches ARE its A fragment (lane = (column, 8-row block)) and stay
+ * (each wave-level load = 32 | 64 consecutive floats of a row: coalesced), splits them into f16 hi + lo parts -- g under a
+ * per-tensor power-of-two scale that puts its largest magnitude (published by the kernel that wrote it: bgk_rqs_backward,
+ * bgk_dense_backward_dx) into [2^14, 2^15), h clamped to the f16 range like the forward's activations: hi*hi + hi*lo + lo*hi carries
+ * 22 significant bits per product, the forward's f32-class arithmetic (rounds 1-4 split into bf16 pairs, 16 bits per product: the
+ * flat KL gradient was 1.3e-4 off its f64 value).  The g values a thread fetches ARE its A fragment (lane = (column, 8-row block)) and stay
  * in registers; the h parts (shared by the four waves) go to LDS as ONE 16-byte value per part -- already the B operand layout;
  * column stride 48 B keeps the ds_read_b128 conflict-free.  LDS is double-buffered (one barrier per step).  The bias gradient is the running sum of the g values a thread loads anyway.  Partials per slab go
  * to a workspace and are summed in fixed order by wgrad_reduce_kernel: deterministic, no atomics.
  */
-#include "bgk_common.h"
+#include "bgk_mfma_h2.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WG_THREADS = 256;
 constexpr int COLS = 128;            /* columns of g (output rows) per workgroup, and max columns of h */
@@ -39,24 +41,15 @@ struct WgArgs {
     int64_t B; int64_t rows_per_slab; int n_slabs; int n_blocks;
     float* part_w;                             /* [n_slabs][n][k] */
     float* part_b;                             /* [2 n_slabs][n] */
+    const float* g_absmax;                     /* [1] largest |g| (device; NULL: g is split unscaled -- values below 6e-5 lose bits) */
 };
 
-typedef __bf16 wg_bf2 __attribute__((ext_vector_type(2)));
-typedef float wg_f2 __attribute__((ext_vector_type(2)));
-
-/* 8 values -> bf16 hi and lo parts (16 B each): v_cvt_pk_bf16_f32 (round to nearest even, 2 values per instruction), hi back to
- * f32 by a shift / mask, lo = bf16(v - hi) -- 2.5 VALU instructions per value (the integer rounding sequence this replaces took
- * 14 and made the kernel VALU-bound: 900 VALU cycles against 384 matrix-core cycles per 16-row step) */
+/* 8 values -> f16 hi and lo parts (16 B each), 1.5 VALU instructions per value + the caller's scale / clamp (h2_split_pair:
+ * v_cvt_pk_f16_f32 + 2 x v_fma_mix) */
 __device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
     unsigned h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const wg_f2 x = {v[2 * e], v[2 * e + 1]};
-        const wg_bf2 hb = __builtin_convertvector(x, wg_bf2);
-        const wg_f2 r = x - __builtin_convertvector(hb, wg_f2);
-        h[e] = __builtin_bit_cast(unsigned, hb);
-        l[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wg_bf2));
-    }
+    for (int e = 0; e < 4; ++e) h2_split_pair(v[2 * e], v[2 * e + 1], h[e], l[e]);
     hi = make_uint4(h[0], h[1], h[2], h[3]);
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
@@ -93,6 +86,8 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgGroup grp_args) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     float bsum = 0.0f;
+    float g_inv;
+    const float g_scale = h2_pow2_scale(a.g_absmax ? a.g_absmax[0] : 0.0f, g_inv);     /* max |g| -> [2^14, 2^15) */
     const int my_off = c * CSTRIDE + rg * 16;                /* where my 16-byte h values go */
     /* software pipeline, two 16-row steps deep: the 16 values of steps s + 1 and s + 2 are in flight while step s is converted /
      * multiplied (one step of distance left every step waiting on HBM: a step takes ~500 cycles, a loaded round trip > 2000).
@@ -140,7 +135,11 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgGroup grp_args) 
             for (int e = 0; e < 8; ++e) hv[e] = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hv[e] * 2.88539008177792681f));
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bsum += gv[e];
+        for (int e = 0; e < 8; ++e) {
+            bsum += gv[e];
+            gv[e] *= g_scale;
+            hv[e] = __builtin_amdgcn_fmed3f(hv[e], -65000.0f, 65000.0f);
+        }
         uint4 ghi, glo, hhi, hlo;
         split8(gv, ghi, glo);
         split8(hv, hhi, hlo);
@@ -148,16 +147,16 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgGroup grp_args) 
         *reinterpret_cast<uint4*>(base + 0 * ARR + my_off) = hhi;
         *reinterpret_cast<uint4*>(base + 1 * ARR + my_off) = hlo;
         __syncthreads();
-        const s16x8 ahi = __builtin_bit_cast(s16x8, ghi), alo = __builtin_bit_cast(s16x8, glo);
+        const h16x8 ahi = __builtin_bit_cast(h16x8, ghi), alo = __builtin_bit_cast(h16x8, glo);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (m < KT) {
                 const int rd_b = (m * 32 + (lane & 31)) * CSTRIDE + (lane >> 5) * 16;
-                const s16x8 bhi = *reinterpret_cast<const s16x8*>(base + 0 * ARR + rd_b);
-                const s16x8 blo = *reinterpret_cast<const s16x8*>(base + 1 * ARR + rd_b);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo, acc[m], 0, 0, 0);
-                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi, acc[m], 0, 0, 0);
+                const h16x8 bhi = *reinterpret_cast<const h16x8*>(base + 0 * ARR + rd_b);
+                const h16x8 blo = *reinterpret_cast<const h16x8*>(base + 1 * ARR + rd_b);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[m], 0, 0, 0);
             }
         }
         /* the other buffer is written next; its readers finished before the barrier above */
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgGroup grp_args) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = nb * COLS + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh, col = m * 32 + j;
-                if (row < a.n && col < a.k) pw[(int64_t)row * a.k + col] = acc[m][r];
+                if (row < a.n && col < a.k) pw[(int64_t)row * a.k + col] = acc[m][r] * g_inv;
             }
         }
     }
@@ -256,7 +255,8 @@ int64_t ws_need(int64_t B, int n, int k) {
     return (int64_t)n_slabs * n * k + (int64_t)2 * n_slabs * n;
 }
 
-struct GemmSpec { const char* what; const float* g; int64_t ldg; int n; const float* h; int64_t ldh; int k; int featurise; int act; float* gW; float* gb; };
+struct GemmSpec { const char* what; const float* g; int64_t ldg; int n; const float* h; int64_t ldh; int k; int featurise; int act; float* gW; float* gb;
+                  const float* g_absmax; };
 
 /* mode bits: 1 launch the GEMMs, 2 launch the reduction (red_out != NULL: also / only hand the reduction's descriptor out) */
 int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t ws_floats, int accumulate, hipStream_t st, int mode = 3,
@@ -279,7 +279,7 @@ int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t w
         BGK_CHECK_ARG(ws_floats >= used + need, "%s: workspace of %lld floats needed, %lld given", sp.what, (long long)(used + need), (long long)ws_floats);
         float* pw = ws + used;
         float* pb = pw + (int64_t)n_slabs * sp.n * sp.k;
-        grp.g[q] = WgArgs{sp.g, sp.ldg, sp.n, sp.h, sp.ldh, sp.k, sp.featurise, sp.act, B, rows, n_slabs, n_blocks, pw, pb};
+        grp.g[q] = WgArgs{sp.g, sp.ldg, sp.n, sp.h, sp.ldh, sp.k, sp.featurise, sp.act, B, rows, n_slabs, n_blocks, pw, pb, sp.g_absmax};
         red.r[q] = RedOne{pw, pb, n_slabs, sp.n, sp.k, sp.gW, sp.gb};
         blocks += n_slabs * n_blocks;
         used += need;
@@ -303,16 +303,18 @@ extern "C" int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t
 extern "C" int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
                                      const float* h1, const float* h0, int32_t h_act, const float* cond, int64_t ldc, int32_t d_c,
                                      int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
-                                     float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate, void* stream) {
+                                     float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
+                                     const float* g_absmax, void* stream) {
     BGK_CHECK_ARG(g_params && g_z1 && g_z0 && h1 && h0 && cond && workspace, "bgk_dense_weight_grad: null pointer");
     BGK_CHECK_ARG(B > 0 && P > 0 && d_c > 0 && h_act >= 0 && h_act <= 3 && accumulate >= 0 && accumulate <= 2, "bgk_dense_weight_grad: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int n_in = periodic ? 2 * d_c : d_c;
     GemmSpec specs[3];
     int count = 0;
-    if (gW2) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, h_act, gW2, gb2};
-    if (gW1) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, h_act, gW1, gb1};
-    if (gW0) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, 0, gW0, gb0};
+    const float* am = g_absmax;      /* {max |g_params|, max |g_z1|, max |g_z0|} on the device, or NULL */
+    if (gW2) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, h_act, gW2, gb2, am};
+    if (gW1) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, h_act, gW1, gb1, am ? am + 1 : nullptr};
+    if (gW0) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, 0, gW0, gb0, am ? am + 2 : nullptr};
     if (count == 0) return 0;
     /* accumulate == 2: the partial sums only -- the caller reduces them later with bgk_dense_weight_grad_reduce_many */
     const int rc = gemm_group(specs, count, B, workspace, workspace_floats, accumulate, st, accumulate == 2 ? 1 : 3);
@@ -335,9 +337,9 @@ extern "C" int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, co
             const int i = base + c;
             BGK_CHECK_ARG(B[i] > 0 && P[i] > 0 && n_in[i] > 0 && n_in[i] <= COLS && workspace[i] && gW2[i] && gW1[i] && gW0[i],
                           "bgk_dense_weight_grad_reduce_many: bad layer %d", i);
-            GemmSpec specs[3] = {GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 2)", nullptr, 0, P[i], nullptr, 0, 128, 0, 0, gW2[i], gb2[i]},
-                                 GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 1)", nullptr, 0, 128, nullptr, 0, 128, 0, 0, gW1[i], gb1[i]},
-                                 GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 0)", nullptr, 0, 128, nullptr, 0, n_in[i], 0, 0, gW0[i], gb0[i]}};
+            GemmSpec specs[3] = {GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 2)", nullptr, 0, P[i], nullptr, 0, 128, 0, 0, gW2[i], gb2[i], nullptr},
+                                 GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 1)", nullptr, 0, 128, nullptr, 0, 128, 0, 0, gW1[i], gb1[i], nullptr},
+                                 GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 0)", nullptr, 0, 128, nullptr, 0, n_in[i], 0, 0, gW0[i], gb0[i], nullptr}};
             const int rc = gemm_group(specs, 3, B[i], workspace[i], (int64_t)1 << 60, accumulate, st, 0, &M.r[c]);
             if (rc != 0) return rc;
             max_outs = M.r[c].first[3] > max_outs ? M.r[c].first[3] : max_outs;

@@ -799,13 +799,30 @@ def _featurise(x, periodic):
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
 
 
+HALF_PAD_ROWS = int(os.environ.get("BGK_HALF_PAD_ROWS", "0"))      # rows of padding between the [B, 128] halves of one allocation
+
 FUSED_MLP_BACKWARD = True    # input-gradient chain of the conditioner on bgk_dense_backward_dx (False: three GEMMs + torch act ops)
 
 
-def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs, want_h=True, t_version=None):
+def absmax_of(*tensors):
+    """[len(tensors)] device floats: max |t| of each 2-d f32 HIP tensor on bgk_absmax (None entries stay 0) -- the scale source of the
+    backward GEMMs for gradient tensors that did not come out of this library's kernels"""
+    dev = next(t for t in tensors if t is not None).device
+    out = torch.zeros(len(tensors), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for i, t in enumerate(tensors):
+            if t is None or t.numel() == 0:
+                continue
+            t2, ld = _lib.rowmajor(t.detach())
+            _lib.check(_lib.lib().bgk_absmax(_lib.ptr(t2), ld, t2.shape[0], t2.shape[1], _lib.ptr(out[i:]), _lib.stream_ptr(dev)), "bgk_absmax")
+    return out
+
+
+def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs, want_h=True, t_version=None, absmax=None):
     """bgk_pack_dense_h2_t + bgk_dense_backward_dx: returns (g_z1, g_z0, h1, h0, g_x or None); ``want_h=False``: the activations
     are not written (h1 = h0 = None: the weight-gradient kernel recomputes them from z1 / z0).  ``t_version``: state key of the three
-    weights; when ``bufs`` already holds the transposed operands of that state (repack_training_plans) the pack is skipped."""
+    weights; when ``bufs`` already holds the transposed operands of that state (repack_training_plans) the pack is skipped.
+    ``absmax``: [3] device floats, [0] = max |g_p| on entry (bgk_rqs_backward's), [1] / [2] zero: raised to max |g_z1| / |g_z0|."""
     dev = g_p.device
     B, P = g_p.shape
     n_in = W0.shape[1]
@@ -814,7 +831,10 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
     g2, ldg = _lib.rowmajor(g_p)
     x2, ldc = _lib.rowmajor(x.detach())
     d_c = x2.shape[1]
-    out = torch.empty((4 if want_h else 2, B, 128), dtype=torch.float32, device=dev)
+    # (the halves of ONE allocation: at B = 2^18 they would sit exactly 2^27 bytes apart -- row r of g_z1 and row r of g_z0, which a
+    # wave writes back to back, on the same memory channel and bank.  HALF_PAD_ROWS rows between them break the power-of-two stride.)
+    n_out = 4 if want_h else 2
+    out = torch.empty((n_out, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)[:, :B]
     g_x = torch.empty((B, d_c), dtype=torch.float32, device=dev) if want_gx else None
     ws = [w.detach().contiguous() for w in (W0, W1, W2)]
     with torch.cuda.device(dev):
@@ -826,7 +846,8 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
         st = _lib.lib().bgk_dense_backward_dx(_lib.ptr(g2), ldg, P, _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic),
                                               _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.ptr(cs), act_code, B,
                                               _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]) if want_h else None,
-                                              _lib.ptr(out[3]) if want_h else None, _lib.ptr(g_x), d_c, _lib.stream_ptr(dev))
+                                              _lib.ptr(out[3]) if want_h else None, _lib.ptr(g_x), d_c,
+                                              _lib.ptr(absmax), _lib.ptr(absmax[1:]) if absmax is not None else None, _lib.stream_ptr(dev))
         _lib.check(st, "bgk_dense_backward_dx")
     return out[0], out[1], (out[2] if want_h else None), (out[3] if want_h else None), g_x
 
@@ -883,13 +904,14 @@ class direct_grad_accumulation:
         return False
 
 
-def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, params=None, h_act=0):
+def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, params=None, h_act=0, absmax=None):
     """bgk_dense_weight_grad: (gW0, gb0, gW1, gb1, gW2, gb2) of one coupling layer's conditioner.
     ``params`` = (W0, b0, W1, b1, W2, b2): inside ``direct_grad_accumulation()`` (entered by FlatAdam.backward / KLTrainer only),
     when ALL of them carry a flat-bucket gradient destination (``_bgk_grad_dst``, set by training.FlatAdam), the kernel accumulates
     straight into the bucket and None is returned for every gradient -- no per-parameter AccumulateGrad add kernels (96 tiny
     launches per cfg-3 step).  ``h_act`` != 0: ``h1`` / ``h0`` are the saved
-    pre-activations and the kernel applies activation ``h_act`` while loading them."""
+    pre-activations and the kernel applies activation ``h_act`` while loading them.  ``absmax``: [3] device floats {max |g_p|,
+    max |g_z1|, max |g_z0|} (the kernels that wrote the gradients publish them; None: measured here with bgk_absmax)."""
     dev = g_p.device
     B, P = g_p.shape
     g2, ldg = _lib.rowmajor(g_p)
@@ -915,6 +937,8 @@ def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, p
     def wbuf(w, b, shape):   # a bias gradient without its weight gradient: give the kernel a scratch weight buffer
         return w if (w is not None or b is None) else torch.empty(shape, dtype=torch.float32, device=dev)
     w2, w1, w0 = wbuf(gW2, gb2, (P, 128)), wbuf(gW1, gb1, (128, 128)), wbuf(gW0, gb0, (128, n_in))
+    if absmax is None:
+        absmax = absmax_of(g_p, g_z1, g_z0)
     mode = int(direct)
     if direct and DEFERRED_WGRAD_REDUCE:
         if ws.data_ptr() in _PENDING_REDUCE:     # the same layer twice in one backward pass: its first partial set goes out first
@@ -925,7 +949,7 @@ def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, p
         st = lib.bgk_dense_weight_grad(_lib.ptr(g2), ldg, P, _lib.ptr(g_z1), _lib.ptr(g_z0), _lib.ptr(h1), _lib.ptr(h0), int(h_act),
                                        _lib.ptr(x2), ldc, x2.shape[1], int(periodic), B, _lib.ptr(ws), ws.numel(),
                                        _lib.ptr(w2), _lib.ptr(gb2), _lib.ptr(w1), _lib.ptr(gb1), _lib.ptr(w0), _lib.ptr(gb0),
-                                       mode, _lib.stream_ptr(dev))
+                                       mode, _lib.ptr(absmax), _lib.stream_ptr(dev))
     _lib.check(st, "bgk_dense_weight_grad")
     if direct:
         return (None,) * 6
@@ -947,8 +971,8 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         P = W2.shape[0]
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
         dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
-        z0 = torch.empty((B, 128), dtype=torch.float32, device=dev)
-        z1 = torch.empty((B, 128), dtype=torch.float32, device=dev)
+        zz = torch.empty((2, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)      # (see _dense_backward_dx on the padding)
+        z0, z1 = zz[0, :B], zz[1, :B]
         ldp = param_pitch(P)
         params = torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :P]
         left, right, bottom, top, s = tcfg
@@ -982,13 +1006,16 @@ class _FusedSplineTrainFn(torch.autograd.Function):
         fused_wg = FUSED_WEIGHT_GRAD and y.is_cuda and W0.shape[1] <= 128
         recompute_h = False
         fused_dx = cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= T_OPERAND_MAX_IN
-        g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp)
+        # largest magnitudes of g_params | g_z1 | g_z0, raised by the kernels that write them: the power-of-two scales under which the
+        # backward GEMMs split these gradients into f16 hi + lo operand pairs (f32-class products whatever the loss scale)
+        absmax = torch.zeros(3, dtype=torch.float32, device=y.device)
+        g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp, absmax=absmax)
         if fused_dx:
             # with the fused weight-gradient kernel downstream the activations h1 / h0 are not materialised: it re-applies the
             # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)
             recompute_h = fused_wg
             g_z1, g_z0, h1, h0, g_x = _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, need[0], ctx.tbufs,
-                                                         want_h=not recompute_h, t_version=ctx.t_version)
+                                                         want_h=not recompute_h, t_version=ctx.t_version, absmax=absmax)
         else:
             h1 = act(z1)
             g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
@@ -1002,13 +1029,14 @@ class _FusedSplineTrainFn(torch.autograd.Function):
                 g_x = torch.autograd.grad(feats, xx, _matmul_nn(g_z0, W0))[0]
             elif need[0]:
                 g_x = _matmul_nn(g_z0, W0)
+            absmax = None            # g_z1 / g_z0 came out of library GEMMs: _dense_weight_grad measures them
         if fused_wg:
             if recompute_h:
                 gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, z1, z0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs,
-                                                                  params=ctx.params, h_act=act_code)
+                                                                  params=ctx.params, h_act=act_code, absmax=absmax)
             else:
                 gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs,
-                                                                  params=ctx.params)
+                                                                  params=ctx.params, absmax=absmax)
         else:
             feats = _featurise(x.detach(), periodic)
             gW2 = _gram_tn(g_p, h1) if need[6] else None

@@ -233,7 +233,7 @@ class _RQSFn(torch.autograd.Function):
         return (g_y, g_p) + (None,) * 9
 
 
-def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp):
+def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp, absmax=None):
     """Launch bgk_rqs_backward: VJP of rqs_transform w.r.t. (y, params); cfg = (n_bins, inverse, left, right, bottom,
     top, settings).  Any bin count: 4 / 8 / 12 / 16 / 32 bins on the register-resident streaming kernel, every other count on the
     kernel's direct variant (the parameters stay in memory and are walked) -- no device torch ops in the backward either."""
@@ -254,7 +254,7 @@ def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp):
             _lib.ptr(y2), ldy, _lib.ptr(p2), ldp, P, _lib.ptr(nc_slot), B, d, n_bins, int(inverse),
             left, right, bottom, top, settings["min_bin_width"], settings["min_bin_height"],
             settings["min_derivative"], int(settings.get("enable_identity_init", False)),
-            _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), ldgp,
+            _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), ldgp, _lib.ptr(absmax),
             _lib.stream_ptr(y.device))
     _lib.check(st, "bgk_rqs_backward")
     return g_y.reshape(y.shape), g_p.reshape(params.shape)

@@ -79,14 +79,17 @@ int bgk_rqs_transform(const float* y, int64_t ldy, const float* params, int64_t 
 
 /* Backward of bgk_rqs_transform for first-order losses (KL / NLL):
  *   given g_out [B,d] (ldgo) and g_dlogp [B], produces g_y [B,d] (ldgy) and g_params [B,P] (ldgp).
- * Replaces torch autograd through the op chain above.  K in {4, 8, 12, 16, 32} (BGK_EUNSUPPORTED otherwise). */
+ * Replaces torch autograd through the op chain above.  Any bin count: 4 / 8 / 12 / 16 / 32 bins on a register-resident streaming
+ * kernel, any other on a variant that walks the element's parameters in memory (round 5; like the forward, more than 64 bins use
+ * compensated knot sums).  g_absmax (device, may be NULL): g_absmax[0] is raised to the largest |g_params| written -- zero it first;
+ * bgk_dense_backward_dx / bgk_dense_weight_grad derive the power-of-two scale of their f16 operand split from it. */
 int bgk_rqs_backward(const float* y, int64_t ldy, const float* params, int64_t ldp, int32_t P,
                      const int32_t* nc_slot, int64_t B, int32_t d, int32_t K, int32_t inverse,
                      double left, double right, double bottom, double top,
                      double min_bin_width, double min_bin_height, double min_derivative,
                      int32_t identity_init,
                      const float* g_out, int64_t ldgo, const float* g_dlogp,
-                     float* g_y, int64_t ldgy, float* g_params, int64_t ldgp, void* stream);
+                     float* g_y, int64_t ldgy, float* g_params, int64_t ldgp, float* g_absmax, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Affine (RealNVP / NICE) transformer, conditioner outputs given.
@@ -426,7 +429,12 @@ int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const
  * written -- bgk_dense_weight_grad can recompute them from z1 / z0) -- the operands of the weight / bias gradient GEMMs -- and g_cond [B, d_c] (NULL to skip; periodic != 0: through the cos / sin
  * featuriser of nn/periodic.py:30-37, needs cond).  T0..T2: transposed-weight operands from bgk_pack_dense_h2_t with the
  * scale table cs of bgk_pack_dense_h2 for the same weights; sizes in 1 KiB blocks: T0 17 ceil(n_in / 32), T1 68,
- * T2 8 S2 + 4 with S2 = ceil(P / 16) rounded up to a multiple of 4 (zero blocks behind the last column). */
+ * T2 8 S2 + 4 with S2 = ceil(P / 16) rounded up to a multiple of 4 (zero blocks behind the last column).
+ * Arithmetic (round 5): every GEMM multiplies f16 hi + lo operand pairs (22 significant bits per product, f32 accumulate) like the
+ * forward; the gradient operands are split under a power-of-two scale -- g under 2^s with max |g| 2^s in [2^14, 2^15), max |g| read from
+ * g_absmax[0] (device; what bgk_rqs_backward / bgk_absmax wrote; NULL: unscaled, values below 6e-5 lose bits), the tiles g_z1 / g_z0
+ * that feed the next GEMM under the scale of the tile's own maximum.  gz_absmax (device, may be NULL): [0] / [1] are raised to the
+ * largest |g_z1| / |g_z0| written (zero them first) -- the scales bgk_dense_weight_grad needs. */
 int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
                         const float* cs, void* T0, void* T1, void* T2, void* stream);
 /* bgk_pack_dense_h2_t for n conditioners in one launch per 16 of them (same results as n single calls) */
@@ -437,7 +445,7 @@ int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z
                           const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                           const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
                           int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
-                          float* g_cond, int64_t ldgc, void* stream);
+                          float* g_cond, int64_t ldgc, const float* g_absmax, float* gz_absmax, void* stream);
 
 /* Optimizer step on the flat parameter bucket (f-2: the optimizer of KLTrainer.train, nn/training/trainers.py:148-201).
  * bgk_grad_nan_flag sets flag[0] = any(isnan(g)) on the device (the reference's "found nan in grad; skipping optimization
@@ -503,7 +511,11 @@ int bgk_philox_fields(uint64_t seed, uint32_t offset, int64_t row0, int32_t n_fi
  *   training forward and the kernel applies the activation while loading (bgk_dense_backward_dx then need not write h1 / h0:
  *   a fifth less HBM traffic in that kernel).
  * Split over the batch into slabs whose partials are summed in fixed order (deterministic); workspace size in floats from
- * bgk_dense_weight_grad_workspace.  Replaces 3 split-K hipBLASLt GEMMs + 3 reductions + 6 column-sum launches per layer. */
+ * bgk_dense_weight_grad_workspace.  Replaces 3 split-K hipBLASLt GEMMs + 3 reductions + 6 column-sum launches per layer.
+ * Arithmetic (round 5): products of f16 hi + lo operand pairs (22 significant bits, f32 accumulate; rounds 1 - 4: bf16 pairs, 16 bits);
+ * g_absmax (device, may be NULL) = {max |g_params|, max |g_z1|, max |g_z0|} as published by bgk_rqs_backward (g_absmax) and
+ * bgk_dense_backward_dx (gz_absmax) or computed by bgk_absmax: each gradient tensor is split under the power of two that puts its
+ * maximum into [2^14, 2^15) (NULL: unscaled -- gradient values below 6e-5 lose bits). */
 /* accumulate = 2: only the partial sums are formed (deterministic slabs in the workspace); bgk_dense_weight_grad_reduce_many then
  * reduces the partial sets of n layers -- same B, P, n_in, workspace and destinations as their bgk_dense_weight_grad calls, all
  * six destinations of a layer given -- in ONE launch per 16 layers (accumulate there: 0 overwrite, 1 add to the destinations): the
@@ -512,7 +524,8 @@ int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in);
 int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
                           const float* h1, const float* h0, int32_t h_act, const float* cond, int64_t ldc, int32_t d_c,
                           int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
-                          float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate, void* stream);
+                          float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
+                          const float* g_absmax, void* stream);
 int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* P, const int32_t* n_in,
                                       float* const* workspace, float* const* gW2, float* const* gb2, float* const* gW1,
                                       float* const* gb1, float* const* gW0, float* const* gb0, int32_t accumulate, void* stream);
@@ -522,6 +535,11 @@ int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t
  * Deterministic two-stage reduction; `partial` is a caller-provided [nblk, P] workspace. */
 int bgk_column_sum(const float* x, int64_t ldx, int64_t B, int32_t P, float* partial, int32_t nblk,
                    float* out, void* stream);
+
+/* out[0] = max(out[0], max |x[r, c]|) over a row-major [B, P] matrix (out[0] >= 0 on entry, e.g. zeroed): the per-tensor power-of-two
+ * scale of the backward GEMMs (bgk_dense_backward_dx, bgk_dense_weight_grad) for a gradient tensor that did not come out of a
+ * kernel of this library (those publish their own maximum: the g_absmax / gz_absmax arguments below). */
+int bgk_absmax(const float* x, int64_t ldx, int64_t B, int32_t P, float* out, void* stream);
 
 /* Static PCA whitening / blackening of a coordinate block on its own: out = (x - pre) T + post.
  * Replaces WhitenFlow._whiten / _blacken (nn/flow/pca.py:74-93: torch.matmul(x - X0mean, Twhiten), torch.matmul(z, Tblacken) + X0mean);

@@ -13,6 +13,7 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "gpu_slow: needs a real MI355X and minutes of host time (opt in with `-m gpu_slow`; not part of `-m gpu`)")
 
 
 @pytest.fixture(scope="session")

@@ -1223,8 +1223,10 @@ def test_global_ic_backward_kernels(hip_lib, golden, dev):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,P,d_c,periodic,gscale", [(4133, 425, 17, 0, 1.0), (1000, 225, 17, 1, 1e-7), (70000, 408, 9, 0, 3e-6)])
 def test_dense_weight_grad_kernel(hip_lib, dev, B, P, d_c, periodic, gscale):
-    """bgk_dense_weight_grad (dW = g^T h, db = sum g over the batch, bf16 hi+lo split on the matrix cores, deterministic
-    slab reduction) against f64 matmuls -- ragged batch, tiny gradient magnitudes, cos/sin featuriser"""
+    """bgk_dense_weight_grad (dW = g^T h, db = sum g over the batch, f16 hi+lo split on the matrix cores under a per-tensor
+    power-of-two scale of g -- here measured by bgk_absmax --, deterministic slab reduction) against f64 matmuls -- ragged batch,
+    tiny gradient magnitudes, cos/sin featuriser.  Round 5: 22-bit products (5e-6 of the largest entry; the bf16 pairs of rounds
+    1 - 4 were held to 3e-5)"""
     from bgflow_amd.dense import _dense_weight_grad
     g = torch.Generator(device=dev).manual_seed(B)
     g_p = torch.randn(B, P, device=dev, generator=g) * gscale
@@ -1241,7 +1243,7 @@ def test_dense_weight_grad_kernel(hip_lib, dev, B, P, d_c, periodic, gscale):
     for got, want, name in zip(res, ref, ("gW0", "gb0", "gW1", "gb1", "gW2", "gb2")):
         scale = float(want.abs().max())
         err = float((got.double() - want).abs().max())
-        assert err <= 3e-5 * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
+        assert err <= 5e-6 * scale, f"{name}: {err:.3e} vs scale {scale:.3e}"
     # activation applied on the fly: the h arrays hold pre-activations (what bgk_dense_backward_dx's caller passes when it does
     # not materialise h1 / h0)
     for code, fn in ((1, torch.nn.functional.silu), (2, torch.relu), (3, torch.tanh)):
@@ -1251,7 +1253,7 @@ def test_dense_weight_grad_kernel(hip_lib, dev, B, P, d_c, periodic, gscale):
         for got, want, name in zip(res_a, ref_a, ("gW0", "gb0", "gW1", "gb1", "gW2", "gb2")):
             scale = float(want.abs().max())
             err = float((got.double() - want).abs().max())
-            assert err <= 3e-5 * scale, f"act {code} {name}: {err:.3e} vs scale {scale:.3e}"
+            assert err <= 5e-6 * scale, f"act {code} {name}: {err:.3e} vs scale {scale:.3e}"
 
 
 def test_flat_adam_matches_torch_adam_and_skips_nan(hip_lib, dev):

@@ -471,9 +471,9 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
     assert "Scaling is not compatible with periodicity." in err()             # transformer/affine.py:26-27
     # valid requests outside a fused kernel's envelope -> BGK_EUNSUPPORTED (callers fall back to the generic kernels)
     # (bgk_rqs_backward takes any bin count since round 5: its argument checks only)
-    assert L.bgk_rqs_backward(P1, 17, P1, 263, 300, P1, 8, 17, 5, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 263, None) == -1
+    assert L.bgk_rqs_backward(P1, 17, P1, 263, 300, P1, 8, 17, 5, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 263, None, None) == -1
     assert "bad params width" in err()
-    assert L.bgk_rqs_backward(P1, 17, P1, 263, 263, P1, 8, 17, 5, 0, 0.0, 1.0, 0.0, 1.0, 0.3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 263, None) == -1
+    assert L.bgk_rqs_backward(P1, 17, P1, 263, 263, P1, 8, 17, 5, 0, 0.0, 1.0, 0.0, 1.0, 0.3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 263, None, None) == -1
     assert "too large for the number of bins" in err()
     tail = (P1, 17, 8, 17, 8, 0, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None)
     assert L.bgk_coupling_rqs_dense_h2(P1, 17, 17, 0, P1, P1, P1, 1.0, 1.0, 1.0, None, 0, 64, 64, 1, *tail) == -2
@@ -482,7 +482,7 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
     assert "operand_dtype" in err()
     assert L.bgk_coupling_affine_dense_h2(P1, 32, 32, 0, P1, P1, P1, 1.0, 1.0, 1.0, 2, P1, P1, P1, 1.0, 1.0, 1.0, 3,
                                           256, P1, 0, 0, 0, P1, 32, 8, 32, P1, 32, P1, 0, None) == -2
-    assert L.bgk_dense_backward_dx(P1, 425, 425, P1, P1, P1, 120, 120, 0, P1, P1, P1, P1, 1, 8, P1, P1, P1, P1, None, 0, None) == -2
+    assert L.bgk_dense_backward_dx(P1, 425, 425, P1, P1, P1, 120, 120, 0, P1, P1, P1, P1, 1, 8, P1, P1, P1, P1, None, 0, None, None, None) == -2
     assert L.bgk_column_sum(P1, 4, 8, 0, P1, 4, P1, None) == -1
     # round 4 entry points: empty batches, envelope and argument checks before any launch
     n1 = (ctypes.c_void_p * 1)(0x1000)
