@@ -82,7 +82,7 @@ _SIGNATURES = {
                                                     i32, vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32, vp]),
     "bgk_pack_dense_h2_t": (ctypes.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "bgk_dense_backward_dx": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, i64,
-                                             vp, vp, vp, vp, vp, i64, vp, vp, vp]),
+                                             vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp]),
     "bgk_dense_weight_grad_reduce_many": (ctypes.c_int, [i32] + [vp] * 10 + [i32, vp]),
     "bgk_pack_dense_h2_many": (ctypes.c_int, [i32] + [vp] * 14 + [vp]),
     "bgk_pack_dense_h2_t_many": (ctypes.c_int, [i32] + [vp] * 9 + [vp]),

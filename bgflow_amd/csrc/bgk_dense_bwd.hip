@@ -36,6 +36,7 @@ struct DenseBwdArgs {
     int act; int64_t B;
     float* g_z1; float* g_z0; float* h1; float* h0;
     float* g_cond; int64_t ldgc;
+    const float* g_cond_add; int64_t ldga;        /* NULL, or a [B, d_c] tensor added to g_cond on the way out (may BE g_cond: accumulation in place) */
     int lds_per_wave;
     const float* g_absmax;                        /* [1] largest |g| of the launch (device; NULL: g enters the first GEMM unscaled) */
     float* gz_absmax;                             /* [2] raised to the largest |g_z1|, |g_z0| written (NULL: not wanted) */
@@ -173,12 +174,13 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
     if (!a.periodic) {
         if (j < rows) {
             float* orow = a.g_cond + (b0 + j) * a.ldgc;
+            const float* arow = a.g_cond_add ? a.g_cond_add + (b0 + j) * a.ldga : nullptr;
 #pragma unroll
             for (int m = 0; m < FT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = h2_row(m, r, hh);
-                    if (f < a.d_c) orow[f] = gf[m][r] * (c0 * inv0);
+                    if (f < a.d_c) orow[f] = gf[m][r] * (c0 * inv0) + (arow ? arow[f] : 0.0f);
                 }
         }
     } else {
@@ -194,7 +196,8 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
             float sv, cv;
             bgk_sincos2pif(a.cond[(b0 + r) * a.ldc + c], &sv, &cv);
             const float gc = s_f[c * DSROW + r], gs = s_f[(a.d_c + c) * DSROW + r];
-            a.g_cond[(b0 + r) * a.ldgc + c] = 6.28318530717958648f * (cv * gs - sv * gc);
+            const float prev = a.g_cond_add ? a.g_cond_add[(b0 + r) * a.ldga + c] : 0.0f;
+            a.g_cond[(b0 + r) * a.ldgc + c] = 6.28318530717958648f * (cv * gs - sv * gc) + prev;
         }
     }
 }
@@ -394,7 +397,8 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
                                      const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                      const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
                                      int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
-                                     float* g_cond, int64_t ldgc, const float* g_absmax, float* gz_absmax, void* stream) {
+                                     float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                                     const float* g_absmax, float* gz_absmax, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(g && z1 && z0 && T0 && T1 && T2 && cs && g_z1 && g_z0, "bgk_dense_backward_dx: null pointer");
     BGK_CHECK_ARG((h1 == nullptr) == (h0 == nullptr), "bgk_dense_backward_dx: h1 and h0 are written both or not at all");
@@ -408,6 +412,8 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.S2 = ((P + 15) / 16 + DBWD_PAD - 1) / DBWD_PAD * DBWD_PAD; a.cs = cs; a.act = act; a.B = B;
     a.g_z1 = g_z1; a.g_z0 = g_z0; a.h1 = h1; a.h0 = h0; a.g_cond = g_cond; a.ldgc = ldgc;
     a.g_absmax = g_absmax; a.gz_absmax = gz_absmax;
+    a.g_cond_add = g_cond ? g_cond_add : nullptr; a.ldga = ldga;
+    BGK_CHECK_ARG(!a.g_cond_add || ldga >= d_c, "bgk_dense_backward_dx: bad row stride of g_cond_add");
     const int FT = (n_in + 31) / 32;
     a.lds_per_wave = 32 * H2_SLAB > 32 * FT * DSROW ? 32 * H2_SLAB : 32 * FT * DSROW;   /* output slab, reused for the g_feat tile */
     const size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;

@@ -818,11 +818,14 @@ def absmax_of(*tensors):
     return out
 
 
-def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs, want_h=True, t_version=None, absmax=None):
+def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_gx, bufs, want_h=True, t_version=None, absmax=None,
+                       gx_add=None, gx_out=None):
     """bgk_pack_dense_h2_t + bgk_dense_backward_dx: returns (g_z1, g_z0, h1, h0, g_x or None); ``want_h=False``: the activations
     are not written (h1 = h0 = None: the weight-gradient kernel recomputes them from z1 / z0).  ``t_version``: state key of the three
     weights; when ``bufs`` already holds the transposed operands of that state (repack_training_plans) the pack is skipped.
-    ``absmax``: [3] device floats, [0] = max |g_p| on entry (bgk_rqs_backward's), [1] / [2] zero: raised to max |g_z1| / |g_z0|."""
+    ``absmax``: [3] device floats, [0] = max |g_p| on entry (bgk_rqs_backward's), [1] / [2] zero: raised to max |g_z1| / |g_z0|.
+    ``gx_add``: a [B, d_c] tensor the kernel adds to the conditioner-input gradient (``gx_out``: where the sum goes; may be ``gx_add``
+    itself -- accumulation in place -- default: a fresh tensor)."""
     dev = g_p.device
     B, P = g_p.shape
     n_in = W0.shape[1]
@@ -835,7 +838,8 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
     # wave writes back to back, on the same memory channel and bank.  HALF_PAD_ROWS rows between them break the power-of-two stride.)
     n_out = 4 if want_h else 2
     out = torch.empty((n_out, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)[:, :B]
-    g_x = torch.empty((B, d_c), dtype=torch.float32, device=dev) if want_gx else None
+    g_x = (gx_out if gx_out is not None else torch.empty((B, d_c), dtype=torch.float32, device=dev)) if want_gx else None
+    add2, lda = _lib.rowmajor(gx_add) if (gx_add is not None and want_gx) else (None, 0)
     ws = [w.detach().contiguous() for w in (W0, W1, W2)]
     with torch.cuda.device(dev):
         if t_version is None or bufs.get("t_version") != t_version:
@@ -846,8 +850,8 @@ def _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, want_
         st = _lib.lib().bgk_dense_backward_dx(_lib.ptr(g2), ldg, P, _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic),
                                               _lib.ptr(T0), _lib.ptr(T1), _lib.ptr(T2), _lib.ptr(cs), act_code, B,
                                               _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]) if want_h else None,
-                                              _lib.ptr(out[3]) if want_h else None, _lib.ptr(g_x), d_c,
-                                              _lib.ptr(absmax), _lib.ptr(absmax[1:]) if absmax is not None else None, _lib.stream_ptr(dev))
+                                              _lib.ptr(out[3]) if want_h else None, _lib.ptr(g_x), _lib.rowmajor(g_x)[1] if g_x is not None else d_c,
+                                              _lib.ptr(add2), lda, _lib.ptr(absmax), _lib.ptr(absmax[1:]) if absmax is not None else None, _lib.stream_ptr(dev))
         _lib.check(st, "bgk_dense_backward_dx")
     return out[0], out[1], (out[2] if want_h else None), (out[3] if want_h else None), g_x
 
@@ -956,101 +960,237 @@ def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, p
     return gW0, gb0, gW1, gb1, gW2, gb2
 
 
-class _FusedSplineTrainFn(torch.autograd.Function):
-    """Forward = ONE launch of bgk_coupling_rqs_dense_h2_train (conditioner MLP on the f16 matrix cores + spline; the
-    pre-activations z0, z1 and the spline parameters are written out for the backward pass).  Backward = bgk_rqs_backward
-    + the MLP's backward as plain GEMMs on the saved tensors (bias gradients on bgk_column_sum)."""
+def _train_forward_launch(x, y, W2, plan, tcfg, inverse, oob, dlogp=None, accumulate=False):
+    """bgk_coupling_rqs_dense_h2_train: (out, dlogp [B], z0, z1, params).  ``dlogp`` / ``accumulate``: the layer's log-det is written
+    (or, accumulate, ADDED) into the caller's [B] buffer -- the running log|det J| of a chain of layers"""
+    A0, A1, A2, (c0, c1, c2) = plan["packed"]
+    x2, ldc = _lib.rowmajor(x)
+    y2, ldy = _lib.rowmajor(y)
+    B, d = y2.shape
+    dev = y.device
+    P = W2.shape[0]
+    out = torch.empty((B, d), dtype=torch.float32, device=dev)
+    if dlogp is None:
+        dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=dev), False
+    zz = torch.empty((2, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)      # (see _dense_backward_dx on the padding)
+    z0, z1 = zz[0, :B], zz[1, :B]
+    ldp = param_pitch(P)
+    params = torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :P]
+    left, right, bottom, top, s = tcfg
+    with torch.cuda.device(dev):
+        st = _lib.lib().bgk_coupling_rqs_dense_h2_train(
+            _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2,
+            _lib.ptr(plan.get("cs")), 128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
+            left, right, bottom, top, s["min_bin_width"], s["min_bin_height"], s["min_derivative"],
+            int(s.get("enable_identity_init", False)), _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)), _lib.ptr(oob),
+            _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), ldp, _lib.ptr(plan["src_col_dev"]), _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_coupling_rqs_dense_h2_train")
+    return out, dlogp, z0, z1, params
 
-    @staticmethod
-    def forward(ctx, x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob, t_version=None):
-        A0, A1, A2, (c0, c1, c2) = plan["packed"]
-        x2, ldc = _lib.rowmajor(x)
-        y2, ldy = _lib.rowmajor(y)
-        B, d = y2.shape
-        dev = y.device
-        P = W2.shape[0]
-        out = torch.empty((B, d), dtype=torch.float32, device=dev)
-        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
-        zz = torch.empty((2, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)      # (see _dense_backward_dx on the padding)
-        z0, z1 = zz[0, :B], zz[1, :B]
-        ldp = param_pitch(P)
-        params = torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :P]
+
+class _LayerCtx:
+    """what the backward of one fused training layer needs besides its saved tensors"""
+    __slots__ = ("params", "cs", "tbufs", "t_version", "act", "periodic", "rcfg")
+
+    def __init__(self, params, plan, tcfg, inverse, t_version):
         left, right, bottom, top, s = tcfg
-        with torch.cuda.device(dev):
-            st = _lib.lib().bgk_coupling_rqs_dense_h2_train(
-                _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2,
-                _lib.ptr(plan.get("cs")), 128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
-                left, right, bottom, top, s["min_bin_width"], s["min_bin_height"], s["min_derivative"],
-                int(s.get("enable_identity_init", False)), _lib.ptr(out), d, _lib.ptr(dlogp), 0, _lib.ptr(oob),
-                _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), ldp, _lib.ptr(plan["src_col_dev"]), _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_coupling_rqs_dense_h2_train")
-        ctx.save_for_backward(x, y, W0, W1, W2, z0, z1, params, nc_dev)
-        ctx.params = (W0, b0, W1, b1, W2, b2)   # the nn.Parameters themselves (flat-bucket gradient destinations hang on them)
-        ctx.cs = plan.get("cs")                 # scale table of the operands packed for this forward (same weights in backward)
-        ctx.tbufs = plan.setdefault("tbufs", {})
+        self.params = params                # the nn.Parameters themselves (flat-bucket gradient destinations hang on them)
+        self.cs = plan.get("cs")            # scale table of the operands packed for this forward (same weights in backward)
+        self.tbufs = plan.setdefault("tbufs", {})
         # state of the three weight PARAMETERS this forward ran on: the key of the transposed operands the backward packs / reuses.
         # (W0..W2 themselves may be temporaries -- the zero-padded views of a narrow conditioner -- whose (data_ptr, version) repeats
         # from step to step once the caching allocator recycles their storage: never key a cache on them.)
-        ctx.t_version = t_version
-        ctx.meta = (plan["act"], bool(plan["periodic"]), (plan["n_bins"], inverse, left, right, bottom, top, dict(s)))
+        self.t_version = t_version
+        self.act, self.periodic = plan["act"], bool(plan["periodic"])
+        self.rcfg = (plan["n_bins"], inverse, left, right, bottom, top, dict(s))
+
+
+def _train_backward_layer(lc, x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g_dlogp, need_gx, need_w, gx_add=None, gx_out=None,
+                          absmax=None):
+    """Backward of one fused training layer: bgk_rqs_backward, the conditioner's input-gradient chain (bgk_dense_backward_dx; layers
+    outside its envelope: library GEMMs) and the weight / bias gradients (bgk_dense_weight_grad).  ``need_w``: the six flags of
+    (W0, b0, W1, b1, W2, b2).  ``gx_add`` / ``gx_out``: see _dense_backward_dx (fused chain only; otherwise added here).
+    Returns (g_x or None, g_y, (gW0, gb0, gW1, gb1, gW2, gb2))."""
+    from .transformer import rqs_backward
+    act_code, periodic, rcfg, cs = lc.act, lc.periodic, lc.rcfg, lc.cs
+    act, act_bwd = _act_fwd_bwd(act_code)
+    need = [need_gx, True] + list(need_w)
+    fused_wg = FUSED_WEIGHT_GRAD and y.is_cuda and W0.shape[1] <= 128
+    recompute_h = False
+    fused_dx = cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= T_OPERAND_MAX_IN
+    # largest magnitudes of g_params | g_z1 | g_z0, raised by the kernels that write them: the power-of-two scales under which the
+    # backward GEMMs split these gradients into f16 hi + lo operand pairs (f32-class products whatever the loss scale)
+    if absmax is None:
+        absmax = torch.zeros(3, dtype=torch.float32, device=y.device)
+    g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp, absmax=absmax)
+    if fused_dx:
+        # with the fused weight-gradient kernel downstream the activations h1 / h0 are not materialised: it re-applies the
+        # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)
+        recompute_h = fused_wg
+        g_z1, g_z0, h1, h0, g_x = _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, need_gx, lc.tbufs,
+                                                     want_h=not recompute_h, t_version=lc.t_version, absmax=absmax,
+                                                     gx_add=gx_add, gx_out=gx_out)
+    else:
+        h1 = act(z1)
+        g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
+        h0 = act(z0)
+        g_z0 = act_bwd(_matmul_nn(g_z1, W1), z0, h0)
+        g_x = None
+        if need_gx and periodic:
+            with torch.enable_grad():
+                xx = x.detach().requires_grad_(True)
+                feats = _featurise(xx, True)
+            g_x = torch.autograd.grad(feats, xx, _matmul_nn(g_z0, W0))[0]
+        elif need_gx:
+            g_x = _matmul_nn(g_z0, W0)
+        if g_x is not None and gx_add is not None:
+            g_x = g_x + gx_add
+        absmax = None            # g_z1 / g_z0 came out of library GEMMs: _dense_weight_grad measures them
+    if fused_wg:
+        if recompute_h:
+            gws = _dense_weight_grad(g_p, g_z1, g_z0, z1, z0, x.detach(), periodic, W0.shape[1], need, lc.tbufs,
+                                     params=lc.params, h_act=act_code, absmax=absmax)
+        else:
+            gws = _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x.detach(), periodic, W0.shape[1], need, lc.tbufs,
+                                     params=lc.params, absmax=absmax)
+    else:
+        feats = _featurise(x.detach(), periodic)
+        gws = (_gram_tn(g_z0, feats.contiguous()) if need[2] else None, column_sum(g_z0) if need[3] else None,
+               _gram_tn(g_z1, h0) if need[4] else None, column_sum(g_z1) if need[5] else None,
+               _gram_tn(g_p, h1) if need[6] else None, column_sum(g_p) if need[7] else None)
+    return g_x, g_y, gws
+
+
+class _FusedSplineTrainFn(torch.autograd.Function):
+    """Forward = ONE launch of bgk_coupling_rqs_dense_h2_train (conditioner MLP on the f16 matrix cores + spline; the
+    pre-activations z0, z1 and the spline parameters are written out for the backward pass).  Backward = _train_backward_layer."""
+
+    @staticmethod
+    def forward(ctx, x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob, t_version=None):
+        out, dlogp, z0, z1, params = _train_forward_launch(x, y, W2, plan, tcfg, inverse, oob)
+        ctx.save_for_backward(x, y, W0, W1, W2, z0, z1, params, nc_dev)
+        ctx.lc = _LayerCtx((W0, b0, W1, b1, W2, b2), plan, tcfg, inverse, t_version)
         return out, dlogp[:, None]
 
     @staticmethod
     def backward(ctx, g_out, g_dlogp):
-        from .transformer import rqs_backward
         x, y, W0, W1, W2, z0, z1, params, nc_dev = ctx.saved_tensors
-        act_code, periodic, rcfg = ctx.meta
-        act, act_bwd = _act_fwd_bwd(act_code)
         need = ctx.needs_input_grad
-        cs = ctx.cs
-        fused_wg = FUSED_WEIGHT_GRAD and y.is_cuda and W0.shape[1] <= 128
-        recompute_h = False
-        fused_dx = cs is not None and FUSED_MLP_BACKWARD and W0.shape[1] <= T_OPERAND_MAX_IN
-        # largest magnitudes of g_params | g_z1 | g_z0, raised by the kernels that write them: the power-of-two scales under which the
-        # backward GEMMs split these gradients into f16 hi + lo operand pairs (f32-class products whatever the loss scale)
-        absmax = torch.zeros(3, dtype=torch.float32, device=y.device)
-        g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp, absmax=absmax)
-        if fused_dx:
-            # with the fused weight-gradient kernel downstream the activations h1 / h0 are not materialised: it re-applies the
-            # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)
-            recompute_h = fused_wg
-            g_z1, g_z0, h1, h0, g_x = _dense_backward_dx(g_p, z1, z0, x, W0, W1, W2, cs, act_code, periodic, need[0], ctx.tbufs,
-                                                         want_h=not recompute_h, t_version=ctx.t_version, absmax=absmax)
-        else:
-            h1 = act(z1)
-            g_z1 = act_bwd(_matmul_nn(g_p, W2), z1, h1)
-            h0 = act(z0)
-            g_z0 = act_bwd(_matmul_nn(g_z1, W1), z0, h0)
-            g_x = None
-            if need[0] and periodic:
-                with torch.enable_grad():
-                    xx = x.detach().requires_grad_(True)
-                    feats = _featurise(xx, True)
-                g_x = torch.autograd.grad(feats, xx, _matmul_nn(g_z0, W0))[0]
-            elif need[0]:
-                g_x = _matmul_nn(g_z0, W0)
-            absmax = None            # g_z1 / g_z0 came out of library GEMMs: _dense_weight_grad measures them
-        if fused_wg:
-            if recompute_h:
-                gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, z1, z0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs,
-                                                                  params=ctx.params, h_act=act_code, absmax=absmax)
-            else:
-                gW0, gb0, gW1, gb1, gW2, gb2 = _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x.detach(), periodic, W0.shape[1], need, ctx.tbufs,
-                                                                  params=ctx.params, absmax=absmax)
-        else:
-            feats = _featurise(x.detach(), periodic)
-            gW2 = _gram_tn(g_p, h1) if need[6] else None
-            gb2 = column_sum(g_p) if need[7] else None
-            gW1 = _gram_tn(g_z1, h0) if need[4] else None
-            gb1 = column_sum(g_z1) if need[5] else None
-            gW0 = _gram_tn(g_z0, feats.contiguous()) if need[2] else None
-            gb0 = column_sum(g_z0) if need[3] else None
-        return (g_x, g_y if need[1] else None, gW0, gb0, gW1, gb1, gW2, gb2) + (None,) * 6
+        g_x, g_y, gws = _train_backward_layer(ctx.lc, x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g_dlogp, need[0], need[2:8])
+        return (g_x, g_y if need[1] else None, *gws) + (None,) * 6
 
 
-def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob_counter):
-    """Differentiable one-launch forward of the spline coupling layer (split-f16 mode only).  Returns (y', dlogp) or None
-    when the conditioner is not a fusable DenseNet."""
+class _SplineChainTrainFn(torch.autograd.Function):
+    """A run of fused spline coupling layers as ONE autograd node.  Forward: one bgk_coupling_rqs_dense_h2_train launch per layer, all of
+    them adding their log-det to one [B] buffer.  Backward: the layers in reverse with the field gradients kept in per-slot buffers --
+    the conditioner-input gradient of a layer is ADDED to its slot's buffer inside bgk_dense_backward_dx (g_cond_add), so the sums
+    autograd forms with one elementwise launch per extra consumer of a field (a field conditions several layers and is transformed by
+    others: 18 adds + 16 log-det adds per step of the 16-layer cfg-3 flow) do not exist; neither do the per-layer autograd nodes.
+
+    apply(layers, n_slots, *slot tensors, *per layer (W0, b0, W1, b1, W2, b2)); ``layers[i]`` = (transformed slot, conditioning slot,
+    (plan, tcfg, nc_dev, inverse, oob, t_version)).  Returns (*the final tensors of the slots some layer transformed -- in slot order --,
+    dlogp [B, 1])."""
+
+    @staticmethod
+    def forward(ctx, layers, n_slots, *tensors):
+        state = list(tensors[:n_slots])
+        weights = tensors[n_slots:]
+        saved, lcs, io = [], [], []
+        dlogp = None
+        for i, (ti, ci, (plan, tcfg, nc_dev, inverse, oob, t_version)) in enumerate(layers):
+            W0, b0, W1, b1, W2, b2 = weights[6 * i:6 * i + 6]
+            x, y = state[ci], state[ti]
+            out, dlogp, z0, z1, params = _train_forward_launch(x, y, W2, plan, tcfg, inverse, oob, dlogp=dlogp, accumulate=i > 0)
+            io.append((len(saved), len(saved) + 1))
+            saved += [x, y, W0, W1, W2, z0, z1, params, nc_dev]
+            lcs.append(_LayerCtx((W0, b0, W1, b1, W2, b2), plan, tcfg, inverse, t_version))
+            state[ti] = out
+        ctx.save_for_backward(*saved)
+        ctx.lcs, ctx.n_slots = lcs, n_slots
+        ctx.route = [(ti, ci) for ti, ci, _ in layers]
+        ctx.outs = sorted({ti for ti, _, _ in layers})
+        # a conditioning slot needs its gradient where the flow's input there does, or where an earlier layer of the chain wrote it
+        touched, want = set(), []
+        for ti, ci, _ in layers:
+            want.append(bool(ctx.needs_input_grad[2 + ci]) or ci in touched)
+            touched.add(ti)
+        ctx.want_gx = want
+        return (*[state[s] for s in ctx.outs], dlogp[:, None])
+
+    @staticmethod
+    def backward(ctx, *grads):
+        saved = ctx.saved_tensors
+        *g_outs, g_dlogp = grads
+        n_slots, L = ctx.n_slots, len(ctx.lcs)
+        G = [None] * n_slots                 # gradient w.r.t. the CURRENT state of every slot, walking the layers backwards
+        owned = [False] * n_slots            # buffers of this backward (may be added to in place); autograd's own are never written
+        for s, g in zip(ctx.outs, g_outs):
+            G[s] = g
+        need = ctx.needs_input_grad
+        dev = g_dlogp.device
+        absmax = torch.zeros((L, 3), dtype=torch.float32, device=dev)       # one fill for the whole chain
+        w_grads = [None] * (6 * L)
+        for i in range(L - 1, -1, -1):
+            ti, ci = ctx.route[i]
+            x, y, W0, W1, W2, z0, z1, params, nc_dev = saved[9 * i:9 * i + 9]
+            g_out = G[ti]
+            if g_out is None:                # the slot's final tensor took no part in the loss
+                g_out = torch.zeros_like(y)
+            prev = G[ci]
+            g_x, g_y, gws = _train_backward_layer(
+                ctx.lcs[i], x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g_dlogp, ctx.want_gx[i], need[2 + n_slots + 6 * i:2 + n_slots + 6 * i + 6],
+                gx_add=prev, gx_out=prev if (prev is not None and owned[ci]) else None, absmax=absmax[i])
+            G[ti], owned[ti] = g_y, True
+            if g_x is not None:
+                G[ci], owned[ci] = g_x, True
+            w_grads[6 * i:6 * i + 6] = gws
+        slot_grads = [G[s] if need[2 + s] else None for s in range(n_slots)]
+        return (None, None, *slot_grads, *w_grads)
+
+
+def spline_chain_train(blocks, xs, inverse):
+    """A run of CouplingFlow blocks (execution order) whose spline transformers all take the fused training path, as ONE autograd node
+    (_SplineChainTrainFn).  Returns the new state tuple and dlogp [B, 1], or None when a block is outside the envelope (the caller
+    then runs the blocks one by one): one transformed and one conditioning tensor per block, 2-d f32 HIP tensors, fusable
+    conditioners in split-f16 mode."""
+    xs = list(xs)
+    used = sorted({int(b.transformed_indices[0]) for b in blocks} | {int(b.cond_indices[0]) for b in blocks})
+    if any(len(b.transformed_indices) != 1 or len(b.cond_indices) != 1 for b in blocks) or used[-1] >= len(xs):
+        return None
+    if not all(torch.is_tensor(xs[s]) and xs[s].is_cuda and xs[s].dtype == torch.float32 and xs[s].dim() == 2 for s in used):
+        return None
+    pos = {s: k for k, s in enumerate(used)}
+    layers, weights = [], []
+    widths = {s: xs[s].shape[-1] for s in used}
+    B = xs[used[0]].shape[0]
+    if B == 0 or any(xs[s].shape[0] != B for s in used):
+        return None
+    dev = xs[used[0]].device
+    for b in blocks:
+        tr = b.transformer
+        ti, ci = int(b.transformed_indices[0]), int(b.cond_indices[0])
+        if not getattr(tr, "allow_fused", False) or getattr(tr, "return_bin_indices", False):
+            return None
+        nc_dev, nc_host = tr._nc_slot(widths[ti], dev)
+        # shapes only: the prep reads nothing of the tensors' values (layer i's inputs do not exist yet)
+        probe_x = torch.empty((0, widths[ci]), dtype=torch.float32, device=dev)
+        probe_y = torch.empty((0, widths[ti]), dtype=torch.float32, device=dev)
+        prep = _spline_train_prep(tr, probe_x, probe_y, nc_dev, nc_host, inverse, tr._oob_counter(dev))
+        if prep is None:
+            return None
+        layers.append((pos[ti], pos[ci], prep[1]))
+        weights += list(prep[0])
+    res = _SplineChainTrainFn.apply(layers, len(used), *[xs[s] for s in used], *weights)
+    outs = sorted({ti for ti, _, _ in layers})
+    for k, o in zip(outs, res[:-1]):
+        xs[used[k]] = o
+    return tuple(xs), res[-1]
+
+
+def _spline_train_prep(transformer, x, y, nc_dev, nc_host, inverse, oob_counter):
+    """What a differentiable one-launch forward of the spline coupling layer needs (split-f16 mode only): (W0, b0, W1, b1, W2, b2 --
+    the parameters, or their zero-padded differentiable views for a narrow conditioner --, plan, tcfg, nc_dev, inverse, oob, t_version),
+    or None when the conditioner is not a fusable DenseNet."""
     if x.dim() != 2 or y.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or _gemm_mode(transformer) != "f16x2":
         return None
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
@@ -1077,5 +1217,13 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
         W0, b0 = pad(W0, (0, 0, 0, h0)), pad(b0, (0, h0))
         W1, b1 = pad(W1, (0, h0, 0, h1)), pad(b1, (0, h1))
         W2 = pad(W2, (0, h1))
-    return _FusedSplineTrainFn.apply(x, y, W0, b0, W1, b1, W2, b2, plan, tcfg, nc_dev, inverse, oob_counter, t_version)
+    return (W0, b0, W1, b1, W2, b2), (plan, tcfg, nc_dev, inverse, oob_counter, t_version)
 
+
+def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob_counter):
+    """Differentiable one-launch forward of the spline coupling layer (split-f16 mode only).  Returns (y', dlogp) or None
+    when the conditioner is not a fusable DenseNet."""
+    prep = _spline_train_prep(transformer, x, y, nc_dev, nc_host, inverse, oob_counter)
+    if prep is None:
+        return None
+    return _FusedSplineTrainFn.apply(x, y, *prep[0], *prep[1])

@@ -8,6 +8,7 @@ transformer.py / ic.py and run hand-written HIP kernels.
 Reference files mirrored here (names, constructor signatures, error behaviour):
   bgflow/nn/flow/base.py, sequential.py, inverted.py, coupling.py.
 """
+import os
 import warnings
 from collections.abc import Sequence
 
@@ -148,6 +149,7 @@ class SequentialFlow(Flow):
     FUSE_GENERATION_TAIL = True   # icdf domain maps + IC -> xyz as one kernel in the sampling direction (bgk_icdf_ic2xyz)
     FUSE_TRAINING_TAIL = True     # ... also when the inputs need gradients: one-launch forward that keeps the mapped fields for the backward
     FUSE_COUPLING_STACKS = True   # Split -> (affine Coupling | Swap)* -> Merge on ONE [B, D] buffer: no cat / per-layer outputs
+    FUSE_TRAINING_CHAINS = os.environ.get("BGK_TRAIN_CHAIN", "1") != "0"   # training: runs of fused spline couplings as ONE autograd node
 
     _bgk_acc = True
     ACCUMULATE_IN_KERNELS = True   # one running log-det buffer, written by the kernels themselves, when no gradient is needed
@@ -165,17 +167,17 @@ class SequentialFlow(Flow):
                 torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             acc = _LogDetAcc(xs[0].shape[0], xs[0].device)
         if acc is None:
-            # same accumulation as the reference (sequential.py:49,58): start from the python float 0.0,
-            # `dlogp += ddlogp` (new tensor for the first block, in place afterwards)
-            total = 0.0
-            for i, (label, seg) in enumerate(self.segments(inverse=inverse)):
+            # the accumulation of the reference (sequential.py:49,58: `dlogp = 0.0; dlogp += ddlogp`) without its first launch: the
+            # first segment's log-det IS the running sum (0.0 + t is t), later ones are added out of place
+            total = None
+            for i, (label, seg) in enumerate(self.segments(inverse=inverse, train=True)):
                 if around is None:
                     *xs, ddlogp = seg(*xs, inverse=inverse, **kwargs)
                 else:
                     with around(i, label):
                         *xs, ddlogp = seg(*xs, inverse=inverse, **kwargs)
-                total += ddlogp
-            return (*xs, total)
+                total = ddlogp if total is None else total + ddlogp
+            return (*xs, 0.0 if total is None else total)
         kwargs[ACC_KW] = acc
         for i, (label, seg) in enumerate(self.segments(inverse=inverse)):
             kw = _acc_kwargs(seg, kwargs)
@@ -188,17 +190,25 @@ class SequentialFlow(Flow):
                     acc.add(ddlogp)
         return (*xs, acc if outer is not None else acc.result())
 
-    def segments(self, inverse=False):
+    def segments(self, inverse=False, train=False):
         """[(label, callable)] in execution order: the blocks themselves, except that in the sampling direction a tail of
         builder domain maps ``WrapFlow(InverseFlow(CDFTransform))`` followed by ``WrapFlow(InverseFlow(<IC transform>))``
-        (generator_builder.py:443-459 + add_map_to_cartesian) runs as ONE fused kernel when the inputs need no gradients."""
+        (generator_builder.py:443-459 + add_map_to_cartesian) runs as ONE fused kernel when the inputs need no gradients.
+        ``train``: the list of a pass that builds an autograd graph -- runs of spline coupling blocks are one segment there
+        (_SplineTrainChain: one autograd node, field gradients accumulated inside the backward kernels)."""
         blocks = list(self._blocks)
-        # the segment list (and what the fused segments cache: descriptor tables) is rebuilt only when the blocks or the switches change
-        key = (bool(inverse), self.FUSE_GENERATION_TAIL, self.FUSE_COUPLING_STACKS, tuple(id(b) for b in blocks))
+        # the segment lists (and what the fused segments cache: descriptor tables) are rebuilt only when the blocks or the switches change
+        train = bool(train) and self.FUSE_TRAINING_CHAINS
+        key = (self.FUSE_GENERATION_TAIL, self.FUSE_COUPLING_STACKS, tuple(id(b) for b in blocks))
         cache = self.__dict__.setdefault("_segment_cache", {})
         if cache.get("key") != key:
-            cache["key"], cache["segments"] = key, self._build_segments(blocks, inverse)
-        return cache["segments"]
+            cache.clear()
+            cache["key"] = key
+        which = (bool(inverse), train)
+        if which not in cache:
+            segs = self._build_segments(blocks, inverse)
+            cache[which] = _with_train_chains(segs) if train else segs
+        return cache[which]
 
     def _build_segments(self, blocks, inverse):
         tail = self._generation_tail() if self.FUSE_GENERATION_TAIL else None
@@ -282,6 +292,62 @@ class SequentialFlow(Flow):
             return self._blocks[index]
         picked = np.arange(len(self))[index]
         return SequentialFlow([self._blocks[i] for i in picked])
+
+
+def _with_train_chains(segs):
+    """``segs`` with every run of >= 2 consecutive spline coupling blocks replaced by one _SplineTrainChain segment"""
+    from .transformer import ConditionalSplineTransformer
+    out, run = [], []
+
+    def flush():
+        if len(run) >= 2:
+            out.append(("spline chain", _SplineTrainChain([b for _, b in run])))
+        else:
+            out.extend(run)
+        run.clear()
+    for label, seg in segs:
+        if type(seg) is CouplingFlow and type(seg.transformer) is ConditionalSplineTransformer and seg.cat_dim == -1 \
+                and len(seg.transformed_indices) == 1 and len(seg.cond_indices) == 1:
+            run.append((label, seg))
+        else:
+            flush()
+            out.append((label, seg))
+    flush()
+    return out
+
+
+class _SplineTrainChain:
+    """callable standing in for a run of spline CouplingFlow blocks in a pass that builds an autograd graph: the whole run is one
+    autograd node (dense._SplineChainTrainFn) -- one training-forward launch per layer adding into one log-det buffer; in the
+    backward the conditioner-input gradients are accumulated per field inside bgk_dense_backward_dx.  Falls back to the blocks
+    themselves when nothing needs a gradient, a block carries extra keyword arguments, or a layer is outside the fused training
+    envelope."""
+
+    _bgk_acc = True
+
+    def __init__(self, blocks):
+        self._blocks = blocks
+
+    def _blocks_path(self, *xs, inverse=False, **kwargs):
+        acc = kwargs.get(ACC_KW)
+        total = None
+        for block in self._blocks:
+            *xs, dd = block(*xs, inverse=inverse, **_acc_kwargs(block, kwargs))
+            if acc is not None:
+                acc.add(dd)
+            else:
+                total = dd if total is None else total + dd
+        return (*xs, acc if acc is not None else total)
+
+    def __call__(self, *xs, inverse=False, **kwargs):
+        from .dense import spline_chain_train
+        if kwargs.get(ACC_KW) is None and not set(kwargs) - {"temperature"} and torch.is_grad_enabled() and (
+                any(torch.is_tensor(x) and x.requires_grad for x in xs)
+                or any(p.requires_grad for b in self._blocks for p in b.parameters())):
+            res = spline_chain_train(self._blocks, xs, inverse)
+            if res is not None:
+                return (*res[0], res[1])
+        return self._blocks_path(*xs, inverse=inverse, **kwargs)
 
 
 def _split_sizes(block, inverse, merging):

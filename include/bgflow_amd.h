@@ -434,7 +434,11 @@ int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const
  * forward; the gradient operands are split under a power-of-two scale -- g under 2^s with max |g| 2^s in [2^14, 2^15), max |g| read from
  * g_absmax[0] (device; what bgk_rqs_backward / bgk_absmax wrote; NULL: unscaled, values below 6e-5 lose bits), the tiles g_z1 / g_z0
  * that feed the next GEMM under the scale of the tile's own maximum.  gz_absmax (device, may be NULL): [0] / [1] are raised to the
- * largest |g_z1| / |g_z0| written (zero them first) -- the scales bgk_dense_weight_grad needs. */
+ * largest |g_z1| / |g_z0| written (zero them first) -- the scales bgk_dense_weight_grad needs.
+ * g_cond_add (may be NULL; row stride ldga): a [B, d_c] tensor added to the conditioner-input gradient on its way out,
+ * g_cond = g_cond_add + (chain result) -- the sum autograd forms with an elementwise launch when the conditioning tensor has other
+ * consumers (a later coupling transforms it, another one is conditioned on it too); g_cond_add may BE g_cond (every element is read
+ * and written by the same lane). */
 int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
                         const float* cs, void* T0, void* T1, void* T2, void* stream);
 /* bgk_pack_dense_h2_t for n conditioners in one launch per 16 of them (same results as n single calls) */
@@ -445,7 +449,8 @@ int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z
                           const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                           const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
                           int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
-                          float* g_cond, int64_t ldgc, const float* g_absmax, float* gz_absmax, void* stream);
+                          float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                          const float* g_absmax, float* gz_absmax, void* stream);
 
 /* Optimizer step on the flat parameter bucket (f-2: the optimizer of KLTrainer.train, nn/training/trainers.py:148-201).
  * bgk_grad_nan_flag sets flag[0] = any(isnan(g)) on the device (the reference's "found nan in grad; skipping optimization

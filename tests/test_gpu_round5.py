@@ -30,9 +30,8 @@ def test_narrow_hidden_layers_over_two_optimizer_steps(hip_lib, dev, hidden):
     second step could run its input-gradient chain on operands packed from the first step's weights.  Two steps with the graph
     freed in between (the allocator then hands the same addresses back), every step's gradients against the layer-by-layer path on
     the same weights."""
-    from bgflow_amd import dense
     layer = _spline_layer(dev, hidden=hidden)
-    opt = torch.optim.SGD(layer.parameters(), lr=0.05)
+    opt = torch.optim.SGD(layer.parameters(), lr=1e-3)      # weights move by ~10 % per step: stale operands would be off by as much
     B = 2048
 
     def step_grads(fused):
@@ -55,7 +54,7 @@ def test_narrow_hidden_layers_over_two_optimizer_steps(hip_lib, dev, hidden):
         layer.zero_grad()
         for p, g in zip(layer.parameters(), g_ref):
             p.grad = g.clone()
-        opt.step()                      # large step: stale operands would be off by far more than the tolerance
+        opt.step()
         torch.cuda.empty_cache() if it == 1 else None
 
 
@@ -208,3 +207,69 @@ def test_hardware_sincos_of_the_generation_tail_on_a_long_chain(hip_lib, oracle,
     assert err <= 4 * err_b + 2e-6, f"hardware sin / cos: {err:.2e} against {err_b:.2e} for the polynomial form"
     rel = np.abs(dl.cpu().numpy().reshape(-1) - np.asarray(dl64).reshape(-1)) / np.maximum(np.abs(np.asarray(dl64).reshape(-1)), 1.0)
     assert np.median(rel) <= 2e-6 and rel.max() <= 1e-4
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("B", [777, 32])
+def test_spline_chain_as_one_autograd_node(hip_lib, dev, B, inverse):
+    """training pass of the cfg-3 couplings as ONE autograd node (flow._SplineTrainChain / dense._SplineChainTrainFn: log-dets added
+    into one buffer by the forward launches, conditioner-input gradients accumulated per field inside bgk_dense_backward_dx) against the
+    block-by-block path (one node per layer, autograd's own accumulation): same outputs, same log-det, same parameter and input
+    gradients -- every field conditions several layers and is transformed by others, inputs that need a gradient and inputs that do not"""
+    import bgflow_amd as bg
+    from bgflow_amd import configs
+    gen = configs.make_ala2_spline_generator(dev)
+    flow = bg.SequentialFlow(list(gen.flow)[:16])
+    assert [lbl for lbl, _ in flow.segments(train=True)] == ["spline chain"] and len(flow.segments()) == 16
+    res = {}
+    for chain in (True, False):
+        flow.FUSE_TRAINING_CHAINS = chain
+        for p in flow.parameters():
+            p.grad = None
+        xs = [torch.rand(B, d, device=dev, generator=torch.Generator(device=dev).manual_seed(40 + i)) for i, d in enumerate((17, 17, 17, 9))]
+        xs[0].requires_grad_(True); xs[2].requires_grad_(True)         # bonds and torsions want gradients, angles / fixed do not
+        *out, dl = flow(*xs, inverse=inverse)
+        w = torch.linspace(0.5, 1.5, B, device=dev)[:, None]
+        (sum((o * o * w).sum() for o in out) - (dl * w).sum()).backward()
+        res[chain] = ([o.detach() for o in out], dl.detach(), [p.grad.clone() for p in flow.parameters()], [xs[0].grad.clone(), xs[2].grad.clone()])
+        assert xs[1].grad is None and xs[3].grad is None
+    (o1, d1, gp1, gx1), (o0, d0, gp0, gx0) = res[True], res[False]
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    assert float((d1 - d0).abs().max()) <= 1e-5 * max(1.0, float(d0.abs().max()))        # (the order of the 16 additions differs)
+    for a, b in zip(gp1 + gx1, gp0 + gx0):
+        assert a.shape == b.shape and bool(torch.isfinite(a).all())
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6), f"gradient of shape {tuple(a.shape)}"
+
+
+def test_kl_step_launches_few_aten_kernels(hip_lib, dev):
+    """the KL training step of the bench (cfg 3) between its first forward launch and the optimizer: what is left of torch's own
+    elementwise / copy kernels once the log-dets and the field gradients are accumulated inside the flow's kernels (round 4: 30 adds +
+    26 copies per step)"""
+    from torch.profiler import ProfilerActivity, profile
+    from bgflow_amd import configs, dp
+    from bgflow_amd.training import FlatAdam
+    gen = configs.make_ala2_spline_generator(dev)
+    opt = FlatAdam(list(gen.flow.parameters()), lr=1e-5)
+    z = [torch.rand(4096, d, device=dev) for d in (17, 17, 17, 9)]
+
+    def step():
+        opt.zero_grad()
+        *x, dlogp = gen.flow(*z)
+        loss = dp.global_kl_mean(gen._target, x, dlogp, drop_nonfinite=True)
+        opt.backward(loss)
+        opt.step()
+    step(); step()
+    torch.cuda.synchronize()
+    try:
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            step()
+            torch.cuda.synchronize()
+    except Exception as e:          # no kernel tracer on this box
+        pytest.skip(f"torch.profiler unavailable: {e!r}")
+    names = [e.key for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA for _ in range(e.count)]
+    aten = [n for n in names if "at::native" in n or "elementwise" in n or "copyBuffer" in n or "fillBuffer" in n or "Memset" in n or "Memcpy" in n]
+    if not names:
+        pytest.skip("torch.profiler recorded no device kernels")
+    print("device kernels of one KL step:", len(names), "of which torch's own:", len(aten), sorted(set(aten)))
+    assert len(aten) <= 12, f"{len(aten)} aten / copy / fill launches in one KL step: {sorted(set(aten))}"

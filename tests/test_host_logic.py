@@ -482,7 +482,7 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
     assert "operand_dtype" in err()
     assert L.bgk_coupling_affine_dense_h2(P1, 32, 32, 0, P1, P1, P1, 1.0, 1.0, 1.0, 2, P1, P1, P1, 1.0, 1.0, 1.0, 3,
                                           256, P1, 0, 0, 0, P1, 32, 8, 32, P1, 32, P1, 0, None) == -2
-    assert L.bgk_dense_backward_dx(P1, 425, 425, P1, P1, P1, 120, 120, 0, P1, P1, P1, P1, 1, 8, P1, P1, P1, P1, None, 0, None, None, None) == -2
+    assert L.bgk_dense_backward_dx(P1, 425, 425, P1, P1, P1, 120, 120, 0, P1, P1, P1, P1, 1, 8, P1, P1, P1, P1, None, 0, None, 0, None, None, None) == -2
     assert L.bgk_column_sum(P1, 4, 8, 0, P1, 4, P1, None) == -1
     # round 4 entry points: empty batches, envelope and argument checks before any launch
     n1 = (ctypes.c_void_p * 1)(0x1000)
