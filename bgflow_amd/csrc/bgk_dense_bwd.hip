@@ -213,6 +213,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
     if (tile >= n_tiles) return;
     const int64_t b0 = tile * 32;
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    SBD_TS(0);
 
     /* ---- g_h1 = W2^T g : B operand straight from the row-major gradient ---- */
     h2_f32x16 acc[4];

@@ -29,6 +29,41 @@ __device__ __forceinline__ void bgk_softmax_knots(const float (&u)[KT], float mn
     kn[KT] = high;
 }
 
+/* BGK_VJP_FAST: the knots on the hardware forms too, in the regrouped form of the fused forward kernels (bgk_fused2.hip::rqs_fast):
+ * knot_k = low + span min (k + 1) + (span scale / sum e) prefix_k(e) -- exp2, one Newton-refined reciprocal, 7 adds + 8 fma per set
+ * instead of 8 polynomial exps and 8 correctly rounded quotients (~330 fewer instructions per set; the stand-alone backward kernel
+ * is VALU-bound: 1.3 k instructions per element x 4.5 M elements = 170 us of the chip's VALU time at 2^18 samples x 17 dims).
+ * The knots then differ from the deterministic forward's by ~1e-7: an input within that distance of a knot may be evaluated in the
+ * neighbouring bin -- the spline is C1 there, so the output gradient is continuous across the knot (the training forward
+ * of the fused layers uses the same hardware forms anyway). */
+#ifndef BGK_VJP_FAST
+#define BGK_VJP_FAST 0
+#endif
+template <int KT>
+__device__ __forceinline__ void bgk_softmax_knots_fast(const float (&u)[KT], float mn, float sc, float span, float low, float high,
+                                                       float (&p)[KT], float (&kn)[KT + 1]) {
+    float m = u[0];
+#pragma unroll
+    for (int k = 1; k < KT; ++k) m = __builtin_fmaxf(m, u[k]);
+    const float nm = -(m * 1.44269504088896341f);
+    float e[KT], c[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) e[k] = __builtin_amdgcn_exp2f(__builtin_fmaf(u[k], 1.44269504088896341f, nm));
+    c[0] = e[0];
+#pragma unroll
+    for (int k = 1; k < KT; ++k) c[k] = c[k - 1] + e[k];
+    const float r0 = __builtin_amdgcn_rcpf(c[KT - 1]);
+    const float r = __builtin_fmaf(__builtin_fmaf(-c[KT - 1], r0, 1.0f), r0, r0);
+    const float g = (span * sc) * r, dstep = span * mn;
+    kn[0] = low;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        p[k] = e[k] * r;
+        kn[k + 1] = __builtin_fmaf(c[k], g, __builtin_fmaf(dstep, (float)(k + 1), low));
+    }
+    kn[KT] = high;
+}
+
 /* Behind the knots (which decide the bin and are bit-identical to the forward's) nothing here is compared bit for bit with
  * anything: hardware reciprocal / exp2 / log2 / sqrt (1 ulp) instead of the correctly rounded sequences -- a third of the
  * element's instructions. */
@@ -133,8 +168,13 @@ __device__ __forceinline__ void bgk_rqs_vjp_element(const BgkRqsCfg& c, int inve
                                                     const float (&rs)[K], float s_K, bool has_slot, float x, float gy, float gl,
                                                     float (&ow)[K], float (&oh)[K], float (&os)[K], float& g_slot, float& gx_out) {
     float pw[K], ph[K], cw[K + 1], ch[K + 1];
+#if BGK_VJP_FAST
+    bgk_softmax_knots_fast<K>(rw, c.min_w, c.w_scale, c.xspan, c.left, c.right, pw, cw);
+    bgk_softmax_knots_fast<K>(rh, c.min_h, c.h_scale, c.yspan, c.bottom, c.top, ph, ch);
+#else
     bgk_softmax_knots<K>(rw, c.min_w, c.w_scale, c.xspan, c.left, c.right, pw, cw);
     bgk_softmax_knots<K>(rh, c.min_h, c.h_scale, c.yspan, c.bottom, c.top, ph, ch);
+#endif
     const bool clamped = (x < c.left) | (x > c.right);
     x = x < c.left ? c.left : (x > c.right ? c.right : x);
     int idx = -1;
