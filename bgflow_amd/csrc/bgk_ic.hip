@@ -11,6 +11,7 @@
  * like the reference, eps clamps included); transcendental functions are the precise OCML ones.
  */
 #include "bgk_common.h"
+#include "bgk_dual.h"
 #include <stdlib.h>
 
 namespace {
@@ -505,6 +506,7 @@ struct IcBwdArgs {
     float* g_bonds; float* g_angles; float* g_torsions; int64_t ldgic;
     float* g_xfix; int64_t ldgf;
     int sx, sic, sfx;
+    float eps; int enforce;             /* the forward's norm clamps (ic_helper.py:372-452): where one fired the adjoint is evaluated on dual numbers */
 };
 
 __device__ __forceinline__ void tile_load64(float* dst, int s, const float* src, int64_t ld, int rows, int cols) {
@@ -524,6 +526,118 @@ __device__ __forceinline__ V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.
 __device__ __forceinline__ V3 proj_out(V3 g, V3 u, float inv_norm) {   /* (g - u (u.g)) / |v|  : adjoint of v -> v/|v| */
     float p = dot(u, g);
     return {(g.x - u.x * p) * inv_norm, (g.y - u.y * p) * inv_norm, (g.z - u.z * p) * inv_norm};
+}
+
+/* 1 / |v| from the squared norm: hardware rsq + one Newton step (the adjoint of a normalisation is amplified by 1 / |v| twice over when
+ * the placement's reference atoms nearly coincide -- a bond of 5e-4 nm makes |v1 x (v1 x v2)| ~ 1e-7) */
+__device__ __forceinline__ float inv_sqrt_refined(float n2) {
+    const float r = __builtin_amdgcn_rsqf(n2);
+    return r * __builtin_fmaf(-0.5f * n2, r * r, 1.5f);
+}
+/* sin(2 pi f), f in [0, 1): the hardware form (|error| <= 1.3e-7 ABSOLUTE) except within 1/32 revolution of a zero, where the
+ * log-det term gl cos a / sin a needs the sine to RELATIVE accuracy (an angle 1e-5 from pi: 1 % off on the hardware form) --
+ * there the odd series in the exact distance to the zero */
+__device__ __forceinline__ float sin_rev_near_zero_exact(float f) {
+    const float k = __builtin_rintf(2.0f * f);                 /* 0, 1 or 2 half revolutions */
+    const float r = __builtin_fmaf(k, -0.5f, f);               /* exact */
+    const float x = r * 6.28318530717958647692f, z = x * x;
+    float p = __builtin_fmaf(z, 8.33333333e-3f, -1.66666667e-1f);
+    p = __builtin_fmaf(p * z, x, x);
+    p = ((int)k & 1) ? -p : p;
+    return __builtin_fabsf(r) < 0.03125f ? p : __builtin_amdgcn_sinf(f);
+}
+
+/* VJP of ONE placement exactly as the reference differentiates it -- torch autograd through ic2xyz_deriv (ic_helper.py:372-452) and
+ * log|det J| of its explicit Jacobian (ic.py:435-513), eps clamps with torch.clamp's derivative (a clamped norm passes none) -- on
+ * forward-mode dual numbers: 12 inputs, 4 passes of Dual<3>.  Taken only where a norm of the placement was clamped (atoms that
+ * nearly coincide: a bond drawn 1e-4 from the lower end of its truncated-normal marginal): there the clamped vectors are no unit
+ * vectors, log|det J| is not 2 ln d + ln|sin a|, and the closed-form adjoint of the sweep below is off by O(1). */
+struct PlaceAdj { V3 g1, g2, g3; float gd, ga, gt; };
+
+__device__ __forceinline__ Dual<3> place_scalar_dual(DV3<3> p1, DV3<3> p2, DV3<3> p3, Dual<3> d, Dual<3> a, Dual<3> t, V3 g, float gl, float eps) {
+    typedef Dual<3> D;
+    typedef DV3<3> W;
+    const W v1 = dsub(p1, p2), v2 = dsub(p1, p3);
+    const W nv = dcross(v1, v2), nn = dcross(v1, nv);
+    const D nvn = dclamp_min(dnorm(nv), eps), nnn = dclamp_min(dnorm(nn), eps);
+    const W nh = ddivs(nv, nvn), nnh = ddivs(nn, nnn);
+    const D st = dsin(t), ct = dcos(t), sa = dsin(a), ca = dcos(a);
+    const W v3 = dadd(dscale(nh, -st), dscale(nnh, ct));
+    const D v3n = dclamp_min(dnorm(v3), eps);
+    const W v3h = ddivs(v3, v3n);
+    const D v1n = dclamp_min(dnorm(v1), eps);
+    const W v1h = ddivs(v1, v1n);
+    const W pos = dadd(p1, dsub(dscale(v3h, d * sa), dscale(v1h, d * ca)));
+    const W Jd = dsub(dscale(v3h, sa), dscale(v1h, ca));
+    const W Ja = dadd(dscale(v3h, d * ca), dscale(v1h, d * sa));
+    const W Jt3 = dadd(dscale(nh, -ct), dscale(nnh, -st));
+    const D h3 = ddot(v3h, Jt3);
+    const W Jt = dscale(dsub(Jt3, dscale(v3h, h3)), (d * sa) / v3n);
+    const W R0 = {Jd.x, Ja.x, Jt.x}, R1 = {Jd.y, Ja.y, Jt.y}, R2 = {Jd.z, Ja.z, Jt.z};
+    const D det = ddot(dcross(R0, R1), R2);
+    return pos.x * g.x + pos.y * g.y + pos.z * g.z + dlog(dabs(det)) * gl;
+}
+
+__device__ __forceinline__ PlaceAdj placement_vjp_dual(V3 p1, V3 p2, V3 p3, float dd, float a_rad, float t_rad, V3 g, float gl, float eps) {
+    typedef Dual<3> D;
+    PlaceAdj o;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {                       /* one instance of the dual evaluation in the code: the path is rare */
+        const int b = 3 * pass;
+        DV3<3> q1 = {dseed<3>(p1.x, 0 - b), dseed<3>(p1.y, 1 - b), dseed<3>(p1.z, 2 - b)};
+        DV3<3> q2 = {dseed<3>(p2.x, 3 - b), dseed<3>(p2.y, 4 - b), dseed<3>(p2.z, 5 - b)};
+        DV3<3> q3 = {dseed<3>(p3.x, 6 - b), dseed<3>(p3.y, 7 - b), dseed<3>(p3.z, 8 - b)};
+        const D s = place_scalar_dual(q1, q2, q3, dseed<3>(dd, 9 - b), dseed<3>(a_rad, 10 - b), dseed<3>(t_rad, 11 - b), g, gl, eps);
+        const V3 r = {s.d[0], s.d[1], s.d[2]};
+        if (pass == 0) o.g1 = r;
+        else if (pass == 1) o.g2 = r;
+        else if (pass == 2) o.g3 = r;
+        else { o.gd = r.x; o.ga = r.y; o.gt = r.z; }
+    }
+    return o;
+}
+
+/* adjoint of one placement: cotangents of the three reference atoms (g1 includes the pass-through of g), of the bond, the angle and
+ * the torsion (in the caller's units: normalised angles get their pi / 2 pi).  Angles go to the hardware sin / cos in revolutions
+ * (tools/ubench/hw_sincos.hip); reciprocals on the hardware form. */
+__device__ __forceinline__ PlaceAdj placement_adjoint(V3 p1, V3 p2, V3 p3, float dd, float an, float t, V3 g, float gl, int normalize,
+                                                      float eps, int enforce) {
+    PlaceAdj o;
+    const float an_rev = normalize ? 0.5f * an : an * (0.5f / PI_F);
+    const float t_rev = normalize ? t - 0.5f : t * (0.5f / PI_F);
+    V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
+    V3 nv = cross(v1, v2), nn = cross(v1, nv);
+    const float n2_nv = dot(nv, nv), n2_nn = dot(nn, nn), n2_v1 = dot(v1, v1), e2 = eps * eps;
+    if (enforce && (n2_nv < e2 || n2_nn < e2 || n2_v1 < e2)) {       /* rare: a norm of this placement was clamped by the forward */
+        const float a_rad = normalize ? an * PI_F : an, t_rad = normalize ? t * (2.0f * PI_F) - PI_F : t;
+        o = placement_vjp_dual(p1, p2, p3, dd, a_rad, t_rad, g, gl, eps);
+        if (normalize) { o.ga *= PI_F; o.gt *= 2.0f * PI_F; }
+        return o;
+    }
+    float inv_nv = inv_sqrt_refined(n2_nv), inv_nn = inv_sqrt_refined(n2_nn), inv_v1 = inv_sqrt_refined(n2_v1);
+    V3 nh = scale(nv, inv_nv), nnh = scale(nn, inv_nn), v1h = scale(v1, inv_v1);
+    const float tf = __builtin_amdgcn_fractf(t_rev), af = __builtin_amdgcn_fractf(an_rev);
+    float st = __builtin_amdgcn_sinf(tf), ct = __builtin_amdgcn_cosf(tf), sa = sin_rev_near_zero_exact(af), ca = __builtin_amdgcn_cosf(af);
+    V3 v3 = add(scale(nh, -st), scale(nnh, ct));
+    float inv_v3 = inv_sqrt_refined(dot(v3, v3));
+    V3 v3h = scale(v3, inv_v3);
+    float gd = dot(g, add(scale(v3h, sa), scale(v1h, -ca))) + gl * 2.0f * __builtin_amdgcn_rcpf(dd);
+    float ga = dot(g, add(scale(v3h, dd * ca), scale(v1h, dd * sa))) + gl * ca * __builtin_amdgcn_rcpf(sa);
+    V3 g_v3 = proj_out(scale(g, dd * sa), v3h, inv_v3);
+    float gt = dot(g_v3, add(scale(nh, -ct), scale(nnh, -st)));
+    V3 g_n = proj_out(scale(g_v3, -st), nh, inv_nv);
+    V3 g_nn = proj_out(scale(g_v3, ct), nnh, inv_nn);
+    V3 g_v1 = cross(nv, g_nn);
+    g_n = add(g_n, cross(g_nn, v1));
+    g_v1 = add(g_v1, cross(v2, g_n));
+    V3 g_v2 = cross(g_n, v1);
+    g_v1 = add(g_v1, proj_out(scale(g, -dd * ca), v1h, inv_v1));
+    o.g1 = {g.x + g_v1.x + g_v2.x, g.y + g_v1.y + g_v2.y, g.z + g_v1.z + g_v2.z};
+    o.g2 = {-g_v1.x, -g_v1.y, -g_v1.z};
+    o.g3 = {-g_v2.x, -g_v2.y, -g_v2.z};
+    if (normalize) { ga = ga * PI_F; gt = gt * (2.0f * PI_F); }
+    o.gd = gd; o.ga = ga; o.gt = gt;
+    return o;
 }
 
 __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a) {
@@ -560,36 +674,12 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
                           i3 = a.place[5 * i + 3], zr = a.place[5 * i + 4];
                 V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
                 float dd = s_b[tid * a.sic + zr], an = s_a[tid * a.sic + zr], t = s_t[tid * a.sic + zr];
-                /* angles in revolutions for the hardware sin / cos (|error| <= 1.3e-7, tools/ubench/hw_sincos.hip); reciprocal
-                 * square roots and reciprocals on the hardware forms: a third of the OCML / IEEE instruction count of this chain,
-                 * which runs latency-bound (one 64-lane wave per 54 KB of LDS rows) */
-                const float an_rev = a.normalize ? 0.5f * an : an * (0.5f / PI_F);
-                const float t_rev = a.normalize ? t - 0.5f : t * (0.5f / PI_F);
-                V3 g = ld3(gp + 3 * at);
-                V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
-                V3 nv = cross(v1, v2), nn = cross(v1, nv);
-                float inv_nv = __builtin_amdgcn_rsqf(dot(nv, nv)), inv_nn = __builtin_amdgcn_rsqf(dot(nn, nn)), inv_v1 = __builtin_amdgcn_rsqf(dot(v1, v1));
-                V3 nh = scale(nv, inv_nv), nnh = scale(nn, inv_nn), v1h = scale(v1, inv_v1);
-                const float tf = __builtin_amdgcn_fractf(t_rev), af = __builtin_amdgcn_fractf(an_rev);
-                float st = __builtin_amdgcn_sinf(tf), ct = __builtin_amdgcn_cosf(tf), sa = __builtin_amdgcn_sinf(af), ca = __builtin_amdgcn_cosf(af);
-                V3 v3 = add(scale(nh, -st), scale(nnh, ct));
-                float inv_v3 = __builtin_amdgcn_rsqf(dot(v3, v3));
-                V3 v3h = scale(v3, inv_v3);
-                float gd = dot(g, add(scale(v3h, sa), scale(v1h, -ca))) + gl * 2.0f * __builtin_amdgcn_rcpf(dd);
-                float ga = dot(g, add(scale(v3h, dd * ca), scale(v1h, dd * sa))) + gl * ca * __builtin_amdgcn_rcpf(sa);
-                V3 g_v3 = proj_out(scale(g, dd * sa), v3h, inv_v3);
-                float gt = dot(g_v3, add(scale(nh, -ct), scale(nnh, -st)));
-                V3 g_n = proj_out(scale(g_v3, -st), nh, inv_nv);
-                V3 g_nn = proj_out(scale(g_v3, ct), nnh, inv_nn);
-                V3 g_v1 = cross(nv, g_nn);
-                g_n = add(g_n, cross(g_nn, v1));
-                g_v1 = add(g_v1, cross(v2, g_n));
-                V3 g_v2 = cross(g_n, v1);
-                g_v1 = add(g_v1, proj_out(scale(g, -dd * ca), v1h, inv_v1));
-                gp[3 * i1] += g.x + g_v1.x + g_v2.x; gp[3 * i1 + 1] += g.y + g_v1.y + g_v2.y; gp[3 * i1 + 2] += g.z + g_v1.z + g_v2.z;
-                gp[3 * i2] -= g_v1.x; gp[3 * i2 + 1] -= g_v1.y; gp[3 * i2 + 2] -= g_v1.z;
-                gp[3 * i3] -= g_v2.x; gp[3 * i3 + 1] -= g_v2.y; gp[3 * i3 + 2] -= g_v2.z;
-                if (a.normalize) { ga = ga * PI_F; gt = gt * (2.0f * PI_F); }
+                const V3 g = ld3(gp + 3 * at);
+                const PlaceAdj q = placement_adjoint(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce);
+                gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
+                gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
+                gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
+                const float gd = q.gd, ga = q.ga, gt = q.gt;
                 s_b[tid * a.sic + zr] = gd; s_a[tid * a.sic + zr] = ga; s_t[tid * a.sic + zr] = gt;
             }
             if (a.T) {
@@ -657,34 +747,13 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_reg_kernel(IcBwdArg
                 const int at = place[5 * i], i1 = place[5 * i + 1], i2 = place[5 * i + 2], i3 = place[5 * i + 3], zr = place[5 * i + 4];
                 float dd = s_b[tid * sreg + zr], an = s_a[tid * sreg + zr], t = s_t[tid * sreg + zr];
                 if (!live) { s_b[tid * sreg + zr] = 0.0f; s_a[tid * sreg + zr] = 0.0f; s_t[tid * sreg + zr] = 0.0f; continue; }
-                const float an_rev = a.normalize ? 0.5f * an : an * (0.5f / PI_F);
-                const float t_rev = a.normalize ? t - 0.5f : t * (0.5f / PI_F);
                 const V3 p1 = {px[i1], py[i1], pz[i1]}, p2 = {px[i2], py[i2], pz[i2]}, p3 = {px[i3], py[i3], pz[i3]};
                 const V3 g = ld3(gp + 3 * at);
-                V3 v1 = sub(p1, p2), v2 = sub(p1, p3);
-                V3 nv = cross(v1, v2), nn = cross(v1, nv);
-                float inv_nv = __builtin_amdgcn_rsqf(dot(nv, nv)), inv_nn = __builtin_amdgcn_rsqf(dot(nn, nn)), inv_v1 = __builtin_amdgcn_rsqf(dot(v1, v1));
-                V3 nh = scale(nv, inv_nv), nnh = scale(nn, inv_nn), v1h = scale(v1, inv_v1);
-                const float tf = __builtin_amdgcn_fractf(t_rev), af = __builtin_amdgcn_fractf(an_rev);
-                float st = __builtin_amdgcn_sinf(tf), ct = __builtin_amdgcn_cosf(tf), sa = __builtin_amdgcn_sinf(af), ca = __builtin_amdgcn_cosf(af);
-                V3 v3 = add(scale(nh, -st), scale(nnh, ct));
-                float inv_v3 = __builtin_amdgcn_rsqf(dot(v3, v3));
-                V3 v3h = scale(v3, inv_v3);
-                float gd = dot(g, add(scale(v3h, sa), scale(v1h, -ca))) + gl * 2.0f * __builtin_amdgcn_rcpf(dd);
-                float ga = dot(g, add(scale(v3h, dd * ca), scale(v1h, dd * sa))) + gl * ca * __builtin_amdgcn_rcpf(sa);
-                V3 g_v3 = proj_out(scale(g, dd * sa), v3h, inv_v3);
-                float gt = dot(g_v3, add(scale(nh, -ct), scale(nnh, -st)));
-                V3 g_n = proj_out(scale(g_v3, -st), nh, inv_nv);
-                V3 g_nn = proj_out(scale(g_v3, ct), nnh, inv_nn);
-                V3 g_v1 = cross(nv, g_nn);
-                g_n = add(g_n, cross(g_nn, v1));
-                g_v1 = add(g_v1, cross(v2, g_n));
-                V3 g_v2 = cross(g_n, v1);
-                g_v1 = add(g_v1, proj_out(scale(g, -dd * ca), v1h, inv_v1));
-                gp[3 * i1] += g.x + g_v1.x + g_v2.x; gp[3 * i1 + 1] += g.y + g_v1.y + g_v2.y; gp[3 * i1 + 2] += g.z + g_v1.z + g_v2.z;
-                gp[3 * i2] -= g_v1.x; gp[3 * i2 + 1] -= g_v1.y; gp[3 * i2 + 2] -= g_v1.z;
-                gp[3 * i3] -= g_v2.x; gp[3 * i3 + 1] -= g_v2.y; gp[3 * i3 + 2] -= g_v2.z;
-                if (a.normalize) { ga = ga * PI_F; gt = gt * (2.0f * PI_F); }
+                const PlaceAdj q = placement_adjoint(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce);
+                gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
+                gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
+                gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
+                const float gd = q.gd, ga = q.ga, gt = q.gt;
                 s_b[tid * sreg + zr] = gd; s_a[tid * sreg + zr] = ga; s_t[tid * sreg + zr] = gt;
             }
             if (a.T) {
@@ -904,7 +973,8 @@ extern "C" int bgk_icdf_ic2xyz(const float* bonds, const float* angles, const fl
 extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float* torsions,
                                       int64_t ldic, const float* x, int64_t ldx, const int32_t* place,
                                       int32_t n, const int32_t* fixed, int32_t n_fixed,
-                                      int32_t normalize_angles, const float* Tblacken, int32_t keep,
+                                      int32_t normalize_angles, float eps, int32_t enforce_boundaries,
+                                      const float* Tblacken, int32_t keep,
                                       int64_t B, const float* g_x, int64_t ldgx, const float* g_dlogp,
                                       float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,
                                       float* g_xfix, int64_t ldgf, void* stream) {
@@ -920,6 +990,7 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
     a.n_atoms = n + n_fixed; a.keep = keep; a.normalize = normalize_angles; a.T = Tblacken; a.B = B;
     a.g_bonds = g_bonds; a.g_angles = g_angles; a.g_torsions = g_torsions; a.ldgic = ldgic; a.g_xfix = g_xfix; a.ldgf = ldgf;
     a.sx = (3 * a.n_atoms) | 1; a.sic = n | 1; a.sfx = keep | 1;
+    a.eps = eps; a.enforce = enforce_boundaries;
     if (a.n_atoms <= 32 && !getenv("BGK_IC_BWD_LDS")) {          /* positions in registers: 38 instead of 54 KB of LDS per wave */
         const int sreg = (a.sx > 3 * a.sic ? a.sx : 3 * a.sic) | 1;
         const size_t shm = sizeof(float) * 64 * (size_t)(2 * sreg + a.sfx);

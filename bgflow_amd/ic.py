@@ -406,7 +406,7 @@ class RelativeInternalCoordinateTransformation(Flow):
             st = _lib.lib().bgk_ic_ic2xyz_backward(
                 _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), ldic, _lib.ptr(x), x.shape[1],
                 _lib.ptr(self._tables.get("place", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
-                int(self._normalize_angles), _lib.ptr(T), keep, B, _lib.ptr(g_x2), ldgx, _lib.ptr(g_dl),
+                int(self._normalize_angles), float(self._eps), int(self._enforce_boundaries), _lib.ptr(T), keep, B, _lib.ptr(g_x2), ldgx, _lib.ptr(g_dl),
                 _lib.ptr(g_ic[0]), _lib.ptr(g_ic[1]), _lib.ptr(g_ic[2]), n, _lib.ptr(g_f), keep, _lib.stream_ptr(dev))
         _lib.check(st, "bgk_ic_ic2xyz_backward")
         return g_ic[0], g_ic[1], g_ic[2], g_f

@@ -226,10 +226,13 @@ int bgk_xyz2ic_cdf_uni(const float* x, const float* desc4, int32_t use_eps, floa
 /* Backward (VJP) of bgk_ic_ic2xyz for first-order losses (replaces torch autograd through
  * ic2xyz_deriv / det3x3, ic.py:435-513): x is the forward OUTPUT; g_x [B, 3*n_atoms], g_dlogp [B]
  * -> g_bonds / g_angles / g_torsions [B, n] (ldgic), g_xfix [B, keep] (ldgf).  The log-det term uses
- * log|det J| = 2 ln d + ln|sin a| (exact away from the eps clamps). */
+ * log|det J| = 2 ln d + ln|sin a|, exact away from the eps clamps; a placement whose norms the forward clamped (eps,
+ * enforce_boundaries: the forward's, ic_helper.py:372-452) is differentiated the way the reference's autograd does it -- the
+ * explicit Jacobian determinant with torch.clamp's derivative -- on forward-mode dual numbers. */
 int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float* torsions, int64_t ldic,
                            const float* x, int64_t ldx, const int32_t* place, int32_t n,
                            const int32_t* fixed, int32_t n_fixed, int32_t normalize_angles,
+                           float eps, int32_t enforce_boundaries,
                            const float* Tblacken, int32_t keep, int64_t B,
                            const float* g_x, int64_t ldgx, const float* g_dlogp,
                            float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,

@@ -162,8 +162,15 @@ def test_spline_backward_for_any_bin_count(hip_lib, dev, Kb, d, B, inverse):
         assert float(err.max()) <= 1e-3 * scale and float(err.quantile(0.99)) <= 1e-4 * scale, \
             f"K = {Kb}: {what} gradient, max error {float(err.max()):.2e} of {scale:.2e}"
     # the forward of the same bin count on the same inputs (bins of forward and backward come from one knot sequence)
+    # -- bit-identical to the C oracle's f32 element routine where that holds the knots (K <= 64); against f64 the bound is f32
+    # conditioning of the inverse's quadratic: K = 24, element (5, 1) is 5.3e-6 off in the oracle's operation order and 1.1e-6 in
+    # torch's f32 op chain
     z, dl = rqs_transform(t(y, dev), t(params, dev), slots, Kb, inverse, 0.0, 1.0, 0.0, 1.0, st)
-    assert float((z.cpu().double() - out.detach()).abs().max()) < 2e-6
+    assert float((z.cpu().double() - out.detach()).abs().max()) < 1e-5
+    if Kb <= 64:
+        from oracle import oracle as co
+        z_c, dl_c = co.rqs(y, params, is_circular=circ, inverse=inverse, n_bins=Kb, **{k: v for k, v in st.items() if k != "enable_identity_init"})
+        assert np.array_equal(z.cpu().numpy(), z_c) and np.array_equal(dl.cpu().numpy().reshape(-1), dl_c.reshape(-1))
 
 
 def test_hardware_sincos_of_the_generation_tail_on_a_long_chain(hip_lib, oracle, dev):
@@ -275,3 +282,55 @@ def test_kl_step_launches_few_aten_kernels(hip_lib, dev):
     short = Counter(n.split("<")[0].replace("void at::native::", "")[:40] + ("|" + n.split("Functor")[0].split("::")[-1] if "Functor" in n else "") for n in aten)
     print("device kernels of one KL step:", len(names), "of which torch's own:", len(aten), dict(short))
     assert len(aten) <= 16, f"{len(aten)} aten / copy / fill launches in one KL step: {dict(short)}"
+
+
+def test_ic_backward_where_the_forward_clamped_a_norm(hip_lib, dev):
+    """IC -> xyz backward on degenerate geometries.  A bond drawn ~1e-4 from the lower end of its marginal (cfg 3: a normal truncated one
+    sigma below its mean -- 0.1 % of uniform prior samples) puts two atoms 1e-4 nm apart; for the placements that refer to them
+    |v1 x (v1 x v2)| falls below eps = 1e-7, the reference clamps the norm (ic_helper.py:372-452), the clamped vector is no unit vector
+    any more and log|det J| is no longer 2 ln d + ln|sin a|: the reference's autograd differentiates the explicit determinant with
+    torch.clamp's derivative.  bgk_ic_ic2xyz_backward evaluates exactly that on dual numbers for such placements (round 5; before,
+    the closed-form adjoint was off by 40 - 60 % on these samples, which carry the largest gradients of a KL step: 2e-4 of the flat
+    gradient).  Also: angles within 1e-5 of 0 / pi, where gl cos a / sin a needs the sine to relative accuracy.  Against f64 autograd
+    of the reference's op chain (oracle/torch_flow.py::ic2xyz_torch)."""
+    from bgflow_amd import configs
+    from oracle import torch_flow as tfl
+    gen = configs.make_ala2_spline_generator(dev)
+    gen64 = configs.make_ala2_spline_generator().double()
+    blk, blk64 = list(gen.flow)[-1], list(gen64.flow)[-1]
+    B = 2048
+    g = torch.Generator().manual_seed(99)
+    bonds = 0.1 + 0.05 * torch.rand(B, 17, generator=g)
+    angles = 0.2 + 0.6 * torch.rand(B, 17, generator=g)
+    tors = torch.rand(B, 17, generator=g)
+    fixed = torch.randn(B, 9, generator=g)
+    tiny = torch.rand(B, 17, generator=g) < 0.02
+    tiny[B // 2:] = False                                              # second half of the batch: regular geometries
+    bonds = torch.where(tiny, 5e-5 + 3.5e-4 * torch.rand(B, 17, generator=g), bonds)
+    near = torch.rand(B, 17, generator=g) < 0.01
+    near[:B // 2] = False
+    angles = torch.where(near, torch.where(torch.rand(B, 17, generator=g) < 0.5, 3e-6 + 1e-5 * torch.rand(B, 17, generator=g),
+                                           1.0 - 3e-6 - 1e-5 * torch.rand(B, 17, generator=g)), angles)
+    w = torch.randn(B, 66, generator=g)
+    v = 0.5 + torch.rand(B, 1, generator=g)
+    ins64 = [t_.double().requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
+    (x64,), dl64 = tfl.run_block(blk64, ins64, False, grad=True)
+    ((x64 * w.double()).sum() - (dl64 * v.double()).sum()).backward()
+    ins = [t_.to(dev).requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
+    x, dl = blk(*ins)
+    ((x * w.to(dev)).sum() - (dl * v.to(dev)).sum()).backward()
+    names = ("bonds", "angles", "torsions", "fixed")
+    halves = {"clamped norms": slice(0, B // 2), "angles at 0 / pi": slice(B // 2, B)}
+    failures = []
+    for what, sl in halves.items():
+        for nm, a, b in zip(names, ins, ins64):
+            got, want = a.grad[sl].cpu().double(), b.grad[sl]
+            assert bool(torch.isfinite(got).all())
+            per = (got - want).norm(dim=1) / want.norm(dim=1).clamp_min(1e-30)
+            rel = float((got - want).norm() / want.norm())
+            worst = torch.argsort(per, descending=True)[:3].tolist()
+            print(f"IC backward, {what}: g_{nm} rel L2 {rel:.2e}, worst sample {float(per.max()):.2e}, median {float(per.median()):.2e}; worst samples "
+                  + "; ".join(f"#{i} ({per[i]:.1e}, |g| {float(want[i].norm()):.1e} of {float(want.norm()):.1e}, tiny bonds at {torch.nonzero(tiny[sl][i]).reshape(-1).tolist()})" for i in worst))
+            if not (rel <= 1e-2 and float(per.median()) <= 1e-4 and float(per.max()) <= 0.1):
+                failures.append(f"{what}: g_{nm} rel L2 {rel:.2e} (worst sample {float(per.max()):.2e}, median {float(per.median()):.2e})")
+    assert not failures, "; ".join(failures)
