@@ -15,7 +15,7 @@ struct Dual {
 };
 
 template <int N> __device__ __forceinline__ Dual<N> dconst(float c) { Dual<N> r; r.v = c; for (int i = 0; i < N; ++i) r.d[i] = 0.0f; return r; }
-template <int N> __device__ __forceinline__ Dual<N> dseed(float c, int k) { Dual<N> r = dconst<N>(c); if (k >= 0 && k < N) r.d[k] = 1.0f; return r; }
+template <int N> __device__ __forceinline__ Dual<N> dseed(float c, int k) { Dual<N> r; r.v = c; for (int i = 0; i < N; ++i) r.d[i] = (i == k) ? 1.0f : 0.0f; return r; }   /* (selects: k may be a run-time value) */
 
 template <int N> __device__ __forceinline__ Dual<N> operator+(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
 template <int N> __device__ __forceinline__ Dual<N> operator-(Dual<N> a, Dual<N> b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }

@@ -492,6 +492,7 @@ __global__ __launch_bounds__(IC2_THREADS) void icdf_ic2xyz_kernel(IcGenArgs g) {
  * Same math as oracle/bgo_impl.h::bgo_ic_ic2xyz_backward (hand-derived adjoint of ic2xyz_deriv,
  * log|det J| = 2 ln d + ln|sin a|).  Lane = sample; x (forward output) and the running position
  * adjoints live in per-lane LDS rows; IC tiles are overwritten in place by their gradients. */
+#include "bgk_dma.h"
 constexpr int ICB_THREADS = 64;
 
 struct IcBwdArgs {
@@ -554,9 +555,10 @@ __device__ __forceinline__ float sin_rev_near_zero_exact(float f) {
  * vectors, log|det J| is not 2 ln d + ln|sin a|, and the closed-form adjoint of the sweep below is off by O(1). */
 struct PlaceAdj { V3 g1, g2, g3; float gd, ga, gt; };
 
-__device__ __forceinline__ Dual<3> place_scalar_dual(DV3<3> p1, DV3<3> p2, DV3<3> p3, Dual<3> d, Dual<3> a, Dual<3> t, V3 g, float gl, float eps) {
-    typedef Dual<3> D;
-    typedef DV3<3> W;
+template <int N>
+__device__ __forceinline__ Dual<N> place_scalar_dual(DV3<N> p1, DV3<N> p2, DV3<N> p3, Dual<N> d, Dual<N> a, Dual<N> t, V3 g, float gl, float eps) {
+    typedef Dual<N> D;
+    typedef DV3<N> W;
     const W v1 = dsub(p1, p2), v2 = dsub(p1, p3);
     const W nv = dcross(v1, v2), nn = dcross(v1, nv);
     const D nvn = dclamp_min(dnorm(nv), eps), nnn = dclamp_min(dnorm(nn), eps);
@@ -578,23 +580,25 @@ __device__ __forceinline__ Dual<3> place_scalar_dual(DV3<3> p1, DV3<3> p2, DV3<3
     return pos.x * g.x + pos.y * g.y + pos.z * g.z + dlog(dabs(det)) * gl;
 }
 
+/* one directional derivative per pass (Dual<1>, 12 passes in a rolled loop): the path is rare, and wider duals would push the sweep's
+ * own registers (the positions of all atoms) out to scratch */
 __device__ __forceinline__ PlaceAdj placement_vjp_dual(V3 p1, V3 p2, V3 p3, float dd, float a_rad, float t_rad, V3 g, float gl, float eps) {
-    typedef Dual<3> D;
-    PlaceAdj o;
+    float o[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[k] = 0.0f;
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {                       /* one instance of the dual evaluation in the code: the path is rare */
-        const int b = 3 * pass;
-        DV3<3> q1 = {dseed<3>(p1.x, 0 - b), dseed<3>(p1.y, 1 - b), dseed<3>(p1.z, 2 - b)};
-        DV3<3> q2 = {dseed<3>(p2.x, 3 - b), dseed<3>(p2.y, 4 - b), dseed<3>(p2.z, 5 - b)};
-        DV3<3> q3 = {dseed<3>(p3.x, 6 - b), dseed<3>(p3.y, 7 - b), dseed<3>(p3.z, 8 - b)};
-        const D s = place_scalar_dual(q1, q2, q3, dseed<3>(dd, 9 - b), dseed<3>(a_rad, 10 - b), dseed<3>(t_rad, 11 - b), g, gl, eps);
-        const V3 r = {s.d[0], s.d[1], s.d[2]};
-        if (pass == 0) o.g1 = r;
-        else if (pass == 1) o.g2 = r;
-        else if (pass == 2) o.g3 = r;
-        else { o.gd = r.x; o.ga = r.y; o.gt = r.z; }
+    for (int pass = 0; pass < 12; ++pass) {
+        DV3<1> q1 = {dseed<1>(p1.x, 0 - pass), dseed<1>(p1.y, 1 - pass), dseed<1>(p1.z, 2 - pass)};
+        DV3<1> q2 = {dseed<1>(p2.x, 3 - pass), dseed<1>(p2.y, 4 - pass), dseed<1>(p2.z, 5 - pass)};
+        DV3<1> q3 = {dseed<1>(p3.x, 6 - pass), dseed<1>(p3.y, 7 - pass), dseed<1>(p3.z, 8 - pass)};
+        const Dual<1> s = place_scalar_dual<1>(q1, q2, q3, dseed<1>(dd, 9 - pass), dseed<1>(a_rad, 10 - pass), dseed<1>(t_rad, 11 - pass), g, gl, eps);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = (k == pass) ? s.d[0] : o[k];
     }
-    return o;
+    PlaceAdj r;
+    r.g1 = {o[0], o[1], o[2]}; r.g2 = {o[3], o[4], o[5]}; r.g3 = {o[6], o[7], o[8]};
+    r.gd = o[9]; r.ga = o[10]; r.gt = o[11];
+    return r;
 }
 
 /* adjoint of one placement: cotangents of the three reference atoms (g1 includes the pass-through of g), of the bond, the angle and
@@ -772,6 +776,98 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_reg_kernel(IcBwdArg
         tile_store64(a.g_torsions + b0 * a.ldgic, a.ldgic, s_t, sreg, rows, n);
         tile_store64(a.g_xfix + b0 * a.ldgf, a.ldgf, s_f, a.sfx, rows, a.keep);
         __syncthreads();
+    }
+}
+
+/* The sweep for CONTIGUOUS tensors (what the flow hands over: x / g_x [B, 3 n_atoms], the three IC fields [B, n] each, g_xfix
+ * [B, keep], all 16-byte aligned) -- round 5.  The two kernels above fetch their tiles with one dword per lane and loop iteration
+ * (an integer division and a dependent global load each: 183 serial round trips per tile at ala2 size, which is where their time
+ * went: 0.30 ms for 2^18 samples = 0.9 TB/s).  Here a wave owns 64 samples and
+ *   1. x and g_x arrive as linear DMA copies (bgk_dma.h: 18 requests per tile, all in flight at once); the lane lifts ITS x row
+ *      into registers (px / py / pz indexed by the wave-uniform atom ids), g_x stays in LDS as the running position adjoints;
+ *   2. the three IC tiles are copied by DMA into the x tile's place (memory image [64][n]: a lane's row has an odd stride);
+ *   3. the reverse sweep overwrites the IC values by their gradients in place, g_xfix goes behind them ([64][keep]);
+ *   4. the four results leave as 16-byte coalesced stores of the tile images.
+ * LDS: 2 x 64 x 3 n_atoms floats per wave (33 KB at ala2 size): four waves per CU. */
+template <int NA>
+__global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = a.n, nf3 = 3 * a.n_fixed, n_atoms = a.n_atoms, na3 = 3 * a.n_atoms, keep = a.keep;
+    const int lane = threadIdx.x;
+    const int region = a.sx;                   /* launcher: 64 * max(3 n_atoms, 3 n + keep), a multiple of 4 */
+    float* s_r = smem;                         /* x tile -> bonds | angles | torsions | g_xfix tiles */
+    float* s_g = smem + region;                /* g_x tile = position adjoints, row stride 3 n_atoms */
+    typedef const __attribute__((address_space(4))) int32_t* ci32_t;
+    const ci32_t place = (ci32_t)a.place, fixed = (ci32_t)a.fixed;
+    const int64_t n_tiles = (a.B + 63) / 64;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t b0 = tile * 64;
+        const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+        dma_tile(s_r, a.x + b0 * na3, na3, rows, lane);
+        dma_tile(s_g, a.g_x + b0 * na3, na3, rows, lane);
+        const float gl = lane < rows ? a.g_dlogp[b0 + lane] : 0.0f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float px[NA], py[NA], pz[NA];
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (k < n_atoms) { px[k] = s_r[lane * na3 + 3 * k]; py[k] = s_r[lane * na3 + 3 * k + 1]; pz[k] = s_r[lane * na3 + 3 * k + 2]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float* s_b = s_r;
+        float* s_a = s_r + 64 * n;
+        float* s_t = s_r + 128 * n;
+        float* s_f = s_r + 192 * n;            /* [64][keep] */
+        dma_tile(s_b, a.bonds + b0 * n, n, rows, lane);
+        dma_tile(s_a, a.angles + b0 * n, n, rows, lane);
+        dma_tile(s_t, a.torsions + b0 * n, n, rows, lane);
+        float* gp = s_g + lane * na3;
+        /* a sample whose upstream adjoints are all zero (e.g. masked out of the loss because its geometry is degenerate and its
+         * log-det is -inf) must get exactly zero gradients, not 0 * inf = NaN */
+        bool live = gl != 0.0f;
+        for (int c = 0; c < na3; ++c) live = live || (gp[c] != 0.0f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = n - 1; i >= 0; --i) {
+            const int at = place[5 * i], i1 = place[5 * i + 1], i2 = place[5 * i + 2], i3 = place[5 * i + 3], zr = place[5 * i + 4];
+            const float dd = s_b[lane * n + zr], an = s_a[lane * n + zr], t = s_t[lane * n + zr];
+            const V3 p1 = {px[i1], py[i1], pz[i1]}, p2 = {px[i2], py[i2], pz[i2]}, p3 = {px[i3], py[i3], pz[i3]};
+            const V3 g = ld3(gp + 3 * at);
+            PlaceAdj q = placement_adjoint(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce);
+            if (!live) { q.g1 = q.g2 = q.g3 = V3{0.0f, 0.0f, 0.0f}; q.gd = q.ga = q.gt = 0.0f; }
+            gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
+            gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
+            gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
+            s_b[lane * n + zr] = q.gd; s_a[lane * n + zr] = q.ga; s_t[lane * n + zr] = q.gt;
+        }
+        if (a.T) {
+            const float* __restrict__ T = a.T;
+            for (int k = 0; k < keep; ++k) {
+                float s = 0.0f;
+                for (int c = 0; c < nf3; ++c) s += gp[3 * fixed[c / 3] + c % 3] * T[k * nf3 + c];
+                s_f[lane * keep + k] = s;
+            }
+        } else {
+            for (int c = 0; c < nf3; ++c) s_f[lane * keep + c] = gp[3 * fixed[c / 3] + c % 3];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {   /* the tile images out: 16-byte pieces, then the 1..3 floats a partial tile may leave over */
+            float* const outs[4] = {a.g_bonds + b0 * n, a.g_angles + b0 * n, a.g_torsions + b0 * n, a.g_xfix + b0 * keep};
+            const float* const srcs[4] = {s_b, s_a, s_t, s_f};
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int total = rows * (f < 3 ? n : keep), total4 = total >> 2;
+                const float4* s4 = reinterpret_cast<const float4*>(srcs[f]);
+                float4* g4 = reinterpret_cast<float4*>(outs[f]);
+                for (int q = lane; q < total4; q += 64) g4[q] = s4[q];
+                for (int q = (total4 << 2) + lane; q < total; q += 64) outs[f][q] = srcs[f][q];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -991,6 +1087,21 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
     a.g_bonds = g_bonds; a.g_angles = g_angles; a.g_torsions = g_torsions; a.ldgic = ldgic; a.g_xfix = g_xfix; a.ldgf = ldgf;
     a.sx = (3 * a.n_atoms) | 1; a.sic = n | 1; a.sfx = keep | 1;
     a.eps = eps; a.enforce = enforce_boundaries;
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool contiguous = ldx == 3 * a.n_atoms && ldgx == 3 * a.n_atoms && ldic == n && ldgic == n && ldgf == keep &&
+                            al16(x) && al16(g_x) && al16(bonds) && al16(angles) && al16(torsions) &&
+                            al16(g_bonds) && al16(g_angles) && al16(g_torsions) && al16(g_xfix);
+    if (a.n_atoms <= 32 && contiguous && !getenv("BGK_IC_BWD_LDS") && !getenv("BGK_IC_BWD_NODMA")) {      /* tiles by DMA, positions in registers */
+        const int w = 3 * a.n_atoms > 3 * n + keep ? 3 * a.n_atoms : 3 * n + keep;
+        IcBwdArgs b = a;
+        b.sx = 64 * ((w + 3) & ~3);                                /* floats of the x / IC region; the g_x tile follows */
+        const size_t shm = sizeof(float) * ((size_t)b.sx + 64 * (size_t)(3 * a.n_atoms));
+        int64_t nt = (B + 63) / 64;
+        int grid = (int)(nt < 256 * 16 ? nt : 256 * 16);
+        if (a.n_atoms <= 24) hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<24>, dim3(grid), dim3(64), shm, (hipStream_t)stream, b);
+        else hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<32>, dim3(grid), dim3(64), shm, (hipStream_t)stream, b);
+        return bgk_launch_status("bgk_ic_ic2xyz_backward");
+    }
     if (a.n_atoms <= 32 && !getenv("BGK_IC_BWD_LDS")) {          /* positions in registers: 38 instead of 54 KB of LDS per wave */
         const int sreg = (a.sx > 3 * a.sic ? a.sx : 3 * a.sic) | 1;
         const size_t shm = sizeof(float) * 64 * (size_t)(2 * sreg + a.sfx);

@@ -291,13 +291,18 @@ def test_ic_backward_where_the_forward_clamped_a_norm(hip_lib, dev):
     any more and log|det J| is no longer 2 ln d + ln|sin a|: the reference's autograd differentiates the explicit determinant with
     torch.clamp's derivative.  bgk_ic_ic2xyz_backward evaluates exactly that on dual numbers for such placements (round 5; before,
     the closed-form adjoint was off by 40 - 60 % on these samples, which carry the largest gradients of a KL step: 2e-4 of the flat
-    gradient).  Also: angles within 1e-5 of 0 / pi, where gl cos a / sin a needs the sine to relative accuracy.  Against f64 autograd
-    of the reference's op chain (oracle/torch_flow.py::ic2xyz_torch)."""
+    gradient -- oracle/bgo_impl.h's closed-form sweep still is, in f64 too: rel L2 0.6 on the first half of this batch).  Second half:
+    angles within 1e-5 of 0 / pi (gl cos a / sin a needs the sine to relative accuracy; the atoms placed next see nearly collinear
+    reference atoms).  Yardstick: f64 autograd of the reference's op chain (oracle/torch_flow.py::ic2xyz_torch), and the SAME chain in
+    f32 on the host -- what the reference's own f32 autograd gives on these inputs: the kernel must not be further from f64 than
+    3 x that (+ 1e-3 of the gradient's norm).  g_fixed of the first half is measured per sample: a fixed atom's adjoint there is the
+    O(1) sum of +-1e5 terms (|g_bonds| of the same sample: 1e5), a handful of samples lose it to f32 cancellation in either code."""
     from bgflow_amd import configs
     from oracle import torch_flow as tfl
     gen = configs.make_ala2_spline_generator(dev)
     gen64 = configs.make_ala2_spline_generator().double()
-    blk, blk64 = list(gen.flow)[-1], list(gen64.flow)[-1]
+    gen32 = configs.make_ala2_spline_generator()
+    blk, blk64, blk32 = list(gen.flow)[-1], list(gen64.flow)[-1], list(gen32.flow)[-1]
     B = 2048
     g = torch.Generator().manual_seed(99)
     bonds = 0.1 + 0.05 * torch.rand(B, 17, generator=g)
@@ -305,7 +310,7 @@ def test_ic_backward_where_the_forward_clamped_a_norm(hip_lib, dev):
     tors = torch.rand(B, 17, generator=g)
     fixed = torch.randn(B, 9, generator=g)
     tiny = torch.rand(B, 17, generator=g) < 0.02
-    tiny[B // 2:] = False                                              # second half of the batch: regular geometries
+    tiny[B // 2:] = False                                              # second half of the batch: regular bonds
     bonds = torch.where(tiny, 5e-5 + 3.5e-4 * torch.rand(B, 17, generator=g), bonds)
     near = torch.rand(B, 17, generator=g) < 0.01
     near[:B // 2] = False
@@ -313,9 +318,12 @@ def test_ic_backward_where_the_forward_clamped_a_norm(hip_lib, dev):
                                            1.0 - 3e-6 - 1e-5 * torch.rand(B, 17, generator=g)), angles)
     w = torch.randn(B, 66, generator=g)
     v = 0.5 + torch.rand(B, 1, generator=g)
-    ins64 = [t_.double().requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
-    (x64,), dl64 = tfl.run_block(blk64, ins64, False, grad=True)
-    ((x64 * w.double()).sum() - (dl64 * v.double()).sum()).backward()
+    ref = {}
+    for key, b_, dt in (("f64", blk64, torch.float64), ("f32", blk32, torch.float32)):
+        ins_ = [t_.to(dt).requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
+        (x_,), dl_ = tfl.run_block(b_, ins_, False, grad=True)
+        ((x_ * w.to(dt)).sum() - (dl_ * v.to(dt)).sum()).backward()
+        ref[key] = [t_.grad.double() for t_ in ins_]
     ins = [t_.to(dev).requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
     x, dl = blk(*ins)
     ((x * w.to(dev)).sum() - (dl * v.to(dev)).sum()).backward()
@@ -323,14 +331,54 @@ def test_ic_backward_where_the_forward_clamped_a_norm(hip_lib, dev):
     halves = {"clamped norms": slice(0, B // 2), "angles at 0 / pi": slice(B // 2, B)}
     failures = []
     for what, sl in halves.items():
-        for nm, a, b in zip(names, ins, ins64):
-            got, want = a.grad[sl].cpu().double(), b.grad[sl]
+        for k, nm in enumerate(names):
+            got, want, host = ins[k].grad[sl].cpu().double(), ref["f64"][k][sl], ref["f32"][k][sl]
             assert bool(torch.isfinite(got).all())
             per = (got - want).norm(dim=1) / want.norm(dim=1).clamp_min(1e-30)
-            rel = float((got - want).norm() / want.norm())
+            rel, rel_host = float((got - want).norm() / want.norm()), float((host - want).norm() / want.norm())
             worst = torch.argsort(per, descending=True)[:3].tolist()
-            print(f"IC backward, {what}: g_{nm} rel L2 {rel:.2e}, worst sample {float(per.max()):.2e}, median {float(per.median()):.2e}; worst samples "
+            print(f"IC backward, {what}: g_{nm} rel L2 {rel:.2e} (reference chain in f32: {rel_host:.2e}), median {float(per.median()):.2e}, 99th percentile "
+                  f"{float(per.quantile(0.99)):.2e}; worst samples "
                   + "; ".join(f"#{i} ({per[i]:.1e}, |g| {float(want[i].norm()):.1e} of {float(want.norm()):.1e}, tiny bonds at {torch.nonzero(tiny[sl][i]).reshape(-1).tolist()})" for i in worst))
-            if not (rel <= 1e-2 and float(per.median()) <= 1e-4 and float(per.max()) <= 0.1):
-                failures.append(f"{what}: g_{nm} rel L2 {rel:.2e} (worst sample {float(per.max()):.2e}, median {float(per.median()):.2e})")
+            ok = float(per.median()) <= 1e-5
+            if what == "clamped norms" and nm == "fixed":
+                ok = ok and float(per.quantile(0.99)) <= 2e-2
+            else:
+                ok = ok and rel <= 3.0 * rel_host + 1e-3
+            if not ok:
+                failures.append(f"{what}: g_{nm} rel L2 {rel:.2e} vs {rel_host:.2e} for the f32 chain (median {float(per.median()):.2e})")
     assert not failures, "; ".join(failures)
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 2085])
+def test_ic_backward_dma_staging_equals_the_row_loop_kernels(hip_lib, dev, B):
+    """bgk_ic_ic2xyz_backward on contiguous tensors stages its tiles by DMA and stores the tile images as 16-byte pieces (round 5);
+    BGK_IC_BWD_NODMA=1 / BGK_IC_BWD_LDS=1 select the earlier kernels (per-lane row loops; positions in registers / in LDS).  Same
+    arithmetic per placement: bit-identical gradients, for whole and partial tiles (row counts that leave 1..3 floats over)."""
+    import os
+    from bgflow_amd import configs
+    gen = configs.make_ala2_spline_generator(dev)
+    blk = list(gen.flow)[-1]
+    g = torch.Generator().manual_seed(B)
+    base = [0.1 + 0.05 * torch.rand(B, 17, generator=g), 0.2 + 0.6 * torch.rand(B, 17, generator=g), torch.rand(B, 17, generator=g),
+            torch.randn(B, 9, generator=g)]
+    if B > 3:
+        base[0][3, 5] = 2e-4                    # one clamped placement: the dual-number path is part of the comparison
+    w = torch.randn(B, 66, generator=g).to(dev)
+    res = {}
+    try:
+        for mode in ("dma", "BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS"):
+            if mode != "dma":
+                os.environ[mode] = "1"
+            ins = [t_.to(dev).requires_grad_(True) for t_ in base]
+            x, dl = blk(*ins)
+            ((x * w).sum() - 0.7 * dl.sum()).backward()
+            res[mode] = [t_.grad.clone() for t_ in ins]
+            os.environ.pop(mode, None)
+    finally:
+        os.environ.pop("BGK_IC_BWD_NODMA", None)
+        os.environ.pop("BGK_IC_BWD_LDS", None)
+    for mode in ("BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS"):
+        for a, b in zip(res["dma"], res[mode]):
+            assert bool(torch.isfinite(a).all())
+            assert torch.equal(a, b), f"B = {B}: DMA-staged sweep vs {mode}: max difference {float((a - b).abs().max()):.2e}"
