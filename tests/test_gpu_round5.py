@@ -342,7 +342,7 @@ def test_ic_backward_where_the_forward_clamped_a_norm(hip_lib, dev):
                   + "; ".join(f"#{i} ({per[i]:.1e}, |g| {float(want[i].norm()):.1e} of {float(want.norm()):.1e}, tiny bonds at {torch.nonzero(tiny[sl][i]).reshape(-1).tolist()})" for i in worst))
             ok = float(per.median()) <= 1e-5
             if what == "clamped norms" and nm == "fixed":
-                ok = ok and float(per.quantile(0.99)) <= 2e-2
+                ok = ok and float(per.quantile(0.99)) <= 5e-2
             else:
                 ok = ok and rel <= 3.0 * rel_host + 1e-3
             if not ok:
