@@ -45,7 +45,7 @@ _SIGNATURES = {
     "bgk_xyz2ic_cdf_uni": (ctypes.c_int, [vp, vp, i32, f32, vp, i32, vp, i32, f32, i32, vp, vp, i32, f64, i64,
                                           vp, vp, vp, vp, vp, i32, vp, vp]),
     "bgk_ic_ic2xyz_backward": (ctypes.c_int, [vp, vp, vp, i64, vp, i64, vp, i32, vp, i32, i32, f32, i32, vp, i32, i64,
-                                              vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]),
+                                              vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp]),
     "bgk_cdf_transform": (ctypes.c_int, [vp, i64, vp, i64, i32, i32, i32, f32, vp, i64, vp, i32, vp]),
     "bgk_cdf_backward": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i32, i32, i32, f32, vp, i64, vp, vp, i64, vp]),
     "bgk_ic_xyz2ic_backward": (ctypes.c_int, [vp, i64, vp, i32, vp, i32, i32, f32, i32, vp, i32, i64,

@@ -508,6 +508,7 @@ struct IcBwdArgs {
     float* g_xfix; int64_t ldgf;
     int sx, sic, sfx;
     float eps; int enforce;             /* the forward's norm clamps (ic_helper.py:372-452): where one fired the adjoint is evaluated on dual numbers */
+    int32_t* fix;                       /* [1 + B]: count and indices of the samples a sweep kernel hands to ic_ic2xyz_bwd_fix_kernel */
 };
 
 __device__ __forceinline__ void tile_load64(float* dst, int s, const float* src, int64_t ld, int rows, int cols) {
@@ -604,8 +605,13 @@ __device__ __forceinline__ PlaceAdj placement_vjp_dual(V3 p1, V3 p2, V3 p3, floa
 /* adjoint of one placement: cotangents of the three reference atoms (g1 includes the pass-through of g), of the bond, the angle and
  * the torsion (in the caller's units: normalised angles get their pi / 2 pi).  Angles go to the hardware sin / cos in revolutions
  * (tools/ubench/hw_sincos.hip); reciprocals on the hardware form. */
+/* DUAL: a placement whose norms the forward clamped is differentiated on dual numbers right here (placement_vjp_dual); !DUAL: the
+ * closed form is evaluated regardless and `bad` is raised -- the sweep kernels hand such samples to ic_ic2xyz_bwd_fix_kernel, so that
+ * the rare path's registers and code stay out of their loops (inlined there it doubled the loop: the position arrays went to AGPRs
+ * and their wave-uniform indexing from v_movrel to select chains). */
+template <bool DUAL>
 __device__ __forceinline__ PlaceAdj placement_adjoint(V3 p1, V3 p2, V3 p3, float dd, float an, float t, V3 g, float gl, int normalize,
-                                                      float eps, int enforce) {
+                                                      float eps, int enforce, bool& bad) {
     PlaceAdj o;
     const float an_rev = normalize ? 0.5f * an : an * (0.5f / PI_F);
     const float t_rev = normalize ? t - 0.5f : t * (0.5f / PI_F);
@@ -613,10 +619,14 @@ __device__ __forceinline__ PlaceAdj placement_adjoint(V3 p1, V3 p2, V3 p3, float
     V3 nv = cross(v1, v2), nn = cross(v1, nv);
     const float n2_nv = dot(nv, nv), n2_nn = dot(nn, nn), n2_v1 = dot(v1, v1), e2 = eps * eps;
     if (enforce && (n2_nv < e2 || n2_nn < e2 || n2_v1 < e2)) {       /* rare: a norm of this placement was clamped by the forward */
-        const float a_rad = normalize ? an * PI_F : an, t_rad = normalize ? t * (2.0f * PI_F) - PI_F : t;
-        o = placement_vjp_dual(p1, p2, p3, dd, a_rad, t_rad, g, gl, eps);
-        if (normalize) { o.ga *= PI_F; o.gt *= 2.0f * PI_F; }
-        return o;
+        if constexpr (DUAL) {
+            const float a_rad = normalize ? an * PI_F : an, t_rad = normalize ? t * (2.0f * PI_F) - PI_F : t;
+            o = placement_vjp_dual(p1, p2, p3, dd, a_rad, t_rad, g, gl, eps);
+            if (normalize) { o.ga *= PI_F; o.gt *= 2.0f * PI_F; }
+            return o;
+        } else {
+            bad = true;
+        }
     }
     float inv_nv = inv_sqrt_refined(n2_nv), inv_nn = inv_sqrt_refined(n2_nn), inv_v1 = inv_sqrt_refined(n2_v1);
     V3 nh = scale(nv, inv_nv), nnh = scale(nn, inv_nn), v1h = scale(v1, inv_v1);
@@ -644,6 +654,14 @@ __device__ __forceinline__ PlaceAdj placement_adjoint(V3 p1, V3 p2, V3 p3, float
     return o;
 }
 
+/* a sample one of whose placements had a clamped norm: the sweep kernels (closed-form adjoint) append it to the list the fix-up
+ * kernel works through */
+__device__ __forceinline__ void flag_for_fixup(int32_t* fix, int64_t b) {
+    const int k = atomicAdd(fix, 1);
+    fix[1 + k] = (int32_t)b;
+}
+
+template <bool DUAL>
 __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TS = (int)blockDim.x, n = a.n, nf3 = 3 * a.n_fixed;
@@ -671,6 +689,7 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
             /* a sample whose upstream adjoints are all zero (e.g. masked out of the loss because its geometry
              * is degenerate and its log-det is -inf) must get exactly zero gradients, not 0 * inf = NaN */
             bool live = gl != 0.0f;
+            bool bad = false;
             for (int c = 0; c < 3 * a.n_atoms; ++c) live = live || (gp[c] != 0.0f);
             for (int i = n - 1; i >= 0; --i) {
                 if (!live) { s_b[tid * a.sic + i] = 0.0f; s_a[tid * a.sic + i] = 0.0f; s_t[tid * a.sic + i] = 0.0f; continue; }
@@ -679,7 +698,7 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
                 V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
                 float dd = s_b[tid * a.sic + zr], an = s_a[tid * a.sic + zr], t = s_t[tid * a.sic + zr];
                 const V3 g = ld3(gp + 3 * at);
-                const PlaceAdj q = placement_adjoint(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce);
+                const PlaceAdj q = placement_adjoint<DUAL>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
                 gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
                 gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
                 gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
@@ -695,6 +714,7 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
             } else {
                 for (int c = 0; c < nf3; ++c) s_f[tid * a.sfx + c] = gp[3 * a.fixed[c / 3] + c % 3];
             }
+            if (!DUAL && bad) flag_for_fixup(a.fix, b0 + tid);
         }
         __syncthreads();
         tile_store64(a.g_bonds + b0 * a.ldgic, a.ldgic, s_b, a.sic, rows, n);
@@ -712,6 +732,7 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_kernel(IcBwdArgs a)
  * 38 KB per wave: four waves per CU. */
 template <int NA>
 __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_reg_kernel(IcBwdArgs a) {
+    constexpr bool DUAL = false;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = a.n, nf3 = 3 * a.n_fixed, n_atoms = a.n_atoms, na3 = 3 * a.n_atoms;
     const int sreg = a.sx;                    /* launcher: max(3 n_atoms, 3 sic) | 1 */
@@ -746,6 +767,7 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_reg_kernel(IcBwdArg
             /* a sample whose upstream adjoints are all zero (e.g. masked out of the loss because its geometry is degenerate and its
              * log-det is -inf) must get exactly zero gradients, not 0 * inf = NaN */
             bool live = gl != 0.0f;
+            bool bad = false;
             for (int c = 0; c < na3; ++c) live = live || (gp[c] != 0.0f);
             for (int i = n - 1; i >= 0; --i) {
                 const int at = place[5 * i], i1 = place[5 * i + 1], i2 = place[5 * i + 2], i3 = place[5 * i + 3], zr = place[5 * i + 4];
@@ -753,7 +775,7 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_reg_kernel(IcBwdArg
                 if (!live) { s_b[tid * sreg + zr] = 0.0f; s_a[tid * sreg + zr] = 0.0f; s_t[tid * sreg + zr] = 0.0f; continue; }
                 const V3 p1 = {px[i1], py[i1], pz[i1]}, p2 = {px[i2], py[i2], pz[i2]}, p3 = {px[i3], py[i3], pz[i3]};
                 const V3 g = ld3(gp + 3 * at);
-                const PlaceAdj q = placement_adjoint(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce);
+                const PlaceAdj q = placement_adjoint<DUAL>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
                 gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
                 gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
                 gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
@@ -769,6 +791,7 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_reg_kernel(IcBwdArg
             } else {
                 for (int c = 0; c < nf3; ++c) s_f[tid * a.sfx + c] = gp[3 * fixed[c / 3] + c % 3];
             }
+            if (bad) flag_for_fixup(a.fix, b0 + tid);
         }
         __syncthreads();
         tile_store64(a.g_bonds + b0 * a.ldgic, a.ldgic, s_b, sreg, rows, n);
@@ -797,8 +820,14 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
     const int region = a.sx;                   /* launcher: 64 * max(3 n_atoms, 3 n + keep), a multiple of 4 */
     float* s_r = smem;                         /* x tile -> bonds | angles | torsions | g_xfix tiles */
     float* s_g = smem + region;                /* g_x tile = position adjoints, row stride 3 n_atoms */
+    float* s_T = s_g + 64 * na3;               /* Tblacken [keep][3 n_fixed] (whitened fixed block) */
+    int* s_fo = reinterpret_cast<int*>(s_T + (a.T ? keep * nf3 : 0));      /* offset of fixed coordinate c in a position row */
     typedef const __attribute__((address_space(4))) int32_t* ci32_t;
-    const ci32_t place = (ci32_t)a.place, fixed = (ci32_t)a.fixed;
+    const ci32_t place = (ci32_t)a.place;
+    /* the wave-uniform tables of the fixed block once per wave: read per sample and coordinate from global memory they were 135
+     * dependent scalar round trips per tile */
+    for (int c = lane; c < nf3; c += 64) s_fo[c] = 3 * a.fixed[c / 3] + c % 3;
+    if (a.T) for (int c = lane; c < keep * nf3; c += 64) s_T[c] = a.T[c];
     const int64_t n_tiles = (a.B + 63) / 64;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t b0 = tile * 64;
@@ -824,34 +853,46 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
         dma_tile(s_t, a.torsions + b0 * n, n, rows, lane);
         float* gp = s_g + lane * na3;
         /* a sample whose upstream adjoints are all zero (e.g. masked out of the loss because its geometry is degenerate and its
-         * log-det is -inf) must get exactly zero gradients, not 0 * inf = NaN */
-        bool live = gl != 0.0f;
-        for (int c = 0; c < na3; ++c) live = live || (gp[c] != 0.0f);
+         * log-det is -inf) must get exactly zero gradients, not 0 * inf = NaN.  (g != 0 on the raw bits, sign dropped: a NaN counts.) */
+        unsigned any = 0u;
+        if ((na3 & 1) == 0) {
+            const uint2* r2 = reinterpret_cast<const uint2*>(gp);
+            for (int c = 0; c < (na3 >> 1); ++c) { const uint2 u = r2[c]; any |= (u.x | u.y); }
+        } else {
+            for (int c = 0; c < na3; ++c) any |= __builtin_bit_cast(unsigned, gp[c]);
+        }
+        const bool live = (gl != 0.0f) || ((any & 0x7fffffffu) != 0u);
+        bool bad = false;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        /* reverse sweep; the record and the three IC values of placement i - 1 are requested while placement i is evaluated */
+        int at = place[5 * (n - 1)], i1 = place[5 * (n - 1) + 1], i2 = place[5 * (n - 1) + 2], i3 = place[5 * (n - 1) + 3], zr = place[5 * (n - 1) + 4];
+        float dd = s_b[lane * n + zr], an = s_a[lane * n + zr], t = s_t[lane * n + zr];
         for (int i = n - 1; i >= 0; --i) {
-            const int at = place[5 * i], i1 = place[5 * i + 1], i2 = place[5 * i + 2], i3 = place[5 * i + 3], zr = place[5 * i + 4];
-            const float dd = s_b[lane * n + zr], an = s_a[lane * n + zr], t = s_t[lane * n + zr];
+            const int in = i > 0 ? i - 1 : 0;
+            const int at_n = place[5 * in], i1_n = place[5 * in + 1], i2_n = place[5 * in + 2], i3_n = place[5 * in + 3], zr_n = place[5 * in + 4];
+            const float dd_n = s_b[lane * n + zr_n], an_n = s_a[lane * n + zr_n], t_n = s_t[lane * n + zr_n];   /* (a different row than zr unless i == 0) */
             const V3 p1 = {px[i1], py[i1], pz[i1]}, p2 = {px[i2], py[i2], pz[i2]}, p3 = {px[i3], py[i3], pz[i3]};
             const V3 g = ld3(gp + 3 * at);
-            PlaceAdj q = placement_adjoint(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce);
+            PlaceAdj q = placement_adjoint<false>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
             if (!live) { q.g1 = q.g2 = q.g3 = V3{0.0f, 0.0f, 0.0f}; q.gd = q.ga = q.gt = 0.0f; }
             gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
             gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
             gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
             s_b[lane * n + zr] = q.gd; s_a[lane * n + zr] = q.ga; s_t[lane * n + zr] = q.gt;
+            at = at_n; i1 = i1_n; i2 = i2_n; i3 = i3_n; zr = zr_n; dd = dd_n; an = an_n; t = t_n;
         }
         if (a.T) {
-            const float* __restrict__ T = a.T;
             for (int k = 0; k < keep; ++k) {
                 float s = 0.0f;
-                for (int c = 0; c < nf3; ++c) s += gp[3 * fixed[c / 3] + c % 3] * T[k * nf3 + c];
+                for (int c = 0; c < nf3; ++c) s += gp[s_fo[c]] * s_T[k * nf3 + c];
                 s_f[lane * keep + k] = s;
             }
         } else {
-            for (int c = 0; c < nf3; ++c) s_f[lane * keep + c] = gp[3 * fixed[c / 3] + c % 3];
+            for (int c = 0; c < nf3; ++c) s_f[lane * keep + c] = gp[s_fo[c]];
         }
+        if (bad && live && lane < rows) flag_for_fixup(a.fix, b0 + lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         {   /* the tile images out: 16-byte pieces, then the 1..3 floats a partial tile may leave over */
@@ -868,6 +909,43 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* The samples the sweep kernels flagged (fix[0] of them, indices behind it), one lane each, everything from global memory except the
+ * running position adjoints (a private LDS row): the same sweep with the dual-number adjoint where a norm was clamped.  A few hundred
+ * samples of 2^18 at cfg 3's uniform prior: the launch costs its latency. */
+__global__ __launch_bounds__(64) void ic_ic2xyz_bwd_fix_kernel(IcBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = a.n, nf3 = 3 * a.n_fixed, na3 = 3 * a.n_atoms;
+    const int count = a.fix[0];
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
+        const int64_t b = a.fix[1 + k];
+        float* gp = smem + threadIdx.x * a.sx;
+        const float* xr = a.x + b * a.ldx;
+        const float gl = a.g_dlogp[b];
+        for (int c = 0; c < na3; ++c) gp[c] = a.g_x[b * a.ldgx + c];
+        bool bad = false;
+        for (int i = n - 1; i >= 0; --i) {
+            const int at = a.place[5 * i], i1 = a.place[5 * i + 1], i2 = a.place[5 * i + 2], i3 = a.place[5 * i + 3], zr = a.place[5 * i + 4];
+            const V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
+            const float dd = a.bonds[b * a.ldic + zr], an = a.angles[b * a.ldic + zr], t = a.torsions[b * a.ldic + zr];
+            const V3 g = ld3(gp + 3 * at);
+            const PlaceAdj q = placement_adjoint<true>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
+            gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
+            gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
+            gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
+            a.g_bonds[b * a.ldgic + zr] = q.gd; a.g_angles[b * a.ldgic + zr] = q.ga; a.g_torsions[b * a.ldgic + zr] = q.gt;
+        }
+        if (a.T) {
+            for (int kk = 0; kk < a.keep; ++kk) {
+                float s = 0.0f;
+                for (int c = 0; c < nf3; ++c) s += gp[3 * a.fixed[c / 3] + c % 3] * a.T[kk * nf3 + c];
+                a.g_xfix[b * a.ldgf + kk] = s;
+            }
+        } else {
+            for (int c = 0; c < nf3; ++c) a.g_xfix[b * a.ldgf + c] = gp[3 * a.fixed[c / 3] + c % 3];
+        }
     }
 }
 
@@ -1073,55 +1151,78 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
                                       const float* Tblacken, int32_t keep,
                                       int64_t B, const float* g_x, int64_t ldgx, const float* g_dlogp,
                                       float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,
-                                      float* g_xfix, int64_t ldgf, void* stream) {
+                                      float* g_xfix, int64_t ldgf, int32_t* fix_ws, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_ic_ic2xyz_backward: bad sizes");
     BGK_CHECK_ARG(bonds && angles && torsions && x && place && fixed && g_x && g_dlogp && g_bonds && g_angles &&
                   g_torsions && g_xfix, "bgk_ic_ic2xyz_backward: null pointer");
     BGK_CHECK_ARG(Tblacken ? keep > 0 : keep == 3 * n_fixed, "bgk_ic_ic2xyz_backward: bad whitening arguments");
-    if (B == 0) return 0;
+    BGK_CHECK_ARG(B < (int64_t)0x7fffffff, "bgk_ic_ic2xyz_backward: batch too large for the fix-up list");
     IcBwdArgs a{};
     a.bonds = bonds; a.angles = angles; a.torsions = torsions; a.ldic = ldic; a.x = x; a.ldx = ldx;
     a.g_x = g_x; a.ldgx = ldgx; a.g_dlogp = g_dlogp; a.place = place; a.fixed = fixed; a.n = n; a.n_fixed = n_fixed;
     a.n_atoms = n + n_fixed; a.keep = keep; a.normalize = normalize_angles; a.T = Tblacken; a.B = B;
     a.g_bonds = g_bonds; a.g_angles = g_angles; a.g_torsions = g_torsions; a.ldgic = ldgic; a.g_xfix = g_xfix; a.ldgf = ldgf;
     a.sx = (3 * a.n_atoms) | 1; a.sic = n | 1; a.sfx = keep | 1;
-    a.eps = eps; a.enforce = enforce_boundaries;
+    a.eps = eps; a.enforce = enforce_boundaries; a.fix = fix_ws;
+    hipStream_t st = (hipStream_t)stream;
+    const char* what = "bgk_ic_ic2xyz_backward";
+    /* the sweep over all samples (closed-form adjoint; samples with a clamped norm are listed in fix_ws), then the listed samples again
+     * with the dual-number adjoint.  Without a list (fix_ws == NULL) the generic kernel evaluates the dual numbers in line. */
+    auto fixup = [&]() -> int {
+        if (!enforce_boundaries) return bgk_launch_status(what);           /* nothing is ever clamped */
+        IcBwdArgs f = a;
+        f.sx = (3 * a.n_atoms) | 1;
+        const size_t shm = sizeof(float) * 64 * (size_t)f.sx;
+        if (shm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_fix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(ic_ic2xyz_bwd_fix_kernel, dim3(64), dim3(64), shm, st, f);
+        return bgk_launch_status(what);
+    };
+    if (fix_ws && enforce_boundaries) {
+        const hipError_t e = hipMemsetAsync(fix_ws, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) { bgk_set_error("%s: %s", what, hipGetErrorString(e)); return (int)e; }
+    }
     const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool contiguous = ldx == 3 * a.n_atoms && ldgx == 3 * a.n_atoms && ldic == n && ldgic == n && ldgf == keep &&
                             al16(x) && al16(g_x) && al16(bonds) && al16(angles) && al16(torsions) &&
                             al16(g_bonds) && al16(g_angles) && al16(g_torsions) && al16(g_xfix);
-    if (a.n_atoms <= 32 && contiguous && !getenv("BGK_IC_BWD_LDS") && !getenv("BGK_IC_BWD_NODMA")) {      /* tiles by DMA, positions in registers */
+    const bool listed = fix_ws != nullptr || !enforce_boundaries;
+    if (listed && a.n_atoms <= 32 && contiguous && !getenv("BGK_IC_BWD_LDS") && !getenv("BGK_IC_BWD_NODMA")) {      /* tiles by DMA, positions in registers */
         const int w = 3 * a.n_atoms > 3 * n + keep ? 3 * a.n_atoms : 3 * n + keep;
         IcBwdArgs b = a;
         b.sx = 64 * ((w + 3) & ~3);                                /* floats of the x / IC region; the g_x tile follows */
-        const size_t shm = sizeof(float) * ((size_t)b.sx + 64 * (size_t)(3 * a.n_atoms));
+        const size_t shm = sizeof(float) * ((size_t)b.sx + 64 * (size_t)(3 * a.n_atoms) + (size_t)(Tblacken ? keep * 3 * n_fixed : 0) + 3 * (size_t)n_fixed);
         int64_t nt = (B + 63) / 64;
         int grid = (int)(nt < 256 * 16 ? nt : 256 * 16);
-        if (a.n_atoms <= 24) hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<24>, dim3(grid), dim3(64), shm, (hipStream_t)stream, b);
-        else hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<32>, dim3(grid), dim3(64), shm, (hipStream_t)stream, b);
-        return bgk_launch_status("bgk_ic_ic2xyz_backward");
+        if (a.n_atoms <= 24) hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<24>, dim3(grid), dim3(64), shm, st, b);
+        else hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<32>, dim3(grid), dim3(64), shm, st, b);
+        return fixup();
     }
-    if (a.n_atoms <= 32 && !getenv("BGK_IC_BWD_LDS")) {          /* positions in registers: 38 instead of 54 KB of LDS per wave */
+    if (listed && a.n_atoms <= 32 && !getenv("BGK_IC_BWD_LDS")) {          /* positions in registers: 38 instead of 54 KB of LDS per wave */
         const int sreg = (a.sx > 3 * a.sic ? a.sx : 3 * a.sic) | 1;
         const size_t shm = sizeof(float) * 64 * (size_t)(2 * sreg + a.sfx);
         IcBwdArgs b = a;
         b.sx = sreg;                                             /* kernel: sreg = max(sx, 3 sic) -> pass it through sx */
         int64_t nt = (B + 63) / 64;
         int grid = (int)(nt < 256 * 28 ? nt : 256 * 28);
-        if (a.n_atoms <= 24) hipLaunchKernelGGL(ic_ic2xyz_bwd_reg_kernel<24>, dim3(grid), dim3(ICB_THREADS), shm, (hipStream_t)stream, b);
-        else hipLaunchKernelGGL(ic_ic2xyz_bwd_reg_kernel<32>, dim3(grid), dim3(ICB_THREADS), shm, (hipStream_t)stream, b);
-        return bgk_launch_status("bgk_ic_ic2xyz_backward");
+        if (a.n_atoms <= 24) hipLaunchKernelGGL(ic_ic2xyz_bwd_reg_kernel<24>, dim3(grid), dim3(ICB_THREADS), shm, st, b);
+        else hipLaunchKernelGGL(ic_ic2xyz_bwd_reg_kernel<32>, dim3(grid), dim3(ICB_THREADS), shm, st, b);
+        return fixup();
     }
     const size_t per = (size_t)(2 * a.sx + 3 * a.sic + a.sfx);
     const int ts = fit_tile(ICB_THREADS, per, 0);
     size_t shmem = sizeof(float) * (size_t)ts * per;
     if (shmem > 160 * 1024) { bgk_set_error("bgk_ic_ic2xyz_backward: %d atoms do not fit the LDS tile", a.n_atoms); return BGK_EUNSUPPORTED; }
-    if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int64_t n_tiles = (B + ts - 1) / ts;
     int grid = (int)(n_tiles < 256 * 12 ? n_tiles : 256 * 12);
-    hipLaunchKernelGGL(ic_ic2xyz_bwd_kernel, dim3(grid), dim3(ts), shmem, (hipStream_t)stream, a);
-    return bgk_launch_status("bgk_ic_ic2xyz_backward");
+    if (listed) {
+        if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(ic_ic2xyz_bwd_kernel<false>, dim3(grid), dim3(ts), shmem, st, a);
+        return fixup();
+    }
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(ic_ic2xyz_bwd_kernel<true>, dim3(grid), dim3(ts), shmem, st, a);
+    return bgk_launch_status(what);
 }
 
 extern "C" int bgk_ic_refsys(const float* in, int64_t B, int32_t inverse, int32_t normalize_angles, float eps,

@@ -255,6 +255,7 @@ class RelativeInternalCoordinateTransformation(Flow):
         self._tables.set("fixed", np.ascontiguousarray(f, dtype=np.int32))
         self._n, self._n_fixed = len(z), len(f)
         self._warn = {}
+        self._fix_ws = {}
 
     # reference properties (ic.py:315-353)
     z_matrix = property(lambda self: self._z_matrix)
@@ -267,6 +268,15 @@ class RelativeInternalCoordinateTransformation(Flow):
     angle_indices = property(lambda self: self._angle_indices)
     torsion_indices = property(lambda self: self._torsion_indices)
     normalize_angles = property(lambda self: self._normalize_angles)
+
+    def _fixup_list(self, device, B):
+        """bgk_ic_ic2xyz_backward's list of samples with a clamped norm (1 + B int32; the library resets its count per call).  One
+        buffer per device, grown as needed: backward launches of this object are ordered on the device's current stream."""
+        key = str(device)
+        buf = self._fix_ws.get(key)
+        if buf is None or buf.numel() < B + 1:
+            buf = self._fix_ws[key] = torch.empty(B + 1, dtype=torch.int32, device=device)
+        return buf
 
     def _warn_counter(self, device):
         if not self._raise_warnings:
@@ -402,12 +412,13 @@ class RelativeInternalCoordinateTransformation(Flow):
         keep = 3 * nf if T is None else T.shape[0]
         g_ic = torch.empty((3, B, n), dtype=torch.float32, device=dev)
         g_f = torch.empty((B, keep), dtype=torch.float32, device=dev)
+        fix = self._fixup_list(dev, B)
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_ic_ic2xyz_backward(
                 _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), ldic, _lib.ptr(x), x.shape[1],
                 _lib.ptr(self._tables.get("place", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
                 int(self._normalize_angles), float(self._eps), int(self._enforce_boundaries), _lib.ptr(T), keep, B, _lib.ptr(g_x2), ldgx, _lib.ptr(g_dl),
-                _lib.ptr(g_ic[0]), _lib.ptr(g_ic[1]), _lib.ptr(g_ic[2]), n, _lib.ptr(g_f), keep, _lib.stream_ptr(dev))
+                _lib.ptr(g_ic[0]), _lib.ptr(g_ic[1]), _lib.ptr(g_ic[2]), n, _lib.ptr(g_f), keep, _lib.ptr(fix), _lib.stream_ptr(dev))
         _lib.check(st, "bgk_ic_ic2xyz_backward")
         return g_ic[0], g_ic[1], g_ic[2], g_f
 

@@ -228,7 +228,11 @@ int bgk_xyz2ic_cdf_uni(const float* x, const float* desc4, int32_t use_eps, floa
  * -> g_bonds / g_angles / g_torsions [B, n] (ldgic), g_xfix [B, keep] (ldgf).  The log-det term uses
  * log|det J| = 2 ln d + ln|sin a|, exact away from the eps clamps; a placement whose norms the forward clamped (eps,
  * enforce_boundaries: the forward's, ic_helper.py:372-452) is differentiated the way the reference's autograd does it -- the
- * explicit Jacobian determinant with torch.clamp's derivative -- on forward-mode dual numbers. */
+ * explicit Jacobian determinant with torch.clamp's derivative -- on forward-mode dual numbers.
+ * fix_ws: device workspace of 1 + B int32 (contents irrelevant on entry), or NULL.  With it the sweep over all samples evaluates the
+ * closed form only and lists the samples with a clamped norm, a second small launch redoes the listed samples with the dual numbers
+ * (a few hundred of 2^18 at cfg 3's uniform prior); without it the dual numbers are evaluated inside a slower generic sweep.
+ * Contiguous 16-byte aligned tensors (ldx = ldgx = 3 n_atoms, ldic = ldgic = n, ldgf = keep) are staged by DMA. */
 int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float* torsions, int64_t ldic,
                            const float* x, int64_t ldx, const int32_t* place, int32_t n,
                            const int32_t* fixed, int32_t n_fixed, int32_t normalize_angles,
@@ -236,7 +240,7 @@ int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, const float*
                            const float* Tblacken, int32_t keep, int64_t B,
                            const float* g_x, int64_t ldgx, const float* g_dlogp,
                            float* g_bonds, float* g_angles, float* g_torsions, int64_t ldgic,
-                           float* g_xfix, int64_t ldgf, void* stream);
+                           float* g_xfix, int64_t ldgf, int32_t* fix_ws, void* stream);
 
 /* Backward (VJP) of bgk_ic_xyz2ic (replaces torch autograd through RelativeInternalCoordinateTransformation._forward,
  * crd_transform/ic.py:386-433, the row Jacobians dist_deriv / angle_deriv / torsion_deriv of ic_helper.py:148-293 and the

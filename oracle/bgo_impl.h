@@ -709,6 +709,10 @@ void FN(bgo_refsys)(const REAL* in, int64_t B, int inverse, int normalize, REAL 
  * ic2xyz_deriv (ic_helper.py:372-452) and det3x3(J).abs().log() (ic.py:503) with torch autograd;
  * this is the hand-derived reverse sweep over the placement table, using the analytic identity
  * log|det J| = 2 ln d + ln|sin a| for the log-det term (exact away from the eps clamps).
+ * NOT valid for a placement whose norms the forward clamped (atoms within ~3e-4 nm of each other: |v1 x (v1 x v2)| < eps): there the
+ * clamped vectors are no unit vectors and the reference's autograd sees torch.clamp's zero derivative -- this sweep is then off by
+ * O(1) in either precision.  The checker for such samples is f64 autograd of oracle/torch_flow.py::ic2xyz_torch (the reference's op
+ * chain); the HIP kernels evaluate that case on dual numbers (tests/test_gpu_round5.py::test_ic_backward_where_the_forward_clamped_a_norm).
  *   x [B,3*n_atoms] = the forward OUTPUT (saved), g_x [B,3*n_atoms], g_dlogp [B]
  *   -> g_bonds, g_angles, g_torsions [B,n], g_xfix [B,keep] */
 void FN(bgo_ic_ic2xyz_backward)(const REAL* bonds, const REAL* angles, const REAL* torsions,

@@ -307,7 +307,9 @@ def ic_ic2xyz(bonds, angles, torsions, xfix, z_matrix, fixed, normalize_angles=T
 
 def ic_ic2xyz_backward(bonds, angles, torsions, x, g_x, g_dlogp, z_matrix, fixed, normalize_angles=True,
                        blacken=None, dtype=np.float32):
-    """Analytic VJP of ``ic_ic2xyz`` (x = its forward output): returns (g_bonds, g_angles, g_torsions, g_xfix)."""
+    """Analytic VJP of ``ic_ic2xyz`` (x = its forward output): returns (g_bonds, g_angles, g_torsions, g_xfix).  Closed-form
+    sweep: valid away from the eps clamps of the placements only (see bgo_impl.h); degenerate geometries are checked against
+    autograd of ``torch_flow.ic2xyz_torch``."""
     sfx, _ = _suffix(dtype)
     bonds, angles, torsions, x, g_x = (_np(t, dtype) for t in (bonds, angles, torsions, x, g_x))
     g_dlogp = _np(np.asarray(g_dlogp).reshape(-1), dtype)

@@ -320,11 +320,11 @@ def test_ic_backward_where_the_forward_clamped_a_norm(hip_lib, dev):
     v = 0.5 + torch.rand(B, 1, generator=g)
     ref = {}
     for key, b_, dt in (("f64", blk64, torch.float64), ("f32", blk32, torch.float32)):
-        ins_ = [t_.to(dt).requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
+        ins_ = [t_.detach().clone().to(dt).requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
         (x_,), dl_ = tfl.run_block(b_, ins_, False, grad=True)
         ((x_ * w.to(dt)).sum() - (dl_ * v.to(dt)).sum()).backward()
         ref[key] = [t_.grad.double() for t_ in ins_]
-    ins = [t_.to(dev).requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
+    ins = [t_.detach().clone().to(dev).requires_grad_(True) for t_ in (bonds, angles, tors, fixed)]
     x, dl = blk(*ins)
     ((x * w.to(dev)).sum() - (dl * v.to(dev)).sum()).backward()
     names = ("bonds", "angles", "torsions", "fixed")
@@ -353,8 +353,10 @@ def test_ic_backward_where_the_forward_clamped_a_norm(hip_lib, dev):
 @pytest.mark.parametrize("B", [1, 63, 64, 2085])
 def test_ic_backward_dma_staging_equals_the_row_loop_kernels(hip_lib, dev, B):
     """bgk_ic_ic2xyz_backward on contiguous tensors stages its tiles by DMA and stores the tile images as 16-byte pieces (round 5);
-    BGK_IC_BWD_NODMA=1 / BGK_IC_BWD_LDS=1 select the earlier kernels (per-lane row loops; positions in registers / in LDS).  Same
-    arithmetic per placement: bit-identical gradients, for whole and partial tiles (row counts that leave 1..3 floats over)."""
+    BGK_IC_BWD_NODMA=1 / BGK_IC_BWD_LDS=1 select the earlier kernels (per-lane row loops; positions in registers / in LDS); all three
+    list the samples with a clamped norm for the fix-up launch (dual-number adjoint); without the list (fix_ws = NULL) the generic
+    sweep evaluates the dual numbers in line.  Same arithmetic per placement: bit-identical gradients, for whole and partial tiles
+    (row counts that leave 1..3 floats over)."""
     import os
     from bgflow_amd import configs
     gen = configs.make_ala2_spline_generator(dev)
@@ -367,9 +369,14 @@ def test_ic_backward_dma_staging_equals_the_row_loop_kernels(hip_lib, dev, B):
     w = torch.randn(B, 66, generator=g).to(dev)
     res = {}
     try:
-        for mode in ("dma", "BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS"):
-            if mode != "dma":
+        rel_ic = [m for m in blk.modules() if hasattr(m, "_fixup_list")]
+        assert rel_ic
+        for mode in ("dma", "BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS", "no list"):
+            if mode.startswith("BGK_"):
                 os.environ[mode] = "1"
+            if mode == "no list":               # without the workspace: the generic sweep with the dual numbers in line
+                for m in rel_ic:
+                    m._fixup_list = lambda device, n_rows: None
             ins = [t_.to(dev).requires_grad_(True) for t_ in base]
             x, dl = blk(*ins)
             ((x * w).sum() - 0.7 * dl.sum()).backward()
@@ -378,7 +385,9 @@ def test_ic_backward_dma_staging_equals_the_row_loop_kernels(hip_lib, dev, B):
     finally:
         os.environ.pop("BGK_IC_BWD_NODMA", None)
         os.environ.pop("BGK_IC_BWD_LDS", None)
-    for mode in ("BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS"):
+        for m in rel_ic:
+            m.__dict__.pop("_fixup_list", None)
+    for mode in ("BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS", "no list"):
         for a, b in zip(res["dma"], res[mode]):
             assert bool(torch.isfinite(a).all())
             assert torch.equal(a, b), f"B = {B}: DMA-staged sweep vs {mode}: max difference {float((a - b).abs().max()):.2e}"
