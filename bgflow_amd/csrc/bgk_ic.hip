@@ -556,15 +556,20 @@ __device__ __forceinline__ float sin_rev_near_zero_exact(float f) {
  * vectors, log|det J| is not 2 ln d + ln|sin a|, and the closed-form adjoint of the sweep below is off by O(1). */
 struct PlaceAdj { V3 g1, g2, g3; float gd, ga, gt; };
 
+/* sin / cos of a dual whose VALUE's sine and cosine are known (they do not change from pass to pass) */
+template <int N> __device__ __forceinline__ Dual<N> dsin_pre(Dual<N> a, float s, float c) { Dual<N> r; r.v = s; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * c; return r; }
+template <int N> __device__ __forceinline__ Dual<N> dcos_pre(Dual<N> a, float s, float c) { Dual<N> r; r.v = c; for (int i = 0; i < N; ++i) r.d[i] = -(a.d[i] * s); return r; }
+
 template <int N>
-__device__ __forceinline__ Dual<N> place_scalar_dual(DV3<N> p1, DV3<N> p2, DV3<N> p3, Dual<N> d, Dual<N> a, Dual<N> t, V3 g, float gl, float eps) {
+__device__ __forceinline__ Dual<N> place_scalar_dual(DV3<N> p1, DV3<N> p2, DV3<N> p3, Dual<N> d, Dual<N> a, Dual<N> t, V3 g, float gl, float eps,
+                                                     float sin_t, float cos_t, float sin_a, float cos_a) {
     typedef Dual<N> D;
     typedef DV3<N> W;
     const W v1 = dsub(p1, p2), v2 = dsub(p1, p3);
     const W nv = dcross(v1, v2), nn = dcross(v1, nv);
     const D nvn = dclamp_min(dnorm(nv), eps), nnn = dclamp_min(dnorm(nn), eps);
     const W nh = ddivs(nv, nvn), nnh = ddivs(nn, nnn);
-    const D st = dsin(t), ct = dcos(t), sa = dsin(a), ca = dcos(a);
+    const D st = dsin_pre(t, sin_t, cos_t), ct = dcos_pre(t, sin_t, cos_t), sa = dsin_pre(a, sin_a, cos_a), ca = dcos_pre(a, sin_a, cos_a);
     const W v3 = dadd(dscale(nh, -st), dscale(nnh, ct));
     const D v3n = dclamp_min(dnorm(v3), eps);
     const W v3h = ddivs(v3, v3n);
@@ -581,20 +586,27 @@ __device__ __forceinline__ Dual<N> place_scalar_dual(DV3<N> p1, DV3<N> p2, DV3<N
     return pos.x * g.x + pos.y * g.y + pos.z * g.z + dlog(dabs(det)) * gl;
 }
 
-/* one directional derivative per pass (Dual<1>, 12 passes in a rolled loop): the path is rare, and wider duals would push the sweep's
- * own registers (the positions of all atoms) out to scratch */
+/* N directional derivatives per pass, 12 / N passes in a rolled loop (the VALUES are recomputed by every pass: the fix-up kernel,
+ * whose registers are free, takes four directions at a time) */
+template <int N>
 __device__ __forceinline__ PlaceAdj placement_vjp_dual(V3 p1, V3 p2, V3 p3, float dd, float a_rad, float t_rad, V3 g, float gl, float eps) {
+    static_assert(12 % N == 0, "whole passes");
     float o[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) o[k] = 0.0f;
+    const float sin_t = sinf(t_rad), cos_t = cosf(t_rad), sin_a = sinf(a_rad), cos_a = cosf(a_rad);
 #pragma unroll 1
-    for (int pass = 0; pass < 12; ++pass) {
-        DV3<1> q1 = {dseed<1>(p1.x, 0 - pass), dseed<1>(p1.y, 1 - pass), dseed<1>(p1.z, 2 - pass)};
-        DV3<1> q2 = {dseed<1>(p2.x, 3 - pass), dseed<1>(p2.y, 4 - pass), dseed<1>(p2.z, 5 - pass)};
-        DV3<1> q3 = {dseed<1>(p3.x, 6 - pass), dseed<1>(p3.y, 7 - pass), dseed<1>(p3.z, 8 - pass)};
-        const Dual<1> s = place_scalar_dual<1>(q1, q2, q3, dseed<1>(dd, 9 - pass), dseed<1>(a_rad, 10 - pass), dseed<1>(t_rad, 11 - pass), g, gl, eps);
+    for (int pass = 0; pass < 12 / N; ++pass) {
+        const int b = N * pass;
+        DV3<N> q1 = {dseed<N>(p1.x, 0 - b), dseed<N>(p1.y, 1 - b), dseed<N>(p1.z, 2 - b)};
+        DV3<N> q2 = {dseed<N>(p2.x, 3 - b), dseed<N>(p2.y, 4 - b), dseed<N>(p2.z, 5 - b)};
+        DV3<N> q3 = {dseed<N>(p3.x, 6 - b), dseed<N>(p3.y, 7 - b), dseed<N>(p3.z, 8 - b)};
+        const Dual<N> s = place_scalar_dual<N>(q1, q2, q3, dseed<N>(dd, 9 - b), dseed<N>(a_rad, 10 - b), dseed<N>(t_rad, 11 - b), g, gl, eps,
+                                               sin_t, cos_t, sin_a, cos_a);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) o[k] = (k == pass) ? s.d[0] : o[k];
+        for (int k = 0; k < 12; ++k)
+#pragma unroll
+            for (int e = 0; e < N; ++e) o[k] = (k == b + e) ? s.d[e] : o[k];
     }
     PlaceAdj r;
     r.g1 = {o[0], o[1], o[2]}; r.g2 = {o[3], o[4], o[5]}; r.g3 = {o[6], o[7], o[8]};
@@ -609,7 +621,7 @@ __device__ __forceinline__ PlaceAdj placement_vjp_dual(V3 p1, V3 p2, V3 p3, floa
  * closed form is evaluated regardless and `bad` is raised -- the sweep kernels hand such samples to ic_ic2xyz_bwd_fix_kernel, so that
  * the rare path's registers and code stay out of their loops (inlined there it doubled the loop: the position arrays went to AGPRs
  * and their wave-uniform indexing from v_movrel to select chains). */
-template <bool DUAL>
+template <bool DUAL, int ND = 1>
 __device__ __forceinline__ PlaceAdj placement_adjoint(V3 p1, V3 p2, V3 p3, float dd, float an, float t, V3 g, float gl, int normalize,
                                                       float eps, int enforce, bool& bad) {
     PlaceAdj o;
@@ -621,7 +633,7 @@ __device__ __forceinline__ PlaceAdj placement_adjoint(V3 p1, V3 p2, V3 p3, float
     if (enforce && (n2_nv < e2 || n2_nn < e2 || n2_v1 < e2)) {       /* rare: a norm of this placement was clamped by the forward */
         if constexpr (DUAL) {
             const float a_rad = normalize ? an * PI_F : an, t_rad = normalize ? t * (2.0f * PI_F) - PI_F : t;
-            o = placement_vjp_dual(p1, p2, p3, dd, a_rad, t_rad, g, gl, eps);
+            o = placement_vjp_dual<ND>(p1, p2, p3, dd, a_rad, t_rad, g, gl, eps);
             if (normalize) { o.ga *= PI_F; o.gt *= 2.0f * PI_F; }
             return o;
         } else {
@@ -883,7 +895,22 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
             s_b[lane * n + zr] = q.gd; s_a[lane * n + zr] = q.ga; s_t[lane * n + zr] = q.gt;
             at = at_n; i1 = i1_n; i2 = i2_n; i3 = i3_n; zr = zr_n; dd = dd_n; an = an_n; t = t_n;
         }
-        if (a.T) {
+        if (a.T && keep <= 16) {
+            /* every whitened coordinate as its own running sum over the fixed coordinates c (ascending, product then sum: the order
+             * and the operations of the other kernels): 16 independent chains instead of keep x 3 n_fixed dependent round trips */
+            float acc[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+            for (int c = 0; c < nf3; ++c) {
+                const float gc = gp[s_fo[c]];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k < keep) { const float pr = gc * s_T[k * nf3 + c]; acc[k] = acc[k] + pr; }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < keep) s_f[lane * keep + k] = acc[k];
+        } else if (a.T) {
             for (int k = 0; k < keep; ++k) {
                 float s = 0.0f;
                 for (int c = 0; c < nf3; ++c) s += gp[s_fo[c]] * s_T[k * nf3 + c];
@@ -917,30 +944,45 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
  * samples of 2^18 at cfg 3's uniform prior: the launch costs its latency. */
 __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_fix_kernel(IcBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int n = a.n, nf3 = 3 * a.n_fixed, na3 = 3 * a.n_atoms;
+    const int n = a.n, nf3 = 3 * a.n_fixed, na3 = 3 * a.n_atoms, keep = a.keep;
     const int count = a.fix[0];
+    if ((int)blockIdx.x * 64 >= count) return;
+    typedef const __attribute__((address_space(4))) int32_t* ci32_t;
+    const ci32_t place = (ci32_t)a.place;
+    /* the wave-uniform tables of the fixed block in LDS when they fit (a.sfx: the launcher's verdict), as in the DMA sweep */
+    float* s_T = smem + 64 * a.sx;
+    int* s_fo = reinterpret_cast<int*>(s_T + (a.T ? keep * nf3 : 0));
+    const bool tables = a.sfx != 0;
+    if (tables) {
+        for (int c = threadIdx.x; c < nf3; c += 64) s_fo[c] = 3 * a.fixed[c / 3] + c % 3;
+        if (a.T) for (int c = threadIdx.x; c < keep * nf3; c += 64) s_T[c] = a.T[c];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     for (int k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
         const int64_t b = a.fix[1 + k];
         float* gp = smem + threadIdx.x * a.sx;
-        const float* xr = a.x + b * a.ldx;
+        const float* __restrict__ xr = a.x + b * a.ldx;
+        const float* __restrict__ gxr = a.g_x + b * a.ldgx;
         const float gl = a.g_dlogp[b];
-        for (int c = 0; c < na3; ++c) gp[c] = a.g_x[b * a.ldgx + c];
+        for (int c = 0; c < na3; ++c) gp[c] = gxr[c];
         bool bad = false;
         for (int i = n - 1; i >= 0; --i) {
-            const int at = a.place[5 * i], i1 = a.place[5 * i + 1], i2 = a.place[5 * i + 2], i3 = a.place[5 * i + 3], zr = a.place[5 * i + 4];
+            const int at = place[5 * i], i1 = place[5 * i + 1], i2 = place[5 * i + 2], i3 = place[5 * i + 3], zr = place[5 * i + 4];
             const V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
             const float dd = a.bonds[b * a.ldic + zr], an = a.angles[b * a.ldic + zr], t = a.torsions[b * a.ldic + zr];
             const V3 g = ld3(gp + 3 * at);
-            const PlaceAdj q = placement_adjoint<true>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
+            const PlaceAdj q = placement_adjoint<true, 4>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
             gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
             gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
             gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
             a.g_bonds[b * a.ldgic + zr] = q.gd; a.g_angles[b * a.ldgic + zr] = q.ga; a.g_torsions[b * a.ldgic + zr] = q.gt;
         }
         if (a.T) {
-            for (int kk = 0; kk < a.keep; ++kk) {
+            for (int kk = 0; kk < keep; ++kk) {
                 float s = 0.0f;
-                for (int c = 0; c < nf3; ++c) s += gp[3 * a.fixed[c / 3] + c % 3] * a.T[kk * nf3 + c];
+                if (tables) for (int c = 0; c < nf3; ++c) s += gp[s_fo[c]] * s_T[kk * nf3 + c];
+                else for (int c = 0; c < nf3; ++c) s += gp[3 * a.fixed[c / 3] + c % 3] * a.T[kk * nf3 + c];
                 a.g_xfix[b * a.ldgf + kk] = s;
             }
         } else {
@@ -1173,7 +1215,9 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
         if (!enforce_boundaries) return bgk_launch_status(what);           /* nothing is ever clamped */
         IcBwdArgs f = a;
         f.sx = (3 * a.n_atoms) | 1;
-        const size_t shm = sizeof(float) * 64 * (size_t)f.sx;
+        const size_t tab = (size_t)(Tblacken ? keep * 3 * n_fixed : 0) + 3 * (size_t)n_fixed;      /* floats: Tblacken + the offsets of the fixed coordinates */
+        f.sfx = tab <= 8192 ? 1 : 0;                           /* the fixed block's tables in LDS (else read from global memory) */
+        const size_t shm = sizeof(float) * (64 * (size_t)f.sx + (f.sfx ? tab : 0));
         if (shm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_fix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(ic_ic2xyz_bwd_fix_kernel, dim3(64), dim3(64), shm, st, f);
         return bgk_launch_status(what);
@@ -1193,7 +1237,7 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
         b.sx = 64 * ((w + 3) & ~3);                                /* floats of the x / IC region; the g_x tile follows */
         const size_t shm = sizeof(float) * ((size_t)b.sx + 64 * (size_t)(3 * a.n_atoms) + (size_t)(Tblacken ? keep * 3 * n_fixed : 0) + 3 * (size_t)n_fixed);
         int64_t nt = (B + 63) / 64;
-        int grid = (int)(nt < 256 * 16 ? nt : 256 * 16);
+        int grid = (int)(nt < 256 * 4 ? nt : 256 * 4);          /* one wave per SIMD (LDS): every wave walks its share of the tiles */
         if (a.n_atoms <= 24) hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<24>, dim3(grid), dim3(64), shm, st, b);
         else hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<32>, dim3(grid), dim3(64), shm, st, b);
         return fixup();

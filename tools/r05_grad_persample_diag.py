@@ -18,6 +18,11 @@ gen64 = configs.make_ala2_spline_generator().double()
 mean64 = gen64._target._mean.detach().double()
 g = torch.Generator().manual_seed(2024)
 z = [torch.rand(B, d, generator=g) for d in (17, 17, 17, 9)]
+if len(sys.argv) > 2 and use_gpu:      # `B chunk`: chunk `chunk` of B samples of tests/test_gpu_round4.py::test_kl_gradient_at_the_bench_batch's batch
+    gg = torch.Generator(device=dev).manual_seed(2024)
+    zz = [torch.rand(1 << 18, d, device=dev, generator=gg) for d in (17, 17, 17, 9)]
+    c = int(sys.argv[2])
+    z = [v[c * B:(c + 1) * B].cpu() for v in zz]
 names = ("bonds", "angles", "torsions", "fixed")
 
 
