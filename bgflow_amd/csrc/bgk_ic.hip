@@ -824,6 +824,16 @@ __global__ __launch_bounds__(ICB_THREADS) void ic_ic2xyz_bwd_reg_kernel(IcBwdArg
  *   3. the reverse sweep overwrites the IC values by their gradients in place, g_xfix goes behind them ([64][keep]);
  *   4. the four results leave as 16-byte coalesced stores of the tile images.
  * LDS: 2 x 64 x 3 n_atoms floats per wave (33 KB at ala2 size): four waves per CU. */
+/* -DBGK_ICB_TS=1: s_memtime stamps of the tile's phases (tools/r05_icb_ts.py); lane 0 writes them over the tile's first g_xfix row */
+#ifndef BGK_ICB_TS
+#define BGK_ICB_TS 0
+#endif
+#if BGK_ICB_TS
+#define ICB_TS(k) do { __builtin_amdgcn_sched_barrier(0); ts_[k] = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ICB_TS(k) do { } while (0)
+#endif
+
 template <int NA>
 __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -832,24 +842,29 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
     const int region = a.sx;                   /* launcher: 64 * max(3 n_atoms, 3 n + keep), a multiple of 4 */
     float* s_r = smem;                         /* x tile -> bonds | angles | torsions | g_xfix tiles */
     float* s_g = smem + region;                /* g_x tile = position adjoints, row stride 3 n_atoms */
-    float* s_T = s_g + 64 * na3;               /* Tblacken [keep][3 n_fixed] (whitened fixed block) */
-    int* s_fo = reinterpret_cast<int*>(s_T + (a.T ? keep * nf3 : 0));      /* offset of fixed coordinate c in a position row */
+    float* s_T = s_g + 64 * na3;               /* Tblacken transposed and padded: [3 n_fixed][16] (column c of the whitened fixed block as four 16-byte reads) */
+    int* s_fo = reinterpret_cast<int*>(s_T + (a.T ? 16 * nf3 : 0));        /* offset of fixed coordinate c in a position row */
     typedef const __attribute__((address_space(4))) int32_t* ci32_t;
     const ci32_t place = (ci32_t)a.place;
     /* the wave-uniform tables of the fixed block once per wave: read per sample and coordinate from global memory they were 135
      * dependent scalar round trips per tile */
     for (int c = lane; c < nf3; c += 64) s_fo[c] = 3 * a.fixed[c / 3] + c % 3;
-    if (a.T) for (int c = lane; c < keep * nf3; c += 64) s_T[c] = a.T[c];
+    if (a.T) for (int e = lane; e < 16 * nf3; e += 64) { const int c = e >> 4, kk = e & 15; s_T[e] = (kk < keep && keep <= 16) ? a.T[kk * nf3 + c] : 0.0f; }
     const int64_t n_tiles = (a.B + 63) / 64;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t b0 = tile * 64;
         const int rows = (int)((a.B - b0) < 64 ? (a.B - b0) : 64);
+#if BGK_ICB_TS
+        unsigned ts_[8];
+#endif
+        ICB_TS(0);
         dma_tile(s_r, a.x + b0 * na3, na3, rows, lane);
         dma_tile(s_g, a.g_x + b0 * na3, na3, rows, lane);
         const float gl = lane < rows ? a.g_dlogp[b0 + lane] : 0.0f;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        ICB_TS(1);
         float px[NA], py[NA], pz[NA];
 #pragma unroll
         for (int k = 0; k < NA; ++k)
@@ -875,9 +890,11 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
         }
         const bool live = (gl != 0.0f) || ((any & 0x7fffffffu) != 0u);
         bool bad = false;
+        ICB_TS(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        ICB_TS(3);
         /* reverse sweep; the record and the three IC values of placement i - 1 are requested while placement i is evaluated */
         int at = place[5 * (n - 1)], i1 = place[5 * (n - 1) + 1], i2 = place[5 * (n - 1) + 2], i3 = place[5 * (n - 1) + 3], zr = place[5 * (n - 1) + 4];
         float dd = s_b[lane * n + zr], an = s_a[lane * n + zr], t = s_t[lane * n + zr];
@@ -895,25 +912,29 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
             s_b[lane * n + zr] = q.gd; s_a[lane * n + zr] = q.ga; s_t[lane * n + zr] = q.gt;
             at = at_n; i1 = i1_n; i2 = i2_n; i3 = i3_n; zr = zr_n; dd = dd_n; an = an_n; t = t_n;
         }
+        ICB_TS(4);
         if (a.T && keep <= 16) {
             /* every whitened coordinate as its own running sum over the fixed coordinates c (ascending, product then sum: the order
              * and the operations of the other kernels): 16 independent chains instead of keep x 3 n_fixed dependent round trips */
             float acc[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[k] = 0.0f;
+#pragma unroll 3
             for (int c = 0; c < nf3; ++c) {
                 const float gc = gp[s_fo[c]];
+                const float4* tc = reinterpret_cast<const float4*>(s_T + 16 * c);
+                const float4 t0 = tc[0], t1 = tc[1], t2 = tc[2], t3 = tc[3];
+                const float tv[16] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w, t3.x, t3.y, t3.z, t3.w};
 #pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k < keep) { const float pr = gc * s_T[k * nf3 + c]; acc[k] = acc[k] + pr; }
+                for (int k = 0; k < 16; ++k) { const float pr = gc * tv[k]; acc[k] = acc[k] + pr; }      /* (rows >= keep of the table are 0) */
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 if (k < keep) s_f[lane * keep + k] = acc[k];
-        } else if (a.T) {
+        } else if (a.T) {                          /* more than 16 whitened coordinates: from global memory */
             for (int k = 0; k < keep; ++k) {
                 float s = 0.0f;
-                for (int c = 0; c < nf3; ++c) s += gp[s_fo[c]] * s_T[k * nf3 + c];
+                for (int c = 0; c < nf3; ++c) s += gp[s_fo[c]] * a.T[k * nf3 + c];
                 s_f[lane * keep + k] = s;
             }
         } else {
@@ -922,6 +943,7 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
         if (bad && live && lane < rows) flag_for_fixup(a.fix, b0 + lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        ICB_TS(5);
         {   /* the tile images out: 16-byte pieces, then the 1..3 floats a partial tile may leave over */
             float* const outs[4] = {a.g_bonds + b0 * n, a.g_angles + b0 * n, a.g_torsions + b0 * n, a.g_xfix + b0 * keep};
             const float* const srcs[4] = {s_b, s_a, s_t, s_f};
@@ -934,43 +956,68 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
                 for (int q = (total4 << 2) + lane; q < total; q += 64) outs[f][q] = srcs[f][q];
             }
         }
+        ICB_TS(6);
+#if BGK_ICB_TS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ICB_TS(7);
+        if (lane == 0)
+            for (int q = 0; q < 8; ++q) reinterpret_cast<unsigned*>(a.g_xfix + b0 * keep)[q] = ts_[q];
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-/* The samples the sweep kernels flagged (fix[0] of them, indices behind it), one lane each, everything from global memory except the
- * running position adjoints (a private LDS row): the same sweep with the dual-number adjoint where a norm was clamped.  A few hundred
- * samples of 2^18 at cfg 3's uniform prior: the launch costs its latency. */
+/* The samples the sweep kernels flagged (fix[0] of them, indices behind it), one lane each: the lane copies its sample's rows (g_x, x,
+ * bonds, angles, torsions) into a private LDS row -- sixteen independent loads per round trip -- and runs the same sweep with the
+ * dual-number adjoint where a norm was clamped.  A few hundred samples of 2^18 at cfg 3's uniform prior: the launch costs its latency.
+ * blockDim.x = lanes per workgroup (64, fewer for molecules whose rows do not fit 160 KB of LDS). */
+__device__ __forceinline__ void copy_row16(float* dst, const float* __restrict__ src, int w) {
+    for (int c0 = 0; c0 < w; c0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[c0 + u < w ? c0 + u : w - 1];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (c0 + u < w) dst[c0 + u] = v[u];
+    }
+}
+
 __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_fix_kernel(IcBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = a.n, nf3 = 3 * a.n_fixed, na3 = 3 * a.n_atoms, keep = a.keep;
-    const int count = a.fix[0];
-    if ((int)blockIdx.x * 64 >= count) return;
+    const int count = a.fix[0], TS = (int)blockDim.x;
+    if ((int)blockIdx.x * TS >= count) return;
     typedef const __attribute__((address_space(4))) int32_t* ci32_t;
     const ci32_t place = (ci32_t)a.place;
     /* the wave-uniform tables of the fixed block in LDS when they fit (a.sfx: the launcher's verdict), as in the DMA sweep */
-    float* s_T = smem + 64 * a.sx;
+    float* s_T = smem + (size_t)TS * a.sx;
     int* s_fo = reinterpret_cast<int*>(s_T + (a.T ? keep * nf3 : 0));
     const bool tables = a.sfx != 0;
     if (tables) {
-        for (int c = threadIdx.x; c < nf3; c += 64) s_fo[c] = 3 * a.fixed[c / 3] + c % 3;
-        if (a.T) for (int c = threadIdx.x; c < keep * nf3; c += 64) s_T[c] = a.T[c];
+        for (int c = threadIdx.x; c < nf3; c += TS) s_fo[c] = 3 * a.fixed[c / 3] + c % 3;
+        if (a.T) for (int c = threadIdx.x; c < keep * nf3; c += TS) s_T[c] = a.T[c];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    for (int k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
+    for (int k = blockIdx.x * TS + threadIdx.x; k < count; k += gridDim.x * TS) {
         const int64_t b = a.fix[1 + k];
-        float* gp = smem + threadIdx.x * a.sx;
-        const float* __restrict__ xr = a.x + b * a.ldx;
-        const float* __restrict__ gxr = a.g_x + b * a.ldgx;
+        float* gp = smem + (size_t)threadIdx.x * a.sx;      /* row: position adjoints | positions | bonds | angles | torsions */
+        float* xr = gp + na3;
+        float* rb = xr + na3;
+        float* ra = rb + n;
+        float* rt = ra + n;
+        copy_row16(gp, a.g_x + b * a.ldgx, na3);
+        copy_row16(xr, a.x + b * a.ldx, na3);
+        copy_row16(rb, a.bonds + b * a.ldic, n);
+        copy_row16(ra, a.angles + b * a.ldic, n);
+        copy_row16(rt, a.torsions + b * a.ldic, n);
         const float gl = a.g_dlogp[b];
-        for (int c = 0; c < na3; ++c) gp[c] = gxr[c];
         bool bad = false;
         for (int i = n - 1; i >= 0; --i) {
             const int at = place[5 * i], i1 = place[5 * i + 1], i2 = place[5 * i + 2], i3 = place[5 * i + 3], zr = place[5 * i + 4];
             const V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
-            const float dd = a.bonds[b * a.ldic + zr], an = a.angles[b * a.ldic + zr], t = a.torsions[b * a.ldic + zr];
+            const float dd = rb[zr], an = ra[zr], t = rt[zr];
             const V3 g = ld3(gp + 3 * at);
             const PlaceAdj q = placement_adjoint<true, 4>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
             gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
@@ -1214,12 +1261,15 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
     auto fixup = [&]() -> int {
         if (!enforce_boundaries) return bgk_launch_status(what);           /* nothing is ever clamped */
         IcBwdArgs f = a;
-        f.sx = (3 * a.n_atoms) | 1;
-        const size_t tab = (size_t)(Tblacken ? keep * 3 * n_fixed : 0) + 3 * (size_t)n_fixed;      /* floats: Tblacken + the offsets of the fixed coordinates */
-        f.sfx = tab <= 8192 ? 1 : 0;                           /* the fixed block's tables in LDS (else read from global memory) */
-        const size_t shm = sizeof(float) * (64 * (size_t)f.sx + (f.sfx ? tab : 0));
+        f.sx = (6 * a.n_atoms + 3 * n) | 1;                    /* a lane's row: position adjoints | positions | bonds | angles | torsions */
+        size_t tab = (size_t)(Tblacken ? keep * 3 * n_fixed : 0) + 3 * (size_t)n_fixed;      /* floats: Tblacken + the offsets of the fixed coordinates */
+        f.sfx = tab <= 4096 ? 1 : 0;                           /* the fixed block's tables in LDS (else read from global memory) */
+        if (!f.sfx) tab = 0;
+        const int ts = fit_tile(64, (size_t)f.sx, tab);
+        const size_t shm = sizeof(float) * ((size_t)ts * (size_t)f.sx + tab);
+        if (shm > 160 * 1024) { bgk_set_error("%s: %d atoms do not fit the LDS rows of the fix-up launch", what, a.n_atoms); return BGK_EUNSUPPORTED; }
         if (shm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_fix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(ic_ic2xyz_bwd_fix_kernel, dim3(64), dim3(64), shm, st, f);
+        hipLaunchKernelGGL(ic_ic2xyz_bwd_fix_kernel, dim3(ts == 64 ? 64 : 256), dim3(ts), shm, st, f);
         return bgk_launch_status(what);
     };
     if (fix_ws && enforce_boundaries) {
@@ -1235,7 +1285,7 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
         const int w = 3 * a.n_atoms > 3 * n + keep ? 3 * a.n_atoms : 3 * n + keep;
         IcBwdArgs b = a;
         b.sx = 64 * ((w + 3) & ~3);                                /* floats of the x / IC region; the g_x tile follows */
-        const size_t shm = sizeof(float) * ((size_t)b.sx + 64 * (size_t)(3 * a.n_atoms) + (size_t)(Tblacken ? keep * 3 * n_fixed : 0) + 3 * (size_t)n_fixed);
+        const size_t shm = sizeof(float) * ((size_t)b.sx + 64 * (size_t)(3 * a.n_atoms) + (size_t)(Tblacken ? 16 * 3 * n_fixed : 0) + 3 * (size_t)n_fixed);
         int64_t nt = (B + 63) / 64;
         int grid = (int)(nt < 256 * 4 ? nt : 256 * 4);          /* one wave per SIMD (LDS): every wave walks its share of the tiles */
         if (a.n_atoms <= 24) hipLaunchKernelGGL(ic_ic2xyz_bwd_dma_kernel<24>, dim3(grid), dim3(64), shm, st, b);
