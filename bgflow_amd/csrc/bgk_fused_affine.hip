@@ -380,6 +380,87 @@ __device__ __forceinline__ void res_net_tail(h2_f32x16 (&res)[OT], h2_f32x16 (&h
 #endif
 }
 
+/* ---- both networks of a coupling layer as ONE software pipeline (round 5).  res_net_tail runs a network as activation -> GEMM ->
+ * activation -> GEMM: pure-VALU and pure-MFMA phases that overlap only across the two waves of a SIMD (r04_cfg2_pmc.txt: MFMA busy
+ * 115 M, VALU active 63 M, SQ_WAIT_ANY 56 M of 183 M wave cycles).  The shift and the scale network are independent, so a GEMM of one
+ * can carry the activation (+ f16 split) of the other inside the same wave: per k-step of the GEMM (2 HT tiles x 3 MFMAs) a quarter of
+ * the other network's 16 activation pairs, laid out MFMA / VALU / VALU ... by sched_group_barrier.
+ *   stage A  act(hs)                       stage B  GEMM1_s  ||  act(ht)          stage C  GEMM1_t  ||  act(h1s)
+ *   stage D  GEMM2_s || act(h1t)           stage E  GEMM2_t
+ * BGK_AFF_PIPE2=0: the two networks one after the other (res_net_tail). */
+#ifndef BGK_AFF_PIPE2
+#define BGK_AFF_PIPE2 1
+#endif
+#ifndef BGK_AFF_PIPE2_VPM
+#define BGK_AFF_PIPE2_VPM 7            /* VALU instructions the pattern asks for behind every MFMA */
+#endif
+
+/* activation + split of pairs [p0, p0 + np) of a 2-tile accumulator set (pair p: tile p >> 3, rows 2 (p & 7), + 1) */
+template <int ACT, int HT>
+__device__ __forceinline__ void r_act_split_pairs(RB<HT>& b, const h2_f32x16 (&in)[HT], float c, float k, int p0, int np) {
+#pragma unroll
+    for (int p = p0; p < p0 + np; ++p) {
+        const int m = p >> 3, r = 2 * (p & 7);
+        const float a0 = r_act<ACT>(in[m][r], c, k), a1 = r_act<ACT>(in[m][r + 1], c, k);
+        unsigned hi, lo;
+        r_split_pair(a0, a1, hi, lo);
+        const int s = 2 * m + (r >> 3), e = (r & 7) >> 1;
+        b.hi[s][e] = hi; b.lo[s][e] = lo;
+    }
+}
+
+/* out = W' * b + bias' (ra_gemm_hidden_pre) while `other_in` is activated and split into `other_b`: S = 2 HT k-steps, each followed by
+ * 8 HT / S activation pairs of the other network */
+template <int ACT, int NT, int HT>
+__device__ __forceinline__ void ra_gemm_with_act(h2_f32x16 (&out)[NT], const RB<HT>& b, const r_u32x4* W, int lane, const RA<NT>& first,
+                                                 RB<HT>& other_b, const h2_f32x16 (&other_in)[HT], float oc) {
+    constexpr int S = 2 * HT, PPS = (8 * HT) / S;
+    const float ok = ACT == 3 ? oc * 2.88539008177792681f : (ACT == 1 ? oc * 1.44269504088896341f : oc);
+    RA<NT> ring[2];
+    ring[0] = first;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) ra_load<NT>(ring[(s + 1) & 1], W, s + 1, lane);
+        else {
+#pragma unroll
+            for (int m = 0; m < NT; ++m) ring[(s + 1) & 1].v[m][0] = W[(S * NT * 2 + m) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);          /* the next step's LDS reads stay in front of this step's MFMAs (see ra_gemm_hidden_pre) */
+        if (s == 0) ra_mfma3<NT, true, false>(out, ring[0], __builtin_bit_cast(h2_h16x8, b.hi[0]), __builtin_bit_cast(h2_h16x8, b.lo[0]));
+        else ra_mfma3<NT, false, false>(out, ring[s & 1], __builtin_bit_cast(h2_h16x8, b.hi[s]), __builtin_bit_cast(h2_h16x8, b.lo[s]));
+        r_act_split_pairs<ACT, HT>(other_b, other_in, oc, ok, PPS * s, PPS);
+#pragma unroll
+        for (int q = 0; q < 3 * NT; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       /* one MFMA */
+            __builtin_amdgcn_sched_group_barrier(0x002, BGK_AFF_PIPE2_VPM, 0);       /* ... then VALU work of the other network */
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const h2_h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+        out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h2_h16x8, ring[S & 1].v[m][0]), one2, out[m], 0, 0, 0);
+}
+
+/* the two networks (same activation ACT) behind their layers 0: hs / ht in, mu / sr (unscaled output-layer accumulators) out */
+template <int ACT, int HT, int OT>
+__device__ __forceinline__ void res_two_nets_t(h2_f32x16 (&mu)[OT], h2_f32x16 (&sr)[OT], h2_f32x16 (&hs)[HT], h2_f32x16 (&ht)[HT],
+                                               const AffNet& ns, const AffNet& nt, const r_u32x4* s_w, ResOff os, ResOff ot, int lane) {
+    RB<HT> bs, bt;
+    RA<HT> f1;
+    ra_load<HT>(f1, s_w + os.a1, 0, lane);
+    r_act_split_t<ACT, HT>(bs, hs, ns.c0);                                                  /* A */
+    BGK_AFF_PRIO(1);
+    ra_gemm_with_act<ACT, HT, HT>(hs, bs, s_w + os.a1, lane, f1, bt, ht, nt.c0);            /* B: hs <- layer-1 pre-activations of the shift net */
+    ra_load<HT>(f1, s_w + ot.a1, 0, lane);
+    ra_gemm_with_act<ACT, HT, HT>(ht, bt, s_w + ot.a1, lane, f1, bs, hs, ns.c1);            /* C */
+    RA<OT> f2;
+    ra_load<OT>(f2, s_w + os.a2, 0, lane);
+    ra_gemm_with_act<ACT, OT, HT>(mu, bs, s_w + os.a2, lane, f2, bt, ht, nt.c1);            /* D */
+    ra_load<OT>(f2, s_w + ot.a2, 0, lane);
+    ra_gemm_hidden_pre<OT, HT>(sr, bt, s_w + ot.a2, lane, f2);                              /* E */
+    BGK_AFF_PRIO(0);
+}
 constexpr int RES_HT = 2;
 
 template <int OT, int RW>
@@ -636,7 +717,9 @@ template <int N> __device__ __forceinline__ void res_wait_vm() {
 #define AFF_TS(k) do { } while (0)
 #endif
 
-template <int RW, int G>
+/* PACT: 0 = the networks one after the other (any activations); 1 SiLU / 2 ReLU / 3 Tanh = both networks carry that activation and run
+ * as one software pipeline (res_two_nets_t; one instance per activation: dispatched inside the kernel the four pipelines spill) */
+template <int RW, int G, int PACT>
 __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_dma_kernel(FusedAffArgs a, ResOff os, ResOff ot, int n16_s0, int n16_s1, int n16_s2,
                                                                                   int n16_t0, int n16_t1, int n16_t2, int w16) {
     constexpr int HT = RES_HT, OT = 1, NQ = 32 * G / 64;          /* NQ: DMA requests (and store instructions) per half */
@@ -737,16 +820,20 @@ __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_dma_kerne
         AFF_TS(2);
 
         h2_f32x16 mu[OT], sr[OT];
-        if (a.has_shift) res_net_tail<HT, OT>(mu, hs, a.shift, s_w, os, lane);
-        else {
+        if constexpr (PACT != 0) {
+            res_two_nets_t<PACT, HT, OT>(mu, sr, hs, ht, a.shift, a.scale, s_w, os, ot, lane);
+        } else {
+            if (a.has_shift) res_net_tail<HT, OT>(mu, hs, a.shift, s_w, os, lane);
+            else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mu[0][r] = 0.0f;
-        }
-        AFF_TS(3);
-        if (a.has_scale) res_net_tail<HT, OT>(sr, ht, a.scale, s_w, ot, lane);
-        else {
+                for (int r = 0; r < 16; ++r) mu[0][r] = 0.0f;
+            }
+            AFF_TS(3);
+            if (a.has_scale) res_net_tail<HT, OT>(sr, ht, a.scale, s_w, ot, lane);
+            else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sr[0][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) sr[0][r] = 0.0f;
+            }
         }
 
         AFF_TS(4);
@@ -886,9 +973,15 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
             int64_t grid = (n_tiles + DRW - 1) / DRW;
             if (grid > 256) grid = 256;
             const int c_s = has_shift, c_t = has_scale;
-            auto K = coupling_affine_resident_dma_kernel<DRW, 8>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipLaunchKernelGGL(K, dim3((int)grid), dim3(DRW * 64), dma_shmem, st, a, os, ot, c_s * n0, c_s * n1, c_s * n2, c_t * n0, c_t * n1, c_t * n2, top);
+            int pact = 0;
+#if BGK_AFF_PIPE2
+            if (has_shift && has_scale && s_act == t_act && s_act >= 1 && s_act <= 3 && !getenv("BGK_AFFINE_NO_PIPE2")) pact = s_act;
+#endif
+#define BGK_LAUNCH_DMA(PA) do { auto K = coupling_affine_resident_dma_kernel<DRW, 8, PA>; \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipLaunchKernelGGL(K, dim3((int)grid), dim3(DRW * 64), dma_shmem, st, a, os, ot, c_s * n0, c_s * n1, c_s * n2, c_t * n0, c_t * n1, c_t * n2, top); } while (0)
+            if (pact == 1) BGK_LAUNCH_DMA(1); else if (pact == 2) BGK_LAUNCH_DMA(2); else if (pact == 3) BGK_LAUNCH_DMA(3); else BGK_LAUNCH_DMA(0);
+#undef BGK_LAUNCH_DMA
             return bgk_launch_status("bgk_coupling_affine_dense_h2");
         }
         if (res_shmem <= 150 * 1024) {
