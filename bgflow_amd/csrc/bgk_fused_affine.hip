@@ -443,20 +443,20 @@ __device__ __forceinline__ void ra_gemm_with_act(h2_f32x16 (&out)[NT], const RB<
 }
 
 /* the two networks (same activation ACT) behind their layers 0: hs / ht in, mu / sr (unscaled output-layer accumulators) out */
-template <int ACT, int HT, int OT>
+template <int AS, int AT, int HT, int OT>
 __device__ __forceinline__ void res_two_nets_t(h2_f32x16 (&mu)[OT], h2_f32x16 (&sr)[OT], h2_f32x16 (&hs)[HT], h2_f32x16 (&ht)[HT],
                                                const AffNet& ns, const AffNet& nt, const r_u32x4* s_w, ResOff os, ResOff ot, int lane) {
     RB<HT> bs, bt;
     RA<HT> f1;
     ra_load<HT>(f1, s_w + os.a1, 0, lane);
-    r_act_split_t<ACT, HT>(bs, hs, ns.c0);                                                  /* A */
+    r_act_split_t<AS, HT>(bs, hs, ns.c0);                                                   /* A */
     BGK_AFF_PRIO(1);
-    ra_gemm_with_act<ACT, HT, HT>(hs, bs, s_w + os.a1, lane, f1, bt, ht, nt.c0);            /* B: hs <- layer-1 pre-activations of the shift net */
+    ra_gemm_with_act<AT, HT, HT>(hs, bs, s_w + os.a1, lane, f1, bt, ht, nt.c0);             /* B: hs <- layer-1 pre-activations of the shift net */
     ra_load<HT>(f1, s_w + ot.a1, 0, lane);
-    ra_gemm_with_act<ACT, HT, HT>(ht, bt, s_w + ot.a1, lane, f1, bs, hs, ns.c1);            /* C */
+    ra_gemm_with_act<AS, HT, HT>(ht, bt, s_w + ot.a1, lane, f1, bs, hs, ns.c1);             /* C */
     RA<OT> f2;
     ra_load<OT>(f2, s_w + os.a2, 0, lane);
-    ra_gemm_with_act<ACT, OT, HT>(mu, bs, s_w + os.a2, lane, f2, bt, ht, nt.c1);            /* D */
+    ra_gemm_with_act<AT, OT, HT>(mu, bs, s_w + os.a2, lane, f2, bt, ht, nt.c1);             /* D */
     ra_load<OT>(f2, s_w + ot.a2, 0, lane);
     ra_gemm_hidden_pre<OT, HT>(sr, bt, s_w + ot.a2, lane, f2);                              /* E */
     BGK_AFF_PRIO(0);
@@ -717,9 +717,10 @@ template <int N> __device__ __forceinline__ void res_wait_vm() {
 #define AFF_TS(k) do { } while (0)
 #endif
 
-/* PACT: 0 = the networks one after the other (any activations); 1 SiLU / 2 ReLU / 3 Tanh = both networks carry that activation and run
- * as one software pipeline (res_two_nets_t; one instance per activation: dispatched inside the kernel the four pipelines spill) */
-template <int RW, int G, int PACT>
+/* AS, AT: the hidden activations of the shift / scale network (1 SiLU, 2 ReLU, 3 Tanh) when both exist and run as one software
+ * pipeline (res_two_nets_t; one kernel instance per pair: dispatched inside the kernel the pipelines spill); AS = 0: the networks
+ * one after the other, activations at run time */
+template <int RW, int G, int AS, int AT>
 __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_dma_kernel(FusedAffArgs a, ResOff os, ResOff ot, int n16_s0, int n16_s1, int n16_s2,
                                                                                   int n16_t0, int n16_t1, int n16_t2, int w16) {
     constexpr int HT = RES_HT, OT = 1, NQ = 32 * G / 64;          /* NQ: DMA requests (and store instructions) per half */
@@ -820,8 +821,8 @@ __global__ __launch_bounds__(RW * 64, 1) void coupling_affine_resident_dma_kerne
         AFF_TS(2);
 
         h2_f32x16 mu[OT], sr[OT];
-        if constexpr (PACT != 0) {
-            res_two_nets_t<PACT, HT, OT>(mu, sr, hs, ht, a.shift, a.scale, s_w, os, ot, lane);
+        if constexpr (AS != 0) {
+            res_two_nets_t<AS, AT, HT, OT>(mu, sr, hs, ht, a.shift, a.scale, s_w, os, ot, lane);
         } else {
             if (a.has_shift) res_net_tail<HT, OT>(mu, hs, a.shift, s_w, os, lane);
             else {
@@ -973,14 +974,16 @@ static int affine_dense_launch(const float* cond, int64_t ldc, int32_t d_c, int3
             int64_t grid = (n_tiles + DRW - 1) / DRW;
             if (grid > 256) grid = 256;
             const int c_s = has_shift, c_t = has_scale;
-            int pact = 0;
+            int pact = 0;                                     /* 16 AS + AT of the pipelined instances: equal activations, or the RealNVP pair ReLU / Tanh */
 #if BGK_AFF_PIPE2
-            if (has_shift && has_scale && s_act == t_act && s_act >= 1 && s_act <= 3 && !getenv("BGK_AFFINE_NO_PIPE2")) pact = s_act;
+            if (has_shift && has_scale && s_act >= 1 && s_act <= 3 && (s_act == t_act || (s_act == 2 && t_act == 3)) && !getenv("BGK_AFFINE_NO_PIPE2"))
+                pact = 16 * s_act + t_act;
 #endif
-#define BGK_LAUNCH_DMA(PA) do { auto K = coupling_affine_resident_dma_kernel<DRW, 8, PA>; \
+#define BGK_LAUNCH_DMA(SA, TA) do { auto K = coupling_affine_resident_dma_kernel<DRW, 8, SA, TA>; \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             hipLaunchKernelGGL(K, dim3((int)grid), dim3(DRW * 64), dma_shmem, st, a, os, ot, c_s * n0, c_s * n1, c_s * n2, c_t * n0, c_t * n1, c_t * n2, top); } while (0)
-            if (pact == 1) BGK_LAUNCH_DMA(1); else if (pact == 2) BGK_LAUNCH_DMA(2); else if (pact == 3) BGK_LAUNCH_DMA(3); else BGK_LAUNCH_DMA(0);
+            if (pact == 0x11) BGK_LAUNCH_DMA(1, 1); else if (pact == 0x22) BGK_LAUNCH_DMA(2, 2); else if (pact == 0x33) BGK_LAUNCH_DMA(3, 3);
+            else if (pact == 0x23) BGK_LAUNCH_DMA(2, 3); else BGK_LAUNCH_DMA(0, 0);
 #undef BGK_LAUNCH_DMA
             return bgk_launch_status("bgk_coupling_affine_dense_h2");
         }

@@ -391,3 +391,32 @@ def test_ic_backward_dma_staging_equals_the_row_loop_kernels(hip_lib, dev, B):
         for a, b in zip(res["dma"], res[mode]):
             assert bool(torch.isfinite(a).all())
             assert torch.equal(a, b), f"B = {B}: DMA-staged sweep vs {mode}: max difference {float((a - b).abs().max()):.2e}"
+
+
+@pytest.mark.parametrize("kind", ["cfg2", "silu64"])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_two_network_pipeline_equals_the_sequential_networks(hip_lib, dev, kind, inverse):
+    """cfg 2's weight-resident kernel runs the shift and the scale network as one software pipeline (a GEMM of one network carries the
+    activation + f16 split of the other, round 5); BGK_AFFINE_NO_PIPE2=1 runs them one after the other.  Same operations on the same
+    operands in the same order per accumulator: bit-identical outputs and log-dets (ReLU / Tanh pair of the RealNVP configs, SiLU / SiLU)."""
+    import os
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    acts = (torch.nn.ReLU(), torch.nn.Tanh()) if kind == "cfg2" else (torch.nn.SiLU(), torch.nn.SiLU())
+    tr = bg.AffineTransformer(bg.DenseNet([32, 64, 64, 32], acts[0]), bg.DenseNet([32, 64, 64, 32], acts[1]))
+    layer = hash_init_(bg.CouplingFlow(tr)).to(dev)
+    B = 4133
+    g = torch.Generator(device=dev).manual_seed(17)
+    x, y = torch.randn(B, 32, device=dev, generator=g), torch.randn(B, 32, device=dev, generator=g)
+    res = {}
+    try:
+        for mode in ("pipeline", "sequential"):
+            if mode == "sequential":
+                os.environ["BGK_AFFINE_NO_PIPE2"] = "1"
+            with torch.no_grad():
+                _, out, dl = layer(x, y, inverse=inverse)
+            res[mode] = (out.clone(), dl.clone())
+    finally:
+        os.environ.pop("BGK_AFFINE_NO_PIPE2", None)
+    assert bool(torch.isfinite(res["pipeline"][0]).all())
+    assert torch.equal(res["pipeline"][0], res["sequential"][0]) and torch.equal(res["pipeline"][1], res["sequential"][1])
