@@ -15,6 +15,8 @@
 
 namespace {
 
+#include "bgk_dma.h"
+
 constexpr int DW = 4;
 constexpr int DSROW = 33;
 #ifndef BGK_DBWD_DG
@@ -202,6 +204,10 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
     }
 }
 
+#ifndef BGK_DBWD_SHARED
+#define BGK_DBWD_SHARED 1      /* first GEMM's operand blocks: 1 = staged once per workgroup in LDS (DMA), 0 = every wave streams them from L2 */
+#endif
+
 template <int FT>
 __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -210,10 +216,17 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
     float* s_f = smem + (size_t)wave * a.lds_per_wave;       /* [32][H2_SLAB] output slab; later the g_feat tile [32 FT][DSROW] */
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * DW + wave;
+#if BGK_DBWD_SHARED
+    const bool active = tile < n_tiles;                      /* a wave without a tile still copies its share of the operands and meets the barriers */
+    const int64_t b0 = (active ? tile : n_tiles - 1) * 32;
+#else
     if (tile >= n_tiles) return;
     const int64_t b0 = tile * 32;
+#endif
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
-    SBD_TS(0);
+#if BGK_SBD_TS
+    const unsigned ts0 = (unsigned)__builtin_amdgcn_s_memtime();       /* (written behind the first GEMM: the slab space holds its operands until then) */
+#endif
 
     /* ---- g_h1 = W2^T g : B operand straight from the row-major gradient ---- */
     h2_f32x16 acc[4];
@@ -238,15 +251,72 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = k0 + e < P ? u0[e] : 0.0f; v[4 + e] = k0 + 4 + e < P ? u1[e] : 0.0f; }
         };
+        constexpr int DG = DBWD_DG;
+        static_assert(DG % 2 == 0, "fragment set parity follows the position in the group");
+        const int S2 = a.S2;
+        sg = h2_pow2_scale(a.g_absmax ? a.g_absmax[0] : 0.0f, inv_sg);      /* per-tensor power of two: max |g| -> [2^14, 2^15) */
+#if BGK_DBWD_SHARED
+        /* Round 5.  The operand blocks of this GEMM (W2^T as f16 hi + lo: 8 KB per k-step, 229 KB per tile at P = 425) are the same for
+         * every tile.  Streamed from L2 by every wave, one k-step ahead, each k-step exposed most of an L2 round trip (operand loads
+         * return in order behind the gradient loads): 76 k of the 147 k cycles a wave lived (s_memtime stamps, tools/r05_dx_ts.py),
+         * for 10.7 k cycles of matrix work.  Now the four waves of the workgroup copy a GROUP of DG k-steps (32 KB) into LDS together
+         * -- each wave a quarter, by DMA, one group ahead, into the half of the workgroup's slab space the previous group has left
+         * (the slabs are not needed before the chain behind this GEMM; a barrier separates the two uses) -- and read their fragments
+         * from there: a quarter of the L2 traffic, LDS latency instead of L2 latency in front of the MFMAs, and the gradient batch of
+         * the next group is requested a whole group ahead (nothing queues behind it any more). */
+        constexpr int GRP16 = DG * 4 * 2 * 64;                         /* 16-byte pieces of a group: k-steps x tiles x {hi, lo} x lanes */
+        uint4* s_op = reinterpret_cast<uint4*>(smem);                   /* two group buffers; DW * lds_per_wave >= 2 * GRP16 * 4 floats (launcher) */
+        auto dma_group = [&](int gi) {
+            const uint4* src = a.T2 + (size_t)gi * GRP16 + wave * (GRP16 / DW);
+            uint4* dst = s_op + (gi & 1) * GRP16 + wave * (GRP16 / DW);
+#pragma unroll
+            for (int i = 0; i < GRP16 / DW / 64; ++i)
+                __builtin_amdgcn_global_load_lds((gvp_t)(src + i * 64 + lane), (lvp_t)(dst + i * 64), 16, 0, 0);
+        };
+        auto lds_frag = [&](H2A<4>& f, const uint4* buf, int u) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f.v[m][0] = buf[((u * 4 + m) * 2 + 0) * 64 + lane];
+                f.v[m][1] = buf[((u * 4 + m) * 2 + 1) * 64 + lane];
+            }
+        };
+        float ring[DG][8];
+        dma_group(0);
+#pragma unroll
+        for (int u = 0; u < DG; ++u) load_g(u, ring[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int s0 = 0, gi = 0; s0 < S2; s0 += DG, ++gi) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* this wave's quarter of group gi and its gradient batch have landed */
+            __syncthreads();                                            /* ... everyone's; and everyone has left the buffer group gi + 1 goes to */
+            h2_h16x8 bhi[DG], blo[DG];
+#pragma unroll
+            for (int u = 0; u < DG; ++u) h2_split8_scaled(ring[u], sg, bhi[u], blo[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + DG < S2) {
+                dma_group(gi + 1);
+#pragma unroll
+                for (int v = 0; v < DG; ++v) load_g(s0 + DG + v, ring[v]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const uint4* buf = s_op + (gi & 1) * GRP16;
+            H2A<4> fr[2];
+            lds_frag(fr[0], buf, 0);
+#pragma unroll
+            for (int u = 0; u < DG; ++u) {
+                if (u + 1 < DG) lds_frag(fr[(u + 1) & 1], buf, u + 1);
+                __builtin_amdgcn_sched_barrier(0);                      /* the next step's LDS reads stay in front of this step's MFMAs */
+                h2_mfma3<4>(acc, fr[u & 1], bhi[u], blo[u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                                                /* the operand buffers are the waves' output slabs from here on */
+        if (!active) return;
+#else
         /* Loads return in order on this part: an operand load (L2 hit) queued behind a gradient load (HBM) waits for it, so a
          * gradient ring refilled one k-step at a time stalls EVERY step for most of an HBM round trip, whatever its depth.  Here the
          * operand fragments of step s + 1 are requested before the MFMAs of step s (two fragment sets), and the gradient values of
          * the next DG k-steps as one batch right behind the group's last operand request: the operand loads never queue behind a
          * fresh gradient request, and a group waits for its gradients once.  a.S2 is a multiple of DG (zero operand blocks). */
-        constexpr int DG = DBWD_DG;
-        static_assert(DG % 2 == 0, "fragment set parity follows the position in the group");
-        const int S2 = a.S2;
-        sg = h2_pow2_scale(a.g_absmax ? a.g_absmax[0] : 0.0f, inv_sg);      /* per-tensor power of two: max |g| -> [2^14, 2^15) */
         H2A<4> fr[2];
         h2a_load<4>(fr[0], a.T2, 0, lane);
         __builtin_amdgcn_sched_barrier(0);
@@ -272,7 +342,11 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
     }
+#if BGK_SBD_TS
+    if (lane == 0) reinterpret_cast<unsigned*>(s_f)[0 * H2_SLAB + 130] = ts0;
+#endif
     SBD_TS(14);
     dx_chain_tail<FT>(a, acc, inv_sg, s_f, b0, lane, rows);
 #if BGK_SBD_TS
@@ -418,6 +492,7 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     const int FT = (n_in + 31) / 32;
     a.lds_per_wave = 32 * H2_SLAB > 32 * FT * DSROW ? 32 * H2_SLAB : 32 * FT * DSROW;   /* output slab, reused for the g_feat tile */
     const size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;
+    static_assert(sizeof(float) * DW * 32 * H2_SLAB >= 2 * (size_t)DBWD_DG * 4 * 2 * 64 * 16, "the slab space holds two operand groups of the first GEMM");
     const int64_t n_wg = ((B + 31) / 32 + DW - 1) / DW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_dense_backward_dx: batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
