@@ -24,7 +24,7 @@ _SIGNATURES = {
                                          vp, i64, vp, i32, vp, vp, vp]),
     "bgk_rqs_backward": (ctypes.c_int, [vp, i64, vp, i64, i32, vp, i64, i32, i32, i32,
                                         f64, f64, f64, f64, f64, f64, f64, i32,
-                                        vp, i64, vp, vp, i64, vp, i64, vp, vp]),
+                                        vp, i64, vp, vp, i64, vp, i64, vp, i32, vp]),
     "bgk_affine_transform": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i64, i32,
                                             vp, i64, vp, i32, vp]),
     "bgk_affine_backward": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i64, i32,
@@ -73,7 +73,7 @@ _SIGNATURES = {
     "bgk_coupling_rqs_dense_h2_train": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, vp, i32, i32, i32,
                                                        vp, i64, i64, i32, i32, ctypes.c_uint64, i32,
                                                        f64, f64, f64, f64, f64, f64, f64, i32,
-                                                       vp, i64, vp, i32, vp, vp, vp, vp, i64, vp, vp]),
+                                                       vp, i64, vp, i32, vp, vp, vp, vp, i64, vp, i32, vp]),
     "bgk_coupling_affine_dense_h2": (ctypes.c_int, [vp, i64, i32, i32,
                                                     vp, vp, vp, f32, f32, f32, i32, vp, vp, vp, f32, f32, f32, i32,
                                                     i32, vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32, vp]),

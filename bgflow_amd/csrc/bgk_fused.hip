@@ -1220,7 +1220,8 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
               uint64_t circ_mask, int32_t inverse, double left, double right, double bottom, double top,
               double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
               float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
-              float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col, void* stream, const BgkCondSegs* segs = nullptr) {
+              float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col, void* stream, const BgkCondSegs* segs = nullptr,
+              int params_layout = 0) {
     if (segs && segs->n >= 1) { cond = segs->ptr[0]; ldc = segs->ld[0]; }
     BGK_CHECK_ARG(cond && A0p && A1p && A2p && y && out && dlogp, "%s: null pointer", what);
     BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "%s: bad sizes", what);
@@ -1242,8 +1243,9 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     /* second-generation kernels: their staging index math uses 24-bit multiplies (row strides below 2^24 floats) */
     const bool v2_ok = bgk_h2_variant == 2 && K == KB && ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24);
     if (segs && segs->n > 1 && !v2_ok) return BGK_EUNSUPPORTED;     /* several conditioning tensors: second-generation kernels only */
-    if (v2_ok && z0 != nullptr && operand_dtype == 0 && src_col && params && z1)   /* training forward */
-        return bgk_launch_rqs_dense_h2v2_train(what, z0, z1, params, ldp, src_col, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev,
+    if (params_layout == 1 && !(v2_ok && z0 != nullptr && operand_dtype == 0 && params && z1)) return BGK_EUNSUPPORTED;   /* element-major parameters: second-generation kernel only */
+    if (v2_ok && z0 != nullptr && operand_dtype == 0 && (src_col || params_layout == 1) && params && z1)   /* training forward */
+        return bgk_launch_rqs_dense_h2v2_train(what, z0, z1, params, ldp, params_layout == 1 ? nullptr : src_col, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev,
                                                act, y, ldy, B, d, circ_mask, inverse, left, right, bottom, top, min_bin_width,
                                                min_bin_height, min_derivative, identity_init, out, ldo, dlogp, accumulate, bin_idx,
                                                oob_count, stream, segs);
@@ -1360,12 +1362,13 @@ extern "C" int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, i
                                                double min_derivative, int32_t identity_init, float* out,
                                                int64_t ldo, float* dlogp, int32_t accumulate,
                                                int32_t* oob_count, float* z0, float* z1, float* params, int64_t ldp,
-                                               const int32_t* src_col_dev, void* stream) {
+                                               const int32_t* src_col_dev, int32_t params_layout, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
-    BGK_CHECK_ARG(z0 && z1 && params && src_col_dev, "bgk_coupling_rqs_dense_h2_train: null save buffer");
+    BGK_CHECK_ARG(params_layout == 0 || params_layout == 1, "bgk_coupling_rqs_dense_h2_train: params_layout %d (0 = the reference's columns, 1 = element-major)", params_layout);
+    BGK_CHECK_ARG(z0 && z1 && params && (src_col_dev || params_layout == 1), "bgk_coupling_rqs_dense_h2_train: null save buffer");
     const int n_nc = d - __builtin_popcountll(circ_mask & (d >= 64 ? ~0ull : ((1ull << d) - 1)));
-    BGK_CHECK_ARG(ldp >= 3 * K * d + n_nc, "bgk_coupling_rqs_dense_h2_train: params row stride %lld too small", (long long)ldp);
+    BGK_CHECK_ARG(ldp >= (params_layout == 1 ? (3 * K + 1) * d + 3 : 3 * K * d + n_nc), "bgk_coupling_rqs_dense_h2_train: params row stride %lld too small", (long long)ldp);
     return launch_h2("bgk_coupling_rqs_dense_h2_train", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, 0, H0, H1, act, y, ldy, B, d,
                      K, circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
-                     identity_init, out, ldo, dlogp, accumulate, nullptr, oob_count, z0, z1, params, ldp, src_col_dev, stream);
+                     identity_init, out, ldo, dlogp, accumulate, nullptr, oob_count, z0, z1, params, ldp, src_col_dev, stream, nullptr, params_layout);
 }

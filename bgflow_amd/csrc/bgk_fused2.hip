@@ -137,8 +137,8 @@ struct V2Args {
     int nfs, ys, stage, y_dma, out_lin;
 #if BGK_V2_SAVE
     float* z0; float* z1;             /* scaled pre-activations [B, 128] */
-    float* params; int64_t ldp;       /* spline parameters [B, P] in the reference's column order */
-    const int32_t* src_col;           /* packed column -> parameter column (-1: padding) */
+    float* params; int64_t ldp;       /* spline parameters [B, P] in the reference's column order, or (src_col == NULL) element-major [B][d][3 K + 1] */
+    const int32_t* src_col;           /* packed column -> parameter column (-1: padding); NULL: element-major layout */
 #endif
 };
 /* the kernel argument block in the constant address space: the spline constants are (re)read with scalar loads where they are
@@ -760,6 +760,25 @@ __device__ __forceinline__ void save_chunk_params(const V2Args& a, const float* 
 #ifdef BGK_V2_ABL_NOPSAVE      /* timing experiment: the parameters are not written (wrong gradients) */
     return;
 #endif
+    if (a.src_col == nullptr) {
+        /* element-major layout [B][d][3 K + 1] (round 5): the chunk's rows ARE that order, so a sample's share of the chunk is one
+         * contiguous run of DPC * PPD = 125 floats -- 32 lanes x 16 bytes, two sample rows per store instruction, 16 instructions
+         * per chunk instead of 64 (the last lane of a row carries the first 3 floats of the next chunk's run, which that chunk
+         * overwrites; the row pitch leaves room behind the last one).  0.29 -> 0.25 ms per layer at 2^18 samples. */
+        typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
+        const int l = lane & 31, half = lane >> 5;
+        const int nd = (a.d - c * DPC) < DPC ? (a.d - c * DPC) : DPC;
+        const bool mine = 4 * l < nd * PPD;
+        for (int jj = 0; jj < rows; jj += 2) {
+            const int r = jj + half;
+            if (r < rows && mine) {
+                float* prow = a.params + (b0 + r) * a.ldp + (DPC * PPD) * c;
+                const f4s v = {s_p[(4 * l) * ST + r] * a.c2, s_p[(4 * l + 1) * ST + r] * a.c2, s_p[(4 * l + 2) * ST + r] * a.c2, s_p[(4 * l + 3) * ST + r] * a.c2};
+                *reinterpret_cast<f4s*>(prow + 4 * l) = v;
+            }
+        }
+        return;
+    }
     const int col_lo = a.src_col[c * 128 + lane], col_hi = a.src_col[c * 128 + 64 + lane];
     for (int jj = 0; jj < rows; ++jj) {
         float* prow = a.params + (b0 + jj) * a.ldp;

@@ -44,7 +44,9 @@ __device__ __forceinline__ void publish_absmax(float* dst, float m) {
     if ((threadIdx.x & 63) == 0 && mb > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), mb);
 }
 
-template <int KT>
+/* PACKED: the parameters arrive element-major, [B][d][3 K + 1] (what the fused training forward writes since round 5: an element's
+ * widths | heights | slopes | slot in one 100-byte run); the gradients leave in the reference's column order either way */
+template <int KT, bool PACKED = false>
 __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
     constexpr int K = KT;
     static_assert(KT % 4 == 0, "KT / 4 16-byte loads per parameter group");
@@ -60,9 +62,9 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
             const int s = (int)(((uint64_t)(uint32_t)e * magicd) >> 32), j = e - s * d;
             const float* row = a.params + (b0 + s) * a.ldp;
             float* grow = a.g_params + (b0 + s) * a.ldgp;
-            const float* gw = row + j * K;
-            const float* gh = gw + d * K;
-            const float* gs = gh + d * K;
+            const float* gw = PACKED ? row + j * (3 * K + 1) : row + j * K;
+            const float* gh = PACKED ? gw + K : gw + d * K;
+            const float* gs = PACKED ? gh + K : gh + d * K;
             float rw[K], rh[K], rs[K], ow[K], oh[K], os[K];
 #pragma unroll
             for (int q = 0; q < K / 4; ++q) {
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
                 for (int k = 0; k < 4; ++k) { rw[4 * q + k] = w4[k]; rh[4 * q + k] = h4[k]; rs[4 * q + k] = t4[k]; }
             }
             const int slot = a.nc_slot[j];
-            const float s_K = slot >= 0 ? row[3 * d * K + slot] : rs[0];   /* slope at knot K */
+            const float s_K = slot >= 0 ? (PACKED ? gw[3 * K] : row[3 * d * K + slot]) : rs[0];   /* slope at knot K */
             const float x = a.y[(b0 + s) * a.ldy + j];
             const float gy = a.g_out[(b0 + s) * a.ldgo + j], gl = a.g_dlogp[b0 + s];
             float g_slot, gx;
@@ -166,11 +168,12 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
                                 double min_bin_width, double min_bin_height, double min_derivative,
                                 int32_t identity_init, const float* g_out, int64_t ldgo,
                                 const float* g_dlogp, float* g_y, int64_t ldgy, float* g_params,
-                                int64_t ldgp, float* g_absmax, void* stream) {
+                                int64_t ldgp, float* g_absmax, int32_t params_layout, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && d > 0 && K > 0, "bgk_rqs_backward: bad sizes");
     BGK_CHECK_ARG(y && params && nc_slot && g_out && g_dlogp && g_y && g_params, "bgk_rqs_backward: null pointer");
-    BGK_CHECK_ARG(P >= 3 * K * d && P <= 3 * K * d + d && ldp >= P && ldgp >= P, "bgk_rqs_backward: bad params width %d", P);
+    BGK_CHECK_ARG(params_layout == 0 || (params_layout == 1 && K == 8), "bgk_rqs_backward: params_layout %d (1 = element-major: 8 bins only)", params_layout);
+    BGK_CHECK_ARG(P >= 3 * K * d && P <= 3 * K * d + d && ldp >= (params_layout == 1 ? (3 * K + 1) * d : P) && ldgp >= P, "bgk_rqs_backward: bad params width %d", P);
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0, "Minimal bin width/height too large for the number of bins");
     RqsBwdArgs a;
     a.y = y; a.ldy = ldy; a.params = params; a.ldp = ldp; a.nc_slot = nc_slot; a.B = B; a.d = d; a.K = K; a.P = P;
@@ -184,7 +187,9 @@ extern "C" int bgk_rqs_backward(const float* y, int64_t ldy, const float* params
     hipStream_t st = (hipStream_t)stream;
     switch (K) {
         case 4: hipLaunchKernelGGL(rqs_bwd_kernel<4>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
-        case 8: hipLaunchKernelGGL(rqs_bwd_kernel<8>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
+        case 8: if (params_layout == 1) hipLaunchKernelGGL((rqs_bwd_kernel<8, true>), dim3(grid), dim3(BWD_THREADS), shmem, st, a);
+                else hipLaunchKernelGGL(rqs_bwd_kernel<8>, dim3(grid), dim3(BWD_THREADS), shmem, st, a);
+                break;
         case 12: hipLaunchKernelGGL(rqs_bwd_kernel<12>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
         case 16: hipLaunchKernelGGL(rqs_bwd_kernel<16>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;
         case 32: hipLaunchKernelGGL(rqs_bwd_kernel<32>, dim3(grid), dim3(BWD_THREADS), shmem, st, a); break;

@@ -800,6 +800,7 @@ def _featurise(x, periodic):
 
 
 HALF_PAD_ROWS = int(os.environ.get("BGK_HALF_PAD_ROWS", "0"))      # rows of padding between the [B, 128] halves of one allocation
+PACKED_PARAMS = os.environ.get("BGK_PACKED_PARAMS", "1") != "0"   # the fused training forward saves the spline parameters element-major
 
 FUSED_MLP_BACKWARD = True    # input-gradient chain of the conditioner on bgk_dense_backward_dx (False: three GEMMs + torch act ops)
 
@@ -974,23 +975,34 @@ def _train_forward_launch(x, y, W2, plan, tcfg, inverse, oob, dlogp=None, accumu
         dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=dev), False
     zz = torch.empty((2, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)      # (see _dense_backward_dx on the padding)
     z0, z1 = zz[0, :B], zz[1, :B]
-    ldp = param_pitch(P)
-    params = torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :P]
     left, right, bottom, top, s = tcfg
-    with torch.cuda.device(dev):
-        st = _lib.lib().bgk_coupling_rqs_dense_h2_train(
-            _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2,
-            _lib.ptr(plan.get("cs")), 128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
-            left, right, bottom, top, s["min_bin_width"], s["min_bin_height"], s["min_derivative"],
-            int(s.get("enable_identity_init", False)), _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)), _lib.ptr(oob),
-            _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), ldp, _lib.ptr(plan["src_col_dev"]), _lib.stream_ptr(dev))
+
+    def launch(layout):
+        # layout 1: the parameters element-major [B, d (3 K + 1)] -- the kernel's own order, written as 16-byte pieces of contiguous
+        # runs (PACKED_PARAMS; bgk_rqs_backward reads that layout); layout 0: the reference's column order [B, P]
+        width = d * (3 * plan["n_bins"] + 1) if layout else P
+        ldp = param_pitch(width + 3) if layout else param_pitch(P)
+        params = torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :width]
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_coupling_rqs_dense_h2_train(
+                _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2,
+                _lib.ptr(plan.get("cs")), 128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
+                left, right, bottom, top, s["min_bin_width"], s["min_bin_height"], s["min_derivative"],
+                int(s.get("enable_identity_init", False)), _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)), _lib.ptr(oob),
+                _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), ldp, _lib.ptr(plan["src_col_dev"]), layout, _lib.stream_ptr(dev))
+        return st, params
+
+    st, params = launch(1) if (PACKED_PARAMS and plan["n_bins"] == 8) else (-2, None)
+    plan["params_packed"] = st == 0   # (the layout of the tensor just written: _LayerCtx hands it to the backward)
+    if st == -2:                      # (BGK_EUNSUPPORTED: the first-generation kernel runs this layer)
+        st, params = launch(0)
     _lib.check(st, "bgk_coupling_rqs_dense_h2_train")
     return out, dlogp, z0, z1, params
 
 
 class _LayerCtx:
     """what the backward of one fused training layer needs besides its saved tensors"""
-    __slots__ = ("params", "cs", "tbufs", "t_version", "act", "periodic", "rcfg")
+    __slots__ = ("params", "cs", "tbufs", "t_version", "act", "periodic", "rcfg", "packed")
 
     def __init__(self, params, plan, tcfg, inverse, t_version):
         left, right, bottom, top, s = tcfg
@@ -1003,6 +1015,7 @@ class _LayerCtx:
         self.t_version = t_version
         self.act, self.periodic = plan["act"], bool(plan["periodic"])
         self.rcfg = (plan["n_bins"], inverse, left, right, bottom, top, dict(s))
+        self.packed = bool(plan.get("params_packed"))        # layout of the parameters the forward launch (just before this) saved
 
 
 def _train_backward_layer(lc, x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g_dlogp, need_gx, need_w, gx_add=None, gx_out=None,
@@ -1022,7 +1035,7 @@ def _train_backward_layer(lc, x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g
     # backward GEMMs split these gradients into f16 hi + lo operand pairs (f32-class products whatever the loss scale)
     if absmax is None:
         absmax = torch.zeros(3, dtype=torch.float32, device=y.device)
-    g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp, absmax=absmax)
+    g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp, absmax=absmax, packed_width=W2.shape[0] if lc.packed else None)
     if fused_dx:
         # with the fused weight-gradient kernel downstream the activations h1 / h0 are not materialised: it re-applies the
         # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)

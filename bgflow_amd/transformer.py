@@ -233,14 +233,17 @@ class _RQSFn(torch.autograd.Function):
         return (g_y, g_p) + (None,) * 9
 
 
-def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp, absmax=None):
+def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp, absmax=None, packed_width=None):
     """Launch bgk_rqs_backward: VJP of rqs_transform w.r.t. (y, params); cfg = (n_bins, inverse, left, right, bottom,
     top, settings).  Any bin count: 4 / 8 / 12 / 16 / 32 bins on the register-resident streaming kernel, every other count on the
-    kernel's direct variant (the parameters stay in memory and are walked) -- no device torch ops in the backward either."""
+    kernel's direct variant (the parameters stay in memory and are walked) -- no device torch ops in the backward either.
+    ``packed_width`` = P: ``params`` is the element-major tensor [B, d (3 K + 1)] the fused training forward saved (its
+    ``params_layout = 1``), P the width of the conditioner's output; the gradient comes back as [B, P] in the reference's order."""
     n_bins, inverse, left, right, bottom, top, settings = cfg
-    d, P = y.shape[-1], params.shape[-1]
+    d = y.shape[-1]
+    P = params.shape[-1] if packed_width is None else int(packed_width)
     y2, ldy = _lib.rowmajor(y.reshape(-1, d))
-    p2, ldp = _lib.rowmajor(params.reshape(-1, P))
+    p2, ldp = _lib.rowmajor(params.reshape(-1, params.shape[-1]))
     B = y2.shape[0]
     g_out2 = g_out.reshape(-1, d).contiguous()
     g_dl = g_dlogp.reshape(-1).contiguous()
@@ -255,9 +258,9 @@ def rqs_backward(y, params, nc_slot, cfg, g_out, g_dlogp, absmax=None):
             left, right, bottom, top, settings["min_bin_width"], settings["min_bin_height"],
             settings["min_derivative"], int(settings.get("enable_identity_init", False)),
             _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), ldgp, _lib.ptr(absmax),
-            _lib.stream_ptr(y.device))
+            0 if packed_width is None else 1, _lib.stream_ptr(y.device))
     _lib.check(st, "bgk_rqs_backward")
-    return g_y.reshape(y.shape), g_p.reshape(params.shape)
+    return g_y.reshape(y.shape), (g_p.reshape(params.shape) if packed_width is None else g_p)
 
 
 class ConditionalSplineTransformer(Transformer):

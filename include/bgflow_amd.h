@@ -89,7 +89,10 @@ int bgk_rqs_backward(const float* y, int64_t ldy, const float* params, int64_t l
                      double min_bin_width, double min_bin_height, double min_derivative,
                      int32_t identity_init,
                      const float* g_out, int64_t ldgo, const float* g_dlogp,
-                     float* g_y, int64_t ldgy, float* g_params, int64_t ldgp, float* g_absmax, void* stream);
+                     float* g_y, int64_t ldgy, float* g_params, int64_t ldgp, float* g_absmax, int32_t params_layout, void* stream);
+/* params_layout: 0 = `params` in the reference's column order [w | h | s | s_nc] (ldp >= P); 1 = element-major [B][d][3 K + 1]
+ * (an element's widths | heights | slopes | slot in one run; ldp >= (3 K + 1) d; 8 bins only) -- what
+ * bgk_coupling_rqs_dense_h2_train writes with its params_layout = 1.  g_params is in the reference's order either way. */
 
 /* ---------------------------------------------------------------------------------------------
  * Affine (RealNVP / NICE) transformer, conditioner outputs given.
@@ -328,7 +331,11 @@ int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32
 /* Training forward of the same layer: additionally writes what the backward pass needs -- the hidden layers'
  * pre-activations z0, z1 [B, 128] and the spline parameters [B, P] in the reference layout [w | h | s | s_nc]
  * (transformer/spline.py:113-126) -- so that autograd (KLTrainer.train, nn/training/trainers.py:158-170) can run
- * bgk_rqs_backward and the MLP backward on them.  src_col_dev: device copy of bgk_pack_rqs_columns' table. */
+ * bgk_rqs_backward and the MLP backward on them.  src_col_dev: device copy of bgk_pack_rqs_columns' table.
+ * params_layout = 1 (round 5): the parameters are written element-major, [B][d][3 K + 1] with ldp >= (3 K + 1) d + 3 -- the order
+ * the kernel holds them in, so they leave as 16-byte pieces of contiguous runs (16 store instructions per 32 x 125 chunk instead of
+ * 64; src_col_dev may be NULL); BGK_EUNSUPPORTED where the second-generation kernel does not run (K != 8, option 1 = 1): call again
+ * with params_layout = 0.  bgk_rqs_backward takes the same flag. */
 int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                     const void* A0p, const void* A1p, const void* A2p,
                                     float c0, float c1, float c2, const float* cs_dev,
@@ -340,7 +347,7 @@ int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, int32_t d_c,
                                     int32_t identity_init,
                                     float* out, int64_t ldo, float* dlogp, int32_t accumulate,
                                     int32_t* oob_count, float* z0, float* z1, float* params, int64_t ldp,
-                                    const int32_t* src_col_dev, void* stream);
+                                    const int32_t* src_col_dev, int32_t params_layout, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused affine coupling layer: replaces CouplingFlow._forward/_inverse (nn/flow/coupling.py:162-182) around

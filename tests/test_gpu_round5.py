@@ -420,3 +420,32 @@ def test_affine_two_network_pipeline_equals_the_sequential_networks(hip_lib, dev
         os.environ.pop("BGK_AFFINE_NO_PIPE2", None)
     assert bool(torch.isfinite(res["pipeline"][0]).all())
     assert torch.equal(res["pipeline"][0], res["sequential"][0]) and torch.equal(res["pipeline"][1], res["sequential"][1])
+
+
+@pytest.mark.parametrize("what,on", [("TORSIONS", "FIXED"), ("FIXED", "TORSIONS"), ("BONDS", "ANGLES")])
+@pytest.mark.parametrize("B", [77, 4133])
+def test_element_major_saved_parameters_equal_the_reference_layout(hip_lib, dev, what, on, B):
+    """the fused training forward saves the spline parameters element-major, [B][d][3 K + 1] -- the order the kernel holds them in, 16
+    store instructions per chunk instead of 64 (round 5) -- and bgk_rqs_backward reads that layout; dense.PACKED_PARAMS = False keeps
+    the reference's column order [w | h | s | s_nc].  Same values either way: bit-identical outputs and gradients -- circular dims
+    (no slot), a last chunk of 2 / 4 dims, partial tiles."""
+    from bgflow_amd import dense
+    layer = _spline_layer(dev, what=what, on=on)
+    res = {}
+    prev = dense.PACKED_PARAMS
+    try:
+        for packed in (True, False):
+            dense.PACKED_PARAMS = packed
+            for p in layer.parameters():
+                p.grad = None
+            xs = _fields(dev, B)
+            *out, dl = layer(*xs)
+            assert layer.transformer._fused_cache.get("params_packed") is packed, "the fused training forward must have run in the requested layout"
+            w = torch.linspace(0.5, 1.5, B, device=dev)[:, None]
+            (sum((o * o * w).sum() for o in out) - (dl * w).sum()).backward()
+            res[packed] = ([o.detach().clone() for o in out], dl.detach().clone(), [p.grad.clone() for p in layer.parameters()],
+                           [x.grad.clone() for x in xs if x.grad is not None])
+    finally:
+        dense.PACKED_PARAMS = prev
+    for a, b in zip(res[True][0] + [res[True][1]] + res[True][2] + res[True][3], res[False][0] + [res[False][1]] + res[False][2] + res[False][3]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)

@@ -471,9 +471,9 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
     assert "Scaling is not compatible with periodicity." in err()             # transformer/affine.py:26-27
     # valid requests outside a fused kernel's envelope -> BGK_EUNSUPPORTED (callers fall back to the generic kernels)
     # (bgk_rqs_backward takes any bin count since round 5: its argument checks only)
-    assert L.bgk_rqs_backward(P1, 17, P1, 263, 300, P1, 8, 17, 5, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 263, None, None) == -1
+    assert L.bgk_rqs_backward(P1, 17, P1, 263, 300, P1, 8, 17, 5, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 263, None, 0, None) == -1
     assert "bad params width" in err()
-    assert L.bgk_rqs_backward(P1, 17, P1, 263, 263, P1, 8, 17, 5, 0, 0.0, 1.0, 0.0, 1.0, 0.3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 263, None, None) == -1
+    assert L.bgk_rqs_backward(P1, 17, P1, 263, 263, P1, 8, 17, 5, 0, 0.0, 1.0, 0.0, 1.0, 0.3, 1e-3, 1e-3, 1, P1, 17, P1, P1, 17, P1, 263, None, 0, None) == -1
     assert "too large for the number of bins" in err()
     tail = (P1, 17, 8, 17, 8, 0, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None)
     assert L.bgk_coupling_rqs_dense_h2(P1, 17, 17, 0, P1, P1, P1, 1.0, 1.0, 1.0, None, 0, 64, 64, 1, *tail) == -2
