@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_fix_kernel(IcBwdArgs a) {
             const V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
             const float dd = rb[zr], an = ra[zr], t = rt[zr];
             const V3 g = ld3(gp + 3 * at);
-            const PlaceAdj q = placement_adjoint<true, 4>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
+            const PlaceAdj q = placement_adjoint<true, 6>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
             gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
             gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
             gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
