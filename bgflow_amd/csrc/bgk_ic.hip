@@ -866,9 +866,10 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
         __builtin_amdgcn_wave_barrier();
         ICB_TS(1);
         float px[NA], py[NA], pz[NA];
+        /* all NA slots unconditionally (slots beyond the molecule read the next row's first floats: in the region, never used): one
+         * run of independent LDS reads instead of a branch and a wait per atom */
 #pragma unroll
-        for (int k = 0; k < NA; ++k)
-            if (k < n_atoms) { px[k] = s_r[lane * na3 + 3 * k]; py[k] = s_r[lane * na3 + 3 * k + 1]; pz[k] = s_r[lane * na3 + 3 * k + 2]; }
+        for (int k = 0; k < NA; ++k) { px[k] = s_r[lane * na3 + 3 * k]; py[k] = s_r[lane * na3 + 3 * k + 1]; pz[k] = s_r[lane * na3 + 3 * k + 2]; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         float* s_b = s_r;
@@ -903,12 +904,15 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
             const int at_n = place[5 * in], i1_n = place[5 * in + 1], i2_n = place[5 * in + 2], i3_n = place[5 * in + 3], zr_n = place[5 * in + 4];
             const float dd_n = s_b[lane * n + zr_n], an_n = s_a[lane * n + zr_n], t_n = s_t[lane * n + zr_n];   /* (a different row than zr unless i == 0) */
             const V3 p1 = {px[i1], py[i1], pz[i1]}, p2 = {px[i2], py[i2], pz[i2]}, p3 = {px[i3], py[i3], pz[i3]};
-            const V3 g = ld3(gp + 3 * at);
+            /* the adjoints of the placed atom and of its three reference atoms in ONE round of LDS reads (four distinct atoms): written
+             * as nine read-modify-writes the compiler has to keep them in order -- they might alias -- and the sweep paid nine LDS
+             * round trips per placement, half of its time */
+            const V3 g = ld3(gp + 3 * at), a1 = ld3(gp + 3 * i1), a2 = ld3(gp + 3 * i2), a3 = ld3(gp + 3 * i3);
             PlaceAdj q = placement_adjoint<false>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
             if (!live) { q.g1 = q.g2 = q.g3 = V3{0.0f, 0.0f, 0.0f}; q.gd = q.ga = q.gt = 0.0f; }
-            gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
-            gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
-            gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
+            gp[3 * i1] = a1.x + q.g1.x; gp[3 * i1 + 1] = a1.y + q.g1.y; gp[3 * i1 + 2] = a1.z + q.g1.z;
+            gp[3 * i2] = a2.x + q.g2.x; gp[3 * i2 + 1] = a2.y + q.g2.y; gp[3 * i2 + 2] = a2.z + q.g2.z;
+            gp[3 * i3] = a3.x + q.g3.x; gp[3 * i3 + 1] = a3.y + q.g3.y; gp[3 * i3 + 2] = a3.z + q.g3.z;
             s_b[lane * n + zr] = q.gd; s_a[lane * n + zr] = q.ga; s_t[lane * n + zr] = q.gt;
             at = at_n; i1 = i1_n; i2 = i2_n; i3 = i3_n; zr = zr_n; dd = dd_n; an = an_n; t = t_n;
         }
