@@ -42,6 +42,8 @@ _SIGNATURES = {
                                            vp, i64, vp, i32, vp, vp]),
     "bgk_icdf_ic2xyz_uni_train": (ctypes.c_int, [vp, vp, vp, vp, vp, i32, f32, vp, i32, vp, i32, f32, i32, vp, vp, i32, f64, i64,
                                                  vp, i64, vp, i32, vp, vp, vp, vp, vp, vp]),
+    "bgk_icdf_ic2xyz_uni_train_kl": (ctypes.c_int, [vp, vp, vp, vp, vp, i32, f32, vp, i32, vp, i32, f32, i32, vp, vp, i32, f64, i64,
+                                                    vp, i64, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, i32, vp, vp, vp, vp, vp]),
     "bgk_xyz2ic_cdf_uni": (ctypes.c_int, [vp, vp, i32, f32, vp, i32, vp, i32, f32, i32, vp, vp, i32, f64, i64,
                                           vp, vp, vp, vp, vp, i32, vp, vp]),
     "bgk_ic_ic2xyz_backward": (ctypes.c_int, [vp, vp, vp, i64, vp, i64, vp, i32, vp, i32, i32, f32, i32, vp, i32, i64,

@@ -110,6 +110,11 @@ class BoltzmannGenerator(Energy, Sampler):
         ready 2-vector).  Not in the reference API: ``kldiv(n).mean()`` is the same number."""
         from . import dp
         z = pack_tensor_in_tuple(self._prior.sample(n_samples, temperature=temperature))
+        fused = getattr(self._flow, "kl_sums", None)
+        if fused is not None:          # the target energy inside the generation tail's launch where the flow / target allow it
+            sums = fused(z, self._target, temperature=temperature, drop_nonfinite=drop_nonfinite)
+            if sums is not None:
+                return dp.global_mean_from_sums(sums)
         *x, dlogp = self._flow(*z, temperature=temperature)
         return dp.global_kl_mean(self._target, x, dlogp, temperature=temperature, drop_nonfinite=drop_nonfinite)
 

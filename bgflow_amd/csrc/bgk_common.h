@@ -232,4 +232,7 @@ __device__ __forceinline__ float bgk_rqs_element(float x, const float* pw, const
     return outv;
 }
 
+/* bgk_energy.hip: [sum, count] float partials -> f64 [2] in a fixed order (one small launch) */
+int bgk_loss_partial_reduce(const float* partial, int n_partials, double* loss_sums, void* stream);
+
 #endif /* BGK_COMMON_H */

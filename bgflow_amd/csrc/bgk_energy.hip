@@ -204,6 +204,12 @@ extern "C" int bgk_energy_fields(const float* const* x, const int64_t* ldx, cons
     return bgk_launch_status("bgk_energy_fields");
 }
 
+/* [sum, count] partials -> loss_sums [2] (f64, fixed order): shared with the KL epilogue of the training tail (bgk_tail.hip) */
+int bgk_loss_partial_reduce(const float* partial, int n_partials, double* loss_sums, void* stream) {
+    hipLaunchKernelGGL(energy_partial_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, n_partials, loss_sums);
+    return bgk_launch_status("bgk_loss_partial_reduce");
+}
+
 extern "C" int bgk_energy_fields_backward(const float* const* x, const int64_t* ldx, const int32_t* d, const int32_t* kind,
                                           const float* const* param, const float* coef, int32_t n_fields, int64_t B,
                                           double temperature, const float* g_u,

@@ -87,6 +87,12 @@ struct TailArgs {
     int64_t B; float* x; int64_t ldx; float* dlogp; int accumulate; int32_t* warn_count;
     int lds_per_wave;
     float* o_bonds; float* o_angles; float* o_torsions; float* o_fixed;      /* outputs of the inverse-direction kernel */
+    /* KL epilogue of the training tail (icdf_ic2xyz_uni_kernel<NA, true, true>): target energy of a normal target about kl_mean and the
+     * [sum (u - dlogp), kept] partial sums of the KL loss, per 64-sample tile */
+    const float* kl_mean;                /* [3 (n + n_fixed)] or NULL (0) */
+    const float* kl_dl_in;               /* [B] log-det of the flow in front of the tail (read only), or NULL */
+    float kl_inv_t, kl_c_in, kl_c_out; int kl_drop;
+    float* kl_u; float* kl_dl; float* kl_partial;      /* [B] target energy, [B] total log-det, [tiles][2] */
 };
 
 
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_reg_kernel(TailArgs a) {
  *   5. the finished rows go to LDS ([64][3 n_atoms], the tile's memory image) and leave as 16-byte coalesced stores. */
 #include "bgk_dma.h"
 
-template <int NA, bool EMIT = false>
+template <int NA, bool EMIT = false, bool KL = false>
 __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -539,9 +545,32 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
         r = rn; dsa = dsa_n; dca = dca_n; tn = tn_n;
     }
 
-    if (lane < rows) {
+    if (!KL && lane < rows) {
         const int64_t b = b0 + lane;
         if (a.accumulate) a.dlogp[b] += acc; else a.dlogp[b] = acc;
+    }
+    if constexpr (KL) {
+        /* the KL integrand of the lane's sample while its coordinates are in registers (BoltzmannGenerator.kldiv, bg.py:140-147, for a
+         * normal target: u = (|x - mean|^2 / 2 + c_in) / T + c_out, distribution/normal.py:61-72) and the tile's share of
+         * [sum (u - dlogp), samples kept]: no second pass over x, no per-sample loss tensor.  Lane sums in a fixed shuffle tree. */
+        const cf32_t km = (cf32_t)a.kl_mean;
+        float e = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            if (k < n_atoms) {
+                const float dx = px[k] - (km ? km[3 * k] : 0.0f), dy = py[k] - (km ? km[3 * k + 1] : 0.0f), dz = pz[k] - (km ? km[3 * k + 2] : 0.0f);
+                e += dx * dx; e += dy * dy; e += dz * dz;
+            }
+        const float u = (0.5f * e + a.kl_c_in) * a.kl_inv_t + a.kl_c_out;
+        const bool valid = lane < rows;
+        const float dl_tot = acc + ((valid && a.kl_dl_in) ? a.kl_dl_in[b0 + lane] : 0.0f);
+        const float loss = u - dl_tot;
+        const bool ok = valid && (!a.kl_drop || __builtin_isfinite(loss));
+        if (valid) { a.kl_u[b0 + lane] = u; a.kl_dl[b0 + lane] = dl_tot; }
+        float s_l = ok ? loss : 0.0f, s_c = ok ? 1.0f : 0.0f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s_l += __shfl_xor(s_l, off); s_c += __shfl_xor(s_c, off); }
+        if (lane == 0) { a.kl_partial[2 * tile] = s_l; a.kl_partial[2 * tile + 1] = s_c; }
     }
     /* ---- rows -> LDS ([64][3 n_atoms] = the tile's memory image) -> 16-byte coalesced stores ---- */
     __builtin_amdgcn_wave_barrier();
@@ -829,10 +858,11 @@ static int icdf_ic2xyz_uni_launch(const float* bonds, const float* angles, const
                                   float eps, int32_t enforce_boundaries,
                                   const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
                                   float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count,
-                                  float* y_bonds, float* y_angles, float* y_torsions, float* y_fixed, void* stream) {
+                                  float* y_bonds, float* y_angles, float* y_torsions, float* y_fixed, void* stream,
+                                  const TailArgs* kl = nullptr) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(B >= 0 && n > 0 && n_fixed > 0, "bgk_icdf_ic2xyz_uni: bad sizes");
-    BGK_CHECK_ARG(x && place8 && fixed && bonds && angles && torsions && xfix && dlogp && desc4, "bgk_icdf_ic2xyz_uni: null pointer");
+    BGK_CHECK_ARG(x && place8 && fixed && bonds && angles && torsions && xfix && (dlogp || kl) && desc4, "bgk_icdf_ic2xyz_uni: null pointer");
     BGK_CHECK_ARG(Tblacken ? (wh_mean != nullptr && keep > 0) : (keep == 3 * n_fixed), "bgk_icdf_ic2xyz_uni: bad whitening arguments");
     const int n_atoms = n + n_fixed;
     if (n_atoms > 32 || keep > KMAX || n > 29 || ldx != 3 * n_atoms) return BGK_EUNSUPPORTED;
@@ -846,6 +876,10 @@ static int icdf_ic2xyz_uni_launch(const float* bonds, const float* angles, const
     a.eps = eps; a.const_ld = (float)const_ld;
     a.B = B; a.x = x; a.ldx = ldx; a.dlogp = dlogp; a.accumulate = accumulate; a.warn_count = warn_count;
     a.o_bonds = y_bonds; a.o_angles = y_angles; a.o_torsions = y_torsions; a.o_fixed = y_fixed;
+    if (kl) {
+        a.kl_mean = kl->kl_mean; a.kl_dl_in = kl->kl_dl_in; a.kl_inv_t = kl->kl_inv_t; a.kl_c_in = kl->kl_c_in; a.kl_c_out = kl->kl_c_out;
+        a.kl_drop = kl->kl_drop; a.kl_u = kl->kl_u; a.kl_dl = kl->kl_dl; a.kl_partial = kl->kl_partial;
+    }
     const int W = n > keep ? n : keep;
     a.lds_per_wave = 64 * (4 * W > 3 * n_atoms ? 4 * W : 3 * n_atoms);
     const size_t shmem = sizeof(float) * (size_t)TW * a.lds_per_wave;
@@ -855,7 +889,13 @@ static int icdf_ic2xyz_uni_launch(const float* bonds, const float* angles, const
     hipStream_t st = (hipStream_t)stream;
 #define BGK_LAUNCH(NA_, EM_) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(icdf_ic2xyz_uni_kernel<NA_, EM_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                                   hipLaunchKernelGGL((icdf_ic2xyz_uni_kernel<NA_, EM_>), dim3((unsigned)n_wg), dim3(TW * 64), shmem, st, a); } while (0)
-    if (y_bonds) { if (n_atoms <= 24) BGK_LAUNCH(24, true); else BGK_LAUNCH(32, true); }
+    if (kl) {
+#define BGK_LAUNCH_KL(NA_) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(icdf_ic2xyz_uni_kernel<NA_, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                                hipLaunchKernelGGL((icdf_ic2xyz_uni_kernel<NA_, true, true>), dim3((unsigned)n_wg), dim3(TW * 64), shmem, st, a); } while (0)
+        if (n_atoms <= 24) BGK_LAUNCH_KL(24); else BGK_LAUNCH_KL(32);
+#undef BGK_LAUNCH_KL
+    }
+    else if (y_bonds) { if (n_atoms <= 24) BGK_LAUNCH(24, true); else BGK_LAUNCH(32, true); }
     else { if (n_atoms <= 24) BGK_LAUNCH(24, false); else BGK_LAUNCH(32, false); }
 #undef BGK_LAUNCH
     return bgk_launch_status("bgk_icdf_ic2xyz_uni");
@@ -886,6 +926,35 @@ extern "C" int bgk_icdf_ic2xyz_uni_train(const float* bonds, const float* angles
     return icdf_ic2xyz_uni_launch(bonds, angles, torsions, xfix, desc4, use_eps, cdf_eps, place8, n, fixed, n_fixed, eps, enforce_boundaries,
                                   wh_mean, Tblacken, keep, const_ld, B, x, ldx, dlogp, accumulate, warn_count, y_bonds, y_angles, y_torsions,
                                   y_fixed, stream);
+}
+
+/* ... and with the KL integrand formed in the same launch (BoltzmannGenerator.kldiv, bg.py:140-147, for a target that is a normal
+ * distribution about t_mean -- distribution/normal.py:61-72: u = (|x - t_mean|^2 / 2 + c_in) / temperature + c_out): every lane has its
+ * sample's coordinates in registers when the placements are done, so the target energy costs no second pass over x and the loss no
+ * per-sample tensor.  dlogp_in [B] (may be NULL): log-det of the flow in front of the tail, read only.  Written: x, the four mapped
+ * fields (as bgk_icdf_ic2xyz_uni_train), u [B], dlogp_total [B] = dlogp_in + the tail's log-det, partial [ceil(B / 64)][2] (per tile:
+ * sum of u - dlogp_total over the samples kept, their number; drop_nonfinite: samples with a non-finite integrand are not kept) and
+ * loss_sums [2] (f64: the partials added in a fixed order by a second small launch). */
+extern "C" int bgk_icdf_ic2xyz_uni_train_kl(const float* bonds, const float* angles, const float* torsions, const float* xfix,
+                                            const float* desc4, int32_t use_eps, float cdf_eps,
+                                            const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                                            float eps, int32_t enforce_boundaries,
+                                            const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
+                                            float* x, int64_t ldx, const float* dlogp_in, int32_t* warn_count,
+                                            float* y_bonds, float* y_angles, float* y_torsions, float* y_fixed,
+                                            const float* t_mean, double temperature, double c_in, double c_out, int32_t drop_nonfinite,
+                                            float* u, float* dlogp_total, float* partial, double* loss_sums, void* stream) {
+    if (B == 0) return 0;
+    BGK_CHECK_ARG(y_bonds && y_angles && y_torsions && y_fixed && u && dlogp_total && partial && loss_sums && temperature > 0.0,
+                  "bgk_icdf_ic2xyz_uni_train_kl: bad arguments");
+    TailArgs kl{};
+    kl.kl_mean = t_mean; kl.kl_dl_in = dlogp_in; kl.kl_inv_t = (float)(1.0 / temperature); kl.kl_c_in = (float)c_in; kl.kl_c_out = (float)c_out;
+    kl.kl_drop = drop_nonfinite; kl.kl_u = u; kl.kl_dl = dlogp_total; kl.kl_partial = partial;
+    const int st = icdf_ic2xyz_uni_launch(bonds, angles, torsions, xfix, desc4, use_eps, cdf_eps, place8, n, fixed, n_fixed, eps, enforce_boundaries,
+                                          wh_mean, Tblacken, keep, const_ld, B, x, ldx, nullptr, 0, warn_count, y_bonds, y_angles, y_torsions,
+                                          y_fixed, stream, &kl);
+    if (st != 0) return st;
+    return bgk_loss_partial_reduce(partial, (int)((B + 63) >> 6), loss_sums, stream);
 }
 
 /* The inverse (NLL) direction of the builder tail in one launch: x [B, 3 (n + n_fixed)] -> cdf-mapped bonds / angles / torsions [B, n]

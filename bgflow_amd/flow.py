@@ -157,6 +157,45 @@ class SequentialFlow(Flow):
     def forward(self, *xs, inverse=False, **kwargs):
         return self.run(xs, inverse=inverse, kwargs=kwargs)
 
+    FUSE_KL_EPILOGUE = os.environ.get("BGK_KL_EPILOGUE", "1") != "0"   # kl_sums: the target energy inside the generation tail's launch
+
+    def kl_sums(self, xs, target, temperature=1.0, drop_nonfinite=False):
+        """f64 [sum_b (u_target(x_b) - dlogp_b), samples kept] of ``x, dlogp = self(*xs)`` (BoltzmannGenerator.kldiv, bg.py:140-147, summed)
+        in a pass that builds an autograd graph, with the target energy formed INSIDE the launch of the generation tail when the flow
+        ends with the builder's [icdf maps, IC -> xyz] and the target is a normal distribution over the Cartesian output; None
+        otherwise (the caller evaluates the flow and the energy one after the other)."""
+        from .distributions import _kernel_plan
+        if not (self.FUSE_KL_EPILOGUE and torch.is_grad_enabled() and isinstance(temperature, (int, float)) and temperature > 0):
+            return None
+        segs = self.segments(inverse=False, train=True)
+        tail = segs[-1][1] if segs else None
+        if not isinstance(tail, _FusedGenerationTail):
+            return None
+        plan = _kernel_plan(target, temperature)
+        if plan is None:
+            return None
+        specs, dims, c_in, c_out, t_eff = plan
+        ic = tail._ic
+        n_cart = 3 * (getattr(ic, "_rel_ic", ic)._n + getattr(ic, "_rel_ic", ic)._n_fixed)
+        if not (len(specs) == 1 and specs[0][0] == 0 and dims == [n_cart]):
+            return None
+        total = None
+        for _label, seg in segs[:-1]:
+            *xs, dd = seg(*xs, inverse=False, temperature=temperature)
+            total = dd if total is None else total + dd
+        if len(xs) != 4:
+            res = None
+        else:
+            res = tail.kl_sums(tuple(xs), total, (specs, t_eff, c_in, c_out), drop_nonfinite)
+        if res is not None:
+            return res
+        # outside the tail's envelope: the tail, then the energy kernel's loss form on its output
+        from .distributions import kl_loss_sums
+        *x, dd = tail(*xs, inverse=False, temperature=temperature)
+        total = dd if total is None else total + dd
+        out = kl_loss_sums(target, tuple(x), total, temperature=temperature, drop_nonfinite=drop_nonfinite)
+        return None if out is None else out[0]
+
     def run(self, xs, inverse=False, kwargs=None, around=None):
         """The pass itself.  ``around(i, label)``, if given, returns a context manager entered around segment i (bench.py times the
         segments with HIP events that way, on the same code path as ``forward``)."""
@@ -495,6 +534,53 @@ class _FusedTailTrainFn(torch.autograd.Function):
         return (*outs, None, None, None)
 
 
+class _FusedTailKLFn(torch.autograd.Function):
+    """the generation tail AND the KL integrand of a normal target as one launch (bgk_icdf_ic2xyz_uni_train_kl): the lanes hold their
+    samples' coordinates in registers when the placements are done, so u_target(x) and the tile's share of [sum (u - dlogp), samples
+    kept] cost no second pass over x (round 5: what SURVEY f-3 asks of `kldiv`).  Returns the f64 pair; backward = the target-energy
+    backward kernel on the saved x (gradient of u and of the mask of kept samples), then the tail's backward kernels."""
+
+    @staticmethod
+    def forward(ctx, zb, za, zt, zf, dl_in, tail, descs, desc20, plan, drop):
+        specs, t_eff, c_in, c_out = plan
+        mean = specs[0][1]
+        t_mean = None if mean is None else mean.detach().to(device=zb.device, dtype=torch.float32).contiguous()
+        dl = None if dl_in is None else dl_in.detach().reshape(-1).to(torch.float32).contiguous()
+        res = tail._ic._generate_fused_train(zb, za, zt, zf, tail._eps, desc20, kl=(t_mean, t_eff, c_in, c_out, drop, dl))
+        if res is None:
+            raise _TailOutsideEnvelope()
+        x, dl_tot, ys, u, sums, rel, blacken = res
+        ctx.rel, ctx.blacken, ctx.descs, ctx.eps = rel, blacken, descs, tail._eps
+        ctx.cfg = (specs, t_eff, bool(drop), None if dl_in is None else dl_in.shape)
+        ctx.save_for_backward(zb, za, zt, zf, *ys, x, u, dl_tot)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g_sums):
+        import ctypes
+        from . import _lib
+        from .cdf import cdf_backward
+        from .distributions import _fields_args
+        zb, za, zt, zf, yb, ya, yt, yf, x, u, dl_tot = ctx.saved_tensors
+        specs, t_eff, drop, dl_shape = ctx.cfg
+        args, _keep = _fields_args(specs, (x,))
+        B, dev = x.shape[0], x.device
+        gs = g_sums[0:1].to(torch.float32).contiguous()
+        g_x = torch.empty_like(x)
+        g_dl = torch.empty(B, dtype=torch.float32, device=dev)
+        G = (ctypes.c_void_p * 1)(g_x.data_ptr())
+        LG = (ctypes.c_int64 * 1)(g_x.shape[1])
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_energy_fields_backward(*args, B, t_eff, None, _lib.ptr(gs), _lib.ptr(u), _lib.ptr(dl_tot), int(drop),
+                                                       _lib.ptr(g_dl), G, LG, _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_energy_fields_backward")
+        g_ys = ctx.rel._ic2xyz_backward(yb, ya, yt, x, ctx.blacken, g_x, g_dl)
+        outs = []
+        for z, y, g_y, desc in zip((zb, za, zt, zf), (yb, ya, yt, yf), g_ys, ctx.descs):
+            outs.append(g_y if desc is None else cdf_backward(z.flatten(1), y, desc, True, ctx.eps, g_y, g_dl).view_as(z))
+        return (*outs, None if dl_shape is None else g_dl.reshape(dl_shape), None, None, None, None, None)
+
+
 class _TailOutsideEnvelope(Exception):
     pass
 
@@ -543,6 +629,26 @@ class _FusedGenerationTail:
             self._desc20_tab.uniform4 = torch.cat([p[:1] for p in parts], dim=0).contiguous() if uniform else None
             self._desc20_parts = parts            # keep the per-map tensors alive: their ids are the cache key
         return self._desc20_tab
+
+    def kl_sums(self, xs, dlogp, plan, drop):
+        """f64 [sum (u - dlogp), kept] of a normal target with the energy formed inside the tail's training launch, or None when the
+        launch is outside its envelope (the caller then runs the tail and the energy kernel one after the other)"""
+        ok = (len(xs) == 4 and all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 for x in xs)
+              and self._flow.FUSE_TRAINING_TAIL and hasattr(self._ic, "_generate_fused_train") and not self._others and len(self._maps) == 4)
+        if not ok:
+            return None
+        descs = [None] * 4
+        for slot, cdf in self._maps.items():
+            descs[slot] = cdf.kernel_descriptor(xs[slot].shape[-1], xs[slot].device)
+            if descs[slot] is None:
+                return None
+        desc20 = self._desc20(xs)
+        if desc20 is None or getattr(desc20, "uniform4", None) is None:
+            return None
+        try:
+            return _FusedTailKLFn.apply(xs[0], xs[1], xs[2], xs[3], dlogp, self, descs, desc20, plan, bool(drop))
+        except _TailOutsideEnvelope:
+            return None
 
     def _blocks_path(self, *xs, **kwargs):
         acc = kwargs.get(ACC_KW)

@@ -365,10 +365,12 @@ class RelativeInternalCoordinateTransformation(Flow):
     UNIFORM_TAIL = True      # ... and on its elementwise variant when every field has one marginal for all its channels
     REGISTER_TAIL = True     # sampling tail on the register-resident kernel (bgk_icdf_ic2xyz_reg) where its envelope allows
 
-    def _icdf_ic2xyz_train(self, bonds, angles, torsions, xfix, eps, blacken, desc20):
+    def _icdf_ic2xyz_train(self, bonds, angles, torsions, xfix, eps, blacken, desc20, kl=None):
         """the fused tail as a TRAINING forward (bgk_icdf_ic2xyz_uni_train): (x, dlogp [B], (y_bonds, y_angles, y_torsions, y_fixed)) with
         y = the mapped fields the backward kernels read, or None outside the elementwise kernel's envelope.  No autograd here
-        (flow._FusedTailTrainFn wraps it)."""
+        (flow._FusedTailTrainFn wraps it).  ``kl`` = (t_mean or None, temperature, c_in, c_out, drop_nonfinite, dlogp_in [B] or None):
+        the KL integrand of a normal target in the same launch (bgk_icdf_ic2xyz_uni_train_kl); then the result is
+        (x, dlogp_total [B], ys, u [B], sums f64 [2])."""
         dev = bonds.device
         B, n, nf = bonds.shape[0], self._n, self._n_fixed
         desc4 = getattr(desc20, "uniform4", None) if desc20 is not None else None
@@ -389,6 +391,23 @@ class RelativeInternalCoordinateTransformation(Flow):
         ys = torch.empty((3, B, n), dtype=torch.float32, device=dev)
         yf = torch.empty((B, keep), dtype=torch.float32, device=dev)
         const_ld = n * (np.log(np.pi) + np.log(2.0 * np.pi)) - (float(jac) if T is not None else 0.0)
+        if kl is not None:
+            t_mean, temperature, c_in, c_out, drop, dl_in = kl
+            u = torch.empty((B,), dtype=torch.float32, device=dev)
+            partial = torch.empty(((B + 63) // 64, 2), dtype=torch.float32, device=dev)
+            sums = torch.empty(2, dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):
+                st = _lib.lib().bgk_icdf_ic2xyz_uni_train_kl(
+                    _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), _lib.ptr(f2), _lib.ptr(desc4), int(eps is not None), float(eps or 0.0),
+                    _lib.ptr(self._tables.get("place8", dev)), n, _lib.ptr(self._tables.get("fixed", dev)), nf,
+                    float(self._eps), int(self._enforce_boundaries), _lib.ptr(mean), _lib.ptr(T), keep, float(const_ld), B,
+                    _lib.ptr(x), x.shape[1], _lib.ptr(dl_in), _lib.ptr(self._warn_counter(dev)),
+                    _lib.ptr(ys[0]), _lib.ptr(ys[1]), _lib.ptr(ys[2]), _lib.ptr(yf), _lib.ptr(t_mean), float(temperature), float(c_in), float(c_out),
+                    int(bool(drop)), _lib.ptr(u), _lib.ptr(dlogp), _lib.ptr(partial), _lib.ptr(sums), _lib.stream_ptr(dev))
+            if st == -2:
+                return None
+            _lib.check(st, "bgk_icdf_ic2xyz_uni_train_kl")
+            return x, dlogp, (ys[0], ys[1], ys[2], yf), u, sums
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_icdf_ic2xyz_uni_train(
                 _lib.ptr(b2), _lib.ptr(a2), _lib.ptr(t2), _lib.ptr(f2), _lib.ptr(desc4), int(eps is not None), float(eps or 0.0),
@@ -479,8 +498,8 @@ class RelativeInternalCoordinateTransformation(Flow):
     def _generate_fused(self, bonds, angles, torsions, x_fixed, descs, eps, acc=None, desc20=None):
         return self._icdf_ic2xyz(bonds, angles, torsions, x_fixed, descs, eps, acc=acc, desc20=desc20)
 
-    def _generate_fused_train(self, bonds, angles, torsions, x_fixed, eps, desc20):
-        res = self._icdf_ic2xyz_train(bonds, angles, torsions, x_fixed, eps, None, desc20)
+    def _generate_fused_train(self, bonds, angles, torsions, x_fixed, eps, desc20, kl=None):
+        res = self._icdf_ic2xyz_train(bonds, angles, torsions, x_fixed, eps, None, desc20, kl=kl)
         return None if res is None else (*res, self, None)
 
     def _xyz2ic_cdf(self, x, desc4, eps, whiten=None, acc=None):
@@ -664,9 +683,9 @@ class MixedCoordinateTransformation(Flow):
         return self._rel_ic._icdf_ic2xyz(bonds, angles, torsions, z_fixed, descs, eps, blacken=self._wh("blacken", bonds.device), acc=acc,
                                          desc20=desc20)
 
-    def _generate_fused_train(self, bonds, angles, torsions, z_fixed, eps, desc20):
+    def _generate_fused_train(self, bonds, angles, torsions, z_fixed, eps, desc20, kl=None):
         blacken = self._wh("blacken", bonds.device)
-        res = self._rel_ic._icdf_ic2xyz_train(bonds, angles, torsions, z_fixed, eps, blacken, desc20)
+        res = self._rel_ic._icdf_ic2xyz_train(bonds, angles, torsions, z_fixed, eps, blacken, desc20, kl=kl)
         return None if res is None else (*res, self._rel_ic, blacken)
 
 

@@ -211,6 +211,22 @@ int bgk_icdf_ic2xyz_uni_train(const float* bonds, const float* angles, const flo
                               const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
                               float* x, int64_t ldx, float* dlogp, int32_t accumulate, int32_t* warn_count,
                               float* y_bonds, float* y_angles, float* y_torsions, float* y_fixed, void* stream);
+/* ... and with the KL integrand of BoltzmannGenerator.kldiv (bg.py:140-147) formed in the same launch, for a target that is a normal
+ * distribution about t_mean [3 (n + n_fixed)] (NULL: 0) -- distribution/normal.py:61-72: u = (|x - t_mean|^2 / 2 + c_in) / temperature
+ * + c_out; every lane holds its sample's coordinates in registers when the placements are done, so the target energy costs no second
+ * pass over x and the loss no per-sample tensor.  dlogp_in [B] (NULL: 0): log-det of the flow in front of the tail, read only.
+ * Written besides x and the mapped fields: u [B], dlogp_total [B], partial [ceil(B / 64)][2] (per 64-sample tile: the sum of
+ * u - dlogp_total over the samples kept and their number; drop_nonfinite: a sample whose integrand is not finite is not kept) and
+ * loss_sums [2] (f64: the partials added in a fixed order by a second small launch) -- what bgk_energy_fields' loss form delivers. */
+int bgk_icdf_ic2xyz_uni_train_kl(const float* bonds, const float* angles, const float* torsions, const float* xfix,
+                                 const float* desc4, int32_t use_eps, float cdf_eps,
+                                 const int32_t* place8, int32_t n, const int32_t* fixed, int32_t n_fixed,
+                                 float eps, int32_t enforce_boundaries,
+                                 const float* wh_mean, const float* Tblacken, int32_t keep, double const_ld, int64_t B,
+                                 float* x, int64_t ldx, const float* dlogp_in, int32_t* warn_count,
+                                 float* y_bonds, float* y_angles, float* y_torsions, float* y_fixed,
+                                 const float* t_mean, double temperature, double c_in, double c_out, int32_t drop_nonfinite,
+                                 float* u, float* dlogp_total, float* partial, double* loss_sums, void* stream);
 
 /* The INVERSE (NLL) direction of the builder tail in one launch: x [B, 3 (n + n_fixed)] -> cdf-mapped bonds / angles / torsions [B, n]
  * and (whitened) fixed coordinates [B, keep], all contiguous and 16-byte aligned, + log|det J|.  Replaces bgk_ic_xyz2ic + 4 x

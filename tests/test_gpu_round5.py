@@ -449,3 +449,38 @@ def test_element_major_saved_parameters_equal_the_reference_layout(hip_lib, dev,
         dense.PACKED_PARAMS = prev
     for a, b in zip(res[True][0] + [res[True][1]] + res[True][2] + res[True][3], res[False][0] + [res[False][1]] + res[False][2] + res[False][3]):
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,drop", [(4096, True), (1000, False)])
+def test_kl_integrand_inside_the_generation_tail(hip_lib, dev, B, drop):
+    """SURVEY f-3's single-pass `kldiv` (round 5): `BoltzmannGenerator.kldiv_mean` evaluates the target energy and the loss sums inside
+    the generation tail's training launch (bgk_icdf_ic2xyz_uni_train_kl -- the lanes hold their samples' coordinates in registers there)
+    instead of a second pass over x (bgk_energy_fields).  Same loss and the same gradients as the two-launch form (the energy's 66 terms
+    are summed in another order: f32 rounding), whole and partial tiles, with and without the non-finite filter."""
+    from bgflow_amd import configs
+    gen = configs.make_ala2_spline_generator(dev)
+    res = {}
+    for fused in (True, False):
+        gen.flow.FUSE_KL_EPILOGUE = fused
+        for p in gen.flow.parameters():
+            p.grad = None
+        torch.manual_seed(123)
+        loss = gen.kldiv_mean(B, drop_nonfinite=drop)
+        if fused:
+            node, seen = loss.grad_fn, set()
+            stack = [node]
+            while stack:                       # the fused node must be part of the graph
+                f = stack.pop()
+                if f is None or f in seen:
+                    continue
+                seen.add(f)
+                stack.extend(g for g, _ in f.next_functions)
+            assert any("_FusedTailKLFn" in type(f).__name__ for f in seen), "kldiv_mean did not take the single-pass form"
+        loss.backward()
+        res[fused] = (float(loss), [p.grad.clone() for p in gen.flow.parameters()])
+    gen.flow.FUSE_KL_EPILOGUE = True
+    (l1, g1), (l0, g0) = res[True], res[False]
+    assert np.isfinite(l1) and abs(l1 - l0) <= 2e-6 * abs(l0)
+    num = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(g1, g0))
+    den = sum(float((b.double() ** 2).sum()) for b in g0)
+    assert (num / den) ** 0.5 <= 2e-6, f"flat gradient: relative L2 {(num / den) ** 0.5:.2e} between the single-pass and the two-launch form"
