@@ -973,16 +973,17 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
 }
 
 /* The samples the sweep kernels flagged (fix[0] of them, indices behind it), one lane each: the lane copies its sample's rows (g_x, x,
- * bonds, angles, torsions) into a private LDS row -- sixteen independent loads per round trip -- and runs the same sweep with the
+ * bonds, angles, torsions) into a private LDS row -- 48 independent loads per round trip -- and runs the same sweep with the
  * dual-number adjoint where a norm was clamped.  A few hundred samples of 2^18 at cfg 3's uniform prior: the launch costs its latency.
  * blockDim.x = lanes per workgroup (64, fewer for molecules whose rows do not fit 160 KB of LDS). */
 __device__ __forceinline__ void copy_row16(float* dst, const float* __restrict__ src, int w) {
-    for (int c0 = 0; c0 < w; c0 += 16) {
-        float v[16];
+    constexpr int CW = 48;                /* loads in flight per round trip (the launch is a latency: the fewer round trips the better) */
+    for (int c0 = 0; c0 < w; c0 += CW) {
+        float v[CW];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = src[c0 + u < w ? c0 + u : w - 1];
+        for (int u = 0; u < CW; ++u) v[u] = src[c0 + u < w ? c0 + u : w - 1];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < CW; ++u)
             if (c0 + u < w) dst[c0 + u] = v[u];
     }
 }
@@ -1023,7 +1024,7 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_fix_kernel(IcBwdArgs a) {
             const V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
             const float dd = rb[zr], an = ra[zr], t = rt[zr];
             const V3 g = ld3(gp + 3 * at);
-            const PlaceAdj q = placement_adjoint<true, 6>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
+            const PlaceAdj q = placement_adjoint<true, 4>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
             gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
             gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
             gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
