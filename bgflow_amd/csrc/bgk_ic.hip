@@ -973,11 +973,11 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_dma_kernel(IcBwdArgs a) {
 }
 
 /* The samples the sweep kernels flagged (fix[0] of them, indices behind it), one lane each: the lane copies its sample's rows (g_x, x,
- * bonds, angles, torsions) into a private LDS row -- 48 independent loads per round trip -- and runs the same sweep with the
+ * bonds, angles, torsions) into a private LDS row -- sixteen independent loads per round trip -- and runs the same sweep with the
  * dual-number adjoint where a norm was clamped.  A few hundred samples of 2^18 at cfg 3's uniform prior: the launch costs its latency.
  * blockDim.x = lanes per workgroup (64, fewer for molecules whose rows do not fit 160 KB of LDS). */
 __device__ __forceinline__ void copy_row16(float* dst, const float* __restrict__ src, int w) {
-    constexpr int CW = 48;                /* loads in flight per round trip (the launch is a latency: the fewer round trips the better) */
+    constexpr int CW = 16;                /* loads in flight per round trip (48: no faster, measured) */
     for (int c0 = 0; c0 < w; c0 += CW) {
         float v[CW];
 #pragma unroll
