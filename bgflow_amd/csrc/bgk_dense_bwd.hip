@@ -17,7 +17,10 @@ namespace {
 
 #include "bgk_dma.h"
 
-constexpr int DW = 4;
+#ifndef BGK_DBWD_DW
+#define BGK_DBWD_DW 4
+#endif
+constexpr int DW = BGK_DBWD_DW;      /* waves (32-row tiles) per workgroup */
 constexpr int DSROW = 33;
 #ifndef BGK_DBWD_DG
 #define BGK_DBWD_DG 4
@@ -208,8 +211,36 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
 #define BGK_DBWD_SHARED 1      /* first GEMM's operand blocks: 1 = staged once per workgroup in LDS (DMA), 0 = every wave streams them from L2 */
 #endif
 
+#ifndef BGK_DBWD_GLDS
+#define BGK_DBWD_GLDS 1        /* first GEMM's gradient tile: 1 = copied into LDS by DMA (whole 128-byte row pieces), 0 = 32-byte pieces straight into registers */
+#endif
+#ifndef BGK_DBWD_GRING
+#define BGK_DBWD_GRING 2       /* gradient groups in flight + in use per wave (LDS ring slots of 4 KB) */
+#endif
+constexpr int DBWD_GD = 2;                                           /* k-steps per group on the BGK_DBWD_GLDS path */
+constexpr int DBWD_OPG = DBWD_GD * 4 * 2 * 64;                        /* 16-byte pieces of an operand group there */
+#ifndef BGK_DBWD_ORING
+#define BGK_DBWD_ORING 3       /* operand groups in flight + in use per workgroup (LDS ring slots of 16 KB) */
+#endif
+constexpr size_t DBWD_GLDS_BYTES = BGK_DBWD_ORING * (size_t)DBWD_OPG * 16 + (size_t)DW * BGK_DBWD_GRING * 4096;
+template <int N> __device__ __forceinline__ void dx_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+/* A-operand fragments of one k-step of the first GEMM, read from LDS by inline asm (see the kernel) */
+typedef unsigned bgk_u4v __attribute__((ext_vector_type(4)));
+struct DxFrag { bgk_u4v r[4][2]; };
+__device__ __forceinline__ void dx_frag_wait(DxFrag& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.r[0][0]), "+v"(f.r[0][1]), "+v"(f.r[1][0]), "+v"(f.r[1][1]),
+                                           "+v"(f.r[2][0]), "+v"(f.r[2][1]), "+v"(f.r[3][0]), "+v"(f.r[3][1]) : : "memory");
+}
+__device__ __forceinline__ void dx_frag_get(const DxFrag& f, H2A<4>& h) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) h.v[m][pp] = make_uint4(f.r[m][pp][0], f.r[m][pp][1], f.r[m][pp][2], f.r[m][pp][3]);
+}
+
 template <int FT>
-__global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a) {
+__global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* uniform: buffer descriptor in SGPRs */
     const int j = lane & 31, hh = lane >> 5;
@@ -249,13 +280,160 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
             const bgk_f4v u0 = __builtin_bit_cast(bgk_f4v, __builtin_amdgcn_raw_buffer_load_b128(rs_gt, gofs + k0 * 4, 0, 0));
             const bgk_f4v u1 = __builtin_bit_cast(bgk_f4v, __builtin_amdgcn_raw_buffer_load_b128(rs_gt, gofs + k0 * 4 + 16, 0, 0));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = k0 + e < P ? u0[e] : 0.0f; v[4 + e] = k0 + 4 + e < P ? u1[e] : 0.0f; }
+            for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
+        };
+        /* The column mask is applied where the values are USED (a group later): a select on the loaded registers right behind the load is
+         * a wait for the whole batch -- and for everything requested before it -- in front of the current group's matrix work. */
+        auto mask_g = [&](int s, float (&v)[8]) {
+            const int k0 = 16 * s + 8 * hh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = k0 + e < P ? v[e] : 0.0f;
         };
         constexpr int DG = DBWD_DG;
         static_assert(DG % 2 == 0, "fragment set parity follows the position in the group");
         const int S2 = a.S2;
         sg = h2_pow2_scale(a.g_absmax ? a.g_absmax[0] : 0.0f, inv_sg);      /* per-tensor power of two: max |g| -> [2^14, 2^15) */
-#if BGK_DBWD_SHARED
+#if BGK_DBWD_SHARED && BGK_DBWD_GLDS
+        /* Round 5, second form.  Stamps of the form below (#elif) showed the first GEMM spending 29 k of its 71 k cycles ISSUING requests:
+         * the gradient loads hand the address unit 64 separate 16-byte pieces per instruction (32 rows x 2), one piece per cycle, eight
+         * waves per CU -- 4 k cycles per group of four k-steps for 1.5 k cycles of matrix work.  Here the gradient goes through LDS as
+         * well: per group of GD = 2 k-steps a wave copies its tile's 32 rows x 128 bytes by DMA, eight adjacent lanes per row piece (four
+         * instructions of 8 whole 128-byte pieces instead of eight of 64 scattered ones), PD groups ahead into a private ring, and reads
+         * its B operand (row j, k = 16 s + 8 hh ..) from there; the 16-byte pieces of a row are stored XOR-swizzled by the row so that
+         * the 64 lanes' reads spread over the banks.  Bounds come from the buffer descriptor (rows past the batch, columns past the
+         * allocation: nothing is read); what such pieces leave in LDS is masked at the point of use.  The operand groups (GD k-steps,
+         * 16 KB) are shared by the workgroup as in the first form.  All LDS reads of this GEMM are inline asm: the compiler's wait
+         * insertion puts vmcnt(0) in front of every LDS read it sees behind an LDS-DMA (possible alias), i.e. in front of the current
+         * group's work it waited for the requests of the NEXT groups. */
+        constexpr int GD = DBWD_GD, OPG = DBWD_OPG, GRING = BGK_DBWD_GRING, ORING = BGK_DBWD_ORING, PDG = GRING - 1, PDO = ORING - 1;
+        constexpr int NG = 4, NO = OPG / DW / 64;                        /* DMA instructions of a wave per group: gradient | operands */
+        /* Requests complete in order.  A group needs its gradient (requested PDG groups ago) and its operands (PDO groups ago); the kind
+         * with the SHORTER distance is requested first inside a group, so that behind the younger of the two needed batches there are
+         * only batches of later groups: REMAIN of them may still be in flight at the top of a group. */
+        constexpr bool G_FIRST = PDO >= PDG;
+        constexpr int REMAIN = PDO == PDG ? (PDG - 1) * (NG + NO) : PDO > PDG ? NO + (PDG - 1) * (NG + NO) : NG + (PDO - 1) * (NG + NO);
+        static_assert(DBWD_DG % GD == 0 && GRING >= 2 && ORING >= 2 && REMAIN < 64, "S2 is a multiple of DBWD_DG");
+        (void)load_g; (void)mask_g;
+        const int ngroups = S2 / GD;
+        char* const smem_b = reinterpret_cast<char*>(smem);
+        const unsigned lds0 = (unsigned)(uintptr_t)(lvp_t)smem;
+        const unsigned lds_a = lds0 + (unsigned)lane * 16u;                                   /* + buffer * OPG * 16 + u * 8192 + immediate */
+        const int gring0 = ORING * OPG * 16 + wave * (GRING * 4096);                               /* byte offset of this wave's gradient ring */
+        /* DMA source: instruction i = rows 8 i .. 8 i + 7, lane -> row 8 i + (lane >> 3), piece (lane & 7) ^ (row & 7) [row & 7 == lane >> 3] */
+        const int gvo = (lane >> 3) * (int)a.ldg * 4 + (((lane & 7) ^ (lane >> 3)) * 16);
+        const int gstep = 8 * (int)a.ldg * 4;
+        /* read addresses: row j of the ring slot, pieces (4 u + 2 hh + e) ^ (j & 7) */
+        const unsigned grow = lds0 + (unsigned)gring0 + (unsigned)(j * 128);
+        const int gpj = (2 * hh) ^ (j & 7);
+        auto dma_op = [&](int gi, int buf) {
+            const uint4* src = a.T2 + (size_t)gi * OPG + wave * (OPG / DW);
+            char* dst = smem_b + (buf * OPG + wave * (OPG / DW)) * 16;
+#pragma unroll
+            for (int i = 0; i < NO; ++i)
+                __builtin_amdgcn_global_load_lds((gvp_t)(src + i * 64 + lane), (lvp_t)(dst + i * 1024), 16, 0, 0);
+        };
+        auto dma_grad = [&](int gi, int slot) {
+            char* dst = smem_b + gring0 + slot * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_gt, (lvp_t)(dst + i * 1024), 16, gvo, gi * (GD * 64) + i * gstep, 0, 0);
+        };
+        /* An asm load's destination counts as written where the statement ends: the wait statement names the registers ("+v"), so
+         * that every use -- a copy the register allocator might place included -- is ordered behind the wait. */
+        auto lds_frag = [&](DxFrag& f, int buf, int u) {
+            const unsigned addr = lds_a + (unsigned)buf * (OPG * 16u) + (unsigned)u * (4 * 2 * 1024u);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.r[m][pp]) : "v"(addr), "i"((m * 2 + pp) * 1024) : "memory");
+        };
+        const int Pj = j < rows ? P : 0;                                 /* rows past the batch: every column masked */
+        /* (past the end the last group is requested again, into ring slots nobody reads any more: the request counts stay uniform) */
+        auto request = [&](int t, int gslot, int oslot) {                /* what group t requests: gradient t + PDG, operands t + PDO */
+            const int gg = t + PDG < ngroups ? t + PDG : ngroups - 1, og = t + PDO < ngroups ? t + PDO : ngroups - 1;
+            if (G_FIRST) { if (t + PDG >= 0) dma_grad(gg, gslot); if (t + PDO >= 0) dma_op(og, oslot); }
+            else { if (t + PDO >= 0) dma_op(og, oslot); if (t + PDG >= 0) dma_grad(gg, gslot); }
+        };
+        constexpr int PDM = PDG > PDO ? PDG : PDO;
+#pragma unroll
+        for (int t = -PDM; t < 0; ++t) request(t, (t + PDG + GRING) % GRING, (t + PDO + ORING) % ORING);
+        __builtin_amdgcn_sched_barrier(0);
+#if BGK_SBD_TS
+        unsigned tsw = 0u, tsb = 0u, tsc = 0u, tss = 0u, tsi = 0u, tq0, tq1, tq3, tq4, tq2 = (unsigned)__builtin_amdgcn_s_memtime();
+#define SBD_Q(v) do { __builtin_amdgcn_sched_barrier(0); v = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
+        int slot = 0, slot_in = PDG % GRING, ob = 0, ob_in = PDO % ORING;
+        for (int gi = 0; gi < ngroups; ++gi) {
+#if BGK_SBD_TS
+            SBD_Q(tq0); tsc += tq0 - tq2;
+#endif
+            dx_wait_vm<REMAIN>();                                       /* this group's gradient tile and this wave's share of its operands have landed */
+#if BGK_SBD_TS
+            SBD_Q(tq1); tsw += tq1 - tq0;
+#endif
+            __syncthreads();                                            /* ... everyone's operand quarter; and everyone has left the buffer group gi + 1 goes to */
+#if BGK_SBD_TS
+            SBD_Q(tq2); tsb += tq2 - tq1;
+#endif
+            h2_h16x8 bhi[GD], blo[GD];
+            {
+                bgk_u4v raw[GD][2];
+                const unsigned so = (unsigned)slot * 4096u;
+#pragma unroll
+                for (int u = 0; u < GD; ++u)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned ad = grow + so + (unsigned)((gpj ^ (4 * u + e)) * 16);
+                        asm volatile("ds_read_b128 %0, %1" : "=&v"(raw[u][e]) : "v"(ad) : "memory");
+                    }
+                static_assert(GD == 2, "the wait names the four registers");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]) : : "memory");
+#pragma unroll
+                for (int u = 0; u < GD; ++u) {
+                    float v[8];
+                    const int k0 = 16 * (gi * GD + u) + 8 * hh;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned w = raw[u][e >> 2][e & 3];            /* (by value: __builtin_bit_cast of a vector ELEMENT picked element 0 every time) */
+                        v[e] = k0 + e < Pj ? __uint_as_float(w) : 0.0f;
+                    }
+                    h2_split8_scaled(v, sg, bhi[u], blo[u]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#if BGK_SBD_TS
+            SBD_Q(tq3); tss += tq3 - tq2;
+#endif
+            request(gi, slot_in, ob_in);
+            __builtin_amdgcn_sched_barrier(0);
+#if BGK_SBD_TS
+            SBD_Q(tq4); tsi += tq4 - tq3;
+#endif
+            DxFrag fr[2];
+            lds_frag(fr[0], ob, 0);
+#pragma unroll
+            for (int u = 0; u < GD; ++u) {
+                dx_frag_wait(fr[u & 1]);                                /* this step's fragments (requested one step ago) have arrived */
+                if (u + 1 < GD) lds_frag(fr[(u + 1) & 1], ob, u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                H2A<4> fa;
+                dx_frag_get(fr[u & 1], fa);
+                h2_mfma3<4>(acc, fa, bhi[u], blo[u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            slot = slot + 1 == GRING ? 0 : slot + 1;
+            slot_in = slot_in + 1 == GRING ? 0 : slot_in + 1;
+            ob = ob + 1 == ORING ? 0 : ob + 1;
+            ob_in = ob_in + 1 == ORING ? 0 : ob_in + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                /* the copies past the end */
+        __syncthreads();                                                /* the buffers are the waves' output slabs from here on */
+        if (!active) return;
+#if BGK_SBD_TS
+        if (lane == 0) { unsigned* q = reinterpret_cast<unsigned*>(s_f); q[1 * H2_SLAB + 130] = tsw; q[2 * H2_SLAB + 130] = tsb; q[3 * H2_SLAB + 130] = tsc; q[4 * H2_SLAB + 130] = tss; q[5 * H2_SLAB + 130] = tsi; }
+#endif
+#elif BGK_DBWD_SHARED
         /* Round 5.  The operand blocks of this GEMM (W2^T as f16 hi + lo: 8 KB per k-step, 229 KB per tile at P = 425) are the same for
          * every tile.  Streamed from L2 by every wave, one k-step ahead, each k-step exposed most of an L2 round trip (operand loads
          * return in order behind the gradient loads): 76 k of the 147 k cycles a wave lived (s_memtime stamps, tools/r05_dx_ts.py),
@@ -273,44 +451,77 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
             for (int i = 0; i < GRP16 / DW / 64; ++i)
                 __builtin_amdgcn_global_load_lds((gvp_t)(src + i * 64 + lane), (lvp_t)(dst + i * 64), 16, 0, 0);
         };
-        auto lds_frag = [&](H2A<4>& f, const uint4* buf, int u) {
+        /* The fragment reads are inline asm: behind a global_load_lds the compiler's wait insertion puts `s_waitcnt vmcnt(0)` in front of
+         * EVERY ds_read it can see (the copy might alias what is read), i.e. the wave waited for the NEXT group's copy and gradient batch
+         * -- a whole memory round trip per group -- before it touched the current group (stamps: 67.7 k of the GEMM's 71 k cycles
+         * "computing", 128 waiting for its own requests).  The copies land in the OTHER buffer; their completion is awaited explicitly at
+         * the top of the next group.  lgkmcnt of these reads is handled by hand (dx_frag_wait). */
+        const unsigned lds_op = (unsigned)(uintptr_t)(lvp_t)s_op + (unsigned)lane * 16u;
+        auto lds_frag = [&](DxFrag& f, int slot, int u) {
+            const unsigned addr = lds_op + (unsigned)slot * (GRP16 * 16u) + (unsigned)u * (4 * 2 * 1024u);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                f.v[m][0] = buf[((u * 4 + m) * 2 + 0) * 64 + lane];
-                f.v[m][1] = buf[((u * 4 + m) * 2 + 1) * 64 + lane];
-            }
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.r[m][pp]) : "v"(addr), "i"((m * 2 + pp) * 1024) : "memory");
         };
         float ring[DG][8];
         dma_group(0);
 #pragma unroll
         for (int u = 0; u < DG; ++u) load_g(u, ring[u]);
         __builtin_amdgcn_sched_barrier(0);
+#if BGK_SBD_TS
+        unsigned tsw = 0u, tsb = 0u, tsc = 0u, tss = 0u, tsi = 0u, tq0, tq1, tq3, tq4, tq2 = (unsigned)__builtin_amdgcn_s_memtime();   /* cycles waiting for the wave's own requests | at the barrier | computing */
+#define SBD_Q(v) do { __builtin_amdgcn_sched_barrier(0); v = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SBD_Q(v) do { } while (0)
+#endif
         for (int s0 = 0, gi = 0; s0 < S2; s0 += DG, ++gi) {
+#if BGK_SBD_TS
+            SBD_Q(tq0); tsc += tq0 - tq2;
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* this wave's quarter of group gi and its gradient batch have landed */
+#if BGK_SBD_TS
+            SBD_Q(tq1); tsw += tq1 - tq0;
+#endif
             __syncthreads();                                            /* ... everyone's; and everyone has left the buffer group gi + 1 goes to */
+#if BGK_SBD_TS
+            SBD_Q(tq2); tsb += tq2 - tq1;
+#endif
             h2_h16x8 bhi[DG], blo[DG];
 #pragma unroll
-            for (int u = 0; u < DG; ++u) h2_split8_scaled(ring[u], sg, bhi[u], blo[u]);
+            for (int u = 0; u < DG; ++u) { mask_g(s0 + u, ring[u]); h2_split8_scaled(ring[u], sg, bhi[u], blo[u]); }
             __builtin_amdgcn_sched_barrier(0);
+#if BGK_SBD_TS
+            SBD_Q(tq3); tss += tq3 - tq2;
+#endif
             if (s0 + DG < S2) {
                 dma_group(gi + 1);
 #pragma unroll
                 for (int v = 0; v < DG; ++v) load_g(s0 + DG + v, ring[v]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const uint4* buf = s_op + (gi & 1) * GRP16;
-            H2A<4> fr[2];
-            lds_frag(fr[0], buf, 0);
+#if BGK_SBD_TS
+            SBD_Q(tq4); tsi += tq4 - tq3;
+#endif
+            DxFrag fr[2];
+            lds_frag(fr[0], gi & 1, 0);
 #pragma unroll
             for (int u = 0; u < DG; ++u) {
-                if (u + 1 < DG) lds_frag(fr[(u + 1) & 1], buf, u + 1);
+                dx_frag_wait(fr[u & 1]);                                /* this step's fragments (requested one step ago) have arrived */
+                if (u + 1 < DG) lds_frag(fr[(u + 1) & 1], gi & 1, u + 1);
                 __builtin_amdgcn_sched_barrier(0);                      /* the next step's LDS reads stay in front of this step's MFMAs */
-                h2_mfma3<4>(acc, fr[u & 1], bhi[u], blo[u]);
+                H2A<4> fa;
+                dx_frag_get(fr[u & 1], fa);
+                h2_mfma3<4>(acc, fa, bhi[u], blo[u]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();                                                /* the operand buffers are the waves' output slabs from here on */
         if (!active) return;
+#if BGK_SBD_TS
+        if (lane == 0) { unsigned* q = reinterpret_cast<unsigned*>(s_f); q[1 * H2_SLAB + 130] = tsw; q[2 * H2_SLAB + 130] = tsb; q[3 * H2_SLAB + 130] = tsc; q[4 * H2_SLAB + 130] = tss; q[5 * H2_SLAB + 130] = tsi; }
+#endif
 #else
         /* Loads return in order on this part: an operand load (L2 hit) queued behind a gradient load (HBM) waits for it, so a
          * gradient ring refilled one k-step at a time stalls EVERY step for most of an HBM round trip, whatever its depth.  Here the
@@ -327,7 +538,7 @@ __global__ __launch_bounds__(DW * 64, 2) void dense_bwd_dx_kernel(DenseBwdArgs a
         for (int s0 = 0; s0 < S2; s0 += DG) {
             h2_h16x8 bhi[DG], blo[DG];
 #pragma unroll
-            for (int u = 0; u < DG; ++u) h2_split8_scaled(ring[u], sg, bhi[u], blo[u]);
+            for (int u = 0; u < DG; ++u) { mask_g(s0 + u, ring[u]); h2_split8_scaled(ring[u], sg, bhi[u], blo[u]); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < DG; ++u) {
@@ -491,13 +702,22 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     BGK_CHECK_ARG(!a.g_cond_add || ldga >= d_c, "bgk_dense_backward_dx: bad row stride of g_cond_add");
     const int FT = (n_in + 31) / 32;
     a.lds_per_wave = 32 * H2_SLAB > 32 * FT * DSROW ? 32 * H2_SLAB : 32 * FT * DSROW;   /* output slab, reused for the g_feat tile */
-    const size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;
+    size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;
+#if !BGK_DBWD_GLDS
     static_assert(sizeof(float) * DW * 32 * H2_SLAB >= 2 * (size_t)DBWD_DG * 4 * 2 * 64 * 16, "the slab space holds two operand groups of the first GEMM");
+#endif
+#if BGK_DBWD_SHARED && BGK_DBWD_GLDS
+    static_assert(DBWD_GLDS_BYTES * (8 / DW) <= 160 * 1024, "eight waves per CU");
+    if (shmem < DBWD_GLDS_BYTES) shmem = DBWD_GLDS_BYTES;            /* two operand groups + the waves' gradient rings (first GEMM) */
+#endif
     const int64_t n_wg = ((B + 31) / 32 + DW - 1) / DW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_dense_backward_dx: batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (FT == 1) hipLaunchKernelGGL(dense_bwd_dx_kernel<1>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a);
-    else if (FT == 2) hipLaunchKernelGGL(dense_bwd_dx_kernel<2>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a);
-    else hipLaunchKernelGGL(dense_bwd_dx_kernel<3>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a);
+#define BGK_LAUNCH_DX(F) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_bwd_dx_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL(dense_bwd_dx_kernel<F>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a); } while (0)
+    if (FT == 1) BGK_LAUNCH_DX(1);
+    else if (FT == 2) BGK_LAUNCH_DX(2);
+    else BGK_LAUNCH_DX(3);
+#undef BGK_LAUNCH_DX
     return bgk_launch_status("bgk_dense_backward_dx");
 }

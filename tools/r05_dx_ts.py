@@ -35,3 +35,7 @@ d = d[ok]
 print(f"{ok.sum()} of {len(ok)} tiles; total cycles per tile (median): {np.median(d.sum(1)):.0f}")
 for k, nm in enumerate(names[1:]):
     print(f"  {nm:34s} median {np.median(d[:, k]):8.0f}   p90 {np.percentile(d[:, k], 90):8.0f}")
+acc = st[ok][:, 1:6]          # slots 1..5: cycles of the first GEMM spent waiting for the wave's own requests | at the workgroup barrier | computing (of which: mask + split | issuing the next group's requests)
+for nm, col in (("first GEMM: waiting for own DMA + gradient requests", 0), ("first GEMM: at the barrier (other waves)", 1), ("first GEMM: split + issue + LDS reads + MFMAs", 2),
+                ("   of which mask + f16 split of the gradient", 3), ("   of which issuing the next group's requests", 4)):
+    print(f"  {nm:52s} median {np.median(acc[:, col]):8.0f}   p90 {np.percentile(acc[:, col], 90):8.0f}")
