@@ -222,6 +222,9 @@ constexpr int DBWD_OPG = DBWD_GD * 4 * 2 * 64;                        /* 16-byte
 #ifndef BGK_DBWD_ORING
 #define BGK_DBWD_ORING 3       /* operand groups in flight + in use per workgroup (LDS ring slots of 16 KB) */
 #endif
+#ifndef BGK_DBWD_PIPE
+#define BGK_DBWD_PIPE 1        /* first GEMM (LDS-gradient form): 1 = the MFMAs of group g - 1 interleaved with the f16 split and the requests of group g */
+#endif
 constexpr size_t DBWD_GLDS_BYTES = BGK_DBWD_ORING * (size_t)DBWD_OPG * 16 + (size_t)DW * BGK_DBWD_GRING * 4096;
 template <int N> __device__ __forceinline__ void dx_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
@@ -350,19 +353,132 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
         };
         const int Pj = j < rows ? P : 0;                                 /* rows past the batch: every column masked */
         /* (past the end the last group is requested again, into ring slots nobody reads any more: the request counts stay uniform) */
-        auto request = [&](int t, int gslot, int oslot) {                /* what group t requests: gradient t + PDG, operands t + PDO */
-            const int gg = t + PDG < ngroups ? t + PDG : ngroups - 1, og = t + PDO < ngroups ? t + PDO : ngroups - 1;
-            if (G_FIRST) { if (t + PDG >= 0) dma_grad(gg, gslot); if (t + PDO >= 0) dma_op(og, oslot); }
-            else { if (t + PDO >= 0) dma_op(og, oslot); if (t + PDG >= 0) dma_grad(gg, gslot); }
+        /* BGK_DBWD_PIPE: the operands of a group are used one turn of the loop after its gradient (LAG = 1), so a turn requests the
+         * operands of group t + PDO - 1; the distances between request and use -- and with them REMAIN -- are the same. */
+        constexpr int LAG = BGK_DBWD_PIPE ? 1 : 0;
+        static_assert(!LAG || (G_FIRST && PDO >= 2), "pipelined form: gradient requests first, an operand slot for the group in use");
+        auto request_g = [&](int t, int gslot) { if (t + PDG >= 0) dma_grad(t + PDG < ngroups ? t + PDG : ngroups - 1, gslot); };
+        auto request_o = [&](int t, int oslot) { if (t + PDO - LAG >= 0) dma_op(t + PDO - LAG < ngroups ? t + PDO - LAG : ngroups - 1, oslot); };
+        auto request = [&](int t, int gslot, int oslot) {                /* what turn t requests: gradient t + PDG, operands t + PDO - LAG */
+            if (G_FIRST) { request_g(t, gslot); request_o(t, oslot); }
+            else { request_o(t, oslot); request_g(t, gslot); }
         };
         constexpr int PDM = PDG > PDO ? PDG : PDO;
 #pragma unroll
-        for (int t = -PDM; t < 0; ++t) request(t, (t + PDG + GRING) % GRING, (t + PDO + ORING) % ORING);
+        for (int t = -PDM; t < 0; ++t) request(t, (t + PDG + GRING) % GRING, (t + PDO - LAG + 2 * ORING) % ORING);
         __builtin_amdgcn_sched_barrier(0);
 #if BGK_SBD_TS
         unsigned tsw = 0u, tsb = 0u, tsc = 0u, tss = 0u, tsi = 0u, tq0, tq1, tq3, tq4, tq2 = (unsigned)__builtin_amdgcn_s_memtime();
 #define SBD_Q(v) do { __builtin_amdgcn_sched_barrier(0); v = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #endif
+        /* the gradient tile of group g out of ring slot `slot`: raw 16-byte pieces (asm reads, see lds_frag) */
+        static_assert(GD == 2, "the wait names the four registers");
+        auto read_raw = [&](bgk_u4v (&raw)[GD][2], int slot) {
+            const unsigned so = (unsigned)slot * 4096u;
+#pragma unroll
+            for (int u = 0; u < GD; ++u)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const unsigned ad = grow + so + (unsigned)((gpj ^ (4 * u + e)) * 16);
+                    asm volatile("ds_read_b128 %0, %1" : "=&v"(raw[u][e]) : "v"(ad) : "memory");
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]) : : "memory");
+        };
+        auto split_step = [&](const bgk_u4v (&raw)[GD][2], int g, int u, h2_h16x8& hi, h2_h16x8& lo) {
+            float v[8];
+            const int k0 = 16 * (g * GD + u) + 8 * hh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned w = raw[u][e >> 2][e & 3];                /* (by value: __builtin_bit_cast of a vector ELEMENT picked element 0 every time) */
+                v[e] = k0 + e < Pj ? __uint_as_float(w) : 0.0f;
+            }
+            h2_split8_scaled(v, sg, hi, lo);
+        };
+#if BGK_DBWD_PIPE
+        /* Turn g of the loop: [wait, barrier] the gradient tile of group g out of LDS, then the 24 MFMAs of group g - 1, one by one, with
+         * the VALU work of group g's f16 split and the eight DMA requests of the turn between them (sched_group_barrier: 1 MFMA, 5 VALU,
+         * a request behind every third) -- in the sequential form the matrix pipe idled through 11 k cycles of split and 10 - 13 k cycles
+         * of request issue per tile (stamps), a wave's instructions being issued in order. */
+        int slot = 0, slot_in = PDG % GRING, ob = (ORING - LAG) % ORING, ob_in = (PDO - LAG) % ORING;
+        h2_h16x8 phi[GD], plo[GD];
+        auto turn_done = [&]() {
+            slot = slot + 1 == GRING ? 0 : slot + 1;
+            slot_in = slot_in + 1 == GRING ? 0 : slot_in + 1;
+            ob = ob + 1 == ORING ? 0 : ob + 1;
+            ob_in = ob_in + 1 == ORING ? 0 : ob_in + 1;
+        };
+        {   /* turn 0: nothing to multiply yet */
+            dx_wait_vm<REMAIN>();
+            bgk_u4v raw[GD][2];
+            read_raw(raw, slot);
+#pragma unroll
+            for (int u = 0; u < GD; ++u) split_step(raw, 0, u, phi[u], plo[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            request(0, slot_in, ob_in);
+            turn_done();
+        }
+#if BGK_SBD_TS
+        tq2 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+        for (int gi = 1; gi < ngroups; ++gi) {
+#if BGK_SBD_TS
+            SBD_Q(tq0); tsc += tq0 - tq2;
+#endif
+            dx_wait_vm<REMAIN>();                                       /* the gradient tile of group gi and this wave's share of the operands of group gi - 1 have landed */
+#if BGK_SBD_TS
+            SBD_Q(tq1); tsw += tq1 - tq0;
+#endif
+            __syncthreads();                                            /* ... everyone's share; and everyone has left the slot this turn's operand request goes to */
+#if BGK_SBD_TS
+            SBD_Q(tq2); tsb += tq2 - tq1;
+#endif
+            bgk_u4v raw[GD][2];
+            read_raw(raw, slot);
+            h2_h16x8 nhi[GD], nlo[GD];
+            DxFrag fr[2];
+            lds_frag(fr[0], ob, 0);
+#pragma unroll
+            for (int u = 0; u < GD; ++u) {
+                dx_frag_wait(fr[u & 1]);                                /* this step's fragments (requested one step ago) have arrived */
+                if (u + 1 < GD) lds_frag(fr[(u + 1) & 1], ob, u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                H2A<4> fa;
+                dx_frag_get(fr[u & 1], fa);
+                h2_mfma3<4>(acc, fa, phi[u], plo[u]);
+                split_step(raw, gi, u, nhi[u], nlo[u]);
+                if (u == 0) request_g(gi, slot_in); else request_o(gi, ob_in);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    if (q % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int u = 0; u < GD; ++u) { phi[u] = nhi[u]; plo[u] = nlo[u]; }
+            turn_done();
+        }
+        {   /* the last group's MFMAs */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            DxFrag fr[2];
+            lds_frag(fr[0], ob, 0);
+#pragma unroll
+            for (int u = 0; u < GD; ++u) {
+                dx_frag_wait(fr[u & 1]);
+                if (u + 1 < GD) lds_frag(fr[(u + 1) & 1], ob, u + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                H2A<4> fa;
+                dx_frag_get(fr[u & 1], fa);
+                h2_mfma3<4>(acc, fa, phi[u], plo[u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#if BGK_SBD_TS
+        SBD_Q(tq0); tsc += tq0 - tq2;
+#endif
+#else
         int slot = 0, slot_in = PDG % GRING, ob = 0, ob_in = PDO % ORING;
         for (int gi = 0; gi < ngroups; ++gi) {
 #if BGK_SBD_TS
@@ -379,27 +495,9 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
             h2_h16x8 bhi[GD], blo[GD];
             {
                 bgk_u4v raw[GD][2];
-                const unsigned so = (unsigned)slot * 4096u;
+                read_raw(raw, slot);
 #pragma unroll
-                for (int u = 0; u < GD; ++u)
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const unsigned ad = grow + so + (unsigned)((gpj ^ (4 * u + e)) * 16);
-                        asm volatile("ds_read_b128 %0, %1" : "=&v"(raw[u][e]) : "v"(ad) : "memory");
-                    }
-                static_assert(GD == 2, "the wait names the four registers");
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]) : : "memory");
-#pragma unroll
-                for (int u = 0; u < GD; ++u) {
-                    float v[8];
-                    const int k0 = 16 * (gi * GD + u) + 8 * hh;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const unsigned w = raw[u][e >> 2][e & 3];            /* (by value: __builtin_bit_cast of a vector ELEMENT picked element 0 every time) */
-                        v[e] = k0 + e < Pj ? __uint_as_float(w) : 0.0f;
-                    }
-                    h2_split8_scaled(v, sg, bhi[u], blo[u]);
-                }
+                for (int u = 0; u < GD; ++u) split_step(raw, gi, u, bhi[u], blo[u]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #if BGK_SBD_TS
@@ -427,6 +525,7 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
             ob = ob + 1 == ORING ? 0 : ob + 1;
             ob_in = ob_in + 1 == ORING ? 0 : ob_in + 1;
         }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                /* the copies past the end */
         __syncthreads();                                                /* the buffers are the waves' output slabs from here on */
         if (!active) return;
