@@ -76,6 +76,9 @@ _SIGNATURES = {
                                                        vp, i64, i64, i32, i32, ctypes.c_uint64, i32,
                                                        f64, f64, f64, f64, f64, f64, f64, i32,
                                                        vp, i64, vp, i32, vp, vp, vp, vp, i64, vp, i32, vp]),
+    "bgk_coupling_rqs_dense_h2_backward": (ctypes.c_int, [vp, vp, f32, vp, i32, i32, vp, i64, i64, i32, i32, i32, ctypes.c_uint64, i32,
+                                                          f64, f64, f64, f64, f64, f64, f64, i32,
+                                                          vp, i64, vp, vp, i64, vp, i64, vp, vp]),
     "bgk_coupling_affine_dense_h2": (ctypes.c_int, [vp, i64, i32, i32,
                                                     vp, vp, vp, f32, f32, f32, i32, vp, vp, vp, f32, f32, f32, i32,
                                                     i32, vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32, vp]),

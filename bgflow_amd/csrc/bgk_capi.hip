@@ -29,6 +29,11 @@ extern "C" int bgk_set_option(int32_t option, int32_t value) {
         bgk_affine_variant = value;
         return prev;
     }
+    if (option == 3 && (value == 1 || value == 2)) {
+        const int prev = bgk_rc_vjp_variant;
+        bgk_rc_vjp_variant = value;
+        return prev;
+    }
     bgk_set_error("bgk_set_option: unknown option %d / value %d", option, value);
     return BGK_EINVAL;
 }

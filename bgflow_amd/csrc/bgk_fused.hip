@@ -1244,8 +1244,9 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     const bool v2_ok = bgk_h2_variant == 2 && K == KB && ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24);
     if (segs && segs->n > 1 && !v2_ok) return BGK_EUNSUPPORTED;     /* several conditioning tensors: second-generation kernels only */
     if (params_layout == 1 && !(v2_ok && z0 != nullptr && operand_dtype == 0 && params && z1)) return BGK_EUNSUPPORTED;   /* element-major parameters: second-generation kernel only */
-    if (v2_ok && z0 != nullptr && operand_dtype == 0 && (src_col || params_layout == 1) && params && z1)   /* training forward */
-        return bgk_launch_rqs_dense_h2v2_train(what, z0, z1, params, ldp, params_layout == 1 ? nullptr : src_col, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev,
+    if (params_layout == 2 && !(v2_ok && z0 != nullptr && operand_dtype == 0 && z1)) return BGK_EUNSUPPORTED;             /* no parameter write-out: likewise */
+    if (v2_ok && z0 != nullptr && operand_dtype == 0 && (src_col || params_layout >= 1) && (params || params_layout == 2) && z1)   /* training forward */
+        return bgk_launch_rqs_dense_h2v2_train(what, z0, z1, params_layout == 2 ? nullptr : params, ldp, params_layout >= 1 ? nullptr : src_col, cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev,
                                                act, y, ldy, B, d, circ_mask, inverse, left, right, bottom, top, min_bin_width,
                                                min_bin_height, min_derivative, identity_init, out, ldo, dlogp, accumulate, bin_idx,
                                                oob_count, stream, segs);
@@ -1364,11 +1365,40 @@ extern "C" int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, i
                                                int32_t* oob_count, float* z0, float* z1, float* params, int64_t ldp,
                                                const int32_t* src_col_dev, int32_t params_layout, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
-    BGK_CHECK_ARG(params_layout == 0 || params_layout == 1, "bgk_coupling_rqs_dense_h2_train: params_layout %d (0 = the reference's columns, 1 = element-major)", params_layout);
-    BGK_CHECK_ARG(z0 && z1 && params && (src_col_dev || params_layout == 1), "bgk_coupling_rqs_dense_h2_train: null save buffer");
+    BGK_CHECK_ARG(params_layout >= 0 && params_layout <= 2, "bgk_coupling_rqs_dense_h2_train: params_layout %d (0 = the reference's columns, 1 = element-major, "
+                  "2 = not written: bgk_coupling_rqs_dense_h2_backward recomputes them)", params_layout);
+    BGK_CHECK_ARG(z0 && z1 && (params || params_layout == 2) && (src_col_dev || params_layout >= 1), "bgk_coupling_rqs_dense_h2_train: null save buffer");
     const int n_nc = d - __builtin_popcountll(circ_mask & (d >= 64 ? ~0ull : ((1ull << d) - 1)));
-    BGK_CHECK_ARG(ldp >= (params_layout == 1 ? (3 * K + 1) * d + 3 : 3 * K * d + n_nc), "bgk_coupling_rqs_dense_h2_train: params row stride %lld too small", (long long)ldp);
+    BGK_CHECK_ARG(params_layout == 2 || ldp >= (params_layout == 1 ? (3 * K + 1) * d + 3 : 3 * K * d + n_nc), "bgk_coupling_rqs_dense_h2_train: params row stride %lld too small", (long long)ldp);
     return launch_h2("bgk_coupling_rqs_dense_h2_train", cond, ldc, d_c, periodic, A0p, A1p, A2p, c0, c1, c2, cs_dev, 0, H0, H1, act, y, ldy, B, d,
                      K, circ_mask, inverse, left, right, bottom, top, min_bin_width, min_bin_height, min_derivative,
                      identity_init, out, ldo, dlogp, accumulate, nullptr, oob_count, z0, z1, params, ldp, src_col_dev, stream, nullptr, params_layout);
+}
+
+/* Backward of the spline transformer of a layer whose training forward ran with params_layout = 2 (no parameter write-out): the
+ * parameters are recomputed from the saved z1 [B, 128] (contiguous) with the forward's packed output-layer operand A2p / scale c2
+ * (cs_dev: the forward's device scale table or NULL; circ_mask as there), then the VJP of bgk_rqs_backward.  g_params [B, P] comes out in the
+ * reference's column order (slot of a non-circular dim = its rank among them), g_y [B, d]; g_absmax as in bgk_rqs_backward.  Fused envelope: hidden width 128, 8 bins, d <= 64. */
+extern "C" int bgk_coupling_rqs_dense_h2_backward(const float* z1, const void* A2p, float c2, const float* cs_dev, int32_t H1, int32_t act,
+                                                  const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K, int32_t P,
+                                                  uint64_t circ_mask, int32_t inverse,
+                                                  double left, double right, double bottom, double top,
+                                                  double min_bin_width, double min_bin_height, double min_derivative,
+                                                  int32_t identity_init, const float* g_out, int64_t ldgo, const float* g_dlogp,
+                                                  float* g_y, int64_t ldgy, float* g_params, int64_t ldgp, float* g_absmax, void* stream) {
+    if (B == 0) return 0;
+    const char* what = "bgk_coupling_rqs_dense_h2_backward";
+    BGK_CHECK_ARG(z1 && A2p && y && g_out && g_dlogp && g_y && g_params, "%s: null pointer", what);
+    BGK_CHECK_ARG(B > 0 && d > 0, "%s: bad sizes", what);
+    if (H1 != HID || K != KB || d > 64 || act < 1 || act > 3 || bgk_h2_variant != 2) {
+        bgk_set_error("%s: only hidden width 128, n_bins=8, d<=64, act in {SiLU,ReLU,Tanh} (got H1=%d K=%d d=%d act=%d)", what, H1, K, d, act);
+        return BGK_EUNSUPPORTED;
+    }
+    const int n_nc = d - __builtin_popcountll(circ_mask & (d >= 64 ? ~0ull : ((1ull << d) - 1)));
+    BGK_CHECK_ARG(P == 3 * K * d + n_nc && ldgp >= P && ldy >= d && ldgo >= d && ldgy >= d, "%s: bad widths / row strides", what);
+    BGK_CHECK_ARG(((uintptr_t)z1 & 15) == 0, "%s: z1 must be 16-byte aligned", what);
+    BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0, "Minimal bin width/height too large for the number of bins");
+    return bgk_launch_rqs_bwd_recompute(what, z1, A2p, c2, cs_dev, act, y, ldy, B, d, circ_mask, inverse, left, right, bottom, top,
+                                        min_bin_width, min_bin_height, min_derivative, identity_init, g_out, ldgo, g_dlogp, g_y, ldgy,
+                                        g_params, ldgp, g_absmax, stream);
 }

@@ -26,6 +26,15 @@ int bgk_launch_rqs_dense_h2v2_train(const char* what, float* z0, float* z1, floa
                                     float* out, int64_t ldo, float* dlogp, int32_t accumulate, int32_t* bin_idx, int32_t* oob_count,
                                     void* stream, const BgkCondSegs* segs = nullptr);
 
+/* spline backward of a layer the training forward ran WITHOUT writing its parameters (params == NULL there): the output layer of
+ * the conditioner redone from z1 on the matrix cores, bgk_rqs_vjp_element on every element (bgk_fused2_train.hip) */
+int bgk_launch_rqs_bwd_recompute(const char* what, const float* z1, const void* A2p, float c2, const float* cs_dev, int32_t act,
+                                 const float* y, int64_t ldy, int64_t B, int32_t d, uint64_t circ_mask, int32_t inverse,
+                                 double left, double right, double bottom, double top,
+                                 double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
+                                 const float* g_out, int64_t ldgo, const float* g_dlogp, float* g_y, int64_t ldgy,
+                                 float* g_params, int64_t ldgp, float* g_absmax, void* stream);
+
 /* reduced-precision mode "bf16" (bgk_fused2_bf16.hip): same kernel, one bf16 MFMA per product */
 int bgk_launch_rqs_dense_h2v2_bf16(const char* what, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                    const void* A0p, const void* A1p, const void* A2p, float c0, float c1, float c2, const float* cs_dev,
@@ -46,5 +55,8 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
 
 /* 2 (default): coupling_rqs_dense_h2v2_kernel for the split-f16 path (inference and training forward); 1: the first-generation kernel */
 extern int bgk_h2_variant;
+/* 2 (default): bgk_coupling_rqs_dense_h2_backward evaluates the element VJP's softmax / knots on the hardware exp2 / rcp forms (like the
+ * fused forward it belongs to); 1: on the deterministic forms of bgk_rqs_backward (bit-identical gradients with the saved-parameter path) */
+extern int bgk_rc_vjp_variant;
 
 #endif

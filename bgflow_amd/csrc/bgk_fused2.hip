@@ -35,6 +35,7 @@
 #endif
 #if BGK_V2_SAVE
 #include "bgk_mfma_h2.h"             /* h2_store_rows128 */
+#include "bgk_rqs_vjp.h"             /* the backward twin of the training forward (coupling_rqs_bwd_recompute_kernel) */
 #define coupling_rqs_dense_h2v2_kernel coupling_rqs_dense_h2v2_train_kernel
 #endif
 #ifndef BGK_V2_BF16
@@ -171,7 +172,7 @@ __device__ __forceinline__ void ld_pair(u32x4& hi, u32x4& lo, const uint4* base,
  * tile-step T = s * NT + m (k-step s, tile m), then NT bias tile-steps; event E = 3 T + p: p = 0 lo*hi, 1 hi*lo, 2 hi*hi
  * (small terms first), bias events one MFMA each.  The ring slot of tile-step T is refilled with T + RD right after its
  * last MFMA has been issued. */
-template <int NT, int MS = 4>                     /* MS: tiles per k-step in the packed operand (spline layers: 4; affine output layer: NT) */
+template <int NT, int MS = 4, int RDX = RD>       /* MS: tiles per k-step in the packed operand (spline layers: 4; affine output layer: NT); RDX: ring depth */
 struct Live {
     static constexpr int NTS = KS * NT;           /* product tile-steps */
     static constexpr int NEV = NPROD * NTS + NT;  /* events */
@@ -179,7 +180,7 @@ struct Live {
     const BFrag& b;
     const uint4* W;
     unsigned voff;
-    TFrag (&ring)[RD];
+    TFrag (&ring)[RDX];
 #if BGK_V2_BUF
     __amdgpu_buffer_rsrc_t rs;
 #endif
@@ -195,30 +196,30 @@ struct Live {
     /* the hi / the lo block of tile-step T alone (event order 1 refills the two halves of a ring slot at different times) */
     template <int T>
     __device__ __forceinline__ void load_hi() {
-        if constexpr (T < NTS) ring[T % RD].hi = blk<((T / NT) * MS + T % NT) * 2>();
-        else if constexpr (T < NTS + NT) ring[T % RD].hi = blk<KS * MS * 2 + (T - NTS)>();
+        if constexpr (T < NTS) ring[T % RDX].hi = blk<((T / NT) * MS + T % NT) * 2>();
+        else if constexpr (T < NTS + NT) ring[T % RDX].hi = blk<KS * MS * 2 + (T - NTS)>();
     }
     template <int T>
     __device__ __forceinline__ void load_lo() {
-        if constexpr (T < NTS) ring[T % RD].lo = blk<((T / NT) * MS + T % NT) * 2 + 1>();
+        if constexpr (T < NTS) ring[T % RDX].lo = blk<((T / NT) * MS + T % NT) * 2 + 1>();
     }
     template <int T>
     __device__ __forceinline__ void load() {
 #ifdef BGK_V2_ABL_NOLOAD     /* timing experiment: only the prologue of each GEMM loads A (wrong results) */
-        if constexpr (T >= RD) return;
+        if constexpr (T >= RDX) return;
 #endif
         if constexpr (T < NTS) {
             constexpr int s = T / NT, m = T % NT;
 #if BGK_V2_BF16
-            ring[T % RD].hi = blk<(s * MS + m) * 2>();         /* the bf16 values sit in the "hi" blocks of the same layout */
+            ring[T % RDX].hi = blk<(s * MS + m) * 2>();         /* the bf16 values sit in the "hi" blocks of the same layout */
 #elif BGK_V2_BUF
-            ring[T % RD].hi = blk<(s * MS + m) * 2>();
-            ring[T % RD].lo = blk<(s * MS + m) * 2 + 1>();
+            ring[T % RDX].hi = blk<(s * MS + m) * 2>();
+            ring[T % RDX].lo = blk<(s * MS + m) * 2 + 1>();
 #else
-            ld_pair<(s * MS + m) * 2>(ring[T % RD].hi, ring[T % RD].lo, W, voff);
+            ld_pair<(s * MS + m) * 2>(ring[T % RDX].hi, ring[T % RDX].lo, W, voff);
 #endif
         } else if constexpr (T < NTS + NT) {
-            ring[T % RD].hi = blk<KS * MS * 2 + (T - NTS)>();
+            ring[T % RDX].hi = blk<KS * MS * 2 + (T - NTS)>();
         }
     }
     template <int T0, int T1>
@@ -230,7 +231,7 @@ struct Live {
 #if BGK_V2_BUF
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);   /* raw buffer, dword3 = gfx9 default format */
 #endif
-        loads<0, RD>();
+        loads<0, RDX>();
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int E>
@@ -239,18 +240,18 @@ struct Live {
 #if BGK_V2_BF16
         if constexpr (E < NTS) {
             constexpr int T = E, s = T / NT, m = T % NT;
-            const s16x8 a = __builtin_bit_cast(s16x8, ring[T % RD].hi), bb = __builtin_bit_cast(s16x8, b.hi[s]);
+            const s16x8 a = __builtin_bit_cast(s16x8, ring[T % RDX].hi), bb = __builtin_bit_cast(s16x8, b.hi[s]);
             if constexpr (s == 0) {
                 const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, z, 0, 0, 0);
             } else {
                 out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, out[m], 0, 0, 0);
             }
-            load<T + RD>();
+            load<T + RDX>();
         } else if constexpr (E < NEV) {
             constexpr int m = E - NTS, T = NTS + m;
             const s16x8 one2 = {(short)0x3f80, (short)0x3f80, 0, 0, 0, 0, 0, 0};
-            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, ring[T % RD].hi), one2, out[m], 0, 0, 0);
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, ring[T % RDX].hi), one2, out[m], 0, 0, 0);
         }
 #elif BGK_V2_EORD
         /* event order 1: within a group of G consecutive tile-steps the products run part-major -- lo*hi of the G tiles, hi*lo of
@@ -259,10 +260,10 @@ struct Live {
          * write-back instead of using the matrix pipe's accumulator forwarding (MI355X_MICROARCH.md: +43 cycles).  The lo half of a
          * ring slot is free after the first part, the hi half after the third: they are refilled separately. */
         if constexpr (E < 3 * NTS) {
-            constexpr int G = (RD < NT ? RD : NT);
+            constexpr int G = (RDX < NT ? RDX : NT);
             static_assert(NTS % G == 0, "groups tile the product tile-steps");
             constexpr int grp = E / (3 * G), rem = E % (3 * G), p = rem / G, T = grp * G + rem % G, s = T / NT, m = T % NT;
-            const TFrag& f = ring[T % RD];
+            const TFrag& f = ring[T % RDX];
             const h16x8 a = __builtin_bit_cast(h16x8, p == 0 ? f.lo : f.hi);
             const h16x8 bb = p == 1 ? b.lo[s] : b.hi[s];
             if constexpr (s == 0 && p == 0) {
@@ -271,17 +272,17 @@ struct Live {
             } else {
                 out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bb, out[m], 0, 0, 0);
             }
-            if constexpr (p == 0) load_lo<T + RD>();
-            if constexpr (p == 2) load_hi<T + RD>();
+            if constexpr (p == 0) load_lo<T + RDX>();
+            if constexpr (p == 2) load_hi<T + RDX>();
         } else if constexpr (E < NEV) {
             constexpr int m = E - 3 * NTS, T = NTS + m;
             const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
-            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[T % RD].hi), one2, out[m], 0, 0, 0);
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[T % RDX].hi), one2, out[m], 0, 0, 0);
         }
 #else
         if constexpr (E < 3 * NTS) {
             constexpr int T = E / 3, p = E % 3, s = T / NT, m = T % NT;
-            const TFrag& f = ring[T % RD];
+            const TFrag& f = ring[T % RDX];
             const h16x8 a = __builtin_bit_cast(h16x8, p == 0 ? f.lo : f.hi);
             const h16x8 bb = p == 1 ? b.lo[s] : b.hi[s];
             if constexpr (s == 0 && p == 0) {
@@ -290,11 +291,11 @@ struct Live {
             } else {
                 out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bb, out[m], 0, 0, 0);
             }
-            if constexpr (p == 2) load<T + RD>();
+            if constexpr (p == 2) load<T + RDX>();
         } else if constexpr (E < NEV) {
             constexpr int m = E - 3 * NTS, T = NTS + m;
             const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
-            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[T % RD].hi), one2, out[m], 0, 0, 0);
+            out[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[T % RDX].hi), one2, out[m], 0, 0, 0);
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
@@ -760,6 +761,7 @@ __device__ __forceinline__ void save_chunk_params(const V2Args& a, const float* 
 #ifdef BGK_V2_ABL_NOPSAVE      /* timing experiment: the parameters are not written (wrong gradients) */
     return;
 #endif
+    if (a.params == nullptr) return;      /* the backward recomputes them from z1 (coupling_rqs_bwd_recompute_kernel below) */
     if (a.src_col == nullptr) {
         /* element-major layout [B][d][3 K + 1] (round 5): the chunk's rows ARE that order, so a sample's share of the chunk is one
          * contiguous run of DPC * PPD = 125 floats -- 32 lanes x 16 bytes, two sample rows per store instruction, 16 instructions
@@ -1437,10 +1439,313 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
 }
 #endif   /* affine layer */
 
+#if BGK_V2_SAVE
+/* ---- spline backward of a fused training layer with the parameters RECOMPUTED (round 5) ------------------------------------------
+ * The training forward wrote the layer's 3 K + 1 = 25 spline parameters per element for the backward: 446 MB per layer at 2^18
+ * samples x 17 dims, 0.11 of its 0.27 ms (the write-out does not overlap: stores and operand loads share one in-order counter),
+ * and bgk_rqs_backward read them back.  They are one GEMM away from z1, which is saved anyway (the weight-gradient and input-gradient
+ * kernels need it): this kernel redoes the conditioner's output layer on the matrix cores -- the SAME operand blocks, activation,
+ * f16 split and MFMA event order as the forward (Live<>, act_split_tile: the parameters come out bit-identical) -- chunk by chunk
+ * into the LDS chunk buffer, and runs bgk_rqs_vjp_element (the arithmetic of bgk_rqs_backward) on every element of the chunk from
+ * there.  Reads z1 (512 B / sample) + y, g_out, g_dlogp; writes g_params in the reference's column order (what
+ * bgk_dense_backward_dx and bgk_dense_weight_grad read) and g_y.  nn/flow/transformer/spline.py:109-188 + nn/dense.py:47-48. */
+struct RcArgs {
+    const float* z1; const uint4* A2; float c2; const float* cs_dev; int n_chunks, last_tiles;
+    const float* y; int64_t ldy; int64_t B; int d; uint64_t nc_mask; int inverse;      /* nc_mask: bit per non-circular dim (its slot = its rank among them) */
+    const float* g_out; int64_t ldgo; const float* g_dlogp; float* g_y; int64_t ldgy; float* g_params; int64_t ldgp;
+    float* g_absmax; BgkRqsCfg cfg; int lds_per_wave;
+};
+
+typedef float rc_f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+/* slot IT of chunk c: element q = 2 IT + hh of sample j (the forward's assignment, spline_slot); invalid slots work on dim 0 of
+ * the chunk and write nothing */
+/* -DBGK_RC_TS=1: s_memtime phase sums of a wave's tile (chunk -> LDS | VJP | next GEMM | gradient stores), written over g_y[b0][0..7] */
+#ifndef BGK_RC_TS
+#define BGK_RC_TS 0
+#endif
+#ifndef BGK_RC_REV
+#define BGK_RC_REV 0
+#endif
+#ifndef BGK_RC_RD
+#define BGK_RC_RD 4           /* (6 / 8: the allocator parks 38 / 54 registers of the B operand in scratch and reloads them inside the VJP) */
+#endif
+#ifndef BGK_RC_EARLY_START
+#define BGK_RC_EARLY_START 0  /* 1: the next GEMM's first ring slots are requested in front of the VJP instead of behind it */
+#endif
+#if BGK_RC_TS
+#define RC_Q(v) do { __builtin_amdgcn_sched_barrier(0); v = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RC_ADD(acc, t1, t0) acc += (t1) - (t0)
+#else
+#define RC_Q(v) do { } while (0)
+#define RC_ADD(acc, t1, t0) do { } while (0)
+#endif
+struct RcTs { unsigned lds, vjp, gemm, st; };
+struct RcIn { float x, gy; };      /* the element's input and output cotangent, requested one slot ahead */
+/* Memory operations of this kernel and the one in-order counter (vmcnt: loads AND stores).  The compiler's wait for a load allows
+ * exactly the operations it KNOWS were issued after it; a conditionally issued one in between (a store under an exec-mask branch, a
+ * uniform `if` around a slot) makes that number uncertain and the wait becomes vmcnt(0) -- a wait for every store before it as well,
+ * i.e. for the HBM write round trip of the previous chunk's 16 KB of gradients (first form of this kernel: 66 k of a tile's 165 k
+ * cycles).  Hence: every global access here is unconditional (buffer descriptors of the tile: lanes with nothing to read or write
+ * point out of range), the slot count of a chunk is a template parameter (straight-line code between a request and its use), the
+ * slot table of the non-circular dims is a bit mask (no load), and the first slot's inputs are consumed BEFORE the chunk's store
+ * pass is issued. */
+struct RcTile { __amdgpu_buffer_rsrc_t y, go, gy, gp; int oy, ogo, ogy; };
+constexpr int RC_OOB = 0x7ffffff0;
+__device__ __forceinline__ RcIn rc_request(const RcTile& t, int c, int it, int nd, int hh) {
+    const int q = 2 * it + hh, dim = c * DPC + (q < nd ? q : 0);
+    return RcIn{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.y, t.oy + dim * 4, 0, 0)),
+                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(t.go, t.ogo + dim * 4, 0, 0))};
+}
+
+/* slot IT of chunk c: element q = 2 IT + hh of sample j (the forward's assignment, spline_slot); invalid slots work on dim 0 of the
+ * chunk and write nothing.  MORE: another slot of this chunk follows (its inputs are requested here); otherwise the first slot of
+ * chunk c + 1 (requested here as well, past the last chunk: dim 0 again, never used). */
+template <int IT, bool MORE, bool FAST>
+__device__ __forceinline__ void rc_vjp_slot(const RcArgs& a, const RcTile& tl, float* s_p, int c, int nd, int hh, int j, int rows, float gl, float& gmax, RcIn& in) {
+    const int q = 2 * IT + hh;
+    const bool valid = q < nd && j < rows;
+    const int qq = q < nd ? q : 0;
+    const int dim = c * DPC + qq, d = a.d;
+    const float x = in.x, gy = in.gy;
+    {   /* the next slot's inputs travel while this one computes */
+        const int cn = MORE ? c : (c + 1 < a.n_chunks ? c + 1 : 0), itn = MORE ? IT + 1 : 0;
+        const int ndn = MORE ? nd : ((d - cn * DPC) < DPC ? (d - cn * DPC) : DPC);
+        in = rc_request(tl, cn, itn, ndn, hh);
+    }
+    float* pe = s_p + (qq * PPD) * ST + j;
+    const bool has_slot = (a.nc_mask >> dim) & 1ull;
+    float gx;
+    /* the spline constants, opaque per slot: the VJP forms ~20 products and sums of them (the knots' base terms low + span min (k + 1),
+     * scale factors, 1 / beta ..) that are the same for every element -- hoisted out of the chunk loop they are 20 more live
+     * registers, which went to scratch (every scratch reload: a vmcnt(0)); recomputed per slot they are 20 instructions of ~700 */
+    BgkRqsCfg cf = a.cfg;
+    asm volatile("" : "+s"(cf.left), "+s"(cf.right), "+s"(cf.bottom), "+s"(cf.top), "+s"(cf.xspan), "+s"(cf.yspan));
+    asm volatile("" : "+s"(cf.min_w), "+s"(cf.min_h), "+s"(cf.min_d), "+s"(cf.w_scale), "+s"(cf.h_scale), "+s"(cf.beta));
+    /* (the gradients take the parameters' places in the chunk: every lane rewrites what it alone read) */
+    const float m = bgk_rqs_vjp_element_lds<KB, FAST>(cf, a.inverse, pe, ST, a.c2, has_slot, q < nd, x, gy, gl, gx);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gx), tl.gy, valid ? tl.ogy + dim * 4 : RC_OOB, 0, 0);
+    gmax = valid ? __builtin_fmaxf(gmax, m) : gmax;
+}
+
+/* the chunk's gradients, LDS -> g_params in the reference's column order [w | h | s | slots]: 16-byte pieces (row r, dim q, set t,
+ * half e) = chunk rows 25 q + 8 t + 4 e .. + 3 of column r; an instruction writes the <= 30 pieces of two sample rows.  Issued BEHIND
+ * the next chunk's GEMM: its operand loads then have no stores in front of them (one in-order counter for loads and stores), and the
+ * stores drain while the next chunk's VJP computes. */
+__device__ __forceinline__ void rc_store_chunk(const RcArgs& a, const RcTile& tl, const float* s_p, int c, int nd, int lane, int rows) {
+    const int p = lane & 31, half = lane >> 5, d = a.d;
+    const int q = p / 6, te = p - 6 * q, t = te >> 1, e = te & 1;
+    const bool mine = p < 6 * nd;
+    const float* src = s_p + ((mine ? q : 0) * PPD + 8 * t + 4 * e) * ST;
+    const int col = t * d * KB + (c * DPC + q) * KB + 4 * e;
+    /* buffer stores on a descriptor of the tile's rows: a 32-bit offset per lane instead of a 64-bit address per store (sixteen address
+     * pairs spilled to scratch here otherwise -- and every scratch reload is a vmcnt(0)); rows past the batch are out of range */
+    const int vo = mine ? col * 4 : RC_OOB;
+    const int pitch = (int)a.ldgp * 4;
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += 8) {           /* four row pairs per round: 16 LDS reads in flight, then 4 stores */
+        rc_f4u v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 2 * u + half;
+            v[u] = (rc_f4u){src[r], src[ST + r], src[2 * ST + r], src[3 * ST + r]};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[u]), tl.gp, vo, (r0 + 2 * u + half) * pitch, 0);
+    }
+    /* the non-circular dims' slot gradients: lane -> (row lane & 31, dims 2 i + (lane >> 5)); three rounds whatever nd */
+    const int r = lane & 31;
+#pragma unroll
+    for (int q0 = 0; q0 < 6; q0 += 2) {
+        const int qs = q0 + half, dim = c * DPC + qs;
+        const bool has = qs < nd && ((a.nc_mask >> dim) & 1ull);
+        const int slot = __builtin_popcountll(a.nc_mask & ((1ull << dim) - 1ull));
+        const float v = s_p[((qs < nd ? qs : 0) * PPD + 3 * KB) * ST + r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), tl.gp, has ? r * pitch + (3 * d * KB + slot) * 4 : RC_OOB, 0, 0);
+    }
+}
+
+/* chunk c (in h; NS slots): h -> LDS, the VJP of the chunk's elements (gradients back into the chunk), the next chunk's GEMM (NT tiles
+ * per k-step; 0: none), then the chunk's gradients out */
+constexpr int RC_RD = BGK_RC_RD;      /* A-fragment ring depth of this kernel's GEMMs: nothing is threaded through them here, so a tile-step costs operand
+                                       * latency / ring depth (depth 4: 8 k of a 100-event GEMM's 11 k cycles are waits) */
+template <int NT, int NS, bool FAST>
+__device__ __forceinline__ void rc_chunk(const RcArgs& a, const RcTile& tl, float* s_p, int c, int nd, int lane_in, int rows, float gl, float& gmax, RcIn& in,
+                                         f32x16 (&h)[4], const BFrag& bf, TFrag (&ring)[RC_RD], unsigned voff, RcTs& ts) {
+    /* the lane index is made opaque per chunk: otherwise every per-lane address of the chunk body (75 parameter reads and write-backs,
+     * the store pass) is hoisted out of the chunk loop as a loop invariant and spilled (72 registers) -- and scratch reloads are
+     * vmcnt(0) waits */
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int j = lane & 31, hh = lane >> 5;
+    Live<(NT > 0 ? NT : 4), 4, RC_RD> g{h, bf, a.A2 + (size_t)(c + 1) * GBLK * 64, voff, ring};
+#if BGK_RC_TS
+    unsigned t0, t1, t2, t3, t4;
+#endif
+    RC_Q(t0);
+    chunk_to_lds(h, s_p, hh, j);
+#if BGK_RC_EARLY_START
+    if constexpr (NT > 0) g.start();
+#endif
+    RC_Q(t1); RC_ADD(ts.lds, t1, t0);
+    __builtin_amdgcn_sched_barrier(0);     /* (the slots one after the other: interleaved by the scheduler they need twice the registers) */
+    rc_vjp_slot<0, (NS > 1), FAST>(a, tl, s_p, c, nd, hh, j, rows, gl, gmax, in);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NS > 1) rc_vjp_slot<1, (NS > 2), FAST>(a, tl, s_p, c, nd, hh, j, rows, gl, gmax, in);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NS > 2) rc_vjp_slot<2, false, FAST>(a, tl, s_p, c, nd, hh, j, rows, gl, gmax, in);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    RC_Q(t2); RC_ADD(ts.vjp, t2, t1);
+#if !BGK_RC_EARLY_START
+    if constexpr (NT > 0) g.start();      /* (behind the VJP: the ring's registers are not live across it) */
+#endif
+    if constexpr (NT > 0) g.template events<0, Live<(NT > 0 ? NT : 4), 4, RC_RD>::NEV>();
+    asm volatile("" : "+v"(in.x), "+v"(in.gy));      /* the next chunk's first inputs are awaited here, in front of the stores below */
+    RC_Q(t3); RC_ADD(ts.gemm, t3, t2);
+    rc_store_chunk(a, tl, s_p, c, nd, lane, rows);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    RC_Q(t4); RC_ADD(ts.st, t4, t3);
+}
+
+template <int ACT, bool FAST>
+__global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_bwd_recompute_kernel(RcArgs a) {
+    if (a.cs_dev) a.c2 = a.cs_dev[5];
+#if BGK_V2_OVFL
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");                 /* MODE.FP16_OVFL, as in the forward */
+#endif
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      /* uniform: the tile's row bases live in scalar registers */
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* first the z1 tile [32][128] (16-byte pieces XOR-swizzled by the row), then the parameter chunks [128][ST] */
+    const int64_t n_tiles = (a.B + 31) / 32;
+#if BGK_RC_REV
+    const int64_t tile = n_tiles - 1 - ((int64_t)blockIdx.x * FW + wave);      /* last tiles first: the consumers start with the rows written last */
+    if (tile < 0) return;
+#else
+    const int64_t tile = (int64_t)blockIdx.x * FW + wave;
+    if (tile >= n_tiles) return;
+#endif
+    const int lane = (int)threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
+    const unsigned voff = (unsigned)lane * 16u;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    RcTs ts{0u, 0u, 0u, 0u};
+#if BGK_RC_TS
+    unsigned q0, q1, q2, q3;
+#endif
+    RC_Q(q0);
+
+    /* z1 tile by DMA: instruction i = rows 2 i, 2 i + 1; lane -> row 2 i + (lane >> 5), 16-byte piece (lane & 31) ^ (row & 15) of it.
+     * A lane then reads pieces 8 m + 2 q + hh of row j (accumulator layout: rows 32 m + 8 q + 4 hh .. + 3 of the layer output). */
+    {
+        const float* zt = a.z1 + b0 * 128;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 2 * i + (lane >> 5), rr = row < rows ? row : 0;
+            const int piece = (lane & 31) ^ (row & 15);
+            __builtin_amdgcn_global_load_lds((gvp_t)(zt + rr * 128 + piece * 4), (lvp_t)(s_p + i * 256), 16, 0, 0);
+        }
+    }
+    f32x16 h[4];
+    TFrag ring[RC_RD];
+    BFrag bf;
+    Live<4, 4, RC_RD> g0{h, bf, a.A2, voff, ring};
+    g0.start();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RC_Q(q1);
+    {
+        f32x16 z[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int piece = (8 * m + 2 * q + hh) ^ (j & 15);
+                const float4 v = *reinterpret_cast<const float4*>(s_p + j * 128 + piece * 4);
+                z[m][4 * q] = v.x; z[m][4 * q + 1] = v.y; z[m][4 * q + 2] = v.z; z[m][4 * q + 3] = v.w;
+            }
+        NoLive none;
+        act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, z[0], 1.0f, bf);
+        act_split_tile<ACT, 1>(Hooks<NoLive, 0, 1>{none}, z[1], 1.0f, bf);
+        act_split_tile<ACT, 2>(Hooks<NoLive, 0, 1>{none}, z[2], 1.0f, bf);
+        act_split_tile<ACT, 3>(Hooks<NoLive, 0, 1>{none}, z[3], 1.0f, bf);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();             /* every lane has its z1 values: the tile's space takes the parameter chunks */
+    RC_Q(q2);
+    g0.template events<0, Live<4, 4, RC_RD>::NEV>();
+    RC_Q(q3);
+    const int jr = j < rows ? j : rows - 1;
+    const float gl = (a.g_dlogp + b0)[jr];
+    float gmax = 0.0f;
+    const RcTile tl{__builtin_amdgcn_make_buffer_rsrc((void*)(a.y + b0 * a.ldy), 0, (int)(rows * a.ldy * 4), 0x00020000),
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(a.g_out + b0 * a.ldgo), 0, (int)(rows * a.ldgo * 4), 0x00020000),
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(a.g_y + b0 * a.ldgy), 0, (int)(rows * a.ldgy * 4), 0x00020000),
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(a.g_params + b0 * a.ldgp), 0, (int)(rows * a.ldgp * 4), 0x00020000),
+                    jr * (int)a.ldy * 4, jr * (int)a.ldgo * 4, j * (int)a.ldgy * 4};
+    RcIn in = rc_request(tl, 0, 0, a.d < DPC ? a.d : DPC, hh);
+    for (int c = 0; c + 1 < a.n_chunks; ++c) {       /* whole chunks: 5 dims, 3 slots */
+        if (c + 2 < a.n_chunks || a.last_tiles > 2) rc_chunk<4, 3, FAST>(a, tl, s_p, c, DPC, lane, rows, gl, gmax, in, h, bf, ring, voff, ts);
+        else rc_chunk<2, 3, FAST>(a, tl, s_p, c, DPC, lane, rows, gl, gmax, in, h, bf, ring, voff, ts);
+    }
+    {
+        const int c = a.n_chunks - 1, nd = a.d - c * DPC;
+        if (nd > 4) rc_chunk<0, 3, FAST>(a, tl, s_p, c, nd, lane, rows, gl, gmax, in, h, bf, ring, voff, ts);
+        else if (nd > 2) rc_chunk<0, 2, FAST>(a, tl, s_p, c, nd, lane, rows, gl, gmax, in, h, bf, ring, voff, ts);
+        else rc_chunk<0, 1, FAST>(a, tl, s_p, c, nd, lane, rows, gl, gmax, in, h, bf, ring, voff, ts);
+    }
+    bgk_publish_absmax(a.g_absmax, gmax);
+#if BGK_RC_TS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned q4;
+    RC_Q(q4);
+    if (lane == 0) {
+        unsigned* o = reinterpret_cast<unsigned*>(a.g_y + b0 * a.ldgy);
+        o[0] = q1 - q0; o[1] = q2 - q1; o[2] = q3 - q2; o[3] = ts.lds; o[4] = ts.vjp; o[5] = ts.gemm; o[6] = ts.st; o[7] = q4 - q0;
+    }
+#endif
+}
+#endif
+
 }  // namespace
 
 #if !BGK_V2_SAVE && !BGK_V2_BF16
 int bgk_h2_variant = 2;
+#endif
+
+#if BGK_V2_SAVE
+int bgk_rc_vjp_variant = 2;      /* 2 (default): the element VJP's knots on the hardware forms (BGK_VJP_FAST); 1: the deterministic forms of bgk_rqs_backward */
+int bgk_launch_rqs_bwd_recompute(const char* what, const float* z1, const void* A2p, float c2, const float* cs_dev, int32_t act,
+                                 const float* y, int64_t ldy, int64_t B, int32_t d, uint64_t circ_mask, int32_t inverse,
+                                 double left, double right, double bottom, double top,
+                                 double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
+                                 const float* g_out, int64_t ldgo, const float* g_dlogp, float* g_y, int64_t ldgy,
+                                 float* g_params, int64_t ldgp, float* g_absmax, void* stream) {
+    RcArgs a;
+    a.z1 = z1; a.A2 = reinterpret_cast<const uint4*>(A2p); a.c2 = c2; a.cs_dev = cs_dev;
+    a.n_chunks = (d + DPC - 1) / DPC;
+    a.last_tiles = ((d - (a.n_chunks - 1) * DPC) * PPD + 31) / 32;
+    a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.nc_mask = ~circ_mask & (d >= 64 ? ~0ull : ((1ull << d) - 1ull)); a.inverse = inverse;
+    BGK_CHECK_ARG(ldy < (1 << 24) && ldgo < (1 << 24) && ldgy < (1 << 24) && ldgp < (1 << 24), "%s: row stride too large", what);
+    a.g_out = g_out; a.ldgo = ldgo; a.g_dlogp = g_dlogp; a.g_y = g_y; a.ldgy = ldgy; a.g_params = g_params; a.ldgp = ldgp;
+    a.g_absmax = g_absmax;
+    a.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, KB);
+    a.lds_per_wave = ((128 * ST + 3) / 4) * 4;
+    static_assert(128 * ST >= 32 * 128, "the chunk buffer holds the z1 tile");
+    const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
+    const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
+    hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCH(A, F) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coupling_rqs_bwd_recompute_kernel<A, F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                              hipLaunchKernelGGL((coupling_rqs_bwd_recompute_kernel<A, F>), dim3((int)n_wg), dim3(FTHREADS), shmem, st, a); } while (0)
+#define BGK_LAUNCH_F(A) do { if (bgk_rc_vjp_variant == 1) BGK_LAUNCH(A, false); else BGK_LAUNCH(A, true); } while (0)
+    if (act == 1) BGK_LAUNCH_F(1); else if (act == 2) BGK_LAUNCH_F(2); else BGK_LAUNCH_F(3);
+#undef BGK_LAUNCH_F
+#undef BGK_LAUNCH
+    return bgk_launch_status(what);
+}
 #endif
 
 #if BGK_V2_SAVE

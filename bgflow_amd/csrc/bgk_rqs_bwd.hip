@@ -34,16 +34,6 @@ struct RqsBwdArgs {
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int BWD_TS = 128;
 
-/* the wave's largest gradient magnitude -> dst[0] (non-negative floats order like their bit patterns; NaNs do not take part: the
- * maximum describes the finite values the consumers scale) */
-__device__ __forceinline__ void publish_absmax(float* dst, float m) {
-    if (dst == nullptr) return;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
-    const unsigned mb = __builtin_bit_cast(unsigned, m);
-    if ((threadIdx.x & 63) == 0 && mb > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), mb);
-}
-
 /* PACKED: the parameters arrive element-major, [B][d][3 K + 1] (what the fused training forward writes since round 5: an element's
  * widths | heights | slopes | slot in one 100-byte run); the gradients leave in the reference's column order either way */
 template <int KT, bool PACKED = false>
@@ -97,7 +87,7 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_kernel(RqsBwdArgs a) {
             }
         }
     }
-    publish_absmax(a.g_absmax, gmax);
+    bgk_publish_absmax(a.g_absmax, gmax);
 }
 
 /* ---- any bin count: every lane walks the 3 K (+1) parameters of ITS element in memory (the backward twin of rqs_direct_kernel,
@@ -157,7 +147,7 @@ __global__ __launch_bounds__(BWD_THREADS) void rqs_bwd_direct_kernel(RqsBwdArgs 
             if (has_slot) grow[(int64_t)3 * d * K + slot] = hi_last ? b.g1 : 0.0f;
         }
     }
-    publish_absmax(a.g_absmax, gmax);
+    bgk_publish_absmax(a.g_absmax, gmax);
 }
 
 }  // namespace

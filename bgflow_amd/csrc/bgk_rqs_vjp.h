@@ -7,6 +7,16 @@
 
 #include "bgk_common.h"
 
+/* the wave's largest gradient magnitude -> dst[0] (non-negative floats order like their bit patterns; NaNs do not take part: the
+ * maximum describes the finite values the consumers scale) */
+__device__ __forceinline__ void bgk_publish_absmax(float* dst, float m) {
+    if (dst == nullptr) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+    const unsigned mb = __builtin_bit_cast(unsigned, m);
+    if ((threadIdx.x & 63) == 0 && mb > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(reinterpret_cast<unsigned*>(dst), mb);
+}
+
 /* softmax probabilities p[k] and the K+1 knots of one parameter set */
 template <int KT>
 __device__ __forceinline__ void bgk_softmax_knots(const float (&u)[KT], float mn, float sc, float span, float low, float high,
@@ -225,6 +235,85 @@ __device__ __forceinline__ void bgk_rqs_vjp_element(const BgkRqsCfg& c, int inve
             os[k] = g;
         }
     }
+}
+
+/* The same VJP for an element whose parameters sit in LDS: u[k * st] (k = 0 .. 3 K: widths | heights | slopes | slot row; true
+ * parameter = value * c2) and whose gradients take their places.  Operation for operation the arithmetic of bgk_rqs_vjp_element
+ * (identical results with FAST = BGK_VJP_FAST) -- but a parameter set is in registers only while its softmax runs, the two slopes of the bin are READ at their
+ * (run-time) row instead of selected out of eight registers, and the gradients are written where they are formed: ~50 live
+ * registers instead of ~110 (bgk_fused2.hip::coupling_rqs_bwd_recompute_kernel holds a 64-register B operand across this).
+ * `wr`: the lane writes (false: an invalid slot working on a duplicate).  Returns the largest gradient magnitude. */
+template <int K, bool FAST>
+__device__ __forceinline__ float bgk_rqs_vjp_element_lds(const BgkRqsCfg& c, int inverse, float* u, int st, float c2, bool has_slot, bool wr,
+                                                        float x, float gy, float gl, float& gx_out) {
+    float pw[K], ph[K], cw[K + 1], ch[K + 1];
+    {
+        float r[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) r[k] = u[k * st] * c2;
+        if constexpr (FAST) bgk_softmax_knots_fast<K>(r, c.min_w, c.w_scale, c.xspan, c.left, c.right, pw, cw);       /* (see BGK_VJP_FAST) */
+        else bgk_softmax_knots<K>(r, c.min_w, c.w_scale, c.xspan, c.left, c.right, pw, cw);
+    }
+    {
+        float r[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) r[k] = u[(K + k) * st] * c2;
+        if constexpr (FAST) bgk_softmax_knots_fast<K>(r, c.min_h, c.h_scale, c.yspan, c.bottom, c.top, ph, ch);
+        else bgk_softmax_knots<K>(r, c.min_h, c.h_scale, c.yspan, c.bottom, c.top, ph, ch);
+    }
+    const bool clamped = (x < c.left) | (x > c.right);
+    x = x < c.left ? c.left : (x > c.right ? c.right : x);
+    int idx = -1;
+#pragma unroll
+    for (int k = 0; k <= K; ++k) {
+        float kn = inverse ? cw[k] : ch[k];
+        if (k == K) kn = kn + 1e-6f;
+        idx += (x >= kn) ? 1 : 0;
+    }
+    idx = idx < 0 ? 0 : (idx > K - 1 ? K - 1 : idx);
+    const bool hi_last = (idx + 1 == K);
+    float cw_i = cw[0], cw_n = cw[1], ch_i = ch[0], ch_n = ch[1];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        cw_i = (idx == k) ? cw[k] : cw_i; cw_n = (idx == k) ? cw[k + 1] : cw_n;
+        ch_i = (idx == k) ? ch[k] : ch_i; ch_n = (idx == k) ? ch[k + 1] : ch_n;
+    }
+    const float s_lo = u[(2 * K + idx) * st] * c2;
+    const float s_hi = u[(hi_last ? (has_slot ? 3 * K : 2 * K) : 2 * K + idx + 1) * st] * c2;
+    const BgkVjpBin b = bgk_rqs_vjp_bin(c, inverse, x, cw_i, cw_n, ch_i, ch_n, s_lo, s_hi, gy, gl);
+    gx_out = clamped ? 0.0f : b.gx;
+    float gm = 0.0f;
+    {
+        const float gA = (idx >= 1) ? (b.G_cw - b.G_W) : 0.0f, gB = (idx + 1 <= K - 1) ? b.G_W : 0.0f;
+        float gp[K], dot = 0.0f;
+#pragma unroll
+        for (int m = 0; m < K; ++m) { gp[m] = c.w_scale * c.xspan * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f)); dot += pw[m] * gp[m]; }
+#pragma unroll
+        for (int m = 0; m < K; ++m) { const float o = pw[m] * (gp[m] - dot); gm = __builtin_fmaxf(gm, __builtin_fabsf(o)); if (wr) u[m * st] = o; }
+    }
+    {
+        const float gA = (idx >= 1) ? (b.G_ch - b.G_H) : 0.0f, gB = (idx + 1 <= K - 1) ? b.G_H : 0.0f;
+        float gp[K], dot = 0.0f;
+#pragma unroll
+        for (int m = 0; m < K; ++m) { gp[m] = c.h_scale * c.yspan * ((m < idx ? gA : 0.0f) + (m <= idx ? gB : 0.0f)); dot += ph[m] * gp[m]; }
+#pragma unroll
+        for (int m = 0; m < K; ++m) { const float o = ph[m] * (gp[m] - dot); gm = __builtin_fmaxf(gm, __builtin_fabsf(o)); if (wr) u[(K + m) * st] = o; }
+    }
+    {
+        /* slopes: zeros, then the bin's two entries (0 + g: the sums of bgk_rqs_vjp_element, which turn -0 into +0) */
+        const float g0 = 0.0f + b.g0, g1 = 0.0f + b.g1;
+        const float g_slot = (has_slot && hi_last) ? b.g1 : 0.0f;
+        gm = __builtin_fmaxf(gm, __builtin_fmaxf(__builtin_fabsf(g0), __builtin_fabsf(g1)));       /* (g1 lands in a slope row or in the slot) */
+        if (wr) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) u[(2 * K + k) * st] = 0.0f;
+            u[3 * K * st] = g_slot;
+            u[(2 * K + idx) * st] = g0;
+            if (!hi_last) u[(2 * K + idx + 1) * st] = g1;
+            else if (!has_slot) u[2 * K * st] = g1;
+        }
+    }
+    return gm;
 }
 
 /* ---- any bin count: the element's parameters stay in memory and are walked (bgk_rqs_bwd.hip::rqs_bwd_direct_kernel) -------------

@@ -801,6 +801,8 @@ def _featurise(x, periodic):
 
 HALF_PAD_ROWS = int(os.environ.get("BGK_HALF_PAD_ROWS", "0"))      # rows of padding between the [B, 128] halves of one allocation
 PACKED_PARAMS = os.environ.get("BGK_PACKED_PARAMS", "1") != "0"   # the fused training forward saves the spline parameters element-major
+# ... or not at all (round 5): bgk_coupling_rqs_dense_h2_backward recomputes them from z1 with the forward's operands (bit-identical)
+RECOMPUTE_PARAMS = os.environ.get("BGK_RECOMPUTE_PARAMS", "1") != "0"
 
 FUSED_MLP_BACKWARD = True    # input-gradient chain of the conditioner on bgk_dense_backward_dx (False: three GEMMs + torch act ops)
 
@@ -979,10 +981,11 @@ def _train_forward_launch(x, y, W2, plan, tcfg, inverse, oob, dlogp=None, accumu
 
     def launch(layout):
         # layout 1: the parameters element-major [B, d (3 K + 1)] -- the kernel's own order, written as 16-byte pieces of contiguous
-        # runs (PACKED_PARAMS; bgk_rqs_backward reads that layout); layout 0: the reference's column order [B, P]
+        # runs (PACKED_PARAMS; bgk_rqs_backward reads that layout); layout 0: the reference's column order [B, P]; layout 2: not
+        # written at all (RECOMPUTE_PARAMS; the backward redoes the output layer from z1)
         width = d * (3 * plan["n_bins"] + 1) if layout else P
-        ldp = param_pitch(width + 3) if layout else param_pitch(P)
-        params = torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :width]
+        ldp = 0 if layout == 2 else (param_pitch(width + 3) if layout else param_pitch(P))
+        params = None if layout == 2 else torch.empty((B, ldp), dtype=torch.float32, device=dev)[:, :width]
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_coupling_rqs_dense_h2_train(
                 _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1, c2,
@@ -992,8 +995,11 @@ def _train_forward_launch(x, y, W2, plan, tcfg, inverse, oob, dlogp=None, accumu
                 _lib.ptr(z0), _lib.ptr(z1), _lib.ptr(params), ldp, _lib.ptr(plan["src_col_dev"]), layout, _lib.stream_ptr(dev))
         return st, params
 
-    st, params = launch(1) if (PACKED_PARAMS and plan["n_bins"] == 8) else (-2, None)
-    plan["params_packed"] = st == 0   # (the layout of the tensor just written: _LayerCtx hands it to the backward)
+    st, params = launch(2) if (RECOMPUTE_PARAMS and plan["n_bins"] == 8) else (-2, None)
+    plan["params_recompute"] = st == 0
+    if st == -2:
+        st, params = launch(1) if (PACKED_PARAMS and plan["n_bins"] == 8) else (-2, None)
+    plan["params_packed"] = st == 0 and params is not None   # (the layout of the tensor just written: _LayerCtx hands it to the backward)
     if st == -2:                      # (BGK_EUNSUPPORTED: the first-generation kernel runs this layer)
         st, params = launch(0)
     _lib.check(st, "bgk_coupling_rqs_dense_h2_train")
@@ -1002,7 +1008,7 @@ def _train_forward_launch(x, y, W2, plan, tcfg, inverse, oob, dlogp=None, accumu
 
 class _LayerCtx:
     """what the backward of one fused training layer needs besides its saved tensors"""
-    __slots__ = ("params", "cs", "tbufs", "t_version", "act", "periodic", "rcfg", "packed")
+    __slots__ = ("params", "cs", "tbufs", "t_version", "act", "periodic", "rcfg", "packed", "recompute")
 
     def __init__(self, params, plan, tcfg, inverse, t_version):
         left, right, bottom, top, s = tcfg
@@ -1016,6 +1022,9 @@ class _LayerCtx:
         self.act, self.periodic = plan["act"], bool(plan["periodic"])
         self.rcfg = (plan["n_bins"], inverse, left, right, bottom, top, dict(s))
         self.packed = bool(plan.get("params_packed"))        # layout of the parameters the forward launch (just before this) saved
+        # ... or (A2 operand, c2) of that launch when it saved none: the backward recomputes them (the packed operands of a plan are
+        # replaced, not rewritten, when the weights change -- holding them here keeps the forward's blocks alive until the backward)
+        self.recompute = (plan["packed"][2], plan["packed"][3][2], plan["circ_mask"]) if plan.get("params_recompute") else None
 
 
 def _train_backward_layer(lc, x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g_dlogp, need_gx, need_w, gx_add=None, gx_out=None,
@@ -1035,7 +1044,10 @@ def _train_backward_layer(lc, x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g
     # backward GEMMs split these gradients into f16 hi + lo operand pairs (f32-class products whatever the loss scale)
     if absmax is None:
         absmax = torch.zeros(3, dtype=torch.float32, device=y.device)
-    g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp, absmax=absmax, packed_width=W2.shape[0] if lc.packed else None)
+    if lc.recompute is not None:
+        g_y, g_p = _rqs_backward_recompute(lc, y, z1, W2.shape[0], nc_dev, g_out, g_dlogp, absmax)
+    else:
+        g_y, g_p = rqs_backward(y, params, nc_dev, rcfg, g_out, g_dlogp, absmax=absmax, packed_width=W2.shape[0] if lc.packed else None)
     if fused_dx:
         # with the fused weight-gradient kernel downstream the activations h1 / h0 are not materialised: it re-applies the
         # activation to the saved pre-activations while loading them (268 MB less written and read per layer at 2^18 samples)
@@ -1072,6 +1084,30 @@ def _train_backward_layer(lc, x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g
                _gram_tn(g_z1, h0) if need[4] else None, column_sum(g_z1) if need[5] else None,
                _gram_tn(g_p, h1) if need[6] else None, column_sum(g_p) if need[7] else None)
     return g_x, g_y, gws
+
+
+def _rqs_backward_recompute(lc, y, z1, P, nc_dev, g_out, g_dlogp, absmax):
+    """bgk_coupling_rqs_dense_h2_backward: (g_y [B, d], g_params [B, P]) of a layer whose forward saved no parameters"""
+    from .transformer import row_pitch
+    n_bins, inverse, left, right, bottom, top, s = lc.rcfg
+    A2, c2, circ_mask = lc.recompute
+    y2, ldy = _lib.rowmajor(y)
+    B, d = y2.shape
+    dev = y.device
+    g_out2 = g_out.reshape(-1, d).contiguous()
+    g_dl = g_dlogp.reshape(-1).contiguous()
+    g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
+    ldgp = row_pitch(P)
+    g_p = torch.empty((B, ldgp), dtype=torch.float32, device=dev)[:, :P]
+    assert z1.is_contiguous() and z1.shape == (B, 128)
+    with torch.cuda.device(dev):
+        st = _lib.lib().bgk_coupling_rqs_dense_h2_backward(
+            _lib.ptr(z1), _lib.ptr(A2), c2, _lib.ptr(lc.cs), 128, lc.act, _lib.ptr(y2), ldy, B, d, n_bins, P, circ_mask, int(inverse),
+            left, right, bottom, top, s["min_bin_width"], s["min_bin_height"], s["min_derivative"],
+            int(s.get("enable_identity_init", False)), _lib.ptr(g_out2), d, _lib.ptr(g_dl), _lib.ptr(g_y), d, _lib.ptr(g_p), ldgp,
+            _lib.ptr(absmax), _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_coupling_rqs_dense_h2_backward")
+    return g_y, g_p
 
 
 class _FusedSplineTrainFn(torch.autograd.Function):

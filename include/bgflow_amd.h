@@ -47,6 +47,9 @@ const char* bgk_last_error(void);            /* thread-local, host string */
  *   option 2: kernel behind bgk_coupling_affine_dense_h2: 2 (default) = for hidden (64, 64) the weight-resident kernel (both
  *             conditioners' packed operands staged once per workgroup in LDS), for hidden (128, 128) the event-threaded kernel
  *             of bgk_fused2.hip; 1 = the streaming kernel (operands from L2, GEMM and activation phases alternate).
+ *   option 3: element VJP inside bgk_coupling_rqs_dense_h2_backward: 2 (default) = softmax / knots on the hardware exp2 / rcp forms
+ *             (what the fused forward it belongs to evaluates the spline with), 1 = the deterministic forms of bgk_rqs_backward
+ *             (gradients bit-identical to the saved-parameter path; ~40 % more VALU instructions per element).
  * Returns the previous value, BGK_EINVAL for an unknown option / value. */
 int bgk_set_option(int32_t option, int32_t value);
 
@@ -364,6 +367,23 @@ int bgk_coupling_rqs_dense_h2_train(const float* cond, int64_t ldc, int32_t d_c,
                                     float* out, int64_t ldo, float* dlogp, int32_t accumulate,
                                     int32_t* oob_count, float* z0, float* z1, float* params, int64_t ldp,
                                     const int32_t* src_col_dev, int32_t params_layout, void* stream);
+/* params_layout = 2 (round 5): the parameters are NOT written (params may be NULL; 446 MB per layer at 2^18 samples x 17 dims,
+ * 0.11 of the launch's 0.27 ms) -- the backward recomputes them from z1:
+ *
+ * bgk_coupling_rqs_dense_h2_backward: backward of the layer's spline transformer (autograd of transformer/spline.py:109-188 + nflows
+ * through the parameters the conditioner's last Linear produced, nn/dense.py:47-48) without saved parameters: the output layer is
+ * redone from z1 [B, 128] (contiguous, 16-byte aligned) on the matrix cores with the forward's operand A2p / scale c2 / device scale
+ * table cs_dev (same blocks, f16 split and MFMA order: bit-identical parameters), then the VJP of bgk_rqs_backward per element.
+ * circ_mask as in the forward call (P = 3 K d + the number of non-circular dims; a non-circular dim's slot is its rank among them).
+ * Outputs as bgk_rqs_backward's: g_y [B, d], g_params [B, P] in the reference's column order, g_absmax.  BGK_EUNSUPPORTED outside
+ * the fused envelope (hidden width 128, 8 bins, d <= 64) or with option 1 = 1. */
+int bgk_coupling_rqs_dense_h2_backward(const float* z1, const void* A2p, float c2, const float* cs_dev, int32_t H1, int32_t act,
+                                       const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K, int32_t P,
+                                       uint64_t circ_mask, int32_t inverse,
+                                       double left, double right, double bottom, double top,
+                                       double min_bin_width, double min_bin_height, double min_derivative,
+                                       int32_t identity_init, const float* g_out, int64_t ldgo, const float* g_dlogp,
+                                       float* g_y, int64_t ldgy, float* g_params, int64_t ldgp, float* g_absmax, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused affine coupling layer: replaces CouplingFlow._forward/_inverse (nn/flow/coupling.py:162-182) around

@@ -432,8 +432,9 @@ def test_element_major_saved_parameters_equal_the_reference_layout(hip_lib, dev,
     from bgflow_amd import dense
     layer = _spline_layer(dev, what=what, on=on)
     res = {}
-    prev = dense.PACKED_PARAMS
+    prev, prev_rc = dense.PACKED_PARAMS, dense.RECOMPUTE_PARAMS
     try:
+        dense.RECOMPUTE_PARAMS = False
         for packed in (True, False):
             dense.PACKED_PARAMS = packed
             for p in layer.parameters():
@@ -446,9 +447,58 @@ def test_element_major_saved_parameters_equal_the_reference_layout(hip_lib, dev,
             res[packed] = ([o.detach().clone() for o in out], dl.detach().clone(), [p.grad.clone() for p in layer.parameters()],
                            [x.grad.clone() for x in xs if x.grad is not None])
     finally:
-        dense.PACKED_PARAMS = prev
+        dense.PACKED_PARAMS, dense.RECOMPUTE_PARAMS = prev, prev_rc
     for a, b in zip(res[True][0] + [res[True][1]] + res[True][2] + res[True][3], res[False][0] + [res[False][1]] + res[False][2] + res[False][3]):
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("what,on", [("TORSIONS", "FIXED"), ("FIXED", "TORSIONS"), ("BONDS", "ANGLES")])
+@pytest.mark.parametrize("B", [1, 77, 4133])
+def test_spline_backward_with_recomputed_parameters_equals_the_saved_parameters(hip_lib, dev, what, on, B):
+    """Round 5: the fused training forward writes NO spline parameters (its params_layout = 2: 446 MB per layer at the bench batch);
+    bgk_coupling_rqs_dense_h2_backward redoes the conditioner's output layer from the saved z1 on the matrix cores -- the forward's
+    operand blocks, f16 split and MFMA order -- and runs the VJP of bgk_rqs_backward from LDS.  The recomputed parameters are the
+    forward's bit for bit, so outputs and every gradient equal the saved-parameter path exactly (circular dims without a slot, last
+    chunks of 2 / 4 dims, partial tiles, a single sample).  transformer/spline.py:109-188, nn/dense.py:47-48."""
+    from bgflow_amd import dense, _lib
+    layer = _spline_layer(dev, what=what, on=on)
+    res = {}
+    prev = dense.RECOMPUTE_PARAMS
+    try:
+        for mode in ("recompute-exact", "recompute", "saved"):
+            dense.RECOMPUTE_PARAMS = mode != "saved"
+            old = _lib.lib().bgk_set_option(3, 1 if mode == "recompute-exact" else 2)
+            try:
+                for p in layer.parameters():
+                    p.grad = None
+                xs = _fields(dev, B)
+                *out, dl = layer(*xs)
+                assert layer.transformer._fused_cache.get("params_recompute") is (mode != "saved"), "the fused training forward must have run in the requested form"
+                w = torch.linspace(0.5, 1.5, B, device=dev)[:, None]
+                (sum((o * o * w).sum() for o in out) - (dl * w).sum()).backward()
+            finally:
+                _lib.lib().bgk_set_option(3, old)
+            res[mode] = ([o.detach().clone() for o in out], dl.detach().clone(), [p.grad.clone() for p in layer.parameters()],
+                         [x.grad.clone() for x in xs if x.grad is not None])
+    finally:
+        dense.RECOMPUTE_PARAMS = prev
+    flat = {m: r[0] + [r[1]] + r[2] + r[3] for m, r in res.items()}
+    # the deterministic VJP forms (option 3 = 1): the arithmetic of bgk_rqs_backward on bit-identical parameters
+    for a, b in zip(flat["recompute-exact"], flat["saved"]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    # the shipped form (hardware exp2 / rcp in the element's softmax and knots, as in the forward): same outputs; gradients: every
+    # tensor to 2e-4 of its scale and 3e-5 in relative L2 (exp2 of a rounded argument: ~5e-7 relative in the bin probabilities, through
+    # the divisions by bin widths of ~0.1; an input within ~1e-7 of a knot may be evaluated in the neighbouring bin -- the spline is
+    # C1 there)
+    n_out = len(res["saved"][0]) + 1
+    worst = []
+    for k, (a, b) in enumerate(zip(flat["recompute"], flat["saved"])):
+        if k < n_out:
+            assert torch.equal(a, b)
+        else:
+            scale = float(b.abs().max()) + 1e-30
+            worst.append((float((a - b).abs().max()) / scale, float((a - b).double().norm()) / (float(b.double().norm()) + 1e-30), k))
+    assert max(w[0] for w in worst) <= 2e-4 and max(w[1] for w in worst) <= 3e-5, f"(max / scale, relative L2, tensor): {sorted(worst)[-3:]}"
 
 
 @pytest.mark.parametrize("B,drop", [(4096, True), (1000, False)])
