@@ -1470,9 +1470,7 @@ typedef float rc_f4u __attribute__((ext_vector_type(4), aligned(4)));
 #ifndef BGK_RC_RD
 #define BGK_RC_RD 4           /* (6 / 8: the allocator parks 38 / 54 registers of the B operand in scratch and reloads them inside the VJP) */
 #endif
-#ifndef BGK_RC_EARLY_START
-#define BGK_RC_EARLY_START 0  /* 1: the next GEMM's first ring slots are requested in front of the VJP instead of behind it */
-#endif
+
 #if BGK_RC_TS
 #define RC_Q(v) do { __builtin_amdgcn_sched_barrier(0); v = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define RC_ADD(acc, t1, t0) acc += (t1) - (t0)
@@ -1585,9 +1583,6 @@ __device__ __forceinline__ void rc_chunk(const RcArgs& a, const RcTile& tl, floa
 #endif
     RC_Q(t0);
     chunk_to_lds(h, s_p, hh, j);
-#if BGK_RC_EARLY_START
-    if constexpr (NT > 0) g.start();
-#endif
     RC_Q(t1); RC_ADD(ts.lds, t1, t0);
     __builtin_amdgcn_sched_barrier(0);     /* (the slots one after the other: interleaved by the scheduler they need twice the registers) */
     rc_vjp_slot<0, (NS > 1), FAST>(a, tl, s_p, c, nd, hh, j, rows, gl, gmax, in);
@@ -1599,9 +1594,12 @@ __device__ __forceinline__ void rc_chunk(const RcArgs& a, const RcTile& tl, floa
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     RC_Q(t2); RC_ADD(ts.vjp, t2, t1);
-#if !BGK_RC_EARLY_START
-    if constexpr (NT > 0) g.start();      /* (behind the VJP: the ring's registers are not live across it) */
-#endif
+    /* Behind the VJP: the ring's registers are not live across it.  Measured alternatives (profiles/r05_ab_runs.txt, call 45 / 47):
+     * requested in front of the VJP 292 us per launch instead of 266, ring depth 6 302 (the allocator parks the B operand in scratch and
+     * reloads it inside the VJP: every scratch reload is a vmcnt(0)), the GEMM's events threaded through hook points of the VJP the way
+     * the forward threads them through the spline 313 (each event's operand wait also waits for the g_y stores and input requests queued
+     * in between: one in-order counter). */
+    if constexpr (NT > 0) g.start();
     if constexpr (NT > 0) g.template events<0, Live<(NT > 0 ? NT : 4), 4, RC_RD>::NEV>();
     asm volatile("" : "+v"(in.x), "+v"(in.gy));      /* the next chunk's first inputs are awaited here, in front of the stores below */
     RC_Q(t3); RC_ADD(ts.gemm, t3, t2);
