@@ -703,8 +703,9 @@ def main():
                                  "tests/test_gpu_slow.py; tests/test_gpu_round4.py::test_kl_gradient_at_the_bench_batch pins chunks at <= 5e-5 -- the distance was the "
                                  "IC backward's treatment of clamped placements, not these GEMMs); spline VJP, activation derivatives, "
                                  "coordinate-transform backward: f32 with hardware exp2 / log2 / rcp / sin / cos forms (1 ulp)",
-                      note="fwd: one-launch coupling layers (training variant, saves pre-activations + spline parameters) + IC / CDF kernels; "
-                           "bwd: bgk_rqs_backward / bgk_ic_ic2xyz_backward, conditioner input-gradient chain on bgk_dense_backward_dx, "
+                      note="fwd: one-launch coupling layers (training variant: saves the pre-activations z0, z1; the spline parameters are "
+                           "not written) + IC / CDF kernels; bwd: bgk_coupling_rqs_dense_h2_backward (the parameters recomputed from z1 on the "
+                           "matrix cores, element VJP from LDS) / bgk_ic_ic2xyz_backward, conditioner input-gradient chain on bgk_dense_backward_dx, "
                            "weight / bias gradients on bgk_dense_weight_grad; one all-reduce of [sum, n] + one all-reduce of the flat gradient bucket; "
                            "bgk_adam_step (device-side NaN skip, trainers.py:198-201)")
             # the same step as ONE call of the generator: z drawn inside the step by the counter-based prior (one launch of
