@@ -1464,9 +1464,6 @@ typedef float rc_f4u __attribute__((ext_vector_type(4), aligned(4)));
 #ifndef BGK_RC_TS
 #define BGK_RC_TS 0
 #endif
-#ifndef BGK_RC_REV
-#define BGK_RC_REV 0
-#endif
 #ifndef BGK_RC_RD
 #define BGK_RC_RD 4           /* (6 / 8: the allocator parks 38 / 54 registers of the B operand in scratch and reloads them inside the VJP) */
 #endif
@@ -1619,13 +1616,8 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_bwd_recompute_kernel
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      /* uniform: the tile's row bases live in scalar registers */
     float* s_p = smem + (size_t)wave * a.lds_per_wave;   /* first the z1 tile [32][128] (16-byte pieces XOR-swizzled by the row), then the parameter chunks [128][ST] */
     const int64_t n_tiles = (a.B + 31) / 32;
-#if BGK_RC_REV
-    const int64_t tile = n_tiles - 1 - ((int64_t)blockIdx.x * FW + wave);      /* last tiles first: the consumers start with the rows written last */
-    if (tile < 0) return;
-#else
-    const int64_t tile = (int64_t)blockIdx.x * FW + wave;
+    const int64_t tile = (int64_t)blockIdx.x * FW + wave;      /* (tiles in reverse order, so that the consumers start with the rows written last: no difference, call 43) */
     if (tile >= n_tiles) return;
-#endif
     const int lane = (int)threadIdx.x & 63, j = lane & 31, hh = lane >> 5;
     const unsigned voff = (unsigned)lane * 16u;
     const int64_t b0 = tile * 32;

@@ -501,6 +501,43 @@ def test_spline_backward_with_recomputed_parameters_equals_the_saved_parameters(
     assert max(w[0] for w in worst) <= 2e-4 and max(w[1] for w in worst) <= 3e-5, f"(max / scale, relative L2, tensor): {sorted(worst)[-3:]}"
 
 
+@pytest.mark.parametrize("what,on,dims", [("BONDS", "ANGLES", (3, 17, 12, 9)), ("TORSIONS", "BONDS", (3, 17, 12, 9)), ("ANGLES", "FIXED", (3, 5, 12, 4)),
+                                          ("FIXED", "TORSIONS", (3, 5, 12, 1))])
+def test_recomputed_parameters_for_other_chunk_shapes(hip_lib, dev, what, on, dims):
+    """the recompute backward on transformed widths that end in every slot count: d = 3 (one chunk, two slots), 12 (5 + 5 + 2: a last chunk of
+    one slot, circular dims), 5 (exactly one whole chunk), 1 (a single element per sample) -- bit-identical to the saved-parameter path
+    with the deterministic VJP forms (bgk_set_option(3, 1))"""
+    from bgflow_amd import configs, dense, _lib
+    from bgflow_amd.utils import hash_init_
+    names = ("BONDS", "ANGLES", "TORSIONS", "FIXED")
+    dd = dict(zip(names, dims))
+    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+    layer = hash_init_(configs._spline_coupling(what, on, dd, circ, slot)).to(dev)
+    B = 555
+    res = {}
+    prev = dense.RECOMPUTE_PARAMS
+    old = _lib.lib().bgk_set_option(3, 1)
+    try:
+        for rc in (True, False):
+            dense.RECOMPUTE_PARAMS = rc
+            for p in layer.parameters():
+                p.grad = None
+            xs = [torch.rand(B, dd[f], device=dev, generator=torch.Generator(device=dev).manual_seed(7 + i)).requires_grad_(True)
+                  for i, f in enumerate(configs.IC_FIELDS)]
+            *out, dl = layer(*xs)
+            assert layer.transformer._fused_cache.get("params_recompute") is rc
+            w = torch.linspace(0.5, 1.5, B, device=dev)[:, None]
+            (sum((o * o * w).sum() for o in out) - (dl * w).sum()).backward()
+            res[rc] = [o.detach().clone() for o in out] + [dl.detach().clone()] + [p.grad.clone() for p in layer.parameters()] + \
+                [x.grad.clone() for x in xs if x.grad is not None]
+    finally:
+        dense.RECOMPUTE_PARAMS = prev
+        _lib.lib().bgk_set_option(3, old)
+    for a, b in zip(res[True], res[False]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,drop", [(4096, True), (1000, False)])
 def test_kl_integrand_inside_the_generation_tail(hip_lib, dev, B, drop):
     """SURVEY f-3's single-pass `kldiv` (round 5): `BoltzmannGenerator.kldiv_mean` evaluates the target energy and the loss sums inside
