@@ -22,15 +22,10 @@ namespace {
 #endif
 constexpr int DW = BGK_DBWD_DW;      /* waves (32-row tiles) per workgroup */
 constexpr int DSROW = 33;
-#ifndef BGK_DBWD_DG
-#define BGK_DBWD_DG 4
-#endif
-constexpr int DBWD_DG = BGK_DBWD_DG;      /* k-steps per gradient batch of the first GEMM */
 constexpr int DBWD_PAD = 4;               /* T2 holds a multiple of 4 k-steps (zero blocks behind ceil(P / 16)): part of the ABI */
-static_assert(DBWD_PAD % DBWD_DG == 0, "the first GEMM runs whole groups");
+constexpr int DBWD_DG = DBWD_PAD;         /* a.S2 is a multiple of this: the first GEMM runs whole groups of DBWD_GD k-steps */
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned bgk_u4 __attribute__((ext_vector_type(4)));
-typedef float bgk_f4v __attribute__((ext_vector_type(4)));
 
 struct DenseBwdArgs {
     const float* g; int64_t ldg; int P;           /* gradient w.r.t. the MLP output [B, P] */
@@ -207,24 +202,17 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
     }
 }
 
-#ifndef BGK_DBWD_SHARED
-#define BGK_DBWD_SHARED 1      /* first GEMM's operand blocks: 1 = staged once per workgroup in LDS (DMA), 0 = every wave streams them from L2 */
-#endif
-
-#ifndef BGK_DBWD_GLDS
-#define BGK_DBWD_GLDS 1        /* first GEMM's gradient tile: 1 = copied into LDS by DMA (whole 128-byte row pieces), 0 = 32-byte pieces straight into registers */
-#endif
+/* First GEMM (g_h1 = W2^T g), LDS plan.  Measured alternatives: profiles/r05_dx_phase_ts.txt (operands streamed from L2 by every wave;
+ * the gradient in 32-byte pieces straight into registers; groups of four k-steps; rings 2 / 3; eight waves per workgroup; the loop
+ * without the interleave below). */
 #ifndef BGK_DBWD_GRING
 #define BGK_DBWD_GRING 2       /* gradient groups in flight + in use per wave (LDS ring slots of 4 KB) */
 #endif
-constexpr int DBWD_GD = 2;                                           /* k-steps per group on the BGK_DBWD_GLDS path */
-constexpr int DBWD_OPG = DBWD_GD * 4 * 2 * 64;                        /* 16-byte pieces of an operand group there */
 #ifndef BGK_DBWD_ORING
 #define BGK_DBWD_ORING 3       /* operand groups in flight + in use per workgroup (LDS ring slots of 16 KB) */
 #endif
-#ifndef BGK_DBWD_PIPE
-#define BGK_DBWD_PIPE 1        /* first GEMM (LDS-gradient form): 1 = the MFMAs of group g - 1 interleaved with the f16 split and the requests of group g */
-#endif
+constexpr int DBWD_GD = 2;                                           /* k-steps per group */
+constexpr int DBWD_OPG = DBWD_GD * 4 * 2 * 64;                        /* 16-byte pieces of an operand group */
 constexpr size_t DBWD_GLDS_BYTES = BGK_DBWD_ORING * (size_t)DBWD_OPG * 16 + (size_t)DW * BGK_DBWD_GRING * 4096;
 template <int N> __device__ __forceinline__ void dx_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 
@@ -250,13 +238,8 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
     float* s_f = smem + (size_t)wave * a.lds_per_wave;       /* [32][H2_SLAB] output slab; later the g_feat tile [32 FT][DSROW] */
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * DW + wave;
-#if BGK_DBWD_SHARED
     const bool active = tile < n_tiles;                      /* a wave without a tile still copies its share of the operands and meets the barriers */
     const int64_t b0 = (active ? tile : n_tiles - 1) * 32;
-#else
-    if (tile >= n_tiles) return;
-    const int64_t b0 = tile * 32;
-#endif
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
 #if BGK_SBD_TS
     const unsigned ts0 = (unsigned)__builtin_amdgcn_s_memtime();       /* (written behind the first GEMM: the slab space holds its operands until then) */
@@ -270,44 +253,24 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
     float sg, inv_sg;
     {
-        /* The gradient rows are far apart in memory (one 32-byte piece of 32 different rows per load instruction).  Raw buffer loads
-         * on a descriptor of the tile: rows past the batch are out of range and read 0, so the loop below has no branch -- the
-         * compiler's wait insertion is exact only on straight-line code (at a join it assumes the path with the fewest operations in
-         * flight and drains the queue; the former per-lane tail path cost a vmcnt(0) per k-step).  Columns >= P (row padding, the
-         * k-steps that pad S2 to a multiple of the group) are masked to 0: the operand blocks there are 0 too, but 0 * NaN is not. */
+        /* descriptor of the tile's gradient rows: rows past the batch (and columns past the allocation) are out of range */
         const __amdgpu_buffer_rsrc_t rs_gt = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + b0 * a.ldg), 0, (int)(rows * a.ldg * 4), 0x00020000);
-        const int gofs = j * (int)a.ldg * 4;
         const int P = a.P;
-        auto load_g = [&](int s, float (&v)[8]) {
-            const int k0 = 16 * s + 8 * hh;
-            const bgk_f4v u0 = __builtin_bit_cast(bgk_f4v, __builtin_amdgcn_raw_buffer_load_b128(rs_gt, gofs + k0 * 4, 0, 0));
-            const bgk_f4v u1 = __builtin_bit_cast(bgk_f4v, __builtin_amdgcn_raw_buffer_load_b128(rs_gt, gofs + k0 * 4 + 16, 0, 0));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = u0[e]; v[4 + e] = u1[e]; }
-        };
-        /* The column mask is applied where the values are USED (a group later): a select on the loaded registers right behind the load is
-         * a wait for the whole batch -- and for everything requested before it -- in front of the current group's matrix work. */
-        auto mask_g = [&](int s, float (&v)[8]) {
-            const int k0 = 16 * s + 8 * hh;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = k0 + e < P ? v[e] : 0.0f;
-        };
-        constexpr int DG = DBWD_DG;
-        static_assert(DG % 2 == 0, "fragment set parity follows the position in the group");
         const int S2 = a.S2;
         sg = h2_pow2_scale(a.g_absmax ? a.g_absmax[0] : 0.0f, inv_sg);      /* per-tensor power of two: max |g| -> [2^14, 2^15) */
-#if BGK_DBWD_SHARED && BGK_DBWD_GLDS
-        /* Round 5, second form.  Stamps of the form below (#elif) showed the first GEMM spending 29 k of its 71 k cycles ISSUING requests:
-         * the gradient loads hand the address unit 64 separate 16-byte pieces per instruction (32 rows x 2), one piece per cycle, eight
-         * waves per CU -- 4 k cycles per group of four k-steps for 1.5 k cycles of matrix work.  Here the gradient goes through LDS as
-         * well: per group of GD = 2 k-steps a wave copies its tile's 32 rows x 128 bytes by DMA, eight adjacent lanes per row piece (four
-         * instructions of 8 whole 128-byte pieces instead of eight of 64 scattered ones), PD groups ahead into a private ring, and reads
-         * its B operand (row j, k = 16 s + 8 hh ..) from there; the 16-byte pieces of a row are stored XOR-swizzled by the row so that
-         * the 64 lanes' reads spread over the banks.  Bounds come from the buffer descriptor (rows past the batch, columns past the
-         * allocation: nothing is read); what such pieces leave in LDS is masked at the point of use.  The operand groups (GD k-steps,
-         * 16 KB) are shared by the workgroup as in the first form.  All LDS reads of this GEMM are inline asm: the compiler's wait
-         * insertion puts vmcnt(0) in front of every LDS read it sees behind an LDS-DMA (possible alias), i.e. in front of the current
-         * group's work it waited for the requests of the NEXT groups. */
+        /* Round 5.  The operand blocks of this GEMM (W2^T as f16 hi + lo: 8 KB per k-step, 229 KB per tile at P = 425) are the same for every
+         * tile: the four waves of the workgroup copy a group of GD = 2 k-steps (16 KB) into an LDS ring together -- each wave a quarter, by
+         * DMA, in the slab space the chain behind this GEMM uses afterwards (a barrier separates the two uses) -- and read their A fragments
+         * from there (streamed from L2 by every wave, each k-step exposed most of an L2 round trip: 76 k of the 147 k cycles a wave lived).
+         * The gradient tile goes through LDS as well: loaded straight into registers as the B operand, a load instruction handed the address
+         * unit 64 separate 16-byte pieces (32 rows x 2), one piece per cycle, eight waves per CU -- 29 k of the GEMM's 71 k cycles were
+         * request ISSUE.  Per group a wave copies its tile's 32 rows x 128 bytes by DMA, eight adjacent lanes per row piece, into a private
+         * ring, and reads its B operand (row j, k = 16 s + 8 hh ..) from there; the 16-byte pieces of a row are stored XOR-swizzled by the
+         * row so that the 64 lanes' reads spread over the banks.  Bounds come from the buffer descriptor; what out-of-range pieces leave in
+         * LDS (zeros) and the columns >= P are masked at the point of USE (a select right behind a load is a wait for the whole batch in
+         * front of the current group's matrix work: the operand blocks there are 0 too, but 0 * NaN is not).  All LDS reads of this GEMM
+         * are inline asm: behind an LDS-DMA the compiler's wait insertion puts vmcnt(0) in front of every LDS read it sees (possible
+         * alias), i.e. in front of the current group's work it waited for the requests of the NEXT groups. */
         constexpr int GD = DBWD_GD, OPG = DBWD_OPG, GRING = BGK_DBWD_GRING, ORING = BGK_DBWD_ORING, PDG = GRING - 1, PDO = ORING - 1;
         constexpr int NG = 4, NO = OPG / DW / 64;                        /* DMA instructions of a wave per group: gradient | operands */
         /* Requests complete in order.  A group needs its gradient (requested PDG groups ago) and its operands (PDO groups ago); the kind
@@ -316,7 +279,6 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
         constexpr bool G_FIRST = PDO >= PDG;
         constexpr int REMAIN = PDO == PDG ? (PDG - 1) * (NG + NO) : PDO > PDG ? NO + (PDG - 1) * (NG + NO) : NG + (PDO - 1) * (NG + NO);
         static_assert(DBWD_DG % GD == 0 && GRING >= 2 && ORING >= 2 && REMAIN < 64, "S2 is a multiple of DBWD_DG");
-        (void)load_g; (void)mask_g;
         const int ngroups = S2 / GD;
         char* const smem_b = reinterpret_cast<char*>(smem);
         const unsigned lds0 = (unsigned)(uintptr_t)(lvp_t)smem;
@@ -353,9 +315,10 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
         };
         const int Pj = j < rows ? P : 0;                                 /* rows past the batch: every column masked */
         /* (past the end the last group is requested again, into ring slots nobody reads any more: the request counts stay uniform) */
-        /* BGK_DBWD_PIPE: the operands of a group are used one turn of the loop after its gradient (LAG = 1), so a turn requests the
-         * operands of group t + PDO - 1; the distances between request and use -- and with them REMAIN -- are the same. */
-        constexpr int LAG = BGK_DBWD_PIPE ? 1 : 0;
+        /* The operands of a group are used one turn of the loop after its gradient (LAG = 1: the loop below multiplies group g - 1 while it
+         * splits group g), so a turn requests the operands of group t + PDO - 1; the distances between request and use -- and with
+         * them REMAIN -- are the same. */
+        constexpr int LAG = 1;
         static_assert(!LAG || (G_FIRST && PDO >= 2), "pipelined form: gradient requests first, an operand slot for the group in use");
         auto request_g = [&](int t, int gslot) { if (t + PDG >= 0) dma_grad(t + PDG < ngroups ? t + PDG : ngroups - 1, gslot); };
         auto request_o = [&](int t, int oslot) { if (t + PDO - LAG >= 0) dma_op(t + PDO - LAG < ngroups ? t + PDO - LAG : ngroups - 1, oslot); };
@@ -394,7 +357,6 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
             }
             h2_split8_scaled(v, sg, hi, lo);
         };
-#if BGK_DBWD_PIPE
         /* Turn g of the loop: [wait, barrier] the gradient tile of group g out of LDS, then the 24 MFMAs of group g - 1, one by one, with
          * the VALU work of group g's f16 split and the eight DMA requests of the turn between them (sched_group_barrier: 1 MFMA, 5 VALU,
          * a request behind every third) -- in the sequential form the matrix pipe idled through 11 k cycles of split and 10 - 13 k cycles
@@ -478,180 +440,11 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
 #if BGK_SBD_TS
         SBD_Q(tq0); tsc += tq0 - tq2;
 #endif
-#else
-        int slot = 0, slot_in = PDG % GRING, ob = 0, ob_in = PDO % ORING;
-        for (int gi = 0; gi < ngroups; ++gi) {
-#if BGK_SBD_TS
-            SBD_Q(tq0); tsc += tq0 - tq2;
-#endif
-            dx_wait_vm<REMAIN>();                                       /* this group's gradient tile and this wave's share of its operands have landed */
-#if BGK_SBD_TS
-            SBD_Q(tq1); tsw += tq1 - tq0;
-#endif
-            __syncthreads();                                            /* ... everyone's operand quarter; and everyone has left the buffer group gi + 1 goes to */
-#if BGK_SBD_TS
-            SBD_Q(tq2); tsb += tq2 - tq1;
-#endif
-            h2_h16x8 bhi[GD], blo[GD];
-            {
-                bgk_u4v raw[GD][2];
-                read_raw(raw, slot);
-#pragma unroll
-                for (int u = 0; u < GD; ++u) split_step(raw, gi, u, bhi[u], blo[u]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-            SBD_Q(tq3); tss += tq3 - tq2;
-#endif
-            request(gi, slot_in, ob_in);
-            __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-            SBD_Q(tq4); tsi += tq4 - tq3;
-#endif
-            DxFrag fr[2];
-            lds_frag(fr[0], ob, 0);
-#pragma unroll
-            for (int u = 0; u < GD; ++u) {
-                dx_frag_wait(fr[u & 1]);                                /* this step's fragments (requested one step ago) have arrived */
-                if (u + 1 < GD) lds_frag(fr[(u + 1) & 1], ob, u + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                H2A<4> fa;
-                dx_frag_get(fr[u & 1], fa);
-                h2_mfma3<4>(acc, fa, bhi[u], blo[u]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            slot = slot + 1 == GRING ? 0 : slot + 1;
-            slot_in = slot_in + 1 == GRING ? 0 : slot_in + 1;
-            ob = ob + 1 == ORING ? 0 : ob + 1;
-            ob_in = ob_in + 1 == ORING ? 0 : ob_in + 1;
-        }
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                /* the copies past the end */
         __syncthreads();                                                /* the buffers are the waves' output slabs from here on */
         if (!active) return;
 #if BGK_SBD_TS
         if (lane == 0) { unsigned* q = reinterpret_cast<unsigned*>(s_f); q[1 * H2_SLAB + 130] = tsw; q[2 * H2_SLAB + 130] = tsb; q[3 * H2_SLAB + 130] = tsc; q[4 * H2_SLAB + 130] = tss; q[5 * H2_SLAB + 130] = tsi; }
-#endif
-#elif BGK_DBWD_SHARED
-        /* Round 5.  The operand blocks of this GEMM (W2^T as f16 hi + lo: 8 KB per k-step, 229 KB per tile at P = 425) are the same for
-         * every tile.  Streamed from L2 by every wave, one k-step ahead, each k-step exposed most of an L2 round trip (operand loads
-         * return in order behind the gradient loads): 76 k of the 147 k cycles a wave lived (s_memtime stamps, tools/r05_dx_ts.py),
-         * for 10.7 k cycles of matrix work.  Now the four waves of the workgroup copy a GROUP of DG k-steps (32 KB) into LDS together
-         * -- each wave a quarter, by DMA, one group ahead, into the half of the workgroup's slab space the previous group has left
-         * (the slabs are not needed before the chain behind this GEMM; a barrier separates the two uses) -- and read their fragments
-         * from there: a quarter of the L2 traffic, LDS latency instead of L2 latency in front of the MFMAs, and the gradient batch of
-         * the next group is requested a whole group ahead (nothing queues behind it any more). */
-        constexpr int GRP16 = DG * 4 * 2 * 64;                         /* 16-byte pieces of a group: k-steps x tiles x {hi, lo} x lanes */
-        uint4* s_op = reinterpret_cast<uint4*>(smem);                   /* two group buffers; DW * lds_per_wave >= 2 * GRP16 * 4 floats (launcher) */
-        auto dma_group = [&](int gi) {
-            const uint4* src = a.T2 + (size_t)gi * GRP16 + wave * (GRP16 / DW);
-            uint4* dst = s_op + (gi & 1) * GRP16 + wave * (GRP16 / DW);
-#pragma unroll
-            for (int i = 0; i < GRP16 / DW / 64; ++i)
-                __builtin_amdgcn_global_load_lds((gvp_t)(src + i * 64 + lane), (lvp_t)(dst + i * 64), 16, 0, 0);
-        };
-        /* The fragment reads are inline asm: behind a global_load_lds the compiler's wait insertion puts `s_waitcnt vmcnt(0)` in front of
-         * EVERY ds_read it can see (the copy might alias what is read), i.e. the wave waited for the NEXT group's copy and gradient batch
-         * -- a whole memory round trip per group -- before it touched the current group (stamps: 67.7 k of the GEMM's 71 k cycles
-         * "computing", 128 waiting for its own requests).  The copies land in the OTHER buffer; their completion is awaited explicitly at
-         * the top of the next group.  lgkmcnt of these reads is handled by hand (dx_frag_wait). */
-        const unsigned lds_op = (unsigned)(uintptr_t)(lvp_t)s_op + (unsigned)lane * 16u;
-        auto lds_frag = [&](DxFrag& f, int slot, int u) {
-            const unsigned addr = lds_op + (unsigned)slot * (GRP16 * 16u) + (unsigned)u * (4 * 2 * 1024u);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int pp = 0; pp < 2; ++pp)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.r[m][pp]) : "v"(addr), "i"((m * 2 + pp) * 1024) : "memory");
-        };
-        float ring[DG][8];
-        dma_group(0);
-#pragma unroll
-        for (int u = 0; u < DG; ++u) load_g(u, ring[u]);
-        __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-        unsigned tsw = 0u, tsb = 0u, tsc = 0u, tss = 0u, tsi = 0u, tq0, tq1, tq3, tq4, tq2 = (unsigned)__builtin_amdgcn_s_memtime();   /* cycles waiting for the wave's own requests | at the barrier | computing */
-#define SBD_Q(v) do { __builtin_amdgcn_sched_barrier(0); v = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SBD_Q(v) do { } while (0)
-#endif
-        for (int s0 = 0, gi = 0; s0 < S2; s0 += DG, ++gi) {
-#if BGK_SBD_TS
-            SBD_Q(tq0); tsc += tq0 - tq2;
-#endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* this wave's quarter of group gi and its gradient batch have landed */
-#if BGK_SBD_TS
-            SBD_Q(tq1); tsw += tq1 - tq0;
-#endif
-            __syncthreads();                                            /* ... everyone's; and everyone has left the buffer group gi + 1 goes to */
-#if BGK_SBD_TS
-            SBD_Q(tq2); tsb += tq2 - tq1;
-#endif
-            h2_h16x8 bhi[DG], blo[DG];
-#pragma unroll
-            for (int u = 0; u < DG; ++u) { mask_g(s0 + u, ring[u]); h2_split8_scaled(ring[u], sg, bhi[u], blo[u]); }
-            __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-            SBD_Q(tq3); tss += tq3 - tq2;
-#endif
-            if (s0 + DG < S2) {
-                dma_group(gi + 1);
-#pragma unroll
-                for (int v = 0; v < DG; ++v) load_g(s0 + DG + v, ring[v]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#if BGK_SBD_TS
-            SBD_Q(tq4); tsi += tq4 - tq3;
-#endif
-            DxFrag fr[2];
-            lds_frag(fr[0], gi & 1, 0);
-#pragma unroll
-            for (int u = 0; u < DG; ++u) {
-                dx_frag_wait(fr[u & 1]);                                /* this step's fragments (requested one step ago) have arrived */
-                if (u + 1 < DG) lds_frag(fr[(u + 1) & 1], gi & 1, u + 1);
-                __builtin_amdgcn_sched_barrier(0);                      /* the next step's LDS reads stay in front of this step's MFMAs */
-                H2A<4> fa;
-                dx_frag_get(fr[u & 1], fa);
-                h2_mfma3<4>(acc, fa, bhi[u], blo[u]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __syncthreads();                                                /* the operand buffers are the waves' output slabs from here on */
-        if (!active) return;
-#if BGK_SBD_TS
-        if (lane == 0) { unsigned* q = reinterpret_cast<unsigned*>(s_f); q[1 * H2_SLAB + 130] = tsw; q[2 * H2_SLAB + 130] = tsb; q[3 * H2_SLAB + 130] = tsc; q[4 * H2_SLAB + 130] = tss; q[5 * H2_SLAB + 130] = tsi; }
-#endif
-#else
-        /* Loads return in order on this part: an operand load (L2 hit) queued behind a gradient load (HBM) waits for it, so a
-         * gradient ring refilled one k-step at a time stalls EVERY step for most of an HBM round trip, whatever its depth.  Here the
-         * operand fragments of step s + 1 are requested before the MFMAs of step s (two fragment sets), and the gradient values of
-         * the next DG k-steps as one batch right behind the group's last operand request: the operand loads never queue behind a
-         * fresh gradient request, and a group waits for its gradients once.  a.S2 is a multiple of DG (zero operand blocks). */
-        H2A<4> fr[2];
-        h2a_load<4>(fr[0], a.T2, 0, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        float ring[DG][8];
-#pragma unroll
-        for (int u = 0; u < DG; ++u) load_g(u, ring[u]);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int s0 = 0; s0 < S2; s0 += DG) {
-            h2_h16x8 bhi[DG], blo[DG];
-#pragma unroll
-            for (int u = 0; u < DG; ++u) { mask_g(s0 + u, ring[u]); h2_split8_scaled(ring[u], sg, bhi[u], blo[u]); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < DG; ++u) {
-                const int s = s0 + u;
-                h2a_load<4>(fr[(u + 1) & 1], a.T2, s + 1 < S2 ? s + 1 : S2 - 1, lane);
-                if (u == DG - 1) {
-#pragma unroll
-                    for (int v = 0; v < DG; ++v) load_g(s0 + DG + v, ring[v]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                h2_mfma3<4>(acc, fr[u & 1], bhi[u], blo[u]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
 #endif
     }
 #if BGK_SBD_TS
@@ -802,13 +595,8 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     const int FT = (n_in + 31) / 32;
     a.lds_per_wave = 32 * H2_SLAB > 32 * FT * DSROW ? 32 * H2_SLAB : 32 * FT * DSROW;   /* output slab, reused for the g_feat tile */
     size_t shmem = sizeof(float) * (size_t)DW * a.lds_per_wave;
-#if !BGK_DBWD_GLDS
-    static_assert(sizeof(float) * DW * 32 * H2_SLAB >= 2 * (size_t)DBWD_DG * 4 * 2 * 64 * 16, "the slab space holds two operand groups of the first GEMM");
-#endif
-#if BGK_DBWD_SHARED && BGK_DBWD_GLDS
     static_assert(DBWD_GLDS_BYTES * (8 / DW) <= 160 * 1024, "eight waves per CU");
-    if (shmem < DBWD_GLDS_BYTES) shmem = DBWD_GLDS_BYTES;            /* two operand groups + the waves' gradient rings (first GEMM) */
-#endif
+    if (shmem < DBWD_GLDS_BYTES) shmem = DBWD_GLDS_BYTES;            /* the operand ring + the waves' gradient rings (first GEMM) */
     const int64_t n_wg = ((B + 31) / 32 + DW - 1) / DW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_dense_backward_dx: batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
