@@ -538,6 +538,39 @@ def test_recomputed_parameters_for_other_chunk_shapes(hip_lib, dev, what, on, di
         assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
 
 
+def test_recomputed_parameters_with_a_mixed_circular_mask(hip_lib, dev):
+    """circular and non-circular dims in one transformer: the recompute backward derives a non-circular dim's slot (its column behind the
+    3 K d regular ones) from the mask -- the rank of the dim among the non-circular ones, what ConditionalSplineTransformer._nc_slot
+    tabulates for bgk_rqs_backward -- bit-identical gradients with the saved-parameter path (deterministic VJP forms)"""
+    import bgflow_amd as bg
+    from bgflow_amd import dense, _lib
+    from bgflow_amd.utils import hash_init_
+    circ = np.array([1, 0, 1, 1, 0, 0, 1, 0, 0, 1, 1, 0], bool)       # d = 12: chunks of 5 + 5 + 2, slots 0 .. 5 spread over all of them
+    d, d_on, B = len(circ), 9, 333
+    net = bg.DenseNet([d_on, 128, 128, 3 * 8 * d + int((~circ).sum())], activation=torch.nn.SiLU())
+    layer = hash_init_(bg.CouplingFlow(bg.ConditionalSplineTransformer(params_net=net, is_circular=torch.tensor(circ)),
+                                       transformed_indices=[0], cond_indices=[1])).to(dev)
+    res = {}
+    prev = dense.RECOMPUTE_PARAMS
+    old = _lib.lib().bgk_set_option(3, 1)
+    try:
+        for rc in (True, False):
+            dense.RECOMPUTE_PARAMS = rc
+            for p in layer.parameters():
+                p.grad = None
+            xs = [torch.rand(B, w, device=dev, generator=torch.Generator(device=dev).manual_seed(11 + i)).requires_grad_(True) for i, w in enumerate((d, d_on))]
+            *out, dl = layer(*xs)
+            assert layer.transformer._fused_cache.get("params_recompute") is rc
+            w = torch.linspace(0.5, 1.5, B, device=dev)[:, None]
+            (sum((o * o * w).sum() for o in out) - (dl * w).sum()).backward()
+            res[rc] = [o.detach().clone() for o in out] + [dl.detach().clone()] + [p.grad.clone() for p in layer.parameters()] + [x.grad.clone() for x in xs]
+    finally:
+        dense.RECOMPUTE_PARAMS = prev
+        _lib.lib().bgk_set_option(3, old)
+    for a, b in zip(res[True], res[False]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,drop", [(4096, True), (1000, False)])
 def test_kl_integrand_inside_the_generation_tail(hip_lib, dev, B, drop):
     """SURVEY f-3's single-pass `kldiv` (round 5): `BoltzmannGenerator.kldiv_mean` evaluates the target energy and the loss sums inside
