@@ -790,7 +790,7 @@ __device__ __forceinline__ void save_chunk_params(const V2Args& a, const float* 
 }
 #endif
 
-template <int INV, int NT>
+template <int INV, int NT, bool SAVEP>
 __device__ __forceinline__ void chunk_piped(const V2Args& a, const SpK& k, float* s_p, float* s_y, int c, int hh, int j, int rows,
                                             float& run, int& oob_local, int (&bins)[3], f32x16 (&h)[4], const BFrag& bf,
                                             TFrag (&ring)[RD], unsigned voff, int64_t b0) {
@@ -798,7 +798,7 @@ __device__ __forceinline__ void chunk_piped(const V2Args& a, const SpK& k, float
     g.start();                       /* the next GEMM's first A fragments travel while this chunk goes through LDS */
     chunk_to_lds(h, s_p, hh, j);
 #if BGK_V2_SAVE
-    save_chunk_params(a, s_p, c, (int)threadIdx.x & 63, b0, rows);
+    if constexpr (SAVEP) save_chunk_params(a, s_p, c, (int)threadIdx.x & 63, b0, rows);
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #if (BGK_V2_ABL & 1)
@@ -1000,7 +1000,10 @@ __device__ __forceinline__ void l0_step(f32x16 (&h)[4], const L0Frag& fr, const 
 #endif
 }
 
-template <int ACT, int INV>
+/* SAVEP (training variant only): the spline parameters are written out.  The instance without it is the default training forward since
+ * the backward recomputes them: with the write-out compiled in (and skipped at run time) its loop-invariant row pointers and LDS
+ * addresses cost 18 spilled registers, one of them reloaded -- behind a vmcnt(0) -- in front of every chunk's transposition. */
+template <int ACT, int INV, bool SAVEP = true>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2Args a) {
     if (a.cs_dev) { a.c0 = a.cs_dev[1]; a.c1 = a.cs_dev[3]; a.c2 = a.cs_dev[5]; }   /* wave-uniform scalar loads */
 #if BGK_V2_OVFL
@@ -1133,14 +1136,14 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2v2_kernel(V2
         int bins[3] = {0, 0, 0};
         const int nd = (d - c * DPC) < DPC ? (d - c * DPC) : DPC;
         if (c + 2 < a.n_chunks || (c + 2 == a.n_chunks && a.last_tiles > 2)) {
-            chunk_piped<INV, 4>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff, b0);
+            chunk_piped<INV, 4, SAVEP>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff, b0);
         } else if (c + 2 == a.n_chunks) {
-            chunk_piped<INV, 2>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff, b0);
+            chunk_piped<INV, 2, SAVEP>(a, k, s_p, s_y, c, hh, j, rows, run, oob_local, bins, h, bf, ring, voff, b0);
         } else {
             NoLive none;
             chunk_to_lds(h, s_p, hh, j);
 #if BGK_V2_SAVE
-            save_chunk_params(a, s_p, c, lane, b0, rows);
+            if constexpr (SAVEP) save_chunk_params(a, s_p, c, lane, b0, rows);
 #endif
 #if (BGK_V2_ABL & 1)
             run += s_p[(threadIdx.x & 127) * ST + j];
@@ -1465,7 +1468,7 @@ typedef float rc_f4u __attribute__((ext_vector_type(4), aligned(4)));
 #define BGK_RC_TS 0
 #endif
 #ifndef BGK_RC_RD
-#define BGK_RC_RD 4           /* (6 / 8: the allocator parks 38 / 54 registers of the B operand in scratch and reloads them inside the VJP) */
+#define BGK_RC_RD 4           /* (6 / 8: no difference, call 52) */
 #endif
 
 #if BGK_RC_TS
@@ -1521,6 +1524,11 @@ __device__ __forceinline__ void rc_vjp_slot(const RcArgs& a, const RcTile& tl, f
     const float m = bgk_rqs_vjp_element_lds<KB, FAST>(cf, a.inverse, pe, ST, a.c2, has_slot, q < nd, x, gy, gl, gx);
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gx), tl.gy, valid ? tl.ogy + dim * 4 : RC_OOB, 0, 0);
     gmax = valid ? __builtin_fmaxf(gmax, m) : gmax;
+    /* the maximum is formed HERE: left to the scheduler, the 25 max operations of a slot sink behind the next chunk's GEMM (their result is
+     * not needed before the kernel ends) and keep the slot's 25 gradient values -- 75 registers per chunk -- alive across it: the
+     * allocator then parks the B operand in scratch, eight registers per ring slot beyond two, and reloads it inside the GEMMs
+     * (0.277 -> 0.252 ms per launch, call 53) */
+    asm volatile("" : "+v"(gmax));
 }
 
 /* the chunk's gradients, LDS -> g_params in the reference's column order [w | h | s | slots]: 16-byte pieces (row r, dim q, set t,
@@ -1591,11 +1599,10 @@ __device__ __forceinline__ void rc_chunk(const RcArgs& a, const RcTile& tl, floa
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     RC_Q(t2); RC_ADD(ts.vjp, t2, t1);
-    /* Behind the VJP: the ring's registers are not live across it.  Measured alternatives (profiles/r05_ab_runs.txt, call 45 / 47):
-     * requested in front of the VJP 292 us per launch instead of 266, ring depth 6 302 (the allocator parks the B operand in scratch and
-     * reloads it inside the VJP: every scratch reload is a vmcnt(0)), the GEMM's events threaded through hook points of the VJP the way
-     * the forward threads them through the spline 313 (each event's operand wait also waits for the g_y stores and input requests queued
-     * in between: one in-order counter). */
+    /* Behind the VJP.  Measured alternatives (profiles/r05_ab_runs.txt, calls 45 / 47 / 52): the GEMM's events threaded through hook points
+     * of the VJP the way the forward threads them through the spline: 313 us per launch instead of 271 (each event's operand wait also
+     * waits for the g_y stores and input requests queued in between: one in-order counter); ring depth 6 / 8 and / or the ring started in
+     * front of the VJP: within 1 % (once the allocator stopped parking the B operand in scratch: see rc_vjp_slot). */
     if constexpr (NT > 0) g.start();
     if constexpr (NT > 0) g.template events<0, Live<(NT > 0 ? NT : 4), 4, RC_RD>::NEV>();
     asm volatile("" : "+v"(in.x), "+v"(in.gy));      /* the next chunk's first inputs are awaited here, in front of the stores below */
@@ -1785,7 +1792,12 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
     BGK_CHECK_ARG(ldy < (1 << 24) && ldo < (1 << 24), "%s: row stride too large", what);
     const int grid = (int)n_wg;
     hipStream_t st = (hipStream_t)stream;
+#if BGK_V2_SAVE
+#define BGK_LAUNCH(A, I) do { if (params) hipLaunchKernelGGL((coupling_rqs_dense_h2v2_kernel<A, I, true>), dim3(grid), dim3(FTHREADS), shmem, st, a); \
+                              else hipLaunchKernelGGL((coupling_rqs_dense_h2v2_kernel<A, I, false>), dim3(grid), dim3(FTHREADS), shmem, st, a); } while (0)
+#else
 #define BGK_LAUNCH(A, I) hipLaunchKernelGGL((coupling_rqs_dense_h2v2_kernel<A, I>), dim3(grid), dim3(FTHREADS), shmem, st, a)
+#endif
     if (act == 1) { if (inverse) BGK_LAUNCH(1, 1); else BGK_LAUNCH(1, 0); }
     else if (act == 2) { if (inverse) BGK_LAUNCH(2, 1); else BGK_LAUNCH(2, 0); }
     else { if (inverse) BGK_LAUNCH(3, 1); else BGK_LAUNCH(3, 0); }

@@ -5,7 +5,7 @@ files = glob.glob(path + "/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in files:
     for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
     if len(sys.argv) > 2 and sys.argv[2] not in k:
         continue

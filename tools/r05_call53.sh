@@ -1,0 +1,16 @@
+#!/bin/bash
+# GPU box, round 5 call 53: recompute backward, same-box A/B of the gradient maximum formed inside the slot (base) against left to the scheduler (nopin)
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r05c53; mkdir -p $O
+for v in nopin base nopin base; do
+  if [ "$v" = base ]; then lib=""; else lib="$PWD/gpurun_variants/lib_$v.so"; fi
+  OUT=gpurun_out/ab_rc_${v}; rm -rf $OUT; mkdir -p $OUT
+  BGK_LIB=$lib rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o kl -- python bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 --kl-steps 5 > $OUT/log.txt 2>&1
+  echo "== $v $(grep '"metric"' $OUT/log.txt | python -c 'import sys,json; print(json.loads(sys.stdin.read())["kl"]["steps_per_s"])')"
+  python - <<PY
+import csv,glob
+f=glob.glob("$OUT/stats/**/*kernel_stats.csv",recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:12]:
+    if any(k in r["Name"] for k in ("recompute","dx_kernel<1>")): print("   ", r["Name"][:70], r["Calls"], round(float(r["AverageNs"])/1e3,1), "us")
+PY
+done 2>&1 | tee $O/ab.txt
