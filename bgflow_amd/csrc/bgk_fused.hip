@@ -1138,6 +1138,210 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
     }
 }
 
+
+/* ---- conditioners with hidden layers of 129 .. 256 units (zero-padded to 256): coupling_rqs_dense_w256_kernel ---------------------
+ * The same decomposition -- a wave owns 32 samples for the whole layer, the previous layer's accumulators are the next GEMM's B
+ * operand without data movement -- at twice the width: 8 accumulator tiles (128 registers) + 16 k16-steps of hi / lo B operands
+ * (128 registers) + the A ring.  That is more than the 256 registers two waves per SIMD leave each other, so the kernel runs ONE wave
+ * per SIMD on the unified 512-entry file (launch bound 1).  Every GEMM produces 128 output rows at a time (four tiles, as in the
+ * width-128 kernel): layer 0 and layer 1 run as two 128-row halves over the same B operand, the parameter chunks as before.  Packed
+ * operands (dense.py::pack_dense_for_fused_w256): per 128-row GEMM the blocks (s, m, p) of the width-128 layout with s = 0 .. 15,
+ * followed by the 4 bias blocks; k order of the hidden layers = the accumulator layout of 8 tiles.  Inference only (both directions):
+ * training of such a layer runs the conditioner layer by layer. */
+constexpr int W_T = 8;                           /* hidden tiles: 256 units */
+constexpr int W_STEPS = 16;                      /* k16-steps over 256 inputs */
+constexpr int W_BLOCKS = W_STEPS * 4 * 2 + 4;    /* 1 KiB blocks of one 128-row GEMM over 256 inputs, incl. bias */
+constexpr int W_RING = 3;                        /* A fragments in flight: two k-steps (24 MFMAs) ahead of their use */
+struct BFragW { h16x8 hi[W_STEPS], lo[W_STEPS]; };
+
+template <int O, int N>
+__device__ __forceinline__ void w_mfma(f32x16 (&out)[N], const AFrag& a, const h16x8& bhi, const h16x8& blo) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[O + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][1]), bhi, out[O + m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[O + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), blo, out[O + m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) out[O + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a.v[m][0]), bhi, out[O + m], 0, 0, 0);
+}
+
+__device__ __forceinline__ void w_make_b(BFragW& b, const f32x16 (&in)[W_T]) {
+#pragma unroll
+    for (int s = 0; s < W_STEPS; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = in[s >> 1][8 * (s & 1) + e];
+        h2_split<false>(v, b.hi[s], b.lo[s]);
+    }
+}
+
+/* out[O .. O + 4) = W' b + b': 128 output rows over the 256 inputs held in b; N = tiles of the out array */
+template <int O, int N>
+__device__ __forceinline__ void w_gemm(f32x16 (&out)[N], const BFragW& b, const uint4* W, int lane) {
+    AFrag ring[W_RING];
+#pragma unroll
+    for (int s = 0; s < W_RING - 1; ++s) h2_load<false>(ring[s], W, s, lane);
+#pragma unroll
+    for (int s = 0; s < W_STEPS; ++s) {
+        constexpr int D = W_RING - 1;
+        if (s + D < W_STEPS) h2_load<false>(ring[(s + D) % W_RING], W, s + D, lane);
+        else if (s + D == W_STEPS) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ring[(s + D) % W_RING].v[m][0] = W[(W_STEPS * 8 + m) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch above this step's MFMAs */
+        w_mfma<O, N>(out, ring[s % W_RING], b.hi[s], b.lo[s]);
+    }
+    const h16x8 one2 = {(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        out[O + m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, ring[W_STEPS % W_RING].v[m][0]), one2, out[O + m], 0, 0, 0);
+}
+
+/* activation of x = t * c, the type chosen at run time (wave-uniform): one kernel instance per (direction, bin count) */
+__device__ __forceinline__ void w_act(f32x16 (&t)[W_T], float c, int act) {
+#pragma unroll
+    for (int m = 0; m < W_T; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[m][r] *= c;
+    if (act == 1) {
+#pragma unroll
+        for (int m = 0; m < W_T; ++m) act_tile_fast<1>(t[m]);
+    } else if (act == 2) {
+#pragma unroll
+        for (int m = 0; m < W_T; ++m) act_tile_fast<2>(t[m]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < W_T; ++m) act_tile_fast<3>(t[m]);
+    }
+}
+
+template <int INV, int KT>
+__global__ __launch_bounds__(FTHREADS, 1) void coupling_rqs_dense_w256_kernel(FusedArgsH2 ah) {
+    constexpr int DPCT = 128 / (3 * KT + 1);              /* dims per 128-column parameter chunk */
+    constexpr int ST = 32;
+    const FusedArgs& a = ah.f;
+    if (ah.cs_dev) { ah.c0 = ah.cs_dev[1]; ah.c1 = ah.cs_dev[3]; ah.c2 = ah.cs_dev[5]; }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;
+    float* s_y = s_p + 128 * ST;
+    const int d = a.d;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * FW + wave;
+    if (tile >= n_tiles) return;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+
+    /* ---- stage the (featurised) conditioner input [feature][sample], a constant-1 row for the bias, zero pad rows ---- */
+    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
+    for (int i = lane; i < 32 * a.d_c; i += 64) {
+        const int r = i / a.d_c, c = i - r * a.d_c;
+        float v = r < rows ? a.cond[(b0 + r) * a.ldc + c] : 0.0f;
+        if (a.periodic) {
+            float sv, cv;
+            bgk_sincos2pif(v, &sv, &cv);
+            s_p[c * SROW + r] = cv;
+            s_p[(a.d_c + c) * SROW + r] = sv;
+        } else {
+            s_p[c * SROW + r] = v;
+        }
+    }
+    for (int i = lane; i < (16 * ah.S0 - n_in) * 32; i += 64)
+        s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
+    for (int i = lane; i < 32 * d; i += 64) {
+        const int r = i / d, c = i - r * d;
+        s_y[c * SROW + r] = r < rows ? a.y[(b0 + r) * a.ldy + c] : 0.5f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    /* ---- layer 0: both 128-row halves per k-step (bias = weight column of the constant-1 feature), next step's A fragments in flight ---- */
+    f32x16 h[W_T];
+#pragma unroll
+    for (int m = 0; m < W_T; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
+    {
+        const uint4* A0b = ah.A0 + (size_t)ah.S0 * 8 * 64;      /* second half: rows 128 .. 255 */
+        AFrag fa, fb;
+        h2_load<false>(fa, ah.A0, 0, lane);
+        h2_load<false>(fb, A0b, 0, lane);
+        for (int s = 0; s < ah.S0; ++s) {
+            AFrag na = fa, nb = fb;
+            if (s + 1 < ah.S0) {
+                h2_load<false>(na, ah.A0, s + 1, lane);
+                h2_load<false>(nb, A0b, s + 1, lane);
+            }
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = s_p[(16 * s + 8 * hh + e) * SROW + j];
+            h16x8 bhi, blo;
+            h2_split<false>(v, bhi, blo);
+            w_mfma<0, W_T>(h, fa, bhi, blo);
+            w_mfma<4, W_T>(h, fb, bhi, blo);
+            fa = na; fb = nb;
+        }
+    }
+    w_act(h, ah.c0, a.act);
+
+    /* ---- layer 1: two 128-row halves over the same B operand ---- */
+    BFragW bf;
+    w_make_b(bf, h);
+#pragma unroll
+    for (int m = 0; m < W_T; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
+    w_gemm<0, W_T>(h, bf, ah.A1, lane);
+    w_gemm<4, W_T>(h, bf, ah.A1 + (size_t)W_BLOCKS * 64, lane);
+    w_act(h, ah.c1, a.act);
+    w_make_b(bf, h);                                /* the layer-2 B operands, shared by all chunks */
+
+    /* ---- layer 2 in chunks of 128 packed columns + spline ---- */
+    float run = 0.0f;
+    int oob_local = 0;
+    for (int c = 0; c < a.n_chunks; ++c) {
+        f32x16 p[4];
+        zero4(p);
+        w_gemm<0, 4>(p, bf, ah.A2 + (size_t)c * W_BLOCKS * 64, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * ST + j] = p[m][r] * ah.c2;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nd = (d - c * DPCT) < DPCT ? (d - c * DPCT) : DPCT;
+        if constexpr (KT == KB) {
+            int bins[3] = {0, 0, 0};
+            NoGemm g;
+            spline_chunk<INV, NoGemm, ST, true>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+            if (a.bin_idx) {
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int q = 2 * it + hh;
+                    if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
+                }
+            }
+        } else {
+            spline_chunk_k<INV, KT, ST, true>(a, s_p, s_y, c, nd, hh, j, rows, b0, run, oob_local);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (hh == 0 && j < rows) {
+        if (a.accumulate) a.dlogp[b0 + j] += run; else a.dlogp[b0 + j] = run;
+    }
+    for (int i = lane; i < rows * d; i += 64) {
+        const int r = i / d, cc = i - r * d;
+        a.out[(b0 + r) * a.ldo + cc] = s_y[cc * SROW + r];
+    }
+    if (a.oob_count) {
+        for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
+        if (lane == 0 && oob_local) atomicAdd(a.oob_count, oob_local);
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t bgk_pack_rqs_columns(int32_t d, int32_t K, const int32_t* nc_slot_host, int32_t* src_col) {
@@ -1226,7 +1430,12 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     BGK_CHECK_ARG(cond && A0p && A1p && A2p && y && out && dlogp, "%s: null pointer", what);
     BGK_CHECK_ARG(B >= 0 && d > 0 && d_c > 0, "%s: bad sizes", what);
     const bool other_k = (K == 4 || K == 12 || K == 16 || K == 32) && operand_dtype == 0;     /* K != 8: split-f16 only (inference and training forward) */
-    if (H0 != HID || H1 != HID || (K != KB && !other_k) || d > 64 || act < 1 || act > 3) {
+    const bool wide = H0 == 32 * W_T && H1 == 32 * W_T;      /* hidden width 256 (129 .. 255 zero-padded by the packer): split-f16 inference */
+    if (wide && (operand_dtype != 0 || z0 || z1 || params || (segs && segs->n > 1))) {
+        bgk_set_error("%s: hidden width 256 runs fused in split-f16 inference from one conditioning tensor only", what);
+        return BGK_EUNSUPPORTED;
+    }
+    if ((!wide && (H0 != HID || H1 != HID)) || (K != KB && !other_k) || d > 64 || act < 1 || act > 3) {
         bgk_set_error("%s: only hidden=(128,128), n_bins=8 (4 | 12 | 16 | 32: split-f16 form only), d<=64, act in {SiLU,ReLU,Tanh} are fused "
                       "(got H0=%d H1=%d K=%d d=%d act=%d)", what, H0, H1, K, d, act);
         return BGK_EUNSUPPORTED;
@@ -1240,6 +1449,38 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0,
                   "Minimal bin width/height too large for the number of bins");
     if (B == 0) return 0;
+    if (wide) {
+        FusedArgsH2 ah;
+        FusedArgs& a = ah.f;
+        a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
+        a.W0 = nullptr; a.W1 = nullptr; a.W2 = nullptr; a.T0 = 0;
+        const int ppd_k = 3 * K + 1, dpc_k = 128 / ppd_k;
+        a.n_chunks = (d + dpc_k - 1) / dpc_k;
+        a.last_tiles = ((d - (a.n_chunks - 1) * dpc_k) * ppd_k + 31) / 32;
+        a.act = act; a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.inverse = inverse;
+        a.circ_mask = circ_mask;
+        a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
+        a.bin_idx = bin_idx; a.oob_count = oob_count;
+        a.lds_per_wave = 128 * 32 + (d + 1) * SROW;
+        a.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, K);
+        ah.A0 = reinterpret_cast<const uint4*>(A0p); ah.S0 = S0;
+        ah.A1 = reinterpret_cast<const uint4*>(A1p);
+        ah.A2 = reinterpret_cast<const uint4*>(A2p);
+        ah.c0 = c0; ah.c1 = c1; ah.c2 = c2; ah.cs_dev = cs_dev;
+        ah.z0 = nullptr; ah.z1 = nullptr; ah.params = nullptr; ah.ldp = 0; ah.src_col = nullptr;
+        const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
+        const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
+        BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
+        const int grid = (int)n_wg;
+        hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCHW(I, KK) hipLaunchKernelGGL((coupling_rqs_dense_w256_kernel<I, KK>), dim3(grid), dim3(FTHREADS), shmem, st, ah)
+#define BGK_LAUNCHW2(KK) do { if (inverse) BGK_LAUNCHW(1, KK); else BGK_LAUNCHW(0, KK); } while (0)
+        if (K == 8) BGK_LAUNCHW2(8); else if (K == 4) BGK_LAUNCHW2(4); else if (K == 12) BGK_LAUNCHW2(12);
+        else if (K == 16) BGK_LAUNCHW2(16); else BGK_LAUNCHW2(32);
+#undef BGK_LAUNCHW2
+#undef BGK_LAUNCHW
+        return bgk_launch_status(what);
+    }
     /* second-generation kernels: their staging index math uses 24-bit multiplies (row strides below 2^24 floats) */
     const bool v2_ok = bgk_h2_variant == 2 && K == KB && ldc < (1 << 24) && ldy < (1 << 24) && ldo < (1 << 24);
     if (segs && segs->n > 1 && !v2_ok) return BGK_EUNSUPPORTED;     /* several conditioning tensors: second-generation kernels only */

@@ -534,6 +534,34 @@ def pack_dense_for_fused_h2(linears, nc_slot_host, d, n_bins):
     return A0, A1, A2, (2.0 ** -e0, 2.0 ** -e1, 2.0 ** -e2)
 
 
+def pack_dense_for_fused_w256(linears, nc_slot_host, d, n_bins):
+    """Pack DenseNet([n_in, 256, 256, P]) for the width-256 kernel behind bgk_coupling_rqs_dense_h2 (H0 = H1 = 256;
+    bgk_fused.hip::coupling_rqs_dense_w256_kernel): every GEMM produces 128 output rows at a time, so layer 0 and layer 1 are packed as
+    two 128-row halves (rows 0..127, then 128..255), each in the width-128 block layout with 16 k16-steps over the 256 hidden inputs
+    (k order = the accumulator layout of 8 tiles), the parameter chunks likewise.  Returns (A0, A1, A2 f16 device tensors, (c0, c1, c2))."""
+    l0, l1, l2 = linears
+    W0, b0 = l0.weight.detach().float(), l0.bias.detach().float()
+    W1, b1 = l1.weight.detach().float(), l1.bias.detach().float()
+    W2, b2 = l2.weight.detach().float(), l2.bias.detach().float()
+    assert W0.shape[0] == 256 and W1.shape == (256, 256) and W2.shape[1] == 256
+    n_in = l0.in_features
+    S0 = (n_in + 1 + 15) // 16
+    e0, e1, e2 = _h2_scale_exp(W0, b0), _h2_scale_exp(W1, b1), _h2_scale_exp(W2, b2)
+    W0e = torch.zeros(256, 16 * S0, dtype=torch.float32, device=W0.device)
+    W0e[:, :n_in] = W0
+    W0e[:, n_in] = b0                                   # column of the constant-1 feature
+    kh = _h2_k_hidden(8)
+    A0 = torch.cat([_pack_h2(W0e[g * 128:(g + 1) * 128] * 2.0 ** e0, None, _h2_k_natural(S0)) for g in range(2)], dim=0).contiguous()
+    A1 = torch.cat([_pack_h2(W1[g * 128:(g + 1) * 128] * 2.0 ** e1, b1[g * 128:(g + 1) * 128] * 2.0 ** e1, kh) for g in range(2)],
+                   dim=0).contiguous()
+    src_t = _src_col_table(d, n_bins, nc_slot_host, W2.device).to(torch.int64)
+    W2r = torch.where(src_t[:, None] >= 0, W2[src_t.clamp_min(0)], torch.zeros((), dtype=W2.dtype, device=W2.device)) * 2.0 ** e2
+    b2r = torch.where(src_t >= 0, b2[src_t.clamp_min(0)], torch.zeros((), dtype=b2.dtype, device=b2.device)) * 2.0 ** e2
+    A2 = torch.cat([_pack_h2(W2r[c * 128:(c + 1) * 128], b2r[c * 128:(c + 1) * 128], kh)
+                    for c in range(src_t.numel() // 128)], dim=0).contiguous()
+    return A0, A1, A2, (2.0 ** -e0, 2.0 ** -e1, 2.0 ** -e2)
+
+
 DEVICE_PACK = True     # pack split-f16 operands with bgk_pack_dense_h2 (no host sync); False: the torch reference packer
 
 
@@ -679,9 +707,14 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
                                         "SiLU / ReLU / Tanh")
         return None
     (l0, l1, l2), act = spec
-    if l0.out_features > 128 or l1.out_features > 128:
-        return _reject(transformer, f"hidden layers ({l0.out_features}, {l1.out_features}): widths up to 128 are fused")
-    padded = (l0.out_features, l1.out_features) != (128, 128)    # narrower hidden layers run zero-padded to the kernels' 128 rows
+    H_max = max(l0.out_features, l1.out_features)
+    if H_max > 256:
+        return _reject(transformer, f"hidden layers ({l0.out_features}, {l1.out_features}): widths up to 256 are fused")
+    if H_max > 128 and mode != "f16x2":
+        return _reject(transformer, f"hidden layers ({l0.out_features}, {l1.out_features}) in gemm_mode '{mode}': widths above 128 are "
+                                    f"fused in mode 'f16x2' only")
+    H_run = 128 if H_max <= 128 else 256                # narrower hidden layers run zero-padded to the kernels' 128 / 256 rows
+    padded = (l0.out_features, l1.out_features) != (H_run, H_run)
     if y_dim > 64:
         return _reject(transformer, f"{y_dim} transformed dims: at most 64 are fused")
     n_nc = int((nc_slot_host >= 0).sum())
@@ -709,12 +742,15 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
         stale = True
     if stale:
         common = dict(version=version, y_dim=y_dim, mode=mode, device=dev, act=act, periodic=periodic, d_c=d_c, n_bins=n_bins,
-                      padded=padded, circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
+                      padded=padded, hidden=H_run, circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)))
         if padded:
-            l0, l1, l2 = _pad_hidden((l0, l1, l2), 128)
+            l0, l1, l2 = _pad_hidden((l0, l1, l2), H_run)
         if mode == "bf16" and dev.type != "cuda":
             return None
-        if mode == "bf16" or (mode == "f16x2" and DEVICE_PACK and dev.type == "cuda"):
+        if H_run == 256:       # the width-256 kernel (inference): operands from the torch packer
+            cache.update(common, packed=pack_dense_for_fused_w256((l0, l1, l2), nc_slot_host, y_dim, n_bins), cs=None)
+            cache.pop("bufs", None)
+        elif mode == "bf16" or (mode == "f16x2" and DEVICE_PACK and dev.type == "cuda"):
             if "src_col_dev" not in cache:
                 cache["src_col_dev"] = _src_col_table(y_dim, n_bins, nc_slot_host, dev)
             n_chunks = cache["src_col_dev"].numel() // 128
@@ -738,7 +774,7 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
     if plan is None or x.shape[-1] != plan["d_c"]:
         return None
     parts = _cond_parts(x)
-    if len(parts) > 1 and (plan["mode"] == "f32" or plan["n_bins"] != 8):
+    if len(parts) > 1 and (plan["mode"] == "f32" or plan["n_bins"] != 8 or plan["hidden"] != 128):
         parts = [x.cat()]                 # several conditioning tensors: the second-generation kernel only
     _lib.require_hip(y, *parts)
     W0p, W1p, W2p = plan["packed"][:3]
@@ -753,7 +789,7 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
         dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=y.device), False
     bins = torch.empty((B, d), dtype=torch.int32, device=y.device) if want_bin_idx else None
     s = transformer._default_settings
-    tail = (128, 128, plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
+    tail = (plan["hidden"], plan["hidden"], plan["act"], _lib.ptr(y2), ldy, B, d, plan["n_bins"], plan["circ_mask"], int(inverse),
             transformer._left, transformer._right, transformer._bottom, transformer._top,
             s["min_bin_width"], s["min_bin_height"], s["min_derivative"], int(s.get("enable_identity_init", False)),
             _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)), _lib.ptr(bins), _lib.ptr(oob_counter), _lib.stream_ptr(y.device))
@@ -1242,9 +1278,13 @@ def _spline_train_prep(transformer, x, y, nc_dev, nc_host, inverse, oob_counter)
     or None when the conditioner is not a fusable DenseNet."""
     if x.dim() != 2 or y.dim() != 2 or not x.is_cuda or x.dtype != torch.float32 or _gemm_mode(transformer) != "f16x2":
         return None
+    net = transformer._params_net
+    spec = _fusable_dense(net.net if type(net) is WrapPeriodic else net)
+    if spec is not None and max(spec[0][0].out_features, spec[0][1].out_features) > 128:
+        return None                 # hidden layers wider than 128: fused in inference only (no operand packing per training step)
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
     if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device \
-            or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
+            or plan["hidden"] != 128 or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
         return None                                        # second-generation kernel, the others on the first-generation one
     _lib.require_hip(x, y)
     if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:

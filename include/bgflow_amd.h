@@ -334,7 +334,10 @@ int bgk_coupling_rqs_dense(const float* cond, int64_t ldc, int32_t d_c, int32_t 
  * unscale factors from bgflow_amd/dense.py::pack_dense_for_fused_h2 (layout in bgk_fused.hip / DESIGN.md); or, when the
  * operands were packed on the device by bgk_pack_dense_h2, cs_dev = its scale table (c0..c2 are then ignored).
  * operand_dtype 0: split-f16 (above); 1: single bf16 operands (bf16 parameter storage + bf16 GEMM inputs, f32
- * accumulate; knots, bin search and log-det stay f32) -- the reduced-precision variant of BASELINE config 5. */
+ * accumulate; knots, bin search and log-det stay f32) -- the reduced-precision variant of BASELINE config 5.
+ * H0 = H1 = 128: the envelope of every variant.  H0 = H1 = 256 (conditioner_factory.py:76-80 takes any `hidden`; 129 .. 255 units
+ * zero-padded by the packer): split-f16 inference (operand_dtype 0) with operands from bgflow_amd/dense.py::pack_dense_for_fused_w256
+ * -- one wave per SIMD on the unified 512-register file (bgk_fused.hip::coupling_rqs_dense_w256_kernel); other widths: BGK_EUNSUPPORTED. */
 int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                               const void* A0p, const void* A1p, const void* A2p,
                               float c0, float c1, float c2, const float* cs_dev, int32_t operand_dtype,

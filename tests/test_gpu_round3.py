@@ -215,7 +215,7 @@ def test_envelope_warnings(hip_lib, dev):
     import warnings
     import bgflow_amd as bg
     from bgflow_amd.utils import hash_init_
-    net = bg.DenseNet([9, 256, 256, 3 * 8 * 17 + 17], activation=torch.nn.SiLU())
+    net = bg.DenseNet([9, 384, 384, 3 * 8 * 17 + 17], activation=torch.nn.SiLU())
     layer = hash_init_(bg.CouplingFlow(bg.ConditionalSplineTransformer(net, is_circular=False), transformed_indices=(0,),
                                        cond_indices=(3,))).to(dev)
     xs = _prior("cfg3", 100, dev, seed=13)
@@ -225,7 +225,7 @@ def test_envelope_warnings(hip_lib, dev):
             layer(*xs)
             layer(*xs)
     msgs = [str(x.message) for x in w if "fused" in str(x.message)]
-    assert len(msgs) == 1 and "(256, 256)" in msgs[0]
+    assert len(msgs) == 1 and "(384, 384)" in msgs[0]
 
 
 @pytest.mark.parametrize("hidden", [(64, 64), (32, 96), (100, 100)])

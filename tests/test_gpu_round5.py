@@ -604,3 +604,90 @@ def test_kl_integrand_inside_the_generation_tail(hip_lib, dev, B, drop):
     num = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(g1, g0))
     den = sum(float((b.double() ** 2).sum()) for b in g0)
     assert (num / den) ** 0.5 <= 2e-6, f"flat gradient: relative L2 {(num / den) ** 0.5:.2e} between the single-pass and the two-launch form"
+
+
+# ---- hidden layers of 129 .. 256 units on the one-launch kernel (bgk_fused.hip::coupling_rqs_dense_w256_kernel) ----------------------
+@pytest.mark.parametrize("hidden", [(256, 256), (200, 130)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_spline_coupling_with_hidden_width_256_runs_fused(hip_lib, dev, hidden, inverse):
+    """conditioners with hidden layers wider than 128 (up to 256; in between zero-padded) run as ONE launch in split-f16 mode: same
+    function as the conditioner evaluated layer by layer, checked against the f64 oracle (non-periodic and periodic conditioner input,
+    non-circular and circular splines, a batch that is not a multiple of the 32-sample tile)"""
+    from bgflow_amd import configs
+    from bgflow_amd.utils import hash_init_, synth
+    from oracle import flow_oracle as fo
+    dims = {"BONDS": 17, "ANGLES": 17, "TORSIONS": 17, "FIXED": 9}
+    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+    t = lambda v: torch.as_tensor(v, dtype=torch.float32, device=dev)                                   # noqa: E731
+    for what, on in (("TORSIONS", "FIXED"), ("BONDS", "TORSIONS"), ("FIXED", "TORSIONS")):
+        layer_cpu = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, hidden=hidden))
+        layer = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, hidden=hidden)).to(dev)
+        B = 1037
+        xs = [synth(B + 7 * i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9))]
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                     # a rejection (RuntimeWarning) would mean the generic path ran
+            with torch.no_grad():
+                *outs, dl = layer(*[t(v) for v in xs], inverse=inverse)
+        plan = layer.transformer._fused_cache
+        assert plan.get("hidden") == 256 and plan.get("padded") == (hidden != (256, 256)), "the width-256 kernel must have run"
+        ti = slot[what]
+        outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, [])
+        np.testing.assert_allclose(outs[ti].cpu().numpy(), outs64[ti], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=2e-5, atol=2e-5)
+        for k in range(4):
+            if k != ti:
+                assert torch.equal(outs[k], t(xs[k])), "conditioning fields pass through untouched"
+    # training falls back to the layer-by-layer conditioner: gradients flow, no operand packing per step
+    xs_t = [t(v) for v in xs]
+    *_, dl_t = layer(*xs_t, inverse=inverse)
+    dl_t.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("n_bins", [4, 12, 16, 32])
+@pytest.mark.parametrize("act", [torch.nn.ReLU, torch.nn.Tanh])
+def test_hidden_width_256_other_bin_counts_and_activations(hip_lib, dev, n_bins, act):
+    """the width-256 kernel for the other fused bin counts and activations, round trip included; bin indices against the layer-by-layer
+    path (ties at a knot aside)"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_, synth
+    from oracle import flow_oracle as fo
+    d, d_c = 11, 23
+    P = 3 * n_bins * d + d
+    mk = lambda: hash_init_(bg.CouplingFlow(bg.ConditionalSplineTransformer(                       # noqa: E731
+        bg.DenseNet([d_c, 192, 256, P], activation=act()), is_circular=False), transformed_indices=(1,), cond_indices=(0,)))
+    layer_cpu, layer = mk(), mk().to(dev)
+    B = 4099
+    xs = [synth(B, B, d_c), synth(B + 5, B, d, uniform=True)]
+    dx = [torch.as_tensor(v, dtype=torch.float32, device=dev) for v in xs]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with torch.no_grad():
+            _, y, dl = layer(*dx)
+            _, back, dl_back = layer(dx[0], y, inverse=True)
+    assert layer.transformer._fused_cache.get("hidden") == 256
+    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], False, np.float64, [])
+    np.testing.assert_allclose(y.cpu().numpy(), outs64[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(back.cpu().numpy(), xs[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose((dl + dl_back).cpu().numpy(), 0.0, atol=1e-4)
+
+
+def test_hidden_width_256_full_size_rows_against_the_layerwise_path(hip_lib, dev):
+    """2^18 samples through the width-256 kernel: every output against the conditioner run layer by layer in f32 (library GEMMs) + the
+    stand-alone spline kernel; the share of samples beyond 1e-5 stays at tie level"""
+    from bgflow_amd.utils import synth
+    layer = _spline_layer(dev, what="ANGLES", on="BONDS", hidden=(256, 256))
+    B = 1 << 18
+    xs = [torch.as_tensor(synth(B + 7 * i, B, d, uniform=True), dtype=torch.float32, device=dev) for i, d in enumerate((17, 17, 17, 9))]
+    with torch.no_grad():
+        *outs, dl = layer(*xs)
+        layer.transformer.allow_fused = False
+        *outs_ref, dl_ref = layer(*xs)
+        layer.transformer.allow_fused = True
+    assert layer.transformer._fused_cache.get("hidden") == 256
+    err = (outs[1] - outs_ref[1]).abs().max(dim=1).values
+    assert float(err.median()) < 2e-6 and float((err > 1e-5).float().mean()) < 2e-3
+    derr = (dl - dl_ref).abs().view(-1)
+    assert float(derr.median()) < 5e-6 and float((derr > 1e-4).float().mean()) < 2e-3

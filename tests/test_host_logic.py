@@ -308,6 +308,71 @@ def test_split_f16_packing_layout():
     np.testing.assert_allclose(got0, W0.double().numpy() @ x0[:n_in] + b0.double().numpy(), rtol=0, atol=1e-5)
 
 
+def test_width_256_packing_reproduces_the_conditioner():
+    """operands of the width-256 kernel (dense.pack_dense_for_fused_w256): layer 0 and layer 1 as two 128-row halves, 16 k16-steps in
+    the accumulator layout of 8 tiles, parameter chunks regrouped per transformed dim -- a numpy restatement of the kernel's dataflow
+    reproduces DenseNet([n_in, 256, 256, P]) column for column"""
+    import bgflow_amd as bg
+    from bgflow_amd import dense
+    from bgflow_amd.utils import hash_init_
+    d, n_in, K = 7, 21, 8
+    P = 3 * K * d + d
+    net = hash_init_(bg.DenseNet([n_in, 256, 256, P], activation=torch.nn.SiLU())).double()
+    l0, l1, l2 = net._layers[0], net._layers[2], net._layers[4]
+    nc_host = np.arange(d, dtype=np.int32)
+    A0, A1, A2, (c0, c1, c2) = dense.pack_dense_for_fused_w256((l0, l1, l2), nc_host, d, K)
+    S0 = (n_in + 1 + 15) // 16
+    src = dense._src_col_table(d, K, nc_host, "cpu").numpy()
+    n_chunks = src.size // 128
+    assert A0.shape == (2 * S0 * 8, 64, 8) and A1.shape == (2 * 132, 64, 8) and A2.shape == (n_chunks * 132, 64, 8)
+    A0, A1, A2 = A0.numpy(), A1.numpy(), A2.numpy()
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=n_in)
+    x0 = np.zeros(16 * S0)
+    x0[:n_in] = x
+    x0[n_in] = 1.0
+    bv0 = [[x0[16 * s + 8 * kb:16 * s + 8 * kb + 8] for kb in range(2)] for s in range(S0)]
+    silu = lambda v: v / (1.0 + np.exp(-v))                                                          # noqa: E731
+
+    def acc_layout(a):      # B operands of the 16 k16-steps taken from 8 accumulator tiles
+        return [[np.array([a[32 * (s >> 1) + ((8 * (s & 1) + ee) & 3) + 8 * ((8 * (s & 1) + ee) >> 2) + 4 * kb] for ee in range(8)])
+                 for kb in range(2)] for s in range(16)]
+
+    h0 = np.concatenate([_emulate_h2_gemm(A0[g * S0 * 8:(g + 1) * S0 * 8], 4, S0, bv0) for g in range(2)]) * c0
+    b1 = acc_layout(silu(h0))
+    h1 = np.concatenate([_emulate_h2_gemm(A1[g * 132:(g + 1) * 132], 4, 16, b1) for g in range(2)]) * c1
+    b2 = acc_layout(silu(h1))
+    got = np.full(P, np.nan)
+    for c in range(n_chunks):
+        pc = _emulate_h2_gemm(A2[c * 132:(c + 1) * 132], 4, 16, b2) * c2
+        live = src[c * 128:(c + 1) * 128] >= 0
+        got[src[c * 128:(c + 1) * 128][live]] = pc[live]
+        assert np.all(pc[~live] == 0.0)
+    ref = net(torch.tensor(x)[None]).detach().numpy()[0]
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
+
+
+def test_width_256_plan_envelope():
+    """hidden layers of 129 .. 256 units plan the width-256 kernel (zero-padded), in split-f16 mode only; wider ones are rejected with
+    one warning -- host logic, no launch"""
+    import warnings
+    import bgflow_amd as bg
+    from bgflow_amd import dense
+    nc = np.full(5, -1, dtype=np.int32)
+    mk = lambda h: bg.ConditionalSplineTransformer(bg.DenseNet([9, *h, 3 * 8 * 5], torch.nn.SiLU()), is_circular=True)     # noqa: E731
+    for h, padded in (((256, 256), False), ((200, 130), True), ((64, 256), True)):
+        plan = dense._fused_plan(mk(h), 5, nc)
+        assert plan["hidden"] == 256 and plan["padded"] == padded and plan["n_bins"] == 8 and plan["cs"] is None
+        assert plan["packed"][1].shape == (2 * 132, 64, 8)
+    tr = mk((256, 256))
+    tr.gemm_mode = "f32"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert dense._fused_plan(tr, 5, nc) is None and dense._fused_plan(mk((384, 384)), 5, nc) is None
+    assert len(w) == 2 and "f16x2" in str(w[0].message) and "up to 256" in str(w[1].message)
+    assert dense._fused_plan(mk((100, 100)), 5, nc)["hidden"] == 128
+
+
 def test_gemm_mode_switch_and_errors():
     import bgflow_amd as bg
     from bgflow_amd import dense

@@ -1,0 +1,41 @@
+"""One spline coupling layer (B|A, 17 dims) with a DenseNet conditioner of hidden width H at 2^20 samples: the one-launch kernel against
+the conditioner run layer by layer (library GEMMs) + the stand-alone spline kernel.  python tools/r05_w256.py [B] [reps]   (GPU box)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bgflow_amd import configs
+from bgflow_amd.utils import hash_init_
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dev = torch.device("cuda:0")
+dims = {"BONDS": 17, "ANGLES": 17, "TORSIONS": 17, "FIXED": 9}
+circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+g = torch.Generator(device=dev).manual_seed(0)
+xs = [torch.rand(B, d, device=dev, generator=g) for d in (17, 17, 17, 9)]
+
+
+def ms(fn):
+    with torch.no_grad():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+for H in (128, 192, 256):
+    layer = hash_init_(configs._spline_coupling("BONDS", "ANGLES", dims, circ, slot, hidden=(H, H))).to(dev)
+    for inverse in (False, True):
+        layer.transformer.allow_fused = True
+        t_f = ms(lambda: layer(*xs, inverse=inverse))
+        layer.transformer.allow_fused = False
+        t_g = ms(lambda: layer(*xs, inverse=inverse))
+        flops = 2.0 * B * (17 * H + H * H + H * 425)
+        print(f"H={H} inverse={int(inverse)} B={B}: one launch {t_f:.3f} ms ({flops / t_f / 1e9:.0f} algorithmic TFLOP/s)   layer by layer {t_g:.3f} ms")
