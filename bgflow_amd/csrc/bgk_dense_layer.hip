@@ -1,0 +1,261 @@
+/* bgk_dense_layer.hip -- ONE Linear layer of a conditioner, y = act(x W^T + b)  (nn/dense.py:30-48: Linear (+ activation) per entry of
+ * DenseNet._layers), for the networks the one-launch coupling kernels do not take: other depths than two / three hidden layers, hidden
+ * layers wider than 256, more than 64 transformed dims, the README flow's [1, 4, 1] nets.  The layer-by-layer path of such a coupling is
+ *   bgk_dense_layer x n_layers  ->  bgk_rqs_transform | bgk_affine_transform
+ * with the activations of a layer in HBM between the launches.
+ *
+ * Roofline: HBM for the builder's shapes (4 (n_in + n_out) B per sample against 2 n_in n_out flops x 3 MFMAs per product: 256 -> 425
+ * is 2.7 KB and 0.65 MFLOP executed per sample, 0.36 ms of traffic and 0.27 ms of matrix work at 2^20), matrix cores beyond ~ 400 x 400.
+ *
+ * Decomposition (gfx950): as in the coupling kernels a wave owns 32 samples and computes EVERY output feature for them, so x is read
+ * once and y written once; D[feature, sample] = W[feature, k] X[k, sample] with v_mfma_f32_32x32x16_f16 in split-f16 form (hi + lo
+ * f16 pairs, three MFMAs per product, f32 accumulate: f32-class).
+ *   - B operand: the wave's [32 samples][n_in] tile arrives as row-contiguous 16-byte pieces (a wave instruction = 1 KB of consecutive
+ *     row bytes) in LDS, is read back in fragment order (lane (kb, j): the 8 consecutive features 16 s + 8 kb .. + 7 of row j, two
+ *     16-byte reads per k16-step; row stride == 4 mod 64 banks), brought under a per-tile power-of-two scale (largest magnitude into
+ *     [2^14, 2^15): inputs of any range, unlike the coupling kernels' bounded activations), split once and kept in registers as
+ *     hi / lo fragments (8 per k-step) for every 128-row group of output features.  Loaded in fragment order straight from global
+ *     memory (32-byte pieces of 32 different rows per instruction, every 128-byte line touched by 8 instructions) the 256-input
+ *     layers ran 1.7 ms at 2^20 whether the fragments then sat in LDS or in registers (profiles/r05_ab_runs.txt calls 58 / 59);
+ *   - A operand: the weights packed on the host (dense.py::pack_linear_layer) under a per-layer power-of-two scale, per 128 output
+ *     rows the blocks (s, m, p) of the coupling kernels' layout (natural k order), streamed from L2 through a ring of 2 - 6 k-steps;
+ *   - epilogue on the accumulators: unscale, + y (accumulate: the second and later 256-column passes of a wider input), + bias,
+ *     activation (the reproducible polynomial SiLU / Tanh of bgk_detmath_pk.h); the 128-feature group leaves through the tile's LDS
+ *     space as row-contiguous 16-byte pieces (32 lanes per 512-byte row segment).
+ * k-steps per pass: template constant S in {1, 2, 4, 8, 12, 16} (the packer pads with zero columns); inputs wider than 256 columns run
+ * as passes of <= 256 columns that accumulate into y.  Registers: 8 S (operand) + 64 (accumulators) + 96 (A ring): two waves per
+ * SIMD up to S = 8, one wave on the unified 512-register file beyond.  LDS: 32 x max(16 S + 4, 132) floats per wave.
+ */
+#include "bgk_mfma_h2.h"
+#include "bgk_detmath_pk.h"
+
+namespace {
+
+constexpr int LW = 4;                 /* waves per workgroup */
+#ifndef BGK_LAYER_RING
+#define BGK_LAYER_RING 6               /* A-ring depth of the one-wave-per-SIMD instances (S = 12, 16): 3 -> 6 is - 3 % (call 62) */
+#endif
+
+struct LayerArgs {
+    const float* x; int64_t ldx; int n_in;       /* this pass' input columns (<= 16 S) */
+    const uint4* A; int G;                       /* packed weights: G groups of 128 output rows x S k16-steps x 4 tiles x {hi, lo} */
+    float c;                                     /* 2^-s of the weights' scale */
+    const float* bias; int act;                  /* applied by the last pass: bias [n_out] or null; 0 none, 1 SiLU, 2 ReLU, 3 Tanh */
+    float* y; int64_t ldy; int n_out; int64_t B;
+    int accumulate;                              /* y = act(y + x W^T + b) */
+    int x_al, y_al;                              /* rows of x / y start on 16-byte boundaries */
+};
+
+__device__ __forceinline__ float layer_act(float v, int act) {
+    if (act == 2) return v > 0.0f ? v : 0.0f;
+    return v;
+}
+
+/* item lane, lane + 64, lane + 128, ... of a row-major [rows][w] tile as (row, column) without a division per item */
+struct RowWalk {
+    int r, c, dr, dc, w;
+    __device__ __forceinline__ RowWalk(int lane, int w_) : w(w_) { r = lane / w; c = lane - r * w; dr = 64 / w; dc = 64 - dr * w; }
+    __device__ __forceinline__ void next() { r += dr; c += dc; if (c >= w) { c -= w; ++r; } }
+};
+
+template <int S>
+__global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(LayerArgs a) {
+    constexpr int XS = 16 * S + 4;                  /* LDS row stride of the input tile, floats (== 4 mod 64 banks: 16-byte reads of 16 rows hit 64 banks) */
+    constexpr int YS = 128 + 4;                     /* ... of a 128-feature output group */
+    constexpr int PER_WAVE = 32 * (XS > YS ? XS : YS);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* s_t = smem + (size_t)wave * PER_WAVE;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * LW + wave;
+    if (tile >= n_tiles) return;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    const bool live = j < rows;
+
+    /* ---- the tile's rows: row-contiguous 16-byte pieces (a wave instruction = 1 KB of consecutive row bytes) into LDS [row][XS] ---- */
+    if (a.x_al && (a.n_in & 3) == 0) {
+        /* every request of the tile in flight before the first LDS write: 2 S pieces per lane at most, no branch (pieces past the
+         * tile's end repeat a piece of its last row: same data to the same place) */
+        RowWalk wk(lane, a.n_in >> 2);
+        float4 t[2 * S];
+        int off[2 * S];
+#pragma unroll
+        for (int it = 0; it < 2 * S; ++it) {
+            const int r = wk.r < rows ? wk.r : rows - 1;
+            t[it] = *reinterpret_cast<const float4*>(a.x + (b0 + r) * a.ldx + 4 * wk.c);
+            off[it] = r * XS + 4 * wk.c;
+            wk.next();
+        }
+#pragma unroll
+        for (int it = 0; it < 2 * S; ++it) *reinterpret_cast<float4*>(s_t + off[it]) = t[it];
+    } else {
+        /* rows that do not start on 16-byte boundaries (17 conditioning features, a column slice): dword requests, consecutive lanes
+         * on consecutive floats, 16 per lane in flight */
+        RowWalk wk(lane, a.n_in);
+        const int n_chunks = (rows * a.n_in + 1023) >> 10;
+        for (int ch = 0; ch < n_chunks; ++ch) {
+            float t[16];
+            int off[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int r = wk.r < rows ? wk.r : rows - 1;
+                t[it] = a.x[(b0 + r) * a.ldx + wk.c];
+                off[it] = r * XS + wk.c;
+                wk.next();
+            }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) s_t[off[it]] = t[it];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    /* ---- fragment order (lane (kb, j): features 16 s + 8 kb .. + 7 of row j), largest magnitude, split under its power-of-two scale ---- */
+    h2_h16x8 bhi[S], blo[S];
+    float inv_tile;
+    {
+        float v[S][8];
+        float m = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int col = 16 * s + 8 * hh + 4 * g;
+                const float4 q = *reinterpret_cast<const float4*>(s_t + j * XS + col);       /* beyond the data: whatever LDS holds, discarded below */
+                v[s][4 * g + 0] = (live && col + 0 < a.n_in) ? q.x : 0.0f;
+                v[s][4 * g + 1] = (live && col + 1 < a.n_in) ? q.y : 0.0f;
+                v[s][4 * g + 2] = (live && col + 2 < a.n_in) ? q.z : 0.0f;
+                v[s][4 * g + 3] = (live && col + 3 < a.n_in) ? q.w : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(v[s][e]));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+        const float sc = h2_pow2_scale(m, inv_tile);
+#pragma unroll
+        for (int s = 0; s < S; ++s) h2_split8_scaled(v[s], sc, bhi[s], blo[s]);
+    }
+    const float cu = a.c * inv_tile;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();                             /* the tile's LDS space now carries the output groups */
+
+    /* ---- every 128-row group of output features: GEMM over the S k-steps, epilogue on the accumulators, rows out through LDS ---- */
+    for (int g = 0; g < a.G; ++g) {
+        const uint4* Wg = a.A + (size_t)g * (S * 8 * 64);
+        h2_f32x16 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.0f;
+        constexpr int R = S == 8 ? 2 : (S >= 12 ? BGK_LAYER_RING : (S >= 3 ? 3 : S));         /* ring depth (S = 8: 64 + 64 + 2 x 32 registers leave room at two waves per SIMD) */
+        H2A<4> ring[R];
+#pragma unroll
+        for (int s = 0; s < R - 1; ++s) h2a_load<4>(ring[s], Wg, s, lane);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s + R - 1 < S) h2a_load<4>(ring[(s + R - 1) % R], Wg, s + R - 1, lane);
+            __builtin_amdgcn_sched_barrier(0);                   /* keep the prefetch above this step's MFMAs */
+            h2_mfma3<4>(acc, ring[s % R], bhi[s], blo[s]);
+        }
+        const float* yrow = a.y + (b0 + (live ? j : 0)) * a.ldy;
+        const int width = a.n_out - 128 * g < 128 ? a.n_out - 128 * g : 128;      /* live features of this group */
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (32 * m >= width) continue;                       /* wave-uniform: padded tiles of the last group */
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int fl = 32 * m + 8 * q + 4 * hh, f0 = 128 * g + fl;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[m][4 * q + e] * cu;
+                if (a.accumulate) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += (live && f0 + e < a.n_out) ? yrow[f0 + e] : 0.0f;
+                }
+                if (a.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += f0 + e < a.n_out ? a.bias[f0 + e] : 0.0f;
+                }
+                if (a.act == 1) {
+                    const bgk_f2 u0 = bgk_siluf2((bgk_f2){o[0], o[1]}), u1 = bgk_siluf2((bgk_f2){o[2], o[3]});
+                    o[0] = u0.x; o[1] = u0.y; o[2] = u1.x; o[3] = u1.y;
+                } else if (a.act == 3) {
+                    const bgk_f2 u0 = bgk_tanhf2((bgk_f2){o[0], o[1]}), u1 = bgk_tanhf2((bgk_f2){o[2], o[3]});
+                    o[0] = u0.x; o[1] = u0.y; o[2] = u1.x; o[3] = u1.y;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = layer_act(o[e], a.act);
+                }
+                *reinterpret_cast<float4*>(s_t + j * YS + fl) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float* yg = a.y + b0 * a.ldy + 128 * g;
+        if (a.y_al && (width & 3) == 0) {                        /* row-contiguous 16-byte pieces: 32 lanes per 512-byte row segment */
+            RowWalk wk(lane, width >> 2);
+            const int n_it = (rows * (width >> 2) + 63) >> 6;
+            for (int it = 0; it < n_it; ++it) {
+                if (wk.r < rows) *reinterpret_cast<float4*>(yg + wk.r * a.ldy + 4 * wk.c) = *reinterpret_cast<const float4*>(s_t + wk.r * YS + 4 * wk.c);
+                wk.next();
+            }
+        } else {                                                 /* e.g. 425 spline parameters per row: dword stores, a row segment per two instructions */
+            for (int r = 0; r < rows; ++r) {
+                if (lane < width) yg[r * a.ldy + lane] = s_t[r * YS + lane];
+                if (lane + 64 < width) yg[r * a.ldy + lane + 64] = s_t[r * YS + lane + 64];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int S>
+int launch_layer(const LayerArgs& a, hipStream_t st) {
+    constexpr int XS = 16 * S + 4, YS = 128 + 4;
+    const size_t shmem = sizeof(float) * (size_t)LW * 32 * (XS > YS ? XS : YS);
+    if (shmem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_layer_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int64_t n_wg = ((a.B + 31) / 32 + LW - 1) / LW;
+    hipLaunchKernelGGL((dense_layer_kernel<S>), dim3((unsigned)n_wg), dim3(LW * 64), shmem, st, a);
+    return bgk_launch_status("bgk_dense_layer");
+}
+
+}  // namespace
+
+extern "C" int bgk_dense_layer_steps(int32_t n_in) {
+    if (n_in <= 0 || n_in > 256) return -1;
+    const int s = (n_in + 15) / 16;
+    return s <= 2 ? s : (s <= 4 ? 4 : (s <= 8 ? 8 : (s <= 12 ? 12 : 16)));
+}
+
+extern "C" int bgk_dense_layer(const float* x, int64_t ldx, int64_t B, int32_t n_in, const void* Ap, int32_t S, float c,
+                               const float* bias, int32_t n_out, int32_t act, float* y, int64_t ldy, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
+    BGK_CHECK_ARG(x && Ap && y && B > 0 && n_in > 0 && n_out > 0 && ldx >= n_in && ldy >= n_out, "bgk_dense_layer: bad arguments");
+    BGK_CHECK_ARG(act >= 0 && act <= 3, "bgk_dense_layer: act %d (0 none, 1 SiLU, 2 ReLU, 3 Tanh)", act);
+    BGK_CHECK_ARG(n_in <= 256 && S == bgk_dense_layer_steps(n_in), "bgk_dense_layer: %d input columns per pass (at most 256: wider inputs run as "
+                  "accumulating passes) in %d k-steps (bgk_dense_layer_steps says %d)", n_in, S, bgk_dense_layer_steps(n_in));
+    BGK_CHECK_ARG(((uintptr_t)Ap & 15) == 0, "bgk_dense_layer: packed weights must be 16-byte aligned");
+    const int64_t n_wg = ((B + 31) / 32 + LW - 1) / LW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_dense_layer: batch too large for one launch");
+    LayerArgs a;
+    a.x = x; a.ldx = ldx; a.n_in = n_in;
+    a.A = reinterpret_cast<const uint4*>(Ap); a.G = (n_out + 127) / 128;
+    a.c = c; a.bias = bias; a.act = act;
+    a.y = y; a.ldy = ldy; a.n_out = n_out; a.B = B; a.accumulate = accumulate;
+    a.x_al = ((uintptr_t)x & 15) == 0 && (ldx & 3) == 0;
+    a.y_al = ((uintptr_t)y & 15) == 0 && (ldy & 3) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    switch (S) {
+        case 1: return launch_layer<1>(a, st);
+        case 2: return launch_layer<2>(a, st);
+        case 4: return launch_layer<4>(a, st);
+        case 8: return launch_layer<8>(a, st);
+        case 12: return launch_layer<12>(a, st);
+        default: return launch_layer<16>(a, st);
+    }
+}

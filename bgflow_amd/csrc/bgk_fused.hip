@@ -1151,7 +1151,10 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_h2_kernel(Fuse
 constexpr int W_T = 8;                           /* hidden tiles: 256 units */
 constexpr int W_STEPS = 16;                      /* k16-steps over 256 inputs */
 constexpr int W_BLOCKS = W_STEPS * 4 * 2 + 4;    /* 1 KiB blocks of one 128-row GEMM over 256 inputs, incl. bias */
-constexpr int W_RING = 3;                        /* A fragments in flight: two k-steps (24 MFMAs) ahead of their use */
+#ifndef BGK_W_RING
+#define BGK_W_RING 3
+#endif
+constexpr int W_RING = BGK_W_RING;                        /* A fragments in flight: two k-steps (24 MFMAs) ahead of their use */
 struct BFragW { h16x8 hi[W_STEPS], lo[W_STEPS]; };
 
 template <int O, int N>

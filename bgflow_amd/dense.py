@@ -57,8 +57,10 @@ class _LinearFn(torch.autograd.Function):
     training step; rocBLAS gemv with a ones vector is slower still)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, lin=None):
         ctx.save_for_backward(x, weight)
+        if lin is not None:                 # the module whose parameters these are: forward on bgk_dense_layer
+            return dense_layer(x, lin, 0)
         return torch.addmm(bias, x, weight.t())
 
     @staticmethod
@@ -68,17 +70,95 @@ class _LinearFn(torch.autograd.Function):
         gx = _matmul_nn(g, weight) if ctx.needs_input_grad[0] else None
         gw = _gram_tn(g, x.contiguous()) if ctx.needs_input_grad[1] else None
         gb = column_sum(g) if ctx.needs_input_grad[2] else None
-        return gx, gw, gb
+        return gx, gw, gb, None
+
+
+LAYER_KERNEL = True     # Linear layers of a DenseNet on HIP tensors run on bgk_dense_layer; False: torch.nn.Linear (hipBLASLt)
+
+_LAYER_ACTS = {torch.nn.SiLU: 1, torch.nn.ReLU: 2, torch.nn.Tanh: 3}
+
+
+def pack_linear_layer(weight):
+    """Operands of bgk_dense_layer for ``weight`` [n_out, n_in]: a list of passes (A f16 [G * S * 8, 64, 8], S, c, k0, k1), one per
+    block of <= 256 input columns [k0, k1): the block scaled by a power of two (largest magnitude into [2^14, 2^15)), zero-padded to
+    16 S columns and 128 G rows, per 128-row group in the split-f16 block layout of the coupling kernels (natural k order)."""
+    W = weight.detach().float()
+    n_out, n_in = W.shape
+    G = (n_out + 127) // 128
+    passes = []
+    for k0 in range(0, n_in, 256):
+        k1 = min(n_in, k0 + 256)
+        S = int(_lib.lib().bgk_dense_layer_steps(k1 - k0))
+        Wb = W[:, k0:k1]
+        e = _h2_scale_exp(Wb)
+        Wp = torch.zeros(128 * G, 16 * S, dtype=torch.float32, device=W.device)
+        Wp[:n_out, :k1 - k0] = Wb * 2.0 ** e
+        A = torch.cat([_pack_h2(Wp[g * 128:(g + 1) * 128], None, _h2_k_natural(S)) for g in range(G)], dim=0).contiguous()
+        passes.append((A, S, 2.0 ** -e, k0, k1))
+    return passes
+
+
+def _layer_operands(lin):
+    """packed operands of a Linear module, re-packed when its weight changes (keyed on the parameter's state)"""
+    key = (param_state_key(lin.weight), lin.weight.device)
+    cached = lin.__dict__.get("_bgk_layer_ops")
+    if cached is None or cached[0] != key:
+        cached = (key, pack_linear_layer(lin.weight))
+        lin.__dict__["_bgk_layer_ops"] = cached
+    return cached[1]
+
+
+def dense_layer(x, lin, act=0):
+    """y = act(x W^T + b) of a Linear module on bgk_dense_layer (x: f32 HIP tensor [..., n_in]; act: 0 none, 1 SiLU, 2 ReLU, 3 Tanh)"""
+    _lib.require_hip(x)
+    lead = x.shape[:-1]
+    x2, ldx = _lib.rowmajor(x.reshape(-1, x.shape[-1]))
+    B, n_out = x2.shape[0], lin.out_features
+    y = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
+    if B and n_out:
+        passes = _layer_operands(lin)
+        bias = None if lin.bias is None else lin.bias.detach().contiguous()
+        with torch.cuda.device(x.device):
+            for i, (A, S, c, k0, k1) in enumerate(passes):
+                last = i == len(passes) - 1
+                st = _lib.lib().bgk_dense_layer(x2.data_ptr() + 4 * k0, ldx, B, k1 - k0, _lib.ptr(A), S, c,
+                                                _lib.ptr(bias) if last else None, n_out, act if last else 0, _lib.ptr(y), n_out, int(i > 0),
+                                                _lib.stream_ptr(x.device))
+                _lib.check(st, "bgk_dense_layer")
+    return y.reshape(*lead, n_out)
+
+
+def _on_layer_kernel(m, x):
+    return (LAYER_KERNEL and type(m) is torch.nn.Linear and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1
+            and m.weight.dtype == torch.float32 and m.weight.device == x.device and m.in_features > 0)
 
 
 def _run_layers(layers, x):
-    """Sequential forward; 2-D HIP inputs under autograd go through _LinearFn"""
-    fast = x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-    for m in layers:
-        if fast and type(m) is torch.nn.Linear and m.bias is not None and (m.weight.requires_grad or x.requires_grad):
-            x = _LinearFn.apply(x, m.weight, m.bias)
-        else:
-            x = m(x)
+    """Sequential forward.  Linear layers on HIP tensors run on bgk_dense_layer -- with the following SiLU / ReLU / Tanh in the same
+    launch when nothing needs a gradient; 2-D inputs under autograd go through _LinearFn (the kernel forward, GEMM backward)."""
+    mods = list(layers)
+    grad = torch.is_grad_enabled()
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if _on_layer_kernel(m, x):
+            needs = grad and (x.requires_grad or m.weight.requires_grad or (m.bias is not None and m.bias.requires_grad))
+            if not needs:
+                act = _LAYER_ACTS.get(type(mods[i + 1]), 0) if i + 1 < len(mods) else 0
+                x = dense_layer(x, m, act)
+                i += 2 if act else 1
+                continue
+            if x.dim() == 2 and m.bias is not None:
+                x = _LinearFn.apply(x, m.weight, m.bias, m)
+                i += 1
+                continue
+        elif grad and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and type(m) is torch.nn.Linear and m.bias is not None \
+                and (m.weight.requires_grad or x.requires_grad):
+            x = _LinearFn.apply(x, m.weight, m.bias, None)
+            i += 1
+            continue
+        x = m(x)
+        i += 1
     return x
 
 

@@ -599,6 +599,23 @@ int bgk_column_sum(const float* x, int64_t ldx, int64_t B, int32_t P, float* par
  * kernel of this library (those publish their own maximum: the g_absmax / gz_absmax arguments below). */
 int bgk_absmax(const float* x, int64_t ldx, int64_t B, int32_t P, float* out, void* stream);
 
+/* One Linear layer (+ bias + activation) of a conditioner network on its own: y = act(x W^T + b).
+ * Replaces one `Linear (, activation)` pair of DenseNet._layers (nn/dense.py:30-48) for the networks the one-launch coupling kernels do
+ * not take (conditioner_factory.py:76-80 allows any `hidden` tuple: other depths, layers wider than 256; README.md:72-79's [1, 4, 1]
+ * nets; couplings of more than 64 transformed dims): the layer-by-layer path is bgk_dense_layer per layer + bgk_rqs_transform /
+ * bgk_affine_transform.  Split-f16 GEMM on the f16 matrix cores (f32-class: hi + lo f16 operand pairs, f32 accumulate), the input tile
+ * under a per-32-sample power-of-two scale (inputs of any range), f32 bias and activation on the accumulators.
+ *   x [B, n_in] (ldx): this pass' input columns, n_in <= 256 -- a wider input runs as passes over column blocks of 256 with
+ *         accumulate = 1 from the second pass on (bias / act given to the last pass only)
+ *   Ap: the weights W[:, block] packed by bgflow_amd/dense.py::pack_linear_layer (ceil(n_out / 128) groups x S k16-steps x 4 tiles x
+ *         {hi, lo} blocks of 1 KiB, natural k order, zero-padded), c = 2^-s its unscale factor, S = bgk_dense_layer_steps(n_in)
+ *   bias [n_out] or NULL; act: 0 none, 1 SiLU, 2 ReLU, 3 Tanh;  y [B, n_out] (ldy); accumulate: y = act(y + x W^T + b). */
+int bgk_dense_layer(const float* x, int64_t ldx, int64_t B, int32_t n_in, const void* Ap, int32_t S, float c,
+                    const float* bias, int32_t n_out, int32_t act, float* y, int64_t ldy, int32_t accumulate, void* stream);
+
+/* k16-steps the kernel instance for n_in input columns runs (1, 2, 4, 8, 12 or 16; the packer pads to it); -1 beyond 256 columns. */
+int bgk_dense_layer_steps(int32_t n_in);
+
 /* Static PCA whitening / blackening of a coordinate block on its own: out = (x - pre) T + post.
  * Replaces WhitenFlow._whiten / _blacken (nn/flow/pca.py:74-93: torch.matmul(x - X0mean, Twhiten), torch.matmul(z, Tblacken) + X0mean);
  * the constant log-det -+ sum log std is formed by the caller.  The VJP w.r.t. x is the same call on the transposed matrix.

@@ -373,6 +373,32 @@ def test_width_256_plan_envelope():
     assert dense._fused_plan(mk((100, 100)), 5, nc)["hidden"] == 128
 
 
+def test_linear_layer_packing_reproduces_the_layer():
+    """operands of bgk_dense_layer (dense.pack_linear_layer): passes over blocks of <= 256 input columns, each zero-padded to the
+    kernel instance's k-steps and to whole 128-row groups -- the numpy restatement of the MFMA dataflow gives W x"""
+    from bgflow_amd import dense, _lib
+    assert [_lib.lib().bgk_dense_layer_steps(n) for n in (1, 16, 17, 33, 64, 65, 128, 129, 192, 193, 256, 257, 0)] == \
+        [1, 1, 2, 4, 4, 8, 8, 12, 12, 16, 16, -1, -1]
+    rng = np.random.default_rng(7)
+    for n_out, n_in in ((4, 1), (130, 21), (5, 300)):
+        W = torch.tensor(rng.normal(size=(n_out, n_in)) * 3.0, dtype=torch.float32)
+        x = rng.normal(size=n_in)
+        got = np.zeros(n_out)
+        passes = dense.pack_linear_layer(W)
+        assert len(passes) == (n_in + 255) // 256
+        G = (n_out + 127) // 128
+        for A, S, c, k0, k1 in passes:
+            assert A.shape == (G * S * 8, 64, 8) and 16 * S >= k1 - k0
+            xp = np.zeros(16 * S)
+            xp[:k1 - k0] = x[k0:k1]
+            bv = [[xp[16 * s + 8 * kb:16 * s + 8 * kb + 8] for kb in range(2)] for s in range(S)]
+            out = np.concatenate([_emulate_h2_gemm(A.numpy()[g * S * 8:(g + 1) * S * 8], 4, S, bv) for g in range(G)]) * c
+            assert np.all(out[n_out:] == 0.0)
+            got += out[:n_out]
+        ref = W.double().numpy() @ x
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * np.abs(W.numpy()).sum(1).max() * np.abs(x).max())
+
+
 def test_gemm_mode_switch_and_errors():
     import bgflow_amd as bg
     from bgflow_amd import dense
