@@ -105,7 +105,8 @@ _SIGNATURES = {
     "bgk_dense_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, vp, i32, vp, i64, i32, i32, i64, vp, i64,
                                              vp, vp, vp, vp, vp, vp, i32, vp, vp]),
     "bgk_pack_rqs_columns": (i32, [i32, i32, vp, vp]),
-    "bgk_dense_layer": (ctypes.c_int, [vp, i64, i64, i32, vp, i32, f32, vp, i32, i32, vp, i64, i32, vp]),
+    "bgk_dense_layer": (ctypes.c_int, [vp, i64, i64, i32, vp, i32, f32, vp, vp, i32, i32, vp, i64, i32, vp]),
+    "bgk_pack_linear_layer": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp]),
     "bgk_dense_layer_steps": (ctypes.c_int, [i32]),
 }
 

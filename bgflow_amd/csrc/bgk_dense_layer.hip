@@ -39,7 +39,7 @@ constexpr int LW = 4;                 /* waves per workgroup */
 struct LayerArgs {
     const float* x; int64_t ldx; int n_in;       /* this pass' input columns (<= 16 S) */
     const uint4* A; int G;                       /* packed weights: G groups of 128 output rows x S k16-steps x 4 tiles x {hi, lo} */
-    float c;                                     /* 2^-s of the weights' scale */
+    float c; const float* c_dev;                 /* 2^-s of the weights' scale; c_dev (if non-null): read it from c_dev[1] (bgk_pack_linear_layer) */
     const float* bias; int act;                  /* applied by the last pass: bias [n_out] or null; 0 none, 1 SiLU, 2 ReLU, 3 Tanh */
     float* y; int64_t ldy; int n_out; int64_t B;
     int accumulate;                              /* y = act(y + x W^T + b) */
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
 #pragma unroll
         for (int s = 0; s < S; ++s) h2_split8_scaled(v[s], sc, bhi[s], blo[s]);
     }
-    const float cu = a.c * inv_tile;
+    const float cu = (a.c_dev ? a.c_dev[1] : a.c) * inv_tile;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();                             /* the tile's LDS space now carries the output groups */
 
@@ -213,6 +213,50 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
     }
 }
 
+/* ---- device-side operand packing (the weights of a training run change every step; dense.py::pack_linear_layer is the layout's
+ * reference, tested against this): cs[0] = max |W| over the column block (atomicMax on the bit pattern, zeroed by the launcher);
+ * every packing thread derives the scale 2^e, e = clamp(floor(log2(32768 / max)), -16, 24), from it, thread 0 publishes 2^-e in cs[1] ---- */
+__global__ __launch_bounds__(256) void layer_max_kernel(const float* W, int64_t ldw, int n_out, int n_in, float* cs) {
+    float m = 0.0f;
+    const int64_t n = (int64_t)n_out * n_in;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / n_in;
+        m = fmaxf(m, fabsf(W[r * ldw + (i - r * n_in)]));
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) {
+        if (!(m < 3.0e38f)) m = 3.4e38f;                       /* inf / NaN weights: largest finite pattern (scale exponent 0 below) */
+        atomicMax(reinterpret_cast<unsigned int*>(cs), __builtin_bit_cast(unsigned int, m));
+    }
+}
+
+__global__ __launch_bounds__(256) void layer_pack_kernel(const float* W, int64_t ldw, int n_out, int n_in, int S, int G, uint4* out, float* cs) {
+    const float m = cs[0];
+    int e = 0;
+    if (m > 0.0f && m < 3.0e38f) {
+        e = (int)floorf(log2f(32768.0f / m));
+        e = e < -16 ? -16 : (e > 24 ? 24 : e);
+    }
+    const float scale = ldexpf(1.0f, e);
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) cs[1] = ldexpf(1.0f, -e);
+    if (t >= (int64_t)G * S * 8 * 64) return;
+    const int lane = (int)(t & 63), blk = (int)(t >> 6);
+    const int i = lane & 31, kb = lane >> 5;
+    const int p = blk & 1, mt = (blk >> 1) & 3, s = (blk >> 3) % S, g = (blk >> 3) / S;
+    const int row = 128 * g + 32 * mt + i;
+    uint16_t o[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = 16 * s + 8 * kb + q;
+        const float v = (row < n_out && k < n_in) ? W[(int64_t)row * ldw + k] * scale : 0.0f;
+        const _Float16 h = (_Float16)v;
+        const _Float16 r = p ? (_Float16)(v - (float)h) : h;
+        o[q] = __builtin_bit_cast(uint16_t, r);
+    }
+    out[t] = *reinterpret_cast<const uint4*>(o);
+}
+
 template <int S>
 int launch_layer(const LayerArgs& a, hipStream_t st) {
     constexpr int XS = 16 * S + 4, YS = 128 + 4;
@@ -232,7 +276,22 @@ extern "C" int bgk_dense_layer_steps(int32_t n_in) {
     return s <= 2 ? s : (s <= 4 ? 4 : (s <= 8 ? 8 : (s <= 12 ? 12 : 16)));
 }
 
-extern "C" int bgk_dense_layer(const float* x, int64_t ldx, int64_t B, int32_t n_in, const void* Ap, int32_t S, float c,
+extern "C" int bgk_pack_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_in, void* Ap, float* cs, void* stream) {
+    BGK_CHECK_ARG(W && Ap && cs && n_out > 0 && n_in > 0 && n_in <= 256 && ldw >= n_in, "bgk_pack_linear_layer: bad arguments (a column block of at most 256)");
+    BGK_CHECK_ARG(((uintptr_t)Ap & 15) == 0, "bgk_pack_linear_layer: the operand buffer must be 16-byte aligned");
+    const int S = bgk_dense_layer_steps(n_in), G = (n_out + 127) / 128;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(cs, 0, 2 * sizeof(float), st) != hipSuccess) return bgk_launch_status("bgk_pack_linear_layer");
+    const int64_t n = (int64_t)n_out * n_in;
+    const int g_max = (int)((n + 255) / 256 < 64 ? (n + 255) / 256 : 64);
+    hipLaunchKernelGGL(layer_max_kernel, dim3(g_max), dim3(256), 0, st, W, ldw, n_out, n_in, cs);
+    const int64_t threads = (int64_t)G * S * 8 * 64;
+    hipLaunchKernelGGL(layer_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, ldw, n_out, n_in, S, G,
+                       reinterpret_cast<uint4*>(Ap), cs);
+    return bgk_launch_status("bgk_pack_linear_layer");
+}
+
+extern "C" int bgk_dense_layer(const float* x, int64_t ldx, int64_t B, int32_t n_in, const void* Ap, int32_t S, float c, const float* c_dev,
                                const float* bias, int32_t n_out, int32_t act, float* y, int64_t ldy, int32_t accumulate, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(x && Ap && y && B > 0 && n_in > 0 && n_out > 0 && ldx >= n_in && ldy >= n_out, "bgk_dense_layer: bad arguments");
@@ -245,7 +304,7 @@ extern "C" int bgk_dense_layer(const float* x, int64_t ldx, int64_t B, int32_t n
     LayerArgs a;
     a.x = x; a.ldx = ldx; a.n_in = n_in;
     a.A = reinterpret_cast<const uint4*>(Ap); a.G = (n_out + 127) / 128;
-    a.c = c; a.bias = bias; a.act = act;
+    a.c = c; a.c_dev = c_dev; a.bias = bias; a.act = act;
     a.y = y; a.ldy = ldy; a.n_out = n_out; a.B = B; a.accumulate = accumulate;
     a.x_al = ((uintptr_t)x & 15) == 0 && (ldx & 3) == 0;
     a.y_al = ((uintptr_t)y & 15) == 0 && (ldy & 3) == 0;

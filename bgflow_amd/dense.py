@@ -98,12 +98,34 @@ def pack_linear_layer(weight):
     return passes
 
 
+def pack_linear_layer_device(weight):
+    """Device-side twin of pack_linear_layer (bgk_pack_linear_layer: no host synchronisation): passes (A, S, cs, k0, k1) with cs the
+    device pair {largest magnitude, unscale factor} of the block"""
+    W = weight.detach()
+    assert W.is_cuda and W.dtype == torch.float32 and W.dim() == 2 and W.stride(1) == 1
+    n_out, n_in = W.shape
+    G = (n_out + 127) // 128
+    passes = []
+    with torch.cuda.device(W.device):
+        for k0 in range(0, n_in, 256):
+            k1 = min(n_in, k0 + 256)
+            S = int(_lib.lib().bgk_dense_layer_steps(k1 - k0))
+            A = torch.empty((G * S * 8, 64, 8), dtype=torch.float16, device=W.device)
+            cs = torch.empty(2, dtype=torch.float32, device=W.device)
+            st = _lib.lib().bgk_pack_linear_layer(W.data_ptr() + 4 * k0, W.stride(0), n_out, k1 - k0, _lib.ptr(A), _lib.ptr(cs),
+                                                  _lib.stream_ptr(W.device))
+            _lib.check(st, "bgk_pack_linear_layer")
+            passes.append((A, S, cs, k0, k1))
+    return passes
+
+
 def _layer_operands(lin):
     """packed operands of a Linear module, re-packed when its weight changes (keyed on the parameter's state)"""
     key = (param_state_key(lin.weight), lin.weight.device)
     cached = lin.__dict__.get("_bgk_layer_ops")
     if cached is None or cached[0] != key:
-        cached = (key, pack_linear_layer(lin.weight))
+        W = lin.weight if lin.weight.stride(1) == 1 else lin.weight.contiguous()
+        cached = (key, pack_linear_layer_device(W))
         lin.__dict__["_bgk_layer_ops"] = cached
     return cached[1]
 
@@ -121,7 +143,8 @@ def dense_layer(x, lin, act=0):
         with torch.cuda.device(x.device):
             for i, (A, S, c, k0, k1) in enumerate(passes):
                 last = i == len(passes) - 1
-                st = _lib.lib().bgk_dense_layer(x2.data_ptr() + 4 * k0, ldx, B, k1 - k0, _lib.ptr(A), S, c,
+                c_host, c_dev = (1.0, _lib.ptr(c)) if torch.is_tensor(c) else (c, None)
+                st = _lib.lib().bgk_dense_layer(x2.data_ptr() + 4 * k0, ldx, B, k1 - k0, _lib.ptr(A), S, c_host, c_dev,
                                                 _lib.ptr(bias) if last else None, n_out, act if last else 0, _lib.ptr(y), n_out, int(i > 0),
                                                 _lib.stream_ptr(x.device))
                 _lib.check(st, "bgk_dense_layer")
@@ -130,7 +153,8 @@ def dense_layer(x, lin, act=0):
 
 def _on_layer_kernel(m, x):
     return (LAYER_KERNEL and type(m) is torch.nn.Linear and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1
-            and m.weight.dtype == torch.float32 and m.weight.device == x.device and m.in_features > 0)
+            and m.weight.dtype == torch.float32 and m.weight.device == x.device and m.in_features > 0
+            and (m.bias is None or m.bias.dtype == torch.float32))
 
 
 def _run_layers(layers, x):
@@ -244,14 +268,14 @@ _ACT_CODES = {torch.nn.SiLU: 1, torch.nn.ReLU: 2, torch.nn.Tanh: 3}
 
 def _reject(transformer, reason):
     """A coupling whose conditioner LOOKS fusable (a DenseNet, optionally behind WrapPeriodic) leaves the one-launch kernels'
-    envelope: say so once per transformer and reason -- the generic path (library GEMMs + the stand-alone transformer kernel) is
-    several times slower (49 vs 8.5 ms per cfg-3 pass, profiles/README.md r01), and K > 64 runs on device torch ops."""
+    envelope: say so once per transformer and reason -- the layer-by-layer path (bgk_dense_layer per Linear + the stand-alone transformer
+    kernel) is several times slower (2.2 vs 0.5 ms per cfg-3 layer at 2^20, profiles/r05_w256_layer.txt)."""
     seen = transformer.__dict__.setdefault("_fused_rejections", set())
     if reason not in seen:
         seen.add(reason)
         import warnings
-        warnings.warn(f"{type(transformer).__name__}: not running as ONE fused kernel ({reason}); falling back to conditioner GEMMs + "
-                      f"the stand-alone transformer kernel", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"{type(transformer).__name__}: not running as ONE fused kernel ({reason}); running the conditioner layer by layer "
+                      f"(bgk_dense_layer) + the stand-alone transformer kernel", RuntimeWarning, stacklevel=3)
     return None
 
 

@@ -607,11 +607,17 @@ int bgk_absmax(const float* x, int64_t ldx, int64_t B, int32_t P, float* out, vo
  * under a per-32-sample power-of-two scale (inputs of any range), f32 bias and activation on the accumulators.
  *   x [B, n_in] (ldx): this pass' input columns, n_in <= 256 -- a wider input runs as passes over column blocks of 256 with
  *         accumulate = 1 from the second pass on (bias / act given to the last pass only)
- *   Ap: the weights W[:, block] packed by bgflow_amd/dense.py::pack_linear_layer (ceil(n_out / 128) groups x S k16-steps x 4 tiles x
- *         {hi, lo} blocks of 1 KiB, natural k order, zero-padded), c = 2^-s its unscale factor, S = bgk_dense_layer_steps(n_in)
+ *   Ap: the weights W[:, block] packed by bgk_pack_linear_layer (below) or bgflow_amd/dense.py::pack_linear_layer (ceil(n_out / 128)
+ *         groups x S k16-steps x 4 tiles x {hi, lo} blocks of 1 KiB, natural k order, zero-padded), S = bgk_dense_layer_steps(n_in);
+ *         c = 2^-s its unscale factor, or c_dev = the packer's device scale pair (c_dev[1] is read instead of c)
  *   bias [n_out] or NULL; act: 0 none, 1 SiLU, 2 ReLU, 3 Tanh;  y [B, n_out] (ldy); accumulate: y = act(y + x W^T + b). */
-int bgk_dense_layer(const float* x, int64_t ldx, int64_t B, int32_t n_in, const void* Ap, int32_t S, float c,
+int bgk_dense_layer(const float* x, int64_t ldx, int64_t B, int32_t n_in, const void* Ap, int32_t S, float c, const float* c_dev,
                     const float* bias, int32_t n_out, int32_t act, float* y, int64_t ldy, int32_t accumulate, void* stream);
+
+/* Operands of bgk_dense_layer for one column block W[:, k0 : k0 + n_in] (pass W + k0, ldw = the weight's row stride; n_in <= 256) of a
+ * Linear layer's weight [n_out, *] (nn/dense.py:30-48), packed on the device without a host synchronisation: Ap receives
+ * ceil(n_out / 128) * bgk_dense_layer_steps(n_in) * 8 blocks of 1 KiB, cs[0] the block's largest magnitude, cs[1] the unscale factor. */
+int bgk_pack_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_in, void* Ap, float* cs, void* stream);
 
 /* k16-steps the kernel instance for n_in input columns runs (1, 2, 4, 8, 12 or 16; the packer pads to it); -1 beyond 256 columns. */
 int bgk_dense_layer_steps(int32_t n_in);

@@ -764,7 +764,7 @@ def test_densenet_layers_run_on_the_layer_kernel(hip_lib, dev):
             y = net(x)
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
-    assert any("dense_layer_kernel" in n for n in names)
+    assert all("_bgk_layer_ops" in m.__dict__ for m in net._layers if isinstance(m, torch.nn.Linear)), "every Linear must have run on the kernel"
     assert not any(("Cijk" in n) or ("gemm" in n.lower()) or n.startswith("aten::addmm") or n.startswith("aten::mm") for n in names), names
     dense.LAYER_KERNEL = False
     try:
@@ -794,5 +794,24 @@ def test_readme_flow_launches_no_library_gemm(hip_lib, dev):
             gen.energy(x)
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
-    assert any("dense_layer_kernel" in n for n in names)
+    lins = [m for m in gen.flow.modules() if isinstance(m, torch.nn.Linear)]
+    assert len(lins) == 4 and all("_bgk_layer_ops" in m.__dict__ for m in lins), "every Linear must have run on the kernel"
     assert not any(("Cijk" in n) or ("gemm" in n.lower()) or n.startswith("aten::addmm") or n.startswith("aten::mm") for n in names), names
+
+
+@pytest.mark.parametrize("n_out,n_in", [(4, 1), (130, 21), (425, 256), (77, 300)])
+def test_linear_layer_device_packer_equals_the_host_packer(hip_lib, dev, n_out, n_in):
+    """bgk_pack_linear_layer (no host synchronisation) writes the operand blocks and the unscale factor of dense.pack_linear_layer
+    (the layout's reference, emulated on the CPU in tests/test_host_logic.py) bit for bit; a column-sliced weight packs like its copy"""
+    from bgflow_amd import dense
+    from bgflow_amd.utils import synth
+    W = torch.as_tensor(synth(17 + n_in, n_out, n_in + 3, scale=0.7), device=dev)[:, 1:1 + n_in]
+    ref = dense.pack_linear_layer(W)
+    got = dense.pack_linear_layer_device(W)
+    assert len(ref) == len(got) == (n_in + 255) // 256
+    for (A, S, c, k0, k1), (Ad, Sd, cs, k0d, k1d) in zip(ref, got):
+        assert (S, k0, k1) == (Sd, k0d, k1d) and float(cs[1]) == c and float(cs[0]) == float(W[:, k0:k1].abs().max())
+        assert torch.equal(A.view(torch.int16), Ad.view(torch.int16))
+    Wz = torch.zeros(5, 9, device=dev)
+    (Az, _, csz, _, _), = dense.pack_linear_layer_device(Wz)
+    assert float(csz[1]) == 1.0 and not Az.view(torch.int16).any()
