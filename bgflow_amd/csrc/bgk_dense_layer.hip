@@ -130,7 +130,11 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
                 v[s][4 * g + 3] = (live && col + 3 < a.n_in) ? q.w : 0.0f;
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(v[s][e]));
+            for (int e = 0; e < 8; ++e) {                        /* finite values only: an inf / NaN entry must not take its tile's scale (and with it the
+                                                                  * 31 other samples' f16 range) along -- it poisons its own sample's outputs and nothing else */
+                const float av = __builtin_fabsf(v[s][e]);
+                m = __builtin_fmaxf(m, av < 3.0e38f ? av : 0.0f);
+            }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));

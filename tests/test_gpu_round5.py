@@ -745,6 +745,16 @@ def test_dense_layer_kernel_input_range_and_shapes(hip_lib, dev):
         xm = (x * mag).astype(np.float32).astype(np.float64)
         ref = xm @ W.T + b
         np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=4e-7 * (np.abs(xm) @ np.abs(W).T + np.abs(b)).max())
+    # a non-finite entry poisons its own sample's outputs and nothing else, whatever the other samples of its 32-row tile hold
+    xb = (x[0] * 1e5).astype(np.float32)
+    xb[3, 7], xb[20, 0] = np.inf, np.nan
+    with torch.no_grad():
+        yb = dense.dense_layer(torch.as_tensor(xb, device=dev), lin, 0).cpu().numpy()
+    good = np.ones(50, bool)
+    good[[3, 20]] = False
+    assert not np.isfinite(yb[3]).any() and np.isnan(yb[20]).all()
+    refb = xb[good].astype(np.float64) @ W.T + b
+    np.testing.assert_allclose(yb[good], refb, rtol=0, atol=4e-7 * (np.abs(xb[good].astype(np.float64)) @ np.abs(W).T + np.abs(b)).max())
     with torch.no_grad():
         assert dense.dense_layer(torch.empty(0, 40, device=dev), lin, 1).shape == (0, 70)
 
