@@ -1345,6 +1345,147 @@ __global__ __launch_bounds__(FTHREADS, 1) void coupling_rqs_dense_w256_kernel(Fu
     }
 }
 
+
+/* ---- conditioners with ANY number of hidden layers (width <= 128, zero-padded): coupling_rqs_dense_deep_kernel ----------------------
+ * conditioner_factory.py:76-80 takes any `hidden` tuple; the second-generation kernel is written for two hidden layers.  This is the
+ * first-generation decomposition with the hidden -> hidden GEMM in a loop over n_hh = n_hidden - 1 packed layers (A1 = their operands
+ * back to back, c1s[l] their unscale factors), n_hh = 0 (one hidden layer) .. DEEP_MAX_HH.  Two waves per SIMD; activation chosen at run
+ * time.  Inference only (both directions): training of such a layer runs the conditioner layer by layer. */
+constexpr int DEEP_MAX_HH = 7;
+struct DeepArgs { FusedArgsH2 h; int n_hh; float c1s[DEEP_MAX_HH]; };
+
+__device__ __forceinline__ void deep_act(f32x16 (&t)[4], float c, int act) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[m][r] *= c;
+    if (act == 1) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) act_tile_fast<1>(t[m]);
+    } else if (act == 2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) act_tile_fast<2>(t[m]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) act_tile_fast<3>(t[m]);
+    }
+}
+
+template <int INV, int KT>
+__global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_dense_deep_kernel(DeepArgs da) {
+    constexpr int DPCT = 128 / (3 * KT + 1);              /* dims per 128-column parameter chunk */
+    constexpr int ST = 32;
+    FusedArgsH2& ah = da.h;
+    const FusedArgs& a = ah.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* s_p = smem + (size_t)wave * a.lds_per_wave;
+    float* s_y = s_p + 128 * ST;
+    const int d = a.d;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * FW + wave;
+    if (tile >= n_tiles) return;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+
+    /* ---- stage the (featurised) conditioner input [feature][sample], a constant-1 row for the bias, zero pad rows ---- */
+    const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
+    for (int i = lane; i < 32 * a.d_c; i += 64) {
+        const int r = i / a.d_c, c = i - r * a.d_c;
+        float v = r < rows ? a.cond[(b0 + r) * a.ldc + c] : 0.0f;
+        if (a.periodic) {
+            float sv, cv;
+            bgk_sincos2pif(v, &sv, &cv);
+            s_p[c * SROW + r] = cv;
+            s_p[(a.d_c + c) * SROW + r] = sv;
+        } else {
+            s_p[c * SROW + r] = v;
+        }
+    }
+    for (int i = lane; i < (16 * ah.S0 - n_in) * 32; i += 64)
+        s_p[(n_in + (i >> 5)) * SROW + (i & 31)] = (i >> 5) == 0 ? 1.0f : 0.0f;
+    for (int i = lane; i < 32 * d; i += 64) {
+        const int r = i / d, c = i - r * d;
+        s_y[c * SROW + r] = r < rows ? a.y[(b0 + r) * a.ldy + c] : 0.5f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    /* ---- layer 0 (bias = weight column of the constant-1 feature) ---- */
+    f32x16 h[4];
+    zero4(h);
+    for (int s = 0; s < ah.S0; ++s) {
+        AFrag fr;
+        h2_load<false>(fr, ah.A0, s, lane);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = s_p[(16 * s + 8 * hh + e) * SROW + j];
+        h16x8 bhi, blo;
+        h2_split<false>(v, bhi, blo);
+        h2_mfma<false>(h, fr, bhi, blo);
+    }
+    deep_act(h, ah.c0, a.act);
+
+    /* ---- hidden -> hidden layers ---- */
+    BFrag bf;
+    H2Ring ring;
+    for (int l = 0; l < da.n_hh; ++l) {
+        const uint4* Wl = ah.A1 + (size_t)l * H2_BLOCKS * 64;
+        h2_gemm_start<false>(ring, Wl, lane);
+        h2_make_b<false>(bf, h);
+        zero4(h);
+        h2_gemm_run<false>(h, ring, bf, Wl, lane);
+        deep_act(h, da.c1s[l], a.act);
+    }
+    h2_make_b<false>(bf, h);                          /* the output layer's B operands, shared by all chunks */
+
+    /* ---- output layer in chunks of 128 packed columns + spline ---- */
+    float run = 0.0f;
+    int oob_local = 0;
+    for (int c = 0; c < a.n_chunks; ++c) {
+        const uint4* Wc = ah.A2 + (size_t)c * H2_BLOCKS * 64;
+        h2_gemm_start<false>(ring, Wc, lane);
+        zero4(h);
+        h2_gemm_run<false>(h, ring, bf, Wc, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_p[drow(m, r, hh) * ST + j] = h[m][r] * ah.c2;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nd = (d - c * DPCT) < DPCT ? (d - c * DPCT) : DPCT;
+        if constexpr (KT == KB) {
+            int bins[3] = {0, 0, 0};
+            NoGemm g;
+            spline_chunk<INV, NoGemm, ST, true>(g, a, s_p, s_y, c, nd, hh, j, rows, run, oob_local, bins);
+            if (a.bin_idx) {
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int q = 2 * it + hh;
+                    if (q < nd && j < rows) a.bin_idx[(b0 + j) * d + c * DPC + q] = bins[it];
+                }
+            }
+        } else {
+            spline_chunk_k<INV, KT, ST, true>(a, s_p, s_y, c, nd, hh, j, rows, b0, run, oob_local);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (hh == 0 && j < rows) {
+        if (a.accumulate) a.dlogp[b0 + j] += run; else a.dlogp[b0 + j] = run;
+    }
+    for (int i = lane; i < rows * d; i += 64) {
+        const int r = i / d, cc = i - r * d;
+        a.out[(b0 + r) * a.ldo + cc] = s_y[cc * SROW + r];
+    }
+    if (a.oob_count) {
+        for (int off = 32; off > 0; off >>= 1) oob_local += __shfl_xor(oob_local, off);
+        if (lane == 0 && oob_local) atomicAdd(a.oob_count, oob_local);
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t bgk_pack_rqs_columns(int32_t d, int32_t K, const int32_t* nc_slot_host, int32_t* src_col) {
@@ -1554,6 +1695,66 @@ int launch_h2(const char* what, const float* cond, int64_t ldc, int32_t d_c, int
     return bgk_launch_status(what);
 }
 }  // namespace
+
+extern "C" int bgk_coupling_rqs_dense_deep(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                           const void* A0p, const void* A1p, const void* A2p, float c0, const float* c1s, float c2,
+                                           int32_t n_hidden, int32_t act, const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
+                                           uint64_t circ_mask, int32_t inverse,
+                                           double left, double right, double bottom, double top,
+                                           double min_bin_width, double min_bin_height, double min_derivative, int32_t identity_init,
+                                           float* out, int64_t ldo, float* dlogp, int32_t accumulate,
+                                           int32_t* bin_idx, int32_t* oob_count, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
+    const char* what = "bgk_coupling_rqs_dense_deep";
+    BGK_CHECK_ARG(cond && A0p && A2p && y && out && dlogp, "%s: null pointer", what);
+    BGK_CHECK_ARG(B > 0 && d > 0 && d_c > 0, "%s: bad sizes", what);
+    BGK_CHECK_ARG(n_hidden == 1 || (A1p && c1s), "%s: null hidden-layer operands", what);
+    if (n_hidden < 1 || n_hidden > DEEP_MAX_HH + 1 || !(K == 4 || K == 8 || K == 12 || K == 16 || K == 32) || d > 64 || act < 1 || act > 3) {
+        bgk_set_error("%s: 1 .. %d hidden layers of width 128, n_bins in {4, 8, 12, 16, 32}, d<=64, act in {SiLU,ReLU,Tanh} are fused "
+                      "(got n_hidden=%d K=%d d=%d act=%d)", what, DEEP_MAX_HH + 1, n_hidden, K, d, act);
+        return BGK_EUNSUPPORTED;
+    }
+    const int n_in = periodic ? 2 * d_c : d_c;
+    const int S0 = (n_in + 1 + 15) / 16;
+    if (16 * S0 * SROW > LDS_P) {        /* outside the envelope, not an error: the caller runs the conditioner layer by layer */
+        bgk_set_error("%s: conditioner input of %d features does not fit the layer-0 tile (at most 111)", what, n_in);
+        return BGK_EUNSUPPORTED;
+    }
+    BGK_CHECK_ARG(min_bin_width * K <= 1.0 && min_bin_height * K <= 1.0, "Minimal bin width/height too large for the number of bins");
+    DeepArgs da;
+    FusedArgsH2& ah = da.h;
+    FusedArgs& a = ah.f;
+    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic;
+    a.W0 = nullptr; a.W1 = nullptr; a.W2 = nullptr; a.T0 = 0;
+    const int ppd_k = 3 * K + 1, dpc_k = 128 / ppd_k;
+    a.n_chunks = (d + dpc_k - 1) / dpc_k;
+    a.last_tiles = ((d - (a.n_chunks - 1) * dpc_k) * ppd_k + 31) / 32;
+    a.act = act; a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.inverse = inverse;
+    a.circ_mask = circ_mask;
+    a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
+    a.bin_idx = bin_idx; a.oob_count = oob_count;
+    a.lds_per_wave = 128 * 32 + (d + 1) * SROW;
+    a.cfg = bgk_make_rqs_cfg(left, right, bottom, top, min_bin_width, min_bin_height, min_derivative, identity_init, K);
+    ah.A0 = reinterpret_cast<const uint4*>(A0p); ah.S0 = S0;
+    ah.A1 = reinterpret_cast<const uint4*>(A1p);
+    ah.A2 = reinterpret_cast<const uint4*>(A2p);
+    ah.c0 = c0; ah.c1 = 1.0f; ah.c2 = c2; ah.cs_dev = nullptr;
+    ah.z0 = nullptr; ah.z1 = nullptr; ah.params = nullptr; ah.ldp = 0; ah.src_col = nullptr;
+    da.n_hh = n_hidden - 1;
+    for (int l = 0; l < DEEP_MAX_HH; ++l) da.c1s[l] = l < da.n_hh ? c1s[l] : 1.0f;
+    const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
+    const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
+    const int grid = (int)n_wg;
+    hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCHD(I, KK) hipLaunchKernelGGL((coupling_rqs_dense_deep_kernel<I, KK>), dim3(grid), dim3(FTHREADS), shmem, st, da)
+#define BGK_LAUNCHD2(KK) do { if (inverse) BGK_LAUNCHD(1, KK); else BGK_LAUNCHD(0, KK); } while (0)
+    if (K == 8) BGK_LAUNCHD2(8); else if (K == 4) BGK_LAUNCHD2(4); else if (K == 12) BGK_LAUNCHD2(12);
+    else if (K == 16) BGK_LAUNCHD2(16); else BGK_LAUNCHD2(32);
+#undef BGK_LAUNCHD2
+#undef BGK_LAUNCHD
+    return bgk_launch_status(what);
+}
 
 extern "C" int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                          const void* A0p, const void* A1p, const void* A2p,

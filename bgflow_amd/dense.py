@@ -302,6 +302,21 @@ def _fusable_dense(net):
     return (l0, l1, l2), _ACT_CODES[type(a0)]
 
 
+def _fusable_dense_any(net):
+    """(linears, act_code) for Linear-(act-Linear) x L, L >= 1 hidden layers, biases, one supported activation type; else None"""
+    if type(net) is not DenseNet:
+        return None
+    mods = list(net._layers)
+    if len(mods) < 3 or len(mods) % 2 == 0:
+        return None
+    lins, acts = mods[0::2], mods[1::2]
+    if not all(isinstance(m, torch.nn.Linear) and m.bias is not None for m in lins):
+        return None
+    if any(type(a) is not type(acts[0]) for a in acts) or type(acts[0]) not in _ACT_CODES:
+        return None
+    return tuple(lins), _ACT_CODES[type(acts[0])]
+
+
 def _fusable_dense_deep(net):
     """(linears, act_code) for Linear-(act-Linear) x 2 | x 3 with one supported activation type (the affine coupling kernels take
     two or three hidden layers), else None"""
@@ -666,6 +681,37 @@ def pack_dense_for_fused_w256(linears, nc_slot_host, d, n_bins):
     return A0, A1, A2, (2.0 ** -e0, 2.0 ** -e1, 2.0 ** -e2)
 
 
+DEEP_MAX_HIDDEN = 8     # hidden layers bgk_coupling_rqs_dense_deep takes (DEEP_MAX_HH + 1 in bgk_fused.hip)
+
+
+def pack_dense_for_fused_deep(linears, nc_slot_host, d, n_bins):
+    """Pack DenseNet([n_in, 128, ..., 128, P]) with 1 .. 8 hidden layers for bgk_coupling_rqs_dense_deep: layer 0 and the parameter chunks
+    as pack_dense_for_fused_h2, the hidden -> hidden layers back to back in A1.  Returns (A0, A1 | None, A2, c0, [c1 per layer], c2)."""
+    l0, l_out, mids = linears[0], linears[-1], linears[1:-1]
+    W0, b0 = l0.weight.detach().float(), l0.bias.detach().float()
+    W2, b2 = l_out.weight.detach().float(), l_out.bias.detach().float()
+    n_in = l0.in_features
+    S0 = (n_in + 1 + 15) // 16
+    e0, e2 = _h2_scale_exp(W0, b0), _h2_scale_exp(W2, b2)
+    W0e = torch.zeros(128, 16 * S0, dtype=torch.float32, device=W0.device)
+    W0e[:, :n_in] = W0
+    W0e[:, n_in] = b0                                   # column of the constant-1 feature
+    A0 = _pack_h2(W0e * 2.0 ** e0, None, _h2_k_natural(S0))
+    blocks, c1s = [], []
+    for lin in mids:
+        W, b = lin.weight.detach().float(), lin.bias.detach().float()
+        e = _h2_scale_exp(W, b)
+        blocks.append(_pack_h2(W * 2.0 ** e, b * 2.0 ** e, _h2_k_hidden()))
+        c1s.append(2.0 ** -e)
+    A1 = torch.cat(blocks, dim=0).contiguous() if blocks else None
+    src_t = _src_col_table(d, n_bins, nc_slot_host, W2.device).to(torch.int64)
+    W2r = torch.where(src_t[:, None] >= 0, W2[src_t.clamp_min(0)], torch.zeros((), dtype=W2.dtype, device=W2.device)) * 2.0 ** e2
+    b2r = torch.where(src_t >= 0, b2[src_t.clamp_min(0)], torch.zeros((), dtype=b2.dtype, device=b2.device)) * 2.0 ** e2
+    A2 = torch.cat([_pack_h2(W2r[c * 128:(c + 1) * 128], b2r[c * 128:(c + 1) * 128], _h2_k_hidden())
+                    for c in range(src_t.numel() // 128)], dim=0).contiguous()
+    return A0, A1, A2, 2.0 ** -e0, c1s, 2.0 ** -e2
+
+
 DEVICE_PACK = True     # pack split-f16 operands with bgk_pack_dense_h2 (no host sync); False: the torch reference packer
 
 
@@ -806,9 +852,13 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
         inner = net
     spec = _fusable_dense(inner)
     if spec is None:
+        deep = _fusable_dense_any(inner)
+        if deep is not None and len(deep[0]) - 1 <= DEEP_MAX_HIDDEN and mode == "f16x2" \
+                and all(lin.out_features <= 128 for lin in deep[0][:-1]):
+            return _deep_plan(transformer, net, deep, periodic, y_dim, nc_slot_host)
         if type(inner) is DenseNet:
-            return _reject(transformer, "the fused spline kernels take a DenseNet with exactly two hidden layers, biases and one of "
-                                        "SiLU / ReLU / Tanh")
+            return _reject(transformer, "the fused spline kernels take a DenseNet with biases and one of SiLU / ReLU / Tanh: two hidden "
+                                        "layers of up to 256 units, or (mode 'f16x2') 1 .. 8 hidden layers of up to 128")
         return None
     (l0, l1, l2), act = spec
     H_max = max(l0.out_features, l1.out_features)
@@ -868,6 +918,39 @@ def _fused_plan(transformer, y_dim, nc_slot_host):
     return cache
 
 
+def _deep_plan(transformer, net, spec, periodic, y_dim, nc_slot_host):
+    """plan of a conditioner with 1, 3, 4, ... hidden layers (width <= 128) for bgk_coupling_rqs_dense_deep (inference), or None"""
+    lins, act = spec
+    if y_dim > 64:
+        return _reject(transformer, f"{y_dim} transformed dims: at most 64 are fused")
+    n_nc = int((nc_slot_host >= 0).sum())
+    P = lins[-1].out_features
+    n_bins = (P - n_nc) // (3 * y_dim)
+    if 3 * n_bins * y_dim + n_nc != P:
+        return None
+    if n_bins not in (4, 8, 12, 16, 32):
+        return _reject(transformer, f"{n_bins} bins: the one-launch kernels take 4 / 8 / 12 / 16 / 32")
+    l0 = lins[0]
+    d_c = l0.in_features // 2 if periodic else l0.in_features
+    if periodic:
+        idx = np.arange(d_c)[net.indices] if not isinstance(net.indices, slice) or net.indices != slice(None) else np.arange(d_c)
+        if len(idx) != d_c or 2 * d_c != l0.in_features or not np.array_equal(np.asarray(idx), np.arange(d_c)):
+            return _reject(transformer, "WrapPeriodic over a subset / permutation of the conditioner inputs")
+    version = tuple(param_state_key(p) for lin in lins for p in (lin.weight, lin.bias))
+    cache = transformer._fused_cache
+    dev = l0.weight.device
+    if cache.get("version") != version or cache.get("y_dim") != y_dim or cache.get("mode") != "f16x2" or cache.get("device") != dev \
+            or not cache.get("deep"):
+        cache.clear()
+        padded = any(lin.out_features != 128 for lin in lins[:-1])
+        run = _pad_hidden(lins, 128) if padded else lins
+        cache.update(version=version, y_dim=y_dim, mode="f16x2", device=dev, act=act, periodic=periodic, d_c=d_c, n_bins=n_bins,
+                     padded=padded, hidden=128, deep=len(lins) - 1, cs=None,
+                     circ_mask=int(sum(1 << j for j in range(y_dim) if nc_slot_host[j] < 0)),
+                     packed=pack_dense_for_fused_deep(run, nc_slot_host, y_dim, n_bins))
+    return cache
+
+
 def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter, want_bin_idx=False, acc=None):
     """Try the one-launch coupling layer (bgk_coupling_rqs_dense).  Returns (y', dlogp[, bin_idx]) or
     None when the conditioner is not a fusable DenseNet (the caller then runs conditioner +
@@ -878,7 +961,7 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
     if plan is None or x.shape[-1] != plan["d_c"]:
         return None
     parts = _cond_parts(x)
-    if len(parts) > 1 and (plan["mode"] == "f32" or plan["n_bins"] != 8 or plan["hidden"] != 128):
+    if len(parts) > 1 and (plan["mode"] == "f32" or plan["n_bins"] != 8 or plan["hidden"] != 128 or plan.get("deep")):
         parts = [x.cat()]                 # several conditioning tensors: the second-generation kernel only
     _lib.require_hip(y, *parts)
     W0p, W1p, W2p = plan["packed"][:3]
@@ -898,7 +981,14 @@ def fused_spline_coupling(transformer, x, y, nc_slot_host, inverse, oob_counter,
             s["min_bin_width"], s["min_bin_height"], s["min_derivative"], int(s.get("enable_identity_init", False)),
             _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)), _lib.ptr(bins), _lib.ptr(oob_counter), _lib.stream_ptr(y.device))
     with torch.cuda.device(y.device):
-        if plan["mode"] == "f32":
+        if plan.get("deep"):
+            A0, A1, A2, c0, c1s, c2 = plan["packed"]
+            x2, ldc = _lib.rowmajor(parts[0])
+            c1_arr = (ctypes.c_float * max(1, len(c1s)))(*c1s)
+            st = _lib.lib().bgk_coupling_rqs_dense_deep(
+                _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, c1_arr, c2,
+                plan["deep"], *tail[2:])
+        elif plan["mode"] == "f32":
             x2, ldc = _lib.rowmajor(parts[0])
             st = _lib.lib().bgk_coupling_rqs_dense(
                 _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), _lib.ptr(W0p), _lib.ptr(W1p), _lib.ptr(W2p), *tail)
@@ -1388,7 +1478,7 @@ def _spline_train_prep(transformer, x, y, nc_dev, nc_host, inverse, oob_counter)
         return None                 # hidden layers wider than 128: fused in inference only (no operand packing per training step)
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
     if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device \
-            or plan["hidden"] != 128 or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
+            or plan["hidden"] != 128 or plan.get("deep") or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
         return None                                        # second-generation kernel, the others on the first-generation one
     _lib.require_hip(x, y)
     if "src_col_dev" not in plan or plan["src_col_dev"].device != y.device:

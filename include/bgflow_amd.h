@@ -350,6 +350,22 @@ int bgk_coupling_rqs_dense_h2(const float* cond, int64_t ldc, int32_t d_c, int32
                               float* out, int64_t ldo, float* dlogp, int32_t accumulate,
                               int32_t* bin_idx, int32_t* oob_count, void* stream);
 
+/* The same layer for a conditioner with ANY number of hidden layers, n_hidden = 1 .. 8 (conditioner_factory.py:76-80 takes any `hidden`
+ * tuple; nn/dense.py:30-48) of up to 128 units (narrower ones zero-padded by the packer): split-f16 inference, both directions,
+ * K in {4, 8, 12, 16, 32}.  Operands from bgflow_amd/dense.py::pack_dense_for_fused_deep: A0p / A2p / c0 / c2 as above, A1p the
+ * n_hidden - 1 hidden -> hidden layers back to back (68 blocks of 1 KiB each; NULL for one hidden layer), c1s their unscale factors
+ * (HOST array of n_hidden - 1 floats).  Remaining arguments as bgk_coupling_rqs_dense_h2. */
+int bgk_coupling_rqs_dense_deep(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                const void* A0p, const void* A1p, const void* A2p, float c0, const float* c1s, float c2,
+                                int32_t n_hidden, int32_t act,
+                                const float* y, int64_t ldy, int64_t B, int32_t d, int32_t K,
+                                uint64_t circ_mask, int32_t inverse,
+                                double left, double right, double bottom, double top,
+                                double min_bin_width, double min_bin_height, double min_derivative,
+                                int32_t identity_init,
+                                float* out, int64_t ldo, float* dlogp, int32_t accumulate,
+                                int32_t* bin_idx, int32_t* oob_count, void* stream);
+
 /* Training forward of the same layer: additionally writes what the backward pass needs -- the hidden layers'
  * pre-activations z0, z1 [B, 128] and the spline parameters [B, P] in the reference layout [w | h | s | s_nc]
  * (transformer/spline.py:113-126) -- so that autograd (KLTrainer.train, nn/training/trainers.py:158-170) can run

@@ -825,3 +825,70 @@ def test_linear_layer_device_packer_equals_the_host_packer(hip_lib, dev, n_out, 
     Wz = torch.zeros(5, 9, device=dev)
     (Az, _, csz, _, _), = dense.pack_linear_layer_device(Wz)
     assert float(csz[1]) == 1.0 and not Az.view(torch.int16).any()
+
+
+# ---- conditioners with 1, 3, 4, ... hidden layers on the one-launch kernel (bgk_coupling_rqs_dense_deep) ----------------------------
+@pytest.mark.parametrize("hidden", [(128,), (128, 128, 128), (64, 128, 32, 100), (96,) * 8])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_spline_coupling_with_other_depths_runs_fused(hip_lib, dev, hidden, inverse):
+    """spline conditioners with one, three, four and eight hidden layers (up to 128 units, narrower ones zero-padded) run as ONE launch in
+    split-f16 mode: same function as the conditioner evaluated layer by layer, against the f64 oracle (non-periodic and periodic input,
+    circular and non-circular splines, a batch that is not a multiple of the tile)"""
+    from bgflow_amd import configs
+    from bgflow_amd.utils import hash_init_, synth
+    from oracle import flow_oracle as fo
+    dims = {"BONDS": 17, "ANGLES": 17, "TORSIONS": 17, "FIXED": 9}
+    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+    t = lambda v: torch.as_tensor(v, dtype=torch.float32, device=dev)                                   # noqa: E731
+    for what, on in (("TORSIONS", "FIXED"), ("BONDS", "TORSIONS")):
+        layer_cpu = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, hidden=hidden))
+        layer = hash_init_(configs._spline_coupling(what, on, dims, circ, slot, hidden=hidden)).to(dev)
+        B = 1037
+        xs = [synth(B + 7 * i, B, d, uniform=True) for i, d in enumerate((17, 17, 17, 9))]
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                     # a rejection (RuntimeWarning) would mean the layer-by-layer path ran
+            with torch.no_grad():
+                *outs, dl = layer(*[t(v) for v in xs], inverse=inverse)
+        assert layer.transformer._fused_cache.get("deep") == len(hidden), "bgk_coupling_rqs_dense_deep must have run"
+        ti = slot[what]
+        outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, [])
+        np.testing.assert_allclose(outs[ti].cpu().numpy(), outs64[ti], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=2e-5, atol=2e-5)
+    # training runs the conditioner layer by layer: gradients flow
+    xs_t = [t(v) for v in xs]
+    *_, dl_t = layer(*xs_t, inverse=inverse)
+    dl_t.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters() if p.requires_grad)
+
+
+@pytest.mark.parametrize("n_bins", [4, 16])
+def test_deep_conditioner_other_bin_counts_bins_and_round_trip(hip_lib, dev, n_bins):
+    """three hidden layers with Tanh, K = 4 / 16: values against the f64 oracle, the round trip, the bin indices against the layer-by-layer
+    path (ties at a knot aside)"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_, synth
+    from oracle import flow_oracle as fo
+    d, d_c = 11, 23
+    P = 3 * n_bins * d + d
+    mk = lambda: hash_init_(bg.CouplingFlow(bg.ConditionalSplineTransformer(                       # noqa: E731
+        bg.DenseNet([d_c, 128, 96, 128, P], activation=torch.nn.Tanh()), is_circular=False), transformed_indices=(1,), cond_indices=(0,)))
+    layer_cpu, layer = mk(), mk().to(dev)
+    B = 4099
+    xs = [synth(B, B, d_c), synth(B + 5, B, d, uniform=True)]
+    dx = [torch.as_tensor(v, dtype=torch.float32, device=dev) for v in xs]
+    layer.transformer.return_bin_indices = True
+    with torch.no_grad():
+        _, y, dl = layer(*dx)
+        bins = layer.transformer.last_bin_indices.clone()
+        _, back, dl_back = layer(dx[0], y, inverse=True)
+        layer.transformer.allow_fused = False
+        _, y_ref, _ = layer(*dx)
+        bins_ref = layer.transformer.last_bin_indices.clone()
+        layer.transformer.allow_fused = True
+    assert layer.transformer._fused_cache.get("deep") == 3
+    outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], False, np.float64, [])
+    np.testing.assert_allclose(y.cpu().numpy(), outs64[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(back.cpu().numpy(), xs[1], rtol=0, atol=2e-5)
+    assert float((bins != bins_ref).float().mean()) < 1e-3 and int((bins - bins_ref).abs().max()) <= 1

@@ -399,6 +399,60 @@ def test_linear_layer_packing_reproduces_the_layer():
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * np.abs(W.numpy()).sum(1).max() * np.abs(x).max())
 
 
+def test_deep_conditioner_plan_and_packing():
+    """spline conditioners with 1, 3, 4 hidden layers (<= 128 units) plan bgk_coupling_rqs_dense_deep: hidden -> hidden layers packed back
+    to back with one unscale factor each; the numpy restatement of the MFMA dataflow reproduces the network; nine hidden layers, a
+    mixed activation list and the exact-f32 mode are outside the envelope"""
+    import warnings
+    import bgflow_amd as bg
+    from bgflow_amd import dense
+    from bgflow_amd.utils import hash_init_
+    d, n_in, K = 5, 9, 8
+    P = 3 * K * d + d
+    nc = np.arange(d, dtype=np.int32)
+    silu = lambda v: v / (1.0 + np.exp(-v))                                                          # noqa: E731
+
+    def acc_layout(a):
+        return [[np.array([a[32 * (s >> 1) + ((8 * (s & 1) + ee) & 3) + 8 * ((8 * (s & 1) + ee) >> 2) + 4 * kb] for ee in range(8)])
+                 for kb in range(2)] for s in range(8)]
+
+    for hidden in ((128,), (128, 128, 128), (64, 128, 32, 100)):
+        net = hash_init_(bg.DenseNet([n_in, *hidden, P], activation=torch.nn.SiLU())).double()
+        tr = bg.ConditionalSplineTransformer(net, is_circular=False)
+        plan = dense._fused_plan(tr, d, nc)
+        assert plan["deep"] == len(hidden) and plan["hidden"] == 128 and plan["padded"] == any(h != 128 for h in hidden)
+        A0, A1, A2, c0, c1s, c2 = plan["packed"]
+        assert len(c1s) == len(hidden) - 1 and (A1 is None) == (len(hidden) == 1)
+        assert A1 is None or A1.shape == ((len(hidden) - 1) * 68, 64, 8)
+        S0 = (n_in + 1 + 15) // 16
+        rng = np.random.default_rng(len(hidden))
+        x = rng.normal(size=n_in)
+        x0 = np.zeros(16 * S0)
+        x0[:n_in] = x
+        x0[n_in] = 1.0
+        bv0 = [[x0[16 * s + 8 * kb:16 * s + 8 * kb + 8] for kb in range(2)] for s in range(S0)]
+        h = silu(_emulate_h2_gemm(A0.numpy(), 4, S0, bv0) * c0)
+        for li, c1 in enumerate(c1s):
+            h = silu(_emulate_h2_gemm(A1.numpy()[li * 68:(li + 1) * 68], 4, 8, acc_layout(h)) * c1)
+        src = dense._src_col_table(d, K, nc, "cpu").numpy()
+        got = np.full(P, np.nan)
+        for c in range(src.size // 128):
+            pc = _emulate_h2_gemm(A2.numpy()[c * 68:(c + 1) * 68], 4, 8, acc_layout(h)) * c2
+            live = src[c * 128:(c + 1) * 128] >= 0
+            got[src[c * 128:(c + 1) * 128][live]] = pc[live]
+        ref = net(torch.tensor(x)[None]).detach().numpy()[0]
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        nine = bg.ConditionalSplineTransformer(bg.DenseNet([n_in] + [32] * 9 + [P], activation=torch.nn.SiLU()), is_circular=False)
+        mixed = bg.ConditionalSplineTransformer(bg.DenseNet([n_in, 32, 32, 32, P], activation=[torch.nn.SiLU(), torch.nn.ReLU(), torch.nn.SiLU()]),
+                                                is_circular=False)
+        exact = bg.ConditionalSplineTransformer(bg.DenseNet([n_in, 32, 32, 32, P], activation=torch.nn.SiLU()), is_circular=False)
+        exact.gemm_mode = "f32"
+        assert all(dense._fused_plan(t, d, nc) is None for t in (nine, mixed, exact))
+    assert len(w) == 3 and all("1 .. 8 hidden layers" in str(x.message) for x in w)
+
+
 def test_gemm_mode_switch_and_errors():
     import bgflow_amd as bg
     from bgflow_amd import dense
