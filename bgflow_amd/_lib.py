@@ -89,6 +89,9 @@ _SIGNATURES = {
     "bgk_coupling_affine_dense_h3": (ctypes.c_int, [vp, i64, i32, i32,
                                                     vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp, vp, vp, f32, f32, f32, f32, i32,
                                                     i32, vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32, vp]),
+    "bgk_coupling_affine_dense_deep": (ctypes.c_int, [vp, i64, i32, i32,
+                                                      vp, vp, vp, f32, vp, f32, i32, vp, vp, vp, f32, vp, f32, i32,
+                                                      i32, i32, vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32, vp]),
     "bgk_pack_dense_h2_t": (ctypes.c_int, [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     "bgk_dense_backward_dx": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, i32, i64,
                                              vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp]),

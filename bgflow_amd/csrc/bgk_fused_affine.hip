@@ -231,20 +231,8 @@ __device__ __forceinline__ void net_eval(h2_f32x16 (&res)[OT], const AffNet& n, 
     ra_gemm_hidden<OT, HT, true>(res, bf, reinterpret_cast<const r_u32x4*>(n.A2), lane);
 }
 
-template <int HT, int OT>
-__global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(FusedAffArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, hh = lane >> 5;
-    float* s_x = smem + (size_t)wave * a.lds_per_wave;
-    const int64_t n_tiles = (a.B + 31) / 32;
-    const int64_t tile = (int64_t)blockIdx.x * AW + wave;
-    if (tile >= n_tiles) return;
-    const int64_t b0 = tile * 32;
-    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
-    const int d = a.d;
-
-    /* conditioner input [feature][sample] + constant-1 row (bias column) + zero pad rows */
+/* conditioner input of a 32-sample tile [feature][sample] + constant-1 row (bias column) + zero pad rows */
+__device__ __forceinline__ void aff_stage_cond(const FusedAffArgs& a, float* s_x, int64_t b0, int rows, int lane) {
     const int n_in = a.periodic ? 2 * a.d_c : a.d_c;
     for (int i = lane; i < 32 * a.d_c; i += 64) {
         const int r = i / a.d_c, c = i - r * a.d_c;
@@ -263,15 +251,13 @@ __global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(Fused
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    h2_f32x16 mu[OT], sr[OT];
-#pragma unroll
-    for (int m = 0; m < OT; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { mu[m][r] = 0.0f; sr[m][r] = 0.0f; }
-    if (a.has_shift) net_eval<HT, OT>(mu, a.shift, s_x, a.S0, lane);
-    if (a.has_scale) net_eval<HT, OT>(sr, a.scale, s_x, a.S0, lane);
+}
 
-    /* ---- affine tail on the accumulator layout: this lane holds dims h2_row(m, r, hh) of sample j ---- */
+/* affine tail on the accumulator layout (mu, sr = the two networks' raw outputs): this lane holds dims h2_row(m, r, hh) of sample j */
+template <int OT>
+__device__ __forceinline__ void aff_tail(const FusedAffArgs& a, h2_f32x16 (&mu)[OT], h2_f32x16 (&sr)[OT], int64_t b0, int rows, int lane) {
+    const int j = lane & 31, hh = lane >> 5;
+    const int d = a.d;
     const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
     float lsum = 0.0f;
 #pragma unroll
@@ -341,6 +327,74 @@ __global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(Fused
             if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
         }
     }
+}
+
+template <int HT, int OT>
+__global__ __launch_bounds__(AW * 64, 2) void coupling_affine_dense_kernel(FusedAffArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s_x = smem + (size_t)wave * a.lds_per_wave;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * AW + wave;
+    if (tile >= n_tiles) return;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    aff_stage_cond(a, s_x, b0, rows, lane);
+    h2_f32x16 mu[OT], sr[OT];
+#pragma unroll
+    for (int m = 0; m < OT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { mu[m][r] = 0.0f; sr[m][r] = 0.0f; }
+    if (a.has_shift) net_eval<HT, OT>(mu, a.shift, s_x, a.S0, lane);
+    if (a.has_scale) net_eval<HT, OT>(sr, a.scale, s_x, a.S0, lane);
+    aff_tail<OT>(a, mu, sr, b0, rows, lane);
+}
+
+/* ---- conditioners with ANY number of hidden layers, n_hidden = 1 .. 8 (other than the 2 / 3 of the kernels above; README.md:72-79's
+ * [1, 4, 1] networks have one): the streaming kernel with the hidden -> hidden GEMM + activation in a loop over the packed layers
+ * (AffNet::A1 = their operands back to back, c1s[l] their unscale factors; both networks have the same depth) ---- */
+constexpr int AFF_DEEP_MAX_HH = 7;
+struct DeepAffArgs { FusedAffArgs a; int n_hh; float sc1s[AFF_DEEP_MAX_HH], tc1s[AFF_DEEP_MAX_HH]; };
+
+template <int HT, int OT>
+__device__ __forceinline__ void net_eval_deep(h2_f32x16 (&res)[OT], const AffNet& n, int n_hh, const float (&c1s)[AFF_DEEP_MAX_HH],
+                                              const float* s_x, int S0, int lane) {
+    h2_f32x16 h[HT];
+#pragma unroll
+    for (int m = 0; m < HT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[m][r] = 0.0f;
+    h2_gemm_lds<HT>(h, s_x, ASROW, S0, n.A0, lane);
+    RB<HT> bf;
+    r_act_split<HT>(bf, h, n.c0, n.act);
+    constexpr int LAYER16 = (2 * HT * HT * 2 + HT) * 64;          /* 16-byte units of one packed hidden -> hidden layer */
+    for (int l = 0; l < n_hh; ++l) {
+        ra_gemm_hidden<HT, HT, true>(h, bf, reinterpret_cast<const r_u32x4*>(n.A1) + (size_t)l * LAYER16, lane);
+        r_act_split<HT>(bf, h, c1s[l], n.act);
+    }
+    ra_gemm_hidden<OT, HT, true>(res, bf, reinterpret_cast<const r_u32x4*>(n.A2), lane);
+}
+
+template <int HT, int OT>
+__global__ __launch_bounds__(AW * 64, 2) void coupling_affine_deep_kernel(DeepAffArgs da) {
+    const FusedAffArgs& a = da.a;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s_x = smem + (size_t)wave * a.lds_per_wave;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * AW + wave;
+    if (tile >= n_tiles) return;
+    const int64_t b0 = tile * 32;
+    const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+    aff_stage_cond(a, s_x, b0, rows, lane);
+    h2_f32x16 mu[OT], sr[OT];
+#pragma unroll
+    for (int m = 0; m < OT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { mu[m][r] = 0.0f; sr[m][r] = 0.0f; }
+    if (a.has_shift) net_eval_deep<HT, OT>(mu, a.shift, da.n_hh, da.sc1s, s_x, a.S0, lane);
+    if (a.has_scale) net_eval_deep<HT, OT>(sr, a.scale, da.n_hh, da.tc1s, s_x, a.S0, lane);
+    aff_tail<OT>(a, mu, sr, b0, rows, lane);
 }
 
 
@@ -1034,6 +1088,57 @@ extern "C" int bgk_coupling_affine_dense_h2(const float* cond, int64_t ldc, int3
     return affine_dense_launch(cond, ldc, d_c, periodic, sA0, sA1, nullptr, sA2, sc0, sc1, 1.0f, sc2, s_act,
                                tA0, tA1, nullptr, tA2, tc0, tc1, 1.0f, tc2, t_act, hidden, log_alpha, preserve_volume, is_circular, inverse,
                                y, ldy, B, d, out, ldo, dlogp, accumulate, stream);
+}
+
+extern "C" int bgk_coupling_affine_dense_deep(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                              const void* sA0, const void* sA1, const void* sA2, float sc0, const float* sc1s, float sc2, int32_t s_act,
+                                              const void* tA0, const void* tA1, const void* tA2, float tc0, const float* tc1s, float tc2, int32_t t_act,
+                                              int32_t n_hidden, int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                              int32_t is_circular, int32_t inverse,
+                                              const float* y, int64_t ldy, int64_t B, int32_t d,
+                                              float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
+    const char* what = "bgk_coupling_affine_dense_deep";
+    BGK_CHECK_ARG(cond && y && out && dlogp, "%s: null pointer", what);
+    BGK_CHECK_ARG(B > 0 && d > 0 && d_c > 0, "%s: bad sizes", what);
+    const int has_shift = sA0 != nullptr, has_scale = tA0 != nullptr;
+    BGK_CHECK_ARG(has_shift || has_scale, "%s: no conditioner network", what);
+    BGK_CHECK_ARG(!has_shift || (sA2 && (n_hidden == 1 || (sA1 && sc1s))), "%s: incomplete shift network", what);
+    BGK_CHECK_ARG(!has_scale || (tA2 && log_alpha && (n_hidden == 1 || (tA1 && tc1s))), "%s: incomplete scale network", what);
+    BGK_CHECK_ARG(!(has_scale && is_circular), "Scaling is not compatible with periodicity.");
+    const int n_in = periodic ? 2 * d_c : d_c;
+    if (n_hidden < 1 || n_hidden > AFF_DEEP_MAX_HH + 1 || (hidden != 64 && hidden != 128) || d > 96 || n_in > 127
+        || s_act < 0 || s_act > 3 || t_act < 0 || t_act > 3) {
+        bgk_set_error("%s: 1 .. %d hidden layers of width 64 | 128, d <= 96, <= 127 input features are fused (got n_hidden=%d hidden=%d d=%d n_in=%d)",
+                      what, AFF_DEEP_MAX_HH + 1, n_hidden, hidden, d, n_in);
+        return BGK_EUNSUPPORTED;
+    }
+    DeepAffArgs da;
+    FusedAffArgs& a = da.a;
+    a.cond = cond; a.ldc = ldc; a.d_c = d_c; a.periodic = periodic; a.S0 = (n_in + 1 + 15) / 16;
+    a.shift = AffNet{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA2, sc0, 1.0f, sc2, s_act, nullptr, 1.0f};
+    a.scale = AffNet{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA2, tc0, 1.0f, tc2, t_act, nullptr, 1.0f};
+    a.has_shift = has_shift; a.has_scale = has_scale;
+    a.log_alpha = log_alpha; a.preserve_volume = preserve_volume; a.is_circular = is_circular; a.inverse = inverse;
+    a.y = y; a.ldy = ldy; a.B = B; a.d = d; a.out = out; a.ldo = ldo; a.dlogp = dlogp; a.accumulate = accumulate;
+    a.lds_per_wave = 16 * a.S0 * ASROW;
+    a.vec4 = (ldy % 4 == 0) && (ldo % 4 == 0) && (((uintptr_t)y | (uintptr_t)out) % 16 == 0);
+    a.cvec4 = (ldc % 4 == 0) && ((uintptr_t)cond % 16 == 0);
+    da.n_hh = n_hidden - 1;
+    for (int l = 0; l < AFF_DEEP_MAX_HH; ++l) {
+        da.sc1s[l] = (has_shift && l < da.n_hh) ? sc1s[l] : 1.0f;
+        da.tc1s[l] = (has_scale && l < da.n_hh) ? tc1s[l] : 1.0f;
+    }
+    const size_t shmem = sizeof(float) * (size_t)AW * a.lds_per_wave;
+    const int64_t n_wg = ((B + 31) / 32 + AW - 1) / AW;
+    BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "%s: batch too large for one launch", what);
+    const int OT = (d + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCH(H, O) hipLaunchKernelGGL((coupling_affine_deep_kernel<H, O>), dim3((int)n_wg), dim3(AW * 64), shmem, st, da)
+    if (hidden == 64) { if (OT == 1) BGK_LAUNCH(2, 1); else if (OT == 2) BGK_LAUNCH(2, 2); else BGK_LAUNCH(2, 3); }
+    else { if (OT == 1) BGK_LAUNCH(4, 1); else if (OT == 2) BGK_LAUNCH(4, 2); else BGK_LAUNCH(4, 3); }
+#undef BGK_LAUNCH
+    return bgk_launch_status(what);
 }
 
 extern "C" int bgk_coupling_affine_dense_h3(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,

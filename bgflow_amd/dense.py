@@ -481,6 +481,33 @@ def pack_dense_for_affine_h2(linears):
     return A0, A1, A2, (2.0 ** -e0, 2.0 ** -e1, 2.0 ** -e2)
 
 
+def pack_dense_for_affine_deep(linears):
+    """Pack DenseNet([n_in, H, ..., H, d]) with 1 .. 8 hidden layers (H = 64 | 128, d <= 96) for bgk_coupling_affine_dense_deep: layer 0
+    and the output layer as pack_dense_for_affine_h2, the hidden -> hidden layers back to back.  Returns (A0, A1 | None, A2, c0, [c1 per
+    hidden -> hidden layer], c2)."""
+    l0, l_out, mids = linears[0], linears[-1], linears[1:-1]
+    W0, b0 = l0.weight.detach().float(), l0.bias.detach().float()
+    W2, b2 = l_out.weight.detach().float(), l_out.bias.detach().float()
+    n_in, H, d = l0.in_features, l0.out_features, l_out.out_features
+    HT, OT = H // 32, (d + 31) // 32
+    S0 = (n_in + 1 + 15) // 16
+    e0, e2 = _h2_scale_exp(W0, b0), _h2_scale_exp(W2, b2)
+    W0e = torch.zeros(H, 16 * S0, dtype=torch.float32, device=W0.device)
+    W0e[:, :n_in] = W0
+    W0e[:, n_in] = b0
+    A0 = _pack_h2(W0e * 2.0 ** e0, None, _h2_k_natural(S0), NT=HT)
+    blocks, c1s = [], []
+    for lin in mids:
+        W, b = lin.weight.detach().float(), lin.bias.detach().float()
+        e = _h2_scale_exp(W, b)
+        blocks.append(_pack_h2(W * 2.0 ** e, b * 2.0 ** e, _h2_k_hidden(HT), NT=HT))
+        c1s.append(2.0 ** -e)
+    A1 = torch.cat(blocks, dim=0).contiguous() if blocks else None
+    W2p, b2p = _pad_rows(W2 * 2.0 ** e2, b2 * 2.0 ** e2, 32 * OT)
+    A2 = _pack_h2(W2p, b2p, _h2_k_hidden(HT), NT=OT)
+    return A0, A1, A2, 2.0 ** -e0, c1s, 2.0 ** -e2
+
+
 def _affine_plan(transformer, y_dim):
     """Decide (and cache) whether an AffineTransformer's conditioners can run fused; pack their weights."""
     nets = (transformer._shift_transformation, transformer._scale_transformation)
@@ -505,16 +532,23 @@ def _affine_plan(transformer, y_dim):
         periodic = per
         spec = _fusable_dense_deep(n)
         if spec is None:
+            spec = _fusable_dense_any(n)          # any other depth: bgk_coupling_affine_dense_deep
+            if spec is not None and len(spec[0]) - 1 > DEEP_MAX_HIDDEN:
+                spec = None
+        if spec is None:
             if type(n) is DenseNet:
-                return _reject(transformer, "the fused affine kernels take DenseNets with two or three hidden layers, biases and one of "
+                return _reject(transformer, "the fused affine kernels take DenseNets with 1 .. 8 hidden layers, biases and one of "
                                             "SiLU / ReLU / Tanh")
             return None
         specs.append(spec)
     live = [sp for sp in specs if sp is not None]
-    H, n_in, depth = live[0][0][0].out_features, live[0][0][0].in_features, len(live[0][0])
+    n_in, depth = live[0][0][0].in_features, len(live[0][0])
+    anydepth = depth not in (3, 4)                      # other than two / three hidden layers: the loop kernel, hidden widths may differ
+    H = max(m.out_features for lins, _ in live for m in lins[:-1])
     for lins, _ in live:
-        if len(lins) != depth or lins[0].in_features != n_in or lins[-1].out_features != y_dim \
-                or any(m.out_features != H for m in lins[:-1]) or any(m.in_features != H for m in lins[1:]):
+        if len(lins) != depth or lins[0].in_features != n_in or lins[-1].out_features != y_dim:
+            return None
+        if not anydepth and (any(m.out_features != H for m in lins[:-1]) or any(m.in_features != H for m in lins[1:])):
             return None
     if H > 128 or y_dim > 96 or n_in > 127 or (periodic and n_in % 2):
         return _reject(transformer, f"hidden width {H} / {y_dim} transformed dims / {n_in} input features: fused for widths up to 128, "
@@ -525,10 +559,12 @@ def _affine_plan(transformer, y_dim):
     cache = transformer._fused_cache
     if cache.get("version") != version or cache.get("y_dim") != y_dim:
         cache.clear()
-        if H_run != H:                                  # (only when the weights changed: the padded copies live in the packed operands)
+        if H_run != H or (anydepth and any(m.out_features != H_run for lins, _ in live for m in lins[:-1])):
+            # (only when the weights changed: the padded copies live in the packed operands)
             specs = [None if sp is None else (_pad_hidden(sp[0], H_run), sp[1]) for sp in specs]
+        pack = pack_dense_for_affine_deep if anydepth else pack_dense_for_affine_h2
         cache.update(version=version, y_dim=y_dim, hidden=H_run, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), depth=depth,
-                     packed=[None if sp is None else (pack_dense_for_affine_h2(sp[0]), sp[1]) for sp in specs])
+                     anydepth=anydepth, packed=[None if sp is None else (pack(sp[0]), sp[1]) for sp in specs])
     return cache
 
 
@@ -587,6 +623,9 @@ def fused_affine_coupling(transformer, x, y, inverse, out=None, dlogp=None, accu
         dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=y.device), False
     ldo = out.stride(0)
     assert out.shape == (B, d) and out.stride(1) == 1 and dlogp.shape == (B,) and dlogp.is_contiguous()
+    if plan.get("anydepth"):
+        return _fused_affine_anydepth(transformer, plan, parts[0] if len(parts) == 1 else x.cat(), y2, ldy, B, d, out, ldo, dlogp, accumulate,
+                                      inverse, acc)
     args = []
     deep = plan["depth"] == 4
     for entry in plan["packed"]:
@@ -620,6 +659,35 @@ def fused_affine_coupling(transformer, x, y, inverse, out=None, dlogp=None, accu
     if st == -2:
         return _reject(transformer, "shape outside the fused affine kernels' envelope: " + _lib.lib().bgk_last_error().decode(errors="replace"))
     _lib.check(st, "bgk_coupling_affine_dense_h3" if deep else "bgk_coupling_affine_dense_h2")
+    if acc is not None:
+        acc.commit()
+        return out, acc
+    return out, dlogp[:, None]
+
+
+def _fused_affine_anydepth(transformer, plan, x, y2, ldy, B, d, out, ldo, dlogp, accumulate, inverse, acc):
+    """launch of bgk_coupling_affine_dense_deep (conditioners with 1, 4, 5 .. 8 hidden layers) for fused_affine_coupling"""
+    args, keep = [], []
+    for entry in plan["packed"]:
+        if entry is None:
+            args += [None, None, None, 1.0, None, 1.0, 0]
+            continue
+        (A0, A1, A2, c0, c1s, c2), act = entry
+        if A0.device != y2.device:
+            return None
+        arr = (ctypes.c_float * max(1, len(c1s)))(*c1s)
+        keep.append(arr)
+        args += [_lib.ptr(A0), _lib.ptr(A1), _lib.ptr(A2), c0, arr, c2, act]
+    log_alpha = transformer._log_alpha.detach().to(device=y2.device, dtype=torch.float32)
+    x2, ldc = _lib.rowmajor(x)
+    with torch.cuda.device(y2.device):
+        st = _lib.lib().bgk_coupling_affine_dense_deep(
+            _lib.ptr(x2), ldc, plan["d_c"], int(plan["periodic"]), *args, plan["depth"] - 1, plan["hidden"], _lib.ptr(log_alpha),
+            int(transformer._preserve_volume), int(transformer._is_circular), int(inverse),
+            _lib.ptr(y2), ldy, B, d, _lib.ptr(out), ldo, _lib.ptr(dlogp), int(bool(accumulate)), _lib.stream_ptr(y2.device))
+    if st == -2:
+        return _reject(transformer, "shape outside the fused affine kernels' envelope: " + _lib.lib().bgk_last_error().decode(errors="replace"))
+    _lib.check(st, "bgk_coupling_affine_dense_deep")
     if acc is not None:
         acc.commit()
         return out, acc

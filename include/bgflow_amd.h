@@ -437,6 +437,18 @@ int bgk_coupling_affine_dense_h3(const float* cond, int64_t ldc, int32_t d_c, in
                                  const float* y, int64_t ldy, int64_t B, int32_t d,
                                  float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
 
+/* The same layer for conditioners with ANY number of hidden layers, n_hidden = 1 .. 8 (both networks alike; README.md:72-79's
+ * DenseNet([dim // 2, 4, dim // 2]) has one; conditioner_factory.py:76-80 takes any `hidden` tuple) of width 64 | 128 (narrower ones
+ * zero-padded by the packer).  Operands from bgflow_amd/dense.py::pack_dense_for_affine_deep: sA0 / sA2 / sc0 / sc2 as above, sA1 the
+ * n_hidden - 1 hidden -> hidden layers back to back (NULL for one hidden layer), sc1s their unscale factors (HOST array); likewise t*. */
+int bgk_coupling_affine_dense_deep(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                   const void* sA0, const void* sA1, const void* sA2, float sc0, const float* sc1s, float sc2, int32_t s_act,
+                                   const void* tA0, const void* tA1, const void* tA2, float tc0, const float* tc1s, float tc2, int32_t t_act,
+                                   int32_t n_hidden, int32_t hidden, const float* log_alpha, int32_t preserve_volume,
+                                   int32_t is_circular, int32_t inverse,
+                                   const float* y, int64_t ldy, int64_t B, int32_t d,
+                                   float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
+
 /* The fused coupling layers with SEVERAL conditioning tensors: CouplingFlow concatenates the tensors at cond_indices before it
  * calls the transformer (torch.cat, nn/flow/coupling.py:162-165; e.g. cfg 5's AUGMENTED | (FIXED, BONDS, ANGLES) layers).  Here
  * cond / ldc / width are HOST arrays of n_cond (1..3) device pointers [B, width_i], row strides and widths; the kernels stage

@@ -795,7 +795,7 @@ def test_densenet_layers_run_on_the_layer_kernel(hip_lib, dev):
 
 def test_readme_flow_launches_no_library_gemm(hip_lib, dev):
     """cfg 1 (README.md:54-96: RealNVP coupling with [1, 4, 1] conditioners): sampling and energy evaluation on the GPU launch no rocBLAS /
-    hipBLASLt kernel -- the conditioner layers run on bgk_dense_layer, the transformer on bgk_affine_transform"""
+    hipBLASLt kernel -- the coupling is ONE launch (conditioners with one hidden layer: bgk_coupling_affine_dense_deep)"""
     from bgflow_amd import configs
     gen = configs.make_readme_generator(dev)
     with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU]) as prof:
@@ -804,8 +804,8 @@ def test_readme_flow_launches_no_library_gemm(hip_lib, dev):
             gen.energy(x)
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages()]
-    lins = [m for m in gen.flow.modules() if isinstance(m, torch.nn.Linear)]
-    assert len(lins) == 4 and all("_bgk_layer_ops" in m.__dict__ for m in lins), "every Linear must have run on the kernel"
+    plan = gen.flow[1].transformer._fused_cache
+    assert plan.get("anydepth") and plan["depth"] == 2, "the coupling must have run as one launch (bgk_coupling_affine_dense_deep)"
     assert not any(("Cijk" in n) or ("gemm" in n.lower()) or n.startswith("aten::addmm") or n.startswith("aten::mm") for n in names), names
 
 
@@ -892,3 +892,38 @@ def test_deep_conditioner_other_bin_counts_bins_and_round_trip(hip_lib, dev, n_b
     np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=5e-5, atol=5e-5)
     np.testing.assert_allclose(back.cpu().numpy(), xs[1], rtol=0, atol=2e-5)
     assert float((bins != bins_ref).float().mean()) < 1e-3 and int((bins - bins_ref).abs().max()) <= 1
+
+
+# ---- affine couplings whose conditioners have 1, 4, 5, ... hidden layers (bgk_coupling_affine_dense_deep) ----------------------------
+@pytest.mark.parametrize("hidden,acts", [((4,), ("ReLU", "Tanh")), ((64,), ("SiLU", "SiLU")), ((128, 64, 32, 100), ("ReLU", "Tanh")),
+                                         ((48,) * 5, ("Tanh", "Tanh")), ((128,) * 8, ("SiLU", "ReLU"))])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_coupling_with_other_depths_runs_fused(hip_lib, dev, hidden, acts, inverse):
+    """affine couplings whose shift / scale networks have one, four, five or eight hidden layers (<= 128 units, zero-padded to 64 / 128)
+    run as ONE launch: same function as the networks evaluated layer by layer, against the f64 oracle; a shift-only coupling too"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_, synth
+    from oracle import flow_oracle as fo
+    t = lambda v: torch.as_tensor(v, dtype=torch.float32, device=dev)                                   # noqa: E731
+    for with_scale in (True, False):
+        mk = lambda: hash_init_(bg.CouplingFlow(bg.AffineTransformer(                           # noqa: E731
+            bg.DenseNet([12, *hidden, 20], getattr(torch.nn, acts[0])()),
+            bg.DenseNet([12, *hidden, 20], getattr(torch.nn, acts[1])()) if with_scale else None),
+            transformed_indices=(1,), cond_indices=(0,)))
+        layer_cpu, layer = mk(), mk().to(dev)
+        B = 2111
+        xs = [synth(B + 3 * i, B, d) for i, d in enumerate((12, 20))]
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                     # a rejection (RuntimeWarning) would mean the layer-by-layer path ran
+            with torch.no_grad():
+                _, y, dl = layer(*[t(v) for v in xs], inverse=inverse)
+        plan = layer.transformer._fused_cache
+        assert plan.get("anydepth") and plan["depth"] == len(hidden) + 1 and plan["hidden"] == (64 if max(hidden) <= 64 else 128)
+        outs64, dl64 = fo.run_block(layer_cpu, [v.astype(np.float64) for v in xs], inverse, np.float64, [])
+        np.testing.assert_allclose(y.cpu().numpy(), outs64[1], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=2e-5, atol=2e-5)
+    # under autograd the networks run layer by layer: gradients flow
+    xg = [t(v) for v in xs]
+    *_, dlg = layer(*xg, inverse=inverse)
+    (dlg.sum() if with_scale else layer(*xg)[1].sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters() if p.requires_grad and p.grad is not None)

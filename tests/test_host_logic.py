@@ -453,6 +453,34 @@ def test_deep_conditioner_plan_and_packing():
     assert len(w) == 3 and all("1 .. 8 hidden layers" in str(x.message) for x in w)
 
 
+def test_deep_affine_plan_and_packing():
+    """affine conditioners with 1 or 4 hidden layers plan bgk_coupling_affine_dense_deep (widths zero-padded to 64 / 128); the numpy
+    restatement of the MFMA dataflow reproduces the README flow's [1, 4, 1] shift network from its packed operands"""
+    import bgflow_amd as bg
+    from bgflow_amd import dense
+    from bgflow_amd.utils import hash_init_
+    tr = hash_init_(bg.AffineTransformer(bg.DenseNet([1, 4, 1], torch.nn.ReLU()), bg.DenseNet([1, 4, 1], torch.nn.Tanh())))
+    plan = dense._affine_plan(tr, 1)
+    assert plan["anydepth"] and plan["depth"] == 2 and plan["hidden"] == 64 and plan["d_c"] == 1
+    (A0, A1, A2, c0, c1s, c2), act = plan["packed"][0]
+    assert A1 is None and c1s == [] and act == 2 and A0.shape == (1 * 2 * 2, 64, 8) and A2.shape == (4 * 1 * 2 + 1, 64, 8)
+    x = 0.37
+    x0 = np.zeros(16)
+    x0[0], x0[1] = x, 1.0
+    h = np.maximum(_emulate_h2_gemm(A0.numpy(), 2, 1, [[x0[8 * kb:8 * kb + 8] for kb in range(2)]]) * c0, 0.0)
+    bv = [[np.array([h[32 * (s >> 1) + ((8 * (s & 1) + ee) & 3) + 8 * ((8 * (s & 1) + ee) >> 2) + 4 * kb] for ee in range(8)])
+           for kb in range(2)] for s in range(4)]
+    out = _emulate_h2_gemm(A2.numpy(), 1, 4, bv) * c2
+    ref = tr._shift_transformation.double()(torch.tensor([[x]], dtype=torch.float64)).item()
+    assert abs(out[0] - ref) < 2e-6 and np.all(out[1:] == 0.0)
+    four = bg.AffineTransformer(bg.DenseNet([12, 128, 64, 32, 100, 20], torch.nn.SiLU()), None)
+    plan4 = dense._affine_plan(four, 20)
+    assert plan4["anydepth"] and plan4["depth"] == 5 and plan4["hidden"] == 128 and plan4["packed"][1] is None
+    assert plan4["packed"][0][0][1].shape == (3 * 68, 64, 8) and len(plan4["packed"][0][0][4]) == 3
+    two = dense._affine_plan(bg.AffineTransformer(bg.DenseNet([12, 64, 64, 20], torch.nn.SiLU()), None), 20)
+    assert not two["anydepth"] and two["depth"] == 3
+
+
 def test_gemm_mode_switch_and_errors():
     import bgflow_amd as bg
     from bgflow_amd import dense
