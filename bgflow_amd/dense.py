@@ -1542,8 +1542,9 @@ def _spline_train_prep(transformer, x, y, nc_dev, nc_host, inverse, oob_counter)
         return None
     net = transformer._params_net
     spec = _fusable_dense(net.net if type(net) is WrapPeriodic else net)
-    if spec is not None and max(spec[0][0].out_features, spec[0][1].out_features) > 128:
-        return None                 # hidden layers wider than 128: fused in inference only (no operand packing per training step)
+    if spec is None or max(spec[0][0].out_features, spec[0][1].out_features) > 128:
+        return None                 # the training kernels take two hidden layers of up to 128 units; wider / deeper conditioners are fused in
+                                    # inference only (and no operands are packed for them per training step)
     plan = _fused_plan(transformer, y.shape[-1], nc_host)
     if plan is None or plan["mode"] != "f16x2" or x.shape[-1] != plan["d_c"] or plan["packed"][0].device != y.device \
             or plan["hidden"] != 128 or plan.get("deep") or plan["n_bins"] not in (4, 8, 12, 16, 32):   # the training variant (saved pre-activations + parameters): K = 8 on the
