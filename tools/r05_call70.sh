@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box, round 5 call 70: the whole GPU suite, the smoke entry and the default bench line with the round's last build
+# GPU box, round 5 call 70+: the whole GPU suite, the smoke entry and the default bench line with the round's last build
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r05c70; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee $O/pytest_all.txt
