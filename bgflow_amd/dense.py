@@ -1,11 +1,16 @@
 """Conditioner networks: DenseNet and the WrapPeriodic featuriser (bgflow/nn/dense.py,
-bgflow/nn/periodic.py) plus the dispatcher of the fused coupling kernel.
+bgflow/nn/periodic.py) plus the dispatchers of the one-launch coupling kernels.
 
-As stand-alone torch modules these run stock PyTorch-ROCm ops (``torch.nn.Linear`` ->
-hipBLASLt), which is what the generic (arbitrary-conditioner) path uses.  When a spline
-transformer's conditioner is a ``DenseNet`` with two hidden layers (optionally inside a
-``WrapPeriodic`` whose inputs are all periodic), ``fused_spline_coupling`` hands the raw weights to
-``bgk_coupling_rqs_dense``: MLP on the f32 matrix cores + spline epilogue in one launch.
+As stand-alone torch modules the Linear layers of a DenseNet on HIP tensors run on ``bgk_dense_layer``
+(one launch per ``Linear (+ SiLU / ReLU / Tanh)``; ``LAYER_KERNEL = False``: ``torch.nn.Linear`` -> hipBLASLt), which is also
+what the layer-by-layer path of a coupling outside the fused envelope uses.  When a transformer's conditioner is a ``DenseNet``
+(optionally inside a ``WrapPeriodic`` whose inputs are all periodic on [0, 1]) the whole coupling layer is ONE launch -- MLP on the
+matrix cores + transformer epilogue:
+  spline  (``fused_spline_coupling``): two hidden layers of <= 128 units (``bgk_coupling_rqs_dense_h2``, also the differentiable
+          training forward) or <= 256 units (same entry, H0 = H1 = 256, inference); 1, 3, 4 .. 8 hidden layers of <= 128 units
+          (``bgk_coupling_rqs_dense_deep``, inference); exact-f32 GEMMs for two hidden layers of 128 (``bgk_coupling_rqs_dense``);
+  affine  (``fused_affine_coupling``): two / three hidden layers of <= 128 units (``bgk_coupling_affine_dense_h2`` / ``_h3``), any other
+          depth from 1 to 8 (``bgk_coupling_affine_dense_deep``).
 state_dict keys match the reference (``_layers.{i}.weight/bias``, ``net._layers...``).
 """
 import ctypes
