@@ -674,6 +674,50 @@ def test_c_abi_argument_validation_needs_no_gpu(hip_lib):
                                        P1, 66, P1, 0, None, None, P1, P1, P1, None) == -1 and "null pointer" in err()
 
 
+def test_c_abi_argument_validation_of_the_wide_envelope_entry_points(hip_lib):
+    """round-5 entry points (hidden width 256, any-depth spline / affine conditioners, bgk_dense_layer and its packer): empty batches are
+    a no-op, bad arguments BGK_EINVAL, shapes outside the envelope BGK_EUNSUPPORTED -- all before any launch (no GPU needed)"""
+    L = hip_lib
+    P1 = ctypes.c_void_p(0x1000)
+    err = lambda: L.bgk_last_error().decode(errors="replace")      # noqa: E731
+    tail = (P1, 17, 8, 17, 8, 0, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None)
+    # hidden width 256: split-f16 inference only (operand_dtype 1 = bf16 is outside the envelope), other widths unsupported
+    assert L.bgk_coupling_rqs_dense_h2(P1, 17, 17, 0, P1, P1, P1, 1.0, 1.0, 1.0, None, 1, 256, 256, 1, *tail) == -2 and "width 256" in err()
+    assert L.bgk_coupling_rqs_dense_h2(P1, 17, 17, 0, P1, P1, P1, 1.0, 1.0, 1.0, None, 0, 192, 192, 1, *tail) == -2
+    # any-depth spline entry: 1 .. 8 hidden layers, the fused bin counts, host array of unscale factors
+    c1 = (ctypes.c_float * 8)(*([1.0] * 8))
+    dtail = (1, P1, 17, 8, 17, 8, 0, 0, 0.0, 1.0, 0.0, 1.0, 1e-3, 1e-3, 1e-3, 1, P1, 17, P1, 0, None, None, None)
+    zero_b = dtail[:3] + (0,) + dtail[4:]
+    assert L.bgk_coupling_rqs_dense_deep(None, 17, 17, 0, None, None, None, 1.0, c1, 1.0, 3, *zero_b) == 0
+    assert L.bgk_coupling_rqs_dense_deep(P1, 17, 17, 0, P1, P1, P1, 1.0, c1, 1.0, 9, *dtail) == -2 and "hidden layers" in err()
+    assert L.bgk_coupling_rqs_dense_deep(P1, 17, 17, 0, P1, P1, P1, 1.0, c1, 1.0, 0, *dtail) == -2
+    assert L.bgk_coupling_rqs_dense_deep(P1, 17, 17, 0, P1, None, P1, 1.0, c1, 1.0, 3, *dtail) == -1 and "hidden-layer operands" in err()
+    k7 = dtail[:5] + (7,) + dtail[6:]
+    assert L.bgk_coupling_rqs_dense_deep(P1, 17, 17, 0, P1, P1, P1, 1.0, c1, 1.0, 3, *k7) == -2
+    assert L.bgk_coupling_rqs_dense_deep(P1, 17, 120, 0, P1, P1, P1, 1.0, c1, 1.0, 3, *dtail) == -2 and "layer-0 tile" in err()
+    # any-depth affine entry
+    atail = (P1, 0, 0, 0, P1, 32, 8, 32, P1, 32, P1, 0, None)
+    nets = (P1, P1, P1, 1.0, c1, 1.0, 2, P1, P1, P1, 1.0, c1, 1.0, 3)
+    assert L.bgk_coupling_affine_dense_deep(P1, 32, 32, 0, *nets, 4, 64, *(atail[:6] + (0,) + atail[7:])) == 0
+    assert L.bgk_coupling_affine_dense_deep(P1, 32, 32, 0, *nets, 9, 64, *atail) == -2 and "hidden layers" in err()
+    assert L.bgk_coupling_affine_dense_deep(P1, 32, 32, 0, *nets, 4, 96, *atail) == -2
+    assert L.bgk_coupling_affine_dense_deep(P1, 32, 32, 0, P1, None, P1, 1.0, c1, 1.0, 2, None, None, None, 1.0, None, 1.0, 0, 4, 64, *atail) == -1 \
+        and "incomplete shift network" in err()
+    assert L.bgk_coupling_affine_dense_deep(P1, 32, 32, 0, None, None, None, 1.0, None, 1.0, 0, None, None, None, 1.0, None, 1.0, 0, 1, 64, *atail) == -1 \
+        and "no conditioner network" in err()
+    assert L.bgk_coupling_affine_dense_deep(P1, 32, 32, 0, *nets, 4, 64, P1, 0, 1, 0, *atail[4:]) == -1 and "not compatible with periodicity" in err()
+    # one Linear layer on its own
+    assert L.bgk_dense_layer(None, 40, 0, 40, None, 4, 1.0, None, None, 70, 1, None, 70, 0, None) == 0
+    assert L.bgk_dense_layer(P1, 40, 8, 40, P1, 4, 1.0, None, None, 70, 4, P1, 70, 0, None) == -1 and "act 4" in err()
+    assert L.bgk_dense_layer(P1, 40, 8, 40, P1, 2, 1.0, None, None, 70, 1, P1, 70, 0, None) == -1 and "k-steps" in err()
+    assert L.bgk_dense_layer(P1, 300, 8, 300, P1, 16, 1.0, None, None, 70, 1, P1, 70, 0, None) == -1 and "at most 256" in err()
+    assert L.bgk_dense_layer(P1, 30, 8, 40, P1, 4, 1.0, None, None, 70, 1, P1, 70, 0, None) == -1
+    assert L.bgk_dense_layer(P1, 40, 8, 40, ctypes.c_void_p(0x1004), 4, 1.0, None, None, 70, 1, P1, 70, 0, None) == -1 and "16-byte aligned" in err()
+    assert L.bgk_pack_linear_layer(P1, 40, 70, 300, P1, P1, None) == -1 and "at most 256" in err()
+    assert L.bgk_pack_linear_layer(P1, 30, 70, 40, P1, P1, None) == -1
+    assert L.bgk_pack_linear_layer(P1, 40, 70, 40, None, P1, None) == -1
+
+
 def test_training_glue_host_semantics():
     """host side of the round-4 training glue, no GPU: row pitches, operand buffer sizes (T2 in whole groups of four k-steps, as the
     header documents), the deferred weight-gradient reductions are dropped when a backward pass raises, and nothing is re-packed
