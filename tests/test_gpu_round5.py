@@ -901,6 +901,8 @@ def test_deep_conditioner_other_bin_counts_bins_and_round_trip(hip_lib, dev, n_b
     np.testing.assert_allclose(y.cpu().numpy(), outs64[1], rtol=0, atol=2e-5)
     np.testing.assert_allclose(dl.cpu().numpy(), dl64, rtol=5e-5, atol=5e-5)
     np.testing.assert_allclose(back.cpu().numpy(), xs[1], rtol=0, atol=2e-5)
+    np.testing.assert_allclose((dl + dl_back).cpu().numpy(), 0.0, atol=1e-4)
+    assert float((y - y_ref).abs().max()) <= 4e-5
     assert float((bins != bins_ref).float().mean()) < 1e-3 and int((bins - bins_ref).abs().max()) <= 1
 
 
