@@ -757,8 +757,64 @@ def g_energies():
     save("g_energies", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# G-envelope: coupling layers whose conditioners sit at the wide / deep end of the one-launch kernels' envelope (round 5):
+# the reference's CouplingFlow around ConditionalSplineTransformer / AffineTransformer with DenseNets of other widths and depths
+# ---------------------------------------------------------------------------------------------
+ENVELOPE_SPLINE = {"w256": (256, 256), "w200_130": (200, 130), "deep1": (128,), "deep3": (128, 128, 128), "deep4": (64, 128, 32, 100)}
+ENVELOPE_AFFINE = {"readme4": (4,), "deep5": (48,) * 5, "deep4mixed": (128, 64, 32, 100)}
+
+
+def envelope_spline_layer(lib, hidden, periodic, circular, d_c=9, d=7, n_bins=8):
+    """``lib`` = bgflow (the reference) or bgflow_amd: the same constructor calls build the same module tree, hash_init_ gives it the
+    same weights"""
+    P = 3 * n_bins * d + (0 if circular else d)
+    net = lib.DenseNet([2 * d_c if periodic else d_c, *hidden, P], activation=torch.nn.SiLU())
+    if periodic:
+        net = lib.WrapPeriodic(net)
+    return hash_init_(lib.CouplingFlow(lib.ConditionalSplineTransformer(net, is_circular=circular), transformed_indices=(1,),
+                                       cond_indices=(0,)))
+
+
+def envelope_affine_layer(lib, hidden, d_c=12, d=20):
+    return hash_init_(lib.CouplingFlow(lib.AffineTransformer(lib.DenseNet([d_c, *hidden, d], activation=torch.nn.ReLU()),
+                                                             lib.DenseNet([d_c, *hidden, d], activation=torch.nn.Tanh())),
+                                       transformed_indices=(1,), cond_indices=(0,)))
+
+
+def g_envelope():
+    out = {}
+    B = 97
+    for tag, hidden in ENVELOPE_SPLINE.items():
+        for kind, (periodic, circular) in (("pc", (True, True)), ("nn", (False, False))):
+            layer = envelope_spline_layer(bg, hidden, periodic, circular)
+            c = rng_f32(61, B, 9, uniform=periodic)
+            y = rng_f32(62, B, 7, uniform=True)
+            for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+                f = layer.to(dt)
+                with torch.no_grad():
+                    _, z, dl = f(torch.tensor(c, dtype=dt), torch.tensor(y, dtype=dt))
+                    _, yb, dli = f(torch.tensor(c, dtype=dt), z, inverse=True)
+                out[f"s_{tag}_{kind}_z{sfx}"] = z.numpy(); out[f"s_{tag}_{kind}_dlogp{sfx}"] = dl.numpy()
+                out[f"s_{tag}_{kind}_back{sfx}"] = yb.numpy(); out[f"s_{tag}_{kind}_dlogp_inv{sfx}"] = dli.numpy()
+    for tag, hidden in ENVELOPE_AFFINE.items():
+        layer = envelope_affine_layer(bg, hidden)
+        c = rng_f32(63, B, 12)
+        y = rng_f32(64, B, 20)
+        for dt, sfx in ((torch.float32, "32"), (torch.float64, "64")):
+            f = layer.to(dt)
+            with torch.no_grad():
+                _, z, dl = f(torch.tensor(c, dtype=dt), torch.tensor(y, dtype=dt))
+                _, yb, dli = f(torch.tensor(c, dtype=dt), z, inverse=True)
+            out[f"a_{tag}_z{sfx}"] = z.numpy(); out[f"a_{tag}_dlogp{sfx}"] = dl.numpy()
+            out[f"a_{tag}_back{sfx}"] = yb.numpy(); out[f"a_{tag}_dlogp_inv{sfx}"] = dli.numpy()
+    save("g_envelope", **out)      # inputs: synth(61..64)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rqs", "bins", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2", "cdfflows", "energies"]
+    which = sys.argv[1:] or ["rqs", "bins", "affine", "ic", "flow16", "aug", "augment", "grads", "grads2", "cdfflows", "energies", "envelope"]
+    if "envelope" in which:
+        g_envelope()
     if "energies" in which:
         g_energies()
     if "rqs" in which:

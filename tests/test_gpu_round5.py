@@ -939,3 +939,42 @@ def test_affine_coupling_with_other_depths_runs_fused(hip_lib, dev, hidden, acts
     *_, dlg = layer(*xg, inverse=inverse)
     (dlg.sum() if with_scale else layer(*xg)[1].sum()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters() if p.requires_grad and p.grad is not None)
+
+
+def test_envelope_layers_vs_reference_goldens(hip_lib, golden, dev):
+    """the wide / deep one-launch kernels against outputs of the REFERENCE's CouplingFlow (tests/golden/g_envelope.npz, generated by
+    importing bgflow): spline layers with hidden (256, 256), (200, 130), one / three / four hidden layers (periodic + circular and
+    plain), affine layers with one / five / four hidden layers; both directions"""
+    import envelope_layers as el
+    G = golden("g_envelope")
+    t = lambda v: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=dev)                      # noqa: E731
+    for tag, hidden in el.SPLINE.items():
+        for kind, (periodic, circular) in el.KINDS.items():
+            c, y = el.spline_inputs(periodic)
+            layer = el.spline_layer(hidden, periodic, circular).to(dev)
+            key = f"s_{tag}_{kind}_"
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")                 # a rejection (RuntimeWarning) would mean the layer-by-layer path ran
+                with torch.no_grad():
+                    _, z, dl = layer(t(c), t(y))
+                    _, yb, dli = layer(t(c), t(G[key + "z64"]), inverse=True)
+            plan = layer.transformer._fused_cache
+            assert (plan.get("hidden") == 256) if tag.startswith("w") else (plan.get("deep") == len(hidden)), (tag, kind)
+            np.testing.assert_allclose(z.cpu().numpy(), G[key + "z64"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(dl.cpu().numpy(), G[key + "dlogp64"], rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(yb.cpu().numpy(), G[key + "back64"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(dli.cpu().numpy(), G[key + "dlogp_inv64"], rtol=2e-5, atol=2e-5)
+    for tag, hidden in el.AFFINE.items():
+        c, y = el.affine_inputs()
+        layer = el.affine_layer(hidden).to(dev)
+        key = f"a_{tag}_"
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            with torch.no_grad():
+                _, z, dl = layer(t(c), t(y))
+                _, yb, dli = layer(t(c), t(G[key + "z64"]), inverse=True)
+        assert layer.transformer._fused_cache.get("anydepth"), tag
+        np.testing.assert_allclose(z.cpu().numpy(), G[key + "z64"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dl.cpu().numpy(), G[key + "dlogp64"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(yb.cpu().numpy(), G[key + "back64"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dli.cpu().numpy(), G[key + "dlogp_inv64"], rtol=2e-5, atol=2e-5)

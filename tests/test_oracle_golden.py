@@ -235,6 +235,38 @@ def test_readme_and_affine8_flows(golden):
         np.testing.assert_allclose(dli, G["dlogp_inv" + sfx], rtol=rt, atol=at)
 
 
+def test_envelope_layers_through_the_oracle_vs_reference(golden):
+    """coupling layers with wide / deep conditioners (g_envelope: hidden (256, 256), (200, 130), one / three / four hidden layers; affine
+    networks with one / five / four hidden layers) through the oracle walker against the reference's outputs, f64 to rounding and f32
+    to f32 noise, both directions"""
+    import envelope_layers as el
+    from oracle import flow_oracle as fo
+    G = golden("g_envelope")
+    for tag, hidden in el.SPLINE.items():
+        for kind, (periodic, circular) in el.KINDS.items():
+            c, y = el.spline_inputs(periodic)
+            layer = el.spline_layer(hidden, periodic, circular)
+            key = f"s_{tag}_{kind}_"
+            for dt, sfx, at in ((np.float64, "64", 1e-11), (np.float32, "32", 2e-5)):
+                (_, z), dl = fo.run_block(layer, [c.astype(dt), y.astype(dt)], False, dt, [])
+                np.testing.assert_allclose(z, G[key + "z" + sfx], rtol=0, atol=at)
+                np.testing.assert_allclose(dl, G[key + "dlogp" + sfx], rtol=at, atol=at * 10)
+                (_, yb), dli = fo.run_block(layer, [c.astype(dt), G[key + "z" + sfx]], True, dt, [])
+                np.testing.assert_allclose(yb, G[key + "back" + sfx], rtol=0, atol=at)
+                np.testing.assert_allclose(dli, G[key + "dlogp_inv" + sfx], rtol=at, atol=at * 10)
+    for tag, hidden in el.AFFINE.items():
+        c, y = el.affine_inputs()
+        layer = el.affine_layer(hidden)
+        key = f"a_{tag}_"
+        for dt, sfx, at in ((np.float64, "64", 1e-11), (np.float32, "32", 2e-5)):
+            (_, z), dl = fo.run_block(layer, [c.astype(dt), y.astype(dt)], False, dt, [])
+            np.testing.assert_allclose(z, G[key + "z" + sfx], rtol=at, atol=at)
+            np.testing.assert_allclose(dl, G[key + "dlogp" + sfx], rtol=at, atol=at)
+            (_, yb), dli = fo.run_block(layer, [c.astype(dt), G[key + "z" + sfx]], True, dt, [])
+            np.testing.assert_allclose(yb, G[key + "back" + sfx], rtol=at, atol=at)
+            np.testing.assert_allclose(dli, G[key + "dlogp_inv" + sfx], rtol=at, atol=at)
+
+
 def test_flow16_whole_flow(golden):
     """cfg 3: 16 spline couplings + domain maps + mixed IC, oracle walker vs the reference builder flow"""
     import torch
