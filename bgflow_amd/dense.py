@@ -137,6 +137,9 @@ def _layer_operands(lin):
 
 def dense_layer(x, lin, act=0):
     """y = act(x W^T + b) of a Linear module on bgk_dense_layer (x: f32 HIP tensor [..., n_in]; act: 0 none, 1 SiLU, 2 ReLU, 3 Tanh)"""
+    if x.dim() < 1 or x.shape[-1] != lin.in_features:
+        raise RuntimeError(f"dense_layer: input of shape {tuple(x.shape)} for a Linear layer with {lin.in_features} input features "
+                           f"(mat1 and mat2 shapes cannot be multiplied)")
     _lib.require_hip(x)
     lead = x.shape[:-1]
     x2, ldx = _lib.rowmajor(x.reshape(-1, x.shape[-1]))

@@ -718,6 +718,24 @@ def test_c_abi_argument_validation_of_the_wide_envelope_entry_points(hip_lib):
     assert L.bgk_pack_linear_layer(P1, 40, 70, 40, None, P1, None) == -1
 
 
+def test_dense_layer_dispatch_host_semantics():
+    """host side of the layer kernel's dispatch, no GPU: CPU tensors and non-f32 inputs keep torch's own Linear (DenseNet on the host is
+    the reference's arithmetic), a wrong input width raises like torch.nn.Linear does instead of reading past the row"""
+    import bgflow_amd as bg
+    from bgflow_amd import dense
+    net = bg.DenseNet([5, 8, 3], activation=torch.nn.Tanh())
+    x = torch.randn(7, 5)
+    lin0, act, lin1 = net._layers
+    assert not dense._on_layer_kernel(lin0, x) and not dense._on_layer_kernel(lin0, x.double())
+    with torch.no_grad():
+        assert torch.equal(net(x), lin1(act(lin0(x))))
+    with pytest.raises(RuntimeError, match="5 input features"):
+        dense.dense_layer(torch.randn(7, 6), lin0)
+    with pytest.raises(RuntimeError):
+        dense.dense_layer(x, lin0)                       # right shape, but not a HIP tensor: no CPU path
+    assert dense._LAYER_ACTS[torch.nn.SiLU] == 1 and dense._LAYER_ACTS[torch.nn.ReLU] == 2 and dense._LAYER_ACTS[torch.nn.Tanh] == 3
+
+
 def test_training_glue_host_semantics():
     """host side of the round-4 training glue, no GPU: row pitches, operand buffer sizes (T2 in whole groups of four k-steps, as the
     header documents), the deferred weight-gradient reductions are dropped when a backward pass raises, and nothing is re-packed
