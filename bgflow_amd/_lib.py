@@ -28,7 +28,18 @@ _SIGNATURES = {
     "bgk_affine_transform": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i64, i32,
                                             vp, i64, vp, i32, vp]),
     "bgk_affine_backward": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, i64, i32,
-                                           vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp]),
+                                           vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp]),
+    "bgk_coupling_affine_dense_h2_train": (ctypes.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32,
+                                                          vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32,
+                                                          vp, vp, vp, vp, vp, vp, i64, vp]),
+    "bgk_pack_mlp_h2": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "bgk_pack_mlp_h2_many": (ctypes.c_int, [i32] + [vp] * 17 + [vp]),
+    "bgk_pack_mlp_h2_t": (ctypes.c_int, [vp, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
+    "bgk_pack_mlp_h2_t_many": (ctypes.c_int, [i32] + [vp] * 11 + [vp]),
+    "bgk_mlp_weight_grad_workspace": (i64, [i64, i32, i32, i32, i32]),
+    "bgk_mlp_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, vp, i64, i32, i32, i32, vp, i64, i32, i32, i64, vp, i64,
+                                           vp, vp, vp, vp, vp, vp, i32, vp, vp]),
+    "bgk_mlp_weight_grad_reduce_many": (ctypes.c_int, [i32] + [vp] * 12 + [i32, vp]),
     "bgk_ic_xyz2ic": (ctypes.c_int, [vp, i64, vp, i32, vp, i32, i32, f32, i32, vp, vp, i32, f32, i64,
                                      vp, vp, vp, i64, vp, i64, vp, i32, vp, vp]),
     "bgk_ic_ic2xyz": (ctypes.c_int, [vp, vp, vp, i64, vp, i64, vp, i32, vp, i32, i32, f32, i32,

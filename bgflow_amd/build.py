@@ -27,13 +27,13 @@ HIPCC_FLAGS = [
 # per-TU additions.  bgk_fused2.hip threads VALU work between MFMAs: packed-f32 ops (which the SLP vectoriser
 # would form from adjacent scalar ops) do not overlap with the matrix pipe on gfx950 (tools/ubench/issue_bench).
 TU_FLAGS = {"bgk_fused2.hip": ["-fno-slp-vectorize"], "bgk_fused2_train.hip": ["-fno-slp-vectorize"],
-            "bgk_fused2_bf16.hip": ["-fno-slp-vectorize"],
+            "bgk_fused2_bf16.hip": ["-fno-slp-vectorize"], "bgk_fused2_afftrain.hip": ["-fno-slp-vectorize"],
             # bgk_tail.hip: the SLP vectoriser packs the 3-vector arithmetic of a placement into v_pk_* pairs and pays for it with
             # register shuffles around the uniformly indexed position arrays (39 instead of 15 v_mov per placement)
             "bgk_tail.hip": ["-fno-slp-vectorize"]}
 
 
-INCLUDES_SOURCE = {"bgk_fused2_train.hip": ["bgk_fused2.hip"], "bgk_fused2_bf16.hip": ["bgk_fused2.hip"]}     # translation units that #include another .hip
+INCLUDES_SOURCE = {"bgk_fused2_train.hip": ["bgk_fused2.hip"], "bgk_fused2_bf16.hip": ["bgk_fused2.hip"], "bgk_fused2_afftrain.hip": ["bgk_fused2.hip"]}     # translation units that #include another .hip
 
 
 HEADER = os.path.join(HERE, "..", "include", "bgflow_amd.h")

@@ -513,13 +513,14 @@ __global__ __launch_bounds__(256) void pack_t_many_kernel(PackTMany) {
 
 }  // namespace
 
+/* H0 / H1: hidden widths of the source weights (W0 [H0, n_in], W1 [H1, H0], W2 [P, H1]); units past them are zero in the operands */
 static int pack_t_fill(PackTGroup& g, const float* W0, int n_in, const float* W1, const float* W2, int P, void* T0, void* T1,
-                       void* T2) {
+                       void* T2, int H0 = 128, int H1 = 128) {
     const int FT = (n_in + 31) / 32;
     const int S2 = ((P + 15) / 16 + DBWD_PAD - 1) / DBWD_PAD * DBWD_PAD;
-    const PackT L2{W2, P, 128, 4, S2, 1, (_Float16*)T2};   /* M[hidden i][k] = W2[col(k)][i], col = output column of the MLP */
-    const PackT L1{W1, 128, 128, 4, 8, 0, (_Float16*)T1};      /* M[i][k] = W1[unit(k)][i] */
-    const PackT L0{W0, 128, n_in, FT, 8, 0, (_Float16*)T0};    /* M[feature i][k] = W0[unit(k)][i] */
+    const PackT L2{W2, P, H1, 4, S2, 1, (_Float16*)T2};   /* M[hidden i][k] = W2[col(k)][i], col = output column of the MLP */
+    const PackT L1{W1, H1, H0, 4, 8, 0, (_Float16*)T1};      /* M[i][k] = W1[unit(k)][i] */
+    const PackT L0{W0, H0, n_in, FT, 8, 0, (_Float16*)T0};    /* M[feature i][k] = W0[unit(k)][i] */
     g.L[0] = L0; g.L[1] = L1; g.L[2] = L2;
     int n_wg = 0;
     for (int l = 0; l < 3; ++l) {
@@ -532,18 +533,19 @@ static int pack_t_fill(PackTGroup& g, const float* W0, int n_in, const float* W1
 }
 
 static int pack_t_launch(const float* W0, int n_in, const float* W1, const float* W2, int P, const float* cs, void* T0, void* T1,
-                         void* T2, hipStream_t st) {
+                         void* T2, hipStream_t st, int H0 = 128, int H1 = 128) {
     PackTGroup g;
-    const int n_wg = pack_t_fill(g, W0, n_in, W1, W2, P, T0, T1, T2);
+    const int n_wg = pack_t_fill(g, W0, n_in, W1, W2, P, T0, T1, T2, H0, H1);
     hipLaunchKernelGGL(pack_t_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, g, cs);
     return 0;
 }
 
-/* bgk_pack_dense_h2_t of n conditioners in one launch per 16 (after an optimizer step: every coupling layer of the flow) */
-extern "C" int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_in, const float* const* W1,
-                                        const float* const* W2, const int32_t* P, const float* const* cs,
-                                        void* const* T0, void* const* T1, void* const* T2, void* stream) {
-    BGK_CHECK_ARG(n >= 0 && W0 && n_in && W1 && W2 && P && cs && T0 && T1 && T2, "bgk_pack_dense_h2_t_many: null pointer");
+/* bgk_pack_mlp_h2_t of n conditioners in one launch per 16 (after an optimizer step: every coupling layer of the flow); H0 / H1 may be
+ * NULL: 128 hidden units everywhere (= bgk_pack_dense_h2_t_many) */
+extern "C" int bgk_pack_mlp_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_in, const int32_t* H0, const float* const* W1,
+                                      const int32_t* H1, const float* const* W2, const int32_t* P, const float* const* cs,
+                                      void* const* T0, void* const* T1, void* const* T2, void* stream) {
+    BGK_CHECK_ARG(n >= 0 && W0 && n_in && W1 && W2 && P && cs && T0 && T1 && T2, "bgk_pack_mlp_h2_t_many: null pointer");
     if (n == 0) return 0;       /* nothing to do (and no launch status to ask a GPU-less box for) */
     for (int base = 0; base < n; base += PACKT_MANY) {
         const int cnt = n - base < PACKT_MANY ? n - base : PACKT_MANY;
@@ -551,16 +553,23 @@ extern "C" int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const
         int max_wg = 0;
         for (int c = 0; c < cnt; ++c) {
             const int i = base + c;
-            BGK_CHECK_ARG(W0[i] && W1[i] && W2[i] && cs[i] && T0[i] && T1[i] && T2[i] && n_in[i] > 0 && n_in[i] <= 96 && P[i] > 0,
-                          "bgk_pack_dense_h2_t_many: bad conditioner %d", i);
-            const int n_wg = pack_t_fill(M.c[c].g, W0[i], n_in[i], W1[i], W2[i], P[i], T0[i], T1[i], T2[i]);
+            const int h0 = H0 ? H0[i] : 128, h1 = H1 ? H1[i] : 128;
+            BGK_CHECK_ARG(W0[i] && W1[i] && W2[i] && cs[i] && T0[i] && T1[i] && T2[i] && n_in[i] > 0 && n_in[i] <= 96 && P[i] > 0
+                          && h0 > 0 && h0 <= 128 && h1 > 0 && h1 <= 128, "bgk_pack_mlp_h2_t_many: bad conditioner %d", i);
+            const int n_wg = pack_t_fill(M.c[c].g, W0[i], n_in[i], W1[i], W2[i], P[i], T0[i], T1[i], T2[i], h0, h1);
             M.c[c].cs = cs[i];
             max_wg = n_wg > max_wg ? n_wg : max_wg;
         }
         for (int c = cnt; c < PACKT_MANY; ++c) M.c[c] = M.c[0];
         hipLaunchKernelGGL(pack_t_many_kernel, dim3((unsigned)max_wg, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream, M);
     }
-    return bgk_launch_status("bgk_pack_dense_h2_t_many");
+    return bgk_launch_status("bgk_pack_mlp_h2_t_many");
+}
+
+extern "C" int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_in, const float* const* W1,
+                                        const float* const* W2, const int32_t* P, const float* const* cs,
+                                        void* const* T0, void* const* T1, void* const* T2, void* stream) {
+    return bgk_pack_mlp_h2_t_many(n, W0, n_in, nullptr, W1, nullptr, W2, P, cs, T0, T1, T2, stream);
 }
 
 extern "C" int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
@@ -569,6 +578,15 @@ extern "C" int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W
     BGK_CHECK_ARG(n_in > 0 && n_in <= 96 && P > 0, "bgk_pack_dense_h2_t: bad sizes (n_in <= 96)");
     pack_t_launch(W0, n_in, W1, W2, P, cs, T0, T1, T2, (hipStream_t)stream);
     return bgk_launch_status("bgk_pack_dense_h2_t");
+}
+
+/* bgk_pack_dense_h2_t for hidden layers of H0 / H1 <= 128 units (the backward kernels run 128: the operands' other units are zero) */
+extern "C" int bgk_pack_mlp_h2_t(const float* W0, int32_t n_in, int32_t H0, const float* W1, int32_t H1, const float* W2, int32_t P,
+                                 const float* cs, void* T0, void* T1, void* T2, void* stream) {
+    BGK_CHECK_ARG(W0 && W1 && W2 && cs && T0 && T1 && T2, "bgk_pack_mlp_h2_t: null pointer");
+    BGK_CHECK_ARG(n_in > 0 && n_in <= 96 && P > 0 && H0 > 0 && H0 <= 128 && H1 > 0 && H1 <= 128, "bgk_pack_mlp_h2_t: bad sizes (n_in <= 96, H <= 128)");
+    pack_t_launch(W0, n_in, W1, W2, P, cs, T0, T1, T2, (hipStream_t)stream, H0, H1);
+    return bgk_launch_status("bgk_pack_mlp_h2_t");
 }
 
 extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,

@@ -53,6 +53,17 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
                                const float* y, int64_t ldy, int64_t B, int32_t d,
                                float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream, const BgkCondSegs* segs = nullptr);
 
+/* the training forward of the affine layer (bgk_fused2_afftrain.hip): the same kernel (two hidden layers) + what the backward reads --
+ * per network the scaled pre-activations z0, z1 [B, 128] and its output rows (mu; the scale values before tanh) [B, ldms];
+ * s_cs / t_cs: device scale tables of the packed operands (NULL: the c values of the call) */
+struct BgkAffTrainSave { const float* s_cs; float* s_z0; float* s_z1; const float* t_cs; float* t_z0; float* t_z1; float* mu; float* s_raw; int64_t ldms; };
+int bgk_launch_affine_dense_v2_train(const BgkAffTrainSave* save, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                               const void* sA0, const void* sA1, const void* sA1b, const void* sA2, float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
+                               const void* tA0, const void* tA1, const void* tA1b, const void* tA2, float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
+                               const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
+                               const float* y, int64_t ldy, int64_t B, int32_t d,
+                               float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream, const BgkCondSegs* segs = nullptr);
+
 /* 2 (default): coupling_rqs_dense_h2v2_kernel for the split-f16 path (inference and training forward); 1: the first-generation kernel */
 extern int bgk_h2_variant;
 /* 2 (default): bgk_coupling_rqs_dense_h2_backward evaluates the element VJP's softmax / knots on the hardware exp2 / rcp forms (like the

@@ -46,6 +46,13 @@
 #define coupling_rqs_dense_h2v2_kernel coupling_rqs_dense_h2v2_bf16_kernel
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #endif
+#ifndef BGK_V2_AFFTRAIN
+#define BGK_V2_AFFTRAIN 0            /* 1 (bgk_fused2_afftrain.hip): the training forward of the AFFINE coupling layer -- coupling_affine_dense_v2_kernel also
+                                      * writes the scaled pre-activations of both networks and their outputs (mu, the pre-tanh scale values) */
+#endif
+#if BGK_V2_AFFTRAIN
+#define coupling_affine_dense_v2_kernel coupling_affine_dense_v2_train_kernel
+#endif
 constexpr int NPROD = BGK_V2_BF16 ? 1 : 3;      /* matrix instructions per (k-step, tile) */
 
 namespace {
@@ -1243,7 +1250,12 @@ bool make_cond_segs(CondSegs& cs, const float* cond, int64_t ldc, int d_c, const
  * ([dim][sample], in the conditioner tile's place) while the scale network runs on the same registers; y and the result pass
  * through a [dim][sample] LDS tile, so that global rows are read and written coalesced (one row-strided 4-byte access per lane and
  * dim costs 64 cache-line requests per instruction). */
-struct AffV2Net { const uint4* A0; const uint4* A1; const uint4* A1b; const uint4* A2; float c0, c1, c1b, c2; };   /* A1b: third hidden layer or NULL */
+struct AffV2Net { const uint4* A0; const uint4* A1; const uint4* A1b; const uint4* A2; float c0, c1, c1b, c2;    /* A1b: third hidden layer or NULL */
+#if BGK_V2_AFFTRAIN
+                  const float* cs;      /* device scale table {2^s, 2^-s} x 3 of bgk_pack_mlp_h2 (NULL: c0 .. c2 as given) */
+                  float* z0; float* z1; /* the scaled pre-activations of the two hidden layers [B, 128], written for the backward */
+#endif
+};
 struct AffV2Args {
     CondSegs cs; int d_c; int periodic; int S0;
     AffV2Net shift, scale; int has_shift, has_scale;
@@ -1253,7 +1265,46 @@ struct AffV2Args {
     uint32_t magic_d;
     int lds_tile, lds_per_wave;  /* floats: conditioner / shift tile, whole wave slice (+ y / out tile) */
     int nfs, ys, stage, y_dma, out_lin;   /* the tile images (see StageTiles) */
+#if BGK_V2_AFFTRAIN
+    float* mu_out; float* s_out; int64_t ldms;     /* the networks' outputs [B, ldms] (ldms = 32 OT): shift values, scale values before tanh */
+    int slab;                                      /* float offset of the 16-row store slab [16][32] inside the wave's conditioner-tile slice */
+#endif
 };
+
+#if BGK_V2_AFFTRAIN
+/* NT tiles held in accumulator layout -> dst[b0 + r][32 m ..] as complete 128-byte lines: half a tile (16 rows) at a time through a
+ * wave-private LDS slab [16][32] whose 16-byte pieces are XOR-swizzled by the row; every store instruction covers 8 rows x 128 B.
+ * (The direct form -- 16-byte pieces of 32 rows per instruction -- costs 1.6 x the write traffic, bgk_mfma_h2.h.)  Stores go through a
+ * buffer descriptor of the tile's rows: rows past the batch are out of range, no store is conditional (the in-order memory counter
+ * stays exact for the operand loads around them). */
+template <int NT>
+__device__ __forceinline__ void aff_store_tiles(const f32x16 (&t)[4], float* dst, int pitch, float* slab, int64_t b0, int rows, int lane) {
+    const int j = lane & 31, hh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + b0 * pitch), 0, rows * pitch * 4, 0x00020000);
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((j >> 4) == half) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(slab + (j & 15) * 32 + 4 * ((2 * q + hh) ^ (j & 7))) =
+                        make_float4(t[m][4 * q], t[m][4 * q + 1], t[m][4 * q + 2], t[m][4 * q + 3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int i = it * 64 + lane, r = i >> 3, p = i & 7;
+                const float4 v = *reinterpret_cast<const float4*>(slab + r * 32 + 4 * (p ^ (r & 7)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((16 * half + r) * pitch + 32 * m + 4 * p) * 4, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+}
+struct AffSave { float* slab; int64_t b0; int rows, lane; };
+#endif
 
 /* layer 0: X = A0' * [features; 1] (l0_step); the A fragments of k-step s + 1 are requested before the MFMAs of k-step s (two fragment
  * sets, loop unrolled by two).  requested: `fa` already holds (or has in flight) the fragments of k-step 0. */
@@ -1278,11 +1329,20 @@ __device__ __forceinline__ void aff_layer0(const AffV2Net& n, int S0, const floa
 }
 
 /* one H x H layer: Y = A' * act(c X) + b', its events threaded through the activation of X's tiles 1..3 */
+#if BGK_V2_AFFTRAIN
+#define AFF_SAVE_PARAMS , float* zdst, const AffSave& sv
+#define AFF_SAVE_Z(X) do { _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) X[m_][r_] *= c; \
+                           aff_store_tiles<4>(X, zdst, 128, sv.slab, sv.b0, sv.rows, sv.lane); c = 1.0f; } while (0)
+#else
+#define AFF_SAVE_PARAMS
+#define AFF_SAVE_Z(X) do { } while (0)
+#endif
 template <int ACT>
-__device__ __forceinline__ void aff_hidden(const uint4* A, float c, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff) {
+__device__ __forceinline__ void aff_hidden(const uint4* A, float c, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff AFF_SAVE_PARAMS) {
     NoLive none;
     Live<4> g{Y, bf, A, voff, ring};
     g.start();
+    AFF_SAVE_Z(X);       /* (training: behind the ring start -- the first MFMAs wait for their operand loads, not for these stores) */
     act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, X[0], c, bf);
     __builtin_amdgcn_sched_barrier(0);
     act_split_tile<ACT, 1>(Hooks<Live<4>, 0, 100>{g}, X[1], c, bf);       /* hook i = event i (100 events) */
@@ -1293,11 +1353,12 @@ __device__ __forceinline__ void aff_hidden(const uint4* A, float c, f32x16 (&X)[
 }
 /* the output layer: Y[0 .. OT) = A2' * act(c X) + b2' (unscaled), OT tiles per k-step */
 template <int ACT, int OT>
-__device__ __forceinline__ void aff_output(const uint4* A, float c, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff) {
+__device__ __forceinline__ void aff_output(const uint4* A, float c, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff AFF_SAVE_PARAMS) {
     NoLive none;
     typedef Live<OT, OT> GO;                                                   /* 25 OT events: 6 OT per activated tile */
     GO g{Y, bf, A, voff, ring};
     g.start();
+    AFF_SAVE_Z(X);
     act_split_tile<ACT, 0>(Hooks<NoLive, 0, 1>{none}, X[0], c, bf);
     __builtin_amdgcn_sched_barrier(0);
     act_split_tile<ACT, 1>(Hooks<GO, 0, 100>{g}, X[1], c, bf);
@@ -1307,6 +1368,14 @@ __device__ __forceinline__ void aff_output(const uint4* A, float c, f32x16 (&X)[
     g.template events<(72 * GO::NEV) / 100, GO::NEV>();
 }
 /* the layers behind layer 0.  Two hidden layers: X -> Y -> X[0 .. OT);  three (DEEP): X -> Y -> X -> Y[0 .. OT) */
+#if BGK_V2_AFFTRAIN
+template <int ACT, int OT, bool DEEP>
+__device__ __forceinline__ void aff_layers(const AffV2Net& n, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff, const AffSave& sv) {
+    static_assert(!DEEP, "the training forward takes two hidden layers");
+    aff_hidden<ACT>(n.A1, n.c0, X, Y, bf, ring, voff, n.z0, sv);
+    aff_output<ACT, OT>(n.A2, n.c1, Y, X, bf, ring, voff, n.z1, sv);
+}
+#else
 template <int ACT, int OT, bool DEEP>
 __device__ __forceinline__ void aff_layers(const AffV2Net& n, f32x16 (&X)[4], f32x16 (&Y)[4], BFrag& bf, TFrag (&ring)[RD], unsigned voff) {
     aff_hidden<ACT>(n.A1, n.c0, X, Y, bf, ring, voff);
@@ -1317,6 +1386,7 @@ __device__ __forceinline__ void aff_layers(const AffV2Net& n, f32x16 (&X)[4], f3
         aff_output<ACT, OT>(n.A2, n.c1, Y, X, bf, ring, voff);
     }
 }
+#endif
 
 /* tanh for the OUTPUT layer (log sigma): hardware exp2 + Newton-refined rcp above 0.625 (abs error ~1e-7), odd polynomial below
  * (the form of the other fused affine kernels, bgk_fused_affine.hip::r_tanh_out) */
@@ -1338,6 +1408,10 @@ template <int ACT_S, int ACT_T, int OT, bool DEEP>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(AffV2Args a) {
 #if BGK_V2_OVFL
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");                 /* MODE.FP16_OVFL (act_split_pair carries no clamps) */
+#endif
+#if BGK_V2_AFFTRAIN
+    if (a.shift.cs) { a.shift.c0 = a.shift.cs[1]; a.shift.c1 = a.shift.cs[3]; a.shift.c2 = a.shift.cs[5]; }    /* wave-uniform scalar loads */
+    if (a.scale.cs) { a.scale.c0 = a.scale.cs[1]; a.scale.c1 = a.scale.cs[3]; a.scale.c2 = a.scale.cs[5]; }
 #endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = threadIdx.x >> 6;
@@ -1372,6 +1446,22 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
     /* ---- shift network: result (unscaled) in mu = h[0 .. OT) (three hidden layers: acc[0 .. OT)) ---- */
     f32x16 (&mu)[4] = DEEP ? acc : h;
     f32x16 (&t0)[4] = DEEP ? h : acc;          /* the scale network's layer-0 output: the array that does not hold mu */
+#if BGK_V2_AFFTRAIN
+    const AffSave sv{s_p + a.slab, b0, rows, lane};
+    if (a.has_shift) {
+        aff_layer0(a.shift, a.S0, s_p, nfs, n_in, lane, j, hh, h, fa, true);
+        aff_layers<ACT_S, OT, DEEP>(a.shift, h, acc, bf, ring, voff, sv);
+        /* the shift values leave for the backward (the scale network's first fragments are requested in front of the stores) */
+        if (a.has_scale) l0_request(fa, a.scale.A0, 0, lane);
+#pragma unroll
+        for (int m = 0; m < OT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mu[m][r] *= a.shift.c2;
+        aff_store_tiles<OT>(mu, a.mu_out, (int)a.ldms, sv.slab, b0, rows, lane);
+        a.shift.c2 = 1.0f;
+    }
+    if (a.has_scale) aff_layer0(a.scale, a.S0, s_p, nfs, n_in, lane, j, hh, t0, fa, true);
+#else
     if (a.has_shift) {
         aff_layer0(a.shift, a.S0, s_p, nfs, n_in, lane, j, hh, h, fa, true);
         aff_layers<ACT_S, OT, DEEP>(a.shift, h, acc, bf, ring, voff);
@@ -1379,6 +1469,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
     /* ---- scale network: layer 0 while the other array still holds the shift values; then they are parked in the (now free) tile.
      * (Its first fragments requested any earlier stay live across the GEMMs above: spills.) ---- */
     if (a.has_scale) aff_layer0(a.scale, a.S0, s_p, nfs, n_in, lane, j, hh, t0, fa, !a.has_shift);
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (a.has_shift) {
@@ -1390,7 +1481,20 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
                 if (dim < d) s_p[dim * SROW + j] = mu[m][r] * a.shift.c2;
             }
     }
+#if BGK_V2_AFFTRAIN
+    if (a.has_scale) {
+        aff_layers<ACT_T, OT, DEEP>(a.scale, t0, mu, bf, ring, voff, sv);
+        /* the scale values before tanh (what bgk_affine_backward differentiates) */
+#pragma unroll
+        for (int m = 0; m < OT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] *= a.scale.c2;
+        aff_store_tiles<OT>(acc, a.s_out, (int)a.ldms, sv.slab, b0, rows, lane);
+        a.scale.c2 = 1.0f;
+    }
+#else
     if (a.has_scale) aff_layers<ACT_T, OT, DEEP>(a.scale, t0, mu, bf, ring, voff);       /* result in acc[0 .. OT) either way */
+#endif
 
     /* ---- affine tail (affine.py:41-70): lane (j, hh) owns sample j, dims drow(m, r, hh) ---- */
     const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
@@ -1708,7 +1812,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_rqs_bwd_recompute_kernel
 
 }  // namespace
 
-#if !BGK_V2_SAVE && !BGK_V2_BF16
+#if !BGK_V2_SAVE && !BGK_V2_BF16 && !BGK_V2_AFFTRAIN
 int bgk_h2_variant = 2;
 #endif
 
@@ -1745,6 +1849,7 @@ int bgk_launch_rqs_bwd_recompute(const char* what, const float* z1, const void* 
 }
 #endif
 
+#if !BGK_V2_AFFTRAIN      /* (the affine training unit holds the affine kernel only) */
 #if BGK_V2_SAVE
 int bgk_launch_rqs_dense_h2v2_train(const char* what, float* z0, float* z1, float* params, int64_t ldp, const int32_t* src_col,
                                     const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
@@ -1804,26 +1909,49 @@ int bgk_launch_rqs_dense_h2v2(const char* what, const float* cond, int64_t ldc, 
 #undef BGK_LAUNCH
     return bgk_launch_status(what);
 }
+#endif   /* !BGK_V2_AFFTRAIN */
 
 #if !BGK_V2_SAVE && !BGK_V2_BF16
 /* hidden width 128, two or three hidden layers; activations (shift, scale): both SiLU, both ReLU, both Tanh, or ReLU / Tanh.
  * Returns BGK_EUNSUPPORTED (no error text) for any other combination: bgk_fused_affine.hip::affine_dense_launch then runs its
  * streaming kernel. */
+#if BGK_V2_AFFTRAIN
+int bgk_launch_affine_dense_v2_train(const BgkAffTrainSave* save,
+                               const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+#else
 int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+#endif
                                const void* sA0, const void* sA1, const void* sA1b, const void* sA2, float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
                                const void* tA0, const void* tA1, const void* tA1b, const void* tA2, float tc0, float tc1, float tc1b, float tc2, int32_t t_act,
                                const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                                const float* y, int64_t ldy, int64_t B, int32_t d,
                                float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream, const BgkCondSegs* segs) {
+#if BGK_V2_AFFTRAIN
+    const char* what = "bgk_coupling_affine_dense_h2_train";
+#else
     const char* what = "bgk_coupling_affine_dense_h2";
+#endif
     AffV2Args a;
     const int n_in = periodic ? 2 * d_c : d_c;
     BGK_CHECK_ARG(make_cond_segs(a.cs, cond, ldc, d_c, segs), "%s: bad conditioning segments", what);
     a.d_c = d_c; a.periodic = periodic; a.S0 = (n_in + 1 + 15) / 16;
+#if BGK_V2_AFFTRAIN
+    a.shift = AffV2Net{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA1b, (const uint4*)sA2, sc0, sc1, sc1b, sc2, save->s_cs, save->s_z0, save->s_z1};
+    a.scale = AffV2Net{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA1b, (const uint4*)tA2, tc0, tc1, tc1b, tc2, save->t_cs, save->t_z0, save->t_z1};
+    a.mu_out = save->mu; a.s_out = save->s_raw; a.ldms = save->ldms;
+#else
     a.shift = AffV2Net{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA1b, (const uint4*)sA2, sc0, sc1, sc1b, sc2};
     a.scale = AffV2Net{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA1b, (const uint4*)tA2, tc0, tc1, tc1b, tc2};
+#endif
     a.has_shift = sA0 != nullptr; a.has_scale = tA0 != nullptr;
     const bool deep = a.has_shift ? sA1b != nullptr : tA1b != nullptr;
+#if BGK_V2_AFFTRAIN
+    if (deep) return BGK_EUNSUPPORTED;
+    BGK_CHECK_ARG((!a.has_shift || (save->s_z0 && save->s_z1 && save->mu)) && (!a.has_scale || (save->t_z0 && save->t_z1 && save->s_raw)),
+                  "%s: null save buffer", what);
+    BGK_CHECK_ARG(save->ldms >= 32 * ((d + 31) / 32) && save->ldms % 4 == 0 && save->ldms < (1 << 20), "%s: ldms = %lld (a multiple of 4, >= 32 ceil(d / 32))",
+                  what, (long long)save->ldms);
+#endif
     if (a.has_shift && a.has_scale && (sA1b != nullptr) != (tA1b != nullptr)) return BGK_EUNSUPPORTED;
     const int as = a.has_shift ? s_act : t_act, at = a.has_scale ? t_act : s_act;
     if (!((as == at && as >= 1 && as <= 3) || (as == 2 && at == 3))) return BGK_EUNSUPPORTED;
@@ -1835,6 +1963,10 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
     a.nfs = tp.nfs; a.ys = tp.ys; a.stage = tp.stage; a.y_dma = tp.y_dma; a.out_lin = tp.out_lin;
     const int tile_f = 32 * a.nfs + (a.stage == 2 ? 32 * d_c : 0) + 16, park_f = d * SROW;
     a.lds_tile = (((tile_f > park_f ? tile_f : park_f) + 3) / 4) * 4;
+#if BGK_V2_AFFTRAIN
+    a.slab = a.lds_tile;             /* behind the conditioner tile AND the parked shift values: both are live while some network's z leaves */
+    a.lds_tile += 16 * 32;
+#endif
     a.lds_per_wave = a.lds_tile + ((32 * a.ys + 3) / 4) * 4;
     const size_t shmem = sizeof(float) * (size_t)FW * a.lds_per_wave;
     const int64_t n_wg = ((B + 31) / 32 + FW - 1) / FW;
@@ -1849,7 +1981,11 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
 #define BGK_LAUNCH(S, T, O, D) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(coupling_affine_dense_v2_kernel<S, T, O, D>), \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                                     hipLaunchKernelGGL((coupling_affine_dense_v2_kernel<S, T, O, D>), dim3((int)n_wg), dim3(FTHREADS), shmem, st, a); } while (0)
+#if BGK_V2_AFFTRAIN
+#define BGK_LAUNCH_D(S, T, O) BGK_LAUNCH(S, T, O, false)
+#else
 #define BGK_LAUNCH_D(S, T, O) do { if (deep) BGK_LAUNCH(S, T, O, true); else BGK_LAUNCH(S, T, O, false); } while (0)
+#endif
 #define BGK_LAUNCH_O(S, T) do { if (OT == 1) BGK_LAUNCH_D(S, T, 1); else if (OT == 2) BGK_LAUNCH_D(S, T, 2); else BGK_LAUNCH_D(S, T, 3); } while (0)
     if (as == 1) BGK_LAUNCH_O(1, 1); else if (as == 3) BGK_LAUNCH_O(3, 3); else if (at == 2) BGK_LAUNCH_O(2, 2); else BGK_LAUNCH_O(2, 3);
 #undef BGK_LAUNCH_D

@@ -206,12 +206,37 @@ extern "C" int bgk_pack_dense_h2(const float* W0, const float* b0, int32_t n_in,
     return bgk_launch_status("bgk_pack_dense_h2");
 }
 
-extern "C" int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const* b0, const int32_t* n_in,
-                                      const float* const* W1, const float* const* b1, const float* const* W2, const float* const* b2,
-                                      const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2,
-                                      void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream) {
+/* bgk_pack_dense_h2 for hidden layers of H0 / H1 <= 32 HT units: the operands are packed for a kernel that runs 32 HT hidden rows
+ * (rows past H0 / H1 and their bias entries are zero: padded units hold act(0) = 0 and feed zero columns of the next layer) -- no
+ * padded copy of the weights exists.  The output layer: rows2 rows in n_groups2 groups of 32 NT2 (row_map2_dev as bgk_pack_dense_h2). */
+extern "C" int bgk_pack_mlp_h2(const float* W0, const float* b0, int32_t n_in, int32_t H0,
+                               const float* W1, const float* b1, int32_t H1,
+                               const float* W2, const float* b2, int32_t rows2,
+                               const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2, int32_t HT,
+                               void* A0, void* A1, void* A2, float* cs, void* stream) {
+    BGK_CHECK_ARG(W0 && b0 && W1 && b1 && W2 && b2 && A0 && A1 && A2 && cs, "bgk_pack_mlp_h2: null pointer");
+    BGK_CHECK_ARG(n_in > 0 && HT >= 1 && HT <= 4 && H0 > 0 && H0 <= 32 * HT && H1 > 0 && H1 <= 32 * HT && rows2 > 0 && n_groups2 > 0
+                  && NT2 > 0 && NT2 <= 4, "bgk_pack_mlp_h2: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    PackLayer L0{W0, b0, H0, n_in, nullptr, 1, HT, (n_in + 1 + 15) / 16, 1, (_Float16*)A0, 0};
+    PackLayer L1{W1, b1, H1, H0, nullptr, 1, HT, 2 * HT, 0, (_Float16*)A1, 0};
+    PackLayer L2{W2, b2, rows2, H1, row_map2_dev, n_groups2, NT2, 2 * HT, 0, (_Float16*)A2, 0};
+    if (hipMemsetAsync(cs, 0, 6 * sizeof(float), st) != hipSuccess) { bgk_set_error("bgk_pack_mlp_h2: memset failed"); return BGK_EINVAL; }
+    hipLaunchKernelGGL(pack_max_kernel, dim3(3 * PACK_SPLIT), dim3(256), 0, st, L0, L1, L2, cs);
+    hipLaunchKernelGGL(pack_scale_kernel, dim3(1), dim3(64), 0, st, L0, L1, L2, cs);
+    launch_pack(L0, L1, L2, cs, st);
+    return bgk_launch_status("bgk_pack_mlp_h2");
+}
+
+/* bgk_pack_mlp_h2 of n conditioners in two launches per 16 (HT = 4: the operands of kernels that run 128 hidden rows); H0 / H1 / NT2
+ * may be NULL: 128 / 128 / 4 for every conditioner (= bgk_pack_dense_h2_many) */
+extern "C" int bgk_pack_mlp_h2_many(int32_t n, const float* const* W0, const float* const* b0, const int32_t* n_in, const int32_t* H0,
+                                    const float* const* W1, const float* const* b1, const int32_t* H1,
+                                    const float* const* W2, const float* const* b2,
+                                    const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2, const int32_t* NT2,
+                                    void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream) {
     BGK_CHECK_ARG(n >= 0 && W0 && b0 && n_in && W1 && b1 && W2 && b2 && rows2 && row_map2_dev && n_groups2 && A0 && A1 && A2 && cs,
-                  "bgk_pack_dense_h2_many: null pointer");
+                  "bgk_pack_mlp_h2_many: null pointer");
     if (n == 0) return 0;       /* nothing to do (and no launch status to ask a GPU-less box for) */
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += PACK_MANY) {
@@ -220,11 +245,13 @@ extern "C" int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const f
         int max_blocks = 0;
         for (int c = 0; c < cnt; ++c) {
             const int i = base + c;
+            const int h0 = H0 ? H0[i] : 128, h1 = H1 ? H1[i] : 128, nt2 = NT2 ? NT2[i] : 4;
             BGK_CHECK_ARG(W0[i] && b0[i] && W1[i] && b1[i] && W2[i] && b2[i] && A0[i] && A1[i] && A2[i] && cs[i] && n_in[i] > 0 && rows2[i] > 0
-                          && n_groups2[i] > 0, "bgk_pack_dense_h2_many: bad conditioner %d", i);
-            PackLayer L0{W0[i], b0[i], 128, n_in[i], nullptr, 1, 4, (n_in[i] + 1 + 15) / 16, 1, (_Float16*)A0[i], 0};
-            PackLayer L1{W1[i], b1[i], 128, 128, nullptr, 1, 4, 8, 0, (_Float16*)A1[i], 0};
-            PackLayer L2{W2[i], b2[i], rows2[i], 128, row_map2_dev[i], n_groups2[i], 4, 8, 0, (_Float16*)A2[i], 0};
+                          && n_groups2[i] > 0 && h0 > 0 && h0 <= 128 && h1 > 0 && h1 <= 128 && nt2 >= 1 && nt2 <= 4,
+                          "bgk_pack_mlp_h2_many: bad conditioner %d", i);
+            PackLayer L0{W0[i], b0[i], h0, n_in[i], nullptr, 1, 4, (n_in[i] + 1 + 15) / 16, 1, (_Float16*)A0[i], 0};
+            PackLayer L1{W1[i], b1[i], h1, h0, nullptr, 1, 4, 8, 0, (_Float16*)A1[i], 0};
+            PackLayer L2{W2[i], b2[i], rows2[i], h1, row_map2_dev[i], n_groups2[i], nt2, 8, 0, (_Float16*)A2[i], 0};
             const int blocks = fill_group(M.c[c].g, L0, L1, L2);
             M.c[c].cs = cs[i];
             max_blocks = blocks > max_blocks ? blocks : max_blocks;
@@ -233,5 +260,12 @@ extern "C" int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const f
         hipLaunchKernelGGL(pack_maxscale_many_kernel, dim3(3, (unsigned)cnt), dim3(1024), 0, st, M);
         hipLaunchKernelGGL(pack_blocks_many_kernel, dim3((unsigned)max_blocks, (unsigned)cnt), dim3(256), 0, st, M);
     }
-    return bgk_launch_status("bgk_pack_dense_h2_many");
+    return bgk_launch_status("bgk_pack_mlp_h2_many");
+}
+
+extern "C" int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const* b0, const int32_t* n_in,
+                                      const float* const* W1, const float* const* b1, const float* const* W2, const float* const* b2,
+                                      const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2,
+                                      void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream) {
+    return bgk_pack_mlp_h2_many(n, W0, b0, n_in, nullptr, W1, b1, nullptr, W2, b2, rows2, row_map2_dev, n_groups2, nullptr, A0, A1, A2, cs, stream);
 }

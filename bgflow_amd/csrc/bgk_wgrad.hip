@@ -295,38 +295,45 @@ int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t w
 
 }  // namespace
 
-extern "C" int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in) {
+/* ---- the general form: hidden layers of H1 / H0 <= 128 units whose pre-activations / gradients sit in arrays of row pitch ldz ----
+ * (an affine coupling's shift / scale networks with 64 hidden units; the conditioners the fused kernels run zero-padded): the
+ * gradients come out in the parameters' own shapes [P, H1], [H1, H0], [H0, n_in] -- no padded copies, nothing to slice. */
+extern "C" int64_t bgk_mlp_weight_grad_workspace(int64_t B, int32_t P, int32_t H1, int32_t H0, int32_t n_in) {
     /* floats: the partial sets of the three GEMMs (they run in one launch) */
-    return ws_need(B, P, 128) + ws_need(B, 128, 128) + ws_need(B, 128, n_in);
+    return ws_need(B, P, H1) + ws_need(B, H1, H0) + ws_need(B, H0, n_in);
 }
 
-extern "C" int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
-                                     const float* h1, const float* h0, int32_t h_act, const float* cond, int64_t ldc, int32_t d_c,
-                                     int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
-                                     float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
-                                     const float* g_absmax, void* stream) {
-    BGK_CHECK_ARG(g_params && g_z1 && g_z0 && h1 && h0 && cond && workspace, "bgk_dense_weight_grad: null pointer");
-    BGK_CHECK_ARG(B > 0 && P > 0 && d_c > 0 && h_act >= 0 && h_act <= 3 && accumulate >= 0 && accumulate <= 2, "bgk_dense_weight_grad: bad sizes");
+extern "C" int bgk_mlp_weight_grad(const float* g_out, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
+                                   const float* h1, const float* h0, int64_t ldz, int32_t H1, int32_t H0, int32_t h_act,
+                                   const float* cond, int64_t ldc, int32_t d_c, int32_t periodic, int64_t B,
+                                   float* workspace, int64_t workspace_floats,
+                                   float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
+                                   const float* g_absmax, void* stream) {
+    BGK_CHECK_ARG(g_out && g_z1 && g_z0 && h1 && h0 && cond && workspace, "bgk_mlp_weight_grad: null pointer");
+    BGK_CHECK_ARG(B > 0 && P > 0 && d_c > 0 && h_act >= 0 && h_act <= 3 && accumulate >= 0 && accumulate <= 2 && H1 > 0 && H1 <= COLS
+                  && H0 > 0 && H0 <= COLS && ldz >= H1 && ldz >= H0, "bgk_mlp_weight_grad: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int n_in = periodic ? 2 * d_c : d_c;
     GemmSpec specs[3];
     int count = 0;
-    const float* am = g_absmax;      /* {max |g_params|, max |g_z1|, max |g_z0|} on the device, or NULL */
-    if (gW2) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 2)", g_params, ldg, P, h1, 128, 128, 0, h_act, gW2, gb2, am};
-    if (gW1) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 1)", g_z1, 128, 128, h0, 128, 128, 0, h_act, gW1, gb1, am ? am + 1 : nullptr};
-    if (gW0) specs[count++] = GemmSpec{"bgk_dense_weight_grad (layer 0)", g_z0, 128, 128, cond, ldc, n_in, periodic, 0, gW0, gb0, am ? am + 2 : nullptr};
+    const float* am = g_absmax;      /* {max |g_out|, max |g_z1|, max |g_z0|} on the device, or NULL */
+    if (gW2) specs[count++] = GemmSpec{"bgk_mlp_weight_grad (layer 2)", g_out, ldg, P, h1, ldz, H1, 0, h_act, gW2, gb2, am};
+    if (gW1) specs[count++] = GemmSpec{"bgk_mlp_weight_grad (layer 1)", g_z1, ldz, H1, h0, ldz, H0, 0, h_act, gW1, gb1, am ? am + 1 : nullptr};
+    if (gW0) specs[count++] = GemmSpec{"bgk_mlp_weight_grad (layer 0)", g_z0, ldz, H0, cond, ldc, n_in, periodic, 0, gW0, gb0, am ? am + 2 : nullptr};
     if (count == 0) return 0;
-    /* accumulate == 2: the partial sums only -- the caller reduces them later with bgk_dense_weight_grad_reduce_many */
+    /* accumulate == 2: the partial sums only -- the caller reduces them later with bgk_mlp_weight_grad_reduce_many */
     const int rc = gemm_group(specs, count, B, workspace, workspace_floats, accumulate, st, accumulate == 2 ? 1 : 3);
     if (rc != 0) return rc;
-    return bgk_launch_status("bgk_dense_weight_grad");
+    return bgk_launch_status("bgk_mlp_weight_grad");
 }
 
-extern "C" int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* P, const int32_t* n_in,
-                                                 float* const* workspace, float* const* gW2, float* const* gb2, float* const* gW1,
-                                                 float* const* gb1, float* const* gW0, float* const* gb0, int32_t accumulate, void* stream) {
+/* H1 / H0 may be NULL: 128 hidden units everywhere (= bgk_dense_weight_grad_reduce_many) */
+extern "C" int bgk_mlp_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* P, const int32_t* H1, const int32_t* H0,
+                                               const int32_t* n_in, float* const* workspace, float* const* gW2, float* const* gb2,
+                                               float* const* gW1, float* const* gb1, float* const* gW0, float* const* gb0,
+                                               int32_t accumulate, void* stream) {
     BGK_CHECK_ARG(n >= 0 && B && P && n_in && workspace && gW2 && gb2 && gW1 && gb1 && gW0 && gb0 && (accumulate == 0 || accumulate == 1),
-                  "bgk_dense_weight_grad_reduce_many: bad arguments");
+                  "bgk_mlp_weight_grad_reduce_many: bad arguments");
     if (n == 0) return 0;       /* nothing to do (and no launch status to ask a GPU-less box for) */
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n; base += RED_MANY) {
@@ -335,11 +342,12 @@ extern "C" int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, co
         int64_t max_outs = 0;
         for (int c = 0; c < cnt; ++c) {
             const int i = base + c;
-            BGK_CHECK_ARG(B[i] > 0 && P[i] > 0 && n_in[i] > 0 && n_in[i] <= COLS && workspace[i] && gW2[i] && gW1[i] && gW0[i],
-                          "bgk_dense_weight_grad_reduce_many: bad layer %d", i);
-            GemmSpec specs[3] = {GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 2)", nullptr, 0, P[i], nullptr, 0, 128, 0, 0, gW2[i], gb2[i], nullptr},
-                                 GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 1)", nullptr, 0, 128, nullptr, 0, 128, 0, 0, gW1[i], gb1[i], nullptr},
-                                 GemmSpec{"bgk_dense_weight_grad_reduce_many (layer 0)", nullptr, 0, 128, nullptr, 0, n_in[i], 0, 0, gW0[i], gb0[i], nullptr}};
+            const int h1 = H1 ? H1[i] : 128, h0 = H0 ? H0[i] : 128;
+            BGK_CHECK_ARG(B[i] > 0 && P[i] > 0 && n_in[i] > 0 && n_in[i] <= COLS && h1 > 0 && h1 <= COLS && h0 > 0 && h0 <= COLS
+                          && workspace[i] && gW2[i] && gW1[i] && gW0[i], "bgk_mlp_weight_grad_reduce_many: bad layer %d", i);
+            GemmSpec specs[3] = {GemmSpec{"bgk_mlp_weight_grad_reduce_many (layer 2)", nullptr, 0, P[i], nullptr, 0, h1, 0, 0, gW2[i], gb2[i], nullptr},
+                                 GemmSpec{"bgk_mlp_weight_grad_reduce_many (layer 1)", nullptr, 0, h1, nullptr, 0, h0, 0, 0, gW1[i], gb1[i], nullptr},
+                                 GemmSpec{"bgk_mlp_weight_grad_reduce_many (layer 0)", nullptr, 0, h0, nullptr, 0, n_in[i], 0, 0, gW0[i], gb0[i], nullptr}};
             const int rc = gemm_group(specs, 3, B[i], workspace[i], (int64_t)1 << 60, accumulate, st, 0, &M.r[c]);
             if (rc != 0) return rc;
             max_outs = M.r[c].first[3] > max_outs ? M.r[c].first[3] : max_outs;
@@ -347,5 +355,22 @@ extern "C" int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, co
         for (int c = cnt; c < RED_MANY; ++c) M.r[c] = M.r[0];
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)((max_outs + 31) / 32), (unsigned)cnt), dim3(256), 0, st, M, accumulate);
     }
-    return bgk_launch_status("bgk_dense_weight_grad_reduce_many");
+    return bgk_launch_status("bgk_mlp_weight_grad_reduce_many");
+}
+
+extern "C" int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in) { return bgk_mlp_weight_grad_workspace(B, P, 128, 128, n_in); }
+
+extern "C" int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
+                                     const float* h1, const float* h0, int32_t h_act, const float* cond, int64_t ldc, int32_t d_c,
+                                     int32_t periodic, int64_t B, float* workspace, int64_t workspace_floats,
+                                     float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
+                                     const float* g_absmax, void* stream) {
+    return bgk_mlp_weight_grad(g_params, ldg, P, g_z1, g_z0, h1, h0, 128, 128, 128, h_act, cond, ldc, d_c, periodic, B, workspace, workspace_floats,
+                               gW2, gb2, gW1, gb1, gW0, gb0, accumulate, g_absmax, stream);
+}
+
+extern "C" int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* P, const int32_t* n_in,
+                                                 float* const* workspace, float* const* gW2, float* const* gb2, float* const* gW1,
+                                                 float* const* gb1, float* const* gW0, float* const* gb0, int32_t accumulate, void* stream) {
+    return bgk_mlp_weight_grad_reduce_many(n, B, P, nullptr, nullptr, n_in, workspace, gW2, gb2, gW1, gb1, gW0, gb0, accumulate, stream);
 }

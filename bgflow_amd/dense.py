@@ -1172,7 +1172,7 @@ _DIRECT_GRADS = [False]
 
 DEFERRED_WGRAD_REDUCE = True    # inside direct_grad_accumulation(): one reduction launch for all layers when the context exits
 
-_PENDING_REDUCE = {}            # workspace data_ptr -> (device, B, P, n_in, workspace, the six destinations)
+_PENDING_REDUCE = {}            # workspace data_ptr -> (device, B, P, n_in, workspace, the six destinations, H1, H0)
 
 
 def flush_weight_grad_reductions():
@@ -1186,14 +1186,16 @@ def flush_weight_grad_reductions():
     _PENDING_REDUCE.clear()
     for dev, items in by_dev.items():
         n = len(items)
-        vps = ctypes.c_void_p * n
+        vps, i32s = ctypes.c_void_p * n, ctypes.c_int32 * n
         dst = lambda k: vps(*[it[4][k].data_ptr() for it in items])       # noqa: E731
         with torch.cuda.device(dev):
-            st = _lib.lib().bgk_dense_weight_grad_reduce_many(
-                n, (ctypes.c_int64 * n)(*[it[0] for it in items]), (ctypes.c_int32 * n)(*[it[1] for it in items]),
-                (ctypes.c_int32 * n)(*[it[2] for it in items]), vps(*[it[3].data_ptr() for it in items]),
+            # (items: B, P, n_in, workspace, destinations, H1, H0 -- the hidden widths of the layer's weight shapes)
+            st = _lib.lib().bgk_mlp_weight_grad_reduce_many(
+                n, (ctypes.c_int64 * n)(*[it[0] for it in items]), i32s(*[it[1] for it in items]),
+                i32s(*[it[5] for it in items]), i32s(*[it[6] for it in items]),
+                i32s(*[it[2] for it in items]), vps(*[it[3].data_ptr() for it in items]),
                 dst(4), dst(5), dst(2), dst(3), dst(0), dst(1), 1, _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_dense_weight_grad_reduce_many")
+        _lib.check(st, "bgk_mlp_weight_grad_reduce_many")
 
 
 class direct_grad_accumulation:
@@ -1256,7 +1258,7 @@ def _dense_weight_grad(g_p, g_z1, g_z0, h1, h0, x, periodic, n_in, need, bufs, p
     if direct and DEFERRED_WGRAD_REDUCE:
         if ws.data_ptr() in _PENDING_REDUCE:     # the same layer twice in one backward pass: its first partial set goes out first
             flush_weight_grad_reductions()
-        _PENDING_REDUCE[ws.data_ptr()] = (dev, B, P, n_in, ws, (gW0, gb0, gW1, gb1, gW2, gb2))
+        _PENDING_REDUCE[ws.data_ptr()] = (dev, B, P, n_in, ws, (gW0, gb0, gW1, gb1, gW2, gb2), 128, 128)
         mode = 2
     with torch.cuda.device(dev):
         st = lib.bgk_dense_weight_grad(_lib.ptr(g2), ldg, P, _lib.ptr(g_z1), _lib.ptr(g_z0), _lib.ptr(h1), _lib.ptr(h0), int(h_act),
@@ -1587,3 +1589,299 @@ def fused_spline_coupling_train(transformer, x, y, nc_dev, nc_host, inverse, oob
     if prep is None:
         return None
     return _FusedSplineTrainFn.apply(x, y, *prep[0], *prep[1])
+
+
+# ---- training path of the fused AFFINE coupling layer (round 6) -----------------------------------------------------------------
+# Forward: ONE launch of bgk_coupling_affine_dense_h2_train (both conditioner networks on the matrix cores + the affine tail; it also
+# writes the scaled pre-activations of the four hidden layers and the two networks' outputs).  Backward: bgk_affine_backward (tail),
+# then per network bgk_dense_backward_dx (input-gradient chain; the second network ADDS its conditioner-input gradient to the
+# first's) and bgk_mlp_weight_grad (weight / bias gradients in the parameters' own shapes, straight into the FlatAdam bucket inside
+# direct_grad_accumulation()).  Before round 6 an affine coupling under autograd ran its networks layer by layer and their backward
+# through _LinearFn (F.linear / bmm -> hipBLASLt) + aten activation kernels.  Reference: nn/flow/transformer/affine.py:35-70,
+# nn/dense.py:30-48, nn/flow/coupling.py:152-182, nn/training/trainers.py:156-163.
+AFFINE_TRAIN = os.environ.get("BGK_AFFINE_TRAIN", "1") != "0"     # 0: the layer-by-layer path (A/B measurements)
+
+_AFF_TRAIN_TRANSFORMERS = weakref.WeakSet()     # affine transformers whose training plan ran a forward since the last repack
+
+
+def _affine_train_net(net):
+    """((l0, l1, l2), act, periodic) of a shift / scale network inside the training kernels' envelope, else None"""
+    per = type(net) is WrapPeriodic
+    inner = net.net if per else net
+    spec = _fusable_dense(inner)
+    if spec is None:
+        return None
+    (l0, l1, l2), act = spec
+    if per:
+        n_raw = l0.in_features // 2
+        if not (net.left == 0.0 and net.right == 1.0) or n_raw == 0 or 2 * n_raw != l0.in_features:
+            return None
+        if not np.array_equal(np.asarray(np.arange(n_raw)[net.indices]), np.arange(n_raw)):
+            return None
+    if l0.out_features > 128 or l1.out_features > 128 or l1.in_features != l0.out_features or l2.in_features != l1.out_features:
+        return None
+    return (l0, l1, l2), act, per
+
+
+def _affine_train_plan(transformer, y_dim, dev):
+    """Operand buffers of the affine training kernels for a transformer whose networks are two-hidden-layer DenseNets of <= 128 units
+    (optionally behind an all-periodic WrapPeriodic): per network the forward operands A0..A2 + device scale table cs (bgk_pack_mlp_h2)
+    and the transposed operands T0..T2 (bgk_pack_mlp_h2_t), re-packed when a parameter's state changed.  None outside the envelope."""
+    nets = (transformer._shift_transformation, transformer._scale_transformation)
+    if all(n is None for n in nets) or _gemm_mode(transformer) == "f32":
+        return None
+    specs = [None if n is None else _affine_train_net(n) for n in nets]
+    if any(n is not None and sp is None for n, sp in zip(nets, specs)):
+        return None
+    live = [sp for sp in specs if sp is not None]
+    n_in, periodic = live[0][0][0].in_features, live[0][2]
+    acts = [sp[1] for sp in live]
+    if not (acts[0] == acts[-1] or (len(live) == 2 and acts == [2, 3])):       # (shift, scale): both equal, or ReLU / Tanh
+        return None
+    for lins, _, per in live:
+        if lins[0].in_features != n_in or per != periodic or lins[2].out_features != y_dim:
+            return None
+        if not all(p.is_cuda and p.device == dev and p.dtype == torch.float32 and p.is_contiguous() for lin in lins for p in (lin.weight, lin.bias)):
+            return None
+    if y_dim > 96 or n_in > T_OPERAND_MAX_IN or (periodic and n_in % 2):
+        return None
+    cache = transformer.__dict__.setdefault("_train_cache", {})
+    key = (y_dim, n_in, bool(periodic), str(dev), tuple(None if sp is None else (sp[0][0].out_features, sp[0][1].out_features, sp[1]) for sp in specs))
+    if cache.get("key") != key:
+        cache.clear()
+        OT, S0 = (y_dim + 31) // 32, (n_in + 1 + 15) // 16
+        entries = []
+        for sp in specs:
+            if sp is None:
+                entries.append(None)
+                continue
+            f16 = lambda nblk: torch.empty((nblk, 64, 8), dtype=torch.float16, device=dev)       # noqa: E731
+            tb = {}
+            _t_operand_bufs(tb, y_dim, n_in, dev)
+            entries.append(dict(lins=sp[0], act=sp[1], H0=sp[0][0].out_features, H1=sp[0][1].out_features,
+                                A0=f16(S0 * 8), A1=f16(8 * 8 + 4), A2=f16(8 * OT * 2 + OT), cs=torch.empty(6, dtype=torch.float32, device=dev),
+                                tbufs=tb, version=None))
+        cache.update(key=key, nets=entries, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), OT=OT, y_dim=y_dim)
+    lib = _lib.lib()
+    for e in cache["nets"]:
+        if e is None:
+            continue
+        l0, l1, l2 = e["lins"]
+        version = tuple(param_state_key(p) for lin in e["lins"] for p in (lin.weight, lin.bias))
+        if e["version"] == version:
+            continue
+        ws = [t.detach() for lin in e["lins"] for t in (lin.weight, lin.bias)]
+        with torch.cuda.device(dev):
+            st = lib.bgk_pack_mlp_h2(_lib.ptr(ws[0]), _lib.ptr(ws[1]), n_in, e["H0"], _lib.ptr(ws[2]), _lib.ptr(ws[3]), e["H1"],
+                                     _lib.ptr(ws[4]), _lib.ptr(ws[5]), y_dim, None, 1, cache["OT"], 4,
+                                     _lib.ptr(e["A0"]), _lib.ptr(e["A1"]), _lib.ptr(e["A2"]), _lib.ptr(e["cs"]), _lib.stream_ptr(dev))
+            _lib.check(st, "bgk_pack_mlp_h2")
+            tb = e["tbufs"]
+            st = lib.bgk_pack_mlp_h2_t(_lib.ptr(ws[0]), n_in, e["H0"], _lib.ptr(ws[2]), e["H1"], _lib.ptr(ws[4]), y_dim, _lib.ptr(e["cs"]),
+                                       _lib.ptr(tb["T0"]), _lib.ptr(tb["T1"]), _lib.ptr(tb["T2"]), _lib.stream_ptr(dev))
+            _lib.check(st, "bgk_pack_mlp_h2_t")
+        e["version"] = version
+    return cache
+
+
+def repack_affine_training_plans(param_ids=None):
+    """After an optimizer step: the forward and the transposed operands of every affine coupling that ran a training forward since the
+    last call, in three launches per 16 networks (bgk_pack_mlp_h2_many + bgk_pack_mlp_h2_t_many).  Returns the number of networks."""
+    if not BATCHED_REPACK:
+        return 0
+    by_dev = {}
+    for tr in list(_AFF_TRAIN_TRANSFORMERS):
+        cache = getattr(tr, "_train_cache", None)
+        if not cache or not cache.pop("train_used", False):
+            continue
+        for e in cache["nets"]:
+            if e is None:
+                continue
+            params = [p for lin in e["lins"] for p in (lin.weight, lin.bias)]
+            if param_ids is not None and not all(id(p) in param_ids for p in params):
+                continue
+            if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+                continue
+            version = tuple(param_state_key(p) for p in params)
+            if e["version"] == version:
+                continue
+            by_dev.setdefault(params[0].device, []).append((cache, e, params, version))
+    done = 0
+    for dev, items in by_dev.items():
+        n = len(items)
+        vps, i32s = (ctypes.c_void_p * n), (ctypes.c_int32 * n)
+        col = lambda f: vps(*[f(it) for it in items])       # noqa: E731
+        num = lambda f: i32s(*[f(it) for it in items])      # noqa: E731
+        n_in = num(lambda it: it[1]["lins"][0].in_features)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_pack_mlp_h2_many(
+                n, col(lambda it: it[2][0].data_ptr()), col(lambda it: it[2][1].data_ptr()), n_in, num(lambda it: it[1]["H0"]),
+                col(lambda it: it[2][2].data_ptr()), col(lambda it: it[2][3].data_ptr()), num(lambda it: it[1]["H1"]),
+                col(lambda it: it[2][4].data_ptr()), col(lambda it: it[2][5].data_ptr()), num(lambda it: it[0]["y_dim"]),
+                vps(*[None] * n), num(lambda it: 1), num(lambda it: it[0]["OT"]),
+                col(lambda it: it[1]["A0"].data_ptr()), col(lambda it: it[1]["A1"].data_ptr()), col(lambda it: it[1]["A2"].data_ptr()),
+                col(lambda it: it[1]["cs"].data_ptr()), _lib.stream_ptr(dev))
+            _lib.check(st, "bgk_pack_mlp_h2_many")
+            st = _lib.lib().bgk_pack_mlp_h2_t_many(
+                n, col(lambda it: it[2][0].data_ptr()), n_in, num(lambda it: it[1]["H0"]), col(lambda it: it[2][2].data_ptr()),
+                num(lambda it: it[1]["H1"]), col(lambda it: it[2][4].data_ptr()), num(lambda it: it[0]["y_dim"]),
+                col(lambda it: it[1]["cs"].data_ptr()), col(lambda it: it[1]["tbufs"]["T0"].data_ptr()),
+                col(lambda it: it[1]["tbufs"]["T1"].data_ptr()), col(lambda it: it[1]["tbufs"]["T2"].data_ptr()), _lib.stream_ptr(dev))
+            _lib.check(st, "bgk_pack_mlp_h2_t_many")
+        for _cache, e, _params, version in items:
+            e["version"] = version
+        done += n
+    return done
+
+
+def _affine_net_backward(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, gx_buf, gx_add, need_w, version):
+    """backward of ONE conditioner network of a fused affine training layer: bgk_dense_backward_dx (g_net [B, d] -> g_z1, g_z0 and the
+    conditioner-input gradient, to which ``gx_add`` is added) + bgk_mlp_weight_grad.  Returns the six gradients (W0, b0, W1, b1, W2, b2)
+    -- None each when they went straight into the FlatAdam bucket or are not needed."""
+    if e["version"] != version:
+        raise RuntimeError("fused affine coupling: the conditioner's parameters changed between the forward and this backward (the packed "
+                           "operands were rewritten); run the backward before the optimizer step, or call forward again")
+    dev = g_net.device
+    B, d = g_net.shape[0], plan["y_dim"]
+    tb = e["tbufs"]
+    d_c, periodic, n_in = plan["d_c"], plan["periodic"], e["lins"][0].in_features
+    gz = torch.empty((2, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)[:, :B]
+    lib = _lib.lib()
+    add2, lda = (gx_add, gx_add.stride(0)) if (gx_add is not None and want_gx) else (None, 0)
+    with torch.cuda.device(dev):
+        st = lib.bgk_dense_backward_dx(_lib.ptr(g_net), ldg, d, _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic),
+                                       _lib.ptr(tb["T0"]), _lib.ptr(tb["T1"]), _lib.ptr(tb["T2"]), _lib.ptr(e["cs"]), e["act"], B,
+                                       _lib.ptr(gz[0]), _lib.ptr(gz[1]), None, None, _lib.ptr(gx_buf) if want_gx else None,
+                                       gx_buf.stride(0) if want_gx else d_c, _lib.ptr(add2), lda, _lib.ptr(absmax), _lib.ptr(absmax[1:]),
+                                       _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_dense_backward_dx")
+    if not any(need_w):
+        return (None,) * 6
+    l0, l1, l2 = e["lins"]
+    params = (l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias)
+    H0, H1 = e["H0"], e["H1"]
+    need_ws = int(lib.bgk_mlp_weight_grad_workspace(B, d, H1, H0, n_in))
+    ws = tb.get("wgrad_ws")
+    if ws is None or ws.numel() < need_ws or ws.device != dev:
+        ws = tb["wgrad_ws"] = torch.empty(need_ws, dtype=torch.float32, device=dev)
+    direct = _DIRECT_GRADS[0] and all(need_w) and all(
+        getattr(p, "_bgk_grad_dst", None) is not None and p.grad is not None and p.grad.data_ptr() == p._bgk_grad_dst.data_ptr()
+        for p in params)
+    if direct:
+        gW0, gb0, gW1, gb1, gW2, gb2 = (p._bgk_grad_dst for p in params)
+    else:
+        new = lambda shape, need: torch.empty(shape, dtype=torch.float32, device=dev) if need else None      # noqa: E731
+        gW0, gb0 = new((H0, n_in), need_w[0] or need_w[1]), new((H0,), need_w[1])
+        gW1, gb1 = new((H1, H0), need_w[2] or need_w[3]), new((H1,), need_w[3])
+        gW2, gb2 = new((d, H1), need_w[4] or need_w[5]), new((d,), need_w[5])
+    mode = int(direct)
+    if direct and DEFERRED_WGRAD_REDUCE:
+        if ws.data_ptr() in _PENDING_REDUCE:
+            flush_weight_grad_reductions()
+        _PENDING_REDUCE[ws.data_ptr()] = (dev, B, d, n_in, ws, (gW0, gb0, gW1, gb1, gW2, gb2), H1, H0)
+        mode = 2
+    with torch.cuda.device(dev):
+        st = lib.bgk_mlp_weight_grad(_lib.ptr(g_net), ldg, d, _lib.ptr(gz[0]), _lib.ptr(gz[1]), _lib.ptr(z1), _lib.ptr(z0), 128, H1, H0,
+                                     e["act"], _lib.ptr(x2), ldc, d_c, int(periodic), B, _lib.ptr(ws), ws.numel(),
+                                     _lib.ptr(gW2), _lib.ptr(gb2), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW0), _lib.ptr(gb0), mode,
+                                     _lib.ptr(absmax), _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_mlp_weight_grad")
+    if direct:
+        return (None,) * 6
+    return tuple(g if n else None for g, n in zip((gW0, gb0, gW1, gb1, gW2, gb2), need_w))
+
+
+class _FusedAffineTrainFn(torch.autograd.Function):
+    """apply(x, y, log_alpha, plan, cfg, *12 network parameters (shift W0, b0, W1, b1, W2, b2, scale ...; None for an absent network))
+    -> (y', dlogp [B, 1]).  ``cfg`` = (preserve_volume, is_circular, inverse)."""
+
+    @staticmethod
+    def forward(ctx, x, y, log_alpha, plan, cfg, *weights):
+        pv, circ, inverse = cfg
+        dev = y.device
+        x2, ldc = _lib.rowmajor(x.detach())
+        y2, ldy = _lib.rowmajor(y.detach())
+        B, d = y2.shape
+        out = torch.empty((B, d), dtype=torch.float32, device=dev)
+        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
+        zz = torch.empty((4, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)[:, :B]
+        ldms = 32 * plan["OT"]
+        ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
+        es, et = plan["nets"]
+        ops = []
+        for e in (es, et):
+            ops += [None, None, None, None, 0] if e is None else [_lib.ptr(e["A0"]), _lib.ptr(e["A1"]), _lib.ptr(e["A2"]), _lib.ptr(e["cs"]), e["act"]]
+        ptrs, lds, widths, n, _keep = _lib.cond_segments([x2])
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_coupling_affine_dense_h2_train(
+                ptrs, lds, widths, n, int(plan["periodic"]), *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
+                _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), 0,
+                _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms, _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_coupling_affine_dense_h2_train")
+        ctx.save_for_backward(x2, y2, log_alpha, zz, ms)
+        ctx.plan, ctx.cfg = plan, cfg
+        ctx.versions = [None if e is None else e["version"] for e in (es, et)]
+        ctx.x_shape = x.shape
+        return out, dlogp[:, None]
+
+    @staticmethod
+    def backward(ctx, g_out, g_dlogp):
+        x2, y2, log_alpha, zz, ms = ctx.saved_tensors
+        plan, (pv, circ, inverse) = ctx.plan, ctx.cfg
+        es, et = plan["nets"]
+        need = ctx.needs_input_grad
+        dev = y2.device
+        B, d = y2.shape
+        ldms = ms.shape[2]
+        ldc = x2.stride(0) if B > 1 else x2.shape[1]
+        g_out2, ldgo = _lib.rowmajor(g_out.reshape(B, d))
+        g_dl = g_dlogp.reshape(-1).contiguous()
+        g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
+        g_ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
+        absmax = torch.zeros((2, 3), dtype=torch.float32, device=dev)
+        la_direct = (_DIRECT_GRADS[0] and need[2] and getattr(log_alpha, "_bgk_grad_dst", None) is not None and log_alpha.grad is not None
+                     and log_alpha.grad.data_ptr() == log_alpha._bgk_grad_dst.data_ptr())
+        g_la = log_alpha._bgk_grad_dst if la_direct else (torch.zeros((1,), dtype=torch.float32, device=dev) if et is not None else None)
+        with torch.cuda.device(dev):
+            st = _lib.lib().bgk_affine_backward(
+                _lib.ptr(y2), y2.stride(0) if B > 1 else d, _lib.ptr(ms[0]) if es is not None else None, ldms,
+                _lib.ptr(ms[1]) if et is not None else None, ldms, _lib.ptr(log_alpha.detach()),
+                int(pv), int(circ), int(inverse), B, d, _lib.ptr(g_out2), ldgo, _lib.ptr(g_dl),
+                _lib.ptr(g_y), d, _lib.ptr(g_ms[0]) if es is not None else None, ldms, _lib.ptr(g_ms[1]) if et is not None else None, ldms,
+                _lib.ptr(g_la), _lib.ptr(absmax[0]), _lib.ptr(absmax[1]), _lib.stream_ptr(dev))
+        _lib.check(st, "bgk_affine_backward")
+        want_gx = bool(need[0])
+        g_x = torch.empty((B, plan["d_c"]), dtype=torch.float32, device=dev) if want_gx else None
+        grads, first = [], True
+        for k, e in enumerate((es, et)):
+            if e is None:
+                grads += [None] * 6
+                continue
+            gws = _affine_net_backward(e, plan, g_ms[k], ldms, zz[2 * k + 1], zz[2 * k], x2, ldc, absmax[k], want_gx, g_x,
+                                       None if first else g_x, need[5 + 6 * k:11 + 6 * k], ctx.versions[k])
+            grads += list(gws)
+            first = False
+        return (g_x.reshape(ctx.x_shape) if want_gx else None, g_y if need[1] else None,
+                (None if (la_direct or et is None) else g_la) if need[2] else None, None, None, *grads)
+
+
+def fused_affine_coupling_train(transformer, x, y, inverse):
+    """Differentiable one-launch forward of the affine coupling layer (see _FusedAffineTrainFn), or None outside the envelope: networks
+    that are not two-hidden-layer DenseNets of <= 128 units with SiLU / ReLU / Tanh, > 96 input features or transformed dims, gemm_mode
+    'f32', inputs that are not 2-d f32 HIP tensors."""
+    if not AFFINE_TRAIN or x.dim() != 2 or y.dim() != 2 or not y.is_cuda or x.dtype != torch.float32 or y.dtype != torch.float32 \
+            or x.shape[0] != y.shape[0] or y.shape[0] == 0:
+        return None
+    plan = _affine_train_plan(transformer, y.shape[-1], y.device)
+    if plan is None or x.shape[-1] != plan["d_c"]:
+        return None
+    _lib.require_hip(x, y)
+    plan["train_used"] = True
+    _AFF_TRAIN_TRANSFORMERS.add(transformer)
+    weights = []
+    for e in plan["nets"]:
+        weights += [None] * 6 if e is None else [p for lin in e["lins"] for p in (lin.weight, lin.bias)]
+    log_alpha = transformer._log_alpha
+    if log_alpha.device != y.device or log_alpha.dtype != torch.float32:
+        log_alpha = log_alpha.to(device=y.device, dtype=torch.float32)
+    return _FusedAffineTrainFn.apply(x, y, log_alpha, plan, (transformer._preserve_volume, transformer._is_circular, inverse), *weights)

@@ -224,6 +224,7 @@ class FlatAdam(torch.optim.Optimizer):
         # ... and re-pack those operands now, for all fused layers at once (three launches instead of five per layer at their next use)
         from . import dense
         dense.repack_training_plans(self._param_ids)
+        dense.repack_affine_training_plans(self._param_ids)
 
     def skipped_steps(self):
         """number of optimizer steps skipped because a gradient was NaN (host sync)"""

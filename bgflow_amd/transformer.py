@@ -21,6 +21,7 @@ def _invalidate_fused_cache(self):
     steps, load_state_dict and ordinary in-place ops are picked up automatically; edits through ``.data`` (EMA / weight-swap code)
     bump no version counter -- call this after them."""
     self._fused_cache.clear()
+    self.__dict__.pop("_train_cache", None)
 
 
 __all__ = ["Transformer", "AffineTransformer", "ConditionalSplineTransformer"]
@@ -119,7 +120,7 @@ class _AffineFn(torch.autograd.Function):
             st = _lib.lib().bgk_affine_backward(
                 _lib.ptr(y2), ldy, _lib.ptr(mu2), ldmu, _lib.ptr(s2), lds, _lib.ptr(log_alpha),
                 int(pv), int(circ), int(inverse), B, d, _lib.ptr(g_out2), ldgo, _lib.ptr(g_dl),
-                _lib.ptr(g_y), d, _lib.ptr(g_mu), d, _lib.ptr(g_s), d, _lib.ptr(g_la), _lib.stream_ptr(dev))
+                _lib.ptr(g_y), d, _lib.ptr(g_mu), d, _lib.ptr(g_s), d, _lib.ptr(g_la), None, None, _lib.stream_ptr(dev))
         _lib.check(st, "bgk_affine_backward")
         shp = (*lead, d)
         return (g_y.reshape(shp), None if g_mu is None else g_mu.reshape(shp),
@@ -161,6 +162,11 @@ class AffineTransformer(Transformer):
             if fused is not None:
                 return fused
         x = as_tensor(x)
+        if grad and self.allow_fused and not cond:
+            from .dense import fused_affine_coupling_train
+            fused = fused_affine_coupling_train(self, x, y, inverse)      # forward and backward on the hand-written kernels (round 6)
+            if fused is not None:
+                return fused
         mu = self._shift_transformation(x, *cond) if self._shift_transformation is not None else None
         s_raw = self._scale_transformation(x, *cond) if self._scale_transformation is not None else None
         if mu is not None:

@@ -111,14 +111,17 @@ int bgk_affine_transform(const float* y, int64_t ldy, const float* mu, int64_t l
                          int64_t B, int32_t d, float* out, int64_t ldo,
                          float* dlogp, int32_t accumulate, void* stream);
 
-/* backward: g_y, g_mu, g_s_raw [B,d] (any may be NULL), g_log_alpha float[1] (+=, may be NULL) */
+/* backward: g_y, g_mu, g_s_raw [B,d] (any may be NULL), g_log_alpha float[1] (+=, may be NULL).
+ * g_mu_absmax / g_s_absmax (round 6; NULL or one device float each, zeroed by the caller): raised to max |g_mu| / max |g_s_raw| -- the
+ * power-of-two scale source of the backward GEMMs that consume them (bgk_dense_backward_dx / bgk_mlp_weight_grad of the shift and
+ * the scale network) */
 int bgk_affine_backward(const float* y, int64_t ldy, const float* mu, int64_t ldmu,
                         const float* s_raw, int64_t lds, const float* log_alpha,
                         int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                         int64_t B, int32_t d,
                         const float* g_out, int64_t ldgo, const float* g_dlogp,
                         float* g_y, int64_t ldgy, float* g_mu, int64_t ldgmu,
-                        float* g_s, int64_t ldgs, float* g_log_alpha, void* stream);
+                        float* g_s, int64_t ldgs, float* g_log_alpha, float* g_mu_absmax, float* g_s_absmax, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Internal coordinates (Z-matrix <-> Cartesian), relative to fixed atoms, optional PCA
@@ -449,6 +452,29 @@ int bgk_coupling_affine_dense_deep(const float* cond, int64_t ldc, int32_t d_c, 
                                    const float* y, int64_t ldy, int64_t B, int32_t d,
                                    float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training forward of the fused affine coupling layer (round 6): what autograd needs of CouplingFlow._forward / _inverse
+ * (nn/flow/coupling.py:162-182) around AffineTransformer (nn/flow/transformer/affine.py:35-70) with DenseNet conditioners
+ * [n_in, H0, H1, d] (nn/dense.py:30-48), H0, H1 <= 128, in ONE launch: the arithmetic of bgk_coupling_affine_dense_h2 (width-128 kernel:
+ * narrower hidden layers run zero-padded inside the operands) plus, per network, the scaled pre-activations z0, z1 [B, 128] of its
+ * two hidden layers (contiguous; padded units hold 0) and its output rows -- mu and the scale network's values before tanh,
+ * [B, ldms] with ldms a multiple of 4 and >= 32 ceil(d / 32) (columns past d hold 0).  Their consumers: bgk_affine_backward
+ * (mu, s_raw), bgk_dense_backward_dx and bgk_mlp_weight_grad (z0, z1) -- the backward of KLTrainer's loss.backward()
+ * (nn/training/trainers.py:156-163) for an affine coupling without a library GEMM or an elementwise torch kernel.
+ *   cond / ldc / width / n_cond: 1 .. 3 conditioning tensors standing for their concatenation (as the *_mc entry points)
+ *   s* / t*: shift / scale network operands from bgk_pack_mlp_h2 (HT = 4, NT2 = ceil(d / 32), one group, identity row map) and its
+ *            device scale table cs; A0 == NULL: network absent; act: 1 SiLU, 2 ReLU, 3 Tanh (both equal, or ReLU / Tanh)
+ * Returns BGK_EUNSUPPORTED outside the envelope (activation pairs, > 127 input features): the caller runs the networks layer by layer.
+ * --------------------------------------------------------------------------------------------- */
+int bgk_coupling_affine_dense_h2_train(const float* const* cond, const int64_t* ldc, const int32_t* width, int32_t n_cond, int32_t periodic,
+                                       const void* sA0, const void* sA1, const void* sA2, const float* s_cs, int32_t s_act,
+                                       const void* tA0, const void* tA1, const void* tA2, const float* t_cs, int32_t t_act,
+                                       const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
+                                       const float* y, int64_t ldy, int64_t B, int32_t d, float* out, int64_t ldo,
+                                       float* dlogp, int32_t accumulate,
+                                       float* s_z0, float* s_z1, float* t_z0, float* t_z1, float* mu, float* s_raw, int64_t ldms,
+                                       void* stream);
+
 /* The fused coupling layers with SEVERAL conditioning tensors: CouplingFlow concatenates the tensors at cond_indices before it
  * calls the transformer (torch.cat, nn/flow/coupling.py:162-165; e.g. cfg 5's AUGMENTED | (FIXED, BONDS, ANGLES) layers).  Here
  * cond / ldc / width are HOST arrays of n_cond (1..3) device pointers [B, width_i], row strides and widths; the kernels stage
@@ -504,6 +530,22 @@ int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const
                            const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2,
                            void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream);
 
+/* bgk_pack_dense_h2 / _many for conditioners whose hidden layers have H0 / H1 <= 32 HT units (DenseNet([n_in, H0, H1, rows2]),
+ * nn/dense.py:9-28; factory/conditioner_factory.py:81-85 takes any `hidden` tuple): the operands are laid out for a kernel that runs
+ * 32 HT hidden rows, the rows / k-slots past H0 / H1 are zero (act(0) = 0 feeds zero columns: the same function), no padded copy of
+ * the weights exists.  Affine networks: row_map2_dev = NULL, n_groups2 = 1, NT2 = ceil(d / 32).  _many: HT = 4; H0 / H1 / NT2 may be
+ * NULL (128 / 128 / 4 for every conditioner). */
+int bgk_pack_mlp_h2(const float* W0, const float* b0, int32_t n_in, int32_t H0,
+                    const float* W1, const float* b1, int32_t H1,
+                    const float* W2, const float* b2, int32_t rows2,
+                    const int32_t* row_map2_dev, int32_t n_groups2, int32_t NT2, int32_t HT,
+                    void* A0, void* A1, void* A2, float* cs, void* stream);
+int bgk_pack_mlp_h2_many(int32_t n, const float* const* W0, const float* const* b0, const int32_t* n_in, const int32_t* H0,
+                         const float* const* W1, const float* const* b1, const int32_t* H1,
+                         const float* const* W2, const float* const* b2,
+                         const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2, const int32_t* NT2,
+                         void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream);
+
 /* Input-gradient chain of the conditioner MLP [n_in, 128, 128, P] in one launch (autograd of nn/dense.py:47-48 in the
  * training step): from g [B, P] (gradient w.r.t. the MLP output, e.g. bgk_rqs_backward's g_params) and the saved
  * pre-activations z1, z0 it writes g_z1, g_z0 (gradients w.r.t. the pre-activations), h1, h0 (the activations; both NULL: not
@@ -522,6 +564,15 @@ int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const
  * and written by the same lane). */
 int bgk_pack_dense_h2_t(const float* W0, int32_t n_in, const float* W1, const float* W2, int32_t P,
                         const float* cs, void* T0, void* T1, void* T2, void* stream);
+/* bgk_pack_dense_h2_t / _many for hidden layers of H0 / H1 <= 128 units (W0 [H0, n_in], W1 [H1, H0], W2 [P, H1]): the transposed operands
+ * of bgk_dense_backward_dx, which runs 128 hidden units -- the others are zero in the operands (round 6: the shift / scale networks
+ * of an affine coupling, P = d).  _many: H0 / H1 may be NULL (128 everywhere). */
+int bgk_pack_mlp_h2_t(const float* W0, int32_t n_in, int32_t H0, const float* W1, int32_t H1, const float* W2, int32_t P,
+                      const float* cs, void* T0, void* T1, void* T2, void* stream);
+int bgk_pack_mlp_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_in, const int32_t* H0, const float* const* W1,
+                           const int32_t* H1, const float* const* W2, const int32_t* P, const float* const* cs,
+                           void* const* T0, void* const* T1, void* const* T2, void* stream);
+
 /* bgk_pack_dense_h2_t for n conditioners in one launch per 16 of them (same results as n single calls) */
 int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_in, const float* const* W1,
                              const float* const* W2, const int32_t* P, const float* const* cs,
@@ -615,6 +666,22 @@ int bgk_dense_weight_grad(const float* g_params, int64_t ldg, int32_t P, const f
 int bgk_dense_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* P, const int32_t* n_in,
                                       float* const* workspace, float* const* gW2, float* const* gb2, float* const* gW1,
                                       float* const* gb1, float* const* gW0, float* const* gb0, int32_t accumulate, void* stream);
+
+/* The general form of bgk_dense_weight_grad (round 6): hidden layers of H1 / H0 <= 128 units whose pre-activations / gradients sit in
+ * arrays of row pitch ldz (the [B, 128] arrays of the fused training forwards); the gradients come out in the parameters' own shapes
+ * gW2 [P, H1], gW1 [H1, H0], gW0 [H0, n_in] -- autograd of nn/dense.py:47-48 for the shift / scale networks of an affine coupling
+ * (nn/flow/transformer/affine.py:35-43), P = d.  Arguments otherwise as bgk_dense_weight_grad; _reduce_many: H1 / H0 may be NULL (128). */
+int64_t bgk_mlp_weight_grad_workspace(int64_t B, int32_t P, int32_t H1, int32_t H0, int32_t n_in);
+int bgk_mlp_weight_grad(const float* g_out, int64_t ldg, int32_t P, const float* g_z1, const float* g_z0,
+                        const float* h1, const float* h0, int64_t ldz, int32_t H1, int32_t H0, int32_t h_act,
+                        const float* cond, int64_t ldc, int32_t d_c, int32_t periodic, int64_t B,
+                        float* workspace, int64_t workspace_floats,
+                        float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
+                        const float* g_absmax, void* stream);
+int bgk_mlp_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* P, const int32_t* H1, const int32_t* H0,
+                                    const int32_t* n_in, float* const* workspace, float* const* gW2, float* const* gb2,
+                                    float* const* gW1, float* const* gb1, float* const* gW0, float* const* gb0,
+                                    int32_t accumulate, void* stream);
 
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).

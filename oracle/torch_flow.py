@@ -240,6 +240,17 @@ def run_block(block, xs, inverse, grad=False):
     if n == "CDFTransform":
         y, dl = cdf_block(block, xs[0], inverse)
         return [y], dl
+    # tuple plumbing of a coupling stack with stock torch ops (differentiable: the KL gradient of cfg 2 passes through them)
+    if n == "MergeFlow":                                                    # InverseFlow(SplitFlow), nn/flow/coupling.py:107-110
+        return run_block(block._delegate, xs, not inverse, grad=grad)
+    if n == "SplitFlow" and block._indices is None:                        # coupling.py:46-57 (sizes; the last may be omitted)
+        zeros = torch.zeros_like(xs[0].narrow(block._split_dim, 0, 1))
+        if inverse:
+            return [torch.cat(list(xs), dim=block._split_dim)], zeros
+        rest = xs[0].shape[block._split_dim] - sum(block._sizes)
+        return list(torch.split(xs[0], list(block._sizes) + ([rest] if rest > 0 else []), dim=block._split_dim)), zeros
+    if n == "SwapFlow":                                                    # coupling.py:113-130
+        return [xs[1], xs[0], *xs[2:]], torch.zeros_like(xs[0][..., :1])
     # everything else (coordinate transforms, split / merge / swap plumbing): the numpy / C oracle
     dt = np.float32 if xs[0].dtype == torch.float32 else np.float64
     ys, dl = fo.run_block(block, [x.numpy() for x in xs], inverse, dt)

@@ -1,0 +1,228 @@
+"""GPU (-m gpu), round 6: affine couplings under autograd on the hand-written kernels -- the one-launch training forward
+(bgk_coupling_affine_dense_h2_train), the tail backward (bgk_affine_backward), the conditioner networks' input-gradient chain
+(bgk_dense_backward_dx) and weight gradients (bgk_mlp_weight_grad) -- against f64 autograd of the reference's op chain
+(oracle/torch_flow.py; reference: nn/flow/transformer/affine.py:35-70, nn/dense.py:30-48, nn/flow/coupling.py:152-182,
+nn/training/trainers.py:156-163).  All kernels are reached through the C ABI (ctypes, bgflow_amd/_lib.py)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_round3 import _make, _prior
+from test_gpu_round4 import _grad_errors
+
+pytestmark = pytest.mark.gpu
+
+
+def _affine_layer(n_c, hidden, d, acts, periodic=False, seed_name="layer", **kw):
+    """CouplingFlow(AffineTransformer(shift, scale)) over two tensors (slot 0 conditions, slot 1 is transformed), hash-initialised"""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    n_in = 2 * n_c if periodic else n_c
+
+    def net(act):
+        n = bg.DenseNet([n_in, *hidden, d], activation=act())
+        return bg.WrapPeriodic(n, indices=np.arange(n_c)) if periodic else n
+    tr = bg.AffineTransformer(shift_transformation=net(acts[0]) if acts[0] else None,
+                              scale_transformation=net(acts[1]) if acts[1] else None, **kw)
+    layer = bg.CouplingFlow(tr, transformed_indices=[1], cond_indices=[0])
+    return hash_init_(bg.SequentialFlow([layer]), scale=1.5)
+
+
+def _f64_layer_grads(flow_cpu, x, y, wy, wl, inverse):
+    """loss = sum(wy * y') + sum(wl * dlogp) through the reference's op chain in f64: gradients w.r.t. x, y and every parameter"""
+    from oracle import torch_flow as tfl
+    for p in flow_cpu.parameters():
+        p.grad = None
+    xs = [x.clone().requires_grad_(True), y.clone().requires_grad_(True)]
+    outs, dl = tfl.run_flow(flow_cpu, xs, inverse=inverse, grad=True)
+    loss = (outs[1] * wy).sum() + (dl * wl).sum()
+    loss.backward()
+    return outs[1].detach(), dl.detach(), xs[0].grad, xs[1].grad, {n: p.grad.clone() for n, p in flow_cpu.named_parameters() if p.grad is not None}
+
+
+SHAPES = [
+    # (n_c, hidden, d, (shift act, scale act), periodic, B)
+    (32, (64, 64), 32, (torch.nn.ReLU, torch.nn.Tanh), False, 1000),          # cfg 2's couplings
+    (17, (128, 128), 66, (torch.nn.SiLU, torch.nn.SiLU), True, 777),          # cfg 5: AUGMENTED | TORSIONS
+    (43, (128, 128), 66, (torch.nn.SiLU, torch.nn.SiLU), False, 4133),        # cfg 5: AUGMENTED | (FIXED, BONDS, ANGLES), concatenated
+    (5, (48, 96), 7, (torch.nn.Tanh, torch.nn.Tanh), False, 33),              # narrow, unequal hidden layers
+    (9, (128, 128), 40, (None, torch.nn.SiLU), False, 65),                    # scale network only
+    (9, (32, 32), 12, (torch.nn.ReLU, None), False, 31),                      # shift network only (NICE)
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"{s[0]}-{'x'.join(map(str, s[1]))}-{s[2]}" + ("-periodic" if s[4] else "") for s in SHAPES])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_coupling_training_layer_against_f64_autograd(hip_lib, dev, shape, inverse):
+    """One affine coupling under autograd: forward values equal the inference kernel's; the gradients w.r.t. the conditioning tensor,
+    the transformed tensor, log_alpha and all twelve weight / bias tensors are those of f64 autograd through the reference's op chain
+    (relative L2 of the flat gradient <= 5e-5: the bound of the spline layers' KL gradient, tests/test_gpu_round4.py)."""
+    from bgflow_amd import dense
+    n_c, hidden, d, acts, periodic, B = shape
+    flow = _affine_layer(n_c, hidden, d, acts, periodic).to(dev)
+    flow_cpu = copy.deepcopy(flow).cpu().double()
+    g = torch.Generator().manual_seed(B + d)
+    x = torch.rand(B, n_c, generator=g, dtype=torch.float64) if periodic else torch.randn(B, n_c, generator=g, dtype=torch.float64)
+    y = torch.randn(B, d, generator=g, dtype=torch.float64)
+    wy = torch.randn(B, d, generator=g, dtype=torch.float64) / B
+    wl = torch.randn(B, 1, generator=g, dtype=torch.float64) / B
+    ref_out, ref_dl, ref_gx, ref_gy, ref_gp = _f64_layer_grads(flow_cpu, x, y, wy, wl, inverse)
+
+    xg, yg = x.float().to(dev).requires_grad_(True), y.float().to(dev).requires_grad_(True)
+    tr = flow[0].transformer
+    _, out, dl = flow(xg, yg, inverse=inverse)
+    assert "_train_cache" in tr.__dict__ and tr._train_cache.get("train_used"), "the layer did not take the fused training path"
+    with torch.no_grad():
+        _, out_inf, dl_inf = flow(xg.detach(), yg.detach(), inverse=inverse)
+    assert torch.equal(out, out_inf) and torch.equal(dl, dl_inf), "training forward and inference kernel disagree"
+    assert float((out.double().cpu() - ref_out).abs().max()) <= 2e-5 * max(1.0, float(ref_out.abs().max()))
+    assert float((dl.double().cpu() - ref_dl).abs().max()) <= 1e-5 * max(1.0, float(ref_dl.abs().max()))
+    ((out * wy.float().to(dev)).sum() + (dl * wl.float().to(dev)).sum()).backward()
+    got = {n: p.grad.double().cpu() for n, p in flow.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref_gp)
+    rel, worst = _grad_errors(got, {n: ref_gp[n] for n in got})
+    print(f"affine training layer {shape[:3]} inverse={inverse}: flat parameter gradient rel L2 {rel:.2e}, worst {worst[1]} {worst[0]:.2e}")
+    assert rel <= 5e-5 and worst[0] <= 3e-4
+    for name, a, b in (("g_x", xg.grad, ref_gx), ("g_y", yg.grad, ref_gy)):
+        err = float((a.double().cpu() - b).norm() / max(float(b.norm()), 1e-30))
+        assert err <= 5e-5, f"{name}: relative L2 {err:.2e}"
+    assert dense.AFFINE_TRAIN
+
+
+def test_affine_training_layer_as_a_library_path_switch(hip_lib, dev):
+    """AFFINE_TRAIN = False is the layer-by-layer path (the A/B leg): same gradients within the two paths' tolerances"""
+    from bgflow_amd import dense
+    flow = _affine_layer(32, (64, 64), 32, (torch.nn.ReLU, torch.nn.Tanh)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x, y = torch.randn(512, 32, device=dev, generator=g), torch.randn(512, 32, device=dev, generator=g)
+
+    def grads():
+        for p in flow.parameters():
+            p.grad = None
+        _, out, dl = flow(x, y)
+        (out.square().mean() - dl.mean()).backward()
+        return {n: p.grad.clone() for n, p in flow.named_parameters()}
+    fused = grads()
+    try:
+        dense.AFFINE_TRAIN = False
+        plain = grads()
+    finally:
+        dense.AFFINE_TRAIN = True
+    rel, worst = _grad_errors(fused, plain)
+    assert rel <= 1e-4, f"fused vs layer-by-layer gradients: {rel:.2e} ({worst})"
+
+
+def test_affine_backward_after_a_parameter_update_raises(hip_lib, dev):
+    """the packed operands are rewritten in place when the weights change: a backward through a graph built on the old ones refuses"""
+    flow = _affine_layer(9, (32, 32), 12, (torch.nn.ReLU, torch.nn.Tanh)).to(dev)
+    x, y = torch.randn(64, 9, device=dev), torch.randn(64, 12, device=dev)
+    _, out, dl = flow(x, y)
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.5)
+    _, out2, _ = flow(x, y)           # re-packs the plan's buffers in place
+    with pytest.raises(RuntimeError, match="changed between the forward and this backward|modified by an inplace operation"):
+        (out.sum() + dl.sum()).backward()
+    out2.sum().backward()
+
+
+def _kl_gradient_cfg2_gpu(gen, z):
+    from bgflow_amd import dp
+    for p in gen.flow.parameters():
+        p.grad = None
+    *x, dlogp = gen.flow(*z)
+    loss = dp.global_kl_mean(gen._target, x, dlogp)
+    loss.backward()
+    return {n: p.grad.detach().cpu().double() for n, p in gen.flow.named_parameters()}, float(loss.detach())
+
+
+def test_kl_gradient_of_cfg2_at_two_to_the_18_against_f64(hip_lib, dev):
+    """BASELINE cfg 2 (8 affine couplings, dim 64, DoubleWellEnergy): the flat KL gradient over 2^18 samples in ONE pass == the mean of
+    the gradients of its 32 chunks (GPU), and the first / last chunk's gradient against f64 autograd of the reference's op chain:
+    relative L2 <= 5e-5 (the verdict's bound), every tensor within 3e-4 of its own norm."""
+    from oracle import torch_flow as tfl
+    B, n_chunks = 1 << 18, 32
+    gen, gen_cpu = _make("cfg2", dev), _make("cfg2").double()
+    z = _prior("cfg2", B, dev)
+    full, loss_full = _kl_gradient_cfg2_gpu(gen, z)
+    assert all(torch.isfinite(v).all() for v in full.values())
+    assert all("_train_cache" in b.transformer.__dict__ for b in gen.flow if hasattr(b, "transformer"))
+    step = B // n_chunks
+    acc, chunk_grads = None, {}
+    for c in range(n_chunks):
+        gc, _ = _kl_gradient_cfg2_gpu(gen, [z[0][c * step:(c + 1) * step]])
+        acc = gc if acc is None else {n: acc[n] + gc[n] for n in gc}
+        if c in (0, n_chunks - 1):
+            chunk_grads[c] = gc
+    report = [("one pass over 2^18 samples vs the mean of 32 chunk gradients", *_grad_errors(full, {n: v / n_chunks for n, v in acc.items()}))]
+    target = gen_cpu._target
+    for c, gc in chunk_grads.items():
+        for p in gen_cpu.flow.parameters():
+            p.grad = None
+        zc = z[0][c * step:(c + 1) * step].cpu().double()
+        xs, dl = tfl.run_flow(gen_cpu.flow, [zc], grad=True)
+        (target.energy(xs[0]) - dl).mean().backward()
+        ref = {n: p.grad.clone() for n, p in gen_cpu.flow.named_parameters()}
+        report.append((f"chunk {c} vs the f64 reference", *_grad_errors(gc, ref)))
+    for what, rel, worst in report:
+        print(f"cfg 2 KL gradient, {what}: relative L2 {rel:.2e}, worst tensor {worst[1]} {worst[0]:.2e} of its norm")
+    for what, rel, worst in report:
+        assert rel <= 5e-5 and worst[0] <= 3e-4, f"{what}: rel L2 {rel:.2e}, {worst[1]} {worst[0]:.2e}"
+
+
+def _device_kernel_names(step):
+    from torch.profiler import ProfilerActivity, profile
+    step(); step()
+    torch.cuda.synchronize()
+    try:
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            step()
+            torch.cuda.synchronize()
+    except Exception as e:          # no kernel tracer on this box
+        pytest.skip(f"torch.profiler unavailable: {e!r}")
+    names = [e.key for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA for _ in range(e.count)]
+    if not names:
+        pytest.skip("torch.profiler recorded no device kernels")
+    return names
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg5"])
+def test_kl_step_of_affine_flows_launches_no_library_gemm(hip_lib, dev, cfg):
+    """A KL training step of BASELINE cfg 2 (8 affine couplings) and cfg 5 (10 spline + 6 affine): no hipBLASLt / rocBLAS GEMM
+    (`Cijk_*`) and no aten activation kernel (silu / tanh / threshold / relu and their backward forms) between the first forward
+    launch and the optimizer -- the conditioners' forward, input-gradient chain and weight gradients are the hand-written kernels."""
+    from bgflow_amd import dp
+    from bgflow_amd.training import FlatAdam
+    gen = _make(cfg, dev)
+    opt = FlatAdam(list(gen.flow.parameters()), lr=1e-5)
+    z = _prior(cfg, 4096, dev)
+
+    def step():
+        opt.zero_grad()
+        *x, dlogp = gen.flow(*z)
+        loss = dp.global_kl_mean(gen._target, x, dlogp, drop_nonfinite=True)
+        opt.backward(loss)
+        opt.step()
+    names = _device_kernel_names(step)
+    bad = [n for n in names if "Cijk_" in n or "gemm" in n.lower() or any(k in n.lower() for k in ("silu", "tanh", "threshold", "relu"))]
+    ours = [n for n in names if "coupling_affine_dense_v2_train_kernel" in n]
+    from collections import Counter
+    print(f"{cfg}: {len(names)} device kernels in one KL step;", dict(Counter(n.split("<")[0].split("(")[0][-60:] for n in names)))
+    assert not bad, f"library / aten kernels in a {cfg} KL step: {sorted(set(bad))}"
+    assert len(ours) == (8 if cfg == "cfg2" else 6), f"{len(ours)} launches of the affine training forward"
+
+
+def test_kl_training_of_cfg2_reduces_the_loss(hip_lib, dev):
+    """KLTrainer on cfg 2 (DoubleWellEnergy, 8 affine couplings): 30 Adam steps on the fused path lower the reverse KL"""
+    from bgflow_amd.training import KLTrainer, FlatAdam
+    gen = _make("cfg2", dev)
+    opt = FlatAdam([p for p in gen.parameters() if p.requires_grad], lr=2e-3)
+    trainer = KLTrainer(gen, optim=opt, train_likelihood=False, train_energy=True)
+    torch.manual_seed(0)
+    trainer.train(30, batchsize=4096)
+    _, _, ys = trainer.losses()
+    kll = ys[0]
+    assert np.isfinite(kll).all() and kll[-5:].mean() < kll[:5].mean() - 0.5, f"KL loss {kll[:5].mean():.3f} -> {kll[-5:].mean():.3f}"
+    assert opt.skipped_steps() == 0
