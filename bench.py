@@ -178,6 +178,51 @@ def flow_pass(gen, zsets, inverse=False):
     return run
 
 
+def kl_side_leg(name, dev, batch, steps):
+    """KL-loss training steps of BASELINE cfg 2 / cfg 5 on this rank (round 6: their affine couplings train on the hand-written kernels --
+    bgk_coupling_affine_dense_h2_train forward, bgk_affine_backward + bgk_dense_backward_dx + bgk_mlp_weight_grad backward).  One step =
+    zero_grad -> flow forward -> target energy with the [sum, n] loss sums -> backward -> FlatAdam step; HIP-event timed; with
+    BGK_BENCH_AB=1 the same step once more with the affine couplings on the layer-by-layer / library-GEMM path of rounds 1 - 5."""
+    from bgflow_amd import dense, dp
+    from bgflow_amd.training import FlatAdam
+    gen, sampler, desc = make_workload(name, dev)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    zks = [sampler(batch, g) for _ in range(N_INPUT_SETS)]
+    opt = FlatAdam(list(gen.flow.parameters()), lr=1e-5)
+    last, k = [None], [0]
+
+    def step():
+        z = zks[k[0] % len(zks)]
+        k[0] += 1
+        opt.zero_grad()
+        *x, dlogp = gen.flow(*z)
+        loss = dp.global_kl_mean(gen._target, x, dlogp, drop_nonfinite=True)
+        opt.backward(loss)
+        opt.allreduce_gradients()
+        opt.step()
+        last[0] = loss
+    step()
+    torch.cuda.synchronize(dev)
+    ms = event_ms_per_call(step, steps, 1)
+    out = dict(workload=desc, steps_per_s=1e3 / ms, samples_per_s=batch * 1e3 / ms, ms_per_step=ms, batch=batch, steps=steps, timer="HIP events",
+               loss=float(last[0].detach()), skipped_steps=opt.skipped_steps(),
+               note="affine couplings: one-launch training forward (both conditioner networks on the f16 matrix cores + the affine tail; saves the "
+                    "hidden layers' pre-activations and the networks' outputs), backward = bgk_affine_backward + per network bgk_dense_backward_dx + "
+                    "bgk_mlp_weight_grad; no library GEMM, no aten activation kernel in the step")
+    if os.environ.get("BGK_BENCH_AB") == "1":
+        try:
+            dense.AFFINE_TRAIN = False
+            step()
+            torch.cuda.synchronize(dev)
+            ms0 = event_ms_per_call(step, max(2, steps // 2), 1)
+            out["layer_by_layer_path"] = dict(ms_per_step=ms0, steps_per_s=1e3 / ms0,
+                                              note="AFFINE_TRAIN = False: conditioners layer by layer, backward through F.linear / bmm (hipBLASLt) + aten "
+                                                   "activation kernels -- the path of rounds 1 - 5")
+        finally:
+            dense.AFFINE_TRAIN = True
+    return out
+
+
 def measured_traffic(kernel, batch):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/<round>_traffic.json, written by
     tools/profile_round.sh: FETCH_SIZE x 2 [gfx950 rule] + WRITE_SIZE), scaled to the batch, or (None, None)"""
@@ -746,6 +791,20 @@ def main():
                 raise
             kl = dict(error=repr(e)[:300])
 
+    # ---- extra: the KL step of the configs with affine couplings (BASELINE configs[1] at 2^20, configs[4] at 2^18)
+    kl_cfg2 = kl_cfg5 = None
+    if args.kl_steps > 0 and args.workload == "cfg3" and solo and not args.no_extras:
+        for nm, bt in (("cfg2", 1 << 20), ("cfg5", 1 << 18)):
+            try:
+                leg = kl_side_leg(nm, dev, bt, max(2, args.kl_steps // 2))
+            except Exception as e:      # a side measurement must never take the headline line down
+                leg = dict(error=repr(e)[:300])
+            if nm == "cfg2":
+                kl_cfg2 = leg
+            else:
+                kl_cfg5 = leg
+            torch.cuda.empty_cache()
+
     total_samples = args.batch * world * args.steps
     value = total_samples / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -855,6 +914,10 @@ def main():
             out["cfg5"] = cfg5
         if kl is not None:
             out["kl"] = kl
+        if kl_cfg2 is not None:
+            out["kl_cfg2"] = kl_cfg2
+        if kl_cfg5 is not None:
+            out["kl_cfg5"] = kl_cfg5
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -76,7 +76,10 @@ def test_affine_coupling_training_layer_against_f64_autograd(hip_lib, dev, shape
     assert "_train_cache" in tr.__dict__ and tr._train_cache.get("train_used"), "the layer did not take the fused training path"
     with torch.no_grad():
         _, out_inf, dl_inf = flow(xg.detach(), yg.detach(), inverse=inverse)
-    assert torch.equal(out, out_inf) and torch.equal(dl, dl_inf), "training forward and inference kernel disagree"
+    if hidden[0] == hidden[1]:       # (unequal hidden widths: inference runs layer by layer, another summation order)
+        assert torch.equal(out, out_inf) and torch.equal(dl, dl_inf), "training forward and inference kernel disagree"
+    else:
+        assert torch.allclose(out, out_inf, rtol=1e-5, atol=1e-5) and torch.allclose(dl, dl_inf, rtol=1e-5, atol=1e-5)
     assert float((out.double().cpu() - ref_out).abs().max()) <= 2e-5 * max(1.0, float(ref_out.abs().max()))
     assert float((dl.double().cpu() - ref_dl).abs().max()) <= 1e-5 * max(1.0, float(ref_dl.abs().max()))
     ((out * wy.float().to(dev)).sum() + (dl * wl.float().to(dev)).sum()).backward()
