@@ -31,7 +31,9 @@ _SIGNATURES = {
                                            vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp]),
     "bgk_coupling_affine_dense_h2_train": (ctypes.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32,
                                                           vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32,
-                                                          vp, vp, vp, vp, vp, vp, i64, vp]),
+                                                          vp, vp, vp, vp, i64, vp, vp, i64, vp]),
+    "bgk_mlp_backward_dx": (ctypes.c_int, [vp, i64, i32, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, i32, i64,
+                                           vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp]),
     "bgk_pack_mlp_h2": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "bgk_pack_mlp_h2_many": (ctypes.c_int, [i32] + [vp] * 17 + [vp]),
     "bgk_pack_mlp_h2_t": (ctypes.c_int, [vp, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
@@ -126,6 +128,7 @@ _SIGNATURES = {
     "bgk_dense_layer": (ctypes.c_int, [vp, i64, i64, i32, vp, i32, f32, vp, vp, i32, i32, vp, i64, i32, vp]),
     "bgk_pack_linear_layer": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp]),
     "bgk_dense_layer_steps": (ctypes.c_int, [i32]),
+    "bgk_refresh_linear_layer": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp, vp]),
 }
 
 ABI_SYMBOLS = tuple(_SIGNATURES)

@@ -77,15 +77,18 @@ __device__ __forceinline__ void act_grad2(int act, bgk_f2 z, bgk_f2 g, bgk_f2& g
  * full rows through the LDS slab.  All sixteen z requests go out BEFORE the arithmetic (64 registers): left to the compiler
  * they were issued a few at a time between the activation code, one exposed memory round trip after the other -- 50 k of the
  * 170 k cycles a wave lived (s_memtime stamps, -DBGK_SBD_TS=1), 19 k with the requests up front. */
+/* ZT: tiles of 32 hidden units the z / g_z / h arrays hold per row (row pitch 32 ZT floats; 4 = the [B, 128] arrays of the spline layers,
+ * 2 = [B, 64]: an affine coupling's 64-unit networks); the tiles past ZT belong to units that do not exist: their gradient is 0 */
+template <int ZT>
 __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, int act, const float* z, float* gz_out, float* h_out,
                                                    float* s_buf, int64_t b0, int lane, int rows, int tsb = 22) {
     float* const s_f = s_buf;
     (void)s_f; (void)tsb;
     const int j = lane & 31, hh = lane >> 5;
-    const int64_t row = (b0 + (j < rows ? j : 0)) * 128;
-    float4 zall[16];
+    const int64_t row = (b0 + (j < rows ? j : 0)) * (32 * ZT);
+    float4 zall[4 * ZT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < ZT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) zall[4 * m + q] = *reinterpret_cast<const float4*>(z + row + 32 * m + 8 * q + 4 * hh);
     __builtin_amdgcn_sched_barrier(0);
@@ -94,7 +97,11 @@ __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, i
     SBD_TS(tsb);
 #endif
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = ZT; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[m][r] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < ZT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 zz = zall[4 * m + q];
@@ -110,7 +117,7 @@ __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, i
     if (h_out) {      /* the activations themselves (NULL: the weight-gradient kernel recomputes act(z) while loading z) */
         h2_f32x16 hv[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < ZT; ++m) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 hv[m][4 * q] = zall[4 * m + q].x; hv[m][4 * q + 1] = zall[4 * m + q].y;
@@ -118,9 +125,9 @@ __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, i
             }
             h2_act_tile(hv[m], 1.0f, act);
         }
-        h2_store_rows128(hv, h_out, s_buf, b0, rows, lane);
+        h2_store_rows<ZT>(hv, h_out, s_buf, b0, rows, lane);
     }
-    h2_store_rows128(t, gz_out, s_buf, b0, rows, lane);
+    h2_store_rows<ZT>(t, gz_out, s_buf, b0, rows, lane);
 #if BGK_SBD_TS || (BGK_DBWD_DRAIN & 2)
     SBD_TS(tsb + 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -132,11 +139,11 @@ __device__ __forceinline__ void act_backward_tiles(h2_f32x16 (&t)[4], float c, i
  * The gradient tiles that feed the next GEMM are split into f16 hi + lo parts under a power-of-two scale taken from the TILE's own
  * largest magnitude (a wave-wide maximum: 32 v_max3 + 6 cross-lane steps per GEMM): whatever the loss scale and the batch size
  * (g ~ 1 / B), every product carries 22 significant bits like the forward's.  inv_g: reciprocal of the first GEMM's scale. */
-template <int FT>
+template <int FT, int ZT>
 __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (&acc)[4], float inv_g, float* s_f, int64_t b0, int lane, int rows) {
     const int j = lane & 31, hh = lane >> 5;
     const float c2 = a.cs[5], c1 = a.cs[3], c0 = a.cs[1];
-    act_backward_tiles(acc, c2 * inv_g, a.act, a.z1, a.g_z1, a.h1, s_f, b0, lane, rows);
+    act_backward_tiles<ZT>(acc, c2 * inv_g, a.act, a.z1, a.g_z1, a.h1, s_f, b0, lane, rows);
     SBD_TS(19);
 
     /* ---- g_h0 = W1^T g_z1 ---- */
@@ -156,7 +163,7 @@ __device__ __forceinline__ void dx_chain_tail(const DenseBwdArgs& a, h2_f32x16 (
     asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][15]));
 #endif
     SBD_TS(20);
-    act_backward_tiles(acc, c1 * inv1, a.act, a.z0, a.g_z0, a.h0, s_f, b0, lane, rows, 26);
+    act_backward_tiles<ZT>(acc, c1 * inv1, a.act, a.z0, a.g_z0, a.h0, s_f, b0, lane, rows, 26);
     SBD_TS(21);
     {
         const float m0 = h2_wave_absmax<4>(acc);
@@ -230,7 +237,7 @@ __device__ __forceinline__ void dx_frag_get(const DxFrag& f, H2A<4>& h) {
         for (int pp = 0; pp < 2; ++pp) h.v[m][pp] = make_uint4(f.r[m][pp][0], f.r[m][pp][1], f.r[m][pp][2], f.r[m][pp][3]);
 }
 
-template <int FT>
+template <int FT, int ZT = 4>
 __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* uniform: buffer descriptor in SGPRs */
@@ -451,12 +458,12 @@ __global__ __launch_bounds__(DW * 64, 8 / DW) void dense_bwd_dx_kernel(DenseBwdA
     if (lane == 0) reinterpret_cast<unsigned*>(s_f)[0 * H2_SLAB + 130] = ts0;
 #endif
     SBD_TS(14);
-    dx_chain_tail<FT>(a, acc, inv_sg, s_f, b0, lane, rows);
+    dx_chain_tail<FT, ZT>(a, acc, inv_sg, s_f, b0, lane, rows);
 #if BGK_SBD_TS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SBD_TS(15);
     if (lane == 0)
-        for (int k = 0; k < 32; ++k) reinterpret_cast<unsigned*>(a.g_z0)[b0 * 128 + k] = reinterpret_cast<unsigned*>(s_f)[k * H2_SLAB + 130];
+        for (int k = 0; k < 32; ++k) reinterpret_cast<unsigned*>(a.g_z0)[b0 * (32 * ZT) + k] = reinterpret_cast<unsigned*>(s_f)[k * H2_SLAB + 130];
 #endif
 }
 
@@ -589,16 +596,18 @@ extern "C" int bgk_pack_mlp_h2_t(const float* W0, int32_t n_in, int32_t H0, cons
     return bgk_launch_status("bgk_pack_mlp_h2_t");
 }
 
-extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,
-                                     const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
-                                     const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
-                                     int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
-                                     float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
-                                     const float* g_absmax, float* gz_absmax, void* stream) {
+/* ldz: row pitch of z1 / z0 / g_z1 / g_z0 / h1 / h0 -- 128, or 64 for networks whose hidden layers have <= 64 units (the operands'
+ * other units are zero: bgk_pack_mlp_h2_t) */
+extern "C" int bgk_mlp_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0, int64_t ldz,
+                                   const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                   const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
+                                   int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
+                                   float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                                   const float* g_absmax, float* gz_absmax, void* stream) {
     if (B == 0) return 0;       /* an empty batch: nothing to do (its tensors have no storage, hence null pointers) */
     BGK_CHECK_ARG(g && z1 && z0 && T0 && T1 && T2 && cs && g_z1 && g_z0, "bgk_dense_backward_dx: null pointer");
     BGK_CHECK_ARG((h1 == nullptr) == (h0 == nullptr), "bgk_dense_backward_dx: h1 and h0 are written both or not at all");
-    BGK_CHECK_ARG(B >= 0 && P > 0 && ldg >= P && d_c > 0 && act >= 1 && act <= 3, "bgk_dense_backward_dx: bad sizes");
+    BGK_CHECK_ARG(B >= 0 && P > 0 && ldg >= P && d_c > 0 && act >= 1 && act <= 3 && (ldz == 128 || ldz == 64), "bgk_dense_backward_dx: bad sizes (ldz: 64 | 128)");
     BGK_CHECK_ARG(!(g_cond && periodic && !cond), "bgk_dense_backward_dx: the periodic featuriser needs the conditioner input");
     const int n_in = periodic ? 2 * d_c : d_c;
     if (n_in > 96) { bgk_set_error("bgk_dense_backward_dx: %d input features > 96", n_in); return BGK_EUNSUPPORTED; }
@@ -618,11 +627,23 @@ extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, con
     const int64_t n_wg = ((B + 31) / 32 + DW - 1) / DW;
     BGK_CHECK_ARG(n_wg < (int64_t)0x7fffffff, "bgk_dense_backward_dx: batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-#define BGK_LAUNCH_DX(F) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_bwd_dx_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL(dense_bwd_dx_kernel<F>, dim3((int)n_wg), dim3(DW * 64), shmem, st, a); } while (0)
+#define BGK_LAUNCH_DXZ(F, Z) do { if (shmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_bwd_dx_kernel<F, Z>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((dense_bwd_dx_kernel<F, Z>), dim3((int)n_wg), dim3(DW * 64), shmem, st, a); } while (0)
+#define BGK_LAUNCH_DX(F) do { if (ldz == 64) BGK_LAUNCH_DXZ(F, 2); else BGK_LAUNCH_DXZ(F, 4); } while (0)
     if (FT == 1) BGK_LAUNCH_DX(1);
     else if (FT == 2) BGK_LAUNCH_DX(2);
     else BGK_LAUNCH_DX(3);
 #undef BGK_LAUNCH_DX
+#undef BGK_LAUNCH_DXZ
     return bgk_launch_status("bgk_dense_backward_dx");
+}
+
+extern "C" int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,
+                                     const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                                     const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
+                                     int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
+                                     float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                                     const float* g_absmax, float* gz_absmax, void* stream) {
+    return bgk_mlp_backward_dx(g, ldg, P, z1, z0, 128, cond, ldc, d_c, periodic, T0, T1, T2, cs, act, B, g_z1, g_z0, h1, h0, g_cond, ldgc,
+                               g_cond_add, ldga, g_absmax, gz_absmax, stream);
 }

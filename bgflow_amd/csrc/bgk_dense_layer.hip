@@ -261,6 +261,68 @@ __global__ __launch_bounds__(256) void layer_pack_kernel(const float* W, int64_t
     out[t] = *reinterpret_cast<const uint4*>(o);
 }
 
+/* Packed operands that follow the weights without a host-side version key (round 6): ONE workgroup reads the column block, forms a
+ * 64-bit fingerprint of its bit patterns (sum over elements of a per-position mix: any changed element changes it, up to a 2^-64
+ * collision) and its largest magnitude; equal to the fingerprint stored with the operands -> done; otherwise it re-packs the block
+ * itself (the arithmetic of layer_max_kernel + layer_pack_kernel) and stores the new fingerprint.  A launch of a few microseconds in
+ * front of every bgk_dense_layer call replaces a cache keyed on (data_ptr, torch's version counter), which updates through `.data`,
+ * old-style optimizers or kernels writing through a view do not bump: stale weights, silently. */
+__global__ __launch_bounds__(1024) void layer_refresh_kernel(const float* W, int64_t ldw, int n_out, int n_in, int S, int G, uint4* out, float* cs,
+                                                             unsigned long long* state) {
+    __shared__ unsigned long long s_fp[16];
+    __shared__ float s_m[16];
+    __shared__ int s_same;
+    const int tid = threadIdx.x;
+    const int64_t n = (int64_t)n_out * n_in;
+    unsigned long long fp = 0ull;
+    float m = 0.0f;
+    for (int64_t i = tid; i < n; i += 1024) {
+        const int64_t r = i / n_in;
+        const float v = W[r * ldw + (i - r * n_in)];
+        unsigned long long x = ((unsigned long long)__builtin_bit_cast(unsigned, v) + 0x9E3779B9ull) * (unsigned long long)(2 * i + 1);
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        fp += x;
+        m = fmaxf(m, fabsf(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) { fp += __shfl_xor(fp, off); m = fmaxf(m, __shfl_xor(m, off)); }
+    if ((tid & 63) == 0) { s_fp[tid >> 6] = fp; s_m[tid >> 6] = m; }
+    __syncthreads();
+    if (tid == 0) {
+        fp = 0ull; m = 0.0f;
+        for (int w = 0; w < 16; ++w) { fp += s_fp[w]; m = fmaxf(m, s_m[w]); }
+        if (!(m < 3.0e38f)) m = 3.4e38f;
+        s_same = state[1] == 1ull && state[0] == fp;
+        if (!s_same) { state[0] = fp; state[1] = 1ull; cs[0] = m; }
+        s_m[0] = m;
+    }
+    __syncthreads();
+    if (s_same) return;
+    m = s_m[0];
+    int e = 0;
+    if (m > 0.0f && m < 3.0e38f) {
+        e = (int)floorf(log2f(32768.0f / m));
+        e = e < -16 ? -16 : (e > 24 ? 24 : e);
+    }
+    const float scale = ldexpf(1.0f, e);
+    if (tid == 0) cs[1] = ldexpf(1.0f, -e);
+    for (int64_t t = tid; t < (int64_t)G * S * 8 * 64; t += 1024) {
+        const int lane = (int)(t & 63), blk = (int)(t >> 6);
+        const int i = lane & 31, kb = lane >> 5;
+        const int p = blk & 1, mt = (blk >> 1) & 3, s = (blk >> 3) % S, g = (blk >> 3) / S;
+        const int row = 128 * g + 32 * mt + i;
+        uint16_t o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = 16 * s + 8 * kb + q;
+            const float v = (row < n_out && k < n_in) ? W[(int64_t)row * ldw + k] * scale : 0.0f;
+            const _Float16 h = (_Float16)v;
+            const _Float16 r = p ? (_Float16)(v - (float)h) : h;
+            o[q] = __builtin_bit_cast(uint16_t, r);
+        }
+        out[t] = *reinterpret_cast<const uint4*>(o);
+    }
+}
+
 template <int S>
 int launch_layer(const LayerArgs& a, hipStream_t st) {
     constexpr int XS = 16 * S + 4, YS = 128 + 4;
@@ -293,6 +355,15 @@ extern "C" int bgk_pack_linear_layer(const float* W, int64_t ldw, int32_t n_out,
     hipLaunchKernelGGL(layer_pack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, W, ldw, n_out, n_in, S, G,
                        reinterpret_cast<uint4*>(Ap), cs);
     return bgk_launch_status("bgk_pack_linear_layer");
+}
+
+extern "C" int bgk_refresh_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_in, void* Ap, float* cs, void* state, void* stream) {
+    BGK_CHECK_ARG(W && Ap && cs && state && n_out > 0 && n_in > 0 && n_in <= 256 && ldw >= n_in, "bgk_refresh_linear_layer: bad arguments (a column block of at most 256)");
+    BGK_CHECK_ARG(((uintptr_t)Ap & 15) == 0 && ((uintptr_t)state & 7) == 0, "bgk_refresh_linear_layer: the operand buffer must be 16-byte, the state 8-byte aligned");
+    const int S = bgk_dense_layer_steps(n_in), G = (n_out + 127) / 128;
+    hipLaunchKernelGGL(layer_refresh_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, W, ldw, n_out, n_in, S, G, reinterpret_cast<uint4*>(Ap), cs,
+                       reinterpret_cast<unsigned long long*>(state));
+    return bgk_launch_status("bgk_refresh_linear_layer");
 }
 
 extern "C" int bgk_dense_layer(const float* x, int64_t ldx, int64_t B, int32_t n_in, const void* Ap, int32_t S, float c, const float* c_dev,

@@ -54,9 +54,10 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
                                float* out, int64_t ldo, float* dlogp, int32_t accumulate, void* stream, const BgkCondSegs* segs = nullptr);
 
 /* the training forward of the affine layer (bgk_fused2_afftrain.hip): the same kernel (two hidden layers) + what the backward reads --
- * per network the scaled pre-activations z0, z1 [B, 128] and its output rows (mu; the scale values before tanh) [B, ldms];
+ * per network the scaled pre-activations z0, z1 [B, ldz] and its output rows (mu; the scale values before tanh) [B, ldms];
  * s_cs / t_cs: device scale tables of the packed operands (NULL: the c values of the call) */
-struct BgkAffTrainSave { const float* s_cs; float* s_z0; float* s_z1; const float* t_cs; float* t_z0; float* t_z1; float* mu; float* s_raw; int64_t ldms; };
+struct BgkAffTrainSave { const float* s_cs; float* s_z0; float* s_z1; const float* t_cs; float* t_z0; float* t_z1; float* mu; float* s_raw; int64_t ldms;
+                         int64_t ldz; };      /* row pitch of the z arrays: 128, or 64 when every hidden layer has <= 64 units */
 int bgk_launch_affine_dense_v2_train(const BgkAffTrainSave* save, const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                                const void* sA0, const void* sA1, const void* sA1b, const void* sA2, float sc0, float sc1, float sc1b, float sc2, int32_t s_act,
                                const void* tA0, const void* tA1, const void* tA1b, const void* tA2, float tc0, float tc1, float tc1b, float tc2, int32_t t_act,

@@ -1268,6 +1268,7 @@ struct AffV2Args {
 #if BGK_V2_AFFTRAIN
     float* mu_out; float* s_out; int64_t ldms;     /* the networks' outputs [B, ldms] (ldms = 32 OT): shift values, scale values before tanh */
     int slab;                                      /* float offset of the 16-row store slab [16][32] inside the wave's conditioner-tile slice */
+    int zt;                                        /* 32-unit tiles per row of the z arrays: 4 ([B, 128]) or 2 ([B, 64]: hidden layers of <= 64 units) */
 #endif
 };
 
@@ -1303,7 +1304,7 @@ __device__ __forceinline__ void aff_store_tiles(const f32x16 (&t)[4], float* dst
             __builtin_amdgcn_wave_barrier();
         }
 }
-struct AffSave { float* slab; int64_t b0; int rows, lane; };
+struct AffSave { float* slab; int64_t b0; int rows, lane, zt; };      /* zt: tiles of a hidden layer that leave (2: [B, 64] arrays, 4: [B, 128]) */
 #endif
 
 /* layer 0: X = A0' * [features; 1] (l0_step); the A fragments of k-step s + 1 are requested before the MFMAs of k-step s (two fragment
@@ -1332,7 +1333,9 @@ __device__ __forceinline__ void aff_layer0(const AffV2Net& n, int S0, const floa
 #if BGK_V2_AFFTRAIN
 #define AFF_SAVE_PARAMS , float* zdst, const AffSave& sv
 #define AFF_SAVE_Z(X) do { _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) X[m_][r_] *= c; \
-                           aff_store_tiles<4>(X, zdst, 128, sv.slab, sv.b0, sv.rows, sv.lane); c = 1.0f; } while (0)
+                           if (sv.zt == 2) aff_store_tiles<2>(X, zdst, 64, sv.slab, sv.b0, sv.rows, sv.lane); \
+                           else aff_store_tiles<4>(X, zdst, 128, sv.slab, sv.b0, sv.rows, sv.lane); \
+                           c = 1.0f; } while (0)
 #else
 #define AFF_SAVE_PARAMS
 #define AFF_SAVE_Z(X) do { } while (0)
@@ -1447,7 +1450,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
     f32x16 (&mu)[4] = DEEP ? acc : h;
     f32x16 (&t0)[4] = DEEP ? h : acc;          /* the scale network's layer-0 output: the array that does not hold mu */
 #if BGK_V2_AFFTRAIN
-    const AffSave sv{s_p + a.slab, b0, rows, lane};
+    const AffSave sv{s_p + a.slab, b0, rows, lane, a.zt};
     if (a.has_shift) {
         aff_layer0(a.shift, a.S0, s_p, nfs, n_in, lane, j, hh, h, fa, true);
         aff_layers<ACT_S, OT, DEEP>(a.shift, h, acc, bf, ring, voff, sv);
@@ -1938,7 +1941,7 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
 #if BGK_V2_AFFTRAIN
     a.shift = AffV2Net{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA1b, (const uint4*)sA2, sc0, sc1, sc1b, sc2, save->s_cs, save->s_z0, save->s_z1};
     a.scale = AffV2Net{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA1b, (const uint4*)tA2, tc0, tc1, tc1b, tc2, save->t_cs, save->t_z0, save->t_z1};
-    a.mu_out = save->mu; a.s_out = save->s_raw; a.ldms = save->ldms;
+    a.mu_out = save->mu; a.s_out = save->s_raw; a.ldms = save->ldms; a.zt = save->ldz == 64 ? 2 : 4;
 #else
     a.shift = AffV2Net{(const uint4*)sA0, (const uint4*)sA1, (const uint4*)sA1b, (const uint4*)sA2, sc0, sc1, sc1b, sc2};
     a.scale = AffV2Net{(const uint4*)tA0, (const uint4*)tA1, (const uint4*)tA1b, (const uint4*)tA2, tc0, tc1, tc1b, tc2};
@@ -1949,6 +1952,7 @@ int bgk_launch_affine_dense_v2(const float* cond, int64_t ldc, int32_t d_c, int3
     if (deep) return BGK_EUNSUPPORTED;
     BGK_CHECK_ARG((!a.has_shift || (save->s_z0 && save->s_z1 && save->mu)) && (!a.has_scale || (save->t_z0 && save->t_z1 && save->s_raw)),
                   "%s: null save buffer", what);
+    BGK_CHECK_ARG(save->ldz == 64 || save->ldz == 128, "%s: ldz = %lld (64 | 128)", what, (long long)save->ldz);
     BGK_CHECK_ARG(save->ldms >= 32 * ((d + 31) / 32) && save->ldms % 4 == 0 && save->ldms < (1 << 20), "%s: ldms = %lld (a multiple of 4, >= 32 ceil(d / 32))",
                   what, (long long)save->ldms);
 #endif

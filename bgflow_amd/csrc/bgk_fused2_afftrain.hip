@@ -1,6 +1,6 @@
 /* bgk_fused2_afftrain.hip -- training forward of the one-launch AFFINE coupling layer (round 6): coupling_affine_dense_v2_kernel
  * (bgk_fused2.hip compiled with BGK_V2_AFFTRAIN = 1) -- same arithmetic and MFMA event threading as the inference kernel, and in
- * addition it writes what the hand-written backward reads: per conditioner network the scaled pre-activations z0, z1 [B, 128] of
+ * addition it writes what the hand-written backward reads: per conditioner network the scaled pre-activations z0, z1 [B, 64 | 128] of
  * its two hidden layers (for bgk_dense_backward_dx / bgk_mlp_weight_grad) and its output rows -- the shift values mu and the scale
  * values before tanh (for bgk_affine_backward).  Replaces, under autograd, CouplingFlow._forward (nn/flow/coupling.py:162-182) around
  * AffineTransformer (nn/flow/transformer/affine.py:35-70) with DenseNet conditioners (nn/dense.py:30-48): before round 6 every
@@ -14,8 +14,8 @@ extern "C" int bgk_coupling_affine_dense_h2_train(const float* const* cond, cons
                                                   const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                                                   const float* y, int64_t ldy, int64_t B, int32_t d, float* out, int64_t ldo,
                                                   float* dlogp, int32_t accumulate,
-                                                  float* s_z0, float* s_z1, float* t_z0, float* t_z1, float* mu, float* s_raw, int64_t ldms,
-                                                  void* stream) {
+                                                  float* s_z0, float* s_z1, float* t_z0, float* t_z1, int64_t ldz,
+                                                  float* mu, float* s_raw, int64_t ldms, void* stream) {
     if (B == 0) return 0;
     const char* what = "bgk_coupling_affine_dense_h2_train";
     BGK_CHECK_ARG(cond && ldc && width && n_cond >= 1 && n_cond <= BGK_MAX_COND, "%s: 1 .. %d conditioning tensors", what, BGK_MAX_COND);
@@ -28,7 +28,7 @@ extern "C" int bgk_coupling_affine_dense_h2_train(const float* const* cond, cons
     segs.n = n_cond;
     const int n_in = periodic ? 2 * d_c : d_c;
     if (n_in > 127) { bgk_set_error("%s: %d input features > 127", what, n_in); return BGK_EUNSUPPORTED; }
-    const BgkAffTrainSave save{s_cs, s_z0, s_z1, t_cs, t_z0, t_z1, mu, s_raw, ldms};
+    const BgkAffTrainSave save{s_cs, s_z0, s_z1, t_cs, t_z0, t_z1, mu, s_raw, ldms, ldz};
     return bgk_launch_affine_dense_v2_train(&save, cond[0], ldc[0], d_c, periodic,
                                             sA0, sA1, nullptr, sA2, 1.0f, 1.0f, 1.0f, 1.0f, s_act,
                                             tA0, tA1, nullptr, tA2, 1.0f, 1.0f, 1.0f, 1.0f, t_act,

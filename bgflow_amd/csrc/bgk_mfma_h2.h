@@ -216,4 +216,28 @@ __device__ __forceinline__ void h2_store_rows128(const h2_f32x16 (&t)[4], float*
     __builtin_amdgcn_wave_barrier();
 }
 
+/* the same for the first ZT tiles only, into rows of 32 ZT floats (hidden layers of <= 32 ZT units: the arrays of an affine coupling's
+ * 64-unit networks are [B, 64] -- half the bytes of the padded form); every store instruction covers 64 / (8 ZT) complete rows */
+template <int ZT>
+__device__ __forceinline__ void h2_store_rows(const h2_f32x16 (&t)[4], float* dst, float* s_buf, int64_t b0, int rows, int lane) {
+    if constexpr (ZT == 4) { h2_store_rows128(t, dst, s_buf, b0, rows, lane); return; }
+    const int j = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < ZT; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(s_buf + j * H2_SLAB + 32 * m + 8 * q + 4 * hh) =
+                make_float4(t[m][4 * q], t[m][4 * q + 1], t[m][4 * q + 2], t[m][4 * q + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4 * ZT; ++it) {
+        const int i = it * 64 + lane, r = i / (8 * ZT), q4 = i % (8 * ZT);
+        const float4 v = *reinterpret_cast<const float4*>(s_buf + r * H2_SLAB + 4 * q4);
+        if (r < rows) *reinterpret_cast<float4*>(dst + (b0 + r) * (32 * ZT) + 4 * q4) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 #endif /* BGK_MFMA_H2_H */

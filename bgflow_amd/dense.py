@@ -125,14 +125,34 @@ def pack_linear_layer_device(weight):
 
 
 def _layer_operands(lin):
-    """packed operands of a Linear module, re-packed when its weight changes (keyed on the parameter's state)"""
-    key = (param_state_key(lin.weight), lin.weight.device)
+    """Packed operands of a Linear module that follow its weight ON THE DEVICE (round 6): the buffers are allocated once per (shape,
+    device); every call launches bgk_refresh_linear_layer per column block, which fingerprints the live weight and re-packs the block
+    only when it changed.  No host-side version key: an update torch's version counter does not see (``p.data.mul_(2)``, an old-style
+    optimizer, a kernel writing through a view of the parameter) is picked up like any other -- what ``torch.nn.Linear`` does, since it
+    reads the parameter itself.  Passes: (A, S, cs, k0, k1)."""
+    Wp = lin.weight
+    W = Wp.detach() if Wp.stride(1) == 1 else Wp.detach().contiguous()
+    assert W.is_cuda and W.dtype == torch.float32 and W.dim() == 2
+    n_out, n_in = W.shape
+    key = (n_out, n_in, W.device)
     cached = lin.__dict__.get("_bgk_layer_ops")
     if cached is None or cached[0] != key:
-        W = lin.weight if lin.weight.stride(1) == 1 else lin.weight.contiguous()
-        cached = (key, pack_linear_layer_device(W))
+        G = (n_out + 127) // 128
+        passes = []
+        for k0 in range(0, n_in, 256):
+            k1 = min(n_in, k0 + 256)
+            S = int(_lib.lib().bgk_dense_layer_steps(k1 - k0))
+            passes.append((torch.empty((G * S * 8, 64, 8), dtype=torch.float16, device=W.device), S,
+                           torch.zeros(2, dtype=torch.float32, device=W.device), k0, k1,
+                           torch.zeros(2, dtype=torch.int64, device=W.device)))
+        cached = (key, passes)
         lin.__dict__["_bgk_layer_ops"] = cached
-    return cached[1]
+    with torch.cuda.device(W.device):
+        for A, _S, cs, k0, k1, state in cached[1]:
+            st = _lib.lib().bgk_refresh_linear_layer(W.data_ptr() + 4 * k0, W.stride(0), n_out, k1 - k0, _lib.ptr(A), _lib.ptr(cs), _lib.ptr(state),
+                                                     _lib.stream_ptr(W.device))
+            _lib.check(st, "bgk_refresh_linear_layer")
+    return [p[:5] for p in cached[1]]
 
 
 def dense_layer(x, lin, act=0):
@@ -160,7 +180,9 @@ def dense_layer(x, lin, act=0):
 
 
 def _on_layer_kernel(m, x):
-    return (LAYER_KERNEL and type(m) is torch.nn.Linear and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1
+    # (a Linear with forward / pre-forward hooks -- old-style weight_norm, activation capture -- runs as the module itself: m(x))
+    return (LAYER_KERNEL and type(m) is torch.nn.Linear and not m._forward_hooks and not m._forward_pre_hooks
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 1
             and m.weight.dtype == torch.float32 and m.weight.device == x.device and m.in_features > 0
             and (m.bias is None or m.bias.dtype == torch.float32))
 
@@ -176,7 +198,8 @@ def _run_layers(layers, x):
         if _on_layer_kernel(m, x):
             needs = grad and (x.requires_grad or m.weight.requires_grad or (m.bias is not None and m.bias.requires_grad))
             if not needs:
-                act = _LAYER_ACTS.get(type(mods[i + 1]), 0) if i + 1 < len(mods) else 0
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                act = _LAYER_ACTS.get(type(nxt), 0) if nxt is not None and not nxt._forward_hooks and not nxt._forward_pre_hooks else 0
                 x = dense_layer(x, m, act)
                 i += 2 if act else 1
                 continue
@@ -1661,7 +1684,9 @@ def _affine_train_plan(transformer, y_dim, dev):
             entries.append(dict(lins=sp[0], act=sp[1], H0=sp[0][0].out_features, H1=sp[0][1].out_features,
                                 A0=f16(S0 * 8), A1=f16(8 * 8 + 4), A2=f16(8 * OT * 2 + OT), cs=torch.empty(6, dtype=torch.float32, device=dev),
                                 tbufs=tb, version=None))
-        cache.update(key=key, nets=entries, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), OT=OT, y_dim=y_dim)
+        # row pitch of the saved pre-activations / their gradients: [B, 64] when no hidden layer has more than 64 units (half the bytes)
+        ldz = 64 if all(max(e["H0"], e["H1"]) <= 64 for e in entries if e is not None) else 128
+        cache.update(key=key, nets=entries, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), OT=OT, y_dim=y_dim, ldz=ldz)
     lib = _lib.lib()
     for e in cache["nets"]:
         if e is None:
@@ -1745,16 +1770,17 @@ def _affine_net_backward(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, 
     B, d = g_net.shape[0], plan["y_dim"]
     tb = e["tbufs"]
     d_c, periodic, n_in = plan["d_c"], plan["periodic"], e["lins"][0].in_features
-    gz = torch.empty((2, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)[:, :B]
+    ldz = plan["ldz"]
+    gz = torch.empty((2, B + HALF_PAD_ROWS, ldz), dtype=torch.float32, device=dev)[:, :B]
     lib = _lib.lib()
     add2, lda = (gx_add, gx_add.stride(0)) if (gx_add is not None and want_gx) else (None, 0)
     with torch.cuda.device(dev):
-        st = lib.bgk_dense_backward_dx(_lib.ptr(g_net), ldg, d, _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, d_c, int(periodic),
+        st = lib.bgk_mlp_backward_dx(_lib.ptr(g_net), ldg, d, _lib.ptr(z1), _lib.ptr(z0), ldz, _lib.ptr(x2), ldc, d_c, int(periodic),
                                        _lib.ptr(tb["T0"]), _lib.ptr(tb["T1"]), _lib.ptr(tb["T2"]), _lib.ptr(e["cs"]), e["act"], B,
                                        _lib.ptr(gz[0]), _lib.ptr(gz[1]), None, None, _lib.ptr(gx_buf) if want_gx else None,
                                        gx_buf.stride(0) if want_gx else d_c, _lib.ptr(add2), lda, _lib.ptr(absmax), _lib.ptr(absmax[1:]),
                                        _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_dense_backward_dx")
+        _lib.check(st, "bgk_mlp_backward_dx")
     if not any(need_w):
         return (None,) * 6
     l0, l1, l2 = e["lins"]
@@ -1781,7 +1807,7 @@ def _affine_net_backward(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, 
         _PENDING_REDUCE[ws.data_ptr()] = (dev, B, d, n_in, ws, (gW0, gb0, gW1, gb1, gW2, gb2), H1, H0)
         mode = 2
     with torch.cuda.device(dev):
-        st = lib.bgk_mlp_weight_grad(_lib.ptr(g_net), ldg, d, _lib.ptr(gz[0]), _lib.ptr(gz[1]), _lib.ptr(z1), _lib.ptr(z0), 128, H1, H0,
+        st = lib.bgk_mlp_weight_grad(_lib.ptr(g_net), ldg, d, _lib.ptr(gz[0]), _lib.ptr(gz[1]), _lib.ptr(z1), _lib.ptr(z0), ldz, H1, H0,
                                      e["act"], _lib.ptr(x2), ldc, d_c, int(periodic), B, _lib.ptr(ws), ws.numel(),
                                      _lib.ptr(gW2), _lib.ptr(gb2), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW0), _lib.ptr(gb0), mode,
                                      _lib.ptr(absmax), _lib.stream_ptr(dev))
@@ -1804,7 +1830,7 @@ class _FusedAffineTrainFn(torch.autograd.Function):
         B, d = y2.shape
         out = torch.empty((B, d), dtype=torch.float32, device=dev)
         dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
-        zz = torch.empty((4, B + HALF_PAD_ROWS, 128), dtype=torch.float32, device=dev)[:, :B]
+        zz = torch.empty((4, B + HALF_PAD_ROWS, plan["ldz"]), dtype=torch.float32, device=dev)[:, :B]
         ldms = 32 * plan["OT"]
         ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
         es, et = plan["nets"]
@@ -1816,7 +1842,8 @@ class _FusedAffineTrainFn(torch.autograd.Function):
             st = _lib.lib().bgk_coupling_affine_dense_h2_train(
                 ptrs, lds, widths, n, int(plan["periodic"]), *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
                 _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), 0,
-                _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms, _lib.stream_ptr(dev))
+                _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), plan["ldz"], _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms,
+                _lib.stream_ptr(dev))
         _lib.check(st, "bgk_coupling_affine_dense_h2_train")
         ctx.save_for_backward(x2, y2, log_alpha, zz, ms)
         ctx.plan, ctx.cfg = plan, cfg

@@ -456,8 +456,8 @@ int bgk_coupling_affine_dense_deep(const float* cond, int64_t ldc, int32_t d_c, 
  * Training forward of the fused affine coupling layer (round 6): what autograd needs of CouplingFlow._forward / _inverse
  * (nn/flow/coupling.py:162-182) around AffineTransformer (nn/flow/transformer/affine.py:35-70) with DenseNet conditioners
  * [n_in, H0, H1, d] (nn/dense.py:30-48), H0, H1 <= 128, in ONE launch: the arithmetic of bgk_coupling_affine_dense_h2 (width-128 kernel:
- * narrower hidden layers run zero-padded inside the operands) plus, per network, the scaled pre-activations z0, z1 [B, 128] of its
- * two hidden layers (contiguous; padded units hold 0) and its output rows -- mu and the scale network's values before tanh,
+ * narrower hidden layers run zero-padded inside the operands) plus, per network, the scaled pre-activations z0, z1 [B, ldz] of its
+ * two hidden layers (contiguous; ldz = 128, or 64 when no hidden layer has more than 64 units; padded units hold 0) and its output rows -- mu and the scale network's values before tanh,
  * [B, ldms] with ldms a multiple of 4 and >= 32 ceil(d / 32) (columns past d hold 0).  Their consumers: bgk_affine_backward
  * (mu, s_raw), bgk_dense_backward_dx and bgk_mlp_weight_grad (z0, z1) -- the backward of KLTrainer's loss.backward()
  * (nn/training/trainers.py:156-163) for an affine coupling without a library GEMM or an elementwise torch kernel.
@@ -472,8 +472,8 @@ int bgk_coupling_affine_dense_h2_train(const float* const* cond, const int64_t* 
                                        const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
                                        const float* y, int64_t ldy, int64_t B, int32_t d, float* out, int64_t ldo,
                                        float* dlogp, int32_t accumulate,
-                                       float* s_z0, float* s_z1, float* t_z0, float* t_z1, float* mu, float* s_raw, int64_t ldms,
-                                       void* stream);
+                                       float* s_z0, float* s_z1, float* t_z0, float* t_z1, int64_t ldz,
+                                       float* mu, float* s_raw, int64_t ldms, void* stream);
 
 /* The fused coupling layers with SEVERAL conditioning tensors: CouplingFlow concatenates the tensors at cond_indices before it
  * calls the transformer (torch.cat, nn/flow/coupling.py:162-165; e.g. cfg 5's AUGMENTED | (FIXED, BONDS, ANGLES) layers).  Here
@@ -577,6 +577,15 @@ int bgk_pack_mlp_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_i
 int bgk_pack_dense_h2_t_many(int32_t n, const float* const* W0, const int32_t* n_in, const float* const* W1,
                              const float* const* W2, const int32_t* P, const float* const* cs,
                              void* const* T0, void* const* T1, void* const* T2, void* stream);
+/* bgk_mlp_backward_dx (round 6): bgk_dense_backward_dx (below) with the row pitch ldz of z1 / z0 / g_z1 / g_z0 / h1 / h0 as an argument
+ * -- 128, or 64 for networks whose hidden layers have <= 64 units (an affine coupling's [32, 64, 64, 32] networks: half the bytes of the
+ * zero-padded form; the operands of bgk_pack_mlp_h2_t hold zeros for the units that do not exist) */
+int bgk_mlp_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0, int64_t ldz,
+                        const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
+                        const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
+                        int64_t B, float* g_z1, float* g_z0, float* h1, float* h0,
+                        float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                        const float* g_absmax, float* gz_absmax, void* stream);
 int bgk_dense_backward_dx(const float* g, int64_t ldg, int32_t P, const float* z1, const float* z0,
                           const float* cond, int64_t ldc, int32_t d_c, int32_t periodic,
                           const void* T0, const void* T1, const void* T2, const float* cs, int32_t act,
@@ -716,6 +725,13 @@ int bgk_pack_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_
 
 /* k16-steps the kernel instance for n_in input columns runs (1, 2, 4, 8, 12 or 16; the packer pads to it); -1 beyond 256 columns. */
 int bgk_dense_layer_steps(int32_t n_in);
+/* bgk_refresh_linear_layer (round 6): the operands of bgk_pack_linear_layer kept in step with the weights ON THE DEVICE -- one small
+ * launch that fingerprints the column block (64-bit, position-mixed sum of the bit patterns) and re-packs Ap / cs only when the
+ * fingerprint differs from the one in `state` (two device uint64, zero-initialised by the caller: {fingerprint, valid}).  Launched in
+ * front of every bgk_dense_layer call by the host mirror: a DenseNet's forward then follows ANY update of its Linear weights
+ * (nn/dense.py:30-48 reads the live parameter) -- also those torch's version counter does not see (`p.data` edits, kernels writing
+ * through a view). */
+int bgk_refresh_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_in, void* Ap, float* cs, void* state, void* stream);
 
 /* Static PCA whitening / blackening of a coordinate block on its own: out = (x - pre) T + post.
  * Replaces WhitenFlow._whiten / _blacken (nn/flow/pca.py:74-93: torch.matmul(x - X0mean, Twhiten), torch.matmul(z, Tblacken) + X0mean);

@@ -76,21 +76,44 @@ def rq_spline(x, uw, uh, ud, inverse, left, right, bottom, top, min_w, min_h, mi
     return out, torch.log(num) - 2 * torch.log(den)
 
 
-def conditioner(net, x):
+# Rounding hook for the GEMM operands of the SPLINE conditioners (None: none).  The reduced-precision mode gemm_mode = "bf16" of the fused
+# kernels feeds the matrix cores bf16-rounded weights and layer inputs and accumulates in f32; with ``SPLINE_GEMM_ROUNDING = bf16_round`` an
+# f64 run of this restatement is the exact value of THAT arithmetic (up to the accumulation order), which bounds the kernel by an oracle
+# instead of by its own f16 twin (tests/test_gpu_round6.py::test_bf16_leg_against_the_rounding_oracle).
+SPLINE_GEMM_ROUNDING = None
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def conditioner(net, x, rnd=None):
     n = _name(net)
     if n == "DenseNet":
+        first = True
         for m in net._layers:
-            x = F.linear(x, m.weight, m.bias) if _name(m) == "Linear" else m(x)
+            if _name(m) == "Linear":
+                if rnd is None:
+                    x = F.linear(x, m.weight, m.bias)
+                else:
+                    # the kernels' operand forms: layer 0 carries its bias as the weight column of a constant-1 input feature (one rounded
+                    # value); the later layers add it as a two-term sum hi + lo of rounded values (their "bias blocks")
+                    b = m.bias
+                    b = rnd(b) if first else rnd(b) + rnd(b - rnd(b))
+                    x = F.linear(rnd(x), rnd(m.weight), b)
+                first = False
+            else:
+                x = m(x)
         return x
     if n == "WrapPeriodic":
         y = x[..., net.indices]
         cs = torch.cat([torch.cos(2 * np.pi * y), torch.sin(2 * np.pi * y)], dim=-1)      # all inputs periodic on [0, 1]
-        return conditioner(net.net, cs)
+        return conditioner(net.net, cs, rnd)
     return net(x)
 
 
 def spline_transformer(tr, cond, y, inverse):
-    p = conditioner(tr._params_net, cond)
+    p = conditioner(tr._params_net, cond, SPLINE_GEMM_ROUNDING)
     d = y.shape[-1]
     circ = torch.as_tensor(np.asarray(tr._is_circular, dtype=bool)) if np.ndim(tr._is_circular) else torch.full((d,), bool(tr._is_circular))
     n_nc = int((~circ).sum())

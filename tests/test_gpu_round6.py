@@ -229,3 +229,78 @@ def test_kl_training_of_cfg2_reduces_the_loss(hip_lib, dev):
     kll = ys[0]
     assert np.isfinite(kll).all() and kll[-5:].mean() < kll[:5].mean() - 0.5, f"KL loss {kll[:5].mean():.3f} -> {kll[-5:].mean():.3f}"
     assert opt.skipped_steps() == 0
+
+
+def test_bf16_leg_against_the_rounding_oracle(hip_lib, dev):
+    """BASELINE cfg 5's reduced-precision leg (gemm_mode "bf16": bf16 weights + GEMM inputs in the 10 spline conditioners, f32 accumulate;
+    splines, log-det, affine layers as in the f32-class mode) against an ORACLE of that arithmetic: the reference's op chain in f64 with
+    the spline conditioners' weights and layer inputs rounded to bf16 (oracle/torch_flow.py::SPLINE_GEMM_ROUNDING).  Rows of a 2^20-sample
+    launch through the 16 couplings (the icdf maps behind them put every f32 evaluation of cfg 5 ~1e-3 from f64: they would hide the
+    conditioners' arithmetic).  The kernel sits far closer to the rounding oracle than to the unrounded f64 evaluation -- whose distance
+    is the price of the mode -- except where a pre-activation's f32 round-off flips a bf16 rounding."""
+    from bgflow_amd import dense
+    from oracle import torch_flow as tfl
+    from test_gpu_round3 import _rows
+    B = 1 << 20
+    gen, gen_cpu = _make("cfg5", dev), _make("cfg5").double()
+    sub, sub_cpu = gen.flow[:16], gen_cpu.flow[:16]
+    z = _prior("cfg5", B, dev)
+    rows = _rows(B, n=1024)
+    rows_t = torch.as_tensor(rows, device=dev)
+    try:
+        dense.GEMM_MODE = "bf16"
+        with torch.no_grad():
+            *x, dl = sub(*z)
+    finally:
+        dense.GEMM_MODE = "f16x2"
+    zr = [v[rows_t].cpu().double() for v in z]
+    try:
+        tfl.SPLINE_GEMM_ROUNDING = tfl.bf16_round
+        xr, dlr = tfl.run_flow(sub_cpu, zr)
+    finally:
+        tfl.SPLINE_GEMM_ROUNDING = None
+    xe, dle = tfl.run_flow(sub_cpu, zr)
+    got_dl = dl[rows_t].cpu().double()
+    e_round = ((got_dl - dlr).abs() / dlr.abs().clamp(min=1.0)).reshape(-1)
+    e_exact = ((got_dl - dle).abs() / dle.abs().clamp(min=1.0)).reshape(-1)
+    ex_round = torch.stack([(a[rows_t].cpu().double() - b).abs().max(-1).values for a, b in zip(x, xr)]).max(0).values
+    ex_exact = torch.stack([(a[rows_t].cpu().double() - b).abs().max(-1).values for a, b in zip(x, xe)]).max(0).values
+    print(f"bf16 leg, 16 couplings, log-det: median error vs the rounding oracle {float(e_round.median()):.2e}, vs unrounded f64 {float(e_exact.median()):.2e}; "
+          f"fields: {float(ex_round.median()):.2e} vs {float(ex_exact.median()):.2e}; rows beyond 1e-4 of the rounding oracle: {float((e_round > 1e-4).float().mean()):.3f}")
+    assert float(e_round.median()) <= 0.2 * float(e_exact.median()), "the bf16 kernel is no closer to its rounding oracle than to the exact evaluation"
+    assert float(ex_round.median()) <= 0.2 * float(ex_exact.median())
+
+
+def test_densenet_follows_weight_edits_torch_does_not_version(hip_lib, dev):
+    """advisor finding (round 5): the packed operands of the per-layer kernel were cached on (data_ptr, _version); `p.data.mul_(2)` (no version
+    bump) left them stale.  Now the operands follow the weights on the device (bgk_refresh_linear_layer): the forward changes."""
+    import bgflow_amd as bg
+    net = bg.DenseNet([7, 300, 19], activation=torch.nn.Tanh()).to(dev)
+    x = torch.randn(50, 7, device=dev)
+    with torch.no_grad():
+        y0 = net(x)
+        ref0 = torch.nn.functional.linear(torch.tanh(torch.nn.functional.linear(x, net._layers[0].weight, net._layers[0].bias)),
+                                          net._layers[2].weight, net._layers[2].bias)
+        assert torch.allclose(y0, ref0, rtol=1e-5, atol=1e-5)
+        v0 = net._layers[2].weight._version
+        net._layers[2].weight.data.mul_(2.0)
+        assert net._layers[2].weight._version == v0          # torch saw nothing
+        y1 = net(x)
+        ref1 = torch.nn.functional.linear(torch.tanh(torch.nn.functional.linear(x, net._layers[0].weight, net._layers[0].bias)),
+                                          net._layers[2].weight, net._layers[2].bias)
+        assert torch.allclose(y1, ref1, rtol=1e-5, atol=1e-5) and not torch.allclose(y1, y0)
+        y2 = net(x)
+        assert torch.equal(y1, y2)                           # unchanged weights: same operands
+
+
+def test_linear_with_forward_hooks_runs_as_the_module(hip_lib, dev):
+    """a Linear (or its activation) carrying forward hooks is not swallowed by the layer kernel"""
+    import bgflow_amd as bg
+    net = bg.DenseNet([5, 16, 3], activation=torch.nn.ReLU()).to(dev)
+    seen = []
+    h1 = net._layers[0].register_forward_hook(lambda m, i, o: seen.append(("lin", tuple(o.shape))))
+    h2 = net._layers[1].register_forward_hook(lambda m, i, o: seen.append(("act", tuple(o.shape))))
+    with torch.no_grad():
+        net(torch.randn(4, 5, device=dev))
+    h1.remove(); h2.remove()
+    assert seen == [("lin", (4, 16)), ("act", (4, 16))]
