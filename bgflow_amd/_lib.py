@@ -128,7 +128,11 @@ _SIGNATURES = {
     "bgk_dense_layer": (ctypes.c_int, [vp, i64, i64, i32, vp, i32, f32, vp, vp, i32, i32, vp, i64, i32, vp]),
     "bgk_pack_linear_layer": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp]),
     "bgk_dense_layer_steps": (ctypes.c_int, [i32]),
-    "bgk_refresh_linear_layer": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, vp, vp]),
+    "bgk_refresh_linear_layer": (ctypes.c_int, [vp, i64, i32, i32, i32, vp, vp, vp, vp]),
+    "bgk_activation": (ctypes.c_int, [vp, i64, i64, i32, i32, vp, i64, vp]),
+    "bgk_activation_backward": (ctypes.c_int, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp]),
+    "bgk_linear_weight_grad_workspace": (i64, [i64, i32, i32]),
+    "bgk_linear_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, i64, i32, i64, vp, i64, vp, vp, i32, vp, vp]),
 }
 
 ABI_SYMBOLS = tuple(_SIGNATURES)

@@ -267,8 +267,10 @@ __global__ __launch_bounds__(256) void layer_pack_kernel(const float* W, int64_t
  * itself (the arithmetic of layer_max_kernel + layer_pack_kernel) and stores the new fingerprint.  A launch of a few microseconds in
  * front of every bgk_dense_layer call replaces a cache keyed on (data_ptr, torch's version counter), which updates through `.data`,
  * old-style optimizers or kernels writing through a view do not bump: stale weights, silently. */
+/* transposed: the operands of the TRANSPOSED matrix -- element (row, k) = W[k * ldw + row] -- for dX = g W, the input gradient of the
+ * Linear layer, as one more bgk_dense_layer call on g (autograd of nn/dense.py:47-48 without a library GEMM). */
 __global__ __launch_bounds__(1024) void layer_refresh_kernel(const float* W, int64_t ldw, int n_out, int n_in, int S, int G, uint4* out, float* cs,
-                                                             unsigned long long* state) {
+                                                             unsigned long long* state, int transposed) {
     __shared__ unsigned long long s_fp[16];
     __shared__ float s_m[16];
     __shared__ int s_same;
@@ -277,8 +279,8 @@ __global__ __launch_bounds__(1024) void layer_refresh_kernel(const float* W, int
     unsigned long long fp = 0ull;
     float m = 0.0f;
     for (int64_t i = tid; i < n; i += 1024) {
-        const int64_t r = i / n_in;
-        const float v = W[r * ldw + (i - r * n_in)];
+        const int64_t r = i / n_in, k = i - r * n_in;
+        const float v = transposed ? W[k * ldw + r] : W[r * ldw + k];
         unsigned long long x = ((unsigned long long)__builtin_bit_cast(unsigned, v) + 0x9E3779B9ull) * (unsigned long long)(2 * i + 1);
         x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
         fp += x;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(1024) void layer_refresh_kernel(const float* W, int
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = 16 * s + 8 * kb + q;
-            const float v = (row < n_out && k < n_in) ? W[(int64_t)row * ldw + k] * scale : 0.0f;
+            const float v = (row < n_out && k < n_in) ? (transposed ? W[(int64_t)k * ldw + row] : W[(int64_t)row * ldw + k]) * scale : 0.0f;
             const _Float16 h = (_Float16)v;
             const _Float16 r = p ? (_Float16)(v - (float)h) : h;
             o[q] = __builtin_bit_cast(uint16_t, r);
@@ -357,12 +359,14 @@ extern "C" int bgk_pack_linear_layer(const float* W, int64_t ldw, int32_t n_out,
     return bgk_launch_status("bgk_pack_linear_layer");
 }
 
-extern "C" int bgk_refresh_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_in, void* Ap, float* cs, void* state, void* stream) {
-    BGK_CHECK_ARG(W && Ap && cs && state && n_out > 0 && n_in > 0 && n_in <= 256 && ldw >= n_in, "bgk_refresh_linear_layer: bad arguments (a column block of at most 256)");
+extern "C" int bgk_refresh_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_in, int32_t transposed, void* Ap, float* cs, void* state,
+                                        void* stream) {
+    BGK_CHECK_ARG(W && Ap && cs && state && n_out > 0 && n_in > 0 && n_in <= 256 && ldw >= (transposed ? n_out : n_in),
+                  "bgk_refresh_linear_layer: bad arguments (a column block of at most 256)");
     BGK_CHECK_ARG(((uintptr_t)Ap & 15) == 0 && ((uintptr_t)state & 7) == 0, "bgk_refresh_linear_layer: the operand buffer must be 16-byte, the state 8-byte aligned");
     const int S = bgk_dense_layer_steps(n_in), G = (n_out + 127) / 128;
     hipLaunchKernelGGL(layer_refresh_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, W, ldw, n_out, n_in, S, G, reinterpret_cast<uint4*>(Ap), cs,
-                       reinterpret_cast<unsigned long long*>(state));
+                       reinterpret_cast<unsigned long long*>(state), transposed ? 1 : 0);
     return bgk_launch_status("bgk_refresh_linear_layer");
 }
 

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(WG_THREADS, 3) void wgrad_kernel(WgGroup grp_args) 
 /* fixed-order sum of the slab partials: 8 lanes per output element each sum every 8th slab (2 accumulators), combined in ascending
  * order through LDS.  The 8 lanes of an element sit in 8 different half-waves: a half-wave reads 32 CONSECUTIVE elements of one slab
  * (128 B, coalesced) -- with the 8 lanes adjacent every load touched 8 slabs x 32 B. */
-struct RedOne { const float* part_w; const float* part_b; int n_slabs, n, k; float* gW; float* gb; };
+struct RedOne { const float* part_w; const float* part_b; int n_slabs, n, k; float* gW; float* gb;
+                int ldo; };     /* row stride of gW (k: a whole contiguous [n, k] gradient; larger: a column block of a wider one) */
 struct RedGroup { RedOne r[3]; int64_t first[4]; };      /* first[q]: first output element of GEMM q */
 
 __device__ __forceinline__ void wgrad_reduce_body(const RedGroup& rg, int accumulate, int bx) {
@@ -221,7 +222,10 @@ __device__ __forceinline__ void wgrad_reduce_body(const RedGroup& rg, int accumu
         float t = s_part[0][el];
 #pragma unroll
         for (int u = 1; u < 8; ++u) t += s_part[u][el];
-        if (i < nk && i < total) o.gW[i] = accumulate ? o.gW[i] + t : t;
+        if (i < nk && i < total) {
+            const int64_t at = o.ldo == o.k ? i : (i / o.k) * (int64_t)o.ldo + (i % o.k);
+            o.gW[at] = accumulate ? o.gW[at] + t : t;
+        }
         else if (i < total) o.gb[i - nk] = accumulate ? o.gb[i - nk] + t : t;
     }
 }
@@ -256,7 +260,7 @@ int64_t ws_need(int64_t B, int n, int k) {
 }
 
 struct GemmSpec { const char* what; const float* g; int64_t ldg; int n; const float* h; int64_t ldh; int k; int featurise; int act; float* gW; float* gb;
-                  const float* g_absmax; };
+                  const float* g_absmax; int ldo = 0; };      /* ldo: row stride of gW (0: k) */
 
 /* mode bits: 1 launch the GEMMs, 2 launch the reduction (red_out != NULL: also / only hand the reduction's descriptor out) */
 int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t ws_floats, int accumulate, hipStream_t st, int mode = 3,
@@ -280,7 +284,7 @@ int gemm_group(const GemmSpec* specs, int count, int64_t B, float* ws, int64_t w
         float* pw = ws + used;
         float* pb = pw + (int64_t)n_slabs * sp.n * sp.k;
         grp.g[q] = WgArgs{sp.g, sp.ldg, sp.n, sp.h, sp.ldh, sp.k, sp.featurise, sp.act, B, rows, n_slabs, n_blocks, pw, pb, sp.g_absmax};
-        red.r[q] = RedOne{pw, pb, n_slabs, sp.n, sp.k, sp.gW, sp.gb};
+        red.r[q] = RedOne{pw, pb, n_slabs, sp.n, sp.k, sp.gW, sp.gb, sp.ldo > 0 ? sp.ldo : sp.k};
         blocks += n_slabs * n_blocks;
         used += need;
         outs += (int64_t)sp.n * sp.k + sp.n;
@@ -356,6 +360,36 @@ extern "C" int bgk_mlp_weight_grad_reduce_many(int32_t n, const int64_t* B, cons
         hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)((max_outs + 31) / 32), (unsigned)cnt), dim3(256), 0, st, M, accumulate);
     }
     return bgk_launch_status("bgk_mlp_weight_grad_reduce_many");
+}
+
+/* ONE Linear layer of any width (round 6): gW [n, k] = g^T h, gb [n] = sum_rows g for g [B, n], h [B, k] -- the input columns in blocks of
+ * 128 (three blocks per launch), each block's partial sums reduced into its columns of gW.  The weight / bias gradient of a Linear
+ * outside the fused training envelopes (a conditioner with other depths / widths, a stand-alone DenseNet): before round 6
+ * torch.bmm + a sum on hipBLASLt (dense._gram_tn). */
+extern "C" int64_t bgk_linear_weight_grad_workspace(int64_t B, int32_t n, int32_t k) {
+    (void)k;
+    return 3 * ws_need(B, n, COLS);
+}
+
+extern "C" int bgk_linear_weight_grad(const float* g, int64_t ldg, int32_t n, const float* h, int64_t ldh, int32_t k, int64_t B,
+                                      float* workspace, int64_t workspace_floats, float* gW, float* gb, int32_t accumulate,
+                                      const float* g_absmax, void* stream) {
+    if (B == 0) return 0;
+    BGK_CHECK_ARG(g && h && workspace && gW && B > 0 && n > 0 && k > 0 && ldg >= n && ldh >= k && (accumulate == 0 || accumulate == 1),
+                  "bgk_linear_weight_grad: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int k0 = 0; k0 < k; k0 += 3 * COLS) {
+        GemmSpec specs[3];
+        int count = 0;
+        for (int kb = k0; kb < k && count < 3; kb += COLS) {
+            const int kw = k - kb < COLS ? k - kb : COLS;
+            specs[count] = GemmSpec{"bgk_linear_weight_grad", g, ldg, n, h + kb, ldh, kw, 0, 0, gW + kb, kb == 0 ? gb : nullptr, g_absmax, k};
+            ++count;
+        }
+        const int rc = gemm_group(specs, count, B, workspace, workspace_floats, accumulate, st);
+        if (rc != 0) return rc;
+    }
+    return bgk_launch_status("bgk_linear_weight_grad");
 }
 
 extern "C" int64_t bgk_dense_weight_grad_workspace(int64_t B, int32_t P, int32_t n_in) { return bgk_mlp_weight_grad_workspace(B, P, 128, 128, n_in); }

@@ -56,14 +56,44 @@ def column_sum(g, nblk=1024):
     return out
 
 
+LAYER_BACKWARD = os.environ.get("BGK_LAYER_BACKWARD", "1") != "0"    # backward of a Linear on the hand-written kernels (0: library GEMMs, the A/B leg)
+
+
+def linear_weight_grad(g, h, gW=None, gb=None, want_bias=True):
+    """(g^T h [n, k], sum_rows g [n]) of 2-d f32 HIP tensors on bgk_linear_weight_grad (any widths); ``gW`` / ``gb``: destinations the
+    result is ADDED to (the flat gradient bucket of training.FlatAdam) instead of fresh tensors"""
+    _lib.require_hip(g, h)
+    g2, ldg = _lib.rowmajor(g)
+    h2, ldh = _lib.rowmajor(h)
+    B, n = g2.shape
+    k = h2.shape[1]
+    dev = g.device
+    accumulate = int(gW is not None)
+    if gW is None:
+        gW = torch.empty((n, k), dtype=torch.float32, device=dev)
+        gb = torch.empty((n,), dtype=torch.float32, device=dev) if want_bias else None
+    lib = _lib.lib()
+    ws = torch.empty(int(lib.bgk_linear_weight_grad_workspace(B, n, k)), dtype=torch.float32, device=dev)
+    am = absmax_of(g2)
+    with torch.cuda.device(dev):
+        st = lib.bgk_linear_weight_grad(_lib.ptr(g2), ldg, n, _lib.ptr(h2), ldh, k, B, _lib.ptr(ws), ws.numel(), _lib.ptr(gW), _lib.ptr(gb),
+                                        accumulate, _lib.ptr(am), _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_linear_weight_grad")
+    return gW, gb
+
+
 class _LinearFn(torch.autograd.Function):
-    """``addmm`` whose backward takes the bias gradient from bgk_column_sum instead of torch's column reduction
-    (``grad.sum(0)`` of a [2^18, 425] tensor runs at ~170 GB/s on MI355X: 2.7 ms per layer, a third of a KL
-    training step; rocBLAS gemv with a ones vector is slower still)."""
+    """A Linear layer under autograd.  On HIP tensors (``lin``: the module): forward on bgk_dense_layer; backward (round 6) on the
+    hand-written kernels too -- dX = g W as one more bgk_dense_layer call on the operands of W^T (bgk_refresh_linear_layer,
+    transposed), dW = g^T x and db = sum g on bgk_linear_weight_grad, added straight into the FlatAdam bucket inside
+    direct_grad_accumulation().  Rounds 1 - 5 ran F.linear + torch.bmm (hipBLASLt) + bgk_column_sum here; that form stays as the
+    A/B leg (LAYER_BACKWARD = False) and for tensors the layer kernel does not take (``lin`` None)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, lin=None):
         ctx.save_for_backward(x, weight)
+        ctx.lin = lin
+        ctx.wb = (weight, bias)
         if lin is not None:                 # the module whose parameters these are: forward on bgk_dense_layer
             return dense_layer(x, lin, 0)
         return torch.addmm(bias, x, weight.t())
@@ -72,10 +102,58 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
-        gx = _matmul_nn(g, weight) if ctx.needs_input_grad[0] else None
-        gw = _gram_tn(g, x.contiguous()) if ctx.needs_input_grad[1] else None
-        gb = column_sum(g) if ctx.needs_input_grad[2] else None
+        need = ctx.needs_input_grad
+        if ctx.lin is not None and LAYER_BACKWARD and g.is_cuda and g.dtype == torch.float32:
+            gx = dense_layer(g, ctx.lin, 0, transposed=True) if need[0] else None
+            gw = gb = None
+            if need[1] or need[2]:
+                W, b = ctx.wb
+                direct = _DIRECT_GRADS[0] and need[1] and need[2] and all(
+                    getattr(p, "_bgk_grad_dst", None) is not None and p.grad is not None and p.grad.data_ptr() == p._bgk_grad_dst.data_ptr()
+                    for p in (W, b))
+                if direct:
+                    linear_weight_grad(g, x.detach(), W._bgk_grad_dst, b._bgk_grad_dst)
+                else:
+                    gw, gb = linear_weight_grad(g, x.detach(), want_bias=bool(need[2]))
+                    gw = gw if need[1] else None
+            return gx, gw, gb, None
+        gx = _matmul_nn(g, weight) if need[0] else None
+        gw = _gram_tn(g, x.contiguous()) if need[1] else None
+        gb = column_sum(g) if need[2] else None
         return gx, gw, gb, None
+
+
+def activation(z, act, g=None):
+    """act(z) (``g`` None) or the VJP g * act'(z) on the elementwise kernels bgk_activation / bgk_activation_backward (act: 1 SiLU, 2 ReLU,
+    3 Tanh; f32 HIP tensors of any shape, last axis = features)"""
+    _lib.require_hip(z, g)
+    z2, ldz = _lib.rowmajor(z.reshape(-1, z.shape[-1]))
+    B, n = z2.shape
+    out = torch.empty((B, n), dtype=torch.float32, device=z.device)
+    if B and n:
+        with torch.cuda.device(z.device):
+            if g is None:
+                st = _lib.lib().bgk_activation(_lib.ptr(z2), ldz, B, n, act, _lib.ptr(out), n, _lib.stream_ptr(z.device))
+            else:
+                g2, ldg = _lib.rowmajor(g.reshape(-1, n))
+                st = _lib.lib().bgk_activation_backward(_lib.ptr(z2), ldz, _lib.ptr(g2), ldg, B, n, act, _lib.ptr(out), n, _lib.stream_ptr(z.device))
+        _lib.check(st, "bgk_activation")
+    return out.reshape(z.shape)
+
+
+class _ActFn(torch.autograd.Function):
+    """hidden activation of a DenseNet under autograd on the elementwise kernels (forward keeps z; backward g * act'(z))"""
+
+    @staticmethod
+    def forward(ctx, z, act):
+        ctx.save_for_backward(z)
+        ctx.act = act
+        return activation(z, act)
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        return activation(z, ctx.act, g.contiguous()), None
 
 
 LAYER_KERNEL = True     # Linear layers of a DenseNet on HIP tensors run on bgk_dense_layer; False: torch.nn.Linear (hipBLASLt)
@@ -124,8 +202,8 @@ def pack_linear_layer_device(weight):
     return passes
 
 
-def _layer_operands(lin):
-    """Packed operands of a Linear module that follow its weight ON THE DEVICE (round 6): the buffers are allocated once per (shape,
+def _layer_operands(lin, transposed=False):
+    """Packed operands of a Linear module that follow its weight ON THE DEVICE (round 6; ``transposed``: those of W^T, for dX = g W): the buffers are allocated once per (shape,
     device); every call launches bgk_refresh_linear_layer per column block, which fingerprints the live weight and re-packs the block
     only when it changed.  No host-side version key: an update torch's version counter does not see (``p.data.mul_(2)``, an old-style
     optimizer, a kernel writing through a view of the parameter) is picked up like any other -- what ``torch.nn.Linear`` does, since it
@@ -133,9 +211,10 @@ def _layer_operands(lin):
     Wp = lin.weight
     W = Wp.detach() if Wp.stride(1) == 1 else Wp.detach().contiguous()
     assert W.is_cuda and W.dtype == torch.float32 and W.dim() == 2
-    n_out, n_in = W.shape
+    n_out, n_in = (W.shape[1], W.shape[0]) if transposed else W.shape        # of the matrix the operands stand for
     key = (n_out, n_in, W.device)
-    cached = lin.__dict__.get("_bgk_layer_ops")
+    slot = "_bgk_layer_ops_t" if transposed else "_bgk_layer_ops"
+    cached = lin.__dict__.get(slot)
     if cached is None or cached[0] != key:
         G = (n_out + 127) // 128
         passes = []
@@ -146,28 +225,32 @@ def _layer_operands(lin):
                            torch.zeros(2, dtype=torch.float32, device=W.device), k0, k1,
                            torch.zeros(2, dtype=torch.int64, device=W.device)))
         cached = (key, passes)
-        lin.__dict__["_bgk_layer_ops"] = cached
+        lin.__dict__[slot] = cached
     with torch.cuda.device(W.device):
         for A, _S, cs, k0, k1, state in cached[1]:
-            st = _lib.lib().bgk_refresh_linear_layer(W.data_ptr() + 4 * k0, W.stride(0), n_out, k1 - k0, _lib.ptr(A), _lib.ptr(cs), _lib.ptr(state),
+            # column block [k0, k1) of the operand matrix: columns of W, or (transposed) rows k0 .. k1 of W
+            base = W.data_ptr() + 4 * (k0 * W.stride(0) if transposed else k0)
+            st = _lib.lib().bgk_refresh_linear_layer(base, W.stride(0), n_out, k1 - k0, int(transposed), _lib.ptr(A), _lib.ptr(cs), _lib.ptr(state),
                                                      _lib.stream_ptr(W.device))
             _lib.check(st, "bgk_refresh_linear_layer")
     return [p[:5] for p in cached[1]]
 
 
-def dense_layer(x, lin, act=0):
-    """y = act(x W^T + b) of a Linear module on bgk_dense_layer (x: f32 HIP tensor [..., n_in]; act: 0 none, 1 SiLU, 2 ReLU, 3 Tanh)"""
-    if x.dim() < 1 or x.shape[-1] != lin.in_features:
-        raise RuntimeError(f"dense_layer: input of shape {tuple(x.shape)} for a Linear layer with {lin.in_features} input features "
+def dense_layer(x, lin, act=0, transposed=False):
+    """y = act(x W^T + b) of a Linear module on bgk_dense_layer (x: f32 HIP tensor [..., n_in]; act: 0 none, 1 SiLU, 2 ReLU, 3 Tanh).
+    ``transposed``: y = x W (no bias): the layer's input gradient for x = the gradient of its output."""
+    n_in_x = lin.out_features if transposed else lin.in_features
+    if x.dim() < 1 or x.shape[-1] != n_in_x:
+        raise RuntimeError(f"dense_layer: input of shape {tuple(x.shape)} for a Linear layer with {n_in_x} input features "
                            f"(mat1 and mat2 shapes cannot be multiplied)")
     _lib.require_hip(x)
     lead = x.shape[:-1]
     x2, ldx = _lib.rowmajor(x.reshape(-1, x.shape[-1]))
-    B, n_out = x2.shape[0], lin.out_features
+    B, n_out = x2.shape[0], (lin.in_features if transposed else lin.out_features)
     y = torch.empty((B, n_out), dtype=torch.float32, device=x.device)
     if B and n_out:
-        passes = _layer_operands(lin)
-        bias = None if lin.bias is None else lin.bias.detach().contiguous()
+        passes = _layer_operands(lin, transposed)
+        bias = None if (lin.bias is None or transposed) else lin.bias.detach().contiguous()
         with torch.cuda.device(x.device):
             for i, (A, S, c, k0, k1) in enumerate(passes):
                 last = i == len(passes) - 1
@@ -210,6 +293,11 @@ def _run_layers(layers, x):
         elif grad and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and type(m) is torch.nn.Linear and m.bias is not None \
                 and (m.weight.requires_grad or x.requires_grad):
             x = _LinearFn.apply(x, m.weight, m.bias, None)
+            i += 1
+            continue
+        elif LAYER_KERNEL and LAYER_BACKWARD and grad and type(m) in _LAYER_ACTS and x.is_cuda and x.dtype == torch.float32 and x.requires_grad \
+                and x.dim() >= 1 and not m._forward_hooks and not m._forward_pre_hooks:
+            x = _ActFn.apply(x, _LAYER_ACTS[type(m)])      # the activation and its VJP on bgk_activation / _backward (round 6; before: aten)
             i += 1
             continue
         x = m(x)

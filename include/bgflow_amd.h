@@ -695,6 +695,16 @@ int bgk_mlp_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* 
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).
  * Deterministic two-stage reduction; `partial` is a caller-provided [nblk, P] workspace. */
+/* bgk_linear_weight_grad (round 6): ONE Linear layer of any width -- gW [n, k] = g^T h (row-major, contiguous), gb [n] = sum_rows g
+ * (may be NULL) for g [B, n], h [B, k]: autograd of nn/dense.py:47-48 for a Linear outside the fused training envelopes (conditioners
+ * of other depths / widths, factory/conditioner_factory.py:81-85; a stand-alone DenseNet).  Split-f16 products under the power-of-two
+ * scale of g_absmax (device float[1] = max |g|, or NULL), deterministic two-stage reduction; workspace from
+ * bgk_linear_weight_grad_workspace; accumulate = 1: added to gW / gb.  Before round 6: torch.bmm + sum on hipBLASLt. */
+int64_t bgk_linear_weight_grad_workspace(int64_t B, int32_t n, int32_t k);
+int bgk_linear_weight_grad(const float* g, int64_t ldg, int32_t n, const float* h, int64_t ldh, int32_t k, int64_t B,
+                           float* workspace, int64_t workspace_floats, float* gW, float* gb, int32_t accumulate,
+                           const float* g_absmax, void* stream);
+
 int bgk_column_sum(const float* x, int64_t ldx, int64_t B, int32_t P, float* partial, int32_t nblk,
                    float* out, void* stream);
 
@@ -731,7 +741,17 @@ int bgk_dense_layer_steps(int32_t n_in);
  * front of every bgk_dense_layer call by the host mirror: a DenseNet's forward then follows ANY update of its Linear weights
  * (nn/dense.py:30-48 reads the live parameter) -- also those torch's version counter does not see (`p.data` edits, kernels writing
  * through a view). */
-int bgk_refresh_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_in, void* Ap, float* cs, void* state, void* stream);
+int bgk_refresh_linear_layer(const float* W, int64_t ldw, int32_t n_out, int32_t n_in, int32_t transposed, void* Ap, float* cs, void* state,
+                             void* stream);
+/* transposed != 0: the operands of W^T -- element (row, k) = W[k * ldw + row], n_out rows, n_in <= 256 columns -- so that the input
+ * gradient of the layer, dX = g W (autograd of nn/dense.py:47-48), is one more bgk_dense_layer call on g.
+ *
+ * bgk_activation / bgk_activation_backward (round 6): the hidden activation of nn/dense.py:30-48 (1 SiLU, 2 ReLU, 3 Tanh; the forms of
+ * bgk_dense_layer's epilogue) and its VJP g_z = g * act'(z) as elementwise kernels: what the layer-by-layer TRAINING path of a
+ * conditioner outside the one-launch envelopes runs between its Linear layers (before: aten silu / tanh / threshold kernels). */
+int bgk_activation(const float* z, int64_t ldz, int64_t B, int32_t n, int32_t act, float* out, int64_t ldo, void* stream);
+int bgk_activation_backward(const float* z, int64_t ldz, const float* g, int64_t ldg, int64_t B, int32_t n, int32_t act,
+                            float* g_z, int64_t ldgz, void* stream);
 
 /* Static PCA whitening / blackening of a coordinate block on its own: out = (x - pre) T + post.
  * Replaces WhitenFlow._whiten / _blacken (nn/flow/pca.py:74-93: torch.matmul(x - X0mean, Twhiten), torch.matmul(z, Tblacken) + X0mean);

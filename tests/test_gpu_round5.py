@@ -793,7 +793,22 @@ def test_densenet_layers_run_on_the_layer_kernel(hip_lib, dev):
     assert float((y - y_ref).abs().max()) <= 2e-6 * max(1.0, float(y_ref.abs().max()))
     net.zero_grad()
     xg = x.clone().requires_grad_(True)
-    (net(xg) ** 2).sum().backward()
+    # round 6: the BACKWARD of these layers launches no library GEMM either (dX on bgk_dense_layer with the operands of W^T, dW / db on
+    # bgk_linear_weight_grad), and SiLU / Tanh / ReLU and their derivatives run on bgk_activation (the LeakyReLU stays torch's)
+    names = []
+    try:
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA, torch.profiler.ProfilerActivity.CPU]) as prof:
+            (net(xg) ** 2).sum().backward()
+            torch.cuda.synchronize()
+        names = [e.key for e in prof.key_averages()]
+    except Exception:
+        net.zero_grad()
+        xg.grad = None
+        (net(xg) ** 2).sum().backward()
+    bad = [n for n in names if ("Cijk" in n) or ("gemm" in n.lower()) or n.startswith("aten::addmm") or n.startswith("aten::mm") or n.startswith("aten::bmm")
+           or any(k in n.lower() for k in ("silu", "tanh", "threshold"))]
+    assert not bad, bad
+    assert all("_bgk_layer_ops_t" in m.__dict__ for m in list(net._layers)[2::2] if isinstance(m, torch.nn.Linear)), "dX of every Linear behind the first on the kernel"
     for a, r in zip([p.grad for p in net.parameters()] + [xg.grad], g_ref):
         assert float((a - r).abs().max()) <= 1e-4 * max(float(r.abs().max()), 1e-6)
 

@@ -304,3 +304,57 @@ def test_linear_with_forward_hooks_runs_as_the_module(hip_lib, dev):
         net(torch.randn(4, 5, device=dev))
     h1.remove(); h2.remove()
     assert seen == [("lin", (4, 16)), ("act", (4, 16))]
+
+
+@pytest.mark.parametrize("units,act", [([17, 256, 256, 425], torch.nn.SiLU), ([9, 32, 64, 32, 40], torch.nn.Tanh), ([300, 520, 7], torch.nn.ReLU)])
+def test_linear_backward_kernels_against_f64_autograd(hip_lib, dev, units, act):
+    """A DenseNet outside the fused training envelopes (wide: 256 hidden units; deep: three hidden layers; a 520-unit layer fed 300 inputs)
+    under autograd: every Linear's forward, input gradient (bgk_dense_layer on the operands of W^T) and weight / bias gradient
+    (bgk_linear_weight_grad) and every activation's VJP (bgk_activation_backward) against f64 autograd of the same network; the loss
+    scale of a KL step (gradients ~ 1 / B)."""
+    import bgflow_amd as bg
+    from bgflow_amd.utils import hash_init_
+    net = hash_init_(bg.DenseNet(units, activation=act())).to(dev)
+    net64 = copy.deepcopy(net).cpu().double()
+    B = 3001
+    g = torch.Generator().manual_seed(units[0])
+    x = torch.randn(B, units[0], generator=g, dtype=torch.float64)
+    w = torch.randn(B, units[-1], generator=g, dtype=torch.float64) / B
+    x64 = x.clone().requires_grad_(True)
+    y64 = x64
+    for m in net64._layers:
+        y64 = m(y64)
+    (y64 * w).sum().backward()
+    xg = x.float().to(dev).requires_grad_(True)
+    y = net(xg)
+    assert float((y.double().cpu() - y64.detach()).abs().max()) <= 1e-5 * max(1.0, float(y64.abs().max()))
+    (y * w.float().to(dev)).sum().backward()
+    got = {n: p.grad.double().cpu() for n, p in net.named_parameters()}
+    ref = {n: p.grad for n, p in net64.named_parameters()}
+    rel, worst = _grad_errors(got, ref)
+    ex = float((xg.grad.double().cpu() - x64.grad).norm() / x64.grad.norm())
+    print(f"DenseNet {units}: parameter gradient rel L2 {rel:.2e} (worst {worst[1]} {worst[0]:.2e}), input gradient {ex:.2e}")
+    assert rel <= 2e-5 and worst[0] <= 1e-4 and ex <= 2e-5
+
+
+def test_training_a_wide_conditioner_launches_no_library_gemm(hip_lib, dev):
+    """a spline coupling whose conditioner has 256-unit hidden layers (fused in inference only) under autograd: layer by
+    layer on bgk_dense_layer / bgk_activation forward, bgk_rqs_backward + the per-Linear backward kernels backward -- no `Cijk_*` kernel"""
+    from bgflow_amd import configs
+    from bgflow_amd.utils import hash_init_
+    dims = {"BONDS": 17, "ANGLES": 17, "TORSIONS": 17, "FIXED": 9}
+    circ = {"BONDS": False, "ANGLES": False, "TORSIONS": True, "FIXED": False}
+    slot = {f: i for i, f in enumerate(configs.IC_FIELDS)}
+    layer = hash_init_(configs._spline_coupling("BONDS", "ANGLES", dims, circ, slot, hidden=(256, 256))).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    xs = [torch.rand(2048, d, device=dev, generator=g) for d in (17, 17, 17, 9)]
+
+    def step():
+        for p in layer.parameters():
+            p.grad = None
+        *ys, dl = layer(*xs)
+        (ys[0].square().sum() - dl.sum()).backward()
+    names = _device_kernel_names(step)
+    bad = [n for n in names if "Cijk_" in n or "gemm" in n.lower() or any(k in n.lower() for k in ("silu", "tanh", "threshold"))]
+    assert not bad, sorted(set(bad))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
