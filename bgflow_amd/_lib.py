@@ -131,6 +131,9 @@ _SIGNATURES = {
     "bgk_refresh_linear_layer": (ctypes.c_int, [vp, i64, i32, i32, i32, vp, vp, vp, vp]),
     "bgk_activation": (ctypes.c_int, [vp, i64, i64, i32, i32, vp, i64, vp]),
     "bgk_activation_backward": (ctypes.c_int, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp]),
+    "bgk_affine_net_backward64_workspace": (i64, [i64, i32, i32, i32, i32]),
+    "bgk_affine_net_backward64": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, i64,
+                                                 vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, i32, vp]),
     "bgk_linear_weight_grad_workspace": (i64, [i64, i32, i32]),
     "bgk_linear_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, i64, i32, i64, vp, i64, vp, vp, i32, vp, vp]),
 }

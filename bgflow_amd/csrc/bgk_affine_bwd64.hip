@@ -1,0 +1,463 @@
+/* bgk_affine_bwd64.hip -- backward of ONE conditioner network of an affine coupling with hidden layers of <= 64 units, input-gradient
+ * chain AND weight / bias gradients in one launch (round 6; BASELINE cfg 2: DenseNet([32, 64, 64, 32]) shift / scale networks,
+ * nn/flow/transformer/affine.py:35-43 + nn/dense.py:30-48 under loss.backward(), nn/training/trainers.py:156-163).
+ *
+ * The three-kernel form (bgk_mlp_backward_dx -> g_z1, g_z0 in HBM -> bgk_mlp_weight_grad reading them and z1, z0 again) moves
+ * 4 (d + 2 n_in + 8 H) B per sample = 2.4 KB for cfg 2's networks; the weight gradients contract over the BATCH, so a wave that holds a
+ * 32-sample tile of g_z and h = act(z) on chip can form its share of g^T h right there: this kernel reads g, z1, z0, x once
+ * (4 (d + n_in + 2 H) = 0.77 KB per sample), writes the conditioner-input gradient, and keeps the three weight gradients of the network
+ * (32 x 64 + 64 x 64 + 64 x 32 values = 8 accumulator tiles, 128 registers) in registers across all its tiles -- the "batch-contracting"
+ * form.  Per tile:
+ *   g_h1 = W2^T g            (B operand: the tile's rows of g; A: the transposed operands of bgk_pack_mlp_h2_t, staged once per workgroup in LDS)
+ *   g_z1 = g_h1 act'(z1), h1 = act(z1);     dW2 += g^T h1,   db2 += sum g
+ *   g_h0 = W1^T g_z1, g_z0 = g_h0 act'(z0), h0 = act(z0);   dW1 += g_z1^T h0, db1 += sum g_z1
+ *   g_x  = W0^T g_z0 (+ what the caller adds);                dW0 += g_z0^T x,  db0 += sum g_z0
+ * The batch contraction needs its operands with the SAMPLE index along k: what a lane holds in accumulator layout (lane = sample) is
+ * transposed through a wave-private LDS tile [unit][sample]; columns of g and x are gathered from the tile's rows (cache hits).  All
+ * products are split-f16 (hi + lo, three MFMAs, f32 accumulate) under power-of-two scales: g under the tensor's (bgk_affine_backward
+ * publishes max |g|), g_z1 / g_z0 under their tile's own -- each tile's product lands in a temporary accumulator and is added to the running
+ * gradient with the scale removed, so tiles of different magnitude accumulate in f32.  Per-wave partial gradients go to a workspace and
+ * are summed in fixed order by wgrad_reduce_kernel's twin below (deterministic, no atomics).
+ * Envelope: d <= 32, n_in <= 32 (not periodic), H0, H1 <= 64; everything else runs the three-kernel form.
+ */
+#include "bgk_mfma_h2.h"
+
+namespace {
+
+constexpr int QW = 4;              /* waves per workgroup */
+#ifndef BGK_BWD64_OCC
+#define BGK_BWD64_OCC 1            /* workgroups per CU = waves per SIMD: 1 -- the 8 gradient tiles (128 registers) + the chain's working set need the 512-register file */
+#endif
+constexpr int TP = 36;             /* row pitch (floats) of the transposed tile [unit][sample]: 16-byte aligned rows */
+constexpr int OPB = 8 + 16 + 8;    /* 1 KiB operand blocks in LDS: T2 (2 k-steps x 2 tiles x {hi, lo}), T1 (4 x 2 x 2), T0 (4 x 1 x 2) */
+
+struct Bwd64Args {
+    const float* g; int64_t ldg; int d;
+    const float* z1; const float* z0;
+    const float* x; int64_t ldc; int n_in;
+    const uint4* T2; const uint4* T1; const uint4* T0; const float* cs;
+    int act; int64_t B;
+    float* g_x; int64_t ldgx; const float* g_x_add; int64_t ldga;
+    const float* g_absmax;
+    float* pw2; float* pw1; float* pw0; float* pb2; float* pb1; float* pb0;
+    int H1, H0, n_slabs;
+};
+
+/* d = g * act'(z), h = act(z) for a pair (hardware exp / rcp; the forms of bgk_dense_backward_dx) */
+__device__ __forceinline__ void q_act_grad2(int act, bgk_f2 z, bgk_f2 g, bgk_f2& gz, bgk_f2& h) {
+    if (act == 1) {
+        const bgk_f2 y = z * bgk_splat2(-1.44269504088896341f);
+        bgk_f2 e; e.x = __builtin_amdgcn_exp2f(y.x); e.y = __builtin_amdgcn_exp2f(y.y);
+        e = e + bgk_splat2(1.0f);
+        bgk_f2 s; s.x = __builtin_amdgcn_rcpf(e.x); s.y = __builtin_amdgcn_rcpf(e.y);
+        h = z * s;
+        gz = g * (s * (bgk_splat2(1.0f) + z * (bgk_splat2(1.0f) - s)));
+    } else if (act == 2) {
+        h.x = z.x > 0.0f ? z.x : 0.0f; h.y = z.y > 0.0f ? z.y : 0.0f;
+        gz.x = z.x > 0.0f ? g.x : 0.0f; gz.y = z.y > 0.0f ? g.y : 0.0f;
+    } else {
+        h = bgk_tanhf2_fast(z);
+        gz = g * (bgk_splat2(1.0f) - h * h);
+    }
+}
+
+/* acc (2 tiles, accumulator layout) * c -> g_z = . * act'(z) in place, h = act(z); z rows of 64 floats */
+__device__ __forceinline__ void q_load_z(float4 (&zz)[8], const float* zrow, int hh) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zz[4 * m + q] = *reinterpret_cast<const float4*>(zrow + 32 * m + 8 * q + 4 * hh);
+}
+__device__ __forceinline__ void q_act_backward(h2_f32x16 (&t)[2], h2_f32x16 (&hv)[2], float c, int act, const float4 (&zz)[8]) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 z = zz[4 * m + q];
+            bgk_f2 g0, g1, a0, a1;
+            q_act_grad2(act, (bgk_f2){z.x, z.y}, (bgk_f2){t[m][4 * q] * c, t[m][4 * q + 1] * c}, g0, a0);
+            q_act_grad2(act, (bgk_f2){z.z, z.w}, (bgk_f2){t[m][4 * q + 2] * c, t[m][4 * q + 3] * c}, g1, a1);
+            t[m][4 * q] = g0.x; t[m][4 * q + 1] = g0.y; t[m][4 * q + 2] = g1.x; t[m][4 * q + 3] = g1.y;
+            hv[m][4 * q] = a0.x; hv[m][4 * q + 1] = a0.y; hv[m][4 * q + 2] = a1.x; hv[m][4 * q + 3] = a1.y;
+        }
+}
+
+/* two tiles held in accumulator layout (lane = sample j) -> LDS [unit][sample] */
+__device__ __forceinline__ void q_transpose_out(const h2_f32x16 (&t)[2], float* sx, int j, int hh) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sx[(32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh) * TP + j] = t[m][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+/* the 8 samples 16 s + 8 kb .. + 7 of unit `u` out of the transposed tile */
+__device__ __forceinline__ void q_read8(const float* sx, int u, int s, int kb, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(sx + u * TP + 16 * s + 8 * kb);
+    const float4 b = *reinterpret_cast<const float4*>(sx + u * TP + 16 * s + 8 * kb + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void q_release(void) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct QFrag { h2_h16x8 hi, lo; };
+__device__ __forceinline__ h2_f32x16 q_mfma3(h2_f32x16 c, const QFrag& a, const QFrag& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, c, 0, 0, 0);
+}
+__device__ __forceinline__ QFrag q_lds_frag(const uint4* s_op, int blk, int lane) {
+    QFrag f;
+    f.hi = __builtin_bit_cast(h2_h16x8, s_op[(blk + 0) * 64 + lane]);
+    f.lo = __builtin_bit_cast(h2_h16x8, s_op[(blk + 1) * 64 + lane]);
+    return f;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kernel(Bwd64Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint4* s_op = reinterpret_cast<uint4*>(smem);                         /* [OPB][64] operand blocks */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    float* sx = smem + OPB * 256 + wave * (64 * TP);                      /* this wave's transposed tile */
+    /* ---- the network's transposed operands, once per workgroup: T2 blocks (s < 2, m < 2), T1 (s < 4, m < 2), T0 (s < 4; FT = 1) ---- */
+    for (int b = wave; b < OPB; b += QW) {
+        const uint4* src;
+        if (b < 8) { const int p = b & 1, m = (b >> 1) & 1, s = b >> 2; src = a.T2 + ((s * 4 + m) * 2 + p) * 64; }
+        else if (b < 24) { const int c = b - 8, p = c & 1, m = (c >> 1) & 1, s = c >> 2; src = a.T1 + ((s * 4 + m) * 2 + p) * 64; }
+        else { const int c = b - 24; src = a.T0 + c * 64; }
+        s_op[b * 64 + lane] = src[lane];
+    }
+    __syncthreads();
+    const float c2 = a.cs[5], c1 = a.cs[3], c0 = a.cs[1];
+    float inv_sg;
+    const float sg = h2_pow2_scale(a.g_absmax ? a.g_absmax[0] : 0.0f, inv_sg);
+    const int slab = blockIdx.x * QW + wave;
+    const int64_t n_tiles = (a.B + 31) / 32;
+    const int d = a.d, n_in = a.n_in;
+
+    h2_f32x16 dW2[2], dW1[4], dW0[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dW2[0][r] = dW2[1][r] = 0.0f; dW1[0][r] = dW1[1][r] = dW1[2][r] = dW1[3][r] = 0.0f; dW0[0][r] = dW0[1][r] = 0.0f; }
+    float bs2 = 0.0f, bs1[2] = {0.0f, 0.0f}, bs0[2] = {0.0f, 0.0f};
+    const h2_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const int lane_in = lane;
+    for (int64_t tile = slab; tile < n_tiles; tile += a.n_slabs) {
+        /* the lane index is made opaque per tile: otherwise every per-lane address of the loop body (the gathers' 32 row offsets, the
+         * transposed tile's 64 write and 16 read addresses) is hoisted out of the loop as an invariant -- 700 live registers */
+        int lane = lane_in;
+        asm volatile("" : "+v"(lane));
+        const int j = lane & 31, hh = lane >> 5;
+        const int64_t b0 = tile * 32;
+        const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
+        const int jr = j < rows ? j : rows - 1;
+        const float* grow = a.g + (b0 + jr) * a.ldg;
+        /* ---- every global request of the tile up front (one exposed round trip per tile instead of five: one wave per SIMD hides none):
+         * the lane's row of g, its rows of z1 / z0, its column of g and of the conditioner input ---- */
+        float grow_v[2][8], gcol_v[2][8], xcol_v[2][8];
+        float4 zz1[8], zz0[8];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int col = 16 * s + 8 * hh + e, smp = col;
+                const int sr = smp < rows ? smp : rows - 1;
+                grow_v[s][e] = grow[col < d ? col : 0];
+                gcol_v[s][e] = a.g[(b0 + sr) * a.ldg + (j < d ? j : 0)];
+                xcol_v[s][e] = a.x[(b0 + sr) * a.ldc + (j < n_in ? j : 0)];
+            }
+        q_load_z(zz1, a.z1 + (b0 + jr) * 64, hh);
+        q_load_z(zz0, a.z0 + (b0 + jr) * 64, hh);
+        __builtin_amdgcn_sched_barrier(0);
+        /* ---- g_h1 = W2^T g: B operand = the lane's sample row of g (columns 16 s + 8 hh ..), rows past the batch are zero ---- */
+        h2_f32x16 acc[2] = {zero16, zero16};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int col = 16 * s + 8 * hh + e; v[e] = (j < rows && col < d) ? grow_v[s][e] : 0.0f; }
+            QFrag bq;
+            h2_split8_scaled(v, sg, bq.hi, bq.lo);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[m] = q_mfma3(acc[m], q_lds_frag(s_op, ((s * 2 + m) * 2), lane), bq);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        /* ---- g_z1, h1 ---- */
+        h2_f32x16 hv[2];
+        q_act_backward(acc, hv, c2 * inv_sg, ACT, zz1);
+        __builtin_amdgcn_sched_barrier(0);
+        /* ---- dW2 += g^T h1, db2: A = columns of g gathered from the tile's rows, B = h1 through the transposed tile ---- */
+        {
+            QFrag aq[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int smp = 16 * s + 8 * hh + e;
+                    v[e] = (smp < rows && j < d) ? gcol_v[s][e] : 0.0f;
+                    bs2 += v[e];
+                }
+                h2_split8_scaled(v, sg, aq[s].hi, aq[s].lo);
+            }
+            q_transpose_out(hv, sx, j, hh);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                h2_f32x16 tmp = zero16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+                    q_read8(sx, 32 * t + j, s, hh, v);
+                    QFrag bq;
+                    h2_split8(v, bq.hi, bq.lo);
+                    tmp = q_mfma3(tmp, aq[s], bq);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dW2[t][r] = __builtin_fmaf(tmp[r], inv_sg, dW2[t][r]);
+            }
+            q_release();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        /* ---- g_h0 = W1^T g_z1; the same g_z1 as the A operand of dW1 (through the transposed tile) ---- */
+        float inv1;
+        QFrag a1[2][2];
+        {
+            const float s1 = h2_pow2_scale(h2_wave_absmax<2>(acc), inv1);
+            H2B<2> bf;
+            h2_make_b_scaled<2>(bf, acc, s1);
+            q_transpose_out(acc, sx, j, hh);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+                    q_read8(sx, 32 * m + j, s, hh, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bs1[m] += v[e];
+                    h2_split8_scaled(v, s1, a1[m][s].hi, a1[m][s].lo);
+                }
+            q_release();
+            acc[0] = zero16; acc[1] = zero16;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                QFrag bq{bf.hi[s], bf.lo[s]};
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = q_mfma3(acc[m], q_lds_frag(s_op, 8 + ((s * 2 + m) * 2), lane), bq);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        q_act_backward(acc, hv, c1 * inv1, ACT, zz0);
+        __builtin_amdgcn_sched_barrier(0);
+        /* ---- dW1 += g_z1^T h0 ---- */
+        q_transpose_out(hv, sx, j, hh);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            QFrag bq[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+                q_read8(sx, 32 * t + j, s, hh, v);
+                h2_split8(v, bq[s].hi, bq[s].lo);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                h2_f32x16 tmp = zero16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) tmp = q_mfma3(tmp, a1[m][s], bq[s]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dW1[2 * m + t][r] = __builtin_fmaf(tmp[r], inv1, dW1[2 * m + t][r]);
+            }
+        }
+        q_release();
+        __builtin_amdgcn_sched_barrier(0);
+        /* ---- g_x = W0^T g_z0 (+ the caller's addend); g_z0 as the A operand of dW0 ---- */
+        float inv0;
+        QFrag a0[2][2];
+        h2_f32x16 gx = zero16;
+        {
+            const float s0 = h2_pow2_scale(h2_wave_absmax<2>(acc), inv0);
+            H2B<2> bf;
+            h2_make_b_scaled<2>(bf, acc, s0);
+            q_transpose_out(acc, sx, j, hh);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float v[8];
+                    q_read8(sx, 32 * m + j, s, hh, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bs0[m] += v[e];
+                    h2_split8_scaled(v, s0, a0[m][s].hi, a0[m][s].lo);
+                }
+            q_release();
+            if (a.g_x) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    QFrag bq{bf.hi[s], bf.lo[s]};
+                    gx = q_mfma3(gx, q_lds_frag(s_op, 24 + s * 2, lane), bq);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.g_x && j < rows) {
+            float* orow = a.g_x + (b0 + j) * a.ldgx;
+            const float* arow = a.g_x_add ? a.g_x_add + (b0 + j) * a.ldga : nullptr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (f < n_in) orow[f] = gx[r] * (c0 * inv0) + (arow ? arow[f] : 0.0f);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        /* ---- dW0 += g_z0^T x: B = columns of the conditioner input gathered from the tile's rows ---- */
+        {
+            QFrag bq[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int smp = 16 * s + 8 * hh + e;
+                    v[e] = (smp < rows && j < n_in) ? xcol_v[s][e] : 0.0f;
+                }
+                h2_split8(v, bq[s].hi, bq[s].lo);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                h2_f32x16 tmp = zero16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) tmp = q_mfma3(tmp, a0[m][s], bq[s]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dW0[m][r] = __builtin_fmaf(tmp[r], inv0, dW0[m][r]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    /* ---- this wave's partial gradients: accumulator layout -> [rows][cols] of the slab ---- */
+    const int H1 = a.H1, H0 = a.H0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int col = 32 * t + j;
+            if (row < d && col < H1) a.pw2[((int64_t)slab * d + row) * H1 + col] = dW2[t][r];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                if (32 * m + row < H1 && col < H0) a.pw1[((int64_t)slab * H1 + 32 * m + row) * H0 + col] = dW1[2 * m + t][r];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+            if (32 * m + row < H0 && j < n_in) a.pw0[((int64_t)slab * H0 + 32 * m + row) * n_in + j] = dW0[m][r];
+    }
+    if (j < d) a.pb2[((int64_t)slab * 2 + hh) * d + j] = bs2;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (32 * m + j < H1) a.pb1[((int64_t)slab * 2 + hh) * H1 + 32 * m + j] = bs1[m];
+        if (32 * m + j < H0) a.pb0[((int64_t)slab * 2 + hh) * H0 + 32 * m + j] = bs0[m];
+    }
+}
+
+/* fixed-order sum of the per-wave partials (the scheme of wgrad_reduce_kernel, bgk_wgrad.hip): element i of a gradient [n, k] (+ its
+ * bias [n] behind it) = sum over slabs; 8 lanes per element each take every 8th slab, combined in ascending order through LDS */
+struct QRed { const float* pw; const float* pb; int n, k; float* gW; float* gb; };
+struct QRedGroup { QRed r[3]; int64_t first[4]; int n_slabs; };
+__global__ __launch_bounds__(256) void bwd64_reduce_kernel(QRedGroup rg, int accumulate) {
+    __shared__ float s_part[8][32];
+    const int sub = threadIdx.x >> 5, el = threadIdx.x & 31;
+    const int64_t gi = (int64_t)blockIdx.x * 32 + el;
+    const int q = gi >= rg.first[2] ? 2 : (gi >= rg.first[1] ? 1 : 0);
+    const QRed& o = rg.r[q];
+    const int64_t i = gi - rg.first[q];
+    const int64_t nk = (int64_t)o.n * o.k;
+    const int64_t total = gi < rg.first[3] ? nk + o.n : 0;
+    float acc = 0.0f;
+    if (i < nk && i < total) {
+        float a0 = 0.0f, a1 = 0.0f;
+        int s = sub;
+        for (; s + 8 < rg.n_slabs; s += 16) { a0 += o.pw[(int64_t)s * nk + i]; a1 += o.pw[(int64_t)(s + 8) * nk + i]; }
+        if (s < rg.n_slabs) a0 += o.pw[(int64_t)s * nk + i];
+        acc = a0 + a1;
+    } else if (i < total) {
+        const int col = (int)(i - nk);
+        float a0 = 0.0f, a1 = 0.0f;
+        int s = sub;
+        for (; s + 8 < 2 * rg.n_slabs; s += 16) { a0 += o.pb[(int64_t)s * o.n + col]; a1 += o.pb[(int64_t)(s + 8) * o.n + col]; }
+        if (s < 2 * rg.n_slabs) a0 += o.pb[(int64_t)s * o.n + col];
+        acc = a0 + a1;
+    }
+    s_part[sub][el] = acc;
+    __syncthreads();
+    if (sub == 0) {
+        float t = s_part[0][el];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) t += s_part[u][el];
+        if (i < nk && i < total) { if (o.gW) o.gW[i] = accumulate ? o.gW[i] + t : t; }
+        else if (i < total) { if (o.gb) o.gb[i - nk] = accumulate ? o.gb[i - nk] + t : t; }
+    }
+}
+
+int bwd64_slabs(int64_t B) {
+    const int64_t tiles = (B + 31) / 32;
+    int64_t want = 256 * BGK_BWD64_OCC * QW;            /* BGK_BWD64_OCC workgroups per CU */
+    if (tiles < want) want = ((tiles + QW - 1) / QW) * QW;
+    return (int)(want < QW ? QW : want);
+}
+
+}  // namespace
+
+extern "C" int64_t bgk_affine_net_backward64_workspace(int64_t B, int32_t d, int32_t H1, int32_t H0, int32_t n_in) {
+    const int64_t s = bwd64_slabs(B);
+    return s * ((int64_t)d * H1 + (int64_t)H1 * H0 + (int64_t)H0 * n_in) + 2 * s * ((int64_t)d + H1 + H0);
+}
+
+extern "C" int bgk_affine_net_backward64(const float* g, int64_t ldg, int32_t d, const float* z1, const float* z0,
+                                         const float* cond, int64_t ldc, int32_t n_in, int32_t H1, int32_t H0,
+                                         const void* T0, const void* T1, const void* T2, const float* cs, int32_t act, int64_t B,
+                                         float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga, const float* g_absmax,
+                                         float* workspace, int64_t workspace_floats,
+                                         float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
+                                         void* stream) {
+    if (B == 0) return 0;
+    BGK_CHECK_ARG(g && z1 && z0 && cond && T0 && T1 && T2 && cs && workspace, "bgk_affine_net_backward64: null pointer");
+    BGK_CHECK_ARG(B > 0 && d > 0 && n_in > 0 && H1 > 0 && H0 > 0 && ldg >= d && ldc >= n_in && act >= 1 && act <= 3 && (accumulate == 0 || accumulate == 1),
+                  "bgk_affine_net_backward64: bad sizes");
+    if (d > 32 || n_in > 32 || H1 > 64 || H0 > 64) {
+        bgk_set_error("bgk_affine_net_backward64: d = %d, n_in = %d, hidden (%d, %d): the kernel takes d, n_in <= 32 and hidden layers of <= 64 units", d, n_in, H0, H1);
+        return BGK_EUNSUPPORTED;
+    }
+    BGK_CHECK_ARG(workspace_floats >= bgk_affine_net_backward64_workspace(B, d, H1, H0, n_in), "bgk_affine_net_backward64: workspace too small");
+    const int n_slabs = bwd64_slabs(B);
+    Bwd64Args a;
+    a.g = g; a.ldg = ldg; a.d = d; a.z1 = z1; a.z0 = z0; a.x = cond; a.ldc = ldc; a.n_in = n_in;
+    a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.cs = cs; a.act = act; a.B = B;
+    a.g_x = g_cond; a.ldgx = ldgc; a.g_x_add = g_cond ? g_cond_add : nullptr; a.ldga = ldga; a.g_absmax = g_absmax;
+    a.H1 = H1; a.H0 = H0; a.n_slabs = n_slabs;
+    float* p = workspace;
+    a.pw2 = p; p += (int64_t)n_slabs * d * H1;
+    a.pw1 = p; p += (int64_t)n_slabs * H1 * H0;
+    a.pw0 = p; p += (int64_t)n_slabs * H0 * n_in;
+    a.pb2 = p; p += (int64_t)2 * n_slabs * d;
+    a.pb1 = p; p += (int64_t)2 * n_slabs * H1;
+    a.pb0 = p;
+    const size_t shmem = sizeof(float) * ((size_t)OPB * 256 + (size_t)QW * 64 * TP);
+    hipStream_t st = (hipStream_t)stream;
+#define BGK_LAUNCH_Q(A) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(affine_net_bwd64_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                             hipLaunchKernelGGL((affine_net_bwd64_kernel<A>), dim3(n_slabs / QW), dim3(QW * 64), shmem, st, a); } while (0)
+    if (act == 1) BGK_LAUNCH_Q(1); else if (act == 2) BGK_LAUNCH_Q(2); else BGK_LAUNCH_Q(3);
+#undef BGK_LAUNCH_Q
+    QRedGroup rg;
+    rg.r[0] = QRed{a.pw2, a.pb2, d, H1, gW2, gb2};
+    rg.r[1] = QRed{a.pw1, a.pb1, H1, H0, gW1, gb1};
+    rg.r[2] = QRed{a.pw0, a.pb0, H0, n_in, gW0, gb0};
+    rg.first[0] = 0;
+    rg.first[1] = (int64_t)d * H1 + d;
+    rg.first[2] = rg.first[1] + (int64_t)H1 * H0 + H1;
+    rg.first[3] = rg.first[2] + (int64_t)H0 * n_in + H0;
+    rg.n_slabs = n_slabs;
+    hipLaunchKernelGGL(bwd64_reduce_kernel, dim3((unsigned)((rg.first[3] + 31) / 32)), dim3(256), 0, st, rg, accumulate);
+    return bgk_launch_status("bgk_affine_net_backward64");
+}

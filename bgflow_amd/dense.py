@@ -1859,6 +1859,8 @@ def _affine_net_backward(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, 
     tb = e["tbufs"]
     d_c, periodic, n_in = plan["d_c"], plan["periodic"], e["lins"][0].in_features
     ldz = plan["ldz"]
+    if FUSED_BWD64 and ldz == 64 and d <= 32 and n_in <= 32 and not periodic and (all(need_w) or not any(need_w)):
+        return _affine_net_backward64(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, gx_buf, gx_add, need_w)
     gz = torch.empty((2, B + HALF_PAD_ROWS, ldz), dtype=torch.float32, device=dev)[:, :B]
     lib = _lib.lib()
     add2, lda = (gx_add, gx_add.stride(0)) if (gx_add is not None and want_gx) else (None, 0)
@@ -1903,6 +1905,46 @@ def _affine_net_backward(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, 
     if direct:
         return (None,) * 6
     return tuple(g if n else None for g, n in zip((gW0, gb0, gW1, gb1, gW2, gb2), need_w))
+
+
+FUSED_BWD64 = os.environ.get("BGK_FUSED_BWD64", "1") != "0"      # networks of <= 64 hidden units: chain + weight gradients in one launch
+
+
+def _affine_net_backward64(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, gx_buf, gx_add, need_w):
+    """bgk_affine_net_backward64: _affine_net_backward's work for a network of <= 64 hidden units in one launch (g_z1 / g_z0 stay on chip)"""
+    dev = g_net.device
+    B, d = g_net.shape[0], plan["y_dim"]
+    tb = e["tbufs"]
+    n_in, H0, H1 = e["lins"][0].in_features, e["H0"], e["H1"]
+    lib = _lib.lib()
+    need_ws = int(lib.bgk_affine_net_backward64_workspace(B, d, H1, H0, n_in))
+    ws = tb.get("bwd64_ws")
+    if ws is None or ws.numel() < need_ws or ws.device != dev:
+        ws = tb["bwd64_ws"] = torch.empty(need_ws, dtype=torch.float32, device=dev)
+    l0, l1, l2 = e["lins"]
+    params = (l0.weight, l0.bias, l1.weight, l1.bias, l2.weight, l2.bias)
+    want_w = all(need_w)
+    direct = want_w and _DIRECT_GRADS[0] and all(
+        getattr(p, "_bgk_grad_dst", None) is not None and p.grad is not None and p.grad.data_ptr() == p._bgk_grad_dst.data_ptr() for p in params)
+    if direct:
+        gW0, gb0, gW1, gb1, gW2, gb2 = (p._bgk_grad_dst for p in params)
+    elif want_w:
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)      # noqa: E731
+        gW0, gb0, gW1, gb1, gW2, gb2 = new(H0, n_in), new(H0), new(H1, H0), new(H1), new(d, H1), new(d)
+    else:
+        gW0 = gb0 = gW1 = gb1 = gW2 = gb2 = None
+    add2, lda = (gx_add, gx_add.stride(0)) if (gx_add is not None and want_gx) else (None, 0)
+    with torch.cuda.device(dev):
+        st = lib.bgk_affine_net_backward64(
+            _lib.ptr(g_net), ldg, d, _lib.ptr(z1), _lib.ptr(z0), _lib.ptr(x2), ldc, n_in, H1, H0,
+            _lib.ptr(tb["T0"]), _lib.ptr(tb["T1"]), _lib.ptr(tb["T2"]), _lib.ptr(e["cs"]), e["act"], B,
+            _lib.ptr(gx_buf) if want_gx else None, gx_buf.stride(0) if want_gx else n_in, _lib.ptr(add2), lda, _lib.ptr(absmax),
+            _lib.ptr(ws), ws.numel(), _lib.ptr(gW2), _lib.ptr(gb2), _lib.ptr(gW1), _lib.ptr(gb1), _lib.ptr(gW0), _lib.ptr(gb0), int(direct),
+            _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_affine_net_backward64")
+    if direct or not want_w:
+        return (None,) * 6
+    return gW0, gb0, gW1, gb1, gW2, gb2
 
 
 class _FusedAffineTrainFn(torch.autograd.Function):

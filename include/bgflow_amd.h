@@ -695,6 +695,26 @@ int bgk_mlp_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* 
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).
  * Deterministic two-stage reduction; `partial` is a caller-provided [nblk, P] workspace. */
+/* bgk_affine_net_backward64 (round 6): backward of ONE conditioner network [n_in, H0, H1, d] of an affine coupling with hidden layers
+ * of <= 64 units, d <= 32 transformed dims and n_in <= 32 (non-periodic) inputs -- BASELINE cfg 2's DenseNet([32, 64, 64, 32]) shift /
+ * scale networks -- in ONE launch + one reduction: the input-gradient chain of bgk_mlp_backward_dx AND the weight / bias gradients of
+ * bgk_mlp_weight_grad, with g_z1 / g_z0 never written to memory: the weight gradients contract over the batch, a wave forms its tiles'
+ * share g^T h on chip (operands transposed through LDS) and keeps the network's three gradients in 128 accumulator registers across all
+ * its tiles; per-wave partials in `workspace` (bgk_affine_net_backward64_workspace floats), summed in fixed order.  Autograd of
+ * nn/dense.py:47-48 behind nn/flow/transformer/affine.py:35-43 in loss.backward() (nn/training/trainers.py:156-163).
+ *   g [B, d] (row stride ldg): gradient w.r.t. the network's output; z1, z0 [B, 64] contiguous (bgk_coupling_affine_dense_h2_train, ldz = 64)
+ *   T0, T1, T2, cs: the transposed operands / scale table of bgk_pack_mlp_h2_t; g_absmax: device float[1] = max |g| (or NULL)
+ *   g_cond (may be NULL) = W0^T g_z0 + g_cond_add; gW2 [d, H1], gW1 [H1, H0], gW0 [H0, n_in] + biases: written, or (accumulate = 1) added to
+ * BGK_EUNSUPPORTED outside the envelope: the caller runs bgk_mlp_backward_dx + bgk_mlp_weight_grad. */
+int64_t bgk_affine_net_backward64_workspace(int64_t B, int32_t d, int32_t H1, int32_t H0, int32_t n_in);
+int bgk_affine_net_backward64(const float* g, int64_t ldg, int32_t d, const float* z1, const float* z0,
+                              const float* cond, int64_t ldc, int32_t n_in, int32_t H1, int32_t H0,
+                              const void* T0, const void* T1, const void* T2, const float* cs, int32_t act, int64_t B,
+                              float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga, const float* g_absmax,
+                              float* workspace, int64_t workspace_floats,
+                              float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
+                              void* stream);
+
 /* bgk_linear_weight_grad (round 6): ONE Linear layer of any width -- gW [n, k] = g^T h (row-major, contiguous), gb [n] = sum_rows g
  * (may be NULL) for g [B, n], h [B, k]: autograd of nn/dense.py:47-48 for a Linear outside the fused training envelopes (conditioners
  * of other depths / widths, factory/conditioner_factory.py:81-85; a stand-alone DenseNet).  Split-f16 products under the power-of-two
