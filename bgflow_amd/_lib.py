@@ -35,7 +35,10 @@ _SIGNATURES = {
     "bgk_mlp_backward_dx": (ctypes.c_int, [vp, i64, i32, vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp, i32, i64,
                                            vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp]),
     "bgk_pack_mlp_h2": (ctypes.c_int, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
-    "bgk_pack_mlp_h2_many": (ctypes.c_int, [i32] + [vp] * 17 + [vp]),
+    "bgk_pack_mlp_h2_many": (ctypes.c_int, [i32] + [vp] * 18 + [vp]),
+    "bgk_coupling_affine_dense_fwd64_train": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32,
+                                                             vp, i32, i32, i32, vp, i64, i64, i32, vp, i64, vp, i32,
+                                                             vp, vp, vp, vp, vp, vp, i64, vp]),
     "bgk_pack_mlp_h2_t": (ctypes.c_int, [vp, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     "bgk_pack_mlp_h2_t_many": (ctypes.c_int, [i32] + [vp] * 11 + [vp]),
     "bgk_mlp_weight_grad_workspace": (i64, [i64, i32, i32, i32, i32]),

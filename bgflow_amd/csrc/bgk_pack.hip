@@ -228,12 +228,13 @@ extern "C" int bgk_pack_mlp_h2(const float* W0, const float* b0, int32_t n_in, i
     return bgk_launch_status("bgk_pack_mlp_h2");
 }
 
-/* bgk_pack_mlp_h2 of n conditioners in two launches per 16 (HT = 4: the operands of kernels that run 128 hidden rows); H0 / H1 / NT2
- * may be NULL: 128 / 128 / 4 for every conditioner (= bgk_pack_dense_h2_many) */
+/* bgk_pack_mlp_h2 of n conditioners in two launches per 16; H0 / H1 / NT2 / HT may be NULL: 128 / 128 / 4 / 4 for every conditioner
+ * (= bgk_pack_dense_h2_many) */
 extern "C" int bgk_pack_mlp_h2_many(int32_t n, const float* const* W0, const float* const* b0, const int32_t* n_in, const int32_t* H0,
                                     const float* const* W1, const float* const* b1, const int32_t* H1,
                                     const float* const* W2, const float* const* b2,
                                     const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2, const int32_t* NT2,
+                                    const int32_t* HT,
                                     void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream) {
     BGK_CHECK_ARG(n >= 0 && W0 && b0 && n_in && W1 && b1 && W2 && b2 && rows2 && row_map2_dev && n_groups2 && A0 && A1 && A2 && cs,
                   "bgk_pack_mlp_h2_many: null pointer");
@@ -245,13 +246,13 @@ extern "C" int bgk_pack_mlp_h2_many(int32_t n, const float* const* W0, const flo
         int max_blocks = 0;
         for (int c = 0; c < cnt; ++c) {
             const int i = base + c;
-            const int h0 = H0 ? H0[i] : 128, h1 = H1 ? H1[i] : 128, nt2 = NT2 ? NT2[i] : 4;
+            const int h0 = H0 ? H0[i] : 128, h1 = H1 ? H1[i] : 128, nt2 = NT2 ? NT2[i] : 4, ht = HT ? HT[i] : 4;
             BGK_CHECK_ARG(W0[i] && b0[i] && W1[i] && b1[i] && W2[i] && b2[i] && A0[i] && A1[i] && A2[i] && cs[i] && n_in[i] > 0 && rows2[i] > 0
-                          && n_groups2[i] > 0 && h0 > 0 && h0 <= 128 && h1 > 0 && h1 <= 128 && nt2 >= 1 && nt2 <= 4,
+                          && n_groups2[i] > 0 && ht >= 1 && ht <= 4 && h0 > 0 && h0 <= 32 * ht && h1 > 0 && h1 <= 32 * ht && nt2 >= 1 && nt2 <= 4,
                           "bgk_pack_mlp_h2_many: bad conditioner %d", i);
-            PackLayer L0{W0[i], b0[i], h0, n_in[i], nullptr, 1, 4, (n_in[i] + 1 + 15) / 16, 1, (_Float16*)A0[i], 0};
-            PackLayer L1{W1[i], b1[i], h1, h0, nullptr, 1, 4, 8, 0, (_Float16*)A1[i], 0};
-            PackLayer L2{W2[i], b2[i], rows2[i], h1, row_map2_dev[i], n_groups2[i], nt2, 8, 0, (_Float16*)A2[i], 0};
+            PackLayer L0{W0[i], b0[i], h0, n_in[i], nullptr, 1, ht, (n_in[i] + 1 + 15) / 16, 1, (_Float16*)A0[i], 0};
+            PackLayer L1{W1[i], b1[i], h1, h0, nullptr, 1, ht, 2 * ht, 0, (_Float16*)A1[i], 0};
+            PackLayer L2{W2[i], b2[i], rows2[i], h1, row_map2_dev[i], n_groups2[i], nt2, 2 * ht, 0, (_Float16*)A2[i], 0};
             const int blocks = fill_group(M.c[c].g, L0, L1, L2);
             M.c[c].cs = cs[i];
             max_blocks = blocks > max_blocks ? blocks : max_blocks;
@@ -267,5 +268,5 @@ extern "C" int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const f
                                       const float* const* W1, const float* const* b1, const float* const* W2, const float* const* b2,
                                       const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2,
                                       void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream) {
-    return bgk_pack_mlp_h2_many(n, W0, b0, n_in, nullptr, W1, b1, nullptr, W2, b2, rows2, row_map2_dev, n_groups2, nullptr, A0, A1, A2, cs, stream);
+    return bgk_pack_mlp_h2_many(n, W0, b0, n_in, nullptr, W1, b1, nullptr, W2, b2, rows2, row_map2_dev, n_groups2, nullptr, nullptr, A0, A1, A2, cs, stream);
 }

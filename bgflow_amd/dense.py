@@ -1757,10 +1757,16 @@ def _affine_train_plan(transformer, y_dim, dev):
     if y_dim > 96 or n_in > T_OPERAND_MAX_IN or (periodic and n_in % 2):
         return None
     cache = transformer.__dict__.setdefault("_train_cache", {})
-    key = (y_dim, n_in, bool(periodic), str(dev), tuple(None if sp is None else (sp[0][0].out_features, sp[0][1].out_features, sp[1]) for sp in specs))
+    key = (y_dim, n_in, bool(periodic), str(dev), FUSED_FWD64,
+           tuple(None if sp is None else (sp[0][0].out_features, sp[0][1].out_features, sp[1]) for sp in specs))
     if cache.get("key") != key:
         cache.clear()
         OT, S0 = (y_dim + 31) // 32, (n_in + 1 + 15) // 16
+        # networks of <= 64 hidden units, <= 32 dims / non-periodic inputs: the kernels sized for them (bgk_coupling_affine_dense_fwd64_train,
+        # bgk_affine_net_backward64) on operands packed for 64 hidden rows (HT = 2)
+        small = (FUSED_FWD64 and y_dim <= 32 and n_in <= 32 and not periodic
+                 and all(max(sp[0][0].out_features, sp[0][1].out_features) <= 64 for sp in specs if sp is not None))
+        HT = 2 if small else 4
         entries = []
         for sp in specs:
             if sp is None:
@@ -1770,11 +1776,12 @@ def _affine_train_plan(transformer, y_dim, dev):
             tb = {}
             _t_operand_bufs(tb, y_dim, n_in, dev)
             entries.append(dict(lins=sp[0], act=sp[1], H0=sp[0][0].out_features, H1=sp[0][1].out_features,
-                                A0=f16(S0 * 8), A1=f16(8 * 8 + 4), A2=f16(8 * OT * 2 + OT), cs=torch.empty(6, dtype=torch.float32, device=dev),
+                                A0=f16(S0 * HT * 2), A1=f16(2 * HT * HT * 2 + HT), A2=f16(2 * HT * OT * 2 + OT),
+                                cs=torch.empty(6, dtype=torch.float32, device=dev),
                                 tbufs=tb, version=None))
         # row pitch of the saved pre-activations / their gradients: [B, 64] when no hidden layer has more than 64 units (half the bytes)
         ldz = 64 if all(max(e["H0"], e["H1"]) <= 64 for e in entries if e is not None) else 128
-        cache.update(key=key, nets=entries, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), OT=OT, y_dim=y_dim, ldz=ldz)
+        cache.update(key=key, nets=entries, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), OT=OT, y_dim=y_dim, ldz=ldz, HT=HT)
     lib = _lib.lib()
     for e in cache["nets"]:
         if e is None:
@@ -1786,7 +1793,7 @@ def _affine_train_plan(transformer, y_dim, dev):
         ws = [t.detach() for lin in e["lins"] for t in (lin.weight, lin.bias)]
         with torch.cuda.device(dev):
             st = lib.bgk_pack_mlp_h2(_lib.ptr(ws[0]), _lib.ptr(ws[1]), n_in, e["H0"], _lib.ptr(ws[2]), _lib.ptr(ws[3]), e["H1"],
-                                     _lib.ptr(ws[4]), _lib.ptr(ws[5]), y_dim, None, 1, cache["OT"], 4,
+                                     _lib.ptr(ws[4]), _lib.ptr(ws[5]), y_dim, None, 1, cache["OT"], cache["HT"],
                                      _lib.ptr(e["A0"]), _lib.ptr(e["A1"]), _lib.ptr(e["A2"]), _lib.ptr(e["cs"]), _lib.stream_ptr(dev))
             _lib.check(st, "bgk_pack_mlp_h2")
             tb = e["tbufs"]
@@ -1831,7 +1838,7 @@ def repack_affine_training_plans(param_ids=None):
                 n, col(lambda it: it[2][0].data_ptr()), col(lambda it: it[2][1].data_ptr()), n_in, num(lambda it: it[1]["H0"]),
                 col(lambda it: it[2][2].data_ptr()), col(lambda it: it[2][3].data_ptr()), num(lambda it: it[1]["H1"]),
                 col(lambda it: it[2][4].data_ptr()), col(lambda it: it[2][5].data_ptr()), num(lambda it: it[0]["y_dim"]),
-                vps(*[None] * n), num(lambda it: 1), num(lambda it: it[0]["OT"]),
+                vps(*[None] * n), num(lambda it: 1), num(lambda it: it[0]["OT"]), num(lambda it: it[0]["HT"]),
                 col(lambda it: it[1]["A0"].data_ptr()), col(lambda it: it[1]["A1"].data_ptr()), col(lambda it: it[1]["A2"].data_ptr()),
                 col(lambda it: it[1]["cs"].data_ptr()), _lib.stream_ptr(dev))
             _lib.check(st, "bgk_pack_mlp_h2_many")
@@ -1907,6 +1914,7 @@ def _affine_net_backward(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, 
     return tuple(g if n else None for g, n in zip((gW0, gb0, gW1, gb1, gW2, gb2), need_w))
 
 
+FUSED_FWD64 = os.environ.get("BGK_FUSED_FWD64", "1") != "0"      # ... and their training forward on the kernel sized for them
 FUSED_BWD64 = os.environ.get("BGK_FUSED_BWD64", "1") != "0"      # networks of <= 64 hidden units: chain + weight gradients in one launch
 
 
@@ -1967,6 +1975,19 @@ class _FusedAffineTrainFn(torch.autograd.Function):
         ops = []
         for e in (es, et):
             ops += [None, None, None, None, 0] if e is None else [_lib.ptr(e["A0"]), _lib.ptr(e["A1"]), _lib.ptr(e["A2"]), _lib.ptr(e["cs"]), e["act"]]
+        st = -2
+        if plan["HT"] == 2:
+            with torch.cuda.device(dev):
+                st = _lib.lib().bgk_coupling_affine_dense_fwd64_train(
+                    _lib.ptr(x2), ldc, x2.shape[1], *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
+                    _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), 0,
+                    _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms, _lib.stream_ptr(dev))
+            _lib.check(st, "bgk_coupling_affine_dense_fwd64_train")
+            ctx.save_for_backward(x2, y2, log_alpha, zz, ms)
+            ctx.plan, ctx.cfg = plan, cfg
+            ctx.versions = [None if e is None else e["version"] for e in (es, et)]
+            ctx.x_shape = x.shape
+            return out, dlogp[:, None]
         ptrs, lds, widths, n, _keep = _lib.cond_segments([x2])
         with torch.cuda.device(dev):
             st = _lib.lib().bgk_coupling_affine_dense_h2_train(

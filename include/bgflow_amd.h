@@ -533,8 +533,8 @@ int bgk_pack_dense_h2_many(int32_t n, const float* const* W0, const float* const
 /* bgk_pack_dense_h2 / _many for conditioners whose hidden layers have H0 / H1 <= 32 HT units (DenseNet([n_in, H0, H1, rows2]),
  * nn/dense.py:9-28; factory/conditioner_factory.py:81-85 takes any `hidden` tuple): the operands are laid out for a kernel that runs
  * 32 HT hidden rows, the rows / k-slots past H0 / H1 are zero (act(0) = 0 feeds zero columns: the same function), no padded copy of
- * the weights exists.  Affine networks: row_map2_dev = NULL, n_groups2 = 1, NT2 = ceil(d / 32).  _many: HT = 4; H0 / H1 / NT2 may be
- * NULL (128 / 128 / 4 for every conditioner). */
+ * the weights exists.  Affine networks: row_map2_dev = NULL, n_groups2 = 1, NT2 = ceil(d / 32).  _many: H0 / H1 / NT2 / HT may be NULL
+ * (128 / 128 / 4 / 4 for every conditioner). */
 int bgk_pack_mlp_h2(const float* W0, const float* b0, int32_t n_in, int32_t H0,
                     const float* W1, const float* b1, int32_t H1,
                     const float* W2, const float* b2, int32_t rows2,
@@ -544,6 +544,7 @@ int bgk_pack_mlp_h2_many(int32_t n, const float* const* W0, const float* const* 
                          const float* const* W1, const float* const* b1, const int32_t* H1,
                          const float* const* W2, const float* const* b2,
                          const int32_t* rows2, const int32_t* const* row_map2_dev, const int32_t* n_groups2, const int32_t* NT2,
+                         const int32_t* HT,
                          void* const* A0, void* const* A1, void* const* A2, float* const* cs, void* stream);
 
 /* Input-gradient chain of the conditioner MLP [n_in, 128, 128, P] in one launch (autograd of nn/dense.py:47-48 in the
@@ -695,6 +696,20 @@ int bgk_mlp_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* 
 /* Column sums of a row-major [B, P] matrix: out[c] = sum_r x[r, c] -- the bias gradient of a Linear layer
  * (autograd of the conditioner MLP, nn/dense.py:47-48, inside KLTrainer.train, nn/training/trainers.py:158-170).
  * Deterministic two-stage reduction; `partial` is a caller-provided [nblk, P] workspace. */
+/* bgk_coupling_affine_dense_fwd64_train (round 6): bgk_coupling_affine_dense_h2_train for networks with hidden layers of <= 64 units,
+ * d <= 32 transformed dims and ONE non-periodic conditioning tensor of n_in <= 32 columns (BASELINE cfg 2's couplings,
+ * nn/flow/transformer/affine.py:35-70 with DenseNet([32, 64, 64, 32]) networks) on a kernel sized for them: operands packed for 64
+ * hidden rows (bgk_pack_mlp_h2 with HT = 2, NT2 = 1) resident in LDS, three waves per SIMD; z0 / z1 [B, 64] contiguous, mu / s_raw
+ * [B, ldms].  Same outputs, bit for bit (same products in the same order).  BGK_EUNSUPPORTED outside the envelope. */
+int bgk_coupling_affine_dense_fwd64_train(const float* cond, int64_t ldc, int32_t n_in,
+                                          const void* sA0, const void* sA1, const void* sA2, const float* s_cs, int32_t s_act,
+                                          const void* tA0, const void* tA1, const void* tA2, const float* t_cs, int32_t t_act,
+                                          const float* log_alpha, int32_t preserve_volume, int32_t is_circular, int32_t inverse,
+                                          const float* y, int64_t ldy, int64_t B, int32_t d, float* out, int64_t ldo,
+                                          float* dlogp, int32_t accumulate,
+                                          float* s_z0, float* s_z1, float* t_z0, float* t_z1, float* mu, float* s_raw, int64_t ldms,
+                                          void* stream);
+
 /* bgk_affine_net_backward64 (round 6): backward of ONE conditioner network [n_in, H0, H1, d] of an affine coupling with hidden layers
  * of <= 64 units, d <= 32 transformed dims and n_in <= 32 (non-periodic) inputs -- BASELINE cfg 2's DenseNet([32, 64, 64, 32]) shift /
  * scale networks -- in ONE launch + one reduction: the input-gradient chain of bgk_mlp_backward_dx AND the weight / bias gradients of

@@ -210,7 +210,8 @@ def test_kl_step_of_affine_flows_launches_no_library_gemm(hip_lib, dev, cfg):
         opt.step()
     names = _device_kernel_names(step)
     bad = [n for n in names if "Cijk_" in n or "gemm" in n.lower() or any(k in n.lower() for k in ("silu", "tanh", "threshold", "relu"))]
-    ours = [n for n in names if "coupling_affine_dense_v2_train_kernel" in n]
+    # (cfg 2's 64-unit networks: the kernel sized for them; cfg 5's 128-unit ones: the width-128 kernel)
+    ours = [n for n in names if "coupling_affine_dense_v2_train_kernel" in n or "coupling_affine_fwd64_train_kernel" in n]
     from collections import Counter
     print(f"{cfg}: {len(names)} device kernels in one KL step;", dict(Counter(n.split("<")[0].split("(")[0][-60:] for n in names)))
     assert not bad, f"library / aten kernels in a {cfg} KL step: {sorted(set(bad))}"
@@ -358,3 +359,35 @@ def test_training_a_wide_conditioner_launches_no_library_gemm(hip_lib, dev):
     bad = [n for n in names if "Cijk_" in n or "gemm" in n.lower() or any(k in n.lower() for k in ("silu", "tanh", "threshold"))]
     assert not bad, sorted(set(bad))
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
+
+
+def test_small_network_kernels_equal_the_general_path(hip_lib, dev):
+    """cfg 2's coupling shape takes the kernels sized for 64-unit networks (bgk_coupling_affine_dense_fwd64_train,
+    bgk_affine_net_backward64); with them switched off the same layer runs the width-128 training forward and the three-kernel
+    backward: identical forward values (same products, same order), gradients equal to accumulation-order noise; partial tiles and a
+    strided conditioning / transformed pair (the two halves of one [B, 64] tensor, as SplitFlow hands them over)."""
+    from bgflow_amd import dense
+    flow = _affine_layer(32, (64, 64), 32, (torch.nn.ReLU, torch.nn.Tanh)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    full = torch.randn(4133, 64, device=dev, generator=g)
+
+    def run():
+        for p in flow.parameters():
+            p.grad = None
+        z = full.clone().requires_grad_(True)
+        x, y = z[:, :32], z[:, 32:]
+        _, out, dl = flow(x, y)
+        (out.square().mean() - dl.mean() + (out * x).mean()).backward()
+        return out.detach(), dl.detach(), z.grad.clone(), {n: p.grad.clone() for n, p in flow.named_parameters()}
+    small = run()
+    assert flow[0].transformer._train_cache["HT"] == 2
+    try:
+        dense.FUSED_FWD64 = dense.FUSED_BWD64 = False
+        general = run()
+        assert flow[0].transformer._train_cache["HT"] == 4
+    finally:
+        dense.FUSED_FWD64 = dense.FUSED_BWD64 = True
+    assert torch.equal(small[0], general[0]) and torch.equal(small[1], general[1])
+    assert float((small[2] - general[2]).norm() / general[2].norm()) <= 2e-6
+    rel, worst = _grad_errors(small[3], general[3])
+    assert rel <= 2e-6, (rel, worst)
