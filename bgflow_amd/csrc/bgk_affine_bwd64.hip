@@ -15,8 +15,8 @@
  * The batch contraction needs its operands with the SAMPLE index along k: what a lane holds in accumulator layout (lane = sample) is
  * transposed through a wave-private LDS tile [unit][sample]; columns of g and x are gathered from the tile's rows (cache hits).  All
  * products are split-f16 (hi + lo, three MFMAs, f32 accumulate) under power-of-two scales: g under the tensor's (bgk_affine_backward
- * publishes max |g|), g_z1 / g_z0 under their tile's own -- each tile's product lands in a temporary accumulator and is added to the running
- * gradient with the scale removed, so tiles of different magnitude accumulate in f32.  Per-wave partial gradients go to a workspace and
+ * publishes max |g|), g_z1 / g_z0 under the scale of the largest tile maximum the wave has seen so far -- the gradients accumulate in that
+ * scaled domain and are rescaled (exactly, by a power of two) on the few occasions the running scale shrinks.  Per-wave partial gradients go to a workspace and
  * are summed in fixed order by wgrad_reduce_kernel's twin below (deterministic, no atomics).
  * Envelope: d <= 32, n_in <= 32 (not periodic), H0, H1 <= 64; everything else runs the three-kernel form.
  */
@@ -41,6 +41,7 @@ struct Bwd64Args {
     const float* g_absmax;
     float* pw2; float* pw1; float* pw0; float* pb2; float* pb1; float* pb0;
     int H1, H0, n_slabs;
+    int vec_gx;          /* rows of g_cond (and of its addend) start on 16-byte boundaries and n_in is a multiple of 4 */
 };
 
 /* d = g * act'(z), h = act(z) for a pair (hardware exp / rcp; the forms of bgk_dense_backward_dx) */
@@ -115,12 +116,78 @@ __device__ __forceinline__ QFrag q_lds_frag(const uint4* s_op, int blk, int lane
     return f;
 }
 
+/* raw buffer loads on a descriptor of the tile's rows: a 32-bit per-lane offset + a wave-uniform offset per request instead of a 64-bit
+ * address per element (the first form of this kernel spent 600 of its 4 000 instructions per tile on address arithmetic), and rows past
+ * the batch / masked columns read as 0 from the hardware range check -- no per-element compare / select */
+constexpr int Q_OOB = 0x7ffffff0;
+__device__ __forceinline__ float q_ld1(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+typedef unsigned q_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 q_ld4(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const q_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    const unsigned w0 = v[0], w1 = v[1], w2 = v[2], w3 = v[3];      /* (by value: __builtin_bit_cast of a vector ELEMENT picks element 0 every time) */
+    return make_float4(__uint_as_float(w0), __uint_as_float(w1), __uint_as_float(w2), __uint_as_float(w3));
+}
+/* f32 -> f16 hi / lo operand halves WITHOUT inline assembly.  The asm form of the other kernels (h2_split_pair: v_cvt_pk_f16_f32 + two
+ * v_fma_mix) is invisible to the compiler's hazard recogniser: a matrix instruction that reads a register such an asm statement wrote a
+ * cycle or two earlier gets the OLD contents.  Elsewhere dozens of instructions sit between the split and its consumer; here (short ReLU
+ * activation code, one wave per SIMD, nothing else to issue) they met: run-to-run different gradients, occasionally inf (the lo half
+ * of an overflowed value), tools/r06_dbg_bwd64_direct.py.  Written with conversions and an fma the compiler knows, it selects the same
+ * instructions (v_cvt_pk_f16_f32, v_fma_mix*) AND keeps the required distance. */
+typedef _Float16 q_h2 __attribute__((ext_vector_type(2)));
+typedef float q_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void q_split8s(const float (&v)[8], float sc, QFrag& f) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const float a0 = v[e] * sc, a1 = v[e + 1] * sc;
+        const q_h2 h = __builtin_convertvector((q_f2){a0, a1}, q_h2);
+        f.hi[e] = h[0]; f.hi[e + 1] = h[1];
+        f.lo[e] = (_Float16)__builtin_fmaf((float)h[0], -1.0f, a0);
+        f.lo[e + 1] = (_Float16)__builtin_fmaf((float)h[1], -1.0f, a1);
+    }
+}
+/* 8 unscaled values (activations, conditioner inputs): clamped to the f16 range like the forward's */
+__device__ __forceinline__ void q_split8(const float (&v)[8], QFrag& f) { h2_split8(v, f.hi, f.lo); }
+
+/* two tiles in accumulator layout x a power-of-two scale -> the B operands of the four k-steps over their 64 rows (h2_make_b_scaled) */
+__device__ __forceinline__ void q_make_b(QFrag (&b)[4], const h2_f32x16 (&in)[2], float sc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = in[s >> 1][8 * (s & 1) + e];
+        q_split8s(v, sc, b[s]);
+    }
+}
+
+/* the running power-of-two scale of a gradient operand whose products accumulate across tiles: the scale of the largest tile maximum
+ * seen so far (monotone: it only ever shrinks); when it shrinks the accumulators (NA tiles, held in the scaled domain) follow by the
+ * exact power-of-two ratio -- a handful of times per launch, against one multiply-add per accumulator element and tile for the
+ * alternative (a temporary accumulator per tile, unscaled and added: 256 accumulator-register moves + 128 fma per tile) */
+template <int NA>
+__device__ __forceinline__ void q_running_scale(float tile_max, float& s_run, float& inv_run, h2_f32x16 (&acc)[NA]) {
+    if (tile_max > 0.0f) {
+        float inv_t;
+        const float s_t = h2_pow2_scale(tile_max, inv_t);
+        if (s_run == 0.0f || s_t < s_run) {
+            if (s_run != 0.0f) {
+                const float ratio = s_t * inv_run;
+#pragma unroll
+                for (int k = 0; k < NA; ++k)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[k][r] *= ratio;
+            }
+            s_run = s_t; inv_run = inv_t;
+        }
+    } else if (s_run == 0.0f) { s_run = 1.0f; inv_run = 1.0f; }
+}
+
 template <int ACT>
 __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kernel(Bwd64Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint4* s_op = reinterpret_cast<uint4*>(smem);                         /* [OPB][64] operand blocks */
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 31, hh = lane >> 5;
+    const int lane_in = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* sx = smem + OPB * 256 + wave * (64 * TP);                      /* this wave's transposed tile */
     /* ---- the network's transposed operands, once per workgroup: T2 blocks (s < 2, m < 2), T1 (s < 4, m < 2), T0 (s < 4; FT = 1) ---- */
     for (int b = wave; b < OPB; b += QW) {
@@ -128,7 +195,7 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
         if (b < 8) { const int p = b & 1, m = (b >> 1) & 1, s = b >> 2; src = a.T2 + ((s * 4 + m) * 2 + p) * 64; }
         else if (b < 24) { const int c = b - 8, p = c & 1, m = (c >> 1) & 1, s = c >> 2; src = a.T1 + ((s * 4 + m) * 2 + p) * 64; }
         else { const int c = b - 24; src = a.T0 + c * 64; }
-        s_op[b * 64 + lane] = src[lane];
+        s_op[b * 64 + lane_in] = src[lane_in];
     }
     __syncthreads();
     const float c2 = a.cs[5], c1 = a.cs[3], c0 = a.cs[1];
@@ -137,50 +204,60 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
     const int slab = blockIdx.x * QW + wave;
     const int64_t n_tiles = (a.B + 31) / 32;
     const int d = a.d, n_in = a.n_in;
+    const int ldg4 = (int)a.ldg * 4, ldc4 = (int)a.ldc * 4;
 
+    /* the network's weight gradients, in the scaled domain of their g operand: dW2 under sg, dW1 / dW0 under their running scales */
     h2_f32x16 dW2[2], dW1[4], dW0[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dW2[0][r] = dW2[1][r] = 0.0f; dW1[0][r] = dW1[1][r] = dW1[2][r] = dW1[3][r] = 0.0f; dW0[0][r] = dW0[1][r] = 0.0f; }
     float bs2 = 0.0f, bs1[2] = {0.0f, 0.0f}, bs0[2] = {0.0f, 0.0f};
+    float s1 = 0.0f, inv1 = 1.0f, s0 = 0.0f, inv0 = 1.0f;
     const h2_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    const int lane_in = lane;
     for (int64_t tile = slab; tile < n_tiles; tile += a.n_slabs) {
-        /* the lane index is made opaque per tile: otherwise every per-lane address of the loop body (the gathers' 32 row offsets, the
-         * transposed tile's 64 write and 16 read addresses) is hoisted out of the loop as an invariant -- 700 live registers */
+        /* the lane index is made opaque per tile: otherwise every per-lane offset of the loop body is hoisted out of the loop as an
+         * invariant and kept live */
         int lane = lane_in;
         asm volatile("" : "+v"(lane));
         const int j = lane & 31, hh = lane >> 5;
         const int64_t b0 = tile * 32;
         const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
-        const int jr = j < rows ? j : rows - 1;
-        const float* grow = a.g + (b0 + jr) * a.ldg;
-        /* ---- every global request of the tile up front (one exposed round trip per tile instead of five: one wave per SIMD hides none):
-         * the lane's row of g, its rows of z1 / z0, its column of g and of the conditioner input ---- */
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + b0 * a.ldg), 0, (rows - 1) * ldg4 + d * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + b0 * a.ldc), 0, (rows - 1) * ldc4 + n_in * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z1 + b0 * 64), 0, rows * 256, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z0 + b0 * 64), 0, rows * 256, 0x00020000);
+        /* ---- every global request of the tile up front (one exposed round trip per tile: one wave per SIMD hides none): the lane's row
+         * of g (columns 16 s + 8 hh ..), its rows of z1 / z0, its column of g and of the conditioner input (samples 16 s + 8 hh ..) ---- */
         float grow_v[2][8], gcol_v[2][8], xcol_v[2][8];
         float4 zz1[8], zz0[8];
+        {
+            const int vrow = j * ldg4 + hh * 32;                                   /* row j, column 8 hh */
+            const int vgc = j < d ? hh * 8 * ldg4 + j * 4 : Q_OOB;                  /* sample 8 hh, column j */
+            const int vxc = j < n_in ? hh * 8 * ldc4 + j * 4 : Q_OOB;
+            const int vz = j * 256 + hh * 16;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int col = 16 * s + 8 * hh + e, smp = col;
-                const int sr = smp < rows ? smp : rows - 1;
-                grow_v[s][e] = grow[col < d ? col : 0];
-                gcol_v[s][e] = a.g[(b0 + sr) * a.ldg + (j < d ? j : 0)];
-                xcol_v[s][e] = a.x[(b0 + sr) * a.ldc + (j < n_in ? j : 0)];
-            }
-        q_load_z(zz1, a.z1 + (b0 + jr) * 64, hh);
-        q_load_z(zz0, a.z0 + (b0 + jr) * 64, hh);
+                for (int e = 0; e < 8; ++e) {
+                    grow_v[s][e] = (16 * s + 8 * hh + e < d) ? q_ld1(rs_g, vrow, (16 * s + e) * 4) : 0.0f;     /* (a row's columns past d belong to the next row) */
+                    gcol_v[s][e] = q_ld1(rs_g, vgc, (16 * s + e) * ldg4);
+                    xcol_v[s][e] = q_ld1(rs_x, vxc, (16 * s + e) * ldc4);
+                }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    zz1[4 * m + q] = q_ld4(rs_z1, vz, (32 * m + 8 * q) * 4);
+                    zz0[4 * m + q] = q_ld4(rs_z0, vz, (32 * m + 8 * q) * 4);
+                }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        /* ---- g_h1 = W2^T g: B operand = the lane's sample row of g (columns 16 s + 8 hh ..), rows past the batch are zero ---- */
+        /* ---- g_h1 = W2^T g ---- */
         h2_f32x16 acc[2] = {zero16, zero16};
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const int col = 16 * s + 8 * hh + e; v[e] = (j < rows && col < d) ? grow_v[s][e] : 0.0f; }
             QFrag bq;
-            h2_split8_scaled(v, sg, bq.hi, bq.lo);
+            q_split8s(grow_v[s], sg, bq);
 #pragma unroll
             for (int m = 0; m < 2; ++m) acc[m] = q_mfma3(acc[m], q_lds_frag(s_op, ((s * 2 + m) * 2), lane), bq);
         }
@@ -189,45 +266,35 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
         h2_f32x16 hv[2];
         q_act_backward(acc, hv, c2 * inv_sg, ACT, zz1);
         __builtin_amdgcn_sched_barrier(0);
-        /* ---- dW2 += g^T h1, db2: A = columns of g gathered from the tile's rows, B = h1 through the transposed tile ---- */
+        /* ---- dW2 += g^T h1 (scaled by sg), db2: A = the lane's column of g, B = h1 through the transposed tile ---- */
         {
             QFrag aq[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                float v[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int smp = 16 * s + 8 * hh + e;
-                    v[e] = (smp < rows && j < d) ? gcol_v[s][e] : 0.0f;
-                    bs2 += v[e];
-                }
-                h2_split8_scaled(v, sg, aq[s].hi, aq[s].lo);
+                for (int e = 0; e < 8; ++e) bs2 += gcol_v[s][e];
+                q_split8s(gcol_v[s], sg, aq[s]);
             }
             q_transpose_out(hv, sx, j, hh);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                h2_f32x16 tmp = zero16;
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     float v[8];
                     q_read8(sx, 32 * t + j, s, hh, v);
                     QFrag bq;
-                    h2_split8(v, bq.hi, bq.lo);
-                    tmp = q_mfma3(tmp, aq[s], bq);
+                    q_split8(v, bq);
+                    dW2[t] = q_mfma3(dW2[t], aq[s], bq);
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dW2[t][r] = __builtin_fmaf(tmp[r], inv_sg, dW2[t][r]);
-            }
             q_release();
         }
         __builtin_amdgcn_sched_barrier(0);
-        /* ---- g_h0 = W1^T g_z1; the same g_z1 as the A operand of dW1 (through the transposed tile) ---- */
-        float inv1;
+        /* ---- g_h0 = W1^T g_z1; the same g_z1 as the A operand of dW1 (through the transposed tile), both under the running scale s1 ---- */
         QFrag a1[2][2];
         {
-            const float s1 = h2_pow2_scale(h2_wave_absmax<2>(acc), inv1);
-            H2B<2> bf;
-            h2_make_b_scaled<2>(bf, acc, s1);
+            q_running_scale<4>(h2_wave_absmax<2>(acc), s1, inv1, dW1);
+            QFrag bf[4];
+            q_make_b(bf, acc, s1);
             q_transpose_out(acc, sx, j, hh);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -237,21 +304,20 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
                     q_read8(sx, 32 * m + j, s, hh, v);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bs1[m] += v[e];
-                    h2_split8_scaled(v, s1, a1[m][s].hi, a1[m][s].lo);
+                    q_split8s(v, s1, a1[m][s]);
                 }
             q_release();
             acc[0] = zero16; acc[1] = zero16;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                QFrag bq{bf.hi[s], bf.lo[s]};
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m] = q_mfma3(acc[m], q_lds_frag(s_op, 8 + ((s * 2 + m) * 2), lane), bq);
+                for (int m = 0; m < 2; ++m) acc[m] = q_mfma3(acc[m], q_lds_frag(s_op, 8 + ((s * 2 + m) * 2), lane), bf[s]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         q_act_backward(acc, hv, c1 * inv1, ACT, zz0);
         __builtin_amdgcn_sched_barrier(0);
-        /* ---- dW1 += g_z1^T h0 ---- */
+        /* ---- dW1 += g_z1^T h0 (scaled by s1) ---- */
         q_transpose_out(hv, sx, j, hh);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -260,27 +326,22 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
             for (int s = 0; s < 2; ++s) {
                 float v[8];
                 q_read8(sx, 32 * t + j, s, hh, v);
-                h2_split8(v, bq[s].hi, bq[s].lo);
+                q_split8(v, bq[s]);
             }
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                h2_f32x16 tmp = zero16;
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) tmp = q_mfma3(tmp, a1[m][s], bq[s]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dW1[2 * m + t][r] = __builtin_fmaf(tmp[r], inv1, dW1[2 * m + t][r]);
-            }
+                for (int s = 0; s < 2; ++s) dW1[2 * m + t] = q_mfma3(dW1[2 * m + t], a1[m][s], bq[s]);
         }
         q_release();
         __builtin_amdgcn_sched_barrier(0);
-        /* ---- g_x = W0^T g_z0 (+ the caller's addend); g_z0 as the A operand of dW0 ---- */
-        float inv0;
+        /* ---- g_x = W0^T g_z0 (+ the caller's addend); g_z0 as the A operand of dW0, under the running scale s0 ---- */
         QFrag a0[2][2];
         h2_f32x16 gx = zero16;
         {
-            const float s0 = h2_pow2_scale(h2_wave_absmax<2>(acc), inv0);
-            H2B<2> bf;
-            h2_make_b_scaled<2>(bf, acc, s0);
+            q_running_scale<2>(h2_wave_absmax<2>(acc), s0, inv0, dW0);
+            QFrag bf[4];
+            q_make_b(bf, acc, s0);
             q_transpose_out(acc, sx, j, hh);
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -290,14 +351,13 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
                     q_read8(sx, 32 * m + j, s, hh, v);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bs0[m] += v[e];
-                    h2_split8_scaled(v, s0, a0[m][s].hi, a0[m][s].lo);
+                    q_split8s(v, s0, a0[m][s]);
                 }
             q_release();
             if (a.g_x) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    QFrag bq{bf.hi[s], bf.lo[s]};
-                    gx = q_mfma3(gx, q_lds_frag(s_op, 24 + s * 2, lane), bq);
+                    gx = q_mfma3(gx, q_lds_frag(s_op, 24 + s * 2, lane), bf[s]);
                 }
             }
         }
@@ -305,38 +365,40 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
         if (a.g_x && j < rows) {
             float* orow = a.g_x + (b0 + j) * a.ldgx;
             const float* arow = a.g_x_add ? a.g_x_add + (b0 + j) * a.ldga : nullptr;
+            const float cu = c0 * inv0;
+            if (a.vec_gx) {                 /* rows on 16-byte boundaries, n_in a multiple of 4: the four features 8 q + 4 hh .. of a register quad as one store */
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (f < n_in) orow[f] = gx[r] * (c0 * inv0) + (arow ? arow[f] : 0.0f);
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 8 * q + 4 * hh;
+                    if (f0 < n_in) {
+                        float4 o = make_float4(gx[4 * q] * cu, gx[4 * q + 1] * cu, gx[4 * q + 2] * cu, gx[4 * q + 3] * cu);
+                        if (arow) { const float4 p = *reinterpret_cast<const float4*>(arow + f0); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                        *reinterpret_cast<float4*>(orow + f0) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (f < n_in) orow[f] = gx[r] * cu + (arow ? arow[f] : 0.0f);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        /* ---- dW0 += g_z0^T x: B = columns of the conditioner input gathered from the tile's rows ---- */
+        /* ---- dW0 += g_z0^T x (scaled by s0): B = the lane's column of the conditioner input ---- */
         {
             QFrag bq[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float v[8];
+            for (int s = 0; s < 2; ++s) q_split8(xcol_v[s], bq[s]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int smp = 16 * s + 8 * hh + e;
-                    v[e] = (smp < rows && j < n_in) ? xcol_v[s][e] : 0.0f;
-                }
-                h2_split8(v, bq[s].hi, bq[s].lo);
-            }
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                h2_f32x16 tmp = zero16;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) tmp = q_mfma3(tmp, a0[m][s], bq[s]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dW0[m][r] = __builtin_fmaf(tmp[r], inv0, dW0[m][r]);
-            }
+                for (int s = 0; s < 2; ++s) dW0[m] = q_mfma3(dW0[m], a0[m][s], bq[s]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    /* ---- this wave's partial gradients: accumulator layout -> [rows][cols] of the slab ---- */
+    /* ---- this wave's partial gradients: out of the scaled domain, accumulator layout -> [rows][cols] of the slab ---- */
+    const int lane = lane_in, j = lane & 31, hh = lane >> 5;
     const int H1 = a.H1, H0 = a.H0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -344,14 +406,14 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int col = 32 * t + j;
-            if (row < d && col < H1) a.pw2[((int64_t)slab * d + row) * H1 + col] = dW2[t][r];
+            if (row < d && col < H1) a.pw2[((int64_t)slab * d + row) * H1 + col] = dW2[t][r] * inv_sg;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
-                if (32 * m + row < H1 && col < H0) a.pw1[((int64_t)slab * H1 + 32 * m + row) * H0 + col] = dW1[2 * m + t][r];
+                if (32 * m + row < H1 && col < H0) a.pw1[((int64_t)slab * H1 + 32 * m + row) * H0 + col] = dW1[2 * m + t][r] * inv1;
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-            if (32 * m + row < H0 && j < n_in) a.pw0[((int64_t)slab * H0 + 32 * m + row) * n_in + j] = dW0[m][r];
+            if (32 * m + row < H0 && j < n_in) a.pw0[((int64_t)slab * H0 + 32 * m + row) * n_in + j] = dW0[m][r] * inv0;
     }
     if (j < d) a.pb2[((int64_t)slab * 2 + hh) * d + j] = bs2;
 #pragma unroll
@@ -436,6 +498,8 @@ extern "C" int bgk_affine_net_backward64(const float* g, int64_t ldg, int32_t d,
     a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.cs = cs; a.act = act; a.B = B;
     a.g_x = g_cond; a.ldgx = ldgc; a.g_x_add = g_cond ? g_cond_add : nullptr; a.ldga = ldga; a.g_absmax = g_absmax;
     a.H1 = H1; a.H0 = H0; a.n_slabs = n_slabs;
+    a.vec_gx = g_cond && n_in % 4 == 0 && ((uintptr_t)g_cond & 15) == 0 && ldgc % 4 == 0 && (!a.g_x_add || (((uintptr_t)a.g_x_add & 15) == 0 && ldga % 4 == 0));
+    BGK_CHECK_ARG(ldg < (1 << 20) && ldc < (1 << 20), "bgk_affine_net_backward64: row stride too large");
     float* p = workspace;
     a.pw2 = p; p += (int64_t)n_slabs * d * H1;
     a.pw1 = p; p += (int64_t)n_slabs * H1 * H0;

@@ -44,7 +44,13 @@ __device__ __forceinline__ void h2_split8(const float (&v)[8], h2_h16x8& hi, h2_
 }
 
 /* f32 pair -> f16 hi pair + f16 lo pair in 3 instructions: v_cvt_pk_f16_f32 (RNE), then lo = f16(a - hi) with the mixed-precision
- * FMA reading hi as an f16 operand and writing one half of the destination each */
+ * FMA reading hi as an f16 operand and writing one half of the destination each.
+ * HAZARD (found in round 6, bgk_affine_bwd64.hip): these are VALU writes the compiler's hazard recogniser does not see (inline asm is
+ * not classified as VALU), so it inserts none of the two wait states a matrix instruction needs behind a VALU write of one of its
+ * source registers.  A v_mfma that reads `hi` / `lo` within two instructions of this sequence gets stale data (run-to-run different
+ * results, inf where a stale lo half meets a new hi half).  Every user in this library keeps other instructions between a split and its
+ * consumer (the split of k-step s + 1 sits behind the MFMAs of k-step s; operands pass through LDS and a barrier; ...): keep it that
+ * way, or split with plain conversions (bgk_affine_bwd64.hip::q_split8s selects the same v_cvt_pk_f16_f32 from C). */
 __device__ __forceinline__ void h2_split_pair(float a0, float a1, unsigned& hi, unsigned& lo) {
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a0), "v"(a1));
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
