@@ -207,8 +207,10 @@ def kl_side_leg(name, dev, batch, steps):
     out = dict(workload=desc, steps_per_s=1e3 / ms, samples_per_s=batch * 1e3 / ms, ms_per_step=ms, batch=batch, steps=steps, timer="HIP events",
                loss=float(last[0].detach()), skipped_steps=opt.skipped_steps(),
                note="affine couplings: one-launch training forward (both conditioner networks on the f16 matrix cores + the affine tail; saves the "
-                    "hidden layers' pre-activations and the networks' outputs), backward = bgk_affine_backward + per network bgk_dense_backward_dx + "
-                    "bgk_mlp_weight_grad; no library GEMM, no aten activation kernel in the step")
+                    "hidden layers' pre-activations and the networks' outputs: bgk_coupling_affine_dense_fwd64_train for cfg 2's 64-unit networks, "
+                    "bgk_coupling_affine_dense_h2_train for cfg 5's 128-unit ones); backward = bgk_affine_backward + per network "
+                    "bgk_affine_net_backward64 (cfg 2: input-gradient chain and weight gradients in one launch, g_z on chip) or "
+                    "bgk_mlp_backward_dx + bgk_mlp_weight_grad (cfg 5); no library GEMM, no aten activation kernel in the step")
     if os.environ.get("BGK_BENCH_AB") == "1":
         try:
             dense.AFFINE_TRAIN = False
@@ -505,6 +507,8 @@ def cpu_baseline(workload, gen_gpu, dev, n_c_samples, kl_batch):
             *_, dl = gen_gpu.flow(*[torch.as_tensor(w).to(dev) for w in v])
         s_gpu, s_c32, s_t32 = _err_stats(dl.cpu().numpy(), dl64), _err_stats(dl32, dl64), _err_stats(dlt.numpy(), dl64)
         parity = dict(samples=n, elements=n_el, bin_index_differences=n_mis, tie_rate=n_mis / max(n_el, 1),
+                      bin_index_policy="tie-level in the shipped gemm_mode f16x2 (a difference only where the input lies within rounding distance of a knot); "
+                                       "bit-exact in gemm_mode f32 (exact_f32_mode leg) and in the generic kernels (bgk_rqs_transform)",
                       max_distance_to_knot_of_differences=far,
                       dlogp_rel_vs_f64_oracle=dict(gpu=s_gpu, c_oracle_f32=s_c32, torch_cpu_f32_chain=s_t32,
                                                    gpu_frac_over_reference_chain=s_gpu["frac_gt_1e5"] / max(s_t32["frac_gt_1e5"], 1e-12),

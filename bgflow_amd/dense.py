@@ -1427,7 +1427,7 @@ def _train_forward_launch(x, y, W2, plan, tcfg, inverse, oob, dlogp=None, accumu
 
 class _LayerCtx:
     """what the backward of one fused training layer needs besides its saved tensors"""
-    __slots__ = ("params", "cs", "tbufs", "t_version", "act", "periodic", "rcfg", "packed", "recompute")
+    __slots__ = ("params", "cs", "tbufs", "t_version", "act", "periodic", "rcfg", "packed", "recompute", "plan", "pack_version")
 
     def __init__(self, params, plan, tcfg, inverse, t_version):
         left, right, bottom, top, s = tcfg
@@ -1441,9 +1441,12 @@ class _LayerCtx:
         self.act, self.periodic = plan["act"], bool(plan["periodic"])
         self.rcfg = (plan["n_bins"], inverse, left, right, bottom, top, dict(s))
         self.packed = bool(plan.get("params_packed"))        # layout of the parameters the forward launch (just before this) saved
-        # ... or (A2 operand, c2) of that launch when it saved none: the backward recomputes them (the packed operands of a plan are
-        # replaced, not rewritten, when the weights change -- holding them here keeps the forward's blocks alive until the backward)
+        # ... or (A2 operand, c2) of that launch when it saved none: the backward recomputes them.  The device packer REWRITES a plan's
+        # operand buffers in place when the weights change (pack_dense_for_fused_h2_device(bufs = ...), repack_training_plans): a
+        # backward that runs after such a re-pack -- a retained graph, update-then-second-forward -- would recompute the parameters from the
+        # NEW weights.  `plan` / `pack_version` let the backward notice and refuse (_rqs_backward_recompute).
         self.recompute = (plan["packed"][2], plan["packed"][3][2], plan["circ_mask"]) if plan.get("params_recompute") else None
+        self.plan, self.pack_version = plan, plan.get("version")
 
 
 def _train_backward_layer(lc, x, y, W0, W1, W2, z0, z1, params, nc_dev, g_out, g_dlogp, need_gx, need_w, gx_add=None, gx_out=None,
@@ -1510,6 +1513,10 @@ def _rqs_backward_recompute(lc, y, z1, P, nc_dev, g_out, g_dlogp, absmax):
     from .transformer import row_pitch
     n_bins, inverse, left, right, bottom, top, s = lc.rcfg
     A2, c2, circ_mask = lc.recompute
+    if lc.plan.get("version") != lc.pack_version:
+        raise RuntimeError("fused spline coupling: the conditioner's parameters changed between the forward and this backward (the packed "
+                           "operands the backward recomputes the spline parameters from were rewritten); run the backward before the "
+                           "optimizer step, or call forward again")
     y2, ldy = _lib.rowmajor(y)
     B, d = y2.shape
     dev = y.device

@@ -279,13 +279,24 @@ def _philox_claim(obj, stream):
 class _FusedSampling(torch.nn.Module):
     """Opt-in (``sample_fused=True``) sampling on bgk_philox_fields.  Key = ``torch.initial_seed()`` (so ``torch.manual_seed`` still
     selects the stream) mixed with the data-parallel rank AND a per-object stream id: two priors of equal shape in one process draw
-    independent numbers.  The id is either given (``set_philox_stream(k)``: reproducible whatever else the process samples -- the
-    builder numbers the priors it makes) or, on first use, the smallest id no live object holds (then it depends on which other
-    fused-sampling objects sampled before).  Offset = a per-object call counter.  Stream id and counter travel in ``state_dict`` once
+    independent numbers.  The id is either given (``set_philox_stream(k)``: reproducible whatever else the process samples; code that
+    builds several fused-sampling priors and needs run-to-run identical draws calls it itself -- nothing in this package does) or, on
+    first use, the smallest id no live object holds (then it depends on which other fused-sampling objects sampled before).  A
+    ``copy.deepcopy`` does not inherit the stream: the copy claims its own id at its first sample (an inherited id would draw the SAME
+    numbers as the original, silently).  Offset = a per-object call counter.  Stream id and counter travel in ``state_dict`` once
     the object has sampled (key ``_philox_state``; absent otherwise, so reference state_dicts load unchanged): a resumed run
     continues the stream instead of replaying it; loading an id a live object already holds warns.  The prior energy of a sample
     comes out of the same launch and is handed back by ``energy`` when it is asked about exactly these, unmodified tensors."""
     sample_fused = False
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_philox_state":                      # the copy is a new sampler: its own stream, claimed at its first sample
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def set_philox_stream(self, stream, calls=0):
         """draw from Philox stream ``stream`` (a non-negative int), continuing at call ``calls``"""

@@ -194,7 +194,15 @@ class SequentialFlow(Flow):
         *x, dd = tail(*xs, inverse=False, temperature=temperature)
         total = dd if total is None else total + dd
         out = kl_loss_sums(target, tuple(x), total, temperature=temperature, drop_nonfinite=drop_nonfinite)
-        return None if out is None else out[0]
+        if out is not None:
+            return out[0]
+        # the flow HAS run (its segments above built their autograd graph, bumped their out-of-domain counters): finish here with the
+        # per-sample form instead of handing None back -- the caller would evaluate the whole flow a second time
+        per = target.energy(*x, temperature=temperature) - total
+        if drop_nonfinite:
+            ok = torch.isfinite(per)
+            return torch.stack([torch.where(ok, per, torch.zeros_like(per)).sum().to(torch.float64), ok.sum().to(torch.float64)])
+        return torch.stack([per.sum().to(torch.float64), torch.tensor(float(per.numel()), dtype=torch.float64, device=per.device)])
 
     def run(self, xs, inverse=False, kwargs=None, around=None):
         """The pass itself.  ``around(i, label)``, if given, returns a context manager entered around segment i (bench.py times the
