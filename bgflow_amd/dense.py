@@ -1962,92 +1962,205 @@ def _affine_net_backward64(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx
     return gW0, gb0, gW1, gb1, gW2, gb2
 
 
+def _affine_train_forward(x, y, log_alpha, plan, cfg, dlogp=None, accumulate=False):
+    """one training-forward launch of an affine coupling: (out [B, d], dlogp [B], saved = (x2, y2, zz, ms)).  ``dlogp`` / ``accumulate``:
+    the layer's log-det written (or added) into the caller's [B] buffer -- the running log|det J| of a stack of layers"""
+    pv, circ, inverse = cfg
+    dev = y.device
+    x2, ldc = _lib.rowmajor(x.detach())
+    y2, ldy = _lib.rowmajor(y.detach())
+    B, d = y2.shape
+    out = torch.empty((B, d), dtype=torch.float32, device=dev)
+    if dlogp is None:
+        dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=dev), False
+    zz = torch.empty((4, B + HALF_PAD_ROWS, plan["ldz"]), dtype=torch.float32, device=dev)[:, :B]
+    ldms = 32 * plan["OT"]
+    ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
+    ops = []
+    for e in plan["nets"]:
+        ops += [None, None, None, None, 0] if e is None else [_lib.ptr(e["A0"]), _lib.ptr(e["A1"]), _lib.ptr(e["A2"]), _lib.ptr(e["cs"]), e["act"]]
+    with torch.cuda.device(dev):
+        if plan["HT"] == 2:
+            what = "bgk_coupling_affine_dense_fwd64_train"
+            st = _lib.lib().bgk_coupling_affine_dense_fwd64_train(
+                _lib.ptr(x2), ldc, x2.shape[1], *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
+                _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)),
+                _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms, _lib.stream_ptr(dev))
+        else:
+            what = "bgk_coupling_affine_dense_h2_train"
+            ptrs, lds, widths, n, _keep = _lib.cond_segments([x2])
+            st = _lib.lib().bgk_coupling_affine_dense_h2_train(
+                ptrs, lds, widths, n, int(plan["periodic"]), *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
+                _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)),
+                _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), plan["ldz"], _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms,
+                _lib.stream_ptr(dev))
+    _lib.check(st, what)
+    return out, dlogp, (x2, y2, zz, ms)
+
+
+def _affine_train_backward(plan, cfg, versions, x2, y2, log_alpha, zz, ms, g_out, g_dl, need_x, need_la, need_w, gx_add=None, gx_out=None):
+    """backward of one fused affine training layer: bgk_affine_backward (tail), then the networks (_affine_net_backward).  ``g_dl``: [B]
+    contiguous; ``need_w``: the twelve flags of the networks' parameters; ``gx_add`` / ``gx_out``: a [B, d_c] tensor the conditioner-input
+    gradient is added to and where the sum goes (may be the same tensor: accumulation in place; default: a fresh tensor).
+    Returns (g_x or None, g_y, g_log_alpha or None, 12 weight gradients -- None where they went straight into the FlatAdam bucket)."""
+    pv, circ, inverse = cfg
+    es, et = plan["nets"]
+    dev = y2.device
+    B, d = y2.shape
+    ldms = ms.shape[2]
+    ldc = x2.stride(0) if B > 1 else x2.shape[1]
+    g_out2, ldgo = _lib.rowmajor(g_out.reshape(B, d))
+    g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
+    g_ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
+    absmax = torch.zeros((2, 3), dtype=torch.float32, device=dev)
+    la_direct = (_DIRECT_GRADS[0] and need_la and getattr(log_alpha, "_bgk_grad_dst", None) is not None and log_alpha.grad is not None
+                 and log_alpha.grad.data_ptr() == log_alpha._bgk_grad_dst.data_ptr())
+    g_la = log_alpha._bgk_grad_dst if la_direct else (torch.zeros((1,), dtype=torch.float32, device=dev) if et is not None else None)
+    with torch.cuda.device(dev):
+        st = _lib.lib().bgk_affine_backward(
+            _lib.ptr(y2), y2.stride(0) if B > 1 else d, _lib.ptr(ms[0]) if es is not None else None, ldms,
+            _lib.ptr(ms[1]) if et is not None else None, ldms, _lib.ptr(log_alpha.detach()),
+            int(pv), int(circ), int(inverse), B, d, _lib.ptr(g_out2), ldgo, _lib.ptr(g_dl),
+            _lib.ptr(g_y), d, _lib.ptr(g_ms[0]) if es is not None else None, ldms, _lib.ptr(g_ms[1]) if et is not None else None, ldms,
+            _lib.ptr(g_la), _lib.ptr(absmax[0]), _lib.ptr(absmax[1]), _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_affine_backward")
+    g_x = None
+    if need_x:
+        g_x = gx_out if gx_out is not None else torch.empty((B, plan["d_c"]), dtype=torch.float32, device=dev)
+    grads, add = [], gx_add
+    for k, e in enumerate((es, et)):
+        if e is None:
+            grads += [None] * 6
+            continue
+        grads += list(_affine_net_backward(e, plan, g_ms[k], ldms, zz[2 * k + 1], zz[2 * k], x2, ldc, absmax[k], need_x, g_x, add,
+                                           need_w[6 * k:6 * k + 6], versions[k]))
+        add = g_x                       # the second network adds to what the first wrote
+    return g_x, g_y, (None if (la_direct or et is None or not need_la) else g_la), grads
+
+
 class _FusedAffineTrainFn(torch.autograd.Function):
     """apply(x, y, log_alpha, plan, cfg, *12 network parameters (shift W0, b0, W1, b1, W2, b2, scale ...; None for an absent network))
     -> (y', dlogp [B, 1]).  ``cfg`` = (preserve_volume, is_circular, inverse)."""
 
     @staticmethod
     def forward(ctx, x, y, log_alpha, plan, cfg, *weights):
-        pv, circ, inverse = cfg
-        dev = y.device
-        x2, ldc = _lib.rowmajor(x.detach())
-        y2, ldy = _lib.rowmajor(y.detach())
-        B, d = y2.shape
-        out = torch.empty((B, d), dtype=torch.float32, device=dev)
-        dlogp = torch.empty((B,), dtype=torch.float32, device=dev)
-        zz = torch.empty((4, B + HALF_PAD_ROWS, plan["ldz"]), dtype=torch.float32, device=dev)[:, :B]
-        ldms = 32 * plan["OT"]
-        ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
-        es, et = plan["nets"]
-        ops = []
-        for e in (es, et):
-            ops += [None, None, None, None, 0] if e is None else [_lib.ptr(e["A0"]), _lib.ptr(e["A1"]), _lib.ptr(e["A2"]), _lib.ptr(e["cs"]), e["act"]]
-        st = -2
-        if plan["HT"] == 2:
-            with torch.cuda.device(dev):
-                st = _lib.lib().bgk_coupling_affine_dense_fwd64_train(
-                    _lib.ptr(x2), ldc, x2.shape[1], *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
-                    _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), 0,
-                    _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms, _lib.stream_ptr(dev))
-            _lib.check(st, "bgk_coupling_affine_dense_fwd64_train")
-            ctx.save_for_backward(x2, y2, log_alpha, zz, ms)
-            ctx.plan, ctx.cfg = plan, cfg
-            ctx.versions = [None if e is None else e["version"] for e in (es, et)]
-            ctx.x_shape = x.shape
-            return out, dlogp[:, None]
-        ptrs, lds, widths, n, _keep = _lib.cond_segments([x2])
-        with torch.cuda.device(dev):
-            st = _lib.lib().bgk_coupling_affine_dense_h2_train(
-                ptrs, lds, widths, n, int(plan["periodic"]), *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
-                _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), 0,
-                _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), plan["ldz"], _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms,
-                _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_coupling_affine_dense_h2_train")
+        out, dlogp, (x2, y2, zz, ms) = _affine_train_forward(x, y, log_alpha, plan, cfg)
         ctx.save_for_backward(x2, y2, log_alpha, zz, ms)
         ctx.plan, ctx.cfg = plan, cfg
-        ctx.versions = [None if e is None else e["version"] for e in (es, et)]
+        ctx.versions = [None if e is None else e["version"] for e in plan["nets"]]
         ctx.x_shape = x.shape
         return out, dlogp[:, None]
 
     @staticmethod
     def backward(ctx, g_out, g_dlogp):
         x2, y2, log_alpha, zz, ms = ctx.saved_tensors
-        plan, (pv, circ, inverse) = ctx.plan, ctx.cfg
-        es, et = plan["nets"]
         need = ctx.needs_input_grad
-        dev = y2.device
-        B, d = y2.shape
-        ldms = ms.shape[2]
-        ldc = x2.stride(0) if B > 1 else x2.shape[1]
-        g_out2, ldgo = _lib.rowmajor(g_out.reshape(B, d))
+        g_x, g_y, g_la, grads = _affine_train_backward(ctx.plan, ctx.cfg, ctx.versions, x2, y2, log_alpha, zz, ms, g_out,
+                                                       g_dlogp.reshape(-1).contiguous(), bool(need[0]), bool(need[2]), need[5:17])
+        return (g_x.reshape(ctx.x_shape) if g_x is not None else None, g_y if need[1] else None, g_la, None, None, *grads)
+
+
+class _AffineStackTrainFn(torch.autograd.Function):
+    """``split -> (CouplingFlow(AffineTransformer) | SwapFlow)* -> merge`` under autograd as ONE node (BASELINE cfg 2's whole flow).
+    Forward: one training-forward launch per coupling, all of them adding their log-det to one [B] buffer, the halves read and written
+    as column views of [B, D] tensors (no per-layer torch.cat, no per-block log-det add).  Backward: the layers in reverse with the two
+    halves' gradients kept in two buffers -- a coupling's conditioner-input gradient is ADDED to its half's buffer inside the networks'
+    backward kernels (g_cond_add), so the sums autograd would form with one elementwise launch per layer (a half conditions one layer
+    and is transformed by the next) do not exist.
+
+    apply(layers, x [B, D], *per layer (log_alpha, 12 network parameters)); ``layers[i]`` = (transformed part 0 | 1, plan, cfg).
+    Returns (out [B, D] with the parts in slot order, dlogp [B, 1])."""
+
+    @staticmethod
+    def forward(ctx, layers, cols, x, *tensors):
+        B = x.shape[0]
+        part = [x[:, cols[0]], x[:, cols[1]]]
+        saved, dlogp = [], None
+        for i, (py, plan, cfg) in enumerate(layers):
+            log_alpha = tensors[13 * i]
+            out, dlogp, (x2, y2, zz, ms) = _affine_train_forward(part[1 - py], part[py], log_alpha, plan, cfg, dlogp=dlogp, accumulate=i > 0)
+            saved += [x2, y2, log_alpha, zz, ms]
+            part[py] = out
+        ctx.save_for_backward(*saved)
+        ctx.layers = layers
+        ctx.versions = [[None if e is None else e["version"] for e in plan["nets"]] for _, plan, _ in layers]
+        ctx.widths = (part[0].shape[1], part[1].shape[1])
+        return torch.cat(part, dim=1), dlogp[:, None]
+
+    @staticmethod
+    def backward(ctx, g_out, g_dlogp):
+        saved = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        w0, w1 = ctx.widths
+        g_out = g_out.contiguous()
+        G = [g_out[:, :w0], g_out[:, w0:]]          # gradient w.r.t. the CURRENT state of each half, walking the layers backwards
+        owned = [False, False]                       # buffers of this backward (may be added to in place)
         g_dl = g_dlogp.reshape(-1).contiguous()
-        g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
-        g_ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
-        absmax = torch.zeros((2, 3), dtype=torch.float32, device=dev)
-        la_direct = (_DIRECT_GRADS[0] and need[2] and getattr(log_alpha, "_bgk_grad_dst", None) is not None and log_alpha.grad is not None
-                     and log_alpha.grad.data_ptr() == log_alpha._bgk_grad_dst.data_ptr())
-        g_la = log_alpha._bgk_grad_dst if la_direct else (torch.zeros((1,), dtype=torch.float32, device=dev) if et is not None else None)
-        with torch.cuda.device(dev):
-            st = _lib.lib().bgk_affine_backward(
-                _lib.ptr(y2), y2.stride(0) if B > 1 else d, _lib.ptr(ms[0]) if es is not None else None, ldms,
-                _lib.ptr(ms[1]) if et is not None else None, ldms, _lib.ptr(log_alpha.detach()),
-                int(pv), int(circ), int(inverse), B, d, _lib.ptr(g_out2), ldgo, _lib.ptr(g_dl),
-                _lib.ptr(g_y), d, _lib.ptr(g_ms[0]) if es is not None else None, ldms, _lib.ptr(g_ms[1]) if et is not None else None, ldms,
-                _lib.ptr(g_la), _lib.ptr(absmax[0]), _lib.ptr(absmax[1]), _lib.stream_ptr(dev))
-        _lib.check(st, "bgk_affine_backward")
-        want_gx = bool(need[0])
-        g_x = torch.empty((B, plan["d_c"]), dtype=torch.float32, device=dev) if want_gx else None
-        grads, first = [], True
-        for k, e in enumerate((es, et)):
-            if e is None:
-                grads += [None] * 6
-                continue
-            gws = _affine_net_backward(e, plan, g_ms[k], ldms, zz[2 * k + 1], zz[2 * k], x2, ldc, absmax[k], want_gx, g_x,
-                                       None if first else g_x, need[5 + 6 * k:11 + 6 * k], ctx.versions[k])
-            grads += list(gws)
-            first = False
-        return (g_x.reshape(ctx.x_shape) if want_gx else None, g_y if need[1] else None,
-                (None if (la_direct or et is None) else g_la) if need[2] else None, None, None, *grads)
+        L = len(ctx.layers)
+        grads = [None] * (13 * L)
+        for i in range(L - 1, -1, -1):
+            py, plan, cfg = ctx.layers[i]
+            pc = 1 - py
+            x2, y2, log_alpha, zz, ms = saved[5 * i:5 * i + 5]
+            nd = need[3 + 13 * i:3 + 13 * i + 13]
+            prev = G[pc]
+            if not owned[pc]:                        # autograd's tensor (a view of g_out): never written -- the sum goes to a fresh buffer
+                gx_out = None
+            else:
+                gx_out = prev
+            g_x, g_y, g_la, gws = _affine_train_backward(plan, cfg, ctx.versions[i], x2, y2, log_alpha, zz, ms, G[py], g_dl, True, bool(nd[0]),
+                                                         nd[1:13], gx_add=prev, gx_out=gx_out)
+            G[py], owned[py] = g_y, True
+            G[pc], owned[pc] = g_x, True
+            grads[13 * i] = g_la
+            grads[13 * i + 1:13 * i + 13] = gws
+        g_in = torch.cat(G, dim=1) if need[2] else None
+        return (None, None, g_in, *grads)
+
+
+def affine_stack_train(blocks, x, inverse):
+    """The blocks ``split, (coupling | swap)*, merge`` (execution order) of a coupling stack on a [B, D] f32 HIP tensor as one autograd node
+    (_AffineStackTrainFn); None when a layer is outside the affine training envelope (the caller then runs the blocks one by one)."""
+    from .flow import CouplingFlow, SplitFlow, SwapFlow
+    if not AFFINE_TRAIN or not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0):
+        return None
+    split = blocks[0] if type(blocks[0]) is SplitFlow else blocks[0]._delegate
+    s0, D = split._sizes[0], x.shape[1]
+    if not (0 < s0 < D and (len(split._sizes) == 1 or split._sizes[1] == D - s0)):
+        return None
+    widths = (s0, D - s0)
+    part = [0, 1]                                   # tuple slot -> half of x
+    layers, tensors = [], []
+    for b in blocks[1:-1]:
+        if type(b) is SwapFlow:
+            part.reverse()
+            continue
+        tr = b.transformer
+        if not getattr(tr, "allow_fused", False):
+            return None
+        pc, py = part
+        plan = _affine_train_plan(tr, widths[py], x.device)
+        if plan is None or plan["d_c"] != widths[pc]:
+            return None
+        plan["train_used"] = True
+        _AFF_TRAIN_TRANSFORMERS.add(tr)
+        log_alpha = tr._log_alpha
+        if log_alpha.device != x.device or log_alpha.dtype != torch.float32:
+            log_alpha = log_alpha.to(device=x.device, dtype=torch.float32)
+        layers.append((py, plan, (tr._preserve_volume, tr._is_circular, inverse)))
+        tensors.append(log_alpha)
+        for e in plan["nets"]:
+            tensors += [None] * 6 if e is None else [p for lin in e["lins"] for p in (lin.weight, lin.bias)]
+    if not layers:
+        return None
+    closing = blocks[-1] if type(blocks[-1]) is SplitFlow else blocks[-1]._delegate
+    if not (closing._sizes[0] == widths[part[0]] and (len(closing._sizes) == 1 or closing._sizes[1] == widths[part[1]])):
+        return None
+    cols = (slice(0, s0), slice(s0, D))
+    out, dlogp = _AffineStackTrainFn.apply(layers, cols, x, *tensors)
+    if part != [0, 1]:                              # odd number of swaps: the merge concatenates (half 1, half 0)
+        out = torch.cat([out[:, s0:], out[:, :s0]], dim=1)
+    return out, dlogp
 
 
 def fused_affine_coupling_train(transformer, x, y, inverse):

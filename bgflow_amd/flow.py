@@ -440,6 +440,7 @@ class _FusedCouplingStack:
     is not a contiguous f32 HIP matrix, or a layer's conditioners are outside the fused envelope."""
 
     _bgk_acc = True
+    FUSE_TRAINING_STACK = os.environ.get("BGK_TRAIN_STACK", "1") != "0"    # under autograd: the stack as one node (dense._AffineStackTrainFn)
 
     def __init__(self, blocks):
         self._blocks = blocks
@@ -464,8 +465,14 @@ class _FusedCouplingStack:
         ok = (x is not None and not set(kwargs_rest) - {"temperature"} and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
               and x.dim() == 2 and x.is_contiguous() and x.shape[0] > 0)
         couplings = [b for b in self._blocks if type(b) is CouplingFlow]
-        if ok and torch.is_grad_enabled():
-            ok = not (x.requires_grad or any(p.requires_grad for b in couplings for p in b.parameters()))
+        if ok and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for b in couplings for p in b.parameters())):
+            # a pass that builds an autograd graph: the whole stack as ONE node on the affine training kernels (round 6), else the blocks
+            ok = False
+            if acc is None and self.FUSE_TRAINING_STACK:
+                from .dense import affine_stack_train
+                res = affine_stack_train(self._blocks, x, inverse)
+                if res is not None:
+                    return res
         if ok:
             split = self._blocks[0] if type(self._blocks[0]) is SplitFlow else self._blocks[0]._delegate
             s0, D = split._sizes[0], x.shape[1]

@@ -391,3 +391,35 @@ def test_small_network_kernels_equal_the_general_path(hip_lib, dev):
     assert float((small[2] - general[2]).norm() / general[2].norm()) <= 2e-6
     rel, worst = _grad_errors(small[3], general[3])
     assert rel <= 2e-6, (rel, worst)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("n_blocks", [8, 3])
+def test_coupling_stack_as_one_autograd_node_equals_the_blocks(hip_lib, dev, inverse, n_blocks):
+    """split -> (affine coupling, swap) x n -> merge under autograd as ONE node (dense._AffineStackTrainFn: one log-det buffer, the halves'
+    gradients accumulated inside the backward kernels) against the same blocks run one by one: identical outputs, gradients equal to
+    accumulation-order noise; an odd number of swaps (the merge then sees the halves exchanged) and the inverse direction included."""
+    import bgflow_amd as bg
+    from bgflow_amd import configs
+    gen = configs.make_affine8_generator(n_blocks=n_blocks, device=dev)
+    g = torch.Generator(device=dev).manual_seed(n_blocks)
+    z0 = torch.randn(2051, 64, device=dev, generator=g)
+
+    def run():
+        for p in gen.flow.parameters():
+            p.grad = None
+        z = z0.clone().requires_grad_(True)
+        x, dl = gen.flow(z, inverse=inverse)
+        (x.square().mean() + (x[:, :7] * dl).mean() - dl.mean()).backward()
+        return x.detach(), dl.detach(), z.grad.clone(), {n: p.grad.clone() for n, p in gen.flow.named_parameters()}
+    one = run()
+    try:
+        bg.flow._FusedCouplingStack.FUSE_TRAINING_STACK = False
+        blocks = run()
+    finally:
+        bg.flow._FusedCouplingStack.FUSE_TRAINING_STACK = True
+    assert torch.equal(one[0], blocks[0])
+    assert float((one[1] - blocks[1]).abs().max()) <= 4e-6 * max(1.0, float(blocks[1].abs().max()))
+    assert float((one[2] - blocks[2]).norm() / blocks[2].norm()) <= 2e-6
+    rel, worst = _grad_errors(one[3], blocks[3])
+    assert rel <= 2e-6, (rel, worst)
