@@ -137,7 +137,19 @@ __device__ __forceinline__ float4 q_ld4(__amdgpu_buffer_rsrc_t rs, int voff, int
  * instructions (v_cvt_pk_f16_f32, v_fma_mix*) AND keeps the required distance. */
 typedef _Float16 q_h2 __attribute__((ext_vector_type(2)));
 typedef float q_f2 __attribute__((ext_vector_type(2)));
+#ifndef BGK_Q_ASMSPLIT
+#define BGK_Q_ASMSPLIT 0      /* experiment: 1 = the three-instruction asm split with an s_nop 1 behind the last pair (the wait states the compiler cannot know about) */
+#endif
 __device__ __forceinline__ void q_split8s(const float (&v)[8], float sc, QFrag& f) {
+#if BGK_Q_ASMSPLIT
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h2_split_pair(v[2 * e] * sc, v[2 * e + 1] * sc, h[e], l[e]);
+    asm volatile("s_nop 1" : "+v"(h[3]), "+v"(l[3]), "+v"(h[0]), "+v"(l[0]), "+v"(h[1]), "+v"(l[1]), "+v"(h[2]), "+v"(l[2]));
+    f.hi = __builtin_bit_cast(h2_h16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    f.lo = __builtin_bit_cast(h2_h16x8, make_uint4(l[0], l[1], l[2], l[3]));
+    return;
+#endif
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
         const float a0 = v[e] * sc, a1 = v[e + 1] * sc;

@@ -2108,10 +2108,12 @@ class _AffineStackTrainFn(torch.autograd.Function):
                 gx_out = None
             else:
                 gx_out = prev
-            g_x, g_y, g_la, gws = _affine_train_backward(plan, cfg, ctx.versions[i], x2, y2, log_alpha, zz, ms, G[py], g_dl, True, bool(nd[0]),
+            want_gx = i > 0 or bool(need[2])          # (the first layer's conditioner-input gradient only matters to the stack's input)
+            g_x, g_y, g_la, gws = _affine_train_backward(plan, cfg, ctx.versions[i], x2, y2, log_alpha, zz, ms, G[py], g_dl, want_gx, bool(nd[0]),
                                                          nd[1:13], gx_add=prev, gx_out=gx_out)
             G[py], owned[py] = g_y, True
-            G[pc], owned[pc] = g_x, True
+            if want_gx:
+                G[pc], owned[pc] = g_x, True
             grads[13 * i] = g_la
             grads[13 * i + 1:13 * i + 13] = gws
         g_in = torch.cat(G, dim=1) if need[2] else None
