@@ -614,6 +614,27 @@ __device__ __forceinline__ PlaceAdj placement_vjp_dual(V3 p1, V3 p2, V3 p3, floa
     return r;
 }
 
+/* The same twelve directional derivatives, one LANE each (lanes 0 .. 11 of a wave whose lanes all hold the SAME placement; the other
+ * lanes compute a zero direction): one pass of Dual<1> instead of three of Dual<4>, the results collected with v_readlane -- the
+ * one-wave-per-sample fix-up kernel (round 6). */
+__device__ __forceinline__ PlaceAdj placement_vjp_dual_lanes(V3 p1, V3 p2, V3 p3, float dd, float a_rad, float t_rad, V3 g, float gl, float eps) {
+    const int b = (int)(threadIdx.x & 63);
+    const float sin_t = sinf(t_rad), cos_t = cosf(t_rad), sin_a = sinf(a_rad), cos_a = cosf(a_rad);
+    DV3<1> q1 = {dseed<1>(p1.x, 0 - b), dseed<1>(p1.y, 1 - b), dseed<1>(p1.z, 2 - b)};
+    DV3<1> q2 = {dseed<1>(p2.x, 3 - b), dseed<1>(p2.y, 4 - b), dseed<1>(p2.z, 5 - b)};
+    DV3<1> q3 = {dseed<1>(p3.x, 6 - b), dseed<1>(p3.y, 7 - b), dseed<1>(p3.z, 8 - b)};
+    const Dual<1> s = place_scalar_dual<1>(q1, q2, q3, dseed<1>(dd, 9 - b), dseed<1>(a_rad, 10 - b), dseed<1>(t_rad, 11 - b), g, gl, eps,
+                                           sin_t, cos_t, sin_a, cos_a);
+    float o[12];
+    const int bits = __builtin_bit_cast(int, s.d[0]);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, k));
+    PlaceAdj r;
+    r.g1 = {o[0], o[1], o[2]}; r.g2 = {o[3], o[4], o[5]}; r.g3 = {o[6], o[7], o[8]};
+    r.gd = o[9]; r.ga = o[10]; r.gt = o[11];
+    return r;
+}
+
 /* adjoint of one placement: cotangents of the three reference atoms (g1 includes the pass-through of g), of the bond, the angle and
  * the torsion (in the caller's units: normalised angles get their pi / 2 pi).  Angles go to the hardware sin / cos in revolutions
  * (tools/ubench/hw_sincos.hip); reciprocals on the hardware form. */
@@ -621,7 +642,7 @@ __device__ __forceinline__ PlaceAdj placement_vjp_dual(V3 p1, V3 p2, V3 p3, floa
  * closed form is evaluated regardless and `bad` is raised -- the sweep kernels hand such samples to ic_ic2xyz_bwd_fix_kernel, so that
  * the rare path's registers and code stay out of their loops (inlined there it doubled the loop: the position arrays went to AGPRs
  * and their wave-uniform indexing from v_movrel to select chains). */
-template <bool DUAL, int ND = 1>
+template <bool DUAL, int ND = 1, bool LANES = false>
 __device__ __forceinline__ PlaceAdj placement_adjoint(V3 p1, V3 p2, V3 p3, float dd, float an, float t, V3 g, float gl, int normalize,
                                                       float eps, int enforce, bool& bad) {
     PlaceAdj o;
@@ -633,7 +654,8 @@ __device__ __forceinline__ PlaceAdj placement_adjoint(V3 p1, V3 p2, V3 p3, float
     if (enforce && (n2_nv < e2 || n2_nn < e2 || n2_v1 < e2)) {       /* rare: a norm of this placement was clamped by the forward */
         if constexpr (DUAL) {
             const float a_rad = normalize ? an * PI_F : an, t_rad = normalize ? t * (2.0f * PI_F) - PI_F : t;
-            o = placement_vjp_dual<ND>(p1, p2, p3, dd, a_rad, t_rad, g, gl, eps);
+            if constexpr (LANES) o = placement_vjp_dual_lanes(p1, p2, p3, dd, a_rad, t_rad, g, gl, eps);       /* (the condition is wave-uniform there) */
+            else o = placement_vjp_dual<ND>(p1, p2, p3, dd, a_rad, t_rad, g, gl, eps);
             if (normalize) { o.ga *= PI_F; o.gt *= 2.0f * PI_F; }
             return o;
         } else {
@@ -1043,6 +1065,63 @@ __global__ __launch_bounds__(64) void ic_ic2xyz_bwd_fix_kernel(IcBwdArgs a) {
     }
 }
 
+/* Round 6: the same fix-up with ONE WAVE per listed sample.  The lane-per-sample kernel above pays for divergence: a listed sample has
+ * one clamped placement (rarely two), but the 64 samples of a wave have theirs at different steps of the sweep, so the wave runs the
+ * dual-number path (three passes of Dual<4>, ~1.8 k instructions) at nearly every step -- 0.139 ms for a few hundred samples at
+ * cfg 3's prior.  Here all lanes of a wave hold the same sample: the clamp condition is wave-uniform (the dual path runs only at the
+ * sample's own clamped steps), its twelve directions are twelve lanes (one pass of Dual<1>), the rows arrive by coalesced loads:
+ * 0.026 ms.  4096 single-wave workgroups stride over the list, so a long list (a collapsed flow) is served no worse than before. */
+__global__ __launch_bounds__(64) void ic_ic2xyz_bwd_fix_wave_kernel(IcBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = a.n, nf3 = 3 * a.n_fixed, na3 = 3 * a.n_atoms, keep = a.keep;
+    const int count = a.fix[0], lane = (int)threadIdx.x;
+    if ((int)blockIdx.x >= count) return;
+    typedef const __attribute__((address_space(4))) int32_t* ci32_t;
+    const ci32_t place = (ci32_t)a.place;
+    float* gp = smem;                           /* position adjoints | positions | bonds | angles | torsions */
+    float* xr = gp + na3;
+    float* rb = xr + na3;
+    float* ra = rb + n;
+    float* rt = ra + n;
+    for (int k = blockIdx.x; k < count; k += gridDim.x) {
+        const int64_t b = a.fix[1 + k];
+        for (int c = lane; c < na3; c += 64) { gp[c] = a.g_x[b * a.ldgx + c]; xr[c] = a.x[b * a.ldx + c]; }
+        for (int c = lane; c < n; c += 64) { rb[c] = a.bonds[b * a.ldic + c]; ra[c] = a.angles[b * a.ldic + c]; rt[c] = a.torsions[b * a.ldic + c]; }
+        const float gl = a.g_dlogp[b];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool bad = false;
+        for (int i = n - 1; i >= 0; --i) {
+            const int at = place[5 * i], i1 = place[5 * i + 1], i2 = place[5 * i + 2], i3 = place[5 * i + 3], zr = place[5 * i + 4];
+            const V3 p1 = ld3(xr + 3 * i1), p2 = ld3(xr + 3 * i2), p3 = ld3(xr + 3 * i3);
+            const float dd = rb[zr], an = ra[zr], t = rt[zr];
+            const V3 g = ld3(gp + 3 * at);
+            const PlaceAdj q = placement_adjoint<true, 1, true>(p1, p2, p3, dd, an, t, g, gl, a.normalize, a.eps, a.enforce, bad);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                gp[3 * i1] += q.g1.x; gp[3 * i1 + 1] += q.g1.y; gp[3 * i1 + 2] += q.g1.z;
+                gp[3 * i2] += q.g2.x; gp[3 * i2 + 1] += q.g2.y; gp[3 * i2 + 2] += q.g2.z;
+                gp[3 * i3] += q.g3.x; gp[3 * i3 + 1] += q.g3.y; gp[3 * i3 + 2] += q.g3.z;
+                a.g_bonds[b * a.ldgic + zr] = q.gd; a.g_angles[b * a.ldgic + zr] = q.ga; a.g_torsions[b * a.ldgic + zr] = q.gt;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (a.T) {
+            for (int kk = lane; kk < keep; kk += 64) {
+                float s = 0.0f;
+                for (int c = 0; c < nf3; ++c) s += gp[3 * a.fixed[c / 3] + c % 3] * a.T[kk * nf3 + c];
+                a.g_xfix[b * a.ldgf + kk] = s;
+            }
+        } else {
+            for (int c = lane; c < nf3; c += 64) a.g_xfix[b * a.ldgf + c] = gp[3 * a.fixed[c / 3] + c % 3];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 /* ---- global reference frame of the first three atoms (ReferenceSystemTransformation) -------------
  * 9 floats in, 9 floats out per sample; log|det J_9x9| in closed form -(2 ln d01 + 2 ln d12 + ln sin a012)
  * (the reference uses a batched autograd Jacobian + 24-term permutation expansion; see oracle bgo_refsys). */
@@ -1274,6 +1353,15 @@ extern "C" int bgk_ic_ic2xyz_backward(const float* bonds, const float* angles, c
         const size_t shm = sizeof(float) * ((size_t)ts * (size_t)f.sx + tab);
         if (shm > 160 * 1024) { bgk_set_error("%s: %d atoms do not fit the LDS rows of the fix-up launch", what, a.n_atoms); return BGK_EUNSUPPORTED; }
         if (shm > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_fix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        /* one wave per listed sample (round 6); BGK_IC_FIX_LANES=1 keeps round 5's lane-per-sample kernel (the A/B of
+         * profiles/r06_ab_runs.txt: 0.144 -> 0.026 ms on the few hundred listed samples of a cfg 3 KL step) */
+        const bool lanes_only = getenv("BGK_IC_FIX_LANES") != nullptr;
+        const size_t shw = sizeof(float) * (size_t)f.sx;
+        if (!lanes_only && shw <= 160 * 1024) {
+            if (shw > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ic_ic2xyz_bwd_fix_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(ic_ic2xyz_bwd_fix_wave_kernel, dim3(4096), dim3(64), shw, st, f);
+            return bgk_launch_status(what);
+        }
         hipLaunchKernelGGL(ic_ic2xyz_bwd_fix_kernel, dim3(ts == 64 ? 64 : 256), dim3(ts), shm, st, f);
         return bgk_launch_status(what);
     };

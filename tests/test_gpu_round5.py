@@ -355,8 +355,9 @@ def test_ic_backward_dma_staging_equals_the_row_loop_kernels(hip_lib, dev, B):
     """bgk_ic_ic2xyz_backward on contiguous tensors stages its tiles by DMA and stores the tile images as 16-byte pieces (round 5);
     BGK_IC_BWD_NODMA=1 / BGK_IC_BWD_LDS=1 select the earlier kernels (per-lane row loops; positions in registers / in LDS); all three
     list the samples with a clamped norm for the fix-up launch (dual-number adjoint); without the list (fix_ws = NULL) the generic
-    sweep evaluates the dual numbers in line.  Same arithmetic per placement: bit-identical gradients, for whole and partial tiles
-    (row counts that leave 1..3 floats over)."""
+    sweep evaluates the dual numbers in line.  The fix-up launch itself is one wave per listed sample, the twelve dual directions on
+    twelve lanes (round 6); BGK_IC_FIX_LANES=1 selects round 5's lane-per-sample form (three passes of four directions).  Same
+    arithmetic per placement and direction: bit-identical gradients, for whole and partial tiles (row counts that leave 1..3 floats over)."""
     import os
     from bgflow_amd import configs
     gen = configs.make_ala2_spline_generator(dev)
@@ -371,7 +372,7 @@ def test_ic_backward_dma_staging_equals_the_row_loop_kernels(hip_lib, dev, B):
     try:
         rel_ic = [m for m in blk.modules() if hasattr(m, "_fixup_list")]
         assert rel_ic
-        for mode in ("dma", "BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS", "no list"):
+        for mode in ("dma", "BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS", "BGK_IC_FIX_LANES", "no list"):
             if mode.startswith("BGK_"):
                 os.environ[mode] = "1"
             if mode == "no list":               # without the workspace: the generic sweep with the dual numbers in line
@@ -385,9 +386,10 @@ def test_ic_backward_dma_staging_equals_the_row_loop_kernels(hip_lib, dev, B):
     finally:
         os.environ.pop("BGK_IC_BWD_NODMA", None)
         os.environ.pop("BGK_IC_BWD_LDS", None)
+        os.environ.pop("BGK_IC_FIX_LANES", None)
         for m in rel_ic:
             m.__dict__.pop("_fixup_list", None)
-    for mode in ("BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS", "no list"):
+    for mode in ("BGK_IC_BWD_NODMA", "BGK_IC_BWD_LDS", "BGK_IC_FIX_LANES", "no list"):
         for a, b in zip(res["dma"], res[mode]):
             assert bool(torch.isfinite(a).all())
             assert torch.equal(a, b), f"B = {B}: DMA-staged sweep vs {mode}: max difference {float((a - b).abs().max()):.2e}"

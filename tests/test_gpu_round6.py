@@ -423,3 +423,45 @@ def test_coupling_stack_as_one_autograd_node_equals_the_blocks(hip_lib, dev, inv
     assert float((one[2] - blocks[2]).norm() / blocks[2].norm()) <= 2e-6
     rel, worst = _grad_errors(one[3], blocks[3])
     assert rel <= 2e-6, (rel, worst)
+
+
+def test_ic_backward_fixup_with_a_long_list(hip_lib, dev):
+    """The fix-up launch of bgk_ic_ic2xyz_backward (one wave per listed sample, round 6) on a batch in which every sample has one or two
+    bonds of 5e-5 .. 4e-4 nm at random Z-matrix rows (a placement that refers to such a pair of atoms gets a clamped norm: 40 % of the
+    6 000 samples end up listed -- more than the launch has workgroups, which stride over the list)
+    against the generic sweep that evaluates the dual numbers in line (no list): bit-identical gradients -- the same placement
+    arithmetic per direction, whichever lane carries it (crd_transform/ic.py:386-513 under autograd, ic_helper.py:372-452)."""
+    from bgflow_amd import configs
+    gen = configs.make_ala2_spline_generator(dev)
+    blk = list(gen.flow)[-1]
+    B = 6000
+    g = torch.Generator().manual_seed(606)
+    base = [0.1 + 0.05 * torch.rand(B, 17, generator=g), 0.2 + 0.6 * torch.rand(B, 17, generator=g), torch.rand(B, 17, generator=g),
+            torch.randn(B, 9, generator=g)]
+    rows = torch.arange(B)
+    for _ in range(2):
+        col = torch.randint(0, 17, (B,), generator=g)
+        base[0][rows, col] = 5e-5 + 3.5e-4 * torch.rand(B, generator=g)
+    w = torch.randn(B, 66, generator=g).to(dev)
+    res = {}
+    rel_ic = [m for m in blk.modules() if hasattr(m, "_fixup_list")]
+    assert rel_ic
+    try:
+        for mode in ("list", "no list"):
+            if mode == "no list":
+                for m in rel_ic:
+                    m._fixup_list = lambda device, n_rows: None
+            ins = [t_.to(dev).requires_grad_(True) for t_ in base]
+            x, dl = blk(*ins)
+            ((x * w).sum() - 0.7 * dl.sum()).backward()
+            res[mode] = [t_.grad.clone() for t_ in ins]
+            if mode == "list":
+                listed = max(int(m._fixup_list(x.device, B)[0]) for m in rel_ic)            # the count the sweep left in the workspace
+                print("listed samples:", listed, "of", B)
+                assert listed > B // 3
+    finally:
+        for m in rel_ic:
+            m.__dict__.pop("_fixup_list", None)
+    for a, b in zip(res["list"], res["no list"]):
+        assert bool(torch.isfinite(a).all())
+        assert torch.equal(a, b), f"max difference {float((a - b).abs().max()):.2e}"
