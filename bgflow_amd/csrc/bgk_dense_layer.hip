@@ -12,7 +12,7 @@
  * f16 pairs, three MFMAs per product, f32 accumulate: f32-class).
  *   - B operand: the wave's [32 samples][n_in] tile arrives as row-contiguous 16-byte pieces (a wave instruction = 1 KB of consecutive
  *     row bytes) in LDS, is read back in fragment order (lane (kb, j): the 8 consecutive features 16 s + 8 kb .. + 7 of row j, two
- *     16-byte reads per k16-step; row stride == 4 mod 64 banks), brought under a per-tile power-of-two scale (largest magnitude into
+ *     16-byte reads per k16-step; row stride == 4 mod 64 banks), brought under a per-SAMPLE power-of-two scale (the row's largest magnitude into
  *     [2^14, 2^15): inputs of any range, unlike the coupling kernels' bounded activations), split once and kept in registers as
  *     hi / lo fragments (8 per k-step) for every 128-row group of output features.  Loaded in fragment order straight from global
  *     memory (32-byte pieces of 32 different rows per instruction, every 128-byte line touched by 8 instructions) the 256-input
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    /* ---- fragment order (lane (kb, j): features 16 s + 8 kb .. + 7 of row j), largest magnitude, split under its power-of-two scale ---- */
+    /* ---- fragment order (lane (kb, j): features 16 s + 8 kb .. + 7 of row j), the row's largest magnitude, split under its power-of-two scale ---- */
     h2_h16x8 bhi[S], blo[S];
     float inv_tile;
     {
@@ -133,11 +133,13 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
             for (int e = 0; e < 8; ++e) {                        /* finite values only: an inf / NaN entry must not take its tile's scale (and with it the
                                                                   * 31 other samples' f16 range) along -- it poisons its own sample's outputs and nothing else */
                 const float av = __builtin_fabsf(v[s][e]);
-                m = __builtin_fmaxf(m, av < 3.0e38f ? av : 0.0f);
+                m = __builtin_fmaxf(m, av < 3.0e38f ? av : 0.0f);      /* (per sample since round 6: the rule now only keeps a row's own finite entries in range) */
             }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off));
+        /* the scale is per SAMPLE (round 6; per 32-sample tile before): lanes j and j + 32 hold the two halves of row j's k range, the
+         * accumulator column of lane (j, hh) is sample j again, so the unscale factor below is a per-lane value -- a row's precision
+         * does not depend on which other rows share its tile (torch.nn.Linear's rows do not either) */
+        m = __builtin_fmaxf(m, __shfl_xor(m, 32));
         const float sc = h2_pow2_scale(m, inv_tile);
 #pragma unroll
         for (int s = 0; s < S; ++s) h2_split8_scaled(v[s], sc, bhi[s], blo[s]);

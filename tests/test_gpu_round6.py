@@ -465,3 +465,32 @@ def test_ic_backward_fixup_with_a_long_list(hip_lib, dev):
     for a, b in zip(res["list"], res["no list"]):
         assert bool(torch.isfinite(a).all())
         assert torch.equal(a, b), f"max difference {float((a - b).abs().max()):.2e}"
+
+
+def test_layer_kernel_scales_every_sample_by_itself(hip_lib, dev):
+    """bgk_dense_layer brings its input under a power-of-two scale before the f16 hi / lo split -- per SAMPLE since round 6 (the advisor's
+    round-5 finding: one scale per 32-sample tile tied a row's precision to the rows that happened to share its wave).  Rows of
+    magnitude 1e-8 .. 1e+8 and a row holding an inf in ONE tile: every finite row within 2e-6 of the f64 product relative to ITS OWN
+    scale (|x_row| |W| bound), and bit-identical to the same row evaluated in a batch of its own (nn/dense.py:30-48 on torch.nn.Linear,
+    whose rows do not see each other either)."""
+    from bgflow_amd import dense
+    from bgflow_amd.utils import hash_init_
+    lin = hash_init_(torch.nn.Linear(96, 80)).to(dev)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(32, 96, generator=g)
+    mags = 10.0 ** torch.linspace(-8, 8, 32)
+    x = x * mags[:, None]
+    x[7, 5] = float("inf")
+    y = dense.dense_layer(x.to(dev), lin).cpu()
+    W, b = lin.weight.detach().cpu().double(), lin.bias.detach().cpu().double()
+    want = x.double() @ W.T + b
+    finite = [r for r in range(32) if r != 7]
+    assert not bool(torch.isfinite(y[7]).all())                       # the inf row poisons itself ...
+    assert bool(torch.isfinite(y[finite]).all())                      # ... and nothing else
+    bound = (x.double().abs() @ W.abs().T + b.abs())[finite]
+    err = ((y[finite].double() - want[finite]).abs() / bound).max()
+    print("layer kernel, rows of 1e-8 .. 1e+8 in one tile: max error relative to the row's own |x||W| bound", float(err))
+    assert float(err) <= 2e-6
+    for r in (0, 15, 31):
+        alone = dense.dense_layer(x[r:r + 1].to(dev), lin).cpu()
+        assert torch.equal(alone[0], y[r]), f"row {r}: its output depends on the rows it shares a tile with"
