@@ -137,6 +137,12 @@ _SIGNATURES = {
     "bgk_affine_net_backward64_workspace": (i64, [i64, i32, i32, i32, i32]),
     "bgk_affine_net_backward64": (ctypes.c_int, [vp, i64, i32, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, i32, i64,
                                                  vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "bgk_affine_coupling_backward64_workspace": (i64, [i64, i32, i32, i32, i32, i32, i32]),
+    "bgk_affine_coupling_backward64": (ctypes.c_int, [vp, i64, i32, vp, i64, i32, vp, i64, vp,
+                                                      vp, vp, vp, vp, vp, i64,
+                                                      vp, vp, vp, vp, vp, vp, i32, i32, i32,
+                                                      vp, vp, vp, vp, vp, vp, vp, i32, i32, i32,
+                                                      vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp, i32, vp]),
     "bgk_linear_weight_grad_workspace": (i64, [i64, i32, i32]),
     "bgk_linear_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, i64, i32, i64, vp, i64, vp, vp, i32, vp, vp]),
 }

@@ -42,7 +42,30 @@ struct Bwd64Args {
     float* pw2; float* pw1; float* pw0; float* pb2; float* pb1; float* pb0;
     int H1, H0, n_slabs;
     int vec_gx;          /* rows of g_cond (and of its addend) start on 16-byte boundaries and n_in is a multiple of 4 */
+    /* RECOMP: the network's FORWARD operands (bgk_pack_mlp_h2, HT = 2) -- z0 / z1 are recomputed from the conditioner rows */
+    const uint4* A0; const uint4* A1; const uint4* A2; int S0;
+    /* TAIL (the scale network of a forward-direction coupling): the affine tail's backward in front of the network's; s_raw [B, lds]: the
+     * network's saved output (!RECOMP) */
+    const float* s_raw; int64_t lds;
+    const float* y; int64_t ldy; const float* g_dl; const float* log_alpha; float* g_y; int64_t ldgy; float* pa; int vec_gy;
 };
+constexpr int FWB = 12 + 18 + 9;   /* forward operand blocks in LDS (RECOMP): A0 (<= 3 k-steps x 2 tiles x {hi, lo}), A1 (4 x 2 x 2 + 2 bias), A2 (4 x 1 x 2 + 1) */
+
+/* tanh of the scale network's OUTPUT (log sigma): the form of the forward kernels (bgk_affine_fwd64.hip::f64_tanh_out) */
+__device__ __forceinline__ float q_tanh_out(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float dn = 1.0f + __builtin_amdgcn_exp2f(ax * 2.88539008177792681f);
+    const float rc = __builtin_amdgcn_rcpf(dn);
+    const float big = __builtin_copysignf(__builtin_fmaf(-2.0f, __builtin_fmaf(__builtin_fmaf(-dn, rc, 1.0f), rc, rc), 1.0f), x);
+    const float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = __builtin_fmaf(p, z, 2.06390887954e-2f);
+    p = __builtin_fmaf(p, z, -5.37397155531e-2f);
+    p = __builtin_fmaf(p, z, 1.33314422036e-1f);
+    p = __builtin_fmaf(p, z, -3.33332819422e-1f);
+    const float small = __builtin_fmaf(p * z, x, x);
+    return ax >= 0.625f ? big : small;
+}
 
 /* d = g * act'(z), h = act(z) for a pair (hardware exp / rcp; the forms of bgk_dense_backward_dx) */
 __device__ __forceinline__ void q_act_grad2(int act, bgk_f2 z, bgk_f2 g, bgk_f2& gz, bgk_f2& h) {
@@ -195,12 +218,31 @@ __device__ __forceinline__ void q_running_scale(float tile_max, float& s_run, fl
     } else if (s_run == 0.0f) { s_run = 1.0f; inv_run = 1.0f; }
 }
 
-template <int ACT>
+/* MODE = RECOMP + 2 TAIL.
+ * !RECOMP: z1 / z0 saved by the forward.  RECOMP (round 6): NOTHING is saved -- the wave redoes the network's forward on its tile (the
+ * forward kernels' products in the forward kernels' order, operands in LDS beside the transposed ones: 44 - 57 matrix instructions) and
+ * the training forward writes only its outputs.
+ * !TAIL: g = the gradient w.r.t. the network's output, under the tensor's scale (g_absmax) or, without one, a running scale like s1 / s0
+ * (the shift network of a forward-direction coupling: g_mu = g_out, read as it is).  TAIL: the scale network of a forward-direction
+ * coupling -- g_s_raw = (g_out e^s y + g_dlogp) alpha (1 - tanh^2 s_raw) is formed on chip from y, g_out, g_dlogp and s_raw (saved, or
+ * recomputed: the output layer too) with bgk_affine_backward's arithmetic (nn/flow/transformer/affine.py:41-70 under autograd),
+ * g_y = g_out e^s leaves from here, the log_alpha gradient as one partial per workgroup: bgk_affine_backward's launch, its g_mu / g_s
+ * arrays (2 x 4 d B per sample written and read again) and its atomics do not exist. */
+template <int ACT, int MODE>
 __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kernel(Bwd64Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint4* s_op = reinterpret_cast<uint4*>(smem);                         /* [OPB][64] operand blocks */
     const int lane_in = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* sx = smem + OPB * 256 + wave * (64 * TP);                      /* this wave's transposed tile */
+    constexpr bool RECOMP = (MODE & 1) != 0, TAIL = (MODE & 2) != 0;
+    const uint4* s_fw = s_op + OPB * 64;                                  /* RECOMP: [FWB][64] forward operand blocks */
+    float* sx = smem + (OPB + (RECOMP ? FWB : 0)) * 256 + wave * (64 * TP); /* this wave's transposed tile */
+    if (RECOMP) {
+        const int nb0 = a.S0 * 4;
+        for (int b = wave; b < FWB; b += QW) {
+            const uint4* src = b < 12 ? (b < nb0 ? a.A0 + b * 64 : nullptr) : (b < 30 ? a.A1 + (b - 12) * 64 : (TAIL ? a.A2 + (b - 30) * 64 : nullptr));
+            if (src) s_op[(OPB + b) * 64 + lane_in] = src[lane_in];
+        }
+    }
     /* ---- the network's transposed operands, once per workgroup: T2 blocks (s < 2, m < 2), T1 (s < 4, m < 2), T0 (s < 4; FT = 1) ---- */
     for (int b = wave; b < OPB; b += QW) {
         const uint4* src;
@@ -211,8 +253,11 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
     }
     __syncthreads();
     const float c2 = a.cs[5], c1 = a.cs[3], c0 = a.cs[1];
-    float inv_sg;
-    const float sg = h2_pow2_scale(a.g_absmax ? a.g_absmax[0] : 0.0f, inv_sg);
+    float inv_sg = 1.0f;
+    const bool run_g = TAIL || a.g_absmax == nullptr;                      /* g under a running scale like s1 / s0 (no tensor maximum published) */
+    float sg = run_g ? 0.0f : h2_pow2_scale(a.g_absmax[0], inv_sg);
+    const float alpha = TAIL ? bgk_expf(a.log_alpha[0]) : 0.0f;
+    float ga_sum = 0.0f;                                                   /* TAIL: the lane's share of d loss / d log_alpha / alpha */
     const int wslab = blockIdx.x * QW + wave;              /* the wave's position among all waves: its tiles are wslab, wslab + n_waves, .. */
     const int64_t n_tiles = (a.B + 31) / 32;
     const int d = a.d, n_in = a.n_in;
@@ -236,12 +281,15 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
         const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
         const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + b0 * a.ldg), 0, (rows - 1) * ldg4 + d * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + b0 * a.ldc), 0, (rows - 1) * ldc4 + n_in * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_z1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z1 + b0 * 64), 0, rows * 256, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_z0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.z0 + b0 * 64), 0, rows * 256, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z1 = __builtin_amdgcn_make_buffer_rsrc((void*)((RECOMP ? a.x : a.z1) + b0 * 64), 0, RECOMP ? 0 : rows * 256, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z0 = __builtin_amdgcn_make_buffer_rsrc((void*)((RECOMP ? a.x : a.z0) + b0 * 64), 0, RECOMP ? 0 : rows * 256, 0x00020000);
         /* ---- every global request of the tile up front (one exposed round trip per tile: one wave per SIMD hides none): the lane's row
          * of g (columns 16 s + 8 hh ..), its rows of z1 / z0, its column of g and of the conditioner input (samples 16 s + 8 hh ..) ---- */
         float grow_v[2][8], gcol_v[2][8], xcol_v[2][8];
         float4 zz1[8], zz0[8];
+        float xr[2][8];                          /* RECOMP: the lane's row of the conditioner input, features 16 s + 8 hh .. (the forward's layer-0 B operand) */
+        float srv[16];                           /* TAIL && !RECOMP: the saved s_raw, accumulator layout */
+        float yv[16], gv[16], gl = 0.0f;         /* TAIL: y and g_out in ACCUMULATOR layout (dims (r & 3) + 8 (r >> 2) + 4 hh of sample j), g_dlogp of sample j */
         {
             const int vrow = j * ldg4 + hh * 32;                                   /* row j, column 8 hh */
             const int vgc = j < d ? hh * 8 * ldg4 + j * 4 : Q_OOB;                  /* sample 8 hh, column j */
@@ -251,19 +299,172 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    grow_v[s][e] = (16 * s + 8 * hh + e < d) ? q_ld1(rs_g, vrow, (16 * s + e) * 4) : 0.0f;     /* (a row's columns past d belong to the next row) */
-                    gcol_v[s][e] = q_ld1(rs_g, vgc, (16 * s + e) * ldg4);
+                    if (!TAIL) {
+                        grow_v[s][e] = (16 * s + 8 * hh + e < d) ? q_ld1(rs_g, vrow, (16 * s + e) * 4) : 0.0f;     /* (a row's columns past d belong to the next row) */
+                        gcol_v[s][e] = q_ld1(rs_g, vgc, (16 * s + e) * ldg4);
+                    }
                     xcol_v[s][e] = q_ld1(rs_x, vxc, (16 * s + e) * ldc4);
+                    if (RECOMP) xr[s][e] = (16 * s + 8 * hh + e < n_in) ? q_ld1(rs_x, j * ldc4 + hh * 32, (16 * s + e) * 4) : 0.0f;
                 }
+            if (TAIL) {
+                const int ldy4 = (int)a.ldy * 4;
+                const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + b0 * a.ldy), 0, (rows - 1) * ldy4 + d * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g_dl + b0), 0, rows * 4, 0x00020000);
+                gl = q_ld1(rs_l, j * 4, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool in = 8 * q + 4 * hh + e < d;
+                        yv[4 * q + e] = in ? q_ld1(rs_y, j * ldy4 + hh * 16, (8 * q + e) * 4) : 0.0f;
+                        gv[4 * q + e] = in ? q_ld1(rs_g, j * ldg4 + hh * 16, (8 * q + e) * 4) : 0.0f;
+                    }
+                if (!RECOMP) {
+                    const int lds4 = (int)a.lds * 4;
+                    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)(a.s_raw + b0 * a.lds), 0, (rows - 1) * lds4 + d * 4, 0x00020000);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) srv[4 * q + e] = (8 * q + 4 * hh + e < d) ? q_ld1(rs_s, j * lds4 + hh * 16, (8 * q + e) * 4) : 0.0f;
+                }
+            }
+            if (!RECOMP) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        zz1[4 * m + q] = q_ld4(rs_z1, vz, (32 * m + 8 * q) * 4);
+                        zz0[4 * m + q] = q_ld4(rs_z0, vz, (32 * m + 8 * q) * 4);
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float sraw[16];                          /* TAIL: the scale network's output before tanh (accumulator layout) */
+        if (RECOMP) {
+            /* ---- the network's forward on this tile, as bgk_affine_fwd64.hip::f64_network runs it: layer 0 from the conditioner rows (the
+             * constant-1 feature n_in carries the bias), hidden layer, (TAIL) output layer; the scaled pre-activations stay in zz0 / zz1 ---- */
+            const uint4* A0s = s_fw;
+            const uint4* A1s = s_fw + 12 * 64;
+            const uint4* A2s = s_fw + 30 * 64;
+            h2_f32x16 fa[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    zz1[4 * m + q] = q_ld4(rs_z1, vz, (32 * m + 8 * q) * 4);
-                    zz0[4 * m + q] = q_ld4(rs_z0, vz, (32 * m + 8 * q) * 4);
+                for (int r = 0; r < 16; ++r) fa[m][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (s < a.S0) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int f = 16 * s + 8 * hh + e;
+                        v[e] = f == n_in ? 1.0f : (s < 2 ? xr[s < 2 ? s : 0][e] : 0.0f);
+                    }
+                    h2_h16x8 bhi, blo;
+                    h2_split8(v, bhi, blo);
+                    H2A<2> fr;
+                    h2a_load<2>(fr, A0s, s, lane);
+                    h2_mfma3<2>(fa, fr, bhi, blo);
                 }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fa[m][r] *= c0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zz0[4 * m + q] = make_float4(fa[m][4 * q], fa[m][4 * q + 1], fa[m][4 * q + 2], fa[m][4 * q + 3]);
+                h2_act_tile(fa[m], 1.0f, ACT);
+            }
+            H2B<2> fb;
+            h2_make_b<2>(fb, fa);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fa[m][r] = 0.0f;
+            h2_gemm_hidden<2, 2>(fa, fb, A1s, lane);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fa[m][r] *= c1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zz1[4 * m + q] = make_float4(fa[m][4 * q], fa[m][4 * q + 1], fa[m][4 * q + 2], fa[m][4 * q + 3]);
+            }
+            if (TAIL) {
+                h2_act_tile(fa[0], 1.0f, ACT);
+                h2_act_tile(fa[1], 1.0f, ACT);
+                h2_make_b<2>(fb, fa);
+                h2_f32x16 so[1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) so[0][r] = 0.0f;
+                h2_gemm_hidden<1, 2>(so, fb, A2s, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sraw[r] = so[0][r] * c2;
+            }
+        } else if (TAIL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sraw[r] = srv[r];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (TAIL) {
+            __builtin_amdgcn_sched_barrier(0);
+            /* ---- the affine tail's backward (forward direction, no volume preservation): per element th = tanh(s_raw), s = alpha th,
+             * g_y = g e^s, g_s = g e^s y + g_dlogp, g_s_raw = g_s alpha (1 - th^2), d / d log_alpha += g_s th alpha ---- */
+            float gs[16], gy[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool in = (r & 3) + 8 * (r >> 2) + 4 * hh < d;
+                const float th = q_tanh_out(sraw[r]);
+                const float ex = __builtin_amdgcn_exp2f(th * alpha * 1.44269504088896341f);
+                gy[r] = gv[r] * ex;
+                const float gls = __builtin_fmaf(gy[r], yv[r], gl);
+                gs[r] = in ? gls * alpha * __builtin_fmaf(-th, th, 1.0f) : 0.0f;
+                ga_sum += in ? gls * th : 0.0f;
+            }
+            if (j < rows) {
+                float* grow_y = a.g_y + (b0 + j) * a.ldgy;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 8 * q + 4 * hh;
+                    if (a.vec_gy && f0 + 3 < d) {
+                        *reinterpret_cast<float4*>(grow_y + f0) = make_float4(gy[4 * q], gy[4 * q + 1], gy[4 * q + 2], gy[4 * q + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (f0 + e < d) grow_y[f0 + e] = gy[4 * q + e];
+                    }
+                }
+            }
+            /* g_s_raw in the two layouts the network's backward reads g in: rows (lane (j, hh): dims 16 s + 8 hh ..: the quads a lane lacks
+             * sit in its partner lane j, 1 - hh) and columns (lane = dim j, samples 16 s + 8 hh ..: through the transposed tile) */
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float own_lo = gs[4 * (2 * s2) + e], own_hi = gs[4 * (2 * s2 + 1) + e];     /* quads q = 2 s, 2 s + 1: dims 16 s + 4 hh + e, 16 s + 8 + 4 hh + e */
+                    const float send = hh ? own_lo : own_hi;                                       /* hh = 0 keeps dims 16 s + 0..3, hh = 1 keeps 16 s + 12..15 */
+                    const float recv = __shfl_xor(send, 32);
+                    grow_v[s2][e] = hh ? recv : own_lo;                                              /* dims 16 s + 8 hh + e */
+                    grow_v[s2][4 + e] = hh ? own_hi : recv;                                          /* dims 16 s + 8 hh + 4 + e */
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sx[((r & 3) + 8 * (r >> 2) + 4 * hh) * TP + j] = gs[r];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) q_read8(sx, j, s2, hh, gcol_v[s2]);
+            q_release();
+        }
+        if (run_g) {
+            /* the running scale of g (its products accumulate in dW2 across the wave's tiles) */
+            float tm = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tm = __builtin_fmaxf(tm, __builtin_fabsf(grow_v[s2][e]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) tm = __builtin_fmaxf(tm, __shfl_xor(tm, off));
+            q_running_scale<2>(tm, sg, inv_sg, dW2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         /* ---- g_h1 = W2^T g ---- */
         h2_f32x16 acc[2] = {zero16, zero16};
 #pragma unroll
@@ -441,12 +642,17 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
         h2_f32x16 bsv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bsv[r] = 0.0f;
-        bsv[0] = bs2; bsv[1] = bs1[0]; bsv[2] = bs1[1]; bsv[3] = bs0[0]; bsv[4] = bs0[1];
+        bsv[0] = bs2; bsv[1] = bs1[0]; bsv[2] = bs1[1]; bsv[3] = bs0[0]; bsv[4] = bs0[1]; bsv[5] = ga_sum;
         wg_sum(bsv);
-        bs2 = bsv[0]; bs1[0] = bsv[1]; bs1[1] = bsv[2]; bs0[0] = bsv[3]; bs0[1] = bsv[4];
+        bs2 = bsv[0]; bs1[0] = bsv[1]; bs1[1] = bsv[2]; bs0[0] = bsv[3]; bs0[1] = bsv[4]; ga_sum = bsv[5];
     }
     if (wave != 0) return;
     const int slab = blockIdx.x;                          /* one slab per workgroup */
+    if (TAIL) {                                           /* the workgroup's share of d loss / d log_alpha (fixed shuffle tree; the slabs are summed in order by the reduction) */
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ga_sum += __shfl_xor(ga_sum, off);
+        if (lane == 0) a.pa[slab] = ga_sum * alpha;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -473,9 +679,17 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
 /* fixed-order sum of the per-wave partials (the scheme of wgrad_reduce_kernel, bgk_wgrad.hip): element i of a gradient [n, k] (+ its
  * bias [n] behind it) = sum over slabs; 8 lanes per element each take every 8th slab, combined in ascending order through LDS */
 struct QRed { const float* pw; const float* pb; int n, k; float* gW; float* gb; };
-struct QRedGroup { QRed r[3]; int64_t first[4]; int n_slabs; };
+struct QRedGroup { QRed r[3]; int64_t first[4]; int n_slabs; const float* pa; float* g_log_alpha; };     /* pa: one partial of the log_alpha gradient per slab (or NULL) */
 __global__ __launch_bounds__(256) void bwd64_reduce_kernel(QRedGroup rg, int accumulate) {
     __shared__ float s_part[8][32];
+    if (blockIdx.x * 32 >= rg.first[3]) {                 /* the block behind the gradients: the log_alpha partials, summed in slab order by one thread */
+        if (threadIdx.x == 0 && rg.pa && rg.g_log_alpha) {
+            float t = 0.0f;
+            for (int k = 0; k < rg.n_slabs; ++k) t += rg.pa[k];
+            rg.g_log_alpha[0] = accumulate ? rg.g_log_alpha[0] + t : t;
+        }
+        return;
+    }
     const int sub = threadIdx.x >> 5, el = threadIdx.x & 31;
     const int64_t gi = (int64_t)blockIdx.x * 32 + el;
     const int q = gi >= rg.first[2] ? 2 : (gi >= rg.first[1] ? 1 : 0);
@@ -523,6 +737,43 @@ extern "C" int64_t bgk_affine_net_backward64_workspace(int64_t B, int32_t d, int
     return s * ((int64_t)d * H1 + (int64_t)H1 * H0 + (int64_t)H0 * n_in) + 2 * s * ((int64_t)d + H1 + H0);
 }
 
+/* one network's launch + reduction (a: everything but the workspace pointers; mode = the kernel's MODE = RECOMP + 2 TAIL) */
+static int bwd64_run(Bwd64Args a, int mode, float* workspace, float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0,
+                     float* g_log_alpha, int accumulate, hipStream_t st, const char* what) {
+    const int d = a.d, H1 = a.H1, H0 = a.H0, n_in = a.n_in;
+    const int n_slabs = bwd64_slabs(a.B);
+    a.n_slabs = n_slabs;
+    a.vec_gx = a.g_x && n_in % 4 == 0 && ((uintptr_t)a.g_x & 15) == 0 && a.ldgx % 4 == 0 && (!a.g_x_add || (((uintptr_t)a.g_x_add & 15) == 0 && a.ldga % 4 == 0));
+    float* p = workspace;
+    a.pw2 = p; p += (int64_t)n_slabs * d * H1;
+    a.pw1 = p; p += (int64_t)n_slabs * H1 * H0;
+    a.pw0 = p; p += (int64_t)n_slabs * H0 * n_in;
+    a.pb2 = p; p += (int64_t)2 * n_slabs * d;
+    a.pb1 = p; p += (int64_t)2 * n_slabs * H1;
+    a.pb0 = p; p += (int64_t)2 * n_slabs * H0;
+    a.pa = p;
+    const size_t shmem = sizeof(float) * ((size_t)(OPB + ((mode & 1) ? FWB : 0)) * 256 + (size_t)QW * 64 * TP);
+#define BGK_LAUNCH_Q(A, M) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(affine_net_bwd64_kernel<A, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                                hipLaunchKernelGGL((affine_net_bwd64_kernel<A, M>), dim3(n_slabs), dim3(QW * 64), shmem, st, a); } while (0)
+#define BGK_LAUNCH_QA(M) do { if (a.act == 1) BGK_LAUNCH_Q(1, M); else if (a.act == 2) BGK_LAUNCH_Q(2, M); else BGK_LAUNCH_Q(3, M); } while (0)
+    if (mode == 0) BGK_LAUNCH_QA(0); else if (mode == 1) BGK_LAUNCH_QA(1); else if (mode == 2) BGK_LAUNCH_QA(2); else BGK_LAUNCH_QA(3);
+#undef BGK_LAUNCH_QA
+#undef BGK_LAUNCH_Q
+    QRedGroup rg;
+    rg.r[0] = QRed{a.pw2, a.pb2, d, H1, gW2, gb2};
+    rg.r[1] = QRed{a.pw1, a.pb1, H1, H0, gW1, gb1};
+    rg.r[2] = QRed{a.pw0, a.pb0, H0, n_in, gW0, gb0};
+    rg.first[0] = 0;
+    rg.first[1] = (int64_t)d * H1 + d;
+    rg.first[2] = rg.first[1] + (int64_t)H1 * H0 + H1;
+    rg.first[3] = rg.first[2] + (int64_t)H0 * n_in + H0;
+    rg.n_slabs = n_slabs;
+    rg.pa = (mode & 2) ? a.pa : nullptr; rg.g_log_alpha = (mode & 2) ? g_log_alpha : nullptr;
+    const unsigned blocks = (unsigned)((rg.first[3] + 31) / 32) + (rg.pa && rg.g_log_alpha ? 1u : 0u);
+    hipLaunchKernelGGL(bwd64_reduce_kernel, dim3(blocks), dim3(256), 0, st, rg, accumulate);
+    return bgk_launch_status(what);
+}
+
 extern "C" int bgk_affine_net_backward64(const float* g, int64_t ldg, int32_t d, const float* z1, const float* z0,
                                          const float* cond, int64_t ldc, int32_t n_in, int32_t H1, int32_t H0,
                                          const void* T0, const void* T1, const void* T2, const float* cs, int32_t act, int64_t B,
@@ -539,36 +790,63 @@ extern "C" int bgk_affine_net_backward64(const float* g, int64_t ldg, int32_t d,
         return BGK_EUNSUPPORTED;
     }
     BGK_CHECK_ARG(workspace_floats >= bgk_affine_net_backward64_workspace(B, d, H1, H0, n_in), "bgk_affine_net_backward64: workspace too small");
-    const int n_slabs = bwd64_slabs(B);
-    Bwd64Args a;
+    BGK_CHECK_ARG(ldg < (1 << 20) && ldc < (1 << 20), "bgk_affine_net_backward64: row stride too large");
+    Bwd64Args a{};
     a.g = g; a.ldg = ldg; a.d = d; a.z1 = z1; a.z0 = z0; a.x = cond; a.ldc = ldc; a.n_in = n_in;
     a.T2 = (const uint4*)T2; a.T1 = (const uint4*)T1; a.T0 = (const uint4*)T0; a.cs = cs; a.act = act; a.B = B;
     a.g_x = g_cond; a.ldgx = ldgc; a.g_x_add = g_cond ? g_cond_add : nullptr; a.ldga = ldga; a.g_absmax = g_absmax;
-    a.H1 = H1; a.H0 = H0; a.n_slabs = n_slabs;
-    a.vec_gx = g_cond && n_in % 4 == 0 && ((uintptr_t)g_cond & 15) == 0 && ldgc % 4 == 0 && (!a.g_x_add || (((uintptr_t)a.g_x_add & 15) == 0 && ldga % 4 == 0));
-    BGK_CHECK_ARG(ldg < (1 << 20) && ldc < (1 << 20), "bgk_affine_net_backward64: row stride too large");
-    float* p = workspace;
-    a.pw2 = p; p += (int64_t)n_slabs * d * H1;
-    a.pw1 = p; p += (int64_t)n_slabs * H1 * H0;
-    a.pw0 = p; p += (int64_t)n_slabs * H0 * n_in;
-    a.pb2 = p; p += (int64_t)2 * n_slabs * d;
-    a.pb1 = p; p += (int64_t)2 * n_slabs * H1;
-    a.pb0 = p;
-    const size_t shmem = sizeof(float) * ((size_t)OPB * 256 + (size_t)QW * 64 * TP);
+    a.H1 = H1; a.H0 = H0;
+    return bwd64_run(a, 0, workspace, gW2, gb2, gW1, gb1, gW0, gb0, nullptr, accumulate, (hipStream_t)stream, "bgk_affine_net_backward64");
+}
+
+extern "C" int64_t bgk_affine_coupling_backward64_workspace(int64_t B, int32_t d, int32_t n_in, int32_t sH1, int32_t sH0, int32_t tH1, int32_t tH0) {
+    const int64_t a = bgk_affine_net_backward64_workspace(B, d, sH1, sH0, n_in), b = bgk_affine_net_backward64_workspace(B, d, tH1, tH0, n_in);
+    return (a > b ? a : b) + bwd64_slabs(B);
+}
+
+extern "C" int bgk_affine_coupling_backward64(const float* cond, int64_t ldc, int32_t n_in, const float* y, int64_t ldy, int32_t d,
+                                              const float* g_out, int64_t ldgo, const float* g_dlogp,
+                                              const float* s_z0, const float* s_z1, const float* t_z0, const float* t_z1, const float* s_raw, int64_t lds,
+                                              const void* sA0, const void* sA1, const void* sT0, const void* sT1, const void* sT2,
+                                              const float* s_cs, int32_t s_act, int32_t sH1, int32_t sH0,
+                                              const void* tA0, const void* tA1, const void* tA2, const void* tT0, const void* tT1, const void* tT2,
+                                              const float* t_cs, int32_t t_act, int32_t tH1, int32_t tH0,
+                                              const float* log_alpha, int64_t B,
+                                              float* g_y, int64_t ldgy, float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                                              float* g_log_alpha, float* workspace, int64_t workspace_floats,
+                                              float* const* s_grads, float* const* t_grads, int32_t accumulate, void* stream) {
+    if (B == 0) return 0;
+    const char* what = "bgk_affine_coupling_backward64";
+    BGK_CHECK_ARG(cond && y && g_out && g_dlogp && g_y && log_alpha && workspace && s_grads && t_grads, "%s: null pointer", what);
+    BGK_CHECK_ARG(sA0 && sA1 && sT0 && sT1 && sT2 && s_cs && tA0 && tA1 && tA2 && tT0 && tT1 && tT2 && t_cs, "%s: null operand", what);
+    BGK_CHECK_ARG(B > 0 && d > 0 && n_in > 0 && sH1 > 0 && sH0 > 0 && tH1 > 0 && tH0 > 0 && ldc >= n_in && ldy >= d && ldgo >= d && ldgy >= d
+                  && s_act >= 1 && s_act <= 3 && t_act >= 1 && t_act <= 3 && (accumulate == 0 || accumulate == 1), "%s: bad sizes", what);
+    if (d > 32 || n_in > 32 || sH1 > 64 || sH0 > 64 || tH1 > 64 || tH0 > 64) {
+        bgk_set_error("%s: d = %d, n_in = %d, hidden (%d, %d) / (%d, %d): the kernel takes d, n_in <= 32 and hidden layers of <= 64 units", what, d, n_in, sH0, sH1, tH0, tH1);
+        return BGK_EUNSUPPORTED;
+    }
+    BGK_CHECK_ARG(workspace_floats >= bgk_affine_coupling_backward64_workspace(B, d, n_in, sH1, sH0, tH1, tH0), "%s: workspace too small", what);
+    BGK_CHECK_ARG(ldc < (1 << 20) && ldy < (1 << 20) && ldgo < (1 << 20), "%s: row stride too large", what);
+    const bool saved = s_z0 || s_z1 || t_z0 || t_z1 || s_raw;          /* the forward's arrays: all five, or none (the networks are recomputed) */
+    BGK_CHECK_ARG(!saved || (s_z0 && s_z1 && t_z0 && t_z1 && s_raw && lds >= d && lds < (1 << 20)), "%s: saved arrays: all five (z0, z1 of both networks, s_raw), or none", what);
+    const int rec = saved ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
-#define BGK_LAUNCH_Q(A) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(affine_net_bwd64_kernel<A>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                             hipLaunchKernelGGL((affine_net_bwd64_kernel<A>), dim3(n_slabs), dim3(QW * 64), shmem, st, a); } while (0)
-    if (act == 1) BGK_LAUNCH_Q(1); else if (act == 2) BGK_LAUNCH_Q(2); else BGK_LAUNCH_Q(3);
-#undef BGK_LAUNCH_Q
-    QRedGroup rg;
-    rg.r[0] = QRed{a.pw2, a.pb2, d, H1, gW2, gb2};
-    rg.r[1] = QRed{a.pw1, a.pb1, H1, H0, gW1, gb1};
-    rg.r[2] = QRed{a.pw0, a.pb0, H0, n_in, gW0, gb0};
-    rg.first[0] = 0;
-    rg.first[1] = (int64_t)d * H1 + d;
-    rg.first[2] = rg.first[1] + (int64_t)H1 * H0 + H1;
-    rg.first[3] = rg.first[2] + (int64_t)H0 * n_in + H0;
-    rg.n_slabs = n_slabs;
-    hipLaunchKernelGGL(bwd64_reduce_kernel, dim3((unsigned)((rg.first[3] + 31) / 32)), dim3(256), 0, st, rg, accumulate);
-    return bgk_launch_status("bgk_affine_net_backward64");
+    Bwd64Args a{};
+    a.g = g_out; a.ldg = ldgo; a.d = d; a.x = cond; a.ldc = ldc; a.n_in = n_in; a.B = B; a.S0 = (n_in + 1 + 15) / 16;
+    a.g_x = g_cond; a.ldgx = ldgc; a.ldga = ldga;
+    /* the scale network first: tail backward (g_y, the log_alpha gradient) + its chain and weight gradients; g_cond = W0^T g_z0 + g_cond_add */
+    a.T2 = (const uint4*)tT2; a.T1 = (const uint4*)tT1; a.T0 = (const uint4*)tT0; a.cs = t_cs; a.act = t_act; a.H1 = tH1; a.H0 = tH0;
+    a.A0 = (const uint4*)tA0; a.A1 = (const uint4*)tA1; a.A2 = (const uint4*)tA2;
+    a.g_x_add = g_cond ? g_cond_add : nullptr;
+    a.y = y; a.ldy = ldy; a.g_dl = g_dlogp; a.log_alpha = log_alpha; a.g_y = g_y; a.ldgy = ldgy;
+    a.vec_gy = ((uintptr_t)g_y & 15) == 0 && ldgy % 4 == 0;
+    a.z1 = t_z1; a.z0 = t_z0; a.s_raw = s_raw; a.lds = lds;
+    int rc = bwd64_run(a, 2 + rec, workspace, t_grads[0], t_grads[1], t_grads[2], t_grads[3], t_grads[4], t_grads[5], g_log_alpha, accumulate, st, what);
+    if (rc) return rc;
+    /* the shift network: g_mu = g_out; its conditioner-input gradient is added to the scale network's */
+    a.T2 = (const uint4*)sT2; a.T1 = (const uint4*)sT1; a.T0 = (const uint4*)sT0; a.cs = s_cs; a.act = s_act; a.H1 = sH1; a.H0 = sH0;
+    a.A0 = (const uint4*)sA0; a.A1 = (const uint4*)sA1; a.A2 = nullptr;
+    a.g_x_add = g_cond; a.ldga = ldgc;
+    a.z1 = s_z1; a.z0 = s_z0;
+    return bwd64_run(a, rec, workspace, s_grads[0], s_grads[1], s_grads[2], s_grads[3], s_grads[4], s_grads[5], nullptr, accumulate, st, what);
 }

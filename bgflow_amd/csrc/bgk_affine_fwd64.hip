@@ -110,7 +110,7 @@ __device__ __forceinline__ void f64_network(const Fwd64Net& n, const uint4* ops,
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] *= c0;
-    f64_store_tiles<2>(acc, n.z0, 64, slab, b0, rows, lane);
+    if (n.z0) f64_store_tiles<2>(acc, n.z0, 64, slab, b0, rows, lane);          /* (NULL: nothing is saved -- bgk_affine_coupling_backward64 recomputes) */
     H2B<2> bf;
     h2_act_tile(acc[0], 1.0f, n.act);
     h2_act_tile(acc[1], 1.0f, n.act);
@@ -124,7 +124,7 @@ __device__ __forceinline__ void f64_network(const Fwd64Net& n, const uint4* ops,
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] *= c1;
-    f64_store_tiles<2>(acc, n.z1, 64, slab, b0, rows, lane);
+    if (n.z1) f64_store_tiles<2>(acc, n.z1, 64, slab, b0, rows, lane);
     h2_act_tile(acc[0], 1.0f, n.act);
     h2_act_tile(acc[1], 1.0f, n.act);
     h2_make_b<2>(bf, acc);
@@ -180,12 +180,12 @@ __global__ __launch_bounds__(FWW * 64, 1) void coupling_affine_fwd64_train_kerne
         if (has_shift) {
             f64_network(a.net[0], s_op, xb, a.S0, mu, slab, b0, rows, lane);
             h2_f32x16 t1[1] = {mu};
-            f64_store_tiles<1>(t1, a.mu, (int)a.ldms, slab, b0, rows, lane);
+            if (a.mu) f64_store_tiles<1>(t1, a.mu, (int)a.ldms, slab, b0, rows, lane);
         }
         if (has_scale) {
             f64_network(a.net[1], s_op + NETB * 64, xb, a.S0, sr, slab, b0, rows, lane);
             h2_f32x16 t1[1] = {sr};
-            f64_store_tiles<1>(t1, a.s_raw, (int)a.ldms, slab, b0, rows, lane);
+            if (a.s_raw) f64_store_tiles<1>(t1, a.s_raw, (int)a.ldms, slab, b0, rows, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         /* y values of the lane's dims (accumulator layout: dims (r & 3) + 8 (r >> 2) + 4 hh of sample j), requested behind the networks (their registers are the networks' while those run) */
@@ -267,9 +267,10 @@ extern "C" int bgk_coupling_affine_dense_fwd64_train(const float* cond, int64_t 
     if (B == 0) return 0;
     const char* what = "bgk_coupling_affine_dense_fwd64_train";
     BGK_CHECK_ARG(cond && y && out && dlogp && B > 0 && d > 0 && n_in > 0 && ldc >= n_in && ldy >= d && ldo >= d, "%s: bad arguments", what);
-    BGK_CHECK_ARG((sA0 || tA0) && (!sA0 || (sA1 && sA2 && s_cs && s_z0 && s_z1 && mu)) && (!tA0 || (tA1 && tA2 && t_cs && t_z0 && t_z1 && s_raw && log_alpha)),
-                  "%s: null operand / save buffer", what);
-    BGK_CHECK_ARG(ldms >= 32 && ldms % 4 == 0 && ldms < (1 << 20), "%s: ldms = %lld (a multiple of 4, >= 32)", what, (long long)ldms);
+    const bool no_save = !s_z0 && !s_z1 && !t_z0 && !t_z1 && !mu && !s_raw;       /* all six NULL: the forward alone (the backward recomputes: bgk_affine_coupling_backward64) */
+    BGK_CHECK_ARG((sA0 || tA0) && (!sA0 || (sA1 && sA2 && s_cs)) && (!tA0 || (tA1 && tA2 && t_cs && log_alpha)), "%s: null operand", what);
+    BGK_CHECK_ARG(no_save || ((!sA0 || (s_z0 && s_z1)) && (!tA0 || (t_z0 && t_z1 && s_raw))), "%s: save buffers: all of a network's (mu may be left out), or none at all", what);
+    BGK_CHECK_ARG(no_save || (ldms >= 32 && ldms % 4 == 0 && ldms < (1 << 20)), "%s: ldms = %lld (a multiple of 4, >= 32)", what, (long long)ldms);
     if (d > 32 || n_in > 32) { bgk_set_error("%s: d = %d, n_in = %d: the kernel takes d, n_in <= 32", what, d, n_in); return BGK_EUNSUPPORTED; }
     const auto act_ok = [](const void* A, int act) { return !A || (act >= 1 && act <= 3); };
     BGK_CHECK_ARG(act_ok(sA0, s_act) && act_ok(tA0, t_act), "%s: act: 1 SiLU, 2 ReLU, 3 Tanh", what);

@@ -1764,7 +1764,7 @@ def _affine_train_plan(transformer, y_dim, dev):
     if y_dim > 96 or n_in > T_OPERAND_MAX_IN or (periodic and n_in % 2):
         return None
     cache = transformer.__dict__.setdefault("_train_cache", {})
-    key = (y_dim, n_in, bool(periodic), str(dev), FUSED_FWD64,
+    key = (y_dim, n_in, bool(periodic), str(dev), FUSED_FWD64, FUSED_BWD64, TAIL_FUSED64, RECOMPUTE64,
            tuple(None if sp is None else (sp[0][0].out_features, sp[0][1].out_features, sp[1]) for sp in specs))
     if cache.get("key") != key:
         cache.clear()
@@ -1788,7 +1788,12 @@ def _affine_train_plan(transformer, y_dim, dev):
                                 tbufs=tb, version=None))
         # row pitch of the saved pre-activations / their gradients: [B, 64] when no hidden layer has more than 64 units (half the bytes)
         ldz = 64 if all(max(e["H0"], e["H1"]) <= 64 for e in entries if e is not None) else 128
-        cache.update(key=key, nets=entries, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), OT=OT, y_dim=y_dim, ldz=ldz, HT=HT)
+        # both networks inside the small kernels' envelope: the backward of a forward-direction layer without volume preservation is ONE
+        # library call (bgk_affine_coupling_backward64: the tail's backward inside the scale network's launch); with RECOMPUTE64 the forward
+        # saves nothing and that call recomputes the networks from the layer's inputs
+        tail_fused = bool(small and FUSED_BWD64 and TAIL_FUSED64 and all(e is not None for e in entries))
+        cache.update(key=key, nets=entries, d_c=n_in // 2 if periodic else n_in, periodic=bool(periodic), OT=OT, y_dim=y_dim, ldz=ldz, HT=HT,
+                     tail_fused=tail_fused, recompute=bool(tail_fused and RECOMPUTE64))
     lib = _lib.lib()
     for e in cache["nets"]:
         if e is None:
@@ -1923,6 +1928,10 @@ def _affine_net_backward(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, 
 
 FUSED_FWD64 = os.environ.get("BGK_FUSED_FWD64", "1") != "0"      # ... and their training forward on the kernel sized for them
 FUSED_BWD64 = os.environ.get("BGK_FUSED_BWD64", "1") != "0"      # networks of <= 64 hidden units: chain + weight gradients in one launch
+TAIL_FUSED64 = os.environ.get("BGK_TAIL_FUSED64", "1") != "0"    # ... with the affine tail's backward inside the scale network's launch (one call per layer)
+# ... and nothing saved by the forward, the backward recomputing both networks: 1.3 KB per sample and layer less memory, 7 % slower than
+# the saved form at cfg 2's shapes (profiles/r06_ab_runs.txt) -- opt-in
+RECOMPUTE64 = os.environ.get("BGK_RECOMPUTE64", "0") != "0"
 
 
 def _affine_net_backward64(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx, gx_buf, gx_add, need_w):
@@ -1973,9 +1982,19 @@ def _affine_train_forward(x, y, log_alpha, plan, cfg, dlogp=None, accumulate=Fal
     out = torch.empty((B, d), dtype=torch.float32, device=dev)
     if dlogp is None:
         dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=dev), False
-    zz = torch.empty((4, B + HALF_PAD_ROWS, plan["ldz"]), dtype=torch.float32, device=dev)[:, :B]
     ldms = 32 * plan["OT"]
-    ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
+    fused_bwd = plan.get("tail_fused") and not inverse and not pv
+    if fused_bwd and plan.get("recompute"):
+        zz = ms = None                    # nothing saved: bgk_affine_coupling_backward64 recomputes the networks
+        zp = [None] * 6
+    elif fused_bwd:                       # ... or reads z0 / z1 of both networks and s_raw (ms of ONE array marks this form); mu is not needed
+        zz = torch.empty((4, B + HALF_PAD_ROWS, plan["ldz"]), dtype=torch.float32, device=dev)[:, :B]
+        ms = torch.empty((1, B, ldms), dtype=torch.float32, device=dev)
+        zp = [_lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), None, _lib.ptr(ms[0])]
+    else:
+        zz = torch.empty((4, B + HALF_PAD_ROWS, plan["ldz"]), dtype=torch.float32, device=dev)[:, :B]
+        ms = torch.empty((2, B, ldms), dtype=torch.float32, device=dev)
+        zp = [_lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), _lib.ptr(ms[0]), _lib.ptr(ms[1])]
     ops = []
     for e in plan["nets"]:
         ops += [None, None, None, None, 0] if e is None else [_lib.ptr(e["A0"]), _lib.ptr(e["A1"]), _lib.ptr(e["A2"]), _lib.ptr(e["cs"]), e["act"]]
@@ -1985,15 +2004,14 @@ def _affine_train_forward(x, y, log_alpha, plan, cfg, dlogp=None, accumulate=Fal
             st = _lib.lib().bgk_coupling_affine_dense_fwd64_train(
                 _lib.ptr(x2), ldc, x2.shape[1], *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
                 _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)),
-                _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms, _lib.stream_ptr(dev))
+                *zp, ldms, _lib.stream_ptr(dev))
         else:
             what = "bgk_coupling_affine_dense_h2_train"
             ptrs, lds, widths, n, _keep = _lib.cond_segments([x2])
             st = _lib.lib().bgk_coupling_affine_dense_h2_train(
                 ptrs, lds, widths, n, int(plan["periodic"]), *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
                 _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)),
-                _lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), plan["ldz"], _lib.ptr(ms[0]), _lib.ptr(ms[1]), ldms,
-                _lib.stream_ptr(dev))
+                *zp[:4], plan["ldz"], *zp[4:], ldms, _lib.stream_ptr(dev))
     _lib.check(st, what)
     return out, dlogp, (x2, y2, zz, ms)
 
@@ -2007,6 +2025,8 @@ def _affine_train_backward(plan, cfg, versions, x2, y2, log_alpha, zz, ms, g_out
     es, et = plan["nets"]
     dev = y2.device
     B, d = y2.shape
+    if zz is None or ms.shape[0] == 1:
+        return _affine_train_backward_fused(plan, versions, x2, y2, zz, ms, log_alpha, g_out, g_dl, need_x, need_la, need_w, gx_add, gx_out)
     ldms = ms.shape[2]
     ldc = x2.stride(0) if B > 1 else x2.shape[1]
     g_out2, ldgo = _lib.rowmajor(g_out.reshape(B, d))
@@ -2036,6 +2056,59 @@ def _affine_train_backward(plan, cfg, versions, x2, y2, log_alpha, zz, ms, g_out
                                            need_w[6 * k:6 * k + 6], versions[k]))
         add = g_x                       # the second network adds to what the first wrote
     return g_x, g_y, (None if (la_direct or et is None or not need_la) else g_la), grads
+
+
+def _affine_train_backward_fused(plan, versions, x2, y2, zz, ms, log_alpha, g_out, g_dl, need_x, need_la, need_w, gx_add, gx_out):
+    """_affine_train_backward for a layer of plan["tail_fused"] (forward direction, no volume preservation): ONE library call,
+    bgk_affine_coupling_backward64 -- tail backward + both networks' backward; from the saved z0 / z1 / s_raw, or (zz is None: the
+    forward saved nothing) from x, y, g_out, g_dlogp alone."""
+    es, et = plan["nets"]
+    for e, v in zip((es, et), versions):
+        if e["version"] != v:
+            raise RuntimeError("fused affine coupling: the conditioner's parameters changed between the forward and this backward (the packed "
+                               "operands were rewritten); run the backward before the optimizer step, or call forward again")
+    dev = y2.device
+    B, d = y2.shape
+    n_in = es["lins"][0].in_features
+    lib = _lib.lib()
+    ldc = x2.stride(0) if B > 1 else x2.shape[1]
+    ldy = y2.stride(0) if B > 1 else d
+    g_out2, ldgo = _lib.rowmajor(g_out.reshape(B, d))
+    g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
+    g_x = (gx_out if gx_out is not None else torch.empty((B, plan["d_c"]), dtype=torch.float32, device=dev)) if need_x else None
+    add2, lda = (gx_add, gx_add.stride(0)) if (gx_add is not None and need_x) else (None, 0)
+    tb = es["tbufs"]
+    need_ws = int(lib.bgk_affine_coupling_backward64_workspace(B, d, n_in, es["H1"], es["H0"], et["H1"], et["H0"]))
+    ws = tb.get("bwd64r_ws")
+    if ws is None or ws.numel() < need_ws or ws.device != dev:
+        ws = tb["bwd64r_ws"] = torch.empty(need_ws, dtype=torch.float32, device=dev)
+    params = [p for e in (es, et) for lin in e["lins"] for p in (lin.weight, lin.bias)]            # W0, b0, W1, b1, W2, b2 per network
+    bucket = lambda p: (getattr(p, "_bgk_grad_dst", None) is not None and p.grad is not None                    # noqa: E731
+                        and p.grad.data_ptr() == p._bgk_grad_dst.data_ptr())
+    direct = _DIRECT_GRADS[0] and all(need_w) and all(bucket(p) for p in params) and (not need_la or bucket(log_alpha))
+    if direct:
+        outs = [p._bgk_grad_dst for p in params]
+        g_la = log_alpha._bgk_grad_dst if need_la else torch.empty((1,), dtype=torch.float32, device=dev)
+    else:
+        outs = [torch.empty_like(p, dtype=torch.float32) if nd else None for p, nd in zip(params, need_w)]
+        g_la = torch.empty((1,), dtype=torch.float32, device=dev)
+    if direct and not need_la:
+        g_la = torch.zeros((1,), dtype=torch.float32, device=dev)       # (accumulate = 1 adds into it; the value is dropped)
+    saved = [None] * 5 + [0] if zz is None else [_lib.ptr(zz[0]), _lib.ptr(zz[1]), _lib.ptr(zz[2]), _lib.ptr(zz[3]), _lib.ptr(ms[0]), ms.shape[2]]
+    arr = lambda six: (ctypes.c_void_p * 6)(*[None if six[i] is None else six[i].data_ptr() for i in (4, 5, 2, 3, 0, 1)])      # noqa: E731  -> gW2, gb2, gW1, gb1, gW0, gb0
+    s_arr, t_arr = arr(outs[:6]), arr(outs[6:])
+    with torch.cuda.device(dev):
+        st = lib.bgk_affine_coupling_backward64(
+            _lib.ptr(x2), ldc, n_in, _lib.ptr(y2), ldy, d, _lib.ptr(g_out2), ldgo, _lib.ptr(g_dl), *saved,
+            _lib.ptr(es["A0"]), _lib.ptr(es["A1"]), _lib.ptr(es["tbufs"]["T0"]), _lib.ptr(es["tbufs"]["T1"]), _lib.ptr(es["tbufs"]["T2"]),
+            _lib.ptr(es["cs"]), es["act"], es["H1"], es["H0"],
+            _lib.ptr(et["A0"]), _lib.ptr(et["A1"]), _lib.ptr(et["A2"]), _lib.ptr(et["tbufs"]["T0"]), _lib.ptr(et["tbufs"]["T1"]), _lib.ptr(et["tbufs"]["T2"]),
+            _lib.ptr(et["cs"]), et["act"], et["H1"], et["H0"],
+            _lib.ptr(log_alpha.detach()), B, _lib.ptr(g_y), d, _lib.ptr(g_x) if need_x else None, g_x.stride(0) if need_x else n_in, _lib.ptr(add2), lda,
+            _lib.ptr(g_la), _lib.ptr(ws), ws.numel(), s_arr, t_arr, int(direct), _lib.stream_ptr(dev))
+    _lib.check(st, "bgk_affine_coupling_backward64")
+    grads = [None] * 12 if direct else outs
+    return g_x, g_y, (None if (direct or not need_la) else g_la), grads
 
 
 class _FusedAffineTrainFn(torch.autograd.Function):

@@ -700,7 +700,9 @@ int bgk_mlp_weight_grad_reduce_many(int32_t n, const int64_t* B, const int32_t* 
  * d <= 32 transformed dims and ONE non-periodic conditioning tensor of n_in <= 32 columns (BASELINE cfg 2's couplings,
  * nn/flow/transformer/affine.py:35-70 with DenseNet([32, 64, 64, 32]) networks) on a kernel sized for them: operands packed for 64
  * hidden rows (bgk_pack_mlp_h2 with HT = 2, NT2 = 1) resident in LDS, three waves per SIMD; z0 / z1 [B, 64] contiguous, mu / s_raw
- * [B, ldms].  Same outputs, bit for bit (same products in the same order).  BGK_EUNSUPPORTED outside the envelope. */
+ * [B, ldms].  Same outputs, bit for bit (same products in the same order).  BGK_EUNSUPPORTED outside the envelope.
+ * mu NULL: the shift values are not saved (bgk_affine_coupling_backward64 does not read them); all six save pointers NULL: nothing is
+ * written for the backward (bgk_affine_coupling_backward64 recomputes the networks). */
 int bgk_coupling_affine_dense_fwd64_train(const float* cond, int64_t ldc, int32_t n_in,
                                           const void* sA0, const void* sA1, const void* sA2, const float* s_cs, int32_t s_act,
                                           const void* tA0, const void* tA1, const void* tA2, const float* t_cs, int32_t t_act,
@@ -729,6 +731,32 @@ int bgk_affine_net_backward64(const float* g, int64_t ldg, int32_t d, const floa
                               float* workspace, int64_t workspace_floats,
                               float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
                               void* stream);
+
+/* bgk_affine_coupling_backward64 (round 6): the WHOLE backward of a forward-direction affine coupling (no volume preservation) with two
+ * networks inside bgk_affine_net_backward64's envelope in two launches (+ their reductions).  The scale network's launch forms
+ * g_y = g_out e^s and g_s_raw = (g_out e^s y + g_dlogp) alpha (1 - tanh^2 s_raw) on chip (bgk_affine_backward's arithmetic: that launch,
+ * its g_mu / g_s arrays and its atomics do not exist) and runs the network's backward; the shift network's takes g_mu = g_out as it is.
+ *   s_z0, s_z1, t_z0, t_z1 [B, 64], s_raw [B, lds]: what bgk_coupling_affine_dense_fwd64_train saved (mu is not needed) -- or ALL FIVE
+ *   NULL: nothing was saved (that entry point with NULL save pointers), every wave recomputes the networks' forward on its tile (the
+ *   forward's products in the forward's order).  HBM per sample and layer for BASELINE cfg 2, forward included: 4.4 KB with
+ *   bgk_affine_backward + 2 x bgk_affine_net_backward64, 3.3 KB here with the saved arrays, 1.6 KB with recomputation.  Autograd of
+ * nn/flow/transformer/affine.py:35-70 + nn/dense.py:30-48 + nn/flow/coupling.py:152-182 under loss.backward().
+ *   sA0, sA1 / tA0, tA1, tA2: forward operands of bgk_pack_mlp_h2 (HT = 2); sT* / tT*: transposed operands of bgk_pack_mlp_h2_t; *_cs: scale tables
+ *   g_y [B, d] written; g_cond (may be NULL) = both networks' conditioner-input gradients + g_cond_add; g_log_alpha: float[1]
+ *   s_grads / t_grads: HOST arrays of six device pointers (gW2, gb2, gW1, gb1, gW0, gb0; NULL: not wanted); accumulate = 1: added to
+ *   (the weight gradients and g_log_alpha alike).  Deterministic (fixed-order partial sums, no atomics). */
+int64_t bgk_affine_coupling_backward64_workspace(int64_t B, int32_t d, int32_t n_in, int32_t sH1, int32_t sH0, int32_t tH1, int32_t tH0);
+int bgk_affine_coupling_backward64(const float* cond, int64_t ldc, int32_t n_in, const float* y, int64_t ldy, int32_t d,
+                                   const float* g_out, int64_t ldgo, const float* g_dlogp,
+                                   const float* s_z0, const float* s_z1, const float* t_z0, const float* t_z1, const float* s_raw, int64_t lds,
+                                   const void* sA0, const void* sA1, const void* sT0, const void* sT1, const void* sT2,
+                                   const float* s_cs, int32_t s_act, int32_t sH1, int32_t sH0,
+                                   const void* tA0, const void* tA1, const void* tA2, const void* tT0, const void* tT1, const void* tT2,
+                                   const float* t_cs, int32_t t_act, int32_t tH1, int32_t tH0,
+                                   const float* log_alpha, int64_t B,
+                                   float* g_y, int64_t ldgy, float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                                   float* g_log_alpha, float* workspace, int64_t workspace_floats,
+                                   float* const* s_grads, float* const* t_grads, int32_t accumulate, void* stream);
 
 /* bgk_linear_weight_grad (round 6): ONE Linear layer of any width -- gW [n, k] = g^T h (row-major, contiguous), gb [n] = sum_rows g
  * (may be NULL) for g [B, n], h [B, k]: autograd of nn/dense.py:47-48 for a Linear outside the fused training envelopes (conditioners

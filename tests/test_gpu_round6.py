@@ -393,6 +393,63 @@ def test_small_network_kernels_equal_the_general_path(hip_lib, dev):
     assert rel <= 2e-6, (rel, worst)
 
 
+@pytest.mark.parametrize("shape", [(32, 32, (64, 64), ("ReLU", "Tanh")), (24, 20, (48, 64), ("SiLU", "SiLU")), (7, 5, (64, 33), ("Tanh", "Tanh"))])
+def test_one_call_backward_variants_of_the_small_couplings(hip_lib, dev, shape):
+    """A forward-direction coupling of cfg 2's class (both networks <= 64 units) has three backward forms: bgk_affine_backward + one
+    bgk_affine_net_backward64 per network (dense.TAIL_FUSED64 = False: the form the round started with), ONE bgk_affine_coupling_backward64
+    on the saved pre-activations (default: the tail's backward inside the scale network's launch, no g_mu / g_s arrays, no atomics), and
+    the same call with NOTHING saved (dense.RECOMPUTE64 = True: every wave recomputes the networks on its tile).  Same forward values
+    bit for bit; gradients equal to accumulation-order noise and each within 2e-6 of f64 autograd of the reference's op chain
+    (oracle/torch_flow.py; nn/flow/transformer/affine.py:35-70, nn/dense.py:30-48); partial tiles, d and n_in below 32, a frozen
+    parameter, a conditioner input that needs no gradient."""
+    from bgflow_amd import dense
+    n_c, d, hidden, acts = shape
+    flow = _affine_layer(n_c, hidden, d, tuple(getattr(torch.nn, a) for a in acts)).to(dev)
+    names = [n for n, _ in flow.named_parameters()]
+    dict(flow.named_parameters())[[n for n in names if n.endswith("bias")][1]].requires_grad_(False)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x0, y0 = torch.randn(1000 + d, n_c, device=dev, generator=g), torch.randn(1000 + d, d, device=dev, generator=g)
+    w = torch.randn(1000 + d, d, device=dev, generator=g)
+
+    def run(need_x):
+        for p in flow.parameters():
+            p.grad = None
+        x, y = x0.clone().requires_grad_(need_x), y0.clone().requires_grad_(True)
+        _, out, dl = flow(x, y)
+        ((out * w).mean() - 0.3 * dl.mean() + out.square().mean()).backward()
+        return (out.detach(), dl.detach(), y.grad.clone(), x.grad.clone() if need_x else None,
+                {n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None})
+    res = {}
+    try:
+        for mode in ("separate", "one call", "recompute"):
+            dense.TAIL_FUSED64, dense.RECOMPUTE64 = mode != "separate", mode == "recompute"
+            res[mode] = [run(True), run(False)]
+            cache = flow[0].transformer._train_cache
+            assert cache["HT"] == 2 and cache["tail_fused"] == (mode != "separate") and cache["recompute"] == (mode == "recompute")
+    finally:
+        dense.TAIL_FUSED64, dense.RECOMPUTE64 = True, False
+    # f64 reference
+    flow64 = _affine_layer(n_c, hidden, d, tuple(getattr(torch.nn, a) for a in acts)).double()
+    x, y = x0.cpu().double().requires_grad_(True), y0.cpu().double().requires_grad_(True)
+    from oracle import torch_flow as tfl
+    outs64, dl64 = tfl.run_flow(flow64, [x, y], inverse=False, grad=True)
+    out64 = outs64[1]
+    ((out64 * w.cpu().double()).mean() - 0.3 * dl64.mean() + out64.square().mean()).backward()
+    ref = {n: p.grad for n, p in flow64.named_parameters()}
+    for mode, (with_x, without_x) in res.items():
+        assert torch.equal(with_x[0], res["separate"][0][0]) and torch.equal(with_x[1], res["separate"][0][1]), mode
+        assert with_x[4].keys() == res["separate"][0][4].keys() and len(with_x[4]) == 12
+        for got in (with_x, without_x):
+            assert float((got[2].cpu().double() - y.grad).norm() / y.grad.norm()) <= 2e-6, mode
+            flat_g = torch.cat([got[4][n].reshape(-1).cpu().double() for n in got[4]])
+            flat_r = torch.cat([ref[n].reshape(-1) for n in got[4]])
+            rel = float((flat_g - flat_r).norm() / flat_r.norm())
+            assert rel <= 2e-6, (mode, rel)
+        assert float((with_x[3].cpu().double() - x.grad).norm() / x.grad.norm()) <= 2e-6, mode
+        assert without_x[3] is None
+    print("one-call backward variants agree for", shape)
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("n_blocks", [8, 3])
 def test_coupling_stack_as_one_autograd_node_equals_the_blocks(hip_lib, dev, inverse, n_blocks):
