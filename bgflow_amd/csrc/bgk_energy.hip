@@ -11,7 +11,8 @@
  *
  * Roofline: HBM, 4 (sum_f d_f + 1) B per sample forward, 4 (2 sum_f d_f + 1) B backward.  Rows of a tile are staged coalesced
  * through LDS (odd stride) in column chunks of 96 (any width fits), one lane per row adds its terms in ascending column order
- * (deterministic). */
+ * (deterministic).  Rows that are multiples of 4 wide at 16-byte aligned addresses take the float4 kernels (energy_rows4_kernel, round 6:
+ * L lanes per row, fixed xor tree); BGK_ENERGY_STAGED=1 keeps the staging kernels for every shape (the A/B). */
 #include "bgk_common.h"
 
 namespace {
@@ -105,6 +106,60 @@ __global__ __launch_bounds__(NE_THREADS) void energy_fields_kernel(EArgs a) {
     }
 }
 
+/* Rows of widths that are multiples of 4 at 16-byte aligned addresses (round 6; cfg 2's DoubleWellEnergy(64) at 2^20 samples ran the
+ * staging kernel above at 1 TB/s: 0.26 ms for 268 MB): a row belongs to L = 2^k >= d / 4 consecutive lanes, every lane reads ONE float4
+ * of the row (a wave instruction = 64 / L whole rows, consecutive in memory), adds its four terms in ascending order and the lanes of
+ * the row combine through a fixed xor tree -- no LDS, no division, deterministic.  Same terms as above (the first column of a double
+ * well apart, 0.5 x the rest). */
+__global__ __launch_bounds__(NE_THREADS) void energy_rows4_kernel(EArgs a, int L) {
+    __shared__ float s_red[2 * NE_THREADS];
+    const eargs_t ka = (eargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const int tid = threadIdx.x, l = tid & (L - 1), grp = tid / L, rpb = NE_THREADS / L;
+    float bsum = 0.0f, bcnt = 0.0f;
+    for (int64_t row = (int64_t)blockIdx.x * rpb + grp; row < a.B; row += (int64_t)gridDim.x * rpb) {
+        float e = 0.0f;
+        for (int fi = 0; fi < a.n; ++fi) {
+            const int kind = ka->f[fi].kind, d = ka->f[fi].d;
+            if (kind == 2) { e += ka->f[fi].a; continue; }
+            float part = 0.0f;
+            if (4 * l < d) {
+                const float4 v = *reinterpret_cast<const float4*>(ka->f[fi].x + row * ka->f[fi].ldx + 4 * l);
+                if (kind == 0) {
+                    const float* mean = ka->f[fi].p;
+                    const float4 m = mean ? *reinterpret_cast<const float4*>(mean + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float t0 = v.x - m.x, t1 = v.y - m.y, t2 = v.z - m.z, t3 = v.w - m.w;
+                    part = 0.5f * (((t0 * t0 + t1 * t1) + t2 * t2) + t3 * t3);
+                } else {
+                    const float v2 = v.x * v.x;
+                    const float first = l == 0 ? (ka->f[fi].a * v.x + ka->f[fi].b * v2) + ka->f[fi].c * (v2 * v2) : 0.5f * v2;
+                    part = first + 0.5f * ((v.y * v.y + v.z * v.z) + v.w * v.w);
+                }
+            }
+            for (int off = L >> 1; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            e += part;
+        }
+        if (l == 0) {
+            const float u = (e + a.c_in) * a.inv_t + a.c_out;
+            a.u[row] = u;
+            if (a.partial) {
+                const float loss = u - a.dlogp[row];
+                const bool ok = !a.drop_nonfinite || __builtin_isfinite(loss);
+                bsum += ok ? loss : 0.0f;
+                bcnt += ok ? 1.0f : 0.0f;
+            }
+        }
+    }
+    if (a.partial) {                   /* block partial: fixed order over the row lanes */
+        s_red[tid] = bsum; s_red[NE_THREADS + tid] = bcnt;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.0f, c = 0.0f;
+            for (int i = 0; i < NE_THREADS; i += L) { s += s_red[i]; c += s_red[NE_THREADS + i]; }
+            a.partial[2 * blockIdx.x] = s; a.partial[2 * blockIdx.x + 1] = c;
+        }
+    }
+}
+
 /* out[0] = sum of the block sums, out[1] = sum of the block counts, both in double and in a fixed order (deterministic): lane t adds
  * the blocks t, t + 64, ... in ascending order, lane 0 then adds the 64 lane sums in ascending order.  (One lane walking all ~2000
  * partials through dependent global loads took 0.13 ms.) */
@@ -161,6 +216,51 @@ __global__ __launch_bounds__(NE_THREADS) void energy_fields_bwd_kernel(EBwdArgs 
     }
 }
 
+/* the float4 form of the backward for the same class of rows (see energy_rows4_kernel): a row = L lanes, no division per element */
+__global__ __launch_bounds__(NE_THREADS) void energy_rows4_bwd_kernel(EBwdArgs a, int L) {
+    const ebargs_t ka = (ebargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const float gs = a.g_scalar ? a.g_scalar[0] : 0.0f;
+    const int tid = threadIdx.x, l = tid & (L - 1), grp = tid / L, rpb = NE_THREADS / L;
+    for (int64_t row = (int64_t)blockIdx.x * rpb + grp; row < a.B; row += (int64_t)gridDim.x * rpb) {
+        float gr;
+        if (a.g_u) gr = a.g_u[row];
+        else gr = (!a.drop_nonfinite || __builtin_isfinite(a.u[row] - a.dlogp[row])) ? gs : 0.0f;
+        if (a.g_dlogp && l == 0) a.g_dlogp[row] = -gr;
+        for (int fi = 0; fi < a.n; ++fi) {
+            const int kind = ka->f[fi].kind, d = ka->f[fi].d;
+            float* g_x = ka->f[fi].g_x;
+            if (kind == 2 || !g_x || 4 * l >= d) continue;
+            const float4 v = *reinterpret_cast<const float4*>(ka->f[fi].x + row * ka->f[fi].ldx + 4 * l);
+            float4 de;
+            if (kind == 0) {
+                const float* mean = ka->f[fi].p;
+                const float4 m = mean ? *reinterpret_cast<const float4*>(mean + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+                de = make_float4(v.x - m.x, v.y - m.y, v.z - m.z, v.w - m.w);
+            } else {
+                de = v;
+                if (l == 0) de.x = ka->f[fi].a + 2.0f * ka->f[fi].b * v.x + 4.0f * ka->f[fi].c * (v.x * v.x * v.x);
+            }
+            *reinterpret_cast<float4*>(g_x + row * ka->f[fi].ldg + 4 * l) =
+                make_float4(gr * de.x * a.inv_t, gr * de.y * a.inv_t, gr * de.z * a.inv_t, gr * de.w * a.inv_t);
+        }
+    }
+}
+
+/* lanes per row of the float4 kernels for these fields (a power of two, <= 64), or 0: some field is not a multiple of 4 wide / wider
+ * than 256 / off 16-byte boundaries */
+template <typename F>
+int rows4_lanes(const F* f, int n, const float* const* g_x, const int64_t* ldg) {
+    int L = 1;
+    const auto al = [](const void* p, int64_t ld) { return ((uintptr_t)p & 15) == 0 && ld % 4 == 0; };
+    for (int i = 0; i < n; ++i) {
+        if (f[i].kind == 2) continue;
+        if (f[i].d % 4 != 0 || f[i].d > 256 || !al(f[i].x, f[i].ldx) || (f[i].kind == 0 && f[i].p && ((uintptr_t)f[i].p & 15) != 0)) return 0;
+        if (g_x && g_x[i] && !al(g_x[i], ldg[i])) return 0;
+        while (4 * L < f[i].d) L <<= 1;
+    }
+    return L;
+}
+
 int fill_fields(const char* what, EField* f, int32_t n_fields, const float* const* x, const int64_t* ldx, const int32_t* d, const int32_t* kind,
                 const float* const* param, const float* coef) {
     BGK_CHECK_ARG(n_fields >= 1 && n_fields <= NE_MAXF && x && ldx && d && kind, "%s: 1..%d fields", what, NE_MAXF);
@@ -196,10 +296,12 @@ extern "C" int bgk_energy_fields(const float* const* x, const int64_t* ldx, cons
     if (st) return st;
     a.n = n_fields; a.B = B; a.inv_t = (float)(1.0 / temperature); a.c_in = (float)c_in; a.c_out = (float)c_out; a.u = u;
     a.dlogp = loss_sums ? dlogp : nullptr; a.drop_nonfinite = drop_nonfinite; a.partial = loss_sums ? partial : nullptr;
-    const int64_t n_tiles = (B + NE_ROWS - 1) / NE_ROWS;
+    const int L = getenv("BGK_ENERGY_STAGED") ? 0 : rows4_lanes(a.f, n_fields, (const float* const*)nullptr, (const int64_t*)nullptr);
+    const int64_t n_tiles = L ? (B + NE_THREADS / L - 1) / (NE_THREADS / L) : (B + NE_ROWS - 1) / NE_ROWS;
     int grid = (int)(n_tiles < 256 * 8 ? n_tiles : 256 * 8);
     if (loss_sums && grid > nblk) grid = nblk;
-    hipLaunchKernelGGL(energy_fields_kernel, dim3(grid), dim3(NE_THREADS), 0, s, a);
+    if (L) hipLaunchKernelGGL(energy_rows4_kernel, dim3(grid), dim3(NE_THREADS), 0, s, a, L);
+    else hipLaunchKernelGGL(energy_fields_kernel, dim3(grid), dim3(NE_THREADS), 0, s, a);
     if (loss_sums) hipLaunchKernelGGL(energy_partial_reduce_kernel, dim3(1), dim3(64), 0, s, partial, grid, loss_sums);
     return bgk_launch_status("bgk_energy_fields");
 }
@@ -230,6 +332,13 @@ extern "C" int bgk_energy_fields_backward(const float* const* x, const int64_t* 
     }
     a.n = n_fields; a.B = B; a.inv_t = (float)(1.0 / temperature);
     a.g_u = g_u; a.g_scalar = g_scalar; a.u = u; a.dlogp = dlogp; a.drop_nonfinite = drop_nonfinite; a.g_dlogp = g_dlogp;
+    const int L = getenv("BGK_ENERGY_STAGED") ? 0 : rows4_lanes(tmp, n_fields, (const float* const*)g_x, ldg);
+    if (L) {
+        const int64_t blocks = (B + NE_THREADS / L - 1) / (NE_THREADS / L);
+        const int grid = (int)(blocks < 256 * 16 ? blocks : 256 * 16);
+        hipLaunchKernelGGL(energy_rows4_bwd_kernel, dim3(grid), dim3(NE_THREADS), 0, (hipStream_t)stream, a, L);
+        return bgk_launch_status("bgk_energy_fields_backward");
+    }
     const int64_t blocks = (total + NE_THREADS * 4 - 1) / (NE_THREADS * 4);
     const int grid = (int)(blocks < 256 * 16 ? (blocks < 1 ? 1 : blocks) : 256 * 16);
     hipLaunchKernelGGL(energy_fields_bwd_kernel, dim3(grid), dim3(NE_THREADS), 0, (hipStream_t)stream, a);

@@ -551,3 +551,47 @@ def test_layer_kernel_scales_every_sample_by_itself(hip_lib, dev):
     for r in (0, 15, 31):
         alone = dense.dense_layer(x[r:r + 1].to(dev), lin).cpu()
         assert torch.equal(alone[0], y[r]), f"row {r}: its output depends on the rows it shares a tile with"
+
+
+@pytest.mark.parametrize("B", [1, 37, 4133])
+def test_energy_float4_rows_equal_the_staging_kernels(hip_lib, dev, B):
+    """bgk_energy_fields(_backward) on rows that are multiples of 4 wide at 16-byte aligned addresses take the float4 kernels (round 6:
+    L lanes per row, fixed xor tree; cfg 2's DoubleWellEnergy(64) at 2^20 samples: 0.26 -> see profiles/r06_ab_runs.txt);
+    BGK_ENERGY_STAGED=1 keeps the staging kernels.  Same terms in another summation order: energies within 2e-6 of each other and of
+    the f64 value, the KL loss sums and the gradients likewise -- DoubleWellEnergy(64) (distribution/energy/double_well.py:17-22),
+    NormalDistribution(8) with a mean (distribution/normal.py:61-72), their product with a uniform component (product.py:13-117),
+    a row view of a wider tensor."""
+    import os
+    import bgflow_amd as bg
+    g = torch.Generator().manual_seed(B)
+    wide = torch.randn(B, 96, generator=g)
+    cases = {
+        "double well 64": (bg.DoubleWellEnergy(64, a=0.3, b=-2.0, c=0.7), [torch.randn(B, 64, generator=g)]),
+        "normal 8": (bg.NormalDistribution(8, mean=torch.randn(8, generator=g)), [torch.randn(B, 8, generator=g)]),
+        "row view": (bg.NormalDistribution(32), [wide[:, 32:64]]),
+        "product": (bg.ProductDistribution([bg.NormalDistribution(64, mean=torch.randn(64, generator=g)), bg.DoubleWellEnergy(32),
+                                            bg.UniformDistribution(torch.zeros(5), 2.0 * torch.ones(5))]),
+                    [torch.randn(B, 64, generator=g), torch.randn(B, 32, generator=g), 2.0 * torch.rand(B, 5, generator=g)]),
+    }
+    for name, (dist, xs) in cases.items():
+        dist = dist.to(dev)
+        res = {}
+        try:
+            for mode in ("float4", "staged"):
+                if mode == "staged":
+                    os.environ["BGK_ENERGY_STAGED"] = "1"
+                xg = [x.to(dev).requires_grad_(True) for x in xs]
+                u = dist.energy(*xg, temperature=1.3)
+                (u * torch.linspace(0.5, 1.5, B, device=dev)[:, None]).sum().backward()
+                res[mode] = (u.detach().cpu(), [x.grad.cpu() if x.grad is not None else torch.zeros(x.shape) for x in xg])
+        finally:
+            os.environ.pop("BGK_ENERGY_STAGED", None)
+        x64 = [x.double().requires_grad_(True) for x in xs]
+        u64 = dist.cpu().double().energy(*x64, temperature=1.3)
+        (u64 * torch.linspace(0.5, 1.5, B, dtype=torch.float64)[:, None]).sum().backward()
+        for mode in res:
+            scale = u64.abs().clamp_min(1.0)
+            assert float(((res[mode][0].double() - u64.detach()).abs() / scale).max()) <= 2e-6, (name, mode)
+            for a, b in zip(res[mode][1], x64):
+                want = b.grad if b.grad is not None else torch.zeros_like(b)          # (a uniform component's energy does not depend on x)
+                assert float((a.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (name, mode)
