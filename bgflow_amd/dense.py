@@ -1971,15 +1971,18 @@ def _affine_net_backward64(e, plan, g_net, ldg, z1, z0, x2, ldc, absmax, want_gx
     return gW0, gb0, gW1, gb1, gW2, gb2
 
 
-def _affine_train_forward(x, y, log_alpha, plan, cfg, dlogp=None, accumulate=False):
+def _affine_train_forward(x, y, log_alpha, plan, cfg, dlogp=None, accumulate=False, out=None):
     """one training-forward launch of an affine coupling: (out [B, d], dlogp [B], saved = (x2, y2, zz, ms)).  ``dlogp`` / ``accumulate``:
-    the layer's log-det written (or added) into the caller's [B] buffer -- the running log|det J| of a stack of layers"""
+    the layer's log-det written (or added) into the caller's [B] buffer -- the running log|det J| of a stack of layers; ``out``: where
+    the transformed half goes ([B, d] rows of any stride: a column range of the stack's output tensor)"""
     pv, circ, inverse = cfg
     dev = y.device
     x2, ldc = _lib.rowmajor(x.detach())
     y2, ldy = _lib.rowmajor(y.detach())
     B, d = y2.shape
-    out = torch.empty((B, d), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((B, d), dtype=torch.float32, device=dev)
+    ldo = out.stride(0) if B > 1 else d
     if dlogp is None:
         dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=dev), False
     ldms = 32 * plan["OT"]
@@ -2003,14 +2006,14 @@ def _affine_train_forward(x, y, log_alpha, plan, cfg, dlogp=None, accumulate=Fal
             what = "bgk_coupling_affine_dense_fwd64_train"
             st = _lib.lib().bgk_coupling_affine_dense_fwd64_train(
                 _lib.ptr(x2), ldc, x2.shape[1], *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
-                _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)),
+                _lib.ptr(y2), ldy, B, d, _lib.ptr(out), ldo, _lib.ptr(dlogp), int(bool(accumulate)),
                 *zp, ldms, _lib.stream_ptr(dev))
         else:
             what = "bgk_coupling_affine_dense_h2_train"
             ptrs, lds, widths, n, _keep = _lib.cond_segments([x2])
             st = _lib.lib().bgk_coupling_affine_dense_h2_train(
                 ptrs, lds, widths, n, int(plan["periodic"]), *ops, _lib.ptr(log_alpha.detach()), int(pv), int(circ), int(inverse),
-                _lib.ptr(y2), ldy, B, d, _lib.ptr(out), d, _lib.ptr(dlogp), int(bool(accumulate)),
+                _lib.ptr(y2), ldy, B, d, _lib.ptr(out), ldo, _lib.ptr(dlogp), int(bool(accumulate)),
                 *zp[:4], plan["ldz"], *zp[4:], ldms, _lib.stream_ptr(dev))
     _lib.check(st, what)
     return out, dlogp, (x2, y2, zz, ms)
@@ -2141,32 +2144,39 @@ class _AffineStackTrainFn(torch.autograd.Function):
     backward kernels (g_cond_add), so the sums autograd would form with one elementwise launch per layer (a half conditions one layer
     and is transformed by the next) do not exist.
 
-    apply(layers, x [B, D], *per layer (log_alpha, 12 network parameters)); ``layers[i]`` = (transformed part 0 | 1, plan, cfg).
+    apply(layers, cols, out_cols, x [B, D], *per layer (log_alpha, 12 network parameters)); ``layers[i]`` = (transformed part 0 | 1, plan,
+    cfg); ``cols`` / ``out_cols``: the column ranges of the two halves in x / in the result (exchanged after an odd number of swaps).
     Returns (out [B, D] with the parts in slot order, dlogp [B, 1])."""
 
     @staticmethod
-    def forward(ctx, layers, cols, x, *tensors):
+    def forward(ctx, layers, cols, out_cols, x, *tensors):
         B = x.shape[0]
         part = [x[:, cols[0]], x[:, cols[1]]]
         saved, dlogp = [], None
+        # the last layer that transforms a half writes it straight into its columns of the result (no torch.cat at the end)
+        last = {py: i for i, (py, _, _) in enumerate(layers)}
+        final = torch.empty_like(x) if len(last) == 2 else None
         for i, (py, plan, cfg) in enumerate(layers):
             log_alpha = tensors[13 * i]
-            out, dlogp, (x2, y2, zz, ms) = _affine_train_forward(part[1 - py], part[py], log_alpha, plan, cfg, dlogp=dlogp, accumulate=i > 0)
+            dst = final[:, out_cols[py]] if (final is not None and last[py] == i) else None
+            out, dlogp, (x2, y2, zz, ms) = _affine_train_forward(part[1 - py], part[py], log_alpha, plan, cfg, dlogp=dlogp, accumulate=i > 0, out=dst)
             saved += [x2, y2, log_alpha, zz, ms]
             part[py] = out
         ctx.save_for_backward(*saved)
         ctx.layers = layers
         ctx.versions = [[None if e is None else e["version"] for e in plan["nets"]] for _, plan, _ in layers]
-        ctx.widths = (part[0].shape[1], part[1].shape[1])
-        return torch.cat(part, dim=1), dlogp[:, None]
+        ctx.out_cols = out_cols
+        if final is None:                            # a half no layer transforms: assemble the result from the parts
+            final = torch.empty_like(x)
+            final[:, out_cols[0]], final[:, out_cols[1]] = part[0], part[1]
+        return final, dlogp[:, None]
 
     @staticmethod
     def backward(ctx, g_out, g_dlogp):
         saved = ctx.saved_tensors
         need = ctx.needs_input_grad
-        w0, w1 = ctx.widths
         g_out = g_out.contiguous()
-        G = [g_out[:, :w0], g_out[:, w0:]]          # gradient w.r.t. the CURRENT state of each half, walking the layers backwards
+        G = [g_out[:, ctx.out_cols[0]], g_out[:, ctx.out_cols[1]]]          # gradient w.r.t. the CURRENT state of each half, walking the layers backwards
         owned = [False, False]                       # buffers of this backward (may be added to in place)
         g_dl = g_dlogp.reshape(-1).contiguous()
         L = len(ctx.layers)
@@ -2175,13 +2185,13 @@ class _AffineStackTrainFn(torch.autograd.Function):
             py, plan, cfg = ctx.layers[i]
             pc = 1 - py
             x2, y2, log_alpha, zz, ms = saved[5 * i:5 * i + 5]
-            nd = need[3 + 13 * i:3 + 13 * i + 13]
+            nd = need[4 + 13 * i:4 + 13 * i + 13]
             prev = G[pc]
             if not owned[pc]:                        # autograd's tensor (a view of g_out): never written -- the sum goes to a fresh buffer
                 gx_out = None
             else:
                 gx_out = prev
-            want_gx = i > 0 or bool(need[2])          # (the first layer's conditioner-input gradient only matters to the stack's input)
+            want_gx = i > 0 or bool(need[3])          # (the first layer's conditioner-input gradient only matters to the stack's input)
             g_x, g_y, g_la, gws = _affine_train_backward(plan, cfg, ctx.versions[i], x2, y2, log_alpha, zz, ms, G[py], g_dl, want_gx, bool(nd[0]),
                                                          nd[1:13], gx_add=prev, gx_out=gx_out)
             G[py], owned[py] = g_y, True
@@ -2189,8 +2199,8 @@ class _AffineStackTrainFn(torch.autograd.Function):
                 G[pc], owned[pc] = g_x, True
             grads[13 * i] = g_la
             grads[13 * i + 1:13 * i + 13] = gws
-        g_in = torch.cat(G, dim=1) if need[2] else None
-        return (None, None, g_in, *grads)
+        g_in = torch.cat(G, dim=1) if need[3] else None
+        return (None, None, None, g_in, *grads)
 
 
 def affine_stack_train(blocks, x, inverse):
@@ -2232,9 +2242,9 @@ def affine_stack_train(blocks, x, inverse):
     if not (closing._sizes[0] == widths[part[0]] and (len(closing._sizes) == 1 or closing._sizes[1] == widths[part[1]])):
         return None
     cols = (slice(0, s0), slice(s0, D))
-    out, dlogp = _AffineStackTrainFn.apply(layers, cols, x, *tensors)
-    if part != [0, 1]:                              # odd number of swaps: the merge concatenates (half 1, half 0)
-        out = torch.cat([out[:, s0:], out[:, :s0]], dim=1)
+    # where the halves sit in the result: an odd number of swaps makes the merge concatenate (half 1, half 0)
+    out_cols = cols if part == [0, 1] else (slice(D - s0, D), slice(0, D - s0))
+    out, dlogp = _AffineStackTrainFn.apply(layers, cols, out_cols, x, *tensors)
     return out, dlogp
 
 
