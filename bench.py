@@ -208,9 +208,10 @@ def kl_side_leg(name, dev, batch, steps):
                loss=float(last[0].detach()), skipped_steps=opt.skipped_steps(),
                note="affine couplings: one-launch training forward (both conditioner networks on the f16 matrix cores + the affine tail; saves the "
                     "hidden layers' pre-activations and the networks' outputs: bgk_coupling_affine_dense_fwd64_train for cfg 2's 64-unit networks, "
-                    "bgk_coupling_affine_dense_h2_train for cfg 5's 128-unit ones); backward = bgk_affine_backward + per network "
-                    "bgk_affine_net_backward64 (cfg 2: input-gradient chain and weight gradients in one launch, g_z on chip) or "
-                    "bgk_mlp_backward_dx + bgk_mlp_weight_grad (cfg 5); no library GEMM, no aten activation kernel in the step")
+                    "bgk_coupling_affine_dense_h2_train for cfg 5's 128-unit ones); backward: cfg 2 -- ONE call per coupling, "
+                    "bgk_affine_coupling_backward64 (the tail's backward inside the scale network's launch; per network the input-gradient "
+                    "chain and the weight gradients in one launch, g_z on chip); cfg 5 -- bgk_affine_backward + per network "
+                    "bgk_mlp_backward_dx + bgk_mlp_weight_grad; no library GEMM, no aten activation kernel in the step")
     if os.environ.get("BGK_BENCH_AB") == "1":
         try:
             dense.AFFINE_TRAIN = False

@@ -680,9 +680,16 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
  * bias [n] behind it) = sum over slabs; 8 lanes per element each take every 8th slab, combined in ascending order through LDS */
 struct QRed { const float* pw; const float* pb; int n, k; float* gW; float* gb; };
 struct QRedGroup { QRed r[3]; int64_t first[4]; int n_slabs; const float* pa; float* g_log_alpha; };     /* pa: one partial of the log_alpha gradient per slab (or NULL) */
-__global__ __launch_bounds__(256) void bwd64_reduce_kernel(QRedGroup rg, int accumulate) {
+struct QRedPair { QRedGroup g[2]; int blocks0; };     /* two networks' partial sets in one launch: blocks [0, blocks0) belong to g[0] */
+__device__ __forceinline__ void bwd64_reduce_body(const QRedGroup& rg, int block, int accumulate);
+__global__ __launch_bounds__(256) void bwd64_reduce_kernel(QRedGroup rg, int accumulate) { bwd64_reduce_body(rg, (int)blockIdx.x, accumulate); }
+__global__ __launch_bounds__(256) void bwd64_reduce2_kernel(QRedPair rp, int accumulate) {
+    if ((int)blockIdx.x < rp.blocks0) bwd64_reduce_body(rp.g[0], (int)blockIdx.x, accumulate);
+    else bwd64_reduce_body(rp.g[1], (int)blockIdx.x - rp.blocks0, accumulate);
+}
+__device__ __forceinline__ void bwd64_reduce_body(const QRedGroup& rg, int block, int accumulate) {
     __shared__ float s_part[8][32];
-    if (blockIdx.x * 32 >= rg.first[3]) {                 /* the block behind the gradients: the log_alpha partials, summed in slab order by one thread */
+    if ((int64_t)block * 32 >= rg.first[3]) {                 /* the block behind the gradients: the log_alpha partials, summed in slab order by one thread */
         if (threadIdx.x == 0 && rg.pa && rg.g_log_alpha) {
             float t = 0.0f;
             for (int k = 0; k < rg.n_slabs; ++k) t += rg.pa[k];
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(256) void bwd64_reduce_kernel(QRedGroup rg, int acc
         return;
     }
     const int sub = threadIdx.x >> 5, el = threadIdx.x & 31;
-    const int64_t gi = (int64_t)blockIdx.x * 32 + el;
+    const int64_t gi = (int64_t)block * 32 + el;
     const int q = gi >= rg.first[2] ? 2 : (gi >= rg.first[1] ? 1 : 0);
     const QRed& o = rg.r[q];
     const int64_t i = gi - rg.first[q];
@@ -739,7 +746,7 @@ extern "C" int64_t bgk_affine_net_backward64_workspace(int64_t B, int32_t d, int
 
 /* one network's launch + reduction (a: everything but the workspace pointers; mode = the kernel's MODE = RECOMP + 2 TAIL) */
 static int bwd64_run(Bwd64Args a, int mode, float* workspace, float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0,
-                     float* g_log_alpha, int accumulate, hipStream_t st, const char* what) {
+                     float* g_log_alpha, int accumulate, hipStream_t st, const char* what, QRedGroup* defer = nullptr, unsigned* defer_blocks = nullptr) {
     const int d = a.d, H1 = a.H1, H0 = a.H0, n_in = a.n_in;
     const int n_slabs = bwd64_slabs(a.B);
     a.n_slabs = n_slabs;
@@ -770,6 +777,7 @@ static int bwd64_run(Bwd64Args a, int mode, float* workspace, float* gW2, float*
     rg.n_slabs = n_slabs;
     rg.pa = (mode & 2) ? a.pa : nullptr; rg.g_log_alpha = (mode & 2) ? g_log_alpha : nullptr;
     const unsigned blocks = (unsigned)((rg.first[3] + 31) / 32) + (rg.pa && rg.g_log_alpha ? 1u : 0u);
+    if (defer) { *defer = rg; *defer_blocks = blocks; return bgk_launch_status(what); }       /* the caller reduces this set together with another */
     hipLaunchKernelGGL(bwd64_reduce_kernel, dim3(blocks), dim3(256), 0, st, rg, accumulate);
     return bgk_launch_status(what);
 }
@@ -801,7 +809,7 @@ extern "C" int bgk_affine_net_backward64(const float* g, int64_t ldg, int32_t d,
 
 extern "C" int64_t bgk_affine_coupling_backward64_workspace(int64_t B, int32_t d, int32_t n_in, int32_t sH1, int32_t sH0, int32_t tH1, int32_t tH0) {
     const int64_t a = bgk_affine_net_backward64_workspace(B, d, sH1, sH0, n_in), b = bgk_affine_net_backward64_workspace(B, d, tH1, tH0, n_in);
-    return (a > b ? a : b) + bwd64_slabs(B);
+    return a + b + bwd64_slabs(B);         /* the two networks' partial sets side by side (one reduction launch for both) + the log_alpha partials */
 }
 
 extern "C" int bgk_affine_coupling_backward64(const float* cond, int64_t ldc, int32_t n_in, const float* y, int64_t ldy, int32_t d,
@@ -841,12 +849,20 @@ extern "C" int bgk_affine_coupling_backward64(const float* cond, int64_t ldc, in
     a.y = y; a.ldy = ldy; a.g_dl = g_dlogp; a.log_alpha = log_alpha; a.g_y = g_y; a.ldgy = ldgy;
     a.vec_gy = ((uintptr_t)g_y & 15) == 0 && ldgy % 4 == 0;
     a.z1 = t_z1; a.z0 = t_z0; a.s_raw = s_raw; a.lds = lds;
-    int rc = bwd64_run(a, 2 + rec, workspace, t_grads[0], t_grads[1], t_grads[2], t_grads[3], t_grads[4], t_grads[5], g_log_alpha, accumulate, st, what);
+    QRedPair rp;
+    unsigned nb0 = 0, nb1 = 0;
+    int rc = bwd64_run(a, 2 + rec, workspace, t_grads[0], t_grads[1], t_grads[2], t_grads[3], t_grads[4], t_grads[5], g_log_alpha, accumulate, st, what,
+                       &rp.g[0], &nb0);
     if (rc) return rc;
+    float* ws_shift = workspace + bgk_affine_net_backward64_workspace(B, d, tH1, tH0, n_in) + bwd64_slabs(B);
     /* the shift network: g_mu = g_out; its conditioner-input gradient is added to the scale network's */
     a.T2 = (const uint4*)sT2; a.T1 = (const uint4*)sT1; a.T0 = (const uint4*)sT0; a.cs = s_cs; a.act = s_act; a.H1 = sH1; a.H0 = sH0;
     a.A0 = (const uint4*)sA0; a.A1 = (const uint4*)sA1; a.A2 = nullptr;
     a.g_x_add = g_cond; a.ldga = ldgc;
     a.z1 = s_z1; a.z0 = s_z0;
-    return bwd64_run(a, rec, workspace, s_grads[0], s_grads[1], s_grads[2], s_grads[3], s_grads[4], s_grads[5], nullptr, accumulate, st, what);
+    rc = bwd64_run(a, rec, ws_shift, s_grads[0], s_grads[1], s_grads[2], s_grads[3], s_grads[4], s_grads[5], nullptr, accumulate, st, what, &rp.g[1], &nb1);
+    if (rc) return rc;
+    rp.blocks0 = (int)nb0;
+    hipLaunchKernelGGL(bwd64_reduce2_kernel, dim3(nb0 + nb1), dim3(256), 0, st, rp, accumulate);      /* both networks' partial sums in one launch */
+    return bgk_launch_status(what);
 }
