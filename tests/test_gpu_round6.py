@@ -595,3 +595,33 @@ def test_energy_float4_rows_equal_the_staging_kernels(hip_lib, dev, B):
             for a, b in zip(res[mode][1], x64):
                 want = b.grad if b.grad is not None else torch.zeros_like(b)          # (a uniform component's energy does not depend on x)
                 assert float((a.double() - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max())), (name, mode)
+
+
+@pytest.mark.parametrize("case", [("B = 1", 1, {}), ("B = 33", 33, {}), ("volume preserving", 200, {"preserve_volume": True})])
+def test_small_coupling_training_edge_cases(hip_lib, dev, case):
+    """cfg 2's coupling class at the edges of the one-call backward: a single sample, one sample past a tile, and the transformer option
+    it does not take (preserve_volume: the log-scales are centred per row, affine.py:46-52 -- that layer keeps bgk_affine_backward +
+    bgk_affine_net_backward64; is_circular excludes a scale network in the reference, affine.py:27-28).  Forward equal to the
+    inference kernel, every gradient within 5e-5 of f64 autograd of the reference's op chain."""
+    label, B, kw = case
+    flow = _affine_layer(32, (64, 64), 32, (torch.nn.ReLU, torch.nn.Tanh), **kw).to(dev)
+    flow_cpu = _affine_layer(32, (64, 64), 32, (torch.nn.ReLU, torch.nn.Tanh), **kw).double()
+    g = torch.Generator().manual_seed(77)
+    x, y = torch.randn(B, 32, generator=g).double(), torch.rand(B, 32, generator=g).double()
+    wy, wl = torch.randn(B, 32, generator=g).double(), torch.randn(B, 1, generator=g).double()
+    ref_out, ref_dl, ref_gx, ref_gy, ref_gp = _f64_layer_grads(flow_cpu, x, y, wy, wl, False)
+    xg, yg = x.float().to(dev).requires_grad_(True), y.float().to(dev).requires_grad_(True)
+    _, out, dl = flow(xg, yg)
+    cache = flow[0].transformer._train_cache
+    assert cache["tail_fused"] and cache["HT"] == 2
+    with torch.no_grad():
+        _, out_inf, dl_inf = flow(xg.detach(), yg.detach())
+    assert torch.equal(out, out_inf) and torch.equal(dl, dl_inf), label
+    ((out * wy.float().to(dev)).sum() + (dl * wl.float().to(dev)).sum()).backward()
+    got = {n: p.grad.double().cpu() for n, p in flow.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref_gp)
+    rel, worst = _grad_errors(got, {n: ref_gp[n] for n in got})
+    assert rel <= 5e-5, (label, rel, worst)
+    for name, a, b in (("g_x", xg.grad, ref_gx), ("g_y", yg.grad, ref_gy)):
+        err = float((a.double().cpu() - b).norm() / max(float(b.norm()), 1e-30))
+        assert err <= 5e-5, f"{label}: {name}: relative L2 {err:.2e}"
