@@ -44,7 +44,30 @@ struct LayerArgs {
     float* y; int64_t ldy; int n_out; int64_t B;
     int accumulate;                              /* y = act(y + x W^T + b) */
     int x_al, y_al;                              /* rows of x / y start on 16-byte boundaries */
+    int bias_lds;                                /* the bias vector (zero-padded to 128 G floats) sits in LDS behind the waves' tiles */
 };
+
+/* SiLU / tanh of the epilogue: hardware exp2 + a Newton-refined reciprocal (1 - 2 ulp; the reproducible polynomial forms of
+ * bgk_detmath_pk.h cost 3 x the instructions and the epilogue was 40 % of the kernel: tools/r06_layer_ts.py).  tanh keeps the odd
+ * polynomial below 0.625, where 1 - 2 / (e + 1) cancels. */
+__device__ __forceinline__ float layer_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float layer_silu(float x) {
+    return x * layer_rcp(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
+__device__ __forceinline__ float layer_tanh(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float big = __builtin_copysignf(__builtin_fmaf(-2.0f, layer_rcp(1.0f + __builtin_amdgcn_exp2f(ax * 2.88539008177792681f)), 1.0f), x);
+    const float z = x * x;
+    float p = -5.70498872745e-3f;
+    p = __builtin_fmaf(p, z, 2.06390887954e-2f);
+    p = __builtin_fmaf(p, z, -5.37397155531e-2f);
+    p = __builtin_fmaf(p, z, 1.33314422036e-1f);
+    p = __builtin_fmaf(p, z, -3.33332819422e-1f);
+    return ax >= 0.625f ? big : __builtin_fmaf(p * z, x, x);
+}
 
 __device__ __forceinline__ float layer_act(float v, int act) {
     if (act == 2) return v > 0.0f ? v : 0.0f;
@@ -58,8 +81,20 @@ struct RowWalk {
     __device__ __forceinline__ void next() { r += dr; c += dc; if (c >= w) { c -= w; ++r; } }
 };
 
+#ifndef BGK_LAYER_TS
+#define BGK_LAYER_TS 0              /* 1: lane 0 stamps s_memtime at the phase boundaries and writes the stamps over the tile's first output row (tools/r06_layer_ts.py) */
+#endif
+#if BGK_LAYER_TS
+#define LAYER_TS(k) do { ts_[k] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LAYER_TS(k) do { } while (0)
+#endif
+
 template <int S>
 __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(LayerArgs a) {
+#if BGK_LAYER_TS
+    unsigned ts_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     constexpr int XS = 16 * S + 4;                  /* LDS row stride of the input tile, floats (== 4 mod 64 banks: 16-byte reads of 16 rows hit 64 banks) */
     constexpr int YS = 128 + 4;                     /* ... of a 128-feature output group */
     constexpr int PER_WAVE = 32 * (XS > YS ? XS : YS);
@@ -67,12 +102,19 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, hh = lane >> 5;
     float* s_t = smem + (size_t)wave * PER_WAVE;
+    const float* s_bias = smem + (size_t)LW * PER_WAVE;             /* [128 G] (bias_lds) */
+    if (a.bias_lds) {                                               /* the whole workgroup, before any wave leaves */
+        float* sb = smem + (size_t)LW * PER_WAVE;
+        for (int i = threadIdx.x; i < 128 * a.G; i += LW * 64) sb[i] = (a.bias && i < a.n_out) ? a.bias[i] : 0.0f;
+        __syncthreads();
+    }
     const int64_t n_tiles = (a.B + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * LW + wave;
     if (tile >= n_tiles) return;
     const int64_t b0 = tile * 32;
     const int rows = (int)((a.B - b0) < 32 ? (a.B - b0) : 32);
     const bool live = j < rows;
+    LAYER_TS(0);
 
     /* ---- the tile's rows: row-contiguous 16-byte pieces (a wave instruction = 1 KB of consecutive row bytes) into LDS [row][XS] ---- */
     if (a.x_al && (a.n_in & 3) == 0) {
@@ -112,29 +154,29 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    LAYER_TS(1);
     /* ---- fragment order (lane (kb, j): features 16 s + 8 kb .. + 7 of row j), the row's largest magnitude, split under its power-of-two scale ---- */
     h2_h16x8 bhi[S], blo[S];
     float inv_tile;
     {
         float v[S][8];
         float m = 0.0f;
+        const bool full = a.n_in == 16 * S;          /* no padded k columns: nothing to mask (a row past the batch may hold anything: it only reaches its own, unwritten, outputs) */
 #pragma unroll
         for (int s = 0; s < S; ++s) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const int col = 16 * s + 8 * hh + 4 * g;
                 const float4 q = *reinterpret_cast<const float4*>(s_t + j * XS + col);       /* beyond the data: whatever LDS holds, discarded below */
-                v[s][4 * g + 0] = (live && col + 0 < a.n_in) ? q.x : 0.0f;
-                v[s][4 * g + 1] = (live && col + 1 < a.n_in) ? q.y : 0.0f;
-                v[s][4 * g + 2] = (live && col + 2 < a.n_in) ? q.z : 0.0f;
-                v[s][4 * g + 3] = (live && col + 3 < a.n_in) ? q.w : 0.0f;
+                v[s][4 * g + 0] = (full || (live && col + 0 < a.n_in)) ? q.x : 0.0f;
+                v[s][4 * g + 1] = (full || (live && col + 1 < a.n_in)) ? q.y : 0.0f;
+                v[s][4 * g + 2] = (full || (live && col + 2 < a.n_in)) ? q.z : 0.0f;
+                v[s][4 * g + 3] = (full || (live && col + 3 < a.n_in)) ? q.w : 0.0f;
             }
+            /* the row's largest magnitude (per sample since round 6: an inf / NaN entry takes only its own row's scale along -- to 1 --
+             * and that row's outputs are poisoned by the entry anyway) */
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {                        /* finite values only: an inf / NaN entry must not take its tile's scale (and with it the
-                                                                  * 31 other samples' f16 range) along -- it poisons its own sample's outputs and nothing else */
-                const float av = __builtin_fabsf(v[s][e]);
-                m = __builtin_fmaxf(m, av < 3.0e38f ? av : 0.0f);      /* (per sample since round 6: the rule now only keeps a row's own finite entries in range) */
-            }
+            for (int e = 0; e < 8; e += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v[s][e]), __builtin_fabsf(v[s][e + 1])));
         }
         /* the scale is per SAMPLE (round 6; per 32-sample tile before): lanes j and j + 32 hold the two halves of row j's k range, the
          * accumulator column of lane (j, hh) is sample j again, so the unscale factor below is a per-lane value -- a row's precision
@@ -149,6 +191,7 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
     __builtin_amdgcn_wave_barrier();                             /* the tile's LDS space now carries the output groups */
 
     /* ---- every 128-row group of output features: GEMM over the S k-steps, epilogue on the accumulators, rows out through LDS ---- */
+    LAYER_TS(2);
     for (int g = 0; g < a.G; ++g) {
         const uint4* Wg = a.A + (size_t)g * (S * 8 * 64);
         h2_f32x16 acc[4];
@@ -166,6 +209,7 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
             __builtin_amdgcn_sched_barrier(0);                   /* keep the prefetch above this step's MFMAs */
             h2_mfma3<4>(acc, ring[s % R], bhi[s], blo[s]);
         }
+        if (g == 0) LAYER_TS(3);
         const float* yrow = a.y + (b0 + (live ? j : 0)) * a.ldy;
         const int width = a.n_out - 128 * g < 128 ? a.n_out - 128 * g : 128;      /* live features of this group */
 #pragma unroll
@@ -181,16 +225,19 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += (live && f0 + e < a.n_out) ? yrow[f0 + e] : 0.0f;
                 }
-                if (a.bias) {
+                if (a.bias_lds) {
+                    const float4 bv = *reinterpret_cast<const float4*>(s_bias + f0);
+                    o[0] += bv.x; o[1] += bv.y; o[2] += bv.z; o[3] += bv.w;
+                } else if (a.bias) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += f0 + e < a.n_out ? a.bias[f0 + e] : 0.0f;
                 }
                 if (a.act == 1) {
-                    const bgk_f2 u0 = bgk_siluf2((bgk_f2){o[0], o[1]}), u1 = bgk_siluf2((bgk_f2){o[2], o[3]});
-                    o[0] = u0.x; o[1] = u0.y; o[2] = u1.x; o[3] = u1.y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = layer_silu(o[e]);
                 } else if (a.act == 3) {
-                    const bgk_f2 u0 = bgk_tanhf2((bgk_f2){o[0], o[1]}), u1 = bgk_tanhf2((bgk_f2){o[2], o[3]});
-                    o[0] = u0.x; o[1] = u0.y; o[2] = u1.x; o[3] = u1.y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = layer_tanh(o[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = layer_act(o[e], a.act);
@@ -200,6 +247,7 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (g == 0) LAYER_TS(4);
         float* yg = a.y + b0 * a.ldy + 128 * g;
         if (a.y_al && (width & 3) == 0) {                        /* row-contiguous 16-byte pieces: 32 lanes per 512-byte row segment */
             RowWalk wk(lane, width >> 2);
@@ -216,7 +264,14 @@ __global__ __launch_bounds__(LW * 64, S <= 8 ? 2 : 1) void dense_layer_kernel(La
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (g == 0) LAYER_TS(5);
     }
+#if BGK_LAYER_TS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LAYER_TS(6);
+    if (lane == 0)
+        for (int q = 0; q < 8; ++q) reinterpret_cast<unsigned*>(a.y + b0 * a.ldy)[q] = ts_[q];
+#endif
 }
 
 /* ---- device-side operand packing (the weights of a training run change every step; dense.py::pack_linear_layer is the layout's
@@ -330,11 +385,14 @@ __global__ __launch_bounds__(1024) void layer_refresh_kernel(const float* W, int
 template <int S>
 int launch_layer(const LayerArgs& a, hipStream_t st) {
     constexpr int XS = 16 * S + 4, YS = 128 + 4;
-    const size_t shmem = sizeof(float) * (size_t)LW * 32 * (XS > YS ? XS : YS);
+    size_t shmem = sizeof(float) * (size_t)LW * 32 * (XS > YS ? XS : YS);
+    LayerArgs b = a;
+    b.bias_lds = a.bias != nullptr && shmem + sizeof(float) * 128 * (size_t)a.G <= 160 * 1024;      /* (else: per-element loads in the epilogue) */
+    if (b.bias_lds) shmem += sizeof(float) * 128 * (size_t)a.G;
     if (shmem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_layer_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int64_t n_wg = ((a.B + 31) / 32 + LW - 1) / LW;
-    hipLaunchKernelGGL((dense_layer_kernel<S>), dim3((unsigned)n_wg), dim3(LW * 64), shmem, st, a);
+    hipLaunchKernelGGL((dense_layer_kernel<S>), dim3((unsigned)n_wg), dim3(LW * 64), shmem, st, b);
     return bgk_launch_status("bgk_dense_layer");
 }
 
