@@ -1407,8 +1407,20 @@ __device__ __forceinline__ float aff_tanh_out(float x) {
     return ax >= 0.625f ? big : small;
 }
 
+#ifndef BGK_V2_AFF_TS
+#define BGK_V2_AFF_TS 0               /* profiling build (tools/r06_aff_ts.py): lane 0 stamps s_memtime at the affine kernel's phase boundaries and writes the stamps over the tile's first output row */
+#endif
+#if BGK_V2_AFF_TS
+#define AFF_TS(k) do { ats_[k] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AFF_TS(k) do { } while (0)
+#endif
+
 template <int ACT_S, int ACT_T, int OT, bool DEEP>
 __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(AffV2Args a) {
+#if BGK_V2_AFF_TS
+    unsigned ats_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 #if BGK_V2_OVFL
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");                 /* MODE.FP16_OVFL (act_split_pair carries no clamps) */
 #endif
@@ -1438,10 +1450,12 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
      * layer-0 fragments travel with them ---- */
     const int nfs = a.nfs, ys = a.ys;
     const StageTiles stg{a.d_c, a.periodic, nfs, ys, a.stage, a.y_dma, d, a.magic_d, rows, lane};
+    AFF_TS(0);
     stage_issue(stg, a.cs, b0, y_t, s_p, s_y);
     L0Frag fa;
     l0_request(fa, a.has_shift ? a.shift.A0 : a.scale.A0, 0, lane);
     stage_finish<AffV2Args>(stg, a.cs, b0, y_t, ldy32, s_p, s_y, 0.0f);
+    AFF_TS(1);
 
     f32x16 h[4], acc[4];
     TFrag ring[RD];
@@ -1467,7 +1481,9 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
 #else
     if (a.has_shift) {
         aff_layer0(a.shift, a.S0, s_p, nfs, n_in, lane, j, hh, h, fa, true);
+        AFF_TS(2);
         aff_layers<ACT_S, OT, DEEP>(a.shift, h, acc, bf, ring, voff);
+        AFF_TS(3);
     }
     /* ---- scale network: layer 0 while the other array still holds the shift values; then they are parked in the (now free) tile.
      * (Its first fragments requested any earlier stay live across the GEMMs above: spills.) ---- */
@@ -1496,8 +1512,10 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
         a.scale.c2 = 1.0f;
     }
 #else
+    AFF_TS(4);
     if (a.has_scale) aff_layers<ACT_T, OT, DEEP>(a.scale, t0, mu, bf, ring, voff);       /* result in acc[0 .. OT) either way */
 #endif
+    AFF_TS(5);
 
     /* ---- affine tail (affine.py:41-70): lane (j, hh) owns sample j, dims drow(m, r, hh) ---- */
     const float alpha = a.has_scale ? bgk_expf(a.log_alpha[0]) : 0.0f;
@@ -1541,11 +1559,18 @@ __global__ __launch_bounds__(FTHREADS, 2) void coupling_affine_dense_v2_kernel(A
         }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    AFF_TS(6);
     if (hh == 0 && j < rows) {
         const float dl = a.inverse ? -total : total;
         if (a.accumulate) a.dlogp[b0 + j] += dl; else a.dlogp[b0 + j] = dl;
     }
     store_tile32(out_t, ldo32, s_y, ys, d, a.magic_d, rows, lane, a.out_lin);
+#if BGK_V2_AFF_TS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AFF_TS(7);
+    if (lane == 0)
+        for (int q = 0; q < 8; ++q) reinterpret_cast<unsigned*>(out_t)[q] = ats_[q];
+#endif
 }
 #endif   /* affine layer */
 
