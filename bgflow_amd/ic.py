@@ -569,6 +569,21 @@ class _WhitenFn(torch.autograd.Function):
         return _whiten_launch(g.contiguous(), ctx.Tt, None, None), None, None, None, None
 
 
+class _WideWhitenFn(torch.autograd.Function):
+    """out = x W^T on bgk_dense_layer for a fixed (buffer) matrix; backward: g_x = g W on the same kernel (operands of W^T)"""
+
+    @staticmethod
+    def forward(ctx, x, lin):
+        from . import dense
+        ctx.lin = lin
+        return dense.dense_layer(x, lin)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import dense
+        return dense.dense_layer(g.contiguous(), ctx.lin, transposed=True), None
+
+
 def _whiten_launch(x, T, pre, post):
     x2, ldx = _lib.rowmajor(x)
     B, n_in = x2.shape
@@ -583,7 +598,7 @@ def _whiten_launch(x, T, pre, post):
 
 class WhitenFlow(Flow):
     """Static PCA whitening ``z = (x - mean) @ Twhiten`` with constant log-det (pca.py:37-107).  Stand-alone, blocks of up to 128
-    coordinates run on bgk_whiten (mean shift fused, VJP on the same kernel); larger ones are a plain library GEMM.  Inside
+    coordinates run on bgk_whiten (mean shift fused, VJP on the same kernel); larger ones on bgk_dense_layer (round 6; a library GEMM before).  Inside
     MixedCoordinateTransformation the product is fused into the IC kernels.  Buffers: X0mean, Twhiten, Tblacken, std."""
 
     def __init__(self, X0, keepdims=None, whiten_inverse=True):
@@ -617,14 +632,41 @@ class WhitenFlow(Flow):
             return _WhitenFn.apply(x, T, Tt, pre, post)
         return _whiten_launch(x, T, pre, post)
 
+    def _wide_kernel(self, x, which):
+        """blocks wider than 128 coordinates on bgk_dense_layer (round 6; before: torch.matmul -> hipBLASLt): the product as a bias-free
+        ``Linear`` whose weight is the (transposed) PCA matrix -- split-f16 MFMA GEMM, f32-class, its input gradient on the same kernel
+        (dense._LinearFn).  None: not a 2-d f32 HIP tensor (the caller runs torch.matmul)."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+            return None
+        from . import dense
+        key = (str(x.device), self.Twhiten.data_ptr(), self.Twhiten._version, self.Tblacken._version)
+        cache = self.__dict__.get("_wide_lins")
+        if cache is None or cache[0] != key:
+            lins = {}
+            for name, T in (("whiten", self.Twhiten), ("blacken", self.Tblacken)):
+                lin = torch.nn.Linear(T.shape[0], T.shape[1], bias=False)
+                lin.weight = torch.nn.Parameter(T.detach().to(device=x.device, dtype=torch.float32).t().contiguous(), requires_grad=False)
+                lins[name] = lin
+            cache = self.__dict__["_wide_lins"] = (key, lins)
+        lin = cache[1][which]
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _WideWhitenFn.apply(x, lin)
+        return dense.dense_layer(x, lin)
+
     def _whiten(self, x):
         z = self._kernel(x, "whiten")
+        if z is None:
+            z = self._wide_kernel(x - self.X0mean, "whiten")
         if z is None:
             z = torch.matmul(x - self.X0mean, self.Twhiten)
         return z, self.jacobian_xz.to(x) * torch.ones((x.shape[0], 1), dtype=x.dtype, device=x.device)
 
     def _blacken(self, z):
         x = self._kernel(z, "blacken")
+        if x is None:
+            x = self._wide_kernel(z, "blacken")
+            if x is not None:
+                x = x + self.X0mean
         if x is None:
             x = torch.matmul(z, self.Tblacken) + self.X0mean
         return x, -self.jacobian_xz.to(z) * torch.ones((z.shape[0], 1), dtype=z.dtype, device=z.device)

@@ -625,3 +625,38 @@ def test_small_coupling_training_edge_cases(hip_lib, dev, case):
     for name, a, b in (("g_x", xg.grad, ref_gx), ("g_y", yg.grad, ref_gy)):
         err = float((a.double().cpu() - b).norm() / max(float(b.norm()), 1e-30))
         assert err <= 5e-5, f"{label}: {name}: relative L2 {err:.2e}"
+
+
+def test_wide_whiten_flow_runs_on_the_layer_kernel(hip_lib, dev):
+    """A stand-alone WhitenFlow over more than 128 coordinates (a 100-atom molecule's 300 Cartesian dofs, 294 kept: pca.py:37-107) ran
+    torch.matmul -> hipBLASLt in rounds 1 - 5 (the verdict's envelope leftover); it is a bias-free Linear on bgk_dense_layer now, in both
+    directions and under autograd: no library GEMM launched, values and the input gradient within 2e-5 (relative to the largest entry) of
+    the f64 product, whiten o blacken = identity on the kept subspace."""
+    import bgflow_amd as bg
+    g = torch.Generator().manual_seed(4)
+    n, keep, B = 300, 294, 1000
+    basis = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))[0]
+    data = (torch.randn(4000, n, generator=g, dtype=torch.float64) * torch.logspace(-1.5, 0.5, n, dtype=torch.float64)) @ basis + 3.0
+    flow = bg.WhitenFlow(data.float(), keepdims=keep, whiten_inverse=False).to(dev)
+    x = data[:B].float().to(dev).requires_grad_(True)
+    w = torch.randn(B, keep, generator=g).to(dev)
+
+    def run():
+        z, dl = flow(x)
+        (z * w).sum().backward()
+        with torch.no_grad():
+            back, dl2 = flow(z.detach(), inverse=True)
+        return z.detach(), back, dl + dl2
+    names = _device_kernel_names(run)
+    assert not [k for k in names if "Cijk_" in k], "library GEMM in the wide WhitenFlow"
+    assert any("dense_layer_kernel" in k for k in names)
+    x.grad = None
+    z, back, dlsum = run()
+    Tw, mean = flow.Twhiten.double().cpu(), flow.X0mean.double().cpu()
+    want = (data[:B] .float().double() - mean) @ Tw
+    assert float((z.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    want_g = w.double().cpu() @ Tw.T
+    assert float((x.grad.double().cpu() - want_g).abs().max()) <= 2e-5 * float(want_g.abs().max())
+    assert float(dlsum.abs().max()) == 0.0
+    proj = (data[:B].float().double() - mean) @ Tw @ flow.Tblacken.double().cpu() + mean
+    assert float((back.double().cpu() - proj).abs().max()) <= 2e-5 * float(proj.abs().max())
