@@ -142,7 +142,7 @@ _SIGNATURES = {
                                                       vp, vp, vp, vp, vp, i64,
                                                       vp, vp, vp, vp, vp, vp, i32, i32, i32,
                                                       vp, vp, vp, vp, vp, vp, vp, i32, i32, i32,
-                                                      vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp, i32, vp]),
+                                                      vp, i32, i64, vp, i64, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, i32, vp]),
     "bgk_linear_weight_grad_workspace": (i64, [i64, i32, i32]),
     "bgk_linear_weight_grad": (ctypes.c_int, [vp, i64, i32, vp, i64, i32, i64, vp, i64, vp, vp, i32, vp, vp]),
 }

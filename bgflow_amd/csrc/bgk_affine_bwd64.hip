@@ -48,6 +48,7 @@ struct Bwd64Args {
      * network's saved output (!RECOMP) */
     const float* s_raw; int64_t lds;
     const float* y; int64_t ldy; const float* g_dl; const float* log_alpha; float* g_y; int64_t ldgy; float* pa; int vec_gy;
+    float* g_mu;                                 /* TAIL + INVERSE (an inverse-direction layer): y = the layer's OUTPUT; g_mu [B, d] (pitch ldgy) = - g_y leaves for the shift network's launch */
 };
 constexpr int FWB = 12 + 18 + 9;   /* forward operand blocks in LDS (RECOMP): A0 (<= 3 k-steps x 2 tiles x {hi, lo}), A1 (4 x 2 x 2 + 2 bias), A2 (4 x 1 x 2 + 1) */
 
@@ -218,7 +219,9 @@ __device__ __forceinline__ void q_running_scale(float tile_max, float& s_run, fl
     } else if (s_run == 0.0f) { s_run = 1.0f; inv_run = 1.0f; }
 }
 
-/* MODE = RECOMP + 2 TAIL.
+/* MODE = RECOMP + 2 TAIL + 4 INVERSE (a compile-time flag: as a run-time one in the tile loop it pushed the kernel's 104 spilled scalar
+ * registers into a miscompile -- wrong bias / log_alpha sums in the forward-direction instance, tools history of round 6).
+ * MODE = RECOMP + 2 TAIL (+ 4 INVERSE).
  * !RECOMP: z1 / z0 saved by the forward.  RECOMP (round 6): NOTHING is saved -- the wave redoes the network's forward on its tile (the
  * forward kernels' products in the forward kernels' order, operands in LDS beside the transposed ones: 44 - 57 matrix instructions) and
  * the training forward writes only its outputs.
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint4* s_op = reinterpret_cast<uint4*>(smem);                         /* [OPB][64] operand blocks */
     const int lane_in = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr bool RECOMP = (MODE & 1) != 0, TAIL = (MODE & 2) != 0;
+    constexpr bool RECOMP = (MODE & 1) != 0, TAIL = (MODE & 2) != 0, INVERSE = (MODE & 4) != 0;     /* (INVERSE: with TAIL only) */
     const uint4* s_fw = s_op + OPB * 64;                                  /* RECOMP: [FWB][64] forward operand blocks */
     float* sx = smem + (OPB + (RECOMP ? FWB : 0)) * 256 + wave * (64 * TP); /* this wave's transposed tile */
     if (RECOMP) {
@@ -413,23 +416,26 @@ __global__ __launch_bounds__(QW * 64, BGK_BWD64_OCC) void affine_net_bwd64_kerne
             for (int r = 0; r < 16; ++r) {
                 const bool in = (r & 3) + 8 * (r >> 2) + 4 * hh < d;
                 const float th = q_tanh_out(sraw[r]);
-                const float ex = __builtin_amdgcn_exp2f(th * alpha * 1.44269504088896341f);
+                const float ex = __builtin_amdgcn_exp2f((INVERSE ? -th : th) * alpha * 1.44269504088896341f);
                 gy[r] = gv[r] * ex;
-                const float gls = __builtin_fmaf(gy[r], yv[r], gl);
+                /* forward: out = y e^s + mu, dlogp = sum s;  inverse: out = (y - mu) e^-s, dlogp = - sum s, and (y - mu) e^-s IS the output (yv) */
+                const float gls = INVERSE ? -__builtin_fmaf(gv[r], yv[r], gl) : __builtin_fmaf(gy[r], yv[r], gl);
                 gs[r] = in ? gls * alpha * __builtin_fmaf(-th, th, 1.0f) : 0.0f;
                 ga_sum += in ? gls * th : 0.0f;
             }
             if (j < rows) {
                 float* grow_y = a.g_y + (b0 + j) * a.ldgy;
+                float* grow_m = INVERSE ? a.g_mu + (b0 + j) * a.ldgy : nullptr;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int f0 = 8 * q + 4 * hh;
                     if (a.vec_gy && f0 + 3 < d) {
                         *reinterpret_cast<float4*>(grow_y + f0) = make_float4(gy[4 * q], gy[4 * q + 1], gy[4 * q + 2], gy[4 * q + 3]);
+                        if (grow_m) *reinterpret_cast<float4*>(grow_m + f0) = make_float4(-gy[4 * q], -gy[4 * q + 1], -gy[4 * q + 2], -gy[4 * q + 3]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (f0 + e < d) grow_y[f0 + e] = gy[4 * q + e];
+                            if (f0 + e < d) { grow_y[f0 + e] = gy[4 * q + e]; if (grow_m) grow_m[f0 + e] = -gy[4 * q + e]; }
                     }
                 }
             }
@@ -763,7 +769,8 @@ static int bwd64_run(Bwd64Args a, int mode, float* workspace, float* gW2, float*
 #define BGK_LAUNCH_Q(A, M) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(affine_net_bwd64_kernel<A, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                                 hipLaunchKernelGGL((affine_net_bwd64_kernel<A, M>), dim3(n_slabs), dim3(QW * 64), shmem, st, a); } while (0)
 #define BGK_LAUNCH_QA(M) do { if (a.act == 1) BGK_LAUNCH_Q(1, M); else if (a.act == 2) BGK_LAUNCH_Q(2, M); else BGK_LAUNCH_Q(3, M); } while (0)
-    if (mode == 0) BGK_LAUNCH_QA(0); else if (mode == 1) BGK_LAUNCH_QA(1); else if (mode == 2) BGK_LAUNCH_QA(2); else BGK_LAUNCH_QA(3);
+    if (mode == 0) BGK_LAUNCH_QA(0); else if (mode == 1) BGK_LAUNCH_QA(1); else if (mode == 2) BGK_LAUNCH_QA(2); else if (mode == 3) BGK_LAUNCH_QA(3);
+    else if (mode == 6) BGK_LAUNCH_QA(6); else BGK_LAUNCH_QA(7);
 #undef BGK_LAUNCH_QA
 #undef BGK_LAUNCH_Q
     QRedGroup rg;
@@ -819,13 +826,14 @@ extern "C" int bgk_affine_coupling_backward64(const float* cond, int64_t ldc, in
                                               const float* s_cs, int32_t s_act, int32_t sH1, int32_t sH0,
                                               const void* tA0, const void* tA1, const void* tA2, const void* tT0, const void* tT1, const void* tT2,
                                               const float* t_cs, int32_t t_act, int32_t tH1, int32_t tH0,
-                                              const float* log_alpha, int64_t B,
-                                              float* g_y, int64_t ldgy, float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                                              const float* log_alpha, int32_t inverse, int64_t B,
+                                              float* g_y, int64_t ldgy, float* g_mu, float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
                                               float* g_log_alpha, float* workspace, int64_t workspace_floats,
                                               float* const* s_grads, float* const* t_grads, int32_t accumulate, void* stream) {
     if (B == 0) return 0;
     const char* what = "bgk_affine_coupling_backward64";
     BGK_CHECK_ARG(cond && y && g_out && g_dlogp && g_y && log_alpha && workspace && s_grads && t_grads, "%s: null pointer", what);
+    BGK_CHECK_ARG((inverse == 0 || inverse == 1) && (!inverse || g_mu), "%s: an inverse-direction layer needs the g_mu [B, d] buffer", what);
     BGK_CHECK_ARG(sA0 && sA1 && sT0 && sT1 && sT2 && s_cs && tA0 && tA1 && tA2 && tT0 && tT1 && tT2 && t_cs, "%s: null operand", what);
     BGK_CHECK_ARG(B > 0 && d > 0 && n_in > 0 && sH1 > 0 && sH0 > 0 && tH1 > 0 && tH0 > 0 && ldc >= n_in && ldy >= d && ldgo >= d && ldgy >= d
                   && s_act >= 1 && s_act <= 3 && t_act >= 1 && t_act <= 3 && (accumulate == 0 || accumulate == 1), "%s: bad sizes", what);
@@ -847,15 +855,18 @@ extern "C" int bgk_affine_coupling_backward64(const float* cond, int64_t ldc, in
     a.A0 = (const uint4*)tA0; a.A1 = (const uint4*)tA1; a.A2 = (const uint4*)tA2;
     a.g_x_add = g_cond ? g_cond_add : nullptr;
     a.y = y; a.ldy = ldy; a.g_dl = g_dlogp; a.log_alpha = log_alpha; a.g_y = g_y; a.ldgy = ldgy;
-    a.vec_gy = ((uintptr_t)g_y & 15) == 0 && ldgy % 4 == 0;
+    a.vec_gy = ((uintptr_t)g_y & 15) == 0 && ldgy % 4 == 0 && (!inverse || ((uintptr_t)g_mu & 15) == 0);
+    a.g_mu = g_mu;
     a.z1 = t_z1; a.z0 = t_z0; a.s_raw = s_raw; a.lds = lds;
     QRedPair rp;
     unsigned nb0 = 0, nb1 = 0;
-    int rc = bwd64_run(a, 2 + rec, workspace, t_grads[0], t_grads[1], t_grads[2], t_grads[3], t_grads[4], t_grads[5], g_log_alpha, accumulate, st, what,
+    int rc = bwd64_run(a, 2 + rec + (inverse ? 4 : 0), workspace, t_grads[0], t_grads[1], t_grads[2], t_grads[3], t_grads[4], t_grads[5], g_log_alpha, accumulate, st, what,
                        &rp.g[0], &nb0);
     if (rc) return rc;
     float* ws_shift = workspace + bgk_affine_net_backward64_workspace(B, d, tH1, tH0, n_in) + bwd64_slabs(B);
-    /* the shift network: g_mu = g_out; its conditioner-input gradient is added to the scale network's */
+    /* the shift network: g_mu = g_out (forward direction) or - g_out e^-s (inverse: written by the launch above); its conditioner-input
+     * gradient is added to the scale network's */
+    if (inverse) { a.g = g_mu; a.ldg = ldgy; }
     a.T2 = (const uint4*)sT2; a.T1 = (const uint4*)sT1; a.T0 = (const uint4*)sT0; a.cs = s_cs; a.act = s_act; a.H1 = sH1; a.H0 = sH0;
     a.A0 = (const uint4*)sA0; a.A1 = (const uint4*)sA1; a.A2 = nullptr;
     a.g_x_add = g_cond; a.ldga = ldgc;

@@ -1986,7 +1986,7 @@ def _affine_train_forward(x, y, log_alpha, plan, cfg, dlogp=None, accumulate=Fal
     if dlogp is None:
         dlogp, accumulate = torch.empty((B,), dtype=torch.float32, device=dev), False
     ldms = 32 * plan["OT"]
-    fused_bwd = plan.get("tail_fused") and not inverse and not pv
+    fused_bwd = plan.get("tail_fused") and not pv          # (either direction; the backward of an inverse-direction layer reads the OUTPUT)
     if fused_bwd and plan.get("recompute"):
         zz = ms = None                    # nothing saved: bgk_affine_coupling_backward64 recomputes the networks
         zp = [None] * 6
@@ -2016,7 +2016,7 @@ def _affine_train_forward(x, y, log_alpha, plan, cfg, dlogp=None, accumulate=Fal
                 _lib.ptr(y2), ldy, B, d, _lib.ptr(out), ldo, _lib.ptr(dlogp), int(bool(accumulate)),
                 *zp[:4], plan["ldz"], *zp[4:], ldms, _lib.stream_ptr(dev))
     _lib.check(st, what)
-    return out, dlogp, (x2, y2, zz, ms)
+    return out, dlogp, (x2, out if (fused_bwd and inverse) else y2, zz, ms)
 
 
 def _affine_train_backward(plan, cfg, versions, x2, y2, log_alpha, zz, ms, g_out, g_dl, need_x, need_la, need_w, gx_add=None, gx_out=None):
@@ -2029,7 +2029,8 @@ def _affine_train_backward(plan, cfg, versions, x2, y2, log_alpha, zz, ms, g_out
     dev = y2.device
     B, d = y2.shape
     if zz is None or ms.shape[0] == 1:
-        return _affine_train_backward_fused(plan, versions, x2, y2, zz, ms, log_alpha, g_out, g_dl, need_x, need_la, need_w, gx_add, gx_out)
+        return _affine_train_backward_fused(plan, versions, x2, y2, zz, ms, log_alpha, g_out, g_dl, need_x, need_la, need_w, gx_add, gx_out,
+                                            bool(inverse))
     ldms = ms.shape[2]
     ldc = x2.stride(0) if B > 1 else x2.shape[1]
     g_out2, ldgo = _lib.rowmajor(g_out.reshape(B, d))
@@ -2061,10 +2062,10 @@ def _affine_train_backward(plan, cfg, versions, x2, y2, log_alpha, zz, ms, g_out
     return g_x, g_y, (None if (la_direct or et is None or not need_la) else g_la), grads
 
 
-def _affine_train_backward_fused(plan, versions, x2, y2, zz, ms, log_alpha, g_out, g_dl, need_x, need_la, need_w, gx_add, gx_out):
-    """_affine_train_backward for a layer of plan["tail_fused"] (forward direction, no volume preservation): ONE library call,
+def _affine_train_backward_fused(plan, versions, x2, y2, zz, ms, log_alpha, g_out, g_dl, need_x, need_la, need_w, gx_add, gx_out, inverse=False):
+    """_affine_train_backward for a layer of plan["tail_fused"] (no volume preservation): ONE library call,
     bgk_affine_coupling_backward64 -- tail backward + both networks' backward; from the saved z0 / z1 / s_raw, or (zz is None: the
-    forward saved nothing) from x, y, g_out, g_dlogp alone."""
+    forward saved nothing) from x, y, g_out, g_dlogp alone.  ``inverse``: the layer ran in the inverse direction and ``y2`` is its OUTPUT."""
     es, et = plan["nets"]
     for e, v in zip((es, et), versions):
         if e["version"] != v:
@@ -2078,6 +2079,7 @@ def _affine_train_backward_fused(plan, versions, x2, y2, zz, ms, log_alpha, g_ou
     ldy = y2.stride(0) if B > 1 else d
     g_out2, ldgo = _lib.rowmajor(g_out.reshape(B, d))
     g_y = torch.empty((B, d), dtype=torch.float32, device=dev)
+    g_mu = torch.empty((B, d), dtype=torch.float32, device=dev) if inverse else None
     g_x = (gx_out if gx_out is not None else torch.empty((B, plan["d_c"]), dtype=torch.float32, device=dev)) if need_x else None
     add2, lda = (gx_add, gx_add.stride(0)) if (gx_add is not None and need_x) else (None, 0)
     tb = es["tbufs"]
@@ -2107,7 +2109,7 @@ def _affine_train_backward_fused(plan, versions, x2, y2, zz, ms, log_alpha, g_ou
             _lib.ptr(es["cs"]), es["act"], es["H1"], es["H0"],
             _lib.ptr(et["A0"]), _lib.ptr(et["A1"]), _lib.ptr(et["A2"]), _lib.ptr(et["tbufs"]["T0"]), _lib.ptr(et["tbufs"]["T1"]), _lib.ptr(et["tbufs"]["T2"]),
             _lib.ptr(et["cs"]), et["act"], et["H1"], et["H0"],
-            _lib.ptr(log_alpha.detach()), B, _lib.ptr(g_y), d, _lib.ptr(g_x) if need_x else None, g_x.stride(0) if need_x else n_in, _lib.ptr(add2), lda,
+            _lib.ptr(log_alpha.detach()), int(inverse), B, _lib.ptr(g_y), d, _lib.ptr(g_mu), _lib.ptr(g_x) if need_x else None, g_x.stride(0) if need_x else n_in, _lib.ptr(add2), lda,
             _lib.ptr(g_la), _lib.ptr(ws), ws.numel(), s_arr, t_arr, int(direct), _lib.stream_ptr(dev))
     _lib.check(st, "bgk_affine_coupling_backward64")
     grads = [None] * 12 if direct else outs

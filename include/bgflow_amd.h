@@ -732,10 +732,12 @@ int bgk_affine_net_backward64(const float* g, int64_t ldg, int32_t d, const floa
                               float* gW2, float* gb2, float* gW1, float* gb1, float* gW0, float* gb0, int32_t accumulate,
                               void* stream);
 
-/* bgk_affine_coupling_backward64 (round 6): the WHOLE backward of a forward-direction affine coupling (no volume preservation) with two
+/* bgk_affine_coupling_backward64 (round 6): the WHOLE backward of an affine coupling (either direction, no volume preservation) with two
  * networks inside bgk_affine_net_backward64's envelope in two launches (+ their reductions).  The scale network's launch forms
  * g_y = g_out e^s and g_s_raw = (g_out e^s y + g_dlogp) alpha (1 - tanh^2 s_raw) on chip (bgk_affine_backward's arithmetic: that launch,
  * its g_mu / g_s arrays and its atomics do not exist) and runs the network's backward; the shift network's takes g_mu = g_out as it is.
+ * inverse = 1 (the layer ran out = (y - mu) e^-s, dlogp = - sum s): `y` is the layer's OUTPUT (g_s = - g_out out - g_dlogp needs nothing
+ * else), g_y = g_out e^-s, and g_mu = - g_y goes through the [B, d] buffer g_mu (pitch ldgy) to the shift network's launch.
  *   s_z0, s_z1, t_z0, t_z1 [B, 64], s_raw [B, lds]: what bgk_coupling_affine_dense_fwd64_train saved (mu is not needed) -- or ALL FIVE
  *   NULL: nothing was saved (that entry point with NULL save pointers), every wave recomputes the networks' forward on its tile (the
  *   forward's products in the forward's order).  HBM per sample and layer for BASELINE cfg 2, forward included: 4.4 KB with
@@ -753,8 +755,8 @@ int bgk_affine_coupling_backward64(const float* cond, int64_t ldc, int32_t n_in,
                                    const float* s_cs, int32_t s_act, int32_t sH1, int32_t sH0,
                                    const void* tA0, const void* tA1, const void* tA2, const void* tT0, const void* tT1, const void* tT2,
                                    const float* t_cs, int32_t t_act, int32_t tH1, int32_t tH0,
-                                   const float* log_alpha, int64_t B,
-                                   float* g_y, int64_t ldgy, float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
+                                   const float* log_alpha, int32_t inverse, int64_t B,
+                                   float* g_y, int64_t ldgy, float* g_mu, float* g_cond, int64_t ldgc, const float* g_cond_add, int64_t ldga,
                                    float* g_log_alpha, float* workspace, int64_t workspace_floats,
                                    float* const* s_grads, float* const* t_grads, int32_t accumulate, void* stream);
 

@@ -393,9 +393,10 @@ def test_small_network_kernels_equal_the_general_path(hip_lib, dev):
     assert rel <= 2e-6, (rel, worst)
 
 
+@pytest.mark.parametrize("inverse", [False, True])
 @pytest.mark.parametrize("shape", [(32, 32, (64, 64), ("ReLU", "Tanh")), (24, 20, (48, 64), ("SiLU", "SiLU")), (7, 5, (64, 33), ("Tanh", "Tanh"))])
-def test_one_call_backward_variants_of_the_small_couplings(hip_lib, dev, shape):
-    """A forward-direction coupling of cfg 2's class (both networks <= 64 units) has three backward forms: bgk_affine_backward + one
+def test_one_call_backward_variants_of_the_small_couplings(hip_lib, dev, shape, inverse):
+    """A coupling of cfg 2's class (either direction: the inverse one reads the layer's OUTPUT in its tail backward) (both networks <= 64 units) has three backward forms: bgk_affine_backward + one
     bgk_affine_net_backward64 per network (dense.TAIL_FUSED64 = False: the form the round started with), ONE bgk_affine_coupling_backward64
     on the saved pre-activations (default: the tail's backward inside the scale network's launch, no g_mu / g_s arrays, no atomics), and
     the same call with NOTHING saved (dense.RECOMPUTE64 = True: every wave recomputes the networks on its tile).  Same forward values
@@ -415,7 +416,7 @@ def test_one_call_backward_variants_of_the_small_couplings(hip_lib, dev, shape):
         for p in flow.parameters():
             p.grad = None
         x, y = x0.clone().requires_grad_(need_x), y0.clone().requires_grad_(True)
-        _, out, dl = flow(x, y)
+        _, out, dl = flow(x, y, inverse=inverse)
         ((out * w).mean() - 0.3 * dl.mean() + out.square().mean()).backward()
         return (out.detach(), dl.detach(), y.grad.clone(), x.grad.clone() if need_x else None,
                 {n: p.grad.clone() for n, p in flow.named_parameters() if p.grad is not None})
@@ -432,7 +433,7 @@ def test_one_call_backward_variants_of_the_small_couplings(hip_lib, dev, shape):
     flow64 = _affine_layer(n_c, hidden, d, tuple(getattr(torch.nn, a) for a in acts)).double()
     x, y = x0.cpu().double().requires_grad_(True), y0.cpu().double().requires_grad_(True)
     from oracle import torch_flow as tfl
-    outs64, dl64 = tfl.run_flow(flow64, [x, y], inverse=False, grad=True)
+    outs64, dl64 = tfl.run_flow(flow64, [x, y], inverse=inverse, grad=True)
     out64 = outs64[1]
     ((out64 * w.cpu().double()).mean() - 0.3 * dl64.mean() + out64.square().mean()).backward()
     ref = {n: p.grad for n, p in flow64.named_parameters()}
@@ -447,7 +448,7 @@ def test_one_call_backward_variants_of_the_small_couplings(hip_lib, dev, shape):
             assert rel <= 2e-6, (mode, rel)
         assert float((with_x[3].cpu().double() - x.grad).norm() / x.grad.norm()) <= 2e-6, mode
         assert without_x[3] is None
-    print("one-call backward variants agree for", shape)
+    print("one-call backward variants agree for", shape, "inverse" if inverse else "forward")
 
 
 @pytest.mark.parametrize("inverse", [False, True])
