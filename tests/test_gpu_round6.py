@@ -661,3 +661,27 @@ def test_wide_whiten_flow_runs_on_the_layer_kernel(hip_lib, dev):
     assert float(dlsum.abs().max()) == 0.0
     proj = (data[:B].float().double() - mean) @ Tw @ flow.Tblacken.double().cpu() + mean
     assert float((back.double().cpu() - proj).abs().max()) <= 2e-5 * float(proj.abs().max())
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_one_call_backward_is_bit_stable(hip_lib, dev, inverse):
+    """bgk_affine_coupling_backward64 sums its partial gradients in a fixed order (no atomics: the log_alpha gradient as one partial per
+    workgroup, summed in slab order): the same inputs give the same bits, run after run, in both directions -- the check that caught a
+    miscompiled instance of this kernel in round 6 (profiles/r06_ab_runs.txt; tools/r06_dbg_coupling_bwd.py is the long form)."""
+    flow = _affine_layer(32, (64, 64), 32, (torch.nn.ReLU, torch.nn.Tanh)).to(dev)
+    g = torch.Generator(device=dev).manual_seed(8)
+    x0, y0, w = (torch.randn(4133, 32, device=dev, generator=g) for _ in range(3))
+
+    def run():
+        for p in flow.parameters():
+            p.grad = None
+        x, y = x0.clone().requires_grad_(True), y0.clone().requires_grad_(True)
+        _, out, dl = flow(x, y, inverse=inverse)
+        ((out * w).sum() + 0.5 * dl.sum()).backward()
+        return [x.grad, y.grad] + [p.grad.clone() for p in flow.parameters()]
+    first = run()
+    assert flow[0].transformer._train_cache["tail_fused"]
+    assert all(bool(torch.isfinite(t).all()) for t in first)
+    for _ in range(8):
+        for a, b in zip(run(), first):
+            assert torch.equal(a, b)
