@@ -403,8 +403,20 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_reg_kernel(TailArgs a) {
  *   5. the finished rows go to LDS ([64][3 n_atoms], the tile's memory image) and leave as 16-byte coalesced stores. */
 #include "bgk_dma.h"
 
+#ifndef BGK_TAIL_TS
+#define BGK_TAIL_TS 0                 /* profiling build (tools/r06_tail_ts.py): lane 0 stamps s_memtime at the sampling tail's phase boundaries and writes the stamps over the tile's first output row */
+#endif
+#if BGK_TAIL_TS
+#define TAIL_TS(k) do { tts_[k] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TAIL_TS(k) do { } while (0)
+#endif
+
 template <int NA, bool EMIT = false, bool KL = false>
 __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
+#if BGK_TAIL_TS
+    unsigned tts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * TW + wave;
@@ -421,6 +433,7 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
     const ci32_t recs = (ci32_t)a.place;
     const CdfClamp cl = a.cl;
 
+    TAIL_TS(0);
     dma_tile(R3, a.xfix + b0 * keep, keep, rows, lane);
     dma_tile(R0, a.bonds + b0 * n, n, rows, lane);
     dma_tile(R1, a.angles + b0 * n, n, rows, lane);
@@ -431,7 +444,8 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
 
     /* ---- fixed pass ---- */
     {
-        wait_vmcnt((n / 4 + n % 4) * 3);             /* the fixed tile has landed; the 3 (n / 4 + n % 4) later requests may still fly */
+        wait_vmcnt((n / 4 + n % 4) * 3);
+        TAIL_TS(1);             /* the fixed tile has landed; the 3 (n / 4 + n % 4) later requests may still fly */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const Desc df = load_desc(desc, 3);
@@ -484,6 +498,7 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
 
+    TAIL_TS(2);
     /* ---- bonds / angles / torsions, elementwise in the tiles' own layout ---- */
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -509,6 +524,7 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
         for (int c = 0; c < n; ++c) acc += R3[lane * n + c];
     }
 
+    TAIL_TS(3);
     /* ---- sequential placement: the inputs of placement i + 1 are requested from LDS one iteration ahead ---- */
     int warn = 0;
     const float eps2 = a.eps * a.eps;
@@ -545,6 +561,7 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
         r = rn; dsa = dsa_n; dca = dca_n; tn = tn_n;
     }
 
+    TAIL_TS(4);
     if (!KL && lane < rows) {
         const int64_t b = b0 + lane;
         if (a.accumulate) a.dlogp[b] += acc; else a.dlogp[b] = acc;
@@ -590,6 +607,13 @@ __global__ __launch_bounds__(TW * 64) void icdf_ic2xyz_uni_kernel(TailArgs a) {
         for (int q = tail0 + lane; q < rows * ld_row; q += 64) a.x[b0 * a.ldx + q] = R0[q];
     }
     if (warn && a.warn_count) atomicAdd(a.warn_count, warn);
+#if BGK_TAIL_TS
+    TAIL_TS(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TAIL_TS(6);
+    if (lane == 0)
+        for (int q = 0; q < 8; ++q) reinterpret_cast<unsigned*>(a.x + b0 * a.ldx)[q] = tts_[q];
+#endif
 }
 
 
